@@ -1,0 +1,263 @@
+"""Oracle (CPU, fp64, numpy) for the SPD half of the hot path.  Test infrastructure only - see oracle/__init__.py.
+
+All citations are paths under the reference tree (BoManifolds/...).  Everything computes in float64; the
+reference's fp32 eigenvalue sink (Riemannian_utils/spd_utils_torch.py:108) is deliberately NOT reproduced,
+so agreement with reference-generated vectors is ~1e-7 on distances while agreement with the independent
+numpy statement of the distance (Riemannian_utils/spd_utils.py:180-197) is ~1e-13.
+"""
+import numpy as np
+
+SQRT2 = 2.0 ** 0.5
+
+
+# ----------------------------------------------------------------------------------------------- Mandel maps
+def mandel_dim(d_vec):
+    """d from d_vec = d(d+1)/2   (spd_utils_torch.py:175)."""
+    d = int((-1.0 + (1.0 + 8.0 * d_vec) ** 0.5) / 2.0)
+    if d * (d + 1) // 2 != d_vec:
+        raise ValueError(f"{d_vec} is not a triangular number")
+    return d
+
+
+def mandel_index(d):
+    """Row/col of every Mandel entry: the main diagonal first, then super-diagonal 1, 2, ... (spd_utils_torch.py:183-187)."""
+    rows, cols = [], []
+    for k in range(d):
+        for i in range(d - k):
+            rows.append(i)
+            cols.append(i + k)
+    return np.array(rows), np.array(cols)
+
+
+def vector_to_symmetric_matrix_mandel(v):
+    """(..., d_vec) -> (..., d, d); off-diagonals divided by sqrt(2)   (spd_utils_torch.py:159-194)."""
+    v = np.asarray(v, dtype=np.float64)
+    d = mandel_dim(v.shape[-1])
+    r, c = mandel_index(d)
+    scale = np.where(r == c, 1.0, 1.0 / SQRT2)
+    m = np.zeros(v.shape[:-1] + (d, d))
+    m[..., r, c] = v * scale
+    m[..., c, r] = v * scale
+    return m
+
+
+def symmetric_matrix_to_vector_mandel(m):
+    """(..., d, d) -> (..., d_vec); off-diagonals sqrt(2) * mean(upper, lower)   (spd_utils_torch.py:197-226, :219)."""
+    m = np.asarray(m, dtype=np.float64)
+    d = m.shape[-1]
+    r, c = mandel_index(d)
+    scale = np.where(r == c, 1.0, SQRT2)
+    return 0.5 * (m[..., r, c] + m[..., c, r]) * scale
+
+
+# ----------------------------------------------------------------------------------------- affine-invariant
+def _chol_inv(x):
+    """L^-1 with L = lower Cholesky factor   (spd_utils_torch.py:87-88)."""
+    L = np.linalg.cholesky(x)
+    eye = np.broadcast_to(np.eye(x.shape[-1]), x.shape)
+    return np.linalg.solve(L, eye)
+
+
+def congruence_matrices(x1, x2):
+    """M_ij = L_i^-1 X2_j L_i^-T for every pair: (..., N1, N2, d, d)   (spd_utils_torch.py:102-103)."""
+    li = _chol_inv(np.asarray(x1, dtype=np.float64))
+    x2 = np.asarray(x2, dtype=np.float64)
+    return np.einsum("...iab,...jbc,...idc->...ijad", li, x2, li, optimize=True)
+
+
+def affine_invariant_distance(x1, x2, diagonal_distance=False):
+    """d_ij = sqrt(sum_k log^2 lambda_k(M_ij) + 1e-15)   (spd_utils_torch.py:53-121).
+
+    x1 (..., N1, d, d), x2 (..., N2, d, d) -> (..., N1, N2).  diagonal_distance=True returns zeros (..., N2, 1)
+    exactly as the reference does (:72-75)."""
+    if diagonal_distance:
+        return np.zeros(tuple(np.shape(x2)[:-2]) + (1,))
+    m = congruence_matrices(x1, x2)
+    # symeig(upper=True) reads the upper triangle only (:110)
+    lam = np.linalg.eigvalsh(m, UPLO="U")
+    lg = np.log(lam)
+    return np.sqrt(np.sum(lg * lg, axis=-1) + 1e-15)
+
+
+def affine_invariant_distance_faithful(x1, x2):
+    """Same result, computed with the reference's OP SEQUENCE on torch CPU: Cholesky, explicit inverse, two
+    batched products over the materialised N1*N2 set, then ONE symmetric eigensolve PER PAIR in a Python loop
+    (spd_utils_torch.py:87-110).  This is the `cpu_baseline` ("port") that bench.py times: it is what the
+    reference spends its time on.  Only difference: eigenvalues stay fp64 (no fp32 sink)."""
+    import torch
+    x1 = torch.as_tensor(x1, dtype=torch.float64)
+    x2 = torch.as_tensor(x2, dtype=torch.float64)
+    d = x1.shape[-1]
+    n1, n2 = x1.shape[-3], x2.shape[-3]
+    li = torch.inverse(torch.linalg.cholesky(x1))
+    li_rep = li.unsqueeze(-3).expand(*li.shape[:-3], n1, n2, d, d).reshape(-1, d, d)
+    x2_rep = x2.unsqueeze(-4).expand(*x2.shape[:-3], n1, n2, d, d).reshape(-1, d, d)
+    m = torch.bmm(torch.bmm(li_rep, x2_rep), li_rep.transpose(-2, -1))
+    lam = torch.empty(m.shape[0], d, dtype=torch.float64)
+    for p in range(m.shape[0]):
+        lam[p] = torch.linalg.eigh(m[p], UPLO="U").eigenvalues
+    lg = torch.log(lam)
+    out = torch.sqrt((lg * lg).sum(-1) + 1e-15)
+    return out.reshape(*x1.shape[:-3], n1, n2).numpy()
+
+
+def spd_ai_gaussian_kernel(x1_mandel, x2_mandel, beta, diagonal_distance=False, faithful=False):
+    """K = exp(-beta d^2) from Mandel inputs   (kernel_utils/kernels_spd.py:72-100)."""
+    m1 = vector_to_symmetric_matrix_mandel(x1_mandel)
+    m2 = vector_to_symmetric_matrix_mandel(x2_mandel)
+    if faithful and not diagonal_distance:
+        dist = affine_invariant_distance_faithful(m1, m2)
+    else:
+        dist = affine_invariant_distance(m1, m2, diagonal_distance)
+    return np.exp(-(dist * dist) * beta)
+
+
+def spd_ai_laplace_kernel(x1_mandel, x2_mandel, beta):
+    """K = exp(-beta d)   (kernels_spd.py:157-187)."""
+    dist = affine_invariant_distance(vector_to_symmetric_matrix_mandel(x1_mandel),
+                                     vector_to_symmetric_matrix_mandel(x2_mandel))
+    return np.exp(-dist * beta)
+
+
+def spd_ai_gaussian_kernel_grads(x1_mandel, x2_mandel, beta, grad_k):
+    """Closed-form d/dx1 and d/dx2 (Mandel) of sum(grad_k * K)   (the reference obtains these by
+    autograd through cholesky/inverse/bmm/symeig, spd_utils_torch.py:87-120).
+
+    grad_A d^2 = -2 L^-T logm(M) L^-1 ; grad_B d^2 = +2 L^-T M^-1 logm(M) L^-1 (= the same formula with the roles
+    of A and B exchanged).  dK/dd^2 = -beta K, and the 1e-15 under the sqrt drops out because K depends on d^2."""
+    a = vector_to_symmetric_matrix_mandel(x1_mandel)
+    b = vector_to_symmetric_matrix_mandel(x2_mandel)
+    li = _chol_inv(a)
+    m = np.einsum("...iab,...jbc,...idc->...ijad", li, b, li, optimize=True)
+    lam, v = np.linalg.eigh(m, UPLO="U")
+    lg = np.log(lam)
+    k = np.exp(-(np.sum(lg * lg, -1) + 1e-15) * beta)
+    w = np.asarray(grad_k) * (-beta) * k                                   # dLoss/d(d^2_ij)
+    logm = np.einsum("...ab,...b,...cb->...ac", v, lg, v)
+    logm_minv = np.einsum("...ab,...b,...cb->...ac", v, lg / lam, v)
+    ga = np.einsum("...ij,...iba,...ijbc,...icd->...iad", -2.0 * w, li, logm, li, optimize=True)
+    gb = np.einsum("...ij,...iba,...ijbc,...icd->...jad", 2.0 * w, li, logm_minv, li, optimize=True)
+    return symmetric_matrix_to_vector_mandel(ga), symmetric_matrix_to_vector_mandel(gb)
+
+
+# ------------------------------------------------------------------------------------- matrix functions
+def _sym_fun(x, f):
+    lam, v = np.linalg.eigh(np.asarray(x, dtype=np.float64), UPLO="U")
+    return np.einsum("...ab,...b,...cb->...ac", v, f(lam), v)
+
+
+def logm(x):
+    """V diag(log lambda) V^-1   (spd_utils_torch.py:13-30; tools/multi.py:55-64 multilog)."""
+    return _sym_fun(x, np.log)
+
+
+def sqrtm(x):
+    """spd_utils_torch.py:33-50."""
+    return _sym_fun(x, np.sqrt)
+
+
+def expm_sym(x):
+    """tools/multi.py:67-75 multiexp(sym=True)."""
+    return _sym_fun(x, np.exp)
+
+
+def frobenius_distance(x1, x2, diagonal_distance=False):
+    """||x1_i - x2_j + 1e-15||_F with the 1e-15 added to EVERY element   (spd_utils_torch.py:124-156)."""
+    if diagonal_distance:
+        return np.zeros(tuple(np.shape(x2)[:-2]) + (1,))
+    diff = np.asarray(x1)[..., :, None, :, :] - np.asarray(x2)[..., None, :, :, :] + 1e-15
+    return np.sqrt(np.sum(diff * diff, axis=(-2, -1)))
+
+
+def log_euclidean_distance(x1, x2):
+    """frobenius_distance(logm(x1), logm(x2))   (kernels_spd.py:289-309)."""
+    return frobenius_distance(logm(x1), logm(x2))
+
+
+def projection_from_spd_to_nested_spd(x, w):
+    """Y = W^T X W   (nested_mappings/nested_spd_utils.py:13-48)."""
+    w = np.asarray(w, dtype=np.float64)
+    return np.einsum("ba,...bc,cd->...ad", w, np.asarray(x, dtype=np.float64), w, optimize=True)
+
+
+# --------------------------------------------------------------------------- exp / log maps & manifold ops
+def expmap(u, s):
+    """Exp_S(U) = S expm(S^-1 U); reference argument order (tangent first)   (spd_utils.py:104-120)."""
+    s = np.asarray(s, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    li = _chol_inv(s)
+    L = np.linalg.cholesky(s)
+    inner = expm_sym(li @ u @ np.swapaxes(li, -1, -2))
+    return L @ inner @ np.swapaxes(L, -1, -2)
+
+
+def logmap(x, s):
+    """Log_S(X) = S logm(S^-1 X); reference argument order (point first, base second)   (spd_utils.py:123-139)."""
+    s = np.asarray(s, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    li = _chol_inv(s)
+    L = np.linalg.cholesky(s)
+    inner = logm(li @ x @ np.swapaxes(li, -1, -2))
+    return L @ inner @ np.swapaxes(L, -1, -2)
+
+
+def _sym(a):
+    return 0.5 * (a + np.swapaxes(a, -1, -2))
+
+
+def spd_inner(x, u, v):
+    """tr(X^-1 U X^-1 V)   [3P pymanopt PositiveDefinite.inner; unpinned]."""
+    xu = np.linalg.solve(x, u)
+    xv = np.linalg.solve(x, v)
+    return np.einsum("...ab,...ba->...", xu, xv)
+
+
+def spd_norm(x, u):
+    return np.sqrt(np.maximum(spd_inner(x, u, u), 0.0))
+
+
+def spd_egrad2rgrad(x, g):
+    """X sym(G) X   [3P]."""
+    return x @ _sym(g) @ x
+
+
+def spd_ehess2rhess(x, eg, eh, u):
+    """X sym(eh) X + sym(U sym(eg) X)   [3P]."""
+    return x @ _sym(eh) @ x + _sym(u @ _sym(eg) @ x)
+
+
+def spd_exp(x, u):
+    """pymanopt argument order (base first) - same map as `expmap(u, x)`."""
+    return expmap(u, x)
+
+
+def spd_log(x, y):
+    """pymanopt argument order: Log at base x of y."""
+    return logmap(y, x)
+
+
+def spd_transp(x1, x2, d):
+    """PositiveDefinite.transp is the identity   [3P]."""
+    return d
+
+
+def spd_sample(n, min_eig, max_eig):
+    """Random SPD matrix drawn from numpy's GLOBAL RNG in the reference's draw order: rand(n) for the eigenvalues,
+    then randn(n, n) for the orthogonal factor   (spd_utils.py:290-306)."""
+    lam = min_eig * np.ones(1) + (max_eig - min_eig) * np.random.rand(n)
+    q, _ = np.linalg.qr(np.random.randn(n, n))
+    return q @ np.diag(lam) @ q.T
+
+
+def max_eigenvalue_constraint(x, maximum_eigenvalue):
+    """maximum_eigenvalue - lambda_max(x) and its Euclidean gradient -v_max v_max^T   (spd_constraints_utils_torch.py:17-32)."""
+    lam, v = np.linalg.eigh(np.asarray(x, dtype=np.float64), UPLO="U")
+    vm = v[..., :, -1]
+    return maximum_eigenvalue - lam[..., -1], -vm[..., :, None] * vm[..., None, :]
+
+
+def min_eigenvalue_constraint(x, minimum_eigenvalue):
+    """lambda_min(x) - minimum_eigenvalue and gradient v_min v_min^T   (spd_constraints_utils_torch.py:35-50)."""
+    lam, v = np.linalg.eigh(np.asarray(x, dtype=np.float64), UPLO="U")
+    vm = v[..., :, 0]
+    return lam[..., 0] - minimum_eigenvalue, vm[..., :, None] * vm[..., None, :]
