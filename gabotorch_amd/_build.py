@@ -1,0 +1,77 @@
+"""Builds gabotorch_amd/libgabo_hip.so from csrc/*.hip with hipcc for gfx950 (cross-compiles without a GPU).
+
+In-tree on purpose: the .so travels to the GPU box with the repository snapshot.  `python -m gabotorch_amd._build`
+rebuilds; `__graft_entry__.build()` calls `build()`.
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(PKG, "libgabo_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-variable"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libgabo_hip.so (set HIPCC=/path/to/hipcc)")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps():
+    hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hdr.append(os.path.join(os.path.dirname(PKG), "include", "gabo_hip.h"))
+    hdr.append(os.path.abspath(__file__))
+    return hdr
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, extra):
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    if not _stale(obj, [src] + _deps()):
+        return obj, False
+    cmd = [_hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return obj, True
+
+
+def build(force=False, extra_flags=(), verbose=False):
+    """Compile every csrc/*.hip for gfx950 and link libgabo_hip.so.  Returns the library path."""
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    srcs = sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, list(extra_flags)), srcs))
+    objs = [o for o, _ in res]
+    if any(changed for _, changed in res) or _stale(LIB, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}"] + objs + ["-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB)} bytes) from {len(srcs)} sources")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")], verbose=True)

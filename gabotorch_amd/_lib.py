@@ -1,0 +1,53 @@
+"""ctypes binding of libgabo_hip.so (the C ABI declared in include/gabo_hip.h).
+
+There is no fallback: if the library is missing or a call fails, this module raises.  Nothing here computes.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgabo_hip.so")
+
+GABO_OK = 0
+GABO_ERR_DIM, GABO_ERR_ARG, GABO_ERR_NOT_SPD, GABO_ERR_LAUNCH = -1, -2, -3, -4
+GABO_OUT_GAUSSIAN, GABO_OUT_DISTANCE, GABO_OUT_LAPLACE, GABO_SYMMETRIC = 0, 1, 2, 4
+GABO_SPD_MAX_DIM = 12
+
+_ERR = {GABO_ERR_DIM: "unsupported dimension", GABO_ERR_ARG: "bad argument", GABO_ERR_NOT_SPD: "input is not SPD",
+        GABO_ERR_LAUNCH: "kernel launch failed"}
+
+_c = ctypes
+_P, _I64, _I, _D, _SZ = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double, _c.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/gabo_hip.h declares (tests/test_abi.py checks it)
+SIGNATURES = {
+    "gabo_version": (_I, []),
+    "gabo_spd_ai_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
+    "gabo_spd_ai_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _P, _SZ, _P, _P]),
+    "gabo_sphere_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _I, _P]),
+    "gabo_mandel_to_matrix": (_I, [_P, _P, _I64, _I, _P]),
+    "gabo_matrix_to_mandel": (_I, [_P, _P, _I64, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built.  Run `python -m gabotorch_amd._build` "
+                "(needs hipcc).  gabotorch_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = header and library out of sync
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != GABO_OK:
+        raise RuntimeError(f"{what}: libgabo_hip error {code} ({_ERR.get(code, 'unknown')})")

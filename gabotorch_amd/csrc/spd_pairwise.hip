@@ -1,0 +1,241 @@
+// SPD affine-invariant pairwise kernel matrix on gfx950.
+//
+//   d_ij^2 = sum_k log^2 lambda_k(L_i^-1 B_j L_i^-T) + 1e-15,   L_i = chol(A_i)
+//
+// replaces kernel_utils/kernels_spd.py:72-100 + Riemannian_utils/spd_utils_torch.py:53-121,159-194.
+//
+// Two launches:
+//   1. spd_prep_kernel  - one lane per input matrix: Mandel vector -> Cholesky.  x1 side stores L^-1 (packed lower,
+//      row contiguous: read back through the scalar cache, it is wave-uniform in step 2); x2 side stores the factor
+//      G (B = G G^T) entry-major ("SoA", [tri][n2]) so that lane j reads G[e][j] fully coalesced.
+//   2. spd_ai_pairwise_kernel - one LANE per pair, a wave = 64 consecutive columns j of one row i at a time.
+//      C = L_i^-1 G_j (lower x lower), M = C C^T (symmetric, lower kept), eigenvalues of M by the per-lane
+//      tridiagonal/QL solver of spd_eig.hpp, all in registers.  No LDS, no cross-lane traffic; the 1.8 MB operand
+//      sets stay L2 resident, the only HBM stream is the N1 x N2 output.
+#include "gabo_device.hpp"
+#include "spd_eig.hpp"
+#include "../../include/gabo_hip.h"
+
+#ifndef GABO_PAIR_WAVES
+#define GABO_PAIR_WAVES 2  /* waves per SIMD the pairwise kernel is register-budgeted for */
+#endif
+
+namespace gabo {
+
+template <int D>
+__global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__ x, double* __restrict__ ws,
+                                                      int64_t batch, int64_t n, int64_t batch_stride, int soa,
+                                                      int* __restrict__ status, int status_base) {
+    constexpr int T = tri_size(D);
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= batch * n) return;
+    int64_t b = g / n, i = g - b * n;
+    const double* v = x + b * batch_stride + i * T;
+    double a[T];
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<r + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            double e = v[mandel_pos(D, r, c)];
+            a[tri(r, c)] = (r == c) ? e : e / kSqrt2;  // spd_utils_torch.py:186-187 divides by 2**0.5
+        });
+    });
+    // in-place lower Cholesky
+    bool bad = false;
+    static_for<D>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        double piv = a[tri(c, c)];
+        static_for<c>([&](auto kk) { constexpr int k = decltype(kk)::value; piv = __builtin_fma(-a[tri(c, k)], a[tri(c, k)], piv); });
+        if (!(piv > 0.0)) bad = true;
+        double lcc = __builtin_sqrt(piv);
+        double inv = 1.0 / lcc;
+        a[tri(c, c)] = lcc;
+        static_for<D - c - 1>([&](auto rr) {
+            constexpr int r = c + 1 + decltype(rr)::value;
+            double s = a[tri(r, c)];
+            static_for<c>([&](auto kk) { constexpr int k = decltype(kk)::value; s = __builtin_fma(-a[tri(r, k)], a[tri(c, k)], s); });
+            a[tri(r, c)] = s * inv;
+        });
+    });
+    if (bad) {
+        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = status_base + (int)g;
+    }
+    if (soa) {
+        // G, entry-major: ws[(b*T + e) * n + i]
+        static_for<T>([&](auto ee) { ws[(b * T + decltype(ee)::value) * n + i] = a[decltype(ee)::value]; });
+    } else {
+        // W = L^-1 (lower), column by column: W[c][c] = 1/L[c][c]; W[r][c] = -(sum_{k=c}^{r-1} L[r][k] W[k][c]) / L[r][r]
+        double w[T];
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            w[tri(c, c)] = 1.0 / a[tri(c, c)];
+        });
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            static_for<D - c - 1>([&](auto rr) {
+                constexpr int r = c + 1 + decltype(rr)::value;
+                double s = 0.0;
+                static_for<r - c>([&](auto kk) {
+                    constexpr int k = c + decltype(kk)::value;
+                    s = __builtin_fma(a[tri(r, k)], w[tri(k, c)], s);
+                });
+                w[tri(r, c)] = -s * w[tri(r, r)];
+            });
+        });
+        double* o = ws + g * T;
+        static_for<T>([&](auto ee) { o[decltype(ee)::value] = w[decltype(ee)::value]; });
+    }
+}
+
+// sum_k log^2(lambda_k) of M = C C^T with C = W * G (both lower triangular, W wave-uniform, G per lane)
+template <int D>
+__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const double* __restrict__ Gj, int64_t gstride) {
+    constexpr int T = tri_size(D);
+    // Column `col` of C = W G depends only on column `col` of G:  C[r][col] = sum_{k=col..r} W[r][k] G[k][col].
+    // M = C C^T = sum_col C[:,col] C[:,col]^T, so M is accumulated by rank-1 updates and C is never held whole:
+    // live state is M (T doubles) + one column of C + one column of G.
+    double m[T];
+    static_for<T>([&](auto ee) { m[decltype(ee)::value] = 0.0; });
+    static_for<D>([&](auto cc) {
+        constexpr int col = decltype(cc)::value;
+        double g[D - col], c[D - col];
+        static_for<D - col>([&](auto kk) { g[decltype(kk)::value] = Gj[(int64_t)tri(col + decltype(kk)::value, col) * gstride]; });
+        static_for<D - col>([&](auto rr) {
+            constexpr int r = col + decltype(rr)::value;
+            double acc = W[tri(r, col)] * g[0];
+            static_for<r - col>([&](auto kk) {
+                constexpr int k = col + 1 + decltype(kk)::value;
+                acc = __builtin_fma(W[tri(r, k)], g[k - col], acc);
+            });
+            c[r - col] = acc;
+        });
+        static_for<D - col>([&](auto rr) {
+            constexpr int r = col + decltype(rr)::value;
+            static_for<r - col + 1>([&](auto qq) {
+                constexpr int q = col + decltype(qq)::value;
+                m[tri(r, q)] = __builtin_fma(c[r - col], c[q - col], m[tri(r, q)]);
+            });
+        });
+    });
+    double dg[D], e2[D];
+    tridiagonalize<D>(m, dg, e2);
+    tridiag_eigenvalues<D>(dg, e2);
+    double s = 0.0;
+    static_for<D>([&](auto kk) { double lg = log(dg[decltype(kk)::value]); s = __builtin_fma(lg, lg, s); });
+    return s;
+}
+
+__device__ __forceinline__ double finish(double sumsq, double beta, int mode) {
+    double dist = __builtin_sqrt(sumsq + 1e-15);  // spd_utils_torch.py:120
+    if (mode == GABO_OUT_DISTANCE) return dist;
+    if (mode == GABO_OUT_LAPLACE) return exp(-(dist * beta));   // kernels_spd.py:185
+    return exp(-((dist * dist) * beta));                        // kernels_spd.py:94-98
+}
+
+// 1-D grid, block id -> (batch, row chunk of `rows` rows, column group of blockDim.x columns), column group fastest
+template <int D>
+__global__ __launch_bounds__(256, GABO_PAIR_WAVES) void spd_ai_pairwise_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
+                                                              double* __restrict__ out, int64_t n1, int64_t n2,
+                                                              int64_t w_batch_stride, int64_t g_batch_stride, int rows,
+                                                              int col_blocks, int row_chunks, double beta, int flags) {
+    constexpr int T = tri_size(D);
+    const int mode = flags & GABO_OUT_MASK;
+    const int64_t bid = blockIdx.x;
+    const int64_t cg = bid % col_blocks;
+    const int64_t rc = (bid / col_blocks) % row_chunks;
+    const int64_t b = bid / ((int64_t)col_blocks * row_chunks);
+    const int64_t j0 = cg * blockDim.x;
+    const int64_t j = j0 + threadIdx.x;
+    const int64_t jc = j < n2 ? j : n2 - 1;  // out-of-range lanes recompute the last column and do not store
+    const int64_t i0 = rc * rows;
+    const int64_t i1 = (i0 + rows < n1) ? i0 + rows : n1;
+    if (flags & GABO_SYMMETRIC) {
+        if (j0 + blockDim.x <= i0) return;  // tile strictly below the diagonal: produced by its mirror tile
+    }
+    const double* Gj = G + b * g_batch_stride + jc;
+    double* ob = out + b * n1 * n2;
+    for (int64_t i = i0; i < i1; ++i) {
+        const double* W = Winv + b * w_batch_stride + i * T;
+        // Launder the column pointer so the 55 G loads are NOT hoisted out of the row loop: keeping G resident costs
+        // 110 VGPRs (one wave per SIMD less); re-reading it from L2 costs 28 KB per wave-row, which is noise here.
+        const double* Gp = Gj;
+        asm volatile("" : "+v"(Gp));
+        double s = ai_sumsq<D>(W, Gp, n2);
+        double val = finish(s, beta, mode);
+        if (j < n2) {
+            ob[i * n2 + j] = val;
+            if (flags & GABO_SYMMETRIC) {
+                // mirror (j, i) unless the tile owning (j, i) computes it itself
+                int64_t mi0 = (j / rows) * rows;                                  // first row of that tile
+                int64_t mj1 = (i / blockDim.x + 1) * (int64_t)blockDim.x;       // one past its last column
+                if (mj1 <= mi0) ob[j * n2 + i] = val;
+            }
+        }
+    }
+}
+
+template <int D>
+static int launch_spd_ai(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
+                         int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st) {
+    constexpr int T = tri_size(D);
+    const int64_t b1 = (s1 == 0) ? 1 : batch;  // a shared set is factored once
+    const int64_t b2 = (s2 == 0) ? 1 : batch;
+    double* W = ws;
+    double* G = ws + b1 * n1 * T;
+    {
+        int64_t tot = b1 * n1;
+        hipLaunchKernelGGL((spd_prep_kernel<D>), dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, x1, W, b1, n1, s1, 0, status, 0);
+        tot = b2 * n2;
+        hipLaunchKernelGGL((spd_prep_kernel<D>), dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, x2, G, b2, n2, s2, 1, status,
+                           (int)(b1 * n1));
+    }
+    // tile shape: 64..256 columns per block, `rows` rows per block; keep >= ~8 blocks per CU when the problem allows
+    int threads = n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
+    int64_t col_blocks = (n2 + threads - 1) / threads;
+    int rows = 16;
+    while (rows > 1 && col_blocks * ((n1 + rows - 1) / rows) * batch < 4096) rows >>= 1;
+    int64_t row_chunks = (n1 + rows - 1) / rows;
+    int64_t nblocks = col_blocks * row_chunks * batch;
+    if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
+    hipLaunchKernelGGL((spd_ai_pairwise_kernel<D>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
+                       (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks,
+                       (int)row_chunks, beta, flags);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+}  // namespace gabo
+
+extern "C" {
+
+size_t gabo_spd_ai_workspace_bytes(int64_t batch, int64_t n1, int64_t n2, int d) {
+    if (batch < 0 || n1 < 0 || n2 < 0 || d < 1) return 0;
+    return (size_t)(batch * (n1 + n2)) * (size_t)gabo::tri_size(d) * sizeof(double);
+}
+
+int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2, int d,
+                         int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, void* workspace,
+                         size_t workspace_bytes, int* status, gabo_stream_t stream) {
+    if (batch < 0 || n1 < 0 || n2 < 0 || x1_batch_stride < 0 || x2_batch_stride < 0) return GABO_ERR_ARG;
+    if (d < 2 || d > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
+    if (batch == 0 || n1 == 0 || n2 == 0) return GABO_OK;
+    if (!x1 || !x2 || !out || !workspace || !status) return GABO_ERR_ARG;
+    if (workspace_bytes < gabo_spd_ai_workspace_bytes(batch, n1, n2, d)) return GABO_ERR_ARG;
+    if ((flags & GABO_SYMMETRIC) && n1 != n2) return GABO_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    double* ws = (double*)workspace;
+#define GABO_CASE(DD) \
+    case DD:          \
+        return gabo::launch_spd_ai<DD>(x1, x2, out, batch, n1, n2, x1_batch_stride, x2_batch_stride, beta, flags, ws, status, st);
+    switch (d) {
+#ifdef GABO_ONLY_DIM  /* development builds: one instantiation compiles in seconds */
+        GABO_CASE(GABO_ONLY_DIM)
+#else
+        GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8) GABO_CASE(9) GABO_CASE(10)
+        GABO_CASE(11) GABO_CASE(12)
+#endif
+    }
+#undef GABO_CASE
+    return GABO_ERR_DIM;
+}
+
+}  // extern "C"

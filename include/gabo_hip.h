@@ -1,0 +1,85 @@
+/*
+ * gabo_hip.h - C ABI of libgabo_hip.so, the MI355X (gfx950) implementation of GaBOtorch's manifold-kernel hot path.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream; no torch types cross this boundary.
+ * All matrices/vectors are fp64, row-major, contiguous in their last dimension(s).  The library allocates nothing
+ * persistent: scratch is passed in by the caller (`workspace`, sized by the matching *_workspace_bytes call).
+ * Calls are stream-ordered, re-entrant, and keep no global state.  Return value: 0 on success, a negative
+ * GABO_ERR_* code for argument errors detected on the host.  Data errors detected on the device (a non-positive
+ * Cholesky pivot = input not SPD) are reported through `status`: a caller-owned device int[2], zeroed by the
+ * caller, that receives {GABO_ERR_NOT_SPD, index of the first offending matrix}.  Nothing throws across the ABI.
+ *
+ * Each function cites the reference code it replaces (paths relative to the GaBOtorch tree, BoManifolds/...).
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ */
+#ifndef GABO_HIP_H
+#define GABO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gabo_stream_t; /* hipStream_t */
+
+#define GABO_OK 0
+#define GABO_ERR_DIM (-1)       /* unsupported matrix / vector dimension */
+#define GABO_ERR_ARG (-2)       /* null pointer, negative size, workspace too small */
+#define GABO_ERR_NOT_SPD (-3)   /* device-side: Cholesky pivot <= 0 (reference: torch.cholesky RuntimeError) */
+#define GABO_ERR_LAUNCH (-4)    /* hipGetLastError() != hipSuccess after a launch */
+
+/* `flags` of the pairwise kernels */
+#define GABO_OUT_GAUSSIAN 0     /* out = exp(-beta * d^2)            kernels_spd.py:96-98, kernels_sphere.py:91-93 */
+#define GABO_OUT_DISTANCE 1     /* out = d                           spd_utils_torch.py:120, sphere_utils_torch.py:55 */
+#define GABO_OUT_LAPLACE 2      /* out = exp(-beta * d)              kernels_spd.py:185, kernels_sphere.py:133 */
+#define GABO_OUT_MASK 3
+#define GABO_SYMMETRIC 4        /* x1 and x2 are the same set (n1 == n2): evaluate i <= j only and mirror */
+
+/* Largest SPD matrix dimension the register-resident pairwise kernels are instantiated for. */
+#define GABO_SPD_MAX_DIM 12
+
+int gabo_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SPD affine-invariant pairwise kernel matrix.
+ * Replaces  SpdAffineInvariantGaussianKernel.forward        kernel_utils/kernels_spd.py:72-100
+ *           SpdAffineInvariantLaplaceKernel.forward         kernel_utils/kernels_spd.py:157-187
+ *           affine_invariant_distance_torch                 Riemannian_utils/spd_utils_torch.py:53-121
+ *           vector_to_symmetric_matrix_mandel_torch (fused) Riemannian_utils/spd_utils_torch.py:159-194
+ *
+ * x1: batch x n1 x d_vec Mandel vectors, x2: batch x n2 x d_vec, d_vec = d(d+1)/2, out: batch x n1 x n2.
+ * x{1,2}_batch_stride: distance in doubles between consecutive batches (0 = one set shared by every batch, which is
+ * how gpytorch hands over the expanded training inputs).  2 <= d <= GABO_SPD_MAX_DIM.
+ * d_ij = sqrt(sum_k log^2 lambda_k(L_i^-1 X2_j L_i^-T) + 1e-15), L_i = chol(X1_i).
+ */
+size_t gabo_spd_ai_workspace_bytes(int64_t batch, int64_t n1, int64_t n2, int d);
+int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
+                         int d, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags,
+                         void* workspace, size_t workspace_bytes, int* status, gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sphere pairwise kernel matrix.
+ * Replaces  SphereGaussianKernel.forward / SphereLaplaceKernel.forward   kernel_utils/kernels_sphere.py:71-94,118-134
+ *           sphere_distance_torch                                        Riemannian_utils/sphere_utils_torch.py:12-55
+ * x1: batch x n1 x dim, x2: batch x n2 x dim, out: batch x n1 x n2;  d_ij = acos(clamp(<x1_i,x2_j>, -1+1e-15, 1-1e-15)).
+ * diag != 0 pairs row k of x1 with row k of x2 (n1 == n2) and writes batch x n1 x 1 (sphere_utils_torch.py:45-49).
+ */
+int gabo_sphere_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
+                         int dim, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, int diag,
+                         gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Mandel vector <-> symmetric matrix.
+ * Replaces  vector_to_symmetric_matrix_mandel_torch   Riemannian_utils/spd_utils_torch.py:159-194
+ *           symmetric_matrix_to_vector_mandel_torch   Riemannian_utils/spd_utils_torch.py:197-226 (averages both triangles, :219)
+ * vec: n x d_vec, mat: n x d x d.   1 <= d <= 64.
+ */
+int gabo_mandel_to_matrix(const double* vec, double* mat, int64_t n, int d, gabo_stream_t stream);
+int gabo_matrix_to_mandel(const double* mat, double* vec, int64_t n, int d, gabo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GABO_HIP_H */

@@ -1,0 +1,194 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors and the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from gabotorch_amd import _lib, ops
+from oracle import spd as ospd
+from oracle import sphere as osph
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+F32 = 5e-7   # fp32 eigenvalue sink of the reference (spd_utils_torch.py:108): golden SPD distances are only this good
+RTOL = 1e-5  # BASELINE.json north_star tolerance (relative, fp64)
+
+
+def t(x):
+    return torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=DEV)
+
+
+def rand_spd_mandel(rng, n, d, lo=0.05, hi=5.0):
+    out = np.empty((n, d, d))
+    for k in range(n):
+        q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        m = (q * rng.uniform(lo, hi, d)) @ q.T
+        out[k] = 0.5 * (m + m.T)
+    return ospd.symmetric_matrix_to_vector_mandel(out)
+
+
+def test_native_library_is_loaded():
+    lib = _lib.load()
+    assert lib.gabo_version() >= 100
+    assert torch.cuda.is_available()
+
+
+def test_mandel_golden(golden):
+    g = golden("mandel.npz")
+    for d in (2, 3, 5, 10, 20):
+        m = ops.mandel_to_matrix(t(g[f"d{d}_vec"])).cpu().numpy()
+        np.testing.assert_array_equal(m, g[f"d{d}_mat"])                      # bit exact: same division by 2**0.5
+        v = ops.matrix_to_mandel(t(g[f"d{d}_nonsym"])).cpu().numpy()
+        np.testing.assert_allclose(v, g[f"d{d}_nonsym_vec"], rtol=1e-15, atol=1e-16)
+        np.testing.assert_allclose(ops.matrix_to_mandel(t(m)).cpu().numpy(), g[f"d{d}_vec"], rtol=1e-15, atol=1e-16)
+
+
+def test_spd_ai_golden(golden):
+    g = golden("spd_ai.npz")
+    for c in range(int(g["ncases"])):
+        p = f"c{c}_"
+        x1, x2, beta = g[p + "x1"], g[p + "x2"], float(g[p + "beta"])
+        dist = ops.spd_ai_pairwise(t(x1), t(x2), mode=_lib.GABO_OUT_DISTANCE).cpu().numpy()
+        assert dist.shape == g[p + "dist"].shape
+        np.testing.assert_allclose(dist, g[p + "dist"], rtol=F32, atol=F32)
+        if p + "dist_np" in g:    # the reference's independent fp64 statement: tight
+            np.testing.assert_allclose(dist, np.sqrt(g[p + "dist_np"] ** 2 + 1e-15), rtol=1e-10, atol=1e-11)
+        k = ops.spd_ai_pairwise(t(x1), t(x2), beta=beta).cpu().numpy()
+        np.testing.assert_allclose(k, g[p + "K"], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(k, ospd.spd_ai_gaussian_kernel(x1, x2, beta), rtol=1e-9, atol=1e-12)
+    d = ops.spd_ai_pairwise(t(ospd.symmetric_matrix_to_vector_mandel(g["kat_a"])),
+                            t(ospd.symmetric_matrix_to_vector_mandel(g["kat_b"])), mode=_lib.GABO_OUT_DISTANCE)
+    np.testing.assert_allclose(d.item(), 1.4033966394735078, rtol=1e-12)
+    i10 = ospd.symmetric_matrix_to_vector_mandel(np.eye(10)[None])
+    d = ops.spd_ai_pairwise(t(i10), t(np.e * i10), mode=_lib.GABO_OUT_DISTANCE)
+    np.testing.assert_allclose(d.item(), 10 ** 0.5, rtol=1e-13)
+    d = ops.spd_ai_pairwise(t(i10), t(i10), mode=_lib.GABO_OUT_DISTANCE)
+    np.testing.assert_allclose(d.item(), 1e-15 ** 0.5, rtol=1e-6)            # d(X,X) = sqrt(1e-15), not 0
+
+
+def test_letters_fixture(golden):
+    g = golden("letters_spd2.npz")
+    x = t(g["x_mandel"])
+    k = ops.spd_ai_pairwise(x, x, beta=float(g["beta"])).cpu().numpy()
+    np.testing.assert_allclose(k, g["K"], rtol=RTOL, atol=1e-7)
+    ks = ops.spd_ai_pairwise(x, x, beta=float(g["beta"]), symmetric=True).cpu().numpy()
+    np.testing.assert_allclose(ks, k, rtol=1e-10, atol=1e-13)
+    np.testing.assert_array_equal(ks, ks.T)
+
+
+@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_MAX_DIM + 1)))
+def test_spd_ai_vs_oracle_all_dims(d):
+    rng = np.random.default_rng(d)
+    x1 = rand_spd_mandel(rng, 37, d)
+    x2 = rand_spd_mandel(rng, 70, d)
+    want = ospd.affine_invariant_distance(ospd.vector_to_symmetric_matrix_mandel(x1),
+                                          ospd.vector_to_symmetric_matrix_mandel(x2))
+    got = ops.spd_ai_pairwise(t(x1), t(x2), mode=_lib.GABO_OUT_DISTANCE).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
+    lap = ops.spd_ai_pairwise(t(x1), t(x2), beta=0.7, mode=_lib.GABO_OUT_LAPLACE).cpu().numpy()
+    np.testing.assert_allclose(lap, np.exp(-0.7 * want), rtol=1e-10)
+
+
+def test_spd_ai_shapes_batches_and_edges():
+    rng = np.random.default_rng(5)
+    d = 5
+    # batched, ragged sizes around the 64/256 tile edges, and the expand()ed train set gpytorch hands over
+    for n1, n2 in [(1, 1), (1, 63), (3, 64), (2, 65), (17, 257), (5, 300)]:
+        x1 = np.stack([rand_spd_mandel(rng, n1, d) for _ in range(3)])
+        x2 = np.stack([rand_spd_mandel(rng, n2, d) for _ in range(3)])
+        want = ospd.spd_ai_gaussian_kernel(x1, x2, 0.4)
+        got = ops.spd_ai_pairwise(t(x1), t(x2), beta=0.4)
+        assert got.shape == (3, n1, n2)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-9, atol=1e-13)
+    train = rand_spd_mandel(rng, 11, d)
+    cand = np.stack([rand_spd_mandel(rng, 1, d) for _ in range(40)])           # b x 1 x d_vec
+    x2 = t(train).expand(40, 11, train.shape[-1])                             # stride-0 batch
+    got = ops.spd_ai_pairwise(t(cand), x2, beta=0.9).cpu().numpy()
+    want = ospd.spd_ai_gaussian_kernel(cand, np.broadcast_to(train, (40,) + train.shape), 0.9)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-13)
+    # two batch dims
+    x1 = np.stack([rand_spd_mandel(rng, 4, 3) for _ in range(6)]).reshape(2, 3, 4, 6)
+    x2 = np.stack([rand_spd_mandel(rng, 5, 3) for _ in range(6)]).reshape(2, 3, 5, 6)
+    got = ops.spd_ai_pairwise(t(x1), t(x2), beta=0.3).cpu().numpy()
+    np.testing.assert_allclose(got, ospd.spd_ai_gaussian_kernel(x1, x2, 0.3), rtol=1e-9, atol=1e-13)
+    # empty
+    assert ops.spd_ai_pairwise(t(np.zeros((0, 15))), t(rand_spd_mandel(rng, 3, 5))).shape == (0, 3)
+    # CPU tensors in -> CPU tensor out (the reference's examples build CPU tensors)
+    k = ops.spd_ai_pairwise(torch.tensor(train), torch.tensor(train), beta=0.5)
+    assert k.device.type == "cpu" and k.dtype == torch.float64
+
+
+def test_spd_not_spd_is_reported():
+    bad = np.array([[1.0, 1.0, 3.0 * 2 ** 0.5]])       # [[1,3],[3,1]]: indefinite
+    good = ospd.symmetric_matrix_to_vector_mandel(np.eye(2)[None])
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        ops.spd_ai_pairwise(t(bad), t(good))
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        ops.spd_ai_pairwise(t(good), t(bad))
+    with pytest.raises(RuntimeError, match="unsupported dimension"):
+        ops.spd_ai_pairwise(t(np.ones((2, 13 * 14 // 2))), t(np.ones((2, 13 * 14 // 2))))
+
+
+def test_spd_properties_at_scale():
+    """Size-independent properties on a larger set: symmetry, unit diagonal, affine invariance, inversion invariance."""
+    rng = np.random.default_rng(77)
+    d, n = 10, 512
+    x = rand_spd_mandel(rng, n, d)
+    X = t(x)
+    D = ops.spd_ai_pairwise(X, X, mode=_lib.GABO_OUT_DISTANCE)
+    np.testing.assert_allclose(D.cpu().numpy(), D.T.cpu().numpy(), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(torch.diagonal(D).cpu().numpy(), 1e-15 ** 0.5, rtol=1e-3)
+    Ds = ops.spd_ai_pairwise(X, X, mode=_lib.GABO_OUT_DISTANCE, symmetric=True)
+    np.testing.assert_array_equal(Ds.cpu().numpy(), Ds.T.cpu().numpy())
+    np.testing.assert_allclose(Ds.cpu().numpy(), D.cpu().numpy(), rtol=1e-9, atol=1e-10)
+    # d(A X A^T, A Y A^T) = d(X, Y)
+    A = rng.standard_normal((d, d)) + 3 * np.eye(d)
+    M = ospd.vector_to_symmetric_matrix_mandel(x[:64])
+    Mc = A @ M @ A.T
+    xc = ospd.symmetric_matrix_to_vector_mandel(0.5 * (Mc + Mc.transpose(0, 2, 1)))
+    Dc = ops.spd_ai_pairwise(t(xc), t(xc), mode=_lib.GABO_OUT_DISTANCE).cpu().numpy()
+    np.testing.assert_allclose(Dc, D[:64, :64].cpu().numpy(), rtol=1e-7, atol=1e-8)
+    # d(X^-1, Y^-1) = d(X, Y)
+    Mi = np.linalg.inv(M)
+    xi = ospd.symmetric_matrix_to_vector_mandel(0.5 * (Mi + Mi.transpose(0, 2, 1)))
+    Di = ops.spd_ai_pairwise(t(xi), t(xi), mode=_lib.GABO_OUT_DISTANCE).cpu().numpy()
+    np.testing.assert_allclose(Di, D[:64, :64].cpu().numpy(), rtol=1e-7, atol=1e-8)
+    # oracle on a sub-block
+    want = ospd.affine_invariant_distance(ospd.vector_to_symmetric_matrix_mandel(x[:48]),
+                                          ospd.vector_to_symmetric_matrix_mandel(x[100:164]))
+    np.testing.assert_allclose(D[:48, 100:164].cpu().numpy(), want, rtol=1e-10, atol=1e-12)
+
+
+def test_sphere_golden(golden):
+    g = golden("sphere.npz")
+    for c in range(int(g["ncases"])):
+        p = f"c{c}_"
+        x1, x2, beta = g[p + "x1"], g[p + "x2"], float(g[p + "beta"])
+        dist = ops.sphere_pairwise(t(x1), t(x2), mode=_lib.GABO_OUT_DISTANCE).cpu().numpy()
+        # acos near +-1 amplifies 1-ulp differences of the inner product to ~1e-8: absolute tolerance there
+        np.testing.assert_allclose(dist, g[p + "dist"], rtol=1e-12, atol=3e-8)
+        k = ops.sphere_pairwise(t(x1), t(x2), beta=beta).cpu().numpy()
+        np.testing.assert_allclose(k, g[p + "K"], rtol=1e-11, atol=1e-14)
+    got = ops.sphere_pairwise(t(g["diag_x"]), t(g["diag_y"]), mode=_lib.GABO_OUT_DISTANCE, diag=True).cpu().numpy()
+    np.testing.assert_allclose(got, g["diag_dist"], rtol=1e-13)
+    e = np.eye(3)
+    assert ops.sphere_pairwise(t(e[0:1]), t(e[1:2]), mode=_lib.GABO_OUT_DISTANCE).item() == np.pi / 2
+    np.testing.assert_allclose(ops.sphere_pairwise(t(e[0:1]), t(-e[0:1]), mode=_lib.GABO_OUT_DISTANCE).item(),
+                               g["kat_e1me1"].item(), rtol=1e-15)
+    np.testing.assert_allclose(ops.sphere_pairwise(t(e[0:1]), t(e[0:1]), mode=_lib.GABO_OUT_DISTANCE).item(),
+                               4.4703483581542975e-08, rtol=1e-9)
+
+
+@pytest.mark.parametrize("dim,n1,n2,batch", [(3, 50, 70, ()), (10, 300, 513, ()), (51, 9, 130, (2,)), (101, 7, 5, (2, 2))])
+def test_sphere_vs_oracle(dim, n1, n2, batch):
+    rng = np.random.default_rng(dim)
+    x1 = rng.standard_normal(batch + (n1, dim))
+    x1 /= np.linalg.norm(x1, axis=-1, keepdims=True)
+    x2 = rng.standard_normal(batch + (n2, dim))
+    x2 /= np.linalg.norm(x2, axis=-1, keepdims=True)
+    for mode, beta, want in [(_lib.GABO_OUT_GAUSSIAN, 1.3, osph.sphere_gaussian_kernel(x1, x2, 1.3)),
+                             (_lib.GABO_OUT_LAPLACE, 0.8, osph.sphere_laplace_kernel(x1, x2, 0.8)),
+                             (_lib.GABO_OUT_DISTANCE, 1.0, osph.sphere_distance(x1, x2))]:
+        got = ops.sphere_pairwise(t(x1), t(x2), beta=beta, mode=mode).cpu().numpy()
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-13)
