@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libgabo_hip.so")
+LIB_PATH = os.environ.get("GABO_HIP_LIB", os.path.join(_PKG, "libgabo_hip.so"))   # override: development A/B builds only
 
 GABO_OK = 0
 GABO_ERR_DIM, GABO_ERR_ARG, GABO_ERR_NOT_SPD, GABO_ERR_LAUNCH = -1, -2, -3, -4

@@ -41,40 +41,40 @@ constexpr double kInvSqrt2 = 0.70710678118654752440;
 constexpr double kSqrt2 = 1.41421356237309504880;
 
 // ---- fp64 scalar math -------------------------------------------------------------------------------------------
-// 1/x: v_rcp_f64 seed + two Newton steps (no denormal/overflow scaling: operands here are O(1e+-150) at worst).
+// Measured on gfx950 (tools/ubench.hip): v_rcp_f64 and v_rsq_f64 return seeds good to 2^-24.  No denormal/overflow
+// scaling anywhere below: operands on this path are O(1e+-100) at worst.
+
+// 1/x.  e = 1 - x r0 (|e| <= 2^-24);  r0 (1 + e + e^2) has error e^3 = 2^-72: one seed + 3 FMAs, ~1 ulp.
 __device__ __forceinline__ double rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
+    double e2 = __builtin_fma(e, e, e);
+    return __builtin_fma(r, e2, r);
+}
+
+// 1/x to ~2^-47 (one Newton step): for quantities that only need to be right to a few 1e-15
+__device__ __forceinline__ double rcp_nr1(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
 }
 
-// sqrt(x), x >= 0: v_rsq_f64 seed, two coupled Goldschmidt steps and a final residual correction.  sqrt(0) = 0.
-__device__ __forceinline__ double sqrt_pos(double x) {
+// sqrt(x), x > 0: seed, one coupled Goldschmidt step (2^-47), then the residual correction g += (x - g^2) h.
+__device__ __forceinline__ double sqrt_nz(double x) {
     double y = __builtin_amdgcn_rsq(x);
     double g = x * y;
     double h = 0.5 * y;
     double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
-    r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
     double dres = __builtin_fma(-g, g, x);
-    g = __builtin_fma(dres, h, g);
-    return x == 0.0 ? 0.0 : g;
+    return __builtin_fma(dres, h, g);
 }
 
-// 1/sqrt(x), x > 0
-__device__ __forceinline__ double rsqrt_pos(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    // Newton: y <- y * (1.5 - 0.5 x y^2), twice
-    double hx = 0.5 * x;
-    double t = __builtin_fma(-hx * y, y, 0.5);
-    y = __builtin_fma(y, t, y);
-    t = __builtin_fma(-hx * y, y, 0.5);
-    return __builtin_fma(y, t, y);
+// sqrt(x), x >= 0 (sqrt(0) = 0)
+__device__ __forceinline__ double sqrt_pos(double x) {
+    double g = sqrt_nz(x);
+    return x == 0.0 ? 0.0 : g;
 }
 
 __device__ __forceinline__ double copysign_d(double mag, double sgn) { return __builtin_copysign(mag, sgn); }

@@ -67,54 +67,67 @@ __device__ __forceinline__ void tridiagonalize(double (&m)[tri_size(D)], double 
     e2[D - 1] = 0.0;
 }
 
-// Eigenvalues of the symmetric tridiagonal (dg, sqrt(e2)) in place in dg (unordered).  Root-free QL with
-// Wilkinson-type shift; per-lane deflation index m is data dependent and handled by predication.
+#ifndef GABO_QL_RCP
+#define GABO_QL_RCP rcp  /* reciprocal used inside the QL sweep: rcp (~1 ulp) or rcp_nr1 (2^-47) */
+#endif
+
+// gamma must never be exactly 0 (p = gamma^2 / c feeds the next rotation as a divisor): nudge an exact zero - a shift
+// that hit an eigenvalue exactly - to +-1e-100, a perturbation far below rounding.  Replaces LAPACK's `c == 0` branch.
+__device__ __forceinline__ double nonzero(double g) {
+    double a = __builtin_fmax(__builtin_fabs(g), 1e-100);
+    return copysign_d(a, g);
+}
+
+// Eigenvalues of the symmetric tridiagonal (dg, sqrt(e2)) in place in dg (unordered).  Root-free QL, Wilkinson shift.
+//
+// Lane-uniform structure on purpose: stage l deflates e2[l]; every sweep of stage l runs the full recurrence from
+// D-2 down to l with NO per-lane interior-split search, so the unrolled steps carry no predicates or branches and the
+// only divergence is the iteration count per stage.  An interior off-diagonal that is (or becomes) negligible is
+// simply swept through: the recurrence restarts by itself there (c -> 1, s -> 0).  p > 0 is an invariant (see
+// `nonzero`), hence r = p + bb > 0 and c = p / r > 0: no division can see a zero.  The last 2x2 block is closed form.
 template <int D>
 __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2)[D]) {
     constexpr double eps = 2.220446049250313e-16;
     constexpr double eps2 = eps * eps;
-    static_for<D - 1>([&](auto ll) {
+    static_for<D - 2>([&](auto ll) {
         constexpr int l = decltype(ll)::value;
-        for (int it = 0; it < 40; ++it) {
-            // m = first index >= l whose off-diagonal is negligible (D-1 if none)
-            int mi = D - 1;
-            static_for_down<D - 2, l>([&](auto mm) {
-                constexpr int q = decltype(mm)::value;
-                if (e2[q] <= eps2 * __builtin_fabs(dg[q] * dg[q + 1])) mi = q;
-            });
-            if (mi == l) break;
-            // shift from the leading 2x2 of the unreduced block
-            double pl = dg[l];
-            double rte = sqrt_pos(e2[l]);
-            double sg = (dg[l + 1] - pl) * rcp(2.0 * rte);
-            double rr = sqrt_pos(__builtin_fma(sg, sg, 1.0));
-            double sigma = pl - rte * rcp(sg + copysign_d(rr, sg));
-            double c = 1.0, s = 0.0, gamma = 0.0, p = 0.0;
+        for (int it = 0; it < 60; ++it) {
+            if (e2[l] <= eps2 * __builtin_fabs(dg[l] * dg[l + 1])) break;
+            // Wilkinson shift from the leading 2x2: sigma = d_l - e2_l / (delta + sign(delta) sqrt(delta^2 + e2_l))
+            double delta = 0.5 * (dg[l + 1] - dg[l]);
+            double den = delta + copysign_d(sqrt_nz(__builtin_fma(delta, delta, e2[l])), delta);
+            double sigma = __builtin_fma(-e2[l], rcp(den), dg[l]);
+            double gamma = nonzero(dg[D - 1] - sigma);
+            double p = gamma * gamma;
+            double c = 1.0, s = 0.0;
             static_for_down<D - 2, l>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
-                if (i < mi) {
-                    if (i == mi - 1) {
-                        gamma = dg[i + 1] - sigma;
-                        p = gamma * gamma;
-                    }
-                    double bb = e2[i];
-                    double r = p + bb;
-                    if (i != mi - 1) e2[i + 1] = s * r;
-                    double oldc = c;
-                    double ir = rcp(r);
-                    c = p * ir;
-                    s = bb * ir;
-                    double oldgam = gamma;
-                    double al = dg[i];
-                    gamma = __builtin_fma(c, al - sigma, -s * oldgam);
-                    dg[i + 1] = oldgam + (al - gamma);
-                    p = (c != 0.0) ? gamma * gamma * rcp(c) : oldc * bb;
-                }
+                double bb = e2[i];
+                double r = p + bb;
+                if constexpr (i != D - 2) e2[i + 1] = s * r;
+                double ir = GABO_QL_RCP(r);
+                c = p * ir;
+                s = bb * ir;
+                double oldgam = gamma;
+                double al = dg[i];
+                gamma = nonzero(__builtin_fma(c, al - sigma, -s * oldgam));
+                dg[i + 1] = oldgam + (al - gamma);
+                p = gamma * gamma * GABO_QL_RCP(c);
             });
             e2[l] = s * p;
             dg[l] = sigma + gamma;
         }
     });
+    // trailing 2x2 [[a, b], [b, c]]: rt1 = larger-magnitude root, rt2 = det / rt1
+    {
+        double a = dg[D - 2], b2 = e2[D - 2], cc = dg[D - 1];
+        double sm = a + cc, df = a - cc;
+        double rt = sqrt_pos(__builtin_fma(df, df, 4.0 * b2));
+        double r1 = 0.5 * (sm + copysign_d(rt, sm));
+        double det = __builtin_fma(a, cc, -b2);
+        dg[D - 2] = r1;
+        dg[D - 1] = (r1 == 0.0) ? 0.0 : det * rcp(r1);
+    }
 }
 
 }  // namespace gabo

@@ -137,21 +137,38 @@ template <int D>
 __global__ __launch_bounds__(256, GABO_PAIR_WAVES) void spd_ai_pairwise_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
                                                               double* __restrict__ out, int64_t n1, int64_t n2,
                                                               int64_t w_batch_stride, int64_t g_batch_stride, int rows,
-                                                              int col_blocks, int row_chunks, double beta, int flags) {
+                                                              int col_blocks, int row_chunks, int64_t sym_tiles, double beta, int flags) {
     constexpr int T = tri_size(D);
     const int mode = flags & GABO_OUT_MASK;
-    const int64_t bid = blockIdx.x;
-    const int64_t cg = bid % col_blocks;
-    const int64_t rc = (bid / col_blocks) % row_chunks;
-    const int64_t b = bid / ((int64_t)col_blocks * row_chunks);
+    int64_t cg, rc, b;
+    if (flags & GABO_SYMMETRIC) {
+        // Only tiles touching the upper triangle exist in the grid: column group cg owns row chunks
+        // [0, min(row_chunks, ceil((cg+1)*cols/rows))).  Enumerating exactly those keeps consecutive block ids
+        // (= consecutive XCDs) equally loaded; skipping blocks of a full grid instead leaves XCD 0 with 1/3 of
+        // the work of XCD 7.
+        const int64_t per_batch = sym_tiles;
+        b = blockIdx.x / per_batch;
+        int64_t t = blockIdx.x - b * per_batch;
+        cg = 0;
+        for (;;) {
+            int64_t cnt = ((cg + 1) * (int64_t)blockDim.x + rows - 1) / rows;
+            if (cnt > row_chunks) cnt = row_chunks;
+            if (t < cnt) break;
+            t -= cnt;
+            ++cg;
+        }
+        rc = t;
+    } else {
+        const int64_t bid = blockIdx.x;
+        cg = bid % col_blocks;
+        rc = (bid / col_blocks) % row_chunks;
+        b = bid / ((int64_t)col_blocks * row_chunks);
+    }
     const int64_t j0 = cg * blockDim.x;
     const int64_t j = j0 + threadIdx.x;
     const int64_t jc = j < n2 ? j : n2 - 1;  // out-of-range lanes recompute the last column and do not store
     const int64_t i0 = rc * rows;
     const int64_t i1 = (i0 + rows < n1) ? i0 + rows : n1;
-    if (flags & GABO_SYMMETRIC) {
-        if (j0 + blockDim.x <= i0) return;  // tile strictly below the diagonal: produced by its mirror tile
-    }
     const double* Gj = G + b * g_batch_stride + jc;
     double* ob = out + b * n1 * n2;
     for (int64_t i = i0; i < i1; ++i) {
@@ -162,15 +179,31 @@ __global__ __launch_bounds__(256, GABO_PAIR_WAVES) void spd_ai_pairwise_kernel(c
         asm volatile("" : "+v"(Gp));
         double s = ai_sumsq<D>(W, Gp, n2);
         double val = finish(s, beta, mode);
-        if (j < n2) {
-            ob[i * n2 + j] = val;
-            if (flags & GABO_SYMMETRIC) {
-                // mirror (j, i) unless the tile owning (j, i) computes it itself
-                int64_t mi0 = (j / rows) * rows;                                  // first row of that tile
-                int64_t mj1 = (i / blockDim.x + 1) * (int64_t)blockDim.x;       // one past its last column
-                if (mj1 <= mi0) ob[j * n2 + i] = val;
-            }
-        }
+        // symmetric mode: only the upper triangle (i <= j) is stored; mirror_upper_kernel fills the rest afterwards,
+        // so the result is exactly symmetric and the mirror writes are coalesced.
+        if (j < n2 && (!(flags & GABO_SYMMETRIC) || i <= j)) ob[i * n2 + j] = val;
+    }
+}
+
+// out[j][i] = out[i][j] for i < j, 32x32 tiles transposed through LDS (reads and writes both run along rows)
+__global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ out, int64_t n, int tiles) {
+    __shared__ double tile[32][33];
+    const int64_t b = blockIdx.y;
+    // block id -> (ti <= tj) over the upper triangle of the tile grid
+    int64_t t = blockIdx.x;
+    int ti = 0;
+    while (t >= tiles - ti) { t -= tiles - ti; ++ti; }
+    int tj = ti + (int)t;
+    double* o = out + b * n * n;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int64_t i = (int64_t)ti * 32 + r, j = (int64_t)tj * 32 + tx;
+        tile[r][tx] = (i < n && j < n) ? o[i * n + j] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int64_t j = (int64_t)tj * 32 + r, i = (int64_t)ti * 32 + tx;  // writes row j, columns i
+        if (i < n && j < n && i < j) o[j * n + i] = tile[tx][r];
     }
 }
 
@@ -195,11 +228,23 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, int64_
     int rows = 16;
     while (rows > 1 && col_blocks * ((n1 + rows - 1) / rows) * batch < 4096) rows >>= 1;
     int64_t row_chunks = (n1 + rows - 1) / rows;
-    int64_t nblocks = col_blocks * row_chunks * batch;
+    int64_t sym_tiles = 0;
+    if (flags & GABO_SYMMETRIC) {
+        for (int64_t cg = 0; cg < col_blocks; ++cg) {
+            int64_t cnt = ((cg + 1) * threads + rows - 1) / rows;
+            sym_tiles += cnt < row_chunks ? cnt : row_chunks;
+        }
+    }
+    int64_t nblocks = ((flags & GABO_SYMMETRIC) ? sym_tiles : col_blocks * row_chunks) * batch;
     if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
     hipLaunchKernelGGL((spd_ai_pairwise_kernel<D>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
                        (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks,
-                       (int)row_chunks, beta, flags);
+                       (int)row_chunks, sym_tiles, beta, flags);
+    if (flags & GABO_SYMMETRIC) {
+        int tiles = (int)((n1 + 31) / 32);
+        hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch), dim3(256), 0, st,
+                           out, n1, tiles);
+    }
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
@@ -220,7 +265,7 @@ int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, int64_
     if (batch == 0 || n1 == 0 || n2 == 0) return GABO_OK;
     if (!x1 || !x2 || !out || !workspace || !status) return GABO_ERR_ARG;
     if (workspace_bytes < gabo_spd_ai_workspace_bytes(batch, n1, n2, d)) return GABO_ERR_ARG;
-    if ((flags & GABO_SYMMETRIC) && n1 != n2) return GABO_ERR_ARG;
+    if ((flags & GABO_SYMMETRIC) && (n1 != n2 || batch > 65535)) return GABO_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     double* ws = (double*)workspace;
 #define GABO_CASE(DD) \

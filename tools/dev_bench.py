@@ -1,7 +1,7 @@
 """Development timing of the pairwise kernels through the C ABI (not the graded bench; see bench.py)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gabotorch_amd import _lib, ops
 from oracle import spd as ospd
 
