@@ -69,7 +69,7 @@ class GramJob:
         self.stream = torch.cuda.current_stream(device)
 
     def step(self):
-        rc = self.lib.gabo_spd_ai_pairwise(self.x.data_ptr(), self.x.data_ptr(), self.out.data_ptr(), 1, self.n, self.n, DIM,
+        rc = self.lib.gabo_spd_ai_pairwise(self.x.data_ptr(), self.x.data_ptr(), self.out.data_ptr(), None, 1, self.n, self.n, DIM,
                                            0, 0, BETA, self.flags, self.ws.data_ptr(), self.wsb, self.status.data_ptr(),
                                            self.stream.cuda_stream)
         if rc != 0:

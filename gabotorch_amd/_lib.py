@@ -23,8 +23,10 @@ _P, _I64, _I, _D, _SZ = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double, _c.c_siz
 SIGNATURES = {
     "gabo_version": (_I, []),
     "gabo_spd_ai_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
-    "gabo_spd_ai_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _P, _SZ, _P, _P]),
+    "gabo_spd_ai_pairwise": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _P, _SZ, _P, _P]),
+    "gabo_spd_ai_backward": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _D, _I, _P, _SZ, _P, _P]),
     "gabo_sphere_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _I, _P]),
+    "gabo_sphere_from_inner": (_I, [_P, _P, _I64, _D, _I, _I, _P]),
     "gabo_mandel_to_matrix": (_I, [_P, _P, _I64, _I, _P]),
     "gabo_matrix_to_mandel": (_I, [_P, _P, _I64, _I, _P]),
 }

@@ -71,6 +71,14 @@ __device__ __forceinline__ double sqrt_nz(double x) {
     return __builtin_fma(dres, h, g);
 }
 
+// 1/sqrt(x), x > 0: e = 1 - x y0^2 (|e| <= 2^-23); y0 (1 + e/2 + 3e^2/8) leaves an e^3 error.
+__device__ __forceinline__ double rsqrt_nz(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-x * y, y, 1.0);
+    double p = e * __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(y, p, y);
+}
+
 // sqrt(x), x >= 0 (sqrt(0) = 0)
 __device__ __forceinline__ double sqrt_pos(double x) {
     double g = sqrt_nz(x);

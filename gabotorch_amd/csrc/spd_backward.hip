@@ -1,0 +1,230 @@
+// Gradient of the SPD affine-invariant pairwise kernels with respect to the FIRST argument (Mandel vectors).
+//
+// The reference gets this by autograd through cholesky / inverse / bmm / symeig(eigenvectors=True) / log / exp
+// (Riemannian_utils/spd_utils_torch.py:87-120, kernel_utils/kernels_spd.py:91-100).  Closed form:
+//
+//     d(d_ij^2)/dA_i = -2 L_i^-T logm(M_ij) L_i^-1,      M_ij = L_i^-1 B_j L_i^-T,  L_i = chol(A_i)
+//     dLoss/dA_i     = -2 L_i^-T [ sum_j w_ij logm(M_ij) ] L_i^-1,   w_ij = dLoss/d(d_ij^2)
+//
+// so only the matrix FUNCTION logm(M) is needed - never an eigenvector derivative - and the congruence with L_i^-1 is
+// applied once per row i.  The gradient with respect to the second argument is this same kernel with the roles of
+// the two sets exchanged and grad_out read transposed (d is symmetric in its arguments).
+//
+// Mapping: one wave per (batch, i); lane = column j, looping over j in chunks of 64.  Each lane forms M (as in the
+// forward kernel), diagonalises it with cyclic Jacobi (eigenvectors needed, so no tridiagonal shortcut), builds
+// logm(M) = V diag(log lambda) V^T, and accumulates w_ij logm(M_ij) into its own LDS column; one cross-lane
+// reduction per row, then the lanes share the final congruence and the Mandel scatter.
+#include "gabo_device.hpp"
+#include "spd_prep.hpp"
+#include "../../include/gabo_hip.h"
+
+namespace gabo {
+
+// Cyclic Jacobi on a packed lower triangle (registers) with accumulated eigenvectors kept in LDS: the D*D doubles of V
+// per lane do not fit the 256 directly addressable VGPRs next to M.  vl[(r*D + c)*64 + lane], columns = eigenvectors.
+template <int D>
+__device__ __forceinline__ void jacobi_eig(double (&m)[tri_size(D)], double* __restrict__ vl) {
+    static_for<D>([&](auto rr) {
+        static_for<D>([&](auto cc) {
+            vl[(decltype(rr)::value * D + decltype(cc)::value) * 64] = (decltype(rr)::value == decltype(cc)::value) ? 1.0 : 0.0;
+        });
+    });
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            dia = __builtin_fma(m[tri(r, r)], m[tri(r, r)], dia);
+            static_for<r>([&](auto cc) { double x = m[tri(r, decltype(cc)::value)]; off = __builtin_fma(x, x, off); });
+        });
+        if (off <= 1e-33 * dia) break;
+        static_for<D - 1>([&](auto pp) {
+            constexpr int p = decltype(pp)::value;
+            static_for<D - 1 - p>([&](auto qq) {
+                constexpr int q = p + 1 + decltype(qq)::value;
+                double apq = m[tri(q, p)];
+                double app = m[tri(p, p)], aqq = m[tri(q, q)];
+                // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)),  theta = (aqq - app) / (2 apq); written division-safe:
+                // t = 2 |apq| sgn(apq h) / (|h| + sqrt(h^2 + 4 apq^2)),  h = aqq - app
+                double h = aqq - app;
+                double den = __builtin_fabs(h) + sqrt_pos(__builtin_fma(h, h, 4.0 * apq * apq));
+                double t = (den == 0.0) ? 0.0 : copysign_d(2.0 * apq, apq * h) * rcp(den == 0.0 ? 1.0 : den);
+                if (h == 0.0) t = (apq == 0.0) ? 0.0 : copysign_d(1.0, apq);
+                double c = rsqrt_nz(__builtin_fma(t, t, 1.0));
+                double s = t * c;
+                m[tri(p, p)] = __builtin_fma(-t, apq, app);
+                m[tri(q, q)] = __builtin_fma(t, apq, aqq);
+                m[tri(q, p)] = 0.0;
+                static_for<D>([&](auto kk) {
+                    constexpr int k = decltype(kk)::value;
+                    if constexpr (k != p && k != q) {
+                        constexpr int ikp = k > p ? tri(k, p) : tri(p, k);
+                        constexpr int ikq = k > q ? tri(k, q) : tri(q, k);
+                        double akp = m[ikp], akq = m[ikq];
+                        m[ikp] = __builtin_fma(c, akp, -s * akq);
+                        m[ikq] = __builtin_fma(s, akp, c * akq);
+                    }
+                    double vkp = vl[(k * D + p) * 64], vkq = vl[(k * D + q) * 64];
+                    vl[(k * D + p) * 64] = __builtin_fma(c, vkp, -s * vkq);
+                    vl[(k * D + q) * 64] = __builtin_fma(s, vkp, c * vkq);
+                });
+            });
+        });
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
+                                                             const double* __restrict__ gout, double* __restrict__ gx,
+                                                             int64_t n1, int64_t n2, int64_t w_batch_stride,
+                                                             int64_t g_batch_stride, int64_t go_sb, int64_t go_si, int64_t go_sj,
+                                                             double beta, int flags) {
+    constexpr int T = tri_size(D);
+    constexpr int LD = 64;  // one accumulator / eigenvector column per lane, lane-contiguous: conflict-free without padding
+    __shared__ double acc[T * LD];
+    __shared__ double vls[D * D * 64];
+    __shared__ double red[T];
+    __shared__ double wl[T];
+    const int mode = flags & GABO_OUT_MASK;
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x / n1;
+    const int64_t i = blockIdx.x - b * n1;
+    const double* W = Winv + b * w_batch_stride + i * T;
+    static_for<T>([&](auto ee) { acc[decltype(ee)::value * LD + lane] = 0.0; });
+    for (int64_t j0 = 0; j0 < n2; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const bool live = j < n2;
+        const int64_t jc = live ? j : n2 - 1;
+        const double* Gj = G + b * g_batch_stride + jc;
+        // M = C C^T, C = W G_j (same construction as the forward kernel)
+        double m[T];
+        static_for<T>([&](auto ee) { m[decltype(ee)::value] = 0.0; });
+        static_for<D>([&](auto cc) {
+            constexpr int col = decltype(cc)::value;
+            double g[D - col], c[D - col];
+            static_for<D - col>([&](auto kk) { g[decltype(kk)::value] = Gj[(int64_t)tri(col + decltype(kk)::value, col) * n2]; });
+            static_for<D - col>([&](auto rr) {
+                constexpr int r = col + decltype(rr)::value;
+                double a = W[tri(r, col)] * g[0];
+                static_for<r - col>([&](auto kk) {
+                    constexpr int k = col + 1 + decltype(kk)::value;
+                    a = __builtin_fma(W[tri(r, k)], g[k - col], a);
+                });
+                c[r - col] = a;
+            });
+            static_for<D - col>([&](auto rr) {
+                constexpr int r = col + decltype(rr)::value;
+                static_for<r - col + 1>([&](auto qq) {
+                    constexpr int q = col + decltype(qq)::value;
+                    m[tri(r, q)] = __builtin_fma(c[r - col], c[q - col], m[tri(r, q)]);
+                });
+            });
+        });
+        double* vl = vls + lane;
+        jacobi_eig<D>(m, vl);
+        double lg[D];
+        double s = 0.0;
+        static_for<D>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            lg[k] = log(m[tri(k, k)]);
+            s = __builtin_fma(lg[k], lg[k], s);
+        });
+        // w = dLoss/d(d^2)
+        double d2 = s + 1e-15;
+        double go = live ? gout[b * go_sb + i * go_si + j * go_sj] : 0.0;
+        double w;
+        if (mode == GABO_OUT_GAUSSIAN) {
+            double dist = __builtin_sqrt(d2);
+            w = go * (-beta) * exp(-((dist * dist) * beta));
+        } else if (mode == GABO_OUT_LAPLACE) {
+            double dist = __builtin_sqrt(d2);
+            w = go * (-beta) * exp(-(dist * beta)) / (2.0 * dist);
+        } else {
+            w = go / (2.0 * __builtin_sqrt(d2));
+        }
+        // acc += w * V diag(lg) V^T   (lower triangle)
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            static_for<r + 1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                double f = 0.0;
+                static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; f = __builtin_fma(vl[(r * D + k) * 64] * lg[k], vl[(c * D + k) * 64], f); });
+                acc[tri(r, c) * LD + lane] = __builtin_fma(w, f, acc[tri(r, c) * LD + lane]);
+            });
+        });
+    }
+    __syncthreads();
+    // reduce over lanes: thread e sums column-array e; also stage W in LDS for the dynamic-index congruence
+    for (int e = lane; e < T; e += 64) {
+        double t = 0.0;
+        for (int l = 0; l < 64; ++l) t += acc[e * LD + ((l + e) & 63)];  // rotated start: threads hit different banks
+        red[e] = t;
+        wl[e] = W[e];
+    }
+    __syncthreads();
+    // grad_A = -2 W^T S W (symmetric); thread e owns entry (a, bb), a >= bb.  W lower: W[r][a] != 0 only for r >= a.
+    for (int e = lane; e < T; e += 64) {
+        int a = 0;
+        while (tri(a + 1, 0) <= e) ++a;
+        int bb = e - tri(a, 0);
+        double t = 0.0;
+        for (int r = a; r < D; ++r) {
+            double inner = 0.0;
+            for (int c = bb; c < D; ++c) {
+                double srs = r >= c ? red[tri(r, c)] : red[tri(c, r)];
+                inner = __builtin_fma(srs, wl[tri(c, bb)], inner);
+            }
+            t = __builtin_fma(wl[tri(r, a)], inner, t);
+        }
+        t *= -2.0;
+        // Mandel: diagonal as is, off-diagonal * sqrt(2)  (= 0.5 (sqrt2 G_rc + sqrt2 G_cr), spd_utils_torch.py:219)
+        gx[(b * n1 + i) * T + mandel_pos(D, a, bb)] = (a == bb) ? t : t * kSqrt2;
+    }
+}
+
+template <int D>
+static int launch_spd_ai_backward(const double* x1, const double* x2, const double* gout, double* gx, int64_t batch, int64_t n1,
+                                  int64_t n2, int64_t s1, int64_t s2, int64_t go_sb, int64_t go_si, int64_t go_sj, double beta,
+                                  int flags, double* ws, int* status, hipStream_t st) {
+    constexpr int T = tri_size(D);
+    const int64_t b1 = (s1 == 0) ? 1 : batch;
+    const int64_t b2 = (s2 == 0) ? 1 : batch;
+    double* W = ws;
+    double* G = ws + b1 * n1 * T;
+    launch_spd_prep<D>(x1, x2, W, G, b1, b2, n1, n2, s1, s2, status, st);
+    int64_t nblocks = batch * n1;
+    if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
+    hipLaunchKernelGGL((spd_ai_backward_kernel<D>), dim3((unsigned)nblocks), dim3(64), 0, st, W, G, gout, gx, n1, n2,
+                       (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, go_sb, go_si, go_sj, beta, flags);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+}  // namespace gabo
+
+extern "C" int gabo_spd_ai_backward(const double* x1, const double* x2, const double* grad_out, double* grad_x1, int64_t batch,
+                                    int64_t n1, int64_t n2, int d, int64_t x1_batch_stride, int64_t x2_batch_stride,
+                                    int64_t go_batch_stride, int64_t go_row_stride, int64_t go_col_stride, double beta, int flags,
+                                    void* workspace, size_t workspace_bytes, int* status, gabo_stream_t stream) {
+    if (batch < 0 || n1 < 0 || n2 < 0 || x1_batch_stride < 0 || x2_batch_stride < 0) return GABO_ERR_ARG;
+    if (d < 2 || d > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
+    if (batch == 0 || n1 == 0) return GABO_OK;
+    if (!x1 || !grad_x1 || !workspace || !status) return GABO_ERR_ARG;
+    if (n2 > 0 && (!x2 || !grad_out)) return GABO_ERR_ARG;
+    if (workspace_bytes < gabo_spd_ai_workspace_bytes(batch, n1, n2, d)) return GABO_ERR_ARG;
+    if (flags & GABO_SYMMETRIC) return GABO_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    double* ws = (double*)workspace;
+#define GABO_CASE(DD) \
+    case DD:          \
+        return gabo::launch_spd_ai_backward<DD>(x1, x2, grad_out, grad_x1, batch, n1, n2, x1_batch_stride, x2_batch_stride, \
+                                                go_batch_stride, go_row_stride, go_col_stride, beta, flags, ws, status, st);
+    switch (d) {
+#ifdef GABO_ONLY_DIM
+        GABO_CASE(GABO_ONLY_DIM)
+#else
+        GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8) GABO_CASE(9) GABO_CASE(10)
+        GABO_CASE(11) GABO_CASE(12)
+#endif
+    }
+#undef GABO_CASE
+    return GABO_ERR_DIM;
+}

@@ -14,6 +14,7 @@
 //      sets stay L2 resident, the only HBM stream is the N1 x N2 output.
 #include "gabo_device.hpp"
 #include "spd_eig.hpp"
+#include "spd_prep.hpp"
 #include "../../include/gabo_hip.h"
 
 #ifndef GABO_PAIR_WAVES
@@ -21,71 +22,6 @@
 #endif
 
 namespace gabo {
-
-template <int D>
-__global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__ x, double* __restrict__ ws,
-                                                      int64_t batch, int64_t n, int64_t batch_stride, int soa,
-                                                      int* __restrict__ status, int status_base) {
-    constexpr int T = tri_size(D);
-    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= batch * n) return;
-    int64_t b = g / n, i = g - b * n;
-    const double* v = x + b * batch_stride + i * T;
-    double a[T];
-    static_for<D>([&](auto rr) {
-        constexpr int r = decltype(rr)::value;
-        static_for<r + 1>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            double e = v[mandel_pos(D, r, c)];
-            a[tri(r, c)] = (r == c) ? e : e / kSqrt2;  // spd_utils_torch.py:186-187 divides by 2**0.5
-        });
-    });
-    // in-place lower Cholesky
-    bool bad = false;
-    static_for<D>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        double piv = a[tri(c, c)];
-        static_for<c>([&](auto kk) { constexpr int k = decltype(kk)::value; piv = __builtin_fma(-a[tri(c, k)], a[tri(c, k)], piv); });
-        if (!(piv > 0.0)) bad = true;
-        double lcc = __builtin_sqrt(piv);
-        double inv = 1.0 / lcc;
-        a[tri(c, c)] = lcc;
-        static_for<D - c - 1>([&](auto rr) {
-            constexpr int r = c + 1 + decltype(rr)::value;
-            double s = a[tri(r, c)];
-            static_for<c>([&](auto kk) { constexpr int k = decltype(kk)::value; s = __builtin_fma(-a[tri(r, k)], a[tri(c, k)], s); });
-            a[tri(r, c)] = s * inv;
-        });
-    });
-    if (bad) {
-        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = status_base + (int)g;
-    }
-    if (soa) {
-        // G, entry-major: ws[(b*T + e) * n + i]
-        static_for<T>([&](auto ee) { ws[(b * T + decltype(ee)::value) * n + i] = a[decltype(ee)::value]; });
-    } else {
-        // W = L^-1 (lower), column by column: W[c][c] = 1/L[c][c]; W[r][c] = -(sum_{k=c}^{r-1} L[r][k] W[k][c]) / L[r][r]
-        double w[T];
-        static_for<D>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            w[tri(c, c)] = 1.0 / a[tri(c, c)];
-        });
-        static_for<D>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            static_for<D - c - 1>([&](auto rr) {
-                constexpr int r = c + 1 + decltype(rr)::value;
-                double s = 0.0;
-                static_for<r - c>([&](auto kk) {
-                    constexpr int k = c + decltype(kk)::value;
-                    s = __builtin_fma(a[tri(r, k)], w[tri(k, c)], s);
-                });
-                w[tri(r, c)] = -s * w[tri(r, r)];
-            });
-        });
-        double* o = ws + g * T;
-        static_for<T>([&](auto ee) { o[decltype(ee)::value] = w[decltype(ee)::value]; });
-    }
-}
 
 // sum_k log^2(lambda_k) of M = C C^T with C = W * G (both lower triangular, W wave-uniform, G per lane)
 template <int D>
@@ -125,8 +61,7 @@ __device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const d
     return s;
 }
 
-__device__ __forceinline__ double finish(double sumsq, double beta, int mode) {
-    double dist = __builtin_sqrt(sumsq + 1e-15);  // spd_utils_torch.py:120
+__device__ __forceinline__ double finish(double dist, double beta, int mode) {
     if (mode == GABO_OUT_DISTANCE) return dist;
     if (mode == GABO_OUT_LAPLACE) return exp(-(dist * beta));   // kernels_spd.py:185
     return exp(-((dist * dist) * beta));                        // kernels_spd.py:94-98
@@ -135,7 +70,8 @@ __device__ __forceinline__ double finish(double sumsq, double beta, int mode) {
 // 1-D grid, block id -> (batch, row chunk of `rows` rows, column group of blockDim.x columns), column group fastest
 template <int D>
 __global__ __launch_bounds__(256, GABO_PAIR_WAVES) void spd_ai_pairwise_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
-                                                              double* __restrict__ out, int64_t n1, int64_t n2,
+                                                              double* __restrict__ out, double* __restrict__ dist_out,
+                                                              int64_t n1, int64_t n2,
                                                               int64_t w_batch_stride, int64_t g_batch_stride, int rows,
                                                               int col_blocks, int row_chunks, int64_t sym_tiles, double beta, int flags) {
     constexpr int T = tri_size(D);
@@ -178,10 +114,14 @@ __global__ __launch_bounds__(256, GABO_PAIR_WAVES) void spd_ai_pairwise_kernel(c
         const double* Gp = Gj;
         asm volatile("" : "+v"(Gp));
         double s = ai_sumsq<D>(W, Gp, n2);
-        double val = finish(s, beta, mode);
+        double dist = __builtin_sqrt(s + 1e-15);  // spd_utils_torch.py:120
+        double val = finish(dist, beta, mode);
         // symmetric mode: only the upper triangle (i <= j) is stored; mirror_upper_kernel fills the rest afterwards,
         // so the result is exactly symmetric and the mirror writes are coalesced.
-        if (j < n2 && (!(flags & GABO_SYMMETRIC) || i <= j)) ob[i * n2 + j] = val;
+        if (j < n2 && (!(flags & GABO_SYMMETRIC) || i <= j)) {
+            ob[i * n2 + j] = val;
+            if (dist_out) dist_out[b * n1 * n2 + i * n2 + j] = dist;
+        }
     }
 }
 
@@ -208,20 +148,14 @@ __global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ 
 }
 
 template <int D>
-static int launch_spd_ai(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
+static int launch_spd_ai(const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
                          int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st) {
     constexpr int T = tri_size(D);
     const int64_t b1 = (s1 == 0) ? 1 : batch;  // a shared set is factored once
     const int64_t b2 = (s2 == 0) ? 1 : batch;
     double* W = ws;
     double* G = ws + b1 * n1 * T;
-    {
-        int64_t tot = b1 * n1;
-        hipLaunchKernelGGL((spd_prep_kernel<D>), dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, x1, W, b1, n1, s1, 0, status, 0);
-        tot = b2 * n2;
-        hipLaunchKernelGGL((spd_prep_kernel<D>), dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, x2, G, b2, n2, s2, 1, status,
-                           (int)(b1 * n1));
-    }
+    launch_spd_prep<D>(x1, x2, W, G, b1, b2, n1, n2, s1, s2, status, st);
     // tile shape: 64..256 columns per block, `rows` rows per block; keep >= ~8 blocks per CU when the problem allows
     int threads = n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
     int64_t col_blocks = (n2 + threads - 1) / threads;
@@ -237,13 +171,16 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, int64_
     }
     int64_t nblocks = ((flags & GABO_SYMMETRIC) ? sym_tiles : col_blocks * row_chunks) * batch;
     if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
-    hipLaunchKernelGGL((spd_ai_pairwise_kernel<D>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
+    hipLaunchKernelGGL((spd_ai_pairwise_kernel<D>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, dist_out, n1, n2,
                        (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks,
                        (int)row_chunks, sym_tiles, beta, flags);
     if (flags & GABO_SYMMETRIC) {
         int tiles = (int)((n1 + 31) / 32);
         hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch), dim3(256), 0, st,
                            out, n1, tiles);
+        if (dist_out)
+            hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch), dim3(256), 0,
+                               st, dist_out, n1, tiles);
     }
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
@@ -257,7 +194,7 @@ size_t gabo_spd_ai_workspace_bytes(int64_t batch, int64_t n1, int64_t n2, int d)
     return (size_t)(batch * (n1 + n2)) * (size_t)gabo::tri_size(d) * sizeof(double);
 }
 
-int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2, int d,
+int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2, int d,
                          int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, void* workspace,
                          size_t workspace_bytes, int* status, gabo_stream_t stream) {
     if (batch < 0 || n1 < 0 || n2 < 0 || x1_batch_stride < 0 || x2_batch_stride < 0) return GABO_ERR_ARG;
@@ -270,7 +207,7 @@ int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, int64_
     double* ws = (double*)workspace;
 #define GABO_CASE(DD) \
     case DD:          \
-        return gabo::launch_spd_ai<DD>(x1, x2, out, batch, n1, n2, x1_batch_stride, x2_batch_stride, beta, flags, ws, status, st);
+        return gabo::launch_spd_ai<DD>(x1, x2, out, dist_out, batch, n1, n2, x1_batch_stride, x2_batch_stride, beta, flags, ws, status, st);
     switch (d) {
 #ifdef GABO_ONLY_DIM  /* development builds: one instantiation compiles in seconds */
         GABO_CASE(GABO_ONLY_DIM)

@@ -1,0 +1,87 @@
+// Per-matrix preparation shared by the forward and backward SPD kernels: Mandel vector -> Cholesky factor.
+//   x1 side: W = L^-1, packed lower, row contiguous  [b][n1][T]   (wave-uniform operand, read through the scalar cache)
+//   x2 side: G = chol(B), entry-major "SoA"           [b][T][n2]   (lane j reads G[e][j]: fully coalesced)
+// A non-positive pivot (input not SPD; the reference raises from torch.cholesky, spd_utils_torch.py:87) sets
+// status[0] = GABO_ERR_NOT_SPD and status[1] = index of the first offender (x1 set first, then x2).
+#pragma once
+#include "gabo_device.hpp"
+#include "../../include/gabo_hip.h"
+
+namespace gabo {
+
+template <int D>
+__global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__ x, double* __restrict__ ws,
+                                                      int64_t batch, int64_t n, int64_t batch_stride, int soa,
+                                                      int* __restrict__ status, int status_base) {
+    constexpr int T = tri_size(D);
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= batch * n) return;
+    int64_t b = g / n, i = g - b * n;
+    const double* v = x + b * batch_stride + i * T;
+    double a[T];
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<r + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            double e = v[mandel_pos(D, r, c)];
+            a[tri(r, c)] = (r == c) ? e : e / kSqrt2;  // spd_utils_torch.py:186-187 divides by 2**0.5
+        });
+    });
+    // in-place lower Cholesky
+    bool bad = false;
+    static_for<D>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        double piv = a[tri(c, c)];
+        static_for<c>([&](auto kk) { constexpr int k = decltype(kk)::value; piv = __builtin_fma(-a[tri(c, k)], a[tri(c, k)], piv); });
+        if (!(piv > 0.0)) bad = true;
+        double lcc = __builtin_sqrt(piv);
+        double inv = 1.0 / lcc;
+        a[tri(c, c)] = lcc;
+        static_for<D - c - 1>([&](auto rr) {
+            constexpr int r = c + 1 + decltype(rr)::value;
+            double s = a[tri(r, c)];
+            static_for<c>([&](auto kk) { constexpr int k = decltype(kk)::value; s = __builtin_fma(-a[tri(r, k)], a[tri(c, k)], s); });
+            a[tri(r, c)] = s * inv;
+        });
+    });
+    if (bad) {
+        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = status_base + (int)g;
+    }
+    if (soa) {
+        // G, entry-major: ws[(b*T + e) * n + i]
+        static_for<T>([&](auto ee) { ws[(b * T + decltype(ee)::value) * n + i] = a[decltype(ee)::value]; });
+    } else {
+        // W = L^-1 (lower), column by column: W[c][c] = 1/L[c][c]; W[r][c] = -(sum_{k=c}^{r-1} L[r][k] W[k][c]) / L[r][r]
+        double w[T];
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            w[tri(c, c)] = 1.0 / a[tri(c, c)];
+        });
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            static_for<D - c - 1>([&](auto rr) {
+                constexpr int r = c + 1 + decltype(rr)::value;
+                double s = 0.0;
+                static_for<r - c>([&](auto kk) {
+                    constexpr int k = c + decltype(kk)::value;
+                    s = __builtin_fma(a[tri(r, k)], w[tri(k, c)], s);
+                });
+                w[tri(r, c)] = -s * w[tri(r, r)];
+            });
+        });
+        double* o = ws + g * T;
+        static_for<T>([&](auto ee) { o[decltype(ee)::value] = w[decltype(ee)::value]; });
+    }
+}
+
+template <int D>
+static void launch_spd_prep(const double* x1, const double* x2, double* W, double* G, int64_t b1, int64_t b2, int64_t n1,
+                            int64_t n2, int64_t s1, int64_t s2, int* status, hipStream_t st) {
+    int64_t tot = b1 * n1;
+    hipLaunchKernelGGL((spd_prep_kernel<D>), dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, x1, W, b1, n1, s1, 0, status, 0);
+    tot = b2 * n2;
+    hipLaunchKernelGGL((spd_prep_kernel<D>), dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, x2, G, b2, n2, s2, 1, status,
+                       (int)(b1 * n1));
+}
+
+}  // namespace gabo

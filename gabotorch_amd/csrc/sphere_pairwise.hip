@@ -70,7 +70,56 @@ __global__ __launch_bounds__(256) void sphere_diag_kernel(const double* __restri
     out[g] = sphere_finish(acc, beta, flags & GABO_OUT_MASK);
 }
 
+// Element-wise f^(order)(c) on a precomputed inner-product matrix c = <x1_i, x2_j>, f(c) = g(clamp(c)):
+//   Gaussian g = exp(-beta acos(c)^2), Laplace g = exp(-beta acos(c)), distance g = acos(c).
+// order 0/1/2 = value / first / second derivative with respect to c (zero where the clamp is active, autograd `clamp`
+// semantics).  This is the differentiable path: the reference differentiates through clamp/acos/exp by autograd, twice for
+// the exact Hessian-vector products of the sphere trust region (pymanopt_addons/tools/autodiff/_pytorch.py:103-116).
+__global__ __launch_bounds__(256) void sphere_from_inner_kernel(const double* __restrict__ cin, double* __restrict__ out, int64_t n,
+                                                                double beta, int mode, int order) {
+    const double lo = -1.0 + 1e-15, hi = 1.0 - 1e-15;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
+        double ip = cin[g];
+        bool inside = ip >= lo && ip <= hi;
+        double c = ip < lo ? lo : (ip > hi ? hi : ip);
+        double th = acos(c);
+        double res;
+        if (order == 0) {
+            res = (mode == GABO_OUT_DISTANCE) ? th : (mode == GABO_OUT_LAPLACE ? exp(-(th * beta)) : exp(-((th * th) * beta)));
+        } else {
+            double om = (1.0 - c) * (1.0 + c);
+            double t1 = -1.0 / __builtin_sqrt(om);     // theta'
+            double t2 = c * t1 / om;                   // theta'' = -c (1-c^2)^-3/2
+            if (mode == GABO_OUT_DISTANCE) {
+                res = order == 1 ? t1 : t2;
+            } else if (mode == GABO_OUT_LAPLACE) {
+                double gv = exp(-(th * beta));
+                double a = -beta * t1;
+                res = order == 1 ? gv * a : gv * (a * a - beta * t2);
+            } else {
+                double gv = exp(-((th * th) * beta));
+                double a = -2.0 * beta * th * t1;
+                res = order == 1 ? gv * a : gv * (a * a - 2.0 * beta * (t1 * t1 + th * t2));
+            }
+            if (!inside) res = 0.0;
+        }
+        out[g] = res;
+    }
+}
+
 }  // namespace gabo
+
+extern "C" int gabo_sphere_from_inner(const double* inner, double* out, int64_t n, double beta, int flags, int order,
+                                      gabo_stream_t stream) {
+    if (n < 0 || order < 0 || order > 2) return GABO_ERR_ARG;
+    if (n == 0) return GABO_OK;
+    if (!inner || !out) return GABO_ERR_ARG;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(gabo::sphere_from_inner_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, inner, out, n, beta,
+                       flags & GABO_OUT_MASK, order);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
 
 extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
                                     int dim, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags,

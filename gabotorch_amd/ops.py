@@ -54,39 +54,136 @@ def _prep(x, device):
     return x.to(device)
 
 
-def spd_ai_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, symmetric=False):
-    """x1 (..., N1, d_vec), x2 (..., N2, d_vec) Mandel vectors -> (..., N1, N2) on x1's device."""
+def _mandel_dim(dv):
+    d = int((-1.0 + (1.0 + 8.0 * dv) ** 0.5) / 2.0)
+    if d * (d + 1) // 2 != dv:
+        raise RuntimeError(f"last dimension {dv} is not d(d+1)/2")
+    return d
+
+
+def _raise_if_not_spd(status, what):
+    if _check_errors:
+        st = status.tolist()
+        if st[0] != 0:
+            raise RuntimeError(f"{what}: input matrix #{st[1]} is not positive definite (Cholesky pivot <= 0)")
+
+
+def spd_ai_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, symmetric=False, return_dist=False):
+    """x1 (..., N1, d_vec), x2 (..., N2, d_vec) Mandel vectors -> (..., N1, N2) on x1's device.
+    return_dist=True also returns the distance matrix written by the same launch."""
     lib = _lib.load()
     if x1.shape[:-2] != x2.shape[:-2] or x1.shape[-1] != x2.shape[-1]:
         raise RuntimeError(f"batch/feature shapes differ: {tuple(x1.shape)} vs {tuple(x2.shape)} (no broadcasting, as in the reference)")
     out_device = x1.device
     dev = _device_for(x1, x2)
     a, b = _prep(x1, dev), _prep(x2, dev)
-    dv = a.shape[-1]
-    d = int((-1.0 + (1.0 + 8.0 * dv) ** 0.5) / 2.0)
-    if d * (d + 1) // 2 != dv:
-        raise RuntimeError(f"last dimension {dv} is not d(d+1)/2")
+    d = _mandel_dim(a.shape[-1])
     n1, n2 = a.shape[-2], b.shape[-2]
     bshape = a.shape[:-2]
     a2, nb, s1 = _flatten_batch(a, 2)
     b2, _, s2 = _flatten_batch(b, 2)
     out = torch.empty(bshape + (n1, n2), dtype=torch.float64, device=dev)
+    dist = torch.empty_like(out) if return_dist else None
     if out.numel() == 0:
-        return out.to(out_device)
+        return (out.to(out_device), dist.to(out_device)) if return_dist else out.to(out_device)
     wsb = lib.gabo_spd_ai_workspace_bytes(nb, n1, n2, d)
     ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
     status = torch.zeros(2, dtype=torch.int32, device=dev)
     flags = int(mode) | (_lib.GABO_SYMMETRIC if symmetric else 0)
     with torch.cuda.device(dev):
-        rc = lib.gabo_spd_ai_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), nb, n1, n2, d, s1, s2, float(beta), flags,
-                                      ws.data_ptr(), wsb, status.data_ptr(), _stream_ptr(dev))
+        rc = lib.gabo_spd_ai_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), dist.data_ptr() if return_dist else None,
+                                      nb, n1, n2, d, s1, s2, float(beta), flags, ws.data_ptr(), wsb, status.data_ptr(),
+                                      _stream_ptr(dev))
     _lib.check(rc, "gabo_spd_ai_pairwise")
-    if _check_errors:
-        st = status.tolist()
-        if st[0] != 0:
-            raise RuntimeError(f"gabo_spd_ai_pairwise: input matrix #{st[1]} is not positive definite "
-                               "(Cholesky pivot <= 0)")
+    _raise_if_not_spd(status, "gabo_spd_ai_pairwise")
+    if return_dist:
+        return out.to(out_device), dist.to(out_device)
     return out.to(out_device)
+
+
+def spd_ai_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, wrt=1):
+    """Gradient of sum(grad_out * spd_ai_pairwise(x1, x2)) with respect to x1 (wrt=1) or x2 (wrt=2), Mandel layout.
+    grad_out (..., N1, N2).  Returns a tensor shaped like the differentiated argument."""
+    lib = _lib.load()
+    out_device = (x1 if wrt == 1 else x2).device
+    dev = _device_for(x1, x2, grad_out)
+    a, b, g = _prep(x1, dev), _prep(x2, dev), _prep(grad_out, dev).contiguous()
+    d = _mandel_dim(a.shape[-1])
+    n1, n2 = a.shape[-2], b.shape[-2]
+    bshape = a.shape[:-2]
+    a2, nb, s1 = _flatten_batch(a, 2)
+    b2, _, s2 = _flatten_batch(b, 2)
+    if wrt == 1:
+        first, second, m1, m2, sf, ss = a2, b2, n1, n2, s1, s2
+        go_si, go_sj = n2, 1
+    else:       # exchange the roles of the two sets and read grad_out transposed
+        first, second, m1, m2, sf, ss = b2, a2, n2, n1, s2, s1
+        go_si, go_sj = 1, n2
+    gx = torch.zeros(bshape + (m1, a.shape[-1]), dtype=torch.float64, device=dev)
+    if gx.numel() == 0 or m2 == 0:
+        return gx.to(out_device)
+    wsb = lib.gabo_spd_ai_workspace_bytes(nb, m1, m2, d)
+    ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gabo_spd_ai_backward(first.data_ptr(), second.data_ptr(), g.data_ptr(), gx.data_ptr(), nb, m1, m2, d, sf, ss,
+                                      n1 * n2, go_si, go_sj, float(beta), int(mode), ws.data_ptr(), wsb, status.data_ptr(),
+                                      _stream_ptr(dev))
+    _lib.check(rc, "gabo_spd_ai_backward")
+    _raise_if_not_spd(status, "gabo_spd_ai_backward")
+    if sf == 0 and nb > 1:      # the differentiated set was one expand()ed set: its gradient is the sum over the batch
+        gx = gx.reshape(nb, m1, -1).sum(0).expand(bshape + (m1, a.shape[-1]))
+    return gx.to(out_device)
+
+
+class _SpdAiKernelFunction(torch.autograd.Function):
+    """K(x1, x2; beta) with the HIP forward and the HIP closed-form backward.  First order only (the reference runs
+    the SPD maximiser with approx_hessian=True for the same reason: manifold_optimize.py:198-202)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, beta, mode):
+        bval = float(beta)
+        need = x1.requires_grad or x2.requires_grad or (torch.is_tensor(beta) and beta.requires_grad)
+        if need:
+            out, dist = spd_ai_pairwise(x1, x2, bval, mode, return_dist=True)
+            ctx.save_for_backward(x1, x2, out, dist)
+        else:
+            same = x1.data_ptr() == x2.data_ptr() and x1.shape == x2.shape and x1.stride() == x2.stride() and x1.dim() == 2
+            out = spd_ai_pairwise(x1, x2, bval, mode, symmetric=same)
+        ctx.bval, ctx.mode = bval, mode
+        ctx.beta_shape = beta.shape if torch.is_tensor(beta) else None
+        ctx.beta_device = beta.device if torch.is_tensor(beta) else None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        x1, x2, out, dist = ctx.saved_tensors
+        g1 = g2 = gb = None
+        if ctx.needs_input_grad[0]:
+            g1 = spd_ai_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=1).to(x1.dtype)
+        if ctx.needs_input_grad[1]:
+            g2 = spd_ai_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=2).to(x2.dtype)
+        if ctx.needs_input_grad[2]:
+            if ctx.mode == _lib.GABO_OUT_GAUSSIAN:
+                gb = -(grad_out * out * dist * dist).sum()      # dK/dbeta = -d^2 K
+            elif ctx.mode == _lib.GABO_OUT_LAPLACE:
+                gb = -(grad_out * out * dist).sum()             # dK/dbeta = -d K
+            else:
+                gb = torch.zeros((), dtype=grad_out.dtype, device=grad_out.device)
+            gb = gb.reshape(ctx.beta_shape).to(ctx.beta_device)
+        return g1, g2, gb, None
+
+
+def spd_ai_kernel(x1, x2, beta, mode=_lib.GABO_OUT_GAUSSIAN):
+    """Differentiable entry point used by the kernel classes.  beta: python float or a one-element tensor."""
+    if torch.is_tensor(beta):
+        if beta.numel() != 1:
+            raise RuntimeError("gabotorch_amd SPD kernels take a single beta (batch_shape == ()), as every reference example does")
+        beta = beta.double()
+    else:
+        beta = torch.tensor(float(beta), dtype=torch.float64)
+    return _SpdAiKernelFunction.apply(x1, x2, beta, int(mode))
 
 
 def sphere_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, diag=False):
@@ -112,6 +209,77 @@ def sphere_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, diag=False):
                                       int(mode), 1 if diag else 0, _stream_ptr(dev))
     _lib.check(rc, "gabo_sphere_pairwise")
     return out.to(out_device)
+
+
+def sphere_from_inner(inner, beta, mode, order):
+    """Element-wise f^(order)(c) on an inner-product tensor (any shape)."""
+    lib = _lib.load()
+    out_device = inner.device
+    dev = _device_for(inner)
+    c = _prep(inner, dev).contiguous()
+    out = torch.empty_like(c)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_sphere_from_inner(c.data_ptr(), out.data_ptr(), c.numel(), float(beta), int(mode), int(order),
+                                              _stream_ptr(dev)), "gabo_sphere_from_inner")
+    return out.to(out_device)
+
+
+class _SphereFromInner(torch.autograd.Function):
+    """f^(order)(c), differentiable in c up to order 2 (value -> gradient -> Hessian-vector product) and, at order 0, in beta."""
+
+    @staticmethod
+    def forward(ctx, c, beta, mode, order):
+        bval = float(beta)
+        out = sphere_from_inner(c, bval, mode, order)
+        ctx.save_for_backward(c, out)
+        ctx.bval, ctx.mode, ctx.order = bval, mode, order
+        ctx.beta_shape = beta.shape if torch.is_tensor(beta) else None
+        ctx.beta_device = beta.device if torch.is_tensor(beta) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        c, out = ctx.saved_tensors
+        gc = gb = None
+        if ctx.needs_input_grad[0]:
+            if ctx.order >= 2:
+                raise RuntimeError("gabotorch_amd sphere kernels are differentiable twice in x, not three times")
+            gc = g * _SphereFromInner.apply(c, torch.tensor(ctx.bval, dtype=torch.float64), ctx.mode, ctx.order + 1)
+        if ctx.needs_input_grad[1]:
+            if ctx.order != 0:
+                raise RuntimeError("mixed x/beta second derivatives of the sphere kernels are not provided")
+            with torch.no_grad():
+                th = sphere_from_inner(c, 1.0, _lib.GABO_OUT_DISTANCE, 0)
+                if ctx.mode == _lib.GABO_OUT_GAUSSIAN:
+                    gb = -(g * out * th * th).sum()
+                elif ctx.mode == _lib.GABO_OUT_LAPLACE:
+                    gb = -(g * out * th).sum()
+                else:
+                    gb = torch.zeros((), dtype=g.dtype, device=g.device)
+                gb = gb.reshape(ctx.beta_shape).to(ctx.beta_device)
+        return gc, gb, None, None
+
+
+def sphere_kernel(x1, x2, beta, mode=_lib.GABO_OUT_GAUSSIAN, diag=False):
+    """Differentiable entry point of the sphere kernels.  Without autograd: one fused pairwise launch.  With autograd: the
+    inner products are a plain batched GEMM (torch.matmul -> rocBLAS) followed by the element-wise HIP kernel, which keeps the
+    expression differentiable twice in x1/x2."""
+    if torch.is_tensor(beta):
+        if beta.numel() != 1:
+            raise RuntimeError("gabotorch_amd sphere kernels take a single beta (batch_shape == ())")
+        beta = beta.double()
+    else:
+        beta = torch.tensor(float(beta), dtype=torch.float64)
+    need = torch.is_grad_enabled() and (x1.requires_grad or x2.requires_grad or beta.requires_grad)
+    if not need:
+        return sphere_pairwise(x1, x2, float(beta), mode, diag=diag)
+    dev = _device_for(x1, x2)
+    a, b = x1.double().to(dev), x2.double().to(dev)
+    if diag:
+        c = (a * b).sum(-1, keepdim=True)
+    else:
+        c = a @ b.transpose(-1, -2)
+    return _SphereFromInner.apply(c, beta, int(mode), 0).to(x1.device)
 
 
 def mandel_to_matrix(vec):

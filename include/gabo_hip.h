@@ -50,14 +50,28 @@ int gabo_version(void);
  *           vector_to_symmetric_matrix_mandel_torch (fused) Riemannian_utils/spd_utils_torch.py:159-194
  *
  * x1: batch x n1 x d_vec Mandel vectors, x2: batch x n2 x d_vec, d_vec = d(d+1)/2, out: batch x n1 x n2.
+ * dist_out: NULL, or a second batch x n1 x n2 buffer that receives the distances d_ij alongside `out` (saved for the
+ * beta-gradient by the autograd wrapper).
  * x{1,2}_batch_stride: distance in doubles between consecutive batches (0 = one set shared by every batch, which is
  * how gpytorch hands over the expanded training inputs).  2 <= d <= GABO_SPD_MAX_DIM.
  * d_ij = sqrt(sum_k log^2 lambda_k(L_i^-1 X2_j L_i^-T) + 1e-15), L_i = chol(X1_i).
  */
 size_t gabo_spd_ai_workspace_bytes(int64_t batch, int64_t n1, int64_t n2, int d);
-int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
-                         int d, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags,
+int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1,
+                         int64_t n2, int d, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags,
                          void* workspace, size_t workspace_bytes, int* status, gabo_stream_t stream);
+
+/* Gradient of the above with respect to x1 (Mandel), given grad_out = dLoss/d(out) for the SAME `flags` output mode.
+ * Replaces the reference's autograd pass through cholesky/inverse/bmm/symeig(eigenvectors=True)
+ * (Riemannian_utils/spd_utils_torch.py:87-120, "Eigenvalue True necessary for derivation" :110); closed form in SURVEY App. C.
+ * grad_out is read as grad_out[b*go_batch_stride + i*go_row_stride + j*go_col_stride] (element strides), so the gradient
+ * with respect to x2 is this same call with the two sets exchanged and the row/column strides swapped.
+ * grad_x1: batch x n1 x d_vec, dense (when x1 is shared across the batch, stride 0, the caller sums over the batch).
+ * Workspace: gabo_spd_ai_workspace_bytes(batch, n1, n2, d).  GABO_SYMMETRIC is not accepted. */
+int gabo_spd_ai_backward(const double* x1, const double* x2, const double* grad_out, double* grad_x1, int64_t batch, int64_t n1,
+                         int64_t n2, int d, int64_t x1_batch_stride, int64_t x2_batch_stride, int64_t go_batch_stride,
+                         int64_t go_row_stride, int64_t go_col_stride, double beta, int flags, void* workspace,
+                         size_t workspace_bytes, int* status, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Sphere pairwise kernel matrix.
@@ -69,6 +83,13 @@ int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, int64_
 int gabo_sphere_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
                          int dim, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, int diag,
                          gabo_stream_t stream);
+
+/* Element-wise value (order 0), first (1) or second (2) derivative, with respect to the inner product c, of
+ * f(c) = g(acos(clamp(c, -1+1e-15, 1-1e-15))) with g chosen by `flags` as above; derivatives are 0 where the clamp is active.
+ * `inner` and `out`: n doubles.  This is the differentiable route (c = x1 x2^T is a plain GEMM): the reference differentiates
+ * sphere_distance_torch / SphereGaussianKernel.forward by autograd, and twice for the exact Hessian-vector products of the
+ * sphere trust region (pymanopt_addons/tools/autodiff/_pytorch.py:103-116). */
+int gabo_sphere_from_inner(const double* inner, double* out, int64_t n, double beta, int flags, int order, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Mandel vector <-> symmetric matrix.

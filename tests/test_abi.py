@@ -27,9 +27,9 @@ def test_host_side_argument_errors_need_no_gpu():
     assert lib.gabo_version() >= 100
     assert lib.gabo_spd_ai_workspace_bytes(2, 3, 4, 10) == 2 * 7 * 55 * 8
     # argument validation happens before any HIP call
-    assert lib.gabo_spd_ai_pairwise(None, None, None, 1, 4, 4, 40, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_ERR_DIM
-    assert lib.gabo_spd_ai_pairwise(None, None, None, 1, 4, 4, 3, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_ERR_ARG
-    assert lib.gabo_spd_ai_pairwise(None, None, None, 1, 0, 4, 3, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_OK
+    assert lib.gabo_spd_ai_pairwise(None, None, None, None, 1, 4, 4, 40, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_spd_ai_pairwise(None, None, None, None, 1, 4, 4, 3, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_spd_ai_pairwise(None, None, None, None, 1, 0, 4, 3, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_OK
     assert lib.gabo_sphere_pairwise(None, None, None, 1, 4, 4, 0, 0, 0, 1.0, 0, 0, None) == _lib.GABO_ERR_DIM
     assert lib.gabo_mandel_to_matrix(None, None, 3, 65, None) == _lib.GABO_ERR_DIM
     assert lib.gabo_mandel_to_matrix(None, None, 0, 5, None) == _lib.GABO_OK
