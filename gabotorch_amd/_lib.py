@@ -12,6 +12,9 @@ GABO_OK = 0
 GABO_ERR_DIM, GABO_ERR_ARG, GABO_ERR_NOT_SPD, GABO_ERR_LAUNCH = -1, -2, -3, -4
 GABO_OUT_GAUSSIAN, GABO_OUT_DISTANCE, GABO_OUT_LAPLACE, GABO_SYMMETRIC = 0, 1, 2, 4
 GABO_SPD_MAX_DIM = 12
+(GABO_SPD_EXP, GABO_SPD_LOG, GABO_SPD_INNER, GABO_SPD_NORM, GABO_SPD_DIST, GABO_SPD_EGRAD2RGRAD, GABO_SPD_EHESS2RHESS,
+ GABO_SPD_LOGM, GABO_SPD_EXPM, GABO_SPD_SQRTM, GABO_SPD_EIGMAX, GABO_SPD_EIGMIN) = range(12)
+GABO_SPH_PROJ, GABO_SPH_RETR, GABO_SPH_EXP, GABO_SPH_LOG, GABO_SPH_DIST, GABO_SPH_EHESS2RHESS = range(6)
 
 _ERR = {GABO_ERR_DIM: "unsupported dimension", GABO_ERR_ARG: "bad argument", GABO_ERR_NOT_SPD: "input is not SPD",
         GABO_ERR_LAUNCH: "kernel launch failed"}
@@ -27,6 +30,11 @@ SIGNATURES = {
     "gabo_spd_ai_backward": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _D, _I, _P, _SZ, _P, _P]),
     "gabo_sphere_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _I, _P]),
     "gabo_sphere_from_inner": (_I, [_P, _P, _I64, _D, _I, _I, _P]),
+    "gabo_spd_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P]),
+    "gabo_spd_project": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
+    "gabo_spd_logm_mandel": (_I, [_P, _P, _I64, _I, _P]),
+    "gabo_frobenius_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _P]),
+    "gabo_sphere_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _I64, _I, _P]),
     "gabo_mandel_to_matrix": (_I, [_P, _P, _I64, _I, _P]),
     "gabo_matrix_to_mandel": (_I, [_P, _P, _I64, _I, _P]),
 }

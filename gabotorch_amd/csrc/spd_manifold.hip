@@ -1,0 +1,526 @@
+// Batched Riemannian operations on the SPD manifold for the acquisition maximiser: one WAVE per matrix, d x d tiles
+// staged in LDS, runtime d (2..32).  These are the per-restart operations the reference calls through pymanopt's
+// PositiveDefinite manifold and its own numpy maps:
+//   exp / retr   X expm(X^-1 U)                       Riemannian_utils/spd_utils.py:104-120 ; [3P] PositiveDefinite.exp/retr
+//   log          L logm(L^-1 Y L^-T) L^T              spd_utils.py:123-139 ; pymanopt_addons/tools/multi.py:55-64
+//   inner/norm   tr(X^-1 U X^-1 V)                    [3P] PositiveDefinite.inner/norm  (call sites robust_trust_regions.py:148,175)
+//   dist         ||logm(L^-1 Y L^-T)||_F              [3P] PositiveDefinite.dist (gabo_spd.py:289)
+//   egrad2rgrad  X sym(G) X                           [3P] (pymanopt_addons/problem.py:135)
+//   ehess2rhess  X sym(H) X + sym(U sym(G) X)         [3P] (problem.py:156)
+//   logm / expm / sqrtm of a symmetric matrix         spd_utils_torch.py:13-50 ; tools/multi.py:55-75
+//   lambda_max / lambda_min and their gradients       spd_constraints_utils_torch.py:17-50
+// R restarts are R independent blocks; inside a block the 64 lanes share the O(d^3) loops element-wise and the
+// eigen-decomposition is cyclic Jacobi with the rotation applied in parallel over the row/column index.
+#include "gabo_device.hpp"
+#include "../../include/gabo_hip.h"
+
+namespace gabo {
+
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+
+// symmetric matrix from a Mandel vector (global) into LDS
+__device__ void lds_from_mandel(const double* __restrict__ v, double* A, int d) {
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
+        int r = e / d, c = e - r * d;
+        int hi = r > c ? r : c, lo = r > c ? c : r;
+        double x = v[mandel_pos(d, hi, lo)];
+        A[e] = (r == c) ? x : x / kSqrt2;
+    }
+    wsync();
+}
+
+__device__ void lds_load(const double* __restrict__ src, double* A, int d) {
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) A[e] = src[e];
+    wsync();
+}
+
+// A <- (A + A^T)/2 using T as scratch
+__device__ void lds_symmetrize(double* A, double* T, int d) {
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
+        int r = e / d, c = e - r * d;
+        T[e] = 0.5 * (A[e] + A[c * d + r]);
+    }
+    wsync();
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) A[e] = T[e];
+    wsync();
+}
+
+// in-place lower Cholesky (strict upper zeroed).  Returns false when a pivot is not positive.
+__device__ bool lds_cholesky(double* A, int d) {
+    bool ok = true;
+    for (int c = 0; c < d; ++c) {
+        double piv = A[c * d + c];
+        for (int k = 0; k < c; ++k) piv -= A[c * d + k] * A[c * d + k];
+        if (!(piv > 0.0)) ok = false;
+        double lcc = __builtin_sqrt(piv);
+        wsync();
+        for (int r = c + threadIdx.x; r < d; r += blockDim.x) {
+            if (r == c) {
+                A[c * d + c] = lcc;
+            } else {
+                double s = A[r * d + c];
+                for (int k = 0; k < c; ++k) s -= A[r * d + k] * A[c * d + k];
+                A[r * d + c] = s / lcc;
+            }
+        }
+        for (int r = threadIdx.x; r < c; r += blockDim.x) A[r * d + c] = 0.0;
+        wsync();
+    }
+    return ok;
+}
+
+// W = L^-1 for lower-triangular L: thread c owns column c (forward substitution)
+__device__ void lds_tri_inverse(const double* L, double* W, int d) {
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        for (int r = 0; r < c; ++r) W[r * d + c] = 0.0;
+        W[c * d + c] = 1.0 / L[c * d + c];
+        for (int r = c + 1; r < d; ++r) {
+            double s = 0.0;
+            for (int k = c; k < r; ++k) s += L[r * d + k] * W[k * d + c];
+            W[r * d + c] = -s / L[r * d + r];
+        }
+    }
+    wsync();
+}
+
+// C = op(A) op(B), thread per output element; C must not alias A or B
+__device__ void lds_mm(const double* A, const double* B, double* C, int d, bool ta, bool tb) {
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
+        int r = e / d, c = e - r * d;
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) {
+            double a = ta ? A[k * d + r] : A[r * d + k];
+            double b = tb ? B[c * d + k] : B[k * d + c];
+            s = __builtin_fma(a, b, s);
+        }
+        C[e] = s;
+    }
+    wsync();
+}
+
+// C = A B A^T (congruence), T scratch
+__device__ void lds_congruence(const double* A, const double* B, double* C, double* T, int d) {
+    lds_mm(A, B, T, d, false, false);
+    lds_mm(T, A, C, d, false, true);
+}
+
+// Cyclic Jacobi: A (symmetric, full storage) -> diagonal; V = eigenvectors in columns.  cs: 2 doubles of LDS.
+__device__ void lds_jacobi(double* A, double* V, double* cs, int d) {
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) V[e] = (e / d == e % d) ? 1.0 : 0.0;
+    wsync();
+    for (int sweep = 0; sweep < 15; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int r = 0; r < d; ++r) {
+            dia += A[r * d + r] * A[r * d + r];
+            for (int c = 0; c < r; ++c) off += A[r * d + c] * A[r * d + c];
+        }
+        if (off <= 1e-33 * dia) break;   // uniform: every thread reads the same LDS values
+        for (int p = 0; p < d - 1; ++p) {
+            for (int q = p + 1; q < d; ++q) {
+                if (threadIdx.x == 0) {
+                    double apq = A[q * d + p], app = A[p * d + p], aqq = A[q * d + q];
+                    double h = aqq - app;
+                    double den = __builtin_fabs(h) + __builtin_sqrt(h * h + 4.0 * apq * apq);
+                    double t = (den == 0.0) ? 0.0 : copysign_d(2.0 * apq, apq * h) / (den == 0.0 ? 1.0 : den);
+                    if (h == 0.0) t = (apq == 0.0) ? 0.0 : copysign_d(1.0, apq);
+                    double c = 1.0 / __builtin_sqrt(t * t + 1.0);
+                    cs[0] = c;
+                    cs[1] = t * c;
+                }
+                wsync();
+                double c = cs[0], s = cs[1];
+                // columns p, q of A and V  (A <- A J)
+                for (int k = threadIdx.x; k < d; k += blockDim.x) {
+                    double akp = A[k * d + p], akq = A[k * d + q];
+                    A[k * d + p] = c * akp - s * akq;
+                    A[k * d + q] = s * akp + c * akq;
+                    double vkp = V[k * d + p], vkq = V[k * d + q];
+                    V[k * d + p] = c * vkp - s * vkq;
+                    V[k * d + q] = s * vkp + c * vkq;
+                }
+                wsync();
+                // rows p, q of A  (A <- J^T A)
+                for (int k = threadIdx.x; k < d; k += blockDim.x) {
+                    double apk = A[p * d + k], aqk = A[q * d + k];
+                    A[p * d + k] = c * apk - s * aqk;
+                    A[q * d + k] = s * apk + c * aqk;
+                }
+                wsync();
+                if (threadIdx.x == 0) { A[p * d + q] = 0.0; A[q * d + p] = 0.0; }
+                wsync();
+            }
+        }
+    }
+}
+
+enum { FN_LOG = 0, FN_EXP = 1, FN_SQRT = 2 };
+
+// F = V f(diag(A)) V^T
+__device__ void lds_fun_from_eig(const double* A, const double* V, double* F, int d, int fn) {
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
+        int r = e / d, c = e - r * d;
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) {
+            double lam = A[k * d + k];
+            double f = fn == FN_LOG ? log(lam) : (fn == FN_EXP ? exp(lam) : __builtin_sqrt(lam));
+            s = __builtin_fma(V[r * d + k] * f, V[c * d + k], s);
+        }
+        F[e] = s;
+    }
+    wsync();
+}
+
+__device__ void lds_store(const double* A, double* __restrict__ dst, int d) {
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) dst[e] = A[e];
+}
+
+// op codes of gabo_spd_manifold_op
+enum {
+    OP_EXP = 0, OP_LOG = 1, OP_INNER = 2, OP_NORM = 3, OP_DIST = 4, OP_EGRAD2RGRAD = 5, OP_EHESS2RHESS = 6, OP_LOGM = 7,
+    OP_EXPM = 8, OP_SQRTM = 9, OP_EIGMAX = 10, OP_EIGMIN = 11
+};
+
+// a, b, c: up to three input matrix batches (n x d x d, row-major); out: n x d x d or n scalars (+ n x d x d gradient in out2)
+__global__ __launch_bounds__(64) void spd_manifold_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
+                                                          const double* __restrict__ c, const double* __restrict__ e,
+                                                          double* __restrict__ out, double* __restrict__ out2, int64_t n, int d,
+                                                          int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int dd = d * d;
+    double* M0 = lds;            // 6 matrices + 2 scalars
+    double* M1 = M0 + dd;
+    double* M2 = M1 + dd;
+    double* M3 = M2 + dd;
+    double* M4 = M3 + dd;
+    double* M5 = M4 + dd;
+    double* cs = M5 + dd;
+    const int64_t i = blockIdx.x;
+    const double* A = a + i * dd;
+    bool ok = true;
+    switch (op) {
+        case OP_EXP:    // a = X (base), b = U (tangent)
+        case OP_LOG: {  // a = X (base), b = Y (point)
+            lds_load(A, M0, d);
+            lds_load(b + i * dd, M1, d);
+            lds_symmetrize(M1, M5, d);
+            ok = lds_cholesky(M0, d);            // M0 = L
+            lds_tri_inverse(M0, M2, d);          // M2 = W
+            lds_congruence(M2, M1, M3, M4, d);   // M3 = W B W^T
+            lds_symmetrize(M3, M5, d);
+            lds_jacobi(M3, M4, cs, d);           // M3 diag, M4 = V
+            lds_fun_from_eig(M3, M4, M1, d, op == OP_EXP ? FN_EXP : FN_LOG);
+            lds_congruence(M0, M1, M3, M4, d);   // L F L^T
+            lds_symmetrize(M3, M5, d);
+            lds_store(M3, out + i * dd, d);
+            break;
+        }
+        case OP_INNER:   // a = X, b = U, c = V
+        case OP_NORM: {  // a = X, b = U
+            lds_load(A, M0, d);
+            lds_load(b + i * dd, M1, d);
+            ok = lds_cholesky(M0, d);
+            lds_tri_inverse(M0, M2, d);
+            lds_congruence(M2, M1, M3, M4, d);
+            if (op == OP_INNER) {
+                lds_load(c + i * dd, M1, d);
+                lds_congruence(M2, M1, M5, M4, d);
+            }
+            const double* Q = op == OP_INNER ? M5 : M3;
+            if (threadIdx.x == 0) {
+                double s = 0.0;
+                for (int k = 0; k < dd; ++k) s = __builtin_fma(M3[k], Q[k], s);
+                out[i] = op == OP_INNER ? s : __builtin_sqrt(s > 0.0 ? s : 0.0);
+            }
+            break;
+        }
+        case OP_DIST: {  // a = X, b = Y
+            lds_load(A, M0, d);
+            lds_load(b + i * dd, M1, d);
+            ok = lds_cholesky(M0, d);
+            lds_tri_inverse(M0, M2, d);
+            lds_congruence(M2, M1, M3, M4, d);
+            lds_symmetrize(M3, M5, d);
+            lds_jacobi(M3, M4, cs, d);
+            if (threadIdx.x == 0) {
+                double s = 0.0;
+                for (int k = 0; k < d; ++k) { double lg = log(M3[k * d + k]); s = __builtin_fma(lg, lg, s); }
+                out[i] = __builtin_sqrt(s);
+            }
+            break;
+        }
+        case OP_EGRAD2RGRAD: {  // a = X, b = G  ->  X sym(G) X
+            lds_load(A, M0, d);
+            lds_load(b + i * dd, M1, d);
+            lds_symmetrize(M1, M5, d);
+            lds_congruence(M0, M1, M3, M4, d);   // X symmetric: X S X^T = X S X
+            lds_store(M3, out + i * dd, d);
+            break;
+        }
+        case OP_EHESS2RHESS: {  // a = X, b = egrad, c = ehess, e = U  ->  X sym(eh) X + sym(U sym(eg) X)
+            lds_load(A, M0, d);
+            lds_load(c + i * dd, M1, d);
+            lds_symmetrize(M1, M5, d);
+            lds_congruence(M0, M1, M3, M4, d);   // M3 = X sym(eh) X
+            lds_load(b + i * dd, M1, d);
+            lds_symmetrize(M1, M5, d);           // M1 = sym(eg)
+            lds_load(e + i * dd, M2, d);         // M2 = U
+            lds_mm(M2, M1, M4, d, false, false); // U sym(eg)
+            lds_mm(M4, M0, M5, d, false, false); // U sym(eg) X
+            for (int k = threadIdx.x; k < dd; k += blockDim.x) {
+                int r = k / d, cc = k - r * d;
+                out[i * dd + k] = M3[k] + 0.5 * (M5[k] + M5[cc * d + r]);
+            }
+            break;
+        }
+        case OP_LOGM:
+        case OP_EXPM:
+        case OP_SQRTM: {
+            lds_load(A, M0, d);
+            lds_symmetrize(M0, M5, d);
+            lds_jacobi(M0, M1, cs, d);
+            lds_fun_from_eig(M0, M1, M2, d, op == OP_LOGM ? FN_LOG : (op == OP_EXPM ? FN_EXP : FN_SQRT));
+            lds_store(M2, out + i * dd, d);
+            break;
+        }
+        case OP_EIGMAX:
+        case OP_EIGMIN: {  // out[i] = extreme eigenvalue, out2 = v v^T (its Euclidean gradient w.r.t. the symmetric matrix)
+            lds_load(A, M0, d);
+            lds_symmetrize(M0, M5, d);
+            lds_jacobi(M0, M1, cs, d);
+            int best = 0;
+            for (int k = 1; k < d; ++k) {
+                bool better = op == OP_EIGMAX ? (M0[k * d + k] > M0[best * d + best]) : (M0[k * d + k] < M0[best * d + best]);
+                if (better) best = k;
+            }
+            if (threadIdx.x == 0) out[i] = M0[best * d + best];
+            if (out2) {
+                for (int k = threadIdx.x; k < dd; k += blockDim.x) {
+                    int r = k / d, cc = k - r * d;
+                    out2[i * dd + k] = M1[r * d + best] * M1[cc * d + best];
+                }
+            }
+            break;
+        }
+        default: break;
+    }
+    if (!ok && threadIdx.x == 0 && status) {
+        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = (int)i;
+    }
+}
+
+// Y = W^T X W straight from / to Mandel vectors: x (n x D_vec), w (D x dl), y (n x dl_vec).   nested_spd_utils.py:13-48
+__global__ __launch_bounds__(64) void spd_project_kernel(const double* __restrict__ x, const double* __restrict__ w,
+                                                         double* __restrict__ y, int64_t n, int D, int dl) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* X = lds;              // D x D
+    double* Wl = X + D * D;       // D x dl
+    double* T = Wl + D * dl;      // D x dl : X W
+    const int64_t i = blockIdx.x;
+    lds_from_mandel(x + i * (int64_t)(D * (D + 1) / 2), X, D);
+    for (int e = threadIdx.x; e < D * dl; e += blockDim.x) Wl[e] = w[e];
+    wsync();
+    for (int e = threadIdx.x; e < D * dl; e += blockDim.x) {
+        int r = e / dl, c = e - r * dl;
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s = __builtin_fma(X[r * D + k], Wl[k * dl + c], s);
+        T[e] = s;
+    }
+    wsync();
+    const int dv = dl * (dl + 1) / 2;
+    for (int e = threadIdx.x; e < dv; e += blockDim.x) {
+        int k = 0;
+        while (k + 1 < dl && (k + 1) * dl - (k + 1) * k / 2 <= e) ++k;
+        int c = e - (k * dl - k * (k - 1) / 2);
+        int r = c + k;
+        double s1 = 0.0, s2 = 0.0;   // (r,c) and (c,r): averaged like symmetric_matrix_to_vector_mandel_torch
+        for (int q = 0; q < D; ++q) {
+            s1 = __builtin_fma(Wl[q * dl + r], T[q * dl + c], s1);
+            s2 = __builtin_fma(Wl[q * dl + c], T[q * dl + r], s2);
+        }
+        y[i * dv + e] = (k == 0) ? s1 : 0.5 * (kSqrt2 * s1 + kSqrt2 * s2);
+    }
+}
+
+// logm of SPD matrices, Mandel in -> Mandel out (the per-point part of SpdLogEuclideanGaussianKernel, kernels_spd.py:289-305)
+__global__ __launch_bounds__(64) void spd_logm_mandel_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t n, int d) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int dd = d * d;
+    double* M0 = lds;
+    double* M1 = M0 + dd;
+    double* M2 = M1 + dd;
+    double* cs = M2 + dd;
+    const int64_t i = blockIdx.x;
+    const int dv = d * (d + 1) / 2;
+    lds_from_mandel(x + i * dv, M0, d);
+    lds_jacobi(M0, M1, cs, d);
+    lds_fun_from_eig(M0, M1, M2, d, FN_LOG);
+    for (int e = threadIdx.x; e < dv; e += blockDim.x) {
+        int k = 0;
+        while (k + 1 < d && (k + 1) * d - (k + 1) * k / 2 <= e) ++k;
+        int c = e - (k * d - k * (k - 1) / 2);
+        int r = c + k;
+        y[i * dv + e] = (k == 0) ? M2[r * d + c] : 0.5 * (kSqrt2 * M2[r * d + c] + kSqrt2 * M2[c * d + r]);
+    }
+}
+
+// Pairwise Frobenius distance between symmetric matrices given as Mandel vectors, with the reference's +1e-15 on EVERY
+// matrix element of the difference (spd_utils_torch.py:156): in Mandel coordinates that is +1e-15 on diagonal entries and
+// +sqrt2*1e-15 on off-diagonal ones.  out = d, exp(-beta d^2) or exp(-beta d).
+__global__ __launch_bounds__(256) void frobenius_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
+                                                                 double* __restrict__ out, int64_t total, int64_t n1, int64_t n2,
+                                                                 int d, int64_t s1, int64_t s2, double beta, int flags) {
+    const int dv = d * (d + 1) / 2;
+    const int mode = flags & GABO_OUT_MASK;
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    int64_t per = n1 * n2;
+    int64_t b = g / per;
+    int64_t rem = g - b * per;
+    int64_t i = rem / n2, j = rem - i * n2;
+    const double* p = x1 + b * s1 + i * dv;
+    const double* q = x2 + b * s2 + j * dv;
+    double s = 0.0;
+    for (int e = 0; e < dv; ++e) {
+        double diff = (p[e] - q[e]) + (e < d ? 1e-15 : kSqrt2 * 1e-15);
+        s = __builtin_fma(diff, diff, s);
+    }
+    double dist = __builtin_sqrt(s);
+    out[g] = mode == GABO_OUT_DISTANCE ? dist : (mode == GABO_OUT_LAPLACE ? exp(-(dist * beta)) : exp(-((dist * dist) * beta)));
+}
+
+// Sphere manifold operations, one lane per point (dim is small): x, u, v: n x dim.
+enum { SOP_PROJ = 0, SOP_RETR = 1, SOP_EXP = 2, SOP_LOG = 3, SOP_DIST = 4, SOP_EHESS2RHESS = 5 };
+
+__global__ __launch_bounds__(256) void sphere_manifold_kernel(int op, const double* __restrict__ x, const double* __restrict__ u,
+                                                              const double* __restrict__ v, const double* __restrict__ w,
+                                                              double* __restrict__ out, int64_t n, int dim) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* X = x + i * dim;
+    const double* U = u + i * dim;
+    double* O = out + i * dim;
+    switch (op) {
+        case SOP_PROJ: {  // H - <X,H> X                          [3P] Sphere.proj / egrad2rgrad / transp(.,Y,U) = proj(Y,U)
+            double ip = 0.0;
+            for (int k = 0; k < dim; ++k) ip = __builtin_fma(X[k], U[k], ip);
+            for (int k = 0; k < dim; ++k) O[k] = U[k] - ip * X[k];
+            break;
+        }
+        case SOP_RETR: {  // (X+U)/|X+U|                           [3P] Sphere.retr
+            double nn = 0.0;
+            for (int k = 0; k < dim; ++k) { double y = X[k] + U[k]; nn = __builtin_fma(y, y, nn); }
+            double inv = 1.0 / __builtin_sqrt(nn);
+            for (int k = 0; k < dim; ++k) O[k] = (X[k] + U[k]) * inv;
+            break;
+        }
+        case SOP_EXP: {  // x cos|u| + u sin|u|/|u| ; x where |u| < 1e-16     sphere_utils.py:14-38 (base = x, tangent = u)
+            double nn = 0.0;
+            for (int k = 0; k < dim; ++k) nn = __builtin_fma(U[k], U[k], nn);
+            double nu = __builtin_sqrt(nn);
+            if (nu < 1e-16) {
+                for (int k = 0; k < dim; ++k) O[k] = X[k];
+            } else {
+                double cn = cos(nu), sn = sin(nu) / nu;
+                for (int k = 0; k < dim; ++k) O[k] = X[k] * cn + U[k] * sn;
+            }
+            break;
+        }
+        case SOP_LOG: {  // (y - x cos t) t / sin t, t = acos(clip(<x,y>)); 0 where t < 1e-16   sphere_utils.py:41-65 (base = x, point = u)
+            double ip = 0.0;
+            for (int k = 0; k < dim; ++k) ip = __builtin_fma(X[k], U[k], ip);
+            ip = ip > 1.0 ? 1.0 : (ip < -1.0 ? -1.0 : ip);
+            double th = acos(ip);
+            if (th < 1e-16) {
+                for (int k = 0; k < dim; ++k) O[k] = 0.0;
+            } else {
+                double cn = cos(th), f = th / sin(th);
+                for (int k = 0; k < dim; ++k) O[k] = (U[k] - X[k] * cn) * f;
+            }
+            break;
+        }
+        case SOP_DIST: {  // acos(clip(<x,y>, -1, 1))              [3P] Sphere.dist
+            double ip = 0.0;
+            for (int k = 0; k < dim; ++k) ip = __builtin_fma(X[k], U[k], ip);
+            ip = ip > 1.0 ? 1.0 : (ip < -1.0 ? -1.0 : ip);
+            out[i] = acos(ip);
+            break;
+        }
+        case SOP_EHESS2RHESS: {  // proj(x, eh) - <x, eg> u : u = egrad, v = ehess, w = tangent    [3P]
+            const double* EH = v + i * dim;
+            const double* TG = w + i * dim;
+            double a = 0.0, bq = 0.0;
+            for (int k = 0; k < dim; ++k) { a = __builtin_fma(X[k], EH[k], a); bq = __builtin_fma(X[k], U[k], bq); }
+            for (int k = 0; k < dim; ++k) O[k] = EH[k] - a * X[k] - bq * TG[k];
+            break;
+        }
+        default: break;
+    }
+}
+
+}  // namespace gabo
+
+extern "C" {
+
+int gabo_spd_manifold_op(int op, const double* a, const double* b, const double* c, const double* e, double* out, double* out2,
+                         int64_t n, int d, int* status, gabo_stream_t stream) {
+    if (n < 0 || op < 0 || op > gabo::OP_EIGMIN) return GABO_ERR_ARG;
+    if (d < 1 || d > 32) return GABO_ERR_DIM;
+    if (n == 0) return GABO_OK;
+    if (!a || !out) return GABO_ERR_ARG;
+    const bool need_b = op <= gabo::OP_EHESS2RHESS;
+    if (need_b && !b) return GABO_ERR_ARG;
+    if ((op == gabo::OP_INNER || op == gabo::OP_EHESS2RHESS) && !c) return GABO_ERR_ARG;
+    if (op == gabo::OP_EHESS2RHESS && !e) return GABO_ERR_ARG;
+    if (n > 0x7fffffffLL) return GABO_ERR_ARG;
+    size_t lds = (size_t)(6 * d * d + 2) * sizeof(double);
+    hipLaunchKernelGGL(gabo::spd_manifold_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
+                       d, status);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_spd_project(const double* x_mandel, const double* w, double* y_mandel, int64_t n, int D, int dl, gabo_stream_t stream) {
+    if (n < 0) return GABO_ERR_ARG;
+    if (D < 1 || D > 64 || dl < 1 || dl > D) return GABO_ERR_DIM;
+    if (n == 0) return GABO_OK;
+    if (!x_mandel || !w || !y_mandel || n > 0x7fffffffLL) return GABO_ERR_ARG;
+    size_t lds = (size_t)(D * D + 2 * D * dl) * sizeof(double);
+    hipLaunchKernelGGL(gabo::spd_project_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel, w, y_mandel, n, D, dl);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_spd_logm_mandel(const double* x_mandel, double* y_mandel, int64_t n, int d, gabo_stream_t stream) {
+    if (n < 0) return GABO_ERR_ARG;
+    if (d < 1 || d > 32) return GABO_ERR_DIM;
+    if (n == 0) return GABO_OK;
+    if (!x_mandel || !y_mandel || n > 0x7fffffffLL) return GABO_ERR_ARG;
+    size_t lds = (size_t)(3 * d * d + 2) * sizeof(double);
+    hipLaunchKernelGGL(gabo::spd_logm_mandel_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel, y_mandel, n, d);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_frobenius_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2, int d,
+                            int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, gabo_stream_t stream) {
+    if (batch < 0 || n1 < 0 || n2 < 0 || x1_batch_stride < 0 || x2_batch_stride < 0) return GABO_ERR_ARG;
+    if (d < 1 || d > 64) return GABO_ERR_DIM;
+    if (batch == 0 || n1 == 0 || n2 == 0) return GABO_OK;
+    if (!x1 || !x2 || !out) return GABO_ERR_ARG;
+    int64_t tot = batch * n1 * n2;
+    int64_t blocks = (tot + 255) / 256;
+    if (blocks > 0x7fffffffLL) return GABO_ERR_ARG;
+    hipLaunchKernelGGL(gabo::frobenius_pairwise_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, out, tot,
+                       n1, n2, d, x1_batch_stride, x2_batch_stride, beta, flags);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_sphere_manifold_op(int op, const double* x, const double* u, const double* v, const double* w, double* out, int64_t n,
+                            int dim, gabo_stream_t stream) {
+    if (n < 0 || op < 0 || op > gabo::SOP_EHESS2RHESS) return GABO_ERR_ARG;
+    if (dim < 1) return GABO_ERR_DIM;
+    if (n == 0) return GABO_OK;
+    if (!x || !u || !out) return GABO_ERR_ARG;
+    if (op == gabo::SOP_EHESS2RHESS && (!v || !w)) return GABO_ERR_ARG;
+    hipLaunchKernelGGL(gabo::sphere_manifold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, x, u, v,
+                       w, out, n, dim);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+}

@@ -56,3 +56,93 @@ class SpdAffineInvariantLaplaceKernel(_BetaKernel):
         if diagonal_distance is True:
             return _diag_ones(x2)
         return ops.spd_ai_kernel(x1, x2, self.beta.double(), _lib.GABO_OUT_LAPLACE)
+
+
+class SpdFrobeniusGaussianKernel(Kernel):
+    """k(X, Y) = exp(-||X - Y + 1e-15||_F^2 / lengthscale^2) on Mandel inputs   (kernels_spd.py:190-241).
+    Forward only on the HIP path (no gradient with respect to the inputs)."""
+
+    def __init__(self, **kwargs):
+        self.has_lengthscale = True
+        super().__init__(has_lengthscale=True, ard_num_dims=None, **kwargs)
+
+    def forward(self, x1, x2, diagonal_distance=False, **params):
+        if diagonal_distance is True:
+            return _diag_ones(x2)
+        ls = self.lengthscale.double()
+        return _lengthscale_kernel(ops.frobenius_pairwise(x1.detach(), x2.detach(), mode=_lib.GABO_OUT_DISTANCE), ls)
+
+
+class SpdLogEuclideanGaussianKernel(Kernel):
+    """k(X, Y) = exp(-||logm X - logm Y + 1e-15||_F^2 / lengthscale^2)   (kernels_spd.py:244-313): O(N) matrix logarithms
+    (one wave per matrix) + one pairwise Frobenius launch, instead of the reference's two Python loops."""
+
+    def __init__(self, **kwargs):
+        self.has_lengthscale = True
+        super().__init__(has_lengthscale=True, ard_num_dims=None, **kwargs)
+
+    def forward(self, x1, x2, diagonal_distance=False, **params):
+        if diagonal_distance is True:
+            return _diag_ones(x2)
+        l1 = ops.spd_logm_mandel(x1.detach())
+        l2 = l1 if x2 is x1 else ops.spd_logm_mandel(x2.detach())
+        return _lengthscale_kernel(ops.frobenius_pairwise(l1, l2, mode=_lib.GABO_OUT_DISTANCE), self.lengthscale.double())
+
+
+def _lengthscale_kernel(dist, ls):
+    # exp(-d^2 / l^2): a one-line epilogue kept in torch so the lengthscale stays differentiable for the GP fit
+    return torch.exp(-(dist * dist) / (ls.to(dist.device) * ls.to(dist.device)))
+
+
+class NestedSpdAffineInvariantGaussianKernel(_BetaKernel):
+    """Affine-invariant Gaussian kernel after the nested projection Y = W^T X W, W in G(D, d)
+    (kernel_utils/kernels_nested_spd.py:19-136).  The projection matrix is a plain parameter here (pymanopt's Grassmann
+    manifold, used by the reference only to draw the initial W, is replaced by qr(randn))."""
+
+    def __init__(self, dim, latent_dim, beta_min, beta_prior=None, **kwargs):
+        super().__init__(beta_min, beta_prior, **kwargs)
+        self.dim, self.latent_dim = dim, latent_dim
+        q, _ = torch.linalg.qr(torch.randn(dim, latent_dim, dtype=torch.float64))
+        self.register_parameter(name="raw_projection_matrix", parameter=torch.nn.Parameter(q.repeat(*self.batch_shape, 1, 1)))
+
+    @property
+    def projection_matrix(self):
+        return self.raw_projection_matrix
+
+    @projection_matrix.setter
+    def projection_matrix(self, value):
+        self.initialize(raw_projection_matrix=value)
+
+    def forward(self, x1, x2, diagonal_distance=False, **params):
+        if diagonal_distance is True:
+            return _diag_ones(x2)
+        w = self.projection_matrix.detach().double()
+        p1 = ops.spd_project(x1.detach(), w)
+        p2 = p1 if x2 is x1 else ops.spd_project(x2.detach(), w)
+        return ops.spd_ai_kernel(p1, p2, self.beta.double(), _lib.GABO_OUT_GAUSSIAN)
+
+
+class NestedSpdLogEuclideanGaussianKernel(SpdLogEuclideanGaussianKernel):
+    """Log-Euclidean Gaussian kernel after the nested projection   (kernels_nested_spd.py:139-246; the kernel examples/hd_gabo_spd.py:164 uses)."""
+
+    def __init__(self, dim, latent_dim, **kwargs):
+        super().__init__(**kwargs)
+        self.dim, self.latent_dim = dim, latent_dim
+        q, _ = torch.linalg.qr(torch.randn(dim, latent_dim, dtype=torch.float64))
+        self.register_parameter(name="raw_projection_matrix", parameter=torch.nn.Parameter(q.repeat(*self.batch_shape, 1, 1)))
+
+    @property
+    def projection_matrix(self):
+        return self.raw_projection_matrix
+
+    @projection_matrix.setter
+    def projection_matrix(self, value):
+        self.initialize(raw_projection_matrix=value)
+
+    def forward(self, x1, x2, diagonal_distance=False, **params):
+        if diagonal_distance is True:
+            return _diag_ones(x2)
+        w = self.projection_matrix.detach().double()
+        p1 = ops.spd_project(x1.detach(), w)
+        p2 = p1 if x2 is x1 else ops.spd_project(x2.detach(), w)
+        return super().forward(p1, p2)

@@ -1,0 +1,106 @@
+"""Manifold objects with pymanopt's duck type (the reference drives its solvers through exactly these methods:
+SURVEY 8a/a9), backed by the batched HIP kernels.  Every method accepts a single point (d, d) / (dim,) or a batch
+(R, d, d) / (R, dim) of restarts, as numpy arrays or torch tensors, and returns the same kind of object it was given.
+
+`rand` stays a host callable on purpose: callers monkey-patch it (examples/gabo_spd.py:102 assigns `spd_sample`).
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+def _wrap(fn):
+    def inner(*args):
+        np_in = any(isinstance(a, np.ndarray) for a in args)
+        targs = [torch.as_tensor(a) if isinstance(a, np.ndarray) else a for a in args]
+        out = fn(*targs)
+        if np_in:
+            if isinstance(out, tuple):
+                return tuple(o.cpu().numpy() for o in out)
+            return out.cpu().numpy()
+        return out
+    return inner
+
+
+class PositiveDefinite:
+    """S^n_++ with the affine-invariant metric ([3P] pymanopt.manifolds.PositiveDefinite)."""
+
+    def __init__(self, n):
+        self._n = n
+        self._shape = (n, n)
+        self.min_eig, self.max_eig = 1.0, 2.0
+
+    @property
+    def dim(self):
+        return self._n * (self._n + 1) // 2
+
+    @property
+    def typicaldist(self):
+        return float(np.sqrt(self.dim))
+
+    def rand(self):
+        """[3P] eigenvalues U[1,2], orthogonal factor from qr(randn); numpy global RNG.  Usually replaced by spd_sample."""
+        lam = 1.0 + np.random.rand(self._n)
+        q, _ = np.linalg.qr(np.random.randn(self._n, self._n))
+        return q @ np.diag(lam) @ q.T
+
+    def zerovec(self, x):
+        return np.zeros_like(x) if isinstance(x, np.ndarray) else torch.zeros_like(x)
+
+    exp = staticmethod(_wrap(lambda x, u: ops.spd_manifold_op(_lib.GABO_SPD_EXP, x, u)))
+    retr = exp                                                                       # [3P] retr = exp
+    log = staticmethod(_wrap(lambda x, y: ops.spd_manifold_op(_lib.GABO_SPD_LOG, x, y)))
+    inner = staticmethod(_wrap(lambda x, u, v: ops.spd_manifold_op(_lib.GABO_SPD_INNER, x, u, v)))
+    norm = staticmethod(_wrap(lambda x, u: ops.spd_manifold_op(_lib.GABO_SPD_NORM, x, u)))
+    dist = staticmethod(_wrap(lambda x, y: ops.spd_manifold_op(_lib.GABO_SPD_DIST, x, y)))
+    egrad2rgrad = staticmethod(_wrap(lambda x, g: ops.spd_manifold_op(_lib.GABO_SPD_EGRAD2RGRAD, x, g)))
+    ehess2rhess = staticmethod(_wrap(lambda x, eg, eh, u: ops.spd_manifold_op(_lib.GABO_SPD_EHESS2RHESS, x, eg, eh, u)))
+
+    @staticmethod
+    def proj(x, u):
+        return 0.5 * (u + (u.swapaxes(-1, -2) if isinstance(u, np.ndarray) else u.transpose(-1, -2)))
+
+    @staticmethod
+    def transp(x1, x2, d):
+        return d                                                                      # [3P] identity transport
+
+
+class Sphere:
+    """S^{n-1} in R^n ([3P] pymanopt.manifolds.Sphere)."""
+
+    def __init__(self, n):
+        self._n = n
+        self._shape = (n,)
+
+    @property
+    def dim(self):
+        return self._n - 1
+
+    @property
+    def typicaldist(self):
+        return float(np.pi)
+
+    def rand(self):
+        x = np.random.randn(self._n)
+        return x / np.linalg.norm(x)
+
+    def zerovec(self, x):
+        return np.zeros_like(x) if isinstance(x, np.ndarray) else torch.zeros_like(x)
+
+    @staticmethod
+    def inner(x, u, v):
+        return (u * v).sum(-1)
+
+    @staticmethod
+    def norm(x, u):
+        return np.sqrt((u * u).sum(-1)) if isinstance(u, np.ndarray) else (u * u).sum(-1).sqrt()
+
+    proj = staticmethod(_wrap(lambda x, h: ops.sphere_manifold_op(_lib.GABO_SPH_PROJ, x, h)))
+    egrad2rgrad = proj
+    retr = staticmethod(_wrap(lambda x, u: ops.sphere_manifold_op(_lib.GABO_SPH_RETR, x, u)))
+    exp = staticmethod(_wrap(lambda x, u: ops.sphere_manifold_op(_lib.GABO_SPH_EXP, x, u)))
+    log = staticmethod(_wrap(lambda x, y: ops.sphere_manifold_op(_lib.GABO_SPH_LOG, x, y)))
+    dist = staticmethod(_wrap(lambda x, y: ops.sphere_manifold_op(_lib.GABO_SPH_DIST, x, y)))
+    ehess2rhess = staticmethod(_wrap(lambda x, eg, eh, u: ops.sphere_manifold_op(_lib.GABO_SPH_EHESS2RHESS, x, eg, eh, u)))
+    transp = staticmethod(_wrap(lambda x, y, u: ops.sphere_manifold_op(_lib.GABO_SPH_PROJ, y, u)))

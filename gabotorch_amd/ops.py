@@ -313,3 +313,107 @@ def matrix_to_mandel(mat):
     with torch.cuda.device(dev):
         _lib.check(lib.gabo_matrix_to_mandel(m.data_ptr(), out.data_ptr(), n, d, _stream_ptr(dev)), "gabo_matrix_to_mandel")
     return out.to(out_device)
+
+
+# ------------------------------------------------------------------------------------------ batched manifold operations
+def _mats(dev, *xs):
+    """Bring (…, d, d) inputs to contiguous fp64 device tensors of one common batch shape."""
+    ts = [None if x is None else _prep(torch.as_tensor(x), dev) for x in xs]
+    shape = None
+    for t_ in ts:
+        if t_ is not None:
+            shape = t_.shape if shape is None else torch.broadcast_shapes(shape, t_.shape)
+    return [None if t_ is None else t_.expand(shape).contiguous() for t_ in ts], shape
+
+
+def spd_manifold_op(op, a, b=None, c=None, e=None, want_grad=False):
+    """Batched SPD-manifold operation `op` (one of _lib.GABO_SPD_*) on (..., d, d) tensors; see include/gabo_hip.h."""
+    lib = _lib.load()
+    first = torch.as_tensor(a)
+    out_device = first.device
+    dev = _device_for(*[torch.as_tensor(x) for x in (a, b, c, e) if x is not None])
+    (A, B, C, E), shape = _mats(dev, a, b, c, e)
+    d = shape[-1]
+    n = A.numel() // (d * d) if d else 0
+    scalar = op in (_lib.GABO_SPD_INNER, _lib.GABO_SPD_NORM, _lib.GABO_SPD_DIST, _lib.GABO_SPD_EIGMAX, _lib.GABO_SPD_EIGMIN)
+    out = torch.empty(shape[:-2] if scalar else shape, dtype=torch.float64, device=dev)
+    out2 = torch.empty(shape, dtype=torch.float64, device=dev) if (want_grad and scalar) else None
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+    with torch.cuda.device(dev):
+        rc = lib.gabo_spd_manifold_op(int(op), ptr(A), ptr(B), ptr(C), ptr(E), out.data_ptr(), ptr(out2), n, d, status.data_ptr(),
+                                      _stream_ptr(dev))
+    _lib.check(rc, "gabo_spd_manifold_op")
+    _raise_if_not_spd(status, "gabo_spd_manifold_op")
+    if out2 is not None:
+        return out.to(out_device), out2.to(out_device)
+    return out.to(out_device)
+
+
+def spd_project(x_mandel, w):
+    """(..., D_vec) Mandel, w (D, dl) -> (..., dl_vec) Mandel of W^T X W."""
+    lib = _lib.load()
+    out_device = x_mandel.device
+    dev = _device_for(x_mandel, w)
+    x = _prep(x_mandel, dev).contiguous()
+    W = _prep(w, dev).contiguous()
+    D = _mandel_dim(x.shape[-1])
+    if W.dim() != 2 or W.shape[0] != D:
+        raise RuntimeError(f"projection matrix must be ({D}, d_latent), got {tuple(W.shape)}")
+    dl = W.shape[1]
+    n = x.numel() // x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (dl * (dl + 1) // 2,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_spd_project(x.data_ptr(), W.data_ptr(), out.data_ptr(), n, D, dl, _stream_ptr(dev)), "gabo_spd_project")
+    return out.to(out_device)
+
+
+def spd_logm_mandel(x_mandel):
+    lib = _lib.load()
+    out_device = x_mandel.device
+    dev = _device_for(x_mandel)
+    x = _prep(x_mandel, dev).contiguous()
+    d = _mandel_dim(x.shape[-1])
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_spd_logm_mandel(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], d, _stream_ptr(dev)),
+                   "gabo_spd_logm_mandel")
+    return out.to(out_device)
+
+
+def frobenius_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN):
+    """Mandel vectors x1 (..., N1, d_vec), x2 (..., N2, d_vec) -> (..., N1, N2) Frobenius distance / kernel."""
+    lib = _lib.load()
+    if x1.shape[:-2] != x2.shape[:-2] or x1.shape[-1] != x2.shape[-1]:
+        raise RuntimeError(f"batch/feature shapes differ: {tuple(x1.shape)} vs {tuple(x2.shape)}")
+    out_device = x1.device
+    dev = _device_for(x1, x2)
+    a, b = _prep(x1, dev), _prep(x2, dev)
+    d = _mandel_dim(a.shape[-1])
+    n1, n2 = a.shape[-2], b.shape[-2]
+    a2, nb, s1 = _flatten_batch(a, 2)
+    b2, _, s2 = _flatten_batch(b, 2)
+    out = torch.empty(a.shape[:-2] + (n1, n2), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_frobenius_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), nb, n1, n2, d, s1, s2, float(beta),
+                                               int(mode), _stream_ptr(dev)), "gabo_frobenius_pairwise")
+    return out.to(out_device)
+
+
+def sphere_manifold_op(op, x, u, v=None, w=None):
+    """Batched sphere-manifold operation (one of _lib.GABO_SPH_*) on (..., dim) tensors."""
+    lib = _lib.load()
+    first = torch.as_tensor(x)
+    out_device = first.device
+    dev = _device_for(*[torch.as_tensor(t_) for t_ in (x, u, v, w) if t_ is not None])
+    ts = [None if t_ is None else _prep(torch.as_tensor(t_), dev) for t_ in (x, u, v, w)]
+    shape = torch.broadcast_shapes(*[t_.shape for t_ in ts if t_ is not None])
+    X, U, V, W = [None if t_ is None else t_.expand(shape).contiguous() for t_ in ts]
+    dim = shape[-1]
+    n = X.numel() // dim
+    out = torch.empty(shape[:-1] if op == _lib.GABO_SPH_DIST else shape, dtype=torch.float64, device=dev)
+    ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_sphere_manifold_op(int(op), ptr(X), ptr(U), ptr(V), ptr(W), out.data_ptr(), n, dim, _stream_ptr(dev)),
+                   "gabo_sphere_manifold_op")
+    return out.to(out_device)

@@ -100,6 +100,68 @@ int gabo_sphere_from_inner(const double* inner, double* out, int64_t n, double b
 int gabo_mandel_to_matrix(const double* vec, double* mat, int64_t n, int d, gabo_stream_t stream);
 int gabo_matrix_to_mandel(const double* mat, double* vec, int64_t n, int d, gabo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Batched Riemannian operations on the SPD manifold (one wave per matrix, LDS tiles, 1 <= d <= 32).
+ * All matrices are full n x d x d row-major batches (what pymanopt's PositiveDefinite and the reference's numpy maps use).
+ * Replaces, per restart of the acquisition maximiser (BoManifolds/manifold_optimization/*):
+ *   GABO_SPD_EXP          out = X expm(X^-1 U)             a=X b=U        spd_utils.py:104-120 ; [3P] PositiveDefinite.exp = retr
+ *   GABO_SPD_LOG          out = Log_X(Y)                   a=X b=Y        spd_utils.py:123-139 ; tools/multi.py:55-64
+ *   GABO_SPD_INNER        out[n] = tr(X^-1 U X^-1 V)       a=X b=U c=V    [3P] inner  (robust_trust_regions.py:148)
+ *   GABO_SPD_NORM         out[n] = sqrt(inner(U,U))        a=X b=U        [3P] norm
+ *   GABO_SPD_DIST         out[n] = ||logm(L^-1 Y L^-T)||_F a=X b=Y        [3P] dist   (examples/gabo_spd.py:289)
+ *   GABO_SPD_EGRAD2RGRAD  out = X sym(G) X                 a=X b=G        [3P] (pymanopt_addons/problem.py:135)
+ *   GABO_SPD_EHESS2RHESS  out = X sym(H) X + sym(U sym(G) X)  a=X b=G c=H e=U   [3P] (problem.py:156)
+ *   GABO_SPD_LOGM/EXPM/SQRTM  out = f(A)                   a=A            spd_utils_torch.py:13-50 ; tools/multi.py:55-75
+ *   GABO_SPD_EIGMAX/EIGMIN    out[n] = extreme eigenvalue, out2 = v v^T (NULL to skip)   spd_constraints_utils_torch.py:17-50
+ * status: device int[2] as above (non-SPD base point) or NULL.
+ */
+#define GABO_SPD_EXP 0
+#define GABO_SPD_LOG 1
+#define GABO_SPD_INNER 2
+#define GABO_SPD_NORM 3
+#define GABO_SPD_DIST 4
+#define GABO_SPD_EGRAD2RGRAD 5
+#define GABO_SPD_EHESS2RHESS 6
+#define GABO_SPD_LOGM 7
+#define GABO_SPD_EXPM 8
+#define GABO_SPD_SQRTM 9
+#define GABO_SPD_EIGMAX 10
+#define GABO_SPD_EIGMIN 11
+int gabo_spd_manifold_op(int op, const double* a, const double* b, const double* c, const double* e, double* out, double* out2,
+                         int64_t n, int d, int* status, gabo_stream_t stream);
+
+/* Y = W^T X W, Mandel in (n x D(D+1)/2) -> Mandel out (n x dl(dl+1)/2); w: D x dl row-major.  1 <= dl <= D <= 64.
+ * Replaces projection_from_spd_to_nested_spd (nested_mappings/nested_spd_utils.py:13-48) fused with both Mandel maps. */
+int gabo_spd_project(const double* x_mandel, const double* w, double* y_mandel, int64_t n, int D, int dl, gabo_stream_t stream);
+
+/* logm of n SPD matrices, Mandel in -> Mandel out: the per-point half of SpdLogEuclideanGaussianKernel.forward
+ * (kernel_utils/kernels_spd.py:289-305, logm_torch spd_utils_torch.py:13-30). */
+int gabo_spd_logm_mandel(const double* x_mandel, double* y_mandel, int64_t n, int d, gabo_stream_t stream);
+
+/* Pairwise Frobenius distance of symmetric matrices given as Mandel vectors, with the reference's +1e-15 on every matrix
+ * element of the difference (frobenius_distance_torch, spd_utils_torch.py:124-156); `flags`/`beta` as for the other pairwise
+ * kernels (SpdFrobeniusGaussianKernel / SpdLogEuclideanGaussianKernel use exp(-d^2 / lengthscale^2): beta = 1/lengthscale^2,
+ * kernels_spd.py:238-240,309-311).  out: batch x n1 x n2. */
+int gabo_frobenius_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2, int d,
+                            int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, gabo_stream_t stream);
+
+/* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
+ *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)
+ *   GABO_SPH_RETR   out = (X+U)/|X+U|        [3P] Sphere.retr  (robust_trust_regions.py:228)
+ *   GABO_SPH_EXP    out = Exp_X(U)           Riemannian_utils/sphere_utils.py:14-38
+ *   GABO_SPH_LOG    out = Log_X(U=point)     sphere_utils.py:41-65
+ *   GABO_SPH_DIST   out[n] = acos(clip(<X,U>))
+ *   GABO_SPH_EHESS2RHESS  out = proj(X, v=ehess) - <X, u=egrad> w=tangent      [3P]
+ */
+#define GABO_SPH_PROJ 0
+#define GABO_SPH_RETR 1
+#define GABO_SPH_EXP 2
+#define GABO_SPH_LOG 3
+#define GABO_SPH_DIST 4
+#define GABO_SPH_EHESS2RHESS 5
+int gabo_sphere_manifold_op(int op, const double* x, const double* u, const double* v, const double* w, double* out, int64_t n,
+                            int dim, gabo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

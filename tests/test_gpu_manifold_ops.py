@@ -1,0 +1,110 @@
+"""Batched Riemannian operations (HIP) against the golden vectors of the reference's numpy maps and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gabotorch_amd import _lib, manifolds, ops
+from oracle import spd as ospd
+from oracle import sphere as osph
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(x):
+    return torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=DEV)
+
+
+def rand_spd(rng, n, d, lo=0.2, hi=4.0):
+    q = np.linalg.qr(rng.standard_normal((n, d, d)))[0]
+    m = np.einsum("nab,nb,ncb->nac", q, rng.uniform(lo, hi, (n, d)), q)
+    return 0.5 * (m + m.transpose(0, 2, 1))
+
+
+def test_spd_maps_golden(golden):
+    g = golden("spd_maps.npz")
+    for d in (2, 3, 5):
+        S, X, U = g[f"d{d}_S"], g[f"d{d}_X"], g[f"d{d}_log"]
+        np.testing.assert_allclose(ops.spd_manifold_op(_lib.GABO_SPD_LOG, t(S), t(X)).cpu().numpy(), U, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(ops.spd_manifold_op(_lib.GABO_SPD_EXP, t(S), t(U)).cpu().numpy(), g[f"d{d}_explog"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(ops.spd_manifold_op(_lib.GABO_SPD_EXPM, t(g[f"d{d}_sym"])).cpu().numpy(), g[f"d{d}_multiexp"],
+                                   rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(ops.spd_manifold_op(_lib.GABO_SPD_LOGM, t(X)).cpu().numpy(), g[f"d{d}_multilog"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(ops.spd_manifold_op(_lib.GABO_SPD_SQRTM, t(X)).cpu().numpy(), g[f"d{d}_sqrtm_torch"], rtol=1e-10, atol=1e-11)
+        lam, grad = ops.spd_manifold_op(_lib.GABO_SPD_EIGMAX, t(X), want_grad=True)
+        np.testing.assert_allclose(5.0 - lam.cpu().numpy(), g[f"d{d}_maxeig"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(-grad.cpu().numpy(), g[f"d{d}_maxeig_grad"], rtol=1e-9, atol=1e-10)
+        lam = ops.spd_manifold_op(_lib.GABO_SPD_EIGMIN, t(X))
+        np.testing.assert_allclose(lam.cpu().numpy() - 0.01, g[f"d{d}_mineig"], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("d", [2, 5, 10, 20])
+def test_spd_manifold_ops_vs_oracle(d):
+    rng = np.random.default_rng(d)
+    R = 37
+    X, Y = rand_spd(rng, R, d), rand_spd(rng, R, d)
+    U = rng.standard_normal((R, d, d)); U = 0.3 * (U + U.transpose(0, 2, 1))
+    V = rng.standard_normal((R, d, d)); V = 0.3 * (V + V.transpose(0, 2, 1))
+    G = rng.standard_normal((R, d, d))
+    H = rng.standard_normal((R, d, d))
+    man = manifolds.PositiveDefinite(d)
+    np.testing.assert_allclose(man.exp(X, U), ospd.spd_exp(X, U), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(man.log(X, Y), ospd.spd_log(X, Y), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(man.exp(X, man.log(X, Y)), Y, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(man.inner(X, U, V), ospd.spd_inner(X, U, V), rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(man.norm(X, U), ospd.spd_norm(X, U), rtol=1e-10)
+    np.testing.assert_allclose(man.egrad2rgrad(X, G), ospd.spd_egrad2rgrad(X, G), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(man.ehess2rhess(X, G, H, U), ospd.spd_ehess2rhess(X, G, H, U), rtol=1e-11, atol=1e-11)
+    dist = man.dist(X, Y)
+    want = np.sqrt(np.maximum(np.diagonal(ospd.affine_invariant_distance(X, Y)) ** 2 - 1e-15, 0))
+    np.testing.assert_allclose(dist, want, rtol=1e-9)
+    # single point, torch tensors on the device
+    one = man.exp(t(X[0]), t(U[0]))
+    assert one.is_cuda and one.shape == (d, d)
+    np.testing.assert_allclose(one.cpu().numpy(), ospd.spd_exp(X[0], U[0]), rtol=1e-9, atol=1e-10)
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        man.exp(-np.eye(d), U[0])
+
+
+def test_projection_and_log_euclid_golden(golden):
+    g = golden("nested_spd.npz")
+    y1 = ops.spd_project(t(g["x1_mandel"]), t(g["W"])).cpu().numpy()
+    np.testing.assert_allclose(ospd.vector_to_symmetric_matrix_mandel(y1), g["Y1"], rtol=1e-11, atol=1e-12)
+    y2 = ops.spd_project(t(g["x2_mandel"]), t(g["W"]))
+    # nested affine-invariant kernel = projection then the pairwise kernel (kernels_nested_spd.py:122-136)
+    dist = ops.spd_ai_pairwise(t(y1), y2, mode=_lib.GABO_OUT_DISTANCE).cpu().numpy()
+    np.testing.assert_allclose(dist, g["ai_dist"], rtol=5e-7, atol=5e-7)
+    l1, l2 = ops.spd_logm_mandel(t(y1)), ops.spd_logm_mandel(y2)
+    np.testing.assert_allclose(ospd.vector_to_symmetric_matrix_mandel(l1.cpu().numpy()), g["logY1"], rtol=1e-9, atol=1e-10)
+    le = ops.frobenius_pairwise(l1, l2, mode=_lib.GABO_OUT_DISTANCE).cpu().numpy()
+    np.testing.assert_allclose(le, g["le_dist"], rtol=1e-9)
+    x5 = ospd.symmetric_matrix_to_vector_mandel(g["X5"])
+    np.testing.assert_allclose(ospd.vector_to_symmetric_matrix_mandel(ops.spd_project(t(x5), t(g["W5"])).cpu().numpy()), g["Y5"],
+                               rtol=1e-11, atol=1e-12)
+    # Frobenius kernel with the element-wise 1e-15 of the reference
+    gm = golden("spd_maps.npz")
+    for d in (2, 3, 5):
+        a = ospd.symmetric_matrix_to_vector_mandel(gm[f"d{d}_S"])
+        b = ospd.symmetric_matrix_to_vector_mandel(gm[f"d{d}_X"])
+        np.testing.assert_allclose(ops.frobenius_pairwise(t(a), t(b), mode=_lib.GABO_OUT_DISTANCE).cpu().numpy(), gm[f"d{d}_frob"], rtol=1e-12)
+        k = ops.frobenius_pairwise(t(a), t(b), beta=0.37).cpu().numpy()
+        np.testing.assert_allclose(k, np.exp(-0.37 * gm[f"d{d}_frob"] ** 2), rtol=1e-12)
+
+
+def test_sphere_manifold_ops(golden):
+    g = golden("sphere.npz")
+    man = manifolds.Sphere(5)
+    np.testing.assert_allclose(man.log(g["map_base"], g["map_x"]), g["map_log"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(man.exp(g["map_base"], g["map_log"]), g["map_exp"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(man.dist(g["map_base"], g["map_x"]), g["map_dist"], rtol=1e-11)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((50, 7)); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = rng.standard_normal((50, 7)); y /= np.linalg.norm(y, axis=1, keepdims=True)
+    h, eh, u = rng.standard_normal((3, 50, 7))
+    man = manifolds.Sphere(7)
+    np.testing.assert_allclose(man.proj(x, h), osph.proj(x, h), rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(man.retr(x, 0.1 * h), osph.retr(x, 0.1 * h), rtol=1e-13)
+    np.testing.assert_allclose(man.ehess2rhess(x, h, eh, u), osph.ehess2rhess(x, h, eh, u), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(man.transp(x, y, u), osph.transp(x, y, u), rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(man.exp(x, np.zeros_like(x)), x, rtol=0, atol=0)
+    np.testing.assert_allclose(man.log(x, x), 0.0, atol=1e-7)
