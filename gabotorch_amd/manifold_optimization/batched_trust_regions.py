@@ -1,0 +1,286 @@
+"""Lock-step Riemannian trust regions over R restarts.
+
+The reference solves the R restarts of the acquisition maximiser one after the other (manifold_optimize.py:207), each
+with pymanopt-style trust regions + truncated CG (robust_trust_regions.py:111-570) or their constrained variant
+(constrained_trust_regions.py:120-734).  Here the same state machine advances ALL restarts together: every cost /
+gradient / Hessian-vector evaluation is one batched acquisition call (one kernel launch over R x n_train pairs), every
+manifold operation one batched launch, and per-restart control flow is carried by boolean masks.  Restart r follows
+exactly the arithmetic the reference's sequential solver would follow from the same initial point.
+
+State lives in torch tensors on whatever device the problem's tensors live on; this file contains no device code.
+"""
+import time
+
+import torch
+
+NEGATIVE_CURVATURE, EXCEEDED_TR, REACHED_TARGET_LINEAR, REACHED_TARGET_SUPERLINEAR, MAX_INNER_ITER, MODEL_INCREASED, \
+    REACHED_CONSTRAINTS = range(7)
+
+
+def _bm(mask, like):
+    """broadcast a (R,) mask / scalar-per-restart tensor against (R, ...)"""
+    return mask.reshape(mask.shape + (1,) * (like.dim() - mask.dim()))
+
+
+class BatchedProblem:
+    """cost / Riemannian gradient / Riemannian Hessian-vector product for a batch of restarts.
+
+    cost_fn(x: R x *shape) -> R tensor, differentiable by autograd (restarts are independent, so the gradient of the sum
+    is the stack of per-restart gradients).  Mirrors pymanopt_addons/problem.py:14-159 + the PytorchBackend contract
+    (tools/autodiff/_pytorch.py:83-116); `approx_hessian=True` is get_hessianfd (approximate_hessian.py:11-62)."""
+
+    def __init__(self, manifold, cost_fn, approx_hessian=False, precon=None):
+        self.manifold = manifold
+        self.cost_fn = cost_fn
+        self.approx_hessian = approx_hessian
+        self.precon = precon or (lambda x, d: d)
+        self.n_cost = 0
+        self.n_grad = 0
+
+    def cost(self, x):
+        self.n_cost += 1
+        with torch.no_grad():
+            return self.cost_fn(x).detach()
+
+    def cost_egrad(self, x, create_graph=False):
+        self.n_grad += 1
+        xx = x.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            f = self.cost_fn(xx)
+            (g,) = torch.autograd.grad(f.sum(), xx, create_graph=create_graph)
+        return f.detach(), g, xx
+
+    def cost_grad(self, x):
+        f, eg, _ = self.cost_egrad(x)
+        return f, self.manifold.egrad2rgrad(x, eg.detach())
+
+    def grad(self, x):
+        return self.cost_grad(x)[1]
+
+    def hess(self, x, u, grad_x=None):
+        man = self.manifold
+        if self.approx_hessian:
+            # finite difference of the gradient along u (approximate_hessian.py:30-60)
+            norm_a = man.norm(x, u)
+            g0 = self.grad(x) if grad_x is None else grad_x
+            tiny = norm_a < 1e-15
+            c = (2.0 ** -14) / torch.where(tiny, torch.ones_like(norm_a), norm_a)
+            x1 = man.retr(x, _bm(c, u) * u)
+            g1 = man.transp(x1, x, self.grad(x1))
+            h = g1 / _bm(c, g1) - g0 / _bm(c, g0)
+            return torch.where(_bm(tiny, h), torch.zeros_like(h), h)
+        _, eg, xx = self.cost_egrad(x, create_graph=True)
+        with torch.enable_grad():
+            (eh,) = torch.autograd.grad((eg * u.detach()).sum(), xx)
+        return man.ehess2rhess(x, eg.detach(), eh.detach(), u)
+
+
+class BatchedTrustRegions:
+    """Riemannian trust regions with truncated CG, all restarts in lock step; optional equality / inequality constraints
+    handled as in ConstrainedTrustRegions (linearised constraints truncate the tCG step at distance Delta_cons)."""
+
+    def __init__(self, miniter=3, kappa=0.1, theta=1.0, rho_prime=0.1, use_rand=False, rho_regularization=1e3, maxtime=1000,
+                 maxiter=1000, mingradnorm=1e-6, minstepsize=1e-10, maxcostevals=5000, logverbosity=0):
+        if use_rand:
+            raise NotImplementedError("use_rand=True (randomised tCG start) is not used by any reference example")
+        self.miniter, self.kappa, self.theta, self.rho_prime = miniter, kappa, theta, rho_prime
+        self.rho_regularization = rho_regularization
+        self.maxtime, self.maxiter, self.mingradnorm = maxtime, maxiter, mingradnorm
+        self.minstepsize, self.maxcostevals = minstepsize, maxcostevals
+        self.log = {}
+
+    # ------------------------------------------------------------------------------------------------- constraints
+    @staticmethod
+    def _constraint_values_grads(problem, x, constraints):
+        """-> fc (R, C), rgrad (C tensors of shape R x *shape)"""
+        vals, grads = [], []
+        for con in constraints:
+            xx = x.detach().clone().requires_grad_(True)
+            with torch.enable_grad():
+                try:
+                    f = con(xx)
+                    if f.shape != x.shape[:1]:
+                        raise RuntimeError
+                except Exception:   # noqa: BLE001  a user callable written for one point: evaluate restart by restart
+                    f = torch.stack([con(xx[i]) for i in range(x.shape[0])])
+                (g,) = torch.autograd.grad(f.sum(), xx, allow_unused=True)
+            if g is None:
+                g = torch.zeros_like(x)
+            vals.append(f.detach().to(x.dtype))
+            grads.append(problem.manifold.egrad2rgrad(x, g.detach()))
+        return torch.stack(vals, dim=1), grads
+
+    # ------------------------------------------------------------------------------------------------- solve
+    def solve(self, problem, x, eq_constraints=None, ineq_constraints=None, mininner=1, maxinner=None, Delta_bar=None,
+              Delta0=None, Delta_cons=None):
+        """x: R x *point_shape initial points.  Returns the R optimised points."""
+        man = problem.manifold
+        x = x.detach().clone()
+        R = x.shape[0]
+        dt, dev = x.dtype, x.device
+        if maxinner is None:
+            maxinner = man.dim
+        if Delta_bar is None:
+            Delta_bar = getattr(man, "typicaldist", None) or float(man.dim) ** 0.5
+        if Delta0 is None:
+            Delta0 = Delta_bar / 8
+        if Delta_cons is None:
+            Delta_cons = 1e-6
+        eqs = list(eq_constraints) if isinstance(eq_constraints, (list, tuple)) else ([eq_constraints] if eq_constraints else [])
+        ineqs = list(ineq_constraints) if isinstance(ineq_constraints, (list, tuple)) else ([ineq_constraints] if ineq_constraints else [])
+        neq = len(eqs)
+        constrained = bool(eqs or ineqs)
+
+        time0 = time.time()
+        fx, g = problem.cost_grad(x)
+        ng = man.norm(x, g)
+        Delta = torch.full((R,), float(Delta0), dtype=dt, device=dev)
+        active = torch.ones(R, dtype=torch.bool, device=dev)
+        iters = torch.zeros(R, dtype=torch.long, device=dev)
+        k = 0
+        eps = torch.finfo(dt).eps
+        while True:
+            if constrained:
+                fc, gc = self._constraint_values_grads(problem, x, eqs + ineqs)
+            else:
+                fc, gc = None, []
+            eta, Heta, stop_inner = self._tcg(problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons)
+            x_prop = man.retr(x, eta)
+            fx_prop = problem.cost(x_prop)
+            rhonum = fx - fx_prop
+            rhoden = -man.inner(x, g, eta) - 0.5 * man.inner(x, eta, Heta)
+            rho_reg = torch.clamp(fx.abs(), min=1.0) * eps * self.rho_regularization
+            rhonum = rhonum + rho_reg
+            rhoden = rhoden + rho_reg
+            model_decreased = rhoden >= 0
+            rho = torch.where(rhoden == 0, torch.full_like(rhoden, float("nan")), rhonum / rhoden)
+            shrink = (rho < 0.25) | ~model_decreased | torch.isnan(rho)
+            boundary = (stop_inner == NEGATIVE_CURVATURE) | (stop_inner == EXCEEDED_TR)
+            if constrained:
+                boundary = boundary | (stop_inner == REACHED_CONSTRAINTS)
+            grow = ~shrink & (rho > 0.75) & boundary
+            newDelta = torch.where(shrink, Delta / 4, torch.where(grow, torch.clamp(2 * Delta, max=float(Delta_bar)), Delta))
+            Delta = torch.where(active, newDelta, Delta)
+            accept = active & model_decreased & (rho > self.rho_prime)
+            if bool(accept.any()):
+                x = torch.where(_bm(accept, x), x_prop, x)
+                fx = torch.where(accept, fx_prop, fx)
+                _, gnew = problem.cost_grad(x)
+                g = torch.where(_bm(accept, g), gnew, g)
+                ng = torch.where(accept, man.norm(x, g), ng)
+            k += 1
+            iters = iters + active.long()
+            stop = (ng < self.mingradnorm) | (iters >= self.maxiter)
+            active = active & ~stop
+            if not bool(active.any()) or (time.time() - time0) >= self.maxtime:
+                break
+        self.log = {"iterations": k, "per_restart_iterations": iters, "final_cost": fx, "final_gradnorm": ng,
+                    "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0}
+        return x
+
+    # ------------------------------------------------------------------------------------------------- truncated CG
+    def _tcg(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons):
+        man = problem.manifold
+        inner = man.inner
+        R = x.shape[0]
+        eta = torch.zeros_like(x)
+        Heta = torch.zeros_like(x)
+        r = g.clone()
+        e_Pe = torch.zeros_like(Delta)
+        r_r = inner(x, r, r)
+        norm_r0 = r_r.sqrt()
+        z = problem.precon(x, r)
+        z_r = inner(x, z, r)
+        d_Pd = z_r.clone()
+        delta = -z
+        e_Pd = torch.zeros_like(Delta)
+        model_value = torch.zeros_like(Delta)
+        stop = torch.full((R,), MAX_INNER_ITER, dtype=torch.long, device=x.device)
+        running = active.clone()
+        constrained = fc is not None
+        if constrained:
+            C = fc.shape[1]
+            is_ineq = torch.arange(C, device=x.device) >= neq
+            fcg_Pe = torch.zeros_like(fc)
+        Delta2 = Delta * Delta
+
+        def cons_step(step):
+            """violation of the linearised constraints after `step` along delta, and the step that stops at Delta_cons"""
+            term = fc + fcg_Pe + step[:, None] * fcg_Pd
+            term = torch.where(is_ineq[None, :], torch.clamp(term, max=0.0), term)
+            cin = (term * term).sum(1)
+            idx = (~is_ineq[None, :]) | (term < 0)          # equality constraints + violated inequalities
+            m = idx.to(fc.dtype)
+            qa = (m * fcg_Pd * fcg_Pd).sum(1)
+            qb = 2.0 * ((m * fc * fcg_Pd).sum(1) + (m * fcg_Pe * fcg_Pd).sum(1))
+            qc = (m * fc * fc).sum(1) + 2.0 * (m * fc * fcg_Pe).sum(1) + (m * fcg_Pe * fcg_Pe).sum(1) - Delta_cons ** 2
+            disc = qb * qb - 4.0 * qa * qc
+            tau = torch.where(disc >= 0, (-qb + disc.clamp(min=0).sqrt()) / (2.0 * qa), torch.zeros_like(disc))
+            return cin, tau
+
+        for j in range(int(maxinner)):
+            Hdelta = problem.hess(x, delta, grad_x=g)
+            d_Hd = inner(x, delta, Hdelta)
+            nz = d_Hd != 0
+            alpha = torch.where(nz, z_r / torch.where(nz, d_Hd, torch.ones_like(d_Hd)), torch.zeros_like(d_Hd))
+            e_Pe_new = torch.where(nz, e_Pe + 2 * alpha * e_Pd + alpha * alpha * d_Pd, e_Pe)
+            if constrained:
+                fcg_Pd = torch.stack([inner(x, gci, delta) for gci in gc], dim=1)
+            # ---- leave through the trust-region boundary / negative curvature
+            out = running & ((d_Hd <= 0) | (e_Pe_new >= Delta2))
+            tau = (-e_Pd + (e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe)).sqrt()) / d_Pd
+            reason = torch.where(d_Hd <= 0, torch.full_like(stop, NEGATIVE_CURVATURE), torch.full_like(stop, EXCEEDED_TR))
+            if constrained:
+                tau = torch.where(torch.isnan(tau), torch.zeros_like(tau), tau)
+                cin, tau_c = cons_step(tau)
+                hit = cin > Delta_cons ** 2
+                tau = torch.where(hit, tau_c, tau)
+                reason = torch.where((d_Hd > 0) & hit, torch.full_like(stop, REACHED_CONSTRAINTS), reason)
+            eta = torch.where(_bm(out, eta), eta + _bm(tau, delta) * delta, eta)
+            Heta = torch.where(_bm(out, Heta), Heta + _bm(tau, Hdelta) * Hdelta, Heta)
+            stop = torch.where(out, reason, stop)
+            running = running & ~out
+            # ---- leave because the linearised constraints are reached inside the trust region
+            if constrained:
+                cin, tau_c = cons_step(alpha)
+                out = running & (cin > Delta_cons ** 2)
+                eta = torch.where(_bm(out, eta), eta + _bm(tau_c, delta) * delta, eta)
+                Heta = torch.where(_bm(out, Heta), Heta + _bm(tau_c, Hdelta) * Hdelta, Heta)
+                stop = torch.where(out, torch.full_like(stop, REACHED_CONSTRAINTS), stop)
+                running = running & ~out
+            # ---- tentative step; reject it if the model did not decrease
+            new_eta = eta + _bm(alpha, delta) * delta
+            new_Heta = Heta + _bm(alpha, Hdelta) * Hdelta
+            new_model = inner(x, new_eta, g) + 0.5 * inner(x, new_eta, new_Heta)
+            out = running & ~(new_model < model_value)
+            stop = torch.where(out, torch.full_like(stop, MODEL_INCREASED), stop)
+            running = running & ~out
+            eta = torch.where(_bm(running, eta), new_eta, eta)
+            Heta = torch.where(_bm(running, Heta), new_Heta, Heta)
+            model_value = torch.where(running, new_model, model_value)
+            e_Pe = torch.where(running, e_Pe_new, e_Pe)
+            r = torch.where(_bm(running, r), r + _bm(alpha, Hdelta) * Hdelta, r)
+            r_r = inner(x, r, r)
+            norm_r = r_r.clamp(min=0).sqrt()
+            # ---- residual small enough
+            if j >= mininner:
+                target = norm_r0 * torch.minimum(norm_r0 ** self.theta, torch.full_like(norm_r0, self.kappa))
+                out = running & (norm_r <= target)
+                reason = torch.where(self.kappa < norm_r0 ** self.theta, torch.full_like(stop, REACHED_TARGET_LINEAR),
+                                     torch.full_like(stop, REACHED_TARGET_SUPERLINEAR))
+                stop = torch.where(out, reason, stop)
+                running = running & ~out
+            if not bool(running.any()):
+                break
+            # ---- next search direction
+            z = problem.precon(x, r)
+            zold = z_r
+            z_r_new = inner(x, z, r)
+            beta = z_r_new / zold
+            delta = torch.where(_bm(running, delta), -z + _bm(beta, delta) * delta, delta)
+            e_Pd = torch.where(running, beta * (e_Pd + alpha * d_Pd), e_Pd)
+            d_Pd = torch.where(running, z_r_new + beta * beta * d_Pd, d_Pd)
+            z_r = torch.where(running, z_r_new, z_r)
+            if constrained:
+                fcg_Pe = torch.where(running[:, None], fcg_Pe + alpha[:, None] * fcg_Pd, fcg_Pe)
+        return eta, Heta, stop

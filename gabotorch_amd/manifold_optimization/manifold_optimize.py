@@ -1,0 +1,181 @@
+"""Multi-start acquisition maximisation on a manifold - same entry points and keyword arguments as the reference
+(BoManifolds/manifold_optimization/manifold_optimize.py:36-321), re-organised for the MI355X:
+
+  * the `raw_samples` candidates are scored in one batched acquisition call (as the reference does, :297-309);
+  * the `num_restarts` local solves run in LOCK STEP (BatchedTrustRegions) instead of the sequential loop at :207;
+  * with torch.distributed initialised, restart r is owned by rank r % world (interleaved: trust-region iteration counts
+    vary), each rank optimises its share on its own GPU, and ONE all_gather of (acquisition value, candidate) per restart
+    followed by a local argmax replaces get_best_candidates (:118-120).  Ties go to the lowest global restart index on
+    every rank, so all ranks return the same candidate.
+"""
+import types
+import warnings
+
+import numpy as np
+import torch
+
+from ..models import (BadInitialCandidatesWarning, get_best_candidates, initialize_q_batch, initialize_q_batch_nonneg,
+                      is_nonnegative)
+from .batched_trust_regions import BatchedProblem, BatchedTrustRegions
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def shard_restarts(num_restarts, rank, world):
+    """Indices of the restarts rank `rank` owns (interleaved)."""
+    return list(range(rank, num_restarts, world))
+
+
+def gather_best(candidates_local, values_local, owned, num_restarts):
+    """all_gather of per-restart (value, candidate) and argmax.  candidates_local: r_local x q x d, values_local:
+    r_local.  Returns (best candidate q x d, all candidates R x q x d, all values R) - identical on every rank."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return get_best_candidates(candidates_local, values_local), candidates_local, values_local
+    world = dist.get_world_size()
+    per = (num_restarts + world - 1) // world
+    q, d = candidates_local.shape[-2:]
+    dev, dt = candidates_local.device, candidates_local.dtype
+    packed = torch.full((per, 1 + q * d), float("-inf"), dtype=dt, device=dev)     # padded slots lose every argmax
+    n = len(owned)
+    if n:
+        packed[:n, 0] = values_local.reshape(-1).to(dt)
+        packed[:n, 1:] = candidates_local.reshape(n, -1)
+    gathered = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(gathered, packed)
+    values = torch.full((num_restarts,), float("-inf"), dtype=dt, device=dev)
+    cands = torch.zeros(num_restarts, q, d, dtype=dt, device=dev)
+    for r in range(world):
+        idx = shard_restarts(num_restarts, r, world)
+        if idx:
+            values[idx] = gathered[r][:len(idx), 0]
+            cands[idx] = gathered[r][:len(idx), 1:].reshape(len(idx), q, d)
+    return get_best_candidates(cands, values), cands, values
+
+
+def joint_optimize_manifold(acq_function, manifold, solver, q, num_restarts, raw_samples, bounds, sample_type=torch.float64,
+                            options=None, inequality_constraints=None, equality_constraints=None, pre_processing_manifold=None,
+                            post_processing_manifold=None, approx_hessian=False, solver_init_conds=False):
+    """Returns the `q x d` best candidate (manifold_optimize.py:36-120)."""
+    options = options or {}
+    analytic = getattr(acq_function, "is_analytic", True)
+    batch_initial_conditions = gen_batch_initial_conditions_manifold(
+        acq_function=acq_function, manifold=manifold, bounds=bounds, q=None if analytic else q, num_restarts=num_restarts,
+        raw_samples=raw_samples, sample_type=sample_type, options=options, post_processing_manifold=post_processing_manifold)
+    dist = _dist()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    if dist is not None and world > 1:
+        # every rank must start from the same initial conditions: rank 0's draw wins
+        batch_initial_conditions = batch_initial_conditions.contiguous()
+        dist.broadcast(batch_initial_conditions, src=0)
+    owned = shard_restarts(num_restarts, rank, world)
+    batch_limit = options.get("batch_limit", num_restarts)
+    cand_list, val_list = [], []
+    start = 0
+    while start < len(owned):
+        idx = owned[start:start + batch_limit]
+        c, v = gen_candidates_manifold(
+            initial_conditions=batch_initial_conditions[idx], acquisition_function=acq_function, manifold=manifold,
+            solver=solver, pre_processing_manifold=pre_processing_manifold, post_processing_manifold=post_processing_manifold,
+            lower_bounds=None if bounds is None else bounds[0], upper_bounds=None if bounds is None else bounds[1],
+            options={k: v for k, v in options.items() if k not in ("batch_limit", "nonnegative")},
+            inequality_constraints=inequality_constraints, equality_constraints=equality_constraints,
+            approx_hessian=approx_hessian, solver_init_conds=solver_init_conds)
+        cand_list.append(c)
+        val_list.append(v)
+        start += batch_limit
+    if cand_list:
+        cands, vals = torch.cat(cand_list), torch.cat(val_list)
+    else:
+        cands = batch_initial_conditions[:0]
+        vals = torch.zeros(0, dtype=batch_initial_conditions.dtype, device=batch_initial_conditions.device)
+    best, _, _ = gather_best(cands, vals, owned, num_restarts)
+    return best
+
+
+def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, solver, pre_processing_manifold=None,
+                            post_processing_manifold=None, lower_bounds=None, upper_bounds=None, inequality_constraints=None,
+                            equality_constraints=None, approx_hessian=False, solver_init_conds=False, options=None):
+    """Optimise every initial condition (R x 1 x d) and return (candidates R x 1 x d, acquisition values R)
+    (manifold_optimize.py:124-228).  `solver` is a BatchedTrustRegions (lock-step); any object exposing the pymanopt
+    `solve(problem, x=...)` duck type is driven restart by restart through a per-point adapter instead."""
+    x0 = initial_conditions.detach()
+    if x0.shape[1] != 1:
+        raise NotImplementedError("q != 1 is not handled (neither does the reference: manifold_optimize.py:206)")
+    x0 = x0[:, 0]
+    if pre_processing_manifold is not None:
+        x0 = pre_processing_manifold(x0)
+
+    def cost(x):
+        if post_processing_manifold is not None:
+            x = post_processing_manifold(x)
+        x = x[:, None].double()                     # R x (q=1) x d: a t-batch per restart  (:182-184)
+        return -acquisition_function(x)
+
+    def precon(x, d):                               # (:190-193)
+        flat = d.reshape(d.shape[0], -1)
+        zero = flat.sum(1) == 0
+        return torch.where(zero.reshape((-1,) + (1,) * (d.dim() - 1)), d + 1e-30, d)
+
+    if not isinstance(solver, BatchedTrustRegions):
+        raise TypeError("gabotorch_amd drives the restarts in lock step: pass a gabotorch_amd BatchedTrustRegions solver "
+                        "(its constructor takes the keyword arguments of the reference's TrustRegions / ConstrainedTrustRegions)")
+    problem = BatchedProblem(manifold, cost, approx_hessian=approx_hessian, precon=precon)
+    if solver_init_conds:
+        x0 = torch.stack([torch.as_tensor(manifold.rand()) for _ in range(x0.shape[0])]).to(x0)
+    if equality_constraints is not None or inequality_constraints is not None:
+        opt_x = solver.solve(problem, x0.double(), eq_constraints=equality_constraints, ineq_constraints=inequality_constraints)
+    else:
+        opt_x = solver.solve(problem, x0.double())
+    candidates = opt_x
+    if post_processing_manifold is not None:
+        candidates = post_processing_manifold(candidates)
+    candidates = candidates[:, None]
+    with torch.no_grad():
+        batch_acquisition = acquisition_function(candidates)
+    return candidates.detach(), batch_acquisition.detach()
+
+
+def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num_restarts, raw_samples,
+                                          sample_type=torch.float64, options=None, post_processing_manifold=None):
+    """`num_restarts x q x d` initial conditions chosen among `raw_samples` random manifold points by the botorch
+    heuristics (manifold_optimize.py:232-321).  `manifold.rand` stays a host callable (callers monkey-patch it)."""
+    options = options or {}
+    batch_limit = options.get("batch_limit")
+    factor, max_factor = 1, 5
+    init_kwargs = {}
+    if "eta" in options:
+        init_kwargs["eta"] = options.get("eta")
+    if options.get("nonnegative") or is_nonnegative(acq_function):
+        init_func = initialize_q_batch_nonneg
+        if "alpha" in options:
+            init_kwargs["alpha"] = options.get("alpha")
+    else:
+        init_func = initialize_q_batch
+    if q is None:
+        q = 1
+    device = options.get("device")
+    while factor < max_factor:
+        with warnings.catch_warnings(record=True) as ws:
+            warnings.simplefilter("always")
+            points = [torch.as_tensor(np.asarray(manifold.rand()))[None, None] for _ in range(raw_samples * factor * q)]
+            X_rnd = torch.cat(points).to(sample_type)
+            if device is not None:
+                X_rnd = X_rnd.to(device)
+            if post_processing_manifold is not None:
+                X_rnd = post_processing_manifold(X_rnd)
+            with torch.no_grad():
+                bl = X_rnd.shape[0] if batch_limit is None else batch_limit
+                Y = [acq_function(X_rnd[s:s + bl]) for s in range(0, X_rnd.shape[0], bl)]
+                Y_rnd = torch.cat(Y).to(X_rnd)
+            batch_initial_conditions = init_func(X=X_rnd, Y=Y_rnd, n=num_restarts, **init_kwargs)
+            if not any(issubclass(w.category, BadInitialCandidatesWarning) for w in ws):
+                return batch_initial_conditions
+            if factor < max_factor:
+                factor += 1
+    warnings.warn("Unable to find non-zero acquisition function values - initial conditions are being selected randomly.",
+                  BadInitialCandidatesWarning)
+    return batch_initial_conditions
