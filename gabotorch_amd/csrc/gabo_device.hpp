@@ -87,4 +87,86 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 
 __device__ __forceinline__ double copysign_d(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
 
+// Polynomial coefficients of acos_fast / exp_neg.  fp64 literals cannot be VALU inline operands and hipcc re-materialises
+// each one with two v_mov_b32 in front of every v_fmac (tripling the VALU cost of a Horner step).  A kernel therefore
+// loads the table ONCE into registers (`MathRegs::load()`, laundered through an empty asm so the values are opaque and
+// cannot be re-materialised) and every Horner step is one v_fma_f64 with a live register addend.
+struct MathRegs {
+    double pS[6], qS[4];           // fdlibm e_acos.c: R(z) = z P(z) / Q(z)
+    double pio2_hi, pio2_lo, pi;
+    double log2e, ln2_hi, ln2_lo;
+    double inv_fact[12];           // 1/13!, 1/12!, ..., 1/2!
+
+    __device__ __forceinline__ static double pin(double v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+    __device__ __forceinline__ static MathRegs load() {
+        MathRegs t;
+        const double pS[6] = {1.66666666666666657415e-01, -3.25565818622400915405e-01, 2.01212532134862925881e-01,
+                              -4.00555345006794114027e-02, 7.91534994289814532176e-04, 3.47933107596021167570e-05};
+        const double qS[4] = {-2.40339491173441421878e+00, 2.02094576023350569471e+00, -6.88283971605453293030e-01,
+                              7.70381505559019352791e-02};
+        const double f[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
+                              1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5};
+        static_for<6>([&](auto i) { t.pS[decltype(i)::value] = pin(pS[decltype(i)::value]); });
+        static_for<4>([&](auto i) { t.qS[decltype(i)::value] = pin(qS[decltype(i)::value]); });
+        static_for<12>([&](auto i) { t.inv_fact[decltype(i)::value] = pin(f[decltype(i)::value]); });
+        t.pio2_hi = pin(1.57079632679489655800e+00);
+        t.pio2_lo = pin(6.12323399573676603587e-17);
+        t.pi = pin(3.14159265358979311600e+00);
+        t.log2e = pin(1.44269504088896338700e+00);
+        t.ln2_hi = pin(6.93147180369123816490e-01);
+        t.ln2_lo = pin(1.90821492927058770002e-10);
+        return t;
+    }
+};
+
+// acos(c) for |c| < 1 (callers clamp to [-1+1e-15, 1-1e-15]), branch-free.  Same rational approximation as fdlibm's
+// e_acos.c: R(z) = z P(z)/Q(z);  |c| <= 1/2: pi/2 - (c + c R(c^2));  c > 1/2: 2 (s + s R(z)), z = (1-c)/2, s = sqrt z;
+// c < -1/2: pi - 2 (s + s R(z)), z = (1+c)/2.  Both ranges share one evaluation of R on a selected z.  1 ulp measured.
+__device__ __forceinline__ double acos_fast(double c, const MathRegs& t) {
+    double a = __builtin_fabs(c);
+    bool small = a <= 0.5;
+    double z = small ? a * a : 0.5 * (1.0 - a);
+    double p = __builtin_fma(z, t.pS[5], t.pS[4]);
+    p = __builtin_fma(z, p, t.pS[3]);
+    p = __builtin_fma(z, p, t.pS[2]);
+    p = __builtin_fma(z, p, t.pS[1]);
+    p = __builtin_fma(z, p, t.pS[0]);
+    p = p * z;
+    double q = __builtin_fma(z, t.qS[3], t.qS[2]);
+    q = __builtin_fma(z, q, t.qS[1]);
+    q = __builtin_fma(z, q, t.qS[0]);
+    q = __builtin_fma(z, q, 1.0);
+    double r = p * rcp(q);
+    double s = sqrt_nz(small ? 1.0 : z);
+    double res_small = t.pio2_hi - (c - __builtin_fma(-c, r, t.pio2_lo));   // pio2_hi - (c - (pio2_lo - c r))
+    double w = __builtin_fma(s, r, s);                                        // s + s r
+    double res_large = (c > 0.0) ? 2.0 * w : __builtin_fma(-2.0, w - t.pio2_lo, t.pi);
+    return small ? res_small : res_large;
+}
+
+// exp(x) for x <= 0 (kernel values): k = rint(x log2 e), r = x - k ln2 (two-word ln2), degree-13 Taylor polynomial in r
+// (|r| <= 0.3466: truncation 4e-18), scaled by 2^k with v_ldexp_f64 (which also handles gradual underflow to 0).  1 ulp.
+__device__ __forceinline__ double exp_neg(double x, const MathRegs& t) {
+    x = x < -800.0 ? -800.0 : x;
+    double k = __builtin_rint(x * t.log2e);
+    double r = __builtin_fma(-k, t.ln2_lo, __builtin_fma(-k, t.ln2_hi, x));
+    double p = __builtin_fma(t.inv_fact[0], r, t.inv_fact[1]);
+    p = __builtin_fma(p, r, t.inv_fact[2]);
+    p = __builtin_fma(p, r, t.inv_fact[3]);
+    p = __builtin_fma(p, r, t.inv_fact[4]);
+    p = __builtin_fma(p, r, t.inv_fact[5]);
+    p = __builtin_fma(p, r, t.inv_fact[6]);
+    p = __builtin_fma(p, r, t.inv_fact[7]);
+    p = __builtin_fma(p, r, t.inv_fact[8]);
+    p = __builtin_fma(p, r, t.inv_fact[9]);
+    p = __builtin_fma(p, r, t.inv_fact[10]);
+    p = __builtin_fma(p, r, t.inv_fact[11]);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+
 }  // namespace gabo

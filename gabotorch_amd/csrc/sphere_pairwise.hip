@@ -11,47 +11,81 @@
 
 namespace gabo {
 
-constexpr int kSphereRows = 8;
+constexpr int kSphereRows = 16;   // rows of the output tile per block
+constexpr int kSphereKC = 16;     // inner-product depth staged through LDS per pass
+constexpr int kSphereLd = 257;    // padded leading dimension of the transposed x2 tile: conflict-free transposed writes
 
-__device__ __forceinline__ double sphere_finish(double ip, double beta, int mode) {
+template <int MODE>
+__device__ __forceinline__ double sphere_finish(double ip, double beta, const MathRegs& mt) {
     const double lo = -1.0 + 1e-15, hi = 1.0 - 1e-15;  // sphere_utils_torch.py:53
-    double c = ip < lo ? lo : (ip > hi ? hi : ip);
-    double dist = acos(c);                                // :55
-    if (mode == GABO_OUT_DISTANCE) return dist;
-    if (mode == GABO_OUT_LAPLACE) return exp(-(dist * beta));
-    return exp(-((dist * dist) * beta));                  // kernels_sphere.py:91-93
+    double c = __builtin_fmin(__builtin_fmax(ip, lo), hi);
+    double dist = acos_fast(c, mt);                       // :55
+    if constexpr (MODE == GABO_OUT_DISTANCE) return dist;
+    if constexpr (MODE == GABO_OUT_LAPLACE) return exp_neg(-(dist * beta), mt);
+    return exp_neg(-((dist * dist) * beta), mt);          // kernels_sphere.py:91-93
 }
 
-// 1-D grid: block id -> (batch, row chunk, column group), column group fastest
-__global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
+// 1-D grid: block id -> (batch, row chunk, column group), column group fastest.  Both operand tiles go through LDS:
+// the x2 tile is read from HBM/L2 fully coalesced (its 256 points are contiguous) and stored TRANSPOSED so that lane j
+// then reads xs2[k][j] conflict-free; the x1 tile is read back as LDS broadcasts (same address for the whole wave).
+// MODE is a template parameter so the 16 row epilogues of a lane are straight-line code the scheduler can interleave:
+// each is a long dependent chain (two Horner polynomials), and with ~110 VGPRs only 4 waves per SIMD hide its latency.
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks,
                                                               double beta, int flags) {
-    const int mode = flags & GABO_OUT_MASK;
+    __shared__ double xs2[kSphereKC * kSphereLd];
+    __shared__ double xs1[kSphereRows * kSphereKC];
+    const int tid = threadIdx.x;
     const int64_t bid = blockIdx.x;
     const int64_t cg = bid % col_blocks;
     const int64_t rc = (bid / col_blocks) % row_chunks;
     const int64_t b = bid / ((int64_t)col_blocks * row_chunks);
-    const int64_t j = cg * blockDim.x + threadIdx.x;
-    const int64_t jc = j < n2 ? j : n2 - 1;
+    const int64_t j0 = cg * blockDim.x;
+    const int64_t j = j0 + tid;
     const int64_t i0 = rc * kSphereRows;
-    const double* a = x1 + b * s1;                 // rows i0.. (uniform)
-    const double* bj = x2 + b * s2 + jc * dim;     // this lane's point
+    const int ncols = (int)((n2 - j0 < (int64_t)blockDim.x) ? n2 - j0 : (int64_t)blockDim.x);
+    const int nrows = (int)((n1 - i0 < kSphereRows) ? n1 - i0 : kSphereRows);
+    const double* a = x1 + b * s1 + i0 * dim;      // nrows x dim, contiguous
+    const double* bt = x2 + b * s2 + j0 * dim;     // ncols x dim, contiguous
     double acc[kSphereRows];
     static_for<kSphereRows>([&](auto r) { acc[decltype(r)::value] = 0.0; });
-    for (int k = 0; k < dim; ++k) {
-        double y = bj[k];
-        static_for<kSphereRows>([&](auto rr) {
-            constexpr int r = decltype(rr)::value;
-            int64_t i = i0 + r < n1 ? i0 + r : n1 - 1;
-            acc[r] = __builtin_fma(a[i * dim + k], y, acc[r]);
-        });
+    for (int k0 = 0; k0 < dim; k0 += kSphereKC) {
+        const int kc = dim - k0 < kSphereKC ? dim - k0 : kSphereKC;
+        if (k0) __syncthreads();
+        if (kc == dim) {
+            // whole points fit one pass: the tile is one contiguous run of ncols*dim doubles
+            for (int e = tid; e < ncols * dim; e += blockDim.x) {
+                int jj = e / dim, kk = e - jj * dim;
+                xs2[kk * kSphereLd + jj] = bt[e];
+            }
+        } else {
+            for (int e = tid; e < ncols * kc; e += blockDim.x) {
+                int jj = e / kc, kk = e - jj * kc;
+                xs2[kk * kSphereLd + jj] = bt[(int64_t)jj * dim + k0 + kk];
+            }
+        }
+        for (int e = tid; e < nrows * kc; e += blockDim.x) {
+            int rr = e / kc, kk = e - rr * kc;
+            xs1[rr * kSphereKC + kk] = a[(int64_t)rr * dim + k0 + kk];
+        }
+        __syncthreads();
+        for (int kk = 0; kk < kc; ++kk) {
+            double y = xs2[kk * kSphereLd + tid];
+            static_for<kSphereRows>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                acc[r] = __builtin_fma(xs1[r * kSphereKC + kk], y, acc[r]);
+            });
+        }
     }
-    if (j < n2) {
-        double* o = out + b * n1 * n2 + j;
+    if (tid < ncols) {
+        const MathRegs mt = MathRegs::load();
+        double* o = out + b * n1 * n2 + i0 * n2 + j;
         static_for<kSphereRows>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
-            if (i0 + r < n1) o[(i0 + r) * n2] = sphere_finish(acc[r], beta, mode);
+            double val = sphere_finish<MODE>(acc[r], beta, mt);
+            if (r < nrows) o[(int64_t)r * n2] = val;
         });
     }
 }
@@ -67,7 +101,11 @@ __global__ __launch_bounds__(256) void sphere_diag_kernel(const double* __restri
     const double* q = x2 + b * s2 + i * dim;
     double acc = 0.0;
     for (int k = 0; k < dim; ++k) acc = __builtin_fma(p[k], q[k], acc);
-    out[g] = sphere_finish(acc, beta, flags & GABO_OUT_MASK);
+    const MathRegs mt = MathRegs::load();
+    const int mode = flags & GABO_OUT_MASK;
+    out[g] = mode == GABO_OUT_DISTANCE ? sphere_finish<GABO_OUT_DISTANCE>(acc, beta, mt)
+                                       : (mode == GABO_OUT_LAPLACE ? sphere_finish<GABO_OUT_LAPLACE>(acc, beta, mt)
+                                                                   : sphere_finish<GABO_OUT_GAUSSIAN>(acc, beta, mt));
 }
 
 // Element-wise f^(order)(c) on a precomputed inner-product matrix c = <x1_i, x2_j>, f(c) = g(clamp(c)):
@@ -140,8 +178,14 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
         int64_t row_chunks = (n1 + gabo::kSphereRows - 1) / gabo::kSphereRows;
         int64_t nblocks = col_blocks * row_chunks * batch;
         if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
-        hipLaunchKernelGGL(gabo::sphere_pairwise_kernel, dim3((unsigned)nblocks), dim3(threads), 0, st, x1, x2, out, n1, n2, dim,
-                           x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, beta, flags);
+        const int mode = flags & GABO_OUT_MASK;
+#define GABO_SPH_LAUNCH(M)                                                                                                   \
+    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M>), dim3((unsigned)nblocks), dim3(threads), 0, st, x1, x2, out, n1, n2, \
+                       dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, beta, flags)
+        if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE);
+        else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE);
+        else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN);
+#undef GABO_SPH_LAUNCH
     }
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }

@@ -1,0 +1,11 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gabotorch_amd import ops
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+rng = np.random.default_rng(0)
+s = rng.standard_normal((n, 10)); s /= np.linalg.norm(s, axis=1, keepdims=True)
+s = torch.tensor(s, device="cuda")
+for _ in range(3):
+    ops.sphere_pairwise(s, s, beta=1.29)
+torch.cuda.synchronize()

@@ -1,0 +1,35 @@
+// accuracy of acos_fast / exp_neg (gabo_device.hpp) against the host libm, on a dense sweep
+#include "../gabotorch_amd/csrc/gabo_device.hpp"
+#include <cmath>
+#include <cstdio>
+#include <vector>
+__global__ void k(const double* x, double* a, double* e, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const gabo::MathRegs mt = gabo::MathRegs::load();
+    if (i < n) { a[i] = gabo::acos_fast(x[i], mt); e[i] = gabo::exp_neg(-700.0 * (x[i] + 1.0) * 0.5, mt); }
+}
+int main() {
+    const int n = 1 << 22;
+    std::vector<double> h(n), ha(n), he(n);
+    for (int i = 0; i < n; ++i) {
+        double t = (i + 0.5) / n;
+        h[i] = (i % 3 == 0) ? 1.0 - std::exp(-35.0 * t) : ((i % 3 == 1) ? -1.0 + std::exp(-35.0 * t) : 2.0 * t - 1.0);
+        if (h[i] > 1 - 1e-15) h[i] = 1 - 1e-15;
+        if (h[i] < -1 + 1e-15) h[i] = -1 + 1e-15;
+    }
+    double *x, *a, *e;
+    hipMalloc(&x, n * 8); hipMalloc(&a, n * 8); hipMalloc(&e, n * 8);
+    hipMemcpy(x, h.data(), n * 8, hipMemcpyHostToDevice);
+    k<<<n / 256, 256>>>(x, a, e, n);
+    hipMemcpy(ha.data(), a, n * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(he.data(), e, n * 8, hipMemcpyDeviceToHost);
+    double ea = 0, ee = 0;
+    for (int i = 0; i < n; ++i) {
+        double ra = std::acos(h[i]);
+        ea = std::fmax(ea, std::fabs(ha[i] - ra) / ra);
+        double arg = -700.0 * (h[i] + 1.0) * 0.5, re = std::exp(arg);
+        if (re > 1e-300) ee = std::fmax(ee, std::fabs(he[i] - re) / re);
+    }
+    printf("acos_fast max rel err %.3e   exp_neg max rel err %.3e\n", ea, ee);
+    return 0;
+}
