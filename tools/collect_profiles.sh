@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> /tmp/pk.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep > $OUT/bench_under_rocprof.json 2> /tmp/pk.err
 cp /tmp/pk/bench_kernel_stats.csv $OUT/bench_kernel_stats.csv
 # PMC passes (counters only, no other trace domains): FETCH_SIZE and WRITE_SIZE cannot share a pass
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python $R/tools/prof_spd.py 4096 10 sym 2 > /dev/null 2>&1

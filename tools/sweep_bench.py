@@ -1,0 +1,58 @@
+"""Config 4 of BASELINE.json: gabo_spd S^5_++ acquisition sweep, 512 restarts (sharded over ranks when launched with torchrun)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gabotorch_amd import manifolds, models, ops
+from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel
+from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions
+from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold
+from gabotorch_amd.Riemannian_utils import spd_constraints_utils_torch as scut
+from gabotorch_amd.Riemannian_utils.spd_utils_torch import symmetric_matrix_to_vector_mandel_torch as to_vec, vector_to_symmetric_matrix_mandel_torch as to_mat
+
+
+def mandel(m):
+    d = m.shape[-1]
+    r, c = [], []
+    for k in range(d):
+        for i in range(d - k):
+            r.append(i); c.append(i + k)
+    r, c = np.array(r), np.array(c)
+    return np.ascontiguousarray(m[..., r, c] * np.where(r == c, 1.0, 2 ** 0.5))
+
+
+def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=1234, maxiter=100):
+    rng = np.random.default_rng(seed)
+    q = np.linalg.qr(rng.standard_normal((n_train, d, d)))[0]
+    X = np.einsum("nab,nb,ncb->nac", q, rng.uniform(1e-3, 5.0, (n_train, d)), q)
+    X = 0.5 * (X + X.transpose(0, 2, 1))
+    lg = np.log(np.linalg.eigvalsh(X) / 2.0)
+    y = (lg ** 2).sum(1)                      # squared AI distance to 2I: a smooth stand-in objective with the optimum at the base
+    kern = SpdAffineInvariantGaussianKernel(beta_min=0.25)
+    gp = models.ExactGP(torch.tensor(mandel(X), device=device), torch.tensor(y, device=device), kern, outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    man = manifolds.PositiveDefinite(d)
+    man.min_eig, man.max_eig = 1e-3, 5.0
+
+    def rand():
+        lam = man.min_eig + (man.max_eig - man.min_eig) * np.random.rand(d)
+        u, _ = np.linalg.qr(np.random.randn(d, d))
+        return u @ np.diag(lam) @ u.T
+    man.rand = rand
+    np.random.seed(seed); torch.manual_seed(seed)
+    ops.set_error_checking(False)
+    device = str(device)
+    solver = BatchedTrustRegions(mingradnorm=1e-4, maxiter=maxiter)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=num_restarts, raw_samples=raw_samples, bounds=None,
+                                   options={"device": device}, inequality_constraints=[lambda x: scut.max_eigenvalue_constraint_torch(x, 5.0)],
+                                   pre_processing_manifold=to_mat, post_processing_manifold=to_vec, approx_hessian=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    return dt, best, float(acq(best[None]).item()), solver.log
+
+
+if __name__ == "__main__":
+    R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    dt, best, val, log = run_sweep("cuda:0", num_restarts=R)
+    print(f"sweep R={R}: {dt:.3f} s  {R/dt:.1f} restarts/s  EI*={val:.6e}  TR iterations={log['iterations']} cost evals={log['cost_evals']} grad evals={log['grad_evals']}")
+    dt, best, val, log = run_sweep("cuda:0", num_restarts=R)
+    print(f"sweep R={R} (warm): {dt:.3f} s  {R/dt:.1f} restarts/s")
