@@ -108,3 +108,40 @@ def test_sphere_manifold_ops(golden):
     np.testing.assert_allclose(man.transp(x, y, u), osph.transp(x, y, u), rtol=1e-13, atol=1e-14)
     np.testing.assert_allclose(man.exp(x, np.zeros_like(x)), x, rtol=0, atol=0)
     np.testing.assert_allclose(man.log(x, x), 0.0, atol=1e-7)
+
+
+def test_numpy_facing_utils_and_objectives(golden):
+    """Reference-named numpy helpers (spd_utils / sphere_utils) and the benchmark objectives, against golden values produced by
+    the reference's own functions."""
+    from gabotorch_amd.BO_test_functions import test_functions as tf
+    from gabotorch_amd.Riemannian_utils import sphere_utils, spd_utils
+    g = golden("spd_maps.npz")
+    S, X, U = g["d3_S"], g["d3_X"], g["d3_log"]
+    np.testing.assert_allclose(spd_utils.logmap(X[0], S[0]), U[0], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(spd_utils.expmap(U[0], S[0]), g["d3_explog"][0], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(spd_utils.symmetric_matrix_to_vector_mandel(np.array([[2., .5], [.5, 1.]])), [2, 1, 0.5 * 2 ** 0.5])
+    np.random.seed(int(g["sample_seed"]))
+    man = manifolds.PositiveDefinite(5)
+    man.min_eig, man.max_eig = 0.001, 5.0
+    np.testing.assert_allclose(np.stack([spd_utils.spd_sample(man) for _ in range(3)]), g["sample_out"], rtol=1e-13, atol=1e-14)
+    gs = golden("sphere.npz")
+    np.testing.assert_allclose(sphere_utils.logmap(gs["map_x"][0], gs["map_base"][0])[:, 0], gs["map_log"][0], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(sphere_utils.expmap(gs["map_log"].T, gs["map_base"].T).T, gs["map_exp"], rtol=1e-11, atol=1e-13)
+    go = golden("objectives.npz")
+    for d in (2, 5):
+        man = manifolds.PositiveDefinite(d)
+        for k in range(5):
+            x = torch.tensor(go[f"spd{d}_x"][k])
+            np.testing.assert_allclose(tf.ackley_function_spd(x, man).item(), go[f"spd{d}_ackley"][k], rtol=1e-9)
+            np.testing.assert_allclose(tf.rosenbrock_function_spd(x, man).item(), go[f"spd{d}_rosenbrock"][k], rtol=1e-8)
+    for n in (3, 5):
+        man = manifolds.Sphere(n)
+        for k in range(5):
+            np.testing.assert_allclose(tf.ackley_function_sphere(torch.tensor(go[f"sph{n}_x"][k]), man).item(),
+                                       go[f"sph{n}_ackley"][k], rtol=1e-10)
+    # known answers quoted in SURVEY App. A
+    man2 = manifolds.PositiveDefinite(2)
+    v = torch.tensor(spd_utils.symmetric_matrix_to_vector_mandel(np.array([[2., .5], [.5, 1.]])))
+    np.testing.assert_allclose(tf.ackley_function_spd(v, man2).item(), 5.409645747183784, rtol=1e-10)
+    np.testing.assert_allclose(tf.rosenbrock_function_spd(v, man2).item(), 533.8104003823937, rtol=1e-10)
+    np.testing.assert_allclose(tf.ackley_function_sphere(torch.tensor([0., 1., 0.], dtype=torch.float64), manifolds.Sphere(3)).item(), 5.652422842950539, rtol=1e-10)
