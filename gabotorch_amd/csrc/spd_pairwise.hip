@@ -31,7 +31,6 @@ __device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const d
     // M = C C^T = sum_col C[:,col] C[:,col]^T, so M is accumulated by rank-1 updates and C is never held whole:
     // live state is M (T doubles) + one column of C + one column of G.
     double m[T];
-    static_for<T>([&](auto ee) { m[decltype(ee)::value] = 0.0; });
     static_for<D>([&](auto cc) {
         constexpr int col = decltype(cc)::value;
         double g[D - col], c[D - col];
@@ -49,7 +48,8 @@ __device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const d
             constexpr int r = col + decltype(rr)::value;
             static_for<r - col + 1>([&](auto qq) {
                 constexpr int q = col + decltype(qq)::value;
-                m[tri(r, q)] = __builtin_fma(c[r - col], c[q - col], m[tri(r, q)]);
+                // column 0 touches every entry of M first: it initialises, the later columns accumulate
+                m[tri(r, q)] = (col == 0) ? c[r - col] * c[q - col] : __builtin_fma(c[r - col], c[q - col], m[tri(r, q)]);
             });
         });
     });

@@ -103,7 +103,7 @@ int gabo_matrix_to_mandel(const double* mat, double* vec, int64_t n, int d, gabo
 /* ------------------------------------------------------------------------------------------------------------
  * Batched Riemannian operations on the SPD manifold (one wave per matrix, LDS tiles, 1 <= d <= 32).
  * All matrices are full n x d x d row-major batches (what pymanopt's PositiveDefinite and the reference's numpy maps use).
- * Replaces, per restart of the acquisition maximiser (BoManifolds/manifold_optimization/*):
+ * Replaces, per restart of the acquisition maximiser (BoManifolds/manifold_optimization/...):
  *   GABO_SPD_EXP          out = X expm(X^-1 U)             a=X b=U        spd_utils.py:104-120 ; [3P] PositiveDefinite.exp = retr
  *   GABO_SPD_LOG          out = Log_X(Y)                   a=X b=Y        spd_utils.py:123-139 ; tools/multi.py:55-64
  *   GABO_SPD_INNER        out[n] = tr(X^-1 U X^-1 V)       a=X b=U c=V    [3P] inner  (robust_trust_regions.py:148)
