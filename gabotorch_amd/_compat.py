@@ -92,7 +92,7 @@ except Exception:  # noqa: BLE001
         def __init__(self, base_kernel, outputscale_prior=None, outputscale_constraint=None, **kwargs):
             super().__init__(**kwargs)
             self.base_kernel = base_kernel
-            self.register_parameter("raw_outputscale", torch.nn.Parameter(torch.zeros(*self.batch_shape)))
+            self.register_parameter("raw_outputscale", torch.nn.Parameter(torch.zeros(tuple(self.batch_shape))))
             self.register_constraint("raw_outputscale", outputscale_constraint or Positive())
             if outputscale_prior is not None:
                 self.register_prior("outputscale_prior", outputscale_prior, lambda: self.outputscale,

@@ -154,3 +154,130 @@ def get_best_candidates(batch_candidates, batch_values):
     """botorch.generation.gen.get_best_candidates [3P]: argmax over restarts (ties -> lowest index)."""
     best = torch.argmax(batch_values.view(-1), dim=0)
     return batch_candidates[best]
+
+
+# ---------------------------------------------------------------------------------------------- trainable surrogate
+class GammaPrior:
+    """Gamma(concentration, rate) log-density (gpytorch.priors.GammaPrior semantics) [3P]."""
+
+    def __init__(self, concentration, rate):
+        self.concentration, self.rate = float(concentration), float(rate)
+
+    def log_prob(self, x):
+        a, b = self.concentration, self.rate
+        return a * math.log(b) + (a - 1.0) * torch.log(x) - b * x - math.lgamma(a)
+
+    @property
+    def mode(self):
+        return max((self.concentration - 1.0) / self.rate, 0.0)
+
+
+class SingleTaskGP(torch.nn.Module):
+    """Constant-mean exact GP with a Gaussian likelihood and trainable hyper-parameters, laid out like the models of the
+    reference examples (examples/gabo_spd.py:165-176: ScaleKernel(base, outputscale_prior=Gamma(2, .15)), noise prior
+    Gamma(1.1, .05), noise constraint GreaterThan(1e-8), initial noise = prior mode).  Priors registered on the kernels through
+    the gpytorch-compatible `register_prior` are picked up when the stand-in Kernel base class is in use."""
+
+    def __init__(self, train_x, train_y, covar_module, noise_prior=None, noise_lower_bound=1e-8):
+        super().__init__()
+        self.train_x = train_x.double()
+        self.train_y = train_y.double().reshape(-1)
+        self.covar_module = covar_module
+        self.noise_prior = noise_prior
+        self.noise_lower_bound = float(noise_lower_bound)
+        init_noise = noise_prior.mode if noise_prior is not None and noise_prior.mode > noise_lower_bound else 1e-2
+        self.raw_noise = torch.nn.Parameter(torch.tensor(math.log(math.expm1(init_noise - self.noise_lower_bound)), dtype=torch.float64))
+        self.mean_constant = torch.nn.Parameter(torch.zeros((), dtype=torch.float64))
+        self._cache = None
+
+    @property
+    def noise(self):
+        return torch.nn.functional.softplus(self.raw_noise) + self.noise_lower_bound
+
+    def _kxx(self):
+        k = self.covar_module.forward(self.train_x, self.train_x)
+        n = k.shape[-1]
+        return k + self.noise.to(k.device) * torch.eye(n, dtype=k.dtype, device=k.device)
+
+    def _priors(self):
+        total = 0.0
+        mods = [self.covar_module] + ([self.covar_module.base_kernel] if hasattr(self.covar_module, "base_kernel") else [])
+        for m in mods:
+            for _, (prior, closure, _) in getattr(m, "_priors", {}).items():
+                total = total + prior.log_prob(closure()).sum()
+        if self.noise_prior is not None:
+            total = total + self.noise_prior.log_prob(self.noise)
+        return total
+
+    def marginal_log_likelihood(self):
+        """(log p(y | X) + log priors) / n, the quantity gpytorch's ExactMarginalLogLikelihood returns [3P]."""
+        k = self._kxx()
+        n = k.shape[-1]
+        L = torch.linalg.cholesky(k)
+        r = (self.train_y.to(k.device) - self.mean_constant.to(k.device)).unsqueeze(-1)
+        alpha = torch.cholesky_solve(r, L)
+        ll = -0.5 * (r * alpha).sum() - torch.log(torch.diagonal(L)).sum() - 0.5 * n * math.log(2 * math.pi)
+        pri = self._priors()
+        return (ll + (pri.to(ll.device) if torch.is_tensor(pri) else pri)) / n
+
+    def invalidate(self):
+        self._cache = None
+
+    def posterior(self, X):
+        if X.dim() == 2:
+            X = X.unsqueeze(-2)
+        b = X.shape[0]
+        if self._cache is None:
+            with torch.no_grad():
+                L = torch.linalg.cholesky(self._kxx())
+                mu = self.mean_constant.detach().to(L.device)
+                alpha = torch.cholesky_solve((self.train_y.to(L.device) - mu).unsqueeze(-1), L).squeeze(-1)
+            self._cache = (L, alpha, mu)
+        L, alpha, mu = self._cache
+        for p in self.covar_module.parameters():
+            p.requires_grad_(False)
+        xt = self.train_x.to(X.device).expand(b, *self.train_x.shape)
+        ks = self.covar_module.forward(X, xt).squeeze(-2)
+        kss = self.covar_module.forward(X, X).reshape(b)
+        Ld, ad = L.to(ks.device), alpha.to(ks.device)
+        mean = mu.to(ks.device) + ks @ ad
+        v = torch.linalg.solve_triangular(Ld, ks.transpose(-1, -2), upper=False)
+        return mean, kss - (v * v).sum(0)
+
+
+def fit_gpytorch_model(model, maxiter=200):
+    """Maximise the marginal log likelihood (+ priors) over every trainable parameter with scipy L-BFGS-B, as
+    botorch.fit_gpytorch_model does for the reference examples (examples/gabo_spd.py:194) [3P]."""
+    import numpy as np
+    from scipy.optimize import minimize
+    params = [p for p in model.parameters()]
+    for p in params:
+        p.requires_grad_(True)
+    shapes = [p.shape for p in params]
+    sizes = [p.numel() for p in params]
+
+    def set_params(v):
+        off = 0
+        with torch.no_grad():
+            for p, sh, sz in zip(params, shapes, sizes):
+                p.copy_(torch.as_tensor(v[off:off + sz], dtype=p.dtype).reshape(sh))
+                off += sz
+
+    def fun(v):
+        set_params(v)
+        for p in params:
+            p.grad = None
+        try:
+            loss = -model.marginal_log_likelihood()
+            loss.backward()
+        except RuntimeError:          # a trial point outside the SPD cone of K + noise I
+            return 1e10, np.zeros_like(v)
+        g = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().double().reshape(-1).numpy()
+                            for p in params])
+        return float(loss.item()), g
+
+    x0 = np.concatenate([p.detach().cpu().double().reshape(-1).numpy() for p in params])
+    res = minimize(fun, x0, jac=True, method="L-BFGS-B", options={"maxiter": maxiter})
+    set_params(res.x)
+    model.invalidate()
+    return model

@@ -1,0 +1,29 @@
+"""End-to-end BO loops (BASELINE.json configs 1 and 4 in miniature): GP fit + EI + manifold maximiser on the HIP path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+pytestmark = pytest.mark.gpu
+
+
+def test_gabo_sphere_loop():
+    import gabo_sphere
+    x, y, best = gabo_sphere.run(dim=3, iters=8, verbose=False)
+    assert x.shape == (13, 3) and np.allclose(x.norm(dim=-1).cpu().numpy(), 1.0, atol=1e-12)
+    assert all(b2 <= b1 + 1e-12 for b1, b2 in zip(best, best[1:])) and np.isfinite(best[-1])
+    assert best[-1] < best[0]            # EI finds something better than 5 random points on S^2 within 8 iterations
+
+
+def test_gabo_spd_loop():
+    import gabo_spd
+    from oracle import spd as ospd
+    x, y, best = gabo_spd.run(dim=3, iters=6, verbose=False)
+    assert x.shape == (11, 6)
+    lam = np.linalg.eigvalsh(ospd.vector_to_symmetric_matrix_mandel(x.cpu().numpy()))
+    assert lam.min() > 0 and lam.max() < 5.5
+    assert all(b2 <= b1 + 1e-12 for b1, b2 in zip(best, best[1:])) and np.isfinite(best[-1])
