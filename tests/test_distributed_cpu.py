@@ -75,3 +75,31 @@ def test_shard_and_gather_helpers_single_process():
     v = torch.tensor([0.1, 0.9, 0.9, 0.3])
     best, _, _ = gather_best(c, v, [0, 1, 2, 3], 4)
     assert torch.equal(best, c[1])                                          # ties -> lowest index
+
+
+def _gram_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from gabotorch_amd.distributed import sharded_gram
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        x1, x2 = torch.randn(11, 4, generator=g, dtype=torch.float64), torch.randn(7, 4, generator=g, dtype=torch.float64)
+        k = lambda a, b: torch.exp(-torch.cdist(a, b) ** 2)       # noqa: E731  stand-in kernel: the partition logic is under test
+        torch.save({"full": sharded_gram(k, x1, x2), "block": sharded_gram(k, x1, x2, gather=False), "ref": k(x1, x2)},
+                   os.path.join(out_dir, f"g{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gram_row_blocks(tmp_path):
+    from gabotorch_amd.distributed import row_block
+    assert [row_block(11, r, 3) for r in range(3)] == [(0, 4), (4, 8), (8, 11)]
+    assert [row_block(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    port = _free_port()
+    mp.spawn(_gram_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"g{r}.pt")) for r in range(3)]
+    for r, o in enumerate(outs):
+        assert torch.equal(o["full"], o["ref"])
+        lo, hi = row_block(11, r, 3)
+        assert torch.equal(o["block"], o["ref"][lo:hi])
