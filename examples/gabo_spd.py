@@ -57,6 +57,7 @@ def run(dim=3, iters=15, restarts=5, raw=100, seed=1234, device="cuda:0", verbos
         best.append(float(y_data.min()))
         if verbose:
             print(f"Iteration {it}\t Best f {best[-1]:.6f}")
+    ops.set_error_checking(True)
     return x_data, y_data, best
 
 

@@ -87,6 +87,14 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 
 __device__ __forceinline__ double copysign_d(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
 
+// a * b + c with the addend read from an SGPR pair (c wave-uniform).  hipcc would pick the two-address v_fmac_f64 and
+// first copy the coefficient into the accumulator with two v_mov_b32; VOP3 v_fma_f64 takes the scalar addend directly.
+__device__ __forceinline__ double fma_s(double a, double b, double c_uniform) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+}
+
 // Polynomial coefficients of acos_fast / exp_neg.  fp64 literals cannot be VALU inline operands and hipcc re-materialises
 // each one with two v_mov_b32 in front of every v_fmac (tripling the VALU cost of a Horner step).  A kernel therefore
 // loads the table ONCE into registers (`MathRegs::load()`, laundered through an empty asm so the values are opaque and
@@ -97,10 +105,19 @@ struct MathRegs {
     double log2e, ln2_hi, ln2_lo;
     double inv_fact[12];           // 1/13!, 1/12!, ..., 1/2!
 
+#ifdef GABO_MATH_SGPR   /* coefficients pinned in SGPRs (kernels with spare scalar registers): frees 56 VGPRs */
+    __device__ __forceinline__ static double pin(double v) {
+        asm volatile("" : "+s"(v));
+        return v;
+    }
+    __device__ __forceinline__ static double fmac(double a, double b, double c) { return fma_s(a, b, c); }
+#else
     __device__ __forceinline__ static double pin(double v) {
         asm volatile("" : "+v"(v));
         return v;
     }
+    __device__ __forceinline__ static double fmac(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#endif
     __device__ __forceinline__ static MathRegs load() {
         MathRegs t;
         const double pS[6] = {1.66666666666666657415e-01, -3.25565818622400915405e-01, 2.01212532134862925881e-01,
@@ -129,15 +146,15 @@ __device__ __forceinline__ double acos_fast(double c, const MathRegs& t) {
     double a = __builtin_fabs(c);
     bool small = a <= 0.5;
     double z = small ? a * a : 0.5 * (1.0 - a);
-    double p = __builtin_fma(z, t.pS[5], t.pS[4]);
-    p = __builtin_fma(z, p, t.pS[3]);
-    p = __builtin_fma(z, p, t.pS[2]);
-    p = __builtin_fma(z, p, t.pS[1]);
-    p = __builtin_fma(z, p, t.pS[0]);
+    double p = MathRegs::fmac(z * t.pS[5], 1.0, t.pS[4]);
+    p = MathRegs::fmac(z, p, t.pS[3]);
+    p = MathRegs::fmac(z, p, t.pS[2]);
+    p = MathRegs::fmac(z, p, t.pS[1]);
+    p = MathRegs::fmac(z, p, t.pS[0]);
     p = p * z;
-    double q = __builtin_fma(z, t.qS[3], t.qS[2]);
-    q = __builtin_fma(z, q, t.qS[1]);
-    q = __builtin_fma(z, q, t.qS[0]);
+    double q = MathRegs::fmac(z * t.qS[3], 1.0, t.qS[2]);
+    q = MathRegs::fmac(z, q, t.qS[1]);
+    q = MathRegs::fmac(z, q, t.qS[0]);
     q = __builtin_fma(z, q, 1.0);
     double r = p * rcp(q);
     double s = sqrt_nz(small ? 1.0 : z);
@@ -153,17 +170,17 @@ __device__ __forceinline__ double exp_neg(double x, const MathRegs& t) {
     x = x < -800.0 ? -800.0 : x;
     double k = __builtin_rint(x * t.log2e);
     double r = __builtin_fma(-k, t.ln2_lo, __builtin_fma(-k, t.ln2_hi, x));
-    double p = __builtin_fma(t.inv_fact[0], r, t.inv_fact[1]);
-    p = __builtin_fma(p, r, t.inv_fact[2]);
-    p = __builtin_fma(p, r, t.inv_fact[3]);
-    p = __builtin_fma(p, r, t.inv_fact[4]);
-    p = __builtin_fma(p, r, t.inv_fact[5]);
-    p = __builtin_fma(p, r, t.inv_fact[6]);
-    p = __builtin_fma(p, r, t.inv_fact[7]);
-    p = __builtin_fma(p, r, t.inv_fact[8]);
-    p = __builtin_fma(p, r, t.inv_fact[9]);
-    p = __builtin_fma(p, r, t.inv_fact[10]);
-    p = __builtin_fma(p, r, t.inv_fact[11]);
+    double p = MathRegs::fmac(r * t.inv_fact[0], 1.0, t.inv_fact[1]);
+    p = MathRegs::fmac(p, r, t.inv_fact[2]);
+    p = MathRegs::fmac(p, r, t.inv_fact[3]);
+    p = MathRegs::fmac(p, r, t.inv_fact[4]);
+    p = MathRegs::fmac(p, r, t.inv_fact[5]);
+    p = MathRegs::fmac(p, r, t.inv_fact[6]);
+    p = MathRegs::fmac(p, r, t.inv_fact[7]);
+    p = MathRegs::fmac(p, r, t.inv_fact[8]);
+    p = MathRegs::fmac(p, r, t.inv_fact[9]);
+    p = MathRegs::fmac(p, r, t.inv_fact[10]);
+    p = MathRegs::fmac(p, r, t.inv_fact[11]);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_ldexp(p, (int)k);

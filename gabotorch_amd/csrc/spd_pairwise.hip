@@ -15,6 +15,7 @@
 #include "gabo_device.hpp"
 #include "spd_eig.hpp"
 #include "spd_prep.hpp"
+#include "gabo_mirror.hpp"
 #include "../../include/gabo_hip.h"
 
 #ifndef GABO_PAIR_WAVES
@@ -125,28 +126,6 @@ __global__ __launch_bounds__(256, GABO_PAIR_WAVES) void spd_ai_pairwise_kernel(c
     }
 }
 
-// out[j][i] = out[i][j] for i < j, 32x32 tiles transposed through LDS (reads and writes both run along rows)
-__global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ out, int64_t n, int tiles) {
-    __shared__ double tile[32][33];
-    const int64_t b = blockIdx.y;
-    // block id -> (ti <= tj) over the upper triangle of the tile grid
-    int64_t t = blockIdx.x;
-    int ti = 0;
-    while (t >= tiles - ti) { t -= tiles - ti; ++ti; }
-    int tj = ti + (int)t;
-    double* o = out + b * n * n;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (int r = ty; r < 32; r += 8) {
-        int64_t i = (int64_t)ti * 32 + r, j = (int64_t)tj * 32 + tx;
-        tile[r][tx] = (i < n && j < n) ? o[i * n + j] : 0.0;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        int64_t j = (int64_t)tj * 32 + r, i = (int64_t)ti * 32 + tx;  // writes row j, columns i
-        if (i < n && j < n && i < j) o[j * n + i] = tile[tx][r];
-    }
-}
-
 template <int D>
 static int launch_spd_ai(const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
                          int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st) {
@@ -176,10 +155,10 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
                        (int)row_chunks, sym_tiles, beta, flags);
     if (flags & GABO_SYMMETRIC) {
         int tiles = (int)((n1 + 31) / 32);
-        hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch), dim3(256), 0, st,
+        hipLaunchKernelGGL((mirror_upper_kernel<0>), dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch), dim3(256), 0, st,
                            out, n1, tiles);
         if (dist_out)
-            hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch), dim3(256), 0,
+            hipLaunchKernelGGL((mirror_upper_kernel<0>), dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch), dim3(256), 0,
                                st, dist_out, n1, tiles);
     }
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;

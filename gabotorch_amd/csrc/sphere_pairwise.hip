@@ -7,6 +7,7 @@
 // row of the lane is read once per tile.  HBM traffic = the output matrix (8 B per pair); this kernel is bound by the
 // fp64 acos+exp epilogue and the output write, not by operand reads.
 #include "gabo_device.hpp"
+#include "gabo_mirror.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
@@ -34,14 +35,28 @@ template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks,
-                                                              double beta, int flags) {
+                                                              int64_t sym_tiles, double beta, int flags) {
     __shared__ double xs2[kSphereKC * kSphereLd];
     __shared__ double xs1[kSphereRows * kSphereKC];
     const int tid = threadIdx.x;
-    const int64_t bid = blockIdx.x;
-    const int64_t cg = bid % col_blocks;
-    const int64_t rc = (bid / col_blocks) % row_chunks;
-    const int64_t b = bid / ((int64_t)col_blocks * row_chunks);
+    int64_t cg, rc, b;
+    if (flags & GABO_SYMMETRIC) {       // x1 is x2: only tiles touching the upper triangle exist (see spd_pairwise.hip)
+        b = blockIdx.x / sym_tiles;
+        int64_t t = blockIdx.x - b * sym_tiles;
+        cg = 0;
+        for (;;) {
+            int64_t cnt = sym_chunks_of(cg, blockDim.x, kSphereRows, row_chunks);
+            if (t < cnt) break;
+            t -= cnt;
+            ++cg;
+        }
+        rc = t;
+    } else {
+        const int64_t bid = blockIdx.x;
+        cg = bid % col_blocks;
+        rc = (bid / col_blocks) % row_chunks;
+        b = bid / ((int64_t)col_blocks * row_chunks);
+    }
     const int64_t j0 = cg * blockDim.x;
     const int64_t j = j0 + tid;
     const int64_t i0 = rc * kSphereRows;
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         static_for<kSphereRows>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
             double val = sphere_finish<MODE>(acc[r], beta, mt);
-            if (r < nrows) o[(int64_t)r * n2] = val;
+            if (r < nrows && (!(flags & GABO_SYMMETRIC) || i0 + r <= j)) o[(int64_t)r * n2] = val;
         });
     }
 }
@@ -176,16 +191,26 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
         int threads = n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
         int64_t col_blocks = (n2 + threads - 1) / threads;
         int64_t row_chunks = (n1 + gabo::kSphereRows - 1) / gabo::kSphereRows;
-        int64_t nblocks = col_blocks * row_chunks * batch;
+        int64_t sym_tiles = 0;
+        if (flags & GABO_SYMMETRIC) {
+            if (n1 != n2 || batch > 65535) return GABO_ERR_ARG;
+            for (int64_t cg = 0; cg < col_blocks; ++cg) sym_tiles += gabo::sym_chunks_of(cg, threads, gabo::kSphereRows, row_chunks);
+        }
+        int64_t nblocks = ((flags & GABO_SYMMETRIC) ? sym_tiles : col_blocks * row_chunks) * batch;
         if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
         const int mode = flags & GABO_OUT_MASK;
 #define GABO_SPH_LAUNCH(M)                                                                                                   \
     hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M>), dim3((unsigned)nblocks), dim3(threads), 0, st, x1, x2, out, n1, n2, \
-                       dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, beta, flags)
+                       dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, sym_tiles, beta, flags)
         if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE);
         else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE);
         else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN);
 #undef GABO_SPH_LAUNCH
+        if (flags & GABO_SYMMETRIC) {
+            int tiles = (int)((n1 + 31) / 32);
+            hipLaunchKernelGGL((gabo::mirror_upper_kernel<1>), dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch),
+                               dim3(256), 0, st, out, n1, tiles);
+        }
     }
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }

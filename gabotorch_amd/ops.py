@@ -186,7 +186,7 @@ def spd_ai_kernel(x1, x2, beta, mode=_lib.GABO_OUT_GAUSSIAN):
     return _SpdAiKernelFunction.apply(x1, x2, beta, int(mode))
 
 
-def sphere_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, diag=False):
+def sphere_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, diag=False, symmetric=False):
     """x1 (..., N1, dim), x2 (..., N2, dim) -> (..., N1, N2)   [diag: (..., N, 1)]."""
     lib = _lib.load()
     if x1.shape[:-2] != x2.shape[:-2] or x1.shape[-1] != x2.shape[-1]:
@@ -206,7 +206,8 @@ def sphere_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, diag=False):
         return out.to(out_device)
     with torch.cuda.device(dev):
         rc = lib.gabo_sphere_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), nb, n1, n2, dim, s1, s2, float(beta),
-                                      int(mode), 1 if diag else 0, _stream_ptr(dev))
+                                      int(mode) | (_lib.GABO_SYMMETRIC if symmetric and not diag else 0), 1 if diag else 0,
+                                      _stream_ptr(dev))
     _lib.check(rc, "gabo_sphere_pairwise")
     return out.to(out_device)
 
@@ -272,6 +273,7 @@ def sphere_kernel(x1, x2, beta, mode=_lib.GABO_OUT_GAUSSIAN, diag=False):
         beta = torch.tensor(float(beta), dtype=torch.float64)
     need = torch.is_grad_enabled() and (x1.requires_grad or x2.requires_grad or beta.requires_grad)
     if not need:
+        # (no automatic GABO_SYMMETRIC here: the sphere launch is so short that the mirror pass costs more than it saves)
         return sphere_pairwise(x1, x2, float(beta), mode, diag=diag)
     dev = _device_for(x1, x2)
     a, b = x1.double().to(dev), x2.double().to(dev)

@@ -22,3 +22,14 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _reset_error_checking():
+    """Some code paths switch the device-status read-back off for latency; every test starts with it on."""
+    yield
+    try:
+        from gabotorch_amd import ops
+        ops.set_error_checking(True)
+    except Exception:   # noqa: BLE001
+        pass

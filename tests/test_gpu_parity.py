@@ -192,3 +192,15 @@ def test_sphere_vs_oracle(dim, n1, n2, batch):
         got = ops.sphere_pairwise(t(x1), t(x2), beta=beta, mode=mode).cpu().numpy()
         assert got.shape == want.shape
         np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-13)
+
+
+def test_sphere_symmetric_mode():
+    rng = np.random.default_rng(8)
+    for n in (1, 17, 256, 700):
+        x = rng.standard_normal((n, 6)); x /= np.linalg.norm(x, axis=1, keepdims=True)
+        X = t(x)
+        full = ops.sphere_pairwise(X, X, beta=2.1).cpu().numpy()
+        sym = ops.sphere_pairwise(X, X, beta=2.1, symmetric=True).cpu().numpy()
+        np.testing.assert_array_equal(sym, sym.T)
+        np.testing.assert_allclose(sym, full, rtol=1e-15, atol=1e-16)
+        np.testing.assert_allclose(sym, osph.sphere_gaussian_kernel(x, x, 2.1), rtol=1e-11, atol=1e-14)

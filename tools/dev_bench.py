@@ -41,3 +41,5 @@ if __name__ == "__main__":
     s = torch.tensor(s, device="cuda")
     ms = timeit(lambda: ops.sphere_pairwise(s, s, beta=1.29))
     print(f"sphere dim=10 N={n}: {ms:.3f} ms  {n*n/ms*1e3:.3e} pairs/s  {n*n*8/ms*1e3/1e9:.1f} GB/s written")
+    ms = timeit(lambda: ops.sphere_pairwise(s, s, beta=1.29, symmetric=True))
+    print(f"sphere dim=10 N={n} symmetric: {ms:.3f} ms  {n*n/ms*1e3:.3e} pairs/s")
