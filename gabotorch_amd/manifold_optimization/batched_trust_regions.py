@@ -80,7 +80,10 @@ class BatchedTrustRegions:
     handled as in ConstrainedTrustRegions (linearised constraints truncate the tCG step at distance Delta_cons)."""
 
     def __init__(self, miniter=3, kappa=0.1, theta=1.0, rho_prime=0.1, use_rand=False, rho_regularization=1e3, maxtime=1000,
-                 maxiter=1000, mingradnorm=1e-6, minstepsize=1e-10, maxcostevals=5000, logverbosity=0):
+                 maxiter=1000, mingradnorm=1e-6, minstepsize=1e-10, maxcostevals=5000, logverbosity=0, strict_constraints=False):
+        # strict_constraints=True = StrictConstrainedTrustRegions (constrained_trust_regions.py:737-1415): a proposal that
+        # violates a constraint is rejected outright (cost = +inf) and the radius shrinks; everything else is identical.
+        self.strict_constraints = strict_constraints
         if use_rand:
             raise NotImplementedError("use_rand=True (randomised tCG start) is not used by any reference example")
         self.miniter, self.kappa, self.theta, self.rho_prime = miniter, kappa, theta, rho_prime
@@ -147,6 +150,13 @@ class BatchedTrustRegions:
             eta, Heta, stop_inner = self._tcg(problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons)
             x_prop = man.retr(x, eta)
             fx_prop = problem.cost(x_prop)
+            invalid = torch.zeros_like(active)
+            if constrained and self.strict_constraints:
+                fcp, _ = self._constraint_values_grads(problem, x_prop, eqs + ineqs)        # (:932-951)
+                viol = fcp.clone()
+                viol[:, neq:] = torch.clamp(viol[:, neq:], max=0.0)
+                invalid = viol.abs().sum(1) != 0
+                fx_prop = torch.where(invalid, torch.full_like(fx_prop, float("inf")), fx_prop)
             rhonum = fx - fx_prop
             rhoden = -man.inner(x, g, eta) - 0.5 * man.inner(x, eta, Heta)
             rho_reg = torch.clamp(fx.abs(), min=1.0) * eps * self.rho_regularization
@@ -154,7 +164,7 @@ class BatchedTrustRegions:
             rhoden = rhoden + rho_reg
             model_decreased = rhoden >= 0
             rho = torch.where(rhoden == 0, torch.full_like(rhoden, float("nan")), rhonum / rhoden)
-            shrink = (rho < 0.25) | ~model_decreased | torch.isnan(rho)
+            shrink = (rho < 0.25) | ~model_decreased | torch.isnan(rho) | invalid
             boundary = (stop_inner == NEGATIVE_CURVATURE) | (stop_inner == EXCEEDED_TR)
             if constrained:
                 boundary = boundary | (stop_inner == REACHED_CONSTRAINTS)

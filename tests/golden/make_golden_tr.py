@@ -60,7 +60,7 @@ sys.modules["pymanopt.solvers"].solver = sys.modules["pymanopt.solvers.solver"]
 sys.modules["pymanopt"].solvers = sys.modules["pymanopt.solvers"]
 
 from BoManifolds.manifold_optimization.robust_trust_regions import TrustRegions  # noqa: E402
-from BoManifolds.manifold_optimization.constrained_trust_regions import ConstrainedTrustRegions  # noqa: E402
+from BoManifolds.manifold_optimization.constrained_trust_regions import ConstrainedTrustRegions, StrictConstrainedTrustRegions  # noqa: E402
 from BoManifolds.manifold_optimization.approximate_hessian import get_hessianfd  # noqa: E402
 from BoManifolds.pymanopt_addons.problem import Problem  # noqa: E402
 from BoManifolds.pymanopt_addons.tools.multi import multiexp, multilog, multiprod, multisym, multitransp  # noqa: E402
@@ -153,6 +153,9 @@ def main():
         x0c = x0.copy(); x0c[:, 0] = np.abs(x0c[:, 0]) + 0.5; x0c /= np.linalg.norm(x0c, axis=1, keepdims=True)
         xs, fs = run(ConstrainedTrustRegions(mingradnorm=1e-6, maxiter=200), prob3, x0c, ineq_constraints=[lambda x: x[0] - 0.3])
         out[f"sph{n}_con_x0"], out[f"sph{n}_con_x"], out[f"sph{n}_con_f"] = x0c, xs, fs
+        prob4 = Problem(manifold=man, cost=cost, verbosity=0, arg=torch.Tensor())
+        xs, fs = run(StrictConstrainedTrustRegions(mingradnorm=1e-6, maxiter=200), prob4, x0c, ineq_constraints=[lambda x: x[0] - 0.3])
+        out[f"sph{n}_strict_x"], out[f"sph{n}_strict_f"] = xs, fs
     # ---------------- SPD d=2,3: FD Hessian, unconstrained + max-eigenvalue constraint (examples/gabo_spd.py:136-138,183,200-203)
     for d in (2, 3):
         def rs(k, lo=0.3, hi=3.0):
@@ -181,6 +184,11 @@ def main():
         xs, fs = run(ConstrainedTrustRegions(mingradnorm=1e-4, maxiter=100), prob2, x0c,
                      ineq_constraints=[lambda x: max_eigenvalue_constraint_torch(x, maxeig)])
         out[f"spd{d}_con_x0"], out[f"spd{d}_con_x"], out[f"spd{d}_con_f"] = x0c, xs, fs
+        prob3 = Problem(manifold=man, cost=cost, verbosity=0, arg=torch.Tensor())
+        prob3._hess = types.MethodType(get_hessianfd, prob3)
+        xs, fs = run(StrictConstrainedTrustRegions(mingradnorm=2e-4, maxiter=100, minstepsize=1e-4), prob3, x0c,
+                     ineq_constraints=[lambda x: max_eigenvalue_constraint_torch(x, maxeig)])     # examples/hd_gabo_spd.py:194
+        out[f"spd{d}_strict_x"], out[f"spd{d}_strict_f"] = xs, fs
         out[f"spd{d}_maxeig"] = np.float64(maxeig)
     np.savez_compressed(os.path.join(HERE, "trust_regions.npz"), **out)
     for k in sorted(out):
