@@ -204,3 +204,38 @@ def test_sphere_symmetric_mode():
         np.testing.assert_array_equal(sym, sym.T)
         np.testing.assert_allclose(sym, full, rtol=1e-15, atol=1e-16)
         np.testing.assert_allclose(sym, osph.sphere_gaussian_kernel(x, x, 2.1), rtol=1e-11, atol=1e-14)
+
+
+def test_baseline_config3_full_size_properties():
+    """BASELINE.json config 3 at full size (N=4096, d=10): size-independent properties + an oracle sub-block."""
+    import bench
+    x = bench.synthetic_spd_mandel(4096, 10, 1234)
+    X = t(x)
+    K = ops.spd_ai_pairwise(X, X, beta=bench.BETA)
+    Ks = ops.spd_ai_pairwise(X, X, beta=bench.BETA, symmetric=True)
+    assert K.shape == (4096, 4096) and bool(torch.isfinite(K).all())
+    assert float((K - K.T).abs().max()) < 1e-10                    # d(A,B) = d(B,A) through two different Cholesky factors
+    assert torch.equal(Ks, Ks.T)
+    assert float((K - Ks).abs().max()) < 1e-10
+    assert float((torch.diagonal(K) - 1).abs().max()) < 1e-12      # exp(-beta 1e-15)
+    assert float(K.max()) <= 1.0 and float(K.min()) >= 0.0
+    # transposed evaluation order: K(X[a], X[b]) == K(X[b], X[a])^T on ragged slices that do not align with the tiles
+    a, b = slice(37, 1000), slice(2111, 4096)
+    np.testing.assert_allclose(ops.spd_ai_pairwise(X[a], X[b], beta=bench.BETA).cpu().numpy(),
+                               ops.spd_ai_pairwise(X[b], X[a], beta=bench.BETA).T.cpu().numpy(), rtol=1e-9, atol=1e-13)
+    np.testing.assert_array_equal(ops.spd_ai_pairwise(X[a], X[b], beta=bench.BETA).cpu().numpy(), K[a, b].cpu().numpy())
+    blk = (slice(4000, 4096), slice(0, 130))
+    want = ospd.spd_ai_gaussian_kernel(x[blk[0]], x[blk[1]], bench.BETA)
+    np.testing.assert_allclose(K[blk].cpu().numpy(), want, rtol=1e-9, atol=1e-14)
+
+
+def test_baseline_config2_full_size_properties():
+    """BASELINE.json config 2 (S^9, N=4096)."""
+    rng = np.random.default_rng(1234)
+    x = rng.standard_normal((4096, 10)); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    X = t(x)
+    K = ops.sphere_pairwise(X, X, beta=0.6 + np.log(2))
+    assert torch.equal(K, K.T)                                      # <x,y> is accumulated in the same order both ways
+    np.testing.assert_allclose(torch.diagonal(K).cpu().numpy(), np.exp(-(0.6 + np.log(2)) * np.arccos(1 - 1e-15) ** 2), rtol=1e-9)
+    np.testing.assert_allclose(K[100:164, 4000:4096].cpu().numpy(), osph.sphere_gaussian_kernel(x[100:164], x[4000:4096], 0.6 + np.log(2)),
+                               rtol=1e-11, atol=1e-14)

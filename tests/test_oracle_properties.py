@@ -1,0 +1,49 @@
+"""Size-independent properties of the CPU oracle (hypothesis): the oracle is what the GPU path is judged against, so its own
+invariants are checked independently of the golden vectors."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from oracle import spd as ospd
+from oracle import sphere as osph
+
+
+def _spd(rng, n, d):
+    q = np.linalg.qr(rng.standard_normal((n, d, d)))[0]
+    m = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.1, 4.0, (n, d)), q)
+    return 0.5 * (m + m.transpose(0, 2, 1))
+
+
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 10_000), d=st.integers(2, 8))
+def test_spd_distance_invariances(seed, d):
+    rng = np.random.default_rng(seed)
+    X, Y = _spd(rng, 4, d), _spd(rng, 5, d)
+    D = ospd.affine_invariant_distance(X, Y)
+    np.testing.assert_allclose(D, ospd.affine_invariant_distance(Y, X).T, rtol=1e-9, atol=1e-10)           # symmetry
+    A = rng.standard_normal((d, d)) + 3 * np.eye(d)
+    cong = lambda M: A @ M @ A.T                                                                           # noqa: E731
+    np.testing.assert_allclose(ospd.affine_invariant_distance(cong(X), cong(Y)), D, rtol=1e-7, atol=1e-8)   # affine invariance
+    np.testing.assert_allclose(ospd.affine_invariant_distance(np.linalg.inv(X), np.linalg.inv(Y)), D, rtol=1e-7, atol=1e-8)
+    v = ospd.symmetric_matrix_to_vector_mandel(X)
+    np.testing.assert_allclose(ospd.vector_to_symmetric_matrix_mandel(v), X, rtol=1e-14, atol=1e-15)        # Mandel round trip
+    np.testing.assert_allclose((v * v).sum(-1), (X * X).sum((-1, -2)), rtol=1e-12)                          # Mandel is an isometry
+    np.testing.assert_allclose(ospd.expmap(ospd.logmap(Y[:4], X), X), Y[:4], rtol=1e-8, atol=1e-9)          # exp o log = id
+    U = ospd.logmap(Y[:4], X)
+    np.testing.assert_allclose(np.sqrt(ospd.spd_inner(X, U, U) + 1e-15), np.diagonal(D[:, :4]), rtol=1e-8)  # |Log_X Y|_X = d(X,Y)
+
+
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 10_000), dim=st.integers(2, 30))
+def test_sphere_invariances(seed, dim):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((6, dim)); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = rng.standard_normal((6, dim)); y /= np.linalg.norm(y, axis=1, keepdims=True)
+    D = osph.sphere_distance(x, y)
+    assert (D >= 0).all() and (D <= np.pi).all()
+    np.testing.assert_allclose(D, osph.sphere_distance(y, x).T, rtol=1e-13)
+    Q = np.linalg.qr(rng.standard_normal((dim, dim)))[0]
+    np.testing.assert_allclose(osph.sphere_distance(x @ Q, y @ Q), D, rtol=1e-9, atol=1e-7)                 # rotation invariance
+    u = osph.logmap(y, x)
+    np.testing.assert_allclose(np.linalg.norm(u, axis=1), np.diagonal(D), rtol=1e-8, atol=1e-7)
+    np.testing.assert_allclose(osph.expmap(u, x), y, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(np.sum(u * x, axis=1), 0.0, atol=1e-9)                                       # tangent
