@@ -16,6 +16,7 @@
 // reduction per row, then the lanes share the final congruence and the Mandel scatter.
 #include "gabo_device.hpp"
 #include "spd_prep.hpp"
+#include "spd_generic.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
@@ -213,6 +214,9 @@ extern "C" int gabo_spd_ai_backward(const double* x1, const double* x2, const do
     if (flags & GABO_SYMMETRIC) return GABO_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     double* ws = (double*)workspace;
+    if (d > GABO_SPD_REG_MAX_DIM)
+        return gabo::launch_spd_ai_backward_generic(x1, x2, grad_out, grad_x1, batch, n1, n2, d, x1_batch_stride, x2_batch_stride,
+                                                    go_batch_stride, go_row_stride, go_col_stride, beta, flags, ws, status, st);
 #define GABO_CASE(DD) \
     case DD:          \
         return gabo::launch_spd_ai_backward<DD>(x1, x2, grad_out, grad_x1, batch, n1, n2, x1_batch_stride, x2_batch_stride, \

@@ -16,6 +16,7 @@
 #include "spd_eig.hpp"
 #include "spd_prep.hpp"
 #include "gabo_mirror.hpp"
+#include "spd_generic.hpp"
 #include "../../include/gabo_hip.h"
 
 #ifndef GABO_PAIR_WAVES
@@ -170,6 +171,8 @@ extern "C" {
 
 size_t gabo_spd_ai_workspace_bytes(int64_t batch, int64_t n1, int64_t n2, int d) {
     if (batch < 0 || n1 < 0 || n2 < 0 || d < 1) return 0;
+    if (d > GABO_SPD_REG_MAX_DIM)   // wave-per-pair fallback: L^-1 (d x d) per x1 matrix, and as much again for the backward sums
+        return (size_t)(2 * batch * n1) * (size_t)d * (size_t)d * sizeof(double);
     return (size_t)(batch * (n1 + n2)) * (size_t)gabo::tri_size(d) * sizeof(double);
 }
 
@@ -184,6 +187,9 @@ int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, double
     if ((flags & GABO_SYMMETRIC) && (n1 != n2 || batch > 65535)) return GABO_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     double* ws = (double*)workspace;
+    if (d > GABO_SPD_REG_MAX_DIM)
+        return gabo::launch_spd_ai_generic(x1, x2, out, dist_out, batch, n1, n2, d, x1_batch_stride, x2_batch_stride, beta, flags, ws,
+                                           status, st);
 #define GABO_CASE(DD) \
     case DD:          \
         return gabo::launch_spd_ai<DD>(x1, x2, out, dist_out, batch, n1, n2, x1_batch_stride, x2_batch_stride, beta, flags, ws, status, st);

@@ -37,8 +37,10 @@ typedef void* gabo_stream_t; /* hipStream_t */
 #define GABO_OUT_MASK 3
 #define GABO_SYMMETRIC 4        /* x1 and x2 are the same set (n1 == n2): evaluate i <= j only and mirror */
 
-/* Largest SPD matrix dimension the register-resident pairwise kernels are instantiated for. */
-#define GABO_SPD_MAX_DIM 12
+/* SPD pairwise kernels: 2 <= d <= GABO_SPD_MAX_DIM.  d <= GABO_SPD_REG_MAX_DIM runs the register-resident lane-per-pair
+ * kernels (the fast path, the metric); larger d falls back to one wave per pair with LDS tiles. */
+#define GABO_SPD_REG_MAX_DIM 12
+#define GABO_SPD_MAX_DIM 32
 
 int gabo_version(void);
 

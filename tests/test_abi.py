@@ -26,6 +26,7 @@ def test_host_side_argument_errors_need_no_gpu():
     lib = _lib.load()
     assert lib.gabo_version() >= 100
     assert lib.gabo_spd_ai_workspace_bytes(2, 3, 4, 10) == 2 * 7 * 55 * 8
+    assert lib.gabo_spd_ai_workspace_bytes(2, 3, 4, 20) == 2 * 2 * 3 * 400 * 8      # wave-per-pair fallback layout
     # argument validation happens before any HIP call
     assert lib.gabo_spd_ai_pairwise(None, None, None, None, 1, 4, 4, 40, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_ERR_DIM
     assert lib.gabo_spd_ai_pairwise(None, None, None, None, 1, 4, 4, 3, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_ERR_ARG

@@ -76,7 +76,7 @@ def test_letters_fixture(golden):
     np.testing.assert_array_equal(ks, ks.T)
 
 
-@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_MAX_DIM + 1)))
+@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_REG_MAX_DIM + 1)) + [13, 16, 20])
 def test_spd_ai_vs_oracle_all_dims(d):
     rng = np.random.default_rng(d)
     x1 = rand_spd_mandel(rng, 37, d)
@@ -126,7 +126,7 @@ def test_spd_not_spd_is_reported():
     with pytest.raises(RuntimeError, match="not positive definite"):
         ops.spd_ai_pairwise(t(good), t(bad))
     with pytest.raises(RuntimeError, match="unsupported dimension"):
-        ops.spd_ai_pairwise(t(np.ones((2, 13 * 14 // 2))), t(np.ones((2, 13 * 14 // 2))))
+        ops.spd_ai_pairwise(t(np.ones((2, 33 * 34 // 2))), t(np.ones((2, 33 * 34 // 2))))
 
 
 def test_spd_properties_at_scale():
