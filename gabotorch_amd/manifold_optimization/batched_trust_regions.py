@@ -29,21 +29,62 @@ class BatchedProblem:
     is the stack of per-restart gradients).  Mirrors pymanopt_addons/problem.py:14-159 + the PytorchBackend contract
     (tools/autodiff/_pytorch.py:83-116); `approx_hessian=True` is get_hessianfd (approximate_hessian.py:11-62)."""
 
-    def __init__(self, manifold, cost_fn, approx_hessian=False, precon=None):
+    def __init__(self, manifold, cost_fn, approx_hessian=False, precon=None, use_hip_graphs=False):
         self.manifold = manifold
         self.cost_fn = cost_fn
         self.approx_hessian = approx_hessian
         self.precon = precon or (lambda x, d: d)
         self.n_cost = 0
         self.n_grad = 0
+        # A lock-step evaluation is a few hundred tiny launches (kernel + prep + GP algebra + their backward): launch bound.
+        # With use_hip_graphs the value and value+gradient evaluations are captured once per input shape into hipGraphs
+        # (torch.cuda.CUDAGraph) and replayed.  Needs a cost function without host synchronisation (error read-back off).
+        self.use_hip_graphs = use_hip_graphs
+        self._graphs = {}
+
+    def _graphed(self, kind, x):
+        key = (kind, tuple(x.shape), x.device)
+        ent = self._graphs.get(key)
+        if ent is None:
+            static_x = x.detach().clone()
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                for _ in range(3):                                  # warm-up outside capture (lazy caches, allocator)
+                    self._eval(kind, static_x)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._eval(kind, static_x)
+            ent = (graph, static_x, outs)
+            self._graphs[key] = ent
+        graph, static_x, outs = ent
+        static_x.copy_(x)
+        graph.replay()
+        return tuple(o.clone() for o in outs)
+
+    def _eval(self, kind, x):
+        if kind == "cost":
+            with torch.no_grad():
+                return (self.cost_fn(x).detach(),)
+        xx = x.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            f = self.cost_fn(xx)
+            (g,) = torch.autograd.grad(f.sum(), xx)
+        return f.detach(), g.detach()
 
     def cost(self, x):
         self.n_cost += 1
+        if self.use_hip_graphs and x.is_cuda:
+            return self._graphed("cost", x)[0]
         with torch.no_grad():
             return self.cost_fn(x).detach()
 
     def cost_egrad(self, x, create_graph=False):
         self.n_grad += 1
+        if self.use_hip_graphs and x.is_cuda and not create_graph:
+            f, g = self._graphed("grad", x)
+            return f, g, None
         xx = x.detach().clone().requires_grad_(True)
         with torch.enable_grad():
             f = self.cost_fn(xx)

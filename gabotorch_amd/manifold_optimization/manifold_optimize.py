@@ -81,7 +81,7 @@ def joint_optimize_manifold(acq_function, manifold, solver, q, num_restarts, raw
             initial_conditions=batch_initial_conditions[idx], acquisition_function=acq_function, manifold=manifold,
             solver=solver, pre_processing_manifold=pre_processing_manifold, post_processing_manifold=post_processing_manifold,
             lower_bounds=None if bounds is None else bounds[0], upper_bounds=None if bounds is None else bounds[1],
-            options={k: v for k, v in options.items() if k not in ("batch_limit", "nonnegative")},
+            options={k: v for k, v in options.items() if k not in ("batch_limit", "nonnegative")},   # "hip_graphs", "device" pass through
             inequality_constraints=inequality_constraints, equality_constraints=equality_constraints,
             approx_hessian=approx_hessian, solver_init_conds=solver_init_conds)
         cand_list.append(c)
@@ -123,7 +123,8 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
     if not isinstance(solver, BatchedTrustRegions):
         raise TypeError("gabotorch_amd drives the restarts in lock step: pass a gabotorch_amd BatchedTrustRegions solver "
                         "(its constructor takes the keyword arguments of the reference's TrustRegions / ConstrainedTrustRegions)")
-    problem = BatchedProblem(manifold, cost, approx_hessian=approx_hessian, precon=precon)
+    problem = BatchedProblem(manifold, cost, approx_hessian=approx_hessian, precon=precon,
+                             use_hip_graphs=bool((options or {}).get("hip_graphs", False)))
     if solver_init_conds:
         x0 = torch.stack([torch.as_tensor(manifold.rand()) for _ in range(x0.shape[0])]).to(x0)
     if equality_constraints is not None or inequality_constraints is not None:

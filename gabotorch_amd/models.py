@@ -30,6 +30,8 @@ class ExactGP(torch.nn.Module):
         self.noise = float(noise)
         self.mean = float(y.mean()) if mean is None else float(mean)
         self._cache = None
+        for p in self.base_kernel.parameters():     # fixed hyper-parameters: no gradient (and no device->host copy of one) in the acquisition path
+            p.requires_grad_(False)
 
     def _train_cache(self):
         if self._cache is None:
@@ -39,7 +41,10 @@ class ExactGP(torch.nn.Module):
                 k = k + self.noise * torch.eye(n, dtype=k.dtype, device=k.device)
                 L = torch.linalg.cholesky(k)
                 alpha = torch.cholesky_solve((self.train_y.to(k.device) - self.mean).unsqueeze(-1), L).squeeze(-1)
-            self._cache = (L, alpha)
+                # L^-1 once: the per-call triangular solve becomes a GEMM (rocBLAS trsm allocates workspace, which a hipGraph
+                # capture of the acquisition evaluation does not allow)
+                Linv = torch.linalg.solve_triangular(L, torch.eye(n, dtype=L.dtype, device=L.device), upper=False)
+            self._cache = (Linv, alpha)
         return self._cache
 
     def posterior(self, X):
@@ -47,15 +52,15 @@ class ExactGP(torch.nn.Module):
         if X.dim() == 2:
             X = X.unsqueeze(-2)
         b = X.shape[0]
-        L, alpha = self._train_cache()
+        Linv, alpha = self._train_cache()
         xt = self.train_x.to(X.device).expand(b, *self.train_x.shape)           # stride-0 batch: factored once by the kernel
         ks = self.outputscale * self.base_kernel.forward(X, xt)                 # b x 1 x n   (candidates first)
         kss = self.outputscale * self.base_kernel.forward(X, X)                 # b x 1 x 1
         ks = ks.squeeze(-2)
-        Ld, ad = L.to(ks.device), alpha.to(ks.device)
+        Li, ad = Linv.to(ks.device), alpha.to(ks.device)
         mean = self.mean + ks @ ad
-        v = torch.linalg.solve_triangular(Ld, ks.transpose(-1, -2), upper=False)  # n x b
-        var = kss.reshape(b) - (v * v).sum(0)
+        v = ks @ Li.transpose(-1, -2)                                           # b x n  = (L^-1 ks^T)^T
+        var = kss.reshape(b) - (v * v).sum(-1)
         return mean, var
 
 
@@ -232,17 +237,18 @@ class SingleTaskGP(torch.nn.Module):
                 L = torch.linalg.cholesky(self._kxx())
                 mu = self.mean_constant.detach().to(L.device)
                 alpha = torch.cholesky_solve((self.train_y.to(L.device) - mu).unsqueeze(-1), L).squeeze(-1)
-            self._cache = (L, alpha, mu)
-        L, alpha, mu = self._cache
+                Linv = torch.linalg.solve_triangular(L, torch.eye(L.shape[-1], dtype=L.dtype, device=L.device), upper=False)
+            self._cache = (Linv, alpha, mu)
+        Linv, alpha, mu = self._cache
         for p in self.covar_module.parameters():
             p.requires_grad_(False)
         xt = self.train_x.to(X.device).expand(b, *self.train_x.shape)
         ks = self.covar_module.forward(X, xt).squeeze(-2)
         kss = self.covar_module.forward(X, X).reshape(b)
-        Ld, ad = L.to(ks.device), alpha.to(ks.device)
+        Li, ad = Linv.to(ks.device), alpha.to(ks.device)
         mean = mu.to(ks.device) + ks @ ad
-        v = torch.linalg.solve_triangular(Ld, ks.transpose(-1, -2), upper=False)
-        return mean, kss - (v * v).sum(0)
+        v = ks @ Li.transpose(-1, -2)
+        return mean, kss - (v * v).sum(-1)
 
 
 def fit_gpytorch_model(model, maxiter=200):

@@ -158,3 +158,13 @@ def test_joint_optimize_sphere_gp_ei_exact_hessian():
     assert best.shape == (1, 3) and abs(best.norm().item() - 1) < 1e-12
     raw = torch.tensor(np.stack([manifolds.Sphere(3).rand() for _ in range(500)]), device=DEV)[:, None]
     assert acq(best[None]).item() >= acq(raw).max().item() - 1e-12
+
+
+def test_hip_graph_evaluations_match_eager():
+    """options={"hip_graphs": True}: the acquisition value / gradient evaluations are captured once and replayed; same optimum."""
+    from tools.sweep_bench import run_sweep
+    _, best_e, val_e, log_e = run_sweep(DEV, num_restarts=32, raw_samples=256)
+    _, best_g, val_g, log_g = run_sweep(DEV, num_restarts=32, raw_samples=256, hip_graphs=True)
+    np.testing.assert_allclose(best_g.cpu().numpy(), best_e.cpu().numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(val_g, val_e, rtol=1e-10)
+    assert int(log_g["grad_evals"]) == int(log_e["grad_evals"])
