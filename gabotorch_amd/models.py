@@ -30,7 +30,7 @@ class ExactGP(torch.nn.Module):
         self.noise = float(noise)
         self.mean = float(y.mean()) if mean is None else float(mean)
         self._cache = None
-        for p in self.base_kernel.parameters():     # fixed hyper-parameters: no gradient (and no device->host copy of one) in the acquisition path
+        for p in (self.base_kernel.parameters() if hasattr(self.base_kernel, "parameters") else ()):     # fixed hyper-parameters: no gradient (and no device->host copy of one) in the acquisition path
             p.requires_grad_(False)
 
     def _train_cache(self):
