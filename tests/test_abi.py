@@ -2,9 +2,19 @@
 import os
 import re
 
+import pytest
+
 from gabotorch_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built_library():
+    """The .so is a build artefact (git-ignored): build it with hipcc when a fresh checkout has none."""
+    if not os.path.exists(_lib.LIB_PATH):
+        from gabotorch_amd import _build
+        _build.build()
 
 
 def _declared():
