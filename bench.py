@@ -211,7 +211,8 @@ def main():
             "roofline_fp64": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach_tf / FP64_PEAK_TFLOPS,
                               "model": f"{FLOP_PER_PAIR:.0f} algorithmic flop/pair (SURVEY 8d); fp64 vector = matrix peak 78.6 TFLOP/s; "
-                                       "this is the binding resource (fp64 VALU issue)"},
+                                       "this is the binding resource (fp64 VALU issue); sustained v_fma_f64 rate measured on this chip "
+                                       "(tools/ubench_fp64.hip): 62.4 TFLOP/s", "measured_sustained_peak": 62.4},
             "symmetric_gram": None if sym is None else {
                 "ms_per_step": sym_ms, "pairs_per_s": pairs_per_step / (sym_ms * 1e-3),
                 "note": "x1 is x2 shortcut (GABO_SYMMETRIC): i <= j evaluated, mirrored; not used for `value`"},
