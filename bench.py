@@ -157,18 +157,18 @@ def main():
         # config 4 (gabo_spd S^5_++, 512 restarts): lock-step trust regions, restarts sharded r % world over the ranks,
         # one all_gather + argmax (RCCL).  Reported beside the headline metric, never mixed into `value`.
         from tools.sweep_bench import run_sweep
-        run_sweep(device, num_restarts=512, hip_graphs=True)                   # warm-up (allocator, code objects)
+        run_sweep(device, num_restarts=512, hip_graphs=True, batched_rand=True)   # warm-up (allocator, code objects)
         if dist is not None:
             dist.barrier()
-        sw_s, sw_best, sw_val, sw_log = run_sweep(device, num_restarts=512, hip_graphs=True)
+        sw_s, sw_best, sw_val, sw_log = run_sweep(device, num_restarts=512, hip_graphs=True, batched_rand=True)
         tt = torch.tensor([sw_s], dtype=torch.float64, device=device)
         if dist is not None:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         sweep = {"workload": "gabo_spd S^5_++: GP(50 obs)+EI, 2048 raw samples, 512 restarts, ConstrainedTR semantics, FD Hessian, "
-                             "lambda_max<=5 constraint; acquisition evaluations replayed from hipGraphs; restarts sharded over ranks, all_gather+argmax",
+                             "lambda_max<=5 constraint; raw samples drawn in one vectorised host call, acquisition evaluations and tCG iterations replayed from hipGraphs; restarts sharded over ranks, all_gather+argmax",
                  "seconds": float(tt.item()), "restarts_per_s": 512 / float(tt.item()), "best_acq": sw_val,
                  "tr_iterations": int(sw_log["iterations"]), "grad_evals": int(sw_log["grad_evals"]),
-                 "note": "latency-bound (a few ms per lock-step iteration, 8 KB collectives): does not scale with GPUs at this size"}
+                 "note": "launch/latency-bound (about 1 ms per lock-step tCG iteration even when replayed from hipGraphs, 8 KB collectives): does not scale with GPUs at this size"}
 
     t = torch.tensor([wall], dtype=torch.float64, device=device)
     if dist is not None:

@@ -75,14 +75,14 @@ class BatchedProblem:
 
     def cost(self, x):
         self.n_cost += 1
-        if self.use_hip_graphs and x.is_cuda:
+        if self.use_hip_graphs and x.is_cuda and not getattr(self, "_capturing", False):
             return self._graphed("cost", x)[0]
         with torch.no_grad():
             return self.cost_fn(x).detach()
 
     def cost_egrad(self, x, create_graph=False):
         self.n_grad += 1
-        if self.use_hip_graphs and x.is_cuda and not create_graph:
+        if self.use_hip_graphs and x.is_cuda and not create_graph and not getattr(self, "_capturing", False):
             f, g = self._graphed("grad", x)
             return f, g, None
         xx = x.detach().clone().requires_grad_(True)
@@ -230,108 +230,192 @@ class BatchedTrustRegions:
         return x
 
     # ------------------------------------------------------------------------------------------------- truncated CG
-    def _tcg(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons):
+    class _TcgState:
+        """All tCG quantities of the R restarts as persistent tensors updated IN PLACE, so that one iteration is a fixed sequence
+        of launches on fixed buffers - which is what lets it be captured in a hipGraph and replayed."""
+
+        def __init__(self, x, ncons):
+            R, dt, dev = x.shape[0], x.dtype, x.device
+            z1 = lambda: torch.zeros(R, dtype=dt, device=dev)       # noqa: E731
+            self.x, self.g = torch.zeros_like(x), torch.zeros_like(x)
+            self.Delta, self.active = z1(), torch.zeros(R, dtype=torch.bool, device=dev)
+            self.eta, self.Heta, self.r, self.delta = (torch.zeros_like(x) for _ in range(4))
+            self.e_Pe, self.e_Pd, self.d_Pd, self.z_r, self.model_value, self.norm_r0 = (z1() for _ in range(6))
+            self.stop = torch.zeros(R, dtype=torch.long, device=dev)
+            self.running = torch.zeros(R, dtype=torch.bool, device=dev)
+            self.any_running = torch.zeros((), dtype=torch.bool, device=dev)
+            self.fc = torch.zeros(R, ncons, dtype=dt, device=dev) if ncons else None
+            self.fcg_Pe = torch.zeros(R, ncons, dtype=dt, device=dev) if ncons else None
+            self.gc = [torch.zeros_like(x) for _ in range(ncons)]
+
+    def _tcg_begin(self, problem, S):
+        man = problem.manifold
+        S.eta.zero_()
+        S.Heta.zero_()
+        S.r.copy_(S.g)
+        S.e_Pe.zero_()
+        S.norm_r0.copy_(man.inner(S.x, S.r, S.r).clamp(min=0).sqrt())
+        z = problem.precon(S.x, S.r)
+        S.z_r.copy_(man.inner(S.x, z, S.r))
+        S.d_Pd.copy_(S.z_r)
+        S.delta.copy_(-z)
+        S.e_Pd.zero_()
+        S.model_value.zero_()
+        S.stop.fill_(MAX_INNER_ITER)
+        S.running.copy_(S.active)
+        if S.fcg_Pe is not None:
+            S.fcg_Pe.zero_()
+
+    def _tcg_step(self, problem, S, neq, Delta_cons, check_residual):
+        """One truncated-CG iteration for every restart (robust_trust_regions.py:476-568, constrained_trust_regions.py:530-732)."""
         man = problem.manifold
         inner = man.inner
-        R = x.shape[0]
-        eta = torch.zeros_like(x)
-        Heta = torch.zeros_like(x)
-        r = g.clone()
-        e_Pe = torch.zeros_like(Delta)
-        r_r = inner(x, r, r)
-        norm_r0 = r_r.sqrt()
-        z = problem.precon(x, r)
-        z_r = inner(x, z, r)
-        d_Pd = z_r.clone()
-        delta = -z
-        e_Pd = torch.zeros_like(Delta)
-        model_value = torch.zeros_like(Delta)
-        stop = torch.full((R,), MAX_INNER_ITER, dtype=torch.long, device=x.device)
-        running = active.clone()
-        constrained = fc is not None
+        x, g, delta = S.x, S.g, S.delta
+        constrained = S.fc is not None
+        Delta2 = S.Delta * S.Delta
+        running = S.running.clone()
+        stop = S.stop
+        Hdelta = problem.hess(x, delta, grad_x=g)
+        d_Hd = inner(x, delta, Hdelta)
+        nz = d_Hd != 0
+        alpha = torch.where(nz, S.z_r / torch.where(nz, d_Hd, torch.ones_like(d_Hd)), torch.zeros_like(d_Hd))
+        e_Pe_new = torch.where(nz, S.e_Pe + 2 * alpha * S.e_Pd + alpha * alpha * S.d_Pd, S.e_Pe)
         if constrained:
+            fc, fcg_Pe = S.fc, S.fcg_Pe
             C = fc.shape[1]
             is_ineq = torch.arange(C, device=x.device) >= neq
-            fcg_Pe = torch.zeros_like(fc)
-        Delta2 = Delta * Delta
+            fcg_Pd = torch.stack([inner(x, gci, delta) for gci in S.gc], dim=1)
 
-        def cons_step(step):
-            """violation of the linearised constraints after `step` along delta, and the step that stops at Delta_cons"""
-            term = fc + fcg_Pe + step[:, None] * fcg_Pd
-            term = torch.where(is_ineq[None, :], torch.clamp(term, max=0.0), term)
-            cin = (term * term).sum(1)
-            idx = (~is_ineq[None, :]) | (term < 0)          # equality constraints + violated inequalities
-            m = idx.to(fc.dtype)
-            qa = (m * fcg_Pd * fcg_Pd).sum(1)
-            qb = 2.0 * ((m * fc * fcg_Pd).sum(1) + (m * fcg_Pe * fcg_Pd).sum(1))
-            qc = (m * fc * fc).sum(1) + 2.0 * (m * fc * fcg_Pe).sum(1) + (m * fcg_Pe * fcg_Pe).sum(1) - Delta_cons ** 2
-            disc = qb * qb - 4.0 * qa * qc
-            tau = torch.where(disc >= 0, (-qb + disc.clamp(min=0).sqrt()) / (2.0 * qa), torch.zeros_like(disc))
-            return cin, tau
-
-        for j in range(int(maxinner)):
-            Hdelta = problem.hess(x, delta, grad_x=g)
-            d_Hd = inner(x, delta, Hdelta)
-            nz = d_Hd != 0
-            alpha = torch.where(nz, z_r / torch.where(nz, d_Hd, torch.ones_like(d_Hd)), torch.zeros_like(d_Hd))
-            e_Pe_new = torch.where(nz, e_Pe + 2 * alpha * e_Pd + alpha * alpha * d_Pd, e_Pe)
-            if constrained:
-                fcg_Pd = torch.stack([inner(x, gci, delta) for gci in gc], dim=1)
-            # ---- leave through the trust-region boundary / negative curvature
-            out = running & ((d_Hd <= 0) | (e_Pe_new >= Delta2))
-            tau = (-e_Pd + (e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe)).sqrt()) / d_Pd
-            reason = torch.where(d_Hd <= 0, torch.full_like(stop, NEGATIVE_CURVATURE), torch.full_like(stop, EXCEEDED_TR))
-            if constrained:
-                tau = torch.where(torch.isnan(tau), torch.zeros_like(tau), tau)
-                cin, tau_c = cons_step(tau)
-                hit = cin > Delta_cons ** 2
-                tau = torch.where(hit, tau_c, tau)
-                reason = torch.where((d_Hd > 0) & hit, torch.full_like(stop, REACHED_CONSTRAINTS), reason)
-            eta = torch.where(_bm(out, eta), eta + _bm(tau, delta) * delta, eta)
-            Heta = torch.where(_bm(out, Heta), Heta + _bm(tau, Hdelta) * Hdelta, Heta)
+            def cons_step(step):
+                """violation of the linearised constraints after `step` along delta, and the step that stops at Delta_cons"""
+                term = fc + fcg_Pe + step[:, None] * fcg_Pd
+                term = torch.where(is_ineq[None, :], torch.clamp(term, max=0.0), term)
+                cin = (term * term).sum(1)
+                m = ((~is_ineq[None, :]) | (term < 0)).to(fc.dtype)         # equality constraints + violated inequalities
+                qa = (m * fcg_Pd * fcg_Pd).sum(1)
+                qb = 2.0 * ((m * fc * fcg_Pd).sum(1) + (m * fcg_Pe * fcg_Pd).sum(1))
+                qc = (m * fc * fc).sum(1) + 2.0 * (m * fc * fcg_Pe).sum(1) + (m * fcg_Pe * fcg_Pe).sum(1) - Delta_cons ** 2
+                disc = qb * qb - 4.0 * qa * qc
+                tau_ = torch.where(disc >= 0, (-qb + disc.clamp(min=0).sqrt()) / (2.0 * qa), torch.zeros_like(disc))
+                return cin, tau_
+        # ---- leave through the trust-region boundary / negative curvature
+        out = running & ((d_Hd <= 0) | (e_Pe_new >= Delta2))
+        tau = (-S.e_Pd + (S.e_Pd * S.e_Pd + S.d_Pd * (Delta2 - S.e_Pe)).sqrt()) / S.d_Pd
+        reason = torch.where(d_Hd <= 0, torch.full_like(stop, NEGATIVE_CURVATURE), torch.full_like(stop, EXCEEDED_TR))
+        if constrained:
+            tau = torch.where(torch.isnan(tau), torch.zeros_like(tau), tau)
+            cin, tau_c = cons_step(tau)
+            hit = cin > Delta_cons ** 2
+            tau = torch.where(hit, tau_c, tau)
+            reason = torch.where((d_Hd > 0) & hit, torch.full_like(stop, REACHED_CONSTRAINTS), reason)
+        eta = torch.where(_bm(out, S.eta), S.eta + _bm(tau, delta) * delta, S.eta)
+        Heta = torch.where(_bm(out, S.Heta), S.Heta + _bm(tau, Hdelta) * Hdelta, S.Heta)
+        stop = torch.where(out, reason, stop)
+        running = running & ~out
+        # ---- leave because the linearised constraints are reached inside the trust region
+        if constrained:
+            cin, tau_c = cons_step(alpha)
+            out = running & (cin > Delta_cons ** 2)
+            eta = torch.where(_bm(out, eta), eta + _bm(tau_c, delta) * delta, eta)
+            Heta = torch.where(_bm(out, Heta), Heta + _bm(tau_c, Hdelta) * Hdelta, Heta)
+            stop = torch.where(out, torch.full_like(stop, REACHED_CONSTRAINTS), stop)
+            running = running & ~out
+        # ---- tentative step; reject it if the model did not decrease
+        new_eta = eta + _bm(alpha, delta) * delta
+        new_Heta = Heta + _bm(alpha, Hdelta) * Hdelta
+        new_model = inner(x, new_eta, g) + 0.5 * inner(x, new_eta, new_Heta)
+        out = running & ~(new_model < S.model_value)
+        stop = torch.where(out, torch.full_like(stop, MODEL_INCREASED), stop)
+        running = running & ~out
+        eta = torch.where(_bm(running, eta), new_eta, eta)
+        Heta = torch.where(_bm(running, Heta), new_Heta, Heta)
+        S.model_value.copy_(torch.where(running, new_model, S.model_value))
+        S.e_Pe.copy_(torch.where(running, e_Pe_new, S.e_Pe))
+        r = torch.where(_bm(running, S.r), S.r + _bm(alpha, Hdelta) * Hdelta, S.r)
+        norm_r = inner(x, r, r).clamp(min=0).sqrt()
+        # ---- residual small enough
+        if check_residual:
+            target = S.norm_r0 * torch.minimum(S.norm_r0 ** self.theta, torch.full_like(S.norm_r0, self.kappa))
+            out = running & (norm_r <= target)
+            reason = torch.where(self.kappa < S.norm_r0 ** self.theta, torch.full_like(stop, REACHED_TARGET_LINEAR),
+                                 torch.full_like(stop, REACHED_TARGET_SUPERLINEAR))
             stop = torch.where(out, reason, stop)
             running = running & ~out
-            # ---- leave because the linearised constraints are reached inside the trust region
-            if constrained:
-                cin, tau_c = cons_step(alpha)
-                out = running & (cin > Delta_cons ** 2)
-                eta = torch.where(_bm(out, eta), eta + _bm(tau_c, delta) * delta, eta)
-                Heta = torch.where(_bm(out, Heta), Heta + _bm(tau_c, Hdelta) * Hdelta, Heta)
-                stop = torch.where(out, torch.full_like(stop, REACHED_CONSTRAINTS), stop)
-                running = running & ~out
-            # ---- tentative step; reject it if the model did not decrease
-            new_eta = eta + _bm(alpha, delta) * delta
-            new_Heta = Heta + _bm(alpha, Hdelta) * Hdelta
-            new_model = inner(x, new_eta, g) + 0.5 * inner(x, new_eta, new_Heta)
-            out = running & ~(new_model < model_value)
-            stop = torch.where(out, torch.full_like(stop, MODEL_INCREASED), stop)
-            running = running & ~out
-            eta = torch.where(_bm(running, eta), new_eta, eta)
-            Heta = torch.where(_bm(running, Heta), new_Heta, Heta)
-            model_value = torch.where(running, new_model, model_value)
-            e_Pe = torch.where(running, e_Pe_new, e_Pe)
-            r = torch.where(_bm(running, r), r + _bm(alpha, Hdelta) * Hdelta, r)
-            r_r = inner(x, r, r)
-            norm_r = r_r.clamp(min=0).sqrt()
-            # ---- residual small enough
-            if j >= mininner:
-                target = norm_r0 * torch.minimum(norm_r0 ** self.theta, torch.full_like(norm_r0, self.kappa))
-                out = running & (norm_r <= target)
-                reason = torch.where(self.kappa < norm_r0 ** self.theta, torch.full_like(stop, REACHED_TARGET_LINEAR),
-                                     torch.full_like(stop, REACHED_TARGET_SUPERLINEAR))
-                stop = torch.where(out, reason, stop)
-                running = running & ~out
-            if not bool(running.any()):
+        # ---- next search direction (only the restarts still running move on)
+        z = problem.precon(x, r)
+        z_r_new = inner(x, z, r)
+        beta = z_r_new / S.z_r
+        new_delta = torch.where(_bm(running, delta), -z + _bm(beta, delta) * delta, delta)
+        new_e_Pd = torch.where(running, beta * (S.e_Pd + alpha * S.d_Pd), S.e_Pd)
+        new_d_Pd = torch.where(running, z_r_new + beta * beta * S.d_Pd, S.d_Pd)
+        new_z_r = torch.where(running, z_r_new, S.z_r)
+        if constrained:
+            S.fcg_Pe.copy_(torch.where(running[:, None], fcg_Pe + alpha[:, None] * fcg_Pd, fcg_Pe))
+        S.eta.copy_(eta)
+        S.Heta.copy_(Heta)
+        S.r.copy_(r)
+        S.delta.copy_(new_delta)
+        S.e_Pd.copy_(new_e_Pd)
+        S.d_Pd.copy_(new_d_Pd)
+        S.z_r.copy_(new_z_r)
+        S.stop.copy_(stop)
+        S.running.copy_(running)
+        S.any_running.copy_(running.any())
+
+    def _tcg(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons):
+        ncons = 0 if fc is None else fc.shape[1]
+        graphs = bool(getattr(problem, "use_hip_graphs", False)) and x.is_cuda
+        key = (tuple(x.shape), x.device, ncons, neq, float(Delta_cons), int(mininner))
+        cache = problem.__dict__.setdefault("_tcg_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            ent = {"S": self._TcgState(x, ncons), "graphs": None}
+            cache[key] = ent
+        S = ent["S"]
+        S.x.copy_(x)
+        S.g.copy_(g)
+        S.Delta.copy_(Delta)
+        S.active.copy_(active)
+        if ncons:
+            S.fc.copy_(fc)
+            for dst, src in zip(S.gc, gc):
+                dst.copy_(src)
+        if graphs and ent["graphs"] is None:
+            # capture begin / first step (j < mininner: no residual test) / later steps once per problem and shape
+            problem._capturing = True
+            try:
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(torch.cuda.current_stream(x.device))
+                with torch.cuda.stream(side):
+                    self._tcg_begin(problem, S)
+                    self._tcg_step(problem, S, neq, Delta_cons, False)
+                    self._tcg_step(problem, S, neq, Delta_cons, True)
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                gb, g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb):
+                    self._tcg_begin(problem, S)
+                with torch.cuda.graph(g0, pool=gb.pool()):
+                    self._tcg_step(problem, S, neq, Delta_cons, False)
+                with torch.cuda.graph(g1, pool=gb.pool()):
+                    self._tcg_step(problem, S, neq, Delta_cons, True)
+                ent["graphs"] = (gb, g0, g1)
+            finally:
+                problem._capturing = False
+            S.x.copy_(x)
+            S.g.copy_(g)
+            S.Delta.copy_(Delta)
+            S.active.copy_(active)
+        if graphs:
+            gb, g0, g1 = ent["graphs"]
+            gb.replay()
+        else:
+            self._tcg_begin(problem, S)
+        for j in range(int(maxinner)):
+            check = j >= mininner
+            if graphs:
+                (g1 if check else g0).replay()
+            else:
+                self._tcg_step(problem, S, neq, Delta_cons, check)
+            if not bool(S.any_running):
                 break
-            # ---- next search direction
-            z = problem.precon(x, r)
-            zold = z_r
-            z_r_new = inner(x, z, r)
-            beta = z_r_new / zold
-            delta = torch.where(_bm(running, delta), -z + _bm(beta, delta) * delta, delta)
-            e_Pd = torch.where(running, beta * (e_Pd + alpha * d_Pd), e_Pd)
-            d_Pd = torch.where(running, z_r_new + beta * beta * d_Pd, d_Pd)
-            z_r = torch.where(running, z_r_new, z_r)
-            if constrained:
-                fcg_Pe = torch.where(running[:, None], fcg_Pe + alpha[:, None] * fcg_Pd, fcg_Pe)
-        return eta, Heta, stop
+        return S.eta.clone(), S.Heta.clone(), S.stop.clone()

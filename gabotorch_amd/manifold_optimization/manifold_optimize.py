@@ -162,8 +162,13 @@ def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num
     while factor < max_factor:
         with warnings.catch_warnings(record=True) as ws:
             warnings.simplefilter("always")
-            points = [torch.as_tensor(np.asarray(manifold.rand()))[None, None] for _ in range(raw_samples * factor * q)]
-            X_rnd = torch.cat(points).to(sample_type)
+            if options.get("batched_rand") and hasattr(manifold, "rand_batch"):
+                # opt-in: one vectorised draw instead of raw_samples host calls of manifold.rand (same distribution, different
+                # order of draws from the global RNG, so not sample-for-sample identical to the reference)
+                X_rnd = torch.as_tensor(np.asarray(manifold.rand_batch(raw_samples * factor * q)))[:, None].to(sample_type)
+            else:
+                points = [torch.as_tensor(np.asarray(manifold.rand()))[None, None] for _ in range(raw_samples * factor * q)]
+                X_rnd = torch.cat(points).to(sample_type)
             if device is not None:
                 X_rnd = X_rnd.to(device)
             if post_processing_manifold is not None:

@@ -48,6 +48,15 @@ class PositiveDefinite:
     def zerovec(self, x):
         return np.zeros_like(x) if isinstance(x, np.ndarray) else torch.zeros_like(x)
 
+    def rand_batch(self, k):
+        """k samples of the `spd_sample` distribution (eigenvalues U[min_eig, max_eig], Haar-like Q from qr(randn)) in one
+        vectorised numpy call.  Same distribution as k calls of spd_utils.spd_sample, NOT the same draw order from the global
+        RNG - used only when the caller opts in (options={"batched_rand": True})."""
+        lam = self.min_eig + (self.max_eig - self.min_eig) * np.random.rand(k, self._n)
+        q = np.linalg.qr(np.random.randn(k, self._n, self._n))[0]
+        m = np.einsum("kab,kb,kcb->kac", q, lam, q)
+        return 0.5 * (m + m.transpose(0, 2, 1))
+
     exp = staticmethod(_wrap(lambda x, u: ops.spd_manifold_op(_lib.GABO_SPD_EXP, x, u)))
     retr = exp                                                                       # [3P] retr = exp
     log = staticmethod(_wrap(lambda x, y: ops.spd_manifold_op(_lib.GABO_SPD_LOG, x, y)))
@@ -84,6 +93,10 @@ class Sphere:
     def rand(self):
         x = np.random.randn(self._n)
         return x / np.linalg.norm(x)
+
+    def rand_batch(self, k):
+        x = np.random.randn(k, self._n)
+        return x / np.linalg.norm(x, axis=1, keepdims=True)
 
     def zerovec(self, x):
         return np.zeros_like(x) if isinstance(x, np.ndarray) else torch.zeros_like(x)

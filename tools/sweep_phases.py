@@ -13,9 +13,6 @@ mo.gen_batch_initial_conditions_manifold = wrap("initial_conditions", mo.gen_bat
 mo.gen_candidates_manifold = wrap("gen_candidates", mo.gen_candidates_manifold)
 from gabotorch_amd.manifold_optimization import batched_trust_regions as btr
 btr.BatchedTrustRegions._tcg = wrap("tcg", btr.BatchedTrustRegions._tcg)
-btr.BatchedProblem.cost_grad = wrap("cost_grad(outer)", btr.BatchedProblem.cost_grad)
-btr.BatchedProblem.hess = wrap("hess(in tcg)", btr.BatchedProblem.hess)
-btr.BatchedTrustRegions._constraint_values_grads = staticmethod(wrap("constraints", btr.BatchedTrustRegions._constraint_values_grads))
 for g in (False, True):
     sweep_bench.run_sweep("cuda:0", hip_graphs=g)
     T.clear()
