@@ -1,0 +1,54 @@
+"""Error behaviour of the host layer and the C ABI on a GPU box (argument validation, shape contracts, dtype/device handling)."""
+import numpy as np
+import pytest
+import torch
+
+from gabotorch_amd import _lib, ops
+from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_shape_contracts():
+    a = torch.rand(4, 6, dtype=torch.float64, device=DEV) + torch.tensor([3., 3, 3, 0, 0, 0], dtype=torch.float64, device=DEV)
+    with pytest.raises(RuntimeError, match="not d\\(d\\+1\\)/2"):
+        ops.spd_ai_pairwise(torch.ones(3, 7, device=DEV), torch.ones(3, 7, device=DEV))
+    with pytest.raises(RuntimeError, match="shapes differ"):
+        ops.spd_ai_pairwise(a[None].expand(2, 4, 6), a)                      # batch shapes must match (no broadcasting)
+    with pytest.raises(RuntimeError, match="shapes differ"):
+        ops.sphere_pairwise(torch.ones(3, 4, device=DEV), torch.ones(3, 5, device=DEV))
+    with pytest.raises(RuntimeError, match="same length"):
+        ops.sphere_pairwise(torch.ones(3, 4, device=DEV), torch.ones(2, 4, device=DEV), diag=True)
+    # fp32 / CPU inputs are accepted, the result is fp64 on the caller's device
+    k = ops.spd_ai_pairwise(a.float().cpu(), a.float().cpu(), beta=0.3)
+    assert k.dtype == torch.float64 and k.device.type == "cpu" and k.shape == (4, 4)
+    # non-contiguous views
+    big = torch.zeros(4, 12, dtype=torch.float64, device=DEV)
+    big[:, ::2] = a
+    np.testing.assert_allclose(ops.spd_ai_pairwise(big[:, ::2], a, beta=0.3).cpu().numpy(), ops.spd_ai_pairwise(a, a, beta=0.3).cpu().numpy())
+
+
+def test_c_abi_argument_errors_on_device():
+    lib = _lib.load()
+    x = torch.ones(2, 3, dtype=torch.float64, device=DEV)
+    out = torch.empty(2, 2, dtype=torch.float64, device=DEV)
+    st = torch.zeros(2, dtype=torch.int32, device=DEV)
+    ws = torch.empty(64, dtype=torch.float64, device=DEV)
+    # workspace too small / symmetric with n1 != n2 / negative sizes
+    assert lib.gabo_spd_ai_pairwise(x.data_ptr(), x.data_ptr(), out.data_ptr(), None, 1, 2, 2, 2, 6, 6, 1.0, 0, ws.data_ptr(), 8, st.data_ptr(), None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_spd_ai_pairwise(x.data_ptr(), x.data_ptr(), out.data_ptr(), None, 1, 2, 1, 2, 6, 6, 1.0, _lib.GABO_SYMMETRIC, ws.data_ptr(), 512, st.data_ptr(), None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_spd_ai_pairwise(x.data_ptr(), x.data_ptr(), out.data_ptr(), None, -1, 2, 2, 2, 6, 6, 1.0, 0, ws.data_ptr(), 512, st.data_ptr(), None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_spd_manifold_op(99, x.data_ptr(), None, None, None, out.data_ptr(), None, 1, 2, None, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_spd_project(x.data_ptr(), x.data_ptr(), out.data_ptr(), 1, 2, 3, None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_sphere_from_inner(x.data_ptr(), out.data_ptr(), 4, 1.0, 0, 3, None) == _lib.GABO_ERR_ARG
+
+
+def test_second_derivative_of_spd_kernel_is_refused():
+    """The SPD kernels are first-order only (the reference uses approx_hessian=True for them): asking autograd for a second
+    derivative must fail loudly, not silently return zeros."""
+    x = (torch.rand(3, 3, dtype=torch.float64, device=DEV) + torch.tensor([2., 2, 0], dtype=torch.float64, device=DEV)).requires_grad_(True)
+    k = SpdAffineInvariantGaussianKernel(beta_min=0.5).forward(x, x.detach())
+    (g,) = torch.autograd.grad(k.sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):
+        torch.autograd.grad(g.sum(), x)
