@@ -7,3 +7,30 @@ def projection_from_spd_to_nested_spd(x_spd, projection_matrix):
     """Y = W^T X W for X (..., D, D) -> (..., d, d), computed by gabo_spd_project (Mandel in / Mandel out)."""
     y = ops.spd_project(symmetric_matrix_to_vector_mandel_torch(x_spd.detach()), projection_matrix.detach())
     return vector_to_symmetric_matrix_mandel_torch(y)
+
+
+def projection_from_nested_spd_to_spd(x_spd_low_dimension, projection_matrix, projection_complement_matrix, bottom_spd_matrix,
+                                      contraction_matrix):
+    """Approximate right inverse of `projection_from_spd_to_nested_spd` (nested_spd_utils.py:51-118): with R = [W, V],
+    Xr = [[Y, B], [B^T, C]], B = Y^1/2 K C^1/2, X = R Xr R^T.  Y: (d, d) or (N, d, d).  The matrix square roots are one
+    batched HIP launch (GABO_SPD_SQRTM); the block assembly and the two small products are host-side torch."""
+    import torch
+
+    from .. import _lib
+    y = x_spd_low_dimension
+    single = y.dim() == 2
+    if single:
+        y = y.unsqueeze(0)
+    dev, dt = y.device, y.dtype
+    W, V = projection_matrix.to(dev, dt), projection_complement_matrix.to(dev, dt)
+    C, K = bottom_spd_matrix.to(dev, dt), contraction_matrix.to(dev, dt)
+    R = torch.cat((W, V), dim=1)
+    sqrt_c = ops.spd_manifold_op(_lib.GABO_SPD_SQRTM, C).to(dt)
+    sqrt_y = ops.spd_manifold_op(_lib.GABO_SPD_SQRTM, y).to(dt)
+    side = sqrt_y @ K @ sqrt_c
+    n = y.shape[0]
+    top = torch.cat((y, side), dim=2)
+    bottom = torch.cat((side.transpose(1, 2), C.expand(n, *C.shape)), dim=2)
+    xr = torch.cat((top, bottom), dim=1)
+    x = R @ xr @ R.T
+    return x[0] if single else x

@@ -246,6 +246,16 @@ def gen_nested():
     W5 = W5[:, :2]
     out["X5"], out["W5"] = X5, W5
     out["Y5"] = nsu.projection_from_spd_to_nested_spd(torch.tensor(X5), torch.tensor(W5)).numpy()
+    # approximate right inverse of the projection (nested_spd_utils.py:51-118)
+    Vc = np.linalg.qr(rng.standard_normal((5, 5)))[0]
+    W5b, V5b = Vc[:, :2], Vc[:, 2:]
+    bottom = rand_spd(rng, 1, 3, 0.5, 2.0)[0]
+    contraction = rng.standard_normal((2, 3))
+    contraction /= 2.0 * np.linalg.norm(contraction, 2)
+    ylow = rand_spd(rng, 4, 2, 0.3, 3.0)
+    back = nsu.projection_from_nested_spd_to_spd(torch.tensor(ylow), torch.tensor(W5b), torch.tensor(V5b), torch.tensor(bottom),
+                                                 torch.tensor(contraction))
+    out["back_W"], out["back_V"], out["back_bottom"], out["back_K"], out["back_ylow"], out["back_X"] = W5b, V5b, bottom, contraction, ylow, back.numpy()
     np.savez_compressed(os.path.join(HERE, "nested_spd.npz"), **out)
 
 

@@ -145,3 +145,15 @@ def test_numpy_facing_utils_and_objectives(golden):
     np.testing.assert_allclose(tf.ackley_function_spd(v, man2).item(), 5.409645747183784, rtol=1e-10)
     np.testing.assert_allclose(tf.rosenbrock_function_spd(v, man2).item(), 533.8104003823937, rtol=1e-10)
     np.testing.assert_allclose(tf.ackley_function_sphere(torch.tensor([0., 1., 0.], dtype=torch.float64), manifolds.Sphere(3)).item(), 5.652422842950539, rtol=1e-10)
+
+
+def test_nested_back_projection_golden(golden):
+    from gabotorch_amd.nested_mappings.nested_spd_utils import projection_from_nested_spd_to_spd, projection_from_spd_to_nested_spd
+    g = golden("nested_spd.npz")
+    back = projection_from_nested_spd_to_spd(t(g["back_ylow"]), t(g["back_W"]), t(g["back_V"]), t(g["back_bottom"]), t(g["back_K"]))
+    np.testing.assert_allclose(back.cpu().numpy(), g["back_X"], rtol=1e-10, atol=1e-11)
+    # W^T X W recovers the latent matrix (it IS a right inverse of the projection)
+    again = projection_from_spd_to_nested_spd(back, t(g["back_W"]))
+    np.testing.assert_allclose(again.cpu().numpy(), g["back_ylow"], rtol=1e-9, atol=1e-10)
+    one = projection_from_nested_spd_to_spd(t(g["back_ylow"][0]), t(g["back_W"]), t(g["back_V"]), t(g["back_bottom"]), t(g["back_K"]))
+    assert one.shape == (5, 5)
