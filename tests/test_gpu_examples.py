@@ -27,3 +27,14 @@ def test_gabo_spd_loop():
     lam = np.linalg.eigvalsh(ospd.vector_to_symmetric_matrix_mandel(x.cpu().numpy()))
     assert lam.min() > 0 and lam.max() < 5.5
     assert all(b2 <= b1 + 1e-12 for b1, b2 in zip(best, best[1:])) and np.isfinite(best[-1])
+
+
+def test_hd_gabo_spd_loop():
+    """Config-5-shaped flow in miniature: S^5_++ observations, nested projection to S^2_++, latent EI maximisation, lift back."""
+    import hd_gabo_spd
+    from oracle import spd as ospd
+    x, y, best = hd_gabo_spd.run(dim=5, latent=2, iters=4, verbose=False)
+    assert x.shape == (9, 15)
+    lam = np.linalg.eigvalsh(ospd.vector_to_symmetric_matrix_mandel(x.cpu().numpy()))
+    assert lam.min() > 0
+    assert all(b2 <= b1 + 1e-12 for b1, b2 in zip(best, best[1:])) and np.isfinite(best[-1])
