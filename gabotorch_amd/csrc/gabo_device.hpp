@@ -186,4 +186,39 @@ __device__ __forceinline__ double exp_neg(double x, const MathRegs& t) {
     return __builtin_ldexp(p, (int)k);
 }
 
+// log(x) for positive normal x (eigenvalues of an SPD matrix), fdlibm e_log.c scheme: x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt 2,
+// s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2)), R a degree-7 minimax polynomial split into even and odd halves.
+// OCML's log is 98 VALU instructions (double-double arithmetic); this is ~35 at 1 ulp.  Coefficients pinned in registers.
+struct LogRegs {
+    double lg[7], ln2_hi, ln2_lo, sqrt_half;
+    __device__ __forceinline__ static LogRegs load() {
+        LogRegs t;
+        const double c[7] = {6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01,
+                             1.818357216161805012e-01, 1.531383769920937332e-01, 1.479819860511658591e-01};
+        static_for<7>([&](auto i) { t.lg[decltype(i)::value] = MathRegs::pin(c[decltype(i)::value]); });
+        t.ln2_hi = MathRegs::pin(6.93147180369123816490e-01);
+        t.ln2_lo = MathRegs::pin(1.90821492927058770002e-10);
+        t.sqrt_half = MathRegs::pin(0.70710678118654752440);
+        return t;
+    }
+};
+
+__device__ __forceinline__ double log_pos(double x, const LogRegs& t) {
+    double m = __builtin_amdgcn_frexp_mant(x);        // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    bool lo = m < t.sqrt_half;
+    m = lo ? m + m : m;                               // [sqrt(1/2), sqrt 2)
+    k = lo ? k - 1 : k;
+    double f = m - 1.0;
+    double s = f * rcp(2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * MathRegs::fmac(w, MathRegs::fmac(w, t.lg[5], t.lg[3]), t.lg[1]);
+    double t2 = z * MathRegs::fmac(w, MathRegs::fmac(w, MathRegs::fmac(w, t.lg[6], t.lg[4]), t.lg[2]), t.lg[0]);
+    double R = t1 + t2;
+    double hfsq = 0.5 * f * f;
+    double dk = (double)k;
+    return __builtin_fma(dk, t.ln2_hi, -((hfsq - __builtin_fma(s, hfsq + R, dk * t.ln2_lo)) - f));
+}
+
 }  // namespace gabo

@@ -59,14 +59,19 @@ __device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const d
     tridiagonalize<D>(m, dg, e2);
     tridiag_eigenvalues<D>(dg, e2);
     double s = 0.0;
+#ifdef GABO_OCML_LOG
     static_for<D>([&](auto kk) { double lg = log(dg[decltype(kk)::value]); s = __builtin_fma(lg, lg, s); });
+#else
+    const LogRegs lr = LogRegs::load();       // pinned here, after M and the tridiagonal are dead: no extra register pressure
+    static_for<D>([&](auto kk) { double lg = log_pos(dg[decltype(kk)::value], lr); s = __builtin_fma(lg, lg, s); });
+#endif
     return s;
 }
 
 __device__ __forceinline__ double finish(double dist, double beta, int mode) {
     if (mode == GABO_OUT_DISTANCE) return dist;
     if (mode == GABO_OUT_LAPLACE) return exp(-(dist * beta));   // kernels_spd.py:185
-    return exp(-((dist * dist) * beta));                        // kernels_spd.py:94-98
+    return exp(-((dist * dist) * beta));                        // kernels_spd.py:94-98   (one exp per pair: OCML's is fine here)
 }
 
 // 1-D grid, block id -> (batch, row chunk of `rows` rows, column group of blockDim.x columns), column group fastest
