@@ -134,18 +134,23 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
                 s = bb * ir;
                 double ic = GABO_QL_RCP(c);
 #else
-                // one reciprocal serves both divisions of the step: t = 1/(p r)  =>  1/r = t p,  1/c = r/p = t r^2
+                // one reciprocal serves both divisions of the step: t = 1/(p r)  =>  1/r = t p,  and
+                // p' = gamma^2 / c = gamma^2 r / p = (gamma r)^2 t
                 double t = GABO_QL_RCP(p * r);
                 double ir = t * p;
                 c = p * ir;
                 s = bb * ir;
-                double ic = (t * r) * r;
 #endif
                 double oldgam = gamma;
                 double al = dg[i];
                 gamma = nonzero(__builtin_fma(c, al - sigma, -s * oldgam));
                 dg[i + 1] = oldgam + (al - gamma);
+#ifdef GABO_QL_TWO_RCP
                 p = gamma * gamma * ic;
+#else
+                double gr = gamma * r;
+                p = (gr * t) * gr;
+#endif
             });
             e2[l] = s * p;
             dg[l] = sigma + gamma;
