@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256, GABO_PAIR_WAVES) void spd_ai_pairwise_kernel(c
     const int64_t jc = j < n2 ? j : n2 - 1;  // out-of-range lanes recompute the last column and do not store
     const int64_t i0 = rc * rows;
     const int64_t i1 = (i0 + rows < n1) ? i0 + rows : n1;
+    // symmetric mode, tile straddling the diagonal: a wave whose 64 columns all lie left of the tile's first row has nothing
+    // to store (i > j for every pair it would evaluate)
+    if ((flags & GABO_SYMMETRIC) && j0 + (int64_t)(threadIdx.x | 63) < i0) return;
     const double* Gj = G + b * g_batch_stride + jc;
     double* ob = out + b * n1 * n2;
     for (int64_t i = i0; i < i1; ++i) {
