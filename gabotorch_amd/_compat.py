@@ -56,7 +56,7 @@ except Exception:  # noqa: BLE001
         @lengthscale.setter
         def lengthscale(self, value):
             if not torch.is_tensor(value):
-                value = torch.as_tensor(value).to(self.raw_lengthscale)
+                value = torch.as_tensor(value, dtype=self.raw_lengthscale.dtype, device=self.raw_lengthscale.device)
             self.initialize(raw_lengthscale=self.raw_lengthscale_constraint.inverse_transform(value))
 
         def register_parameter(self, name, parameter):

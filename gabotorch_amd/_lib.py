@@ -35,6 +35,8 @@ SIGNATURES = {
     "gabo_spd_project": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "gabo_spd_logm_mandel": (_I, [_P, _P, _I64, _I, _P]),
     "gabo_frobenius_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _P]),
+    "gabo_spd_logm_mandel_backward": (_I, [_P, _P, _P, _I64, _I, _P]),
+    "gabo_frobenius_backward": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _D, _I, _D, _P]),
     "gabo_sphere_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _I64, _I, _P]),
     "gabo_mandel_to_matrix": (_I, [_P, _P, _I64, _I, _P]),
     "gabo_matrix_to_mandel": (_I, [_P, _P, _I64, _I, _P]),

@@ -231,6 +231,102 @@ __global__ __launch_bounds__(256) void frobenius_pairwise_kernel(const double* _
     out[g] = mode == GABO_OUT_DISTANCE ? dist : (mode == GABO_OUT_LAPLACE ? exp(-(dist * beta)) : exp(-((dist * dist) * beta)));
 }
 
+// Adjoint of the Frechet derivative of logm (Daleckii-Krein): gx = V ((V^T G V) o F) V^T, F_kl = (log l_k - log l_l)/(l_k - l_l),
+// F_kk = 1/l_k, Mandel in / out.  The Mandel map is an isometry, so gx is the gradient of the loss w.r.t. the Mandel
+// vector x when g is its gradient w.r.t. the Mandel vector of logm(X): what autograd through logm_torch
+// (spd_utils_torch.py:13-30) produces, without its 1/(l_k - l_l) singularity at repeated eigenvalues.
+__global__ __launch_bounds__(64) void spd_logm_mandel_backward_kernel(const double* __restrict__ x, const double* __restrict__ g,
+                                                                      double* __restrict__ gx, int64_t n, int d) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int dd = d * d;
+    double* M0 = lds;
+    double* M1 = M0 + dd;
+    double* M2 = M1 + dd;
+    double* M3 = M2 + dd;
+    double* cs = M3 + dd;
+    const int64_t i = blockIdx.x;
+    const int dv = d * (d + 1) / 2;
+    lds_from_mandel(x + i * dv, M0, d);
+    lds_from_mandel(g + i * dv, M2, d);
+    lds_jacobi(M0, M1, cs, d);                  // M0 = diag(lambda), M1 = V
+    lds_mm(M1, M2, M3, d, true, false);         // V^T G
+    lds_mm(M3, M1, M2, d, false, false);        // V^T G V
+    for (int e = threadIdx.x; e < dd; e += blockDim.x) {
+        int r = e / d, c = e - r * d;
+        double lr = M0[r * d + r], lc = M0[c * d + c];
+        double mean = 0.5 * (lr + lc), dl = lr - lc;
+        // log(lr/lc)/(lr-lc) = atanh(z)/(z mean) with z = dl/(2 mean): series near z = 0 keeps full precision
+        double z = dl / (2.0 * mean), z2 = z * z;
+        double f = (__builtin_fabs(z) < 1e-3) ? (1.0 + z2 * (1.0 / 3.0 + z2 * (0.2 + z2 * (1.0 / 7.0)))) / mean
+                                              : (log(lr) - log(lc)) / dl;
+        M2[e] *= f;
+    }
+    wsync();
+    lds_mm(M1, M2, M3, d, false, false);        // V (.)
+    lds_mm(M3, M1, M2, d, false, true);         // V (.) V^T
+    for (int e = threadIdx.x; e < dv; e += blockDim.x) {
+        int k = 0;
+        while (k + 1 < d && (k + 1) * d - (k + 1) * k / 2 <= e) ++k;
+        int c = e - (k * d - k * (k - 1) / 2);
+        int r = c + k;
+        gx[i * dv + e] = (k == 0) ? M2[r * d + c] : 0.5 * (kSqrt2 * M2[r * d + c] + kSqrt2 * M2[c * d + r]);
+    }
+}
+
+// Gradient of frobenius_pairwise w.r.t. x1 (Mandel): gx1[b,i,e] = sum_j w_ij (x1_ie - x2_je + sgn*eps_e), with
+// w_ij = go_ij * dOut/d(d^2) * 2 recomputed from the inputs (Gaussian: -2 beta K; Laplace: -beta K / d; distance: 1/d).
+// One block per (b, i): phase 1 the threads own 256 columns j and put w_j in LDS, phase 2 they own the Mandel entries e and
+// walk the 256 columns with coalesced reads of x2.  The x2-gradient is this kernel with the sets exchanged and eps_sign = -1.
+__global__ __launch_bounds__(256) void frobenius_backward_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
+                                                                 const double* __restrict__ go, double* __restrict__ gx1,
+                                                                 int64_t n1, int64_t n2, int d, int64_t s1, int64_t s2,
+                                                                 int64_t go_bs, int64_t go_rs, int64_t go_cs, double beta, int flags,
+                                                                 double eps_sign) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int dv = d * (d + 1) / 2;
+    double* P = lds;          // dv : x1 row + eps
+    double* Wj = P + dv;      // 256
+    const int mode = flags & GABO_OUT_MASK;
+    const int64_t b = blockIdx.x / n1, i = blockIdx.x - b * n1;
+    const double* p = x1 + b * s1 + i * dv;
+    for (int e = threadIdx.x; e < dv; e += blockDim.x) P[e] = p[e] + eps_sign * (e < d ? 1e-15 : kSqrt2 * 1e-15);
+    __syncthreads();
+    const int per = (dv + (int)blockDim.x - 1) / (int)blockDim.x;   // <= 3 for d <= 32
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t j0 = 0; j0 < n2; j0 += blockDim.x) {
+        int64_t j = j0 + threadIdx.x;
+        double w = 0.0;
+        if (j < n2) {
+            const double* q = x2 + b * s2 + j * dv;
+            double s = 0.0;
+            for (int e = 0; e < dv; ++e) { double diff = P[e] - q[e]; s = __builtin_fma(diff, diff, s); }
+            double g = go[b * go_bs + i * go_rs + j * go_cs];
+            if (mode == GABO_OUT_GAUSSIAN) w = g * (-2.0 * beta) * exp(-(s * beta));
+            else {
+                double dist = __builtin_sqrt(s);
+                w = mode == GABO_OUT_LAPLACE ? g * (-beta) * exp(-(dist * beta)) / dist : g / dist;
+            }
+        }
+        Wj[threadIdx.x] = w;
+        __syncthreads();
+        int64_t cnt = n2 - j0 < (int64_t)blockDim.x ? n2 - j0 : (int64_t)blockDim.x;
+        for (int t = 0; t < per; ++t) {
+            int e = threadIdx.x + t * blockDim.x;
+            if (e < dv) {
+                const double* q = x2 + b * s2 + j0 * dv + e;
+                double pe = P[e], a = acc[t];
+                for (int64_t jj = 0; jj < cnt; ++jj) a = __builtin_fma(Wj[jj], pe - q[jj * dv], a);
+                acc[t] = a;
+            }
+        }
+        __syncthreads();
+    }
+    for (int t = 0; t < per; ++t) {
+        int e = threadIdx.x + t * blockDim.x;
+        if (e < dv) gx1[(b * n1 + i) * dv + e] = acc[t];
+    }
+}
+
 // Sphere manifold operations, one lane per point (dim is small): x, u, v: n x dim.
 enum { SOP_PROJ = 0, SOP_RETR = 1, SOP_EXP = 2, SOP_LOG = 3, SOP_DIST = 4, SOP_EHESS2RHESS = 5 };
 
@@ -323,7 +419,7 @@ int gabo_spd_manifold_op(int op, const double* a, const double* b, const double*
 
 int gabo_spd_project(const double* x_mandel, const double* w, double* y_mandel, int64_t n, int D, int dl, gabo_stream_t stream) {
     if (n < 0) return GABO_ERR_ARG;
-    if (D < 1 || D > 64 || dl < 1 || dl > D) return GABO_ERR_DIM;
+    if (D < 1 || D > 64 || dl < 1 || dl > 64) return GABO_ERR_DIM;
     if (n == 0) return GABO_OK;
     if (!x_mandel || !w || !y_mandel || n > 0x7fffffffLL) return GABO_ERR_ARG;
     size_t lds = (size_t)(D * D + 2 * D * dl) * sizeof(double);
@@ -352,6 +448,32 @@ int gabo_frobenius_pairwise(const double* x1, const double* x2, double* out, int
     if (blocks > 0x7fffffffLL) return GABO_ERR_ARG;
     hipLaunchKernelGGL(gabo::frobenius_pairwise_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, out, tot,
                        n1, n2, d, x1_batch_stride, x2_batch_stride, beta, flags);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_spd_logm_mandel_backward(const double* x_mandel, const double* grad_y, double* grad_x, int64_t n, int d,
+                                  gabo_stream_t stream) {
+    if (d < 1 || d > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
+    if (n < 0 || (n > 0 && (!x_mandel || !grad_y || !grad_x))) return GABO_ERR_ARG;
+    if (n == 0) return GABO_OK;
+    size_t lds = (size_t)(4 * d * d + 2) * sizeof(double);
+    hipLaunchKernelGGL(gabo::spd_logm_mandel_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel,
+                       grad_y, grad_x, n, d);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_frobenius_backward(const double* x1, const double* x2, const double* grad_out, double* grad_x1, int64_t batch, int64_t n1,
+                            int64_t n2, int d, int64_t x1_batch_stride, int64_t x2_batch_stride, int64_t go_batch_stride,
+                            int64_t go_row_stride, int64_t go_col_stride, double beta, int flags, double eps_sign,
+                            gabo_stream_t stream) {
+    if (d < 1 || d > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
+    if (batch < 0 || n1 < 0 || n2 < 0 || (flags & ~GABO_OUT_MASK)) return GABO_ERR_ARG;
+    if (batch * n1 == 0) return GABO_OK;
+    if (!x1 || !grad_x1 || (n2 > 0 && (!x2 || !grad_out))) return GABO_ERR_ARG;
+    size_t lds = (size_t)(d * (d + 1) / 2 + 256) * sizeof(double);
+    hipLaunchKernelGGL(gabo::frobenius_backward_kernel, dim3((unsigned)(batch * n1)), dim3(256), lds, (hipStream_t)stream, x1, x2,
+                       grad_out, grad_x1, n1, n2, d, x1_batch_stride, x2_batch_stride, go_batch_stride, go_row_stride,
+                       go_col_stride, beta, flags, eps_sign);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

@@ -60,7 +60,7 @@ class SpdAffineInvariantLaplaceKernel(_BetaKernel):
 
 class SpdFrobeniusGaussianKernel(Kernel):
     """k(X, Y) = exp(-||X - Y + 1e-15||_F^2 / lengthscale^2) on Mandel inputs   (kernels_spd.py:190-241).
-    Forward only on the HIP path (no gradient with respect to the inputs)."""
+    Differentiable (first order) in x1, x2 and the lengthscale through the HIP backward."""
 
     def __init__(self, **kwargs):
         self.has_lengthscale = True
@@ -69,8 +69,7 @@ class SpdFrobeniusGaussianKernel(Kernel):
     def forward(self, x1, x2, diagonal_distance=False, **params):
         if diagonal_distance is True:
             return _diag_ones(x2)
-        ls = self.lengthscale.double()
-        return _lengthscale_kernel(ops.frobenius_pairwise(x1.detach(), x2.detach(), mode=_lib.GABO_OUT_DISTANCE), ls)
+        return ops.frobenius_kernel(x1, x2, _beta_from_lengthscale(self.lengthscale), _lib.GABO_OUT_GAUSSIAN)
 
 
 class SpdLogEuclideanGaussianKernel(Kernel):
@@ -84,14 +83,15 @@ class SpdLogEuclideanGaussianKernel(Kernel):
     def forward(self, x1, x2, diagonal_distance=False, **params):
         if diagonal_distance is True:
             return _diag_ones(x2)
-        l1 = ops.spd_logm_mandel(x1.detach())
-        l2 = l1 if x2 is x1 else ops.spd_logm_mandel(x2.detach())
-        return _lengthscale_kernel(ops.frobenius_pairwise(l1, l2, mode=_lib.GABO_OUT_DISTANCE), self.lengthscale.double())
+        l1 = ops.spd_logm_mandel_diff(x1)
+        l2 = l1 if x2 is x1 else ops.spd_logm_mandel_diff(x2)
+        return ops.frobenius_kernel(l1, l2, _beta_from_lengthscale(self.lengthscale), _lib.GABO_OUT_GAUSSIAN)
 
 
-def _lengthscale_kernel(dist, ls):
-    # exp(-d^2 / l^2): a one-line epilogue kept in torch so the lengthscale stays differentiable for the GP fit
-    return torch.exp(-(dist * dist) / (ls.to(dist.device) * ls.to(dist.device)))
+def _beta_from_lengthscale(ls):
+    # exp(-d^2 / l^2) = exp(-beta d^2) with beta = l^-2, kept in torch so the lengthscale stays differentiable for the GP fit
+    ls = ls.double().reshape(())
+    return 1.0 / (ls * ls)
 
 
 class NestedSpdAffineInvariantGaussianKernel(_BetaKernel):
@@ -116,9 +116,9 @@ class NestedSpdAffineInvariantGaussianKernel(_BetaKernel):
     def forward(self, x1, x2, diagonal_distance=False, **params):
         if diagonal_distance is True:
             return _diag_ones(x2)
-        w = self.projection_matrix.detach().double()
-        p1 = ops.spd_project(x1.detach(), w)
-        p2 = p1 if x2 is x1 else ops.spd_project(x2.detach(), w)
+        w = self.projection_matrix.double()
+        p1 = ops.spd_project_diff(x1, w)
+        p2 = p1 if x2 is x1 else ops.spd_project_diff(x2, w)
         return ops.spd_ai_kernel(p1, p2, self.beta.double(), _lib.GABO_OUT_GAUSSIAN)
 
 
@@ -142,7 +142,7 @@ class NestedSpdLogEuclideanGaussianKernel(SpdLogEuclideanGaussianKernel):
     def forward(self, x1, x2, diagonal_distance=False, **params):
         if diagonal_distance is True:
             return _diag_ones(x2)
-        w = self.projection_matrix.detach().double()
-        p1 = ops.spd_project(x1.detach(), w)
-        p2 = p1 if x2 is x1 else ops.spd_project(x2.detach(), w)
+        w = self.projection_matrix.double()
+        p1 = ops.spd_project_diff(x1, w)
+        p2 = p1 if x2 is x1 else ops.spd_project_diff(x2, w)
         return super().forward(p1, p2)

@@ -370,6 +370,36 @@ def spd_project(x_mandel, w):
     return out.to(out_device)
 
 
+class _SpdProject(torch.autograd.Function):
+    """Mandel(W^T X W), differentiable in X (adjoint = the same kernel with W^T) and in W (2 sum_n X_n W G_n)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return spd_project(x, w)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = spd_project(g, w.t().contiguous()).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            dev = _device_for(x, w, g)
+            X = mandel_to_matrix(_prep(x, dev)).reshape(-1, w.shape[0], w.shape[0])
+            G = mandel_to_matrix(_prep(g, dev)).reshape(-1, w.shape[1], w.shape[1])
+            gw = 2.0 * torch.einsum("nab,bc,ncd->ad", X, _prep(w, dev), G).to(w.device, w.dtype)
+        return gx, gw
+
+
+def spd_project_diff(x_mandel, w):
+    """Differentiable spd_project."""
+    if x_mandel.requires_grad or w.requires_grad:
+        return _SpdProject.apply(x_mandel, w)
+    return spd_project(x_mandel, w)
+
+
 def spd_logm_mandel(x_mandel):
     lib = _lib.load()
     out_device = x_mandel.device
@@ -400,6 +430,112 @@ def frobenius_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN):
         _lib.check(lib.gabo_frobenius_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), nb, n1, n2, d, s1, s2, float(beta),
                                                int(mode), _stream_ptr(dev)), "gabo_frobenius_pairwise")
     return out.to(out_device)
+
+
+def spd_logm_mandel_backward(x_mandel, grad_y):
+    """Gradient w.r.t. x (Mandel) of a loss whose gradient w.r.t. spd_logm_mandel(x) is grad_y."""
+    lib = _lib.load()
+    out_device = x_mandel.device
+    dev = _device_for(x_mandel, grad_y)
+    x = _prep(x_mandel, dev).contiguous()
+    g = _prep(grad_y, dev).expand(x.shape).contiguous()
+    d = _mandel_dim(x.shape[-1])
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_spd_logm_mandel_backward(x.data_ptr(), g.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], d,
+                                                     _stream_ptr(dev)), "gabo_spd_logm_mandel_backward")
+    return out.to(out_device)
+
+
+class _SpdLogmMandel(torch.autograd.Function):
+    """Mandel(logm(X)) with the Daleckii-Krein adjoint as backward (first order)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return spd_logm_mandel(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return spd_logm_mandel_backward(x, g).to(x.dtype)
+
+
+def spd_logm_mandel_diff(x_mandel):
+    """Differentiable spd_logm_mandel."""
+    return _SpdLogmMandel.apply(x_mandel) if x_mandel.requires_grad else spd_logm_mandel(x_mandel)
+
+
+def frobenius_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, wrt=1):
+    """Gradient of sum(grad_out * frobenius_pairwise(x1, x2)) with respect to x1 (wrt=1) or x2 (wrt=2)."""
+    lib = _lib.load()
+    out_device = (x1 if wrt == 1 else x2).device
+    dev = _device_for(x1, x2, grad_out)
+    a, b, g = _prep(x1, dev), _prep(x2, dev), _prep(grad_out, dev).contiguous()
+    d = _mandel_dim(a.shape[-1])
+    n1, n2 = a.shape[-2], b.shape[-2]
+    bshape = a.shape[:-2]
+    a2, nb, s1 = _flatten_batch(a, 2)
+    b2, _, s2 = _flatten_batch(b, 2)
+    if wrt == 1:
+        first, second, m1, m2, sf, ss, go_si, go_sj, sgn = a2, b2, n1, n2, s1, s2, n2, 1, 1.0
+    else:
+        first, second, m1, m2, sf, ss, go_si, go_sj, sgn = b2, a2, n2, n1, s2, s1, 1, n2, -1.0
+    gx = torch.zeros(bshape + (m1, a.shape[-1]), dtype=torch.float64, device=dev)
+    if gx.numel() == 0 or m2 == 0:
+        return gx.to(out_device)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_frobenius_backward(first.data_ptr(), second.data_ptr(), g.data_ptr(), gx.data_ptr(), nb, m1, m2, d, sf,
+                                               ss, n1 * n2, go_si, go_sj, float(beta), int(mode), sgn, _stream_ptr(dev)),
+                   "gabo_frobenius_backward")
+    if sf == 0 and nb > 1:
+        gx = gx.reshape(nb, m1, -1).sum(0).expand(bshape + (m1, a.shape[-1]))
+    return gx.to(out_device)
+
+
+class _FrobeniusKernelFunction(torch.autograd.Function):
+    """frobenius_pairwise(x1, x2; beta) with HIP forward and backward (first order), differentiable in x1, x2 and beta."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, beta, mode):
+        bval = float(beta)
+        out = frobenius_pairwise(x1, x2, bval, mode)
+        ctx.save_for_backward(x1, x2, out)
+        ctx.bval, ctx.mode = bval, mode
+        ctx.beta_shape = beta.shape if torch.is_tensor(beta) else None
+        ctx.beta_device = beta.device if torch.is_tensor(beta) else None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        x1, x2, out = ctx.saved_tensors
+        g1 = g2 = gb = None
+        if ctx.needs_input_grad[0]:
+            g1 = frobenius_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=1).to(x1.dtype)
+        if ctx.needs_input_grad[1]:
+            g2 = frobenius_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=2).to(x2.dtype)
+        if ctx.needs_input_grad[2]:
+            if ctx.mode == _lib.GABO_OUT_DISTANCE:
+                gb = torch.zeros((), dtype=grad_out.dtype, device=grad_out.device)
+            else:       # K = exp(-beta t) with t = d^2 (Gaussian) or d (Laplace): dK/dbeta = -t K
+                dist = frobenius_pairwise(x1, x2, 1.0, _lib.GABO_OUT_DISTANCE).to(out.device)
+                t = dist * dist if ctx.mode == _lib.GABO_OUT_GAUSSIAN else dist
+                gb = -(grad_out * out * t).sum()
+            gb = gb.reshape(ctx.beta_shape).to(ctx.beta_device)
+        return g1, g2, gb, None
+
+
+def frobenius_kernel(x1, x2, beta, mode=_lib.GABO_OUT_GAUSSIAN):
+    """Differentiable entry point used by SpdFrobeniusGaussianKernel / SpdLogEuclideanGaussianKernel."""
+    if torch.is_tensor(beta):
+        if beta.numel() != 1:
+            raise RuntimeError("gabotorch_amd SPD kernels take a single lengthscale (batch_shape == ())")
+        beta = beta.double()
+    else:
+        beta = torch.tensor(float(beta), dtype=torch.float64)
+    return _FrobeniusKernelFunction.apply(x1, x2, beta, int(mode))
 
 
 def sphere_manifold_op(op, x, u, v=None, w=None):

@@ -132,7 +132,8 @@ int gabo_matrix_to_mandel(const double* mat, double* vec, int64_t n, int d, gabo
 int gabo_spd_manifold_op(int op, const double* a, const double* b, const double* c, const double* e, double* out, double* out2,
                          int64_t n, int d, int* status, gabo_stream_t stream);
 
-/* Y = W^T X W, Mandel in (n x D(D+1)/2) -> Mandel out (n x dl(dl+1)/2); w: D x dl row-major.  1 <= dl <= D <= 64.
+/* Y = W^T X W, Mandel in (n x D(D+1)/2) -> Mandel out (n x dl(dl+1)/2); w: D x dl row-major.  1 <= D, dl <= 64
+ * (dl > D is the adjoint map G -> W G W^T of the projection, i.e. its gradient with respect to X).
  * Replaces projection_from_spd_to_nested_spd (nested_mappings/nested_spd_utils.py:13-48) fused with both Mandel maps. */
 int gabo_spd_project(const double* x_mandel, const double* w, double* y_mandel, int64_t n, int D, int dl, gabo_stream_t stream);
 
@@ -146,6 +147,20 @@ int gabo_spd_logm_mandel(const double* x_mandel, double* y_mandel, int64_t n, in
  * kernels_spd.py:238-240,309-311).  out: batch x n1 x n2. */
 int gabo_frobenius_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2, int d,
                             int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, gabo_stream_t stream);
+
+/* Gradients of the two calls above (the reference differentiates them by autograd; kernels_spd.py:238-240,305-311).
+ * gabo_spd_logm_mandel_backward: grad_x = Mandel( V ((V^T G V) o F) V^T ), the adjoint Frechet derivative of logm at X applied
+ *   to G = grad_y (Mandel), F the divided differences of log at the eigenvalues of X.
+ * gabo_frobenius_backward: grad_x1[b,i,:] = sum_j grad_out[b,i,j] dOut_ij/dx1_i for the same `flags`/`beta`; grad_out strides as
+ *   in gabo_spd_ai_backward.  The gradient with respect to x2 is the same call with the sets exchanged, the row/column strides
+ *   swapped and eps_sign = -1 (the reference's +1e-15 is added to x1 - x2, so it changes sign with the roles); eps_sign = +1
+ *   otherwise. */
+int gabo_spd_logm_mandel_backward(const double* x_mandel, const double* grad_y, double* grad_x, int64_t n, int d,
+                                  gabo_stream_t stream);
+int gabo_frobenius_backward(const double* x1, const double* x2, const double* grad_out, double* grad_x1, int64_t batch, int64_t n1,
+                            int64_t n2, int d, int64_t x1_batch_stride, int64_t x2_batch_stride, int64_t go_batch_stride,
+                            int64_t go_row_stride, int64_t go_col_stride, double beta, int flags, double eps_sign,
+                            gabo_stream_t stream);
 
 /* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
  *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)

@@ -261,3 +261,40 @@ def min_eigenvalue_constraint(x, minimum_eigenvalue):
     lam, v = np.linalg.eigh(np.asarray(x, dtype=np.float64), UPLO="U")
     vm = v[..., :, 0]
     return lam[..., 0] - minimum_eigenvalue, vm[..., :, None] * vm[..., None, :]
+
+
+# ------------------------------------------------------------------------- log-Euclidean kernel and its gradients
+def dlogm_adjoint(a, g):
+    """Adjoint of the Frechet derivative of the matrix logarithm at SPD `a`, applied to symmetric `g` (Daleckii-Krein):
+    V ((V^T G V) o F) V^T with F_kl = (log l_k - log l_l)/(l_k - l_l), F_kk = 1/l_k.  This is what autograd through
+    logm_torch (spd_utils_torch.py:13-30) computes, without the 1/(l_k - l_l) blow-up for (nearly) repeated eigenvalues."""
+    lam, v = np.linalg.eigh(np.asarray(a, dtype=np.float64), UPLO="U")
+    lg = np.log(lam)
+    dl = lam[..., :, None] - lam[..., None, :]
+    dlg = lg[..., :, None] - lg[..., None, :]
+    mean = 0.5 * (lam[..., :, None] + lam[..., None, :])
+    close = np.abs(dl) <= 1e-9 * mean
+    f = np.where(close, 1.0 / mean, dlg / np.where(close, 1.0, dl))
+    inner = np.swapaxes(v, -1, -2) @ np.asarray(g, dtype=np.float64) @ v
+    return v @ (inner * f) @ np.swapaxes(v, -1, -2)
+
+
+def log_euclidean_gaussian_kernel(x1_mandel, x2_mandel, lengthscale):
+    """exp(-||logm X1_i - logm X2_j + 1e-15||_F^2 / lengthscale^2)   (kernels_spd.py:267-313)."""
+    d = log_euclidean_distance(vector_to_symmetric_matrix_mandel(x1_mandel), vector_to_symmetric_matrix_mandel(x2_mandel))
+    return np.exp(-(d * d) / (lengthscale * lengthscale))
+
+
+def log_euclidean_gaussian_kernel_grads(x1_mandel, x2_mandel, lengthscale, grad_k):
+    """d/dx1, d/dx2 (Mandel) of sum(grad_k * K_logEuclid)."""
+    a = vector_to_symmetric_matrix_mandel(x1_mandel)
+    b = vector_to_symmetric_matrix_mandel(x2_mandel)
+    la, lb = logm(a), logm(b)
+    diff = la[..., :, None, :, :] - lb[..., None, :, :, :] + 1e-15
+    d2 = np.sum(diff * diff, axis=(-2, -1))
+    k = np.exp(-d2 / lengthscale ** 2)
+    w = np.asarray(grad_k) * k * (-2.0 / lengthscale ** 2)
+    ga_log = np.einsum("...ij,...ijab->...iab", w, diff)
+    gb_log = -np.einsum("...ij,...ijab->...jab", w, diff)
+    return (symmetric_matrix_to_vector_mandel(dlogm_adjoint(a, _sym(ga_log))),
+            symmetric_matrix_to_vector_mandel(dlogm_adjoint(b, _sym(gb_log))))

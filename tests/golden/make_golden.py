@@ -246,6 +246,21 @@ def gen_nested():
     W5 = W5[:, :2]
     out["X5"], out["W5"] = X5, W5
     out["Y5"] = nsu.projection_from_spd_to_nested_spd(torch.tensor(X5), torch.tensor(W5)).numpy()
+    # log-Euclidean Gaussian kernel (op sequence of kernels_spd.py:289-311) with autograd gradients w.r.t. both Mandel inputs
+    for dd_, n1_, n2_ in ((2, 5, 4), (3, 4, 6)):
+        a_ = to_mandel_ref(rand_spd(rng, n1_, dd_, 0.3, 3.0))
+        b_ = to_mandel_ref(rand_spd(rng, n2_, dd_, 0.3, 3.0))
+        ta, tb = torch.tensor(a_, requires_grad=True), torch.tensor(b_, requires_grad=True)
+        ma, mb = sut.vector_to_symmetric_matrix_mandel_torch(ta), sut.vector_to_symmetric_matrix_mandel_torch(tb)
+        la = torch.stack([sut.logm_torch(m) for m in ma])
+        lb = torch.stack([sut.logm_torch(m) for m in mb])
+        dist_ = sut.frobenius_distance_torch(la, lb)
+        ls_ = 0.9
+        k_ = torch.exp(-(dist_ * dist_) / (ls_ * ls_))
+        gup_ = rng.standard_normal((n1_, n2_))
+        (k_ * torch.tensor(gup_)).sum().backward()
+        out[f"le{dd_}_x1"], out[f"le{dd_}_x2"], out[f"le{dd_}_gup"], out[f"le{dd_}_ls"] = a_, b_, gup_, np.float64(ls_)
+        out[f"le{dd_}_K"], out[f"le{dd_}_g1"], out[f"le{dd_}_g2"] = k_.detach().numpy(), ta.grad.numpy(), tb.grad.numpy()
     # approximate right inverse of the projection (nested_spd_utils.py:51-118)
     Vc = np.linalg.qr(rng.standard_normal((5, 5)))[0]
     W5b, V5b = Vc[:, :2], Vc[:, 2:]

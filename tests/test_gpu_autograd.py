@@ -170,3 +170,117 @@ def test_sphere_second_order_matches_plain_torch_autograd():
     np.testing.assert_allclose(out.detach().cpu().numpy(), osph.sphere_laplace_kernel(x, y, 1 / kl.lengthscale.double().item() ** 2), rtol=1e-11)   # lengthscale is an fp32 parameter
     out.sum().backward()
     assert kl.raw_lengthscale.grad is not None and np.isfinite(kl.raw_lengthscale.grad.item())
+
+
+# ------------------------------------------------------------------ Frobenius / log-Euclidean / nested kernels: input gradients
+def test_log_euclidean_kernel_grads_golden(golden):
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdLogEuclideanGaussianKernel
+    g = golden("nested_spd.npz")
+    for d in (2, 3):
+        x1, x2, ls = t(g[f"le{d}_x1"], True), t(g[f"le{d}_x2"], True), float(g[f"le{d}_ls"])
+        kern = SpdLogEuclideanGaussianKernel().double()      # gpytorch's raw_lengthscale is fp32 by default
+        kern.lengthscale = ls
+        k = kern.forward(x1, x2)
+        np.testing.assert_allclose(k.detach().cpu().numpy(), g[f"le{d}_K"], rtol=1e-10)
+        (k * t(g[f"le{d}_gup"])).sum().backward()
+        # reference = torch autograd through eig-based logm (spd_utils_torch.py:13-30) in fp64
+        np.testing.assert_allclose(x1.grad.cpu().numpy(), g[f"le{d}_g1"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(x2.grad.cpu().numpy(), g[f"le{d}_g2"], rtol=1e-8, atol=1e-10)
+        # lengthscale gradient against a central difference of the oracle kernel
+        gl = kern.raw_lengthscale.grad
+        assert gl is not None and torch.isfinite(gl).all()
+
+
+@pytest.mark.parametrize("d", [2, 5, 10, 16, 32])
+def test_log_euclidean_grads_vs_oracle(d):
+    rng = np.random.default_rng(100 + d)
+    n1, n2 = 37, 300            # n2 > 256: more than one column chunk in the backward kernel
+    x1, x2 = rand_spd_mandel(rng, n1, d), rand_spd_mandel(rng, n2, d)
+    x2[:3] = x1[:3]             # coincident points: zero distance, finite gradient
+    ls = 1.7
+    gup = rng.standard_normal((n1, n2))
+    a, b = t(x1, True), t(x2, True)
+    beta = torch.tensor(1.0 / ls ** 2, dtype=torch.float64, requires_grad=True)
+    k = ops.frobenius_kernel(ops.spd_logm_mandel_diff(a), ops.spd_logm_mandel_diff(b), beta)
+    np.testing.assert_allclose(k.detach().cpu().numpy(), ospd.log_euclidean_gaussian_kernel(x1, x2, ls), rtol=1e-9, atol=1e-14)
+    (k * t(gup)).sum().backward()
+    o1, o2 = ospd.log_euclidean_gaussian_kernel_grads(x1, x2, ls, gup)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), o1, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(o1).max()))
+    np.testing.assert_allclose(b.grad.cpu().numpy(), o2, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(o2).max()))
+    # d/dbeta by central difference on the oracle
+    h = 1e-6
+    kp = ospd.log_euclidean_gaussian_kernel(x1, x2, (1.0 / ls ** 2 + h) ** -0.5)
+    km = ospd.log_euclidean_gaussian_kernel(x1, x2, (1.0 / ls ** 2 - h) ** -0.5)
+    np.testing.assert_allclose(float(beta.grad), float((gup * (kp - km)).sum() / (2 * h)), rtol=1e-6)
+
+
+def test_logm_adjoint_repeated_eigenvalues():
+    # X = c I has all eigenvalues equal: autograd through eig() gives inf/nan there, the divided-difference form gives G / c
+    d, c = 4, 2.5
+    x = t(ospd.symmetric_matrix_to_vector_mandel(c * np.eye(d))[None], True)
+    gy = np.random.default_rng(3).standard_normal((1, d * (d + 1) // 2))
+    (ops.spd_logm_mandel_diff(x) * t(gy)).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gy / c, rtol=1e-12)
+
+
+def test_frobenius_kernel_modes_by_finite_differences():
+    rng = np.random.default_rng(8)
+    d, n1, n2 = 3, 5, 7
+    x1, x2 = rand_spd_mandel(rng, n1, d), rand_spd_mandel(rng, n2, d)
+    gup = rng.standard_normal((n1, n2))
+    for mode in (_lib.GABO_OUT_GAUSSIAN, _lib.GABO_OUT_LAPLACE, _lib.GABO_OUT_DISTANCE):
+        a, b = t(x1, True), t(x2, True)
+        (ops.frobenius_kernel(a, b, 0.3, mode) * t(gup)).sum().backward()
+        f = lambda p, q: float((ops.frobenius_pairwise(t(p), t(q), 0.3, mode).cpu().numpy() * gup).sum())   # noqa: E731
+        for arr, grad, which in ((x1, a.grad, 0), (x2, b.grad, 1)):
+            num = np.zeros_like(arr)
+            for idx in np.ndindex(arr.shape):
+                hp, hm = arr.copy(), arr.copy()
+                hp[idx] += 1e-6
+                hm[idx] -= 1e-6
+                num[idx] = (f(hp, x2) - f(hm, x2)) / 2e-6 if which == 0 else (f(x1, hp) - f(x1, hm)) / 2e-6
+            np.testing.assert_allclose(grad.cpu().numpy(), num, rtol=2e-6, atol=1e-8)
+
+
+def test_nested_kernels_differentiable_in_inputs_and_projection():
+    from gabotorch_amd.kernel_utils.kernels_spd import NestedSpdLogEuclideanGaussianKernel, NestedSpdAffineInvariantGaussianKernel
+    rng = np.random.default_rng(21)
+    D, dl, n1, n2 = 6, 3, 9, 11
+    x1, x2 = rand_spd_mandel(rng, n1, D), rand_spd_mandel(rng, n2, D)
+    w = np.linalg.qr(rng.standard_normal((D, dl)))[0]
+    gup = rng.standard_normal((n1, n2))
+
+    def oracle_value(p, q, ww, ai):
+        P = np.einsum("da,ndc,cb->nab", ww, ospd.vector_to_symmetric_matrix_mandel(p), ww)
+        Q = np.einsum("da,ndc,cb->nab", ww, ospd.vector_to_symmetric_matrix_mandel(q), ww)
+        pm, qm = ospd.symmetric_matrix_to_vector_mandel(P), ospd.symmetric_matrix_to_vector_mandel(Q)
+        k = ospd.spd_ai_gaussian_kernel(pm, qm, 0.8) if ai else ospd.log_euclidean_gaussian_kernel(pm, qm, 1.3)
+        return float((k * gup).sum())
+
+    for ai in (False, True):
+        if ai:
+            kern = NestedSpdAffineInvariantGaussianKernel(D, dl, beta_min=0.1).double()
+            kern.beta = 0.8
+        else:
+            kern = NestedSpdLogEuclideanGaussianKernel(D, dl).double()
+            kern.lengthscale = 1.3
+        kern.projection_matrix = torch.tensor(w)
+        a, b = t(x1, True), t(x2, True)
+        (kern.forward(a, b) * t(gup)).sum().backward()
+        gw = kern.raw_projection_matrix.grad.cpu().numpy()
+        h = 1e-6
+        num_w = np.zeros_like(w)
+        for idx in np.ndindex(w.shape):
+            wp, wm = w.copy(), w.copy()
+            wp[idx] += h
+            wm[idx] -= h
+            num_w[idx] = (oracle_value(x1, x2, wp, ai) - oracle_value(x1, x2, wm, ai)) / (2 * h)
+        np.testing.assert_allclose(gw, num_w, rtol=1e-5, atol=1e-7)
+        num_a = np.zeros_like(x1)
+        for idx in np.ndindex(x1.shape):
+            hp, hm = x1.copy(), x1.copy()
+            hp[idx] += h
+            hm[idx] -= h
+            num_a[idx] = (oracle_value(hp, x2, w, ai) - oracle_value(hm, x2, w, ai)) / (2 * h)
+        np.testing.assert_allclose(a.grad.cpu().numpy(), num_a, rtol=1e-5, atol=1e-7)
+        assert torch.isfinite(b.grad).all()

@@ -126,3 +126,13 @@ def test_letters_fixture(golden):
     np.testing.assert_allclose(k, g["K"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(k, k.T, rtol=1e-12)
     np.testing.assert_allclose(np.diagonal(k), 1.0, atol=1e-12)
+
+
+def test_log_euclidean_kernel_and_gradients(golden):
+    g = golden("nested_spd.npz")
+    for d in (2, 3):
+        x1, x2, ls = g[f"le{d}_x1"], g[f"le{d}_x2"], float(g[f"le{d}_ls"])
+        np.testing.assert_allclose(ospd.log_euclidean_gaussian_kernel(x1, x2, ls), g[f"le{d}_K"], rtol=1e-10)
+        g1, g2 = ospd.log_euclidean_gaussian_kernel_grads(x1, x2, ls, g[f"le{d}_gup"])
+        np.testing.assert_allclose(g1, g[f"le{d}_g1"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(g2, g[f"le{d}_g2"], rtol=1e-8, atol=1e-10)
