@@ -15,6 +15,7 @@ GABO_SPD_REG_MAX_DIM = 12
 GABO_SPD_MAX_DIM = 32
 (GABO_SPD_EXP, GABO_SPD_LOG, GABO_SPD_INNER, GABO_SPD_NORM, GABO_SPD_DIST, GABO_SPD_EGRAD2RGRAD, GABO_SPD_EHESS2RHESS,
  GABO_SPD_LOGM, GABO_SPD_EXPM, GABO_SPD_SQRTM, GABO_SPD_EIGMAX, GABO_SPD_EIGMIN) = range(12)
+GABO_ACQ_EXPECTED_IMPROVEMENT, GABO_ACQ_POSTERIOR_MEAN = 0, 1
 GABO_SPH_PROJ, GABO_SPH_RETR, GABO_SPH_EXP, GABO_SPH_LOG, GABO_SPH_DIST, GABO_SPH_EHESS2RHESS = range(6)
 
 _ERR = {GABO_ERR_DIM: "unsupported dimension", GABO_ERR_ARG: "bad argument", GABO_ERR_NOT_SPD: "input is not SPD",
@@ -35,6 +36,7 @@ SIGNATURES = {
     "gabo_spd_project": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "gabo_spd_logm_mandel": (_I, [_P, _P, _I64, _I, _P]),
     "gabo_frobenius_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _P]),
+    "gabo_gp_acquisition": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _D, _D, _D, _D, _I, _I, _D, _P]),
     "gabo_spd_logm_mandel_backward": (_I, [_P, _P, _P, _I64, _I, _P]),
     "gabo_frobenius_backward": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _D, _I, _D, _P]),
     "gabo_sphere_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _I64, _I, _P]),

@@ -29,9 +29,12 @@ class BatchedProblem:
     is the stack of per-restart gradients).  Mirrors pymanopt_addons/problem.py:14-159 + the PytorchBackend contract
     (tools/autodiff/_pytorch.py:83-116); `approx_hessian=True` is get_hessianfd (approximate_hessian.py:11-62)."""
 
-    def __init__(self, manifold, cost_fn, approx_hessian=False, precon=None, use_hip_graphs=False):
+    def __init__(self, manifold, cost_fn, approx_hessian=False, precon=None, use_hip_graphs=False, fused=None):
         self.manifold = manifold
         self.cost_fn = cost_fn
+        # optional fused_acquisition.FusedAcquisition: value and first derivative as a fixed chain of HIP launches (no autograd);
+        # cost_fn stays the definition and serves whatever the fused chain does not (exact Hessian-vector products)
+        self.fused = fused
         self.approx_hessian = approx_hessian
         self.precon = precon or (lambda x, d: d)
         self.n_cost = 0
@@ -64,6 +67,9 @@ class BatchedProblem:
         return tuple(o.clone() for o in outs)
 
     def _eval(self, kind, x):
+        if self.fused is not None:
+            with torch.no_grad():
+                return (self.fused.cost(x),) if kind == "cost" else self.fused.cost_egrad(x)
         if kind == "cost":
             with torch.no_grad():
                 return (self.cost_fn(x).detach(),)
@@ -77,13 +83,15 @@ class BatchedProblem:
         self.n_cost += 1
         if self.use_hip_graphs and x.is_cuda and not getattr(self, "_capturing", False):
             return self._graphed("cost", x)[0]
-        with torch.no_grad():
-            return self.cost_fn(x).detach()
+        return self._eval("cost", x)[0]
 
     def cost_egrad(self, x, create_graph=False):
         self.n_grad += 1
         if self.use_hip_graphs and x.is_cuda and not create_graph and not getattr(self, "_capturing", False):
             f, g = self._graphed("grad", x)
+            return f, g, None
+        if self.fused is not None and not create_graph:
+            f, g = self._eval("grad", x)
             return f, g, None
         xx = x.detach().clone().requires_grad_(True)
         with torch.enable_grad():

@@ -16,6 +16,7 @@ import torch
 
 from ..models import (BadInitialCandidatesWarning, get_best_candidates, initialize_q_batch, initialize_q_batch_nonneg,
                       is_nonnegative)
+from ..fused_acquisition import FusedAcquisition
 from .batched_trust_regions import BatchedProblem, BatchedTrustRegions
 
 
@@ -123,8 +124,12 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
     if not isinstance(solver, BatchedTrustRegions):
         raise TypeError("gabotorch_amd drives the restarts in lock step: pass a gabotorch_amd BatchedTrustRegions solver "
                         "(its constructor takes the keyword arguments of the reference's TrustRegions / ConstrainedTrustRegions)")
+    fused = None
+    if (options or {}).get("fused_acquisition", True) and x0.is_cuda:
+        # built-in surrogate + kernel + Mandel post-processing: value and gradient as a fixed chain of HIP launches
+        fused = FusedAcquisition.build(acquisition_function, post_processing_manifold, x0.device)
     problem = BatchedProblem(manifold, cost, approx_hessian=approx_hessian, precon=precon,
-                             use_hip_graphs=bool((options or {}).get("hip_graphs", False)))
+                             use_hip_graphs=bool((options or {}).get("hip_graphs", False)), fused=fused)
     if solver_init_conds:
         x0 = torch.stack([torch.as_tensor(manifold.rand()) for _ in range(x0.shape[0])]).to(x0)
     if equality_constraints is not None or inequality_constraints is not None:

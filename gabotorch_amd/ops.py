@@ -538,6 +538,23 @@ def frobenius_kernel(x1, x2, beta, mode=_lib.GABO_OUT_GAUSSIAN):
     return _FrobeniusKernelFunction.apply(x1, x2, beta, int(mode))
 
 
+def gp_acquisition(kstar, alpha, linv, linv_t, mean, outputscale, kxx, best_f, kind, maximize, out_sign=1.0, need_grad=True):
+    """Fused GP posterior + acquisition on the strip kstar (R x n, base kernel values): -> (value R, d value / d kstar R x n or None).
+    All tensors fp64 on one HIP device."""
+    lib = _lib.load()
+    dev = kstar.device
+    ks = kstar.contiguous()
+    r, n = ks.shape
+    value = torch.empty(r, dtype=torch.float64, device=dev)
+    grad = torch.empty_like(ks) if need_grad else None
+    ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_gp_acquisition(ks.data_ptr(), alpha.data_ptr(), ptr(linv), ptr(linv_t), value.data_ptr(), ptr(grad), r, n,
+                                           float(mean), float(outputscale), float(kxx), float(best_f), int(kind), 1 if maximize else 0,
+                                           float(out_sign), _stream_ptr(dev)), "gabo_gp_acquisition")
+    return value, grad
+
+
 def sphere_manifold_op(op, x, u, v=None, w=None):
     """Batched sphere-manifold operation (one of _lib.GABO_SPH_*) on (..., dim) tensors."""
     lib = _lib.load()

@@ -162,6 +162,22 @@ int gabo_frobenius_backward(const double* x1, const double* x2, const double* gr
                             int64_t go_row_stride, int64_t go_col_stride, double beta, int flags, double eps_sign,
                             gabo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused exact-GP posterior + analytic acquisition on a cross-covariance strip: the consumer of the kernel strip
+ * K(X*, X_train) inside the acquisition maximiser (manifold_optimize.py:182-184; botorch ExpectedImprovement / PosteriorMean
+ * over a gpytorch ExactGP, [3P] semantics in SURVEY App. B).  One launch replaces the posterior algebra and its autograd.
+ *   kstar: r x n BASE kernel values k(x*_r, x_train_j) (before the outputscale); alpha = (K + noise I)^-1 (y - mean), n;
+ *   linv = L^-1 and linv_t = L^-T (both n x n row-major, L = chol(K + noise I)); kxx = base kernel k(x*, x*).
+ *   value[r]      = out_sign * acquisition(x*_r)
+ *   grad_kstar    = NULL or r x n: out_sign * d acquisition / d kstar   (chain it into gabo_spd_ai_backward / the sphere backward)
+ *   kind GABO_ACQ_EXPECTED_IMPROVEMENT: sigma = sqrt(max(var, 1e-9)), u = +-(mean - best_f)/sigma, EI = sigma (phi(u) + u Phi(u))
+ *        GABO_ACQ_POSTERIOR_MEAN:       +-mean          (maximize != 0 selects '+'). */
+#define GABO_ACQ_EXPECTED_IMPROVEMENT 0
+#define GABO_ACQ_POSTERIOR_MEAN 1
+int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* linv, const double* linv_t, double* value,
+                        double* grad_kstar, int64_t r, int64_t n, double mean, double outputscale, double kxx, double best_f,
+                        int kind, int maximize, double out_sign, gabo_stream_t stream);
+
 /* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
  *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)
  *   GABO_SPH_RETR   out = (X+U)/|X+U|        [3P] Sphere.retr  (robust_trust_regions.py:228)

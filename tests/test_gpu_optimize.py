@@ -168,3 +168,86 @@ def test_hip_graph_evaluations_match_eager():
     np.testing.assert_allclose(best_g.cpu().numpy(), best_e.cpu().numpy(), rtol=0, atol=1e-9)
     np.testing.assert_allclose(val_g, val_e, rtol=1e-10)
     assert int(log_g["iterations"]) == int(log_e["iterations"])          # same trust-region trajectory
+
+
+# ------------------------------------------------------------------------------------------- fused acquisition chain
+def _spd_gp(d=4, n_train=23, seed=5):
+    rng = np.random.default_rng(seed)
+    q = np.linalg.qr(rng.standard_normal((n_train, d, d)))[0]
+    Xm = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (n_train, d)), q)
+    X = ospd.symmetric_matrix_to_vector_mandel(0.5 * (Xm + Xm.transpose(0, 2, 1)))
+    y = np.log(np.linalg.eigvalsh(Xm)).sum(1) ** 2 + 0.1 * rng.standard_normal(n_train)
+    return rng, X, y
+
+
+@pytest.mark.parametrize("which", ["ei_min", "ei_max", "mean_min", "laplace_ei_min"])
+def test_fused_spd_acquisition_matches_autograd(which):
+    from gabotorch_amd.fused_acquisition import FusedAcquisition
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantLaplaceKernel
+    d = 4
+    rng, X, y = _spd_gp(d)
+    kern = (SpdAffineInvariantLaplaceKernel if which.startswith("laplace") else SpdAffineInvariantGaussianKernel)(beta_min=0.4)
+    gp = models.ExactGP(t(X), t(y), kern, outputscale=1.7, noise=1e-2)
+    if "ei" in which:
+        acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=which.endswith("max"))
+    else:
+        acq = models.PosteriorMean(gp, maximize=False)
+    post = symmetric_matrix_to_vector_mandel_torch
+    fused = FusedAcquisition.build(acq, post, torch.device(DEV))
+    assert fused is not None
+    R = 70
+    q = np.linalg.qr(rng.standard_normal((R, d, d)))[0]
+    P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (R, d)), q)
+    if not which.startswith("laplace"):      # (exp(-beta d) has a kink at d = 0: no gradient to compare there)
+        P[:5] = ospd.vector_to_symmetric_matrix_mandel(X[:5])      # candidates ON training points (variance clamp region)
+    x = t(0.5 * (P + P.transpose(0, 2, 1)))
+    xx = x.clone().requires_grad_(True)
+    f_ref = -acq(post(xx)[:, None])
+    (g_ref,) = torch.autograd.grad(f_ref.sum(), xx)
+    f, g = fused.cost_egrad(x)
+    scale = max(1.0, float(g_ref.abs().max()))
+    np.testing.assert_allclose(f.cpu().numpy(), f_ref.detach().cpu().numpy(), rtol=1e-10, atol=1e-14)
+    # autograd also differentiates k(x, x), which is constant: for exp(-beta d) that adds rounding noise of logm(I) amplified by
+    # 1/d(x, x) = 3e7 (~5e-9 absolute); the fused chain treats k(x, x) as the constant it is
+    atol = 1e-7 if which.startswith("laplace") else 1e-11
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-8, atol=atol * scale)
+    np.testing.assert_allclose(fused.cost(x).cpu().numpy(), f.cpu().numpy(), rtol=0, atol=0)
+
+
+def test_fused_sphere_acquisition_matches_autograd():
+    from gabotorch_amd.fused_acquisition import FusedAcquisition
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((150, 5)); X /= np.linalg.norm(X, axis=1, keepdims=True)       # n_train > 128: 256-thread blocks
+    y = np.arccos(np.clip(X[:, 0], -1, 1)) ** 2 + 0.05 * rng.standard_normal(150)
+    gp = models.ExactGP(t(X), t(y), SphereGaussianKernel(beta_min=1.2), outputscale=0.8, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    fused = FusedAcquisition.build(acq, None, torch.device(DEV))
+    assert fused is not None
+    P = rng.standard_normal((40, 5)); P /= np.linalg.norm(P, axis=1, keepdims=True)
+    x = t(P)
+    xx = x.clone().requires_grad_(True)
+    f_ref = -acq(xx[:, None])
+    (g_ref,) = torch.autograd.grad(f_ref.sum(), xx)
+    f, g = fused.cost_egrad(x)
+    np.testing.assert_allclose(f.cpu().numpy(), f_ref.detach().cpu().numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-8, atol=1e-11 * max(1.0, float(g_ref.abs().max())))
+
+
+def test_fused_path_declines_what_it_does_not_know():
+    from gabotorch_amd.fused_acquisition import FusedAcquisition
+    _, X, y = _spd_gp()
+    gp = models.ExactGP(t(X), t(y), SpdAffineInvariantGaussianKernel(beta_min=0.4), outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=0.0, maximize=False)
+    assert FusedAcquisition.build(acq, lambda m: symmetric_matrix_to_vector_mandel_torch(m), torch.device(DEV)) is None   # user callable
+    assert FusedAcquisition.build(lambda X_: X_.sum((-1, -2)), symmetric_matrix_to_vector_mandel_torch, torch.device(DEV)) is None
+
+
+def test_sweep_with_fused_chain_matches_autograd_sweep():
+    from tools.sweep_bench import run_sweep
+    _, best_a, val_a, log_a = run_sweep(DEV, num_restarts=32, raw_samples=256, fused=False)
+    _, best_f, val_f, log_f = run_sweep(DEV, num_restarts=32, raw_samples=256, fused=True)
+    _, best_g, val_g, log_g = run_sweep(DEV, num_restarts=32, raw_samples=256, fused=True, hip_graphs=True)
+    np.testing.assert_allclose(best_f.cpu().numpy(), best_a.cpu().numpy(), rtol=0, atol=1e-8)
+    np.testing.assert_allclose(val_f, val_a, rtol=1e-9)
+    np.testing.assert_allclose(val_g, val_a, rtol=1e-9)
+    assert int(log_f["iterations"]) == int(log_a["iterations"]) == int(log_g["iterations"])
