@@ -71,6 +71,14 @@ class FusedAcquisition:
         c = pts @ self.train.t()
         return pts, ops.sphere_from_inner(c, self.beta, self.mode, 0), c
 
+    def egrad_mandel(self, pts):
+        """Euclidean gradient of the cost at SPD points given (and returned) as Mandel vectors: the chain without the two
+        Mandel maps, used by the fused trust-region inner loop."""
+        ks = ops.spd_ai_pairwise(pts, self.train, self.beta, self.mode)
+        _, gk = ops.gp_acquisition(ks, self.alpha, self.linv, self.linv_t, self.mean, self.outputscale, self.kxx, self.best_f,
+                                   self.kind, self.maximize, out_sign=-1.0, need_grad=True)
+        return ops.spd_ai_backward(pts, self.train, gk, self.beta, self.mode, wrt=1)
+
     def cost(self, x):
         _, ks, _ = self._strip(x.detach())
         val, _ = ops.gp_acquisition(ks, self.alpha, self.linv, self.linv_t, self.mean, self.outputscale, self.kxx, self.best_f,

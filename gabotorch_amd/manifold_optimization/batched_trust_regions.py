@@ -238,6 +238,15 @@ class BatchedTrustRegions:
         return x
 
     # ------------------------------------------------------------------------------------------------- truncated CG
+    @staticmethod
+    def _device_tcg_applies(problem, x, ncons):
+        """SPD manifold + fused acquisition chain + FD Hessian + the reference preconditioner: the whole tCG runs in HIP kernels."""
+        from ..manifolds import PositiveDefinite
+        fused = getattr(problem, "fused", None)
+        return (fused is not None and fused.family == "spd" and fused.matrix_input and problem.approx_hessian and x.is_cuda
+                and isinstance(problem.manifold, PositiveDefinite) and getattr(problem, "reference_precon", False)
+                and getattr(problem, "device_tcg", True) and ncons <= 8 and x.shape[-1] <= 32 and x.dtype == torch.float64)
+
     class _TcgState:
         """All tCG quantities of the R restarts as persistent tensors updated IN PLACE, so that one iteration is a fixed sequence
         of launches on fixed buffers - which is what lets it be captured in a hipGraph and replayed."""
@@ -370,8 +379,52 @@ class BatchedTrustRegions:
         S.running.copy_(running)
         S.any_running.copy_(running.any())
 
+    def _tcg_device(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons):
+        """The tCG loop on the device-resident state machine (csrc/spd_tcg.hip): per inner iteration one FD-point launch, the
+        fused acquisition-gradient chain and one step launch; with hipGraphs the three are one replay."""
+        from .. import ops
+        ncons = 0 if fc is None else fc.shape[1]
+        R, d = x.shape[0], x.shape[-1]
+        key = ("dev", R, d, ncons, x.device)
+        cache = problem.__dict__.setdefault("_tcg_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            ent = {"T": ops.SpdTcg(R, d, ncons, x.device), "graph": None}
+            cache[key] = ent
+        T = ent["T"]
+        fused = problem.fused
+        args = (neq, Delta_cons, self.theta, self.kappa, mininner)
+
+        def one_step():
+            T.step(fused.egrad_mandel(T.fd_point()), *args)
+
+        T.begin(x, g, torch.stack(gc) if ncons else None, fc, active, Delta)
+        graphs = bool(getattr(problem, "use_hip_graphs", False))
+        if graphs and ent["graph"] is None:
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                one_step()                                          # warm-up outside capture
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                one_step()
+            ent["graph"] = graph
+            T.begin(x, g, torch.stack(gc) if ncons else None, fc, active, Delta)      # the warm-up and capture advanced the state
+        for _ in range(int(maxinner)):
+            if graphs:
+                ent["graph"].replay()
+            else:
+                one_step()
+            problem.n_grad += 1
+            if not bool(T.any_running.item()):
+                break
+        return T.end()
+
     def _tcg(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons):
         ncons = 0 if fc is None else fc.shape[1]
+        if self._device_tcg_applies(problem, x, ncons):
+            return self._tcg_device(problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons)
         graphs = bool(getattr(problem, "use_hip_graphs", False)) and x.is_cuda
         key = (tuple(x.shape), x.device, ncons, neq, float(Delta_cons), int(mininner))
         cache = problem.__dict__.setdefault("_tcg_cache", {})

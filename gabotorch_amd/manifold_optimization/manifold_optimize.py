@@ -130,6 +130,8 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
         fused = FusedAcquisition.build(acquisition_function, post_processing_manifold, x0.device)
     problem = BatchedProblem(manifold, cost, approx_hessian=approx_hessian, precon=precon,
                              use_hip_graphs=bool((options or {}).get("hip_graphs", False)), fused=fused)
+    problem.reference_precon = True          # `precon` above is the one csrc/spd_tcg.hip implements
+    problem.device_tcg = bool((options or {}).get("device_tcg", True))
     if solver_init_conds:
         x0 = torch.stack([torch.as_tensor(manifold.rand()) for _ in range(x0.shape[0])]).to(x0)
     if equality_constraints is not None or inequality_constraints is not None:

@@ -555,6 +555,51 @@ def gp_acquisition(kstar, alpha, linv, linv_t, mean, outputscale, kxx, best_f, k
     return value, grad
 
 
+class SpdTcg:
+    """Device-resident truncated CG of the SPD trust regions (gabo_spd_tcg_*): thin handle around the workspace."""
+
+    def __init__(self, r, d, n_constraints, device):
+        self.lib = _lib.load()
+        self.r, self.d, self.c, self.dev = int(r), int(d), int(n_constraints), device
+        self.wsb = self.lib.gabo_spd_tcg_workspace_bytes(self.r, self.d, self.c)
+        self.ws = torch.zeros(self.wsb // 8 + 1, dtype=torch.float64, device=device)
+        self.x_fd = torch.empty(self.r, d * (d + 1) // 2, dtype=torch.float64, device=device)
+        self.any_running = torch.zeros(1, dtype=torch.int32, device=device)
+        self.status = torch.zeros(2, dtype=torch.int32, device=device)
+
+    def begin(self, x, g, gc, fc, active, Delta):
+        ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+        self._keep = (x.contiguous(), g.contiguous(), None if gc is None else gc.contiguous(), None if fc is None else fc.contiguous(),
+                      active.to(torch.uint8).contiguous(), Delta.contiguous())
+        xx, gg, gcc, fcc, act, dl = self._keep
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_spd_tcg_begin(xx.data_ptr(), gg.data_ptr(), ptr(gcc), ptr(fcc), act.data_ptr(), dl.data_ptr(),
+                                                   self.ws.data_ptr(), self.wsb, self.r, self.d, self.c, self.status.data_ptr(),
+                                                   _stream_ptr(self.dev)), "gabo_spd_tcg_begin")
+
+    def fd_point(self):
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_spd_tcg_fd_point(self.ws.data_ptr(), self.x_fd.data_ptr(), self.r, self.d, self.c,
+                                                      _stream_ptr(self.dev)), "gabo_spd_tcg_fd_point")
+        return self.x_fd
+
+    def step(self, egrad_mandel, neq, delta_cons, theta, kappa, mininner):
+        eg = egrad_mandel.contiguous()
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_spd_tcg_step(self.ws.data_ptr(), eg.data_ptr(), self.any_running.data_ptr(), self.r, self.d,
+                                                  self.c, int(neq), float(delta_cons), float(theta), float(kappa), int(mininner),
+                                                  _stream_ptr(self.dev)), "gabo_spd_tcg_step")
+
+    def end(self):
+        eta = torch.empty(self.r, self.d, self.d, dtype=torch.float64, device=self.dev)
+        heta = torch.empty_like(eta)
+        stop = torch.empty(self.r, dtype=torch.int32, device=self.dev)
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_spd_tcg_end(self.ws.data_ptr(), eta.data_ptr(), heta.data_ptr(), stop.data_ptr(), self.r,
+                                                 self.d, self.c, _stream_ptr(self.dev)), "gabo_spd_tcg_end")
+        return eta, heta, stop.long()
+
+
 def sphere_manifold_op(op, x, u, v=None, w=None):
     """Batched sphere-manifold operation (one of _lib.GABO_SPH_*) on (..., dim) tensors."""
     lib = _lib.load()

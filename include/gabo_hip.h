@@ -178,6 +178,32 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
                         double* grad_kstar, int64_t r, int64_t n, double mean, double outputscale, double kxx, double best_f,
                         int kind, int maximize, double out_sign, gabo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Truncated conjugate gradients of the Riemannian trust-region solvers on S^d_++, R restarts in lock step (one wave each).
+ * Replaces the per-restart numpy loops of  TrustRegions._truncated_conjugate_gradient   robust_trust_regions.py:417-570
+ *                                          ConstrainedTrustRegions (linearised constraints) constrained_trust_regions.py:530-732
+ *                                          get_hessianfd                                    approximate_hessian.py:11-62
+ * with the preconditioner of manifold_optimize.py:190-193.  One inner iteration = gabo_spd_tcg_fd_point, the caller's
+ * acquisition gradient at the finite-difference points (Euclidean, Mandel), gabo_spd_tcg_step.
+ *   begin:    x, grad (Riemannian gradient at x): r x d x d; cons_grads: n_constraints x r x d x d Riemannian gradients of the
+ *             constraints (equalities first), cons_values: r x n_constraints; active: r bytes (0 = restart already converged);
+ *             trust_radius: r.  Non-SPD x is reported through `status` like the other entry points.
+ *   fd_point: writes the points x1 = retr(x, 2^-14 delta / ||delta||_x) as Mandel vectors (r x d_vec).
+ *   step:     consumes the Euclidean gradient at those points (Mandel, r x d_vec) and advances every running restart;
+ *             *any_running (device int) = 1 while at least one restart continues.  `mininner`: no residual test before.
+ *   end:      eta, heta (r x d x d tangent vectors at x) and the stop reasons (0 negative curvature, 1 exceeded trust region,
+ *             2/3 reached target linear/superlinear, 4 max inner iterations, 5 model increased, 6 reached constraints).
+ * The state lives in `workspace` (gabo_spd_tcg_workspace_bytes); n_constraints <= 8. */
+size_t gabo_spd_tcg_workspace_bytes(int64_t r, int d, int n_constraints);
+int gabo_spd_tcg_begin(const double* x, const double* grad, const double* cons_grads, const double* cons_values,
+                       const uint8_t* active, const double* trust_radius, void* workspace, size_t workspace_bytes, int64_t r, int d,
+                       int n_constraints, int* status, gabo_stream_t stream);
+int gabo_spd_tcg_fd_point(void* workspace, double* x_fd_mandel, int64_t r, int d, int n_constraints, gabo_stream_t stream);
+int gabo_spd_tcg_step(void* workspace, const double* egrad_fd_mandel, int* any_running, int64_t r, int d, int n_constraints,
+                      int n_equalities, double delta_cons, double theta, double kappa, int mininner, gabo_stream_t stream);
+int gabo_spd_tcg_end(void* workspace, double* eta, double* heta, int* stop_reason, int64_t r, int d, int n_constraints,
+                     gabo_stream_t stream);
+
 /* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
  *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)
  *   GABO_SPH_RETR   out = (X+U)/|X+U|        [3P] Sphere.retr  (robust_trust_regions.py:228)

@@ -251,3 +251,18 @@ def test_sweep_with_fused_chain_matches_autograd_sweep():
     np.testing.assert_allclose(val_f, val_a, rtol=1e-9)
     np.testing.assert_allclose(val_g, val_a, rtol=1e-9)
     assert int(log_f["iterations"]) == int(log_a["iterations"]) == int(log_g["iterations"])
+
+
+def test_device_tcg_matches_torch_tcg():
+    """csrc/spd_tcg.hip (whitened-coordinate tCG, one wave per restart) against the torch lock-step tCG on the same constrained
+    sweep: same trust-region trajectory, same optimum."""
+    from tools.sweep_bench import run_sweep
+    _, best_t, val_t, log_t = run_sweep(DEV, num_restarts=48, raw_samples=256, device_tcg=False)
+    _, best_d, val_d, log_d = run_sweep(DEV, num_restarts=48, raw_samples=256, device_tcg=True)
+    _, best_g, val_g, log_g = run_sweep(DEV, num_restarts=48, raw_samples=256, device_tcg=True, hip_graphs=True)
+    np.testing.assert_allclose(val_d, val_t, rtol=1e-9)
+    np.testing.assert_allclose(val_g, val_t, rtol=1e-9)
+    np.testing.assert_allclose(best_d.cpu().numpy(), best_t.cpu().numpy(), rtol=0, atol=1e-7)
+    assert int(log_d["iterations"]) == int(log_t["iterations"]) == int(log_g["iterations"])
+    np.testing.assert_array_equal(log_d["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
+    np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-8, atol=1e-12)

@@ -20,7 +20,7 @@ def mandel(m):
     return np.ascontiguousarray(m[..., r, c] * np.where(r == c, 1.0, 2 ** 0.5))
 
 
-def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=1234, maxiter=100, hip_graphs=False, batched_rand=False, fused=True):
+def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=1234, maxiter=100, hip_graphs=False, batched_rand=False, fused=True, device_tcg=True):
     rng = np.random.default_rng(seed)
     q = np.linalg.qr(rng.standard_normal((n_train, d, d)))[0]
     X = np.einsum("nab,nb,ncb->nac", q, rng.uniform(1e-3, 5.0, (n_train, d)), q)
@@ -45,7 +45,7 @@ def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=
     solver = BatchedTrustRegions(mingradnorm=1e-4, maxiter=maxiter)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=num_restarts, raw_samples=raw_samples, bounds=None,
-                                   options={"device": device, "hip_graphs": hip_graphs, "batched_rand": batched_rand, "fused_acquisition": fused}, inequality_constraints=[lambda x: scut.max_eigenvalue_constraint_torch(x, 5.0)],
+                                   options={"device": device, "hip_graphs": hip_graphs, "batched_rand": batched_rand, "fused_acquisition": fused, "device_tcg": device_tcg}, inequality_constraints=[lambda x: scut.max_eigenvalue_constraint_torch(x, 5.0)],
                                    pre_processing_manifold=to_mat, post_processing_manifold=to_vec, approx_hessian=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     return dt, best, float(acq(best[None]).item()), solver.log
@@ -55,6 +55,8 @@ if __name__ == "__main__":
     R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     dt, best, val, log = run_sweep("cuda:0", num_restarts=R, fused=False)
     print(f"sweep R={R} autograd evaluations: {dt:.3f} s  EI*={val:.6e}")
+    dt, best, val, log = run_sweep("cuda:0", num_restarts=R, device_tcg=False)
+    print(f"sweep R={R} torch tCG: {dt:.3f} s  EI*={val:.6e} TR iterations={log['iterations']} grad evals={log['grad_evals']}")
     dt, best, val, log = run_sweep("cuda:0", num_restarts=R)
     print(f"sweep R={R}: {dt:.3f} s  {R/dt:.1f} restarts/s  EI*={val:.6e}  TR iterations={log['iterations']} cost evals={log['cost_evals']} grad evals={log['grad_evals']}")
     dt, best, val, log = run_sweep("cuda:0", num_restarts=R)
