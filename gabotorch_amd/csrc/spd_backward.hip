@@ -16,62 +16,11 @@
 // reduction per row, then the lanes share the final congruence and the Mandel scatter.
 #include "gabo_device.hpp"
 #include "spd_prep.hpp"
+#include "spd_jacobi.hpp"
 #include "spd_generic.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
-
-// Cyclic Jacobi on a packed lower triangle (registers) with accumulated eigenvectors kept in LDS: the D*D doubles of V
-// per lane do not fit the 256 directly addressable VGPRs next to M.  vl[(r*D + c)*64 + lane], columns = eigenvectors.
-template <int D>
-__device__ __forceinline__ void jacobi_eig(double (&m)[tri_size(D)], double* __restrict__ vl) {
-    static_for<D>([&](auto rr) {
-        static_for<D>([&](auto cc) {
-            vl[(decltype(rr)::value * D + decltype(cc)::value) * 64] = (decltype(rr)::value == decltype(cc)::value) ? 1.0 : 0.0;
-        });
-    });
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        double off = 0.0, dia = 0.0;
-        static_for<D>([&](auto rr) {
-            constexpr int r = decltype(rr)::value;
-            dia = __builtin_fma(m[tri(r, r)], m[tri(r, r)], dia);
-            static_for<r>([&](auto cc) { double x = m[tri(r, decltype(cc)::value)]; off = __builtin_fma(x, x, off); });
-        });
-        if (off <= 1e-33 * dia) break;
-        static_for<D - 1>([&](auto pp) {
-            constexpr int p = decltype(pp)::value;
-            static_for<D - 1 - p>([&](auto qq) {
-                constexpr int q = p + 1 + decltype(qq)::value;
-                double apq = m[tri(q, p)];
-                double app = m[tri(p, p)], aqq = m[tri(q, q)];
-                // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)),  theta = (aqq - app) / (2 apq); written division-safe:
-                // t = 2 |apq| sgn(apq h) / (|h| + sqrt(h^2 + 4 apq^2)),  h = aqq - app
-                double h = aqq - app;
-                double den = __builtin_fabs(h) + sqrt_pos(__builtin_fma(h, h, 4.0 * apq * apq));
-                double t = (den == 0.0) ? 0.0 : copysign_d(2.0 * apq, apq * h) * rcp(den == 0.0 ? 1.0 : den);
-                if (h == 0.0) t = (apq == 0.0) ? 0.0 : copysign_d(1.0, apq);
-                double c = rsqrt_nz(__builtin_fma(t, t, 1.0));
-                double s = t * c;
-                m[tri(p, p)] = __builtin_fma(-t, apq, app);
-                m[tri(q, q)] = __builtin_fma(t, apq, aqq);
-                m[tri(q, p)] = 0.0;
-                static_for<D>([&](auto kk) {
-                    constexpr int k = decltype(kk)::value;
-                    if constexpr (k != p && k != q) {
-                        constexpr int ikp = k > p ? tri(k, p) : tri(p, k);
-                        constexpr int ikq = k > q ? tri(k, q) : tri(q, k);
-                        double akp = m[ikp], akq = m[ikq];
-                        m[ikp] = __builtin_fma(c, akp, -s * akq);
-                        m[ikq] = __builtin_fma(s, akp, c * akq);
-                    }
-                    double vkp = vl[(k * D + p) * 64], vkq = vl[(k * D + q) * 64];
-                    vl[(k * D + p) * 64] = __builtin_fma(c, vkp, -s * vkq);
-                    vl[(k * D + q) * 64] = __builtin_fma(s, vkp, c * vkq);
-                });
-            });
-        });
-    }
-}
 
 template <int D>
 __global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __restrict__ Winv, const double* __restrict__ G,

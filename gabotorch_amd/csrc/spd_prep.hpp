@@ -9,16 +9,9 @@
 
 namespace gabo {
 
+// Mandel vector -> packed lower Cholesky factor a (in registers); returns true when a pivot is not positive
 template <int D>
-__global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__ x, double* __restrict__ ws,
-                                                      int64_t batch, int64_t n, int64_t batch_stride, int soa,
-                                                      int* __restrict__ status, int status_base) {
-    constexpr int T = tri_size(D);
-    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= batch * n) return;
-    int64_t b = g / n, i = g - b * n;
-    const double* v = x + b * batch_stride + i * T;
-    double a[T];
+__device__ __forceinline__ bool mandel_cholesky(const double* __restrict__ v, double (&a)[tri_size(D)]) {
     static_for<D>([&](auto rr) {
         constexpr int r = decltype(rr)::value;
         static_for<r + 1>([&](auto cc) {
@@ -27,7 +20,6 @@ __global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__
             a[tri(r, c)] = (r == c) ? e : e / kSqrt2;  // spd_utils_torch.py:186-187 divides by 2**0.5
         });
     });
-    // in-place lower Cholesky
     bool bad = false;
     static_for<D>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
@@ -44,6 +36,41 @@ __global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__
             a[tri(r, c)] = s * inv;
         });
     });
+    return bad;
+}
+
+// W = L^-1 (lower), column by column: W[c][c] = 1/L[c][c]; W[r][c] = -(sum_{k=c}^{r-1} L[r][k] W[k][c]) / L[r][r]
+template <int D>
+__device__ __forceinline__ void lower_inverse(const double (&a)[tri_size(D)], double (&w)[tri_size(D)]) {
+    static_for<D>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        w[tri(c, c)] = 1.0 / a[tri(c, c)];
+    });
+    static_for<D>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        static_for<D - c - 1>([&](auto rr) {
+            constexpr int r = c + 1 + decltype(rr)::value;
+            double s = 0.0;
+            static_for<r - c>([&](auto kk) {
+                constexpr int k = c + decltype(kk)::value;
+                s = __builtin_fma(a[tri(r, k)], w[tri(k, c)], s);
+            });
+            w[tri(r, c)] = -s * w[tri(r, r)];
+        });
+    });
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__ x, double* __restrict__ ws,
+                                                      int64_t batch, int64_t n, int64_t batch_stride, int soa,
+                                                      int* __restrict__ status, int status_base) {
+    constexpr int T = tri_size(D);
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= batch * n) return;
+    int64_t b = g / n, i = g - b * n;
+    const double* v = x + b * batch_stride + i * T;
+    double a[T];
+    const bool bad = mandel_cholesky<D>(v, a);
     if (bad) {
         if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = status_base + (int)g;
     }
@@ -53,22 +80,7 @@ __global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__
     } else {
         // W = L^-1 (lower), column by column: W[c][c] = 1/L[c][c]; W[r][c] = -(sum_{k=c}^{r-1} L[r][k] W[k][c]) / L[r][r]
         double w[T];
-        static_for<D>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            w[tri(c, c)] = 1.0 / a[tri(c, c)];
-        });
-        static_for<D>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            static_for<D - c - 1>([&](auto rr) {
-                constexpr int r = c + 1 + decltype(rr)::value;
-                double s = 0.0;
-                static_for<r - c>([&](auto kk) {
-                    constexpr int k = c + decltype(kk)::value;
-                    s = __builtin_fma(a[tri(r, k)], w[tri(k, c)], s);
-                });
-                w[tri(r, c)] = -s * w[tri(r, r)];
-            });
-        });
+        lower_inverse<D>(a, w);
         double* o = ws + g * T;
         static_for<T>([&](auto ee) { o[decltype(ee)::value] = w[decltype(ee)::value]; });
     }

@@ -409,6 +409,11 @@ size_t gabo_spd_tcg_workspace_bytes(int64_t r, int d, int n_constraints) {
     return gabo::tcg_layout(nullptr, r, d, n_constraints).bytes;
 }
 
+size_t gabo_spd_tcg_running_offset(int64_t r, int d, int n_constraints) {
+    if (r < 0 || d < 1 || n_constraints < 0) return 0;
+    return (size_t)((char*)gabo::tcg_layout(nullptr, r, d, n_constraints).running - (char*)nullptr);
+}
+
 static int tcg_args_ok(int64_t r, int d, int c) {
     if (d < 1 || d > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
     if (r < 0 || r > 0x7fffffffLL || c < 0 || c > gabo::kMaxCons) return GABO_ERR_ARG;

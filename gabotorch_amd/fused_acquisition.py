@@ -31,6 +31,10 @@ class FusedAcquisition:
         self.linv_t = self.linv.t().contiguous()
         self.alpha = alpha.to(device).contiguous()
         self.train = gp.train_x.to(device).contiguous()
+        # d <= 12: value + gradient in ONE launch per evaluation (csrc/spd_acq.hip); the training side is factored once here
+        self.single_launch = (family == "spd" and self.train.shape[-1] <= _lib.GABO_SPD_REG_MAX_DIM * (_lib.GABO_SPD_REG_MAX_DIM + 1) // 2
+                              and self.train.shape[0] <= 2048)
+        self.train_factors = ops.spd_acq_prepare_train(self.train) if self.single_launch else None
         if family == "spd":
             # d(X, X)^2 = 1e-15 exactly (the eigenvalues of L^-1 X L^-T are 1 to rounding): spd_utils_torch.py:120
             self.kxx = math.exp(-beta * (1e-15 if mode == _lib.GABO_OUT_GAUSSIAN else math.sqrt(1e-15)))
@@ -71,21 +75,33 @@ class FusedAcquisition:
         c = pts @ self.train.t()
         return pts, ops.sphere_from_inner(c, self.beta, self.mode, 0), c
 
-    def egrad_mandel(self, pts):
+    def egrad_mandel(self, pts, active_ptr=None, out=None):
         """Euclidean gradient of the cost at SPD points given (and returned) as Mandel vectors: the chain without the two
         Mandel maps, used by the fused trust-region inner loop."""
+        if self.single_launch:
+            return self._single(pts, True, active_ptr, out)[1]
         ks = ops.spd_ai_pairwise(pts, self.train, self.beta, self.mode)
         _, gk = ops.gp_acquisition(ks, self.alpha, self.linv, self.linv_t, self.mean, self.outputscale, self.kxx, self.best_f,
                                    self.kind, self.maximize, out_sign=-1.0, need_grad=True)
         return ops.spd_ai_backward(pts, self.train, gk, self.beta, self.mode, wrt=1)
 
+    def _single(self, pts, need_grad, active_ptr=None, out=None):
+        return ops.spd_acq_eval(pts, self.train_factors, self.alpha, self.linv, self.linv_t, self.beta, self.mode, self.mean,
+                                self.outputscale, self.kxx, self.best_f, self.kind, self.maximize, out_sign=-1.0, need_grad=need_grad,
+                                active_ptr=active_ptr, out=out)
+
     def cost(self, x):
+        if self.single_launch:
+            return self._single(ops.matrix_to_mandel(x.detach()) if self.matrix_input else x.detach(), False)[0]
         _, ks, _ = self._strip(x.detach())
         val, _ = ops.gp_acquisition(ks, self.alpha, self.linv, self.linv_t, self.mean, self.outputscale, self.kxx, self.best_f,
                                     self.kind, self.maximize, out_sign=-1.0, need_grad=False)
         return val
 
     def cost_egrad(self, x):
+        if self.single_launch:
+            val, g = self._single(ops.matrix_to_mandel(x.detach()) if self.matrix_input else x.detach(), True)
+            return val, (ops.mandel_to_matrix(g) if self.matrix_input else g)
         pts, ks, c = self._strip(x.detach())
         val, gk = ops.gp_acquisition(ks, self.alpha, self.linv, self.linv_t, self.mean, self.outputscale, self.kxx, self.best_f,
                                      self.kind, self.maximize, out_sign=-1.0, need_grad=True)

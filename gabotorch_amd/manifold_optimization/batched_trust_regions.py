@@ -183,6 +183,8 @@ class BatchedTrustRegions:
         neq = len(eqs)
         constrained = bool(eqs or ineqs)
 
+        if self._device_tcg_applies(problem, x, len(eqs) + len(ineqs)) and getattr(problem, "device_outer", True):
+            return self._solve_device(problem, x, eqs, ineqs, mininner, maxinner, Delta_bar, Delta0, Delta_cons)
         time0 = time.time()
         fx, g = problem.cost_grad(x)
         ng = man.norm(x, g)
@@ -236,6 +238,106 @@ class BatchedTrustRegions:
         self.log = {"iterations": k, "per_restart_iterations": iters, "final_cost": fx, "final_gradnorm": ng,
                     "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0}
         return x
+
+    # ------------------------------------------------------------------------------------------------- device-resident solve
+    def _solve_device(self, problem, x, eqs, ineqs, mininner, maxinner, Delta_bar, Delta0, Delta_cons):
+        """solve() for the case _device_tcg_applies: one trust-region iteration is a FIXED sequence of launches on persistent
+        buffers with per-restart masks (no data-dependent host control flow), so with hipGraphs it is captured once and each outer
+        iteration is one replay + one read-back of "any restart still active".  Same arithmetic per restart as solve()."""
+        from .. import ops
+        man, fused = problem.manifold, problem.fused
+        R, d = x.shape[0], x.shape[-1]
+        dt, dev = x.dtype, x.device
+        cons = eqs + ineqs
+        ncons, neq = len(cons), len(eqs)
+        graphs = bool(getattr(problem, "use_hip_graphs", False))
+        T = ops.SpdTcg(R, d, ncons, dev)
+        val_buf = torch.zeros(R, dtype=dt, device=dev)
+        eg_buf = torch.zeros(R, d * (d + 1) // 2, dtype=dt, device=dev)
+        eps = torch.finfo(dt).eps
+        time0 = time.time()
+        fx, eg = fused.cost_egrad(x)
+        problem.n_grad += 1
+
+        class S:      # persistent state, updated in place
+            pass
+        S.x, S.fx = x.detach().clone(), fx.clone()
+        S.g = man.egrad2rgrad(S.x, eg)
+        S.ng = man.norm(S.x, S.g)
+        S.Delta = torch.full((R,), float(Delta0), dtype=dt, device=dev)
+        S.active = torch.ones(R, dtype=torch.bool, device=dev)
+        S.iters = torch.zeros(R, dtype=torch.long, device=dev)
+        S.any_active = torch.ones((), dtype=torch.bool, device=dev)
+        step_args = (neq, Delta_cons, self.theta, self.kappa, mininner)
+
+        def body(sync):
+            if ncons:
+                fc, gc = self._constraint_values_grads(problem, S.x, cons)
+                T.begin(S.x, S.g, torch.stack(gc), fc, S.active, S.Delta)
+            else:
+                T.begin(S.x, S.g, None, None, S.active, S.Delta)
+            for _ in range(int(maxinner)):
+                T.step(fused.egrad_mandel(T.fd_point(), active_ptr=T.running_ptr, out=(val_buf, eg_buf)), *step_args)
+                problem.n_grad += 1
+                if sync and not bool(T.any_running.item()):
+                    break
+            eta, Heta, stop_inner = T.end()
+            x_prop = man.retr(S.x, eta)
+            fx_prop, eg_prop = fused.cost_egrad(x_prop)
+            problem.n_grad += 1
+            invalid = torch.zeros_like(S.active)
+            if ncons and self.strict_constraints:
+                fcp, _ = self._constraint_values_grads(problem, x_prop, cons)
+                viol = fcp.clone()
+                viol[:, neq:] = torch.clamp(viol[:, neq:], max=0.0)
+                invalid = viol.abs().sum(1) != 0
+                fx_prop = torch.where(invalid, torch.full_like(fx_prop, float("inf")), fx_prop)
+            rhonum = S.fx - fx_prop
+            rhoden = -man.inner(S.x, S.g, eta) - 0.5 * man.inner(S.x, eta, Heta)
+            rho_reg = torch.clamp(S.fx.abs(), min=1.0) * eps * self.rho_regularization
+            rhonum = rhonum + rho_reg
+            rhoden = rhoden + rho_reg
+            model_decreased = rhoden >= 0
+            rho = torch.where(rhoden == 0, torch.full_like(rhoden, float("nan")), rhonum / rhoden)
+            shrink = (rho < 0.25) | ~model_decreased | torch.isnan(rho) | invalid
+            boundary = (stop_inner == NEGATIVE_CURVATURE) | (stop_inner == EXCEEDED_TR)
+            if ncons:
+                boundary = boundary | (stop_inner == REACHED_CONSTRAINTS)
+            grow = ~shrink & (rho > 0.75) & boundary
+            newDelta = torch.where(shrink, S.Delta / 4, torch.where(grow, torch.clamp(2 * S.Delta, max=float(Delta_bar)), S.Delta))
+            S.Delta.copy_(torch.where(S.active, newDelta, S.Delta))
+            accept = S.active & model_decreased & (rho > self.rho_prime)
+            gnew = man.egrad2rgrad(x_prop, eg_prop)                 # the gradient at the proposal IS the gradient at the new x
+            S.x.copy_(torch.where(_bm(accept, S.x), x_prop, S.x))
+            S.fx.copy_(torch.where(accept, fx_prop, S.fx))
+            S.g.copy_(torch.where(_bm(accept, S.g), gnew, S.g))
+            S.ng.copy_(torch.where(accept, man.norm(S.x, S.g), S.ng))
+            S.iters.add_(S.active.long())
+            stop = (S.ng < self.mingradnorm) | (S.iters >= self.maxiter)
+            S.active.copy_(S.active & ~stop)
+            S.any_active.copy_(S.active.any())
+
+        graph = None
+        if graphs:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    body(False)
+            except Exception:        # noqa: BLE001  a constraint callable that cannot be captured (host sync inside): run eagerly
+                graph = None
+                torch.cuda.synchronize(dev)
+        k = 0
+        while True:
+            if graph is not None:
+                graph.replay()
+            else:
+                body(True)
+            k += 1
+            if not bool(S.any_active) or (time.time() - time0) >= self.maxtime:
+                break
+        self.log = {"iterations": k, "per_restart_iterations": S.iters, "final_cost": S.fx, "final_gradnorm": S.ng,
+                    "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0}
+        return S.x
 
     # ------------------------------------------------------------------------------------------------- truncated CG
     @staticmethod

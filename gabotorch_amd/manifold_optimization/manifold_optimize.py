@@ -132,6 +132,7 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
                              use_hip_graphs=bool((options or {}).get("hip_graphs", False)), fused=fused)
     problem.reference_precon = True          # `precon` above is the one csrc/spd_tcg.hip implements
     problem.device_tcg = bool((options or {}).get("device_tcg", True))
+    problem.device_outer = bool((options or {}).get("device_outer", True))
     if solver_init_conds:
         x0 = torch.stack([torch.as_tensor(manifold.rand()) for _ in range(x0.shape[0])]).to(x0)
     if equality_constraints is not None or inequality_constraints is not None:

@@ -555,6 +555,46 @@ def gp_acquisition(kstar, alpha, linv, linv_t, mean, outputscale, kxx, best_f, k
     return value, grad
 
 
+def spd_acq_prepare_train(train_mandel):
+    """Entry-major Cholesky factors of the training matrices for spd_acq_eval (d_vec x n)."""
+    lib = _lib.load()
+    x = train_mandel.contiguous()
+    n, dv = x.shape
+    d = _mandel_dim(dv)
+    out = torch.empty(dv, n, dtype=torch.float64, device=x.device)
+    status = torch.zeros(2, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.gabo_spd_acq_prepare_train(x.data_ptr(), out.data_ptr(), n, d, status.data_ptr(), _stream_ptr(x.device)),
+                   "gabo_spd_acq_prepare_train")
+    _raise_if_not_spd(status, "gabo_spd_acq_prepare_train")
+    return out
+
+
+def spd_acq_eval(x_mandel, train_factors, alpha, linv, linv_t, beta, mode, mean, outputscale, kxx, best_f, kind, maximize,
+                 out_sign=1.0, need_grad=True, active_ptr=None, out=None):
+    """Single-launch acquisition value (R) and Euclidean gradient (R x d_vec, Mandel) at SPD candidates."""
+    lib = _lib.load()
+    x = x_mandel.contiguous()
+    dev = x.device
+    r, dv = x.shape
+    n = train_factors.shape[1]
+    if out is not None:           # (value, grad) buffers to update in place: masked candidates keep their previous entries
+        value, grad = out
+    else:
+        value = torch.empty(r, dtype=torch.float64, device=dev)
+        grad = torch.empty_like(x) if need_grad else None
+    scratch = torch.empty(r * dv * n, dtype=torch.float64, device=dev) if need_grad else None
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_spd_acq_eval(x.data_ptr(), train_factors.data_ptr(), alpha.data_ptr(), ptr(linv), ptr(linv_t),
+                                         value.data_ptr(), ptr(grad), ptr(scratch), r, n, _mandel_dim(dv), float(beta), int(mode),
+                                         float(mean), float(outputscale), float(kxx), float(best_f), int(kind), 1 if maximize else 0,
+                                         float(out_sign), active_ptr, status.data_ptr(), _stream_ptr(dev)), "gabo_spd_acq_eval")
+    _raise_if_not_spd(status, "gabo_spd_acq_eval")
+    return value, grad
+
+
 class SpdTcg:
     """Device-resident truncated CG of the SPD trust regions (gabo_spd_tcg_*): thin handle around the workspace."""
 
@@ -565,6 +605,7 @@ class SpdTcg:
         self.ws = torch.zeros(self.wsb // 8 + 1, dtype=torch.float64, device=device)
         self.x_fd = torch.empty(self.r, d * (d + 1) // 2, dtype=torch.float64, device=device)
         self.any_running = torch.zeros(1, dtype=torch.int32, device=device)
+        self.running_ptr = self.ws.data_ptr() + self.lib.gabo_spd_tcg_running_offset(self.r, self.d, self.c)
         self.status = torch.zeros(2, dtype=torch.int32, device=device)
 
     def begin(self, x, g, gc, fc, active, Delta):

@@ -179,6 +179,23 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
                         int kind, int maximize, double out_sign, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Acquisition value and gradient at r candidate SPD points in one launch (one wave per candidate): the affine-invariant kernel
+ * strip against the training set, gabo_gp_acquisition's posterior + EI / posterior mean, and the closed-form gradient back to
+ * the candidate, fused.  Same reference code as gabo_spd_ai_pairwise + gabo_gp_acquisition + gabo_spd_ai_backward; exists because
+ * the lock-step trust regions evaluate this once per inner iteration and are launch-count bound.  2 <= d <= GABO_SPD_REG_MAX_DIM.
+ *   gabo_spd_acq_prepare_train: Cholesky factors of the n training matrices, entry-major (d_vec x n), once per surrogate.
+ *   gabo_spd_acq_eval: x_mandel r x d_vec; value r; grad_mandel NULL or r x d_vec (then scratch: r * d_vec * n doubles);
+ *     flags GABO_OUT_GAUSSIAN or GABO_OUT_LAPLACE; active: NULL, or r ints - candidates with active[i] == 0 are skipped and their
+ *     outputs left untouched (the trust regions pass the running flags of gabo_spd_tcg_*); remaining arguments as in
+ *     gabo_gp_acquisition. */
+int gabo_spd_acq_prepare_train(const double* x_train_mandel, double* train_factors, int64_t n, int d, int* status,
+                               gabo_stream_t stream);
+int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const double* alpha, const double* linv,
+                      const double* linv_t, double* value, double* grad_mandel, double* scratch, int64_t r, int64_t n, int d,
+                      double beta, int flags, double mean, double outputscale, double kxx, double best_f, int kind, int maximize,
+                      double out_sign, const int* active, int* status, gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Truncated conjugate gradients of the Riemannian trust-region solvers on S^d_++, R restarts in lock step (one wave each).
  * Replaces the per-restart numpy loops of  TrustRegions._truncated_conjugate_gradient   robust_trust_regions.py:417-570
  *                                          ConstrainedTrustRegions (linearised constraints) constrained_trust_regions.py:530-732
@@ -195,6 +212,8 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
  *             2/3 reached target linear/superlinear, 4 max inner iterations, 5 model increased, 6 reached constraints).
  * The state lives in `workspace` (gabo_spd_tcg_workspace_bytes); n_constraints <= 8. */
 size_t gabo_spd_tcg_workspace_bytes(int64_t r, int d, int n_constraints);
+/* byte offset, inside the workspace, of the r ints "restart still running" (readable mask for gabo_spd_acq_eval's `active`) */
+size_t gabo_spd_tcg_running_offset(int64_t r, int d, int n_constraints);
 int gabo_spd_tcg_begin(const double* x, const double* grad, const double* cons_grads, const double* cons_values,
                        const uint8_t* active, const double* trust_radius, void* workspace, size_t workspace_bytes, int64_t r, int d,
                        int n_constraints, int* status, gabo_stream_t stream);

@@ -194,7 +194,7 @@ def test_fused_spd_acquisition_matches_autograd(which):
         acq = models.PosteriorMean(gp, maximize=False)
     post = symmetric_matrix_to_vector_mandel_torch
     fused = FusedAcquisition.build(acq, post, torch.device(DEV))
-    assert fused is not None
+    assert fused is not None and fused.single_launch
     R = 70
     q = np.linalg.qr(rng.standard_normal((R, d, d)))[0]
     P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (R, d)), q)
@@ -212,6 +212,13 @@ def test_fused_spd_acquisition_matches_autograd(which):
     atol = 1e-7 if which.startswith("laplace") else 1e-11
     np.testing.assert_allclose(g.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-8, atol=atol * scale)
     np.testing.assert_allclose(fused.cost(x).cpu().numpy(), f.cpu().numpy(), rtol=0, atol=0)
+    # the separate-launch chain (strip -> gabo_gp_acquisition -> kernel backward) serves d > 12; same numbers
+    fused.single_launch = False
+    f2, g2 = fused.cost_egrad(x)
+    np.testing.assert_allclose(f2.cpu().numpy(), f_ref.detach().cpu().numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(g2.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-8, atol=atol * scale)
+    np.testing.assert_allclose(fused.egrad_mandel(ops.matrix_to_mandel(x)).cpu().numpy(), ops.matrix_to_mandel(g2).cpu().numpy(),
+                               rtol=1e-12, atol=1e-14 * scale)
 
 
 def test_fused_sphere_acquisition_matches_autograd():
@@ -260,6 +267,10 @@ def test_device_tcg_matches_torch_tcg():
     _, best_t, val_t, log_t = run_sweep(DEV, num_restarts=48, raw_samples=256, device_tcg=False)
     _, best_d, val_d, log_d = run_sweep(DEV, num_restarts=48, raw_samples=256, device_tcg=True)
     _, best_g, val_g, log_g = run_sweep(DEV, num_restarts=48, raw_samples=256, device_tcg=True, hip_graphs=True)
+    _, best_i, val_i, log_i = run_sweep(DEV, num_restarts=48, raw_samples=256, device_tcg=True, device_outer=False)   # tCG only
+    np.testing.assert_allclose(val_i, val_t, rtol=1e-9)
+    np.testing.assert_array_equal(log_i["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
+    np.testing.assert_array_equal(log_g["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
     np.testing.assert_allclose(val_d, val_t, rtol=1e-9)
     np.testing.assert_allclose(val_g, val_t, rtol=1e-9)
     np.testing.assert_allclose(best_d.cpu().numpy(), best_t.cpu().numpy(), rtol=0, atol=1e-7)
