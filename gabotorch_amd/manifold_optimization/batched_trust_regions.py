@@ -270,12 +270,24 @@ class BatchedTrustRegions:
         S.any_active = torch.ones((), dtype=torch.bool, device=dev)
         step_args = (neq, Delta_cons, self.theta, self.kappa, mininner)
 
-        def body(sync):
-            if ncons:
-                fc, gc = self._constraint_values_grads(problem, S.x, cons)
-                T.begin(S.x, S.g, torch.stack(gc), fc, S.active, S.Delta)
-            else:
-                T.begin(S.x, S.g, None, None, S.active, S.Delta)
+        fc_buf = torch.zeros(R, ncons, dtype=dt, device=dev) if ncons else None
+        gc_buf = torch.zeros((ncons,) + tuple(x.shape), dtype=dt, device=dev) if ncons else None
+        invalid_buf = torch.zeros(R, dtype=torch.bool, device=dev)
+        strict = bool(ncons and self.strict_constraints)
+
+        def constraints_at_x():                      # user callables (torch): captured only on request, see below
+            fc, gc = self._constraint_values_grads(problem, S.x, cons)
+            fc_buf.copy_(fc)
+            gc_buf.copy_(torch.stack(gc))
+
+        def constraints_at_proposal(A):              # StrictConstrainedTrustRegions (constrained_trust_regions.py:932-951)
+            fcp, _ = self._constraint_values_grads(problem, A["x_prop"], cons)
+            viol = fcp.clone()
+            viol[:, neq:] = torch.clamp(viol[:, neq:], max=0.0)
+            invalid_buf.copy_(viol.abs().sum(1) != 0)
+
+        def part_a(sync):
+            T.begin(S.x, S.g, gc_buf, fc_buf, S.active, S.Delta)
             for _ in range(int(maxinner)):
                 T.step(fused.egrad_mandel(T.fd_point(), active_ptr=T.running_ptr, out=(val_buf, eg_buf)), *step_args)
                 problem.n_grad += 1
@@ -285,12 +297,13 @@ class BatchedTrustRegions:
             x_prop = man.retr(S.x, eta)
             fx_prop, eg_prop = fused.cost_egrad(x_prop)
             problem.n_grad += 1
-            invalid = torch.zeros_like(S.active)
-            if ncons and self.strict_constraints:
-                fcp, _ = self._constraint_values_grads(problem, x_prop, cons)
-                viol = fcp.clone()
-                viol[:, neq:] = torch.clamp(viol[:, neq:], max=0.0)
-                invalid = viol.abs().sum(1) != 0
+            return {"eta": eta, "Heta": Heta, "stop_inner": stop_inner, "x_prop": x_prop, "fx_prop": fx_prop, "eg_prop": eg_prop}
+
+        def part_b(A):
+            eta, Heta, stop_inner, x_prop, eg_prop = A["eta"], A["Heta"], A["stop_inner"], A["x_prop"], A["eg_prop"]
+            fx_prop = A["fx_prop"]
+            invalid = invalid_buf
+            if strict:
                 fx_prop = torch.where(invalid, torch.full_like(fx_prop, float("inf")), fx_prop)
             rhonum = S.fx - fx_prop
             rhoden = -man.inner(S.x, S.g, eta) - 0.5 * man.inner(S.x, eta, Heta)
@@ -317,24 +330,60 @@ class BatchedTrustRegions:
             S.active.copy_(S.active & ~stop)
             S.any_active.copy_(S.active.any())
 
-        graph = None
-        if graphs:
-            try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    body(False)
-            except Exception:        # noqa: BLE001  a constraint callable that cannot be captured (host sync inside): run eagerly
-                graph = None
-                torch.cuda.synchronize(dev)
-        k = 0
-        while True:
-            if graph is not None:
-                graph.replay()
+        # Execution plan.  Eager: the parts in order, with the inner loop leaving as soon as no restart runs.  hipGraphs: the
+        # launches between two evaluations of the USER's constraint callables form one graph; the callables themselves run
+        # eagerly between replays (they may synchronise) unless the caller vouches for them with capture_constraints=True.
+        capture_cons = bool(getattr(problem, "capture_constraints", False))
+        plan = []               # list of callables executed once per outer iteration
+        prev_check = None
+        if not graphs:
+            holder = {}
+            if ncons:
+                plan.append(constraints_at_x)
+            plan.append(lambda: holder.update(part_a(True)))
+            if strict:
+                plan.append(lambda: constraints_at_proposal(holder))
+            plan.append(lambda: part_b(holder))
+        else:
+            prev_check = ops.set_error_checking(False)       # a status read-back is a host sync: not capturable
+            pool = None
+
+            def capture(fn):
+                nonlocal pool
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, pool=pool):
+                    out = fn()
+                pool = gr.pool()
+                return gr, out
+
+            if not ncons or capture_cons:
+                def whole():
+                    if ncons:
+                        constraints_at_x()
+                    A = part_a(False)
+                    if strict:
+                        constraints_at_proposal(A)
+                    part_b(A)
+                gr, _ = capture(whole)
+                plan.append(gr.replay)
+            elif not strict:
+                gr, _ = capture(lambda: part_b(part_a(False)))
+                plan += [constraints_at_x, gr.replay]
             else:
-                body(True)
-            k += 1
-            if not bool(S.any_active) or (time.time() - time0) >= self.maxtime:
-                break
+                ga, A = capture(lambda: part_a(False))
+                gb, _ = capture(lambda: part_b(A))
+                plan += [constraints_at_x, ga.replay, lambda: constraints_at_proposal(A), gb.replay]
+        k = 0
+        try:
+            while True:
+                for stage in plan:
+                    stage()
+                k += 1
+                if not bool(S.any_active) or (time.time() - time0) >= self.maxtime:
+                    break
+        finally:
+            if prev_check is not None:
+                ops.set_error_checking(prev_check)
         self.log = {"iterations": k, "per_restart_iterations": S.iters, "final_cost": S.fx, "final_gradnorm": S.ng,
                     "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0}
         return S.x

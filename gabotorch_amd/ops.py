@@ -15,7 +15,9 @@ def set_error_checking(flag):
     """Device-side data errors (non-SPD input) are read back after each call when enabled (costs a stream sync).
     The reference raises from torch.cholesky in that case; disable inside latency-critical loops."""
     global _check_errors
+    prev = _check_errors
     _check_errors = bool(flag)
+    return prev
 
 
 def _device_for(*tensors):

@@ -277,3 +277,18 @@ def test_device_tcg_matches_torch_tcg():
     assert int(log_d["iterations"]) == int(log_t["iterations"]) == int(log_g["iterations"])
     np.testing.assert_array_equal(log_d["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
     np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_device_solve_graph_plans_match_torch_path(strict):
+    """Every execution plan of the device-resident solve (eager; graphs with the constraint callables between replays; graphs
+    with the callables captured) follows the torch lock-step solver restart for restart."""
+    from tools.sweep_bench import run_sweep
+    kw = dict(num_restarts=40, raw_samples=256, strict=strict)
+    _, _, val_t, log_t = run_sweep(DEV, device_tcg=False, **kw)
+    ref_iters = log_t["per_restart_iterations"].cpu().numpy()
+    for extra in (dict(), dict(hip_graphs=True), dict(hip_graphs=True, capture_constraints=True)):
+        _, _, val, log = run_sweep(DEV, **kw, **extra)
+        np.testing.assert_allclose(val, val_t, rtol=1e-9)
+        np.testing.assert_array_equal(log["per_restart_iterations"].cpu().numpy(), ref_iters)
+        np.testing.assert_allclose(log["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-8, atol=1e-12)

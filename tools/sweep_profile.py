@@ -28,5 +28,11 @@ wrap(btr.BatchedProblem, "cost", "cost")
 wrap(btr.BatchedProblem, "cost_grad", "cost_grad")
 wrap(btr.BatchedTrustRegions, "solve", "solve_total")
 wrap(mo, "gen_candidates_manifold", "gen_candidates_total")
+wrap(btr.BatchedTrustRegions, "_solve_device", "solve_device")
+wrap(torch.cuda.CUDAGraph, "replay", "graph_replay")
+wrap(torch.cuda.CUDAGraph, "capture_end", "capture_end")
+wrap(mo.FusedAcquisition, "build", "fused_build")
+import gabotorch_amd.models as models
+wrap(models.ExactGP, "_train_cache", "gp_train_cache")
 dt, *_ = run_sweep("cuda:0", hip_graphs=True, batched_rand=True)
 print(json.dumps({"sweep_s_with_syncs": dt, "phases_ms": {k: round(v * 1e3, 3) for k, v in acc.items()}, "calls": cnt}, indent=1))
