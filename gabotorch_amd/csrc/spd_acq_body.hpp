@@ -1,0 +1,201 @@
+// Device-side body of the fused acquisition evaluation (see spd_acq.hip for the description): shared by the stand-alone kernel
+// and by the trust-region iteration kernel (spd_tr.hip).
+#pragma once
+#include "gabo_device.hpp"
+#include "spd_prep.hpp"
+#include "spd_jacobi.hpp"
+#include "../../include/gabo_hip.h"
+
+namespace gabo {
+
+static __device__ __forceinline__ double wave_sum64(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+using AcqParams = gabo_spd_acq_params;   // include/gabo_hip.h
+
+// LDS needed by acq_eval<D>: static part (doubles) + 3 n doubles of dynamic scratch
+template <int D>
+struct AcqLds {
+    static constexpr int T = tri_size(D);
+    double acc[T * 64];
+    double vls[D * D * 64];
+    double red[T];
+    double wl[T];
+};
+
+// One wave: acquisition value and (grad != nullptr) Euclidean gradient, Mandel, at the SPD point xrow (Mandel, global or LDS).
+// F: T * n doubles of global scratch owned by this wave; dyn: 3 n doubles of LDS.  All 64 lanes call it; ends with the outputs
+// written by the owning lanes (no trailing barrier).
+template <int D>
+__device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const AcqParams& P, double* __restrict__ value_out,
+                                         double* __restrict__ grad_out, double* __restrict__ F, AcqLds<D>& L, double* dyn,
+                                         int* __restrict__ status, int64_t index) {
+    constexpr int T = tri_size(D);
+    constexpr int LD = 64;
+    const double* __restrict__ G = P.train_factors;
+    const double* __restrict__ alpha = P.alpha;
+    const double* __restrict__ linv = P.linv;
+    const double* __restrict__ linv_t = P.linv_t;
+    const int64_t n = P.n;
+    const double beta = P.beta, mean0 = P.mean, os = P.outputscale, kxx = P.kxx, best_f = P.best_f, out_sign = P.out_sign;
+    const int mode = P.flags, kind = P.kind, maximize = P.maximize;
+    double* acc = L.acc;
+    double* vls = L.vls;
+    double* red = L.red;
+    double* wl = L.wl;
+    double* ks = dyn;          // n : outputscale * k_j
+    double* kd = ks + n;       // n : d k_j / d (d_j^2)
+    double* vv = kd + n;       // n : L^-1 ks
+    const int lane = threadIdx.x;
+    const int64_t i = index;
+    const bool want_grad = grad_out != nullptr;
+    // ---- candidate side: W = chol(x*)^-1, computed by every lane (wave-uniform, a few hundred flops)
+    // and kept in LDS (broadcast reads with compile-time offsets) so that it does not compete with M for registers
+    {
+        double a[T], w[T];
+        const bool bad = mandel_cholesky<D>(xrow, a);
+        if (bad && lane == 0 && status) {
+            if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = (int)i;
+        }
+        lower_inverse<D>(a, w);
+        if (lane == 0) static_for<T>([&](auto ee) { wl[decltype(ee)::value] = w[decltype(ee)::value]; });
+    }
+    __syncthreads();
+    const double* w = wl;
+    for (int64_t j0 = 0; j0 < n; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const bool live = j < n;
+        const double* Gj = G + (live ? j : n - 1);
+        double m[T];
+        static_for<T>([&](auto ee) { m[decltype(ee)::value] = 0.0; });
+        static_for<D>([&](auto cc) {
+            constexpr int col = decltype(cc)::value;
+            double g[D - col], c[D - col];
+            static_for<D - col>([&](auto kk) { g[decltype(kk)::value] = Gj[(int64_t)tri(col + decltype(kk)::value, col) * n]; });
+            static_for<D - col>([&](auto rr) {
+                constexpr int r = col + decltype(rr)::value;
+                double a = w[tri(r, col)] * g[0];
+                static_for<r - col>([&](auto kk) {
+                    constexpr int k = col + 1 + decltype(kk)::value;
+                    a = __builtin_fma(w[tri(r, k)], g[k - col], a);
+                });
+                c[r - col] = a;
+            });
+            static_for<D - col>([&](auto rr) {
+                constexpr int r = col + decltype(rr)::value;
+                static_for<r - col + 1>([&](auto qq) {
+                    constexpr int q = col + decltype(qq)::value;
+                    m[tri(r, q)] = __builtin_fma(c[r - col], c[q - col], m[tri(r, q)]);
+                });
+            });
+        });
+        double* vl = vls + lane;
+        jacobi_eig<D>(m, vl);
+        double lg[D];
+        double s = 0.0;
+        static_for<D>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            lg[k] = log(m[tri(k, k)]);
+            s = __builtin_fma(lg[k], lg[k], s);
+        });
+        const double d2 = s + 1e-15;                      // spd_utils_torch.py:120
+        const double dist = __builtin_sqrt(d2);
+        double kj, dk;
+        if (mode == GABO_OUT_GAUSSIAN) {
+            kj = exp(-((dist * dist) * beta));
+            dk = -beta * kj;
+        } else {
+            kj = exp(-(dist * beta));
+            dk = -beta * kj / (2.0 * dist);
+        }
+        if (live) {
+            ks[j] = os * kj;
+            kd[j] = dk;
+            if (want_grad) {
+                static_for<D>([&](auto rr) {
+                    constexpr int r = decltype(rr)::value;
+                    static_for<r + 1>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        double f = 0.0;
+                        static_for<D>([&](auto kk) {
+                            constexpr int k = decltype(kk)::value;
+                            f = __builtin_fma(vl[(r * D + k) * 64] * lg[k], vl[(c * D + k) * 64], f);
+                        });
+                        F[(int64_t)tri(r, c) * n + j] = f;
+                    });
+                });
+            }
+        }
+    }
+    __syncthreads();
+    // ---- exact-GP posterior + acquisition (same arithmetic as gp_acquisition.hip)
+    double part = 0.0;
+    for (int64_t j = lane; j < n; j += 64) part = __builtin_fma(ks[j], alpha[j], part);
+    const double mean = mean0 + wave_sum64(part);
+    const double sgn = maximize ? 1.0 : -1.0;
+    double g_mean, g_var = 0.0;
+    if (kind == GABO_ACQ_POSTERIOR_MEAN) {
+        if (lane == 0) *value_out = out_sign * sgn * mean;
+        g_mean = sgn;
+    } else {
+        part = 0.0;
+        for (int64_t r = lane; r < n; r += 64) {
+            double a = 0.0;
+            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(linv_t[j * n + r], ks[j], a);
+            vv[r] = a;
+            part = __builtin_fma(a, a, part);
+        }
+        const double var = os * kxx - wave_sum64(part);
+        const bool clamped = !(var > 1e-9);
+        const double sigma = __builtin_sqrt(clamped ? 1e-9 : var);
+        const double u = sgn * (mean - best_f) / sigma;
+        const double pdf = exp(-0.5 * u * u) * 0.3989422804014327;
+        const double cdf = 0.5 * (1.0 + erf(u * 0.7071067811865476));
+        if (lane == 0) *value_out = out_sign * sigma * (pdf + u * cdf);
+        g_mean = sgn * cdf;
+        g_var = clamped ? 0.0 : 0.5 * pdf / sigma;
+    }
+    if (!want_grad) return;
+    __syncthreads();
+    // ---- weights w_j = d(out_sign acq)/d(d_j^2) and S = sum_j w_j logm(M_j), one accumulator column per lane
+    static_for<T>([&](auto ee) { acc[decltype(ee)::value * LD + lane] = 0.0; });
+    for (int64_t j = lane; j < n; j += 64) {
+        double ws = 0.0;
+        if (kind != GABO_ACQ_POSTERIOR_MEAN)
+            for (int64_t r = j; r < n; ++r) ws = __builtin_fma(linv[r * n + j], vv[r], ws);
+        const double gk = out_sign * os * (g_mean * alpha[j] - 2.0 * g_var * ws);
+        const double wj = gk * kd[j];
+        static_for<T>([&](auto ee) {
+            constexpr int e = decltype(ee)::value;
+            acc[e * LD + lane] = __builtin_fma(wj, F[(int64_t)e * n + j], acc[e * LD + lane]);
+        });
+    }
+    __syncthreads();
+    for (int e = lane; e < T; e += 64) {
+        double t = 0.0;
+        for (int l = 0; l < 64; ++l) t += acc[e * LD + ((l + e) & 63)];
+        red[e] = t;
+    }
+    __syncthreads();
+    // grad = -2 W^T S W, Mandel  (as in spd_backward.hip)
+    for (int e = lane; e < T; e += 64) {
+        int a = 0;
+        while (tri(a + 1, 0) <= e) ++a;
+        int bb = e - tri(a, 0);
+        double t = 0.0;
+        for (int r = a; r < D; ++r) {
+            double inner = 0.0;
+            for (int c = bb; c < D; ++c) {
+                double srs = r >= c ? red[tri(r, c)] : red[tri(c, r)];
+                inner = __builtin_fma(srs, wl[tri(c, bb)], inner);
+            }
+            t = __builtin_fma(wl[tri(r, a)], inner, t);
+        }
+        t *= -2.0;
+        grad_out[mandel_pos(D, a, bb)] = (a == bb) ? t : t * kSqrt2;
+    }
+}
+
+}  // namespace gabo

@@ -7,366 +7,39 @@
 // Everything is kept in WHITENED coordinates u~ = L^-1 u L^-T (L = chol(x), x fixed during tCG), where the affine-invariant
 // metric tr(x^-1 u x^-1 v) is the Frobenius dot, retr(x, u) = L expm(u~) L^T and the Riemannian gradient at x1 = L E L^T
 // transported back to x (identity transport) is  E L^T sym(egrad) L E.
-#include "gabo_device.hpp"
-#include "lds_linalg.hpp"
-#include "../../include/gabo_hip.h"
+#include "spd_tcg_body.hpp"
 
 namespace gabo {
-
-enum { TCG_NEGATIVE_CURVATURE = 0, TCG_EXCEEDED_TR, TCG_REACHED_TARGET_LINEAR, TCG_REACHED_TARGET_SUPERLINEAR, TCG_MAX_INNER_ITER,
-       TCG_MODEL_INCREASED, TCG_REACHED_CONSTRAINTS };
-enum { SC_DELTA = 0, SC_E_PE, SC_E_PD, SC_D_PD, SC_Z_R, SC_MODEL, SC_NORM_R0, SC_C_FD, SC_COUNT };
-constexpr int kMaxCons = 8;
-
-struct TcgWs {
-    double *chol, *g_w, *eta_w, *heta_w, *r_w, *delta_w, *expm, *w_ones, *scal, *gc_w, *fc, *fcg_pe;
-    int *stop, *running, *counters;
-    size_t bytes;
-};
-
-static __host__ __device__ inline TcgWs tcg_layout(void* base, int64_t R, int d, int C) {
-    TcgWs w;
-    double* p = (double*)base;
-    const int64_t m = R * d * d;
-    w.chol = p;     p += m;
-    w.g_w = p;      p += m;
-    w.eta_w = p;    p += m;
-    w.heta_w = p;   p += m;
-    w.r_w = p;      p += m;
-    w.delta_w = p;  p += m;
-    w.expm = p;     p += m;
-    w.w_ones = p;   p += R * d;
-    w.scal = p;     p += R * SC_COUNT;
-    w.gc_w = p;     p += (int64_t)C * m;
-    w.fc = p;       p += R * (C > 0 ? C : 1);
-    w.fcg_pe = p;   p += R * (C > 0 ? C : 1);
-    int* q = (int*)p;
-    w.stop = q;     q += R;
-    w.running = q;  q += R;
-    w.counters = q; q += 4;
-    w.bytes = (size_t)((char*)q - (char*)base);
-    return w;
-}
-
-static __device__ __forceinline__ double wave_sum(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-static __device__ __forceinline__ double wave_dot(const double* a, const double* b, int n) {
-    double s = 0.0;
-    for (int e = threadIdx.x; e < n; e += 64) s = __builtin_fma(a[e], b[e], s);
-    return wave_sum(s);
-}
-
-// z = precon(r): the reference adds 1e-30 to every element of a direction whose elements sum to exactly zero
-// (manifold_optimize.py:190-193); in whitened coordinates that is + 1e-30 (L^-1 1)(L^-1 1)^T.
-static __device__ __forceinline__ double precon_entry(double r, bool zero_sum, const double* w1, int e, int d) {
-    return zero_sum ? r + 1e-30 * w1[e / d] * w1[e % d] : r;
-}
-
-// sum of the elements of the UNwhitened matrix L r~ L^T = (L^T 1)^T r~ (L^T 1)
-static __device__ double unwhitened_sum(const double* L, const double* rw, int d) {
-    double s = 0.0;
-    for (int e = threadIdx.x; e < d * d; e += 64) {
-        int a = e / d, b = e - a * d;
-        double ca = 0.0, cb = 0.0;      // column sums of L
-        for (int k = a; k < d; ++k) ca += L[k * d + a];
-        for (int k = b; k < d; ++k) cb += L[k * d + b];
-        s = __builtin_fma(ca * rw[e], cb, s);
-    }
-    return wave_sum(s);
-}
 
 __global__ __launch_bounds__(64) void spd_tcg_begin_kernel(const double* __restrict__ x, const double* __restrict__ g,
                                                            const double* __restrict__ gc, const double* __restrict__ fc,
                                                            const uint8_t* __restrict__ active, const double* __restrict__ delta_tr,
                                                            void* wsbase, int64_t R, int d, int C, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int dd = d * d;
-    double* M0 = lds;          // L
-    double* M1 = M0 + dd;      // W = L^-1
-    double* M2 = M1 + dd;
-    double* M3 = M2 + dd;
-    double* M4 = M3 + dd;
     const int64_t i = blockIdx.x;
     TcgWs w = tcg_layout(wsbase, R, d, C);
     if (i == 0 && threadIdx.x == 0) { w.counters[0] = 0; w.counters[1] = 0; }
-    lds_load(x + i * dd, M0, d);
-    lds_symmetrize(M0, M4, d);
-    bool ok = lds_cholesky(M0, d);
-    lds_tri_inverse(M0, M1, d);
-    if (!ok && threadIdx.x == 0 && status) {
-        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = (int)i;
-    }
-    lds_load(g + i * dd, M2, d);
-    lds_symmetrize(M2, M4, d);
-    lds_congruence(M1, M2, M3, M4, d);      // g~ = W g W^T
-    lds_symmetrize(M3, M4, d);
-    double* gw = w.g_w + i * dd;
-    double* rw = w.r_w + i * dd;
-    for (int e = threadIdx.x; e < dd; e += 64) {
-        w.chol[i * dd + e] = M0[e];
-        gw[e] = M3[e];
-        rw[e] = M3[e];
-        w.eta_w[i * dd + e] = 0.0;
-        w.heta_w[i * dd + e] = 0.0;
-    }
-    for (int r = threadIdx.x; r < d; r += 64) {
-        double s = 0.0;
-        for (int k = 0; k <= r; ++k) s += M1[r * d + k];
-        w.w_ones[i * d + r] = s;
-    }
-    __syncthreads();
-    const double rr = wave_dot(M3, M3, dd);
-    const double usum = unwhitened_sum(M0, M3, d);
-    const bool zero_sum = usum == 0.0;
-    double zr = 0.0;
-    for (int e = threadIdx.x; e < dd; e += 64) {
-        double z = precon_entry(M3[e], zero_sum, w.w_ones + i * d, e, d);
-        w.delta_w[i * dd + e] = -z;
-        zr = __builtin_fma(z, M3[e], zr);
-    }
-    zr = wave_sum(zr);
-    for (int k = 0; k < C; ++k) {
-        lds_load(gc + ((int64_t)k * R + i) * dd, M2, d);
-        lds_symmetrize(M2, M4, d);
-        lds_congruence(M1, M2, M3, M4, d);
-        lds_symmetrize(M3, M4, d);
-        for (int e = threadIdx.x; e < dd; e += 64) w.gc_w[((int64_t)k * R + i) * dd + e] = M3[e];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        double* sc = w.scal + i * SC_COUNT;
-        sc[SC_DELTA] = delta_tr[i];
-        sc[SC_E_PE] = 0.0;
-        sc[SC_E_PD] = 0.0;
-        sc[SC_D_PD] = zr;
-        sc[SC_Z_R] = zr;
-        sc[SC_MODEL] = 0.0;
-        sc[SC_NORM_R0] = __builtin_sqrt(rr > 0.0 ? rr : 0.0);
-        sc[SC_C_FD] = 0.0;
-        w.stop[i] = TCG_MAX_INNER_ITER;
-        w.running[i] = active[i] ? 1 : 0;
-        for (int k = 0; k < C; ++k) { w.fc[i * C + k] = fc[i * C + k]; w.fcg_pe[i * C + k] = 0.0; }
-    }
+    tcg_begin(x + i * d * d, g + i * d * d, gc, fc, active[i] != 0, delta_tr[i], w, i, R, d, C, status, lds);
 }
 
-// FD point of get_hessianfd (approximate_hessian.py:30-47): c = 2^-14 / ||delta||_x, x1 = retr(x, c delta) = L expm(c delta~) L^T.
-// Restarts that are not running get x1 = x (their gradient is evaluated but not used).
 __global__ __launch_bounds__(64) void spd_tcg_fd_point_kernel(void* wsbase, double* __restrict__ x_fd, int64_t R, int d, int C) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int dd = d * d, dv = d * (d + 1) / 2;
-    double* M0 = lds;
-    double* M1 = M0 + dd;
-    double* M2 = M1 + dd;
-    double* M3 = M2 + dd;
-    double* cs = M3 + dd;
     const int64_t i = blockIdx.x;
     TcgWs w = tcg_layout(wsbase, R, d, C);
     if (i == 0 && threadIdx.x == 0) w.counters[0] = 0;       // any_running, set again by the step kernel
-    const bool run = w.running[i] != 0;
-    lds_load(w.chol + i * dd, M0, d);
-    double c = 0.0;
-    bool tiny = true;
-    if (run) {
-        const double* dl = w.delta_w + i * dd;
-        const double nrm = __builtin_sqrt(wave_dot(dl, dl, dd));
-        tiny = nrm < 1e-15;
-        c = 0.0001220703125 / (tiny ? 1.0 : nrm);             // 2^-14
-        for (int e = threadIdx.x; e < dd; e += 64) M1[e] = c * dl[e];
-        __syncthreads();
-        lds_jacobi(M1, M2, cs, d);
-        lds_fun_from_eig(M1, M2, M3, d, FN_EXP);             // E
-    } else {
-        for (int e = threadIdx.x; e < dd; e += 64) M3[e] = (e / d == e % d) ? 1.0 : 0.0;
-        __syncthreads();
-    }
-    for (int e = threadIdx.x; e < dd; e += 64) w.expm[i * dd + e] = M3[e];
-    if (threadIdx.x == 0) w.scal[i * SC_COUNT + SC_C_FD] = tiny ? -c : c;      // sign bit carries the "tiny" flag
-    lds_congruence(M0, M3, M1, M2, d);                       // x1 = L E L^T
-    for (int e = threadIdx.x; e < dv; e += 64) {
-        int k = 0;
-        while (k + 1 < d && (k + 1) * d - (k + 1) * k / 2 <= e) ++k;
-        int cc = e - (k * d - k * (k - 1) / 2);
-        int r = cc + k;
-        x_fd[i * dv + e] = (k == 0) ? M1[r * d + cc] : 0.5 * (kSqrt2 * M1[r * d + cc] + kSqrt2 * M1[cc * d + r]);
-    }
-}
-
-struct ConsStep { double cin, tau; };
-
-// violation of the linearised constraints after `step` along delta and the step that stops at Delta_cons
-// (constrained_trust_regions.py:583-640, same algebra as batched_trust_regions._tcg_step.cons_step)
-static __device__ ConsStep cons_step(double step, const double* fc, const double* fcg_pe, const double* fcg_pd, int C, int neq,
-                                     double dc2) {
-    double cin = 0.0, qa = 0.0, qb1 = 0.0, qb2 = 0.0, qc1 = 0.0, qc2 = 0.0, qc3 = 0.0;
-    for (int k = 0; k < C; ++k) {
-        double term = fc[k] + fcg_pe[k] + step * fcg_pd[k];
-        const bool ineq = k >= neq;
-        if (ineq && term > 0.0) term = 0.0;
-        cin += term * term;
-        const double m = (!ineq || term < 0.0) ? 1.0 : 0.0;
-        qa += m * fcg_pd[k] * fcg_pd[k];
-        qb1 += m * fc[k] * fcg_pd[k];
-        qb2 += m * fcg_pe[k] * fcg_pd[k];
-        qc1 += m * fc[k] * fc[k];
-        qc2 += m * fc[k] * fcg_pe[k];
-        qc3 += m * fcg_pe[k] * fcg_pe[k];
-    }
-    const double qb = 2.0 * (qb1 + qb2);
-    const double qc = qc1 + 2.0 * qc2 + qc3 - dc2;
-    const double disc = qb * qb - 4.0 * qa * qc;
-    ConsStep r;
-    r.cin = cin;
-    r.tau = disc >= 0.0 ? (-qb + __builtin_sqrt(disc)) / (2.0 * qa) : 0.0;
-    return r;
+    tcg_fd_point(w, i, d, x_fd + i * (int64_t)(d * (d + 1) / 2), lds);
 }
 
 __global__ __launch_bounds__(64) void spd_tcg_step_kernel(void* wsbase, const double* __restrict__ egrad_fd, int64_t R, int d, int C,
                                                           int neq, double delta_cons, double theta, double kappa, int mininner) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int dd = d * d;
-    double* M0 = lds;
-    double* M1 = M0 + dd;
-    double* M2 = M1 + dd;
-    double* M3 = M2 + dd;
-    double* M4 = M3 + dd;
     const int64_t i = blockIdx.x;
     TcgWs w = tcg_layout(wsbase, R, d, C);
     const int iter = w.counters[1];
-    if (i == 0 && threadIdx.x == 0) w.counters[2] = iter + 1;   // published to counters[1] by the next fd_point... see below
-    if (w.running[i] == 0) return;
-    double* sc = w.scal + i * SC_COUNT;
-    // ---- Hessian-vector product by finite differences, whitened:  Hd~ = (E L^T sym(eg1) L E - g~) / c
-    lds_load(w.chol + i * dd, M0, d);
-    lds_load(w.expm + i * dd, M1, d);
-    lds_from_mandel(egrad_fd + i * (int64_t)(d * (d + 1) / 2), M2, d);
-    lds_mm(M0, M2, M3, d, true, false);     // L^T S
-    lds_mm(M3, M0, M4, d, false, false);    // L^T S L
-    lds_mm(M1, M4, M3, d, false, false);    // E .
-    lds_mm(M3, M1, M4, d, false, false);    // E . E   = g1~
-    lds_symmetrize(M4, M3, d);
-    const double cs = sc[SC_C_FD];
-    const bool tiny = cs <= 0.0;
-    const double c = __builtin_fabs(cs);
-    const double* gw = w.g_w + i * dd;
-    double* Hd = M4;
-    double* dl = M2;
-    for (int e = threadIdx.x; e < dd; e += 64) {
-        Hd[e] = tiny ? 0.0 : Hd[e] / c - gw[e] / c;
-        dl[e] = w.delta_w[i * dd + e];
-    }
-    __syncthreads();
-    double* eta = w.eta_w + i * dd;
-    double* heta = w.heta_w + i * dd;
-    double* rw = w.r_w + i * dd;
-    const double Delta = sc[SC_DELTA], e_Pe = sc[SC_E_PE], e_Pd = sc[SC_E_PD], d_Pd = sc[SC_D_PD], z_r = sc[SC_Z_R];
-    const double dc2 = delta_cons * delta_cons;
-    const double d_Hd = wave_dot(dl, Hd, dd);
-    const bool nz = d_Hd != 0.0;
-    const double alpha = nz ? z_r / d_Hd : 0.0;
-    const double e_Pe_new = nz ? e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd : e_Pe;
-    const double Delta2 = Delta * Delta;
-    double fcl[kMaxCons], fpe[kMaxCons], fpd[kMaxCons];
-    for (int k = 0; k < C; ++k) {
-        fcl[k] = w.fc[i * C + k];
-        fpe[k] = w.fcg_pe[i * C + k];
-        fpd[k] = wave_dot(w.gc_w + ((int64_t)k * R + i) * dd, dl, dd);
-    }
-    int stop = -1;
-    double step = 0.0;       // eta += step * delta, Heta += step * Hd when leaving
-    // ---- leave through the trust-region boundary / negative curvature
-    if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {
-        double tau = (-e_Pd + __builtin_sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;
-        stop = d_Hd <= 0.0 ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;
-        if (C > 0) {
-            if (tau != tau) tau = 0.0;
-            ConsStep cst = cons_step(tau, fcl, fpe, fpd, C, neq, dc2);
-            if (cst.cin > dc2) {
-                tau = cst.tau;
-                if (d_Hd > 0.0) stop = TCG_REACHED_CONSTRAINTS;
-            }
-        }
-        step = tau;
-    } else if (C > 0) {
-        // ---- leave because the linearised constraints are reached inside the trust region
-        ConsStep cst = cons_step(alpha, fcl, fpe, fpd, C, neq, dc2);
-        if (cst.cin > dc2) { stop = TCG_REACHED_CONSTRAINTS; step = cst.tau; }
-    }
-    if (stop >= 0) {
-        for (int e = threadIdx.x; e < dd; e += 64) {
-            eta[e] = eta[e] + step * dl[e];
-            heta[e] = heta[e] + step * Hd[e];
-        }
-        if (threadIdx.x == 0) { w.stop[i] = stop; w.running[i] = 0; }
-        return;
-    }
-    // ---- tentative step; reject it if the model did not decrease
-    double* ne = M0;
-    double* nh = M1;
-    double m1 = 0.0, m2 = 0.0;
-    for (int e = threadIdx.x; e < dd; e += 64) {
-        double a = eta[e] + alpha * dl[e], b = heta[e] + alpha * Hd[e];
-        ne[e] = a;
-        nh[e] = b;
-        m1 = __builtin_fma(a, gw[e], m1);
-        m2 = __builtin_fma(a, b, m2);
-    }
-    const double new_model = wave_sum(m1) + 0.5 * wave_sum(m2);
-    if (!(new_model < sc[SC_MODEL])) {
-        if (threadIdx.x == 0) { w.stop[i] = TCG_MODEL_INCREASED; w.running[i] = 0; }
-        return;
-    }
-    double rr = 0.0;
-    double* rn = M3;
-    for (int e = threadIdx.x; e < dd; e += 64) {
-        eta[e] = ne[e];
-        heta[e] = nh[e];
-        double r = rw[e] + alpha * Hd[e];
-        rw[e] = r;
-        rn[e] = r;
-        rr = __builtin_fma(r, r, rr);
-    }
-    rr = wave_sum(rr);
-    __syncthreads();
-    const double norm_r = __builtin_sqrt(rr > 0.0 ? rr : 0.0);
-    bool running = true;
-    // ---- residual small enough
-    if (iter >= mininner) {
-        const double nr0 = sc[SC_NORM_R0];
-        const double p = pow(nr0, theta);
-        const double target = nr0 * (p < kappa ? p : kappa);
-        if (norm_r <= target) {
-            stop = kappa < p ? TCG_REACHED_TARGET_LINEAR : TCG_REACHED_TARGET_SUPERLINEAR;
-            running = false;
-        }
-    }
-    if (threadIdx.x == 0) {
-        sc[SC_MODEL] = new_model;
-        sc[SC_E_PE] = e_Pe_new;
-        if (!running) { w.stop[i] = stop; w.running[i] = 0; }
-    }
-    if (!running) return;
-    // ---- next search direction
-    lds_load(w.chol + i * dd, M0, d);
-    const bool zero_sum = unwhitened_sum(M0, rn, d) == 0.0;
-    double zr = 0.0;
-    for (int e = threadIdx.x; e < dd; e += 64) {
-        double z = precon_entry(rn[e], zero_sum, w.w_ones + i * d, e, d);
-        M1[e] = z;
-        zr = __builtin_fma(z, rn[e], zr);
-    }
-    const double z_r_new = wave_sum(zr);
-    const double beta = z_r_new / z_r;
-    for (int e = threadIdx.x; e < dd; e += 64) w.delta_w[i * dd + e] = -M1[e] + beta * dl[e];
-    if (threadIdx.x == 0) {
-        sc[SC_E_PD] = beta * (e_Pd + alpha * d_Pd);
-        sc[SC_D_PD] = z_r_new + beta * beta * d_Pd;
-        sc[SC_Z_R] = z_r_new;
-        for (int k = 0; k < C; ++k) w.fcg_pe[i * C + k] = fpe[k] + alpha * fpd[k];
-        atomicOr(w.counters, 1);
-    }
+    if (i == 0 && threadIdx.x == 0) w.counters[2] = iter + 1;   // published to counters[1] by spd_tcg_advance_kernel
+    const bool running = tcg_step(w, i, R, d, C, egrad_fd + i * (int64_t)(d * (d + 1) / 2), neq, delta_cons, theta, kappa, mininner,
+                                  iter, lds);
+    if (running && threadIdx.x == 0) atomicOr(w.counters, 1);
 }
 
 // publishes the inner-iteration index written by the step kernel (one thread; ordered by the stream)
@@ -376,27 +49,12 @@ __global__ void spd_tcg_advance_kernel(void* wsbase, int64_t R, int d, int C, in
     if (any_running_out) *any_running_out = w.counters[0];
 }
 
-// eta = L eta~ L^T, Heta = L Heta~ L^T, stop reasons
 __global__ __launch_bounds__(64) void spd_tcg_end_kernel(void* wsbase, double* __restrict__ eta, double* __restrict__ heta,
                                                          int* __restrict__ stop, int64_t R, int d, int C) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int dd = d * d;
-    double* M0 = lds;
-    double* M1 = M0 + dd;
-    double* M2 = M1 + dd;
-    double* M3 = M2 + dd;
     const int64_t i = blockIdx.x;
     TcgWs w = tcg_layout(wsbase, R, d, C);
-    lds_load(w.chol + i * dd, M0, d);
-    lds_load(w.eta_w + i * dd, M1, d);
-    lds_congruence(M0, M1, M2, M3, d);
-    lds_symmetrize(M2, M3, d);
-    lds_store(M2, eta + i * dd, d);
-    __syncthreads();
-    lds_load(w.heta_w + i * dd, M1, d);
-    lds_congruence(M0, M1, M2, M3, d);
-    lds_symmetrize(M2, M3, d);
-    lds_store(M2, heta + i * dd, d);
+    tcg_end(w, i, d, eta + i * d * d, heta + i * d * d, lds);
     if (threadIdx.x == 0) stop[i] = w.stop[i];
 }
 

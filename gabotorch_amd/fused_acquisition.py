@@ -85,6 +85,12 @@ class FusedAcquisition:
                                    self.kind, self.maximize, out_sign=-1.0, need_grad=True)
         return ops.spd_ai_backward(pts, self.train, gk, self.beta, self.mode, wrt=1)
 
+    def acq_params(self):
+        """The surrogate as the gabo_spd_acq_params struct of the C ABI (single-launch path only)."""
+        return _lib.AcqParams(self.train_factors.data_ptr(), self.alpha.data_ptr(), self.linv.data_ptr(), self.linv_t.data_ptr(),
+                              self.train.shape[0], self.beta, int(self.mode), self.mean, self.outputscale, self.kxx, self.best_f,
+                              int(self.kind), 1 if self.maximize else 0, -1.0)
+
     def _single(self, pts, need_grad, active_ptr=None, out=None):
         return ops.spd_acq_eval(pts, self.train_factors, self.alpha, self.linv, self.linv_t, self.beta, self.mode, self.mean,
                                 self.outputscale, self.kxx, self.best_f, self.kind, self.maximize, out_sign=-1.0, need_grad=need_grad,

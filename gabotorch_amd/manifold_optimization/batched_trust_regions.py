@@ -330,6 +330,23 @@ class BatchedTrustRegions:
             S.active.copy_(S.active & ~stop)
             S.any_active.copy_(S.active.any())
 
+        # d <= 12: the two parts are ONE launch each (csrc/spd_tr.hip: every wave runs its restart's whole tCG loop, proposal and
+        # acquisition evaluations by itself)
+        if getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True):
+            TR = ops.SpdTr(R, d, ncons, fused.acq_params(), fused.train.shape[0], dev)
+            S.active_u8 = S.active.view(torch.uint8)
+            inv_u8 = invalid_buf.view(torch.uint8)
+
+            def part_a(sync):       # noqa: F811
+                xp = TR.propose(S.x, S.g, S.Delta, S.active_u8, gc_buf, fc_buf, neq, Delta_cons, self.theta, self.kappa, mininner,
+                                maxinner)
+                return {"x_prop": xp}
+
+            def part_b(A):          # noqa: F811
+                TR.update(S.x, S.fx, S.g, S.ng, S.Delta, S.active_u8, S.iters, inv_u8 if strict else None, Delta_bar, self.rho_prime,
+                          self.rho_regularization, self.mingradnorm, self.maxiter)
+                S.any_active.copy_(TR.any_active[0] != 0)
+
         # Execution plan.  Eager: the parts in order, with the inner loop leaving as soon as no restart runs.  hipGraphs: the
         # launches between two evaluations of the USER's constraint callables form one graph; the callables themselves run
         # eagerly between replays (they may synchronise) unless the caller vouches for them with capture_constraints=True.

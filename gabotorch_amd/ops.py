@@ -643,6 +643,40 @@ class SpdTcg:
         return eta, heta, stop.long()
 
 
+class SpdTr:
+    """Device-resident trust-region iteration (gabo_spd_tr_propose / gabo_spd_tr_update) on persistent state tensors."""
+
+    def __init__(self, r, d, n_constraints, acq_params, n_train, device):
+        import ctypes
+        self.lib = _lib.load()
+        self.r, self.d, self.c, self.n, self.dev = int(r), int(d), int(n_constraints), int(n_train), device
+        self.acq = acq_params                      # _lib.AcqParams; the tensors it points to are owned by the caller
+        self.acq_ref = ctypes.byref(self.acq)
+        self.wsb = self.lib.gabo_spd_tr_workspace_bytes(self.r, self.d, self.c, self.n)
+        self.ws = torch.zeros(self.wsb // 8 + 1, dtype=torch.float64, device=device)
+        self.x_prop = torch.zeros(self.r, d, d, dtype=torch.float64, device=device)
+        self.any_active = torch.ones(1, dtype=torch.int32, device=device)
+        self.status = torch.zeros(2, dtype=torch.int32, device=device)
+
+    def propose(self, x, g, Delta, active, gc, fc, neq, delta_cons, theta, kappa, mininner, maxinner):
+        ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_spd_tr_propose(x.data_ptr(), g.data_ptr(), Delta.data_ptr(), active.data_ptr(), ptr(gc), ptr(fc),
+                                                    self.acq_ref, self.ws.data_ptr(), self.wsb, self.x_prop.data_ptr(), self.r, self.d,
+                                                    self.c, int(neq), float(delta_cons), float(theta), float(kappa), int(mininner),
+                                                    int(maxinner), self.any_active.data_ptr(), self.status.data_ptr(),
+                                                    _stream_ptr(self.dev)), "gabo_spd_tr_propose")
+        return self.x_prop
+
+    def update(self, x, fx, g, ng, Delta, active, iters, invalid, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter):
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_spd_tr_update(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
+                                                   active.data_ptr(), iters.data_ptr(), None if invalid is None else invalid.data_ptr(),
+                                                   self.x_prop.data_ptr(), self.ws.data_ptr(), self.r, self.d, self.c, self.n,
+                                                   float(delta_bar), float(rho_prime), float(rho_regularization), float(mingradnorm),
+                                                   int(maxiter), self.any_active.data_ptr(), _stream_ptr(self.dev)), "gabo_spd_tr_update")
+
+
 def sphere_manifold_op(op, x, u, v=None, w=None):
     """Batched sphere-manifold operation (one of _lib.GABO_SPH_*) on (..., dim) tensors."""
     lib = _lib.load()

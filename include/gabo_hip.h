@@ -188,6 +188,19 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
  *     flags GABO_OUT_GAUSSIAN or GABO_OUT_LAPLACE; active: NULL, or r ints - candidates with active[i] == 0 are skipped and their
  *     outputs left untouched (the trust regions pass the running flags of gabo_spd_tcg_*); remaining arguments as in
  *     gabo_gp_acquisition. */
+typedef struct {
+    const double* train_factors; /* gabo_spd_acq_prepare_train output, d_vec x n */
+    const double* alpha;         /* n */
+    const double* linv;          /* n x n */
+    const double* linv_t;        /* n x n */
+    int64_t n;
+    double beta;
+    int flags;                   /* GABO_OUT_GAUSSIAN / GABO_OUT_LAPLACE */
+    double mean, outputscale, kxx, best_f;
+    int kind, maximize;          /* GABO_ACQ_*, maximize != 0 */
+    double out_sign;
+} gabo_spd_acq_params;           /* the surrogate, as one argument (same fields as gabo_spd_acq_eval's scalar list) */
+
 int gabo_spd_acq_prepare_train(const double* x_train_mandel, double* train_factors, int64_t n, int d, int* status,
                                gabo_stream_t stream);
 int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const double* alpha, const double* linv,
@@ -222,6 +235,27 @@ int gabo_spd_tcg_step(void* workspace, const double* egrad_fd_mandel, int* any_r
                       int n_equalities, double delta_cons, double theta, double kappa, int mininner, gabo_stream_t stream);
 int gabo_spd_tcg_end(void* workspace, double* eta, double* heta, int* stop_reason, int64_t r, int d, int n_constraints,
                      gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * One trust-region iteration of the acquisition maximiser on S^d_++ for r restarts (one wave each), 2 <= d <= 12.
+ * Replaces one pass of the while-loop of TrustRegions.solve / ConstrainedTrustRegions.solve / StrictConstrainedTrustRegions.solve
+ * (robust_trust_regions.py:180-415, constrained_trust_regions.py:190-528, 812-1160) together with everything it calls.
+ *   propose: tCG from (x, grad = Riemannian gradient, trust_radius) under the linearised constraints, then the proposal
+ *            x_prop = retr(x, eta) (r x d x d, written for the caller: the strict variant evaluates the constraints there) and the
+ *            acquisition value / gradient at x_prop (kept in the workspace).  Restarts with active[i] == 0 are skipped.
+ *   update:  rho test against `fx`, radius update (shrink / grow up to delta_bar), acceptance (rho > rho_prime), in-place update of
+ *            x, fx, grad, grad_norm, trust_radius, iters; active[i] <- 0 when grad_norm < mingradnorm or iters >= maxiter;
+ *            *any_active = 1 while a restart remains.  invalid: NULL or r bytes (strict variant: proposal violates a constraint).
+ * The caller loops  [constraints at x] -> propose -> [constraints at x_prop] -> update  until *any_active == 0. */
+size_t gabo_spd_tr_workspace_bytes(int64_t r, int d, int n_constraints, int64_t n_train);
+int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust_radius, const uint8_t* active,
+                        const double* cons_grads, const double* cons_values, const gabo_spd_acq_params* acq, void* workspace,
+                        size_t workspace_bytes, double* x_prop, int64_t r, int d, int n_constraints, int n_equalities, double delta_cons,
+                        double theta, double kappa, int mininner, int maxinner, int* any_active, int* status, gabo_stream_t stream);
+int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
+                       const uint8_t* invalid, const double* x_prop, void* workspace, int64_t r, int d, int n_constraints,
+                       int64_t n_train, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
+                       int64_t maxiter, int* any_active, gabo_stream_t stream);
 
 /* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
  *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)

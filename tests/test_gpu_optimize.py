@@ -287,7 +287,8 @@ def test_device_solve_graph_plans_match_torch_path(strict):
     kw = dict(num_restarts=40, raw_samples=256, strict=strict)
     _, _, val_t, log_t = run_sweep(DEV, device_tcg=False, **kw)
     ref_iters = log_t["per_restart_iterations"].cpu().numpy()
-    for extra in (dict(), dict(hip_graphs=True), dict(hip_graphs=True, capture_constraints=True)):
+    for extra in (dict(), dict(hip_graphs=True), dict(hip_graphs=True, capture_constraints=True),
+                  dict(device_iteration=False), dict(device_iteration=False, hip_graphs=True)):
         _, _, val, log = run_sweep(DEV, **kw, **extra)
         np.testing.assert_allclose(val, val_t, rtol=1e-9)
         np.testing.assert_array_equal(log["per_restart_iterations"].cpu().numpy(), ref_iters)

@@ -22,15 +22,11 @@ def wrap(obj, name, label, static=False):
 for _ in range(2):
     run_sweep("cuda:0", hip_graphs=True, batched_rand=True)
 wrap(mo, "gen_batch_initial_conditions_manifold", "init_conditions")
-wrap(btr.BatchedTrustRegions, "_tcg", "tcg")
 wrap(btr.BatchedTrustRegions, "_constraint_values_grads", "constraints", static=True)
-wrap(btr.BatchedProblem, "cost", "cost")
-wrap(btr.BatchedProblem, "cost_grad", "cost_grad")
 wrap(btr.BatchedTrustRegions, "solve", "solve_total")
 wrap(mo, "gen_candidates_manifold", "gen_candidates_total")
 wrap(btr.BatchedTrustRegions, "_solve_device", "solve_device")
 wrap(torch.cuda.CUDAGraph, "replay", "graph_replay")
-wrap(torch.cuda.CUDAGraph, "capture_end", "capture_end")
 wrap(mo.FusedAcquisition, "build", "fused_build")
 import gabotorch_amd.models as models
 wrap(models.ExactGP, "_train_cache", "gp_train_cache")
