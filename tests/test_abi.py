@@ -44,3 +44,32 @@ def test_host_side_argument_errors_need_no_gpu():
     assert lib.gabo_sphere_pairwise(None, None, None, 1, 4, 4, 0, 0, 0, 1.0, 0, 0, None) == _lib.GABO_ERR_DIM
     assert lib.gabo_mandel_to_matrix(None, None, 3, 65, None) == _lib.GABO_ERR_DIM
     assert lib.gabo_mandel_to_matrix(None, None, 0, 5, None) == _lib.GABO_OK
+
+
+def test_acquisition_and_trust_region_entry_points_validate_on_the_host():
+    import ctypes
+    lib = _lib.load()
+    # fused GP acquisition: n out of range, unknown kind, empty batch
+    assert lib.gabo_gp_acquisition(None, None, None, None, None, None, 4, 0, 0.0, 1.0, 1.0, 0.0, 0, 1, 1.0, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_gp_acquisition(None, None, None, None, None, None, 4, 8, 0.0, 1.0, 1.0, 0.0, 7, 1, 1.0, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_gp_acquisition(None, None, None, None, None, None, 0, 8, 0.0, 1.0, 1.0, 0.0, 0, 1, 1.0, None) == _lib.GABO_OK
+    # single-launch SPD acquisition: d > 12 is served by the separate-launch chain, not by this entry
+    assert lib.gabo_spd_acq_eval(None, None, None, None, None, None, None, None, 4, 8, 13, 1.0, 0, 0.0, 1.0, 1.0, 0.0, 0, 1, 1.0, None, None, None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_spd_acq_eval(None, None, None, None, None, None, None, None, 4, 8, 5, 1.0, _lib.GABO_OUT_DISTANCE, 0.0, 1.0, 1.0, 0.0, 0, 1, 1.0, None, None, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_spd_acq_prepare_train(None, None, 8, 5, None, None) == _lib.GABO_ERR_ARG
+    # tCG / trust-region state machines: workspace sizes grow with every argument, bad dims and constraint counts are refused
+    w0 = lib.gabo_spd_tcg_workspace_bytes(16, 5, 0)
+    assert 0 < w0 < lib.gabo_spd_tcg_workspace_bytes(16, 5, 2) < lib.gabo_spd_tcg_workspace_bytes(17, 5, 2)
+    assert 0 < lib.gabo_spd_tcg_running_offset(16, 5, 2) < lib.gabo_spd_tcg_workspace_bytes(16, 5, 2)
+    assert lib.gabo_spd_tr_workspace_bytes(16, 5, 2, 50) > lib.gabo_spd_tcg_workspace_bytes(16, 5, 2) + 16 * 15 * 50 * 8
+    assert lib.gabo_spd_tcg_begin(None, None, None, None, None, None, None, 0, 4, 33, 0, None, None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_spd_tcg_begin(None, None, None, None, None, None, None, 0, 4, 5, 9, None, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_spd_tcg_step(None, None, None, 4, 5, 2, 3, 1e-6, 1.0, 0.1, 1, None) == _lib.GABO_ERR_ARG    # n_eq > n_constraints
+    assert lib.gabo_spd_tcg_end(None, None, None, None, 0, 5, 0, None) == _lib.GABO_OK
+    acq = _lib.AcqParams()
+    assert lib.gabo_spd_tr_propose(None, None, None, None, None, None, ctypes.byref(acq), None, 0, None, 4, 13, 0, 0, 1e-6, 1.0, 0.1, 1, 15, None, None, None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_spd_tr_propose(None, None, None, None, None, None, None, None, 0, None, 4, 5, 0, 0, 1e-6, 1.0, 0.1, 1, 15, None, None, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_spd_tr_update(None, None, None, None, None, None, None, None, None, None, 0, 5, 0, 50, 3.0, 0.1, 1e3, 1e-4, 100, None, None) == _lib.GABO_OK
+    # gradients of the Frobenius / log-Euclidean kernels
+    assert lib.gabo_frobenius_backward(None, None, None, None, 1, 4, 4, 33, 0, 0, 16, 4, 1, 1.0, 0, 1.0, None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_spd_logm_mandel_backward(None, None, None, 4, 5, None) == _lib.GABO_ERR_ARG

@@ -40,7 +40,7 @@ def test_c_abi_argument_errors_on_device():
     assert lib.gabo_spd_ai_pairwise(x.data_ptr(), x.data_ptr(), out.data_ptr(), None, 1, 2, 1, 2, 6, 6, 1.0, _lib.GABO_SYMMETRIC, ws.data_ptr(), 512, st.data_ptr(), None) == _lib.GABO_ERR_ARG
     assert lib.gabo_spd_ai_pairwise(x.data_ptr(), x.data_ptr(), out.data_ptr(), None, -1, 2, 2, 2, 6, 6, 1.0, 0, ws.data_ptr(), 512, st.data_ptr(), None) == _lib.GABO_ERR_ARG
     assert lib.gabo_spd_manifold_op(99, x.data_ptr(), None, None, None, out.data_ptr(), None, 1, 2, None, None) == _lib.GABO_ERR_ARG
-    assert lib.gabo_spd_project(x.data_ptr(), x.data_ptr(), out.data_ptr(), 1, 2, 3, None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_spd_project(x.data_ptr(), x.data_ptr(), out.data_ptr(), 1, 2, 65, None) == _lib.GABO_ERR_DIM
     assert lib.gabo_sphere_from_inner(x.data_ptr(), out.data_ptr(), 4, 1.0, 0, 3, None) == _lib.GABO_ERR_ARG
 
 
