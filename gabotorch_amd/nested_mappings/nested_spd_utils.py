@@ -5,7 +5,7 @@ from ..Riemannian_utils.spd_utils_torch import symmetric_matrix_to_vector_mandel
 
 def projection_from_spd_to_nested_spd(x_spd, projection_matrix):
     """Y = W^T X W for X (..., D, D) -> (..., d, d), computed by gabo_spd_project (Mandel in / Mandel out)."""
-    y = ops.spd_project(symmetric_matrix_to_vector_mandel_torch(x_spd.detach()), projection_matrix.detach())
+    y = ops.spd_project_diff(symmetric_matrix_to_vector_mandel_torch(x_spd), projection_matrix)
     return vector_to_symmetric_matrix_mandel_torch(y)
 
 

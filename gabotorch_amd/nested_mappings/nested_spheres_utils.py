@@ -1,0 +1,79 @@
+"""Nested-sphere projections with the reference's names and signatures (BoManifolds/nested_mappings/nested_spheres_utils.py).
+
+Per level S^d -> S^(d-1): the rotation of the axis to the north pole is ONE d x d matrix for all points, so rotating is a
+plain GEMM (torch.matmul -> rocBLAS) and the point-wise part (distance to the axis, rescaling, renormalisation with the
+reference's + 1e-6 terms) is the HIP epilogue gabo_nested_sphere_epilogue, differentiable through its HIP backward.  The
+axes stay differentiable through the rotation matrix (torch)."""
+import math
+
+import torch
+
+from .. import ops
+from ..Riemannian_utils.sphere_utils_torch import rotation_from_sphere_points_torch
+
+
+def _dist_value(sphere_distance_to_axis):
+    return float(sphere_distance_to_axis.reshape(-1)[0]) if torch.is_tensor(sphere_distance_to_axis) else float(sphere_distance_to_axis)
+
+
+def _rotation_to_north(sphere_axis, like):
+    axis = sphere_axis.unsqueeze(-2) if sphere_axis.dim() == 1 else sphere_axis
+    axis = axis.to(like.device, like.dtype)
+    north = torch.zeros_like(axis)
+    north[:, -1] = 1.0
+    return rotation_from_sphere_points_torch(axis, north)
+
+
+def projection_from_sphere_to_nested_sphere(x, sphere_axis, sphere_distance_to_axis):
+    """Points of S^d projected onto the small circle at distance `sphere_distance_to_axis` from `sphere_axis`
+    (nested_spheres_utils.py:13-65).  x: (N, d) or (..., N, d)."""
+    rot = _rotation_to_north(sphere_axis, x)
+    flat = x.reshape(-1, x.shape[-1])
+    y_rot = ops.nested_sphere_epilogue((flat @ rot.T).detach(), _dist_value(sphere_distance_to_axis), mode=1).to(x.dtype)
+    return (y_rot @ rot).reshape(x.shape)
+
+
+def projection_from_sphere_to_next_subsphere(x, sphere_axis, sphere_distance_to_axis):
+    """S^d -> S^(d-1) (nested_spheres_utils.py:68-114); differentiable in x and in the axis."""
+    rot = _rotation_to_north(sphere_axis, x)
+    flat = x.reshape(-1, x.shape[-1])
+    z = ops.nested_sphere_next(flat @ rot.T, _dist_value(sphere_distance_to_axis))
+    return z.reshape(tuple(x.shape[:-1]) + (x.shape[-1] - 1,))
+
+
+def projection_from_sphere_to_subsphere(x, sphere_axes, sphere_distances_to_axes):
+    """[x, x_{d-1}, ..., x_{d-r}] (nested_spheres_utils.py:117-146)."""
+    if not isinstance(sphere_axes, list):
+        sphere_axes = [sphere_axes]
+    if not isinstance(sphere_distances_to_axes, list):
+        sphere_distances_to_axes = [sphere_distances_to_axes]
+    x_subsphere = [x]
+    for axis, dist in zip(sphere_axes, sphere_distances_to_axes):
+        x_subsphere.append(projection_from_sphere_to_next_subsphere(x_subsphere[-1], axis, dist))
+    return x_subsphere
+
+
+def projection_from_subsphere_to_next_sphere(x_subsphere, sphere_axis, sphere_distance_to_axis):
+    """S^(d-1) -> S^d: [sin r z, cos r] rotated from the north pole to the axis (nested_spheres_utils.py:149-179).  A concatenation
+    and one small GEMM: torch on the inputs' device."""
+    axis = sphere_axis.unsqueeze(-2) if sphere_axis.dim() == 1 else sphere_axis
+    axis = axis.to(x_subsphere.device, x_subsphere.dtype)
+    north = torch.zeros_like(axis)
+    north[:, -1] = 1.0
+    rot = rotation_from_sphere_points_torch(north, axis)
+    r = _dist_value(sphere_distance_to_axis)
+    cos_vector = math.cos(r) * torch.ones(x_subsphere.shape[0], 1, dtype=x_subsphere.dtype, device=x_subsphere.device)
+    return torch.cat((math.sin(r) * x_subsphere, cos_vector), 1) @ rot.T
+
+
+def projection_from_subsphere_to_sphere(x_subsphere, sphere_axes, sphere_distances_to_axes):
+    """[x_subsphere, x_{d-r+1}, ..., x_d], axes used in reverse order (nested_spheres_utils.py:182-218)."""
+    if not isinstance(sphere_axes, list):
+        sphere_axes = [sphere_axes]
+    if not isinstance(sphere_distances_to_axes, list):
+        sphere_distances_to_axes = [sphere_distances_to_axes]
+    x = [x_subsphere]
+    nb = len(sphere_axes)
+    for s in range(nb):
+        x.append(projection_from_subsphere_to_next_sphere(x[-1], sphere_axes[nb - s - 1], sphere_distances_to_axes[nb - s - 1]))
+    return x

@@ -597,6 +597,58 @@ def spd_acq_eval(x_mandel, train_factors, alpha, linv, linv_t, beta, mode, mean,
     return value, grad
 
 
+def nested_sphere_epilogue(rotated, dist_to_axis, mode=0):
+    """Per-point part of the nested-sphere projection on already rotated points (..., d) -> (..., d-1) [mode 0] / (..., d) [mode 1]."""
+    lib = _lib.load()
+    out_device = rotated.device
+    dev = _device_for(rotated)
+    u = _prep(rotated, dev).contiguous()
+    d = u.shape[-1]
+    n = u.numel() // d
+    out = torch.empty(u.shape[:-1] + ((d - 1) if mode == 0 else d,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_nested_sphere_epilogue(u.data_ptr(), out.data_ptr(), n, d, float(dist_to_axis), int(mode), _stream_ptr(dev)),
+                   "gabo_nested_sphere_epilogue")
+    return out.to(out_device)
+
+
+def nested_sphere_epilogue_backward(rotated, grad_out, dist_to_axis):
+    lib = _lib.load()
+    out_device = rotated.device
+    dev = _device_for(rotated, grad_out)
+    u = _prep(rotated, dev).contiguous()
+    g = _prep(grad_out, dev).contiguous()
+    d = u.shape[-1]
+    gu = torch.empty_like(u)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_nested_sphere_epilogue_backward(u.data_ptr(), g.data_ptr(), gu.data_ptr(), u.numel() // d, d,
+                                                            float(dist_to_axis), _stream_ptr(dev)), "gabo_nested_sphere_epilogue_backward")
+    return gu.to(out_device)
+
+
+class _NestedSphereEpilogue(torch.autograd.Function):
+    """mode-0 epilogue, differentiable (first order) in the rotated points."""
+
+    @staticmethod
+    def forward(ctx, u, dist):
+        ctx.save_for_backward(u)
+        ctx.dist = float(dist)
+        return nested_sphere_epilogue(u, ctx.dist, 0).to(u.dtype)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (u,) = ctx.saved_tensors
+        return nested_sphere_epilogue_backward(u, g, ctx.dist).to(u.dtype), None
+
+
+def nested_sphere_next(rotated, dist_to_axis):
+    """Differentiable mode-0 epilogue."""
+    if rotated.requires_grad:
+        return _NestedSphereEpilogue.apply(rotated, float(dist_to_axis))
+    return nested_sphere_epilogue(rotated, dist_to_axis, 0)
+
+
 class SpdTcg:
     """Device-resident truncated CG of the SPD trust regions (gabo_spd_tcg_*): thin handle around the workspace."""
 

@@ -179,6 +179,21 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
                         int kind, int maximize, double out_sign, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Nested-sphere projection S^(d-1) c R^d -> next subsphere, per-point part.
+ * Replaces projection_from_sphere_to_nested_sphere / projection_from_sphere_to_next_subsphere
+ * (nested_mappings/nested_spheres_utils.py:13-114), the body of NestedSphereGaussianKernel.forward
+ * (kernel_utils/kernels_nested_sphere.py:125-152), and autograd through them.
+ * rotated: n x d, the points already rotated so that the nested sphere's axis is the north pole (U = X R^T, a plain GEMM with
+ * R = rotation_from_sphere_points_torch(axis, north), sphere_utils_torch.py:58-93).
+ *   mode 0: out n x (d-1), the points of the next subsphere  (+1e-6 regularisations of :56,105,110 included)
+ *   mode 1: out n x d, the nested-sphere points, still in the rotated frame (multiply by R to rotate back)
+ * backward (mode 0): grad_rotated n x d from grad_out n x (d-1). */
+int gabo_nested_sphere_epilogue(const double* rotated, double* out, int64_t n, int d, double dist_to_axis, int mode,
+                                gabo_stream_t stream);
+int gabo_nested_sphere_epilogue_backward(const double* rotated, const double* grad_out, double* grad_rotated, int64_t n, int d,
+                                         double dist_to_axis, gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Acquisition value and gradient at r candidate SPD points in one launch (one wave per candidate): the affine-invariant kernel
  * strip against the training set, gabo_gp_acquisition's posterior + EI / posterior mean, and the closed-form gradient back to
  * the candidate, fused.  Same reference code as gabo_spd_ai_pairwise + gabo_gp_acquisition + gabo_spd_ai_backward; exists because

@@ -93,3 +93,72 @@ def ehess2rhess(x, eg, eh, u):
 
 def transp(x, y, u):
     return proj(y, u)
+
+
+# ------------------------------------------------------------------------------- nested spheres (principal nested spheres)
+def _north(dim):
+    n = np.zeros((1, dim))
+    n[0, -1] = 1.0
+    return n
+
+
+def projection_from_sphere_to_nested_sphere(x, axis, dist_to_axis):
+    """Projection of points of S^d onto the small circle {distance to `axis` = dist_to_axis}, computed after rotating the
+    axis to the north pole and rotating back   (nested_spheres_utils.py:13-65; note the + 1e-6 in the rescaling :56-57)."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1, np.shape(x)[-1])
+    dim = x.shape[-1]
+    north = _north(dim)
+    rot = rotation_from_sphere_points(np.asarray(axis).reshape(1, -1), north)
+    xr = x @ rot.T
+    theta = sphere_distance(xr, north)                                        # (N, 1)
+    r = float(np.asarray(dist_to_axis).reshape(-1)[0])
+    y = (np.sin(r) * xr + np.sin(theta - r) * north) / (np.sin(theta) + 1e-6)
+    return y @ rot
+
+
+def projection_from_sphere_to_next_subsphere(x, axis, dist_to_axis):
+    """S^d -> S^(d-1): nested-sphere projection, rotation of the axis to the north pole, drop the last coordinate, rescale by
+    1/(sin r + 1e-6) and renormalise with another + 1e-6   (nested_spheres_utils.py:68-114)."""
+    shape = np.shape(x)
+    x = np.asarray(x, dtype=np.float64).reshape(-1, shape[-1])
+    dim = x.shape[-1]
+    rot = rotation_from_sphere_points(np.asarray(axis).reshape(1, -1), _north(dim))
+    r = float(np.asarray(dist_to_axis).reshape(-1)[0])
+    y = projection_from_sphere_to_nested_sphere(x, axis, dist_to_axis)
+    z = (y @ rot[:-1, :].T) / (np.sin(r) + 1e-6)
+    z = z / (np.linalg.norm(z, axis=-1, keepdims=True) + 1e-6)
+    return z.reshape(shape[:-1] + (dim - 1,))
+
+
+def projection_from_sphere_to_subsphere(x, axes, dists):
+    """[x, x_{d-1}, ..., x_{d-r}]   (nested_spheres_utils.py:117-146)."""
+    out = [np.asarray(x, dtype=np.float64)]
+    for a, r in zip(axes, dists):
+        out.append(projection_from_sphere_to_next_subsphere(out[-1], a, r))
+    return out
+
+
+def projection_from_subsphere_to_next_sphere(z, axis, dist_to_axis):
+    """S^(d-1) -> S^d: [sin r z, cos r] rotated from the north pole to the axis   (nested_spheres_utils.py:149-179)."""
+    z = np.asarray(z, dtype=np.float64)
+    dim = z.shape[-1] + 1
+    rot = rotation_from_sphere_points(_north(dim), np.asarray(axis).reshape(1, -1))
+    r = float(np.asarray(dist_to_axis).reshape(-1)[0])
+    lifted = np.concatenate([np.sin(r) * z, np.cos(r) * np.ones(z.shape[:-1] + (1,))], axis=-1)
+    return lifted @ rot.T
+
+
+def projection_from_subsphere_to_sphere(z, axes, dists):
+    """[z, x_{d-r+1}, ..., x_d], axes used in reverse order   (nested_spheres_utils.py:182-218)."""
+    out = [np.asarray(z, dtype=np.float64)]
+    for a, r in zip(list(axes)[::-1], list(dists)[::-1]):
+        out.append(projection_from_subsphere_to_next_sphere(out[-1], a, r))
+    return out
+
+
+def nested_sphere_gaussian_kernel(x1, x2, axes, dists, beta):
+    """exp(-beta d(p(x1), p(x2))^2)   (kernels_nested_sphere.py:125-152)."""
+    p1 = projection_from_sphere_to_subsphere(x1, axes, dists)[-1]
+    p2 = projection_from_sphere_to_subsphere(x2, axes, dists)[-1]
+    d = sphere_distance(p1, p2)
+    return np.exp(-beta * d * d)

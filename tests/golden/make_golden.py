@@ -32,6 +32,7 @@ from BoManifolds.Riemannian_utils import spd_utils_torch as sut  # noqa: E402
 from BoManifolds.Riemannian_utils import sphere_utils_torch as sphut  # noqa: E402
 from BoManifolds.Riemannian_utils import spd_constraints_utils_torch as scut  # noqa: E402
 from BoManifolds.nested_mappings import nested_spd_utils as nsu  # noqa: E402
+from BoManifolds.nested_mappings import nested_spheres_utils as nsph  # noqa: E402
 from BoManifolds.BO_test_functions import test_functions_spd as tf_spd  # noqa: E402
 from BoManifolds.BO_test_functions import test_functions_sphere as tf_sph  # noqa: E402
 from BoManifolds.pymanopt_addons.tools import multi as ref_multi  # noqa: E402
@@ -336,6 +337,50 @@ def gen_objectives():
     np.savez_compressed(os.path.join(HERE, "objectives.npz"), **out)
 
 
+def gen_nested_sphere():
+    """f3: nested-sphere projections (nested_spheres_utils.py:13-218) and the op sequence of NestedSphereGaussianKernel.forward
+    (kernels_nested_sphere.py:125-152), with autograd gradients with respect to the inputs and the axes."""
+    out = {}
+    rng = np.random.default_rng(41)
+    for tag, dim, latent, dist in (("a", 5, 3, np.pi / 2), ("b", 6, 2, np.pi / 4), ("c", 4, 3, 1.1)):
+        n1, n2 = 7, 5
+        x1 = rng.standard_normal((n1, dim)); x1 /= np.linalg.norm(x1, axis=1, keepdims=True)
+        x2 = rng.standard_normal((n2, dim)); x2 /= np.linalg.norm(x2, axis=1, keepdims=True)
+        axes = []
+        for d in range(dim, latent, -1):
+            a = rng.standard_normal((1, d)); a /= np.linalg.norm(a)
+            axes.append(a)
+        dists = [torch.tensor([[dist]], dtype=torch.float64) for _ in axes]
+        beta = 0.9
+        gup = rng.standard_normal((n1, n2))
+        t1 = torch.tensor(x1, requires_grad=True)
+        t2 = torch.tensor(x2, requires_grad=True)
+        tax = [torch.tensor(a, requires_grad=True) for a in axes]
+        levels1 = nsph.projection_from_sphere_to_subsphere(t1, tax, dists)
+        levels2 = nsph.projection_from_sphere_to_subsphere(t2, tax, dists)
+        dd = sphut.sphere_distance_torch(levels1[-1], levels2[-1])
+        K = torch.exp(-dd * dd * beta)
+        (K * torch.tensor(gup)).sum().backward()
+        out.update({f"{tag}_x1": x1, f"{tag}_x2": x2, f"{tag}_dist": np.array(dist), f"{tag}_beta": np.array(beta), f"{tag}_gup": gup,
+                    f"{tag}_K": K.detach().numpy(), f"{tag}_g1": t1.grad.numpy(), f"{tag}_g2": t2.grad.numpy(),
+                    f"{tag}_nlevels": np.array(len(axes))})
+        for k, a in enumerate(axes):
+            out[f"{tag}_axis{k}"] = a
+            out[f"{tag}_gaxis{k}"] = tax[k].grad.numpy()
+        for k, lv in enumerate(levels1):
+            out[f"{tag}_level{k}"] = lv.detach().numpy()
+        # first level: the nested-sphere point in the ambient sphere, and the rotation it uses
+        nested = nsph.projection_from_sphere_to_nested_sphere(torch.tensor(x1), torch.tensor(axes[0]), dists[0])
+        north = torch.zeros(1, dim, dtype=torch.float64); north[:, -1] = 1.0
+        out[f"{tag}_nested0"] = nested.numpy()
+        out[f"{tag}_rot0"] = sphut.rotation_from_sphere_points_torch(torch.tensor(axes[0]), north).numpy()
+        # back projection from the latent sphere to the ambient one
+        back = nsph.projection_from_subsphere_to_sphere(levels1[-1].detach(), [torch.tensor(a) for a in axes], dists)
+        for k, b in enumerate(back):
+            out[f"{tag}_back{k}"] = b.numpy()
+    np.savez_compressed(os.path.join(HERE, "nested_sphere.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     gen_spd_ai()
@@ -343,6 +388,7 @@ if __name__ == "__main__":
     gen_sphere()
     gen_spd_maps()
     gen_nested()
+    gen_nested_sphere()
     gen_letters()
     gen_objectives()
     for f in sorted(os.listdir(HERE)):

@@ -157,3 +157,51 @@ def test_nested_back_projection_golden(golden):
     np.testing.assert_allclose(again.cpu().numpy(), g["back_ylow"], rtol=1e-9, atol=1e-10)
     one = projection_from_nested_spd_to_spd(t(g["back_ylow"][0]), t(g["back_W"]), t(g["back_V"]), t(g["back_bottom"]), t(g["back_K"]))
     assert one.shape == (5, 5)
+
+
+def test_nested_sphere_projections_and_kernel_golden(golden):
+    """f3: nested-sphere projection chain, back projection, NestedSphereGaussianKernel and its gradients with respect to the inputs
+    AND the axes, against vectors produced by the reference (autograd)."""
+    from gabotorch_amd.kernel_utils.kernels_nested_sphere import NestedSphereGaussianKernel
+    from gabotorch_amd.nested_mappings import nested_spheres_utils as nsu
+    from gabotorch_amd.Riemannian_utils.sphere_utils_torch import rotation_from_sphere_points_torch
+    g = golden("nested_sphere.npz")
+    for tag in "abc":
+        nl = int(g[f"{tag}_nlevels"])
+        dist = float(g[f"{tag}_dist"])
+        x1 = torch.tensor(g[f"{tag}_x1"], device=DEV, requires_grad=True)
+        x2 = torch.tensor(g[f"{tag}_x2"], device=DEV, requires_grad=True)
+        axes = [torch.tensor(g[f"{tag}_axis{k}"], device=DEV, requires_grad=True) for k in range(nl)]
+        dists = [torch.tensor([[dist]], dtype=torch.float64) for _ in range(nl)]
+        dim = x1.shape[1]
+        north = torch.zeros(1, dim, dtype=torch.float64, device=DEV)
+        north[:, -1] = 1.0
+        np.testing.assert_allclose(rotation_from_sphere_points_torch(axes[0].detach(), north).cpu().numpy(), g[f"{tag}_rot0"], atol=1e-14)
+        np.testing.assert_allclose(nsu.projection_from_sphere_to_nested_sphere(x1.detach(), axes[0].detach(), dists[0]).cpu().numpy(),
+                                   g[f"{tag}_nested0"], atol=1e-12)
+        lv1 = nsu.projection_from_sphere_to_subsphere(x1, axes, dists)
+        lv2 = nsu.projection_from_sphere_to_subsphere(x2, axes, dists)
+        for k, lv in enumerate(lv1):
+            np.testing.assert_allclose(lv.detach().cpu().numpy(), g[f"{tag}_level{k}"], atol=1e-12)
+        back = nsu.projection_from_subsphere_to_sphere(lv1[-1].detach(), [a.detach() for a in axes], dists)
+        for k, b in enumerate(back):
+            np.testing.assert_allclose(b.cpu().numpy(), g[f"{tag}_back{k}"], atol=1e-12)
+        beta = float(g[f"{tag}_beta"])
+        K = ops.sphere_kernel(lv1[-1], lv2[-1], beta)
+        np.testing.assert_allclose(K.detach().cpu().numpy(), g[f"{tag}_K"], rtol=1e-10)
+        (K * torch.tensor(g[f"{tag}_gup"], device=DEV)).sum().backward()
+        np.testing.assert_allclose(x1.grad.cpu().numpy(), g[f"{tag}_g1"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(x2.grad.cpu().numpy(), g[f"{tag}_g2"], rtol=1e-8, atol=1e-10)
+        for k in range(nl):
+            np.testing.assert_allclose(axes[k].grad.cpu().numpy(), g[f"{tag}_gaxis{k}"], rtol=1e-7, atol=1e-9)
+    # the kernel class (distances fixed at pi/2 as in the reference): case "a" used pi/2
+    kern = NestedSphereGaussianKernel(dim=5, latent_dim=3, beta_min=0.1).double()
+    kern.axes = [torch.tensor(g[f"a_axis{k}"]) for k in range(2)]
+    kern.beta = torch.tensor(float(g["a_beta"]), dtype=torch.float64)      # (a python float would pass through fp32, as in the reference)
+    xa, xb = torch.tensor(g["a_x1"], device=DEV, requires_grad=True), torch.tensor(g["a_x2"], device=DEV)
+    Kc = kern.forward(xa, xb)
+    np.testing.assert_allclose(Kc.detach().cpu().numpy(), g["a_K"], rtol=1e-10)
+    (Kc * torch.tensor(g["a_gup"], device=DEV)).sum().backward()
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), g["a_g1"], rtol=1e-8, atol=1e-10)
+    assert kern.raw_axis_S5.grad is not None and kern.raw_beta.grad is not None
+    np.testing.assert_allclose(kern.raw_axis_S5.grad.numpy(), g["a_gaxis0"] , rtol=1e-6, atol=1e-8)

@@ -136,3 +136,22 @@ def test_log_euclidean_kernel_and_gradients(golden):
         g1, g2 = ospd.log_euclidean_gaussian_kernel_grads(x1, x2, ls, g[f"le{d}_gup"])
         np.testing.assert_allclose(g1, g[f"le{d}_g1"], rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(g2, g[f"le{d}_g2"], rtol=1e-8, atol=1e-10)
+
+
+def test_nested_sphere_projections_and_kernel(golden):
+    g = golden("nested_sphere.npz")
+    for tag in "abc":
+        nl = int(g[f"{tag}_nlevels"])
+        axes = [g[f"{tag}_axis{k}"] for k in range(nl)]
+        dists = [float(g[f"{tag}_dist"])] * nl
+        np.testing.assert_allclose(osph.rotation_from_sphere_points(axes[0], np.eye(axes[0].shape[1])[-1:]), g[f"{tag}_rot0"], atol=1e-14)
+        np.testing.assert_allclose(osph.projection_from_sphere_to_nested_sphere(g[f"{tag}_x1"], axes[0], dists[0]), g[f"{tag}_nested0"],
+                                   atol=1e-13)
+        levels = osph.projection_from_sphere_to_subsphere(g[f"{tag}_x1"], axes, dists)
+        for k, lv in enumerate(levels):
+            np.testing.assert_allclose(lv, g[f"{tag}_level{k}"], atol=1e-13)
+        back = osph.projection_from_subsphere_to_sphere(levels[-1], axes, dists)
+        for k, b in enumerate(back):
+            np.testing.assert_allclose(b, g[f"{tag}_back{k}"], atol=1e-13)
+        np.testing.assert_allclose(osph.nested_sphere_gaussian_kernel(g[f"{tag}_x1"], g[f"{tag}_x2"], axes, dists, float(g[f"{tag}_beta"])),
+                                   g[f"{tag}_K"], rtol=1e-11)
