@@ -18,19 +18,31 @@ from .kernel_utils import kernels_spd, kernels_sphere
 from .Riemannian_utils import spd_utils_torch
 
 
+def _surrogate_view(gp):
+    """(base kernel, outputscale, constant mean, (L^-1, alpha), train_x) of a built-in surrogate in prediction mode, else None."""
+    from ._compat import ScaleKernel
+    if type(gp) is models.ExactGP:
+        return gp.base_kernel, float(gp.outputscale), float(gp.mean), gp._train_cache(), gp.train_x
+    if type(gp) is models.SingleTaskGP:
+        cm = gp.covar_module
+        base, outputscale = (cm.base_kernel, float(cm.outputscale.detach())) if type(cm) is ScaleKernel else (cm, 1.0)
+        linv, alpha, mu = gp._ensure_cache()
+        return base, outputscale, float(mu), (linv, alpha), gp.train_x
+    return None
+
+
 class FusedAcquisition:
     def __init__(self, acq, family, mode, beta, matrix_input, device):
-        gp = acq.model
+        base, outputscale, mean, (linv, alpha), train_x = _surrogate_view(acq.model)
         self.family, self.mode, self.beta, self.matrix_input = family, mode, beta, matrix_input
         self.kind = _lib.GABO_ACQ_EXPECTED_IMPROVEMENT if isinstance(acq, models.ExpectedImprovement) else _lib.GABO_ACQ_POSTERIOR_MEAN
         self.maximize = bool(acq.maximize)
         self.best_f = float(getattr(acq, "best_f", 0.0))
-        self.mean, self.outputscale = gp.mean, gp.outputscale
-        linv, alpha = gp._train_cache()
+        self.mean, self.outputscale = mean, outputscale
         self.linv = linv.to(device).contiguous()
         self.linv_t = self.linv.t().contiguous()
         self.alpha = alpha.to(device).contiguous()
-        self.train = gp.train_x.to(device).contiguous()
+        self.train = train_x.to(device).contiguous()
         # d <= 12: value + gradient in ONE launch per evaluation (csrc/spd_acq.hip); the training side is factored once here
         self.single_launch = (family == "spd" and self.train.shape[-1] <= _lib.GABO_SPD_REG_MAX_DIM * (_lib.GABO_SPD_REG_MAX_DIM + 1) // 2
                               and self.train.shape[0] <= 2048)
@@ -48,10 +60,10 @@ class FusedAcquisition:
         """-> FusedAcquisition, or None when the acquisition / surrogate / kernel / post-processing is not a built-in."""
         if not isinstance(acq, (models.ExpectedImprovement, models.PosteriorMean)):
             return None
-        gp = getattr(acq, "model", None)
-        if type(gp) is not models.ExactGP:
+        view = _surrogate_view(getattr(acq, "model", None))
+        if view is None:
             return None
-        k = gp.base_kernel
+        k = view[0]
         if type(k) in (kernels_spd.SpdAffineInvariantGaussianKernel, kernels_spd.SpdAffineInvariantLaplaceKernel):
             if post_processing is not spd_utils_torch.symmetric_matrix_to_vector_mandel_torch:
                 return None

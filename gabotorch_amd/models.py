@@ -228,10 +228,8 @@ class SingleTaskGP(torch.nn.Module):
     def invalidate(self):
         self._cache = None
 
-    def posterior(self, X):
-        if X.dim() == 2:
-            X = X.unsqueeze(-2)
-        b = X.shape[0]
+    def _ensure_cache(self):
+        """(L^-1, alpha, mean) of the fitted model; freezes the kernel hyper-parameters (prediction mode)."""
         if self._cache is None:
             with torch.no_grad():
                 L = torch.linalg.cholesky(self._kxx())
@@ -239,9 +237,15 @@ class SingleTaskGP(torch.nn.Module):
                 alpha = torch.cholesky_solve((self.train_y.to(L.device) - mu).unsqueeze(-1), L).squeeze(-1)
                 Linv = torch.linalg.solve_triangular(L, torch.eye(L.shape[-1], dtype=L.dtype, device=L.device), upper=False)
             self._cache = (Linv, alpha, mu)
-        Linv, alpha, mu = self._cache
         for p in self.covar_module.parameters():
             p.requires_grad_(False)
+        return self._cache
+
+    def posterior(self, X):
+        if X.dim() == 2:
+            X = X.unsqueeze(-2)
+        b = X.shape[0]
+        Linv, alpha, mu = self._ensure_cache()
         xt = self.train_x.to(X.device).expand(b, *self.train_x.shape)
         ks = self.covar_module.forward(X, xt).squeeze(-2)
         kss = self.covar_module.forward(X, X).reshape(b)

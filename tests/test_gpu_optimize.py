@@ -293,3 +293,28 @@ def test_device_solve_graph_plans_match_torch_path(strict):
         np.testing.assert_allclose(val, val_t, rtol=1e-9)
         np.testing.assert_array_equal(log["per_restart_iterations"].cpu().numpy(), ref_iters)
         np.testing.assert_allclose(log["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-8, atol=1e-12)
+
+
+def test_fused_acquisition_on_trainable_surrogate():
+    """SingleTaskGP(ScaleKernel(SpdAffineInvariantGaussianKernel)) - the surrogate of the reference examples (gabo_spd.py:165-176) -
+    takes the same fused chain once fitted."""
+    from gabotorch_amd._compat import ScaleKernel
+    from gabotorch_amd.fused_acquisition import FusedAcquisition
+    d = 3
+    rng, X, y = _spd_gp(d, n_train=15, seed=9)
+    kern = ScaleKernel(SpdAffineInvariantGaussianKernel(beta_min=0.5), outputscale_prior=models.GammaPrior(2.0, 0.15))
+    gp = models.SingleTaskGP(t(X), t((y - y.mean()) / y.std()), kern, noise_prior=models.GammaPrior(1.1, 0.05))
+    models.fit_gpytorch_model(gp, maxiter=20)
+    acq = models.ExpectedImprovement(gp, best_f=float(gp.train_y.min()), maximize=False)
+    post = symmetric_matrix_to_vector_mandel_torch
+    fused = FusedAcquisition.build(acq, post, torch.device(DEV))
+    assert fused is not None and fused.single_launch
+    q = np.linalg.qr(rng.standard_normal((33, d, d)))[0]
+    P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (33, d)), q)
+    x = t(0.5 * (P + P.transpose(0, 2, 1)))
+    xx = x.clone().requires_grad_(True)
+    f_ref = -acq(post(xx)[:, None])
+    (g_ref,) = torch.autograd.grad(f_ref.sum(), xx)
+    f, g = fused.cost_egrad(x)
+    np.testing.assert_allclose(f.cpu().numpy(), f_ref.detach().cpu().numpy(), rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-7, atol=1e-10 * max(1.0, float(g_ref.abs().max())))
