@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
+from ..manifold_optimization.host_manifolds import Sphere as HostSphere
 from ..nested_mappings.nested_spheres_utils import projection_from_sphere_to_subsphere
 from .kernels_spd import _BetaKernel
 
@@ -18,6 +19,7 @@ class NestedSphereGaussianKernel(_BetaKernel):
             axis = torch.randn(1, d)
             axis = axis / torch.norm(axis)
             self.register_parameter(name="raw_axis_S" + str(d), parameter=torch.nn.Parameter(axis.repeat(*self.batch_shape, 1, 1)))
+            setattr(self, "raw_axis_S" + str(d) + "_manifold", HostSphere(d))        # kernels_nested_sphere.py:88-90
         # distance to each axis fixed at pi/2: great subspheres  (kernels_nested_sphere.py:93-94)
         self.distances_to_axis = [np.pi / 2 * torch.ones(1, 1) for _ in range(self.dim, self.latent_dim, -1)]
 

@@ -104,6 +104,8 @@ class NestedSpdAffineInvariantGaussianKernel(_BetaKernel):
         self.dim, self.latent_dim = dim, latent_dim
         q, _ = torch.linalg.qr(torch.randn(dim, latent_dim, dtype=torch.float64))
         self.register_parameter(name="raw_projection_matrix", parameter=torch.nn.Parameter(q.repeat(*self.batch_shape, 1, 1)))
+        from ..manifold_optimization.host_manifolds import Grassmann
+        self.raw_projection_matrix_manifold = Grassmann(dim, latent_dim)          # kernels_nested_spd.py:75,175
 
     @property
     def projection_matrix(self):
@@ -130,6 +132,8 @@ class NestedSpdLogEuclideanGaussianKernel(SpdLogEuclideanGaussianKernel):
         self.dim, self.latent_dim = dim, latent_dim
         q, _ = torch.linalg.qr(torch.randn(dim, latent_dim, dtype=torch.float64))
         self.register_parameter(name="raw_projection_matrix", parameter=torch.nn.Parameter(q.repeat(*self.batch_shape, 1, 1)))
+        from ..manifold_optimization.host_manifolds import Grassmann
+        self.raw_projection_matrix_manifold = Grassmann(dim, latent_dim)          # kernels_nested_spd.py:75,175
 
     @property
     def projection_matrix(self):

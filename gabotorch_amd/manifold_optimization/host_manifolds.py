@@ -1,0 +1,143 @@
+"""Host-side (numpy) manifolds for the GP HYPER-PARAMETERS: the handful of numbers the surrogate fit moves on a product of
+Euclidean spaces, spheres (nested-sphere axes) and a Grassmannian (nested-SPD projection matrix) - the objects the reference
+takes from pymanopt in manifold_gp_fit.py:163-173 ([3P] pymanopt 0.2.x semantics restated from memory).
+They never see the data: the marginal likelihood and its gradient, where the time goes, run through the HIP kernels."""
+import numpy as np
+
+
+class Euclidean:
+    def __init__(self, *shape):
+        self._shape = tuple(shape)
+        self.dim = int(np.prod(shape))
+        self.typicaldist = float(np.sqrt(self.dim))
+
+    def inner(self, x, u, v):
+        return float(np.tensordot(u, v, axes=u.ndim))
+
+    def norm(self, x, u):
+        return float(np.linalg.norm(u))
+
+    def proj(self, x, u):
+        return u
+
+    egrad2rgrad = proj
+
+    def retr(self, x, u):
+        return x + u
+
+    exp = retr
+
+    def transp(self, x1, x2, u):
+        return u
+
+    def rand(self):
+        return np.random.randn(*self._shape)
+
+    def zerovec(self, x):
+        return np.zeros(self._shape)
+
+
+class Sphere:
+    """Unit sphere of R^n, points of shape (n,)."""
+
+    def __init__(self, n):
+        self._shape = (n,)
+        self.dim = n - 1
+        self.typicaldist = np.pi
+
+    def inner(self, x, u, v):
+        return float(np.dot(u.reshape(-1), v.reshape(-1)))
+
+    def norm(self, x, u):
+        return float(np.linalg.norm(u))
+
+    def proj(self, x, u):
+        return u - np.dot(x.reshape(-1), u.reshape(-1)) * x
+
+    egrad2rgrad = proj
+
+    def retr(self, x, u):
+        y = x + u
+        return y / np.linalg.norm(y)
+
+    def transp(self, x1, x2, u):
+        return self.proj(x2, u)
+
+    def rand(self):
+        y = np.random.randn(*self._shape)
+        return y / np.linalg.norm(y)
+
+    def zerovec(self, x):
+        return np.zeros(self._shape)
+
+
+class Grassmann:
+    """Subspaces of dimension p of R^n represented by orthonormal n x p matrices."""
+
+    def __init__(self, n, p):
+        self._n, self._p = n, p
+        self._shape = (n, p)
+        self.dim = n * p - p * p
+        self.typicaldist = float(np.sqrt(p))
+
+    def inner(self, x, u, v):
+        return float(np.tensordot(u, v, axes=2))
+
+    def norm(self, x, u):
+        return float(np.linalg.norm(u))
+
+    def proj(self, x, u):
+        return u - x @ (x.T @ u)
+
+    egrad2rgrad = proj
+
+    def retr(self, x, u):
+        # polar retraction: the orthonormal factor of x + u
+        uu, _, vt = np.linalg.svd(x + u, full_matrices=False)
+        return uu @ vt
+
+    def transp(self, x1, x2, u):
+        return self.proj(x2, u)
+
+    def rand(self):
+        q, _ = np.linalg.qr(np.random.randn(self._n, self._p))
+        return q
+
+    def zerovec(self, x):
+        return np.zeros(self._shape)
+
+
+class Product:
+    """Product manifold: points and tangent vectors are lists, one entry per factor."""
+
+    def __init__(self, manifolds):
+        self._manifolds = list(manifolds)
+        self.dim = int(sum(m.dim for m in self._manifolds))
+        self.typicaldist = float(np.sqrt(sum(m.typicaldist ** 2 for m in self._manifolds)))
+
+    def _map(self, name, *args):
+        return [getattr(m, name)(*[a[k] for a in args]) for k, m in enumerate(self._manifolds)]
+
+    def inner(self, x, u, v):
+        return float(sum(self._map("inner", x, u, v)))
+
+    def norm(self, x, u):
+        return float(np.sqrt(max(self.inner(x, u, u), 0.0)))
+
+    def proj(self, x, u):
+        return self._map("proj", x, u)
+
+    def egrad2rgrad(self, x, u):
+        return self._map("egrad2rgrad", x, u)
+
+    def retr(self, x, u):
+        return self._map("retr", x, u)
+
+    def transp(self, x1, x2, u):
+        return self._map("transp", x1, x2, u)
+
+    def rand(self):
+        return [m.rand() for m in self._manifolds]
+
+    def zerovec(self, x):
+        return self._map("zerovec", x)

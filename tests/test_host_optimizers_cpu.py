@@ -1,0 +1,63 @@
+"""Host-side pieces of the surrogate fit (manifold_gp_fit.py in the reference): numpy manifolds and Riemannian conjugate gradients.
+No GPU needed: they only ever move hyper-parameters."""
+import numpy as np
+
+from gabotorch_amd.manifold_optimization.conjugate_gradient import ConjugateGradient
+from gabotorch_amd.manifold_optimization.host_manifolds import Euclidean, Grassmann, Product, Sphere
+
+
+class _Problem:
+    def __init__(self, manifold, cost, egrad):
+        self.manifold, self.cost, self._egrad = manifold, cost, egrad
+
+    def grad(self, x):
+        return self.manifold.egrad2rgrad(x, self._egrad(x))
+
+
+def test_manifold_axioms():
+    np.random.seed(0)
+    for man in (Sphere(6), Grassmann(7, 3), Euclidean(4)):
+        x = man.rand()
+        u = man.proj(x, np.random.randn(*man._shape))
+        v = man.proj(x, np.random.randn(*man._shape))
+        np.testing.assert_allclose(man.proj(x, u), u, atol=1e-14)                       # projection is idempotent
+        y = man.retr(x, 0.3 * u)
+        if isinstance(man, Sphere):
+            assert abs(np.linalg.norm(y) - 1) < 1e-14 and abs(np.dot(x, u)) < 1e-14
+        if isinstance(man, Grassmann):
+            np.testing.assert_allclose(y.T @ y, np.eye(3), atol=1e-13)
+            np.testing.assert_allclose(x.T @ u, 0, atol=1e-13)
+        w = man.transp(x, y, v)
+        np.testing.assert_allclose(man.proj(y, w), w, atol=1e-13)                       # transported vector is tangent at y
+        assert abs(man.inner(x, u, v) - man.inner(x, v, u)) < 1e-14
+        # first-order retraction: retr(x, t u) = x + t u + O(t^2)
+        t = 1e-6
+        np.testing.assert_allclose((man.retr(x, t * u) - x) / t, u, atol=1e-5)
+
+
+def test_conjugate_gradient_rayleigh_quotient_on_sphere():
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((8, 8))
+    a = a + a.T
+    man = Sphere(8)
+    np.random.seed(1)
+    x, log = ConjugateGradient(maxiter=500, mingradnorm=1e-9).solve(_Problem(man, lambda x: float(x @ a @ x), lambda x: 2 * a @ x))
+    lam = np.linalg.eigvalsh(a)
+    assert abs(log["final_cost"] - lam[0]) < 1e-9 and abs(np.linalg.norm(x) - 1) < 1e-12
+    assert all(b <= a_ + 1e-12 for a_, b in zip(log["cost_history"], log["cost_history"][1:]))      # monotone decrease
+
+
+def test_conjugate_gradient_dominant_subspace_on_product():
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((9, 9))
+    a = a @ a.T
+    target = rng.standard_normal(3)
+    man = Product([Grassmann(9, 2), Euclidean(3)])
+    cost = lambda x: float(-np.trace(x[0].T @ a @ x[0]) + np.sum((x[1] - target) ** 2))            # noqa: E731
+    egrad = lambda x: [-2 * a @ x[0], 2 * (x[1] - target)]                                           # noqa: E731
+    np.random.seed(2)
+    x, log = ConjugateGradient(maxiter=2000, mingradnorm=1e-8).solve(_Problem(man, cost, egrad))
+    lam = np.linalg.eigvalsh(a)
+    assert abs(-log["final_cost"] - (lam[-1] + lam[-2])) < 1e-6
+    np.testing.assert_allclose(x[1], target, atol=1e-6)
+    np.testing.assert_allclose(x[0].T @ x[0], np.eye(2), atol=1e-12)
