@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""High-dimensional GaBO on S^D_++ through a nested S^d_++ (the data flow of the reference's examples/hd_gabo_spd.py) on the MI355X:
-observations live on S^D_++; they are projected to the latent S^d_++ with Y = W^T X W (gabo_spd_project), a GP with the
-affine-invariant kernel is fitted on the latent points, EI is maximised ON THE LATENT MANIFOLD with the strict constrained trust
-regions (eigenvalue box, FD Hessian), and the winner is lifted back with projection_from_nested_spd_to_spd.
+"""High-dimensional GaBO on S^D_++ through a nested S^d_++ (the data flow of the reference's examples/hd_gabo_spd.py:163-290) on the
+MI355X: a GP with the nested log-Euclidean kernel is fitted on the HIGH-dimensional observations with fit_gpytorch_manifold -
+which LEARNS the projection W on the Grassmannian together with the Euclidean hyper-parameters (conjugate gradients, 20 initial
+candidates, as hd_gabo_spd.py:205) -, the data are projected with Y = W^T X W, a latent GP with the log-Euclidean kernel and the
+same hyper-parameters is built on them, EI is maximised ON THE LATENT MANIFOLD with the strict constrained trust regions
+(eigenvalue box, FD Hessian), and the winner is lifted back with projection_from_nested_spd_to_spd.
 
-Scope note: the reference also LEARNS the projection W (GP fit on a product manifold with pymanopt's conjugate gradient) and the
-reconstruction parameters (augmented Lagrangian); those host-side optimisers are outside this repository's hot path,
-so W, the bottom block and the contraction are fixed here.
+Scope note: the reference additionally optimises the reconstruction parameters (complement basis, bottom block, contraction) with
+an augmented-Lagrangian solver (nested_spd_optimization.py:95-186); that host-side optimiser is not part of this repository
+(SURVEY 8f-4), so the complement is the orthogonal complement of the learnt W, the bottom block is I and the contraction is 0.
 
     python examples/hd_gabo_spd.py [--dim 5] [--latent 2] [--iters 10]
 """
@@ -22,7 +24,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gabotorch_amd import manifolds, models, ops                                                                 # noqa: E402
 from gabotorch_amd._compat import ScaleKernel                                                                     # noqa: E402
 from gabotorch_amd.BO_test_functions.test_functions import rosenbrock_function_spd                                # noqa: E402
-from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel                               # noqa: E402
+from gabotorch_amd.kernel_utils.kernels_spd import NestedSpdLogEuclideanGaussianKernel, SpdLogEuclideanGaussianKernel    # noqa: E402
+from gabotorch_amd.manifold_optimization.conjugate_gradient import ConjugateGradient                              # noqa: E402
+from gabotorch_amd.manifold_optimization.manifold_gp_fit import fit_gpytorch_manifold                             # noqa: E402
 from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions                         # noqa: E402
 from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold                         # noqa: E402
 from gabotorch_amd.nested_mappings.nested_spd_utils import projection_from_nested_spd_to_spd                      # noqa: E402
@@ -33,7 +37,7 @@ from gabotorch_amd.Riemannian_utils.spd_utils_torch import (symmetric_matrix_to_
                                                             vector_to_symmetric_matrix_mandel_torch)
 
 
-def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:0", verbose=True):
+def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:0", verbose=True, fit_iters=50):
     np.random.seed(seed)
     torch.manual_seed(seed)
     big = manifolds.PositiveDefinite(dim)
@@ -42,9 +46,6 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
     small = manifolds.PositiveDefinite(latent)
     small.min_eig, small.max_eig = 0.1, 5.0
     small.rand = types.MethodType(spd_sample, small)
-    R = np.linalg.qr(np.random.randn(dim, dim))[0]
-    W = torch.tensor(R[:, :latent], device=device)
-    V = torch.tensor(R[:, latent:], device=device)
     bottom = torch.eye(dim - latent, dtype=torch.float64, device=device)
     contraction = torch.zeros(latent, dim - latent, dtype=torch.float64, device=device)
     objective = lambda x: rosenbrock_function_spd(x, big)          # noqa: E731  evaluated on the HIGH-dimensional manifold
@@ -52,14 +53,21 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
     y_data = torch.cat([objective(x) for x in x_data]).reshape(-1).to(device)
     cons = [lambda x: max_eigenvalue_constraint_torch(x, small.max_eig), lambda x: min_eigenvalue_constraint_torch(x, small.min_eig)]
     solver = BatchedTrustRegions(mingradnorm=2e-4, maxiter=100, minstepsize=1e-4, strict_constraints=True)   # hd_gabo_spd.py:194
+    k_fct = ScaleKernel(NestedSpdLogEuclideanGaussianKernel(dim, latent), outputscale_prior=models.GammaPrior(2.0, 0.15)).double()
     ops.set_error_checking(False)
     best = [float(y_data.min())]
     for it in range(iters):
+        y_std = (y_data - y_data.mean()) / (y_data.std() + 1e-12)
+        model = models.SingleTaskGP(x_data, y_std, k_fct, noise_prior=models.GammaPrior(1.1, 0.05))
+        fit_gpytorch_manifold(model, solver=ConjugateGradient(maxiter=fit_iters), nb_init_candidates=20)           # :205
+        W = k_fct.base_kernel.projection_matrix.detach().clone().to(device)
+        V = torch.linalg.svd(W, full_matrices=True)[0][:, latent:]                  # orthonormal complement of span(W)
         z_data = ops.spd_project(x_data, W)                                          # latent Mandel vectors, one launch
-        kern = ScaleKernel(SpdAffineInvariantGaussianKernel(beta_min=0.6), outputscale_prior=models.GammaPrior(2.0, 0.15))
-        gp = models.SingleTaskGP(z_data, (y_data - y_data.mean()) / (y_data.std() + 1e-12), kern, noise_prior=models.GammaPrior(1.1, 0.05))
-        models.fit_gpytorch_model(gp)
-        acq = models.ExpectedImprovement(gp, best_f=float(gp.train_y.min()), maximize=False)
+        latent_kernel = SpdLogEuclideanGaussianKernel().double()
+        latent_kernel.lengthscale = k_fct.base_kernel.lengthscale.detach().clone()   # same hyper-parameters (:217-219)
+        gp = models.ExactGP(z_data, y_std, latent_kernel, outputscale=float(k_fct.outputscale.detach()), noise=float(model.noise.detach()),
+                            mean=float(model.mean_constant.detach()))
+        acq = models.ExpectedImprovement(gp, best_f=float(y_std.min()), maximize=False)
         z_new = joint_optimize_manifold(acq, small, solver, q=1, num_restarts=restarts, raw_samples=raw, bounds=None,
                                         options={"device": device}, inequality_constraints=cons,
                                         pre_processing_manifold=vector_to_symmetric_matrix_mandel_torch,
