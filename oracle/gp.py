@@ -1,0 +1,28 @@
+"""Oracle (CPU, numpy/scipy) for the step that consumes the kernel strip in the acquisition maximiser: exact-GP posterior and
+analytic acquisition values.  Test infrastructure only - see oracle/__init__.py.
+
+[3P] botorch / gpytorch semantics (unpinned: the packages are absent from the image):
+  eval-mode ExactGP:  mean = m + k*^T (K + s2 I)^-1 (y - m),  var = k** - k*^T (K + s2 I)^-1 k*,  K = outputscale * base kernel
+  botorch.acquisition.ExpectedImprovement(model, best_f, maximize):  sigma = sqrt(clamp_min(var, 1e-9)),
+      u = (mean - best_f) / sigma (negated when maximize=False),  EI = sigma (phi(u) + u Phi(u))
+  call sites in the reference: examples/gabo_spd.py:197 (EI, maximize=False), manifold_optimize.py:182-184 (cost = -acq)."""
+import numpy as np
+from scipy.stats import norm
+
+
+def gp_posterior(k_train, k_star, k_star_star, y, mean, outputscale, noise):
+    """k_train (n, n), k_star (r, n), k_star_star (r,): BASE kernel values.  -> posterior mean (r,), variance (r,)."""
+    kt = outputscale * np.asarray(k_train, dtype=np.float64) + noise * np.eye(len(y))
+    ks = outputscale * np.asarray(k_star, dtype=np.float64)
+    sol = np.linalg.solve(kt, ks.T)                       # (n, r)
+    mu = mean + ks @ np.linalg.solve(kt, np.asarray(y, dtype=np.float64) - mean)
+    var = outputscale * np.asarray(k_star_star, dtype=np.float64) - np.sum(ks * sol.T, axis=1)
+    return mu, var
+
+
+def expected_improvement(mu, var, best_f, maximize):
+    sigma = np.sqrt(np.maximum(var, 1e-9))
+    u = (mu - best_f) / sigma
+    if not maximize:
+        u = -u
+    return sigma * (norm.pdf(u) + u * norm.cdf(u))

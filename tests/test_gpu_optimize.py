@@ -318,3 +318,37 @@ def test_fused_acquisition_on_trainable_surrogate():
     f, g = fused.cost_egrad(x)
     np.testing.assert_allclose(f.cpu().numpy(), f_ref.detach().cpu().numpy(), rtol=1e-9, atol=1e-14)
     np.testing.assert_allclose(g.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-7, atol=1e-10 * max(1.0, float(g_ref.abs().max())))
+
+
+def test_gp_acquisition_kernel_against_the_numpy_oracle():
+    """gabo_gp_acquisition (value and d/dK*) against oracle/gp.py: posterior by dense solves, EI by scipy.stats.norm, gradient by
+    central differences of the oracle."""
+    from oracle import gp as ogp
+    rng = np.random.default_rng(12)
+    n, r = 37, 9
+    a = rng.standard_normal((n, 3))
+    ktr = np.exp(-0.5 * ((a[:, None] - a[None]) ** 2).sum(-1))
+    b = rng.standard_normal((r, 3))
+    ks = np.exp(-0.5 * ((b[:, None] - a[None]) ** 2).sum(-1))
+    y = rng.standard_normal(n)
+    mean, osc, noise, best = 0.3, 1.7, 1e-2, float(y.min())
+    L = np.linalg.cholesky(osc * ktr + noise * np.eye(n))
+    linv = np.linalg.inv(L)
+    alpha = np.linalg.solve(L.T, np.linalg.solve(L, y - mean))
+    for kind, maximize in ((_lib.GABO_ACQ_EXPECTED_IMPROVEMENT, False), (_lib.GABO_ACQ_EXPECTED_IMPROVEMENT, True),
+                           (_lib.GABO_ACQ_POSTERIOR_MEAN, False)):
+        def oracle_value(k):
+            mu, var = ogp.gp_posterior(ktr, k, np.ones(len(k)), y, mean, osc, noise)
+            if kind == _lib.GABO_ACQ_POSTERIOR_MEAN:
+                return mu if maximize else -mu
+            return ogp.expected_improvement(mu, var, best, maximize)
+        val, grad = ops.gp_acquisition(t(ks), t(alpha), t(linv), t(np.ascontiguousarray(linv.T)), mean, osc, 1.0, best, kind, maximize)
+        np.testing.assert_allclose(val.cpu().numpy(), oracle_value(ks), rtol=1e-9, atol=1e-13)
+        num = np.zeros_like(ks)
+        h = 1e-6
+        for idx in np.ndindex(ks.shape):
+            kp, km = ks.copy(), ks.copy()
+            kp[idx] += h
+            km[idx] -= h
+            num[idx] = (oracle_value(kp)[idx[0]] - oracle_value(km)[idx[0]]) / (2 * h)
+        np.testing.assert_allclose(grad.cpu().numpy(), num, rtol=1e-5, atol=1e-8)

@@ -47,3 +47,22 @@ def test_sphere_invariances(seed, dim):
     np.testing.assert_allclose(np.linalg.norm(u, axis=1), np.diagonal(D), rtol=1e-8, atol=1e-7)
     np.testing.assert_allclose(osph.expmap(u, x), y, rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(np.sum(u * x, axis=1), 0.0, atol=1e-9)                                       # tangent
+
+
+def test_gp_oracle_known_answers():
+    from oracle import gp as ogp
+    # noise-free GP interpolates its data with zero variance
+    x = np.array([[0.0], [1.0], [2.5]])
+    k = np.exp(-0.5 * (x - x.T) ** 2)
+    y = np.array([1.0, -2.0, 0.5])
+    mu, var = ogp.gp_posterior(k, k, np.ones(3), y, 0.2, 1.3, 1e-12)
+    np.testing.assert_allclose(mu, y, atol=1e-8)
+    np.testing.assert_allclose(var, 0.0, atol=1e-8)
+    # far from the data the posterior is the prior
+    mu, var = ogp.gp_posterior(k, np.zeros((1, 3)), np.ones(1), y, 0.2, 1.3, 1e-2)
+    np.testing.assert_allclose([mu[0], var[0]], [0.2, 1.3], atol=1e-14)
+    # EI: u = 0 gives sigma * phi(0); the variance clamp at 1e-9; symmetry between maximize and minimize
+    np.testing.assert_allclose(ogp.expected_improvement(np.array([1.0]), np.array([4.0]), 1.0, True), 2.0 / np.sqrt(2 * np.pi))
+    np.testing.assert_allclose(ogp.expected_improvement(np.array([1.0]), np.array([-1.0]), 1.0, True), np.sqrt(1e-9) / np.sqrt(2 * np.pi))
+    np.testing.assert_allclose(ogp.expected_improvement(np.array([0.3]), np.array([0.5]), 1.0, False),
+                               ogp.expected_improvement(np.array([1.7]), np.array([0.5]), 1.0, True))
