@@ -32,9 +32,10 @@ def _surrogate_view(gp):
 
 
 class FusedAcquisition:
-    def __init__(self, acq, family, mode, beta, matrix_input, device):
+    def __init__(self, acq, family, mode, beta, matrix_input, device, flavour="ai"):
         base, outputscale, mean, (linv, alpha), train_x = _surrogate_view(acq.model)
         self.family, self.mode, self.beta, self.matrix_input = family, mode, beta, matrix_input
+        self.flavour = flavour          # SPD kernels: "ai" affine-invariant, "le" log-Euclidean, "frob" Frobenius
         self.kind = _lib.GABO_ACQ_EXPECTED_IMPROVEMENT if isinstance(acq, models.ExpectedImprovement) else _lib.GABO_ACQ_POSTERIOR_MEAN
         self.maximize = bool(acq.maximize)
         self.best_f = float(getattr(acq, "best_f", 0.0))
@@ -44,10 +45,14 @@ class FusedAcquisition:
         self.alpha = alpha.to(device).contiguous()
         self.train = train_x.to(device).contiguous()
         # d <= 12: value + gradient in ONE launch per evaluation (csrc/spd_acq.hip); the training side is factored once here
-        self.single_launch = (family == "spd" and self.train.shape[-1] <= _lib.GABO_SPD_REG_MAX_DIM * (_lib.GABO_SPD_REG_MAX_DIM + 1) // 2
+        self.single_launch = (family == "spd" and flavour == "ai" and self.train.shape[-1] <= _lib.GABO_SPD_REG_MAX_DIM * (_lib.GABO_SPD_REG_MAX_DIM + 1) // 2
                               and self.train.shape[0] <= 2048)
         self.train_factors = ops.spd_acq_prepare_train(self.train) if self.single_launch else None
-        if family == "spd":
+        if family == "spd" and flavour != "ai":
+            # ||0 + 1e-15||_F^2 = d^2 1e-30 (spd_utils_torch.py:156): k(x, x) = 1 to the last bit; logm of the training set once
+            self.kxx = 1.0
+            self.train_feat = ops.spd_logm_mandel(self.train) if flavour == "le" else self.train
+        elif family == "spd":
             # d(X, X)^2 = 1e-15 exactly (the eigenvalues of L^-1 X L^-T are 1 to rounding): spd_utils_torch.py:120
             self.kxx = math.exp(-beta * (1e-15 if mode == _lib.GABO_OUT_GAUSSIAN else math.sqrt(1e-15)))
         else:
@@ -69,6 +74,12 @@ class FusedAcquisition:
                 return None
             mode = _lib.GABO_OUT_GAUSSIAN if type(k) is kernels_spd.SpdAffineInvariantGaussianKernel else _lib.GABO_OUT_LAPLACE
             return FusedAcquisition(acq, "spd", mode, float(k.beta.double()), True, device)
+        if type(k) in (kernels_spd.SpdLogEuclideanGaussianKernel, kernels_spd.SpdFrobeniusGaussianKernel):
+            if post_processing is not spd_utils_torch.symmetric_matrix_to_vector_mandel_torch:
+                return None
+            ls = float(k.lengthscale.detach().double())
+            flavour = "le" if type(k) is kernels_spd.SpdLogEuclideanGaussianKernel else "frob"
+            return FusedAcquisition(acq, "spd", _lib.GABO_OUT_GAUSSIAN, 1.0 / (ls * ls), True, device, flavour=flavour)
         if type(k) in (kernels_sphere.SphereGaussianKernel, kernels_sphere.SphereLaplaceKernel):
             if post_processing is not None:
                 return None
@@ -82,8 +93,11 @@ class FusedAcquisition:
 
     def _strip(self, x):
         pts = ops.matrix_to_mandel(x) if self.matrix_input else x.contiguous()
-        if self.family == "spd":
+        if self.family == "spd" and self.flavour == "ai":
             return pts, ops.spd_ai_pairwise(pts, self.train, self.beta, self.mode), None
+        if self.family == "spd":
+            feat = ops.spd_logm_mandel(pts) if self.flavour == "le" else pts
+            return pts, ops.frobenius_pairwise(feat, self.train_feat, self.beta, self.mode), feat
         c = pts @ self.train.t()
         return pts, ops.sphere_from_inner(c, self.beta, self.mode, 0), c
 
@@ -92,10 +106,23 @@ class FusedAcquisition:
         Mandel maps, used by the fused trust-region inner loop."""
         if self.single_launch:
             return self._single(pts, True, active_ptr, out)[1]
-        ks = ops.spd_ai_pairwise(pts, self.train, self.beta, self.mode)
+        _, ks, feat = self._strip_mandel(pts)
         _, gk = ops.gp_acquisition(ks, self.alpha, self.linv, self.linv_t, self.mean, self.outputscale, self.kxx, self.best_f,
                                    self.kind, self.maximize, out_sign=-1.0, need_grad=True)
-        return ops.spd_ai_backward(pts, self.train, gk, self.beta, self.mode, wrt=1)
+        return self._strip_backward(pts, feat, gk)
+
+    def _strip_mandel(self, pts):
+        if self.flavour == "ai":
+            return pts, ops.spd_ai_pairwise(pts, self.train, self.beta, self.mode), None
+        feat = ops.spd_logm_mandel(pts) if self.flavour == "le" else pts
+        return pts, ops.frobenius_pairwise(feat, self.train_feat, self.beta, self.mode), feat
+
+    def _strip_backward(self, pts, feat, gk):
+        """d/d pts (Mandel) of sum(gk * strip)"""
+        if self.flavour == "ai":
+            return ops.spd_ai_backward(pts, self.train, gk, self.beta, self.mode, wrt=1)
+        g = ops.frobenius_backward(feat, self.train_feat, gk, self.beta, self.mode, wrt=1)
+        return ops.spd_logm_mandel_backward(pts, g) if self.flavour == "le" else g
 
     def acq_params(self):
         """The surrogate as the gabo_spd_acq_params struct of the C ABI (single-launch path only)."""
@@ -124,7 +151,7 @@ class FusedAcquisition:
         val, gk = ops.gp_acquisition(ks, self.alpha, self.linv, self.linv_t, self.mean, self.outputscale, self.kxx, self.best_f,
                                      self.kind, self.maximize, out_sign=-1.0, need_grad=True)
         if self.family == "spd":
-            g = ops.spd_ai_backward(pts, self.train, gk, self.beta, self.mode, wrt=1)
+            g = self._strip_backward(pts, c, gk)         # (c = the per-point features of the log-Euclidean / Frobenius flavours)
         else:
             g = (gk * ops.sphere_from_inner(c, self.beta, self.mode, 1)) @ self.train
         return val, (ops.mandel_to_matrix(g) if self.matrix_input else g)

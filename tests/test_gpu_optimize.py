@@ -352,3 +352,31 @@ def test_gp_acquisition_kernel_against_the_numpy_oracle():
             km[idx] -= h
             num[idx] = (oracle_value(kp)[idx[0]] - oracle_value(km)[idx[0]]) / (2 * h)
         np.testing.assert_allclose(grad.cpu().numpy(), num, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("flavour", ["le", "frob"])
+def test_fused_chain_for_log_euclidean_and_frobenius_kernels(flavour):
+    """The latent surrogate of config 5 (SpdLogEuclideanGaussianKernel, hd_gabo_spd.py:166) takes the fused chain too."""
+    from gabotorch_amd.fused_acquisition import FusedAcquisition
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdFrobeniusGaussianKernel, SpdLogEuclideanGaussianKernel
+    d = 2
+    rng, X, y = _spd_gp(d, n_train=17, seed=4)
+    kern = (SpdLogEuclideanGaussianKernel if flavour == "le" else SpdFrobeniusGaussianKernel)().double()
+    kern.lengthscale = torch.tensor(1.3, dtype=torch.float64)
+    gp = models.ExactGP(t(X), t(y), kern, outputscale=1.2, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    post = symmetric_matrix_to_vector_mandel_torch
+    fused = FusedAcquisition.build(acq, post, torch.device(DEV))
+    assert fused is not None and not fused.single_launch and fused.flavour == flavour
+    q = np.linalg.qr(rng.standard_normal((50, d, d)))[0]
+    P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (50, d)), q)
+    x = t(0.5 * (P + P.transpose(0, 2, 1)))
+    xx = x.clone().requires_grad_(True)
+    f_ref = -acq(post(xx)[:, None])
+    (g_ref,) = torch.autograd.grad(f_ref.sum(), xx)
+    f, g = fused.cost_egrad(x)
+    np.testing.assert_allclose(f.cpu().numpy(), f_ref.detach().cpu().numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-8, atol=1e-11 * max(1.0, float(g_ref.abs().max())))
+    np.testing.assert_allclose(fused.cost(x).cpu().numpy(), f.cpu().numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(fused.egrad_mandel(ops.matrix_to_mandel(x)).cpu().numpy(), ops.matrix_to_mandel(g).cpu().numpy(),
+                               rtol=1e-12, atol=1e-14)
