@@ -20,3 +20,42 @@ lg = ops.spd_logm_mandel(y)
 ms_le = timeit(lambda: ops.frobenius_pairwise(lg, lg, beta=1.0), 20)
 print(f"config5 N={n} D={D}->d={d}: project {ms_p*1e3:.1f} us ({n/ms_p*1e3:.3e} matrices/s) | nested AI Gram {ms_ai*1e3:.1f} us ({n*n/ms_ai*1e3:.3e} pairs/s) | "
       f"logm {ms_lg*1e3:.1f} us | log-Euclid Gram {ms_le*1e3:.1f} us ({n*n/ms_le*1e3:.3e} pairs/s)")
+
+# ---- the acquisition sweep of config 5: latent S^2_++, log-Euclidean kernel, StrictConstrainedTrustRegions semantics, eigenvalue box
+import time
+from gabotorch_amd import manifolds, models
+from gabotorch_amd.kernel_utils.kernels_spd import SpdLogEuclideanGaussianKernel
+from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions
+from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold
+from gabotorch_amd.Riemannian_utils import spd_constraints_utils_torch as scut
+from gabotorch_amd.Riemannian_utils.spd_utils_torch import symmetric_matrix_to_vector_mandel_torch as to_vec, vector_to_symmetric_matrix_mandel_torch as to_mat
+
+
+def latent_sweep(R=512, raw=2048, n_train=50, graphs=True, fused=True):
+    z = y[:n_train]
+    lam = np.linalg.eigvalsh(np.einsum("da,ndc,cb->nab", W, X[:n_train], W))
+    f = (np.log(lam / 2.0) ** 2).sum(1)
+    kern = SpdLogEuclideanGaussianKernel().double()
+    kern.lengthscale = torch.tensor(1.5, dtype=torch.float64)
+    gp = models.ExactGP(z, torch.tensor(f, device="cuda"), kern, outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(f.min()), maximize=False)
+    man = manifolds.PositiveDefinite(d)
+    man.min_eig, man.max_eig = 0.05, 5.0
+    man.rand = lambda: (lambda u, l: u @ np.diag(l) @ u.T)(np.linalg.qr(np.random.randn(d, d))[0], 0.05 + 4.95 * np.random.rand(d))
+    cons = [lambda m: scut.max_eigenvalue_constraint_torch(m, 5.0), lambda m: scut.min_eigenvalue_constraint_torch(m, 0.05)]
+    np.random.seed(7); torch.manual_seed(7)
+    solver = BatchedTrustRegions(mingradnorm=2e-4, maxiter=100, minstepsize=1e-4, strict_constraints=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=R, raw_samples=raw, bounds=None,
+                                   options={"device": "cuda:0", "hip_graphs": graphs, "batched_rand": True, "fused_acquisition": fused},
+                                   inequality_constraints=cons, pre_processing_manifold=to_mat, post_processing_manifold=to_vec,
+                                   approx_hessian=True)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, float(acq(best[None]).item()), solver.log["iterations"]
+
+
+for label, kw in (("generic autograd path, eager", dict(graphs=False, fused=False)), ("fused chain + device tCG, eager", dict(graphs=False)),
+                  ("fused chain + device tCG, hipGraphs", dict())):
+    latent_sweep(**kw)
+    dt, val, its = latent_sweep(**kw)
+    print(f"config5 latent sweep (512 restarts, n=50, strict TR, log-Euclid kernel) {label}: {dt*1e3:.1f} ms  EI*={val:.6e}  TR iterations={its}")
