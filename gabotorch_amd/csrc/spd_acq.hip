@@ -47,6 +47,15 @@ static int launch_prepare_train(const double* x, double* G, int64_t n, int* stat
 
 extern "C" {
 
+// LDS budget of the kernels built on acq_eval<D>: static tables + the trust-region tiles + 3 n doubles, within 160 KB per CU
+int64_t gabo_spd_acq_max_train(int d) {
+    if (d < 2 || d > GABO_SPD_REG_MAX_DIM) return 0;
+    const int64_t t = (int64_t)d * (d + 1) / 2;
+    const int64_t fixed = (t * 64 + (int64_t)d * d * 64 + 2 * t + 5 * d * d + 2) * 8 + 1024;
+    const int64_t n = (160 * 1024 - fixed) / 24;
+    return n > 2048 ? 2048 : (n < 0 ? 0 : n);
+}
+
 int gabo_spd_acq_prepare_train(const double* x_train_mandel, double* train_factors, int64_t n, int d, int* status,
                                gabo_stream_t stream) {
     if (n < 1 || n > 0x7fffffffLL || !x_train_mandel || !train_factors || !status) return GABO_ERR_ARG;
@@ -66,8 +75,8 @@ int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const
                       const double* linv_t, double* value, double* grad_mandel, double* scratch, int64_t r, int64_t n, int d,
                       double beta, int flags, double mean, double outputscale, double kxx, double best_f, int kind, int maximize,
                       double out_sign, const int* active, int* status, gabo_stream_t stream) {
-    if (r < 0 || r > 0x7fffffffLL || n < 1 || n > 2048) return GABO_ERR_ARG;
     if (d < 2 || d > GABO_SPD_REG_MAX_DIM) return GABO_ERR_DIM;
+    if (r < 0 || r > 0x7fffffffLL || n < 1 || n > gabo_spd_acq_max_train(d)) return GABO_ERR_ARG;
     if (flags != GABO_OUT_GAUSSIAN && flags != GABO_OUT_LAPLACE) return GABO_ERR_ARG;
     if (kind != GABO_ACQ_EXPECTED_IMPROVEMENT && kind != GABO_ACQ_POSTERIOR_MEAN) return GABO_ERR_ARG;
     if (r == 0) return GABO_OK;

@@ -188,7 +188,7 @@ int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust
     if (!x || !grad || !trust_radius || !active || !workspace || !x_prop || !any_active || !status ||
         (n_constraints > 0 && (!cons_grads || !cons_values)))
         return GABO_ERR_ARG;
-    if (acq->n < 1 || acq->n > 2048 || !acq->train_factors || !acq->alpha) return GABO_ERR_ARG;
+    if (acq->n < 1 || acq->n > gabo_spd_acq_max_train(d) || !acq->train_factors || !acq->alpha) return GABO_ERR_ARG;
     if (acq->kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!acq->linv || !acq->linv_t)) return GABO_ERR_ARG;
     if (workspace_bytes < gabo_spd_tr_workspace_bytes(r, d, n_constraints, acq->n)) return GABO_ERR_ARG;
 #define GABO_CASE(DD) \

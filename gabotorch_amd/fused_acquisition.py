@@ -45,8 +45,11 @@ class FusedAcquisition:
         self.alpha = alpha.to(device).contiguous()
         self.train = train_x.to(device).contiguous()
         # d <= 12: value + gradient in ONE launch per evaluation (csrc/spd_acq.hip); the training side is factored once here
-        self.single_launch = (family == "spd" and flavour == "ai" and self.train.shape[-1] <= _lib.GABO_SPD_REG_MAX_DIM * (_lib.GABO_SPD_REG_MAX_DIM + 1) // 2
-                              and self.train.shape[0] <= 2048)
+        self.single_launch = False
+        if family == "spd" and flavour == "ai":
+            d_spd = ops._mandel_dim(self.train.shape[-1])
+            self.single_launch = (d_spd <= _lib.GABO_SPD_REG_MAX_DIM
+                                  and self.train.shape[0] <= _lib.load().gabo_spd_acq_max_train(d_spd))
         self.train_factors = ops.spd_acq_prepare_train(self.train) if self.single_launch else None
         if family == "spd" and flavour != "ai":
             # ||0 + 1e-15||_F^2 = d^2 1e-30 (spd_utils_torch.py:156): k(x, x) = 1 to the last bit; logm of the training set once

@@ -216,6 +216,8 @@ typedef struct {
     double out_sign;
 } gabo_spd_acq_params;           /* the surrogate, as one argument (same fields as gabo_spd_acq_eval's scalar list) */
 
+/* largest training-set size the fused kernels take at dimension d (LDS budget; 2048 up to d = 11, 1755 at d = 12) */
+int64_t gabo_spd_acq_max_train(int d);
 int gabo_spd_acq_prepare_train(const double* x_train_mandel, double* train_factors, int64_t n, int d, int* status,
                                gabo_stream_t stream);
 int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const double* alpha, const double* linv,

@@ -58,7 +58,7 @@ def test_fit_learns_the_projection_matrix_on_the_grassmannian():
     np.random.seed(0)
     kern = ScaleKernel(NestedSpdLogEuclideanGaussianKernel(D, dl), outputscale_prior=models.GammaPrior(2.0, 0.15)).double()
     gp = models.SingleTaskGP(torch.tensor(X, device=DEV), torch.tensor(y, device=DEV), kern, noise_prior=models.GammaPrior(1.1, 0.05))
-    before = float(-gp.marginal_log_likelihood())
+    before = float(-gp.marginal_log_likelihood().detach())
     _, info = fit_gpytorch_manifold(gp, solver=ConjugateGradient(maxiter=60), nb_init_candidates=40)
     W = kern.base_kernel.raw_projection_matrix.detach().numpy()
     np.testing.assert_allclose(W.T @ W, np.eye(dl), atol=1e-10)        # stayed on the manifold
@@ -79,7 +79,7 @@ def test_fit_moves_nested_sphere_axes_on_their_spheres():
     np.random.seed(1)
     kern = ScaleKernel(NestedSphereGaussianKernel(dim, latent, beta_min=0.5)).double()
     gp = models.SingleTaskGP(torch.tensor(X, device=DEV), torch.tensor(y, device=DEV), kern)
-    before = float(-gp.marginal_log_likelihood())
+    before = float(-gp.marginal_log_likelihood().detach())
     a0 = [a.detach().clone() for a in kern.base_kernel.axes]
     _, info = fit_gpytorch_manifold(gp, solver=ConjugateGradient(maxiter=40), nb_init_candidates=20)
     assert info["fopt"] <= before + 1e-12

@@ -380,3 +380,47 @@ def test_fused_chain_for_log_euclidean_and_frobenius_kernels(flavour):
     np.testing.assert_allclose(fused.cost(x).cpu().numpy(), f.cpu().numpy(), rtol=0, atol=0)
     np.testing.assert_allclose(fused.egrad_mandel(ops.matrix_to_mandel(x)).cpu().numpy(), ops.matrix_to_mandel(g).cpu().numpy(),
                                rtol=1e-12, atol=1e-14)
+
+
+def test_single_launch_acquisition_at_the_lds_limits():
+    """d = 12 is the largest register-resident dimension (120 KB of static LDS in the fused kernels) and gabo_spd_acq_max_train(12)
+    the largest training set that still fits the 160 KB of a CU: the single launch must agree with the separate-launch chain."""
+    from gabotorch_amd.fused_acquisition import FusedAcquisition
+    d = 12
+    n_max = int(_lib.load().gabo_spd_acq_max_train(d))
+    assert 1500 < n_max <= 2048
+    rng = np.random.default_rng(77)
+    q = np.linalg.qr(rng.standard_normal((n_max, d, d)))[0]
+    Xm = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.5, 2.0, (n_max, d)), q)
+    X = ospd.symmetric_matrix_to_vector_mandel(0.5 * (Xm + Xm.transpose(0, 2, 1)))
+    y = rng.standard_normal(n_max)
+    gp = models.ExactGP(t(X), t(y), SpdAffineInvariantGaussianKernel(beta_min=0.16), outputscale=1.0, noise=0.5)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    fused = FusedAcquisition.build(acq, symmetric_matrix_to_vector_mandel_torch, torch.device(DEV))
+    assert fused is not None and fused.single_launch
+    x = t(Xm[:5] + 0.05 * np.eye(d))
+    f1, g1 = fused.cost_egrad(x)
+    fused.single_launch = False
+    f2, g2 = fused.cost_egrad(x)
+    np.testing.assert_allclose(f1.cpu().numpy(), f2.cpu().numpy(), rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), rtol=1e-7, atol=1e-12 * max(1.0, float(g2.abs().max())))
+    # one more training point: the fused kernels decline, the chain takes over
+    gp2 = models.ExactGP(t(np.concatenate([X, X[:1]])), t(np.concatenate([y, y[:1]])), SpdAffineInvariantGaussianKernel(beta_min=0.16),
+                         outputscale=1.0, noise=0.5)
+    fused2 = FusedAcquisition.build(models.ExpectedImprovement(gp2, best_f=0.0, maximize=False), symmetric_matrix_to_vector_mandel_torch,
+                                    torch.device(DEV))
+    assert fused2 is not None and not fused2.single_launch
+
+
+def test_device_trust_region_iteration_at_d12():
+    """the propose/update kernels at the largest supported dimension against the torch lock-step solver.  Three iterations agree
+    to rounding; later ones only approximately: at d = 12 the tCG runs up to 78 inner iterations on a finite-difference Hessian
+    (1/c = 2^14 ||delta|| amplifies the last bits of the gradient), so one exit test decided differently moves a restart by 1e-6."""
+    from tools.sweep_bench import run_sweep
+    for maxiter, tol in ((3, 1e-9), (6, 1e-4)):
+        kw = dict(num_restarts=12, raw_samples=64, d=12, n_train=30, maxiter=maxiter)
+        _, _, val_t, log_t = run_sweep(DEV, device_tcg=False, **kw)
+        _, _, val_d, log_d = run_sweep(DEV, **kw)
+        np.testing.assert_allclose(val_d, val_t, rtol=tol)
+        np.testing.assert_array_equal(log_d["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
+        np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=tol, atol=1e-11)
