@@ -91,8 +91,14 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
                 });
             });
         });
+        // eigenvectors: registers for D <= 8 (this kernel runs 1-2 waves per SIMD: LDS round trips would be exposed latency),
+        // the lane's LDS column above that
+        constexpr bool kRegV = D <= 8;
         double* vl = vls + lane;
-        jacobi_eig<D>(m, vl);
+        double vreg[kRegV ? D * D : 1];
+        if constexpr (kRegV) jacobi_eig_reg<D>(m, vreg);
+        else jacobi_eig<D>(m, vl);
+        auto Vat = [&](int r, int c) -> double { if constexpr (kRegV) return vreg[r * D + c]; else return vl[(r * D + c) * 64]; };
         double lg[D];
         double s = 0.0;
         static_for<D>([&](auto kk) {
@@ -121,7 +127,7 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
                         double f = 0.0;
                         static_for<D>([&](auto kk) {
                             constexpr int k = decltype(kk)::value;
-                            f = __builtin_fma(vl[(r * D + k) * 64] * lg[k], vl[(c * D + k) * 64], f);
+                            f = __builtin_fma(Vat(r, k) * lg[k], Vat(c, k), f);
                         });
                         F[(int64_t)tri(r, c) * n + j] = f;
                     });

@@ -7,11 +7,13 @@ namespace gabo {
 
 // Cyclic Jacobi on a packed lower triangle (registers) with accumulated eigenvectors kept in LDS: the D*D doubles of V
 // per lane do not fit the 256 directly addressable VGPRs next to M.  vl[(r*D + c)*64 + lane], columns = eigenvectors.
-template <int D>
-__device__ __forceinline__ void jacobi_eig(double (&m)[tri_size(D)], double* __restrict__ vl) {
+// V(r, c) -> double& : where the eigenvector entries live (LDS column of the lane, or a register array); every call site passes
+// compile-time r, c, so a register-array accessor resolves to fixed registers after inlining.
+template <int D, class VAcc>
+__device__ __forceinline__ void jacobi_eig_acc(double (&m)[tri_size(D)], VAcc&& V) {
     static_for<D>([&](auto rr) {
         static_for<D>([&](auto cc) {
-            vl[(decltype(rr)::value * D + decltype(cc)::value) * 64] = (decltype(rr)::value == decltype(cc)::value) ? 1.0 : 0.0;
+            V(decltype(rr)::value, decltype(cc)::value) = (decltype(rr)::value == decltype(cc)::value) ? 1.0 : 0.0;
         });
     });
     for (int sweep = 0; sweep < 12; ++sweep) {
@@ -48,13 +50,25 @@ __device__ __forceinline__ void jacobi_eig(double (&m)[tri_size(D)], double* __r
                         m[ikp] = __builtin_fma(c, akp, -s * akq);
                         m[ikq] = __builtin_fma(s, akp, c * akq);
                     }
-                    double vkp = vl[(k * D + p) * 64], vkq = vl[(k * D + q) * 64];
-                    vl[(k * D + p) * 64] = __builtin_fma(c, vkp, -s * vkq);
-                    vl[(k * D + q) * 64] = __builtin_fma(s, vkp, c * vkq);
+                    double vkp = V(k, p), vkq = V(k, q);
+                    V(k, p) = __builtin_fma(c, vkp, -s * vkq);
+                    V(k, q) = __builtin_fma(s, vkp, c * vkq);
                 });
             });
         });
     }
+}
+
+// eigenvectors in LDS: vl[(r*D + c)*64] (one column of 64-lane-strided entries per lane)
+template <int D>
+__device__ __forceinline__ void jacobi_eig(double (&m)[tri_size(D)], double* __restrict__ vl) {
+    jacobi_eig_acc<D>(m, [&](int r, int c) -> double& { return vl[(r * D + c) * 64]; });
+}
+
+// eigenvectors in registers (latency-bound callers with few waves per SIMD and D small enough: D*D + D(D+1)/2 doubles live)
+template <int D>
+__device__ __forceinline__ void jacobi_eig_reg(double (&m)[tri_size(D)], double (&v)[D * D]) {
+    jacobi_eig_acc<D>(m, [&](int r, int c) -> double& { return v[r * D + c]; });
 }
 
 }  // namespace gabo

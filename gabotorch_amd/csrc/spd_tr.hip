@@ -79,9 +79,34 @@ __global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __rest
     const double ehe = wave_dot(etaw, w.heta_w + i * dd, dd);
     if (threadIdx.x == 0) t.rhoden[i] = -ge - 0.5 * ehe;
     lds_load(w.chol + i * dd, M0, D);
-    lds_load(etaw, M1, D);
-    lds_jacobi(M1, M2, cs, D);
-    lds_fun_from_eig(M1, M2, M3, D, FN_EXP);
+    if constexpr (D <= 8) {
+        // expm(eta~) by the register Jacobi (every lane redundantly, no barriers); lane 0 publishes E
+        double m[T], v[D * D];
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            static_for<r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; m[tri(r, c)] = 0.5 * (etaw[r * D + c] + etaw[c * D + r]); });
+        });
+        jacobi_eig_reg<D>(m, v);
+        double ex[D];
+        static_for<D>([&](auto kk) { ex[decltype(kk)::value] = exp(m[tri(decltype(kk)::value, decltype(kk)::value)]); });
+        if (threadIdx.x == 0) {
+            static_for<D>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                static_for<r + 1>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    double f = 0.0;
+                    static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; f = __builtin_fma(v[r * D + k] * ex[k], v[c * D + k], f); });
+                    M3[r * D + c] = f;
+                    M3[c * D + r] = f;
+                });
+            });
+        }
+        __syncthreads();
+    } else {
+        lds_load(etaw, M1, D);
+        lds_jacobi(M1, M2, cs, D);
+        lds_fun_from_eig(M1, M2, M3, D, FN_EXP);
+    }
     lds_congruence(M0, M3, M1, M2, D);
     lds_symmetrize(M1, M2, D);
     lds_store(M1, x_prop + i * dd, D);
