@@ -1,0 +1,123 @@
+// Random SPD matrices with the distribution of spd_sample (Riemannian_utils/spd_utils.py:290-306): eigenvalues U[min_eig, max_eig],
+// eigenvectors = the orthogonal factor of a Gaussian matrix, X = Q diag(lambda) Q^T - drawn on the device, one lane per matrix.
+// The reference draws raw_samples of them per BO iteration through manifold.rand on the host (manifold_optimize.py:288); this is
+// the opt-in device path of that stage (same distribution, its own counter-based random stream: Philox4x32-10 keyed by the seed,
+// counter = (matrix index, draw index), so a sample does not depend on the launch geometry).
+#include "gabo_device.hpp"
+#include "../../include/gabo_hip.h"
+
+namespace gabo {
+
+struct Philox {
+    uint32_t k0, k1;
+    uint64_t idx;
+    uint32_t draw;
+    __device__ __forceinline__ void next(uint32_t (&o)[4]) {
+        uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = draw++, c3 = 0x6761626fu;
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b;
+            c1 = (uint32_t)p1;
+            c3 = (uint32_t)p0;
+            c0 = n0;
+            c2 = n2;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+    }
+    // two uniforms: u1 in (0, 1], u2 in [0, 1), 53 bits each
+    __device__ __forceinline__ void uniform2(double& u1, double& u2) {
+        uint32_t o[4];
+        next(o);
+        const uint64_t a = (((uint64_t)o[0] << 32) | o[1]) >> 11, b = (((uint64_t)o[2] << 32) | o[3]) >> 11;
+        u1 = ((double)a + 1.0) * 0x1.0p-53;
+        u2 = (double)b * 0x1.0p-53;
+    }
+    __device__ __forceinline__ void normal2(double& z0, double& z1) {
+        double u1, u2;
+        uniform2(u1, u2);
+        const double r = __builtin_sqrt(-2.0 * log(u1));
+        double s, c;
+        sincospi(2.0 * u2, &s, &c);
+        z0 = r * c;
+        z1 = r * s;
+    }
+};
+
+// lane-private d x d scratch in LDS: element e of lane l at q[e * 64 + l] (bank-conflict free, dynamically indexable)
+__global__ __launch_bounds__(64) void spd_sample_kernel(double* __restrict__ out, int64_t n, int d, double min_eig, double max_eig,
+                                                        uint64_t seed, int mandel) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    if (i >= n) return;
+    double* q = lds + lane;
+    Philox rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint64_t)i, 0u};
+    const int dd = d * d;
+    for (int e = 0; e < dd; e += 2) {
+        double z0, z1;
+        rng.normal2(z0, z1);
+        q[e * 64] = z0;
+        if (e + 1 < dd) q[(e + 1) * 64] = z1;
+    }
+    // orthonormalise the columns: modified Gram-Schmidt, two passes per column (orthogonal to rounding for any conditioning met here)
+    for (int c = 0; c < d; ++c) {
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int p = 0; p < c; ++p) {
+                double dot = 0.0;
+                for (int r = 0; r < d; ++r) dot = __builtin_fma(q[(r * d + p) * 64], q[(r * d + c) * 64], dot);
+                for (int r = 0; r < d; ++r) q[(r * d + c) * 64] = __builtin_fma(-dot, q[(r * d + p) * 64], q[(r * d + c) * 64]);
+            }
+        }
+        double nn = 0.0;
+        for (int r = 0; r < d; ++r) nn = __builtin_fma(q[(r * d + c) * 64], q[(r * d + c) * 64], nn);
+        const double inv = 1.0 / __builtin_sqrt(nn);
+        for (int r = 0; r < d; ++r) q[(r * d + c) * 64] *= inv;
+    }
+    // scale column k by sqrt(lambda_k):  X = (Q sqrt(L)) (Q sqrt(L))^T is symmetric positive definite by construction
+    for (int k = 0; k < d; k += 2) {
+        double u1, u2;
+        rng.uniform2(u1, u2);
+        const double s0 = __builtin_sqrt(min_eig + (max_eig - min_eig) * u2);
+        const double s1 = __builtin_sqrt(min_eig + (max_eig - min_eig) * (1.0 - u1));
+        for (int r = 0; r < d; ++r) {
+            q[(r * d + k) * 64] *= s0;
+            if (k + 1 < d) q[(r * d + k + 1) * 64] *= s1;
+        }
+    }
+    if (mandel) {
+        double* o = out + i * (int64_t)(d * (d + 1) / 2);
+        for (int r = 0; r < d; ++r)
+            for (int c = 0; c <= r; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < d; ++k) s = __builtin_fma(q[(r * d + k) * 64], q[(c * d + k) * 64], s);
+                o[mandel_pos(d, r, c)] = (r == c) ? s : s * kSqrt2;
+            }
+    } else {
+        double* o = out + i * (int64_t)dd;
+        for (int r = 0; r < d; ++r)
+            for (int c = 0; c <= r; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < d; ++k) s = __builtin_fma(q[(r * d + k) * 64], q[(c * d + k) * 64], s);
+                o[r * d + c] = s;
+                o[c * d + r] = s;
+            }
+    }
+}
+
+}  // namespace gabo
+
+extern "C" int gabo_spd_sample(double* out, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, int mandel,
+                               gabo_stream_t stream) {
+    if (d < 1 || d > 16) return GABO_ERR_DIM;
+    if (n < 0 || !(min_eig > 0.0) || !(max_eig >= min_eig)) return GABO_ERR_ARG;
+    if (n == 0) return GABO_OK;
+    if (!out) return GABO_ERR_ARG;
+    size_t lds = (size_t)d * d * 64 * sizeof(double);
+    hipLaunchKernelGGL(gabo::spd_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream, out, n, d, min_eig,
+                       max_eig, seed, mandel);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}

@@ -173,7 +173,10 @@ def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num
     while factor < max_factor:
         with warnings.catch_warnings(record=True) as ws:
             warnings.simplefilter("always")
-            if options.get("batched_rand") and hasattr(manifold, "rand_batch"):
+            if options.get("device_rand") and device is not None and hasattr(manifold, "rand_batch_device"):
+                # opt-in: the raw samples are drawn on the device (same distribution as manifold.rand_batch, own random stream)
+                X_rnd = manifold.rand_batch_device(raw_samples * factor * q, device)[:, None].to(sample_type)
+            elif options.get("batched_rand") and hasattr(manifold, "rand_batch"):
                 # opt-in: one vectorised draw instead of raw_samples host calls of manifold.rand (same distribution, different
                 # order of draws from the global RNG, so not sample-for-sample identical to the reference)
                 X_rnd = torch.as_tensor(np.asarray(manifold.rand_batch(raw_samples * factor * q)))[:, None].to(sample_type)

@@ -57,6 +57,12 @@ class PositiveDefinite:
         m = np.einsum("kab,kb,kcb->kac", q, lam, q)
         return 0.5 * (m + m.transpose(0, 2, 1))
 
+    def rand_batch_device(self, k, device):
+        """k samples of the same distribution drawn on the device (gabo_spd_sample); the seed comes from numpy's global RNG, so
+        np.random.seed(...) makes the draw reproducible.  Used when the caller opts in (options={"device_rand": True})."""
+        seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+        return ops.spd_sample(k, self._n, self.min_eig, self.max_eig, seed, device)
+
     exp = staticmethod(_wrap(lambda x, u: ops.spd_manifold_op(_lib.GABO_SPD_EXP, x, u)))
     retr = exp                                                                       # [3P] retr = exp
     log = staticmethod(_wrap(lambda x, y: ops.spd_manifold_op(_lib.GABO_SPD_LOG, x, y)))

@@ -597,6 +597,17 @@ def spd_acq_eval(x_mandel, train_factors, alpha, linv, linv_t, beta, mode, mean,
     return value, grad
 
 
+def spd_sample(n, d, min_eig, max_eig, seed, device, mandel=False):
+    """n random SPD matrices (n, d, d) - or Mandel vectors (n, d_vec) - drawn on the device with spd_sample's distribution."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    out = torch.empty((n, d * (d + 1) // 2) if mandel else (n, d, d), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_spd_sample(out.data_ptr(), n, d, float(min_eig), float(max_eig), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                       1 if mandel else 0, _stream_ptr(dev)), "gabo_spd_sample")
+    return out
+
+
 def nested_sphere_epilogue(rotated, dist_to_axis, mode=0):
     """Per-point part of the nested-sphere projection on already rotated points (..., d) -> (..., d-1) [mode 0] / (..., d) [mode 1]."""
     lib = _lib.load()

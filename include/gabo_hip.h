@@ -179,6 +179,13 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
                         int kind, int maximize, double out_sign, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * n random SPD matrices with the distribution of spd_sample (Riemannian_utils/spd_utils.py:290-306; the raw samples of
+ * gen_batch_initial_conditions_manifold, manifold_optimize.py:288): eigenvalues U[min_eig, max_eig], eigenvectors = orthogonal
+ * factor of a Gaussian matrix.  out: n x d x d (mandel == 0) or n x d_vec Mandel vectors.  Counter-based stream (Philox4x32-10,
+ * key = seed, counter = matrix index): reproducible for a seed, independent of the launch geometry, NOT numpy's stream. d <= 16. */
+int gabo_spd_sample(double* out, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, int mandel, gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Nested-sphere projection S^(d-1) c R^d -> next subsphere, per-point part.
  * Replaces projection_from_sphere_to_nested_sphere / projection_from_sphere_to_next_subsphere
  * (nested_mappings/nested_spheres_utils.py:13-114), the body of NestedSphereGaussianKernel.forward

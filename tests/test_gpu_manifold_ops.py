@@ -205,3 +205,34 @@ def test_nested_sphere_projections_and_kernel_golden(golden):
     np.testing.assert_allclose(xa.grad.cpu().numpy(), g["a_g1"], rtol=1e-8, atol=1e-10)
     assert kern.raw_axis_S5.grad is not None and kern.raw_beta.grad is not None
     np.testing.assert_allclose(kern.raw_axis_S5.grad.numpy(), g["a_gaxis0"] , rtol=1e-6, atol=1e-8)
+
+
+def test_device_spd_sampler_distribution_and_reproducibility():
+    """gabo_spd_sample: spd_sample's distribution (eigenvalues U[min, max], Haar eigenvectors) from a counter-based stream."""
+    n, d, lo, hi = 20000, 5, 0.3, 4.0
+    a = ops.spd_sample(n, d, lo, hi, seed=1234, device=DEV).cpu().numpy()
+    np.testing.assert_array_equal(a, a.transpose(0, 2, 1))
+    lam, vec = np.linalg.eigh(a)
+    assert lam.min() >= lo - 1e-12 and lam.max() <= hi + 1e-12
+    # uniform eigenvalues: mean (lo+hi)/2, variance (hi-lo)^2/12 ; pooled over all eigenvalues
+    assert abs(lam.mean() - 0.5 * (lo + hi)) < 0.02 and abs(lam.var() - (hi - lo) ** 2 / 12) < 0.03
+    # Haar eigenvectors: E[v_i^2] = 1/d for every coordinate, E[v_i v_j] = 0; take the eigenvector of the LARGEST eigenvalue
+    v = vec[:, :, -1]
+    np.testing.assert_allclose((v ** 2).mean(0), 1.0 / d, atol=0.01)
+    np.testing.assert_allclose((v[:, 0] * v[:, 1]).mean(), 0.0, atol=0.01)
+    # E[X] = mean eigenvalue * I
+    np.testing.assert_allclose(a.mean(0), 0.5 * (lo + hi) * np.eye(d), atol=0.03)
+    # same seed -> same matrices, whatever the batch size; another seed -> different
+    b = ops.spd_sample(100, d, lo, hi, seed=1234, device=DEV).cpu().numpy()
+    np.testing.assert_array_equal(b, a[:100])
+    c = ops.spd_sample(100, d, lo, hi, seed=1235, device=DEV).cpu().numpy()
+    assert np.abs(c - b).max() > 0.1
+    # Mandel output is the same draw
+    m = ops.spd_sample(100, d, lo, hi, seed=1234, device=DEV, mandel=True).cpu().numpy()
+    np.testing.assert_allclose(ospd.vector_to_symmetric_matrix_mandel(m), b, atol=1e-14)
+    # d = 1 and the largest supported d
+    one = ops.spd_sample(1000, 1, lo, hi, seed=5, device=DEV).cpu().numpy()
+    assert one.min() >= lo and one.max() <= hi
+    big = ops.spd_sample(64, 16, lo, hi, seed=5, device=DEV).cpu().numpy()
+    lam16 = np.linalg.eigvalsh(big)
+    assert lam16.min() >= lo - 1e-10 and lam16.max() <= hi + 1e-10
