@@ -174,6 +174,15 @@ def main():
         sw_c, _, sw_val_c, _ = run_sweep(device, num_restarts=512, hip_graphs=True, batched_rand=True, capture_constraints=True)
         sw_d = min(run_sweep(device, num_restarts=512, hip_graphs=True, device_rand=True, capture_constraints=True)[0] for _ in range(3))
         sw_val_d = run_sweep(device, num_restarts=512, hip_graphs=True, device_rand=True, capture_constraints=True)[2]
+        weak = None
+        if world > 1:
+            # weak scaling of the same sweep: 512 restarts PER GPU (the 512-restart sweep itself is latency-bound on one GPU)
+            kw = dict(num_restarts=512 * world, raw_samples=2048 * world, hip_graphs=True, device_rand=True, capture_constraints=True)
+            run_sweep(device, **kw)
+            dist.barrier()
+            ww = torch.tensor([run_sweep(device, **kw)[0]], dtype=torch.float64, device=device)
+            dist.all_reduce(ww, op=dist.ReduceOp.MAX)
+            weak = {"restarts": 512 * world, "seconds": float(ww.item()), "restarts_per_s": 512 * world / float(ww.item())}
         sweep = {"workload": "gabo_spd S^5_++: GP(50 obs)+EI, 2048 raw samples, 512 restarts, ConstrainedTR semantics, FD Hessian, "
                              "lambda_max<=5 constraint; raw samples drawn in one vectorised host call; every trust-region iteration = "
                              "the constraint callables (eager torch) + two launches (propose: whole tCG loop, proposal and acquisition "
@@ -182,6 +191,7 @@ def main():
                  "tr_iterations": int(sw_log["iterations"]),
                  "seconds_constraints_captured": float(sw_c), "best_acq_constraints_captured": sw_val_c,
                  "seconds_constraints_captured_device_rand": float(sw_d), "best_acq_device_rand": sw_val_d,
+                 "weak_scaling_512_restarts_per_gpu": weak,
                  "note": "latency-bound: 512 restarts are 2 waves per CU and each wave runs its restart serially (about 0.45 ms per "
                          "trust-region iteration); plus about 3.5 ms of initial-condition generation and 0.4 ms per iteration of user "
                          "constraint callables.  Does not speed up with more GPUs at this size (weak scaling only)"}

@@ -424,3 +424,48 @@ def test_device_trust_region_iteration_at_d12():
         np.testing.assert_allclose(val_d, val_t, rtol=tol)
         np.testing.assert_array_equal(log_d["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
         np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=tol, atol=1e-11)
+
+
+@pytest.mark.parametrize("case", ["unconstrained_ei", "posterior_mean", "laplace_ei_3_iterations", "tiny_training_set_two_constraints"])
+def test_device_solve_variants_match_torch_path(case):
+    """Corners of the device-resident solve: no constraints, PosteriorMean, the Laplace kernel (its surrogate has kinks at the
+    training points, so trajectories are only compared over the first iterations), d = 2 with 3 training points and an eigenvalue box
+    (two inequality constraints) - all against the torch lock-step solver from the same initial points."""
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantLaplaceKernel
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    d, n_train, R = (2, 3, 37) if case.startswith("tiny") else (3, 20, 70)
+    rng, X, y = _spd_gp(d, n_train=n_train, seed=31)
+    maxiter = 25
+    if case == "posterior_mean":
+        gp = models.ExactGP(t(X), t(y), SpdAffineInvariantGaussianKernel(beta_min=0.5), outputscale=1.0, noise=1e-2)
+        acq = models.PosteriorMean(gp, maximize=False)
+    elif case.startswith("laplace"):
+        gp = models.ExactGP(t(X), t(y), SpdAffineInvariantLaplaceKernel(beta_min=0.5), outputscale=1.0, noise=1e-2)
+        acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+        maxiter = 3
+    else:
+        gp = models.ExactGP(t(X), t(y), SpdAffineInvariantGaussianKernel(beta_min=0.5), outputscale=1.0, noise=1e-2)
+        acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    cons = None
+    if case.startswith("tiny"):
+        cons = [lambda m: scut.max_eigenvalue_constraint_torch(m, 3.5), lambda m: scut.min_eigenvalue_constraint_torch(m, 0.1)]
+    q = np.linalg.qr(rng.standard_normal((R, d, d)))[0]
+    P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.3, 3.0, (R, d)), q)
+    x0 = ops.matrix_to_mandel(t(0.5 * (P + P.transpose(0, 2, 1))))[:, None]
+    man = manifolds.PositiveDefinite(d)
+    out = {}
+    ops.set_error_checking(False)
+    for name, opts in (("torch", {"device_tcg": False}), ("device", {}), ("graphs", {"hip_graphs": True}), ("two_launch_off", {"device_iteration": False})):
+        solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=maxiter)
+        c, v = gen_candidates_manifold(x0, acq, man, solver, vector_to_symmetric_matrix_mandel_torch, symmetric_matrix_to_vector_mandel_torch,
+                                       inequality_constraints=cons, approx_hessian=True, options=opts)
+        out[name] = (c.cpu().numpy(), v.cpu().numpy(), solver.log["per_restart_iterations"].cpu().numpy())
+    ops.set_error_checking(True)
+    # smooth unconstrained cases agree to 1e-7; with the kinked Laplace surrogate or with constraints (exit tests against
+    # Delta_cons^2 = 1e-12) single restarts can take a rounding-decided branch differently: BASELINE.json's 1e-5 on the optimum
+    tol = 1e-7 if case in ("unconstrained_ei", "posterior_mean") else 2e-5
+    for name in ("device", "graphs", "two_launch_off"):
+        np.testing.assert_array_equal(out[name][2], out["torch"][2])
+        np.testing.assert_allclose(out[name][1], out["torch"][1], rtol=tol, atol=1e-12)
+        np.testing.assert_allclose(out[name][0], out["torch"][0], rtol=0, atol=1e-6 if tol < 1e-6 else 1e-3)
+    np.testing.assert_allclose(out["graphs"][1], out["device"][1], rtol=1e-12, atol=0)      # the execution plans are the same arithmetic
