@@ -104,20 +104,24 @@ def cpu_baseline(x):
     sample of the same workload: the first `rows` rows of the Gram matrix against all columns."""
     from oracle import spd as ospd
     rows = 320
+    # the port's time is the per-pair eigh loop, which is scalar: pin torch to ONE thread so that `cores` is what was used
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     t0 = time.perf_counter()
     k = ospd.spd_ai_gaussian_kernel(x[:rows], x, BETA, faithful=True)
     dt = time.perf_counter() - t0
+    torch.set_num_threads(prev_threads)
     # context line (SURVEY 8d): the same arithmetic vectorised on the CPU (batched LAPACK eigvalsh), not what the reference does
     vrows = 64
     t1 = time.perf_counter()
     kv = ospd.spd_ai_gaussian_kernel(x[:vrows], x, BETA, faithful=False)
     dtv = time.perf_counter() - t1
     assert np.allclose(kv, k[:vrows], rtol=1e-9, atol=1e-14)
-    return {"value": rows * x.shape[0] / dt, "unit": "pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    return {"value": rows * x.shape[0] / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
             "vectorised_numpy_pairs_per_s": vrows * x.shape[0] / dtv,
             "sample": f"first {rows} of {x.shape[0]} Gram rows x all {x.shape[0]} columns ({rows * x.shape[0]} pairs, {dt:.1f} s): "
                       "oracle.spd.affine_invariant_distance_faithful = the reference's op sequence (Mandel->matrix, Cholesky, "
-                      "inverse, two bmm, one torch.linalg.eigh per pair in a Python loop, exp), torch CPU fp64",
+                      "inverse, two bmm, one torch.linalg.eigh per pair in a Python loop, exp), torch CPU fp64, one thread (the loop is scalar)",
             "host_cpus": os.cpu_count()}, k
 
 
