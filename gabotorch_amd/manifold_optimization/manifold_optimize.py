@@ -185,12 +185,22 @@ def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num
                 X_rnd = torch.cat(points).to(sample_type)
             if device is not None:
                 X_rnd = X_rnd.to(device)
-            if post_processing_manifold is not None:
-                X_rnd = post_processing_manifold(X_rnd)
-            with torch.no_grad():
-                bl = X_rnd.shape[0] if batch_limit is None else batch_limit
-                Y = [acq_function(X_rnd[s:s + bl]) for s in range(0, X_rnd.shape[0], bl)]
-                Y_rnd = torch.cat(Y).to(X_rnd)
+            fused = None
+            if options.get("fused_acquisition", True) and X_rnd.is_cuda and q == 1:
+                fused = FusedAcquisition.build(acq_function, post_processing_manifold, X_rnd.device)
+            if fused is not None:
+                # built-in surrogate: the raw samples are scored by the fused chain (one launch for the SPD kernels); same values
+                with torch.no_grad():
+                    Y_rnd = -fused.cost(X_rnd[:, 0].contiguous())
+                if post_processing_manifold is not None:
+                    X_rnd = post_processing_manifold(X_rnd)
+            else:
+                if post_processing_manifold is not None:
+                    X_rnd = post_processing_manifold(X_rnd)
+                with torch.no_grad():
+                    bl = X_rnd.shape[0] if batch_limit is None else batch_limit
+                    Y = [acq_function(X_rnd[s:s + bl]) for s in range(0, X_rnd.shape[0], bl)]
+                    Y_rnd = torch.cat(Y).to(X_rnd)
             batch_initial_conditions = init_func(X=X_rnd, Y=Y_rnd, n=num_restarts, **init_kwargs)
             if not any(issubclass(w.category, BadInitialCandidatesWarning) for w in ws):
                 return batch_initial_conditions
