@@ -250,6 +250,32 @@ def main():
         }
         if sweep is not None:
             line["acq_sweep"] = sweep
+        if not args.no_sweep:
+            # config 2 of BASELINE.json beside the headline: SphereGaussianKernel S^9, N=4096 (HBM-write bound: 8.04 B/pair)
+            from gabotorch_amd import ops as _ops
+            from oracle import sphere as osph
+            srng = np.random.default_rng(1234)
+            sx = srng.standard_normal((N_POINTS, 10))
+            sx /= np.linalg.norm(sx, axis=1, keepdims=True)
+            st_ = torch.tensor(sx, device=device)
+            sbeta = 0.6 + float(np.log(2.0))
+            for _ in range(5):
+                _ops.sphere_pairwise(st_, st_, beta=sbeta)
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(20):
+                ks = _ops.sphere_pairwise(st_, st_, beta=sbeta)
+            s1.record()
+            torch.cuda.synchronize()
+            sph_ms = s0.elapsed_time(s1) / 20
+            sph_err = float(np.max(np.abs(ks[:128, 4000:].cpu().numpy() - osph.sphere_gaussian_kernel(sx[:128], sx[4000:], sbeta))))
+            line["sphere_gram"] = {"workload": "SphereGaussianKernel S^9 Gram, N=4096 (BASELINE config 2)", "ms_per_step": sph_ms,
+                                   "pairs_per_s": pairs_per_step / (sph_ms * 1e-3),
+                                   "roofline": {"bound": "hbm", "achieved": pairs_per_step * 8.04 / (sph_ms * 1e-3) / 1e9,
+                                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": pairs_per_step * 8.04 / (sph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "model": "8.04 algorithmic B/pair (one fp64 output + amortised operand reads)"},
+                                   "max_abs_err_vs_oracle_block": sph_err}
         if world == 1 and not args.no_cpu_baseline:
             cb, kcpu = cpu_baseline(x)
             cb["max_rel_diff_gpu_vs_cpu_port"] = float(np.max(np.abs(job.out[:kcpu.shape[0]].cpu().numpy() - kcpu) / np.abs(kcpu)))

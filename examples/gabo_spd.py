@@ -28,7 +28,7 @@ from gabotorch_amd.Riemannian_utils.spd_utils_torch import (symmetric_matrix_to_
 BETA_MIN = {2: 0.6, 3: 0.5, 5: 0.25, 7: 0.22, 10: 0.2, 12: 0.16}      # examples/gabo_spd.py:151-162
 
 
-def run(dim=3, iters=15, restarts=5, raw=100, seed=1234, device="cuda:0", verbose=True):
+def run(dim=3, iters=15, restarts=5, raw=100, seed=1234, device="cuda:0", verbose=True, hip_graphs=False):
     np.random.seed(seed)
     torch.manual_seed(seed)
     man = manifolds.PositiveDefinite(dim)
@@ -48,7 +48,7 @@ def run(dim=3, iters=15, restarts=5, raw=100, seed=1234, device="cuda:0", verbos
         models.fit_gpytorch_model(gp)
         acq = models.ExpectedImprovement(gp, best_f=float(y_data.min()), maximize=False)
         new_x = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=restarts, raw_samples=raw, bounds=None,
-                                        options={"device": device}, inequality_constraints=[constraint],
+                                        options={"device": device, "hip_graphs": hip_graphs}, inequality_constraints=[constraint],
                                         pre_processing_manifold=vector_to_symmetric_matrix_mandel_torch,
                                         post_processing_manifold=symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
         new_y = objective(new_x[0]).reshape(-1).to(device)
