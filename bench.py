@@ -144,8 +144,15 @@ def main():
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("GABO_BENCH_ONE_DEVICE"):
+            # test hook: exercise the multi-rank code paths on a ONE-GPU box (all ranks on cuda:0, gloo instead of RCCL, which
+            # refuses two ranks on one device); never set by the driver
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist_mod.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
     elif args.gpus != 1:
         raise SystemExit("launch multi-GPU runs through torch.distributed.run (one process per GPU)")
@@ -162,6 +169,29 @@ def main():
     if not args.no_symmetric:
         sym = GramJob(x, device, symmetric=True)
         _, sym_ms = timed(sym, args.steps, args.warmup, None)
+
+    sharded = None
+    if world > 1:
+        # strong scaling of ONE N=4096 Gram: row blocks over the ranks, left sharded or assembled with one all_gather
+        from gabotorch_amd import ops as _ops
+        from gabotorch_amd.distributed import sharded_gram
+        xs = torch.tensor(np.ascontiguousarray(synthetic_spd_mandel(N_POINTS, DIM, 1234)), device=device)
+        fwd = lambda a, b: _ops.spd_ai_pairwise(a, b, beta=BETA)       # noqa: E731
+        res = {}
+        for gather in (False, True):
+            for _ in range(3):
+                sharded_gram(fwd, xs, xs, gather=gather)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                sharded_gram(fwd, xs, xs, gather=gather)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tt = torch.tensor([(time.perf_counter() - t0) / 10], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            res["all_gathered" if gather else "left_sharded"] = {"ms": float(tt.item()) * 1e3, "pairs_per_s": N_POINTS * N_POINTS / float(tt.item())}
+        sharded = {"workload": "one N=4096 d=10 Gram, row blocks of x1 over the ranks (replicated inputs)", **res}
 
     sweep = None
     if not args.no_sweep:
@@ -196,8 +226,8 @@ def main():
                  "seconds_constraints_captured": float(sw_c), "best_acq_constraints_captured": sw_val_c,
                  "seconds_constraints_captured_device_rand": float(sw_d), "best_acq_device_rand": sw_val_d,
                  "weak_scaling_512_restarts_per_gpu": weak,
-                 "note": "latency-bound: 512 restarts are 2 waves per CU and each wave runs its restart serially (about 0.45 ms per "
-                         "trust-region iteration); plus about 3.5 ms of initial-condition generation and 0.4 ms per iteration of user "
+                 "note": "latency-bound: 512 restarts are 2 waves per CU and each wave runs its restart serially (about 0.25 ms per "
+                         "trust-region iteration); plus 1.5-3.5 ms of initial-condition generation (host sampling) and 0.4 ms per iteration of user "
                          "constraint callables.  Does not speed up with more GPUs at this size (weak scaling only)"}
 
     t = torch.tensor([wall], dtype=torch.float64, device=device)
@@ -250,6 +280,8 @@ def main():
         }
         if sweep is not None:
             line["acq_sweep"] = sweep
+        if sharded is not None:
+            line["sharded_gram"] = sharded
         if not args.no_sweep:
             # config 2 of BASELINE.json beside the headline: SphereGaussianKernel S^9, N=4096 (HBM-write bound: 8.04 B/pair)
             from gabotorch_amd import ops as _ops

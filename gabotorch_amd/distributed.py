@@ -38,6 +38,11 @@ def sharded_gram(kernel_forward, x1, x2, gather=True):
         return block
     pad = torch.zeros(per, n2, dtype=torch.float64, device=block.device)
     pad[:hi - lo] = block
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad)
-    return torch.cat(parts)[:n1]
+    full = torch.empty(world * per, n2, dtype=torch.float64, device=block.device)
+    try:
+        dist.all_gather_into_tensor(full, pad)           # one collective straight into the assembled matrix
+    except (RuntimeError, NotImplementedError, AttributeError):
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        full = torch.cat(parts)
+    return full[:n1]
