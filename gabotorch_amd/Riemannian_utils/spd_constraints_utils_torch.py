@@ -8,6 +8,8 @@ from .. import _lib, ops
 class _ExtremeEig(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, op):
+        if not x.requires_grad:            # value only (e.g. the strict solver's feasibility test): skip the v v^T output
+            return ops.spd_manifold_op(op, x).to(x.dtype)
         lam, vv = ops.spd_manifold_op(op, x, want_grad=True)
         ctx.save_for_backward(vv)
         return lam.to(x.dtype)

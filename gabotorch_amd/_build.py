@@ -60,7 +60,7 @@ def build(force=False, extra_flags=(), verbose=False):
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
     srcs = sources()
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, list(extra_flags)), srcs))
     objs = [o for o, _ in res]
     if any(changed for _, changed in res) or _stale(LIB, objs):

@@ -16,6 +16,7 @@ GABO_SPD_MAX_DIM = 32
 (GABO_SPD_EXP, GABO_SPD_LOG, GABO_SPD_INNER, GABO_SPD_NORM, GABO_SPD_DIST, GABO_SPD_EGRAD2RGRAD, GABO_SPD_EHESS2RHESS,
  GABO_SPD_LOGM, GABO_SPD_EXPM, GABO_SPD_SQRTM, GABO_SPD_EIGMAX, GABO_SPD_EIGMIN) = range(12)
 GABO_ACQ_EXPECTED_IMPROVEMENT, GABO_ACQ_POSTERIOR_MEAN = 0, 1
+GABO_METRIC_AFFINE_INVARIANT, GABO_METRIC_LOG_EUCLIDEAN, GABO_METRIC_FROBENIUS = 0, 8, 16
 GABO_SPH_PROJ, GABO_SPH_RETR, GABO_SPH_EXP, GABO_SPH_LOG, GABO_SPH_DIST, GABO_SPH_EHESS2RHESS = range(6)
 
 _ERR = {GABO_ERR_DIM: "unsupported dimension", GABO_ERR_ARG: "bad argument", GABO_ERR_NOT_SPD: "input is not SPD",

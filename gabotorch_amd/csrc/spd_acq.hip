@@ -14,7 +14,7 @@
 
 namespace gabo {
 
-template <int D>
+template <int D, int METRIC>
 __global__ __launch_bounds__(64) void spd_acq_kernel(const double* __restrict__ x, AcqParams P, double* __restrict__ value,
                                                      double* __restrict__ grad, double* __restrict__ scratch,
                                                      const int* __restrict__ active, int* __restrict__ status) {
@@ -23,7 +23,8 @@ __global__ __launch_bounds__(64) void spd_acq_kernel(const double* __restrict__ 
     __shared__ AcqLds<D> lds;
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
-    acq_eval<D>(x + i * T, P, value + i, grad ? grad + i * T : nullptr, scratch ? scratch + i * T * P.n : nullptr, lds, dyn, status, i);
+    acq_eval_any<D, METRIC>(x + i * T, P, value + i, grad ? grad + i * T : nullptr, scratch ? scratch + i * T * P.n : nullptr, lds, dyn,
+                            status, i);
 }
 
 template <int D>
@@ -32,7 +33,17 @@ static int launch_spd_acq(const double* x, const double* G, const double* alpha,
                           double os, double kxx, double best_f, int kind, int maximize, double out_sign, const int* active, int* status, hipStream_t st) {
     size_t lds = (size_t)(3 * n) * sizeof(double);
     AcqParams P{G, alpha, linv, linv_t, n, beta, mode, mean, os, kxx, best_f, kind, maximize, out_sign};
-    hipLaunchKernelGGL((spd_acq_kernel<D>), dim3((unsigned)r), dim3(64), lds, st, x, P, value, grad, scratch, active, status);
+    const int metric = mode & GABO_METRIC_MASK;
+    if (metric == GABO_METRIC_AFFINE_INVARIANT) {
+        hipLaunchKernelGGL((spd_acq_kernel<D, 0>), dim3((unsigned)r), dim3(64), lds, st, x, P, value, grad, scratch, active, status);
+    } else if constexpr (D <= 8) {
+        if (metric == GABO_METRIC_LOG_EUCLIDEAN)
+            hipLaunchKernelGGL((spd_acq_kernel<D, 1>), dim3((unsigned)r), dim3(64), lds, st, x, P, value, grad, scratch, active, status);
+        else
+            hipLaunchKernelGGL((spd_acq_kernel<D, 2>), dim3((unsigned)r), dim3(64), lds, st, x, P, value, grad, scratch, active, status);
+    } else {
+        return GABO_ERR_DIM;
+    }
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
@@ -77,10 +88,17 @@ int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const
                       double out_sign, const int* active, int* status, gabo_stream_t stream) {
     if (d < 2 || d > GABO_SPD_REG_MAX_DIM) return GABO_ERR_DIM;
     if (r < 0 || r > 0x7fffffffLL || n < 1 || n > gabo_spd_acq_max_train(d)) return GABO_ERR_ARG;
-    if (flags != GABO_OUT_GAUSSIAN && flags != GABO_OUT_LAPLACE) return GABO_ERR_ARG;
+    {
+        const int out = flags & GABO_OUT_MASK, metric = flags & GABO_METRIC_MASK;
+        if ((flags & ~(GABO_OUT_MASK | GABO_METRIC_MASK)) || (out != GABO_OUT_GAUSSIAN && out != GABO_OUT_LAPLACE)) return GABO_ERR_ARG;
+        if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN && metric != GABO_METRIC_FROBENIUS)
+            return GABO_ERR_ARG;
+        if (metric != GABO_METRIC_AFFINE_INVARIANT && (out != GABO_OUT_GAUSSIAN || d > 8)) return d > 8 ? GABO_ERR_DIM : GABO_ERR_ARG;
+    }
     if (kind != GABO_ACQ_EXPECTED_IMPROVEMENT && kind != GABO_ACQ_POSTERIOR_MEAN) return GABO_ERR_ARG;
     if (r == 0) return GABO_OK;
-    if (!x_mandel || !train_factors || !alpha || !value || !status || (grad_mandel && !scratch)) return GABO_ERR_ARG;
+    if (!x_mandel || !train_factors || !alpha || !value || !status) return GABO_ERR_ARG;
+    if (grad_mandel && !scratch && (flags & GABO_METRIC_MASK) == GABO_METRIC_AFFINE_INVARIANT) return GABO_ERR_ARG;
     if (kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!linv || !linv_t)) return GABO_ERR_ARG;
 #define GABO_CASE(DD) \
     case DD:          \

@@ -40,7 +40,7 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
     const double* __restrict__ linv_t = P.linv_t;
     const int64_t n = P.n;
     const double beta = P.beta, mean0 = P.mean, os = P.outputscale, kxx = P.kxx, best_f = P.best_f, out_sign = P.out_sign;
-    const int mode = P.flags, kind = P.kind, maximize = P.maximize;
+    const int mode = P.flags & GABO_OUT_MASK, kind = P.kind, maximize = P.maximize;
     double* acc = L.acc;
     double* vls = L.vls;
     double* red = L.red;
@@ -202,6 +202,170 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
         t *= -2.0;
         grad_out[mandel_pos(D, a, bb)] = (a == bb) ? t : t * kSqrt2;
     }
+}
+
+// Same contract as acq_eval<D> for the two Frobenius-type surrogates (kernels_spd.py:190-313):
+//   METRIC 1: log-Euclidean  k_j = exp(-beta ||logm x - logm X_j + 1e-15||_F^2),  P.train_factors = Mandel(logm X_j), entry-major [T][n]
+//   METRIC 2: Frobenius      k_j = exp(-beta ||x - X_j + 1e-15||_F^2),            P.train_factors = Mandel(X_j),      entry-major [T][n]
+// The candidate's eigen-decomposition (registers, every lane redundantly: D <= 8) serves both logm(x) and the adjoint of its
+// Frechet derivative (Daleckii-Krein) that carries the gradient from log space back to x.  dyn: 3 n doubles of LDS.
+template <int D, int METRIC>
+__device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, const AcqParams& P, double* __restrict__ value_out,
+                                              double* __restrict__ grad_out, double* dyn) {
+    static_assert(D <= 8, "register-resident eigenvectors");
+    constexpr int T = tri_size(D);
+    const double* __restrict__ Ft = P.train_factors;
+    const double* __restrict__ alpha = P.alpha;
+    const double* __restrict__ linv = P.linv;
+    const double* __restrict__ linv_t = P.linv_t;
+    const int64_t n = P.n;
+    const double beta = P.beta, mean0 = P.mean, os = P.outputscale, kxx = P.kxx, best_f = P.best_f, out_sign = P.out_sign;
+    const int kind = P.kind, maximize = P.maximize;
+    double* ks = dyn;
+    double* kd = ks + n;
+    double* vv = kd + n;
+    const int lane = threadIdx.x;
+    const bool want_grad = grad_out != nullptr;
+    // ---- candidate features (Mandel order), wave-uniform
+    double fx[T];
+    double m[T], v[D * D], lam[D], lg[D];
+    if constexpr (METRIC == 1) {
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            static_for<r + 1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                double e = xrow[mandel_pos(D, r, c)];
+                m[tri(r, c)] = (r == c) ? e : e / kSqrt2;
+            });
+        });
+        jacobi_eig_reg<D>(m, v);
+        static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; lam[k] = m[tri(k, k)]; lg[k] = log(lam[k]); });
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            static_for<r + 1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                double f = 0.0;
+                static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; f = __builtin_fma(v[r * D + k] * lg[k], v[c * D + k], f); });
+                fx[mandel_pos(D, r, c)] = (r == c) ? f : f * kSqrt2;
+            });
+        });
+    } else {
+        static_for<T>([&](auto ee) { fx[decltype(ee)::value] = xrow[decltype(ee)::value]; });
+    }
+    // the reference adds 1e-15 to every MATRIX element of the difference (spd_utils_torch.py:156): Mandel off-diagonals carry sqrt2
+    for (int64_t j = lane; j < n; j += 64) {
+        double s = 0.0;
+        static_for<T>([&](auto ee) {
+            constexpr int e = decltype(ee)::value;
+            const double diff = (fx[e] - Ft[(int64_t)e * n + j]) + (e < D ? 1e-15 : kSqrt2 * 1e-15);
+            s = __builtin_fma(diff, diff, s);
+        });
+        const double kj = exp(-(s * beta));
+        ks[j] = os * kj;
+        kd[j] = -beta * kj;
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int64_t j = lane; j < n; j += 64) part = __builtin_fma(ks[j], alpha[j], part);
+    const double mean = mean0 + wave_sum64(part);
+    const double sgn = maximize ? 1.0 : -1.0;
+    double g_mean, g_var = 0.0;
+    if (kind == GABO_ACQ_POSTERIOR_MEAN) {
+        if (lane == 0) *value_out = out_sign * sgn * mean;
+        g_mean = sgn;
+    } else {
+        part = 0.0;
+        for (int64_t r = lane; r < n; r += 64) {
+            double a = 0.0;
+            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(linv_t[j * n + r], ks[j], a);
+            vv[r] = a;
+            part = __builtin_fma(a, a, part);
+        }
+        const double var = os * kxx - wave_sum64(part);
+        const bool clamped = !(var > 1e-9);
+        const double sigma = __builtin_sqrt(clamped ? 1e-9 : var);
+        const double u = sgn * (mean - best_f) / sigma;
+        const double pdf = exp(-0.5 * u * u) * 0.3989422804014327;
+        const double cdf = 0.5 * (1.0 + erf(u * 0.7071067811865476));
+        if (lane == 0) *value_out = out_sign * sigma * (pdf + u * cdf);
+        g_mean = sgn * cdf;
+        g_var = clamped ? 0.0 : 0.5 * pdf / sigma;
+    }
+    if (!want_grad) return;
+    __syncthreads();
+    // ---- G = d(out_sign acq)/d(features) = sum_j w_j 2 (fx - F_j + eps),  w_j = d/d(d_j^2)
+    double gacc[T];
+    static_for<T>([&](auto ee) { gacc[decltype(ee)::value] = 0.0; });
+    for (int64_t j = lane; j < n; j += 64) {
+        double ws = 0.0;
+        if (kind != GABO_ACQ_POSTERIOR_MEAN)
+            for (int64_t r = j; r < n; ++r) ws = __builtin_fma(linv[r * n + j], vv[r], ws);
+        const double gk = out_sign * os * (g_mean * alpha[j] - 2.0 * g_var * ws);
+        const double wj = 2.0 * gk * kd[j];
+        static_for<T>([&](auto ee) {
+            constexpr int e = decltype(ee)::value;
+            const double diff = (fx[e] - Ft[(int64_t)e * n + j]) + (e < D ? 1e-15 : kSqrt2 * 1e-15);
+            gacc[e] = __builtin_fma(wj, diff, gacc[e]);
+        });
+    }
+    static_for<T>([&](auto ee) { gacc[decltype(ee)::value] = wave_sum64(gacc[decltype(ee)::value]); });
+    if constexpr (METRIC == 2) {
+        if (lane == 0) static_for<T>([&](auto ee) { grad_out[decltype(ee)::value] = gacc[decltype(ee)::value]; });
+    } else {
+        // adjoint of dlogm at x:  V ((V^T Gm V) o Fdd) V^T,  Fdd_kl = (log l_k - log l_l)/(l_k - l_l), Fdd_kk = 1/l_k
+        double inner[D * D];
+        static_for<D>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            static_for<D>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                double sacc = 0.0;
+                static_for<D>([&](auto rr) {
+                    constexpr int r = decltype(rr)::value;
+                    double t = 0.0;      // (Gm V)[r][b]
+                    static_for<D>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        constexpr int hi = r > c ? r : c, lo = r > c ? c : r;
+                        const double gm = (r == c) ? gacc[mandel_pos(D, hi, lo)] : gacc[mandel_pos(D, hi, lo)] / kSqrt2;
+                        t = __builtin_fma(gm, v[c * D + b], t);
+                    });
+                    sacc = __builtin_fma(v[r * D + a], t, sacc);
+                });
+                const double la = lam[a], lb = lam[b];
+                const double meanl = 0.5 * (la + lb), dl = la - lb;
+                const double z = dl / (2.0 * meanl), z2 = z * z;
+                const double fdd = (__builtin_fabs(z) < 1e-3) ? (1.0 + z2 * (1.0 / 3.0 + z2 * (0.2 + z2 * (1.0 / 7.0)))) / meanl
+                                                               : (lg[a] - lg[b]) / dl;
+                inner[a * D + b] = sacc * fdd;
+            });
+        });
+        if (lane == 0) {
+            static_for<D>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                static_for<r + 1>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    double f1 = 0.0, f2 = 0.0;       // (r, c) and (c, r): averaged like symmetric_matrix_to_vector_mandel
+                    static_for<D>([&](auto aa) {
+                        constexpr int a = decltype(aa)::value;
+                        static_for<D>([&](auto bb) {
+                            constexpr int b = decltype(bb)::value;
+                            f1 = __builtin_fma(v[r * D + a] * inner[a * D + b], v[c * D + b], f1);
+                            f2 = __builtin_fma(v[c * D + a] * inner[a * D + b], v[r * D + b], f2);
+                        });
+                    });
+                    grad_out[mandel_pos(D, r, c)] = (r == c) ? f1 : 0.5 * (kSqrt2 * f1 + kSqrt2 * f2);
+                });
+            });
+        }
+    }
+}
+
+// metric dispatch: GABO_METRIC_* bits of P.flags are resolved by the host into the METRIC template parameter
+template <int D, int METRIC>
+__device__ __forceinline__ void acq_eval_any(const double* __restrict__ xrow, const AcqParams& P, double* __restrict__ value_out,
+                                             double* __restrict__ grad_out, double* __restrict__ F, AcqLds<D>& L, double* dyn,
+                                             int* __restrict__ status, int64_t index) {
+    if constexpr (METRIC == 0) acq_eval<D>(xrow, P, value_out, grad_out, F, L, dyn, status, index);
+    else acq_eval_frob<D, METRIC>(xrow, P, value_out, grad_out, dyn);
 }
 
 }  // namespace gabo

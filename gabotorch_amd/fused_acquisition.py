@@ -50,11 +50,17 @@ class FusedAcquisition:
             d_spd = ops._mandel_dim(self.train.shape[-1])
             self.single_launch = (d_spd <= _lib.GABO_SPD_REG_MAX_DIM
                                   and self.train.shape[0] <= _lib.load().gabo_spd_acq_max_train(d_spd))
+        self.metric = {"ai": _lib.GABO_METRIC_AFFINE_INVARIANT, "le": _lib.GABO_METRIC_LOG_EUCLIDEAN, "frob": _lib.GABO_METRIC_FROBENIUS}[flavour]
         self.train_factors = ops.spd_acq_prepare_train(self.train) if self.single_launch else None
         if family == "spd" and flavour != "ai":
             # ||0 + 1e-15||_F^2 = d^2 1e-30 (spd_utils_torch.py:156): k(x, x) = 1 to the last bit; logm of the training set once
             self.kxx = 1.0
             self.train_feat = ops.spd_logm_mandel(self.train) if flavour == "le" else self.train
+            d_spd = ops._mandel_dim(self.train.shape[-1])
+            if d_spd <= 8 and self.train.shape[0] <= _lib.load().gabo_spd_acq_max_train(d_spd) and mode == _lib.GABO_OUT_GAUSSIAN:
+                # one launch per evaluation for these too: the "factors" are the training features, entry-major
+                self.single_launch = True
+                self.train_factors = self.train_feat.t().contiguous()
         elif family == "spd":
             # d(X, X)^2 = 1e-15 exactly (the eigenvalues of L^-1 X L^-T are 1 to rounding): spd_utils_torch.py:120
             self.kxx = math.exp(-beta * (1e-15 if mode == _lib.GABO_OUT_GAUSSIAN else math.sqrt(1e-15)))
@@ -130,11 +136,11 @@ class FusedAcquisition:
     def acq_params(self):
         """The surrogate as the gabo_spd_acq_params struct of the C ABI (single-launch path only)."""
         return _lib.AcqParams(self.train_factors.data_ptr(), self.alpha.data_ptr(), self.linv.data_ptr(), self.linv_t.data_ptr(),
-                              self.train.shape[0], self.beta, int(self.mode), self.mean, self.outputscale, self.kxx, self.best_f,
+                              self.train.shape[0], self.beta, int(self.mode) | self.metric, self.mean, self.outputscale, self.kxx, self.best_f,
                               int(self.kind), 1 if self.maximize else 0, -1.0)
 
     def _single(self, pts, need_grad, active_ptr=None, out=None):
-        return ops.spd_acq_eval(pts, self.train_factors, self.alpha, self.linv, self.linv_t, self.beta, self.mode, self.mean,
+        return ops.spd_acq_eval(pts, self.train_factors, self.alpha, self.linv, self.linv_t, self.beta, int(self.mode) | self.metric, self.mean,
                                 self.outputscale, self.kxx, self.best_f, self.kind, self.maximize, out_sign=-1.0, need_grad=need_grad,
                                 active_ptr=active_ptr, out=out)
 

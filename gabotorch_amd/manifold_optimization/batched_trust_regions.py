@@ -162,6 +162,21 @@ class BatchedTrustRegions:
             grads.append(problem.manifold.egrad2rgrad(x, g.detach()))
         return torch.stack(vals, dim=1), grads
 
+    @staticmethod
+    def _constraint_values(x, constraints):
+        """-> fc (R, C) only (the strict variant's feasibility test of a proposal needs no gradients)"""
+        vals = []
+        with torch.no_grad():
+            for con in constraints:
+                try:
+                    f = con(x)
+                    if f.shape != x.shape[:1]:
+                        raise RuntimeError
+                except Exception:   # noqa: BLE001  a user callable written for one point
+                    f = torch.stack([con(x[i]) for i in range(x.shape[0])])
+                vals.append(f.detach().to(x.dtype))
+        return torch.stack(vals, dim=1)
+
     # ------------------------------------------------------------------------------------------------- solve
     def solve(self, problem, x, eq_constraints=None, ineq_constraints=None, mininner=1, maxinner=None, Delta_bar=None,
               Delta0=None, Delta_cons=None):
@@ -203,7 +218,7 @@ class BatchedTrustRegions:
             fx_prop = problem.cost(x_prop)
             invalid = torch.zeros_like(active)
             if constrained and self.strict_constraints:
-                fcp, _ = self._constraint_values_grads(problem, x_prop, eqs + ineqs)        # (:932-951)
+                fcp = self._constraint_values(x_prop, eqs + ineqs)                          # (:932-951)
                 viol = fcp.clone()
                 viol[:, neq:] = torch.clamp(viol[:, neq:], max=0.0)
                 invalid = viol.abs().sum(1) != 0
@@ -281,7 +296,7 @@ class BatchedTrustRegions:
             gc_buf.copy_(torch.stack(gc))
 
         def constraints_at_proposal(A):              # StrictConstrainedTrustRegions (constrained_trust_regions.py:932-951)
-            fcp, _ = self._constraint_values_grads(problem, A["x_prop"], cons)
+            fcp = self._constraint_values(A["x_prop"], cons)
             viol = fcp.clone()
             viol[:, neq:] = torch.clamp(viol[:, neq:], max=0.0)
             invalid_buf.copy_(viol.abs().sum(1) != 0)

@@ -585,7 +585,8 @@ def spd_acq_eval(x_mandel, train_factors, alpha, linv, linv_t, beta, mode, mean,
     else:
         value = torch.empty(r, dtype=torch.float64, device=dev)
         grad = torch.empty_like(x) if need_grad else None
-    scratch = torch.empty(r * dv * n, dtype=torch.float64, device=dev) if need_grad else None
+    affine = (int(mode) & 24) == 0           # only the affine-invariant metric spills logm(M_j) to scratch
+    scratch = torch.empty(r * dv * n, dtype=torch.float64, device=dev) if (need_grad and affine) else None
     status = torch.zeros(2, dtype=torch.int32, device=dev)
     ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
     with torch.cuda.device(dev):

@@ -36,6 +36,11 @@ typedef void* gabo_stream_t; /* hipStream_t */
 #define GABO_OUT_LAPLACE 2      /* out = exp(-beta * d)              kernels_spd.py:185, kernels_sphere.py:133 */
 #define GABO_OUT_MASK 3
 #define GABO_SYMMETRIC 4        /* x1 and x2 are the same set (n1 == n2): evaluate i <= j only and mirror */
+/* distance used by the fused acquisition kernels (gabo_spd_acq_params.flags, OR-ed with GABO_OUT_GAUSSIAN / GABO_OUT_LAPLACE) */
+#define GABO_METRIC_AFFINE_INVARIANT 0
+#define GABO_METRIC_LOG_EUCLIDEAN 8   /* kernels_spd.py:244-313; Gaussian only, d <= 8 */
+#define GABO_METRIC_FROBENIUS 16      /* kernels_spd.py:190-241; Gaussian only, d <= 8 */
+#define GABO_METRIC_MASK 24
 
 /* SPD pairwise kernels: 2 <= d <= GABO_SPD_MAX_DIM.  d <= GABO_SPD_REG_MAX_DIM runs the register-resident lane-per-pair
  * kernels (the fast path, the metric); larger d falls back to one wave per pair with LDS tiles. */
@@ -211,13 +216,14 @@ int gabo_nested_sphere_epilogue_backward(const double* rotated, const double* gr
  *     outputs left untouched (the trust regions pass the running flags of gabo_spd_tcg_*); remaining arguments as in
  *     gabo_gp_acquisition. */
 typedef struct {
-    const double* train_factors; /* gabo_spd_acq_prepare_train output, d_vec x n */
+    const double* train_factors; /* affine-invariant: gabo_spd_acq_prepare_train output; log-Euclidean / Frobenius: the Mandel vectors of
+                                    logm(X_j) / X_j; always entry-major d_vec x n */
     const double* alpha;         /* n */
     const double* linv;          /* n x n */
     const double* linv_t;        /* n x n */
     int64_t n;
     double beta;
-    int flags;                   /* GABO_OUT_GAUSSIAN / GABO_OUT_LAPLACE */
+    int flags;                   /* GABO_OUT_GAUSSIAN / GABO_OUT_LAPLACE | GABO_METRIC_* */
     double mean, outputscale, kxx, best_f;
     int kind, maximize;          /* GABO_ACQ_*, maximize != 0 */
     double out_sign;

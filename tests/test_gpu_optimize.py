@@ -354,20 +354,20 @@ def test_gp_acquisition_kernel_against_the_numpy_oracle():
         np.testing.assert_allclose(grad.cpu().numpy(), num, rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("d", [2, 5, 8])
 @pytest.mark.parametrize("flavour", ["le", "frob"])
-def test_fused_chain_for_log_euclidean_and_frobenius_kernels(flavour):
+def test_fused_chain_for_log_euclidean_and_frobenius_kernels(flavour, d):
     """The latent surrogate of config 5 (SpdLogEuclideanGaussianKernel, hd_gabo_spd.py:166) takes the fused chain too."""
     from gabotorch_amd.fused_acquisition import FusedAcquisition
     from gabotorch_amd.kernel_utils.kernels_spd import SpdFrobeniusGaussianKernel, SpdLogEuclideanGaussianKernel
-    d = 2
-    rng, X, y = _spd_gp(d, n_train=17, seed=4)
+    rng, X, y = _spd_gp(d, n_train=70 if d == 5 else 17, seed=4)
     kern = (SpdLogEuclideanGaussianKernel if flavour == "le" else SpdFrobeniusGaussianKernel)().double()
     kern.lengthscale = torch.tensor(1.3, dtype=torch.float64)
     gp = models.ExactGP(t(X), t(y), kern, outputscale=1.2, noise=1e-2)
     acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
     post = symmetric_matrix_to_vector_mandel_torch
     fused = FusedAcquisition.build(acq, post, torch.device(DEV))
-    assert fused is not None and not fused.single_launch and fused.flavour == flavour
+    assert fused is not None and fused.single_launch and fused.flavour == flavour      # d <= 8: one launch per evaluation
     q = np.linalg.qr(rng.standard_normal((50, d, d)))[0]
     P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (50, d)), q)
     x = t(0.5 * (P + P.transpose(0, 2, 1)))
@@ -380,6 +380,11 @@ def test_fused_chain_for_log_euclidean_and_frobenius_kernels(flavour):
     np.testing.assert_allclose(fused.cost(x).cpu().numpy(), f.cpu().numpy(), rtol=0, atol=0)
     np.testing.assert_allclose(fused.egrad_mandel(ops.matrix_to_mandel(x)).cpu().numpy(), ops.matrix_to_mandel(g).cpu().numpy(),
                                rtol=1e-12, atol=1e-14)
+    # the separate-launch chain (d > 8) gives the same numbers
+    fused.single_launch = False
+    f2, g2 = fused.cost_egrad(x)
+    np.testing.assert_allclose(f2.cpu().numpy(), f.cpu().numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(g2.cpu().numpy(), g.cpu().numpy(), rtol=1e-8, atol=1e-11 * max(1.0, float(g.abs().max())))
 
 
 def test_single_launch_acquisition_at_the_lds_limits():

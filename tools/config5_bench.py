@@ -31,7 +31,7 @@ from gabotorch_amd.Riemannian_utils import spd_constraints_utils_torch as scut
 from gabotorch_amd.Riemannian_utils.spd_utils_torch import symmetric_matrix_to_vector_mandel_torch as to_vec, vector_to_symmetric_matrix_mandel_torch as to_mat
 
 
-def latent_sweep(R=512, raw=2048, n_train=50, graphs=True, fused=True):
+def latent_sweep(R=512, raw=2048, n_train=50, graphs=True, fused=True, capture=False):
     z = y[:n_train]
     lam = np.linalg.eigvalsh(np.einsum("da,ndc,cb->nab", W, X[:n_train], W))
     f = (np.log(lam / 2.0) ** 2).sum(1)
@@ -47,15 +47,16 @@ def latent_sweep(R=512, raw=2048, n_train=50, graphs=True, fused=True):
     solver = BatchedTrustRegions(mingradnorm=2e-4, maxiter=100, minstepsize=1e-4, strict_constraints=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=R, raw_samples=raw, bounds=None,
-                                   options={"device": "cuda:0", "hip_graphs": graphs, "batched_rand": True, "fused_acquisition": fused},
+                                   options={"device": "cuda:0", "hip_graphs": graphs, "batched_rand": True, "fused_acquisition": fused, "capture_constraints": capture},
                                    inequality_constraints=cons, pre_processing_manifold=to_mat, post_processing_manifold=to_vec,
                                    approx_hessian=True)
     torch.cuda.synchronize()
     return time.perf_counter() - t0, float(acq(best[None]).item()), solver.log["iterations"]
 
 
-for label, kw in (("generic autograd path, eager", dict(graphs=False, fused=False)), ("fused chain + device tCG, eager", dict(graphs=False)),
-                  ("fused chain + device tCG, hipGraphs", dict())):
+for label, kw in (("generic autograd path, eager", dict(graphs=False, fused=False)), ("device-resident TR iteration (single-launch log-Euclidean acquisition), eager", dict(graphs=False)),
+                  ("device-resident TR iteration, hipGraphs", dict()),
+                  ("device-resident TR iteration, hipGraphs incl. the constraint callables", dict(capture=True))):
     latent_sweep(**kw)
     dt, val, its = latent_sweep(**kw)
     print(f"config5 latent sweep (512 restarts, n=50, strict TR, log-Euclid kernel) {label}: {dt*1e3:.1f} ms  EI*={val:.6e}  TR iterations={its}")
