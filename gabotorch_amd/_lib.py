@@ -17,6 +17,7 @@ GABO_SPD_MAX_DIM = 32
  GABO_SPD_LOGM, GABO_SPD_EXPM, GABO_SPD_SQRTM, GABO_SPD_EIGMAX, GABO_SPD_EIGMIN) = range(12)
 GABO_ACQ_EXPECTED_IMPROVEMENT, GABO_ACQ_POSTERIOR_MEAN = 0, 1
 GABO_METRIC_AFFINE_INVARIANT, GABO_METRIC_LOG_EUCLIDEAN, GABO_METRIC_FROBENIUS = 0, 8, 16
+GABO_CONSTRAINT_MAX_EIGENVALUE, GABO_CONSTRAINT_MIN_EIGENVALUE = 0, 1
 GABO_SPH_PROJ, GABO_SPH_RETR, GABO_SPH_EXP, GABO_SPH_LOG, GABO_SPH_DIST, GABO_SPH_EHESS2RHESS = range(6)
 
 _ERR = {GABO_ERR_DIM: "unsupported dimension", GABO_ERR_ARG: "bad argument", GABO_ERR_NOT_SPD: "input is not SPD",
@@ -60,6 +61,7 @@ SIGNATURES = {
     "gabo_spd_tr_workspace_bytes": (_SZ, [_I64, _I, _I, _I64]),
     "gabo_spd_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
     "gabo_spd_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I64, _D, _D, _D, _D, _I64, _P, _P]),
+    "gabo_spd_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _SZ, _I64, _I, _D, _D, _D, _I, _I, _D, _D, _D, _D, _I64, _P, _P]),
     "gabo_spd_logm_mandel_backward": (_I, [_P, _P, _P, _I64, _I, _P]),
     "gabo_frobenius_backward": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _D, _I, _D, _P]),
     "gabo_sphere_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _I64, _I, _P]),

@@ -119,7 +119,7 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
         zr = __builtin_fma(z, M3[e], zr);
     }
     zr = wave_sum(zr);
-    for (int k = 0; k < C; ++k) {
+    for (int k = 0; gc != nullptr && k < C; ++k) {
         lds_load(gc + ((int64_t)k * R + i) * dd, M2, d);
         lds_symmetrize(M2, M4, d);
         lds_congruence(M1, M2, M3, M4, d);
@@ -139,7 +139,7 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
         sc[SC_C_FD] = 0.0;
         w.stop[i] = TCG_MAX_INNER_ITER;
         w.running[i] = active ? 1 : 0;
-        for (int k = 0; k < C; ++k) { w.fc[i * C + k] = fc[i * C + k]; w.fcg_pe[i * C + k] = 0.0; }
+        for (int k = 0; k < C; ++k) { if (fc != nullptr) w.fc[i * C + k] = fc[i * C + k]; w.fcg_pe[i * C + k] = 0.0; }
     }
 }
 

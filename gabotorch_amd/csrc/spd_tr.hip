@@ -12,7 +12,6 @@
 
 namespace gabo {
 
-// rho test and state update (robust_trust_regions.py:236-330; same algebra as batched_trust_regions.BatchedTrustRegions.solve)
 __global__ __launch_bounds__(64) void spd_tr_update_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
                                                            double* __restrict__ ng, double* __restrict__ delta_tr,
                                                            uint8_t* __restrict__ active, int64_t* __restrict__ iters,
@@ -22,52 +21,14 @@ __global__ __launch_bounds__(64) void spd_tr_update_kernel(double* __restrict__ 
                                                            int64_t maxiter, int* __restrict__ any_active) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int dd = d * d;
-    double* M0 = lds;
-    double* M1 = M0 + dd;
-    double* M2 = M1 + dd;
-    double* M3 = M2 + dd;
     const int64_t i = blockIdx.x;
     if (active[i] == 0) return;
     TrWs t = tr_layout(wsbase, R, d, C, n);
     const bool inval = invalid != nullptr && invalid[i] != 0;
-    const double fx0 = fx[i];
-    const double fxp = inval ? __builtin_inf() : t.fx_prop[i];
-    const double rho_reg = (__builtin_fabs(fx0) > 1.0 ? __builtin_fabs(fx0) : 1.0) * 2.220446049250313e-16 * rho_regularization;
-    const double rhonum = (fx0 - fxp) + rho_reg;
-    const double rhoden = t.rhoden[i] + rho_reg;
-    const bool model_decreased = rhoden >= 0.0;
-    const double rho = rhoden == 0.0 ? __builtin_nan("") : rhonum / rhoden;
-    const bool shrink = (rho < 0.25) || !model_decreased || (rho != rho) || inval;
-    const int stop_inner = t.tcg.stop[i];
-    const bool boundary = stop_inner == TCG_NEGATIVE_CURVATURE || stop_inner == TCG_EXCEEDED_TR ||
-                          (C > 0 && stop_inner == TCG_REACHED_CONSTRAINTS);
-    const bool grow = !shrink && rho > 0.75 && boundary;
-    const double D0 = delta_tr[i];
-    const double Dn = shrink ? D0 / 4 : (grow ? (2 * D0 < delta_bar ? 2 * D0 : delta_bar) : D0);
-    const bool accept = model_decreased && rho > rho_prime;
-    double ngi = ng[i];
-    if (accept) {
-        // x <- x+, g <- x+ sym(egrad) x+ (egrad2rgrad), ||g||_x = sqrt(tr(S x S x))
-        lds_load(x_prop + i * dd, M0, d);
-        lds_from_mandel(t.eg_prop + i * (int64_t)(d * (d + 1) / 2), M1, d);
-        lds_mm(M1, M0, M2, d, false, false);          // P = S X
-        lds_mm(M0, M2, M3, d, false, false);          // X S X
-        double s = 0.0;
-        for (int e = threadIdx.x; e < dd; e += 64) {
-            int r = e / d, c = e - r * d;
-            s = __builtin_fma(M2[e], M2[c * d + r], s);
-            x[i * dd + e] = M0[e];
-            g[i * dd + e] = 0.5 * (M3[e] + M3[c * d + r]);
-        }
-        s = wave_sum(s);
-        ngi = __builtin_sqrt(s > 0.0 ? s : 0.0);
-    }
+    const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, x_prop + i * dd, t, i, d, C,
+                                      delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter, lds);
     if (threadIdx.x == 0) {
-        delta_tr[i] = Dn;
-        if (accept) { fx[i] = fxp; ng[i] = ngi; }
-        const int64_t it = iters[i] + 1;
-        iters[i] = it;
-        if (ngi < mingradnorm || it >= maxiter) active[i] = 0;
+        if (!still) active[i] = 0;
         else atomicOr(any_active, 1);
     }
 }
@@ -128,6 +89,38 @@ int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, d
                        trust_radius, active, iters, invalid, x_prop, workspace, r, d, n_constraints, n_train, delta_bar, rho_prime,
                        rho_regularization, mingradnorm, maxiter, any_active);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
+                      const gabo_spd_acq_params* acq, int n_constraints, const int* constraint_kind, const double* constraint_bound,
+                      int strict, void* workspace, size_t workspace_bytes, int64_t r, int d, double delta_cons, double theta, double kappa,
+                      int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
+                      int64_t maxiter, int* status, gabo_stream_t stream) {
+    if (d < 2 || d > 8) return GABO_ERR_DIM;
+    if (r < 0 || r > 0x7fffffffLL || n_constraints < 0 || n_constraints > gabo::kMaxCons || maxinner < 1 || maxiter < 1 || !acq)
+        return GABO_ERR_ARG;
+    if (r == 0) return GABO_OK;
+    if (!x || !fx || !grad || !grad_norm || !trust_radius || !active || !iters || !workspace || !status ||
+        (n_constraints > 0 && (!constraint_kind || !constraint_bound)))
+        return GABO_ERR_ARG;
+    if (acq->n < 1 || acq->n > gabo_spd_acq_max_train(d) || !acq->train_factors || !acq->alpha) return GABO_ERR_ARG;
+    if (acq->kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!acq->linv || !acq->linv_t)) return GABO_ERR_ARG;
+    if (workspace_bytes < gabo_spd_tr_workspace_bytes(r, d, n_constraints, acq->n)) return GABO_ERR_ARG;
+    gabo::BuiltinCons B;
+    B.n = n_constraints;
+    B.strict = strict ? 1 : 0;
+    for (int k = 0; k < gabo::kMaxCons; ++k) {
+        B.kind[k] = k < n_constraints ? constraint_kind[k] : 0;
+        B.bound[k] = k < n_constraints ? constraint_bound[k] : 0.0;
+        if (k < n_constraints && B.kind[k] != GABO_CONSTRAINT_MAX_EIGENVALUE && B.kind[k] != GABO_CONSTRAINT_MIN_EIGENVALUE) return GABO_ERR_ARG;
+    }
+    gabo::SolveArgs a{x, fx, grad, grad_norm, trust_radius, active, iters, acq, B, workspace, r, d, delta_cons, theta, kappa, mininner,
+                      maxinner, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter, status, (hipStream_t)stream};
+    switch (acq->flags & GABO_METRIC_MASK) {
+        case GABO_METRIC_AFFINE_INVARIANT: return gabo::solve_affine_invariant(a);
+        case GABO_METRIC_LOG_EUCLIDEAN: return gabo::solve_log_euclidean(a);
+    }
+    return GABO_ERR_ARG;      /* (the Frobenius surrogate iterates through gabo_spd_tr_propose / gabo_spd_tr_update) */
 }
 
 }  // extern "C"

@@ -7,7 +7,7 @@ namespace gabo {
 
 struct TrWs {
     TcgWs tcg;
-    double *x_fd, *eg_fd, *val_fd, *xp_mandel, *eg_prop, *fx_prop, *rhoden, *F;
+    double *x_fd, *eg_fd, *val_fd, *xp_mandel, *eg_prop, *fx_prop, *rhoden, *xp_mat, *F;
     size_t bytes;
 };
 
@@ -24,33 +24,114 @@ static __host__ __device__ inline TrWs tr_layout(void* base, int64_t R, int d, i
     t.eg_prop = p;    p += R * dv;
     t.fx_prop = p;    p += R;
     t.rhoden = p;     p += R;
+    t.xp_mat = p;     p += R * (int64_t)d * d;
     t.F = p;          p += R * dv * n;
     t.bytes = (size_t)((char*)p - (char*)base);
     return t;
 }
 
+// The constraints the library can evaluate itself (no host callable needed): extreme eigenvalues of the iterate
+// (max/min_eigenvalue_constraint_torch, spd_constraints_utils_torch.py:17-50).  kind 0: bound - lambda_max(x) >= 0, 1: lambda_min(x) - bound >= 0.
+struct BuiltinCons {
+    int n;
+    int strict;
+    int kind[kMaxCons];
+    double bound[kMaxCons];
+};
+
+// extreme eigenpair of the symmetric D x D matrix at `a` (row-major, global or LDS), every lane redundantly (D <= 8)
+template <int D>
+__device__ __forceinline__ void eig_extremes(const double* __restrict__ a, double (&lam)[D], double (&v)[D * D]) {
+    constexpr int T = tri_size(D);
+    double m[T];
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; m[tri(r, c)] = 0.5 * (a[r * D + c] + a[c * D + r]); });
+    });
+    jacobi_eig_reg<D>(m, v);
+    static_for<D>([&](auto kk) { lam[decltype(kk)::value] = m[tri(decltype(kk)::value, decltype(kk)::value)]; });
+}
+
+// values and WHITENED Riemannian gradients of the built-in constraints at x (L = chol x already in the workspace):
+// f = bound - lambda_max: egrad = -v v^T, rgrad = x egrad x, whitened L^-1 rgrad L^-T = -(L^T v)(L^T v)^T  (and + for lambda_min - bound)
+template <int D>
+__device__ __forceinline__ void builtin_constraints(const double* __restrict__ x, const TcgWs& w, int64_t i, int64_t R,
+                                                    const BuiltinCons& B) {
+    constexpr int dd = D * D;
+    double lam[D], v[dd];
+    eig_extremes<D>(x, lam, v);
+    const double* L = w.chol + i * dd;
+    for (int k = 0; k < B.n; ++k) {
+        const bool want_max = B.kind[k] == 0;
+        double best = lam[0];
+        double vec[D];
+        static_for<D>([&](auto rr) { vec[decltype(rr)::value] = v[decltype(rr)::value * D]; });
+        static_for<D - 1>([&](auto kk) {
+            constexpr int c = decltype(kk)::value + 1;
+            const bool better = want_max ? (lam[c] > best) : (lam[c] < best);
+            best = better ? lam[c] : best;
+            static_for<D>([&](auto rr) { constexpr int r = decltype(rr)::value; vec[r] = better ? v[r * D + c] : vec[r]; });
+        });
+        double u[D];       // L^T v
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            double sacc = 0.0;
+            static_for<D - c>([&](auto rr) { constexpr int r = c + decltype(rr)::value; sacc = __builtin_fma(L[r * D + c], vec[r], sacc); });
+            u[c] = sacc;
+        });
+        if (threadIdx.x == 0) {
+            const double sign = want_max ? -1.0 : 1.0;
+            w.fc[i * B.n + k] = want_max ? B.bound[k] - best : best - B.bound[k];
+            double* out = w.gc_w + ((int64_t)k * R + i) * dd;
+            static_for<D>([&](auto rr) {
+                static_for<D>([&](auto cc) { out[decltype(rr)::value * D + decltype(cc)::value] = sign * u[decltype(rr)::value] * u[decltype(cc)::value]; });
+            });
+        }
+    }
+}
+
+// strict variant: does the proposal violate a built-in constraint?  (constrained_trust_regions.py:932-951)
+template <int D>
+__device__ __forceinline__ bool builtin_infeasible(const double* __restrict__ xp, const BuiltinCons& B) {
+    double lam[D], v[D * D];
+    eig_extremes<D>(xp, lam, v);
+    double lmax = lam[0], lmin = lam[0];
+    static_for<D - 1>([&](auto kk) {
+        constexpr int c = decltype(kk)::value + 1;
+        lmax = lam[c] > lmax ? lam[c] : lmax;
+        lmin = lam[c] < lmin ? lam[c] : lmin;
+    });
+    bool bad = false;
+    for (int k = 0; k < B.n; ++k) {
+        const double f = B.kind[k] == 0 ? B.bound[k] - lmax : lmin - B.bound[k];
+        bad = bad || (f < 0.0);
+    }
+    return bad;
+}
+
+// tCG + proposal + acquisition at the proposal for restart i (one wave).  gc/fc: host-evaluated constraints, or null with
+// `builtin` set (then the wave evaluates them itself).  mats: 5 D^2 + 2 doubles of LDS, dyn: 3 n doubles.
 template <int D, int METRIC>
-__global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __restrict__ x, const double* __restrict__ g,
-                                                            const double* __restrict__ delta_tr, const uint8_t* __restrict__ active,
-                                                            const double* __restrict__ gc, const double* __restrict__ fc,
-                                                            AcqParams P, void* wsbase, double* __restrict__ x_prop, int64_t R, int C,
-                                                            int neq, double delta_cons, double theta, double kappa, int mininner,
-                                                            int maxinner, int* __restrict__ any_active, int* __restrict__ status) {
+__device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta,
+                                                const double* __restrict__ gc, const double* __restrict__ fc, const AcqParams& P,
+                                                const TrWs& t, double* __restrict__ x_prop, int64_t i, int64_t R, int C, int neq,
+                                                double delta_cons, double theta, double kappa, int mininner, int maxinner,
+                                                AcqLds<D>& acq, double* mats, double* dyn, int* __restrict__ status,
+                                                const BuiltinCons* builtin) {
     constexpr int T = tri_size(D);
     constexpr int dd = D * D;
-    __shared__ AcqLds<D> acq;
-    __shared__ __attribute__((aligned(16))) double mats[5 * dd + 2];
-    extern __shared__ __attribute__((aligned(16))) double dyn[];
-    const int64_t i = blockIdx.x;
-    if (i == 0 && threadIdx.x == 0) *any_active = 0;          // set again by the update kernel
-    if (active[i] == 0) return;
-    TrWs t = tr_layout(wsbase, R, D, C, P.n);
     const TcgWs& w = t.tcg;
     double* xfd = t.x_fd + i * T;
     double* egfd = t.eg_fd + i * T;
     double* F = t.F + i * T * P.n;
-    tcg_begin(x + i * dd, g + i * dd, gc, fc, true, delta_tr[i], w, i, R, D, C, status, mats);
+    tcg_begin(x, g, gc, fc, true, delta, w, i, R, D, C, status, mats);
     __syncthreads();
+    if constexpr (D <= 8) {
+        if (builtin != nullptr && builtin->n > 0) {
+            builtin_constraints<D>(x, w, i, R, *builtin);
+            __syncthreads();
+        }
+    }
     for (int it = 0; it < maxinner; ++it) {
         tcg_fd_point(w, i, D, xfd, mats);
         __syncthreads();
@@ -101,7 +182,7 @@ __global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __rest
     }
     lds_congruence(M0, M3, M1, M2, D);
     lds_symmetrize(M1, M2, D);
-    lds_store(M1, x_prop + i * dd, D);
+    lds_store(M1, x_prop, D);
     double* xpm = t.xp_mandel + i * T;
     for (int e = threadIdx.x; e < T; e += 64) {
         int k = 0;
@@ -112,6 +193,111 @@ __global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __rest
     }
     __syncthreads();
     acq_eval_any<D, METRIC>(xpm, P, t.fx_prop + i, t.eg_prop + i * T, F, acq, dyn, status, i);
+}
+
+template <int D, int METRIC>
+__global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __restrict__ x, const double* __restrict__ g,
+                                                            const double* __restrict__ delta_tr, const uint8_t* __restrict__ active,
+                                                            const double* __restrict__ gc, const double* __restrict__ fc,
+                                                            AcqParams P, void* wsbase, double* __restrict__ x_prop, int64_t R, int C,
+                                                            int neq, double delta_cons, double theta, double kappa, int mininner,
+                                                            int maxinner, int* __restrict__ any_active, int* __restrict__ status) {
+    constexpr int dd = D * D;
+    __shared__ AcqLds<D> acq;
+    __shared__ __attribute__((aligned(16))) double mats[5 * dd + 2];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int64_t i = blockIdx.x;
+    if (i == 0 && threadIdx.x == 0) *any_active = 0;          // set again by the update kernel
+    if (active[i] == 0) return;
+    TrWs t = tr_layout(wsbase, R, D, C, P.n);
+    tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], gc, fc, P, t, x_prop + i * dd, i, R, C, neq, delta_cons, theta, kappa,
+                               mininner, maxinner, acq, mats, dyn, status, nullptr);
+}
+
+// rho test and state update of restart i (robust_trust_regions.py:236-330; same algebra as BatchedTrustRegions.solve).
+// lds: 4 d^2 doubles.  Returns true while the restart stays active.
+static __device__ bool tr_update_body(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g, double* __restrict__ ng,
+                                      double* __restrict__ delta_tr, int64_t* __restrict__ iters, bool inval,
+                                      const double* __restrict__ x_prop, const TrWs& t, int64_t i, int d, int C, double delta_bar,
+                                      double rho_prime, double rho_regularization, double mingradnorm, int64_t maxiter, double* lds) {
+    const int dd = d * d;
+    double* M0 = lds;
+    double* M1 = M0 + dd;
+    double* M2 = M1 + dd;
+    double* M3 = M2 + dd;
+    const double fx0 = *fx;
+    const double fxp = inval ? __builtin_inf() : t.fx_prop[i];
+    const double rho_reg = (__builtin_fabs(fx0) > 1.0 ? __builtin_fabs(fx0) : 1.0) * 2.220446049250313e-16 * rho_regularization;
+    const double rhonum = (fx0 - fxp) + rho_reg;
+    const double rhoden = t.rhoden[i] + rho_reg;
+    const bool model_decreased = rhoden >= 0.0;
+    const double rho = rhoden == 0.0 ? __builtin_nan("") : rhonum / rhoden;
+    const bool shrink = (rho < 0.25) || !model_decreased || (rho != rho) || inval;
+    const int stop_inner = t.tcg.stop[i];
+    const bool boundary = stop_inner == TCG_NEGATIVE_CURVATURE || stop_inner == TCG_EXCEEDED_TR ||
+                          (C > 0 && stop_inner == TCG_REACHED_CONSTRAINTS);
+    const bool grow = !shrink && rho > 0.75 && boundary;
+    const double D0 = *delta_tr;
+    const double Dn = shrink ? D0 / 4 : (grow ? (2 * D0 < delta_bar ? 2 * D0 : delta_bar) : D0);
+    const bool accept = model_decreased && rho > rho_prime;
+    double ngi = *ng;
+    const int64_t it = *iters + 1;
+    __syncthreads();                 // every lane has read the scalars before lane 0 rewrites them
+    if (accept) {
+        // x <- x+, g <- x+ sym(egrad) x+ (egrad2rgrad), ||g||_x = sqrt(tr(S x S x))
+        lds_load(x_prop, M0, d);
+        lds_from_mandel(t.eg_prop + i * (int64_t)(d * (d + 1) / 2), M1, d);
+        lds_mm(M1, M0, M2, d, false, false);          // P = S X
+        lds_mm(M0, M2, M3, d, false, false);          // X S X
+        double s = 0.0;
+        for (int e = threadIdx.x; e < dd; e += 64) {
+            int r = e / d, c = e - r * d;
+            s = __builtin_fma(M2[e], M2[c * d + r], s);
+            x[e] = M0[e];
+            g[e] = 0.5 * (M3[e] + M3[c * d + r]);
+        }
+        s = wave_sum(s);
+        ngi = __builtin_sqrt(s > 0.0 ? s : 0.0);
+    }
+    if (threadIdx.x == 0) {
+        *delta_tr = Dn;
+        if (accept) { *fx = fxp; *ng = ngi; }
+        *iters = it;
+    }
+    __syncthreads();
+    return !(ngi < mingradnorm || it >= maxiter);
+}
+
+// The whole trust-region solve of restart i in one launch: no host involvement between iterations.  Possible when the
+// constraints are the built-in eigenvalue bounds (or there are none); D <= 8.
+template <int D, int METRIC>
+__global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
+                                                          double* __restrict__ ng, double* __restrict__ delta_tr,
+                                                          uint8_t* __restrict__ active, int64_t* __restrict__ iters, AcqParams P,
+                                                          BuiltinCons B, void* wsbase, int64_t R, double delta_cons, double theta,
+                                                          double kappa, int mininner, int maxinner, double delta_bar, double rho_prime,
+                                                          double rho_regularization, double mingradnorm, int64_t maxiter,
+                                                          int* __restrict__ status) {
+    static_assert(D <= 8, "built-in constraints use the register eigen-solver");
+    constexpr int dd = D * D;
+    __shared__ AcqLds<D> acq;
+    __shared__ __attribute__((aligned(16))) double mats[5 * dd + 2];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int64_t i = blockIdx.x;
+    if (active[i] == 0) return;
+    const int C = B.n;
+    TrWs t = tr_layout(wsbase, R, D, C, P.n);
+    double* xp = t.xp_mat + i * dd;
+    for (;;) {
+        tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, P, t, xp, i, R, C, 0, delta_cons, theta, kappa,
+                                   mininner, maxinner, acq, mats, dyn, status, &B);
+        __syncthreads();
+        const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B) : false;
+        const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, i, D, C, delta_bar,
+                                          rho_prime, rho_regularization, mingradnorm, maxiter, mats);
+        if (!still) break;
+    }
+    if (threadIdx.x == 0) active[i] = 0;
 }
 
 // one translation unit per metric (spd_tr.hip, spd_tr_le.hip, spd_tr_frob.hip) so that the instantiations compile in parallel
@@ -158,7 +344,43 @@ static int dispatch_propose(const ProposeArgs& a) {
     return GABO_ERR_DIM;
 }
 
-// defined in spd_tr.hip / spd_tr_le.hip / spd_tr_frob.hip
+struct SolveArgs {
+    double *x, *fx, *g, *ng, *delta_tr;
+    uint8_t* active;
+    int64_t* iters;
+    const AcqParams* P;
+    BuiltinCons B;
+    void* ws;
+    int64_t r;
+    int d;
+    double delta_cons, theta, kappa;
+    int mininner, maxinner;
+    double delta_bar, rho_prime, rho_regularization, mingradnorm;
+    int64_t maxiter;
+    int* status;
+    hipStream_t st;
+};
+
+template <int METRIC>
+static int dispatch_solve(const SolveArgs& a) {
+    size_t lds = (size_t)(3 * a.P->n) * sizeof(double);
+#define GABO_CASE(DD)                                                                                                              \
+    case DD:                                                                                                                       \
+        hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
+                           a.active, a.iters, *a.P, a.B, a.ws, a.r, a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.delta_bar, \
+                           a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status);                               \
+        break;
+    switch (a.d) {
+        GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8)
+        default: return GABO_ERR_DIM;
+    }
+#undef GABO_CASE
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+// defined in spd_tr.hip / spd_tr_le.hip / spd_tr_frob.hip / spd_tr_solve.hip / spd_tr_solve_le.hip
+int solve_affine_invariant(const SolveArgs& a);
+int solve_log_euclidean(const SolveArgs& a);
 int propose_affine_invariant(const ProposeArgs& a);
 int propose_log_euclidean(const ProposeArgs& a);
 int propose_frobenius(const ProposeArgs& a);

@@ -13,6 +13,11 @@ import time
 
 import torch
 
+def _lib_frobenius():
+    from .. import _lib
+    return _lib.GABO_METRIC_FROBENIUS
+
+
 NEGATIVE_CURVATURE, EXCEEDED_TR, REACHED_TARGET_LINEAR, REACHED_TARGET_SUPERLINEAR, MAX_INNER_ITER, MODEL_INCREASED, \
     REACHED_CONSTRAINTS = range(7)
 
@@ -361,6 +366,20 @@ class BatchedTrustRegions:
                 TR.update(S.x, S.fx, S.g, S.ng, S.Delta, S.active_u8, S.iters, inv_u8 if strict else None, Delta_bar, self.rho_prime,
                           self.rho_regularization, self.mingradnorm, self.maxiter)
                 S.any_active.copy_(TR.any_active[0] != 0)
+
+            # no constraint needs a host callable (none, or eigenvalue bounds built with functools.partial as in the reference
+            # examples): the whole solve is ONE launch, every wave iterating its restart to the end
+            from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint
+            builtins = [builtin_constraint(c) for c in cons]
+            if (d <= 8 and neq == 0 and all(b is not None for b in builtins) and fused.metric != _lib_frobenius()
+                    and getattr(problem, "device_solve", True) and self.maxtime >= 1000):
+                TR.solve(S.x, S.fx, S.g, S.ng, S.Delta, S.active_u8, S.iters, [b[0] for b in builtins], [b[1] for b in builtins], strict,
+                          Delta_cons, self.theta, self.kappa, mininner, maxinner, Delta_bar, self.rho_prime, self.rho_regularization,
+                          self.mingradnorm, self.maxiter)
+                k = int(S.iters.max().item())
+                self.log = {"iterations": k, "per_restart_iterations": S.iters, "final_cost": S.fx, "final_gradnorm": S.ng,
+                            "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0}
+                return S.x
 
         # Execution plan.  Eager: the parts in order, with the inner loop leaving as soon as no restart runs.  hipGraphs: the
         # launches between two evaluations of the USER's constraint callables form one graph; the callables themselves run

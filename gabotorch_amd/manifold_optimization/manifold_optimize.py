@@ -134,6 +134,7 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
     problem.device_tcg = bool((options or {}).get("device_tcg", True))
     problem.device_outer = bool((options or {}).get("device_outer", True))
     problem.device_iteration = bool((options or {}).get("device_iteration", True))
+    problem.device_solve = bool((options or {}).get("device_solve", True))
     # the constraint callables are user code: they run eagerly between graph replays unless the caller states they are capturable
     problem.capture_constraints = bool((options or {}).get("capture_constraints", False))
     if solver_init_conds:

@@ -732,6 +732,21 @@ class SpdTr:
                                                     _stream_ptr(self.dev)), "gabo_spd_tr_propose")
         return self.x_prop
 
+    def solve(self, x, fx, g, ng, Delta, active, iters, kinds, bounds, strict, delta_cons, theta, kappa, mininner, maxinner, delta_bar,
+              rho_prime, rho_regularization, mingradnorm, maxiter):
+        """The whole solve in one launch (built-in eigenvalue constraints `kinds`/`bounds`, or none)."""
+        import ctypes
+        nc = len(kinds)
+        ck = (ctypes.c_int * max(nc, 1))(*kinds)
+        cb = (ctypes.c_double * max(nc, 1))(*bounds)
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_spd_tr_solve(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
+                                                  active.data_ptr(), iters.data_ptr(), self.acq_ref, nc, ck, cb, 1 if strict else 0,
+                                                  self.ws.data_ptr(), self.wsb, self.r, self.d, float(delta_cons), float(theta),
+                                                  float(kappa), int(mininner), int(maxinner), float(delta_bar), float(rho_prime),
+                                                  float(rho_regularization), float(mingradnorm), int(maxiter), self.status.data_ptr(),
+                                                  _stream_ptr(self.dev)), "gabo_spd_tr_solve")
+
     def update(self, x, fx, g, ng, Delta, active, iters, invalid, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter):
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.gabo_spd_tr_update(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),

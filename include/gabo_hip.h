@@ -287,6 +287,19 @@ int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, d
                        int64_t n_train, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
                        int64_t maxiter, int* any_active, gabo_stream_t stream);
 
+/* The whole solve in ONE launch: every wave iterates propose/update for its restart until its gradient norm or iteration limit is
+ * reached.  Possible when the constraints need no host callable: none, or bounds on the extreme eigenvalues of the iterate
+ * (max_eigenvalue_constraint_torch / min_eigenvalue_constraint_torch, spd_constraints_utils_torch.py:17-50), all inequalities;
+ * strict != 0 rejects infeasible proposals (StrictConstrainedTrustRegions).  2 <= d <= 8; affine-invariant and log-Euclidean
+ * surrogates.  State arrays as in gabo_spd_tr_update, updated in place; active[i] is 0 for every restart on return. */
+#define GABO_CONSTRAINT_MAX_EIGENVALUE 0   /* bound - lambda_max(x) >= 0 */
+#define GABO_CONSTRAINT_MIN_EIGENVALUE 1   /* lambda_min(x) - bound >= 0 */
+int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
+                      const gabo_spd_acq_params* acq, int n_constraints, const int* constraint_kind, const double* constraint_bound,
+                      int strict, void* workspace, size_t workspace_bytes, int64_t r, int d, double delta_cons, double theta, double kappa,
+                      int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
+                      int64_t maxiter, int* status, gabo_stream_t stream);
+
 /* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
  *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)
  *   GABO_SPH_RETR   out = (X+U)/|X+U|        [3P] Sphere.retr  (robust_trust_regions.py:228)

@@ -474,3 +474,50 @@ def test_device_solve_variants_match_torch_path(case):
         np.testing.assert_allclose(out[name][1], out["torch"][1], rtol=tol, atol=1e-12)
         np.testing.assert_allclose(out[name][0], out["torch"][0], rtol=0, atol=1e-6 if tol < 1e-6 else 1e-3)
     np.testing.assert_allclose(out["graphs"][1], out["device"][1], rtol=1e-12, atol=0)      # the execution plans are the same arithmetic
+
+
+@pytest.mark.parametrize("case", ["ai_unconstrained", "ai_max_eig", "ai_box_strict", "le_box_strict"])
+def test_single_launch_solve_matches_torch_path(case):
+    """gabo_spd_tr_solve (every wave iterates its restart to the end; the eigenvalue bounds - functools.partial objects as in the
+    reference examples - are evaluated on the device) against the torch lock-step solver, and against the same constraints given
+    as opaque lambdas (which take the propose/update plan)."""
+    import functools
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdLogEuclideanGaussianKernel
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    d, n_train, R = (2, 15, 90) if case.startswith("le") else (3, 20, 90)
+    rng, X, y = _spd_gp(d, n_train=n_train, seed=41)
+    if case.startswith("le"):
+        kern = SpdLogEuclideanGaussianKernel().double()
+        kern.lengthscale = torch.tensor(1.4, dtype=torch.float64)
+    else:
+        kern = SpdAffineInvariantGaussianKernel(beta_min=0.5)
+    gp = models.ExactGP(t(X), t(y), kern, outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    strict = case.endswith("strict")
+    if case.endswith("unconstrained"):
+        partials = lambdas = None
+    else:
+        partials = [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=2.5)]
+        lambdas = [lambda m: scut.max_eigenvalue_constraint_torch(m, 2.5)]
+        if "box" in case:
+            partials.append(functools.partial(scut.min_eigenvalue_constraint_torch, minimum_eigenvalue=0.35))
+            lambdas.append(lambda m: scut.min_eigenvalue_constraint_torch(m, 0.35))
+    q = np.linalg.qr(rng.standard_normal((R, d, d)))[0]
+    P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.4, 2.4, (R, d)), q)
+    x0 = ops.matrix_to_mandel(t(0.5 * (P + P.transpose(0, 2, 1))))[:, None]
+    man = manifolds.PositiveDefinite(d)
+    out = {}
+    ops.set_error_checking(False)
+    for name, cons, opts in (("torch", lambdas, {"device_tcg": False}), ("plan", lambdas, {}), ("solve", partials, {}),
+                             ("solve_off", partials, {"device_solve": False})):
+        solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=20, strict_constraints=strict)
+        c, v = gen_candidates_manifold(x0, acq, man, solver, vector_to_symmetric_matrix_mandel_torch, symmetric_matrix_to_vector_mandel_torch,
+                                       inequality_constraints=cons, approx_hessian=True, options=opts)
+        out[name] = (c.cpu().numpy(), v.cpu().numpy(), solver.log["per_restart_iterations"].cpu().numpy())
+    ops.set_error_checking(True)
+    for name in ("plan", "solve", "solve_off"):
+        np.testing.assert_array_equal(out[name][2], out["torch"][2])
+        np.testing.assert_allclose(out[name][1], out["torch"][1], rtol=2e-5, atol=1e-12)
+    np.testing.assert_allclose(out["solve"][1], out["plan"][1], rtol=1e-9, atol=1e-13)       # same device arithmetic, two drivers
+    np.testing.assert_allclose(out["solve"][0], out["plan"][0], rtol=0, atol=1e-8)
+    assert scut.builtin_constraint(lambdas[0]) is None if lambdas else True

@@ -1,5 +1,5 @@
 """Config 4 of BASELINE.json: gabo_spd S^5_++ acquisition sweep, 512 restarts (sharded over ranks when launched with torchrun)."""
-import os, sys, time
+import functools, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gabotorch_amd import manifolds, models, ops
@@ -20,7 +20,7 @@ def mandel(m):
     return np.ascontiguousarray(m[..., r, c] * np.where(r == c, 1.0, 2 ** 0.5))
 
 
-def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=1234, maxiter=100, hip_graphs=False, batched_rand=False, fused=True, device_tcg=True, device_outer=True, capture_constraints=False, strict=False, device_iteration=True, device_rand=False):
+def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=1234, maxiter=100, hip_graphs=False, batched_rand=False, fused=True, device_tcg=True, device_outer=True, capture_constraints=False, strict=False, device_iteration=True, device_rand=False, device_solve=True, builtin_constraint=False):
     rng = np.random.default_rng(seed)
     q = np.linalg.qr(rng.standard_normal((n_train, d, d)))[0]
     X = np.einsum("nab,nb,ncb->nac", q, rng.uniform(1e-3, 5.0, (n_train, d)), q)
@@ -45,7 +45,8 @@ def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=
     solver = BatchedTrustRegions(mingradnorm=1e-4, maxiter=maxiter, strict_constraints=strict)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=num_restarts, raw_samples=raw_samples, bounds=None,
-                                   options={"device": device, "hip_graphs": hip_graphs, "batched_rand": batched_rand, "fused_acquisition": fused, "device_tcg": device_tcg, "device_outer": device_outer, "capture_constraints": capture_constraints, "device_iteration": device_iteration, "device_rand": device_rand}, inequality_constraints=[lambda x: scut.max_eigenvalue_constraint_torch(x, 5.0)],
+                                   options={"device": device, "hip_graphs": hip_graphs, "batched_rand": batched_rand, "fused_acquisition": fused, "device_tcg": device_tcg, "device_outer": device_outer, "capture_constraints": capture_constraints, "device_iteration": device_iteration, "device_rand": device_rand, "device_solve": device_solve}, inequality_constraints=[functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=5.0) if builtin_constraint
+                                                           else (lambda x: scut.max_eigenvalue_constraint_torch(x, 5.0))],
                                    pre_processing_manifold=to_mat, post_processing_manifold=to_vec, approx_hessian=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     return dt, best, float(acq(best[None]).item()), solver.log
@@ -67,6 +68,12 @@ if __name__ == "__main__":
     for _ in range(2):
         dt, best, val2, log = run_sweep("cuda:0", num_restarts=R, hip_graphs=True, batched_rand=True, capture_constraints=True)
         print(f"sweep R={R} hipGraphs incl. constraints: {dt:.3f} s  {R/dt:.1f} restarts/s  EI*={val2:.6e}")
+    for _ in range(2):
+        dt, best, val2, log = run_sweep("cuda:0", num_restarts=R, batched_rand=True, builtin_constraint=True)
+        print(f"sweep R={R} single-launch solve (constraint = functools.partial of the built-in): {dt:.4f} s  {R/dt:.1f} restarts/s  EI*={val2:.6e}")
+    for _ in range(2):
+        dt, best, val2, log = run_sweep("cuda:0", num_restarts=R, device_rand=True, builtin_constraint=True)
+        print(f"sweep R={R} single-launch solve, raw samples drawn on the device: {dt:.4f} s  {R/dt:.1f} restarts/s  EI*={val2:.6e}")
     for _ in range(2):
         dt, best, val2, log = run_sweep("cuda:0", num_restarts=R, hip_graphs=True, device_rand=True, capture_constraints=True)
         print(f"sweep R={R} hipGraphs incl. constraints, raw samples drawn on the device: {dt:.4f} s  {R/dt:.1f} restarts/s  EI*={val2:.6e}")
