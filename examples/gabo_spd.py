@@ -6,6 +6,7 @@ manifold operations running in libgabo_hip.so and the acquisition restarts advan
     python examples/gabo_spd.py [--dim 3] [--iters 15] [--restarts 5] [--raw 100]
 """
 import argparse
+import functools
 import os
 import sys
 import types
@@ -35,7 +36,7 @@ def run(dim=3, iters=15, restarts=5, raw=100, seed=1234, device="cuda:0", verbos
     man.min_eig, man.max_eig = 0.001, 5.0
     man.rand = types.MethodType(spd_sample, man)                        # examples/gabo_spd.py:102
     objective = lambda x: ackley_function_spd(x, man)                  # noqa: E731
-    constraint = lambda x: max_eigenvalue_constraint_torch(x, man.max_eig)   # noqa: E731  (:136-138)
+    constraint = functools.partial(max_eigenvalue_constraint_torch, maximum_eigenvalue=man.max_eig)     # (:136-138)
     x_data = torch.tensor(np.stack([symmetric_matrix_to_vector_mandel(man.rand()) for _ in range(5)]), device=device)
     y_data = torch.cat([objective(x) for x in x_data]).reshape(-1).to(device)
     beta_min = BETA_MIN.get(dim, 0.2)

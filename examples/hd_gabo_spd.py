@@ -13,6 +13,7 @@ an augmented-Lagrangian solver (nested_spd_optimization.py:95-186); that host-si
     python examples/hd_gabo_spd.py [--dim 5] [--latent 2] [--iters 10]
 """
 import argparse
+import functools
 import os
 import sys
 import types
@@ -51,7 +52,8 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
     objective = lambda x: rosenbrock_function_spd(x, big)          # noqa: E731  evaluated on the HIGH-dimensional manifold
     x_data = torch.tensor(np.stack([symmetric_matrix_to_vector_mandel(big.rand()) for _ in range(5)]), device=device)
     y_data = torch.cat([objective(x) for x in x_data]).reshape(-1).to(device)
-    cons = [lambda x: max_eigenvalue_constraint_torch(x, small.max_eig), lambda x: min_eigenvalue_constraint_torch(x, small.min_eig)]
+    cons = [functools.partial(max_eigenvalue_constraint_torch, maximum_eigenvalue=small.max_eig),
+            functools.partial(min_eigenvalue_constraint_torch, minimum_eigenvalue=small.min_eig)]
     solver = BatchedTrustRegions(mingradnorm=2e-4, maxiter=100, minstepsize=1e-4, strict_constraints=True)   # hd_gabo_spd.py:194
     k_fct = ScaleKernel(NestedSpdLogEuclideanGaussianKernel(dim, latent), outputscale_prior=models.GammaPrior(2.0, 0.15)).double()
     ops.set_error_checking(False)
