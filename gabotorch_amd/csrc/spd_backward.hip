@@ -20,6 +20,10 @@
 #include "spd_generic.hpp"
 #include "../../include/gabo_hip.h"
 
+#ifndef GABO_BWD_REGV_MAX_DIM
+#define GABO_BWD_REGV_MAX_DIM 8
+#endif
+
 namespace gabo {
 
 template <int D>
@@ -29,9 +33,12 @@ __global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __res
                                                              int64_t g_batch_stride, int64_t go_sb, int64_t go_si, int64_t go_sj,
                                                              double beta, int flags) {
     constexpr int T = tri_size(D);
-    constexpr int LD = 64;  // one accumulator / eigenvector column per lane, lane-contiguous: conflict-free without padding
-    __shared__ double acc[T * LD];
-    __shared__ double vls[D * D * 64];
+    __shared__ double vls[(D <= GABO_BWD_REGV_MAX_DIM) ? 64 : D * D * 64];
+    // accumulators of sum_j w_ij logm(M_ij): per lane in LDS while LDS is free (D <= 8, V in registers); for larger D the V columns
+    // already take 51-74 KB per wave, so each chunk is reduced across the wave at once instead (330 shuffles against ~50 k Jacobi
+    // instructions per lane) - that is what lifts the kernel from 1-2 to 2-3 waves per CU at d = 10..12
+    constexpr bool kLdsAcc = D <= GABO_BWD_REGV_MAX_DIM;
+    __shared__ double acc[kLdsAcc ? T * 64 : 1];
     __shared__ double red[T];
     __shared__ double wl[T];
     const int mode = flags & GABO_OUT_MASK;
@@ -39,7 +46,9 @@ __global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __res
     const int64_t b = blockIdx.x / n1;
     const int64_t i = blockIdx.x - b * n1;
     const double* W = Winv + b * w_batch_stride + i * T;
-    static_for<T>([&](auto ee) { acc[decltype(ee)::value * LD + lane] = 0.0; });
+    double tot[kLdsAcc ? 1 : T];      // (D > 8) sum over the chunks of the wave-reduced w_ij logm(M_ij); identical in every lane
+    if constexpr (kLdsAcc) static_for<T>([&](auto ee) { acc[decltype(ee)::value * 64 + lane] = 0.0; });
+    else static_for<T>([&](auto ee) { tot[decltype(ee)::value] = 0.0; });
     for (int64_t j0 = 0; j0 < n2; j0 += 64) {
         const int64_t j = j0 + lane;
         const bool live = j < n2;
@@ -69,8 +78,13 @@ __global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __res
                 });
             });
         });
+        // eigenvectors: registers up to GABO_BWD_REGV_MAX_DIM (no LDS round trips in the rotations), the lane's LDS column above
+        constexpr bool kRegV = D <= GABO_BWD_REGV_MAX_DIM;
         double* vl = vls + lane;
-        jacobi_eig<D>(m, vl);
+        double vreg[kRegV ? D * D : 1];
+        if constexpr (kRegV) jacobi_eig_reg<D>(m, vreg);
+        else jacobi_eig<D>(m, vl);
+        auto Vat = [&](int r, int c) -> double { if constexpr (kRegV) return vreg[r * D + c]; else return vl[(r * D + c) * 64]; };
         double lg[D];
         double s = 0.0;
         static_for<D>([&](auto kk) {
@@ -97,19 +111,29 @@ __global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __res
             static_for<r + 1>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 double f = 0.0;
-                static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; f = __builtin_fma(vl[(r * D + k) * 64] * lg[k], vl[(c * D + k) * 64], f); });
-                acc[tri(r, c) * LD + lane] = __builtin_fma(w, f, acc[tri(r, c) * LD + lane]);
+                static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; f = __builtin_fma(Vat(r, k) * lg[k], Vat(c, k), f); });
+                if constexpr (kLdsAcc) {
+                    acc[tri(r, c) * 64 + lane] = __builtin_fma(w, f, acc[tri(r, c) * 64 + lane]);
+                } else {
+                    double wf = w * f;
+                    for (int off = 32; off > 0; off >>= 1) wf += __shfl_xor(wf, off, 64);
+                    tot[tri(r, c)] += wf;
+                }
             });
         });
     }
-    __syncthreads();
-    // reduce over lanes: thread e sums column-array e; also stage W in LDS for the dynamic-index congruence
-    for (int e = lane; e < T; e += 64) {
-        double t = 0.0;
-        for (int l = 0; l < 64; ++l) t += acc[e * LD + ((l + e) & 63)];  // rotated start: threads hit different banks
-        red[e] = t;
-        wl[e] = W[e];
+    // publish the sums and stage W in LDS for the dynamic-index congruence
+    if constexpr (kLdsAcc) {
+        __syncthreads();
+        for (int e = lane; e < T; e += 64) {
+            double t = 0.0;
+            for (int l = 0; l < 64; ++l) t += acc[e * 64 + ((l + e) & 63)];  // rotated start: threads hit different banks
+            red[e] = t;
+        }
+    } else {
+        if (lane == 0) static_for<T>([&](auto ee) { red[decltype(ee)::value] = tot[decltype(ee)::value]; });
     }
+    for (int e = lane; e < T; e += 64) wl[e] = W[e];
     __syncthreads();
     // grad_A = -2 W^T S W (symmetric); thread e owns entry (a, bb), a >= bb.  W lower: W[r][a] != 0 only for r >= a.
     for (int e = lane; e < T; e += 64) {
