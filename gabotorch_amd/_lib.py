@@ -80,6 +80,10 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension is not built.  Run `python -m gabotorch_amd._build` "
                 "(needs hipcc).  gabotorch_amd has no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64.so.7; the library must bind to THAT runtime (the streams and pointers it is handed
+        # belong to it).  Same SONAME as the system one, so importing torch first is enough - loading this library before torch
+        # would pull in /opt/rocm's copy and leave two HIP runtimes in the process (every launch then fails).
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError here = header and library out of sync
