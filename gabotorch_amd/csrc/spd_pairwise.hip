@@ -12,176 +12,20 @@
 //      C = L_i^-1 G_j (lower x lower), M = C C^T (symmetric, lower kept), eigenvalues of M by the per-lane
 //      tridiagonal/QL solver of spd_eig.hpp, all in registers.  No LDS, no cross-lane traffic; the 1.8 MB operand
 //      sets stay L2 resident, the only HBM stream is the N1 x N2 output.
-#include "gabo_device.hpp"
-#include "spd_eig.hpp"
-#include "spd_prep.hpp"
-#include "gabo_mirror.hpp"
-#include "spd_generic.hpp"
-#include "../../include/gabo_hip.h"
+#include "spd_pairwise_body.hpp"
 
-#ifndef GABO_PAIR_WAVES
-#define GABO_PAIR_WAVES 2  /* waves per SIMD the pairwise kernel is register-budgeted for */
-#endif
-
-namespace gabo {
-
-// sum_k log^2(lambda_k) of M = C C^T with C = W * G (both lower triangular, W wave-uniform, G per lane)
-template <int D>
-__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const double* __restrict__ Gj, int64_t gstride) {
-    constexpr int T = tri_size(D);
-    // Column `col` of C = W G depends only on column `col` of G:  C[r][col] = sum_{k=col..r} W[r][k] G[k][col].
-    // M = C C^T = sum_col C[:,col] C[:,col]^T, so M is accumulated by rank-1 updates and C is never held whole:
-    // live state is M (T doubles) + one column of C + one column of G.
-    double m[T];
-    static_for<D>([&](auto cc) {
-        constexpr int col = decltype(cc)::value;
-        double g[D - col], c[D - col];
-        static_for<D - col>([&](auto kk) { g[decltype(kk)::value] = Gj[(int64_t)tri(col + decltype(kk)::value, col) * gstride]; });
-        static_for<D - col>([&](auto rr) {
-            constexpr int r = col + decltype(rr)::value;
-            double acc = W[tri(r, col)] * g[0];
-            static_for<r - col>([&](auto kk) {
-                constexpr int k = col + 1 + decltype(kk)::value;
-                acc = __builtin_fma(W[tri(r, k)], g[k - col], acc);
-            });
-            c[r - col] = acc;
-        });
-        static_for<D - col>([&](auto rr) {
-            constexpr int r = col + decltype(rr)::value;
-            static_for<r - col + 1>([&](auto qq) {
-                constexpr int q = col + decltype(qq)::value;
-                // column 0 touches every entry of M first: it initialises, the later columns accumulate
-                m[tri(r, q)] = (col == 0) ? c[r - col] * c[q - col] : __builtin_fma(c[r - col], c[q - col], m[tri(r, q)]);
-            });
-        });
-    });
-    double dg[D], e2[D];
-    tridiagonalize<D>(m, dg, e2);
-    tridiag_eigenvalues<D>(dg, e2);
-    double s = 0.0;
-#ifdef GABO_OCML_LOG
-    static_for<D>([&](auto kk) { double lg = log(dg[decltype(kk)::value]); s = __builtin_fma(lg, lg, s); });
-#else
-    const LogRegs lr = LogRegs::load();       // pinned here, after M and the tridiagonal are dead: no extra register pressure
-    static_for<D>([&](auto kk) { double lg = log_pos(dg[decltype(kk)::value], lr); s = __builtin_fma(lg, lg, s); });
-#endif
-    return s;
-}
-
-__device__ __forceinline__ double finish(double dist, double beta, int mode) {
-    if (mode == GABO_OUT_DISTANCE) return dist;
-    if (mode == GABO_OUT_LAPLACE) return exp(-(dist * beta));   // kernels_spd.py:185
-    return exp(-((dist * dist) * beta));                        // kernels_spd.py:94-98   (one exp per pair: OCML's is fine here)
-}
-
-// 1-D grid, block id -> (batch, row chunk of `rows` rows, column group of blockDim.x columns), column group fastest
-template <int D>
-__global__ __launch_bounds__(256, GABO_PAIR_WAVES) void spd_ai_pairwise_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
-                                                              double* __restrict__ out, double* __restrict__ dist_out,
-                                                              int64_t n1, int64_t n2,
-                                                              int64_t w_batch_stride, int64_t g_batch_stride, int rows,
-                                                              int col_blocks, int row_chunks, int64_t sym_tiles, double beta, int flags) {
-    constexpr int T = tri_size(D);
-    const int mode = flags & GABO_OUT_MASK;
-    int64_t cg, rc, b;
-    if (flags & GABO_SYMMETRIC) {
-        // Only tiles touching the upper triangle exist in the grid: column group cg owns row chunks
-        // [0, min(row_chunks, ceil((cg+1)*cols/rows))).  Enumerating exactly those keeps consecutive block ids
-        // (= consecutive XCDs) equally loaded; skipping blocks of a full grid instead leaves XCD 0 with 1/3 of
-        // the work of XCD 7.
-        const int64_t per_batch = sym_tiles;
-        b = blockIdx.x / per_batch;
-        int64_t t = blockIdx.x - b * per_batch;
-        cg = 0;
-        for (;;) {
-            int64_t cnt = ((cg + 1) * (int64_t)blockDim.x + rows - 1) / rows;
-            if (cnt > row_chunks) cnt = row_chunks;
-            if (t < cnt) break;
-            t -= cnt;
-            ++cg;
-        }
-        rc = t;
-    } else {
-        const int64_t bid = blockIdx.x;
-        cg = bid % col_blocks;
-        rc = (bid / col_blocks) % row_chunks;
-        b = bid / ((int64_t)col_blocks * row_chunks);
-    }
-    const int64_t j0 = cg * blockDim.x;
-    const int64_t j = j0 + threadIdx.x;
-    const int64_t jc = j < n2 ? j : n2 - 1;  // out-of-range lanes recompute the last column and do not store
-    const int64_t i0 = rc * rows;
-    const int64_t i1 = (i0 + rows < n1) ? i0 + rows : n1;
-    // symmetric mode, tile straddling the diagonal: a wave whose 64 columns all lie left of the tile's first row has nothing
-    // to store (i > j for every pair it would evaluate)
-    if ((flags & GABO_SYMMETRIC) && j0 + (int64_t)(threadIdx.x | 63) < i0) return;
-    const double* Gj = G + b * g_batch_stride + jc;
-    double* ob = out + b * n1 * n2;
-    for (int64_t i = i0; i < i1; ++i) {
-        const double* W = Winv + b * w_batch_stride + i * T;
-        // Launder the column pointer so the 55 G loads are NOT hoisted out of the row loop: keeping G resident costs
-        // 110 VGPRs (one wave per SIMD less); re-reading it from L2 costs 28 KB per wave-row, which is noise here.
-        const double* Gp = Gj;
-        asm volatile("" : "+v"(Gp));
-        double s = ai_sumsq<D>(W, Gp, n2);
-        double dist = __builtin_sqrt(s + 1e-15);  // spd_utils_torch.py:120
-        double val = finish(dist, beta, mode);
-        // symmetric mode: only the upper triangle (i <= j) is stored; mirror_upper_kernel fills the rest afterwards,
-        // so the result is exactly symmetric and the mirror writes are coalesced.
-        if (j < n2 && (!(flags & GABO_SYMMETRIC) || i <= j)) {
-            ob[i * n2 + j] = val;
-            if (dist_out) dist_out[b * n1 * n2 + i * n2 + j] = dist;
-        }
-    }
-}
-
-template <int D>
-static int launch_spd_ai(const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
-                         int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st) {
-    constexpr int T = tri_size(D);
-    const int64_t b1 = (s1 == 0) ? 1 : batch;  // a shared set is factored once
-    const int64_t b2 = (s2 == 0) ? 1 : batch;
-    double* W = ws;
-    double* G = ws + b1 * n1 * T;
-    launch_spd_prep<D>(x1, x2, W, G, b1, b2, n1, n2, s1, s2, status, st);
-    // tile shape: 64..256 columns per block, `rows` rows per block; keep >= ~8 blocks per CU when the problem allows
-    int threads = n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
-    int64_t col_blocks = (n2 + threads - 1) / threads;
-    int rows = 16;
-    while (rows > 1 && col_blocks * ((n1 + rows - 1) / rows) * batch < 4096) rows >>= 1;
-    int64_t row_chunks = (n1 + rows - 1) / rows;
-    int64_t sym_tiles = 0;
-    if (flags & GABO_SYMMETRIC) {
-        for (int64_t cg = 0; cg < col_blocks; ++cg) {
-            int64_t cnt = ((cg + 1) * threads + rows - 1) / rows;
-            sym_tiles += cnt < row_chunks ? cnt : row_chunks;
-        }
-    }
-    int64_t nblocks = ((flags & GABO_SYMMETRIC) ? sym_tiles : col_blocks * row_chunks) * batch;
-    if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
-    hipLaunchKernelGGL((spd_ai_pairwise_kernel<D>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, dist_out, n1, n2,
-                       (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks,
-                       (int)row_chunks, sym_tiles, beta, flags);
-    if (flags & GABO_SYMMETRIC) {
-        int tiles = (int)((n1 + 31) / 32);
-        hipLaunchKernelGGL((mirror_upper_kernel<0>), dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch), dim3(256), 0, st,
-                           out, n1, tiles);
-        if (dist_out)
-            hipLaunchKernelGGL((mirror_upper_kernel<0>), dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch), dim3(256), 0,
-                               st, dist_out, n1, tiles);
-    }
-    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
-}
-
-}  // namespace gabo
 
 extern "C" {
 
 size_t gabo_spd_ai_workspace_bytes(int64_t batch, int64_t n1, int64_t n2, int d) {
     if (batch < 0 || n1 < 0 || n2 < 0 || d < 1) return 0;
-    if (d > GABO_SPD_REG_MAX_DIM)   // wave-per-pair fallback: L^-1 (d x d) per x1 matrix, and as much again for the backward sums
-        return (size_t)(2 * batch * n1) * (size_t)d * (size_t)d * sizeof(double);
-    return (size_t)(batch * (n1 + n2)) * (size_t)gabo::tri_size(d) * sizeof(double);
+    const size_t packed = (size_t)(batch * (n1 + n2)) * (size_t)gabo::tri_size(d) * sizeof(double);
+    // wave-per-pair fallback (forward above GABO_SPD_FWD_REG_MAX_DIM, backward above GABO_SPD_REG_MAX_DIM): L^-1 (d x d) per x1
+    // matrix, and as much again for the backward sums
+    const size_t generic = (size_t)(2 * batch * n1) * (size_t)d * (size_t)d * sizeof(double);
+    if (d > GABO_SPD_FWD_REG_MAX_DIM) return generic;
+    if (d > GABO_SPD_REG_MAX_DIM) return packed > generic ? packed : generic;
+    return packed;
 }
 
 int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2, int d,
@@ -195,7 +39,7 @@ int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, double
     if ((flags & GABO_SYMMETRIC) && (n1 != n2 || batch > 65535)) return GABO_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     double* ws = (double*)workspace;
-    if (d > GABO_SPD_REG_MAX_DIM)
+    if (d > GABO_SPD_FWD_REG_MAX_DIM)
         return gabo::launch_spd_ai_generic(x1, x2, out, dist_out, batch, n1, n2, d, x1_batch_stride, x2_batch_stride, beta, flags, ws,
                                            status, st);
 #define GABO_CASE(DD) \
@@ -210,6 +54,10 @@ int gabo_spd_ai_pairwise(const double* x1, const double* x2, double* out, double
 #endif
     }
 #undef GABO_CASE
+#ifndef GABO_ONLY_DIM
+    if (d > GABO_SPD_REG_MAX_DIM)
+        return gabo::launch_spd_ai_wide(d, x1, x2, out, dist_out, batch, n1, n2, x1_batch_stride, x2_batch_stride, beta, flags, ws, status, st);
+#endif
     return GABO_ERR_DIM;
 }
 

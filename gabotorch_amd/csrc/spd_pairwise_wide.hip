@@ -1,0 +1,19 @@
+// SPD pairwise Gram, dimensions 13..16 (17..20 in spd_pairwise_wide2.hip): the same register-resident lane-per-pair kernels, budgeted for ONE wave per SIMD (512 VGPRs
+// per lane; a little scratch from d = 18).  Instantiations only; templates in spd_pairwise_body.hpp.
+#include "spd_pairwise_body.hpp"
+
+namespace gabo {
+
+int launch_spd_ai_wide(int d, const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
+                       int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st) {
+#define GABO_CASE(DD) \
+    case DD:          \
+        return launch_spd_ai<DD>(x1, x2, out, dist_out, batch, n1, n2, s1, s2, beta, flags, ws, status, st);
+    switch (d) {
+        GABO_CASE(13) GABO_CASE(14) GABO_CASE(15) GABO_CASE(16)
+    }
+#undef GABO_CASE
+    return launch_spd_ai_wide2(d, x1, x2, out, dist_out, batch, n1, n2, s1, s2, beta, flags, ws, status, st);
+}
+
+}  // namespace gabo

@@ -36,7 +36,7 @@ def test_host_side_argument_errors_need_no_gpu():
     lib = _lib.load()
     assert lib.gabo_version() >= 100
     assert lib.gabo_spd_ai_workspace_bytes(2, 3, 4, 10) == 2 * 7 * 55 * 8
-    assert lib.gabo_spd_ai_workspace_bytes(2, 3, 4, 20) == 2 * 2 * 3 * 400 * 8      # wave-per-pair fallback layout
+    assert lib.gabo_spd_ai_workspace_bytes(2, 3, 4, 24) == 2 * 2 * 3 * 576 * 8      # wave-per-pair fallback layout
     # argument validation happens before any HIP call
     assert lib.gabo_spd_ai_pairwise(None, None, None, None, 1, 4, 4, 40, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_ERR_DIM
     assert lib.gabo_spd_ai_pairwise(None, None, None, None, 1, 4, 4, 3, 0, 0, 1.0, 0, None, 0, None, None) == _lib.GABO_ERR_ARG
@@ -73,3 +73,14 @@ def test_acquisition_and_trust_region_entry_points_validate_on_the_host():
     # gradients of the Frobenius / log-Euclidean kernels
     assert lib.gabo_frobenius_backward(None, None, None, None, 1, 4, 4, 33, 0, 0, 16, 4, 1, 1.0, 0, 1.0, None) == _lib.GABO_ERR_DIM
     assert lib.gabo_spd_logm_mandel_backward(None, None, None, 4, 5, None) == _lib.GABO_ERR_ARG
+
+
+def test_workspace_covers_both_layouts_between_the_register_limits():
+    """12 < d <= 16: the forward kernels use the packed layout, the backward the wave-per-pair one - the workspace must fit either."""
+    lib = _lib.load()
+    assert _lib.GABO_SPD_REG_MAX_DIM == 12 and _lib.GABO_SPD_FWD_REG_MAX_DIM == 20
+    for d in (13, 16, 20):
+        t = d * (d + 1) // 2
+        assert lib.gabo_spd_ai_workspace_bytes(1, 3, 50, d) == max((3 + 50) * t, 2 * 3 * d * d) * 8
+        assert lib.gabo_spd_ai_workspace_bytes(1, 50, 3, d) == max((3 + 50) * t, 2 * 50 * d * d) * 8
+    assert lib.gabo_spd_ai_workspace_bytes(1, 3, 50, 21) == 2 * 3 * 21 * 21 * 8

@@ -6,10 +6,12 @@ from gabotorch_amd import ops
 from tools.dev_bench import spd_set, timeit
 ops.set_error_checking(False)
 n = 4096
-for d in (2, 3, 5, 7, 10, 12, 16, 20):
-    nn = n if d <= 12 else 512          # the wave-per-pair fallback (d > 12) is a correctness path: smaller problem
+for d in (2, 3, 5, 7, 10, 12, 13, 16, 20, 24):
+    nn = n if d <= 20 else 512          # the wave-per-pair fallback (forward d > 16, backward d > 12) is a correctness path
     x = torch.tensor(spd_set(nn, d), device="cuda")
     ms = timeit(lambda: ops.spd_ai_pairwise(x, x, beta=0.5), 5 if d > 12 else 10)
-    go = torch.ones(nn, nn, dtype=torch.float64, device="cuda")
-    msb = timeit(lambda: ops.spd_ai_backward(x, x, go, 0.5), 3)
-    print(f"d={d:2d} N={nn}: forward {ms:8.3f} ms {nn*nn/ms*1e3:.3e} pairs/s | backward {msb:8.3f} ms {nn*nn/msb*1e3:.3e} pairs/s")
+    nb = nn if d <= 12 else 512
+    xb = x[:nb]
+    go = torch.ones(nb, nb, dtype=torch.float64, device="cuda")
+    msb = timeit(lambda: ops.spd_ai_backward(xb, xb, go, 0.5), 3)
+    print(f"d={d:2d} N={nn}: forward {ms:8.3f} ms {nn*nn/ms*1e3:.3e} pairs/s | backward (N={nb}) {msb:8.3f} ms {nb*nb/msb*1e3:.3e} pairs/s")
