@@ -24,8 +24,16 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build libgabo_hip.so (set HIPCC=/path/to/hipcc)")
 
 
+# translation units that instantiate the big unrolled templates, longest first: they are started before everything else so
+# that the parallel build does not end on one of them
+_HEAVY = ["spd_tr_wide.hip", "spd_acq.hip", "spd_pairwise_wide.hip", "spd_backward.hip", "spd_tr_solve.hip", "spd_tr.hip",
+          "spd_pairwise.hip", "spd_tr_le.hip", "spd_tr_solve_le.hip", "spd_acq_le.hip"]
+
+
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    names.sort(key=lambda f: _HEAVY.index(f) if f in _HEAVY else len(_HEAVY))
+    return [os.path.join(CSRC, f) for f in names]
 
 
 def _deps():

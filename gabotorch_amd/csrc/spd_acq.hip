@@ -10,42 +10,11 @@
 // (manifold_optimize.py:175-184).  The separate-launch chain (gabo_spd_ai_pairwise -> gabo_gp_acquisition -> gabo_spd_ai_backward)
 // computes the same numbers in 7 launches; this kernel exists because the lock-step trust regions are launch-count bound.
 // The training side (Cholesky factors, entry-major) is prepared once per surrogate by gabo_spd_acq_prepare_train.
-#include "spd_acq_body.hpp"
+#include "spd_acq_kernel.hpp"
 
 namespace gabo {
 
-template <int D, int METRIC>
-__global__ __launch_bounds__(64) void spd_acq_kernel(const double* __restrict__ x, AcqParams P, double* __restrict__ value,
-                                                     double* __restrict__ grad, double* __restrict__ scratch,
-                                                     const int* __restrict__ active, int* __restrict__ status) {
-    constexpr int T = tri_size(D);
-    if (active && active[blockIdx.x] == 0) return;     // masked candidate: outputs left untouched
-    __shared__ AcqLds<D> lds;
-    extern __shared__ __attribute__((aligned(16))) double dyn[];
-    const int64_t i = blockIdx.x;
-    acq_eval_any<D, METRIC>(x + i * T, P, value + i, grad ? grad + i * T : nullptr, scratch ? scratch + i * T * P.n : nullptr, lds, dyn,
-                            status, i);
-}
-
-template <int D>
-static int launch_spd_acq(const double* x, const double* G, const double* alpha, const double* linv, const double* linv_t,
-                          double* value, double* grad, double* scratch, int64_t r, int64_t n, double beta, int mode, double mean,
-                          double os, double kxx, double best_f, int kind, int maximize, double out_sign, const int* active, int* status, hipStream_t st) {
-    size_t lds = (size_t)(3 * n) * sizeof(double);
-    AcqParams P{G, alpha, linv, linv_t, n, beta, mode, mean, os, kxx, best_f, kind, maximize, out_sign};
-    const int metric = mode & GABO_METRIC_MASK;
-    if (metric == GABO_METRIC_AFFINE_INVARIANT) {
-        hipLaunchKernelGGL((spd_acq_kernel<D, 0>), dim3((unsigned)r), dim3(64), lds, st, x, P, value, grad, scratch, active, status);
-    } else if constexpr (D <= 8) {
-        if (metric == GABO_METRIC_LOG_EUCLIDEAN)
-            hipLaunchKernelGGL((spd_acq_kernel<D, 1>), dim3((unsigned)r), dim3(64), lds, st, x, P, value, grad, scratch, active, status);
-        else
-            hipLaunchKernelGGL((spd_acq_kernel<D, 2>), dim3((unsigned)r), dim3(64), lds, st, x, P, value, grad, scratch, active, status);
-    } else {
-        return GABO_ERR_DIM;
-    }
-    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
-}
+int acq_affine_invariant(const AcqLaunch& a) { return dispatch_acq<0, 12>(a); }
 
 template <int D>
 static int launch_prepare_train(const double* x, double* G, int64_t n, int* status, hipStream_t st) {
@@ -91,8 +60,7 @@ int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const
     {
         const int out = flags & GABO_OUT_MASK, metric = flags & GABO_METRIC_MASK;
         if ((flags & ~(GABO_OUT_MASK | GABO_METRIC_MASK)) || (out != GABO_OUT_GAUSSIAN && out != GABO_OUT_LAPLACE)) return GABO_ERR_ARG;
-        if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN && metric != GABO_METRIC_FROBENIUS)
-            return GABO_ERR_ARG;
+        if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN) return GABO_ERR_ARG;
         if (metric != GABO_METRIC_AFFINE_INVARIANT && (out != GABO_OUT_GAUSSIAN || d > 8)) return d > 8 ? GABO_ERR_DIM : GABO_ERR_ARG;
     }
     if (kind != GABO_ACQ_EXPECTED_IMPROVEMENT && kind != GABO_ACQ_POSTERIOR_MEAN) return GABO_ERR_ARG;
@@ -100,15 +68,13 @@ int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const
     if (!x_mandel || !train_factors || !alpha || !value || !status) return GABO_ERR_ARG;
     if (grad_mandel && !scratch && (flags & GABO_METRIC_MASK) == GABO_METRIC_AFFINE_INVARIANT) return GABO_ERR_ARG;
     if (kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!linv || !linv_t)) return GABO_ERR_ARG;
-#define GABO_CASE(DD) \
-    case DD:          \
-        return gabo::launch_spd_acq<DD>(x_mandel, train_factors, alpha, linv, linv_t, value, grad_mandel, scratch, r, n, beta, flags, \
-                                        mean, outputscale, kxx, best_f, kind, maximize, out_sign, active, status, (hipStream_t)stream);
-    switch (d) {
-        GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8) GABO_CASE(9) GABO_CASE(10)
-        GABO_CASE(11) GABO_CASE(12)
+    gabo::AcqLaunch a{x_mandel, gabo::AcqParams{train_factors, alpha, linv, linv_t, n, beta, flags, mean, outputscale, kxx, best_f, kind,
+                                                maximize, out_sign},
+                      value, grad_mandel, scratch, r, d, active, status, (hipStream_t)stream};
+    switch (flags & GABO_METRIC_MASK) {
+        case GABO_METRIC_AFFINE_INVARIANT: return gabo::acq_affine_invariant(a);
+        case GABO_METRIC_LOG_EUCLIDEAN: return gabo::acq_log_euclidean(a);
     }
-#undef GABO_CASE
     return GABO_ERR_DIM;
 }
 

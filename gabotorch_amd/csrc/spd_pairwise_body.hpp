@@ -164,9 +164,7 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
 }  // namespace gabo
 
 namespace gabo {
-// dimensions 13..20 are instantiated in their own translation units (spd_pairwise_wide.hip, spd_pairwise_wide2.hip)
-int launch_spd_ai_wide2(int d, const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
-                        int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st);
+// dimensions 13..16 are instantiated in their own translation unit (spd_pairwise_wide.hip)
 int launch_spd_ai_wide(int d, const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
                        int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st);
 }  // namespace gabo

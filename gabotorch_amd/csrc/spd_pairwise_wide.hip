@@ -1,5 +1,5 @@
-// SPD pairwise Gram, dimensions 13..16 (17..20 in spd_pairwise_wide2.hip): the same register-resident lane-per-pair kernels, budgeted for ONE wave per SIMD (512 VGPRs
-// per lane; a little scratch from d = 18).  Instantiations only; templates in spd_pairwise_body.hpp.
+// SPD pairwise Gram, dimensions 13..16: the same register-resident lane-per-pair kernels, budgeted for ONE wave per SIMD (512 VGPRs
+// per lane).  (d = 17..20 also fit - a little scratch from d = 18, 4.7e8 pairs/s at d = 20 - but cost 2.5 minutes of compile time.)  Instantiations only; templates in spd_pairwise_body.hpp.
 #include "spd_pairwise_body.hpp"
 
 namespace gabo {
@@ -13,7 +13,7 @@ int launch_spd_ai_wide(int d, const double* x1, const double* x2, double* out, d
         GABO_CASE(13) GABO_CASE(14) GABO_CASE(15) GABO_CASE(16)
     }
 #undef GABO_CASE
-    return launch_spd_ai_wide2(d, x1, x2, out, dist_out, batch, n1, n2, s1, s2, beta, flags, ws, status, st);
+    return GABO_ERR_DIM;
 }
 
 }  // namespace gabo

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void spd_tr_update_kernel(double* __restrict__ 
     }
 }
 
-int propose_affine_invariant(const ProposeArgs& a) { return dispatch_propose<0, 12>(a); }
+int propose_affine_invariant(const ProposeArgs& a) { return a.d <= 8 ? dispatch_propose<0, 8>(a) : propose_affine_invariant_wide(a); }
 
 }  // namespace gabo
 
@@ -60,8 +60,7 @@ int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust
     if (acq->kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!acq->linv || !acq->linv_t)) return GABO_ERR_ARG;
     {
         const int metric = acq->flags & GABO_METRIC_MASK;
-        if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN && metric != GABO_METRIC_FROBENIUS)
-            return GABO_ERR_ARG;
+        if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN) return GABO_ERR_ARG;
         if (metric != GABO_METRIC_AFFINE_INVARIANT && d > 8) return GABO_ERR_DIM;
     }
     if (workspace_bytes < gabo_spd_tr_workspace_bytes(r, d, n_constraints, acq->n)) return GABO_ERR_ARG;
@@ -70,7 +69,6 @@ int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust
     switch (acq->flags & GABO_METRIC_MASK) {
         case GABO_METRIC_AFFINE_INVARIANT: return gabo::propose_affine_invariant(a);
         case GABO_METRIC_LOG_EUCLIDEAN: return gabo::propose_log_euclidean(a);
-        case GABO_METRIC_FROBENIUS: return gabo::propose_frobenius(a);
     }
     return GABO_ERR_DIM;
 }

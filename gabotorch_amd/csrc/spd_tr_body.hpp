@@ -327,11 +327,11 @@ struct ProposeArgs {
     hipStream_t st;
 };
 
-template <int METRIC, int DMAX>
+template <int METRIC, int DMAX, int DMIN = 2>
 static int dispatch_propose(const ProposeArgs& a) {
 #define GABO_CASE(DD)                                                                                                                  \
     case DD:                                                                                                                           \
-        if constexpr (DD <= DMAX)                                                                                                      \
+        if constexpr (DD <= DMAX && DD >= DMIN)                                                                                                      \
             return launch_propose_one<DD, METRIC>(a.x, a.g, a.delta_tr, a.active, a.gc, a.fc, *a.P, a.ws, a.x_prop, a.r, a.c, a.neq, \
                                                   a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.any_active, a.status, a.st); \
         else                                                                                                                           \
@@ -382,7 +382,7 @@ static int dispatch_solve(const SolveArgs& a) {
 int solve_affine_invariant(const SolveArgs& a);
 int solve_log_euclidean(const SolveArgs& a);
 int propose_affine_invariant(const ProposeArgs& a);
+int propose_affine_invariant_wide(const ProposeArgs& a);      // d = 9..12 (spd_tr_wide.hip)
 int propose_log_euclidean(const ProposeArgs& a);
-int propose_frobenius(const ProposeArgs& a);
 
 }  // namespace gabo

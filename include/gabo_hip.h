@@ -39,14 +39,15 @@ typedef void* gabo_stream_t; /* hipStream_t */
 /* distance used by the fused acquisition kernels (gabo_spd_acq_params.flags, OR-ed with GABO_OUT_GAUSSIAN / GABO_OUT_LAPLACE) */
 #define GABO_METRIC_AFFINE_INVARIANT 0
 #define GABO_METRIC_LOG_EUCLIDEAN 8   /* kernels_spd.py:244-313; Gaussian only, d <= 8 */
-#define GABO_METRIC_FROBENIUS 16      /* kernels_spd.py:190-241; Gaussian only, d <= 8 */
+#define GABO_METRIC_FROBENIUS 16      /* kernels_spd.py:190-241: reserved - this surrogate is served by the separate-launch chain
+                                         (gabo_frobenius_pairwise -> gabo_gp_acquisition -> gabo_frobenius_backward) */
 #define GABO_METRIC_MASK 24
 
 /* SPD pairwise kernels: 2 <= d <= GABO_SPD_MAX_DIM.  The forward runs the register-resident lane-per-pair kernels (the fast path,
  * the metric) up to GABO_SPD_FWD_REG_MAX_DIM; the closed-form backward and the fused acquisition kernels up to
  * GABO_SPD_REG_MAX_DIM; larger d falls back to one wave per pair with LDS tiles. */
 #define GABO_SPD_REG_MAX_DIM 12
-#define GABO_SPD_FWD_REG_MAX_DIM 20   /* the forward kernels stay register-resident up to here (one wave per SIMD above 12) */
+#define GABO_SPD_FWD_REG_MAX_DIM 16   /* the forward kernels stay register-resident up to here (one wave per SIMD above 12) */
 #define GABO_SPD_MAX_DIM 32
 
 int gabo_version(void);

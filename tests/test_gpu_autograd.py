@@ -41,7 +41,7 @@ def test_spd_grads_golden(golden):
         np.testing.assert_allclose(x2.grad.cpu().numpy(), o2, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(o2).max()))
 
 
-@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_REG_MAX_DIM + 1)) + [13, 16, 20, 24])
+@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_REG_MAX_DIM + 1)) + [13, 16, 20])
 def test_spd_backward_all_dims_vs_oracle(d):
     rng = np.random.default_rng(40 + d)
     x1, x2 = rand_spd_mandel(rng, 5, d), rand_spd_mandel(rng, 70, d)

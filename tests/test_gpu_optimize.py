@@ -367,7 +367,8 @@ def test_fused_chain_for_log_euclidean_and_frobenius_kernels(flavour, d):
     acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
     post = symmetric_matrix_to_vector_mandel_torch
     fused = FusedAcquisition.build(acq, post, torch.device(DEV))
-    assert fused is not None and fused.single_launch and fused.flavour == flavour      # d <= 8: one launch per evaluation
+    assert fused is not None and fused.flavour == flavour
+    assert fused.single_launch == (flavour == "le")      # log-Euclidean, d <= 8: one launch per evaluation; Frobenius: the chain
     q = np.linalg.qr(rng.standard_normal((50, d, d)))[0]
     P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (50, d)), q)
     x = t(0.5 * (P + P.transpose(0, 2, 1)))

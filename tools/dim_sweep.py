@@ -6,8 +6,8 @@ from gabotorch_amd import ops
 from tools.dev_bench import spd_set, timeit
 ops.set_error_checking(False)
 n = 4096
-for d in (2, 3, 5, 7, 10, 12, 13, 16, 20, 24):
-    nn = n if d <= 20 else 512          # the wave-per-pair fallback (forward d > 16, backward d > 12) is a correctness path
+for d in (2, 3, 5, 7, 10, 12, 13, 16, 20):
+    nn = n if d <= 16 else 512          # the wave-per-pair fallback (forward d > 16, backward d > 12) is a correctness path
     x = torch.tensor(spd_set(nn, d), device="cuda")
     ms = timeit(lambda: ops.spd_ai_pairwise(x, x, beta=0.5), 5 if d > 12 else 10)
     nb = nn if d <= 12 else 512
