@@ -72,7 +72,27 @@ class FusedAcquisition:
 
     @staticmethod
     def build(acq, post_processing, device):
-        """-> FusedAcquisition, or None when the acquisition / surrogate / kernel / post-processing is not a built-in."""
+        """-> FusedAcquisition, or None when the acquisition / surrogate / kernel / post-processing is not a built-in.
+        Cached on the acquisition object (one sweep asks twice: raw-sample scoring and the solve); the key includes the
+        surrogate's prediction cache, so refitting or changing the data rebuilds it."""
+        gp = getattr(acq, "model", None)
+        cached = getattr(acq, "_gabo_fused", None)
+        if cached is not None:
+            post_c, dev_c, cache_c, best_c, max_c, fused_c = cached      # (the objects themselves are held: no id() reuse)
+            if (post_c is post_processing and dev_c == str(device) and cache_c is not None and cache_c is getattr(gp, "_cache", None)
+                    and best_c == getattr(acq, "best_f", None) and max_c == getattr(acq, "maximize", None)):
+                return fused_c
+        fused = FusedAcquisition._build(acq, post_processing, device)
+        if fused is not None and getattr(gp, "_cache", None) is not None:
+            try:
+                object.__setattr__(acq, "_gabo_fused", (post_processing, str(device), gp._cache, getattr(acq, "best_f", None),
+                                                        getattr(acq, "maximize", None), fused))
+            except Exception:       # noqa: BLE001
+                pass
+        return fused
+
+    @staticmethod
+    def _build(acq, post_processing, device):
         if not isinstance(acq, (models.ExpectedImprovement, models.PosteriorMean)):
             return None
         view = _surrogate_view(getattr(acq, "model", None))

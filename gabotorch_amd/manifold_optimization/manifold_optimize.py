@@ -148,7 +148,10 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
         candidates = post_processing_manifold(candidates)
     candidates = candidates[:, None]
     with torch.no_grad():
-        batch_acquisition = acquisition_function(candidates)
+        if fused is not None:
+            batch_acquisition = -fused.cost(opt_x)          # same values through the fused chain (one launch for the SPD kernels)
+        else:
+            batch_acquisition = acquisition_function(candidates)
     return candidates.detach(), batch_acquisition.detach()
 
 

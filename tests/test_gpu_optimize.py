@@ -564,3 +564,25 @@ def test_device_solve_matches_reference_solver_optima(golden, d):
             assert lam.max() <= mx + 1e-9                                            # the strict solver never leaves the feasible set
     finally:
         ops.set_error_checking(True)
+
+
+def test_fused_acquisition_cache_follows_the_surrogate():
+    """FusedAcquisition.build is cached on the acquisition object; new data / a refit (a new prediction cache) must rebuild it."""
+    from gabotorch_amd.fused_acquisition import FusedAcquisition
+    rng, X, y = _spd_gp(3, n_train=10, seed=3)
+    gp = models.ExactGP(t(X), t(y), SpdAffineInvariantGaussianKernel(beta_min=0.5), outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    post = symmetric_matrix_to_vector_mandel_torch
+    f1 = FusedAcquisition.build(acq, post, torch.device(DEV))
+    assert FusedAcquisition.build(acq, post, torch.device(DEV)) is f1                 # cache hit
+    x = vector_to_symmetric_matrix_mandel_torch(t(X[:4]) * 1.1)
+    v1 = f1.cost(x).clone()
+    gp.train_y = gp.train_y * 2.0 + 1.0          # change the surrogate: a new prediction cache
+    gp.mean = float(gp.train_y.mean())
+    gp._cache = None
+    f2 = FusedAcquisition.build(acq, post, torch.device(DEV))
+    assert f2 is not f1
+    np.testing.assert_allclose(f2.cost(x).cpu().numpy(), -acq(post(x)[:, None]).detach().cpu().numpy(), rtol=1e-10, atol=1e-14)
+    assert float((f2.cost(x) - v1).abs().max()) > 1e-6
+    acq.best_f = acq.best_f - 0.5                 # a different incumbent also rebuilds
+    assert FusedAcquisition.build(acq, post, torch.device(DEV)) is not f2
