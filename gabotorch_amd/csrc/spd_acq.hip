@@ -31,7 +31,7 @@ extern "C" {
 int64_t gabo_spd_acq_max_train(int d) {
     if (d < 2 || d > GABO_SPD_REG_MAX_DIM) return 0;
     const int64_t t = (int64_t)d * (d + 1) / 2;
-    const int64_t fixed = (t * 64 + (int64_t)d * d * 64 + 2 * t + 5 * d * d + 2) * 8 + 1024;
+    const int64_t fixed = (t * 64 + (d <= 8 ? 64 : (int64_t)d * d * 64) + 2 * t + 5 * d * d + 2) * 8 + 1024;
     const int64_t n = (160 * 1024 - fixed) / 24;
     return n > 2048 ? 2048 : (n < 0 ? 0 : n);
 }

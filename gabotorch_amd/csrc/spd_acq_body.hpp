@@ -20,7 +20,7 @@ template <int D>
 struct AcqLds {
     static constexpr int T = tri_size(D);
     double acc[T * 64];
-    double vls[D * D * 64];
+    double vls[(D <= 8) ? 64 : D * D * 64];      // eigenvector columns of the lanes: only when they do not live in registers
     double red[T];
     double wl[T];
 };

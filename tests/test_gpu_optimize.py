@@ -586,3 +586,39 @@ def test_fused_acquisition_cache_follows_the_surrogate():
     assert float((f2.cost(x) - v1).abs().max()) > 1e-6
     acq.best_f = acq.best_f - 0.5                 # a different incumbent also rebuilds
     assert FusedAcquisition.build(acq, post, torch.device(DEV)) is not f2
+
+
+def test_single_launch_solve_properties_at_scale():
+    """4096 restarts through gabo_spd_tr_solve (strict eigenvalue box): size-independent properties - every restart ends no worse than
+    it started (the solver only accepts decreasing steps), never leaves the feasible set, stays SPD, respects the iteration limit,
+    and the result does not depend on how many restarts share the launch."""
+    import functools
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    d, R = 4, 4096
+    rng, X, y = _spd_gp(d, n_train=40, seed=77)
+    gp = models.ExactGP(t(X), t(y), SpdAffineInvariantGaussianKernel(beta_min=0.4), outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    cons = [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=3.2),
+            functools.partial(scut.min_eigenvalue_constraint_torch, minimum_eigenvalue=0.15)]
+    x0m = ops.spd_sample(R, d, 0.2, 3.0, seed=99, device=DEV)
+    x0 = ops.matrix_to_mandel(x0m)[:, None]
+    man = manifolds.PositiveDefinite(d)
+    pre, post = vector_to_symmetric_matrix_mandel_torch, symmetric_matrix_to_vector_mandel_torch
+    ops.set_error_checking(False)
+    try:
+        solver = BatchedTrustRegions(mingradnorm=1e-4, maxiter=30, strict_constraints=True)
+        c, v = gen_candidates_manifold(x0, acq, man, solver, pre, post, inequality_constraints=cons, approx_hessian=True)
+        s2 = BatchedTrustRegions(mingradnorm=1e-4, maxiter=30, strict_constraints=True)
+        c2, v2 = gen_candidates_manifold(x0[:100], acq, man, s2, pre, post, inequality_constraints=cons, approx_hessian=True)
+    finally:
+        ops.set_error_checking(True)
+    with torch.no_grad():
+        v0 = acq(x0)
+    assert torch.isfinite(c).all() and torch.isfinite(v).all()
+    assert bool((v >= v0 - 1e-12).all())                                  # acquisition never decreases (cost never increases)
+    lam = np.linalg.eigvalsh(ospd.vector_to_symmetric_matrix_mandel(c[:, 0].cpu().numpy()))
+    assert lam.min() >= 0.15 - 1e-9 and lam.max() <= 3.2 + 1e-9
+    it = solver.log["per_restart_iterations"].cpu().numpy()
+    assert it.min() >= 1 and it.max() <= 30
+    np.testing.assert_array_equal(c2.cpu().numpy(), c[:100].cpu().numpy())    # restarts are independent: bit-identical in a smaller launch
+    assert float(v.max()) > float(v0.max()) - 1e-12
