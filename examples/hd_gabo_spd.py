@@ -6,9 +6,9 @@ candidates, as hd_gabo_spd.py:205) -, the data are projected with Y = W^T X W, a
 same hyper-parameters is built on them, EI is maximised ON THE LATENT MANIFOLD with the strict constrained trust regions
 (eigenvalue box, FD Hessian), and the winner is lifted back with projection_from_nested_spd_to_spd.
 
-Scope note: the reference additionally optimises the reconstruction parameters (complement basis, bottom block, contraction) with
-an augmented-Lagrangian solver (nested_spd_optimization.py:95-186); that host-side optimiser is not part of this repository
-(SURVEY 8f-4), so the complement is the orthogonal complement of the learnt W, the bottom block is I and the contraction is 0.
+The reconstruction parameters (complement basis, bottom block, contraction) are optimised as in the reference
+(optimize_reconstruction_parameters_nested_spd with the log-Euclidean cost, hd_gabo_spd.py:229-232; augmented Lagrangian + conjugate
+gradients, --rec-iters 0 skips it and uses the orthogonal complement of W, C = I, K = 0).
 
     python examples/hd_gabo_spd.py [--dim 5] [--latent 2] [--iters 10]
 """
@@ -31,6 +31,8 @@ from gabotorch_amd.manifold_optimization.manifold_gp_fit import fit_gpytorch_man
 from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions                         # noqa: E402
 from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold                         # noqa: E402
 from gabotorch_amd.nested_mappings.nested_spd_utils import projection_from_nested_spd_to_spd                      # noqa: E402
+from gabotorch_amd.nested_mappings.nested_spd_optimization import (min_log_euclidean_distance_reconstruction_cost,  # noqa: E402
+                                                                   optimize_reconstruction_parameters_nested_spd)
 from gabotorch_amd.Riemannian_utils.spd_constraints_utils_torch import (max_eigenvalue_constraint_torch,          # noqa: E402
                                                                         min_eigenvalue_constraint_torch)
 from gabotorch_amd.Riemannian_utils.spd_utils import spd_sample, symmetric_matrix_to_vector_mandel                # noqa: E402
@@ -38,7 +40,7 @@ from gabotorch_amd.Riemannian_utils.spd_utils_torch import (symmetric_matrix_to_
                                                             vector_to_symmetric_matrix_mandel_torch)
 
 
-def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:0", verbose=True, fit_iters=50):
+def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:0", verbose=True, fit_iters=50, rec_iters=6):
     np.random.seed(seed)
     torch.manual_seed(seed)
     big = manifolds.PositiveDefinite(dim)
@@ -63,8 +65,14 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
         model = models.SingleTaskGP(x_data, y_std, k_fct, noise_prior=models.GammaPrior(1.1, 0.05))
         fit_gpytorch_manifold(model, solver=ConjugateGradient(maxiter=fit_iters), nb_init_candidates=20)           # :205
         W = k_fct.base_kernel.projection_matrix.detach().clone().to(device)
-        V = torch.linalg.svd(W, full_matrices=True)[0][:, latent:]                  # orthonormal complement of span(W)
         z_data = ops.spd_project(x_data, W)                                          # latent Mandel vectors, one launch
+        if rec_iters > 0:                                                            # (:229-232)
+            V, bottom, contraction = optimize_reconstruction_parameters_nested_spd(
+                vector_to_symmetric_matrix_mandel_torch(x_data), vector_to_symmetric_matrix_mandel_torch(z_data), W,
+                ConjugateGradient(maxiter=100), cost_function=min_log_euclidean_distance_reconstruction_cost, nb_init_candidates=20,
+                maxiter=rec_iters)
+        else:
+            V = torch.linalg.svd(W, full_matrices=True)[0][:, latent:]              # orthonormal complement of span(W)
         latent_kernel = SpdLogEuclideanGaussianKernel().double()
         latent_kernel.lengthscale = k_fct.base_kernel.lengthscale.detach().clone()   # same hyper-parameters (:217-219)
         gp = models.ExactGP(z_data, y_std, latent_kernel, outputscale=float(k_fct.outputscale.detach()), noise=float(model.noise.detach()),
@@ -91,5 +99,6 @@ if __name__ == "__main__":
     ap.add_argument("--dim", type=int, default=5)
     ap.add_argument("--latent", type=int, default=2)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--rec-iters", type=int, default=6)
     a = ap.parse_args()
-    run(a.dim, a.latent, a.iters)
+    run(a.dim, a.latent, a.iters, rec_iters=a.rec_iters)

@@ -45,3 +45,23 @@ def affine_invariant_distance_torch(x1, x2, diagonal_distance=False):
     v1 = symmetric_matrix_to_vector_mandel_torch(x1)
     v2 = symmetric_matrix_to_vector_mandel_torch(x2)
     return ops.spd_ai_kernel(v1, v2, 1.0, _lib.GABO_OUT_DISTANCE)
+
+
+def logm_torch(x):
+    """Matrix logarithm of SPD matrices (..., d, d)   (spd_utils_torch.py:13-30); differentiable (first order)."""
+    return ops.spd_matrix_function(x, _lib.GABO_SPD_LOGM)
+
+
+def sqrtm_torch(x):
+    """Matrix square root of SPD matrices (..., d, d)   (spd_utils_torch.py:33-50); differentiable (first order)."""
+    return ops.spd_matrix_function(x, _lib.GABO_SPD_SQRTM)
+
+
+def frobenius_distance_torch(x1, x2, diagonal_distance=False):
+    """||x1_i - x2_j + 1e-15||_F for symmetric matrices x1 (..., N1, d, d), x2 (..., N2, d, d) -> (..., N1, N2)
+    (spd_utils_torch.py:124-156); differentiable (first order) through the HIP backward."""
+    if diagonal_distance is True:
+        return torch.zeros(tuple(x2.shape[:-2]) + (1,), dtype=x1.dtype, device=x1.device)
+    v1 = symmetric_matrix_to_vector_mandel_torch(x1)
+    v2 = symmetric_matrix_to_vector_mandel_torch(x2)
+    return ops.frobenius_kernel(v1, v2, 1.0, _lib.GABO_OUT_DISTANCE)

@@ -273,6 +273,50 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_backward_kernel(const doub
     }
 }
 
+// Adjoint of the Frechet derivative of a primary matrix function f in {log, exp, sqrt} at the symmetric matrix A, matrices in and
+// out: out = V ((V^T sym(G) V) o F) V^T with F_kl the divided differences of f at the eigenvalues (F_kk = f').  This is what autograd
+// through logm_torch / sqrtm_torch (spd_utils_torch.py:13-50) computes, in the form that stays finite at repeated eigenvalues.
+__global__ __launch_bounds__(64) void spd_matfun_backward_kernel(const double* __restrict__ a, const double* __restrict__ g,
+                                                                 double* __restrict__ out, int64_t n, int d, int fn) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int dd = d * d;
+    double* M0 = lds;
+    double* M1 = M0 + dd;
+    double* M2 = M1 + dd;
+    double* M3 = M2 + dd;
+    double* cs = M3 + dd;
+    const int64_t i = blockIdx.x;
+    lds_load(a + i * dd, M0, d);
+    lds_symmetrize(M0, M3, d);
+    lds_load(g + i * dd, M2, d);
+    lds_symmetrize(M2, M3, d);
+    lds_jacobi(M0, M1, cs, d);                  // M0 = diag(lambda), M1 = V
+    lds_mm(M1, M2, M3, d, true, false);         // V^T G
+    lds_mm(M3, M1, M2, d, false, false);        // V^T G V
+    for (int e = threadIdx.x; e < dd; e += blockDim.x) {
+        int r = e / d, c = e - r * d;
+        const double lr = M0[r * d + r], lc = M0[c * d + c];
+        const double mean = 0.5 * (lr + lc), dl = lr - lc;
+        double f;
+        if (fn == FN_LOG) {
+            const double z = dl / (2.0 * mean), z2 = z * z;
+            f = (__builtin_fabs(z) < 1e-3) ? (1.0 + z2 * (1.0 / 3.0 + z2 * (0.2 + z2 * (1.0 / 7.0)))) / mean : (log(lr) - log(lc)) / dl;
+        } else if (fn == FN_SQRT) {
+            f = 1.0 / (__builtin_sqrt(lr) + __builtin_sqrt(lc));          // (sqrt lr - sqrt lc)/(lr - lc), exact and stable
+        } else {
+            const double h = 0.5 * dl, h2 = h * h;                         // (e^lr - e^lc)/(lr - lc) = e^mean sinh(h)/h
+            const double sh = (__builtin_fabs(h) < 1e-2) ? 1.0 + h2 * (1.0 / 6.0 + h2 * (1.0 / 120.0 + h2 / 5040.0)) : sinh(h) / h;
+            f = exp(mean) * sh;
+        }
+        M2[e] *= f;
+    }
+    wsync();
+    lds_mm(M1, M2, M3, d, false, false);        // V (.)
+    lds_mm(M3, M1, M2, d, false, true);         // V (.) V^T
+    lds_symmetrize(M2, M3, d);
+    lds_store(M2, out + i * dd, d);
+}
+
 // Gradient of frobenius_pairwise w.r.t. x1 (Mandel): gx1[b,i,e] = sum_j w_ij (x1_ie - x2_je + sgn*eps_e), with
 // w_ij = go_ij * dOut/d(d^2) * 2 recomputed from the inputs (Gaussian: -2 beta K; Laplace: -beta K / d; distance: 1/d).
 // One block per (b, i): phase 1 the threads own 256 columns j and put w_j in LDS, phase 2 they own the Mandel entries e and
@@ -459,6 +503,18 @@ int gabo_spd_logm_mandel_backward(const double* x_mandel, const double* grad_y, 
     size_t lds = (size_t)(4 * d * d + 2) * sizeof(double);
     hipLaunchKernelGGL(gabo::spd_logm_mandel_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel,
                        grad_y, grad_x, n, d);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_spd_matfun_backward(int op, const double* a, const double* grad_out, double* grad_a, int64_t n, int d, gabo_stream_t stream) {
+    if (d < 1 || d > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
+    if (op != GABO_SPD_LOGM && op != GABO_SPD_EXPM && op != GABO_SPD_SQRTM) return GABO_ERR_ARG;
+    if (n < 0 || (n > 0 && (!a || !grad_out || !grad_a))) return GABO_ERR_ARG;
+    if (n == 0) return GABO_OK;
+    const int fn = op == GABO_SPD_LOGM ? gabo::FN_LOG : (op == GABO_SPD_EXPM ? gabo::FN_EXP : gabo::FN_SQRT);
+    size_t lds = (size_t)(4 * d * d + 2) * sizeof(double);
+    hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, a, grad_out, grad_a, n, d,
+                       fn);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

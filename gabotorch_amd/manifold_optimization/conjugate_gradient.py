@@ -48,6 +48,14 @@ class ConjugateGradient:
         self.orth_value = orth_value
         self._logverbosity = logverbosity
 
+    @property
+    def _mingradnorm(self):          # pymanopt's attribute name: the augmented Lagrangian method tightens it between subproblems
+        return self.mingradnorm
+
+    @_mingradnorm.setter
+    def _mingradnorm(self, value):
+        self.mingradnorm = float(value)
+
     def solve(self, problem, x=None):
         """problem: object with .manifold, .cost(x) -> float, .grad(x) -> Riemannian gradient.  Returns (x, log)."""
         man = problem.manifold

@@ -36,6 +36,9 @@ class Euclidean:
     def zerovec(self, x):
         return np.zeros(self._shape)
 
+    def dist(self, x, y):
+        return float(np.linalg.norm(x - y))
+
 
 class Sphere:
     """Unit sphere of R^n, points of shape (n,)."""
@@ -69,6 +72,9 @@ class Sphere:
 
     def zerovec(self, x):
         return np.zeros(self._shape)
+
+    def dist(self, x, y):
+        return float(np.arccos(np.clip(np.dot(x.reshape(-1), y.reshape(-1)), -1.0, 1.0)))
 
 
 class Grassmann:
@@ -106,6 +112,61 @@ class Grassmann:
     def zerovec(self, x):
         return np.zeros(self._shape)
 
+    def dist(self, x, y):
+        s = np.clip(np.linalg.svd(x.T @ y, compute_uv=False), -1.0, 1.0)      # cosines of the principal angles
+        return float(np.linalg.norm(np.arccos(s)))
+
+
+class PositiveDefinite:
+    """S^n_++ with the affine-invariant metric, single matrices (hyper-parameter sized: the bottom block of the nested-SPD
+    reconstruction) ([3P] pymanopt.manifolds.PositiveDefinite)."""
+
+    def __init__(self, n):
+        self._n = n
+        self._shape = (n, n)
+        self.dim = n * (n + 1) // 2
+        self.typicaldist = float(np.sqrt(self.dim))
+
+    @staticmethod
+    def _sym(a):
+        return 0.5 * (a + a.T)
+
+    def inner(self, x, u, v):
+        return float(np.tensordot(np.linalg.solve(x, u), np.linalg.solve(x, v).T, axes=2))
+
+    def norm(self, x, u):
+        return float(np.sqrt(max(self.inner(x, u, u), 0.0)))
+
+    def proj(self, x, u):
+        return self._sym(u)
+
+    def egrad2rgrad(self, x, g):
+        return x @ self._sym(g) @ x
+
+    def retr(self, x, u):          # retr = exp = L expm(L^-1 U L^-T) L^T
+        L = np.linalg.cholesky(x)
+        Li = np.linalg.inv(L)
+        w, q = np.linalg.eigh(self._sym(Li @ u @ Li.T))
+        return self._sym(L @ (q * np.exp(w)) @ q.T @ L.T)
+
+    exp = retr
+
+    def transp(self, x1, x2, u):
+        return u
+
+    def rand(self):
+        q, _ = np.linalg.qr(np.random.randn(self._n, self._n))
+        return self._sym((q * (1.0 + np.random.rand(self._n))) @ q.T)
+
+    def zerovec(self, x):
+        return np.zeros(self._shape)
+
+    def dist(self, x, y):
+        L = np.linalg.cholesky(x)
+        Li = np.linalg.inv(L)
+        lam = np.linalg.eigvalsh(self._sym(Li @ y @ Li.T))
+        return float(np.sqrt(np.sum(np.log(lam) ** 2)))
+
 
 class Product:
     """Product manifold: points and tangent vectors are lists, one entry per factor."""
@@ -141,3 +202,6 @@ class Product:
 
     def zerovec(self, x):
         return self._map("zerovec", x)
+
+    def dist(self, x, y):
+        return float(np.sqrt(sum(di * di for di in self._map("dist", x, y))))

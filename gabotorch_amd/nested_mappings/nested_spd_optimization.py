@@ -1,0 +1,83 @@
+"""Reconstruction parameters of the nested-SPD mapping, with the reference's names and signatures
+(BoManifolds/nested_mappings/nested_spd_optimization.py:23-186): the costs are sums of squared affine-invariant or log-Euclidean
+distances between the data and their reconstructions (HIP kernels, differentiable through the closed-form backward kernels and the
+matrix-function adjoint), minimised over  V in G(D, D-d),  C in S^(D-d)_++,  K = t * unit vector reshaped, t = sigmoid(.) in (0, 1),
+under W^T V = 0 by the augmented Lagrangian method."""
+import numpy as np
+import torch
+
+from .. import ops
+from ..manifold_optimization.augmented_lagrange_method import AugmentedLagrangeMethod, _Constraint
+from ..manifold_optimization.host_manifolds import Euclidean, Grassmann, PositiveDefinite, Product, Sphere
+from ..Riemannian_utils.spd_utils_torch import (affine_invariant_distance_torch, logm_torch,
+                                                symmetric_matrix_to_vector_mandel_torch)
+from .nested_spd_utils import projection_from_nested_spd_to_spd
+
+
+def min_affine_invariant_distance_reconstruction_cost(x_data, x_data_projected, projection_matrix, projection_complement_matrix,
+                                                      bottom_spd_matrix, contraction_matrix):
+    """sum_n d_AI(X_n, reconstruction(Y_n))^2   (nested_spd_optimization.py:23-56).  One batched launch for the N distances."""
+    x_rec = projection_from_nested_spd_to_spd(x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix,
+                                              contraction_matrix)
+    dist = affine_invariant_distance_torch(x_data.to(x_rec.device)[:, None], x_rec[:, None])        # batch N of 1 x 1 problems
+    return torch.sum(dist * dist)
+
+
+def min_log_euclidean_distance_reconstruction_cost(x_data, x_data_projected, projection_matrix, projection_complement_matrix,
+                                                   bottom_spd_matrix, contraction_matrix):
+    """sum_n ||logm X_n - logm reconstruction(Y_n) + 1e-15||_F^2   (nested_spd_optimization.py:59-92)."""
+    x_rec = projection_from_nested_spd_to_spd(x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix,
+                                              contraction_matrix)
+    diff = logm_torch(x_data.to(x_rec.device)) - logm_torch(x_rec) + 1e-15
+    return torch.sum(diff * diff)
+
+
+def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, projection_matrix, inner_solver,
+                                                  cost_function=min_affine_invariant_distance_reconstruction_cost,
+                                                  nb_init_candidates=100, maxiter=50):
+    """-> (projection_complement_matrix D x (D-d), bottom_spd_matrix (D-d) x (D-d), contraction_matrix d x (D-d))
+    (nested_spd_optimization.py:95-186)."""
+    dev, dt = x_data.device, torch.float64
+    x_data, x_data_projected, W = x_data.to(dt), x_data_projected.to(dev, dt), projection_matrix.to(dev, dt)
+    dim, latent = x_data.shape[1], W.shape[1]
+    manifold = Product([Grassmann(dim, dim - latent), PositiveDefinite(dim - latent), Sphere(latent * (dim - latent)), Euclidean(1)])
+
+    def to_torch(params, grad=False):
+        return [torch.tensor(np.asarray(p), dtype=dt, device=dev, requires_grad=grad) for p in params]
+
+    def cost_torch(p):
+        norm = torch.sigmoid(p[3])                                       # gpytorch Interval(0, 1).transform   (:139,155)
+        K = norm * p[2].reshape(latent, dim - latent)
+        return cost_function(x_data, x_data_projected, W, p[0], p[1], K)
+
+    def constraint_torch(p):
+        return torch.norm(p[0].T @ W)                                    # W^T V = 0   (:142-147)
+
+    def value_and_egrad(fn):
+        def vg(x):
+            p = to_torch(x, grad=True)
+            v = fn(p)
+            grads = torch.autograd.grad(v, p, allow_unused=True)
+            return float(v.detach()), [np.zeros(np.shape(xi)) if g is None else g.detach().cpu().numpy().reshape(np.shape(xi))
+                                       for g, xi in zip(grads, x)]
+        return vg
+
+    class _Problem:
+        pass
+    problem = _Problem()
+    problem.manifold = manifold
+    cost_vg = value_and_egrad(cost_torch)
+    problem.cost = lambda x: cost_vg(x)[0]
+    problem.grad = lambda x: manifold.egrad2rgrad(x, cost_vg(x)[1])
+    constraint = _Constraint(manifold, value_and_egrad(constraint_torch))
+    with torch.no_grad():
+        cands = [manifold.rand() for _ in range(nb_init_candidates)]
+        vals = [float(cost_torch(to_torch(c))) for c in cands]
+    x0 = cands[int(np.argmin(vals))]
+    solver = AugmentedLagrangeMethod(maxiter=maxiter, inner_solver=inner_solver, lambdas_fact=0.05)
+    opt = solver.solve(problem, x=x0, eq_constraints=[constraint])
+    V = torch.tensor(opt[0], dtype=dt, device=dev)
+    C = torch.tensor(opt[1], dtype=dt, device=dev)
+    K = torch.sigmoid(torch.tensor(opt[3], dtype=dt, device=dev)) * torch.tensor(opt[2], dtype=dt, device=dev).reshape(latent, dim - latent)
+    optimize_reconstruction_parameters_nested_spd.last_log = dict(solver.log, init_cost=float(np.min(vals)), final_cost=problem.cost(opt))
+    return V, C, K

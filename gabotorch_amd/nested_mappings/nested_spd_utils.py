@@ -13,7 +13,8 @@ def projection_from_nested_spd_to_spd(x_spd_low_dimension, projection_matrix, pr
                                       contraction_matrix):
     """Approximate right inverse of `projection_from_spd_to_nested_spd` (nested_spd_utils.py:51-118): with R = [W, V],
     Xr = [[Y, B], [B^T, C]], B = Y^1/2 K C^1/2, X = R Xr R^T.  Y: (d, d) or (N, d, d).  The matrix square roots are one
-    batched HIP launch (GABO_SPD_SQRTM); the block assembly and the two small products are host-side torch."""
+    batched HIP launch (GABO_SPD_SQRTM, differentiable through gabo_spd_matfun_backward); the block assembly and the two small
+    products are torch on the inputs' device."""
     import torch
 
     from .. import _lib
@@ -25,8 +26,8 @@ def projection_from_nested_spd_to_spd(x_spd_low_dimension, projection_matrix, pr
     W, V = projection_matrix.to(dev, dt), projection_complement_matrix.to(dev, dt)
     C, K = bottom_spd_matrix.to(dev, dt), contraction_matrix.to(dev, dt)
     R = torch.cat((W, V), dim=1)
-    sqrt_c = ops.spd_manifold_op(_lib.GABO_SPD_SQRTM, C).to(dt)
-    sqrt_y = ops.spd_manifold_op(_lib.GABO_SPD_SQRTM, y).to(dt)
+    sqrt_c = ops.spd_matrix_function(C, _lib.GABO_SPD_SQRTM).to(dt)        # differentiable (reconstruction costs, f4)
+    sqrt_y = ops.spd_matrix_function(y, _lib.GABO_SPD_SQRTM).to(dt)
     side = sqrt_y @ K @ sqrt_c
     n = y.shape[0]
     top = torch.cat((y, side), dim=2)

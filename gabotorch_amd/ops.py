@@ -354,6 +354,36 @@ def spd_manifold_op(op, a, b=None, c=None, e=None, want_grad=False):
     return out.to(out_device)
 
 
+class _SpdMatFun(torch.autograd.Function):
+    """logm / expm / sqrtm of symmetric (SPD) matrices with the divided-difference adjoint as backward (first order)."""
+
+    @staticmethod
+    def forward(ctx, a, op):
+        ctx.save_for_backward(a)
+        ctx.op = int(op)
+        return spd_manifold_op(int(op), a).to(a.dtype)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        lib = _lib.load()
+        dev = _device_for(a, g)
+        A = _prep(a, dev).contiguous()
+        G = _prep(g, dev).expand(A.shape).contiguous()
+        d = A.shape[-1]
+        out = torch.empty_like(A)
+        with torch.cuda.device(dev):
+            _lib.check(lib.gabo_spd_matfun_backward(ctx.op, A.data_ptr(), G.data_ptr(), out.data_ptr(), A.numel() // (d * d), d,
+                                                    _stream_ptr(dev)), "gabo_spd_matfun_backward")
+        return out.to(a.device, a.dtype), None
+
+
+def spd_matrix_function(a, op):
+    """Differentiable GABO_SPD_LOGM / GABO_SPD_EXPM / GABO_SPD_SQRTM on (..., d, d) matrices."""
+    return _SpdMatFun.apply(a, int(op)) if a.requires_grad else spd_manifold_op(int(op), a)
+
+
 def spd_project(x_mandel, w):
     """(..., D_vec) Mandel, w (D, dl) -> (..., dl_vec) Mandel of W^T X W."""
     lib = _lib.load()

@@ -163,6 +163,11 @@ int gabo_frobenius_pairwise(const double* x1, const double* x2, double* out, int
  *   in gabo_spd_ai_backward.  The gradient with respect to x2 is the same call with the sets exchanged, the row/column strides
  *   swapped and eps_sign = -1 (the reference's +1e-15 is added to x1 - x2, so it changes sign with the roles); eps_sign = +1
  *   otherwise. */
+/* Gradient of GABO_SPD_LOGM / GABO_SPD_EXPM / GABO_SPD_SQRTM (gabo_spd_manifold_op) with respect to the input matrices:
+ * grad_a = V ((V^T sym(grad_out) V) o F) V^T, F = divided differences of log / exp / sqrt at the eigenvalues of a (n x d x d each).
+ * Replaces autograd through logm_torch / sqrtm_torch (spd_utils_torch.py:13-50), e.g. in the reconstruction costs of
+ * nested_mappings/nested_spd_optimization.py:23-92. */
+int gabo_spd_matfun_backward(int op, const double* a, const double* grad_out, double* grad_a, int64_t n, int d, gabo_stream_t stream);
 int gabo_spd_logm_mandel_backward(const double* x_mandel, const double* grad_y, double* grad_x, int64_t n, int d,
                                   gabo_stream_t stream);
 int gabo_frobenius_backward(const double* x1, const double* x2, const double* grad_out, double* grad_x1, int64_t batch, int64_t n1,

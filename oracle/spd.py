@@ -298,3 +298,50 @@ def log_euclidean_gaussian_kernel_grads(x1_mandel, x2_mandel, lengthscale, grad_
     gb_log = -np.einsum("...ij,...ijab->...jab", w, diff)
     return (symmetric_matrix_to_vector_mandel(dlogm_adjoint(a, _sym(ga_log))),
             symmetric_matrix_to_vector_mandel(dlogm_adjoint(b, _sym(gb_log))))
+
+
+# ------------------------------------------------------------------------------- nested SPD reconstruction (f4)
+def projection_from_nested_spd_to_spd(y, w, v, c, k):
+    """X = R [[Y, B], [B^T, C]] R^T with R = [W, V], B = Y^1/2 K C^1/2   (nested_spd_utils.py:51-118)."""
+    y = np.asarray(y, dtype=np.float64)
+    single = y.ndim == 2
+    if single:
+        y = y[None]
+    rot = np.concatenate([w, v], axis=1)
+    sc = sqrtm(c)
+    out = []
+    for yn in y:
+        side = sqrtm(yn) @ k @ sc
+        xr = np.block([[yn, side], [side.T, c]])
+        out.append(rot @ xr @ rot.T)
+    out = np.stack(out)
+    return out[0] if single else out
+
+
+def reconstruction_cost(x, y, w, v, c, k, metric="ai"):
+    """sum_n dist(X_n, reconstruction(Y_n))^2 with the affine-invariant ("ai") or log-Euclidean ("le") distance
+    (nested_spd_optimization.py:23-92; the reference accumulates the N distances in a float32 tensor)."""
+    xr = projection_from_nested_spd_to_spd(y, w, v, c, k)
+    total = 0.0
+    for xn, rn in zip(np.asarray(x, dtype=np.float64), xr):
+        if metric == "ai":
+            dist = affine_invariant_distance(xn[None], rn[None])[0, 0]
+        else:
+            dist = frobenius_distance(logm(xn)[None], logm(rn)[None])[0, 0]
+        total += dist * dist
+    return total
+
+
+def matfun_adjoint(a, g, fn):
+    """Adjoint of the Frechet derivative of fn in {"log", "sqrt"} at SPD a applied to g (what autograd through
+    logm_torch / sqrtm_torch computes, spd_utils_torch.py:13-50)."""
+    lam, v = np.linalg.eigh(np.asarray(a, dtype=np.float64), UPLO="U")
+    f = np.log(lam) if fn == "log" else np.sqrt(lam)
+    fp = 1.0 / lam if fn == "log" else 0.5 / np.sqrt(lam)
+    dl = lam[..., :, None] - lam[..., None, :]
+    df = f[..., :, None] - f[..., None, :]
+    close = np.abs(dl) <= 1e-9 * np.abs(lam[..., :, None] + lam[..., None, :])
+    dd = np.where(close, 0.5 * (fp[..., :, None] + fp[..., None, :]), df / np.where(close, 1.0, dl))
+    gs = 0.5 * (np.asarray(g) + np.swapaxes(np.asarray(g), -1, -2))
+    inner = np.swapaxes(v, -1, -2) @ gs @ v
+    return v @ (inner * dd) @ np.swapaxes(v, -1, -2)

@@ -61,3 +61,46 @@ def test_conjugate_gradient_dominant_subspace_on_product():
     assert abs(-log["final_cost"] - (lam[-1] + lam[-2])) < 1e-6
     np.testing.assert_allclose(x[1], target, atol=1e-6)
     np.testing.assert_allclose(x[0].T @ x[0], np.eye(2), atol=1e-12)
+
+
+def test_host_positive_definite_manifold():
+    from gabotorch_amd.manifold_optimization.host_manifolds import PositiveDefinite
+    np.random.seed(3)
+    man = PositiveDefinite(4)
+    x, y = man.rand(), man.rand()
+    assert np.linalg.eigvalsh(x).min() > 0
+    u = man.proj(x, np.random.randn(4, 4))
+    np.testing.assert_allclose(u, u.T)
+    z = man.retr(x, 0.3 * u)
+    assert np.linalg.eigvalsh(z).min() > 0
+    np.testing.assert_allclose(man.dist(x, z), 0.3 * man.norm(x, u), rtol=1e-10)      # exp is a geodesic: d(x, exp_x(t u)) = t |u|_x
+    np.testing.assert_allclose(man.dist(x, y), man.dist(y, x), rtol=1e-12)
+    a = np.random.randn(4, 4)
+    np.testing.assert_allclose(man.dist(a @ x @ a.T, a @ y @ a.T), man.dist(x, y), rtol=1e-9)      # affine invariance
+    g = np.random.randn(4, 4)
+    rg = man.egrad2rgrad(x, g)
+    np.testing.assert_allclose(man.inner(x, rg, u), np.tensordot(0.5 * (g + g.T), u, axes=2), rtol=1e-10)   # <rgrad, u>_x = <egrad, u>
+
+
+def test_augmented_lagrange_method_on_a_constrained_toy_problem():
+    """min x^T A x over R^5 subject to |x|^2 = 1 (equality) and x_0 >= 0.1 (inequality, inactive at the solution): lambda_min(A)."""
+    from gabotorch_amd.manifold_optimization.augmented_lagrange_method import AugmentedLagrangeMethod, _Constraint
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((5, 5))
+    a = a @ a.T + np.eye(5)
+    man = Product([Euclidean(5)])
+
+    class P:
+        manifold = man
+        cost = staticmethod(lambda x: float(x[0] @ a @ x[0]))
+        grad = staticmethod(lambda x: [2 * a @ x[0]])
+    eq = _Constraint(man, lambda x: (float(x[0] @ x[0] - 1.0), [2 * x[0]]))
+    ineq = _Constraint(man, lambda x: (float(x[0][0] - 0.1), [np.eye(5)[0]]))
+    np.random.seed(4)
+    solver = AugmentedLagrangeMethod(ConjugateGradient(maxiter=300), maxiter=60, ending_tolgradnorm=1e-8)
+    x = solver.solve(P, x=[np.ones(5) / np.sqrt(5)], eq_constraints=[eq], ineq_constraints=[ineq])[0]
+    lam, vec = np.linalg.eigh(a)
+    assert abs(vec[0, 0]) > 0.15            # the inequality is inactive at the global solution: the optimum is the smallest eigenvalue
+    # the method stops when the iterate moves less than 1e-10 (pymanopt's default minstepsize), with the violation at ~1e-4
+    assert abs(x @ x - 1.0) < 1e-3 and x[0] >= 0.1 - 1e-3
+    np.testing.assert_allclose(x @ a @ x, lam[0], rtol=2e-3)

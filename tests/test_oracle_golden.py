@@ -155,3 +155,18 @@ def test_nested_sphere_projections_and_kernel(golden):
             np.testing.assert_allclose(b, g[f"{tag}_back{k}"], atol=1e-13)
         np.testing.assert_allclose(osph.nested_sphere_gaussian_kernel(g[f"{tag}_x1"], g[f"{tag}_x2"], axes, dists, float(g[f"{tag}_beta"])),
                                    g[f"{tag}_K"], rtol=1e-11)
+
+
+def test_reconstruction_costs_and_matrix_function_adjoints(golden):
+    g = golden("reconstruction.npz")
+    for tag in "ab":
+        args = [g[f"{tag}_{k}"] for k in ("X", "Y", "W", "V", "C", "K")]
+        # the reference accumulates the per-matrix distances in float32 (torch.zeros(n_data)): 1e-6 is its own resolution
+        np.testing.assert_allclose(ospd.reconstruction_cost(*args, metric="ai"), g[f"{tag}_ai_cost"], rtol=2e-6)
+        np.testing.assert_allclose(ospd.reconstruction_cost(*args, metric="le"), g[f"{tag}_le_cost"], rtol=2e-6)
+    np.testing.assert_allclose(ospd.logm(g["mf_A"]), g["logm_val"], atol=1e-12)
+    np.testing.assert_allclose(ospd.sqrtm(g["mf_A"]), g["sqrtm_val"], atol=1e-12)
+    sym = lambda a: 0.5 * (a + a.transpose(0, 2, 1))     # noqa: E731  autograd's gradient w.r.t. a general matrix; we compare its symmetric part
+    np.testing.assert_allclose(ospd.matfun_adjoint(g["mf_A"], g["mf_G"], "log"), sym(g["logm_grad"]), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ospd.matfun_adjoint(g["mf_A"], g["mf_G"], "sqrt"), sym(g["sqrtm_grad"]), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ospd.frobenius_distance(g["frob_x1"], g["frob_x2"]), g["frob_d"], rtol=1e-12)
