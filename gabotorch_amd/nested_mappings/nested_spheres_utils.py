@@ -61,9 +61,13 @@ def projection_from_subsphere_to_next_sphere(x_subsphere, sphere_axis, sphere_di
     north = torch.zeros_like(axis)
     north[:, -1] = 1.0
     rot = rotation_from_sphere_points_torch(north, axis)
-    r = _dist_value(sphere_distance_to_axis)
-    cos_vector = math.cos(r) * torch.ones(x_subsphere.shape[0], 1, dtype=x_subsphere.dtype, device=x_subsphere.device)
-    return torch.cat((math.sin(r) * x_subsphere, cos_vector), 1) @ rot.T
+    if torch.is_tensor(sphere_distance_to_axis):          # kept as a tensor: the reconstruction cost is differentiated w.r.t. it
+        r = sphere_distance_to_axis.reshape(()).to(x_subsphere.device, x_subsphere.dtype)
+        sin_r, cos_r = torch.sin(r), torch.cos(r)
+    else:
+        sin_r, cos_r = math.sin(float(sphere_distance_to_axis)), math.cos(float(sphere_distance_to_axis))
+    cos_vector = cos_r * torch.ones(x_subsphere.shape[0], 1, dtype=x_subsphere.dtype, device=x_subsphere.device)
+    return torch.cat((sin_r * x_subsphere, cos_vector), 1) @ rot.T
 
 
 def projection_from_subsphere_to_sphere(x_subsphere, sphere_axes, sphere_distances_to_axes):

@@ -162,3 +162,10 @@ def nested_sphere_gaussian_kernel(x1, x2, axes, dists, beta):
     p2 = projection_from_sphere_to_subsphere(x2, axes, dists)[-1]
     d = sphere_distance(p1, p2)
     return np.exp(-beta * d * d)
+
+
+def nested_sphere_reconstruction_cost(x, x_sub, axes, dists):
+    """sum_n d(x_n, reconstruction_n)^2   (nested_spheres_optimization.py:20-38)."""
+    rec = projection_from_subsphere_to_sphere(x_sub, axes, dists)[-1]
+    d = sphere_distance(np.asarray(x, dtype=np.float64), rec, diag=True)
+    return float(np.sum(d * d))

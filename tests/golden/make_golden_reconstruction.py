@@ -26,6 +26,8 @@ sys.modules["pymanopt.solvers"].solver = sys.modules["pymanopt.solvers.solver"]
 
 from BoManifolds.nested_mappings import nested_spd_optimization as nso  # noqa: E402
 from BoManifolds.Riemannian_utils import spd_utils_torch as sut  # noqa: E402
+from BoManifolds.nested_mappings import nested_spheres_optimization as nsso  # noqa: E402
+from BoManifolds.nested_mappings import nested_spheres_utils as nsu  # noqa: E402
 
 
 def rand_spd(rng, n, d, lo=0.3, hi=3.0):
@@ -68,6 +70,20 @@ def main():
     x1, x2 = rand_spd(rng, 4, 3), rand_spd(rng, 5, 3)
     out["frob_x1"], out["frob_x2"] = x1, x2
     out["frob_d"] = sut.frobenius_distance_torch(torch.tensor(x1), torch.tensor(x2)).numpy()
+    # nested spheres: reconstruction error as a function of the distances to the axes (nested_spheres_optimization.py:20-38)
+    dim, latent, n = 5, 3, 9
+    xs = rng.standard_normal((n, dim)); xs /= np.linalg.norm(xs, axis=1, keepdims=True)
+    axes = []
+    for dd in range(dim, latent, -1):
+        a = rng.standard_normal((1, dd)); a /= np.linalg.norm(a)
+        axes.append(a)
+    r_proj = [torch.tensor([[1.2]], dtype=torch.float64), torch.tensor([[1.4]], dtype=torch.float64)]
+    sub = nsu.projection_from_sphere_to_subsphere(torch.tensor(xs), [torch.tensor(a) for a in axes], r_proj)[-1]
+    r_eval = [torch.tensor([[1.0]], dtype=torch.float64, requires_grad=True), torch.tensor([[1.5]], dtype=torch.float64, requires_grad=True)]
+    cost = nsso.min_error_reconstruction_cost(torch.tensor(xs), sub, [torch.tensor(a) for a in axes], r_eval)
+    cost.backward()
+    out.update({"ns_x": xs, "ns_sub": sub.numpy(), "ns_axis0": axes[0], "ns_axis1": axes[1], "ns_r": np.array([1.0, 1.5]),
+                "ns_cost": np.array(cost.item()), "ns_grad": np.array([r_eval[0].grad.item(), r_eval[1].grad.item()])})
     np.savez_compressed(os.path.join(HERE, "reconstruction.npz"), **out)
     print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith("cost")}, out["a_ai_cost"], out["a_le_cost"])
 

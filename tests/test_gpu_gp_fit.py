@@ -84,7 +84,7 @@ def test_fit_moves_nested_sphere_axes_on_their_spheres():
     _, info = fit_gpytorch_manifold(gp, solver=ConjugateGradient(maxiter=40), nb_init_candidates=20)
     assert info["fopt"] <= before + 1e-12
     for a, b in zip(kern.base_kernel.axes, a0):
-        assert abs(float(a.norm()) - 1.0) < 1e-10
+        assert abs(float(a.detach().norm()) - 1.0) < 1e-10
     assert any(float((a.detach() - b).abs().max()) > 1e-6 for a, b in zip(kern.base_kernel.axes, a0))
     # the fitted model predicts
     mean, var = gp.posterior(torch.tensor(X[:4], device=DEV))
@@ -144,3 +144,29 @@ def test_optimize_reconstruction_parameters_nested_spd():
     assert np.linalg.eigvalsh(C.cpu().numpy()).min() > 0 and float(torch.linalg.matrix_norm(K, 2)) < 1.0
     Xr = projection_from_nested_spd_to_spd(T(Y), T(W), V, C, K)
     assert np.linalg.eigvalsh(Xr.cpu().numpy()).min() > 0
+
+
+def test_nested_sphere_reconstruction_cost_and_optimiser(golden):
+    from gabotorch_amd.nested_mappings import nested_spheres_optimization as nsso
+    from gabotorch_amd.nested_mappings.nested_spheres_utils import projection_from_sphere_to_subsphere
+    g = golden("reconstruction.npz")
+    T = lambda a, grad=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV, requires_grad=grad)   # noqa: E731
+    axes = [T(g["ns_axis0"]), T(g["ns_axis1"])]
+    r = [T([[g["ns_r"][0]]], True), T([[g["ns_r"][1]]], True)]
+    cost = nsso.min_error_reconstruction_cost(T(g["ns_x"]), T(g["ns_sub"]), axes, r)
+    np.testing.assert_allclose(float(cost), g["ns_cost"], rtol=1e-10)
+    cost.backward()
+    np.testing.assert_allclose([float(r[0].grad), float(r[1].grad)], g["ns_grad"], rtol=1e-8)
+    # optimiser: data lying exactly on nested small circles of radii (1.1, 0.9) are reconstructed with zero error at those radii
+    rng = np.random.default_rng(12)
+    true_r = [torch.tensor([[1.1]], dtype=torch.float64), torch.tensor([[0.9]], dtype=torch.float64)]
+    z = rng.standard_normal((20, 3))
+    z /= np.linalg.norm(z, axis=1, keepdims=True)
+    from gabotorch_amd.nested_mappings.nested_spheres_utils import projection_from_subsphere_to_sphere
+    x = projection_from_subsphere_to_sphere(T(z), axes, true_r)[-1]
+    np.random.seed(2)
+    found = nsso.optimize_reconstruction_parameters_nested_sphere(x, T(z), axes, ConjugateGradient(maxiter=200, mingradnorm=1e-9),
+                                                                  nb_init_candidates=30)
+    np.testing.assert_allclose([float(f) for f in found], [1.1, 0.9], atol=1e-5)
+    assert float(nsso.min_error_reconstruction_cost(x, T(z), axes, found)) < 1e-9
+    assert projection_from_sphere_to_subsphere(x, axes, found)[-1].shape == (20, 3)

@@ -170,3 +170,13 @@ def test_reconstruction_costs_and_matrix_function_adjoints(golden):
     np.testing.assert_allclose(ospd.matfun_adjoint(g["mf_A"], g["mf_G"], "log"), sym(g["logm_grad"]), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(ospd.matfun_adjoint(g["mf_A"], g["mf_G"], "sqrt"), sym(g["sqrtm_grad"]), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(ospd.frobenius_distance(g["frob_x1"], g["frob_x2"]), g["frob_d"], rtol=1e-12)
+
+
+def test_nested_sphere_reconstruction_cost(golden):
+    g = golden("reconstruction.npz")
+    axes = [g["ns_axis0"], g["ns_axis1"]]
+    cost = lambda r: osph.nested_sphere_reconstruction_cost(g["ns_x"], g["ns_sub"], axes, list(r))   # noqa: E731
+    np.testing.assert_allclose(cost(g["ns_r"]), g["ns_cost"], rtol=1e-10)
+    h = 1e-6
+    num = [(cost(g["ns_r"] + h * np.eye(2)[k]) - cost(g["ns_r"] - h * np.eye(2)[k])) / (2 * h) for k in range(2)]
+    np.testing.assert_allclose(num, g["ns_grad"], rtol=1e-6)
