@@ -4,7 +4,7 @@ MI355X: a GP with the nested log-Euclidean kernel is fitted on the HIGH-dimensio
 which LEARNS the projection W on the Grassmannian together with the Euclidean hyper-parameters (conjugate gradients, 20 initial
 candidates, as hd_gabo_spd.py:205) -, the data are projected with Y = W^T X W, a latent GP with the log-Euclidean kernel and the
 same hyper-parameters is built on them, EI is maximised ON THE LATENT MANIFOLD with the strict constrained trust regions
-(eigenvalue box, FD Hessian), and the winner is lifted back with projection_from_nested_spd_to_spd.
+(eigenvalue bounds stated in the original space, FD Hessian), and the winner is lifted back with projection_from_nested_spd_to_spd.
 
 The reconstruction parameters (complement basis, bottom block, contraction) are optimised as in the reference
 (optimize_reconstruction_parameters_nested_spd with the log-Euclidean cost, hd_gabo_spd.py:229-232; augmented Lagrangian + conjugate
@@ -33,8 +33,9 @@ from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize
 from gabotorch_amd.nested_mappings.nested_spd_utils import projection_from_nested_spd_to_spd                      # noqa: E402
 from gabotorch_amd.nested_mappings.nested_spd_optimization import (min_log_euclidean_distance_reconstruction_cost,  # noqa: E402
                                                                    optimize_reconstruction_parameters_nested_spd)
-from gabotorch_amd.Riemannian_utils.spd_constraints_utils_torch import (max_eigenvalue_constraint_torch,          # noqa: E402
-                                                                        min_eigenvalue_constraint_torch)
+from gabotorch_amd.nested_mappings.nested_spd_constraints_utils import (max_eigenvalue_nested_spd_constraint,    # noqa: E402
+                                                                        min_eigenvalue_nested_spd_constraint,
+                                                                        random_nested_spd_with_spd_eigenvalue_constraints)
 from gabotorch_amd.Riemannian_utils.spd_utils import spd_sample, symmetric_matrix_to_vector_mandel                # noqa: E402
 from gabotorch_amd.Riemannian_utils.spd_utils_torch import (symmetric_matrix_to_vector_mandel_torch,              # noqa: E402
                                                             vector_to_symmetric_matrix_mandel_torch)
@@ -54,8 +55,6 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
     objective = lambda x: rosenbrock_function_spd(x, big)          # noqa: E731  evaluated on the HIGH-dimensional manifold
     x_data = torch.tensor(np.stack([symmetric_matrix_to_vector_mandel(big.rand()) for _ in range(5)]), device=device)
     y_data = torch.cat([objective(x) for x in x_data]).reshape(-1).to(device)
-    cons = [functools.partial(max_eigenvalue_constraint_torch, maximum_eigenvalue=small.max_eig),
-            functools.partial(min_eigenvalue_constraint_torch, minimum_eigenvalue=small.min_eig)]
     solver = BatchedTrustRegions(mingradnorm=2e-4, maxiter=100, minstepsize=1e-4, strict_constraints=True)   # hd_gabo_spd.py:194
     k_fct = ScaleKernel(NestedSpdLogEuclideanGaussianKernel(dim, latent), outputscale_prior=models.GammaPrior(2.0, 0.15)).double()
     ops.set_error_checking(False)
@@ -75,6 +74,13 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
             V = torch.linalg.svd(W, full_matrices=True)[0][:, latent:]              # orthonormal complement of span(W)
         latent_kernel = SpdLogEuclideanGaussianKernel().double()
         latent_kernel.lengthscale = k_fct.base_kernel.lengthscale.detach().clone()   # same hyper-parameters (:217-219)
+        # constraints and raw samples of the latent optimisation are stated in the ORIGINAL space (:239-256)
+        small.rand = types.MethodType(functools.partial(random_nested_spd_with_spd_eigenvalue_constraints, random_spd_fct=big.rand,
+                                                        projection_matrix=W), small)
+        cons = [functools.partial(max_eigenvalue_nested_spd_constraint, maximum_eigenvalue=big.max_eig, projection_matrix=W,
+                                  projection_complement_matrix=V, bottom_spd_matrix=bottom, contraction_matrix=contraction),
+                functools.partial(min_eigenvalue_nested_spd_constraint, minimum_eigenvalue=big.min_eig, projection_matrix=W,
+                                  projection_complement_matrix=V, bottom_spd_matrix=bottom, contraction_matrix=contraction)]
         gp = models.ExactGP(z_data, y_std, latent_kernel, outputscale=float(k_fct.outputscale.detach()), noise=float(model.noise.detach()),
                             mean=float(model.mean_constant.detach()))
         acq = models.ExpectedImprovement(gp, best_f=float(y_std.min()), maximize=False)

@@ -28,6 +28,7 @@ from BoManifolds.nested_mappings import nested_spd_optimization as nso  # noqa: 
 from BoManifolds.Riemannian_utils import spd_utils_torch as sut  # noqa: E402
 from BoManifolds.nested_mappings import nested_spheres_optimization as nsso  # noqa: E402
 from BoManifolds.nested_mappings import nested_spheres_utils as nsu  # noqa: E402
+from BoManifolds.nested_mappings import nested_spd_constraints_utils as nscu  # noqa: E402
 
 
 def rand_spd(rng, n, d, lo=0.3, hi=3.0):
@@ -70,6 +71,17 @@ def main():
     x1, x2 = rand_spd(rng, 4, 3), rand_spd(rng, 5, 3)
     out["frob_x1"], out["frob_x2"] = x1, x2
     out["frob_d"] = sut.frobenius_distance_torch(torch.tensor(x1), torch.tensor(x2)).numpy()
+    # eigenvalue constraints stated in the original space (nested_spd_constraints_utils.py:14-73), value and gradient w.r.t. the nested point
+    for k in range(3):
+        y = torch.tensor(out["a_Y"][k], requires_grad=True)
+        args = [torch.tensor(out[f"a_{n}"]) for n in ("W", "V", "C", "K")]
+        fmax = nscu.max_eigenvalue_nested_spd_constraint(y, 4.0, *args)
+        fmax.backward()
+        out[f"nc_max{k}"], out[f"nc_gmax{k}"] = np.array(fmax.item()), y.grad.numpy().copy()
+        y2 = torch.tensor(out["a_Y"][k], requires_grad=True)
+        fmin = nscu.min_eigenvalue_nested_spd_constraint(y2, 0.1, *args)
+        fmin.backward()
+        out[f"nc_min{k}"], out[f"nc_gmin{k}"] = np.array(fmin.item()), y2.grad.numpy().copy()
     # nested spheres: reconstruction error as a function of the distances to the axes (nested_spheres_optimization.py:20-38)
     dim, latent, n = 5, 3, 9
     xs = rng.standard_normal((n, dim)); xs /= np.linalg.norm(xs, axis=1, keepdims=True)

@@ -170,3 +170,28 @@ def test_nested_sphere_reconstruction_cost_and_optimiser(golden):
     np.testing.assert_allclose([float(f) for f in found], [1.1, 0.9], atol=1e-5)
     assert float(nsso.min_error_reconstruction_cost(x, T(z), axes, found)) < 1e-9
     assert projection_from_sphere_to_subsphere(x, axes, found)[-1].shape == (20, 3)
+
+
+def test_nested_spd_eigenvalue_constraints_golden(golden):
+    """max/min_eigenvalue_nested_spd_constraint (bounds in the original space, hd_gabo_spd.py:245-256) with their gradients w.r.t.
+    the nested point, single points and a batch, against the reference."""
+    from gabotorch_amd.nested_mappings import nested_spd_constraints_utils as nscu
+    g = golden("reconstruction.npz")
+    T = lambda a, grad=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV, requires_grad=grad)   # noqa: E731
+    args = [T(g[f"a_{n}"]) for n in ("W", "V", "C", "K")]
+    sym = lambda a: 0.5 * (a + a.T)     # noqa: E731
+    for k in range(3):
+        y = T(g["a_Y"][k], True)
+        f = nscu.max_eigenvalue_nested_spd_constraint(y, 4.0, *args)
+        np.testing.assert_allclose(float(f), g[f"nc_max{k}"], rtol=1e-10)
+        f.backward()
+        np.testing.assert_allclose(sym(y.grad.cpu().numpy()), sym(g[f"nc_gmax{k}"]), rtol=1e-7, atol=1e-9)
+        y2 = T(g["a_Y"][k], True)
+        f2 = nscu.min_eigenvalue_nested_spd_constraint(y2, 0.1, *args)
+        np.testing.assert_allclose(float(f2), g[f"nc_min{k}"], rtol=1e-10)
+        f2.backward()
+        np.testing.assert_allclose(sym(y2.grad.cpu().numpy()), sym(g[f"nc_gmin{k}"]), rtol=1e-7, atol=1e-9)
+    batch = nscu.max_eigenvalue_nested_spd_constraint(T(g["a_Y"][:3]), 4.0, *args)
+    np.testing.assert_allclose(batch.cpu().numpy(), [g[f"nc_max{k}"] for k in range(3)], rtol=1e-10)
+    sample = nscu.random_nested_spd_with_spd_eigenvalue_constraints(None, lambda: g["a_X"][0], args[0])
+    np.testing.assert_allclose(sample, g["a_Y"][0], atol=1e-10)
