@@ -38,3 +38,13 @@ def test_hd_gabo_spd_loop():
     lam = np.linalg.eigvalsh(ospd.vector_to_symmetric_matrix_mandel(x.cpu().numpy()))
     assert lam.min() > 0
     assert all(b2 <= b1 + 1e-12 for b1, b2 in zip(best, best[1:])) and np.isfinite(best[-1])
+
+
+def test_hd_gabo_sphere_loop():
+    """HD-GaBO on S^4 through nested spheres down to S^2: axes learnt on their spheres, reconstruction distances optimised,
+    latent EI maximisation, lift back."""
+    import hd_gabo_sphere
+    x, y, best = hd_gabo_sphere.run(dim=5, latent=3, iters=3, verbose=False, fit_iters=15)
+    assert x.shape == (8, 5)
+    np.testing.assert_allclose(np.linalg.norm(x.cpu().numpy(), axis=1), 1.0, atol=1e-12)
+    assert all(b2 <= b1 + 1e-12 for b1, b2 in zip(best, best[1:])) and np.isfinite(best[-1])
