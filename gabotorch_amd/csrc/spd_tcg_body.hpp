@@ -219,6 +219,151 @@ static __device__ ConsStep cons_step(double step, const double* fc, const double
     return r;
 }
 
+// Per-restart views of the tCG state (vectors of length L = d^2 whitened matrices for S^d_++, or the ambient dimension for the sphere)
+struct TcgVecs {
+    const double* g;            // gradient (whitened for SPD)
+    double *eta, *heta, *r, *delta;
+    const double* gc;           // constraint gradients: gc + k * gc_stride, k < C
+    int64_t gc_stride;
+    double* scal;               // SC_COUNT scalars
+    const double* fc;           // C constraint values
+    double* fcg_pe;             // C
+    int *stop, *running;
+};
+
+// The manifold-independent part of one tCG iteration (robust_trust_regions.py:476-568, constrained_trust_regions.py:530-732): Hd and a
+// copy dl of delta are in LDS (length L), the inner product is the plain dot of the stored vectors.  s0..s3: four LDS scratch vectors
+// of length L (may alias whatever produced Hd).  Precon: zero_sum(rn) -> bool, entry(r_e, zero_sum, e) -> z_e  (the reference's
+// "+1e-30 when the elements sum to zero" preconditioner in the caller's coordinates).
+template <class Precon>
+static __device__ bool tcg_step_core(const TcgVecs& v, int L, int C, double* Hd, double* dl, double* s0, double* s1, double* s2, int neq,
+                                     double delta_cons, double theta, double kappa, int mininner, int iter, Precon precon) {
+    double* sc = v.scal;
+    const double* gw = v.g;
+    double* eta = v.eta;
+    double* heta = v.heta;
+    double* rw = v.r;
+    const double Delta = sc[SC_DELTA], e_Pe = sc[SC_E_PE], e_Pd = sc[SC_E_PD], d_Pd = sc[SC_D_PD], z_r = sc[SC_Z_R];
+    const double dc2 = delta_cons * delta_cons;
+    const double d_Hd = wave_dot(dl, Hd, L);
+    const bool nz = d_Hd != 0.0;
+    const double alpha = nz ? z_r / d_Hd : 0.0;
+    const double e_Pe_new = nz ? e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd : e_Pe;
+    const double Delta2 = Delta * Delta;
+    double fcl[kMaxCons], fpe[kMaxCons], fpd[kMaxCons];
+    for (int k = 0; k < C; ++k) {
+        fcl[k] = v.fc[k];
+        fpe[k] = v.fcg_pe[k];
+        fpd[k] = wave_dot(v.gc + (int64_t)k * v.gc_stride, dl, L);
+    }
+    int stop = -1;
+    double step = 0.0;       // eta += step * delta, Heta += step * Hd when leaving
+    // ---- leave through the trust-region boundary / negative curvature
+    if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {
+        double tau = (-e_Pd + __builtin_sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;
+        stop = d_Hd <= 0.0 ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;
+        if (C > 0) {
+            if (tau != tau) tau = 0.0;
+            ConsStep cst = cons_step(tau, fcl, fpe, fpd, C, neq, dc2);
+            if (cst.cin > dc2) {
+                tau = cst.tau;
+                if (d_Hd > 0.0) stop = TCG_REACHED_CONSTRAINTS;
+            }
+        }
+        step = tau;
+    } else if (C > 0) {
+        // ---- leave because the linearised constraints are reached inside the trust region
+        ConsStep cst = cons_step(alpha, fcl, fpe, fpd, C, neq, dc2);
+        if (cst.cin > dc2) { stop = TCG_REACHED_CONSTRAINTS; step = cst.tau; }
+    }
+    if (stop >= 0) {
+        for (int e = threadIdx.x; e < L; e += 64) {
+            eta[e] = eta[e] + step * dl[e];
+            heta[e] = heta[e] + step * Hd[e];
+        }
+        if (threadIdx.x == 0) { *v.stop = stop; *v.running = 0; }
+        return false;
+    }
+    // ---- tentative step; reject it if the model did not decrease
+    double* ne = s0;
+    double* nh = s1;
+    double m1 = 0.0, m2 = 0.0;
+    for (int e = threadIdx.x; e < L; e += 64) {
+        double a = eta[e] + alpha * dl[e], b = heta[e] + alpha * Hd[e];
+        ne[e] = a;
+        nh[e] = b;
+        m1 = __builtin_fma(a, gw[e], m1);
+        m2 = __builtin_fma(a, b, m2);
+    }
+    const double new_model = wave_sum(m1) + 0.5 * wave_sum(m2);
+    if (!(new_model < sc[SC_MODEL])) {
+        if (threadIdx.x == 0) { *v.stop = TCG_MODEL_INCREASED; *v.running = 0; }
+        return false;
+    }
+    double rr = 0.0;
+    double* rn = s2;
+    for (int e = threadIdx.x; e < L; e += 64) {
+        eta[e] = ne[e];
+        heta[e] = nh[e];
+        double r = rw[e] + alpha * Hd[e];
+        rw[e] = r;
+        rn[e] = r;
+        rr = __builtin_fma(r, r, rr);
+    }
+    rr = wave_sum(rr);
+    __syncthreads();
+    const double norm_r = __builtin_sqrt(rr > 0.0 ? rr : 0.0);
+    bool running = true;
+    // ---- residual small enough
+    if (iter >= mininner) {
+        const double nr0 = sc[SC_NORM_R0];
+        const double p = pow(nr0, theta);
+        const double target = nr0 * (p < kappa ? p : kappa);
+        if (norm_r <= target) {
+            stop = kappa < p ? TCG_REACHED_TARGET_LINEAR : TCG_REACHED_TARGET_SUPERLINEAR;
+            running = false;
+        }
+    }
+    if (threadIdx.x == 0) {
+        sc[SC_MODEL] = new_model;
+        sc[SC_E_PE] = e_Pe_new;
+        if (!running) { *v.stop = stop; *v.running = 0; }
+    }
+    if (!running) return false;
+    // ---- next search direction
+    const bool zero_sum = precon.zero_sum(rn);
+    double zr = 0.0;
+    double* zv = s1;
+    for (int e = threadIdx.x; e < L; e += 64) {
+        double z = precon.entry(rn[e], zero_sum, e);
+        zv[e] = z;
+        zr = __builtin_fma(z, rn[e], zr);
+    }
+    const double z_r_new = wave_sum(zr);
+    const double beta = z_r_new / z_r;
+    for (int e = threadIdx.x; e < L; e += 64) v.delta[e] = -zv[e] + beta * dl[e];
+    if (threadIdx.x == 0) {
+        sc[SC_E_PD] = beta * (e_Pd + alpha * d_Pd);
+        sc[SC_D_PD] = z_r_new + beta * beta * d_Pd;
+        sc[SC_Z_R] = z_r_new;
+        for (int k = 0; k < C; ++k) v.fcg_pe[k] = fpe[k] + alpha * fpd[k];
+    }
+    return true;
+}
+
+// the preconditioner of manifold_optimize.py:190-193 in whitened SPD coordinates (see precon_entry / unwhitened_sum)
+struct SpdPrecon {
+    double* Lbuf;           // LDS, d x d: receives chol(x)
+    const double* chol;     // global
+    const double* w1;       // row sums of L^-1
+    int d;
+    __device__ bool zero_sum(const double* rn) const {
+        lds_load(chol, Lbuf, d);
+        return unwhitened_sum(Lbuf, rn, d) == 0.0;
+    }
+    __device__ double entry(double r, bool zs, int e) const { return precon_entry(r, zs, w1, e, d); }
+};
+
 // egrad_fd: this restart's Euclidean gradient at the FD point (Mandel row, global or LDS).  lds: 5 d^2 doubles.
 // Returns true while the restart keeps running.  `iter` = index of this inner iteration (0-based).
 static __device__ bool tcg_step(const TcgWs& w, int64_t i, int64_t R, int d, int C, const double* __restrict__ egrad_fd, int neq,
@@ -251,115 +396,10 @@ static __device__ bool tcg_step(const TcgWs& w, int64_t i, int64_t R, int d, int
         dl[e] = w.delta_w[i * dd + e];
     }
     __syncthreads();
-    double* eta = w.eta_w + i * dd;
-    double* heta = w.heta_w + i * dd;
-    double* rw = w.r_w + i * dd;
-    const double Delta = sc[SC_DELTA], e_Pe = sc[SC_E_PE], e_Pd = sc[SC_E_PD], d_Pd = sc[SC_D_PD], z_r = sc[SC_Z_R];
-    const double dc2 = delta_cons * delta_cons;
-    const double d_Hd = wave_dot(dl, Hd, dd);
-    const bool nz = d_Hd != 0.0;
-    const double alpha = nz ? z_r / d_Hd : 0.0;
-    const double e_Pe_new = nz ? e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd : e_Pe;
-    const double Delta2 = Delta * Delta;
-    double fcl[kMaxCons], fpe[kMaxCons], fpd[kMaxCons];
-    for (int k = 0; k < C; ++k) {
-        fcl[k] = w.fc[i * C + k];
-        fpe[k] = w.fcg_pe[i * C + k];
-        fpd[k] = wave_dot(w.gc_w + ((int64_t)k * R + i) * dd, dl, dd);
-    }
-    int stop = -1;
-    double step = 0.0;       // eta += step * delta, Heta += step * Hd when leaving
-    // ---- leave through the trust-region boundary / negative curvature
-    if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {
-        double tau = (-e_Pd + __builtin_sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;
-        stop = d_Hd <= 0.0 ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;
-        if (C > 0) {
-            if (tau != tau) tau = 0.0;
-            ConsStep cst = cons_step(tau, fcl, fpe, fpd, C, neq, dc2);
-            if (cst.cin > dc2) {
-                tau = cst.tau;
-                if (d_Hd > 0.0) stop = TCG_REACHED_CONSTRAINTS;
-            }
-        }
-        step = tau;
-    } else if (C > 0) {
-        // ---- leave because the linearised constraints are reached inside the trust region
-        ConsStep cst = cons_step(alpha, fcl, fpe, fpd, C, neq, dc2);
-        if (cst.cin > dc2) { stop = TCG_REACHED_CONSTRAINTS; step = cst.tau; }
-    }
-    if (stop >= 0) {
-        for (int e = threadIdx.x; e < dd; e += 64) {
-            eta[e] = eta[e] + step * dl[e];
-            heta[e] = heta[e] + step * Hd[e];
-        }
-        if (threadIdx.x == 0) { w.stop[i] = stop; w.running[i] = 0; }
-        return false;
-    }
-    // ---- tentative step; reject it if the model did not decrease
-    double* ne = M0;
-    double* nh = M1;
-    double m1 = 0.0, m2 = 0.0;
-    for (int e = threadIdx.x; e < dd; e += 64) {
-        double a = eta[e] + alpha * dl[e], b = heta[e] + alpha * Hd[e];
-        ne[e] = a;
-        nh[e] = b;
-        m1 = __builtin_fma(a, gw[e], m1);
-        m2 = __builtin_fma(a, b, m2);
-    }
-    const double new_model = wave_sum(m1) + 0.5 * wave_sum(m2);
-    if (!(new_model < sc[SC_MODEL])) {
-        if (threadIdx.x == 0) { w.stop[i] = TCG_MODEL_INCREASED; w.running[i] = 0; }
-        return false;
-    }
-    double rr = 0.0;
-    double* rn = M3;
-    for (int e = threadIdx.x; e < dd; e += 64) {
-        eta[e] = ne[e];
-        heta[e] = nh[e];
-        double r = rw[e] + alpha * Hd[e];
-        rw[e] = r;
-        rn[e] = r;
-        rr = __builtin_fma(r, r, rr);
-    }
-    rr = wave_sum(rr);
-    __syncthreads();
-    const double norm_r = __builtin_sqrt(rr > 0.0 ? rr : 0.0);
-    bool running = true;
-    // ---- residual small enough
-    if (iter >= mininner) {
-        const double nr0 = sc[SC_NORM_R0];
-        const double p = pow(nr0, theta);
-        const double target = nr0 * (p < kappa ? p : kappa);
-        if (norm_r <= target) {
-            stop = kappa < p ? TCG_REACHED_TARGET_LINEAR : TCG_REACHED_TARGET_SUPERLINEAR;
-            running = false;
-        }
-    }
-    if (threadIdx.x == 0) {
-        sc[SC_MODEL] = new_model;
-        sc[SC_E_PE] = e_Pe_new;
-        if (!running) { w.stop[i] = stop; w.running[i] = 0; }
-    }
-    if (!running) return false;
-    // ---- next search direction
-    lds_load(w.chol + i * dd, M0, d);
-    const bool zero_sum = unwhitened_sum(M0, rn, d) == 0.0;
-    double zr = 0.0;
-    for (int e = threadIdx.x; e < dd; e += 64) {
-        double z = precon_entry(rn[e], zero_sum, w.w_ones + i * d, e, d);
-        M1[e] = z;
-        zr = __builtin_fma(z, rn[e], zr);
-    }
-    const double z_r_new = wave_sum(zr);
-    const double beta = z_r_new / z_r;
-    for (int e = threadIdx.x; e < dd; e += 64) w.delta_w[i * dd + e] = -M1[e] + beta * dl[e];
-    if (threadIdx.x == 0) {
-        sc[SC_E_PD] = beta * (e_Pd + alpha * d_Pd);
-        sc[SC_D_PD] = z_r_new + beta * beta * d_Pd;
-        sc[SC_Z_R] = z_r_new;
-        for (int k = 0; k < C; ++k) w.fcg_pe[i * C + k] = fpe[k] + alpha * fpd[k];
-    }
-    return true;
+    TcgVecs v{gw, w.eta_w + i * dd, w.heta_w + i * dd, w.r_w + i * dd, w.delta_w + i * dd, w.gc_w + i * dd, (int64_t)R * dd, sc,
+              w.fc + i * C, w.fcg_pe + i * C, w.stop + i, w.running + i};
+    SpdPrecon pc{M0, w.chol + i * dd, w.w_ones + i * d, d};
+    return tcg_step_core(v, dd, C, Hd, dl, M0, M1, M3, neq, delta_cons, theta, kappa, mininner, iter, pc);
 }
 
 // eta = L eta~ L^T, Heta = L Heta~ L^T, stop reasons
