@@ -35,6 +35,14 @@ class AcqParams(_c.Structure):
                 ("kxx", _c.c_double), ("best_f", _c.c_double), ("kind", _c.c_int), ("maximize", _c.c_int), ("out_sign", _c.c_double)]
 
 
+class SphereAcqParams(_c.Structure):
+    """gabo_sphere_acq_params of include/gabo_hip.h"""
+    _fields_ = [("train", _c.c_void_p), ("train_t", _c.c_void_p), ("alpha", _c.c_void_p), ("linv", _c.c_void_p), ("linv_t", _c.c_void_p),
+                ("n", _c.c_int64), ("dim", _c.c_int), ("beta", _c.c_double), ("flags", _c.c_int), ("mean", _c.c_double),
+                ("outputscale", _c.c_double), ("kxx", _c.c_double), ("best_f", _c.c_double), ("kind", _c.c_int), ("maximize", _c.c_int),
+                ("out_sign", _c.c_double)]
+
+
 SIGNATURES = {
     "gabo_version": (_I, []),
     "gabo_spd_ai_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
@@ -64,6 +72,11 @@ SIGNATURES = {
     "gabo_spd_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I64, _D, _D, _D, _D, _I64, _P, _P]),
     "gabo_spd_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _SZ, _I64, _I, _D, _D, _D, _I, _I, _D, _D, _D, _D, _I64, _P, _P]),
     "gabo_spd_matfun_backward": (_I, [_I, _P, _P, _P, _I64, _I, _P]),
+    "gabo_sphere_acq_eval": (_I, [_P, _P, _P, _P, _I64, _P]),
+    "gabo_sphere_tr_workspace_bytes": (_SZ, [_I64, _I, _I]),
+    "gabo_sphere_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _D, _D, _D, _I, _I, _P, _P]),
+    "gabo_sphere_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _D, _D, _D, _D, _I64, _P, _P]),
+    "gabo_sphere_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I64, _D, _D, _I, _I, _D, _D, _D, _D, _I64, _P]),
     "gabo_spd_logm_mandel_backward": (_I, [_P, _P, _P, _I64, _I, _P]),
     "gabo_frobenius_backward": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _D, _I, _D, _P]),
     "gabo_sphere_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _I64, _I, _P]),

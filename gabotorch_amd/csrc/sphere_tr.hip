@@ -1,0 +1,428 @@
+// Acquisition maximisation on the sphere S^(dim-1), R restarts, one wave per restart - the sphere twin of spd_acq.hip / spd_tr.hip:
+//   gabo_sphere_acq_eval    acquisition value and Euclidean gradient at R points in one launch: kernel strip
+//                           k_j = f(acos(clamp <x, X_j>)) (kernels_sphere.py:71-94,118-134, sphere_utils_torch.py:12-55), exact-GP
+//                           posterior + EI / posterior mean ([3P], as gp_acquisition.hip), gradient sum_j w_j f'(c_j) X_j
+//   gabo_sphere_tr_propose  truncated CG with the finite-difference Hessian (robust_trust_regions.py:417-570,
+//                           constrained_trust_regions.py:530-732, approximate_hessian.py:11-62) on pymanopt's Sphere geometry
+//                           ([3P], SURVEY App. B: inner = dot, proj(x, u) = u - <x, u> x, retr = normalise(x + u),
+//                           transp(x1, x2, u) = proj(x2, u)), then the proposal and the acquisition at the proposal
+//   gabo_sphere_tr_update   rho test and state update (robust_trust_regions.py:236-330)
+//   gabo_sphere_tr_solve    the whole solve in one launch when there are no constraints
+// The scalar logic of the tCG iteration is tcg_step_core of spd_tcg_body.hpp (shared with the SPD kernels).
+#include "spd_tcg_body.hpp"
+
+namespace gabo {
+
+using SphAcq = gabo_sphere_acq_params;
+
+struct SphWs {
+    double *g, *eta, *heta, *r, *delta, *x_fd, *eg_fd, *x_prop, *eg_prop, *gc, *scal, *fc, *fcg_pe, *val_fd, *fx_prop, *rhoden;
+    int *stop, *running;
+    size_t bytes;
+};
+
+static __host__ __device__ inline SphWs sph_layout(void* base, int64_t R, int dim, int C) {
+    SphWs w;
+    double* p = (double*)base;
+    const int64_t m = R * dim;
+    w.g = p;        p += m;
+    w.eta = p;      p += m;
+    w.heta = p;     p += m;
+    w.r = p;        p += m;
+    w.delta = p;    p += m;
+    w.x_fd = p;     p += m;
+    w.eg_fd = p;    p += m;
+    w.x_prop = p;   p += m;
+    w.eg_prop = p;  p += m;
+    w.gc = p;       p += (int64_t)C * m;
+    w.scal = p;     p += R * SC_COUNT;
+    w.fc = p;       p += R * (C > 0 ? C : 1);
+    w.fcg_pe = p;   p += R * (C > 0 ? C : 1);
+    w.val_fd = p;   p += R;
+    w.fx_prop = p;  p += R;
+    w.rhoden = p;   p += R;
+    int* q = (int*)p;
+    w.stop = q;     q += R;
+    w.running = q;  q += R;
+    w.bytes = (size_t)((char*)q - (char*)base);
+    return w;
+}
+
+// value and (grad != nullptr) Euclidean gradient of out_sign * acquisition at x (dim doubles, global or LDS).  dyn: 3 n doubles of LDS.
+static __device__ void sph_acq_eval(const double* __restrict__ x, const SphAcq& P, double* __restrict__ value_out,
+                                    double* __restrict__ grad_out, double* dyn) {
+    const int64_t n = P.n;
+    const int dim = P.dim;
+    double* ks = dyn;
+    double* kd = ks + n;      // f'(c_j), then the weights w_j
+    double* vv = kd + n;
+    const int lane = threadIdx.x;
+    const int mode = P.flags & GABO_OUT_MASK;
+    const double lo = -1.0 + 1e-15, hi = 1.0 - 1e-15;       // sphere_utils_torch.py:53
+    for (int64_t j = lane; j < n; j += 64) {
+        double ip = 0.0;
+        for (int k = 0; k < dim; ++k) ip = __builtin_fma(x[k], P.train_t[(int64_t)k * n + j], ip);
+        const bool inside = ip >= lo && ip <= hi;
+        const double c = ip < lo ? lo : (ip > hi ? hi : ip);
+        const double th = acos(c);
+        const double t1 = -1.0 / __builtin_sqrt((1.0 - c) * (1.0 + c));       // theta'(c)
+        double kj, dk;
+        if (mode == GABO_OUT_GAUSSIAN) {
+            kj = exp(-((th * th) * P.beta));
+            dk = kj * (-2.0 * P.beta * th * t1);
+        } else {
+            kj = exp(-(th * P.beta));
+            dk = kj * (-P.beta * t1);
+        }
+        ks[j] = P.outputscale * kj;
+        kd[j] = inside ? dk : 0.0;                                              // clamp passes no gradient outside
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int64_t j = lane; j < n; j += 64) part = __builtin_fma(ks[j], P.alpha[j], part);
+    const double mean = P.mean + wave_sum(part);
+    const double sgn = P.maximize ? 1.0 : -1.0;
+    double g_mean, g_var = 0.0;
+    if (P.kind == GABO_ACQ_POSTERIOR_MEAN) {
+        if (lane == 0) *value_out = P.out_sign * sgn * mean;
+        g_mean = sgn;
+    } else {
+        part = 0.0;
+        for (int64_t r = lane; r < n; r += 64) {
+            double a = 0.0;
+            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(P.linv_t[j * n + r], ks[j], a);
+            vv[r] = a;
+            part = __builtin_fma(a, a, part);
+        }
+        const double var = P.outputscale * P.kxx - wave_sum(part);
+        const bool clamped = !(var > 1e-9);
+        const double sigma = __builtin_sqrt(clamped ? 1e-9 : var);
+        const double u = sgn * (mean - P.best_f) / sigma;
+        const double pdf = exp(-0.5 * u * u) * 0.3989422804014327;
+        const double cdf = 0.5 * (1.0 + erf(u * 0.7071067811865476));
+        if (lane == 0) *value_out = P.out_sign * sigma * (pdf + u * cdf);
+        g_mean = sgn * cdf;
+        g_var = clamped ? 0.0 : 0.5 * pdf / sigma;
+    }
+    if (grad_out == nullptr) return;
+    __syncthreads();
+    for (int64_t j = lane; j < n; j += 64) {
+        double ws = 0.0;
+        if (P.kind != GABO_ACQ_POSTERIOR_MEAN)
+            for (int64_t r = j; r < n; ++r) ws = __builtin_fma(P.linv[r * n + j], vv[r], ws);
+        const double gk = P.out_sign * P.outputscale * (g_mean * P.alpha[j] - 2.0 * g_var * ws);
+        kd[j] = gk * kd[j];                                                    // w_j = d/dc_j
+    }
+    __syncthreads();
+    for (int k = lane; k < dim; k += 64) {
+        double a = 0.0;
+        for (int64_t j = 0; j < n; ++j) a = __builtin_fma(kd[j], P.train[j * dim + k], a);
+        grad_out[k] = a;
+    }
+}
+
+// preconditioner of manifold_optimize.py:190-193 in ambient coordinates
+struct SphPrecon {
+    int dim;
+    __device__ bool zero_sum(const double* rn) const {
+        double s = 0.0;
+        for (int e = threadIdx.x; e < dim; e += 64) s += rn[e];
+        return wave_sum(s) == 0.0;
+    }
+    __device__ double entry(double r, bool zs, int) const { return zs ? r + 1e-30 : r; }
+};
+
+static __device__ __forceinline__ double dotg(const double* a, const double* b, int n) {
+    double s = 0.0;
+    for (int e = threadIdx.x; e < n; e += 64) s = __builtin_fma(a[e], b[e], s);
+    return wave_sum(s);
+}
+
+// tCG + proposal + acquisition at the proposal for restart i.  lds: 6 dim doubles; dyn: 3 n doubles.
+static __device__ void sph_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta_tr,
+                                        const double* __restrict__ gc, const double* __restrict__ fc, const SphAcq& P, const SphWs& w,
+                                        int64_t i, int64_t R, int C, int neq, double delta_cons, double theta, double kappa,
+                                        int mininner, int maxinner, double* lds, double* dyn) {
+    const int dim = P.dim;
+    double* Hd = lds;
+    double* dl = Hd + dim;
+    double* s0 = dl + dim;
+    double* s1 = s0 + dim;
+    double* s2 = s1 + dim;
+    double* xs = s2 + dim;       // x staged in LDS (read by every lane)
+    double* gi = w.g + i * dim;
+    double* eta = w.eta + i * dim;
+    double* heta = w.heta + i * dim;
+    double* rr = w.r + i * dim;
+    double* delta = w.delta + i * dim;
+    double* sc = w.scal + i * SC_COUNT;
+    SphPrecon pc{dim};
+    // ---- begin (robust_trust_regions.py:430-470)
+    for (int e = threadIdx.x; e < dim; e += 64) {
+        xs[e] = x[e];
+        s2[e] = g[e];
+        gi[e] = g[e];
+        rr[e] = g[e];
+        eta[e] = 0.0;
+        heta[e] = 0.0;
+    }
+    for (int k = 0; k < C; ++k)
+        for (int e = threadIdx.x; e < dim; e += 64) w.gc[((int64_t)k * R + i) * dim + e] = gc[((int64_t)k * R + i) * dim + e];
+    __syncthreads();
+    const double r2 = dotg(s2, s2, dim);
+    const bool zs = pc.zero_sum(s2);
+    double zr = 0.0;
+    for (int e = threadIdx.x; e < dim; e += 64) {
+        const double z = pc.entry(s2[e], zs, e);
+        delta[e] = -z;
+        zr = __builtin_fma(z, s2[e], zr);
+    }
+    zr = wave_sum(zr);
+    if (threadIdx.x == 0) {
+        sc[SC_DELTA] = delta_tr;
+        sc[SC_E_PE] = 0.0;
+        sc[SC_E_PD] = 0.0;
+        sc[SC_D_PD] = zr;
+        sc[SC_Z_R] = zr;
+        sc[SC_MODEL] = 0.0;
+        sc[SC_NORM_R0] = __builtin_sqrt(r2 > 0.0 ? r2 : 0.0);
+        w.stop[i] = TCG_MAX_INNER_ITER;
+        w.running[i] = 1;
+        for (int k = 0; k < C; ++k) { w.fc[i * C + k] = fc[i * C + k]; w.fcg_pe[i * C + k] = 0.0; }
+    }
+    __syncthreads();
+    TcgVecs v{gi, eta, heta, rr, delta, w.gc + i * dim, (int64_t)R * dim, sc, w.fc + i * C, w.fcg_pe + i * C, w.stop + i, w.running + i};
+    double* xfd = w.x_fd + i * dim;
+    double* egfd = w.eg_fd + i * dim;
+    for (int it = 0; it < maxinner; ++it) {
+        // FD point (approximate_hessian.py:30-47): c = 2^-14 / |delta|, x1 = retr(x, c delta)
+        for (int e = threadIdx.x; e < dim; e += 64) dl[e] = delta[e];
+        __syncthreads();
+        const double nrm = __builtin_sqrt(dotg(dl, dl, dim));
+        const bool tiny = nrm < 1e-15;
+        const double c = 0.0001220703125 / (tiny ? 1.0 : nrm);
+        double yy = 0.0;
+        for (int e = threadIdx.x; e < dim; e += 64) { const double y = xs[e] + c * dl[e]; s0[e] = y; yy = __builtin_fma(y, y, yy); }
+        const double inv = 1.0 / __builtin_sqrt(wave_sum(yy));
+        for (int e = threadIdx.x; e < dim; e += 64) { s0[e] *= inv; xfd[e] = s0[e]; }
+        __syncthreads();
+        sph_acq_eval(s0, P, w.val_fd + i, egfd, dyn);
+        __syncthreads();
+        // Hd = transp(x1 -> x, proj_x1(eg1)) / c - g / c
+        const double a1 = dotg(s0, egfd, dim);
+        for (int e = threadIdx.x; e < dim; e += 64) s1[e] = egfd[e] - a1 * s0[e];
+        __syncthreads();
+        const double a0 = dotg(xs, s1, dim);
+        for (int e = threadIdx.x; e < dim; e += 64) Hd[e] = tiny ? 0.0 : (s1[e] - a0 * xs[e]) / c - gi[e] / c;
+        __syncthreads();
+        const bool running = tcg_step_core(v, dim, C, Hd, dl, s0, s1, s2, neq, delta_cons, theta, kappa, mininner, it, pc);
+        __syncthreads();
+        if (!running) break;
+    }
+    // ---- proposal and model decrease
+    const double ge = dotg(gi, eta, dim);
+    const double ehe = dotg(eta, heta, dim);
+    double yy = 0.0;
+    for (int e = threadIdx.x; e < dim; e += 64) { const double y = xs[e] + eta[e]; s0[e] = y; yy = __builtin_fma(y, y, yy); }
+    const double inv = 1.0 / __builtin_sqrt(wave_sum(yy));
+    double* xp = w.x_prop + i * dim;
+    for (int e = threadIdx.x; e < dim; e += 64) { s0[e] *= inv; xp[e] = s0[e]; }
+    if (threadIdx.x == 0) w.rhoden[i] = -ge - 0.5 * ehe;
+    __syncthreads();
+    sph_acq_eval(s0, P, w.fx_prop + i, w.eg_prop + i * dim, dyn);
+}
+
+static __device__ bool sph_update_body(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g, double* __restrict__ ng,
+                                       double* __restrict__ delta_tr, int64_t* __restrict__ iters, bool inval, const SphWs& w, int64_t i,
+                                       int dim, int C, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
+                                       int64_t maxiter) {
+    const double fx0 = *fx;
+    const double fxp = inval ? __builtin_inf() : w.fx_prop[i];
+    const double rho_reg = (__builtin_fabs(fx0) > 1.0 ? __builtin_fabs(fx0) : 1.0) * 2.220446049250313e-16 * rho_regularization;
+    const double rhonum = (fx0 - fxp) + rho_reg;
+    const double rhoden = w.rhoden[i] + rho_reg;
+    const bool model_decreased = rhoden >= 0.0;
+    const double rho = rhoden == 0.0 ? __builtin_nan("") : rhonum / rhoden;
+    const bool shrink = (rho < 0.25) || !model_decreased || (rho != rho) || inval;
+    const int stop_inner = w.stop[i];
+    const bool boundary = stop_inner == TCG_NEGATIVE_CURVATURE || stop_inner == TCG_EXCEEDED_TR ||
+                          (C > 0 && stop_inner == TCG_REACHED_CONSTRAINTS);
+    const bool grow = !shrink && rho > 0.75 && boundary;
+    const double D0 = *delta_tr;
+    const double Dn = shrink ? D0 / 4 : (grow ? (2 * D0 < delta_bar ? 2 * D0 : delta_bar) : D0);
+    const bool accept = model_decreased && rho > rho_prime;
+    double ngi = *ng;
+    const int64_t it = *iters + 1;
+    __syncthreads();
+    if (accept) {
+        const double* xp = w.x_prop + i * dim;
+        const double* eg = w.eg_prop + i * dim;
+        const double a = dotg(xp, eg, dim);
+        double s = 0.0;
+        for (int e = threadIdx.x; e < dim; e += 64) {
+            const double gg = eg[e] - a * xp[e];                 // egrad2rgrad = proj
+            x[e] = xp[e];
+            g[e] = gg;
+            s = __builtin_fma(gg, gg, s);
+        }
+        ngi = __builtin_sqrt(wave_sum(s));
+    }
+    if (threadIdx.x == 0) {
+        *delta_tr = Dn;
+        if (accept) { *fx = fxp; *ng = ngi; }
+        *iters = it;
+    }
+    __syncthreads();
+    return !(ngi < mingradnorm || it >= maxiter);
+}
+
+__global__ __launch_bounds__(64) void sphere_acq_kernel(const double* __restrict__ x, SphAcq P, double* __restrict__ value,
+                                                        double* __restrict__ grad, int64_t R) {
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    double* xs = dyn + 3 * P.n;
+    const int64_t i = blockIdx.x;
+    for (int e = threadIdx.x; e < P.dim; e += 64) xs[e] = x[i * P.dim + e];
+    __syncthreads();
+    sph_acq_eval(xs, P, value + i, grad ? grad + i * P.dim : nullptr, dyn);
+}
+
+__global__ __launch_bounds__(64) void sphere_tr_propose_kernel(const double* __restrict__ x, const double* __restrict__ g,
+                                                               const double* __restrict__ delta_tr, const uint8_t* __restrict__ active,
+                                                               const double* __restrict__ gc, const double* __restrict__ fc, SphAcq P,
+                                                               void* wsbase, double* __restrict__ x_prop, int64_t R, int C, int neq,
+                                                               double delta_cons, double theta, double kappa, int mininner, int maxinner,
+                                                               int* __restrict__ any_active) {
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int64_t i = blockIdx.x;
+    if (i == 0 && threadIdx.x == 0) *any_active = 0;
+    if (active[i] == 0) return;
+    SphWs w = sph_layout(wsbase, R, P.dim, C);
+    sph_propose_body(x + i * P.dim, g + i * P.dim, delta_tr[i], gc, fc, P, w, i, R, C, neq, delta_cons, theta, kappa, mininner, maxinner,
+                     dyn + 3 * P.n, dyn);
+    __syncthreads();
+    for (int e = threadIdx.x; e < P.dim; e += 64) x_prop[i * P.dim + e] = w.x_prop[i * P.dim + e];
+}
+
+__global__ __launch_bounds__(64) void sphere_tr_update_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
+                                                              double* __restrict__ ng, double* __restrict__ delta_tr,
+                                                              uint8_t* __restrict__ active, int64_t* __restrict__ iters,
+                                                              const uint8_t* __restrict__ invalid, void* wsbase, int64_t R, int dim, int C,
+                                                              double delta_bar, double rho_prime, double rho_regularization,
+                                                              double mingradnorm, int64_t maxiter, int* __restrict__ any_active) {
+    const int64_t i = blockIdx.x;
+    if (active[i] == 0) return;
+    SphWs w = sph_layout(wsbase, R, dim, C);
+    const bool inval = invalid != nullptr && invalid[i] != 0;
+    const bool still = sph_update_body(x + i * dim, fx + i, g + i * dim, ng + i, delta_tr + i, iters + i, inval, w, i, dim, C, delta_bar,
+                                       rho_prime, rho_regularization, mingradnorm, maxiter);
+    if (threadIdx.x == 0) {
+        if (!still) active[i] = 0;
+        else atomicOr(any_active, 1);
+    }
+}
+
+__global__ __launch_bounds__(64) void sphere_tr_solve_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
+                                                             double* __restrict__ ng, double* __restrict__ delta_tr,
+                                                             uint8_t* __restrict__ active, int64_t* __restrict__ iters, SphAcq P,
+                                                             void* wsbase, int64_t R, double theta, double kappa, int mininner,
+                                                             int maxinner, double delta_bar, double rho_prime, double rho_regularization,
+                                                             double mingradnorm, int64_t maxiter) {
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int64_t i = blockIdx.x;
+    if (active[i] == 0) return;
+    SphWs w = sph_layout(wsbase, R, P.dim, 0);
+    for (;;) {
+        sph_propose_body(x + i * P.dim, g + i * P.dim, delta_tr[i], nullptr, nullptr, P, w, i, R, 0, 0, 1e-6, theta, kappa, mininner,
+                         maxinner, dyn + 3 * P.n, dyn);
+        __syncthreads();
+        const bool still = sph_update_body(x + i * P.dim, fx + i, g + i * P.dim, ng + i, delta_tr + i, iters + i, false, w, i, P.dim, 0,
+                                           delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter);
+        if (!still) break;
+    }
+    if (threadIdx.x == 0) active[i] = 0;
+}
+
+static int sph_acq_ok(const SphAcq* a) {
+    if (!a || a->n < 1 || a->n > 4096 || a->dim < 2 || a->dim > 512 || !a->train || !a->train_t || !a->alpha) return GABO_ERR_ARG;
+    const int out = a->flags & GABO_OUT_MASK;
+    if ((a->flags & ~GABO_OUT_MASK) || (out != GABO_OUT_GAUSSIAN && out != GABO_OUT_LAPLACE)) return GABO_ERR_ARG;
+    if (a->kind != GABO_ACQ_EXPECTED_IMPROVEMENT && a->kind != GABO_ACQ_POSTERIOR_MEAN) return GABO_ERR_ARG;
+    if (a->kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!a->linv || !a->linv_t)) return GABO_ERR_ARG;
+    if ((size_t)(3 * a->n + 6 * a->dim) * sizeof(double) > 150 * 1024) return GABO_ERR_ARG;
+    return GABO_OK;
+}
+
+}  // namespace gabo
+
+extern "C" {
+
+int gabo_sphere_acq_eval(const double* x, const gabo_sphere_acq_params* acq, double* value, double* grad, int64_t r,
+                         gabo_stream_t stream) {
+    int rc = gabo::sph_acq_ok(acq);
+    if (rc != GABO_OK) return rc;
+    if (r < 0 || r > 0x7fffffffLL) return GABO_ERR_ARG;
+    if (r == 0) return GABO_OK;
+    if (!x || !value) return GABO_ERR_ARG;
+    size_t lds = (size_t)(3 * acq->n + acq->dim) * sizeof(double);
+    hipLaunchKernelGGL(gabo::sphere_acq_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, *acq, value, grad, r);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+size_t gabo_sphere_tr_workspace_bytes(int64_t r, int dim, int n_constraints) {
+    if (r < 0 || dim < 1 || n_constraints < 0) return 0;
+    return gabo::sph_layout(nullptr, r, dim, n_constraints).bytes;
+}
+
+int gabo_sphere_tr_propose(const double* x, const double* grad, const double* trust_radius, const uint8_t* active,
+                           const double* cons_grads, const double* cons_values, const gabo_sphere_acq_params* acq, void* workspace,
+                           size_t workspace_bytes, double* x_prop, int64_t r, int n_constraints, int n_equalities, double delta_cons,
+                           double theta, double kappa, int mininner, int maxinner, int* any_active, gabo_stream_t stream) {
+    int rc = gabo::sph_acq_ok(acq);
+    if (rc != GABO_OK) return rc;
+    if (r < 0 || r > 0x7fffffffLL || n_constraints < 0 || n_constraints > gabo::kMaxCons || n_equalities < 0 ||
+        n_equalities > n_constraints || maxinner < 1)
+        return GABO_ERR_ARG;
+    if (r == 0) return GABO_OK;
+    if (!x || !grad || !trust_radius || !active || !workspace || !x_prop || !any_active ||
+        (n_constraints > 0 && (!cons_grads || !cons_values)))
+        return GABO_ERR_ARG;
+    if (workspace_bytes < gabo_sphere_tr_workspace_bytes(r, acq->dim, n_constraints)) return GABO_ERR_ARG;
+    size_t lds = (size_t)(3 * acq->n + 6 * acq->dim) * sizeof(double);
+    hipLaunchKernelGGL(gabo::sphere_tr_propose_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, grad, trust_radius, active,
+                       cons_grads, cons_values, *acq, workspace, x_prop, r, n_constraints, n_equalities, delta_cons, theta, kappa,
+                       mininner, maxinner, any_active);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_sphere_tr_update(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
+                          const uint8_t* invalid, void* workspace, int64_t r, int dim, int n_constraints, double delta_bar,
+                          double rho_prime, double rho_regularization, double mingradnorm, int64_t maxiter, int* any_active,
+                          gabo_stream_t stream) {
+    if (dim < 2 || dim > 512) return GABO_ERR_DIM;
+    if (r < 0 || r > 0x7fffffffLL || n_constraints < 0 || n_constraints > gabo::kMaxCons) return GABO_ERR_ARG;
+    if (r == 0) return GABO_OK;
+    if (!x || !fx || !grad || !grad_norm || !trust_radius || !active || !iters || !workspace || !any_active) return GABO_ERR_ARG;
+    hipLaunchKernelGGL(gabo::sphere_tr_update_kernel, dim3((unsigned)r), dim3(64), 0, (hipStream_t)stream, x, fx, grad, grad_norm,
+                       trust_radius, active, iters, invalid, workspace, r, dim, n_constraints, delta_bar, rho_prime, rho_regularization,
+                       mingradnorm, maxiter, any_active);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
+                         const gabo_sphere_acq_params* acq, void* workspace, size_t workspace_bytes, int64_t r, double theta, double kappa,
+                         int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
+                         int64_t maxiter, gabo_stream_t stream) {
+    int rc = gabo::sph_acq_ok(acq);
+    if (rc != GABO_OK) return rc;
+    if (r < 0 || r > 0x7fffffffLL || maxinner < 1 || maxiter < 1) return GABO_ERR_ARG;
+    if (r == 0) return GABO_OK;
+    if (!x || !fx || !grad || !grad_norm || !trust_radius || !active || !iters || !workspace) return GABO_ERR_ARG;
+    if (workspace_bytes < gabo_sphere_tr_workspace_bytes(r, acq->dim, 0)) return GABO_ERR_ARG;
+    size_t lds = (size_t)(3 * acq->n + 6 * acq->dim) * sizeof(double);
+    hipLaunchKernelGGL(gabo::sphere_tr_solve_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, fx, grad, grad_norm,
+                       trust_radius, active, iters, *acq, workspace, r, theta, kappa, mininner, maxinner, delta_bar, rho_prime,
+                       rho_regularization, mingradnorm, maxiter);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+}  // extern "C"

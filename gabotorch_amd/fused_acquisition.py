@@ -50,8 +50,13 @@ class FusedAcquisition:
             d_spd = ops._mandel_dim(self.train.shape[-1])
             self.single_launch = (d_spd <= _lib.GABO_SPD_REG_MAX_DIM
                                   and self.train.shape[0] <= _lib.load().gabo_spd_acq_max_train(d_spd))
+        if family == "sphere":
+            # one launch per evaluation for the sphere kernels too (csrc/sphere_tr.hip); needs the training set in both layouts
+            n_tr, dim_tr = self.train.shape
+            self.single_launch = (3 * n_tr + 6 * dim_tr) * 8 <= 150 * 1024 and n_tr <= 4096 and 2 <= dim_tr <= 512
+            self.train_t = self.train.t().contiguous() if self.single_launch else None
         self.metric = {"ai": _lib.GABO_METRIC_AFFINE_INVARIANT, "le": _lib.GABO_METRIC_LOG_EUCLIDEAN, "frob": _lib.GABO_METRIC_FROBENIUS}[flavour]
-        self.train_factors = ops.spd_acq_prepare_train(self.train) if self.single_launch else None
+        self.train_factors = ops.spd_acq_prepare_train(self.train) if (self.single_launch and family == "spd") else None
         if family == "spd" and flavour != "ai":
             # ||0 + 1e-15||_F^2 = d^2 1e-30 (spd_utils_torch.py:156): k(x, x) = 1 to the last bit; logm of the training set once
             self.kxx = 1.0
@@ -154,6 +159,12 @@ class FusedAcquisition:
         g = ops.frobenius_backward(feat, self.train_feat, gk, self.beta, self.mode, wrt=1)
         return ops.spd_logm_mandel_backward(pts, g) if self.flavour == "le" else g
 
+    def sphere_acq_params(self):
+        """The surrogate as the gabo_sphere_acq_params struct of the C ABI."""
+        return _lib.SphereAcqParams(self.train.data_ptr(), self.train_t.data_ptr(), self.alpha.data_ptr(), self.linv.data_ptr(),
+                                    self.linv_t.data_ptr(), self.train.shape[0], self.train.shape[1], self.beta, int(self.mode), self.mean,
+                                    self.outputscale, self.kxx, self.best_f, int(self.kind), 1 if self.maximize else 0, -1.0)
+
     def acq_params(self):
         """The surrogate as the gabo_spd_acq_params struct of the C ABI (single-launch path only)."""
         return _lib.AcqParams(self.train_factors.data_ptr(), self.alpha.data_ptr(), self.linv.data_ptr(), self.linv_t.data_ptr(),
@@ -166,6 +177,8 @@ class FusedAcquisition:
                                 active_ptr=active_ptr, out=out)
 
     def cost(self, x):
+        if self.single_launch and self.family == "sphere":
+            return ops.sphere_acq_eval(x.detach(), self.sphere_acq_params(), need_grad=False)[0]
         if self.single_launch:
             return self._single(ops.matrix_to_mandel(x.detach()) if self.matrix_input else x.detach(), False)[0]
         _, ks, _ = self._strip(x.detach())
@@ -174,6 +187,8 @@ class FusedAcquisition:
         return val
 
     def cost_egrad(self, x):
+        if self.single_launch and self.family == "sphere":
+            return ops.sphere_acq_eval(x.detach(), self.sphere_acq_params(), need_grad=True)
         if self.single_launch:
             val, g = self._single(ops.matrix_to_mandel(x.detach()) if self.matrix_input else x.detach(), True)
             return val, (ops.mandel_to_matrix(g) if self.matrix_input else g)

@@ -271,7 +271,8 @@ class BatchedTrustRegions:
         cons = eqs + ineqs
         ncons, neq = len(cons), len(eqs)
         graphs = bool(getattr(problem, "use_hip_graphs", False))
-        T = ops.SpdTcg(R, d, ncons, dev)
+        sphere = fused.family == "sphere"
+        T = None if sphere else ops.SpdTcg(R, d, ncons, dev)
         val_buf = torch.zeros(R, dtype=dt, device=dev)
         eg_buf = torch.zeros(R, d * (d + 1) // 2, dtype=dt, device=dev)
         eps = torch.finfo(dt).eps
@@ -353,7 +354,10 @@ class BatchedTrustRegions:
         # d <= 12: the two parts are ONE launch each (csrc/spd_tr.hip: every wave runs its restart's whole tCG loop, proposal and
         # acquisition evaluations by itself)
         if getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True):
-            TR = ops.SpdTr(R, d, ncons, fused.acq_params(), fused.train.shape[0], dev)
+            if sphere:
+                TR = ops.SphereTr(R, d, ncons, fused.sphere_acq_params(), dev)
+            else:
+                TR = ops.SpdTr(R, d, ncons, fused.acq_params(), fused.train.shape[0], dev)
             S.active_u8 = S.active.view(torch.uint8)
             inv_u8 = invalid_buf.view(torch.uint8)
 
@@ -371,8 +375,9 @@ class BatchedTrustRegions:
             # examples): the whole solve is ONE launch, every wave iterating its restart to the end
             from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint
             builtins = [builtin_constraint(c) for c in cons]
-            if (d <= 8 and neq == 0 and all(b is not None for b in builtins) and fused.metric != _lib_frobenius()
-                    and getattr(problem, "device_solve", True) and self.maxtime >= 1000):
+            solve_ok = (ncons == 0) if sphere else (d <= 8 and neq == 0 and all(b is not None for b in builtins)
+                                                    and fused.metric != _lib_frobenius())
+            if solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000:
                 TR.solve(S.x, S.fx, S.g, S.ng, S.Delta, S.active_u8, S.iters, [b[0] for b in builtins], [b[1] for b in builtins], strict,
                           Delta_cons, self.theta, self.kappa, mininner, maxinner, Delta_bar, self.rho_prime, self.rho_regularization,
                           self.mingradnorm, self.maxiter)
@@ -443,11 +448,15 @@ class BatchedTrustRegions:
     @staticmethod
     def _device_tcg_applies(problem, x, ncons):
         """SPD manifold + fused acquisition chain + FD Hessian + the reference preconditioner: the whole tCG runs in HIP kernels."""
-        from ..manifolds import PositiveDefinite
+        from ..manifolds import PositiveDefinite, Sphere
         fused = getattr(problem, "fused", None)
-        return (fused is not None and fused.family == "spd" and fused.matrix_input and problem.approx_hessian and x.is_cuda
-                and isinstance(problem.manifold, PositiveDefinite) and getattr(problem, "reference_precon", False)
-                and getattr(problem, "device_tcg", True) and ncons <= 8 and x.shape[-1] <= 32 and x.dtype == torch.float64)
+        if (fused is None or not problem.approx_hessian or not x.is_cuda or not getattr(problem, "reference_precon", False)
+                or not getattr(problem, "device_tcg", True) or ncons > 8 or x.dtype != torch.float64):
+            return False
+        if fused.family == "sphere":       # csrc/sphere_tr.hip: propose / update / solve kernels only (no separate-launch tCG)
+            return (isinstance(problem.manifold, Sphere) and fused.single_launch and x.dim() == 2
+                    and getattr(problem, "device_iteration", True))
+        return fused.family == "spd" and fused.matrix_input and isinstance(problem.manifold, PositiveDefinite) and x.shape[-1] <= 32
 
     class _TcgState:
         """All tCG quantities of the R restarts as persistent tensors updated IN PLACE, so that one iteration is a fixed sequence

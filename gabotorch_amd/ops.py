@@ -786,6 +786,64 @@ class SpdTr:
                                                    int(maxiter), self.any_active.data_ptr(), _stream_ptr(self.dev)), "gabo_spd_tr_update")
 
 
+def sphere_acq_eval(x, acq_params, need_grad=True):
+    """Single-launch acquisition value (R) and Euclidean gradient (R x dim) at points of the sphere; acq_params: _lib.SphereAcqParams."""
+    import ctypes
+    lib = _lib.load()
+    xx = x.contiguous()
+    dev = xx.device
+    r = xx.shape[0]
+    value = torch.empty(r, dtype=torch.float64, device=dev)
+    grad = torch.empty_like(xx) if need_grad else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_sphere_acq_eval(xx.data_ptr(), ctypes.byref(acq_params), value.data_ptr(), None if grad is None else grad.data_ptr(),
+                                            r, _stream_ptr(dev)), "gabo_sphere_acq_eval")
+    return value, grad
+
+
+class SphereTr:
+    """Device-resident trust-region iteration on the sphere (gabo_sphere_tr_*): same interface as SpdTr."""
+
+    def __init__(self, r, dim, n_constraints, acq_params, device):
+        import ctypes
+        self.lib = _lib.load()
+        self.r, self.d, self.c, self.dev = int(r), int(dim), int(n_constraints), device
+        self.acq = acq_params
+        self.acq_ref = ctypes.byref(self.acq)
+        self.wsb = self.lib.gabo_sphere_tr_workspace_bytes(self.r, self.d, self.c)
+        self.ws = torch.zeros(self.wsb // 8 + 1, dtype=torch.float64, device=device)
+        self.x_prop = torch.zeros(self.r, dim, dtype=torch.float64, device=device)
+        self.any_active = torch.ones(1, dtype=torch.int32, device=device)
+
+    def propose(self, x, g, Delta, active, gc, fc, neq, delta_cons, theta, kappa, mininner, maxinner):
+        ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_sphere_tr_propose(x.data_ptr(), g.data_ptr(), Delta.data_ptr(), active.data_ptr(), ptr(gc), ptr(fc),
+                                                       self.acq_ref, self.ws.data_ptr(), self.wsb, self.x_prop.data_ptr(), self.r, self.c,
+                                                       int(neq), float(delta_cons), float(theta), float(kappa), int(mininner),
+                                                       int(maxinner), self.any_active.data_ptr(), _stream_ptr(self.dev)),
+                       "gabo_sphere_tr_propose")
+        return self.x_prop
+
+    def update(self, x, fx, g, ng, Delta, active, iters, invalid, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter):
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_sphere_tr_update(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
+                                                      active.data_ptr(), iters.data_ptr(), None if invalid is None else invalid.data_ptr(),
+                                                      self.ws.data_ptr(), self.r, self.d, self.c, float(delta_bar), float(rho_prime),
+                                                      float(rho_regularization), float(mingradnorm), int(maxiter),
+                                                      self.any_active.data_ptr(), _stream_ptr(self.dev)), "gabo_sphere_tr_update")
+
+    def solve(self, x, fx, g, ng, Delta, active, iters, kinds, bounds, strict, delta_cons, theta, kappa, mininner, maxinner, delta_bar,
+              rho_prime, rho_regularization, mingradnorm, maxiter):
+        assert not kinds, "the sphere has no built-in constraints"
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_sphere_tr_solve(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
+                                                     active.data_ptr(), iters.data_ptr(), self.acq_ref, self.ws.data_ptr(), self.wsb, self.r,
+                                                     float(theta), float(kappa), int(mininner), int(maxinner), float(delta_bar),
+                                                     float(rho_prime), float(rho_regularization), float(mingradnorm), int(maxiter),
+                                                     _stream_ptr(self.dev)), "gabo_sphere_tr_solve")
+
+
 def sphere_manifold_op(op, x, u, v=None, w=None):
     """Batched sphere-manifold operation (one of _lib.GABO_SPH_*) on (..., dim) tensors."""
     lib = _lib.load()

@@ -308,6 +308,44 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
                       int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
                       int64_t maxiter, int* status, gabo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Acquisition maximisation on the sphere S^(dim-1) (the sphere twins of gabo_spd_acq_eval / gabo_spd_tr_*): kernel strip of
+ * SphereGaussianKernel / SphereLaplaceKernel (kernels_sphere.py:71-94,118-134) + exact-GP posterior + EI / posterior mean + gradient
+ * in one launch, and the trust-region iteration of robust_trust_regions.py / constrained_trust_regions.py with the finite-difference
+ * Hessian (approximate_hessian.py:11-62) on pymanopt's Sphere geometry, one wave per restart.  State arrays: x, grad r x dim
+ * (grad = Riemannian gradient), fx, grad_norm, trust_radius r; active r bytes; iters r int64; cons_grads n_constraints x r x dim
+ * (Riemannian gradients, equalities first), cons_values r x n_constraints.  gabo_sphere_tr_solve runs the whole solve in one launch
+ * when there are no constraints (constraints on the sphere are user callables). */
+typedef struct {
+    const double* train;     /* n x dim training points, row-major */
+    const double* train_t;   /* dim x n, the same points transposed (coalesced strip evaluation) */
+    const double* alpha;     /* n */
+    const double* linv;      /* n x n */
+    const double* linv_t;    /* n x n */
+    int64_t n;
+    int dim;
+    double beta;
+    int flags;               /* GABO_OUT_GAUSSIAN / GABO_OUT_LAPLACE */
+    double mean, outputscale, kxx, best_f;
+    int kind, maximize;
+    double out_sign;
+} gabo_sphere_acq_params;
+int gabo_sphere_acq_eval(const double* x, const gabo_sphere_acq_params* acq, double* value, double* grad, int64_t r,
+                         gabo_stream_t stream);
+size_t gabo_sphere_tr_workspace_bytes(int64_t r, int dim, int n_constraints);
+int gabo_sphere_tr_propose(const double* x, const double* grad, const double* trust_radius, const uint8_t* active,
+                           const double* cons_grads, const double* cons_values, const gabo_sphere_acq_params* acq, void* workspace,
+                           size_t workspace_bytes, double* x_prop, int64_t r, int n_constraints, int n_equalities, double delta_cons,
+                           double theta, double kappa, int mininner, int maxinner, int* any_active, gabo_stream_t stream);
+int gabo_sphere_tr_update(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
+                          const uint8_t* invalid, void* workspace, int64_t r, int dim, int n_constraints, double delta_bar,
+                          double rho_prime, double rho_regularization, double mingradnorm, int64_t maxiter, int* any_active,
+                          gabo_stream_t stream);
+int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
+                         const gabo_sphere_acq_params* acq, void* workspace, size_t workspace_bytes, int64_t r, double theta, double kappa,
+                         int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
+                         int64_t maxiter, gabo_stream_t stream);
+
 /* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
  *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)
  *   GABO_SPH_RETR   out = (X+U)/|X+U|        [3P] Sphere.retr  (robust_trust_regions.py:228)

@@ -9,7 +9,7 @@ from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTru
 from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold
 
 
-def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrained=True, approx=True):
+def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrained=True, approx=True, device_tcg=True, maxiter=50, capture=False):
     rng = np.random.default_rng(3)
     X = rng.standard_normal((n_train, dim)); X /= np.linalg.norm(X, axis=1, keepdims=True)
     y = np.arccos(np.clip(X[:, 0], -1, 1)) ** 2 + 0.05 * rng.standard_normal(n_train)
@@ -18,19 +18,25 @@ def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrain
     man = manifolds.Sphere(dim)
     np.random.seed(5); torch.manual_seed(5)
     cons = [lambda x: x[..., 0] - 0.1] if constrained else None
-    solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=50)
+    solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=maxiter)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=R, raw_samples=raw, bounds=None,
-                                   options={"device": "cuda:0", "hip_graphs": graphs, "batched_rand": True, "fused_acquisition": fused},
+                                   options={"device": "cuda:0", "hip_graphs": graphs, "batched_rand": True, "fused_acquisition": fused, "device_tcg": device_tcg, "capture_constraints": capture},
                                    inequality_constraints=cons, approx_hessian=approx)
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, float(acq(best[None]).item()), solver.log["iterations"]
+    dt = time.perf_counter() - t0
+    return dt, float(acq(best[None]).item()), solver.log["iterations"], solver.log
 
 
 if __name__ == "__main__":
     ops.set_error_checking(False)
-    for label, kw in (("generic autograd, eager", dict(fused=False)), ("fused chain, eager", dict()), ("fused chain, hipGraphs", dict(graphs=True)),
+    for label, kw in (("generic autograd, eager", dict(fused=False)), ("fused chain + torch tCG, eager", dict(device_tcg=False)),
+                      ("fused chain + torch tCG, hipGraphs", dict(device_tcg=False, graphs=True)),
+                      ("device-resident iteration (opaque constraint lambda), eager", dict()),
+                      ("device-resident iteration, hipGraphs incl. the constraint", dict(graphs=True, capture=True)),
+                      ("unconstrained, FD Hessian: single-launch solve", dict(constrained=False)),
+                      ("unconstrained, FD Hessian: torch tCG + hipGraphs", dict(constrained=False, device_tcg=False, graphs=True)),
                       ("exact Hessian (autograd double backward), unconstrained", dict(approx=False, constrained=False, fused=False))):
         run(**kw)
-        dt, val, its = run(**kw)
+        dt, val, its, _ = run(**kw)
         print(f"sphere sweep S^9 512 restarts {label}: {dt*1e3:.1f} ms  EI*={val:.6e}  TR iterations={its}")
