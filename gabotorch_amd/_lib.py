@@ -74,9 +74,9 @@ SIGNATURES = {
     "gabo_spd_matfun_backward": (_I, [_I, _P, _P, _P, _I64, _I, _P]),
     "gabo_sphere_acq_eval": (_I, [_P, _P, _P, _P, _I64, _P]),
     "gabo_sphere_tr_workspace_bytes": (_SZ, [_I64, _I, _I]),
-    "gabo_sphere_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _D, _D, _D, _I, _I, _P, _P]),
+    "gabo_sphere_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _D, _D, _D, _I, _I, _I, _P, _P]),
     "gabo_sphere_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _D, _D, _D, _D, _I64, _P, _P]),
-    "gabo_sphere_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I64, _D, _D, _I, _I, _D, _D, _D, _D, _I64, _P]),
+    "gabo_sphere_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I64, _D, _D, _I, _I, _I, _D, _D, _D, _D, _I64, _P]),
     "gabo_spd_logm_mandel_backward": (_I, [_P, _P, _P, _I64, _I, _P]),
     "gabo_frobenius_backward": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _D, _I, _D, _P]),
     "gabo_sphere_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _I64, _I, _P]),

@@ -121,6 +121,136 @@ static __device__ void sph_acq_eval(const double* __restrict__ x, const SphAcq& 
     }
 }
 
+// Exact Euclidean Hessian-vector product of out_sign * acquisition at x along u (what double backward through the sphere kernel,
+// the GP posterior and EI gives the reference: pymanopt_addons/tools/autodiff/_pytorch.py:103-116), together with the gradient:
+//   c_j = <x, X_j>, s_j = <u, X_j>;  ks = os f(c), d = os f'(c) s;  q = K^-1 ks, qd = K^-1 d;  mu' = alpha.d, var' = -2 q.d
+//   G_j = A_mu alpha_j - 2 A_v q_j,  G'_j = (A_mumu mu' + A_muv var') alpha_j - 2 (A_muv mu' + A_vv var') q_j - 2 A_v qd_j
+//   egrad = sum_j G_j os f'(c_j) X_j,   ehess u = sum_j [G'_j os f'(c_j) + G_j os f''(c_j) s_j] X_j
+// dyn: 7 n doubles of LDS.
+static __device__ void sph_acq_hess(const double* __restrict__ x, const double* __restrict__ u, const SphAcq& P,
+                                    double* __restrict__ egrad_out, double* __restrict__ ehess_out, double* dyn) {
+    const int64_t n = P.n;
+    const int dim = P.dim;
+    double* ks = dyn;          // os f(c)
+    double* f1 = ks + n;       // os f'(c)  (0 outside the clamp)
+    double* f2 = f1 + n;       // os f''(c) (0 outside the clamp)
+    double* sj = f2 + n;       // <u, X_j>
+    double* vv = sj + n;       // scratch: L^-1 (.)
+    double* q = vv + n;        // K^-1 ks
+    double* qd = q + n;        // K^-1 d
+    const int lane = threadIdx.x;
+    const int mode = P.flags & GABO_OUT_MASK;
+    const double lo = -1.0 + 1e-15, hi = 1.0 - 1e-15;
+    for (int64_t j = lane; j < n; j += 64) {
+        double ip = 0.0, su = 0.0;
+        for (int k = 0; k < dim; ++k) {
+            const double xt = P.train_t[(int64_t)k * n + j];
+            ip = __builtin_fma(x[k], xt, ip);
+            su = __builtin_fma(u[k], xt, su);
+        }
+        const bool inside = ip >= lo && ip <= hi;
+        const double c = ip < lo ? lo : (ip > hi ? hi : ip);
+        const double th = acos(c);
+        const double om = (1.0 - c) * (1.0 + c);
+        const double t1 = -1.0 / __builtin_sqrt(om);
+        const double t2 = c * t1 / om;
+        double kj, d1, d2;
+        if (mode == GABO_OUT_GAUSSIAN) {
+            kj = exp(-((th * th) * P.beta));
+            const double a = -2.0 * P.beta * th * t1;
+            d1 = kj * a;
+            d2 = kj * (a * a - 2.0 * P.beta * (t1 * t1 + th * t2));
+        } else {
+            kj = exp(-(th * P.beta));
+            const double a = -P.beta * t1;
+            d1 = kj * a;
+            d2 = kj * (a * a - P.beta * t2);
+        }
+        ks[j] = P.outputscale * kj;
+        f1[j] = inside ? P.outputscale * d1 : 0.0;
+        f2[j] = inside ? P.outputscale * d2 : 0.0;
+        sj[j] = su;
+    }
+    __syncthreads();
+    const double sgn = P.maximize ? 1.0 : -1.0;
+    double A_mu, A_v = 0.0, A_mumu = 0.0, A_muv = 0.0, A_vv = 0.0, mud = 0.0, vard = 0.0;
+    double part = 0.0, pd = 0.0;
+    for (int64_t j = lane; j < n; j += 64) {
+        part = __builtin_fma(ks[j], P.alpha[j], part);
+        pd = __builtin_fma(f1[j] * sj[j], P.alpha[j], pd);
+    }
+    const double mean = P.mean + wave_sum(part);
+    mud = wave_sum(pd);
+    if (P.kind == GABO_ACQ_POSTERIOR_MEAN) {
+        A_mu = sgn;
+        for (int64_t j = lane; j < n; j += 64) { q[j] = 0.0; qd[j] = 0.0; }
+    } else {
+        // q = L^-T (L^-1 ks), qd = L^-T (L^-1 d)
+        double pv = 0.0;
+        for (int64_t r = lane; r < n; r += 64) {
+            double a = 0.0;
+            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(P.linv_t[j * n + r], ks[j], a);
+            vv[r] = a;
+            pv = __builtin_fma(a, a, pv);
+        }
+        const double var = P.outputscale * P.kxx - wave_sum(pv);
+        __syncthreads();
+        for (int64_t j = lane; j < n; j += 64) {
+            double a = 0.0;
+            for (int64_t r = j; r < n; ++r) a = __builtin_fma(P.linv[r * n + j], vv[r], a);
+            q[j] = a;
+        }
+        __syncthreads();
+        for (int64_t r = lane; r < n; r += 64) {
+            double a = 0.0;
+            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(P.linv_t[j * n + r], f1[j] * sj[j], a);
+            vv[r] = a;
+        }
+        __syncthreads();
+        double pq = 0.0;
+        for (int64_t j = lane; j < n; j += 64) {
+            double a = 0.0;
+            for (int64_t r = j; r < n; ++r) a = __builtin_fma(P.linv[r * n + j], vv[r], a);
+            qd[j] = a;
+            pq = __builtin_fma(q[j], f1[j] * sj[j], pq);
+        }
+        vard = -2.0 * wave_sum(pq);
+        const bool clamped = !(var > 1e-9);
+        const double sigma = __builtin_sqrt(clamped ? 1e-9 : var);
+        const double uu = sgn * (mean - P.best_f) / sigma;
+        const double pdf = exp(-0.5 * uu * uu) * 0.3989422804014327;
+        const double cdf = 0.5 * (1.0 + erf(uu * 0.7071067811865476));
+        A_mu = sgn * cdf;
+        A_mumu = pdf / sigma;                                  // d/dmu (s Phi(u)) = phi / sigma
+        if (!clamped) {
+            A_v = 0.5 * pdf / sigma;
+            A_muv = -sgn * pdf * uu / (2.0 * var);
+            A_vv = pdf * (uu * uu - 1.0) / (4.0 * sigma * sigma * sigma);
+        }
+    }
+    __syncthreads();
+    const double cm = A_mumu * mud + A_muv * vard;
+    const double cv = A_muv * mud + A_vv * vard;
+    // weights on X_j: wg_j (gradient) in ks, wh_j (Hessian-vector) in vv
+    for (int64_t j = lane; j < n; j += 64) {
+        const double G = A_mu * P.alpha[j] - 2.0 * A_v * q[j];
+        const double Gd = cm * P.alpha[j] - 2.0 * cv * q[j] - 2.0 * A_v * qd[j];
+        ks[j] = P.out_sign * G * f1[j];
+        vv[j] = P.out_sign * (Gd * f1[j] + G * f2[j] * sj[j]);
+    }
+    __syncthreads();
+    for (int k = lane; k < dim; k += 64) {
+        double a = 0.0, b = 0.0;
+        for (int64_t j = 0; j < n; ++j) {
+            const double xt = P.train[j * dim + k];
+            a = __builtin_fma(ks[j], xt, a);
+            b = __builtin_fma(vv[j], xt, b);
+        }
+        egrad_out[k] = a;
+        ehess_out[k] = b;
+    }
+}
+
 // preconditioner of manifold_optimize.py:190-193 in ambient coordinates
 struct SphPrecon {
     int dim;
@@ -142,7 +272,7 @@ static __device__ __forceinline__ double dotg(const double* a, const double* b, 
 static __device__ void sph_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta_tr,
                                         const double* __restrict__ gc, const double* __restrict__ fc, const SphAcq& P, const SphWs& w,
                                         int64_t i, int64_t R, int C, int neq, double delta_cons, double theta, double kappa,
-                                        int mininner, int maxinner, double* lds, double* dyn) {
+                                        int mininner, int maxinner, double* lds, double* dyn, int exact_hessian) {
     const int dim = P.dim;
     double* Hd = lds;
     double* dl = Hd + dim;
@@ -195,9 +325,22 @@ static __device__ void sph_propose_body(const double* __restrict__ x, const doub
     double* xfd = w.x_fd + i * dim;
     double* egfd = w.eg_fd + i * dim;
     for (int it = 0; it < maxinner; ++it) {
-        // FD point (approximate_hessian.py:30-47): c = 2^-14 / |delta|, x1 = retr(x, c delta)
         for (int e = threadIdx.x; e < dim; e += 64) dl[e] = delta[e];
         __syncthreads();
+        if (exact_hessian) {
+            // Riemannian Hessian ([3P] Sphere.ehess2rhess): proj_x(ehess delta) - <x, egrad> delta
+            sph_acq_hess(xs, dl, P, egfd, xfd, dyn);               // egfd <- egrad(x), xfd <- ehess(x) delta
+            __syncthreads();
+            const double xe = dotg(xs, egfd, dim);
+            const double xh = dotg(xs, xfd, dim);
+            for (int e = threadIdx.x; e < dim; e += 64) Hd[e] = (xfd[e] - xh * xs[e]) - xe * dl[e];
+            __syncthreads();
+            const bool running_e = tcg_step_core(v, dim, C, Hd, dl, s0, s1, s2, neq, delta_cons, theta, kappa, mininner, it, pc);
+            __syncthreads();
+            if (!running_e) break;
+            continue;
+        }
+        // FD point (approximate_hessian.py:30-47): c = 2^-14 / |delta|, x1 = retr(x, c delta)
         const double nrm = __builtin_sqrt(dotg(dl, dl, dim));
         const bool tiny = nrm < 1e-15;
         const double c = 0.0001220703125 / (tiny ? 1.0 : nrm);
@@ -291,14 +434,14 @@ __global__ __launch_bounds__(64) void sphere_tr_propose_kernel(const double* __r
                                                                const double* __restrict__ gc, const double* __restrict__ fc, SphAcq P,
                                                                void* wsbase, double* __restrict__ x_prop, int64_t R, int C, int neq,
                                                                double delta_cons, double theta, double kappa, int mininner, int maxinner,
-                                                               int* __restrict__ any_active) {
+                                                               int* __restrict__ any_active, int exact_hessian) {
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
     if (i == 0 && threadIdx.x == 0) *any_active = 0;
     if (active[i] == 0) return;
     SphWs w = sph_layout(wsbase, R, P.dim, C);
     sph_propose_body(x + i * P.dim, g + i * P.dim, delta_tr[i], gc, fc, P, w, i, R, C, neq, delta_cons, theta, kappa, mininner, maxinner,
-                     dyn + 3 * P.n, dyn);
+                     dyn + 7 * P.n, dyn, exact_hessian);
     __syncthreads();
     for (int e = threadIdx.x; e < P.dim; e += 64) x_prop[i * P.dim + e] = w.x_prop[i * P.dim + e];
 }
@@ -326,14 +469,14 @@ __global__ __launch_bounds__(64) void sphere_tr_solve_kernel(double* __restrict_
                                                              uint8_t* __restrict__ active, int64_t* __restrict__ iters, SphAcq P,
                                                              void* wsbase, int64_t R, double theta, double kappa, int mininner,
                                                              int maxinner, double delta_bar, double rho_prime, double rho_regularization,
-                                                             double mingradnorm, int64_t maxiter) {
+                                                             double mingradnorm, int64_t maxiter, int exact_hessian) {
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
     if (active[i] == 0) return;
     SphWs w = sph_layout(wsbase, R, P.dim, 0);
     for (;;) {
         sph_propose_body(x + i * P.dim, g + i * P.dim, delta_tr[i], nullptr, nullptr, P, w, i, R, 0, 0, 1e-6, theta, kappa, mininner,
-                         maxinner, dyn + 3 * P.n, dyn);
+                         maxinner, dyn + 7 * P.n, dyn, exact_hessian);
         __syncthreads();
         const bool still = sph_update_body(x + i * P.dim, fx + i, g + i * P.dim, ng + i, delta_tr + i, iters + i, false, w, i, P.dim, 0,
                                            delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter);
@@ -348,7 +491,7 @@ static int sph_acq_ok(const SphAcq* a) {
     if ((a->flags & ~GABO_OUT_MASK) || (out != GABO_OUT_GAUSSIAN && out != GABO_OUT_LAPLACE)) return GABO_ERR_ARG;
     if (a->kind != GABO_ACQ_EXPECTED_IMPROVEMENT && a->kind != GABO_ACQ_POSTERIOR_MEAN) return GABO_ERR_ARG;
     if (a->kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!a->linv || !a->linv_t)) return GABO_ERR_ARG;
-    if ((size_t)(3 * a->n + 6 * a->dim) * sizeof(double) > 150 * 1024) return GABO_ERR_ARG;
+    if ((size_t)(7 * a->n + 6 * a->dim) * sizeof(double) > 150 * 1024) return GABO_ERR_ARG;
     return GABO_OK;
 }
 
@@ -376,7 +519,7 @@ size_t gabo_sphere_tr_workspace_bytes(int64_t r, int dim, int n_constraints) {
 int gabo_sphere_tr_propose(const double* x, const double* grad, const double* trust_radius, const uint8_t* active,
                            const double* cons_grads, const double* cons_values, const gabo_sphere_acq_params* acq, void* workspace,
                            size_t workspace_bytes, double* x_prop, int64_t r, int n_constraints, int n_equalities, double delta_cons,
-                           double theta, double kappa, int mininner, int maxinner, int* any_active, gabo_stream_t stream) {
+                           double theta, double kappa, int mininner, int maxinner, int exact_hessian, int* any_active, gabo_stream_t stream) {
     int rc = gabo::sph_acq_ok(acq);
     if (rc != GABO_OK) return rc;
     if (r < 0 || r > 0x7fffffffLL || n_constraints < 0 || n_constraints > gabo::kMaxCons || n_equalities < 0 ||
@@ -387,10 +530,10 @@ int gabo_sphere_tr_propose(const double* x, const double* grad, const double* tr
         (n_constraints > 0 && (!cons_grads || !cons_values)))
         return GABO_ERR_ARG;
     if (workspace_bytes < gabo_sphere_tr_workspace_bytes(r, acq->dim, n_constraints)) return GABO_ERR_ARG;
-    size_t lds = (size_t)(3 * acq->n + 6 * acq->dim) * sizeof(double);
+    size_t lds = (size_t)(7 * acq->n + 6 * acq->dim) * sizeof(double);
     hipLaunchKernelGGL(gabo::sphere_tr_propose_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, grad, trust_radius, active,
                        cons_grads, cons_values, *acq, workspace, x_prop, r, n_constraints, n_equalities, delta_cons, theta, kappa,
-                       mininner, maxinner, any_active);
+                       mininner, maxinner, any_active, exact_hessian);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
@@ -410,18 +553,18 @@ int gabo_sphere_tr_update(double* x, double* fx, double* grad, double* grad_norm
 
 int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
                          const gabo_sphere_acq_params* acq, void* workspace, size_t workspace_bytes, int64_t r, double theta, double kappa,
-                         int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
-                         int64_t maxiter, gabo_stream_t stream) {
+                         int mininner, int maxinner, int exact_hessian, double delta_bar, double rho_prime, double rho_regularization,
+                         double mingradnorm, int64_t maxiter, gabo_stream_t stream) {
     int rc = gabo::sph_acq_ok(acq);
     if (rc != GABO_OK) return rc;
     if (r < 0 || r > 0x7fffffffLL || maxinner < 1 || maxiter < 1) return GABO_ERR_ARG;
     if (r == 0) return GABO_OK;
     if (!x || !fx || !grad || !grad_norm || !trust_radius || !active || !iters || !workspace) return GABO_ERR_ARG;
     if (workspace_bytes < gabo_sphere_tr_workspace_bytes(r, acq->dim, 0)) return GABO_ERR_ARG;
-    size_t lds = (size_t)(3 * acq->n + 6 * acq->dim) * sizeof(double);
+    size_t lds = (size_t)(7 * acq->n + 6 * acq->dim) * sizeof(double);
     hipLaunchKernelGGL(gabo::sphere_tr_solve_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, fx, grad, grad_norm,
                        trust_radius, active, iters, *acq, workspace, r, theta, kappa, mininner, maxinner, delta_bar, rho_prime,
-                       rho_regularization, mingradnorm, maxiter);
+                       rho_regularization, mingradnorm, maxiter, exact_hessian);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

@@ -53,7 +53,7 @@ class FusedAcquisition:
         if family == "sphere":
             # one launch per evaluation for the sphere kernels too (csrc/sphere_tr.hip); needs the training set in both layouts
             n_tr, dim_tr = self.train.shape
-            self.single_launch = (3 * n_tr + 6 * dim_tr) * 8 <= 150 * 1024 and n_tr <= 4096 and 2 <= dim_tr <= 512
+            self.single_launch = (7 * n_tr + 6 * dim_tr) * 8 <= 150 * 1024 and n_tr <= 4096 and 2 <= dim_tr <= 512
             self.train_t = self.train.t().contiguous() if self.single_launch else None
         self.metric = {"ai": _lib.GABO_METRIC_AFFINE_INVARIANT, "le": _lib.GABO_METRIC_LOG_EUCLIDEAN, "frob": _lib.GABO_METRIC_FROBENIUS}[flavour]
         self.train_factors = ops.spd_acq_prepare_train(self.train) if (self.single_launch and family == "spd") else None

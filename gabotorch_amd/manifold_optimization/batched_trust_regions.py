@@ -355,7 +355,7 @@ class BatchedTrustRegions:
         # acquisition evaluations by itself)
         if getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True):
             if sphere:
-                TR = ops.SphereTr(R, d, ncons, fused.sphere_acq_params(), dev)
+                TR = ops.SphereTr(R, d, ncons, fused.sphere_acq_params(), dev, exact_hessian=not problem.approx_hessian)
             else:
                 TR = ops.SpdTr(R, d, ncons, fused.acq_params(), fused.train.shape[0], dev)
             S.active_u8 = S.active.view(torch.uint8)
@@ -450,13 +450,14 @@ class BatchedTrustRegions:
         """SPD manifold + fused acquisition chain + FD Hessian + the reference preconditioner: the whole tCG runs in HIP kernels."""
         from ..manifolds import PositiveDefinite, Sphere
         fused = getattr(problem, "fused", None)
-        if (fused is None or not problem.approx_hessian or not x.is_cuda or not getattr(problem, "reference_precon", False)
+        if (fused is None or not x.is_cuda or not getattr(problem, "reference_precon", False)
                 or not getattr(problem, "device_tcg", True) or ncons > 8 or x.dtype != torch.float64):
             return False
-        if fused.family == "sphere":       # csrc/sphere_tr.hip: propose / update / solve kernels only (no separate-launch tCG)
+        if fused.family == "sphere":       # csrc/sphere_tr.hip: propose / update / solve kernels, FD or exact (closed-form) Hessian
             return (isinstance(problem.manifold, Sphere) and fused.single_launch and x.dim() == 2
                     and getattr(problem, "device_iteration", True))
-        return fused.family == "spd" and fused.matrix_input and isinstance(problem.manifold, PositiveDefinite) and x.shape[-1] <= 32
+        return (problem.approx_hessian and fused.family == "spd" and fused.matrix_input
+                and isinstance(problem.manifold, PositiveDefinite) and x.shape[-1] <= 32)
 
     class _TcgState:
         """All tCG quantities of the R restarts as persistent tensors updated IN PLACE, so that one iteration is a fixed sequence

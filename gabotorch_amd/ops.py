@@ -804,10 +804,11 @@ def sphere_acq_eval(x, acq_params, need_grad=True):
 class SphereTr:
     """Device-resident trust-region iteration on the sphere (gabo_sphere_tr_*): same interface as SpdTr."""
 
-    def __init__(self, r, dim, n_constraints, acq_params, device):
+    def __init__(self, r, dim, n_constraints, acq_params, device, exact_hessian=False):
         import ctypes
         self.lib = _lib.load()
         self.r, self.d, self.c, self.dev = int(r), int(dim), int(n_constraints), device
+        self.exact = 1 if exact_hessian else 0
         self.acq = acq_params
         self.acq_ref = ctypes.byref(self.acq)
         self.wsb = self.lib.gabo_sphere_tr_workspace_bytes(self.r, self.d, self.c)
@@ -821,7 +822,7 @@ class SphereTr:
             _lib.check(self.lib.gabo_sphere_tr_propose(x.data_ptr(), g.data_ptr(), Delta.data_ptr(), active.data_ptr(), ptr(gc), ptr(fc),
                                                        self.acq_ref, self.ws.data_ptr(), self.wsb, self.x_prop.data_ptr(), self.r, self.c,
                                                        int(neq), float(delta_cons), float(theta), float(kappa), int(mininner),
-                                                       int(maxinner), self.any_active.data_ptr(), _stream_ptr(self.dev)),
+                                                       int(maxinner), self.exact, self.any_active.data_ptr(), _stream_ptr(self.dev)),
                        "gabo_sphere_tr_propose")
         return self.x_prop
 
@@ -839,7 +840,7 @@ class SphereTr:
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.gabo_sphere_tr_solve(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
                                                      active.data_ptr(), iters.data_ptr(), self.acq_ref, self.ws.data_ptr(), self.wsb, self.r,
-                                                     float(theta), float(kappa), int(mininner), int(maxinner), float(delta_bar),
+                                                     float(theta), float(kappa), int(mininner), int(maxinner), self.exact, float(delta_bar),
                                                      float(rho_prime), float(rho_regularization), float(mingradnorm), int(maxiter),
                                                      _stream_ptr(self.dev)), "gabo_sphere_tr_solve")
 

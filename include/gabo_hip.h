@@ -315,7 +315,10 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
  * Hessian (approximate_hessian.py:11-62) on pymanopt's Sphere geometry, one wave per restart.  State arrays: x, grad r x dim
  * (grad = Riemannian gradient), fx, grad_norm, trust_radius r; active r bytes; iters r int64; cons_grads n_constraints x r x dim
  * (Riemannian gradients, equalities first), cons_values r x n_constraints.  gabo_sphere_tr_solve runs the whole solve in one launch
- * when there are no constraints (constraints on the sphere are user callables). */
+ * when there are no constraints (constraints on the sphere are user callables).  exact_hessian != 0: the tCG uses the exact
+ * Riemannian Hessian-vector product (closed form of the double backward the reference runs through its sphere kernel,
+ * pymanopt_addons/tools/autodiff/_pytorch.py:103-116; the stock TrustRegions of examples/gabo_sphere.py:151) instead of
+ * get_hessianfd. */
 typedef struct {
     const double* train;     /* n x dim training points, row-major */
     const double* train_t;   /* dim x n, the same points transposed (coalesced strip evaluation) */
@@ -336,15 +339,15 @@ size_t gabo_sphere_tr_workspace_bytes(int64_t r, int dim, int n_constraints);
 int gabo_sphere_tr_propose(const double* x, const double* grad, const double* trust_radius, const uint8_t* active,
                            const double* cons_grads, const double* cons_values, const gabo_sphere_acq_params* acq, void* workspace,
                            size_t workspace_bytes, double* x_prop, int64_t r, int n_constraints, int n_equalities, double delta_cons,
-                           double theta, double kappa, int mininner, int maxinner, int* any_active, gabo_stream_t stream);
+                           double theta, double kappa, int mininner, int maxinner, int exact_hessian, int* any_active, gabo_stream_t stream);
 int gabo_sphere_tr_update(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
                           const uint8_t* invalid, void* workspace, int64_t r, int dim, int n_constraints, double delta_bar,
                           double rho_prime, double rho_regularization, double mingradnorm, int64_t maxiter, int* any_active,
                           gabo_stream_t stream);
 int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
                          const gabo_sphere_acq_params* acq, void* workspace, size_t workspace_bytes, int64_t r, double theta, double kappa,
-                         int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
-                         int64_t maxiter, gabo_stream_t stream);
+                         int mininner, int maxinner, int exact_hessian, double delta_bar, double rho_prime, double rho_regularization,
+                         double mingradnorm, int64_t maxiter, gabo_stream_t stream);
 
 /* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
  *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)

@@ -624,7 +624,7 @@ def test_single_launch_solve_properties_at_scale():
     assert float(v.max()) > float(v0.max()) - 1e-12
 
 
-@pytest.mark.parametrize("case", ["unconstrained", "bound_constraint", "laplace_mean"])
+@pytest.mark.parametrize("case", ["unconstrained", "bound_constraint", "laplace_mean", "exact_hessian", "exact_hessian_bound", "exact_hessian_mean"])
 def test_sphere_device_solve_matches_torch_path(case):
     """csrc/sphere_tr.hip (single-launch acquisition on the sphere, tCG with the FD Hessian, propose / update / solve) against the
     torch lock-step solver from the same initial points."""
@@ -635,7 +635,11 @@ def test_sphere_device_solve_matches_torch_path(case):
     rng = np.random.default_rng(14)
     X = rng.standard_normal((n_train, dim)); X /= np.linalg.norm(X, axis=1, keepdims=True)
     y = np.arccos(np.clip(X[:, 0], -1, 1)) ** 2 + 0.05 * rng.standard_normal(n_train)
-    if case == "laplace_mean":
+    approx = not case.startswith("exact")
+    if case == "exact_hessian_mean":
+        gp = models.ExactGP(t(X), t(y), SphereGaussianKernel(beta_min=1.0), outputscale=1.3, noise=1e-2)
+        acq = models.PosteriorMean(gp, maximize=False)
+    elif case == "laplace_mean":
         kern = SphereLaplaceKernel().double()
         kern.lengthscale = torch.tensor(0.9, dtype=torch.float64)
         gp = models.ExactGP(t(X), t(y), kern, outputscale=1.0, noise=1e-2)
@@ -654,16 +658,16 @@ def test_sphere_device_solve_matches_torch_path(case):
     f, g = fused.cost_egrad(x)
     np.testing.assert_allclose(f.cpu().numpy(), f_ref.detach().cpu().numpy(), rtol=1e-10, atol=1e-14)
     np.testing.assert_allclose(g.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-8, atol=1e-11 * max(1.0, float(g_ref.abs().max())))
-    cons = [lambda p: p[..., 0] + 0.3] if case == "bound_constraint" else None
+    cons = [lambda p: p[..., 0] + 0.3] if case.endswith("bound_constraint") or case.endswith("_bound") else None
     man = manifolds.Sphere(dim)
     out = {}
     maxiter = 1 if case == "laplace_mean" else 40        # (the Laplace surrogate has kinks: only the first iteration is comparable)
     for name, opts in (("torch", {"device_tcg": False}), ("device", {}), ("graphs", {"hip_graphs": True}),
                        ("graphs_captured", {"hip_graphs": True, "capture_constraints": True})):
         solver = BatchedTrustRegions(mingradnorm=1e-6, maxiter=maxiter)
-        c, v = gen_candidates_manifold(x[:, None], acq, man, solver, inequality_constraints=cons, approx_hessian=True, options=opts)
+        c, v = gen_candidates_manifold(x[:, None], acq, man, solver, inequality_constraints=cons, approx_hessian=approx, options=opts)
         out[name] = (c.cpu().numpy(), v.cpu().numpy(), solver.log["per_restart_iterations"].cpu().numpy())
-    tol = 2e-5 if case == "bound_constraint" else 1e-7
+    tol = 2e-5 if cons is not None else 1e-7
     for name in ("device", "graphs", "graphs_captured"):
         np.testing.assert_array_equal(out[name][2], out["torch"][2])
         np.testing.assert_allclose(out[name][1], out["torch"][1], rtol=tol, atol=1e-12)

@@ -36,7 +36,9 @@ if __name__ == "__main__":
                       ("device-resident iteration, hipGraphs incl. the constraint", dict(graphs=True, capture=True)),
                       ("unconstrained, FD Hessian: single-launch solve", dict(constrained=False)),
                       ("unconstrained, FD Hessian: torch tCG + hipGraphs", dict(constrained=False, device_tcg=False, graphs=True)),
-                      ("exact Hessian (autograd double backward), unconstrained", dict(approx=False, constrained=False, fused=False))):
+                      ("exact Hessian (autograd double backward), unconstrained, generic", dict(approx=False, constrained=False, fused=False)),
+                      ("exact Hessian (closed form on the device), unconstrained: single-launch solve", dict(approx=False, constrained=False)),
+                      ("exact Hessian (closed form on the device), bound constraint lambda", dict(approx=False))):
         run(**kw)
         dt, val, its, _ = run(**kw)
         print(f"sphere sweep S^9 512 restarts {label}: {dt*1e3:.1f} ms  EI*={val:.6e}  TR iterations={its}")
