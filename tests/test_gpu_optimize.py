@@ -673,3 +673,31 @@ def test_sphere_device_solve_matches_torch_path(case):
         np.testing.assert_allclose(out[name][1], out["torch"][1], rtol=tol, atol=1e-12)
         np.testing.assert_allclose(np.linalg.norm(out[name][0][:, 0], axis=1), 1.0, atol=1e-12)
     np.testing.assert_allclose(out["graphs"][1], out["device"][1], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("n", [3, 5])
+def test_sphere_device_solve_matches_reference_solver_optima(golden, n):
+    """The golden sphere problems (the REFERENCE's TrustRegions with exact and FD Hessians, ConstrainedTrustRegions and
+    StrictConstrainedTrustRegions on cost(x) = -sum_j w_j exp(-beta d(x, Y_j)^2)) are posterior-mean acquisitions with alpha = w: the
+    device-resident sphere solve (closed-form exact Hessian, FD Hessian, constraint lambdas, strict) must land on the reference's optima."""
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    g = golden("trust_regions.npz")
+    Y, w, beta = g[f"sph{n}_Y"], g[f"sph{n}_w"], float(g[f"sph{n}_beta"])
+    kern = SphereGaussianKernel(beta_min=0.1).double()
+    kern.beta = torch.tensor(beta, dtype=torch.float64)
+    gp = models.ExactGP(t(Y), t(np.zeros(len(w))), kern, outputscale=1.0, noise=1.0, mean=0.0)
+    gp._cache = (torch.eye(len(w), dtype=torch.float64, device=DEV), t(w))
+    acq = models.PosteriorMean(gp, maximize=True)                  # cost = -acq = the golden cost
+    man = manifolds.Sphere(n)
+    for approx, key in ((False, "exact"), (True, "fd")):
+        c, v = gen_candidates_manifold(t(g[f"sph{n}_x0"])[:, None], acq, man, BatchedTrustRegions(), approx_hessian=approx)
+        np.testing.assert_allclose(-v.cpu().numpy(), g[f"sph{n}_{key}_f"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(c[:, 0].cpu().numpy(), g[f"sph{n}_{key}_x"], rtol=0, atol=1e-4)
+    cons = [lambda p: p[..., 0] - 0.3]
+    x0c = t(g[f"sph{n}_con_x0"])[:, None]
+    c, v = gen_candidates_manifold(x0c, acq, man, BatchedTrustRegions(mingradnorm=1e-6, maxiter=200), inequality_constraints=cons)
+    np.testing.assert_allclose(-v.cpu().numpy(), g[f"sph{n}_con_f"], rtol=2e-3, atol=1e-6)
+    c, v = gen_candidates_manifold(x0c, acq, man, BatchedTrustRegions(mingradnorm=1e-6, maxiter=200, strict_constraints=True),
+                                   inequality_constraints=cons)
+    np.testing.assert_allclose(-v.cpu().numpy(), g[f"sph{n}_strict_f"], rtol=2e-3, atol=1e-6)
+    assert float(c[:, 0, 0].min()) >= 0.3 - 1e-9
