@@ -296,6 +296,16 @@ def main():
         if sharded is not None:
             line["sharded_gram"] = sharded
         if not args.no_sweep:
+            # the sphere counterpart of the sweep (gabo_sphere's setting: stock trust regions with EXACT Hessian-vector products,
+            # no constraints): GP(50 obs) + EI on S^9, 512 restarts - one launch for the whole solve (csrc/sphere_tr.hip)
+            from tools.sphere_sweep_bench import run as sphere_sweep
+            sphere_sweep(approx=False, constrained=False)
+            ssw = min(sphere_sweep(approx=False, constrained=False)[0] for _ in range(3))
+            sval = sphere_sweep(approx=False, constrained=False)[1]
+            line["acq_sweep_sphere"] = {"workload": "SphereGaussianKernel GP(50 obs)+EI on S^9, 2048 raw samples, 512 restarts, stock trust "
+                                                    "regions with exact Hessian-vector products (closed form on the device)",
+                                        "seconds": ssw, "restarts_per_s": 512 / ssw, "best_acq": sval}
+        if not args.no_sweep:
             # config 2 of BASELINE.json beside the headline: SphereGaussianKernel S^9, N=4096 (HBM-write bound: 8.04 B/pair)
             from gabotorch_amd import ops as _ops
             from oracle import sphere as osph
