@@ -243,6 +243,25 @@ def main():
                          "(0.1 ms on the device).  Opaque constraint callables cost 0.4 ms per iteration and one graph replay each.  Does not "
                          "speed up with more GPUs at this size (weak scaling only)"}
 
+    sphere_sweep_result = None
+    if not args.no_sweep:
+        # the sphere counterpart of the sweep (gabo_sphere's setting: stock trust regions with EXACT Hessian-vector products, no
+        # constraints): GP(50 obs) + EI on S^9, 512 restarts sharded over the ranks - one launch for the whole solve (csrc/sphere_tr.hip).
+        # Every rank takes part: the maximiser broadcasts / all_gathers when torch.distributed is initialised.
+        from tools.sphere_sweep_bench import run as sphere_sweep
+        sphere_sweep(approx=False, constrained=False, device=device)
+        if dist is not None:
+            dist.barrier()
+        ssw = min(sphere_sweep(approx=False, constrained=False, device=device)[0] for _ in range(3))
+        sval = sphere_sweep(approx=False, constrained=False, device=device)[1]
+        tsw = torch.tensor([ssw], dtype=torch.float64, device=device)
+        if dist is not None:
+            dist.all_reduce(tsw, op=dist.ReduceOp.MAX)
+        ssw = float(tsw.item())
+        sphere_sweep_result = {"workload": "SphereGaussianKernel GP(50 obs)+EI on S^9, 2048 raw samples, 512 restarts, stock trust regions "
+                                           "with exact Hessian-vector products (closed form on the device)",
+                               "seconds": ssw, "restarts_per_s": 512 / ssw, "best_acq": sval}
+
     t = torch.tensor([wall], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -295,16 +314,8 @@ def main():
             line["acq_sweep"] = sweep
         if sharded is not None:
             line["sharded_gram"] = sharded
-        if not args.no_sweep:
-            # the sphere counterpart of the sweep (gabo_sphere's setting: stock trust regions with EXACT Hessian-vector products,
-            # no constraints): GP(50 obs) + EI on S^9, 512 restarts - one launch for the whole solve (csrc/sphere_tr.hip)
-            from tools.sphere_sweep_bench import run as sphere_sweep
-            sphere_sweep(approx=False, constrained=False)
-            ssw = min(sphere_sweep(approx=False, constrained=False)[0] for _ in range(3))
-            sval = sphere_sweep(approx=False, constrained=False)[1]
-            line["acq_sweep_sphere"] = {"workload": "SphereGaussianKernel GP(50 obs)+EI on S^9, 2048 raw samples, 512 restarts, stock trust "
-                                                    "regions with exact Hessian-vector products (closed form on the device)",
-                                        "seconds": ssw, "restarts_per_s": 512 / ssw, "best_acq": sval}
+        if sphere_sweep_result is not None:
+            line["acq_sweep_sphere"] = sphere_sweep_result
         if not args.no_sweep:
             # config 2 of BASELINE.json beside the headline: SphereGaussianKernel S^9, N=4096 (HBM-write bound: 8.04 B/pair)
             from gabotorch_amd import ops as _ops

@@ -9,11 +9,12 @@ from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTru
 from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold
 
 
-def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrained=True, approx=True, device_tcg=True, maxiter=50, capture=False):
+def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrained=True, approx=True, device_tcg=True, maxiter=50, capture=False, device=None):
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     rng = np.random.default_rng(3)
     X = rng.standard_normal((n_train, dim)); X /= np.linalg.norm(X, axis=1, keepdims=True)
     y = np.arccos(np.clip(X[:, 0], -1, 1)) ** 2 + 0.05 * rng.standard_normal(n_train)
-    gp = models.ExactGP(torch.tensor(X, device="cuda"), torch.tensor(y, device="cuda"), SphereGaussianKernel(beta_min=0.6), outputscale=1.0, noise=1e-2)
+    gp = models.ExactGP(torch.tensor(X, device=device), torch.tensor(y, device=device), SphereGaussianKernel(beta_min=0.6), outputscale=1.0, noise=1e-2)
     acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
     man = manifolds.Sphere(dim)
     np.random.seed(5); torch.manual_seed(5)
@@ -21,7 +22,7 @@ def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrain
     solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=maxiter)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=R, raw_samples=raw, bounds=None,
-                                   options={"device": "cuda:0", "hip_graphs": graphs, "batched_rand": True, "fused_acquisition": fused, "device_tcg": device_tcg, "capture_constraints": capture},
+                                   options={"device": str(device), "hip_graphs": graphs, "batched_rand": True, "fused_acquisition": fused, "device_tcg": device_tcg, "capture_constraints": capture},
                                    inequality_constraints=cons, approx_hessian=approx)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
