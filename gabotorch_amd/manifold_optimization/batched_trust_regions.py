@@ -381,6 +381,8 @@ class BatchedTrustRegions:
                 TR.solve(S.x, S.fx, S.g, S.ng, S.Delta, S.active_u8, S.iters, [b[0] for b in builtins], [b[1] for b in builtins], strict,
                           Delta_cons, self.theta, self.kappa, mininner, maxinner, Delta_bar, self.rho_prime, self.rho_regularization,
                           self.mingradnorm, self.maxiter)
+                if hasattr(TR, "status"):
+                    ops._raise_if_not_spd(TR.status, "gabo_spd_tr_solve")       # (when error checking is on: one read-back per solve)
                 k = int(S.iters.max().item())
                 self.log = {"iterations": k, "per_restart_iterations": S.iters, "final_cost": S.fx, "final_gradnorm": S.ng,
                             "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0}

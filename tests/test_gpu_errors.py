@@ -52,3 +52,24 @@ def test_second_derivative_of_spd_kernel_is_refused():
     (g,) = torch.autograd.grad(k.sum(), x, create_graph=True)
     with pytest.raises(RuntimeError):
         torch.autograd.grad(g.sum(), x)
+
+
+def test_device_solve_reports_a_non_spd_start():
+    """The single-launch solve writes the device status word like every other entry point: a non-SPD starting matrix raises."""
+    import functools
+    from gabotorch_amd import manifolds, models
+    from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    from gabotorch_amd.Riemannian_utils.spd_utils_torch import symmetric_matrix_to_vector_mandel_torch, vector_to_symmetric_matrix_mandel_torch
+    rng = np.random.default_rng(0)
+    q = np.linalg.qr(rng.standard_normal((8, 3, 3)))[0]
+    Xm = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.5, 2.0, (8, 3)), q)
+    X = torch.tensor(Xm, device=DEV)
+    xv = symmetric_matrix_to_vector_mandel_torch(X)
+    gp = models.ExactGP(xv, torch.tensor(rng.standard_normal(8), device=DEV), SpdAffineInvariantGaussianKernel(beta_min=0.5), outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=0.0, maximize=False)
+    bad = xv[:3].clone()
+    bad[1, :3] = torch.tensor([1.0, -2.0, 1.0], dtype=torch.float64, device=DEV)        # a negative diagonal entry: not SPD
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        gen_candidates_manifold(bad[:, None], acq, manifolds.PositiveDefinite(3), BatchedTrustRegions(maxiter=3),
+                                vector_to_symmetric_matrix_mandel_torch, symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
