@@ -4,7 +4,6 @@ kernel classes keep their reference signatures.  The stand-in only covers what t
 (kernels_spd.py:33-70): has_lengthscale / batch_shape kwargs, register_parameter, register_prior, register_constraint,
 `raw_<name>_constraint`, initialize(), and a dense __call__.
 """
-import math
 
 import torch
 

@@ -11,8 +11,6 @@ another kernel, user pre/post-processing callables, second derivatives) stays on
 """
 import math
 
-import torch
-
 from . import _lib, models, ops
 from .kernel_utils import kernels_spd, kernels_sphere
 from .Riemannian_utils import spd_utils_torch

@@ -8,7 +8,6 @@
     followed by a local argmax replaces get_best_candidates (:118-120).  Ties go to the lowest global restart index on
     every rank, so all ranks return the same candidate.
 """
-import types
 import warnings
 
 import numpy as np

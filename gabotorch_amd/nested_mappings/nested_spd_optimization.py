@@ -6,11 +6,9 @@ under W^T V = 0 by the augmented Lagrangian method."""
 import numpy as np
 import torch
 
-from .. import ops
 from ..manifold_optimization.augmented_lagrange_method import AugmentedLagrangeMethod, _Constraint
 from ..manifold_optimization.host_manifolds import Euclidean, Grassmann, PositiveDefinite, Product, Sphere
-from ..Riemannian_utils.spd_utils_torch import (affine_invariant_distance_torch, logm_torch,
-                                                symmetric_matrix_to_vector_mandel_torch)
+from ..Riemannian_utils.spd_utils_torch import affine_invariant_distance_torch, logm_torch
 from .nested_spd_utils import projection_from_nested_spd_to_spd
 
 

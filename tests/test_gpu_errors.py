@@ -56,7 +56,6 @@ def test_second_derivative_of_spd_kernel_is_refused():
 
 def test_device_solve_reports_a_non_spd_start():
     """The single-launch solve writes the device status word like every other entry point: a non-SPD starting matrix raises."""
-    import functools
     from gabotorch_amd import manifolds, models
     from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions
     from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
