@@ -701,3 +701,41 @@ def test_sphere_device_solve_matches_reference_solver_optima(golden, n):
                                    inequality_constraints=cons)
     np.testing.assert_allclose(-v.cpu().numpy(), g[f"sph{n}_strict_f"], rtol=2e-3, atol=1e-6)
     assert float(c[:, 0, 0].min()) >= 0.3 - 1e-9
+
+
+def test_device_solvers_at_the_smallest_sizes():
+    """One restart, one training point, the smallest manifolds (S^2_++ and the circle S^1): the device solvers against the torch path."""
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    # SPD: d = 2, n = 1, R = 1
+    xtr = ospd.symmetric_matrix_to_vector_mandel(np.array([[[1.5, 0.2], [0.2, 0.8]]]))
+    gp = models.ExactGP(t(xtr), t(np.array([0.3])), SpdAffineInvariantGaussianKernel(beta_min=0.5), outputscale=1.0, noise=1e-2, mean=0.0)
+    acq = models.PosteriorMean(gp, maximize=True)                    # peaks at the training point (a flat EI tail would be ill-posed)
+    x0 = ops.matrix_to_mandel(t(np.array([[[0.9, -0.1], [-0.1, 1.7]]])))[:, None]
+    man = manifolds.PositiveDefinite(2)
+    res = {}
+    ops.set_error_checking(False)
+    try:
+        for name, opts in (("torch", {"device_tcg": False}), ("device", {}), ("plan", {"device_solve": False})):
+            s_ = BatchedTrustRegions(mingradnorm=1e-7, maxiter=15)
+            c, v = gen_candidates_manifold(x0, acq, man, s_, vector_to_symmetric_matrix_mandel_torch, symmetric_matrix_to_vector_mandel_torch,
+                                           approx_hessian=True, options=opts)
+            res[name] = (c.cpu().numpy(), v.cpu().numpy())
+    finally:
+        ops.set_error_checking(True)
+    for name in ("device", "plan"):
+        np.testing.assert_allclose(res[name][1], res["torch"][1], rtol=1e-7, atol=1e-13)
+        np.testing.assert_allclose(res[name][0], res["torch"][0], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(res[name][0][0, 0], xtr[0], atol=1e-5)
+    # circle S^1: dim = 2, n = 1, R = 1, exact and FD Hessian
+    gp = models.ExactGP(t(np.array([[0.6, 0.8]])), t(np.array([0.1])), SphereGaussianKernel(beta_min=1.0), outputscale=1.0, noise=1e-2, mean=0.0)
+    acq = models.PosteriorMean(gp, maximize=True)
+    x0 = t(np.array([[1.0, 0.0]]))[:, None]
+    for approx in (False, True):
+        out = []
+        for opts in ({"device_tcg": False}, {}):
+            c, v = gen_candidates_manifold(x0, acq, manifolds.Sphere(2), BatchedTrustRegions(mingradnorm=1e-9, maxiter=30), approx_hessian=approx,
+                                           options=opts)
+            out.append((c.cpu().numpy(), v.cpu().numpy()))
+        np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-8)
+        np.testing.assert_allclose(out[1][0], out[0][0], atol=1e-6)
+        np.testing.assert_allclose(out[1][0][0, 0], [0.6, 0.8], atol=1e-5)          # the posterior mean peaks at the training point
