@@ -17,6 +17,7 @@ GABO_SPD_MAX_DIM = 32
 (GABO_SPD_EXP, GABO_SPD_LOG, GABO_SPD_INNER, GABO_SPD_NORM, GABO_SPD_DIST, GABO_SPD_EGRAD2RGRAD, GABO_SPD_EHESS2RHESS,
  GABO_SPD_LOGM, GABO_SPD_EXPM, GABO_SPD_SQRTM, GABO_SPD_EIGMAX, GABO_SPD_EIGMIN) = range(12)
 GABO_ACQ_EXPECTED_IMPROVEMENT, GABO_ACQ_POSTERIOR_MEAN = 0, 1
+GABO_GP_MLL_MAX_N = 160
 GABO_METRIC_AFFINE_INVARIANT, GABO_METRIC_LOG_EUCLIDEAN, GABO_METRIC_FROBENIUS = 0, 8, 16
 GABO_CONSTRAINT_MAX_EIGENVALUE, GABO_CONSTRAINT_MIN_EIGENVALUE = 0, 1
 GABO_SPH_PROJ, GABO_SPH_RETR, GABO_SPH_EXP, GABO_SPH_LOG, GABO_SPH_DIST, GABO_SPH_EHESS2RHESS = range(6)
@@ -55,6 +56,7 @@ SIGNATURES = {
     "gabo_spd_logm_mandel": (_I, [_P, _P, _I64, _I, _P]),
     "gabo_frobenius_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _P]),
     "gabo_gp_acquisition": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _D, _D, _D, _D, _I, _I, _D, _P]),
+    "gabo_gp_mll": (_I, [_P, _P, _I64, _D, _D, _D, _D, _P, _P]),
     "gabo_spd_acq_max_train": (_I64, [_I]),
     "gabo_spd_acq_prepare_train": (_I, [_P, _P, _I64, _I, _P, _P]),
     "gabo_spd_acq_eval": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _D, _I, _D, _D, _D, _D, _I, _I, _D, _P, _P, _P]),

@@ -228,6 +228,152 @@ class SingleTaskGP(torch.nn.Module):
     def invalidate(self):
         self._cache = None
 
+    # ---- fast surrogate fit: the distances are evaluated once, each evaluation is one gabo_gp_mll launch ------------------
+    def _stationary_form(self):
+        """(E, theta_fn, outputscale_fn) when the covariance is [ScaleKernel of] one of the path's plain kernels, all of which
+        are exp(-theta * E) with E = d^2 or d fixed during a fit; None for anything else (nested kernels carry extra
+        parameters inside the distance, batched hyper-parameters, more than GABO_GP_MLL_MAX_N points)."""
+        from . import _lib, ops
+        from .kernel_utils import kernels_sphere as ksph
+        from .kernel_utils import kernels_spd as kspd
+        cm = self.covar_module
+        base = getattr(cm, "base_kernel", None)
+        if base is None:
+            base, os_fn = cm, (lambda: torch.ones((), dtype=torch.float64))
+        elif type(cm).__name__ == "ScaleKernel" and cm.raw_outputscale.numel() == 1:
+            os_fn = lambda: cm.outputscale.double().reshape(())                                # noqa: E731
+        else:
+            return None
+        x = self.train_x
+        if x.dim() != 2 or not 1 <= x.shape[0] <= _lib.GABO_GP_MLL_MAX_N:
+            return None
+        kind = type(base)
+        dist_mode = _lib.GABO_OUT_DISTANCE
+        beta_fn = lambda: base.beta.double().reshape(())                                       # noqa: E731
+        ls_fn = lambda: 1.0 / base.lengthscale.double().reshape(()) ** 2                       # noqa: E731
+        if kind in (kspd.SpdAffineInvariantGaussianKernel, kspd.SpdAffineInvariantLaplaceKernel):
+            dist, theta_fn = (lambda v: ops.spd_ai_pairwise(v, v, 1.0, dist_mode)), beta_fn
+            power = 2 if kind is kspd.SpdAffineInvariantGaussianKernel else 1
+        elif kind is kspd.SpdFrobeniusGaussianKernel:
+            dist, theta_fn, power = (lambda v: ops.frobenius_pairwise(v, v, 1.0, dist_mode)), ls_fn, 2
+        elif kind is kspd.SpdLogEuclideanGaussianKernel:
+            dist, theta_fn, power = (lambda v: ops.frobenius_pairwise(*(2 * (ops.spd_logm_mandel(v),)), 1.0, dist_mode)), ls_fn, 2
+        elif kind is ksph.SphereGaussianKernel:
+            dist, theta_fn, power = (lambda v: ops.sphere_pairwise(v, v, 1.0, dist_mode)), beta_fn, 2
+        elif kind is ksph.SphereLaplaceKernel:
+            dist, theta_fn, power = (lambda v: ops.sphere_pairwise(v, v, 1.0, dist_mode)), ls_fn, 1
+        else:
+            return None
+        if theta_fn().numel() != 1:
+            return None
+        with torch.no_grad():
+            d = dist(x.to(ops._device_for(x)))
+            e = (d * d if power == 2 else d).contiguous()
+        return e, theta_fn, os_fn
+
+    def _fast_mll_closure(self):
+        """() -> (value, backward_fn) evaluating `marginal_log_likelihood` and the gradients of all parameters with one
+        gabo_gp_mll launch: the device returns d ll / d (theta, outputscale, noise, mean); the chain rule through the parameter
+        transforms and the priors is a handful of scalar torch operations on the parameters' own device."""
+        from . import ops
+        form = self._stationary_form()
+        if form is None:
+            return None
+        e, theta_fn, os_fn = form
+        y = self.train_y.to(e.device).contiguous()
+        n = y.numel()
+
+        def evaluate():
+            theta, os_, noise, mean = theta_fn(), os_fn(), self.noise, self.mean_constant
+            ll, g_theta, g_os, g_noise, g_mean, bad = ops.gp_mll(e, y, theta.item(), os_.item(), noise.item(), mean.item())
+            if bad:
+                raise RuntimeError("K + noise I is not positive definite")
+            pri = self._priors()
+            value = (ll + (pri.item() if torch.is_tensor(pri) else pri)) / n
+            # a linear stand-in with the same first derivatives as ll at this point, so that autograd does the chain rule
+            proxy = (g_theta * theta + g_os * os_.to(theta.device) + g_noise * noise.to(theta.device)
+                     + g_mean * mean.to(theta.device) + (pri.to(theta.device) if torch.is_tensor(pri) else 0.0)) / n
+            return value, proxy
+
+        return evaluate
+
+    def _fast_scalar_objective(self, params):
+        """v -> (loss, gradient) in plain Python floats for the layout every reference example uses (stand-in ScaleKernel / kernel
+        classes with softplus constraints, Gamma priors): the chain rule through softplus and the priors costs microseconds, so an
+        L-BFGS evaluation is the gabo_gp_mll launch and its 48-byte read-back.  None when the model is laid out differently (the
+        caller then lets autograd do the chain rule)."""
+        import numpy as np
+
+        from . import _compat, ops
+        if _compat.HAVE_GPYTORCH:
+            return None
+        form = self._stationary_form()
+        if form is None:
+            return None
+        e = form[0]
+        cm = self.covar_module
+        base = getattr(cm, "base_kernel", cm)
+        index = {id(p): i for i, p in enumerate(params)}
+        plan = {}                      # hyper-parameter -> (position in v, fp32?, lower bound)
+
+        def softplus_param(name, module, raw_name):
+            raw = getattr(module, raw_name)
+            con = getattr(module, raw_name + "_constraint", None)
+            if type(con) not in (_compat.GreaterThan, _compat.Positive) or raw.numel() != 1 or id(raw) not in index:
+                return False
+            plan[name] = (index[id(raw)], raw.dtype == torch.float32, float(con.lower_bound))
+            return True
+
+        uses_beta = hasattr(base, "raw_beta")
+        if not softplus_param("theta", base, "raw_beta" if uses_beta else "raw_lengthscale"):
+            return None
+        if base is not cm and not softplus_param("os", cm, "raw_outputscale"):
+            return None
+        if id(self.raw_noise) not in index or id(self.mean_constant) not in index:
+            return None
+        plan["noise"] = (index[id(self.raw_noise)], False, self.noise_lower_bound)
+        i_mean = index[id(self.mean_constant)]
+        if len(plan) + 1 != len(params):
+            return None
+        priors = []                    # (hyper-parameter the prior is on, concentration, rate)
+        on_base = {"beta_prior": "theta", "lengthscale_prior": "theta"}      # (a lengthscale prior is on l, the constrained value)
+        for module, allowed in ([(cm, on_base)] if base is cm else [(cm, {"outputscale_prior": "os"}), (base, on_base)]):
+            for name, (prior, _, _) in getattr(module, "_priors", {}).items():
+                if name not in allowed or type(prior) is not GammaPrior:
+                    return None
+                priors.append((allowed[name], prior.concentration, prior.rate))
+        if self.noise_prior is not None:
+            if type(self.noise_prior) is not GammaPrior:
+                return None
+            priors.append(("noise", self.noise_prior.concentration, self.noise_prior.rate))
+        y = self.train_y.to(e.device).contiguous()
+        n = y.numel()
+
+        def objective(v):
+            val, dval = {}, {}
+            for name, (i, is32, lb) in plan.items():
+                raw = float(np.float32(v[i])) if is32 else float(v[i])
+                val[name] = lb + max(raw, 0.0) + math.log1p(math.exp(-abs(raw)))           # softplus
+                dval[name] = 1.0 / (1.0 + math.exp(-raw)) if raw >= 0 else math.exp(raw) / (1.0 + math.exp(raw))
+            positive = val["theta"]                       # beta, or the lengthscale l with theta = l^-2
+            theta, dtheta = (positive, 1.0) if uses_beta else (positive ** -2, -2.0 * positive ** -3)
+            ll, g_theta, g_os, g_noise, g_mean, bad = ops.gp_mll(e, y, theta, val.get("os", 1.0), val["noise"], float(v[i_mean]))
+            grad = np.zeros_like(v)
+            if bad:
+                return 1e10, grad
+            d_positive = {"theta": g_theta * dtheta, "os": g_os, "noise": g_noise}       # d total / d (constrained value)
+            total = ll
+            for name, a, b in priors:
+                x = val[name]
+                total += a * math.log(b) + (a - 1.0) * math.log(x) - b * x - math.lgamma(a)
+                d_positive[name] += (a - 1.0) / x - b
+            for name, (i, _, _) in plan.items():
+                grad[i] = -d_positive[name] * dval[name] / n
+            grad[i_mean] = -g_mean / n
+            return -total / n, grad
+
+        return objective
+
     def _ensure_cache(self):
         """(L^-1, alpha, mean) of the fitted model; freezes the kernel hyper-parameters (prediction mode)."""
         if self._cache is None:
@@ -255,9 +401,12 @@ class SingleTaskGP(torch.nn.Module):
         return mean, kss - (v * v).sum(-1)
 
 
-def fit_gpytorch_model(model, maxiter=200):
+def fit_gpytorch_model(model, maxiter=200, fast=True):
     """Maximise the marginal log likelihood (+ priors) over every trainable parameter with scipy L-BFGS-B, as
-    botorch.fit_gpytorch_model does for the reference examples (examples/gabo_spd.py:194) [3P]."""
+    botorch.fit_gpytorch_model does for the reference examples (examples/gabo_spd.py:194) [3P].
+    fast=True: for the plain kernels of the path the pairwise distances are evaluated once and every L-BFGS evaluation is a single
+    gabo_gp_mll launch (value + analytic gradient) instead of a kernel launch, a Cholesky and their autograd; fast=False (and any
+    other model) differentiates `marginal_log_likelihood` with autograd."""
     import numpy as np
     from scipy.optimize import minimize
     params = [p for p in model.parameters()]
@@ -273,13 +422,23 @@ def fit_gpytorch_model(model, maxiter=200):
                 p.copy_(torch.as_tensor(v[off:off + sz], dtype=p.dtype).reshape(sh))
                 off += sz
 
+    scalar = model._fast_scalar_objective(params) if fast and hasattr(model, "_fast_scalar_objective") else None
+    fast = model._fast_mll_closure() if fast and scalar is None and hasattr(model, "_fast_mll_closure") else None
+
     def fun(v):
+        if scalar is not None:
+            return scalar(v)
         set_params(v)
         for p in params:
             p.grad = None
         try:
-            loss = -model.marginal_log_likelihood()
-            loss.backward()
+            if fast is not None:
+                value, proxy = fast()
+                (-proxy).backward()
+                loss = torch.tensor(-value)
+            else:
+                loss = -model.marginal_log_likelihood()
+                loss.backward()
         except RuntimeError:          # a trial point outside the SPD cone of K + noise I
             return 1e10, np.zeros_like(v)
         g = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().double().reshape(-1).numpy()

@@ -587,6 +587,22 @@ def gp_acquisition(kstar, alpha, linv, linv_t, mean, outputscale, kxx, best_f, k
     return value, grad
 
 
+def gp_mll(e, y, theta, outputscale, noise, mean):
+    """One evaluation of the exact-GP marginal log likelihood with K = outputscale * exp(-theta * e) + noise * I (gabo_gp_mll):
+    -> [ll, dll/dtheta, dll/doutputscale, dll/dnoise, dll/dmean, not_positive_definite] as Python floats (one device->host copy).
+    e: n x n fp64 on a HIP device (n <= GABO_GP_MLL_MAX_N), y: n."""
+    lib = _lib.load()
+    dev = e.device
+    n = e.shape[-1]
+    if e.dim() != 2 or e.shape[0] != n or y.numel() != n or not e.is_contiguous() or not y.is_contiguous():
+        raise RuntimeError("gp_mll: e must be a contiguous n x n matrix and y a contiguous vector of n targets")
+    out = torch.empty(6, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_gp_mll(e.data_ptr(), y.data_ptr(), n, float(theta), float(outputscale), float(noise), float(mean),
+                                   out.data_ptr(), _stream_ptr(dev)), "gabo_gp_mll")
+    return out.tolist()
+
+
 def spd_acq_prepare_train(train_mandel):
     """Entry-major Cholesky factors of the training matrices for spd_acq_eval (d_vec x n)."""
     lib = _lib.load()

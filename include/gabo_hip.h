@@ -192,6 +192,22 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
                         int kind, int maximize, double out_sign, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Exact-GP marginal log likelihood and its analytic gradient, one launch per evaluation of the surrogate fit
+ * (fit_gpytorch_model(mll) at examples/bo_spd/benchmark_examples/gabo_spd.py:194 and its siblings; [3P] gpytorch
+ * ExactMarginalLogLikelihood semantics).  Every kernel of the path is exp(-theta * E) with E = d^2 (Gaussian) or
+ * d (Laplace), fixed during a fit: evaluate the distances once with GABO_OUT_DISTANCE, then call this per L-BFGS evaluation.
+ *   e: n x n (row-major, symmetric; the lower triangle is read), y: n targets,
+ *   Ky = outputscale * exp(-theta * e) + noise * I.
+ *   out[0] = log N(y | mean, Ky)  (no priors, not divided by n)
+ *   out[1..4] = d out[0] / d theta, d outputscale, d noise, d mean
+ *   out[5] = 1.0 when Ky is not numerically positive definite (out[0..4] are then 0), else 0.0.
+ * One workgroup, the bordered matrix [[Ky, r], [r^T, 0]] held in registers and inverted in place by n symmetric sweeps (one barrier
+ * each): n <= GABO_GP_MLL_MAX_N (GABO_ERR_DIM beyond). */
+#define GABO_GP_MLL_MAX_N 160
+int gabo_gp_mll(const double* e, const double* y, int64_t n, double theta, double outputscale, double noise, double mean,
+                double* out, gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * n random SPD matrices with the distribution of spd_sample (Riemannian_utils/spd_utils.py:290-306; the raw samples of
  * gen_batch_initial_conditions_manifold, manifold_optimize.py:288): eigenvalues U[min_eig, max_eig], eigenvectors = orthogonal
  * factor of a Gaussian matrix.  out: n x d x d (mandel == 0) or n x d_vec Mandel vectors.  Counter-based stream (Philox4x32-10,

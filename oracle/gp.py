@@ -26,3 +26,23 @@ def expected_improvement(mu, var, best_f, maximize):
     if not maximize:
         u = -u
     return sigma * (norm.pdf(u) + u * norm.cdf(u))
+
+
+def marginal_log_likelihood(e, y, theta, outputscale, noise, mean):
+    """Exact-GP log marginal likelihood log N(y | mean, Ky), Ky = outputscale * exp(-theta * e) + noise * I, and its gradient with
+    respect to (theta, outputscale, noise, mean): [3P] the quantity gpytorch's ExactMarginalLogLikelihood differentiates (before its
+    priors and its division by n) inside fit_gpytorch_model (call site: examples/bo_spd/benchmark_examples/gabo_spd.py:194).
+    Textbook identities (Rasmussen & Williams eq. 5.8-5.9): d ll / d p = tr((alpha alpha^T - Ky^-1) dKy/dp) / 2.
+    -> (ll, grad (4,))."""
+    e = np.asarray(e, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    n = len(y)
+    kb = np.exp(-theta * e)
+    ky = outputscale * kb + noise * np.eye(n)
+    chol = np.linalg.cholesky(ky)
+    r = y - mean
+    alpha = np.linalg.solve(ky, r)
+    ll = -0.5 * r @ alpha - np.log(np.diag(chol)).sum() - 0.5 * n * np.log(2.0 * np.pi)
+    w = np.outer(alpha, alpha) - np.linalg.inv(ky)
+    grad = np.array([0.5 * np.sum(w * (-outputscale * e * kb)), 0.5 * np.sum(w * kb), 0.5 * np.trace(w), alpha.sum()])
+    return ll, grad

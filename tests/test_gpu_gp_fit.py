@@ -195,3 +195,96 @@ def test_nested_spd_eigenvalue_constraints_golden(golden):
     np.testing.assert_allclose(batch.cpu().numpy(), [g[f"nc_max{k}"] for k in range(3)], rtol=1e-10)
     sample = nscu.random_nested_spd_with_spd_eigenvalue_constraints(None, lambda: g["a_X"][0], args[0])
     np.testing.assert_allclose(sample, g["a_Y"][0], atol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------- one-launch marginal likelihood
+@pytest.mark.parametrize("n,power", [(1, 2), (2, 1), (5, 2), (37, 1), (64, 2), (65, 2), (128, 2), (160, 2)])
+def test_gp_mll_kernel_matches_the_oracle(n, power):
+    from gabotorch_amd import ops
+    from oracle import gp as ogp
+    rng = np.random.default_rng(n)
+    pts = rng.standard_normal((n, 4))
+    e = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1)) ** power
+    y = rng.standard_normal(n)
+    par = (0.4, 1.7, 0.03, -0.2)
+    ll, g = ogp.marginal_log_likelihood(e, y, *par)
+    out = ops.gp_mll(torch.tensor(e, device=DEV), torch.tensor(y, device=DEV), *par)
+    assert out[5] == 0.0
+    np.testing.assert_allclose(out[0], ll, rtol=1e-11)
+    np.testing.assert_allclose(out[1:5], g, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(g).max()))
+
+
+def test_gp_mll_kernel_reports_indefinite_matrices_and_sizes():
+    from gabotorch_amd import _lib, ops
+    e = torch.zeros(3, 3, dtype=torch.float64, device=DEV)       # K = os * ones + noise I with a negative "noise": indefinite
+    out = ops.gp_mll(e, torch.ones(3, dtype=torch.float64, device=DEV), 1.0, 1.0, -0.5, 0.0)
+    assert out[5] == 1.0 and out[:5] == [0.0] * 5
+    n = _lib.GABO_GP_MLL_MAX_N + 1
+    with pytest.raises(RuntimeError):
+        ops.gp_mll(torch.zeros(n, n, dtype=torch.float64, device=DEV), torch.zeros(n, dtype=torch.float64, device=DEV), 1.0, 1.0, 0.1, 0.0)
+
+
+def _plain_models(rng, n=17):
+    from gabotorch_amd.kernel_utils import kernels_sphere as ksph
+    from gabotorch_amd.kernel_utils import kernels_spd as kspd
+    X = torch.tensor(ospd.symmetric_matrix_to_vector_mandel(_rand_spd(rng, n, 3)), device=DEV)
+    S = rng.standard_normal((n, 4))
+    S = torch.tensor(S / np.linalg.norm(S, axis=1, keepdims=True), device=DEV)
+    y = torch.tensor(rng.standard_normal(n), device=DEV)
+    prior = lambda: models.GammaPrior(2.0, 0.15)             # noqa: E731
+    out = []
+    for make, x in ((lambda: kspd.SpdAffineInvariantGaussianKernel(beta_min=0.3, beta_prior=models.GammaPrior(3.0, 2.0)), X),
+                    (lambda: kspd.SpdAffineInvariantLaplaceKernel(beta_min=0.3), X),
+                    (lambda: kspd.SpdFrobeniusGaussianKernel(), X),
+                    (lambda: kspd.SpdLogEuclideanGaussianKernel(), X),
+                    (lambda: ksph.SphereGaussianKernel(beta_min=0.5), S),
+                    (lambda: ksph.SphereLaplaceKernel(), S)):
+        out.append(lambda make=make, x=x: models.SingleTaskGP(x, y, ScaleKernel(make(), outputscale_prior=prior()),
+                                                              noise_prior=models.GammaPrior(1.1, 0.05)))
+    out.append(lambda: models.SingleTaskGP(S, y, ksph.SphereGaussianKernel(beta_min=0.5)))        # no ScaleKernel
+    return out
+
+
+def test_fast_mll_value_and_gradients_match_autograd_for_every_plain_kernel():
+    for make in _plain_models(np.random.default_rng(3)):
+        gp = make()
+        with torch.no_grad():
+            for p in gp.parameters():
+                p.add_(0.3)
+        ref = gp.marginal_log_likelihood()
+        ref.backward()
+        want = [p.grad.clone() for p in gp.parameters()]
+        for p in gp.parameters():
+            p.grad = None
+        fast = gp._fast_mll_closure()
+        assert fast is not None, type(gp.covar_module)
+        value, proxy = fast()
+        proxy.backward()
+        np.testing.assert_allclose(value, float(ref), rtol=1e-11)
+        for p, w in zip(gp.parameters(), want):
+            np.testing.assert_allclose(p.grad.numpy(), w.numpy(), rtol=2e-6, atol=1e-9)     # raw_beta / lengthscale are fp32 parameters
+        # the same through the plain-float chain rule that fit_gpytorch_model uses with the stand-in kernel classes
+        params = list(gp.parameters())
+        objective = gp._fast_scalar_objective(params)
+        assert objective is not None
+        loss, grad = objective(np.array([float(p) for p in params]))
+        np.testing.assert_allclose(loss, -float(ref), rtol=1e-7)
+        np.testing.assert_allclose(grad, [-float(w) for w in want], rtol=2e-6, atol=1e-9)
+
+
+def test_fast_fit_reaches_the_same_hyper_parameters_as_the_autograd_fit():
+    for make in _plain_models(np.random.default_rng(4))[:2] + _plain_models(np.random.default_rng(4))[4:5]:
+        a, b = make(), make()
+        models.fit_gpytorch_model(a, fast=True)
+        models.fit_gpytorch_model(b, fast=False)
+        np.testing.assert_allclose(float(a.marginal_log_likelihood()), float(b.marginal_log_likelihood()), rtol=1e-6, atol=1e-8)
+        hyper = lambda m: [float(m.noise), float(m.mean_constant), float(m.covar_module.outputscale),      # noqa: E731
+                           float(m.covar_module.base_kernel.beta)]
+        np.testing.assert_allclose(hyper(a), hyper(b), rtol=2e-3, atol=1e-4)     # (raw parameters saturate where softplus is flat)
+
+
+def test_nested_kernels_do_not_take_the_fast_fit():
+    rng = np.random.default_rng(5)
+    X = torch.tensor(ospd.symmetric_matrix_to_vector_mandel(_rand_spd(rng, 6, 4)), device=DEV)
+    gp = models.SingleTaskGP(X, torch.tensor(rng.standard_normal(6), device=DEV), ScaleKernel(NestedSpdLogEuclideanGaussianKernel(4, 2)))
+    assert gp._fast_mll_closure() is None

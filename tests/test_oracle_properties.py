@@ -66,3 +66,26 @@ def test_gp_oracle_known_answers():
     np.testing.assert_allclose(ogp.expected_improvement(np.array([1.0]), np.array([-1.0]), 1.0, True), np.sqrt(1e-9) / np.sqrt(2 * np.pi))
     np.testing.assert_allclose(ogp.expected_improvement(np.array([0.3]), np.array([0.5]), 1.0, False),
                                ogp.expected_improvement(np.array([1.7]), np.array([0.5]), 1.0, True))
+
+
+def test_gp_mll_oracle_known_answers():
+    """The marginal likelihood restatement against scipy's multivariate normal density and central differences of itself."""
+    from scipy.stats import multivariate_normal
+    from oracle import gp as ogp
+    rng = np.random.default_rng(7)
+    for n, p in ((1, 2), (6, 2), (23, 1)):
+        pts = rng.standard_normal((n, 3))
+        d = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+        e = d ** p
+        y = rng.standard_normal(n)
+        par = np.array([0.7, 1.9, 0.05, 0.3])
+        ll, g = ogp.marginal_log_likelihood(e, y, *par)
+        ky = par[1] * np.exp(-par[0] * e) + par[2] * np.eye(n)
+        np.testing.assert_allclose(ll, multivariate_normal(mean=np.full(n, par[3]), cov=ky).logpdf(y), rtol=1e-11)
+        for k in range(4):
+            h = 1e-6 * max(1.0, abs(par[k]))
+            up, dn = par.copy(), par.copy()
+            up[k] += h
+            dn[k] -= h
+            fd = (ogp.marginal_log_likelihood(e, y, *up)[0] - ogp.marginal_log_likelihood(e, y, *dn)[0]) / (2 * h)
+            np.testing.assert_allclose(g[k], fd, rtol=2e-6, atol=1e-7)
