@@ -111,7 +111,7 @@ def test_matrix_function_gradients_and_reconstruction_costs_golden(golden):
         for name, fn in (("ai", nso.min_affine_invariant_distance_reconstruction_cost), ("le", nso.min_log_euclidean_distance_reconstruction_cost)):
             V, C, K = T(g[f"{tag}_V"], True), T(g[f"{tag}_C"], True), T(g[f"{tag}_K"], True)
             cost = fn(T(g[f"{tag}_X"]), T(g[f"{tag}_Y"]), T(g[f"{tag}_W"]), V, C, K)
-            np.testing.assert_allclose(float(cost), g[f"{tag}_{name}_cost"], rtol=2e-6)          # (the reference sums in float32)
+            np.testing.assert_allclose(cost.item(), g[f"{tag}_{name}_cost"], rtol=2e-6)          # (the reference sums in float32)
             cost.backward()
             np.testing.assert_allclose(V.grad.cpu().numpy(), g[f"{tag}_{name}_gV"], rtol=1e-4, atol=1e-5)
             np.testing.assert_allclose(0.5 * (C.grad + C.grad.T).cpu().numpy(), 0.5 * (g[f"{tag}_{name}_gC"] + g[f"{tag}_{name}_gC"].T),
