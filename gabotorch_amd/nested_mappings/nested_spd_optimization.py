@@ -40,34 +40,84 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
     dim, latent = x_data.shape[1], W.shape[1]
     manifold = Product([Grassmann(dim, dim - latent), PositiveDefinite(dim - latent), Sphere(latent * (dim - latent)), Euclidean(1)])
 
-    def to_torch(params, grad=False):
-        return [torch.tensor(np.asarray(p), dtype=dt, device=dev, requires_grad=grad) for p in params]
+    shapes = [(dim, dim - latent), (dim - latent, dim - latent), (latent * (dim - latent),), (1,)]
+    sizes = [int(np.prod(sh)) for sh in shapes]
+
+    def to_torch(params, grad=False, device=dev):
+        # one host-to-device copy for the four factors
+        flat = torch.from_numpy(np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1) for p in params])).to(device)
+        parts = [t.reshape(sh) for t, sh in zip(torch.split(flat, sizes), shapes)]
+        return [t.requires_grad_(True) for t in parts] if grad else parts
+
+    # what does not depend on the parameters is evaluated once: logm of the data (log-Euclidean cost) and sqrtm of the latent points
+    from .. import _lib, ops
+    sqrt_low = ops.spd_matrix_function(x_data_projected, _lib.GABO_SPD_SQRTM).to(dt)
+    if cost_function is min_log_euclidean_distance_reconstruction_cost:
+        log_data = logm_torch(x_data)
+
+        def data_cost(V, C, K):
+            x_rec = projection_from_nested_spd_to_spd(x_data_projected, W, V, C, K, sqrt_low=sqrt_low)
+            diff = log_data - logm_torch(x_rec) + 1e-15
+            return torch.sum(diff * diff)
+    elif cost_function is min_affine_invariant_distance_reconstruction_cost:
+        def data_cost(V, C, K):
+            x_rec = projection_from_nested_spd_to_spd(x_data_projected, W, V, C, K, sqrt_low=sqrt_low)
+            dist = affine_invariant_distance_torch(x_data[:, None], x_rec[:, None])
+            return torch.sum(dist * dist)
+    else:
+        def data_cost(V, C, K):
+            return cost_function(x_data, x_data_projected, W, V, C, K)
 
     def cost_torch(p):
         norm = torch.sigmoid(p[3])                                       # gpytorch Interval(0, 1).transform   (:139,155)
         K = norm * p[2].reshape(latent, dim - latent)
-        return cost_function(x_data, x_data_projected, W, p[0], p[1], K)
+        return data_cost(p[0], p[1], K)
+
+    W_host = W.cpu()
 
     def constraint_torch(p):
-        return torch.norm(p[0].T @ W)                                    # W^T V = 0   (:142-147)
+        return torch.norm(p[0].T @ W_host)                               # W^T V = 0   (:142-147); a few hundred flops: host
 
-    def value_and_egrad(fn):
-        def vg(x):
-            p = to_torch(x, grad=True)
-            v = fn(p)
-            grads = torch.autograd.grad(v, p, allow_unused=True)
-            return float(v.detach()), [np.zeros(np.shape(xi)) if g is None else g.detach().cpu().numpy().reshape(np.shape(xi))
-                                       for g, xi in zip(grads, x)]
-        return vg
+    class _Evaluator:
+        """value / (value, Euclidean gradient) of fn at a point, remembering the last point: the augmented Lagrangian asks for the
+        cost and the gradient of the same point separately, and line searches only need values (no autograd graph)."""
+
+        def __init__(self, fn, device):
+            self.fn, self.device, self.key, self.value, self.grads = fn, device, None, None, None
+
+        def _at(self, x):
+            key = b"".join(np.ascontiguousarray(p, dtype=np.float64).tobytes() for p in x)
+            if key != self.key:
+                self.key, self.value, self.grads = key, None, None
+
+        def cost(self, x):
+            self._at(x)
+            if self.value is None:
+                with torch.no_grad():
+                    self.value = float(self.fn(to_torch(x, device=self.device)))
+            return self.value
+
+        def __call__(self, x):
+            self._at(x)
+            if self.grads is None:
+                p = to_torch(x, grad=True, device=self.device)
+                v = self.fn(p)
+                grads = torch.autograd.grad(v, p, allow_unused=True)
+                flat = torch.cat([torch.zeros_like(pi).reshape(-1) if g is None else g.reshape(-1) for g, pi in zip(grads, p)]).cpu().numpy()
+                self.value = float(v.detach())
+                self.grads = [a.reshape(np.shape(xi)) for a, xi in zip(np.split(flat, np.cumsum(sizes)[:-1]), x)]
+            return self.value, self.grads
 
     class _Problem:
         pass
     problem = _Problem()
     problem.manifold = manifold
-    cost_vg = value_and_egrad(cost_torch)
-    problem.cost = lambda x: cost_vg(x)[0]
+    cost_vg = _Evaluator(cost_torch, dev)
+    problem.cost = cost_vg.cost
     problem.grad = lambda x: manifold.egrad2rgrad(x, cost_vg(x)[1])
-    constraint = _Constraint(manifold, value_and_egrad(constraint_torch))
+    con_vg = _Evaluator(constraint_torch, "cpu")
+    constraint = _Constraint(manifold, con_vg)
+    constraint.cost = con_vg.cost
     with torch.no_grad():
         cands = [manifold.rand() for _ in range(nb_init_candidates)]
         vals = [float(cost_torch(to_torch(c))) for c in cands]

@@ -10,11 +10,12 @@ def projection_from_spd_to_nested_spd(x_spd, projection_matrix):
 
 
 def projection_from_nested_spd_to_spd(x_spd_low_dimension, projection_matrix, projection_complement_matrix, bottom_spd_matrix,
-                                      contraction_matrix):
+                                      contraction_matrix, sqrt_low=None):
     """Approximate right inverse of `projection_from_spd_to_nested_spd` (nested_spd_utils.py:51-118): with R = [W, V],
     Xr = [[Y, B], [B^T, C]], B = Y^1/2 K C^1/2, X = R Xr R^T.  Y: (d, d) or (N, d, d).  The matrix square roots are one
     batched HIP launch (GABO_SPD_SQRTM, differentiable through gabo_spd_matfun_backward); the block assembly and the two small
-    products are torch on the inputs' device."""
+    products are torch on the inputs' device.  sqrt_low (extension): Y^1/2 when the caller already has it (the reconstruction
+    optimiser evaluates this map thousands of times for fixed Y)."""
     import torch
 
     from .. import _lib
@@ -27,7 +28,10 @@ def projection_from_nested_spd_to_spd(x_spd_low_dimension, projection_matrix, pr
     C, K = bottom_spd_matrix.to(dev, dt), contraction_matrix.to(dev, dt)
     R = torch.cat((W, V), dim=1)
     sqrt_c = ops.spd_matrix_function(C, _lib.GABO_SPD_SQRTM).to(dt)        # differentiable (reconstruction costs, f4)
-    sqrt_y = ops.spd_matrix_function(y, _lib.GABO_SPD_SQRTM).to(dt)
+    if sqrt_low is None:
+        sqrt_y = ops.spd_matrix_function(y, _lib.GABO_SPD_SQRTM).to(dt)
+    else:
+        sqrt_y = (sqrt_low.unsqueeze(0) if sqrt_low.dim() == 2 else sqrt_low).to(dev, dt)
     side = sqrt_y @ K @ sqrt_c
     n = y.shape[0]
     top = torch.cat((y, side), dim=2)

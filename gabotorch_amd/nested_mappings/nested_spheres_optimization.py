@@ -43,7 +43,11 @@ def optimize_reconstruction_parameters_nested_sphere(x_data, x_subsphere, sphere
         pass
     problem = _Problem()
     problem.manifold = manifold
-    problem.cost = lambda x: value_and_egrad(x)[0]
+
+    def value_only(x):                 # line searches and the candidate screening need no autograd graph
+        with torch.no_grad():
+            return float(cost_torch([torch.tensor(np.asarray(xi), dtype=dt, device=dev) for xi in x]))
+    problem.cost = value_only
     problem.grad = lambda x: manifold.egrad2rgrad(x, value_and_egrad(x)[1])
     cands = [manifold.rand() for _ in range(nb_init_candidates)]
     vals = [problem.cost(c) for c in cands]
