@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gabotorch_amd import _lib, ops
+from gabotorch_amd import ops
 from tools.dev_bench import timeit
 from tools.sweep_bench import mandel
 n, D, d = 4096, 20, 2

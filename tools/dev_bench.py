@@ -1,8 +1,8 @@
 """Development timing of the pairwise kernels through the C ABI (not the graded bench; see bench.py)."""
-import sys, time
+import sys
 import numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gabotorch_amd import _lib, ops
+from gabotorch_amd import ops
 
 def spd_set(n, d, seed=1234):
     rng = np.random.default_rng(seed)

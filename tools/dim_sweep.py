@@ -1,7 +1,7 @@
 """Gram throughput of the SPD affine-invariant kernel versus the matrix dimension (N = 4096, all N^2 pairs; forward and backward)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from gabotorch_amd import ops
 from tools.dev_bench import spd_set, timeit
 ops.set_error_checking(False)

@@ -1,6 +1,6 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import gabotorch_amd.manifold_optimization.manifold_optimize as mo
 from tools import sweep_bench
 T = {}

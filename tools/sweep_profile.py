@@ -1,7 +1,7 @@
 """Host-side phase timing of the graph-replay sweep (warm): where the remaining milliseconds go."""
 import os, sys, time, json, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from tools.sweep_bench import run_sweep
 from gabotorch_amd.manifold_optimization import batched_trust_regions as btr, manifold_optimize as mo
 
