@@ -96,56 +96,99 @@ static __device__ void lds_congruence(const double* A, const double* B, double* 
     lds_mm(T, A, C, d, false, true);
 }
 
-// Cyclic Jacobi: A (symmetric, full storage) -> diagonal; V = eigenvectors in columns (V may be null: eigenvalues only).
-// cs: 2 doubles of LDS.
+// LDS scratch (doubles) lds_jacobi needs next to the matrices: (c, s) and the index pair of up to 16 concurrent rotations (d <= 32)
+constexpr int kJacobiScratch = 40;
+
+// pair (p < q) of slot s in round r of the circle-method schedule over np + 1 players (np odd); q may be the padding player
+static __device__ __forceinline__ void jacobi_pair(int r, int s, int np, int& p, int& q) {
+    const int a = (s == 0) ? np : (r + s) % np;
+    const int b = (s == 0) ? r : (r - s + np) % np;
+    p = a < b ? a : b;
+    q = a < b ? b : a;
+}
+
+// Jacobi eigen-decomposition: A (symmetric, full storage) -> diagonal; V = eigenvectors in columns (V may be null: eigenvalues
+// only).  cs: kJacobiScratch doubles of LDS.  The block is ONE wave of 64 threads (all callers).
+// Parallel ordering: a sweep is d-1 (d even) or d (d odd) rounds of floor(d/2) rotations on disjoint index pairs (round-robin
+// tournament), so a round costs three barrier phases - angles, columns of all pairs, rows of all pairs - instead of four per
+// single rotation: at d = 20 a sweep is 57 phases, not 760.  Rotations of one round commute exactly (disjoint rows/columns).
 static __device__ void lds_jacobi(double* A, double* V, double* cs, int d) {
     if (V) {
         for (int e = threadIdx.x; e < d * d; e += blockDim.x) V[e] = (e / d == e % d) ? 1.0 : 0.0;
     }
     wsync();
+    const int np = (d + (d & 1)) - 1, half = (d + (d & 1)) / 2;
+    int* pq = reinterpret_cast<int*>(cs + 32);       // 16 ints: (p << 8) | q of each slot of the round, -1 = idle
     for (int sweep = 0; sweep < 15; ++sweep) {
         double off = 0.0, dia = 0.0;
-        for (int r = 0; r < d; ++r) {
-            dia += A[r * d + r] * A[r * d + r];
-            for (int c = 0; c < r; ++c) off += A[r * d + c] * A[r * d + c];
+        for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
+            const int r = e / d, c = e - r * d;
+            const double x = A[e];
+            if (r == c) dia = __builtin_fma(x, x, dia);
+            else if (c < r) off = __builtin_fma(x, x, off);
         }
-        if (off <= 1e-33 * dia) break;   // uniform: every thread reads the same LDS values
-        for (int p = 0; p < d - 1; ++p) {
-            for (int q = p + 1; q < d; ++q) {
-                if (threadIdx.x == 0) {
-                    double apq = A[q * d + p], app = A[p * d + p], aqq = A[q * d + q];
-                    double h = aqq - app;
-                    double den = __builtin_fabs(h) + __builtin_sqrt(h * h + 4.0 * apq * apq);
+        for (int o = 32; o > 0; o >>= 1) {
+            off += __shfl_xor(off, o, 64);
+            dia += __shfl_xor(dia, o, 64);
+        }
+        if (off <= 1e-33 * dia) break;   // uniform: the butterfly leaves the same sums in every lane
+        for (int r = 0; r < np; ++r) {
+            if ((int)threadIdx.x < half) {
+                int p, q;
+                jacobi_pair(r, threadIdx.x, np, p, q);
+                double c = 1.0, sn = 0.0;
+                if (q < d) {
+                    const double apq = A[q * d + p], app = A[p * d + p], aqq = A[q * d + q];
+                    const double h = aqq - app;
+                    const double den = __builtin_fabs(h) + __builtin_sqrt(h * h + 4.0 * apq * apq);
                     double t = (den == 0.0) ? 0.0 : copysign_d(2.0 * apq, apq * h) / (den == 0.0 ? 1.0 : den);
                     if (h == 0.0) t = (apq == 0.0) ? 0.0 : copysign_d(1.0, apq);
-                    double c = 1.0 / __builtin_sqrt(t * t + 1.0);
-                    cs[0] = c;
-                    cs[1] = t * c;
+                    c = 1.0 / __builtin_sqrt(t * t + 1.0);
+                    sn = t * c;
+                } else {
+                    p = q = -1;          // the pair with the padding index sits out this round
                 }
-                wsync();
-                double c = cs[0], s = cs[1];
-                // columns p, q of A and V  (A <- A J)
-                for (int k = threadIdx.x; k < d; k += blockDim.x) {
-                    double akp = A[k * d + p], akq = A[k * d + q];
-                    A[k * d + p] = c * akp - s * akq;
-                    A[k * d + q] = s * akp + c * akq;
-                    if (V) {
-                        double vkp = V[k * d + p], vkq = V[k * d + q];
-                        V[k * d + p] = c * vkp - s * vkq;
-                        V[k * d + q] = s * vkp + c * vkq;
+                cs[2 * threadIdx.x] = c;
+                cs[2 * threadIdx.x + 1] = sn;
+                pq[threadIdx.x] = (p << 8) | (q & 0xff);
+            }
+            wsync();
+            // columns p, q of A and V for every pair of the round  (A <- A J): lane = (row group, pair), no integer division
+            {
+                const int sl = threadIdx.x & 15, k0 = threadIdx.x >> 4;
+                const int code = sl < half ? pq[sl] : -1;
+                if (code >= 0) {
+                    const int p = code >> 8, q = code & 0xff;
+                    const double c = cs[2 * sl], sn = cs[2 * sl + 1];
+                    for (int k = k0; k < d; k += 4) {
+                        const double akp = A[k * d + p], akq = A[k * d + q];
+                        A[k * d + p] = c * akp - sn * akq;
+                        A[k * d + q] = sn * akp + c * akq;
+                        if (V) {
+                            const double vkp = V[k * d + p], vkq = V[k * d + q];
+                            V[k * d + p] = c * vkp - sn * vkq;
+                            V[k * d + q] = sn * vkp + c * vkq;
+                        }
                     }
                 }
-                wsync();
-                // rows p, q of A  (A <- J^T A)
-                for (int k = threadIdx.x; k < d; k += blockDim.x) {
-                    double apk = A[p * d + k], aqk = A[q * d + k];
-                    A[p * d + k] = c * apk - s * aqk;
-                    A[q * d + k] = s * apk + c * aqk;
-                }
-                wsync();
-                if (threadIdx.x == 0) { A[p * d + q] = 0.0; A[q * d + p] = 0.0; }
-                wsync();
             }
+            wsync();
+            // rows p, q of A  (A <- J^T A): lane = (pair group, column); the rotated pair itself is annihilated exactly
+            {
+                const int k = threadIdx.x & 31;
+                if (k < d) {
+                    for (int sl = threadIdx.x >> 5; sl < half; sl += 2) {
+                        const int code = pq[sl];
+                        if (code < 0) continue;
+                        const int p = code >> 8, q = code & 0xff;
+                        const double c = cs[2 * sl], sn = cs[2 * sl + 1];
+                        const double apk = A[p * d + k], aqk = A[q * d + k];
+                        A[p * d + k] = (k == q) ? 0.0 : c * apk - sn * aqk;
+                        A[q * d + k] = (k == p) ? 0.0 : sn * apk + c * aqk;
+                    }
+                }
+            }
+            wsync();
         }
     }
 }

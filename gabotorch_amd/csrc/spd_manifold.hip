@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void spd_manifold_kernel(int op, const double* 
                                                           int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int dd = d * d;
-    double* M0 = lds;            // 6 matrices + 2 scalars
+    double* M0 = lds;            // 6 matrices + the Jacobi scratch
     double* M1 = M0 + dd;
     double* M2 = M1 + dd;
     double* M3 = M2 + dd;
@@ -455,7 +455,7 @@ int gabo_spd_manifold_op(int op, const double* a, const double* b, const double*
     if ((op == gabo::OP_INNER || op == gabo::OP_EHESS2RHESS) && !c) return GABO_ERR_ARG;
     if (op == gabo::OP_EHESS2RHESS && !e) return GABO_ERR_ARG;
     if (n > 0x7fffffffLL) return GABO_ERR_ARG;
-    size_t lds = (size_t)(6 * d * d + 2) * sizeof(double);
+    size_t lds = (size_t)(6 * d * d + gabo::kJacobiScratch) * sizeof(double);
     hipLaunchKernelGGL(gabo::spd_manifold_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
                        d, status);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
@@ -476,7 +476,7 @@ int gabo_spd_logm_mandel(const double* x_mandel, double* y_mandel, int64_t n, in
     if (d < 1 || d > 32) return GABO_ERR_DIM;
     if (n == 0) return GABO_OK;
     if (!x_mandel || !y_mandel || n > 0x7fffffffLL) return GABO_ERR_ARG;
-    size_t lds = (size_t)(3 * d * d + 2) * sizeof(double);
+    size_t lds = (size_t)(3 * d * d + gabo::kJacobiScratch) * sizeof(double);
     hipLaunchKernelGGL(gabo::spd_logm_mandel_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel, y_mandel, n, d);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
@@ -500,7 +500,7 @@ int gabo_spd_logm_mandel_backward(const double* x_mandel, const double* grad_y, 
     if (d < 1 || d > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
     if (n < 0 || (n > 0 && (!x_mandel || !grad_y || !grad_x))) return GABO_ERR_ARG;
     if (n == 0) return GABO_OK;
-    size_t lds = (size_t)(4 * d * d + 2) * sizeof(double);
+    size_t lds = (size_t)(4 * d * d + gabo::kJacobiScratch) * sizeof(double);
     hipLaunchKernelGGL(gabo::spd_logm_mandel_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel,
                        grad_y, grad_x, n, d);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
@@ -512,7 +512,7 @@ int gabo_spd_matfun_backward(int op, const double* a, const double* grad_out, do
     if (n < 0 || (n > 0 && (!a || !grad_out || !grad_a))) return GABO_ERR_ARG;
     if (n == 0) return GABO_OK;
     const int fn = op == GABO_SPD_LOGM ? gabo::FN_LOG : (op == GABO_SPD_EXPM ? gabo::FN_EXP : gabo::FN_SQRT);
-    size_t lds = (size_t)(4 * d * d + 2) * sizeof(double);
+    size_t lds = (size_t)(4 * d * d + gabo::kJacobiScratch) * sizeof(double);
     hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, a, grad_out, grad_a, n, d,
                        fn);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;

@@ -113,7 +113,7 @@ int launch_spd_ai_generic(const double* x1, const double* x2, double* out, doubl
     const int64_t dd = (int64_t)d * d;
     if (b1 * n1 > 0x7fffffffLL || batch * n1 * n2 > 0x7fffffffLL) return GABO_ERR_ARG;
     hipLaunchKernelGGL(spd_prep_generic_kernel, dim3((unsigned)(b1 * n1)), dim3(64), (size_t)(2 * dd) * 8, st, x1, ws, n1, s1, d, status);
-    hipLaunchKernelGGL((spd_pair_generic_kernel<false>), dim3((unsigned)(batch * n1 * n2)), dim3(64), (size_t)(5 * dd + 2) * 8, st, ws, x2,
+    hipLaunchKernelGGL((spd_pair_generic_kernel<false>), dim3((unsigned)(batch * n1 * n2)), dim3(64), (size_t)(5 * dd + kJacobiScratch) * 8, st, ws, x2,
                        out, dist_out, (const double*)nullptr, (double*)nullptr, n1, n2, d, (s1 == 0) ? (int64_t)0 : n1 * dd, s2,
                        (int64_t)0, (int64_t)0, (int64_t)0, beta, flags & ~GABO_SYMMETRIC);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
@@ -130,7 +130,7 @@ int launch_spd_ai_backward_generic(const double* x1, const double* x2, const dou
     hipLaunchKernelGGL(spd_prep_generic_kernel, dim3((unsigned)(b1 * n1)), dim3(64), (size_t)(2 * dd) * 8, st, x1, W, n1, s1, d, status);
     hipMemsetAsync(S, 0, (size_t)(batch * n1 * dd) * 8, st);
     if (n2 > 0)
-        hipLaunchKernelGGL((spd_pair_generic_kernel<true>), dim3((unsigned)(batch * n1 * n2)), dim3(64), (size_t)(5 * dd + 2) * 8, st, W,
+        hipLaunchKernelGGL((spd_pair_generic_kernel<true>), dim3((unsigned)(batch * n1 * n2)), dim3(64), (size_t)(5 * dd + kJacobiScratch) * 8, st, W,
                            x2, (double*)nullptr, (double*)nullptr, gout, S, n1, n2, d, (s1 == 0) ? (int64_t)0 : n1 * dd, s2, go_sb,
                            go_si, go_sj, beta, flags);
     hipLaunchKernelGGL(spd_bwd_finalize_generic_kernel, dim3((unsigned)(batch * n1)), dim3(64), (size_t)(4 * dd) * 8, st, W, S, gx, d,

@@ -110,7 +110,7 @@ __device__ __forceinline__ bool builtin_infeasible(const double* __restrict__ xp
 }
 
 // tCG + proposal + acquisition at the proposal for restart i (one wave).  gc/fc: host-evaluated constraints, or null with
-// `builtin` set (then the wave evaluates them itself).  mats: 5 D^2 + 2 doubles of LDS, dyn: 3 n doubles.
+// `builtin` set (then the wave evaluates them itself).  mats: 5 D^2 + kJacobiScratch doubles of LDS, dyn: 3 n doubles.
 template <int D, int METRIC>
 __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta,
                                                 const double* __restrict__ gc, const double* __restrict__ fc, const AcqParams& P,
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __rest
                                                             int maxinner, int* __restrict__ any_active, int* __restrict__ status) {
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
-    __shared__ __attribute__((aligned(16))) double mats[5 * dd + 2];
+    __shared__ __attribute__((aligned(16))) double mats[5 * dd + kJacobiScratch];
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
     if (i == 0 && threadIdx.x == 0) *any_active = 0;          // set again by the update kernel
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     static_assert(D <= 8, "built-in constraints use the register eigen-solver");
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
-    __shared__ __attribute__((aligned(16))) double mats[5 * dd + 2];
+    __shared__ __attribute__((aligned(16))) double mats[5 * dd + kJacobiScratch];
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
     if (active[i] == 0) return;
