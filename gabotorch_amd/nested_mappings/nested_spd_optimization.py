@@ -73,10 +73,23 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
         K = norm * p[2].reshape(latent, dim - latent)
         return data_cost(p[0], p[1], K)
 
-    W_host = W.cpu()
+    W_host = W.cpu().numpy()
 
-    def constraint_torch(p):
-        return torch.norm(p[0].T @ W_host)                               # W^T V = 0   (:142-147); a few hundred flops: host
+    class _OrthogonalityConstraint:
+        """||V^T W||_F = 0 (W^T V = 0, :142-147) and its Euclidean gradient W (W^T V) / ||V^T W||_F with respect to V, in numpy: a
+        few hundred flops on a host-resident parameter (a torch CPU call here costs milliseconds of thread-pool wake-up on a
+        many-core host, a device launch a round trip)."""
+
+        @staticmethod
+        def cost(x):
+            return float(np.linalg.norm(np.asarray(x[0]).T @ W_host))
+
+        def __call__(self, x):
+            V = np.asarray(x[0], dtype=np.float64)
+            wtv = W_host.T @ V
+            value = float(np.linalg.norm(wtv))
+            gV = (W_host @ wtv) / value if value > 0.0 else np.zeros_like(V)
+            return value, [gV] + [np.zeros(np.shape(xi)) for xi in x[1:]]
 
     class _Evaluator:
         """value / (value, Euclidean gradient) of fn at a point, remembering the last point: the augmented Lagrangian asks for the
@@ -115,7 +128,7 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
     cost_vg = _Evaluator(cost_torch, dev)
     problem.cost = cost_vg.cost
     problem.grad = lambda x: manifold.egrad2rgrad(x, cost_vg(x)[1])
-    con_vg = _Evaluator(constraint_torch, "cpu")
+    con_vg = _OrthogonalityConstraint()
     constraint = _Constraint(manifold, con_vg)
     constraint.cost = con_vg.cost
     with torch.no_grad():
