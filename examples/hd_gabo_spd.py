@@ -41,7 +41,16 @@ from gabotorch_amd.Riemannian_utils.spd_utils_torch import (symmetric_matrix_to_
                                                             vector_to_symmetric_matrix_mandel_torch)
 
 
-def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:0", verbose=True, fit_iters=50, rec_iters=6):
+def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:0", verbose=True, fit_iters=50, rec_iters=6,
+        timings=None):
+    """timings: optional dict; the wall-clock seconds of the phases of every iteration are appended to its lists."""
+    import time
+
+    def lap(name, since):
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings.setdefault(name, []).append(time.perf_counter() - since)
+        return time.perf_counter()
     np.random.seed(seed)
     torch.manual_seed(seed)
     big = manifolds.PositiveDefinite(dim)
@@ -60,11 +69,13 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
     ops.set_error_checking(False)
     best = [float(y_data.min())]
     for it in range(iters):
+        tick = time.perf_counter()
         y_std = (y_data - y_data.mean()) / (y_data.std() + 1e-12)
         model = models.SingleTaskGP(x_data, y_std, k_fct, noise_prior=models.GammaPrior(1.1, 0.05))
         fit_gpytorch_manifold(model, solver=ConjugateGradient(maxiter=fit_iters), nb_init_candidates=20)           # :205
         W = k_fct.base_kernel.projection_matrix.detach().clone().to(device)
         z_data = ops.spd_project(x_data, W)                                          # latent Mandel vectors, one launch
+        tick = lap("surrogate_fit", tick)
         if rec_iters > 0:                                                            # (:229-232)
             V, bottom, contraction = optimize_reconstruction_parameters_nested_spd(
                 vector_to_symmetric_matrix_mandel_torch(x_data), vector_to_symmetric_matrix_mandel_torch(z_data), W,
@@ -72,6 +83,7 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
                 maxiter=rec_iters)
         else:
             V = torch.linalg.svd(W, full_matrices=True)[0][:, latent:]              # orthonormal complement of span(W)
+        tick = lap("reconstruction", tick)
         latent_kernel = SpdLogEuclideanGaussianKernel().double()
         latent_kernel.lengthscale = k_fct.base_kernel.lengthscale.detach().clone()   # same hyper-parameters (:217-219)
         # constraints and raw samples of the latent optimisation are stated in the ORIGINAL space (:239-256)
@@ -88,12 +100,14 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
                                         options={"device": device}, inequality_constraints=cons,
                                         pre_processing_manifold=vector_to_symmetric_matrix_mandel_torch,
                                         post_processing_manifold=symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
+        tick = lap("latent_sweep", tick)
         x_new_mat = projection_from_nested_spd_to_spd(vector_to_symmetric_matrix_mandel_torch(z_new[0]), W, V, bottom, contraction)
         x_new = symmetric_matrix_to_vector_mandel_torch(x_new_mat)[None]
         y_new = objective(x_new[0]).reshape(-1).to(device)
         x_data = torch.cat([x_data, x_new.detach()])
         y_data = torch.cat([y_data, y_new])
         best.append(float(y_data.min()))
+        lap("objective", tick)
         if verbose:
             print(f"Iteration {it}\t Best f {best[-1]:.6f}")
     ops.set_error_checking(True)
