@@ -123,6 +123,11 @@ __global__ __launch_bounds__(64) void spd_manifold_kernel(int op, const double* 
             lds_jacobi(M0, M1, cs, d);
             lds_fun_from_eig(M0, M1, M2, d, op == OP_LOGM ? FN_LOG : (op == OP_EXPM ? FN_EXP : FN_SQRT));
             lds_store(M2, out + i * dd, d);
+            if (out2) {          // hand the eigen-decomposition to gabo_spd_matfun_backward_eig: V (d x d), then the d eigenvalues
+                double* eg = out2 + i * (dd + d);
+                for (int k = threadIdx.x; k < dd; k += blockDim.x) eg[k] = M1[k];
+                for (int k = threadIdx.x; k < d; k += blockDim.x) eg[dd + k] = M0[k * d + k];
+            }
             break;
         }
         case OP_EIGMAX:
@@ -276,8 +281,11 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_backward_kernel(const doub
 // Adjoint of the Frechet derivative of a primary matrix function f in {log, exp, sqrt} at the symmetric matrix A, matrices in and
 // out: out = V ((V^T sym(G) V) o F) V^T with F_kl the divided differences of f at the eigenvalues (F_kk = f').  This is what autograd
 // through logm_torch / sqrtm_torch (spd_utils_torch.py:13-50) computes, in the form that stays finite at repeated eigenvalues.
-__global__ __launch_bounds__(64) void spd_matfun_backward_kernel(const double* __restrict__ a, const double* __restrict__ g,
-                                                                 double* __restrict__ out, int64_t n, int d, int fn) {
+// eig != nullptr: the eigen-decomposition saved by the forward launch (n x (d^2 + d): V, then the eigenvalues) replaces the Jacobi
+// solve of `a`, which is most of this kernel's time.
+__global__ __launch_bounds__(64) void spd_matfun_backward_kernel(const double* __restrict__ a, const double* __restrict__ eig,
+                                                                 const double* __restrict__ g, double* __restrict__ out, int64_t n,
+                                                                 int d, int fn) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int dd = d * d;
     double* M0 = lds;
@@ -286,11 +294,18 @@ __global__ __launch_bounds__(64) void spd_matfun_backward_kernel(const double* _
     double* M3 = M2 + dd;
     double* cs = M3 + dd;
     const int64_t i = blockIdx.x;
-    lds_load(a + i * dd, M0, d);
-    lds_symmetrize(M0, M3, d);
     lds_load(g + i * dd, M2, d);
     lds_symmetrize(M2, M3, d);
-    lds_jacobi(M0, M1, cs, d);                  // M0 = diag(lambda), M1 = V
+    if (eig) {
+        const double* eg = eig + i * (dd + d);
+        for (int k = threadIdx.x; k < dd; k += blockDim.x) M1[k] = eg[k];
+        for (int k = threadIdx.x; k < d; k += blockDim.x) M0[k * d + k] = eg[dd + k];
+        wsync();
+    } else {
+        lds_load(a + i * dd, M0, d);
+        lds_symmetrize(M0, M3, d);
+        lds_jacobi(M0, M1, cs, d);              // M0 = diag(lambda), M1 = V
+    }
     lds_mm(M1, M2, M3, d, true, false);         // V^T G
     lds_mm(M3, M1, M2, d, false, false);        // V^T G V
     for (int e = threadIdx.x; e < dd; e += blockDim.x) {
@@ -513,8 +528,21 @@ int gabo_spd_matfun_backward(int op, const double* a, const double* grad_out, do
     if (n == 0) return GABO_OK;
     const int fn = op == GABO_SPD_LOGM ? gabo::FN_LOG : (op == GABO_SPD_EXPM ? gabo::FN_EXP : gabo::FN_SQRT);
     size_t lds = (size_t)(4 * d * d + gabo::kJacobiScratch) * sizeof(double);
-    hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, a, grad_out, grad_a, n, d,
-                       fn);
+    hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, a, (const double*)nullptr,
+                       grad_out, grad_a, n, d, fn);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_spd_matfun_backward_eig(int op, const double* eig, const double* grad_out, double* grad_a, int64_t n, int d,
+                                 gabo_stream_t stream) {
+    if (d < 1 || d > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
+    if (op != GABO_SPD_LOGM && op != GABO_SPD_EXPM && op != GABO_SPD_SQRTM) return GABO_ERR_ARG;
+    if (n < 0 || (n > 0 && (!eig || !grad_out || !grad_a))) return GABO_ERR_ARG;
+    if (n == 0) return GABO_OK;
+    const int fn = op == GABO_SPD_LOGM ? gabo::FN_LOG : (op == GABO_SPD_EXPM ? gabo::FN_EXP : gabo::FN_SQRT);
+    size_t lds = (size_t)(4 * d * d + gabo::kJacobiScratch) * sizeof(double);
+    hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, (const double*)nullptr,
+                       eig, grad_out, grad_a, n, d, fn);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

@@ -341,7 +341,12 @@ def spd_manifold_op(op, a, b=None, c=None, e=None, want_grad=False):
     n = A.numel() // (d * d) if d else 0
     scalar = op in (_lib.GABO_SPD_INNER, _lib.GABO_SPD_NORM, _lib.GABO_SPD_DIST, _lib.GABO_SPD_EIGMAX, _lib.GABO_SPD_EIGMIN)
     out = torch.empty(shape[:-2] if scalar else shape, dtype=torch.float64, device=dev)
-    out2 = torch.empty(shape, dtype=torch.float64, device=dev) if (want_grad and scalar) else None
+    matfun = op in (_lib.GABO_SPD_LOGM, _lib.GABO_SPD_EXPM, _lib.GABO_SPD_SQRTM)
+    out2 = None
+    if want_grad and scalar:
+        out2 = torch.empty(shape, dtype=torch.float64, device=dev)               # v v^T of the extreme eigenvalue
+    elif want_grad and matfun:
+        out2 = torch.empty(shape[:-2] + (d * d + d,), dtype=torch.float64, device=dev)      # V and the eigenvalues, for the backward
     status = torch.zeros(2, dtype=torch.int32, device=dev)
     ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
     with torch.cuda.device(dev):
@@ -350,7 +355,7 @@ def spd_manifold_op(op, a, b=None, c=None, e=None, want_grad=False):
     _lib.check(rc, "gabo_spd_manifold_op")
     _raise_if_not_spd(status, "gabo_spd_manifold_op")
     if out2 is not None:
-        return out.to(out_device), out2.to(out_device)
+        return out.to(out_device), (out2 if matfun else out2.to(out_device))
     return out.to(out_device)
 
 
@@ -359,24 +364,25 @@ class _SpdMatFun(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, op):
-        ctx.save_for_backward(a)
-        ctx.op = int(op)
-        return spd_manifold_op(int(op), a).to(a.dtype)
+        # the forward launch hands its eigen-decomposition (device-resident) to the backward: no second eigen-solve
+        out, eig = spd_manifold_op(int(op), a, want_grad=True)
+        ctx.save_for_backward(eig)
+        ctx.op, ctx.shape, ctx.device, ctx.dtype = int(op), tuple(a.shape), a.device, a.dtype
+        return out.to(a.dtype)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        (a,) = ctx.saved_tensors
+        (eig,) = ctx.saved_tensors
         lib = _lib.load()
-        dev = _device_for(a, g)
-        A = _prep(a, dev).contiguous()
-        G = _prep(g, dev).expand(A.shape).contiguous()
-        d = A.shape[-1]
-        out = torch.empty_like(A)
+        dev = eig.device
+        d = ctx.shape[-1]
+        G = _prep(g, dev).expand(eig.shape[:-1] + (d, d)).contiguous()
+        out = torch.empty_like(G)
         with torch.cuda.device(dev):
-            _lib.check(lib.gabo_spd_matfun_backward(ctx.op, A.data_ptr(), G.data_ptr(), out.data_ptr(), A.numel() // (d * d), d,
-                                                    _stream_ptr(dev)), "gabo_spd_matfun_backward")
-        return out.to(a.device, a.dtype), None
+            _lib.check(lib.gabo_spd_matfun_backward_eig(ctx.op, eig.data_ptr(), G.data_ptr(), out.data_ptr(), G.numel() // (d * d), d,
+                                                        _stream_ptr(dev)), "gabo_spd_matfun_backward_eig")
+        return out.reshape(ctx.shape).to(ctx.device, ctx.dtype), None
 
 
 def spd_matrix_function(a, op):

@@ -122,6 +122,8 @@ int gabo_matrix_to_mandel(const double* mat, double* vec, int64_t n, int d, gabo
  *   GABO_SPD_EGRAD2RGRAD  out = X sym(G) X                 a=X b=G        [3P] (pymanopt_addons/problem.py:135)
  *   GABO_SPD_EHESS2RHESS  out = X sym(H) X + sym(U sym(G) X)  a=X b=G c=H e=U   [3P] (problem.py:156)
  *   GABO_SPD_LOGM/EXPM/SQRTM  out = f(A)                   a=A            spd_utils_torch.py:13-50 ; tools/multi.py:55-75
+ *                             out2 (NULL to skip) = the eigen-decomposition, n x (d*d + d): V row-major, then the d eigenvalues;
+ *                             gabo_spd_matfun_backward_eig takes it instead of solving the eigen-problem again
  *   GABO_SPD_EIGMAX/EIGMIN    out[n] = extreme eigenvalue, out2 = v v^T (NULL to skip)   spd_constraints_utils_torch.py:17-50
  * status: device int[2] as above (non-SPD base point) or NULL.
  */
@@ -168,6 +170,9 @@ int gabo_frobenius_pairwise(const double* x1, const double* x2, double* out, int
  * Replaces autograd through logm_torch / sqrtm_torch (spd_utils_torch.py:13-50), e.g. in the reconstruction costs of
  * nested_mappings/nested_spd_optimization.py:23-92. */
 int gabo_spd_matfun_backward(int op, const double* a, const double* grad_out, double* grad_a, int64_t n, int d, gabo_stream_t stream);
+/* The same from the eigen-decomposition the forward call wrote to out2 (`eig`: n x (d*d + d)): no eigen-solve, four small products. */
+int gabo_spd_matfun_backward_eig(int op, const double* eig, const double* grad_out, double* grad_a, int64_t n, int d,
+                                 gabo_stream_t stream);
 int gabo_spd_logm_mandel_backward(const double* x_mandel, const double* grad_y, double* grad_x, int64_t n, int d,
                                   gabo_stream_t stream);
 int gabo_frobenius_backward(const double* x1, const double* x2, const double* grad_out, double* grad_x1, int64_t batch, int64_t n1,

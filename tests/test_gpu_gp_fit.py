@@ -288,3 +288,23 @@ def test_nested_kernels_do_not_take_the_fast_fit():
     X = torch.tensor(ospd.symmetric_matrix_to_vector_mandel(_rand_spd(rng, 6, 4)), device=DEV)
     gp = models.SingleTaskGP(X, torch.tensor(rng.standard_normal(6), device=DEV), ScaleKernel(NestedSpdLogEuclideanGaussianKernel(4, 2)))
     assert gp._fast_mll_closure() is None
+
+
+def test_matrix_function_backward_from_saved_eigen_decomposition_matches_the_standalone_entry():
+    """gabo_spd_matfun_backward_eig (what autograd uses: the forward launch's V, lambda) against gabo_spd_matfun_backward (solves the
+    eigen-problem again) for log / exp / sqrt, incl. a repeated eigenvalue and the largest dimension."""
+    from gabotorch_amd import _lib, ops
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for d in (1, 2, 5, 20, 32):
+        a = _rand_spd(rng, 6, d)
+        a[0] = 1.7 * np.eye(d)                                  # repeated eigenvalues: the divided differences must stay finite
+        A = torch.tensor(a, device=DEV)
+        G = torch.tensor(rng.standard_normal(a.shape), device=DEV)
+        for op in (_lib.GABO_SPD_LOGM, _lib.GABO_SPD_EXPM, _lib.GABO_SPD_SQRTM):
+            x = A.clone().requires_grad_(True)
+            (ops.spd_matrix_function(x, op) * G).sum().backward()
+            want = torch.empty_like(A)
+            _lib.check(lib.gabo_spd_matfun_backward(op, A.data_ptr(), G.data_ptr(), want.data_ptr(), 6, d,
+                                                    torch.cuda.current_stream().cuda_stream), "gabo_spd_matfun_backward")
+            np.testing.assert_allclose(x.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-11, atol=1e-12)
