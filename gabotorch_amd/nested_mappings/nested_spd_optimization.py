@@ -32,9 +32,9 @@ def min_log_euclidean_distance_reconstruction_cost(x_data, x_data_projected, pro
 
 def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, projection_matrix, inner_solver,
                                                   cost_function=min_affine_invariant_distance_reconstruction_cost,
-                                                  nb_init_candidates=100, maxiter=50):
+                                                  nb_init_candidates=100, maxiter=50, hip_graphs=True):
     """-> (projection_complement_matrix D x (D-d), bottom_spd_matrix (D-d) x (D-d), contraction_matrix d x (D-d))
-    (nested_spd_optimization.py:95-186)."""
+    (nested_spd_optimization.py:95-186).  hip_graphs (extension): replay the evaluations of the two built-in costs from hipGraphs."""
     dev, dt = x_data.device, torch.float64
     x_data, x_data_projected, W = x_data.to(dt), x_data_projected.to(dev, dt), projection_matrix.to(dev, dt)
     dim, latent = x_data.shape[1], W.shape[1]
@@ -42,12 +42,6 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
 
     shapes = [(dim, dim - latent), (dim - latent, dim - latent), (latent * (dim - latent),), (1,)]
     sizes = [int(np.prod(sh)) for sh in shapes]
-
-    def to_torch(params, grad=False, device=dev):
-        # one host-to-device copy for the four factors
-        flat = torch.from_numpy(np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1) for p in params])).to(device)
-        parts = [t.reshape(sh) for t, sh in zip(torch.split(flat, sizes), shapes)]
-        return [t.requires_grad_(True) for t in parts] if grad else parts
 
     # what does not depend on the parameters is evaluated once: logm of the data (log-Euclidean cost) and sqrtm of the latent points
     from .. import _lib, ops
@@ -93,47 +87,85 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
 
     class _Evaluator:
         """value / (value, Euclidean gradient) of fn at a point, remembering the last point: the augmented Lagrangian asks for the
-        cost and the gradient of the same point separately, and line searches only need values (no autograd graph)."""
+        cost and the gradient of the same point separately, and line searches only need values (no autograd graph).
+        graphs=True: an evaluation is a fixed sequence of ~40 small launches on fixed shapes (two eigen-solves, a dozen products,
+        their adjoints), so both variants are captured once into hipGraphs (torch.cuda.CUDAGraph) on a static parameter buffer and
+        replayed: one host-to-device copy, one graph launch and one read-back per evaluation instead of ~40 eager launches."""
 
-        def __init__(self, fn, device):
+        def __init__(self, fn, device, graphs=False):
             self.fn, self.device, self.key, self.value, self.grads = fn, device, None, None, None
+            self.graphs = bool(graphs) and torch.device(device).type == "cuda"
+            self._captured = {}
 
         def _at(self, x):
             key = b"".join(np.ascontiguousarray(p, dtype=np.float64).tobytes() for p in x)
             if key != self.key:
                 self.key, self.value, self.grads = key, None, None
 
+        def _eval(self, flat, with_grad):
+            parts = [t.reshape(sh) for t, sh in zip(torch.split(flat, sizes), shapes)]
+            if not with_grad:
+                with torch.no_grad():
+                    return self.fn(parts).reshape(1)
+            parts = [t.requires_grad_(True) for t in parts]
+            v = self.fn(parts)
+            grads = torch.autograd.grad(v, parts, allow_unused=True)
+            return torch.cat([v.detach().reshape(1)] + [torch.zeros_like(pi).reshape(-1) if g is None else g.reshape(-1)
+                                                        for g, pi in zip(grads, parts)])
+
+        def _run(self, x, with_grad):
+            host = torch.from_numpy(np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1) for p in x]))
+            if not self.graphs:
+                return self._eval(host.to(self.device), with_grad).cpu().numpy()
+            ent = self._captured.get(with_grad)
+            if ent is None:
+                previous = ops.set_error_checking(False)          # the status read-back would synchronise inside the capture
+                try:
+                    static_in = host.to(self.device)
+                    side = torch.cuda.Stream(device=self.device)
+                    side.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(side):
+                        for _ in range(3):                          # warm-up outside capture (lazy caches, allocator)
+                            self._eval(static_in, with_grad)
+                    torch.cuda.current_stream(self.device).wait_stream(side)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        out = self._eval(static_in, with_grad)
+                finally:
+                    ops.set_error_checking(previous)
+                ent = self._captured[with_grad] = (graph, static_in, out)
+            graph, static_in, out = ent
+            static_in.copy_(host)
+            graph.replay()
+            return out.cpu().numpy()
+
         def cost(self, x):
             self._at(x)
             if self.value is None:
-                with torch.no_grad():
-                    self.value = float(self.fn(to_torch(x, device=self.device)))
+                self.value = float(self._run(x, False)[0])
             return self.value
 
         def __call__(self, x):
             self._at(x)
             if self.grads is None:
-                p = to_torch(x, grad=True, device=self.device)
-                v = self.fn(p)
-                grads = torch.autograd.grad(v, p, allow_unused=True)
-                flat = torch.cat([torch.zeros_like(pi).reshape(-1) if g is None else g.reshape(-1) for g, pi in zip(grads, p)]).cpu().numpy()
-                self.value = float(v.detach())
-                self.grads = [a.reshape(np.shape(xi)) for a, xi in zip(np.split(flat, np.cumsum(sizes)[:-1]), x)]
+                flat = self._run(x, True)
+                self.value = float(flat[0])
+                self.grads = [a.reshape(np.shape(xi)) for a, xi in zip(np.split(flat[1:], np.cumsum(sizes)[:-1]), x)]
             return self.value, self.grads
 
     class _Problem:
         pass
     problem = _Problem()
     problem.manifold = manifold
-    cost_vg = _Evaluator(cost_torch, dev)
+    builtin_cost = cost_function in (min_log_euclidean_distance_reconstruction_cost, min_affine_invariant_distance_reconstruction_cost)
+    cost_vg = _Evaluator(cost_torch, dev, graphs=hip_graphs and builtin_cost)      # (a user cost may synchronise: eager)
     problem.cost = cost_vg.cost
     problem.grad = lambda x: manifold.egrad2rgrad(x, cost_vg(x)[1])
     con_vg = _OrthogonalityConstraint()
     constraint = _Constraint(manifold, con_vg)
     constraint.cost = con_vg.cost
-    with torch.no_grad():
-        cands = [manifold.rand() for _ in range(nb_init_candidates)]
-        vals = [float(cost_torch(to_torch(c))) for c in cands]
+    cands = [manifold.rand() for _ in range(nb_init_candidates)]
+    vals = [cost_vg.cost(c) for c in cands]
     x0 = cands[int(np.argmin(vals))]
     solver = AugmentedLagrangeMethod(maxiter=maxiter, inner_solver=inner_solver, lambdas_fact=0.05)
     opt = solver.solve(problem, x=x0, eq_constraints=[constraint])
