@@ -97,7 +97,7 @@ def run(dim=5, latent=2, iters=10, restarts=5, raw=100, seed=1234, device="cuda:
                             mean=float(model.mean_constant.detach()))
         acq = models.ExpectedImprovement(gp, best_f=float(y_std.min()), maximize=False)
         z_new = joint_optimize_manifold(acq, small, solver, q=1, num_restarts=restarts, raw_samples=raw, bounds=None,
-                                        options={"device": device}, inequality_constraints=cons,
+                                        options={"device": device, "hip_graphs": True}, inequality_constraints=cons,
                                         pre_processing_manifold=vector_to_symmetric_matrix_mandel_torch,
                                         post_processing_manifold=symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
         tick = lap("latent_sweep", tick)

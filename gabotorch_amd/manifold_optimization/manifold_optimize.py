@@ -96,6 +96,18 @@ def joint_optimize_manifold(acq_function, manifold, solver, q, num_restarts, raw
     return best
 
 
+def _library_constraint(con):
+    """functools.partial over one of the library's eigenvalue constraints (plain or stated in the original space of a nested
+    SPD mapping): torch code without host synchronisation, safe to capture into the hipGraphs of the trust-region iteration."""
+    import functools
+
+    from ..nested_mappings import nested_spd_constraints_utils as nested
+    from ..Riemannian_utils import spd_constraints_utils_torch as plain
+    return isinstance(con, functools.partial) and con.func in (
+        plain.max_eigenvalue_constraint_torch, plain.min_eigenvalue_constraint_torch,
+        nested.max_eigenvalue_nested_spd_constraint, nested.min_eigenvalue_nested_spd_constraint)
+
+
 def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, solver, pre_processing_manifold=None,
                             post_processing_manifold=None, lower_bounds=None, upper_bounds=None, inequality_constraints=None,
                             equality_constraints=None, approx_hessian=False, solver_init_conds=False, options=None):
@@ -134,8 +146,10 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
     problem.device_outer = bool((options or {}).get("device_outer", True))
     problem.device_iteration = bool((options or {}).get("device_iteration", True))
     problem.device_solve = bool((options or {}).get("device_solve", True))
-    # the constraint callables are user code: they run eagerly between graph replays unless the caller states they are capturable
-    problem.capture_constraints = bool((options or {}).get("capture_constraints", False))
+    # the constraint callables are user code: they run eagerly between graph replays unless the caller states they are capturable -
+    # or they are this library's own eigenvalue constraints with their bounds bound by functools.partial (sync-free by construction)
+    cons = list(equality_constraints or []) + list(inequality_constraints or [])
+    problem.capture_constraints = bool((options or {}).get("capture_constraints", bool(cons) and all(_library_constraint(c) for c in cons)))
     if solver_init_conds:
         x0 = torch.stack([torch.as_tensor(manifold.rand()) for _ in range(x0.shape[0])]).to(x0)
     if equality_constraints is not None or inequality_constraints is not None:
