@@ -57,6 +57,7 @@ SIGNATURES = {
     "gabo_frobenius_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _P]),
     "gabo_gp_acquisition": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _D, _D, _D, _D, _I, _I, _D, _P]),
     "gabo_gp_mll": (_I, [_P, _P, _I64, _D, _D, _D, _D, _P, _P]),
+    "gabo_gp_mll_gram": (_I, [_P, _P, _I64, _D, _D, _D, _P, _P, _P]),
     "gabo_spd_acq_max_train": (_I64, [_I]),
     "gabo_spd_acq_prepare_train": (_I, [_P, _P, _I64, _I, _P, _P]),
     "gabo_spd_acq_eval": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _D, _I, _D, _D, _D, _D, _I, _I, _D, _P, _P, _P]),

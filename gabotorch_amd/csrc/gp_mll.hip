@@ -38,7 +38,7 @@ static __device__ __forceinline__ double mll_block_sum(double v, double* red) {
 template <int THREADS, int MAXE>
 __global__ __launch_bounds__(THREADS) void gp_mll_kernel(const double* __restrict__ e, const double* __restrict__ y, int n,
                                                          double theta, double os, double noise, double mean,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, int gram, double* __restrict__ w_out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = n + 1;
     double* col0 = lds;           // m + 1: the pivot column of the current sweep (entry k is the pivot itself; entry m is padding)
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(THREADS) void gp_mll_kernel(const double* __restric
             const int j = idx - ltri_i(i);
             ij[q] = (i << 16) | j;
             if (i < n)
-                v[q] = os * exp(-theta * e[(int64_t)i * n + j]) + (i == j ? noise : 0.0);
+                v[q] = os * (gram ? e[(int64_t)i * n + j] : exp(-theta * e[(int64_t)i * n + j])) + (i == j ? noise : 0.0);
             else
                 v[q] = (j < n) ? y[j] - mean : 0.0;
             if (j == 0) col0[i] = v[q];
@@ -147,7 +147,11 @@ __global__ __launch_bounds__(THREADS) void gp_mll_kernel(const double* __restric
             const int i = ij[q] >> 16, j = ij[q] & 0xffff;
             const double w = __builtin_fma(al[i], al[j], v[q]);
             const double eij = e[(int64_t)i * n + j];
-            const double kb = exp(-theta * eij);
+            const double kb = gram ? eij : exp(-theta * eij);
+            if (w_out) {
+                w_out[(int64_t)i * n + j] = w;
+                w_out[(int64_t)j * n + i] = w;
+            }
             const double wgt = (i == j) ? 1.0 : 2.0;
             acc_kb = __builtin_fma(wgt * w, kb, acc_kb);
             acc_e = __builtin_fma(wgt * w, eij * kb, acc_e);
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(THREADS) void gp_mll_kernel(const double* __restric
     acc_tr = mll_block_sum<THREADS>(acc_tr, red);
     if (t == 0) {
         out[0] = -0.5 * quad - 0.5 * logdet - 0.5 * (double)n * 1.8378770664093453;      // log(2 pi)
-        out[1] = -0.5 * os * acc_e;
+        out[1] = gram ? 0.0 : -0.5 * os * acc_e;
         out[2] = 0.5 * acc_kb;
         out[3] = 0.5 * acc_tr;
         out[4] = alpha_sum;
@@ -169,26 +173,37 @@ __global__ __launch_bounds__(THREADS) void gp_mll_kernel(const double* __restric
 
 template <int THREADS, int MAXE>
 static void launch_mll(const double* e, const double* y, int n, double theta, double os, double noise, double mean, double* out,
-                       hipStream_t st) {
+                       int gram, double* w_out, hipStream_t st) {
     const size_t lds = (size_t)(2 * (n + 2) + 2 * n + THREADS / 64) * sizeof(double);
-    hipLaunchKernelGGL((gp_mll_kernel<THREADS, MAXE>), dim3(1), dim3(THREADS), lds, st, e, y, n, theta, os, noise, mean, out);
+    hipLaunchKernelGGL((gp_mll_kernel<THREADS, MAXE>), dim3(1), dim3(THREADS), lds, st, e, y, n, theta, os, noise, mean, out,
+                       gram, w_out);
 }
 
 }  // namespace gabo
 
-extern "C" int gabo_gp_mll(const double* e, const double* y, int64_t n, double theta, double outputscale, double noise, double mean,
-                           double* out, gabo_stream_t stream) {
+static int gp_mll_dispatch(const double* e, const double* y, int64_t n, double theta, double outputscale, double noise, double mean,
+                           double* out, int gram, double* w_out, gabo_stream_t stream) {
     if (n < 1 || n > GABO_GP_MLL_MAX_N) return GABO_ERR_DIM;
     if (!e || !y || !out) return GABO_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int64_t pairs = (n + 1) * (n + 2) / 2;      // packed entries of the bordered matrix
     if (pairs <= 256 * 2)              // n <= 30
-        gabo::launch_mll<256, 2>(e, y, (int)n, theta, outputscale, noise, mean, out, st);
+        gabo::launch_mll<256, 2>(e, y, (int)n, theta, outputscale, noise, mean, out, gram, w_out, st);
     else if (pairs <= 256 * 8)         // n <= 62
-        gabo::launch_mll<256, 8>(e, y, (int)n, theta, outputscale, noise, mean, out, st);
+        gabo::launch_mll<256, 8>(e, y, (int)n, theta, outputscale, noise, mean, out, gram, w_out, st);
     else if (pairs <= 512 * 13)        // n <= 113
-        gabo::launch_mll<512, 13>(e, y, (int)n, theta, outputscale, noise, mean, out, st);
+        gabo::launch_mll<512, 13>(e, y, (int)n, theta, outputscale, noise, mean, out, gram, w_out, st);
     else                               // n <= 160 (GABO_GP_MLL_MAX_N): 26 entries per thread is what 256 VGPRs hold without spilling
-        gabo::launch_mll<512, 26>(e, y, (int)n, theta, outputscale, noise, mean, out, st);
+        gabo::launch_mll<512, 26>(e, y, (int)n, theta, outputscale, noise, mean, out, gram, w_out, st);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+extern "C" int gabo_gp_mll(const double* e, const double* y, int64_t n, double theta, double outputscale, double noise, double mean,
+                           double* out, gabo_stream_t stream) {
+    return gp_mll_dispatch(e, y, n, theta, outputscale, noise, mean, out, 0, nullptr, stream);
+}
+
+extern "C" int gabo_gp_mll_gram(const double* k, const double* y, int64_t n, double outputscale, double noise, double mean, double* out,
+                                double* w, gabo_stream_t stream) {
+    return gp_mll_dispatch(k, y, n, 0.0, outputscale, noise, mean, out, 1, w, stream);
 }

@@ -177,6 +177,32 @@ class GammaPrior:
         return max((self.concentration - 1.0) / self.rate, 0.0)
 
 
+class _ExactMll(torch.autograd.Function):
+    """log N(y | mean, outputscale * K + noise * I) for a base Gram matrix K on the device: forward and the whole gradient in one
+    gabo_gp_mll_gram launch (d ll / d K = outputscale * W / 2 with W = alpha alpha^T - Ky^-1).  A Gram matrix that is not positive
+    definite gives -inf (and zero gradients) instead of an exception: the fit's line searches then reject the point."""
+
+    @staticmethod
+    def forward(ctx, kbase, y, outputscale, noise, mean):
+        from . import ops
+        out, w = ops.gp_mll_gram(kbase.detach(), y.detach(), outputscale.item(), noise.item(), mean.item())
+        ctx.save_for_backward(out, w)
+        ctx.os = outputscale.item()
+        ctx.host = [(t.device, t.dtype) for t in (outputscale, noise, mean)]
+        return torch.where(out[5] > 0, torch.full_like(out[0], -math.inf), out[0])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        out, w = ctx.saved_tensors
+        ok = (out[5] == 0).to(out.dtype)
+        scalars = (g * ok * out[2:5])
+        gk = (g * ok * 0.5 * ctx.os) * w
+        if any(dev_.type == "cpu" for dev_, _ in ctx.host):
+            scalars = scalars.cpu()                       # one read-back for the three host-resident hyper-parameters
+        return (gk, None) + tuple(scalars[i].to(dev_, dt_) for i, (dev_, dt_) in enumerate(ctx.host))
+
+
 class SingleTaskGP(torch.nn.Module):
     """Constant-mean exact GP with a Gaussian likelihood and trainable hyper-parameters, laid out like the models of the
     reference examples (examples/gabo_spd.py:165-176: ScaleKernel(base, outputscale_prior=Gamma(2, .15)), noise prior
@@ -215,7 +241,23 @@ class SingleTaskGP(torch.nn.Module):
         return total
 
     def marginal_log_likelihood(self):
-        """(log p(y | X) + log priors) / n, the quantity gpytorch's ExactMarginalLogLikelihood returns [3P]."""
+        """(log p(y | X) + log priors) / n, the quantity gpytorch's ExactMarginalLogLikelihood returns [3P].
+        Up to GABO_GP_MLL_MAX_N training points the likelihood and its gradient with respect to the Gram matrix, outputscale, noise
+        and mean are ONE launch (gabo_gp_mll_gram) behind a custom autograd node, so autograd only has to differentiate the kernel
+        itself (its own HIP backward); above that, torch's Cholesky / solve."""
+        from . import _lib
+        cm = self.covar_module
+        scaled = hasattr(cm, "base_kernel") and type(cm).__name__ == "ScaleKernel" and cm.raw_outputscale.numel() == 1
+        kb = (cm.base_kernel if scaled else cm).forward(self.train_x, self.train_x)
+        if kb.is_cuda and kb.dim() == 2 and kb.shape[-1] <= _lib.GABO_GP_MLL_MAX_N:
+            os_ = cm.outputscale.double().reshape(()) if scaled else torch.ones((), dtype=torch.float64)
+            ll = _ExactMll.apply(kb.double(), self.train_y.to(kb.device), os_, self.noise.reshape(()), self.mean_constant.reshape(()))
+            pri = self._priors()
+            return (ll + (pri.to(ll.device) if torch.is_tensor(pri) else pri)) / kb.shape[-1]
+        return self._marginal_log_likelihood_torch()
+
+    def _marginal_log_likelihood_torch(self):
+        """The same through torch.linalg (any size; the path the launch above is tested against)."""
         k = self._kxx()
         n = k.shape[-1]
         L = torch.linalg.cholesky(k)
@@ -443,7 +485,10 @@ def fit_gpytorch_model(model, maxiter=200, fast=True):
             return 1e10, np.zeros_like(v)
         g = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().double().reshape(-1).numpy()
                             for p in params])
-        return float(loss.item()), g
+        value = float(loss.item())
+        if not math.isfinite(value):  # (the one-launch likelihood reports a matrix that is not positive definite as -inf)
+            return 1e10, np.zeros_like(v)
+        return value, g
 
     x0 = np.concatenate([p.detach().cpu().double().reshape(-1).numpy() for p in params])
     res = minimize(fun, x0, jac=True, method="L-BFGS-B", options={"maxiter": maxiter})

@@ -609,6 +609,24 @@ def gp_mll(e, y, theta, outputscale, noise, mean):
     return out.tolist()
 
 
+def gp_mll_gram(k, y, outputscale, noise, mean, want_w=True):
+    """gabo_gp_mll_gram: exact-GP marginal log likelihood for Ky = outputscale * k + noise * I with k an arbitrary base Gram matrix
+    (n x n fp64 on a HIP device, n <= GABO_GP_MLL_MAX_N).  -> (out (6,) device tensor: ll, 0, dll/doutputscale, dll/dnoise, dll/dmean,
+    not-positive-definite flag;  W = alpha alpha^T - Ky^-1 (n x n) or None).  No host synchronisation."""
+    lib = _lib.load()
+    dev = k.device
+    n = k.shape[-1]
+    if k.dim() != 2 or k.shape[0] != n or y.numel() != n:
+        raise RuntimeError("gp_mll_gram: k must be an n x n matrix and y a vector of n targets")
+    k, y = k.contiguous(), y.contiguous()
+    out = torch.empty(6, dtype=torch.float64, device=dev)
+    w = torch.empty(n, n, dtype=torch.float64, device=dev) if want_w else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_gp_mll_gram(k.data_ptr(), y.data_ptr(), n, float(outputscale), float(noise), float(mean), out.data_ptr(),
+                                        None if w is None else w.data_ptr(), _stream_ptr(dev)), "gabo_gp_mll_gram")
+    return out, w
+
+
 def spd_acq_prepare_train(train_mandel):
     """Entry-major Cholesky factors of the training matrices for spd_acq_eval (d_vec x n)."""
     lib = _lib.load()

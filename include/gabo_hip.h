@@ -211,6 +211,12 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
 #define GABO_GP_MLL_MAX_N 160
 int gabo_gp_mll(const double* e, const double* y, int64_t n, double theta, double outputscale, double noise, double mean,
                 double* out, gabo_stream_t stream);
+/* The same for a Gram matrix that is not of the exp(-theta E) form (kernels with parameters inside the distance: the nested kernels
+ * fitted by fit_gpytorch_manifold, manifold_gp_fit.py:54-222): k = BASE kernel matrix (n x n, lower triangle read),
+ * Ky = outputscale * k + noise * I.  out as above with out[1] = 0; w (NULL to skip) receives W = alpha alpha^T - Ky^-1 (n x n), so that
+ * d out[0] / d k = outputscale * W / 2 chains into the kernel's own backward - no Cholesky / solve / log-det autograd. */
+int gabo_gp_mll_gram(const double* k, const double* y, int64_t n, double outputscale, double noise, double mean, double* out, double* w,
+                     gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * n random SPD matrices with the distribution of spd_sample (Riemannian_utils/spd_utils.py:290-306; the raw samples of

@@ -308,3 +308,41 @@ def test_matrix_function_backward_from_saved_eigen_decomposition_matches_the_sta
             _lib.check(lib.gabo_spd_matfun_backward(op, A.data_ptr(), G.data_ptr(), want.data_ptr(), 6, d,
                                                     torch.cuda.current_stream().cuda_stream), "gabo_spd_matfun_backward")
             np.testing.assert_allclose(x.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-11, atol=1e-12)
+
+
+def test_one_launch_likelihood_node_matches_the_torch_linalg_path():
+    """marginal_log_likelihood (gabo_gp_mll_gram behind a custom autograd node) against the same quantity through torch.linalg's
+    Cholesky / solve and autograd, for plain and nested kernels (parameters inside the distance), with and without ScaleKernel."""
+    rng = np.random.default_rng(8)
+    makers = _plain_models(rng)[:1] + _plain_models(rng)[3:5] + _plain_models(rng)[6:]
+    X = torch.tensor(ospd.symmetric_matrix_to_vector_mandel(_rand_spd(rng, 12, 4)), device=DEV)
+    y = torch.tensor(rng.standard_normal(12), device=DEV)
+    makers.append(lambda: models.SingleTaskGP(X, y, ScaleKernel(NestedSpdLogEuclideanGaussianKernel(4, 2)).double(),
+                                              noise_prior=models.GammaPrior(1.1, 0.05)))
+    for make in makers:
+        gp = make()
+        with torch.no_grad():
+            for p in gp.parameters():
+                if p.numel() == 1:
+                    p.add_(0.2)
+        a = gp.marginal_log_likelihood()
+        a.backward()
+        got = [None if p.grad is None else p.grad.clone() for p in gp.parameters()]
+        for p in gp.parameters():
+            p.grad = None
+        b = gp._marginal_log_likelihood_torch()
+        b.backward()
+        np.testing.assert_allclose(float(a), float(b), rtol=1e-11)
+        for p, w in zip(gp.parameters(), got):
+            assert (w is None) == (p.grad is None)
+            if w is not None:
+                np.testing.assert_allclose(w.numpy(), p.grad.numpy(), rtol=2e-6, atol=1e-9)
+
+
+def test_one_launch_likelihood_reports_indefinite_gram_matrices_as_minus_infinity():
+    k = torch.tensor([[1.0, 2.0], [2.0, 1.0]], dtype=torch.float64, device=DEV, requires_grad=True)      # indefinite "kernel"
+    one = torch.ones((), dtype=torch.float64)
+    ll = models._ExactMll.apply(k, torch.zeros(2, dtype=torch.float64, device=DEV), one, 0.1 * one, 0.0 * one)
+    assert float(ll) == -np.inf
+    ll.backward()
+    assert float(k.grad.abs().max()) == 0.0
