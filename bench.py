@@ -342,6 +342,28 @@ def main():
                                                 "frac": pairs_per_step * 8.04 / (sph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "model": "8.04 algorithmic B/pair (one fp64 output + amortised operand reads)"},
                                    "max_abs_err_vs_oracle_block": sph_err}
+            # the step before the sweep in a BO iteration: surrogate fit (fit_gpytorch_model), 50 observations on S^5_++
+            import time as _time
+            from gabotorch_amd import models as _models
+            from gabotorch_amd._compat import ScaleKernel as _Scale
+            from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel as _AiKernel
+            fx_ = torch.tensor(synthetic_spd_mandel(50, 5, 99), device=device)
+            fy_ = torch.tensor(np.random.default_rng(99).standard_normal(50), device=device)
+            fit_ms = {}
+            for label, fast in (("one_launch_per_evaluation", True), ("autograd_through_the_kernels", False)):
+                best_t = float("inf")
+                for _ in range(3):
+                    gp_ = _models.SingleTaskGP(fx_, fy_, _Scale(_AiKernel(beta_min=0.25), outputscale_prior=_models.GammaPrior(2.0, 0.15)),
+                                               noise_prior=_models.GammaPrior(1.1, 0.05))
+                    torch.cuda.synchronize()
+                    t0_ = _time.perf_counter()
+                    _models.fit_gpytorch_model(gp_, fast=fast)
+                    torch.cuda.synchronize()
+                    best_t = min(best_t, _time.perf_counter() - t0_)
+                fit_ms[label] = best_t * 1e3
+            line["surrogate_fit"] = {"workload": "fit_gpytorch_model: SingleTaskGP(ScaleKernel(SpdAffineInvariantGaussianKernel)), 50 "
+                                                 "observations on S^5_++, Gamma priors, L-BFGS-B (gabo_gp_mll: likelihood + analytic "
+                                                 "gradient in one launch per evaluation)", "ms": fit_ms}
         if world == 1 and not args.no_cpu_baseline:
             cb, kcpu = cpu_baseline(x)
             cb["max_rel_diff_gpu_vs_cpu_port"] = float(np.max(np.abs(job.out[:kcpu.shape[0]].cpu().numpy() - kcpu) / np.abs(kcpu)))
