@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Randomised parity soak: pairwise kernels, their gradients and the manifold operations against the numpy oracle on random shapes.
+    python tools/soak_parity.py [--cases 150] [--seed 0]     (oracle = test infrastructure; this tool is a test driver)"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gabotorch_amd import _lib, ops                       # noqa: E402
+from oracle import sphere as osph                         # noqa: E402
+from oracle import spd as ospd                            # noqa: E402
+
+
+def rand_spd(rng, shape, d, lo=0.05, hi=5.0):
+    n = int(np.prod(shape))
+    q = np.linalg.qr(rng.standard_normal((n, d, d)))[0]
+    m = np.einsum("nab,nb,ncb->nac", q, rng.uniform(lo, hi, (n, d)), q)
+    return (0.5 * (m + m.transpose(0, 2, 1))).reshape(*shape, d, d)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    dev = "cuda:0"
+    worst = {}
+
+    def note(tag, err):
+        worst[tag] = max(worst.get(tag, 0.0), float(err))
+
+    for case in range(a.cases):
+        d = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16]))
+        n1, n2 = int(rng.integers(1, 70)), int(rng.integers(1, 140))
+        batch = () if rng.random() < 0.6 else (int(rng.integers(1, 4)),)
+        A, B = rand_spd(rng, batch + (n1,), d), rand_spd(rng, batch + (n2,), d)
+        x1, x2 = ospd.symmetric_matrix_to_vector_mandel(A), ospd.symmetric_matrix_to_vector_mandel(B)
+        beta = float(rng.uniform(0.1, 1.5))
+        mode = int(rng.choice([_lib.GABO_OUT_GAUSSIAN, _lib.GABO_OUT_LAPLACE, _lib.GABO_OUT_DISTANCE]))
+        t1, t2 = torch.tensor(x1, device=dev), torch.tensor(x2, device=dev)
+        got = ops.spd_ai_pairwise(t1, t2, beta, mode).cpu().numpy()
+        dist = ospd.affine_invariant_distance(A, B)
+        want = dist if mode == _lib.GABO_OUT_DISTANCE else np.exp(-beta * (dist ** 2 if mode == _lib.GABO_OUT_GAUSSIAN else dist))
+        note(f"spd_fwd_mode{mode}", np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300)))
+        if d <= 12 and rng.random() < 0.5:
+            go = rng.standard_normal(got.shape)
+            g = ops.spd_ai_backward(t1, t2, torch.tensor(go, device=dev), beta, mode, wrt=1).cpu().numpy()
+            h = 1e-6
+            k = tuple(int(rng.integers(0, s)) for s in x1.shape)
+            xp, xm = x1.copy(), x1.copy()
+            xp[k] += h
+            xm[k] -= h
+            fp = ops.spd_ai_pairwise(torch.tensor(xp, device=dev), t2, beta, mode).cpu().numpy()
+            fm = ops.spd_ai_pairwise(torch.tensor(xm, device=dev), t2, beta, mode).cpu().numpy()
+            fd = ((fp - fm) * go).sum() / (2 * h)
+            note("spd_bwd_fd", abs(g[k] - fd) / max(1.0, abs(fd)))
+        # sphere
+        dim = int(rng.integers(2, 60))
+        s1 = rng.standard_normal(batch + (n1, dim))
+        s2 = rng.standard_normal(batch + (n2, dim))
+        s1 /= np.linalg.norm(s1, axis=-1, keepdims=True)
+        s2 /= np.linalg.norm(s2, axis=-1, keepdims=True)
+        if rng.random() < 0.3:
+            s2[..., 0, :] = s1[..., 0, :]              # an identical pair: the clamp edge
+        gs = ops.sphere_pairwise(torch.tensor(s1, device=dev), torch.tensor(s2, device=dev), beta, _lib.GABO_OUT_GAUSSIAN).cpu().numpy()
+        note("sphere_fwd", np.max(np.abs(gs - osph.sphere_gaussian_kernel(s1, s2, beta))))
+        # manifold ops: logm / expm round trip and log / exp maps
+        M = torch.tensor(rand_spd(rng, (5,), d), device=dev)
+        lg = ops.spd_manifold_op(_lib.GABO_SPD_LOGM, M)
+        note("expm_logm_roundtrip", (ops.spd_manifold_op(_lib.GABO_SPD_EXPM, lg) - M).abs().max() / M.abs().max())
+        Y = torch.tensor(rand_spd(rng, (5,), d), device=dev)
+        U = ops.spd_manifold_op(_lib.GABO_SPD_LOG, M, Y)
+        note("exp_log_map_roundtrip", (ops.spd_manifold_op(_lib.GABO_SPD_EXP, M, U) - Y).abs().max() / Y.abs().max())
+    for k in sorted(worst):
+        print(f"{k:28s} worst {worst[k]:.2e}")
+    bad = {k: v for k, v in worst.items() if v > (1e-5 if "fd" in k else 1e-9)}
+    print("FAIL" if bad else "OK", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
