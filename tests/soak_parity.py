@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity soak: pairwise kernels, their gradients and the manifold operations against the numpy oracle on random shapes.
-    python tools/soak_parity.py [--cases 150] [--seed 0]     (oracle = test infrastructure; this tool is a test driver)"""
+    python tests/soak_parity.py [--cases 150] [--seed 0]     (a test driver, not collected by pytest: long randomised runs)"""
 import argparse
 import os
 import sys
