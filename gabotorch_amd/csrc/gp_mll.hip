@@ -11,20 +11,216 @@
 // The reference leaves this to autograd through the per-pair Python loop of the kernel on every evaluation.
 //
 // The problem is one small matrix, so the design target is latency, not throughput: one workgroup, the bordered matrix
-// [[Ky, r], [r^T, 0]] (packed lower triangle) distributed over the threads' REGISTERS, and the symmetric sweep operator
-// (Gauss-Jordan on the pivots 0..n-1: a_kk <- -1/p, a_ik <- a_ik/p, a_ij <- a_ij - a_ik a_jk/p) applied in place.  After the n
-// sweeps the matrix block holds -Ky^-1, the border holds alpha and the corner -r.alpha; the pivots are the Schur complements, so
-// log det(Ky) = sum log p_k and Ky is positive definite iff every p_k > 0.  One sweep is one barrier: only the pivot column
-// travels through LDS (double-buffered: the owners of the next pivot's row/column publish it while they update it).
+// [[Ky, r], [r^T, 0]] distributed over the threads' REGISTERS as 4 x 4 tiles of its lower triangle (one tile per thread, diagonal
+// tiles stored in full), and the symmetric sweep operator (Gauss-Jordan on the pivots 0..n-1: a_kk <- -1/p, a_ik <- a_ik/p,
+// a_ij <- a_ij - a_ik a_jk/p) applied in place.  After the n sweeps the matrix block holds -Ky^-1, the border holds alpha and the
+// corner -r.alpha; the pivots are the Schur complements, so log det(Ky) = sum log p_k and Ky is positive definite iff every p_k > 0.
+// One sweep is one barrier: only the pivot column travels through LDS (double-buffered).  A thread reads the 4 + 4 column entries of
+// its tile's rows and columns and does 16 FMAs, x_ab <- x_ab - g_a h_b with g = c_row / p, h = c_col.  The pivot row and column need no
+// special case in that update: their owners publish them for the next sweep one step ahead and ZERO their register copies, and the
+// sweep uses g = -1/p at the pivot row and h = -1 at the pivot column, which turns the same FMA into c_i / p, c_j / p and -1/p there.
 #include "gabo_device.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
 
+constexpr int kMllMaxThreads = 1024;
+
+static __device__ __forceinline__ double mll_block_sum(double v, double* red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+    return s;
+}
+
+// publish row R / column R of the tile as entries of the next pivot's column, then zero them (see the header comment)
+template <int R>
+static __device__ __forceinline__ void mll_publish(double (&x)[4][4], int I, int J, int kt1, double* __restrict__ nxt) {
+    if (J == kt1) {                       // the tile holds column k+1 (rows 4I .. 4I+3, the diagonal tile included)
+        static_for<4>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            nxt[4 * I + a] = x[a][R];
+            x[a][R] = 0.0;
+        });
+    }
+    if (I == kt1) {                       // the tile holds row k+1; columns left of the diagonal tile are published from here
+        static_for<4>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            if (J != kt1) nxt[4 * J + b] = x[R][b];
+            x[R][b] = 0.0;
+        });
+    }
+}
+
+// blockDim.x = number of tiles rounded up to whole waves; tile (I, J), I >= J, of thread t in row-major packed order
+__global__ __launch_bounds__(kMllMaxThreads) void gp_mll_kernel(const double* __restrict__ e, const double* __restrict__ y, int n,
+                                                               double theta, double os, double noise, double mean,
+                                                               double* __restrict__ out, int gram, double* __restrict__ w_out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int m = n + 1;                       // bordered matrix
+    const int nt = (m + 3) / 4, mp = 4 * nt;   // tiles per side, padded size
+    double* col0 = lds;            // mp: the pivot column of the current sweep (entry k is the pivot itself)
+    double* col1 = col0 + mp;      // mp: ... of the next sweep
+    double* piv = col1 + mp;       // n
+    double* al = piv + n;          // mp: alpha
+    double* red = al + mp;         // 16
+    const int t = threadIdx.x;
+    const int tiles = nt * (nt + 1) / 2;
+    const bool live = t < tiles;
+    int I = 0, J = 0;
+    if (live) {
+        I = (int)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        while (I * (I + 1) / 2 > t) --I;
+        J = t - I * (I + 1) / 2;
+    }
+    // every global load of the tile is issued before anything waits on one (clamped addresses instead of branches)
+    double x[4][4], ev[4][4], yv[4];
+    static_for<4>([&](auto bb) {
+        constexpr int b = decltype(bb)::value;
+        const int j = 4 * J + b;
+        yv[b] = y[j < n ? j : n - 1];
+    });
+    static_for<4>([&](auto aa) {
+        constexpr int a = decltype(aa)::value;
+        static_for<4>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            const int i = 4 * I + a, j = 4 * J + b;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            ev[a][b] = e[hi < n ? (int64_t)hi * n + lo : 0];
+        });
+    });
+    static_for<4>([&](auto aa) {
+        constexpr int a = decltype(aa)::value;
+        static_for<4>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            const int i = 4 * I + a, j = 4 * J + b;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            const double kern = os * (gram ? ev[a][b] : exp(-theta * ev[a][b])) + (i == j ? noise : 0.0);
+            // border row (hi == n; only lower tiles own it, so lo = j), corner, identity padding
+            const double ident = (i == j) ? 1.0 : 0.0;
+            const double other = (hi == n) ? ((lo < n) ? yv[i > j ? b : a] - mean : 0.0) : ident;      // (diagonal tiles: I == J)
+            x[a][b] = !live ? ident : (hi < n ? kern : other);
+        });
+    });
+    // column 0 for the first sweep, published and zeroed like every later one
+    if (live) mll_publish<0>(x, I, J, 0, col0);
+
+    bool bad = false;
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        const double* cur = (k & 1) ? col1 : col0;
+        double* nxt = (k & 1) ? col0 : col1;
+        const int kt = k >> 2, kr = k & 3;
+        double ci[4], cj[4];
+        static_for<4>([&](auto aa) {
+            ci[decltype(aa)::value] = cur[4 * I + decltype(aa)::value];
+            cj[decltype(aa)::value] = cur[4 * J + decltype(aa)::value];
+        });
+        const double p = cur[k];
+        if (!(p > 0.0)) {          // every thread reads the same value: the exit is uniform
+            bad = true;
+            break;
+        }
+        const double ip = rcp(p);
+        if (t == 0) piv[k] = p;
+        double g[4], h[4];
+        static_for<4>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            g[a] = (I == kt && a == kr) ? -ip : ci[a] * ip;
+            h[a] = (J == kt && a == kr) ? -1.0 : cj[a];
+        });
+        static_for<4>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            static_for<4>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                x[a][b] = __builtin_fma(-g[a], h[b], x[a][b]);
+            });
+        });
+        if (live) {
+            const int k1 = k + 1, kt1 = k1 >> 2;
+            switch (k1 & 3) {          // wave-uniform
+                case 0: mll_publish<0>(x, I, J, kt1, nxt); break;
+                case 1: mll_publish<1>(x, I, J, kt1, nxt); break;
+                case 2: mll_publish<2>(x, I, J, kt1, nxt); break;
+                default: mll_publish<3>(x, I, J, kt1, nxt); break;
+            }
+        }
+    }
+    if (bad) {
+        if (t == 0) {
+            out[0] = out[1] = out[2] = out[3] = out[4] = 0.0;
+            out[5] = 1.0;
+        }
+        return;
+    }
+    __syncthreads();
+    // The border row n was published as "row k+1" at the last sweep and zeroed in the registers: alpha is that column buffer
+    const double* fin = (n & 1) ? col1 : col0;
+    for (int i = t; i < mp; i += blockDim.x) al[i] = (i < n) ? fin[i] : 0.0;
+    const double quad = -fin[n];                  // corner: -r.alpha (every thread reads the same LDS word)
+    double part = 0.0, asum = 0.0;
+    __syncthreads();
+    for (int i = t; i < n; i += blockDim.x) {
+        part += log(piv[i]);
+        asum += al[i];
+    }
+    const double logdet = mll_block_sum(part, red);
+    const double alpha_sum = mll_block_sum(asum, red);
+
+    // traces of W = alpha alpha^T - Ky^-1 against exp(-theta E) and E o exp(-theta E); the matrix block holds -Ky^-1
+    double acc_kb = 0.0, acc_e = 0.0, acc_tr = 0.0;
+    static_for<4>([&](auto aa) {               // (reloaded rather than kept: 32 registers less during the sweeps)
+        constexpr int a = decltype(aa)::value;
+        static_for<4>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            const int i = 4 * I + a, j = 4 * J + b;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            ev[a][b] = e[hi < n ? (int64_t)hi * n + lo : 0];
+        });
+    });
+    if (live) {
+        static_for<4>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            static_for<4>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                const int i = 4 * I + a, j = 4 * J + b;
+                if (i < n && j < n && j <= i) {           // every unordered pair once (diagonal tiles hold both triangles)
+                    const double w = __builtin_fma(al[i], al[j], x[a][b]);
+                    const double eij = ev[a][b];
+                    const double kb = gram ? eij : exp(-theta * eij);
+                    if (w_out) {
+                        w_out[(int64_t)i * n + j] = w;
+                        w_out[(int64_t)j * n + i] = w;
+                    }
+                    const double wgt = (i == j) ? 1.0 : 2.0;
+                    acc_kb = __builtin_fma(wgt * w, kb, acc_kb);
+                    acc_e = __builtin_fma(wgt * w, eij * kb, acc_e);
+                    if (i == j) acc_tr += w;
+                }
+            });
+        });
+    }
+    acc_kb = mll_block_sum(acc_kb, red);
+    acc_e = mll_block_sum(acc_e, red);
+    acc_tr = mll_block_sum(acc_tr, red);
+    if (t == 0) {
+        out[0] = -0.5 * quad - 0.5 * logdet - 0.5 * (double)n * 1.8378770664093453;      // log(2 pi)
+        out[1] = gram ? 0.0 : -0.5 * os * acc_e;
+        out[2] = 0.5 * acc_kb;
+        out[3] = 0.5 * acc_tr;
+        out[4] = alpha_sum;
+        out[5] = 0.0;
+    }
+}
+
 static __device__ __forceinline__ int ltri_i(int r) { return r * (r + 1) / 2; }
 
 template <int THREADS>
-static __device__ __forceinline__ double mll_block_sum(double v, double* red) {
+static __device__ __forceinline__ double mll_small_block_sum(double v, double* red) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -34,9 +230,10 @@ static __device__ __forceinline__ double mll_block_sum(double v, double* red) {
     return s;
 }
 
-// MAXE: packed entries of the (n+1) x (n+1) bordered matrix owned by one thread (entry idx = e * THREADS + t)
+// Small training sets (n <= 30): the same sweeps with the packed lower triangle distributed entry by entry (MAXE entries per thread,
+// entry idx = q * THREADS + t) - the 4 x 4 tiles above would spend more on their 32 exponentials per thread than on the sweeps.
 template <int THREADS, int MAXE>
-__global__ __launch_bounds__(THREADS) void gp_mll_kernel(const double* __restrict__ e, const double* __restrict__ y, int n,
+__global__ __launch_bounds__(THREADS) void gp_mll_small_kernel(const double* __restrict__ e, const double* __restrict__ y, int n,
                                                          double theta, double os, double noise, double mean,
                                                          double* __restrict__ out, int gram, double* __restrict__ w_out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -130,14 +327,14 @@ __global__ __launch_bounds__(THREADS) void gp_mll_kernel(const double* __restric
                 quad_part = -v[q];
         }
     }
-    const double quad = mll_block_sum<THREADS>(quad_part, red);      // (its barriers also publish al and piv)
+    const double quad = mll_small_block_sum<THREADS>(quad_part, red);      // (its barriers also publish al and piv)
     double part = 0.0, asum = 0.0;
     for (int i = t; i < n; i += THREADS) {
         part += log(piv[i]);
         asum += al[i];
     }
-    const double logdet = mll_block_sum<THREADS>(part, red);
-    const double alpha_sum = mll_block_sum<THREADS>(asum, red);
+    const double logdet = mll_small_block_sum<THREADS>(part, red);
+    const double alpha_sum = mll_small_block_sum<THREADS>(asum, red);
 
     // traces of W = alpha alpha^T - Ky^-1 against exp(-theta E) and E o exp(-theta E); the matrix block holds -Ky^-1
     double acc_kb = 0.0, acc_e = 0.0, acc_tr = 0.0;
@@ -158,9 +355,9 @@ __global__ __launch_bounds__(THREADS) void gp_mll_kernel(const double* __restric
             if (i == j) acc_tr += w;
         }
     }
-    acc_kb = mll_block_sum<THREADS>(acc_kb, red);
-    acc_e = mll_block_sum<THREADS>(acc_e, red);
-    acc_tr = mll_block_sum<THREADS>(acc_tr, red);
+    acc_kb = mll_small_block_sum<THREADS>(acc_kb, red);
+    acc_e = mll_small_block_sum<THREADS>(acc_e, red);
+    acc_tr = mll_small_block_sum<THREADS>(acc_tr, red);
     if (t == 0) {
         out[0] = -0.5 * quad - 0.5 * logdet - 0.5 * (double)n * 1.8378770664093453;      // log(2 pi)
         out[1] = gram ? 0.0 : -0.5 * os * acc_e;
@@ -171,13 +368,6 @@ __global__ __launch_bounds__(THREADS) void gp_mll_kernel(const double* __restric
     }
 }
 
-template <int THREADS, int MAXE>
-static void launch_mll(const double* e, const double* y, int n, double theta, double os, double noise, double mean, double* out,
-                       int gram, double* w_out, hipStream_t st) {
-    const size_t lds = (size_t)(2 * (n + 2) + 2 * n + THREADS / 64) * sizeof(double);
-    hipLaunchKernelGGL((gp_mll_kernel<THREADS, MAXE>), dim3(1), dim3(THREADS), lds, st, e, y, n, theta, os, noise, mean, out,
-                       gram, w_out);
-}
 
 }  // namespace gabo
 
@@ -185,16 +375,18 @@ static int gp_mll_dispatch(const double* e, const double* y, int64_t n, double t
                            double* out, int gram, double* w_out, gabo_stream_t stream) {
     if (n < 1 || n > GABO_GP_MLL_MAX_N) return GABO_ERR_DIM;
     if (!e || !y || !out) return GABO_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t pairs = (n + 1) * (n + 2) / 2;      // packed entries of the bordered matrix
-    if (pairs <= 256 * 2)              // n <= 30
-        gabo::launch_mll<256, 2>(e, y, (int)n, theta, outputscale, noise, mean, out, gram, w_out, st);
-    else if (pairs <= 256 * 8)         // n <= 62
-        gabo::launch_mll<256, 8>(e, y, (int)n, theta, outputscale, noise, mean, out, gram, w_out, st);
-    else if (pairs <= 512 * 13)        // n <= 113
-        gabo::launch_mll<512, 13>(e, y, (int)n, theta, outputscale, noise, mean, out, gram, w_out, st);
-    else                               // n <= 160 (GABO_GP_MLL_MAX_N): 26 entries per thread is what 256 VGPRs hold without spilling
-        gabo::launch_mll<512, 26>(e, y, (int)n, theta, outputscale, noise, mean, out, gram, w_out, st);
+    if (n <= 30) {                                        // (n + 1)(n + 2) / 2 <= 512 packed entries: two per thread
+        const size_t lds_small = (size_t)(2 * (n + 2) + 2 * n + 4) * sizeof(double);
+        hipLaunchKernelGGL((gabo::gp_mll_small_kernel<256, 2>), dim3(1), dim3(256), lds_small, (hipStream_t)stream, e, y, (int)n, theta,
+                           outputscale, noise, mean, out, gram, w_out);
+        return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+    }
+    const int nt = (int)((n + 1 + 3) / 4);
+    const int tiles = nt * (nt + 1) / 2;                   // <= 861 at n = 160
+    const int threads = ((tiles + 63) / 64) * 64;
+    const size_t lds = (size_t)(3 * 4 * nt + n + 16) * sizeof(double);
+    hipLaunchKernelGGL(gabo::gp_mll_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, e, y, (int)n, theta, outputscale, noise,
+                       mean, out, gram, w_out);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
