@@ -35,7 +35,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks,
-                                                              int64_t sym_tiles, double beta, int flags) {
+                                                              int64_t sym_tiles, double beta, int flags, uint32_t dim_magic) {
     __shared__ double xs2[kSphereKC * kSphereLd];
     __shared__ double xs1[kSphereRows * kSphereKC];
     const int tid = threadIdx.x;
@@ -71,8 +71,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         if (k0) __syncthreads();
         if (kc == dim) {
             // whole points fit one pass: the tile is one contiguous run of ncols*dim doubles
+            // e / dim by multiply-high with dim_magic = ceil(2^32 / dim) (exact for e < 2^16): a runtime integer division is ~40
+            // VALU instructions and there are ten of them per thread here - a fifth of the kernel's instruction count
             for (int e = tid; e < ncols * dim; e += blockDim.x) {
-                int jj = e / dim, kk = e - jj * dim;
+                int jj = dim == 1 ? e : (int)__umulhi((uint32_t)e, dim_magic), kk = e - jj * dim;
                 xs2[kk * kSphereLd + jj] = bt[e];
             }
         } else {
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             }
         }
         for (int e = tid; e < nrows * kc; e += blockDim.x) {
-            int rr = e / kc, kk = e - rr * kc;
+            int rr = (kc == dim && dim > 1) ? (int)__umulhi((uint32_t)e, dim_magic) : e / kc, kk = e - rr * kc;
             xs1[rr * kSphereKC + kk] = a[(int64_t)rr * dim + k0 + kk];
         }
         __syncthreads();
@@ -199,9 +201,10 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
         int64_t nblocks = ((flags & GABO_SYMMETRIC) ? sym_tiles : col_blocks * row_chunks) * batch;
         if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
         const int mode = flags & GABO_OUT_MASK;
+        const uint32_t dim_magic = (uint32_t)((0x100000000ULL + (uint64_t)dim - 1) / (uint64_t)dim);     // ceil(2^32 / dim); dim = 1: unused
 #define GABO_SPH_LAUNCH(M)                                                                                                   \
     hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M>), dim3((unsigned)nblocks), dim3(threads), 0, st, x1, x2, out, n1, n2, \
-                       dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, sym_tiles, beta, flags)
+                       dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, sym_tiles, beta, flags, dim_magic)
         if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE);
         else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE);
         else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN);
