@@ -97,7 +97,7 @@ static __device__ void lds_congruence(const double* A, const double* B, double* 
 }
 
 // LDS scratch (doubles) lds_jacobi needs next to the matrices: (c, s) and the index pair of up to 16 concurrent rotations (d <= 32)
-constexpr int kJacobiScratch = 40;
+constexpr int kJacobiScratch = 48;
 
 // pair (p < q) of slot s in round r of the circle-method schedule over np + 1 players (np odd); q may be the padding player
 static __device__ __forceinline__ void jacobi_pair(int r, int s, int np, int& p, int& q) {
@@ -108,7 +108,8 @@ static __device__ __forceinline__ void jacobi_pair(int r, int s, int np, int& p,
 }
 
 // Jacobi eigen-decomposition: A (symmetric, full storage) -> diagonal; V = eigenvectors in columns (V may be null: eigenvalues
-// only).  cs: kJacobiScratch doubles of LDS.  The block is ONE wave of 64 threads (all callers).
+// only).  cs: kJacobiScratch doubles of LDS.  The block is one wave, or up to four (blockDim.x a multiple of 64, <= 256): above
+// d = 12 a round's 2 x d x d/2 work items are worth spreading over 256 threads.
 // Parallel ordering: a sweep is d-1 (d even) or d (d odd) rounds of floor(d/2) rotations on disjoint index pairs (round-robin
 // tournament), so a round costs three barrier phases - angles, columns of all pairs, rows of all pairs - instead of four per
 // single rotation: at d = 20 a sweep is 57 phases, not 760.  Rotations of one round commute exactly (disjoint rows/columns).
@@ -119,6 +120,8 @@ static __device__ void lds_jacobi(double* A, double* V, double* cs, int d) {
     wsync();
     const int np = (d + (d & 1)) - 1, half = (d + (d & 1)) / 2;
     int* pq = reinterpret_cast<int*>(cs + 32);       // 16 ints: (p << 8) | q of each slot of the round, -1 = idle
+    double* xw = cs + 40;                            // 8 doubles: per-wave partial sums when the block has more than one wave
+    const int kstep = blockDim.x >> 4, slstep = blockDim.x >> 5;
     for (int sweep = 0; sweep < 15; ++sweep) {
         double off = 0.0, dia = 0.0;
         for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
@@ -131,7 +134,22 @@ static __device__ void lds_jacobi(double* A, double* V, double* cs, int d) {
             off += __shfl_xor(off, o, 64);
             dia += __shfl_xor(dia, o, 64);
         }
-        if (off <= 1e-33 * dia) break;   // uniform: the butterfly leaves the same sums in every lane
+        if (blockDim.x > 64) {            // up to 4 waves: combine the per-wave sums in a fixed order (block-uniform result)
+            const int nw = blockDim.x >> 6;
+            if ((threadIdx.x & 63) == 0) {
+                xw[2 * (threadIdx.x >> 6)] = off;
+                xw[2 * (threadIdx.x >> 6) + 1] = dia;
+            }
+            wsync();
+            off = 0.0;
+            dia = 0.0;
+            for (int w = 0; w < nw; ++w) {
+                off += xw[2 * w];
+                dia += xw[2 * w + 1];
+            }
+            wsync();
+        }
+        if (off <= 1e-33 * dia) break;   // uniform: every thread holds the same sums
         for (int r = 0; r < np; ++r) {
             if ((int)threadIdx.x < half) {
                 int p, q;
@@ -160,7 +178,7 @@ static __device__ void lds_jacobi(double* A, double* V, double* cs, int d) {
                 if (code >= 0) {
                     const int p = code >> 8, q = code & 0xff;
                     const double c = cs[2 * sl], sn = cs[2 * sl + 1];
-                    for (int k = k0; k < d; k += 4) {
+                    for (int k = k0; k < d; k += kstep) {
                         const double akp = A[k * d + p], akq = A[k * d + q];
                         A[k * d + p] = c * akp - sn * akq;
                         A[k * d + q] = sn * akp + c * akq;
@@ -177,7 +195,7 @@ static __device__ void lds_jacobi(double* A, double* V, double* cs, int d) {
             {
                 const int k = threadIdx.x & 31;
                 if (k < d) {
-                    for (int sl = threadIdx.x >> 5; sl < half; sl += 2) {
+                    for (int sl = threadIdx.x >> 5; sl < half; sl += slstep) {
                         const int code = pq[sl];
                         if (code < 0) continue;
                         const int p = code >> 8, q = code & 0xff;

@@ -24,7 +24,9 @@ enum {
 };
 
 // a, b, c: up to three input matrix batches (n x d x d, row-major); out: n x d x d or n scalars (+ n x d x d gradient in out2)
-__global__ __launch_bounds__(64) void spd_manifold_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
+// THREADS = 64: one wave per matrix (the compiler drops the barriers of a single-wave workgroup); 256: four waves for d > 12
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void spd_manifold_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
                                                           const double* __restrict__ c, const double* __restrict__ e,
                                                           double* __restrict__ out, double* __restrict__ out2, int64_t n, int d,
                                                           int* __restrict__ status) {
@@ -283,7 +285,8 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_backward_kernel(const doub
 // through logm_torch / sqrtm_torch (spd_utils_torch.py:13-50) computes, in the form that stays finite at repeated eigenvalues.
 // eig != nullptr: the eigen-decomposition saved by the forward launch (n x (d^2 + d): V, then the eigenvalues) replaces the Jacobi
 // solve of `a`, which is most of this kernel's time.
-__global__ __launch_bounds__(64) void spd_matfun_backward_kernel(const double* __restrict__ a, const double* __restrict__ eig,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void spd_matfun_backward_kernel(const double* __restrict__ a, const double* __restrict__ eig,
                                                                  const double* __restrict__ g, double* __restrict__ out, int64_t n,
                                                                  int d, int fn) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -471,7 +474,11 @@ int gabo_spd_manifold_op(int op, const double* a, const double* b, const double*
     if (op == gabo::OP_EHESS2RHESS && !e) return GABO_ERR_ARG;
     if (n > 0x7fffffffLL) return GABO_ERR_ARG;
     size_t lds = (size_t)(6 * d * d + gabo::kJacobiScratch) * sizeof(double);
-    hipLaunchKernelGGL(gabo::spd_manifold_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
+    if (d > 12)
+        hipLaunchKernelGGL(gabo::spd_manifold_kernel<256>, dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
+                       d, status);
+    else
+        hipLaunchKernelGGL(gabo::spd_manifold_kernel<64>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
                        d, status);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
@@ -528,7 +535,11 @@ int gabo_spd_matfun_backward(int op, const double* a, const double* grad_out, do
     if (n == 0) return GABO_OK;
     const int fn = op == GABO_SPD_LOGM ? gabo::FN_LOG : (op == GABO_SPD_EXPM ? gabo::FN_EXP : gabo::FN_SQRT);
     size_t lds = (size_t)(4 * d * d + gabo::kJacobiScratch) * sizeof(double);
-    hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, a, (const double*)nullptr,
+    if (d > 12)
+        hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel<256>, dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, a, (const double*)nullptr,
+                       grad_out, grad_a, n, d, fn);
+    else
+        hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel<64>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, a, (const double*)nullptr,
                        grad_out, grad_a, n, d, fn);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
@@ -541,7 +552,11 @@ int gabo_spd_matfun_backward_eig(int op, const double* eig, const double* grad_o
     if (n == 0) return GABO_OK;
     const int fn = op == GABO_SPD_LOGM ? gabo::FN_LOG : (op == GABO_SPD_EXPM ? gabo::FN_EXP : gabo::FN_SQRT);
     size_t lds = (size_t)(4 * d * d + gabo::kJacobiScratch) * sizeof(double);
-    hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, (const double*)nullptr,
+    if (d > 12)
+        hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel<256>, dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, (const double*)nullptr,
+                       eig, grad_out, grad_a, n, d, fn);
+    else
+        hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel<64>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, (const double*)nullptr,
                        eig, grad_out, grad_a, n, d, fn);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
