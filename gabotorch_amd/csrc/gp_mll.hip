@@ -22,6 +22,10 @@
 #include "gabo_device.hpp"
 #include "../../include/gabo_hip.h"
 
+#ifndef GABO_MLL_SMALL_N
+#define GABO_MLL_SMALL_N 30
+#endif
+
 namespace gabo {
 
 constexpr int kMllMaxThreads = 1024;
@@ -56,7 +60,9 @@ static __device__ __forceinline__ void mll_publish(double (&x)[4][4], int I, int
 }
 
 // blockDim.x = number of tiles rounded up to whole waves; tile (I, J), I >= J, of thread t in row-major packed order
-__global__ __launch_bounds__(kMllMaxThreads) void gp_mll_kernel(const double* __restrict__ e, const double* __restrict__ y, int n,
+// MAXT = 64: the whole matrix fits one wave's tiles (n <= 39) and the compiler drops the barriers of a single-wave workgroup
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void gp_mll_kernel(const double* __restrict__ e, const double* __restrict__ y, int n,
                                                                double theta, double os, double noise, double mean,
                                                                double* __restrict__ out, int gram, double* __restrict__ w_out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -375,7 +381,7 @@ static int gp_mll_dispatch(const double* e, const double* y, int64_t n, double t
                            double* out, int gram, double* w_out, gabo_stream_t stream) {
     if (n < 1 || n > GABO_GP_MLL_MAX_N) return GABO_ERR_DIM;
     if (!e || !y || !out) return GABO_ERR_ARG;
-    if (n <= 30) {                                        // (n + 1)(n + 2) / 2 <= 512 packed entries: two per thread
+    if (n <= GABO_MLL_SMALL_N) {                          // (n + 1)(n + 2) / 2 <= 512 packed entries: two per thread
         const size_t lds_small = (size_t)(2 * (n + 2) + 2 * n + 4) * sizeof(double);
         hipLaunchKernelGGL((gabo::gp_mll_small_kernel<256, 2>), dim3(1), dim3(256), lds_small, (hipStream_t)stream, e, y, (int)n, theta,
                            outputscale, noise, mean, out, gram, w_out);
@@ -385,8 +391,12 @@ static int gp_mll_dispatch(const double* e, const double* y, int64_t n, double t
     const int tiles = nt * (nt + 1) / 2;                   // <= 861 at n = 160
     const int threads = ((tiles + 63) / 64) * 64;
     const size_t lds = (size_t)(3 * 4 * nt + n + 16) * sizeof(double);
-    hipLaunchKernelGGL(gabo::gp_mll_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, e, y, (int)n, theta, outputscale, noise,
-                       mean, out, gram, w_out);
+    if (threads == 64)
+        hipLaunchKernelGGL(gabo::gp_mll_kernel<64>, dim3(1), dim3(64), lds, (hipStream_t)stream, e, y, (int)n, theta, outputscale, noise,
+                           mean, out, gram, w_out);
+    else
+        hipLaunchKernelGGL(gabo::gp_mll_kernel<gabo::kMllMaxThreads>, dim3(1), dim3(threads), lds, (hipStream_t)stream, e, y, (int)n,
+                           theta, outputscale, noise, mean, out, gram, w_out);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
