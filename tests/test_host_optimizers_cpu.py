@@ -104,3 +104,19 @@ def test_augmented_lagrange_method_on_a_constrained_toy_problem():
     # the method stops when the iterate moves less than 1e-10 (pymanopt's default minstepsize), with the violation at ~1e-4
     assert abs(x @ x - 1.0) < 1e-3 and x[0] >= 0.1 - 1e-3
     np.testing.assert_allclose(x @ a @ x, lam[0], rtol=2e-3)
+
+
+def test_library_constraints_are_recognised_for_graph_capture():
+    """functools.partial over the library's eigenvalue constraints (plain or nested) is what the maximiser may capture with the
+    trust-region graphs; anything else (lambdas, partials over user functions) stays eager."""
+    import functools
+    from gabotorch_amd.manifold_optimization.manifold_optimize import _library_constraint
+    from gabotorch_amd.nested_mappings.nested_spd_constraints_utils import max_eigenvalue_nested_spd_constraint
+    from gabotorch_amd.Riemannian_utils.spd_constraints_utils_torch import builtin_constraint, min_eigenvalue_constraint_torch
+    plain = functools.partial(min_eigenvalue_constraint_torch, minimum_eigenvalue=0.1)
+    nested = functools.partial(max_eigenvalue_nested_spd_constraint, maximum_eigenvalue=5.0, projection_matrix=None,
+                               projection_complement_matrix=None, bottom_spd_matrix=None, contraction_matrix=None)
+    assert _library_constraint(plain) and _library_constraint(nested)
+    assert not _library_constraint(lambda x: min_eigenvalue_constraint_torch(x, 0.1))
+    assert not _library_constraint(functools.partial(lambda x, b: x.sum() - b, b=1.0))
+    assert builtin_constraint(plain) is not None and builtin_constraint(nested) is None      # only the plain ones run inside the kernel
