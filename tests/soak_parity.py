@@ -68,6 +68,30 @@ def main():
             s2[..., 0, :] = s1[..., 0, :]              # an identical pair: the clamp edge
         gs = ops.sphere_pairwise(torch.tensor(s1, device=dev), torch.tensor(s2, device=dev), beta, _lib.GABO_OUT_GAUSSIAN).cpu().numpy()
         note("sphere_fwd", np.max(np.abs(gs - osph.sphere_gaussian_kernel(s1, s2, beta))))
+        # log-Euclidean kernel (O(N) matrix logarithms + Frobenius pairs) and its gradient
+        if d <= 12:
+            from gabotorch_amd.kernel_utils.kernels_spd import SpdLogEuclideanGaussianKernel
+            ls = float(rng.uniform(0.7, 2.0))
+            kern = SpdLogEuclideanGaussianKernel().double()
+            kern.lengthscale = torch.tensor(ls, dtype=torch.float64)
+            q1 = t1.clone().requires_grad_(True)
+            kle = kern.forward(q1, t2)
+            note("le_fwd", np.max(np.abs(kle.detach().cpu().numpy() - ospd.log_euclidean_gaussian_kernel(x1, x2, ls))))
+            go = rng.standard_normal(kle.shape)
+            (kle * torch.tensor(go, device=dev)).sum().backward()
+            g1 = ospd.log_euclidean_gaussian_kernel_grads(x1, x2, ls, go)[0]
+            note("le_bwd", np.max(np.abs(q1.grad.cpu().numpy() - g1)) / max(1.0, np.abs(g1).max()))
+        # marginal likelihood kernel on a random distance matrix
+        from oracle import gp as ogp
+        nm = int(rng.integers(1, 161))
+        pts = rng.standard_normal((nm, 3))
+        e = ((pts[:, None] - pts[None]) ** 2).sum(-1)
+        yv = rng.standard_normal(nm)
+        par = (float(rng.uniform(0.2, 1.5)), float(rng.uniform(0.5, 2.0)), float(rng.uniform(1e-3, 0.2)), float(rng.normal()))
+        ll, gl = ogp.marginal_log_likelihood(e, yv, *par)
+        outm = ops.gp_mll(torch.tensor(e, device=dev), torch.tensor(yv, device=dev), *par)
+        note("gp_mll_value", abs(outm[0] - ll) / max(1.0, abs(ll)))
+        note("gp_mll_grad", np.max(np.abs(np.array(outm[1:5]) - gl)) / max(1.0, np.abs(gl).max()))
         # manifold ops: logm / expm round trip and log / exp maps
         M = torch.tensor(rand_spd(rng, (5,), d), device=dev)
         lg = ops.spd_manifold_op(_lib.GABO_SPD_LOGM, M)
@@ -77,7 +101,7 @@ def main():
         note("exp_log_map_roundtrip", (ops.spd_manifold_op(_lib.GABO_SPD_EXP, M, U) - Y).abs().max() / Y.abs().max())
     for k in sorted(worst):
         print(f"{k:28s} worst {worst[k]:.2e}")
-    bad = {k: v for k, v in worst.items() if v > (1e-5 if "fd" in k else 1e-9)}
+    bad = {k: v for k, v in worst.items() if v > (1e-5 if "fd" in k else (1e-7 if "gp_mll" in k else 1e-9))}
     print("FAIL" if bad else "OK", bad)
     return 1 if bad else 0
 
