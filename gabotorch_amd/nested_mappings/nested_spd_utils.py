@@ -27,7 +27,19 @@ def projection_from_nested_spd_to_spd(x_spd_low_dimension, projection_matrix, pr
     W, V = projection_matrix.to(dev, dt), projection_complement_matrix.to(dev, dt)
     C, K = bottom_spd_matrix.to(dev, dt), contraction_matrix.to(dev, dt)
     R = torch.cat((W, V), dim=1)
-    sqrt_c = ops.spd_matrix_function(C, _lib.GABO_SPD_SQRTM).to(dt)        # differentiable (reconstruction costs, f4)
+    if C.requires_grad:
+        sqrt_c = ops.spd_matrix_function(C, _lib.GABO_SPD_SQRTM).to(dt)    # differentiable (reconstruction costs, f4)
+    else:
+        # a fixed bottom matrix (the latent constraints evaluate this map thousands of times per sweep): its square root - an
+        # eigen-solve of a (D-d) x (D-d) matrix - is computed once and kept on the tensor
+        memo = getattr(bottom_spd_matrix, "_gabo_sqrt", None)
+        if memo is None or memo[0] != bottom_spd_matrix._version or memo[1].device != dev or memo[1].dtype != dt:
+            memo = (bottom_spd_matrix._version, ops.spd_matrix_function(C, _lib.GABO_SPD_SQRTM).to(dt))
+            try:
+                bottom_spd_matrix._gabo_sqrt = memo
+            except AttributeError:      # (not every tensor subclass takes attributes)
+                pass
+        sqrt_c = memo[1]
     if sqrt_low is None:
         sqrt_y = ops.spd_matrix_function(y, _lib.GABO_SPD_SQRTM).to(dt)
     else:
