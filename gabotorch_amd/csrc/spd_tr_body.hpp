@@ -7,7 +7,7 @@ namespace gabo {
 
 struct TrWs {
     TcgWs tcg;
-    double *x_fd, *eg_fd, *val_fd, *xp_mandel, *eg_prop, *fx_prop, *rhoden, *xp_mat, *F;
+    double *x_fd, *eg_fd, *eg_fd0, *val_fd, *xp_mandel, *eg_prop, *fx_prop, *rhoden, *xp_mat, *F;
     size_t bytes;
 };
 
@@ -19,6 +19,7 @@ static __host__ __device__ inline TrWs tr_layout(void* base, int64_t R, int d, i
     const int64_t dv = (int64_t)d * (d + 1) / 2;
     t.x_fd = p;       p += R * dv;
     t.eg_fd = p;      p += R * dv;
+    t.eg_fd0 = p;     p += R * dv;      // gradient at the FIRST FD point of the current x (reused while x does not move)
     t.val_fd = p;     p += R;
     t.xp_mandel = p;  p += R * dv;
     t.eg_prop = p;    p += R * dv;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
                                                 const TrWs& t, double* __restrict__ x_prop, int64_t i, int64_t R, int C, int neq,
                                                 double delta_cons, double theta, double kappa, int mininner, int maxinner,
                                                 AcqLds<D>& acq, double* mats, double* dyn, int* __restrict__ status,
-                                                const BuiltinCons* builtin) {
+                                                const BuiltinCons* builtin, bool x_unchanged = false) {
     constexpr int T = tri_size(D);
     constexpr int dd = D * D;
     const TcgWs& w = t.tcg;
@@ -127,17 +128,25 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
     tcg_begin(x, g, gc, fc, true, delta, w, i, R, D, C, status, mats);
     __syncthreads();
     if constexpr (D <= 8) {
-        if (builtin != nullptr && builtin->n > 0) {
+        // (x_unchanged: the previous proposal of this launch was rejected, so the constraint values and whitened gradients in the
+        // workspace are still those of x: skip the eigen-solve)
+        if (builtin != nullptr && builtin->n > 0 && !x_unchanged) {
             builtin_constraints<D>(x, w, i, R, *builtin);
             __syncthreads();
         }
     }
+    double* egfd0 = t.eg_fd0 + i * T;
     for (int it = 0; it < maxinner; ++it) {
         tcg_fd_point(w, i, D, xfd, mats);
         __syncthreads();
-        acq_eval_any<D, METRIC>(xfd, P, t.val_fd + i, egfd, F, acq, dyn, status, i);
+        // tCG restarts from eta = 0 with the same x, g and preconditioner after a rejected proposal (only the radius changed), so its
+        // first direction, first FD point and the acquisition gradient there are bit for bit those of the previous iteration: keep
+        // that gradient instead of evaluating the acquisition again (a restart that sits on a bound does one tCG step per
+        // iteration - this is half of its acquisition evaluations)
+        double* eg_it = (it == 0) ? egfd0 : egfd;
+        if (!(it == 0 && x_unchanged)) acq_eval_any<D, METRIC>(xfd, P, t.val_fd + i, eg_it, F, acq, dyn, status, i);
         __syncthreads();
-        const bool running = tcg_step(w, i, R, D, C, egfd, neq, delta_cons, theta, kappa, mininner, it, mats);
+        const bool running = tcg_step(w, i, R, D, C, eg_it, neq, delta_cons, theta, kappa, mininner, it, mats);
         __syncthreads();
         if (!running) break;
     }
@@ -219,7 +228,8 @@ __global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __rest
 static __device__ bool tr_update_body(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g, double* __restrict__ ng,
                                       double* __restrict__ delta_tr, int64_t* __restrict__ iters, bool inval,
                                       const double* __restrict__ x_prop, const TrWs& t, int64_t i, int d, int C, double delta_bar,
-                                      double rho_prime, double rho_regularization, double mingradnorm, int64_t maxiter, double* lds) {
+                                      double rho_prime, double rho_regularization, double mingradnorm, int64_t maxiter, double* lds,
+                                      bool* accepted = nullptr) {
     const int dd = d * d;
     double* M0 = lds;
     double* M1 = M0 + dd;
@@ -240,6 +250,7 @@ static __device__ bool tr_update_body(double* __restrict__ x, double* __restrict
     const double D0 = *delta_tr;
     const double Dn = shrink ? D0 / 4 : (grow ? (2 * D0 < delta_bar ? 2 * D0 : delta_bar) : D0);
     const bool accept = model_decreased && rho > rho_prime;
+    if (accepted) *accepted = accept;                  // (the same value in every lane)
     double ngi = *ng;
     const int64_t it = *iters + 1;
     __syncthreads();                 // every lane has read the scalars before lane 0 rewrites them
@@ -288,14 +299,17 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     const int C = B.n;
     TrWs t = tr_layout(wsbase, R, D, C, P.n);
     double* xp = t.xp_mat + i * dd;
+    bool cons_fresh = false;          // wave-uniform: the constraints in the workspace belong to the current x
     for (;;) {
         tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, P, t, xp, i, R, C, 0, delta_cons, theta, kappa,
-                                   mininner, maxinner, acq, mats, dyn, status, &B);
+                                   mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh);
         __syncthreads();
         const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B) : false;
+        bool accepted = false;
         const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, i, D, C, delta_bar,
-                                          rho_prime, rho_regularization, mingradnorm, maxiter, mats);
+                                          rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
         if (!still) break;
+        cons_fresh = !accepted;
     }
     if (threadIdx.x == 0) active[i] = 0;
 }
