@@ -16,7 +16,7 @@ namespace gabo {
 using SphAcq = gabo_sphere_acq_params;
 
 struct SphWs {
-    double *g, *eta, *heta, *r, *delta, *x_fd, *eg_fd, *x_prop, *eg_prop, *gc, *scal, *fc, *fcg_pe, *val_fd, *fx_prop, *rhoden;
+    double *g, *eta, *heta, *r, *delta, *x_fd, *eg_fd, *hd0, *x_prop, *eg_prop, *gc, *scal, *fc, *fcg_pe, *val_fd, *fx_prop, *rhoden;
     int *stop, *running;
     size_t bytes;
 };
@@ -32,6 +32,7 @@ static __host__ __device__ inline SphWs sph_layout(void* base, int64_t R, int di
     w.delta = p;    p += m;
     w.x_fd = p;     p += m;
     w.eg_fd = p;    p += m;
+    w.hd0 = p;      p += m;       // Hessian-vector product of the FIRST tCG direction at the current x (kept while x does not move)
     w.x_prop = p;   p += m;
     w.eg_prop = p;  p += m;
     w.gc = p;       p += (int64_t)C * m;
@@ -272,7 +273,8 @@ static __device__ __forceinline__ double dotg(const double* a, const double* b, 
 static __device__ void sph_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta_tr,
                                         const double* __restrict__ gc, const double* __restrict__ fc, const SphAcq& P, const SphWs& w,
                                         int64_t i, int64_t R, int C, int neq, double delta_cons, double theta, double kappa,
-                                        int mininner, int maxinner, double* lds, double* dyn, int exact_hessian) {
+                                        int mininner, int maxinner, double* lds, double* dyn, int exact_hessian,
+                                        bool x_unchanged = false) {
     const int dim = P.dim;
     double* Hd = lds;
     double* dl = Hd + dim;
@@ -327,13 +329,26 @@ static __device__ void sph_propose_body(const double* __restrict__ x, const doub
     for (int it = 0; it < maxinner; ++it) {
         for (int e = threadIdx.x; e < dim; e += 64) dl[e] = delta[e];
         __syncthreads();
+        if (it == 0 && x_unchanged) {
+            // after a rejected proposal tCG restarts from eta = 0 with the same x and g (only the radius changed): its first
+            // direction and H delta_0 are bit for bit those of the previous iteration - no acquisition evaluation needed
+            for (int e = threadIdx.x; e < dim; e += 64) Hd[e] = w.hd0[i * dim + e];
+            __syncthreads();
+            const bool running_c = tcg_step_core(v, dim, C, Hd, dl, s0, s1, s2, neq, delta_cons, theta, kappa, mininner, it, pc);
+            __syncthreads();
+            if (!running_c) break;
+            continue;
+        }
         if (exact_hessian) {
             // Riemannian Hessian ([3P] Sphere.ehess2rhess): proj_x(ehess delta) - <x, egrad> delta
             sph_acq_hess(xs, dl, P, egfd, xfd, dyn);               // egfd <- egrad(x), xfd <- ehess(x) delta
             __syncthreads();
             const double xe = dotg(xs, egfd, dim);
             const double xh = dotg(xs, xfd, dim);
-            for (int e = threadIdx.x; e < dim; e += 64) Hd[e] = (xfd[e] - xh * xs[e]) - xe * dl[e];
+            for (int e = threadIdx.x; e < dim; e += 64) {
+                Hd[e] = (xfd[e] - xh * xs[e]) - xe * dl[e];
+                if (it == 0) w.hd0[i * dim + e] = Hd[e];
+            }
             __syncthreads();
             const bool running_e = tcg_step_core(v, dim, C, Hd, dl, s0, s1, s2, neq, delta_cons, theta, kappa, mininner, it, pc);
             __syncthreads();
@@ -356,7 +371,10 @@ static __device__ void sph_propose_body(const double* __restrict__ x, const doub
         for (int e = threadIdx.x; e < dim; e += 64) s1[e] = egfd[e] - a1 * s0[e];
         __syncthreads();
         const double a0 = dotg(xs, s1, dim);
-        for (int e = threadIdx.x; e < dim; e += 64) Hd[e] = tiny ? 0.0 : (s1[e] - a0 * xs[e]) / c - gi[e] / c;
+        for (int e = threadIdx.x; e < dim; e += 64) {
+            Hd[e] = tiny ? 0.0 : (s1[e] - a0 * xs[e]) / c - gi[e] / c;
+            if (it == 0) w.hd0[i * dim + e] = Hd[e];
+        }
         __syncthreads();
         const bool running = tcg_step_core(v, dim, C, Hd, dl, s0, s1, s2, neq, delta_cons, theta, kappa, mininner, it, pc);
         __syncthreads();
@@ -378,7 +396,7 @@ static __device__ void sph_propose_body(const double* __restrict__ x, const doub
 static __device__ bool sph_update_body(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g, double* __restrict__ ng,
                                        double* __restrict__ delta_tr, int64_t* __restrict__ iters, bool inval, const SphWs& w, int64_t i,
                                        int dim, int C, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
-                                       int64_t maxiter) {
+                                       int64_t maxiter, bool* accepted = nullptr) {
     const double fx0 = *fx;
     const double fxp = inval ? __builtin_inf() : w.fx_prop[i];
     const double rho_reg = (__builtin_fabs(fx0) > 1.0 ? __builtin_fabs(fx0) : 1.0) * 2.220446049250313e-16 * rho_regularization;
@@ -394,6 +412,7 @@ static __device__ bool sph_update_body(double* __restrict__ x, double* __restric
     const double D0 = *delta_tr;
     const double Dn = shrink ? D0 / 4 : (grow ? (2 * D0 < delta_bar ? 2 * D0 : delta_bar) : D0);
     const bool accept = model_decreased && rho > rho_prime;
+    if (accepted) *accepted = accept;                  // (the same value in every lane)
     double ngi = *ng;
     const int64_t it = *iters + 1;
     __syncthreads();
@@ -474,13 +493,16 @@ __global__ __launch_bounds__(64) void sphere_tr_solve_kernel(double* __restrict_
     const int64_t i = blockIdx.x;
     if (active[i] == 0) return;
     SphWs w = sph_layout(wsbase, R, P.dim, 0);
+    bool x_unchanged = false;         // wave-uniform: the previous proposal of this launch was rejected
     for (;;) {
         sph_propose_body(x + i * P.dim, g + i * P.dim, delta_tr[i], nullptr, nullptr, P, w, i, R, 0, 0, 1e-6, theta, kappa, mininner,
-                         maxinner, dyn + 7 * P.n, dyn, exact_hessian);
+                         maxinner, dyn + 7 * P.n, dyn, exact_hessian, x_unchanged);
         __syncthreads();
+        bool accepted = false;
         const bool still = sph_update_body(x + i * P.dim, fx + i, g + i * P.dim, ng + i, delta_tr + i, iters + i, false, w, i, P.dim, 0,
-                                           delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter);
+                                           delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter, &accepted);
         if (!still) break;
+        x_unchanged = !accepted;
     }
     if (threadIdx.x == 0) active[i] = 0;
 }
