@@ -14,7 +14,10 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libgabo_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-variable"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators allocated in VGPRs (gfx950 has one unified register file); without it hipcc keeps
+# them in AGPRs and copies all of them to and from VGPRs around every loop iteration that carries an accumulator (sphere_pairwise.hip)
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-variable",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc():
@@ -50,11 +53,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _recorded_deps(depfile):
+    """headers a translation unit actually included, as hipcc recorded them at its last compilation (-MD); None if unknown"""
+    try:
+        text = open(depfile).read().replace("\\\n", " ")
+    except OSError:
+        return None
+    deps = [t for t in text.split(":", 1)[-1].split() if not t.startswith("/opt/") and not t.startswith("/usr/")]
+    return deps if all(os.path.exists(d) for d in deps) else None
+
+
 def _compile(src, extra):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-    if not _stale(obj, [src] + _deps()):
+    depfile = obj[:-2] + ".d"
+    known = _recorded_deps(depfile)
+    deps = ([src, os.path.abspath(__file__)] + known) if known is not None else ([src] + _deps())
+    if not _stale(obj, deps):
         return obj, False
-    cmd = [_hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + extra + ["-MD", "-MF", depfile, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

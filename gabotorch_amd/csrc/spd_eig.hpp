@@ -116,19 +116,53 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
     static_for<D - 2>([&](auto ll) {
         constexpr int l = decltype(ll)::value;
         for (int it = 0; it < 60; ++it) {
+#ifdef GABO_QL_NO_LOOKAHEAD
             if (e2[l] <= eps2 * __builtin_fabs(dg[l] * dg[l + 1])) break;
+            const double sa = dg[l], sb = dg[l + 1], se = e2[l];
+#else
+            // Look-ahead shift.  The 64 lanes of a wave share the instruction stream, so stage l lasts until the SLOWEST lane has
+            // deflated e2[l]; a lane that is done would idle through the other lanes' sweeps (measured on the benchmark
+            // distribution: 180 sweep steps per wave against 128 per lane).  Instead it keeps sweeping with the wave - same
+            // extent D-2 .. l, no per-lane masks in the unrolled steps - but takes its Wilkinson shift from block l+1, i.e. it
+            // already works on its NEXT stage.  Its deflated e2[l] is set to exactly 0 first: then the steps below block l+1 pass
+            // through as the identity (bb = 0 => c = 1, s = 0) whatever p has become; with a merely negligible e2[l] a tiny p at
+            // the end of a converged sweep makes s = bb / (p + bb) large and the pass-through re-couples the deflated row
+            // (tools/sim/ql_lookahead_sim.py: 180 -> 189 steps without the zeroing, 180 -> 129 with it).
+            const bool done0 = e2[l] <= eps2 * __builtin_fabs(dg[l] * dg[l + 1]);
+            // the WAVE leaves stage l when its last lane has deflated e2[l] (a per-lane `break` would keep the wave here until every lane
+            // had finished its look-ahead work too, at stage l's longer sweep extent)
+            if (__builtin_amdgcn_ballot_w64(!done0) == 0) break;
+            const double e2l = done0 ? 0.0 : e2[l];        // (e2[l] itself is rewritten at the end of the sweep: s p = 0 for these lanes)
+            double sa = dg[l], sb = dg[l + 1], se = e2l;
+            bool idle = false;
+            if constexpr (l + 1 <= D - 3) {
+                const bool done1 = e2[l + 1] <= eps2 * __builtin_fabs(dg[l + 1] * dg[l + 2]);
+                idle = done0 && done1;                      // nothing to do within the look-ahead window: sit this sweep out
+                sa = done0 ? dg[l + 1] : sa;
+                sb = done0 ? dg[l + 2] : sb;
+                se = done0 ? e2[l + 1] : se;
+            } else {
+                idle = done0;
+            }
+            if (idle) continue;
+            const double keep = dg[l];
+#endif
             // Wilkinson shift from the leading 2x2: sigma = d_l - e2_l / (delta + sign(delta) sqrt(delta^2 + e2_l)),
             // evaluated division-free as d_l - sign(delta) (sqrt(delta^2 + e2_l) - |delta|).  The cancellation of the
             // rationalised form only costs ~eps |delta| in the SHIFT, which changes the convergence rate, never the result.
-            double delta = 0.5 * (dg[l + 1] - dg[l]);
-            double root = sqrt_nz(__builtin_fma(delta, delta, e2[l]));
-            double sigma = dg[l] - copysign_d(root - __builtin_fabs(delta), delta);
+            double delta = 0.5 * (sb - sa);
+            double root = sqrt_nz(__builtin_fma(delta, delta, se));
+            double sigma = sa - copysign_d(root - __builtin_fabs(delta), delta);
             double gamma = nonzero(dg[D - 1] - sigma);
             double p = gamma * gamma;
             double c = 1.0, s = 0.0;
             static_for_down<D - 2, l>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
+#ifdef GABO_QL_NO_LOOKAHEAD
                 double bb = e2[i];
+#else
+                double bb = (i == l) ? e2l : e2[i];
+#endif
                 double r = p + bb;
                 if constexpr (i != D - 2) e2[i + 1] = s * r;
 #ifdef GABO_QL_TWO_RCP
@@ -156,7 +190,12 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
 #endif
             });
             e2[l] = s * p;
+#ifdef GABO_QL_NO_LOOKAHEAD
             dg[l] = sigma + gamma;
+#else
+            // a deflated d_l passed through unchanged (sigma + (d_l - sigma) would round it)
+            dg[l] = done0 ? keep : sigma + gamma;
+#endif
         }
     });
     // trailing 2x2 [[a, b], [b, c]]: rt1 = larger-magnitude root, rt2 = det / rt1

@@ -1,20 +1,89 @@
 // Sphere pairwise kernel matrix on gfx950:  out_ij = f(acos(clamp(<x1_i, x2_j>, -1+1e-15, 1-1e-15)))
 // replaces kernel_utils/kernels_sphere.py:71-94,118-134 + Riemannian_utils/sphere_utils_torch.py:12-55.
 //
-// The reference materialises two N1 x N2 x dim tensors and a degenerate bmm; here a block owns a ROWS x 256 output
-// tile.  Lane = column j (so the fp64 stores of a wave are one contiguous 512 B run), each lane keeps ROWS running
-// inner products in registers.  The x1 rows of the tile are wave-uniform and come through the scalar cache; the x2
-// row of the lane is read once per tile.  HBM traffic = the output matrix (8 B per pair); this kernel is bound by the
-// fp64 acos+exp epilogue and the output write, not by operand reads.
+// The reference materialises two N1 x N2 x dim tensors and a degenerate bmm; here the inner products run as fp64 MFMA tiles
+// (16 x 16 x 4) on operands read straight from L2 and each lane finishes its 16 results in registers.  HBM traffic = the output
+// matrix (8 B per pair).  Measured at N = 4096, dim 10 (tools/ab_sphere.py, development probes): MFMA + stores alone 26 us (5.1 TB/s),
+// everything but the stores 44 us, the kernel 47-50 us - bound by fp64 issue of the acos^2 + exp epilogue, not by the write.
 #include "gabo_device.hpp"
 #include "gabo_mirror.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
 
-constexpr int kSphereRows = 16;   // rows of the output tile per block
-constexpr int kSphereKC = 16;     // inner-product depth staged through LDS per pass
-constexpr int kSphereLd = 257;    // padded leading dimension of the transposed x2 tile: conflict-free transposed writes
+
+// ---- Gaussian epilogue: K = exp(-beta acos(c)^2) without acos, in ~55 fp64 VALU instructions ------------------------------
+// With z = (1 - |c|) / 2 = sin^2(phi / 2), phi = acos|c|:  phi = 2 asin(sqrt z) = 2 sqrt(z) w(z),  w(z) = asin(sqrt z) / sqrt z analytic
+// on z in [0, 1/2] (degree-17 polynomial, 2.2e-16, tools/sim/fit_sphere_poly.py).  Then
+//     c >= 0:  theta^2 = phi^2 = 4 z w^2                      (no square root, no acos)
+//     c <  0:  theta   = pi - phi = pi - 2 sqrt(z w^2)
+// and the reference's clamp of c to [-1+1e-15, 1-1e-15] (sphere_utils_torch.py:53) is the lower bound z >= kSphZmin.
+// exp(x), x <= 0: x = (64 e + j) ln2/64 + r, |r| <= ln2/128: 2^e * 2^(j/64) (LDS table) * (1 + r + ... + r^5/120)  (3.5e-17).
+// Against exp(-beta arccos(clip(c))^2) in 60-digit arithmetic this is as accurate as the numpy oracle itself (4e-15 vs 3e-15
+// relative at beta = 1.3: the conditioning of exp(-beta theta^2), not the approximation).
+constexpr int kSphWDeg = 17;
+__constant__ double kSphW[kSphWDeg + 1] = {
+    0.9999999999999999, 0.166666666666762, 0.07499999997954958, 0.04464285887635292, 0.03038186720347429, 0.022374245713577247,
+    0.01731559954431618, 0.014425198539078435, 0.007444628520337835, 0.03675841815436629, -0.12408231204352452, 0.4950065878219168,
+    -1.3361380175788322, 2.733327968715509, -3.974232006625551, 3.9651660247789384, -2.4213345116985456, 0.7052735073244606};
+// [0] ln2/64 high part (33 bits: k * hi is exact), [1] low part, [2] 64/ln2, [3..5] 1/120, 1/24, 1/6, [6] pi, [7] z of the clamp
+__constant__ double kSphC[8] = {0.010830424695086549, 1.162596423439437e-12, 92.33248261689366, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0,
+                                3.14159265358979311600e+00, 4.996003610813204e-16};
+__constant__ double kExp2Tab[64] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237,
+    1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916,
+    1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.202156731452703, 1.215247359980469,
+    1.22848053610687, 1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096,
+    1.3109612115247644, 1.3252366431597413, 1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832,
+    1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993,
+    1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837, 1.5759808451078865,
+    1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364, 1.681792830507429,
+    1.7001063537185235, 1.718619298122478, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072,
+    1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474,
+    1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+
+struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar cache, lives in SGPRs
+    double w[kSphWDeg + 1], c[8], neg_beta, neg_4beta;
+    double w_top, e_top;          // the leading coefficient of each Horner chain in a VGPR: a VALU instruction reads ONE scalar operand
+    __device__ __forceinline__ static SphGauss load(double beta) {
+        SphGauss t;
+        static_for<kSphWDeg + 1>([&](auto i) { t.w[decltype(i)::value] = kSphW[decltype(i)::value]; });
+        static_for<8>([&](auto i) { t.c[decltype(i)::value] = kSphC[decltype(i)::value]; });
+        t.neg_beta = -beta;
+        t.neg_4beta = -4.0 * beta;
+        t.w_top = t.w[kSphWDeg];
+        t.e_top = t.c[3];
+        asm volatile("" : "+v"(t.w_top), "+v"(t.e_top));
+        return t;
+    }
+};
+
+// max(x, bound) for x known not to be a signalling NaN (hipcc otherwise canonicalises x with an extra v_max_f64 x, x first)
+__device__ __forceinline__ double max_raw(double x, double bound_uniform) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(bound_uniform));
+    return r;
+}
+
+__device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss& g, const double* __restrict__ tab) {
+    double z = max_raw(__builtin_fma(-0.5, __builtin_fabs(ip), 0.5), g.c[7]);
+    double w = g.w_top;
+    static_for<kSphWDeg>([&](auto i) { w = __builtin_fma(w, z, g.w[kSphWDeg - 1 - decltype(i)::value]); });
+    double q = (z * w) * w;                                   // (phi / 2)^2
+    double th = __builtin_fma(-2.0, sqrt_nz(q), g.c[6]);      // pi - phi
+    double x = (ip < 0.0) ? (th * th) * g.neg_beta : q * g.neg_4beta;
+    x = max_raw(x, -800.0);
+    double k = __builtin_rint(x * g.c[2]);
+    double r = __builtin_fma(-k, g.c[1], __builtin_fma(-k, g.c[0], x));
+    double p = __builtin_fma(r, g.e_top, g.c[4]);
+    p = __builtin_fma(p, r, g.c[5]);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;                                                 // exp(r) - 1
+    int ki = (int)k;
+    double t = tab[ki & 63];
+    return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 6);   // (v_ldexp_f64 also does the gradual underflow)
+}
 
 template <int MODE>
 __device__ __forceinline__ double sphere_finish(double ip, double beta, const MathRegs& mt) {
@@ -26,84 +95,123 @@ __device__ __forceinline__ double sphere_finish(double ip, double beta, const Ma
     return exp_neg(-((dist * dist) * beta), mt);          // kernels_sphere.py:91-93
 }
 
-// 1-D grid: block id -> (batch, row chunk, column group), column group fastest.  Both operand tiles go through LDS:
-// the x2 tile is read from HBM/L2 fully coalesced (its 256 points are contiguous) and stored TRANSPOSED so that lane j
-// then reads xs2[k][j] conflict-free; the x1 tile is read back as LDS broadcasts (same address for the whole wave).
-// MODE is a template parameter so the 16 row epilogues of a lane are straight-line code the scheduler can interleave:
-// each is a long dependent chain (two Horner polynomials), and with ~110 VGPRs only 4 waves per SIMD hide its latency.
+typedef double sph_v4d __attribute__((ext_vector_type(4)));
+
+// grid.x: (row chunk, column group), column group fastest; grid.y: batch.  A block owns `rows` = 16 * chunks rows x blockDim.x columns.
+// The inner products <x1_i, x2_j> are a GEMM with K = dim: v_mfma_f64_16x16x4_f64.  A wave owns 64 columns = four 16 x 16 MFMA tiles
+// per 16-row chunk and walks the block's row chunks; per K step of 4 a lane holds ONE double of x1 (A[i = lane & 15][k = lane >> 4])
+// and one of each x2 tile (B[k = lane >> 4][j = lane & 15]), loaded straight from L2 (the point sets are a few hundred KB) - no LDS
+// staging, no transposes (keeping the x2 fragments in registers across the chunks measured no gain: 50.7 vs 49.5 us).  Result layout of the f64 MFMA: register r of
+// lane l is row (l >> 4) + 4 r, column l & 15 - a wave store writes four full 128-byte lines.
+// What binds the kernel is fp64 issue: tools/ubench_mfma_f64.hip shows the f64 matrix pipe and the f64 vector pipe do NOT overlap
+// on gfx950 (MFMA alone 77.8, v_fma_f64 alone 60.6, both together 64.9 TFLOP/s), so per output the MFMA costs 12 issue slots beside
+// the ~56 instructions of the epilogue; what the MFMA form removes is the LDS staging and its index arithmetic.
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
+__global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
-                                                              int64_t s1, int64_t s2, int col_blocks, int row_chunks,
-                                                              int64_t sym_tiles, double beta, int flags, uint32_t dim_magic) {
-    __shared__ double xs2[kSphereKC * kSphereLd];
-    __shared__ double xs1[kSphereRows * kSphereKC];
+                                                              int64_t s1, int64_t s2, int col_blocks, int row_chunks, int chunks,
+                                                              double beta, int flags) {
+    __shared__ double tab[64];
     const int tid = threadIdx.x;
-    int64_t cg, rc, b;
+    if constexpr (MODE == GABO_OUT_GAUSSIAN) {
+        if (tid < 64) tab[tid] = kExp2Tab[tid];
+        __syncthreads();
+    }
+    const int rows = 16 * chunks;
+    uint32_t cg, rc;
     if (flags & GABO_SYMMETRIC) {       // x1 is x2: only tiles touching the upper triangle exist (see spd_pairwise.hip)
-        b = blockIdx.x / sym_tiles;
-        int64_t t = blockIdx.x - b * sym_tiles;
+        uint32_t t = blockIdx.x;
         cg = 0;
         for (;;) {
-            int64_t cnt = sym_chunks_of(cg, blockDim.x, kSphereRows, row_chunks);
+            uint32_t cnt = (uint32_t)sym_chunks_of(cg, blockDim.x, rows, row_chunks);
             if (t < cnt) break;
             t -= cnt;
             ++cg;
         }
         rc = t;
     } else {
-        const int64_t bid = blockIdx.x;
-        cg = bid % col_blocks;
-        rc = (bid / col_blocks) % row_chunks;
-        b = bid / ((int64_t)col_blocks * row_chunks);
+        rc = blockIdx.x / (uint32_t)col_blocks;
+        cg = blockIdx.x - rc * (uint32_t)col_blocks;
     }
-    const int64_t j0 = cg * blockDim.x;
-    const int64_t j = j0 + tid;
-    const int64_t i0 = rc * kSphereRows;
-    const int ncols = (int)((n2 - j0 < (int64_t)blockDim.x) ? n2 - j0 : (int64_t)blockDim.x);
-    const int nrows = (int)((n1 - i0 < kSphereRows) ? n1 - i0 : kSphereRows);
-    const double* a = x1 + b * s1 + i0 * dim;      // nrows x dim, contiguous
-    const double* bt = x2 + b * s2 + j0 * dim;     // ncols x dim, contiguous
-    double acc[kSphereRows];
-    static_for<kSphereRows>([&](auto r) { acc[decltype(r)::value] = 0.0; });
-    for (int k0 = 0; k0 < dim; k0 += kSphereKC) {
-        const int kc = dim - k0 < kSphereKC ? dim - k0 : kSphereKC;
-        if (k0) __syncthreads();
-        if (kc == dim) {
-            // whole points fit one pass: the tile is one contiguous run of ncols*dim doubles
-            // e / dim by multiply-high with dim_magic = ceil(2^32 / dim) (exact for e < 2^16): a runtime integer division is ~40
-            // VALU instructions and there are ten of them per thread here - a fifth of the kernel's instruction count
-            for (int e = tid; e < ncols * dim; e += blockDim.x) {
-                int jj = dim == 1 ? e : (int)__umulhi((uint32_t)e, dim_magic), kk = e - jj * dim;
-                xs2[kk * kSphereLd + jj] = bt[e];
-            }
-        } else {
-            for (int e = tid; e < ncols * kc; e += blockDim.x) {
-                int jj = e / kc, kk = e - jj * kc;
-                xs2[kk * kSphereLd + jj] = bt[(int64_t)jj * dim + k0 + kk];
+    const int64_t b = blockIdx.y;
+    const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int64_t j0 = (int64_t)cg * blockDim.x + (tid & ~63);       // first column of this wave
+    if (j0 >= n2) return;
+    const double* pb[4];
+    static_for<4>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        int64_t jb = j0 + 16 * t + li;
+        jb = jb < n2 ? jb : n2 - 1;                   // out-of-range rows / columns recompute the last one and are not stored
+        pb[t] = x2 + b * s2 + jb * dim;
+    });
+    SphGauss g;
+    MathRegs mt;
+    if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load(beta);
+    else mt = MathRegs::load();
+    auto finish = [&](double ip) {
+#if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 1     /* development probe: MFMA + stores only */
+        return ip;
+#endif
+        if constexpr (MODE == GABO_OUT_GAUSSIAN) return sphere_gauss_finish(ip, g, tab);
+        else return sphere_finish<MODE>(ip, beta, mt);
+    };
+    const uint32_t loff = (uint32_t)lk * (uint32_t)n2 + (uint32_t)li;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int64_t i0 = (int64_t)rc * rows + 16 * ch;
+        if (i0 >= n1) break;
+        // x1 is x2, wave entirely left of the chunk's first row: i > j for every pair it would evaluate (and for every later chunk)
+        if ((flags & GABO_SYMMETRIC) && j0 + 63 < i0) break;
+        const int64_t ia = (i0 + li < n1) ? i0 + li : n1 - 1;
+        const double* pa = x1 + b * s1 + ia * dim;
+        sph_v4d acc[4];
+        static_for<4>([&](auto tt) { acc[decltype(tt)::value] = sph_v4d{0.0, 0.0, 0.0, 0.0}; });
+        {
+            // K is padded to a multiple of 4 with zeros: the padded lanes load the last valid entry (no divergent load) and drop it
+            for (int k0 = 0; k0 < dim; k0 += 4) {
+                const int kk = k0 + lk;
+                const bool ok = kk < dim;
+                const int kc = ok ? kk : dim - 1;
+                double a = pa[kc];
+                double bv[4];
+                static_for<4>([&](auto tt) { bv[decltype(tt)::value] = pb[decltype(tt)::value][kc]; });
+                a = ok ? a : 0.0;
+                static_for<4>([&](auto tt) {
+                    constexpr int t = decltype(tt)::value;
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ok ? bv[t] : 0.0, acc[t], 0, 0, 0);
+                });
             }
         }
-        for (int e = tid; e < nrows * kc; e += blockDim.x) {
-            int rr = (kc == dim && dim > 1) ? (int)__umulhi((uint32_t)e, dim_magic) : e / kc, kk = e - rr * kc;
-            xs1[rr * kSphereKC + kk] = a[(int64_t)rr * dim + k0 + kk];
-        }
-        __syncthreads();
-        for (int kk = 0; kk < kc; ++kk) {
-            double y = xs2[kk * kSphereLd + tid];
-            static_for<kSphereRows>([&](auto rr) {
+        // Stores: wave-uniform base of the chunk + a 32-bit lane offset.  A chunk that lies fully inside the matrix (and, with
+        // x1 is x2, fully above the diagonal) stores without predicates.
+        double* ob = out + b * n1 * n2 + i0 * n2 + j0;
+        const bool inside = i0 + 16 <= n1 && j0 + 64 <= n2 && (uint64_t)n2 < (1ull << 27) &&
+                            (!(flags & GABO_SYMMETRIC) || i0 + 15 <= j0);
+        if (inside) {
+            static_for<4>([&](auto rr) {
                 constexpr int r = decltype(rr)::value;
-                acc[r] = __builtin_fma(xs1[r * kSphereKC + kk], y, acc[r]);
+                double* orow = ob + (int64_t)(4 * r) * n2;       // wave-uniform
+                static_for<4>([&](auto tt) {
+                    constexpr int t = decltype(tt)::value;
+#if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 2     /* development probe: everything but the stores */
+                    double v_ = finish(acc[t][r]);
+                    if (v_ == 12345.678) orow[loff + 16u * t] = v_;
+#else
+                    orow[loff + 16u * t] = finish(acc[t][r]);
+#endif
+                });
+            });
+        } else {
+            static_for<4>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                const int64_t j = j0 + 16 * t + li;
+                static_for<4>([&](auto rr) {
+                    constexpr int r = decltype(rr)::value;
+                    const int64_t i = i0 + lk + 4 * r;
+                    double val = finish(acc[t][r]);
+                    if (i < n1 && j < n2 && (!(flags & GABO_SYMMETRIC) || i <= j)) ob[(int64_t)(lk + 4 * r) * n2 + 16 * t + li] = val;
+                });
             });
         }
-    }
-    if (tid < ncols) {
-        const MathRegs mt = MathRegs::load();
-        double* o = out + b * n1 * n2 + i0 * n2 + j;
-        static_for<kSphereRows>([&](auto rr) {
-            constexpr int r = decltype(rr)::value;
-            double val = sphere_finish<MODE>(acc[r], beta, mt);
-            if (r < nrows && (!(flags & GABO_SYMMETRIC) || i0 + r <= j)) o[(int64_t)r * n2] = val;
-        });
     }
 }
 
@@ -190,21 +298,28 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
         hipLaunchKernelGGL(gabo::sphere_diag_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x1, x2, out, batch, n1,
                            dim, x1_batch_stride, x2_batch_stride, beta, flags);
     } else {
+        if (batch > 65535) return GABO_ERR_ARG;
         int threads = n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
         int64_t col_blocks = (n2 + threads - 1) / threads;
-        int64_t row_chunks = (n1 + gabo::kSphereRows - 1) / gabo::kSphereRows;
-        int64_t sym_tiles = 0;
+        // 16-row chunks per block: as many as keep >= 1024 blocks in flight (each wave re-uses its x2 fragments across the chunks)
+#ifndef GABO_SPH_CHUNKS
+#define GABO_SPH_CHUNKS 4
+#endif
+        int chunks = GABO_SPH_CHUNKS;
+        while (chunks > 1 && col_blocks * ((n1 + 16 * chunks - 1) / (16 * chunks)) * batch < 1024) chunks >>= 1;
+        const int rows = 16 * chunks;
+        int64_t row_chunks = (n1 + rows - 1) / rows;
+        int64_t tiles_x = col_blocks * row_chunks;
         if (flags & GABO_SYMMETRIC) {
-            if (n1 != n2 || batch > 65535) return GABO_ERR_ARG;
-            for (int64_t cg = 0; cg < col_blocks; ++cg) sym_tiles += gabo::sym_chunks_of(cg, threads, gabo::kSphereRows, row_chunks);
+            if (n1 != n2) return GABO_ERR_ARG;
+            tiles_x = 0;
+            for (int64_t cg = 0; cg < col_blocks; ++cg) tiles_x += gabo::sym_chunks_of(cg, threads, rows, row_chunks);
         }
-        int64_t nblocks = ((flags & GABO_SYMMETRIC) ? sym_tiles : col_blocks * row_chunks) * batch;
-        if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
+        if (tiles_x > 0x7fffffffLL) return GABO_ERR_ARG;
         const int mode = flags & GABO_OUT_MASK;
-        const uint32_t dim_magic = (uint32_t)((0x100000000ULL + (uint64_t)dim - 1) / (uint64_t)dim);     // ceil(2^32 / dim); dim = 1: unused
-#define GABO_SPH_LAUNCH(M)                                                                                                   \
-    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M>), dim3((unsigned)nblocks), dim3(threads), 0, st, x1, x2, out, n1, n2, \
-                       dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, sym_tiles, beta, flags, dim_magic)
+#define GABO_SPH_LAUNCH(M)                                                                                                         \
+    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M>), dim3((unsigned)tiles_x, (unsigned)batch), dim3(threads), 0, st, x1, x2, out, \
+                       n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, chunks, beta, flags)
         if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE);
         else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE);
         else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN);

@@ -27,6 +27,18 @@ def _bm(mask, like):
     return mask.reshape(mask.shape + (1,) * (like.dim() - mask.dim()))
 
 
+def _randvec(man, x):
+    """unit-norm random tangent vectors at the R points x ([3P] pymanopt `randvec`: a normal draw pushed into the tangent space and
+    normalised in the manifold's metric); drawn from torch's global generator on x's device"""
+    h = torch.randn_like(x)
+    if hasattr(man, "proj"):
+        h = man.proj(x, h)
+    else:
+        h = man.egrad2rgrad(x, h)
+    n = man.norm(x, h)
+    return h / _bm(torch.where(n > 0, n, torch.ones_like(n)), h)
+
+
 class BatchedProblem:
     """cost / Riemannian gradient / Riemannian Hessian-vector product for a batch of restarts.
 
@@ -129,6 +141,50 @@ class BatchedProblem:
         return man.ehess2rhess(x, eg.detach(), eh.detach(), u)
 
 
+class PointwiseProblemAdapter:
+    """A pymanopt-style problem (`cost(x) -> float`, `grad(x)`, `hess(x, a)` on ONE point given as a numpy array - the object the
+    reference hands to its solvers, pymanopt_addons/problem.py:14-159) presented with the BatchedProblem interface: every call
+    walks the restarts on the host.  This is the route for user-supplied problems; the library's own acquisition problems are
+    BatchedProblem instances and never come through here."""
+
+    fused = None
+    approx_hessian = False
+    use_hip_graphs = False
+
+    def __init__(self, problem):
+        self.problem = problem
+        self.manifold = problem.manifold
+        self.n_cost = 0
+        self.n_grad = 0
+
+    @staticmethod
+    def _np(t):
+        return t.detach().cpu().numpy()
+
+    def _stack(self, vals, like):
+        import numpy as np
+        return torch.as_tensor(np.stack([np.asarray(v, dtype=np.float64) for v in vals])).to(like)
+
+    def cost(self, x):
+        self.n_cost += 1
+        return self._stack([self.problem.cost(self._np(xi)) for xi in x], x).reshape(x.shape[0])
+
+    def cost_grad(self, x):
+        self.n_grad += 1
+        pts = [self._np(xi) for xi in x]
+        f = self._stack([self.problem.cost(p) for p in pts], x).reshape(x.shape[0])
+        return f, self._stack([self.problem.grad(p) for p in pts], x)
+
+    def grad(self, x):
+        return self.cost_grad(x)[1]
+
+    def hess(self, x, u, grad_x=None):
+        return self._stack([self.problem.hess(self._np(xi), self._np(ui)) for xi, ui in zip(x, u)], x)
+
+    def precon(self, x, d):
+        return self._stack([self.problem.precon(self._np(xi), self._np(di).copy()) for xi, di in zip(x, d)], x)
+
+
 class BatchedTrustRegions:
     """Riemannian trust regions with truncated CG, all restarts in lock step; optional equality / inequality constraints
     handled as in ConstrainedTrustRegions (linearised constraints truncate the tCG step at distance Delta_cons)."""
@@ -138,13 +194,24 @@ class BatchedTrustRegions:
         # strict_constraints=True = StrictConstrainedTrustRegions (constrained_trust_regions.py:737-1415): a proposal that
         # violates a constraint is rejected outright (cost = +inf) and the radius shrinks; everything else is identical.
         self.strict_constraints = strict_constraints
-        if use_rand:
-            raise NotImplementedError("use_rand=True (randomised tCG start) is not used by any reference example")
+        # use_rand=True (robust_trust_regions.py:173-219, 407-452): tCG starts from a tiny random tangent vector instead of zero, runs
+        # without the preconditioner, and its result is compared with the Cauchy point.  Served by the generic lock-step path only.
+        self.use_rand = bool(use_rand)
         self.miniter, self.kappa, self.theta, self.rho_prime = miniter, kappa, theta, rho_prime
         self.rho_regularization = rho_regularization
         self.maxtime, self.maxiter, self.mingradnorm = maxtime, maxiter, mingradnorm
         self.minstepsize, self.maxcostevals = minstepsize, maxcostevals
+        self.logverbosity = logverbosity
         self.log = {}
+
+    # pymanopt's Solver keeps its stopping criteria under underscored names and outer solvers (e.g. an augmented Lagrangian loop)
+    # tighten `_mingradnorm` between calls: same storage here
+    _maxtime = property(lambda self: self.maxtime, lambda self, v: setattr(self, "maxtime", v))
+    _maxiter = property(lambda self: self.maxiter, lambda self, v: setattr(self, "maxiter", v))
+    _mingradnorm = property(lambda self: self.mingradnorm, lambda self, v: setattr(self, "mingradnorm", v))
+    _minstepsize = property(lambda self: self.minstepsize, lambda self, v: setattr(self, "minstepsize", v))
+    _maxcostevals = property(lambda self: self.maxcostevals, lambda self, v: setattr(self, "maxcostevals", v))
+    _logverbosity = property(lambda self: self.logverbosity, lambda self, v: setattr(self, "logverbosity", v))
 
     # ------------------------------------------------------------------------------------------------- constraints
     @staticmethod
@@ -183,8 +250,29 @@ class BatchedTrustRegions:
         return torch.stack(vals, dim=1)
 
     # ------------------------------------------------------------------------------------------------- solve
-    def solve(self, problem, x, eq_constraints=None, ineq_constraints=None, mininner=1, maxinner=None, Delta_bar=None,
+    def solve(self, problem, x=None, eq_constraints=None, ineq_constraints=None, mininner=1, maxinner=None, Delta_bar=None,
               Delta0=None, Delta_cons=None):
+        """The reference solvers' entry point (robust_trust_regions.py:111-112, constrained_trust_regions.py:120-121, :783-784).
+
+        Lock-step form: `problem` a BatchedProblem, `x` a tensor R x *point_shape of initial points -> the R optimised points.
+        pymanopt form: `problem` exposes cost/grad/hess on single numpy points (pymanopt_addons Problem) and `x` is ONE point (numpy
+        array or tensor; None draws `manifold.rand()`) -> the optimised point as the same kind of object.  Both run the same state
+        machine; the second evaluates the problem's callables restart by restart on the host."""
+        import numpy as np
+        batched = isinstance(problem, BatchedProblem) or hasattr(problem, "cost_grad")
+        if not batched:
+            problem = PointwiseProblemAdapter(problem)
+        if x is None:
+            x = problem.manifold.rand()
+        single = not batched or not torch.is_tensor(x) or x.dim() == len(getattr(problem.manifold, "_shape", (0,) * (x.dim() - 1)))
+        if single:
+            was_numpy = not torch.is_tensor(x)
+            xt = torch.as_tensor(np.asarray(x, dtype=np.float64)) if was_numpy else x.detach().double()
+            out = self._solve(problem, xt[None], eq_constraints, ineq_constraints, mininner, maxinner, Delta_bar, Delta0, Delta_cons)[0]
+            return out.cpu().numpy() if was_numpy else out
+        return self._solve(problem, x, eq_constraints, ineq_constraints, mininner, maxinner, Delta_bar, Delta0, Delta_cons)
+
+    def _solve(self, problem, x, eq_constraints, ineq_constraints, mininner, maxinner, Delta_bar, Delta0, Delta_cons):
         """x: R x *point_shape initial points.  Returns the R optimised points."""
         man = problem.manifold
         x = x.detach().clone()
@@ -203,7 +291,7 @@ class BatchedTrustRegions:
         neq = len(eqs)
         constrained = bool(eqs or ineqs)
 
-        if self._device_tcg_applies(problem, x, len(eqs) + len(ineqs)) and getattr(problem, "device_outer", True):
+        if not self.use_rand and self._device_tcg_applies(problem, x, len(eqs) + len(ineqs)) and getattr(problem, "device_outer", True):
             return self._solve_device(problem, x, eqs, ineqs, mininner, maxinner, Delta_bar, Delta0, Delta_cons)
         time0 = time.time()
         fx, g = problem.cost_grad(x)
@@ -218,7 +306,28 @@ class BatchedTrustRegions:
                 fc, gc = self._constraint_values_grads(problem, x, eqs + ineqs)
             else:
                 fc, gc = None, []
-            eta, Heta, stop_inner = self._tcg(problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons)
+            eta0 = None
+            if self.use_rand:                                             # (robust_trust_regions.py:176-181)
+                eta0 = 1e-6 * _randvec(man, x)
+                for _ in range(64):
+                    big = man.norm(x, eta0) > Delta
+                    if not bool(big.any()):
+                        break
+                    eta0 = torch.where(_bm(big, eta0), eta0 * float(eps) ** 0.25, eta0)
+            eta, Heta, stop_inner = self._tcg(problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons, eta0=eta0)
+            if self.use_rand:
+                # keep the better of the tCG step and the Cauchy point (:196-219)
+                Hg = problem.hess(x, g, grad_x=g)
+                g_Hg = man.inner(x, g, Hg)
+                safe = torch.where(g_Hg > 0, g_Hg, torch.ones_like(g_Hg))
+                tau_c = torch.where(g_Hg <= 0, torch.ones_like(ng), torch.clamp(ng ** 3 / (Delta * safe), max=1.0))
+                scale = -tau_c * Delta / torch.where(ng > 0, ng, torch.ones_like(ng))
+                eta_c, Heta_c = _bm(scale, g) * g, _bm(scale, Hg) * Hg
+                mdle = fx + man.inner(x, g, eta) + 0.5 * man.inner(x, Heta, eta)
+                mdlec = fx + man.inner(x, g, eta_c) + 0.5 * man.inner(x, Heta_c, eta_c)
+                cauchy = mdlec < mdle
+                eta = torch.where(_bm(cauchy, eta), eta_c, eta)
+                Heta = torch.where(_bm(cauchy, Heta), Heta_c, Heta)
             x_prop = man.retr(x, eta)
             fx_prop = problem.cost(x_prop)
             invalid = torch.zeros_like(active)
@@ -479,19 +588,29 @@ class BatchedTrustRegions:
             self.fcg_Pe = torch.zeros(R, ncons, dtype=dt, device=dev) if ncons else None
             self.gc = [torch.zeros_like(x) for _ in range(ncons)]
 
-    def _tcg_begin(self, problem, S):
+    def _tcg_begin(self, problem, S, eta0=None):
         man = problem.manifold
-        S.eta.zero_()
-        S.Heta.zero_()
-        S.r.copy_(S.g)
-        S.e_Pe.zero_()
+        if eta0 is None:
+            S.eta.zero_()
+            S.Heta.zero_()
+            S.r.copy_(S.g)
+            S.e_Pe.zero_()
+        else:                                       # use_rand: eta0 ~ 0 given by the caller, no preconditioner (:411-415)
+            S.eta.copy_(eta0)
+            S.Heta.copy_(problem.hess(S.x, S.eta, grad_x=S.g))
+            S.r.copy_(S.g + S.Heta)
+            S.e_Pe.copy_(man.inner(S.x, S.eta, S.eta))
         S.norm_r0.copy_(man.inner(S.x, S.r, S.r).clamp(min=0).sqrt())
-        z = problem.precon(S.x, S.r)
+        z = problem.precon(S.x, S.r) if eta0 is None else S.r
         S.z_r.copy_(man.inner(S.x, z, S.r))
         S.d_Pd.copy_(S.z_r)
         S.delta.copy_(-z)
-        S.e_Pd.zero_()
-        S.model_value.zero_()
+        if eta0 is None:
+            S.e_Pd.zero_()
+            S.model_value.zero_()
+        else:
+            S.e_Pd.copy_(man.inner(S.x, S.eta, S.delta))
+            S.model_value.copy_(man.inner(S.x, S.eta, S.g) + 0.5 * man.inner(S.x, S.eta, S.Heta))
         S.stop.fill_(MAX_INNER_ITER)
         S.running.copy_(S.active)
         if S.fcg_Pe is not None:
@@ -573,7 +692,7 @@ class BatchedTrustRegions:
             stop = torch.where(out, reason, stop)
             running = running & ~out
         # ---- next search direction (only the restarts still running move on)
-        z = problem.precon(x, r)
+        z = r if self.use_rand else problem.precon(x, r)
         z_r_new = inner(x, z, r)
         beta = z_r_new / S.z_r
         new_delta = torch.where(_bm(running, delta), -z + _bm(beta, delta) * delta, delta)
@@ -635,11 +754,11 @@ class BatchedTrustRegions:
                 break
         return T.end()
 
-    def _tcg(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons):
+    def _tcg(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons, eta0=None):
         ncons = 0 if fc is None else fc.shape[1]
-        if self._device_tcg_applies(problem, x, ncons):
+        if eta0 is None and self._device_tcg_applies(problem, x, ncons):
             return self._tcg_device(problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons)
-        graphs = bool(getattr(problem, "use_hip_graphs", False)) and x.is_cuda
+        graphs = bool(getattr(problem, "use_hip_graphs", False)) and x.is_cuda and eta0 is None
         key = (tuple(x.shape), x.device, ncons, neq, float(Delta_cons), int(mininner))
         cache = problem.__dict__.setdefault("_tcg_cache", {})
         ent = cache.get(key)
@@ -684,7 +803,7 @@ class BatchedTrustRegions:
             gb, g0, g1 = ent["graphs"]
             gb.replay()
         else:
-            self._tcg_begin(problem, S)
+            self._tcg_begin(problem, S, eta0)
         for j in range(int(maxinner)):
             check = j >= mininner
             if graphs:

@@ -112,8 +112,9 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
                             post_processing_manifold=None, lower_bounds=None, upper_bounds=None, inequality_constraints=None,
                             equality_constraints=None, approx_hessian=False, solver_init_conds=False, options=None):
     """Optimise every initial condition (R x 1 x d) and return (candidates R x 1 x d, acquisition values R)
-    (manifold_optimize.py:124-228).  `solver` is a BatchedTrustRegions (lock-step); any object exposing the pymanopt
-    `solve(problem, x=...)` duck type is driven restart by restart through a per-point adapter instead."""
+    (manifold_optimize.py:124-228).  `solver` is one of this package's trust-region classes (TrustRegions, ConstrainedTrustRegions,
+    StrictConstrainedTrustRegions = BatchedTrustRegions: all restarts in lock step); any other object exposing pymanopt's
+    `solve(problem, x=...)` is driven restart by restart (`_gen_candidates_pointwise`)."""
     x0 = initial_conditions.detach()
     if x0.shape[1] != 1:
         raise NotImplementedError("q != 1 is not handled (neither does the reference: manifold_optimize.py:206)")
@@ -133,8 +134,8 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
         return torch.where(zero.reshape((-1,) + (1,) * (d.dim() - 1)), d + 1e-30, d)
 
     if not isinstance(solver, BatchedTrustRegions):
-        raise TypeError("gabotorch_amd drives the restarts in lock step: pass a gabotorch_amd BatchedTrustRegions solver "
-                        "(its constructor takes the keyword arguments of the reference's TrustRegions / ConstrainedTrustRegions)")
+        return _gen_candidates_pointwise(x0, acquisition_function, manifold, solver, post_processing_manifold, inequality_constraints,
+                                         equality_constraints, approx_hessian, solver_init_conds)
     fused = None
     if (options or {}).get("fused_acquisition", True) and x0.is_cuda:
         # built-in surrogate + kernel + Mandel post-processing: value and gradient as a fixed chain of HIP launches
@@ -165,6 +166,50 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
             batch_acquisition = -fused.cost(opt_x)          # same values through the fused chain (one launch for the SPD kernels)
         else:
             batch_acquisition = acquisition_function(candidates)
+    return candidates.detach(), batch_acquisition.detach()
+
+
+def _gen_candidates_pointwise(x0, acquisition_function, manifold, solver, post_processing_manifold, inequality_constraints,
+                              equality_constraints, approx_hessian, solver_init_conds):
+    """The reference's own loop (manifold_optimize.py:175-228) for a solver that is not one of this package's lock-step trust regions:
+    any object with pymanopt's `solve(problem, x=ndarray[, eq_constraints=, ineq_constraints=])`.  One pymanopt-style `Problem` on
+    single points (autograd through the acquisition function, whose kernel evaluations are still the HIP kernels), restarts one
+    after the other on the host."""
+    import types
+
+    from ..pymanopt_addons.problem import Problem
+    from .approximate_hessian import get_hessianfd
+
+    def cost(x):                                     # (:177-185)
+        if post_processing_manifold is not None:
+            x = post_processing_manifold(x)
+        return -acquisition_function(x[None].double()).sum()
+
+    def precon(x, d):                                # (:189-192)
+        if np.sum(d) == 0.0:
+            d += 1e-30
+        return d
+
+    problem = Problem(manifold=manifold, cost=cost, verbosity=0, arg=torch.Tensor(), precon=precon)
+    if approx_hessian:
+        problem._hess = types.MethodType(get_hessianfd, problem)
+    constrained = equality_constraints is not None or inequality_constraints is not None
+    points = []
+    for i in range(x0.shape[0]):
+        if solver_init_conds:
+            opt_x = solver.solve(problem)
+        elif constrained:
+            opt_x = solver.solve(problem, x=x0[i].detach().cpu().numpy(), eq_constraints=equality_constraints,
+                                 ineq_constraints=inequality_constraints)
+        else:
+            opt_x = solver.solve(problem, x=x0[i].detach().cpu().numpy())
+        points.append(torch.as_tensor(np.asarray(opt_x), dtype=torch.float64))
+    candidates = torch.stack(points).to(x0.device)
+    if post_processing_manifold is not None:
+        candidates = post_processing_manifold(candidates)
+    candidates = candidates[:, None]
+    with torch.no_grad():
+        batch_acquisition = acquisition_function(candidates)
     return candidates.detach(), batch_acquisition.detach()
 
 

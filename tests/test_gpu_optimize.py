@@ -254,7 +254,8 @@ def test_sweep_with_fused_chain_matches_autograd_sweep():
     _, best_a, val_a, log_a = run_sweep(DEV, num_restarts=32, raw_samples=256, fused=False)
     _, best_f, val_f, log_f = run_sweep(DEV, num_restarts=32, raw_samples=256, fused=True)
     _, best_g, val_g, log_g = run_sweep(DEV, num_restarts=32, raw_samples=256, fused=True, hip_graphs=True)
-    np.testing.assert_allclose(best_f.cpu().numpy(), best_a.cpu().numpy(), rtol=0, atol=1e-8)
+    # two different evaluation orders stopped by |grad| < 1e-4: the optimum's coordinates agree to rounding noise / curvature ~ 1e-8
+    np.testing.assert_allclose(best_f.cpu().numpy(), best_a.cpu().numpy(), rtol=0, atol=5e-8)
     np.testing.assert_allclose(val_f, val_a, rtol=1e-9)
     np.testing.assert_allclose(val_g, val_a, rtol=1e-9)
     assert int(log_f["iterations"]) == int(log_a["iterations"]) == int(log_g["iterations"])
