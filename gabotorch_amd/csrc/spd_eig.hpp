@@ -71,12 +71,39 @@ __device__ __forceinline__ void tridiagonalize(double (&m)[tri_size(D)], double 
 #define GABO_QL_RCP rcp  /* reciprocal used inside the QL sweep: rcp (~1 ulp) or rcp_nr1 (2^-47) */
 #endif
 
-// gamma must never be exactly 0 (p = gamma^2 / c feeds the next rotation as a divisor): nudge an exact zero - a shift
-// that hit an eigenvalue exactly - to +-1e-75 (so p >= 1e-150 and the product p r
-// below stays a normal number), a perturbation far below rounding.  Replaces LAPACK's `c == 0` branch.
+// sqrt(x), x > 0, to ~2^-46: hardware seed + one coupled Goldschmidt step.  For the Wilkinson SHIFT only - its accuracy sets the
+// convergence rate of a sweep, never the eigenvalues (three instructions less per sweep than sqrt_nz).
+__device__ __forceinline__ double sqrt_shift(double x) {
+#ifdef GABO_QL_EXACT_SHIFT_SQRT
+    return sqrt_nz(x);
+#else
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(g, r, g);
+#endif
+}
+
+// p = gamma^2 / c feeds the next rotation as a divisor and must never be exactly 0 (a shift that hit an eigenvalue exactly gives
+// gamma = 0): floor it at 1e-150, so that the product p r below stays a normal number - a perturbation far below rounding.
+// Replaces LAPACK's `c == 0` branch.  One v_max_f64 per step (the first version nudged gamma itself to +-1e-75: two instructions).
+__device__ __forceinline__ double floor_p(double p) {
+#ifdef GABO_QL_GAMMA_NUDGE
+    return p;
+#else
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(p), "s"(1e-150));      // (p is a product of finite numbers: no NaN to canonicalise)
+    return r;
+#endif
+}
 __device__ __forceinline__ double nonzero(double g) {
+#ifdef GABO_QL_GAMMA_NUDGE
     double a = __builtin_fmax(__builtin_fabs(g), 1e-75);
     return copysign_d(a, g);
+#else
+    return g;
+#endif
 }
 
 // Eigenvalues of the symmetric tridiagonal (dg, sqrt(e2)) in place in dg (unordered).  Root-free QL, Wilkinson shift.
@@ -85,14 +112,18 @@ __device__ __forceinline__ double nonzero(double g) {
 // D-2 down to l with NO per-lane interior-split search, so the unrolled steps carry no predicates or branches and the
 // only divergence is the iteration count per stage.  An interior off-diagonal that is (or becomes) negligible is
 // simply swept through: the recurrence restarts by itself there (c -> 1, s -> 0).  p > 0 is an invariant (see
-// `nonzero`), hence r = p + bb > 0 and c = p / r > 0: no division can see a zero.  The last 2x2 block is closed form.
+// `floor_p`), hence r = p + bb > 0 and c = p / r > 0: no division can see a zero.  The last 2x2 block is closed form.
 template <int D>
 __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2)[D]) {
-    // Deflation threshold on e2[l] / |d[l] d[l+1]|.  LAPACK uses eps^2 (4.9e-32); 1e-22 is enough here: dropping an
-    // off-diagonal e perturbs a SYMMETRIC function of the eigenvalues (sum log^2) only to second order, ~e^2 f'' <= 1e-22,
+    // Deflation threshold on e2[l] / |d[l] d[l+1]|.  LAPACK uses eps^2 (4.9e-32); 1e-20 is enough here: dropping an
+    // off-diagonal e perturbs a SYMMETRIC function of the eigenvalues (sum log^2) only to second order, ~e^2 f'' <= 1e-20,
     // whatever the gap, and the iteration converges cubically, so the looser test saves the last sweep of many stages
-    // (measured: -6 % sweep steps, identical 3e-14 worst-case error of d^2 on the benchmark distribution).
-    constexpr double eps2 = 1e-22;
+    // (measured: 1e-32 -> 1e-22: -6 % sweep steps; 1e-22 -> 1e-20: another -1 % of the kernel's time; worst-case error of d^2 on the
+    // benchmark distribution 1e-13 in all three, tools/sim/ql_lookahead_sim.py).
+#ifndef GABO_QL_EPS2
+#define GABO_QL_EPS2 1e-20
+#endif
+    constexpr double eps2 = GABO_QL_EPS2;
 #ifndef GABO_QL_NOFLIP
     // QL deflates at the top (index 0) and converges fastest when the small end of a graded matrix sits there (LAPACK's
     // dsterf chooses QL vs QR on the same criterion): reverse the arrays per lane when |d[0]| > |d[D-1]|.  Measured on the
@@ -151,10 +182,10 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
             // evaluated division-free as d_l - sign(delta) (sqrt(delta^2 + e2_l) - |delta|).  The cancellation of the
             // rationalised form only costs ~eps |delta| in the SHIFT, which changes the convergence rate, never the result.
             double delta = 0.5 * (sb - sa);
-            double root = sqrt_nz(__builtin_fma(delta, delta, se));
+            double root = sqrt_shift(__builtin_fma(delta, delta, se));
             double sigma = sa - copysign_d(root - __builtin_fabs(delta), delta);
             double gamma = nonzero(dg[D - 1] - sigma);
-            double p = gamma * gamma;
+            double p = floor_p(gamma * gamma);
             double c = 1.0, s = 0.0;
             static_for_down<D - 2, l>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
@@ -186,7 +217,7 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
                 p = gamma * gamma * ic;
 #else
                 double gr = gamma * r;
-                p = (gr * t) * gr;
+                p = floor_p((gr * t) * gr);
 #endif
             });
             e2[l] = s * p;

@@ -24,7 +24,8 @@ def row_block(n_rows, rank, world):
 def sharded_gram(kernel_forward, x1, x2, gather=True):
     """K = kernel_forward(x1, x2) with the rows of x1 split over the ranks.  kernel_forward: any of this package's kernel
     `forward`s (or ops.spd_ai_pairwise / ops.sphere_pairwise partials).  Returns the full (N1, N2) matrix on every rank when
-    `gather`, else this rank's (rows, N2) block."""
+    `gather`, else this rank's (rows, N2) block.  x1 (..., N1, d) / x2 (..., N2, d) may carry leading batch dimensions (kept whole on
+    every rank)."""
     dist = _dist()
     if dist is None or dist.get_world_size() == 1:
         return kernel_forward(x1, x2)
@@ -33,16 +34,21 @@ def sharded_gram(kernel_forward, x1, x2, gather=True):
     lo, hi = row_block(n1, rank, world)
     per = (n1 + world - 1) // world
     n2 = x2.shape[-2]
-    block = kernel_forward(x1[lo:hi], x2) if hi > lo else x1.new_zeros((0, n2), dtype=torch.float64)
+    lead = tuple(x1.shape[:-2])                     # leading batch dimensions stay whole on every rank: only the rows are split
+    if hi > lo:
+        block = kernel_forward(x1[..., lo:hi, :], x2)
+    else:
+        block = x1.new_zeros(lead + (0, n2), dtype=torch.float64)
     if not gather:
         return block
-    pad = torch.zeros(per, n2, dtype=torch.float64, device=block.device)
-    pad[:hi - lo] = block
-    full = torch.empty(world * per, n2, dtype=torch.float64, device=block.device)
+    # rows first for the collective: each rank contributes one contiguous (per, *lead, n2) slab
+    pad = torch.zeros((per,) + lead + (n2,), dtype=torch.float64, device=block.device)
+    pad[:hi - lo] = block.movedim(-2, 0)
+    full = torch.empty((world * per,) + lead + (n2,), dtype=torch.float64, device=block.device)
     try:
         dist.all_gather_into_tensor(full, pad)           # one collective straight into the assembled matrix
     except (RuntimeError, NotImplementedError, AttributeError):
         parts = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(parts, pad)
         full = torch.cat(parts)
-    return full[:n1]
+    return full[:n1].movedim(0, -2)

@@ -141,6 +141,60 @@ class BatchedProblem:
         return man.ehess2rhess(x, eg.detach(), eh.detach(), u)
 
 
+class _PointwiseManifold:
+    """A manifold object whose methods take ONE point / tangent vector as numpy arrays (pymanopt's own classes) presented with
+    batched torch signatures: every call walks the restarts on the host."""
+
+    def __init__(self, manifold):
+        self.base = manifold
+        self._shape = getattr(manifold, "_shape", None)
+
+    @property
+    def dim(self):
+        return self.base.dim
+
+    @property
+    def typicaldist(self):
+        try:
+            return self.base.typicaldist
+        except NotImplementedError:
+            return None
+
+    def _map(self, name, like, *args):
+        import numpy as np
+        fn = getattr(self.base, name)
+        rows = [fn(*[a[i].detach().cpu().numpy() for a in args]) for i in range(args[0].shape[0])]
+        return torch.as_tensor(np.stack([np.asarray(r, dtype=np.float64) for r in rows])).to(like)
+
+    def inner(self, x, u, v):
+        return self._map("inner", x, x, u, v)
+
+    def norm(self, x, u):
+        return self._map("norm", x, x, u)
+
+    def retr(self, x, u):
+        return self._map("retr", x, x, u)
+
+    def transp(self, x1, x2, d):
+        return self._map("transp", x1, x1, x2, d)
+
+    def egrad2rgrad(self, x, g):
+        return self._map("egrad2rgrad", x, x, g)
+
+    def ehess2rhess(self, x, eg, eh, u):
+        return self._map("ehess2rhess", x, x, eg, eh, u)
+
+    def proj(self, x, u):
+        return self._map("proj", x, x, u)
+
+    def rand(self):
+        return self.base.rand()
+
+    @staticmethod
+    def zerovec(x):
+        return torch.zeros_like(x)
+
+
 class PointwiseProblemAdapter:
     """A pymanopt-style problem (`cost(x) -> float`, `grad(x)`, `hess(x, a)` on ONE point given as a numpy array - the object the
     reference hands to its solvers, pymanopt_addons/problem.py:14-159) presented with the BatchedProblem interface: every call
@@ -153,7 +207,9 @@ class PointwiseProblemAdapter:
 
     def __init__(self, problem):
         self.problem = problem
-        self.manifold = problem.manifold
+        # this package's manifolds (gabotorch_amd.manifolds) take batches of torch tensors natively; anything else is pymanopt's
+        man = problem.manifold
+        self.manifold = man if getattr(man, "batched", False) else _PointwiseManifold(man)
         self.n_cost = 0
         self.n_grad = 0
 
@@ -203,6 +259,9 @@ class BatchedTrustRegions:
         self.minstepsize, self.maxcostevals = minstepsize, maxcostevals
         self.logverbosity = logverbosity
         self.log = {}
+        # set to a list to record, per outer iteration of the generic lock-step path, the state the reference's solvers go through
+        # (iterate, radius, tCG step / stop reason, ratio, acceptance): what tests/golden/tr_traces.npz holds for the reference
+        self.trace = None
 
     # pymanopt's Solver keeps its stopping criteria under underscored names and outer solvers (e.g. an augmented Lagrangian loop)
     # tighten `_mingradnorm` between calls: same storage here
@@ -350,8 +409,12 @@ class BatchedTrustRegions:
                 boundary = boundary | (stop_inner == REACHED_CONSTRAINTS)
             grow = ~shrink & (rho > 0.75) & boundary
             newDelta = torch.where(shrink, Delta / 4, torch.where(grow, torch.clamp(2 * Delta, max=float(Delta_bar)), Delta))
+            Delta_before = Delta
             Delta = torch.where(active, newDelta, Delta)
             accept = active & model_decreased & (rho > self.rho_prime)
+            if self.trace is not None:
+                self.trace.append({"x": x.clone(), "Delta": Delta_before, "eta": eta.clone(), "stop_inner": stop_inner.clone(),
+                                   "rho": rho.clone(), "accept": accept.clone(), "active": active.clone(), "fx": fx.clone()})
             if bool(accept.any()):
                 x = torch.where(_bm(accept, x), x_prop, x)
                 fx = torch.where(accept, fx_prop, fx)

@@ -26,6 +26,8 @@ def _wrap(fn):
 class PositiveDefinite:
     """S^n_++ with the affine-invariant metric ([3P] pymanopt.manifolds.PositiveDefinite)."""
 
+    batched = True        # every method takes one point or a batch of restarts
+
     def __init__(self, n):
         self._n = n
         self._shape = (n, n)
@@ -83,6 +85,8 @@ class PositiveDefinite:
 
 class Sphere:
     """S^{n-1} in R^n ([3P] pymanopt.manifolds.Sphere)."""
+
+    batched = True
 
     def __init__(self, n):
         self._n = n

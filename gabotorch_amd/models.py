@@ -209,14 +209,17 @@ class SingleTaskGP(torch.nn.Module):
     Gamma(1.1, .05), noise constraint GreaterThan(1e-8), initial noise = prior mode).  Priors registered on the kernels through
     the gpytorch-compatible `register_prior` are picked up when the stand-in Kernel base class is in use."""
 
-    def __init__(self, train_x, train_y, covar_module, noise_prior=None, noise_lower_bound=1e-8):
+    def __init__(self, train_x, train_y, covar_module, noise_prior=None, noise_lower_bound=1e-8, initial_noise=None):
         super().__init__()
         self.train_x = train_x.double()
         self.train_y = train_y.double().reshape(-1)
         self.covar_module = covar_module
         self.noise_prior = noise_prior
         self.noise_lower_bound = float(noise_lower_bound)
-        init_noise = noise_prior.mode if noise_prior is not None and noise_prior.mode > noise_lower_bound else 1e-2
+        if initial_noise is not None and initial_noise > noise_lower_bound:
+            init_noise = float(initial_noise)
+        else:
+            init_noise = noise_prior.mode if noise_prior is not None and noise_prior.mode > noise_lower_bound else 1e-2
         self.raw_noise = torch.nn.Parameter(torch.tensor(math.log(math.expm1(init_noise - self.noise_lower_bound)), dtype=torch.float64))
         self.mean_constant = torch.nn.Parameter(torch.zeros((), dtype=torch.float64))
         self._cache = None
@@ -269,6 +272,19 @@ class SingleTaskGP(torch.nn.Module):
 
     def invalidate(self):
         self._cache = None
+
+    def set_train_data(self, inputs=None, targets=None, strict=True):
+        """gpytorch ExactGP.set_train_data [3P]: replace the training set between BO iterations (examples/gabo_spd.py:216; the
+        hyper-parameters keep their current values and stay trainable for the next fit)"""
+        if inputs is not None:
+            if strict and tuple(inputs.shape) != tuple(self.train_x.shape):
+                raise RuntimeError("Cannot modify shape of inputs (expected strict=False)")
+            self.train_x = inputs.double()
+        if targets is not None:
+            if strict and targets.numel() != self.train_y.numel():
+                raise RuntimeError("Cannot modify shape of targets (expected strict=False)")
+            self.train_y = targets.double().reshape(-1)
+        self.invalidate()
 
     # ---- fast surrogate fit: the distances are evaluated once, each evaluation is one gabo_gp_mll launch ------------------
     def _stationary_form(self):
@@ -329,7 +345,7 @@ class SingleTaskGP(torch.nn.Module):
             theta, os_, noise, mean = theta_fn(), os_fn(), self.noise, self.mean_constant
             ll, g_theta, g_os, g_noise, g_mean, bad = ops.gp_mll(e, y, theta.item(), os_.item(), noise.item(), mean.item())
             if bad:
-                raise RuntimeError("K + noise I is not positive definite")
+                raise torch.linalg.LinAlgError("K + noise I is not positive definite")
             pri = self._priors()
             value = (ll + (pri.item() if torch.is_tensor(pri) else pri)) / n
             # a linear stand-in with the same first derivatives as ll at this point, so that autograd does the chain rule
@@ -481,8 +497,8 @@ def fit_gpytorch_model(model, maxiter=200, fast=True):
             else:
                 loss = -model.marginal_log_likelihood()
                 loss.backward()
-        except RuntimeError:          # a trial point outside the SPD cone of K + noise I
-            return 1e10, np.zeros_like(v)
+        except torch.linalg.LinAlgError:      # a trial point outside the SPD cone of K + noise I (torch.linalg.cholesky); any other
+            return 1e10, np.zeros_like(v)      # error - a failed launch, a non-SPD kernel INPUT - is a real failure and propagates
         g = np.concatenate([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().double().reshape(-1).numpy()
                             for p in params])
         value = float(loss.item())

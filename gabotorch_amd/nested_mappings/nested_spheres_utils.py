@@ -1,7 +1,7 @@
 """Nested-sphere projections with the reference's names and signatures (BoManifolds/nested_mappings/nested_spheres_utils.py).
 
-Per level S^d -> S^(d-1): the rotation of the axis to the north pole is ONE d x d matrix for all points, so rotating is a
-plain GEMM (torch.matmul -> rocBLAS) and the point-wise part (distance to the axis, rescaling, renormalisation with the
+Per level S^d -> S^(d-1): the rotation of the axis to the north pole acts in one plane only, so it is applied to the points as a rank-2
+update (two inner products per point, `rotate_along_geodesic`; the d x d matrix is never formed) and the point-wise part (distance to the axis, rescaling, renormalisation with the
 reference's + 1e-6 terms) is the HIP epilogue gabo_nested_sphere_epilogue, differentiable through its HIP backward.  The
 axes stay differentiable through the rotation matrix (torch)."""
 import math
@@ -9,35 +9,43 @@ import math
 import torch
 
 from .. import ops
-from ..Riemannian_utils.sphere_utils_torch import rotation_from_sphere_points_torch
+from ..Riemannian_utils.sphere_utils_torch import rotate_along_geodesic
 
 
 def _dist_value(sphere_distance_to_axis):
     return float(sphere_distance_to_axis.reshape(-1)[0]) if torch.is_tensor(sphere_distance_to_axis) else float(sphere_distance_to_axis)
 
 
-def _rotation_to_north(sphere_axis, like):
-    axis = sphere_axis.unsqueeze(-2) if sphere_axis.dim() == 1 else sphere_axis
-    axis = axis.to(like.device, like.dtype)
-    north = torch.zeros_like(axis)
-    north[:, -1] = 1.0
-    return rotation_from_sphere_points_torch(axis, north)
+def _north(like_axis):
+    north = torch.zeros_like(like_axis.reshape(-1))
+    north[-1] = 1.0
+    return north
+
+
+def _to_north(points, sphere_axis):
+    """points rotated by the rotation that carries the axis to the north pole (nested_spheres_utils.py:33-36): a rank-2 update of the
+    points - two inner products per point, no d x d matrix, no GEMM"""
+    axis = sphere_axis.reshape(-1).to(points.device, points.dtype)
+    return rotate_along_geodesic(points, axis, _north(axis))
+
+
+def _from_north(points, sphere_axis):
+    axis = sphere_axis.reshape(-1).to(points.device, points.dtype)
+    return rotate_along_geodesic(points, axis, _north(axis), inverse=True)
 
 
 def projection_from_sphere_to_nested_sphere(x, sphere_axis, sphere_distance_to_axis):
     """Points of S^d projected onto the small circle at distance `sphere_distance_to_axis` from `sphere_axis`
     (nested_spheres_utils.py:13-65).  x: (N, d) or (..., N, d)."""
-    rot = _rotation_to_north(sphere_axis, x)
     flat = x.reshape(-1, x.shape[-1])
-    y_rot = ops.nested_sphere_epilogue((flat @ rot.T).detach(), _dist_value(sphere_distance_to_axis), mode=1).to(x.dtype)
-    return (y_rot @ rot).reshape(x.shape)
+    y_rot = ops.nested_sphere_epilogue(_to_north(flat, sphere_axis).detach(), _dist_value(sphere_distance_to_axis), mode=1).to(x.dtype)
+    return _from_north(y_rot, sphere_axis).reshape(x.shape)
 
 
 def projection_from_sphere_to_next_subsphere(x, sphere_axis, sphere_distance_to_axis):
     """S^d -> S^(d-1) (nested_spheres_utils.py:68-114); differentiable in x and in the axis."""
-    rot = _rotation_to_north(sphere_axis, x)
     flat = x.reshape(-1, x.shape[-1])
-    z = ops.nested_sphere_next(flat @ rot.T, _dist_value(sphere_distance_to_axis))
+    z = ops.nested_sphere_next(_to_north(flat, sphere_axis), _dist_value(sphere_distance_to_axis))
     return z.reshape(tuple(x.shape[:-1]) + (x.shape[-1] - 1,))
 
 
@@ -55,19 +63,15 @@ def projection_from_sphere_to_subsphere(x, sphere_axes, sphere_distances_to_axes
 
 def projection_from_subsphere_to_next_sphere(x_subsphere, sphere_axis, sphere_distance_to_axis):
     """S^(d-1) -> S^d: [sin r z, cos r] rotated from the north pole to the axis (nested_spheres_utils.py:149-179).  A concatenation
-    and one small GEMM: torch on the inputs' device."""
-    axis = sphere_axis.unsqueeze(-2) if sphere_axis.dim() == 1 else sphere_axis
-    axis = axis.to(x_subsphere.device, x_subsphere.dtype)
-    north = torch.zeros_like(axis)
-    north[:, -1] = 1.0
-    rot = rotation_from_sphere_points_torch(north, axis)
+    and one rank-2 update: torch on the inputs' device."""
     if torch.is_tensor(sphere_distance_to_axis):          # kept as a tensor: the reconstruction cost is differentiated w.r.t. it
         r = sphere_distance_to_axis.reshape(()).to(x_subsphere.device, x_subsphere.dtype)
         sin_r, cos_r = torch.sin(r), torch.cos(r)
     else:
         sin_r, cos_r = math.sin(float(sphere_distance_to_axis)), math.cos(float(sphere_distance_to_axis))
     cos_vector = cos_r * torch.ones(x_subsphere.shape[0], 1, dtype=x_subsphere.dtype, device=x_subsphere.device)
-    return torch.cat((sin_r * x_subsphere, cos_vector), 1) @ rot.T
+    # R(north -> axis) = R(axis -> north)^T
+    return _from_north(torch.cat((sin_r * x_subsphere, cos_vector), 1), sphere_axis)
 
 
 def projection_from_subsphere_to_sphere(x_subsphere, sphere_axes, sphere_distances_to_axes):

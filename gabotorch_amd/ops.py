@@ -56,6 +56,21 @@ def _prep(x, device):
     return x.to(device)
 
 
+def _require(dev, **tensors):
+    """The pointer-taking wrappers below hand raw device addresses to the library: anything that is not a contiguous tensor on
+    `dev` of the dtype the C ABI reads there would be reinterpreted silently.  fp64 unless the name says otherwise."""
+    dev = torch.device(dev)
+    for name, t in tensors.items():
+        if t is None:
+            continue
+        want = (torch.uint8, torch.bool) if name in ("active", "invalid") else ((torch.int64,) if name == "iters" else (torch.float64,))
+        on_dev = torch.is_tensor(t) and t.device.type == dev.type and (dev.index is None or t.device.index == dev.index)
+        if not on_dev or t.dtype not in want or not t.is_contiguous():
+            raise TypeError(f"{name}: expected a contiguous {want[0]} tensor on {dev}, got "
+                            f"{getattr(t, 'dtype', type(t))} on {getattr(t, 'device', None)}"
+                            f"{'' if not torch.is_tensor(t) or t.is_contiguous() else ' (not contiguous)'}")
+
+
 def _mandel_dim(dv):
     d = int((-1.0 + (1.0 + 8.0 * dv) ** 0.5) / 2.0)
     if d * (d + 1) // 2 != dv:
@@ -646,8 +661,9 @@ def spd_acq_eval(x_mandel, train_factors, alpha, linv, linv_t, beta, mode, mean,
                  out_sign=1.0, need_grad=True, active_ptr=None, out=None):
     """Single-launch acquisition value (R) and Euclidean gradient (R x d_vec, Mandel) at SPD candidates."""
     lib = _lib.load()
-    x = x_mandel.contiguous()
-    dev = x.device
+    dev = _device_for(train_factors, x_mandel)
+    x = _prep(x_mandel, dev).contiguous()
+    _require(dev, train_factors=train_factors, alpha=alpha, linv=linv, linv_t=linv_t)
     r, dv = x.shape
     n = train_factors.shape[1]
     if out is not None:           # (value, grad) buffers to update in place: masked candidates keep their previous entries
@@ -793,6 +809,7 @@ class SpdTr:
         self.status = torch.zeros(2, dtype=torch.int32, device=device)
 
     def propose(self, x, g, Delta, active, gc, fc, neq, delta_cons, theta, kappa, mininner, maxinner):
+        _require(self.dev, x=x, g=g, Delta=Delta, active=active, gc=gc, fc=fc)
         ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.gabo_spd_tr_propose(x.data_ptr(), g.data_ptr(), Delta.data_ptr(), active.data_ptr(), ptr(gc), ptr(fc),
@@ -805,6 +822,7 @@ class SpdTr:
     def solve(self, x, fx, g, ng, Delta, active, iters, kinds, bounds, strict, delta_cons, theta, kappa, mininner, maxinner, delta_bar,
               rho_prime, rho_regularization, mingradnorm, maxiter):
         """The whole solve in one launch (built-in eigenvalue constraints `kinds`/`bounds`, or none)."""
+        _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters)
         import ctypes
         nc = len(kinds)
         ck = (ctypes.c_int * max(nc, 1))(*kinds)
@@ -818,6 +836,7 @@ class SpdTr:
                                                   _stream_ptr(self.dev)), "gabo_spd_tr_solve")
 
     def update(self, x, fx, g, ng, Delta, active, iters, invalid, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter):
+        _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters, invalid=invalid)
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.gabo_spd_tr_update(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
                                                    active.data_ptr(), iters.data_ptr(), None if invalid is None else invalid.data_ptr(),
@@ -830,8 +849,8 @@ def sphere_acq_eval(x, acq_params, need_grad=True):
     """Single-launch acquisition value (R) and Euclidean gradient (R x dim) at points of the sphere; acq_params: _lib.SphereAcqParams."""
     import ctypes
     lib = _lib.load()
-    xx = x.contiguous()
-    dev = xx.device
+    dev = _device_for(x)
+    xx = _prep(x, dev).contiguous()           # a float32 / host tensor would otherwise be read as fp64 device memory
     r = xx.shape[0]
     value = torch.empty(r, dtype=torch.float64, device=dev)
     grad = torch.empty_like(xx) if need_grad else None
@@ -857,6 +876,7 @@ class SphereTr:
         self.any_active = torch.ones(1, dtype=torch.int32, device=device)
 
     def propose(self, x, g, Delta, active, gc, fc, neq, delta_cons, theta, kappa, mininner, maxinner):
+        _require(self.dev, x=x, g=g, Delta=Delta, active=active, gc=gc, fc=fc)
         ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.gabo_sphere_tr_propose(x.data_ptr(), g.data_ptr(), Delta.data_ptr(), active.data_ptr(), ptr(gc), ptr(fc),
@@ -867,6 +887,7 @@ class SphereTr:
         return self.x_prop
 
     def update(self, x, fx, g, ng, Delta, active, iters, invalid, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter):
+        _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters, invalid=invalid)
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.gabo_sphere_tr_update(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
                                                       active.data_ptr(), iters.data_ptr(), None if invalid is None else invalid.data_ptr(),
@@ -876,6 +897,7 @@ class SphereTr:
 
     def solve(self, x, fx, g, ng, Delta, active, iters, kinds, bounds, strict, delta_cons, theta, kappa, mininner, maxinner, delta_bar,
               rho_prime, rho_regularization, mingradnorm, maxiter):
+        _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters)
         assert not kinds, "the sphere has no built-in constraints"
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.gabo_sphere_tr_solve(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),

@@ -86,7 +86,9 @@ def _gram_worker(rank, world, port, out_dir):
         g = torch.Generator().manual_seed(0)
         x1, x2 = torch.randn(11, 4, generator=g, dtype=torch.float64), torch.randn(7, 4, generator=g, dtype=torch.float64)
         k = lambda a, b: torch.exp(-torch.cdist(a, b) ** 2)       # noqa: E731  stand-in kernel: the partition logic is under test
-        torch.save({"full": sharded_gram(k, x1, x2), "block": sharded_gram(k, x1, x2, gather=False), "ref": k(x1, x2)},
+        b1, b2 = torch.randn(2, 3, 11, 4, generator=g, dtype=torch.float64), torch.randn(2, 3, 7, 4, generator=g, dtype=torch.float64)
+        torch.save({"full": sharded_gram(k, x1, x2), "block": sharded_gram(k, x1, x2, gather=False), "ref": k(x1, x2),
+                    "bfull": sharded_gram(k, b1, b2), "bblock": sharded_gram(k, b1, b2, gather=False), "bref": k(b1, b2)},
                    os.path.join(out_dir, f"g{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -103,3 +105,6 @@ def test_sharded_gram_row_blocks(tmp_path):
         assert torch.equal(o["full"], o["ref"])
         lo, hi = row_block(11, r, 3)
         assert torch.equal(o["block"], o["ref"][lo:hi])
+        # leading batch dimensions: only the rows (dim -2) are split
+        assert o["bfull"].shape == (2, 3, 11, 7) and torch.equal(o["bfull"], o["bref"])
+        assert torch.equal(o["bblock"], o["bref"][..., lo:hi, :])

@@ -223,7 +223,11 @@ def test_baseline_config3_full_size_properties():
     a, b = slice(37, 1000), slice(2111, 4096)
     np.testing.assert_allclose(ops.spd_ai_pairwise(X[a], X[b], beta=bench.BETA).cpu().numpy(),
                                ops.spd_ai_pairwise(X[b], X[a], beta=bench.BETA).T.cpu().numpy(), rtol=1e-9, atol=1e-13)
-    np.testing.assert_array_equal(ops.spd_ai_pairwise(X[a], X[b], beta=bench.BETA).cpu().numpy(), K[a, b].cpu().numpy())
+    # a slice evaluated on its own groups other pairs into a wave: the look-ahead QL (spd_eig.hpp) lets a lane spend the sweeps its wave
+    # still needs on its own next stage, so the result depends on the wave's company in the last bits (equally accurate, not bitwise)
+    np.testing.assert_allclose(ops.spd_ai_pairwise(X[a], X[b], beta=bench.BETA).cpu().numpy(), K[a, b].cpu().numpy(), rtol=1e-11, atol=1e-300)
+    # ... and the same call is deterministic
+    assert torch.equal(ops.spd_ai_pairwise(X[a], X[b], beta=bench.BETA), ops.spd_ai_pairwise(X[a], X[b], beta=bench.BETA))
     blk = (slice(4000, 4096), slice(0, 130))
     want = ospd.spd_ai_gaussian_kernel(x[blk[0]], x[blk[1]], bench.BETA)
     np.testing.assert_allclose(K[blk].cpu().numpy(), want, rtol=1e-9, atol=1e-14)

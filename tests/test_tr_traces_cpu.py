@@ -1,0 +1,119 @@
+"""The lock-step solver against per-iteration TRACES of the reference's own solvers (tests/golden/tr_traces.npz, produced by
+tests/golden/make_golden_tr_traces.py from the unmodified reference code), on CPU with the torch stand-in manifolds.
+
+Two reference runs are stored: "f32" = the reference as it is (its SPD distance keeps the eigenvalues in a float32 buffer,
+spd_utils_torch.py:108), "f64" = the same code under torch's float64 default dtype.  The solver here is fp64 and must follow the f64
+trace iterate by iterate; the f32 trace is the same algorithm with the reference's own single-precision noise on every gradient,
+which get_hessianfd amplifies by 1/c = 2^14 |a|: that noise - not a difference of algorithm - is what limits agreement with the
+reference-as-is, and the tests below measure it."""
+import numpy as np
+import pytest
+import torch
+
+from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedProblem
+from gabotorch_amd.manifold_optimization.constrained_trust_regions import ConstrainedTrustRegions, StrictConstrainedTrustRegions
+from gabotorch_amd.manifold_optimization.robust_trust_regions import TrustRegions
+from tests._cpu_manifolds import CpuSpd, CpuSphere, sphere_kernel_mean_cost, spd_kernel_mean_cost
+from tests._traces import compare_with_reference_trace
+
+T = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64)   # noqa: E731
+
+
+def _problem(g, name, approx):
+    if name.startswith("sph"):
+        n = int(name[3:])
+        return BatchedProblem(CpuSphere(n), sphere_kernel_mean_cost(T(g[f"{name}_Y"]), T(g[f"{name}_w"]), float(g[f"{name}_beta"])),
+                              approx_hessian=approx)
+    base = name.rstrip("c")
+    d = int(base[3:])
+    return BatchedProblem(CpuSpd(d), spd_kernel_mean_cost(T(g[f"{name}_Y"]), T(g[f"{name}_w"]), float(g[f"{name}_beta"])),
+                          approx_hessian=True)
+
+
+@pytest.mark.parametrize("name", ["sph3", "sph5", "spd2", "spd3", "spd5"])
+def test_get_hessianfd_matches_reference(golden, name):
+    """approximate_hessian.py:11-62 at fixed (x, a): <= 1e-8 of the reference's fp64 run; the reference-as-is is 1e-3 .. 1e-2 away
+    from its own fp64 run on the SPD manifold (single-precision gradients divided by c), and exact on the sphere."""
+    g = golden("tr_traces.npz")
+    prob = _problem(g, name, True)
+    x, a = T(g[f"{name}_x0"]), T(g[f"{name}_hv_a"])
+    f, grad = prob.cost_grad(x)
+    np.testing.assert_allclose(f.numpy(), g[f"{name}_hv_cost_f64"], rtol=1e-12)
+    np.testing.assert_allclose(grad.numpy(), g[f"{name}_hv_grad_f64"], rtol=0, atol=1e-11 * np.abs(g[f"{name}_hv_grad_f64"]).max())
+    hv = prob.hess(x, a, grad_x=grad).numpy()
+    ref64, ref32 = g[f"{name}_hv_fd_f64"], g[f"{name}_hv_fd_f32"]
+    scale = np.abs(ref64).reshape(len(ref64), -1).max(1).reshape((-1,) + (1,) * (ref64.ndim - 1))
+    assert np.max(np.abs(hv - ref64) / scale) < 1e-8
+    noise = np.max(np.abs(ref32 - ref64) / scale)
+    if name.startswith("sph"):
+        assert noise < 1e-8                         # no single-precision buffer on the sphere path
+    else:
+        assert 1e-4 < noise < 5e-2                  # the reference's own noise floor on S^d_++ (documented in DESIGN.md)
+        assert np.max(np.abs(hv - ref32) / scale) < 2 * noise
+
+
+@pytest.mark.parametrize("name,run,cls,kw", [
+    ("sph3", "tr_exact", TrustRegions, {}), ("sph5", "tr_exact", TrustRegions, {}),
+    ("sph3", "tr_fd", TrustRegions, {}), ("sph5", "tr_fd", TrustRegions, {}),
+    ("sph3", "con", ConstrainedTrustRegions, {"mingradnorm": 1e-6, "maxiter": 100}),
+    ("sph5", "strict", StrictConstrainedTrustRegions, {"mingradnorm": 1e-6, "maxiter": 100}),
+    ("spd2", "tr_fd", TrustRegions, {"mingradnorm": 1e-4, "maxiter": 100}),
+    ("spd3", "tr_fd", TrustRegions, {"mingradnorm": 1e-4, "maxiter": 100}),
+    ("spd2", "con", ConstrainedTrustRegions, {"mingradnorm": 1e-4, "maxiter": 100}),
+    ("spd3", "con", ConstrainedTrustRegions, {"mingradnorm": 1e-4, "maxiter": 100}),
+    ("spd3", "strict", StrictConstrainedTrustRegions, {"mingradnorm": 2e-4, "maxiter": 100, "minstepsize": 1e-4}),
+])
+def test_iterates_follow_the_reference_fp64_trace(golden, name, run, cls, kw):
+    g = golden("tr_traces.npz")
+    prob = _problem(g, name, approx=(run == "tr_fd" or name.startswith("spd")))      # as make_golden_tr_traces.py ran the reference
+    solver = cls(**kw)
+    solver.trace = []
+    constrained = run in ("con", "strict")
+    x0 = T(g[f"{name}_con_x0"] if (constrained and name.startswith("sph")) else g[f"{name}_x0"])
+    cons = None
+    if constrained:
+        if name.startswith("sph"):
+            cons = [lambda x: x[..., 0] - 0.3]
+        else:
+            mx = float(g[f"{name}_maxeig"])
+            cons = [lambda x: mx - torch.linalg.eigvalsh(x)[..., -1]]
+    x = solver.solve(prob, x0, ineq_constraints=cons) if constrained else solver.solve(prob, x0)
+    res = compare_with_reference_trace(solver.trace, g, f"{name}_{run}_f64", atol_x=1e-6)
+    ok = g[f"{name}_{run}_f64_ok"]
+    for s, (agree, nit, worst, parted_at, drift) in enumerate(res):
+        if not ok[s]:
+            continue
+        # every outer iteration of the reference is reproduced: same radius, same tCG stop reason, iterate within 1e-6 (FD Hessian:
+        # differences of fp64 gradients divided by c = 2^-14/|a| carry ~1e-10 relative rounding noise, which the iteration contracts).
+        # The one way the runs may part: a restart of the STRICT variant crawling along the constraint bound - whether a proposal that
+        # lands within ~1e-8 of the bound is feasible (accepted, radius doubled) or not (rejected, radius quartered) is decided by the
+        # 1e-11 the iterates differ by.  The two runs then keep shadowing each other along the bound: the drift stays below 1e-6.
+        assert agree == nit or (run == "strict" and agree >= 30 and drift < 1e-6), (name, run, s, agree, nit, worst, parted_at, drift)
+    fin = g[f"{name}_{run}_f64_x"]
+    np.testing.assert_allclose(x.numpy()[ok], fin[ok], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(prob.cost(x).numpy()[ok], g[f"{name}_{run}_f64_f"][ok], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["spd2", "spd3", "spd5", "spd5c"])
+def test_distance_to_the_reference_as_is_is_the_references_own_noise(golden, name):
+    """Against the reference AS IT IS (single-precision eigenvalue buffer) the end costs of the constrained solvers can only agree to
+    the distance between the reference's own two runs (f32 vs f64 default dtype): measured here per problem - 1e-8 .. 1.6e-2
+    relative, largest on S^3_++ where every restart runs into maxiter on the bound - and required of this implementation with a factor 2.  This is
+    where the 2e-3 of tests/test_trust_regions_cpu.py / test_gpu_optimize.py comes from; against the fp64 run the bound is 1e-9
+    (test_iterates_follow_the_reference_fp64_trace)."""
+    g = golden("tr_traces.npz")
+    prob = _problem(g, name, True)
+    mx = float(g[f"{name}_maxeig"])
+    x0 = T(g[f"{name}_x0"])
+    for run, cls, kw in (("con", ConstrainedTrustRegions, {"mingradnorm": 1e-4, "maxiter": 100}),
+                         ("strict", StrictConstrainedTrustRegions, {"mingradnorm": 2e-4, "maxiter": 100, "minstepsize": 1e-4})):
+        ok = g[f"{name}_{run}_f64_ok"] & g[f"{name}_{run}_f32_ok"]
+        f32, f64 = g[f"{name}_{run}_f32_f"][ok], g[f"{name}_{run}_f64_f"][ok]
+        own_noise = np.max(np.abs(f32 - f64) / np.maximum(np.abs(f64), 1e-3))
+        x = cls(**kw).solve(prob, x0[torch.tensor(ok)], ineq_constraints=[lambda x: mx - torch.linalg.eigvalsh(x)[..., -1]])
+        ours = prob.cost(x).numpy()
+        to_f64 = np.max(np.abs(ours - f64) / np.maximum(np.abs(f64), 1e-3))
+        to_f32 = np.max(np.abs(ours - f32) / np.maximum(np.abs(f64), 1e-3))
+        assert own_noise < 5e-2, (name, run, own_noise)                 # (1.6e-2 on S^3_++ strict: |f| ~ 3e-3 at a maxiter end point)
+        assert to_f64 < 1e-5, (name, run, to_f64)               # north_star: acquisition optima within 1e-5 relative fp64
+        assert to_f32 < 2 * own_noise + 1e-9, (name, run, to_f32, own_noise)

@@ -12,6 +12,7 @@ import numpy as np
 D = 10
 EPS2 = 1e-22
 ZERO = True
+PFLOOR = False
 
 
 def synth(n, d, seed):
@@ -101,8 +102,8 @@ def ql(dg, e2, lookahead, wave=64):
             delta = 0.5 * (d1 - d0)
             root = np.sqrt(delta * delta + ee)
             sigma = d0 - np.copysign(root - np.abs(delta), delta)
-            gamma = nonzero(dg[idx, D - 1] - sigma)
-            p = gamma * gamma
+            gamma = (dg[idx, D - 1] - sigma) if PFLOOR else nonzero(dg[idx, D - 1] - sigma)
+            p = np.maximum(gamma * gamma, 1e-150) if PFLOOR else gamma * gamma
             c = np.ones(len(idx))
             s = np.zeros(len(idx))
             for i in range(D - 2, l - 1, -1):
@@ -116,10 +117,10 @@ def ql(dg, e2, lookahead, wave=64):
                 s = bb * ir
                 oldgam = gamma
                 al = dg[idx, i]
-                gamma = nonzero(c * (al - sigma) - s * oldgam)
+                gamma = (c * (al - sigma) - s * oldgam) if PFLOOR else nonzero(c * (al - sigma) - s * oldgam)
                 dg[idx, i + 1] = oldgam + (al - gamma)
                 gr = gamma * r
-                p = (gr * t) * gr
+                p = np.maximum((gr * t) * gr, 1e-150) if PFLOOR else (gr * t) * gr
             e2[idx, l] = s * p
             dg[idx, l] = sigma + gamma
     a, b2, cc = dg[:, D - 2].copy(), e2[:, D - 2].copy(), dg[:, D - 1].copy()
