@@ -7,10 +7,12 @@ A "step" = one Gram build K = SpdAffineInvariantGaussianKernel(X, X) on a synthe
 `symmetric_gram`, it is not `value`).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...                 (spawns its N ranks itself through torch.distributed.run, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Multi-GPU: the path shards by independent Gram builds (one point set per rank, no data-path collective) -> "weak".
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  `roofline` is the binding resource of the dominant kernel (fp64 issue, flop model of SURVEY 8d);
+the streaming-byte model the scope contract also names is reported under `roofline_hbm_streaming_model` and marked non-physical.
 """
 import argparse
 import json
@@ -101,16 +103,24 @@ def timed(job, steps, warmup, dist):
 
 def cpu_baseline(x):
     """The oracle's reference-faithful port (per-pair eigh loop, spd_utils_torch.py:87-120 op sequence) on a bounded
-    sample of the same workload: the first `rows` rows of the Gram matrix against all columns."""
+    sample of the same workload: the first `rows` rows of the Gram matrix against all columns.  Timed twice: torch pinned to ONE
+    thread (`value`, `cores` = 1: the per-pair loop is scalar, so this is what the reference's structure can use) and with every
+    host core offered to torch (`all_threads`: the 10 x 10 eigh calls do not parallelise, extra threads only add overhead)."""
     from oracle import spd as ospd
     rows = 320
-    # the port's time is the per-pair eigh loop, which is scalar: pin torch to ONE thread so that `cores` is what was used
     prev_threads = torch.get_num_threads()
     torch.set_num_threads(1)
     t0 = time.perf_counter()
     k = ospd.spd_ai_gaussian_kernel(x[:rows], x, BETA, faithful=True)
     dt = time.perf_counter() - t0
+    ncpu = os.cpu_count() or 1
+    rows_all = 96
+    torch.set_num_threads(ncpu)
+    t2 = time.perf_counter()
+    ka = ospd.spd_ai_gaussian_kernel(x[:rows_all], x, BETA, faithful=True)
+    dta = time.perf_counter() - t2
     torch.set_num_threads(prev_threads)
+    assert np.allclose(ka, k[:rows_all], rtol=1e-9, atol=1e-14)
     # context line (SURVEY 8d): the same arithmetic vectorised on the CPU (batched LAPACK eigvalsh), not what the reference does
     vrows = 64
     t1 = time.perf_counter()
@@ -118,11 +128,82 @@ def cpu_baseline(x):
     dtv = time.perf_counter() - t1
     assert np.allclose(kv, k[:vrows], rtol=1e-9, atol=1e-14)
     return {"value": rows * x.shape[0] / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "all_threads": {"value": rows_all * x.shape[0] / dta, "unit": "pairs/s", "cores": ncpu, "torch_threads": ncpu,
+                            "sample": f"first {rows_all} Gram rows ({rows_all * x.shape[0]} pairs, {dta:.1f} s)"},
             "vectorised_numpy_pairs_per_s": vrows * x.shape[0] / dtv,
             "sample": f"first {rows} of {x.shape[0]} Gram rows x all {x.shape[0]} columns ({rows * x.shape[0]} pairs, {dt:.1f} s): "
                       "oracle.spd.affine_invariant_distance_faithful = the reference's op sequence (Mandel->matrix, Cholesky, "
                       "inverse, two bmm, one torch.linalg.eigh per pair in a Python loop, exp), torch CPU fp64, one thread (the loop is scalar)",
-            "host_cpus": os.cpu_count()}, k
+            "host_cpus": ncpu}, k
+
+
+def config5_pieces(device):
+    """BASELINE.json config 5 at its stated size: N = 4096 points of S^20_++ projected to S^2_++ (Y = W^T X W, nested_spd_utils.py:13-48)
+    followed by the nested affine-invariant Gram and the log-Euclidean Gram of the latent points; parity of a block against the oracle."""
+    from gabotorch_amd import ops as _ops
+    from oracle import spd as ospd
+    n, D, d = N_POINTS, 20, 2
+    xm = synthetic_spd_mandel(n, D, 1234)
+    rng = np.random.default_rng(4321)
+    W = np.ascontiguousarray(np.linalg.qr(rng.standard_normal((D, D)))[0][:, :d])
+    x, w = torch.tensor(xm, device=device), torch.tensor(W, device=device)
+    beta5 = 0.6 + math.log(2.0)                     # beta_min of S^2_++ (examples/gabo_spd.py:151-152)
+
+    def ev_ms(fn, iters=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    ms_p = ev_ms(lambda: _ops.spd_project(x, w))
+    y = _ops.spd_project(x, w)
+    ms_ai = ev_ms(lambda: _ops.spd_ai_pairwise(y, y, beta=beta5))
+    ms_lg = ev_ms(lambda: _ops.spd_logm_mandel(y))
+    lg = _ops.spd_logm_mandel(y)
+    ms_le = ev_ms(lambda: _ops.frobenius_pairwise(lg, lg, beta=1.0))
+    # parity: projection, then both Gram blocks against the oracle
+    xs = ospd.vector_to_symmetric_matrix_mandel(xm[:96])
+    yo = ospd.symmetric_matrix_to_vector_mandel(ospd.projection_from_spd_to_nested_spd(xs, W))
+    e_p = float(np.max(np.abs(y[:96].cpu().numpy() - yo)))
+    kai = _ops.spd_ai_pairwise(y[:96], y[:96], beta=beta5).cpu().numpy()
+    e_ai = float(np.max(np.abs(kai - ospd.spd_ai_gaussian_kernel(yo, yo, beta5))))
+    kle = _ops.frobenius_pairwise(lg[:96], lg[:96], beta=1.0).cpu().numpy()
+    e_le = float(np.max(np.abs(kle - ospd.log_euclidean_gaussian_kernel(yo, yo, 1.0))))
+    if not (e_p < 1e-10 and e_ai < 1e-9 and e_le < 1e-9):
+        raise RuntimeError(f"config 5 parity gate failed: {e_p} {e_ai} {e_le}")
+    pairs = n * n
+    hbm = lambda nbytes, ms: {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",   # noqa: E731
+                              "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return {"workload": "hd_gabo_spd pieces, N=4096: projection S^20_++ -> S^2_++ (W from qr(randn), seed 4321), nested affine-invariant "
+                        "Gram (beta=0.6+ln2), logm of the latent points, log-Euclidean Gram (lengthscale 1)",
+            "projection_ms": ms_p, "projection_matrices_per_s": n / (ms_p * 1e-3),
+            "projection_roofline": dict(hbm(n * (D * (D + 1) // 2 + 3) * 8, ms_p),
+                                        model="one read of the 210-entry Mandel vector + one write of the 3-entry result per matrix"),
+            "nested_ai_gram_ms": ms_ai, "nested_ai_gram_pairs_per_s": pairs / (ms_ai * 1e-3),
+            "nested_ai_gram_roofline": dict(hbm(pairs * 8.0, ms_ai), model="8 algorithmic B/pair: one fp64 output (2 x 2 operands are L2-resident)"),
+            "logm_ms": ms_lg,
+            "log_euclidean_gram_ms": ms_le, "log_euclidean_gram_pairs_per_s": pairs / (ms_le * 1e-3),
+            "log_euclidean_gram_roofline": dict(hbm(pairs * 8.0, ms_le), model="8 algorithmic B/pair: one fp64 output"),
+            "parity": {"projection_max_abs": e_p, "nested_ai_gram_max_abs": e_ai, "log_euclidean_gram_max_abs": e_le, "block": "96 x 96"}}
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks (one process per GPU, RCCL over
+    xGMI) and relay their output - rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -155,7 +236,7 @@ def main():
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
     elif args.gpus != 1:
-        raise SystemExit("launch multi-GPU runs through torch.distributed.run (one process per GPU)")
+        _self_launch(args)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -227,7 +308,7 @@ def main():
             ww = torch.tensor([run_sweep(device, **kw)[0]], dtype=torch.float64, device=device)
             dist.all_reduce(ww, op=dist.ReduceOp.MAX)
             weak = {"restarts": 512 * world, "seconds": float(ww.item()), "restarts_per_s": 512 * world / float(ww.item())}
-        sweep = {"workload": "gabo_spd S^5_++: GP(50 obs)+EI, 2048 raw samples, 512 restarts, ConstrainedTR semantics, FD Hessian, "
+        sweep = {"workload": "gabo_spd S^5_++: GP(50 obs of the Ackley objective, SURVEY 8d)+EI, 2048 raw samples, 512 restarts, ConstrainedTR semantics, FD Hessian, "
                              "lambda_max<=5 constraint built with functools.partial as in the reference example; raw samples drawn in one "
                              "vectorised host call and scored by the fused chain; the trust-region solve is ONE launch (every wave iterates "
                              "its restart: tCG, proposal, acquisition, constraint, update); restarts sharded over ranks, all_gather+argmax",
@@ -296,15 +377,21 @@ def main():
             "config": {"workload": "SpdAffineInvariantGaussianKernel S^10_++ Gram K(X,X), N=4096 random SPD 10x10 (Mandel, "
                                    "eig U[0.05,5], seed 1234+rank), beta=0.2+ln2, all N^2 pairs evaluated; one independent "
                                    "point set per GPU", "n_points": N_POINTS, "dim": DIM, "parallelism": f"independent Gram builds x{world}"},
-            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "gabo::spd_ai_pairwise_kernel<10>", "kernel_ms": ev_ms,
-                         "model": f"SURVEY 8(d) streaming model: {BYTES_PER_PAIR} algorithmic B/pair x {pairs_per_step} pairs per launch; "
-                                  "compulsory traffic is 8.1 B/pair (operands are L2-resident), see DESIGN.md"},
-            "roofline_fp64": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach_tf / FP64_PEAK_TFLOPS,
-                              "model": f"{FLOP_PER_PAIR:.0f} algorithmic flop/pair (SURVEY 8d); fp64 vector = matrix peak 78.6 TFLOP/s; "
-                                       "this is the binding resource (fp64 VALU issue); sustained v_fma_f64 rate measured on this chip "
-                                       "(tools/ubench_fp64.hip): 62.4 TFLOP/s", "measured_sustained_peak": 62.4},
+            "roofline": {"bound": "mfma", "binding_resource": "fp64 issue (vector pipe; the f64 matrix pipe shares it: tools/ubench_mfma_f64.hip)",
+                         "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
+                         "same launch, committed; not re-measured inside this run)",
+                         "traffic_over_compulsory": None if traffic is None else traffic / (pairs_per_step * 8.0 + 2 * N_POINTS * (DIM * (DIM + 1) // 2) * 8),
+                         "kernel": "gabo::spd_ai_pairwise_kernel<10>", "kernel_ms": ev_ms,
+                         "model": f"{FLOP_PER_PAIR:.0f} algorithmic flop/pair (SURVEY 8d: congruence + tridiagonalisation + QL) x {pairs_per_step} "
+                                  "pairs per launch / launch duration (HIP events on the launch stream over the timed steps); fp64 vector = matrix "
+                                  "peak 78.6 TFLOP/s",
+                         "measured_sustained_v_fma_f64": 60.6, "measured_sustained_mfma_f64": 77.8},
+            "roofline_hbm_streaming_model": {"non_physical": True, "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": ach_gbs / HBM_PEAK_GBS,
+                                             "model": f"SURVEY 8(d) streaming model: {BYTES_PER_PAIR} B/pair (both d x d tiles charged to every pair). "
+                                                      "The operands are L2-resident and never re-fetched from HBM, so this figure can exceed 1 and is "
+                                                      "not evidence of bandwidth use; the measured HBM traffic is `roofline.traffic`"},
             "symmetric_gram": None if sym is None else {
                 "ms_per_step": sym_ms, "pairs_per_s": pairs_per_step / (sym_ms * 1e-3),
                 "note": "x1 is x2 shortcut (GABO_SYMMETRIC): i <= j evaluated, mirrored; not used for `value`"},
@@ -342,6 +429,9 @@ def main():
                                                 "frac": pairs_per_step * 8.04 / (sph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "model": "8.04 algorithmic B/pair (one fp64 output + amortised operand reads)"},
                                    "max_abs_err_vs_oracle_block": sph_err}
+            line["roofline_sphere"] = dict(line["sphere_gram"]["roofline"], kernel="gabo::sphere_pairwise_kernel<0>", kernel_ms=sph_ms,
+                                           binding_resource="fp64 issue of the acos^2 + exp epilogue (MFMA + stores alone: 26 us)")
+            line["config5"] = config5_pieces(device)
             # the step before the sweep in a BO iteration: surrogate fit (fit_gpytorch_model), 50 observations on S^5_++
             import time as _time
             from gabotorch_amd import models as _models

@@ -4,6 +4,7 @@
 #include "gabo_device.hpp"
 #include "spd_prep.hpp"
 #include "spd_jacobi.hpp"
+#include "spd_eigvec.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
@@ -93,17 +94,24 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
         });
         // eigenvectors: registers for D <= 8 (this kernel runs 1-2 waves per SIMD: LDS round trips would be exposed latency),
         // the lane's LDS column above that
+        // (registers: Householder + QL with vectors, spd_eigvec.hpp - a far shorter dependent chain than the cyclic Jacobi it replaced,
+        // which was 47 % of an evaluation at one wave per SIMD)
         constexpr bool kRegV = D <= 8;
         double* vl = vls + lane;
         double vreg[kRegV ? D * D : 1];
-        if constexpr (kRegV) jacobi_eig_reg<D>(m, vreg);
-        else jacobi_eig<D>(m, vl);
+        double lam[D];
+        if constexpr (kRegV) {
+            sym_eig_reg<D>(m, lam, vreg);
+        } else {
+            jacobi_eig<D>(m, vl);
+            static_for<D>([&](auto kk) { lam[decltype(kk)::value] = m[tri(decltype(kk)::value, decltype(kk)::value)]; });
+        }
         auto Vat = [&](int r, int c) -> double { if constexpr (kRegV) return vreg[r * D + c]; else return vl[(r * D + c) * 64]; };
         double lg[D];
         double s = 0.0;
         static_for<D>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
-            lg[k] = log(m[tri(k, k)]);
+            lg[k] = log(lam[k]);
             s = __builtin_fma(lg[k], lg[k], s);
         });
         const double d2 = s + 1e-15;                      // spd_utils_torch.py:120
@@ -238,8 +246,8 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
                 m[tri(r, c)] = (r == c) ? e : e / kSqrt2;
             });
         });
-        jacobi_eig_reg<D>(m, v);
-        static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; lam[k] = m[tri(k, k)]; lg[k] = log(lam[k]); });
+        sym_eig_reg<D>(m, lam, v);
+        static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; lg[k] = log(lam[k]); });
         static_for<D>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
             static_for<r + 1>([&](auto cc) {

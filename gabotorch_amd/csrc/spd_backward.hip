@@ -11,34 +11,38 @@
 // the two sets exchanged and grad_out read transposed (d is symmetric in its arguments).
 //
 // Mapping: one wave per (batch, i); lane = column j, looping over j in chunks of 64.  Each lane forms M (as in the
-// forward kernel), diagonalises it with cyclic Jacobi (eigenvectors needed, so no tridiagonal shortcut), builds
-// logm(M) = V diag(log lambda) V^T, and accumulates w_ij logm(M_ij) into its own LDS column; one cross-lane
-// reduction per row, then the lanes share the final congruence and the Mandel scatter.
+// forward kernel), diagonalises it WITH eigenvectors, builds logm(M) = V diag(log lambda) V^T, and accumulates
+// w_ij logm(M_ij) into its own LDS column; one cross-lane reduction per row, then the lanes share the final congruence
+// and the Mandel scatter.  Eigen-solver: Householder + implicit QL with the eigenvector matrix in registers (spd_eigvec.hpp);
+// Z takes 200 VGPRs at d = 10, so above d = 8 the kernel is budgeted for ONE wave per SIMD and 512 VGPRs.  The first version
+// ran cyclic Jacobi (V in registers up to d = 8, in LDS above: 51-74 KB per wave, ~4e4 instructions per pair); full N = 4096
+// backward, ms, Jacobi -> QL: d = 8: 39.7 -> see DESIGN.md, d = 10: 70 -> 8.8, d = 12: 228 -> 23.
 #include "gabo_device.hpp"
 #include "spd_prep.hpp"
 #include "spd_jacobi.hpp"
+#include "spd_eigvec.hpp"
 #include "spd_generic.hpp"
 #include "../../include/gabo_hip.h"
 
-#ifndef GABO_BWD_REGV_MAX_DIM
-#define GABO_BWD_REGV_MAX_DIM 8
+#ifndef GABO_BWD_JACOBI_MAX_DIM
+#define GABO_BWD_JACOBI_MAX_DIM 0   /* dimensions up to this use the cyclic Jacobi (A/B builds); the QL solver is faster from d = 3 on */
+#endif
+#ifndef GABO_BWD_TWO_WAVE_MAX_DIM
+#define GABO_BWD_TWO_WAVE_MAX_DIM 8  /* Z + M fit 256 VGPRs up to here: two waves per SIMD */
 #endif
 
 namespace gabo {
 
 template <int D>
-__global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
+__global__ __launch_bounds__(64, (D > GABO_BWD_TWO_WAVE_MAX_DIM ? 1 : 2)) void spd_ai_backward_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
                                                              const double* __restrict__ gout, double* __restrict__ gx,
                                                              int64_t n1, int64_t n2, int64_t w_batch_stride,
                                                              int64_t g_batch_stride, int64_t go_sb, int64_t go_si, int64_t go_sj,
                                                              double beta, int flags) {
     constexpr int T = tri_size(D);
-    __shared__ double vls[(D <= GABO_BWD_REGV_MAX_DIM) ? 64 : D * D * 64];
-    // accumulators of sum_j w_ij logm(M_ij): per lane in LDS while LDS is free (D <= 8, V in registers); for larger D the V columns
-    // already take 51-74 KB per wave, so each chunk is reduced across the wave at once instead (330 shuffles against ~50 k Jacobi
-    // instructions per lane) - that is what lifts the kernel from 1-2 to 2-3 waves per CU at d = 10..12
-    constexpr bool kLdsAcc = D <= GABO_BWD_REGV_MAX_DIM;
-    __shared__ double acc[kLdsAcc ? T * 64 : 1];
+    // accumulators of sum_j w_ij logm(M_ij): one LDS column per lane (T x 64 doubles: 28 KB at d = 10, 40 KB at d = 12; with one
+    // wave per SIMD that is at most 4 blocks = 160 KB per CU), reduced across the wave once per row
+    __shared__ double acc[T * 64];
     __shared__ double red[T];
     __shared__ double wl[T];
     const int mode = flags & GABO_OUT_MASK;
@@ -46,9 +50,7 @@ __global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __res
     const int64_t b = blockIdx.x / n1;
     const int64_t i = blockIdx.x - b * n1;
     const double* W = Winv + b * w_batch_stride + i * T;
-    double tot[kLdsAcc ? 1 : T];      // (D > 8) sum over the chunks of the wave-reduced w_ij logm(M_ij); identical in every lane
-    if constexpr (kLdsAcc) static_for<T>([&](auto ee) { acc[decltype(ee)::value * 64 + lane] = 0.0; });
-    else static_for<T>([&](auto ee) { tot[decltype(ee)::value] = 0.0; });
+    static_for<T>([&](auto ee) { acc[decltype(ee)::value * 64 + lane] = 0.0; });
     for (int64_t j0 = 0; j0 < n2; j0 += 64) {
         const int64_t j = j0 + lane;
         const bool live = j < n2;
@@ -78,18 +80,22 @@ __global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __res
                 });
             });
         });
-        // eigenvectors: registers up to GABO_BWD_REGV_MAX_DIM (no LDS round trips in the rotations), the lane's LDS column above
-        constexpr bool kRegV = D <= GABO_BWD_REGV_MAX_DIM;
-        double* vl = vls + lane;
-        double vreg[kRegV ? D * D : 1];
-        if constexpr (kRegV) jacobi_eig_reg<D>(m, vreg);
-        else jacobi_eig<D>(m, vl);
-        auto Vat = [&](int r, int c) -> double { if constexpr (kRegV) return vreg[r * D + c]; else return vl[(r * D + c) * 64]; };
+        // eigen-decomposition in registers: Householder + QL with vectors (spd_eigvec.hpp)
+        constexpr bool kJacobi = D <= GABO_BWD_JACOBI_MAX_DIM;
+        double vreg[D * D];
+        double lam[D];
+        if constexpr (kJacobi) {
+            jacobi_eig_reg<D>(m, vreg);
+            static_for<D>([&](auto kk) { lam[decltype(kk)::value] = m[tri(decltype(kk)::value, decltype(kk)::value)]; });
+        } else {
+            sym_eig_reg<D>(m, lam, vreg);
+        }
+        auto Vat = [&](int r, int c) -> double { return vreg[r * D + c]; };
         double lg[D];
         double s = 0.0;
         static_for<D>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
-            lg[k] = log(m[tri(k, k)]);
+            lg[k] = log(lam[k]);
             s = __builtin_fma(lg[k], lg[k], s);
         });
         // w = dLoss/d(d^2)
@@ -108,30 +114,22 @@ __global__ __launch_bounds__(64) void spd_ai_backward_kernel(const double* __res
         // acc += w * V diag(lg) V^T   (lower triangle)
         static_for<D>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
+            double vl[D];                                   // row r of V diag(w lg)
+            static_for<D>([&](auto kk) { vl[decltype(kk)::value] = Vat(r, decltype(kk)::value) * (w * lg[decltype(kk)::value]); });
             static_for<r + 1>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                double f = 0.0;
-                static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; f = __builtin_fma(Vat(r, k) * lg[k], Vat(c, k), f); });
-                if constexpr (kLdsAcc) {
-                    acc[tri(r, c) * 64 + lane] = __builtin_fma(w, f, acc[tri(r, c) * 64 + lane]);
-                } else {
-                    double wf = w * f;
-                    for (int off = 32; off > 0; off >>= 1) wf += __shfl_xor(wf, off, 64);
-                    tot[tri(r, c)] += wf;
-                }
+                double f = acc[tri(r, c) * 64 + lane];
+                static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; f = __builtin_fma(vl[k], Vat(c, k), f); });
+                acc[tri(r, c) * 64 + lane] = f;
             });
         });
     }
     // publish the sums and stage W in LDS for the dynamic-index congruence
-    if constexpr (kLdsAcc) {
-        __syncthreads();
-        for (int e = lane; e < T; e += 64) {
-            double t = 0.0;
-            for (int l = 0; l < 64; ++l) t += acc[e * 64 + ((l + e) & 63)];  // rotated start: threads hit different banks
-            red[e] = t;
-        }
-    } else {
-        if (lane == 0) static_for<T>([&](auto ee) { red[decltype(ee)::value] = tot[decltype(ee)::value]; });
+    __syncthreads();
+    for (int e = lane; e < T; e += 64) {
+        double t = 0.0;
+        for (int l = 0; l < 64; ++l) t += acc[e * 64 + ((l + e) & 63)];  // rotated start: threads hit different banks
+        red[e] = t;
     }
     for (int e = lane; e < T; e += 64) wl[e] = W[e];
     __syncthreads();

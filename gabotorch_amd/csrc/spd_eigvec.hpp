@@ -1,0 +1,172 @@
+// Per-lane symmetric eigen-DECOMPOSITION (eigenvalues and eigenvectors) of a small fixed-size matrix, everything in the
+// lane's registers: Householder tridiagonalisation, explicit accumulation of the reflectors, implicit-shift QL with the plane
+// rotations applied to the eigenvector columns (the EISPACK tred2 + tql2 / LAPACK dsytrd + dorgtr + dsteqr scheme).
+//
+// Used wherever a matrix FUNCTION is needed per lane: the SPD backward kernel (logm(M) = Z diag(log lambda) Z^T per pair), the fused
+// acquisition evaluation and the trust-region kernels (logm, expm of tangent vectors, extreme eigenpairs).  The cyclic Jacobi it
+// replaced (spd_jacobi.hpp, still used with V in LDS by the acquisition kernels above d = 8) costs ~4e4 instructions per matrix at
+// d = 10 and is one long dependent chain; this one is ~1.2e4 with Z in registers (200 VGPRs at d = 10: one wave per SIMD, 512
+// VGPRs) and no LDS traffic in the iteration.  One lane owns one matrix; all register-array indices are compile-time
+// constants.  Like the eigenvalue-only solver (spd_eig.hpp) every sweep of stage l runs the whole recurrence D-2 .. l without an
+// interior split search, and a lane that has deflated its stage pre-converges the next one while its wave finishes (look-ahead).
+#pragma once
+#include "gabo_device.hpp"
+
+namespace gabo {
+
+// m: packed lower triangle (destroyed).  Out: dg (diagonal), e (signed sub-diagonal, e[D-1] = 0) of T = Q^T M Q and z = Q
+// (row-major D x D), Q = H_0 H_1 ... H_{D-3}.
+template <int D>
+__device__ __forceinline__ void tridiagonalize_q(double (&m)[tri_size(D)], double (&dg)[D], double (&e)[D], double (&z)[D * D]) {
+    double ihh[D >= 3 ? D - 2 : 1];
+    static_for<D - 2>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int n = D - k - 1;  // order of the trailing block; the column below the diagonal is x_0..x_{n-1}
+        // u = x + sign(x0)|x| e0 ;  H = I - u u^T / hh,  hh = |x|^2 + |x0||x| ;  H x = -sign(x0)|x| e0
+        double alpha = m[tri(k + 1, k)];
+        double sig = 0.0;
+        static_for<n - 1>([&](auto t) { double x = m[tri(k + 2 + decltype(t)::value, k)]; sig = __builtin_fma(x, x, sig); });
+        double nn = __builtin_fma(alpha, alpha, sig);
+        double nrm = sqrt_pos(nn);
+        double u[n];
+        u[0] = alpha + copysign_d(nrm, alpha);
+        static_for<n - 1>([&](auto t) { u[decltype(t)::value + 1] = m[tri(k + 2 + decltype(t)::value, k)]; });
+        double hh = __builtin_fma(__builtin_fabs(alpha), nrm, nn);
+        double inv_hh = hh == 0.0 ? 0.0 : rcp(hh);
+        double p[n];
+        static_for<n>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            double acc = 0.0;
+            static_for<n>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int hi = r > c ? r : c, lo = r > c ? c : r;
+                acc = __builtin_fma(m[tri(k + 1 + hi, k + 1 + lo)], u[c], acc);
+            });
+            p[r] = acc * inv_hh;
+        });
+        double up = 0.0;
+        static_for<n>([&](auto rr) { up = __builtin_fma(u[decltype(rr)::value], p[decltype(rr)::value], up); });
+        double kap = 0.5 * up * inv_hh;
+        static_for<n>([&](auto rr) { p[decltype(rr)::value] = __builtin_fma(-kap, u[decltype(rr)::value], p[decltype(rr)::value]); });
+        static_for<n>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            static_for<r + 1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                double v = m[tri(k + 1 + r, k + 1 + c)];
+                v = __builtin_fma(-u[r], p[c], v);
+                v = __builtin_fma(-p[r], u[c], v);
+                m[tri(k + 1 + r, k + 1 + c)] = v;
+            });
+        });
+        dg[k] = m[tri(k, k)];
+        e[k] = hh == 0.0 ? alpha : -copysign_d(nrm, alpha);   // (hh == 0: the column is already zero, H = I)
+        m[tri(k + 1, k)] = u[0];                                 // the reflector stays in column k for the accumulation below
+        ihh[k] = inv_hh;
+    });
+    if constexpr (D >= 2) {
+        dg[D - 2] = m[tri(D - 2, D - 2)];
+        e[D - 2] = m[tri(D - 1, D - 2)];
+    }
+    dg[D - 1] = m[tri(D - 1, D - 1)];
+    e[D - 1] = 0.0;
+    // z = H_0 ... H_{D-3}: identity, then the reflectors from the last to the first; H_k touches rows k+1.. only, and what has been
+    // built so far is non-trivial in rows / columns >= k+2, so each step fills the block [k+1.., k+1..] (everything else stays 0 / 1
+    // and folds away at compile time)
+    static_for<D>([&](auto rr) {
+        static_for<D>([&](auto cc) { z[decltype(rr)::value * D + decltype(cc)::value] = (decltype(rr)::value == decltype(cc)::value) ? 1.0 : 0.0; });
+    });
+    static_for_down<D - 3, 0>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int n = D - k - 1;
+        static_for<n>([&](auto cc) {
+            constexpr int c = k + 1 + decltype(cc)::value;
+            double t = 0.0;
+            static_for<n>([&](auto rr) {
+                constexpr int r = k + 1 + decltype(rr)::value;
+                t = __builtin_fma(m[tri(r, k)], z[r * D + c], t);
+            });
+            t *= ihh[k];
+            static_for<n>([&](auto rr) {
+                constexpr int r = k + 1 + decltype(rr)::value;
+                z[r * D + c] = __builtin_fma(-m[tri(r, k)], t, z[r * D + c]);
+            });
+        });
+    });
+}
+
+// Eigen-decomposition of the symmetric tridiagonal (dg, e) with the rotations accumulated into z (columns become the eigenvectors of
+// the ORIGINAL matrix when z enters as the Q of tridiagonalize_q).  Eigenvalues in dg, unordered.
+template <int D>
+__device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[D], double (&z)[D * D]) {
+    // dropping an off-diagonal e perturbs a matrix FUNCTION to first order in e / gap (the eigenvalue-only solver can be looser: a
+    // symmetric function of the eigenvalues moves only to second order): |e| <= eps (|d_l| + |d_{l+1}|), the EISPACK / LAPACK
+    // criterion in the form that also terminates on indefinite input (tangent vectors) with zeros on the diagonal
+    constexpr double eps2 = 1.2e-32;
+    static_for<D - 1>([&](auto ll) {
+        constexpr int l = decltype(ll)::value;
+        for (int it = 0; it < 60; ++it) {
+            const double s01 = __builtin_fabs(dg[l]) + __builtin_fabs(dg[l + 1]);
+            const bool done0 = e[l] * e[l] <= eps2 * (s01 * s01);
+            if (__builtin_amdgcn_ballot_w64(!done0) == 0) break;          // the wave leaves the stage with its last lane
+            const double el = done0 ? 0.0 : e[l];
+            double sa = dg[l], sb = dg[l + 1], se = el;
+            bool idle = done0;
+            if constexpr (l + 1 <= D - 2) {
+                // look-ahead (see spd_eig.hpp): a lane that is done with stage l takes its shift from block l+1; its e[l] is exactly 0,
+                // so the steps below that block are identities (c = +-1, s = 0)
+                const double s12 = __builtin_fabs(dg[l + 1]) + __builtin_fabs(dg[l + 2]);
+                const bool done1 = e[l + 1] * e[l + 1] <= eps2 * (s12 * s12);
+                idle = done0 && done1;
+                sa = done0 ? dg[l + 1] : sa;
+                sb = done0 ? dg[l + 2] : sb;
+                se = done0 ? e[l + 1] : se;
+            }
+            if (idle) continue;
+            // Wilkinson shift from the leading 2x2 [[sa, se], [se, sb]]: sigma = sa - se / (theta + sign(theta) sqrt(theta^2 + 1)),
+            // theta = (sb - sa) / (2 se); written without the division by se: sigma = sa - se^2 / (delta + sign(delta) sqrt(delta^2 + se^2))
+            double delta = 0.5 * (sb - sa);
+            double root = sqrt_nz(__builtin_fma(delta, delta, se * se));
+            double sigma = sa - copysign_d(root - __builtin_fabs(delta), delta);
+            double g = dg[D - 1] - sigma;
+            double s = 1.0, c = 1.0, p = 0.0;
+            static_for_down<D - 2, l>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const double ei = (i == l) ? el : e[i];
+                double f = s * ei;
+                double b = c * ei;
+                // g must not vanish together with f (r = 0): nudge an exact zero to +-1e-150, far below rounding
+                g = copysign_d(__builtin_fmax(__builtin_fabs(g), 1e-150), g);
+                double r2 = __builtin_fma(f, f, g * g);
+                double ir = rsqrt_nz(r2);
+                e[i + 1] = r2 * ir;
+                s = f * ir;
+                c = g * ir;
+                g = dg[i + 1] - p;
+                double r = __builtin_fma(dg[i] - g, s, 2.0 * c * b);
+                p = s * r;
+                dg[i + 1] = g + p;
+                g = __builtin_fma(c, r, -b);
+                static_for<D>([&](auto kk) {
+                    constexpr int k = decltype(kk)::value;
+                    double zi = z[k * D + i], zj = z[k * D + i + 1];
+                    z[k * D + i + 1] = __builtin_fma(s, zi, c * zj);
+                    z[k * D + i] = __builtin_fma(c, zi, -s * zj);
+                });
+            });
+            dg[l] -= p;
+            e[l] = g;
+            e[D - 1] = 0.0;
+        }
+    });
+}
+
+// m (packed lower triangle, destroyed) = V diag(lam) V^T: eigenvalues (unordered) and eigenvectors (columns of v, row-major D x D).
+// Every lane of the wave must call it (the iteration leaves a stage by a wave-wide vote).
+template <int D>
+__device__ __forceinline__ void sym_eig_reg(double (&m)[tri_size(D)], double (&lam)[D], double (&v)[D * D]) {
+    double sub[D];
+    tridiagonalize_q<D>(m, lam, sub, v);
+    tridiag_ql_vectors<D>(lam, sub, v);
+}
+
+}  // namespace gabo

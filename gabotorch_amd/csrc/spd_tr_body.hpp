@@ -49,8 +49,7 @@ __device__ __forceinline__ void eig_extremes(const double* __restrict__ a, doubl
         constexpr int r = decltype(rr)::value;
         static_for<r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; m[tri(r, c)] = 0.5 * (a[r * D + c] + a[c * D + r]); });
     });
-    jacobi_eig_reg<D>(m, v);
-    static_for<D>([&](auto kk) { lam[decltype(kk)::value] = m[tri(decltype(kk)::value, decltype(kk)::value)]; });
+    sym_eig_reg<D>(m, lam, v);
 }
 
 // values and WHITENED Riemannian gradients of the built-in constraints at x (L = chol x already in the workspace):
@@ -162,15 +161,16 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
     if (threadIdx.x == 0) t.rhoden[i] = -ge - 0.5 * ehe;
     lds_load(w.chol + i * dd, M0, D);
     if constexpr (D <= 8) {
-        // expm(eta~) by the register Jacobi (every lane redundantly, no barriers); lane 0 publishes E
+        // expm(eta~) from the register eigen-decomposition (every lane redundantly, no barriers); lane 0 publishes E
         double m[T], v[D * D];
         static_for<D>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
             static_for<r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; m[tri(r, c)] = 0.5 * (etaw[r * D + c] + etaw[c * D + r]); });
         });
-        jacobi_eig_reg<D>(m, v);
+        double lam_e[D];
+        sym_eig_reg<D>(m, lam_e, v);
         double ex[D];
-        static_for<D>([&](auto kk) { ex[decltype(kk)::value] = exp(m[tri(decltype(kk)::value, decltype(kk)::value)]); });
+        static_for<D>([&](auto kk) { ex[decltype(kk)::value] = exp(lam_e[decltype(kk)::value]); });
         if (threadIdx.x == 0) {
             static_for<D>([&](auto rr) {
                 constexpr int r = decltype(rr)::value;

