@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preheat", type=int, default=60, help="untimed launches BEFORE the W warm-up steps: a cold MI355X needs ~20 launches "
+                    "(~60 ms) of fp64 load to reach its sustained clock (rocprofv3: 3.30 ms for the first dispatch, 2.67 ms from the "
+                    "20th on, profiles/pmc_summary.json); reported in the line as `untimed_preheat_steps`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-symmetric", action="store_true", help="skip the separately reported x1-is-x2 run (profiling: keeps "
@@ -242,6 +245,9 @@ def main():
 
     x = synthetic_spd_mandel(N_POINTS, DIM, 1234 + rank)      # one independent point set per rank
     job = GramJob(x, device, symmetric=False)
+    for _ in range(max(args.preheat, 0)):
+        job.step()
+    torch.cuda.synchronize()
     wall, ev_ms = timed(job, args.steps, args.warmup, dist)
     st = job.status.tolist()
     if st[0] != 0:
@@ -372,6 +378,7 @@ def main():
         line = {
             "metric": "SPD affine-invariant kernel-matrix build, pairs/sec (N=4096,d=10)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "untimed_preheat_steps": max(args.preheat, 0),
             "ms_per_step": wall_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SpdAffineInvariantGaussianKernel S^10_++ Gram K(X,X), N=4096 random SPD 10x10 (Mandel, "

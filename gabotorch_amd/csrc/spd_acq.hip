@@ -18,8 +18,7 @@ int acq_affine_invariant(const AcqLaunch& a) { return dispatch_acq<0, 12>(a); }
 
 template <int D>
 static int launch_prepare_train(const double* x, double* G, int64_t n, int* status, hipStream_t st) {
-    hipLaunchKernelGGL((spd_prep_kernel<D>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, x, G, (int64_t)1, n, (int64_t)0, 1,
-                       status, 0);
+    launch_spd_prep<D>(nullptr, x, nullptr, G, 0, 1, 0, n, 0, 0, status, st);          // only the second (entry-major Cholesky) set
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

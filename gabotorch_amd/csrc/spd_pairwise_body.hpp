@@ -59,7 +59,7 @@ __device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const d
 __device__ __forceinline__ double finish(double dist, double beta, int mode) {
     if (mode == GABO_OUT_DISTANCE) return dist;
     if (mode == GABO_OUT_LAPLACE) return exp(-(dist * beta));   // kernels_spd.py:185
-    return exp(-((dist * dist) * beta));                        // kernels_spd.py:94-98   (one exp per pair: OCML's is fine here)
+    return exp(-((dist * dist) * beta));                        // kernels_spd.py:94-98
 }
 
 // 1-D grid, block id -> (batch, row chunk of `rows` rows, column group of blockDim.x columns), column group fastest
@@ -112,8 +112,17 @@ __global__ __launch_bounds__(256, (D > 12 ? 1 : GABO_PAIR_WAVES)) void spd_ai_pa
         const double* Gp = Gj;
         asm volatile("" : "+v"(Gp));
         double s = ai_sumsq<D>(W, Gp, n2);
-        double dist = __builtin_sqrt(s + 1e-15);  // spd_utils_torch.py:120
-        double val = finish(dist, beta, mode);
+        double dist, val;
+        if (mode == GABO_OUT_GAUSSIAN && !dist_out) {
+            // exp(-beta sqrt(s + 1e-15)^2) (spd_utils_torch.py:120, kernels_spd.py:94-98) without the square root: sqrt(x)^2 = x to an ulp,
+            // i.e. 1e-16 beta d^2 relative in K.  (OCML's exp stays: the register-table exp_neg of gabo_device.hpp measured 4 % SLOWER here,
+            // 2.75 vs 2.63 ms - its 28 pinned coefficients cost more than the instructions they save once per pair.)
+            dist = 0.0;
+            val = exp(-((s + 1e-15) * beta));
+        } else {
+            dist = __builtin_sqrt(s + 1e-15);  // spd_utils_torch.py:120
+            val = finish(dist, beta, mode);
+        }
         // symmetric mode: only the upper triangle (i <= j) is stored; mirror_upper_kernel fills the rest afterwards,
         // so the result is exactly symmetric and the mirror writes are coalesced.
         if (j < n2 && (!(flags & GABO_SYMMETRIC) || i <= j)) {

@@ -60,28 +60,32 @@ __device__ __forceinline__ void lower_inverse(const double (&a)[tri_size(D)], do
     });
 }
 
+// One launch factors BOTH point sets: blocks [0, blocks1) handle x1 (W = chol(x1)^-1, row contiguous), the rest x2 (G = chol(x2),
+// entry-major).  (Two launches of ~6 us each were 0.5 % of a d = 10, N = 4096 Gram build.)
 template <int D>
-__global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__ x, double* __restrict__ ws,
-                                                      int64_t batch, int64_t n, int64_t batch_stride, int soa,
-                                                      int* __restrict__ status, int status_base) {
+__global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
+                                                      double* __restrict__ W, double* __restrict__ G, int64_t b1, int64_t b2,
+                                                      int64_t n1, int64_t n2, int64_t s1, int64_t s2, unsigned blocks1,
+                                                      int* __restrict__ status) {
     constexpr int T = tri_size(D);
-    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= batch * n) return;
-    int64_t b = g / n, i = g - b * n;
-    const double* v = x + b * batch_stride + i * T;
+    const bool second = blockIdx.x >= blocks1;
+    const int64_t g = (int64_t)(second ? blockIdx.x - blocks1 : blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t n = second ? n2 : n1;
+    if (g >= (second ? b2 : b1) * n) return;
+    const int64_t b = g / n, i = g - b * n;
+    const double* v = (second ? x2 + b * s2 : x1 + b * s1) + i * T;
     double a[T];
     const bool bad = mandel_cholesky<D>(v, a);
     if (bad) {
-        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = status_base + (int)g;
+        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = (second ? (int)(b1 * n1) : 0) + (int)g;
     }
-    if (soa) {
-        // G, entry-major: ws[(b*T + e) * n + i]
-        static_for<T>([&](auto ee) { ws[(b * T + decltype(ee)::value) * n + i] = a[decltype(ee)::value]; });
+    if (second) {
+        // G, entry-major: G[(b*T + e) * n + i]
+        static_for<T>([&](auto ee) { G[(b * T + decltype(ee)::value) * n + i] = a[decltype(ee)::value]; });
     } else {
-        // W = L^-1 (lower), column by column: W[c][c] = 1/L[c][c]; W[r][c] = -(sum_{k=c}^{r-1} L[r][k] W[k][c]) / L[r][r]
         double w[T];
         lower_inverse<D>(a, w);
-        double* o = ws + g * T;
+        double* o = W + g * T;
         static_for<T>([&](auto ee) { o[decltype(ee)::value] = w[decltype(ee)::value]; });
     }
 }
@@ -89,11 +93,10 @@ __global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__
 template <int D>
 static void launch_spd_prep(const double* x1, const double* x2, double* W, double* G, int64_t b1, int64_t b2, int64_t n1,
                             int64_t n2, int64_t s1, int64_t s2, int* status, hipStream_t st) {
-    int64_t tot = b1 * n1;
-    hipLaunchKernelGGL((spd_prep_kernel<D>), dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, x1, W, b1, n1, s1, 0, status, 0);
-    tot = b2 * n2;
-    hipLaunchKernelGGL((spd_prep_kernel<D>), dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, x2, G, b2, n2, s2, 1, status,
-                       (int)(b1 * n1));
+    const unsigned blocks1 = (unsigned)((b1 * n1 + 63) / 64), blocks2 = (unsigned)((b2 * n2 + 63) / 64);
+    if (blocks1 + blocks2 == 0) return;
+    hipLaunchKernelGGL((spd_prep_kernel<D>), dim3(blocks1 + blocks2), dim3(64), 0, st, x1, x2, W, G, b1, b2, n1, n2, s1, s2, blocks1,
+                       status);
 }
 
 }  // namespace gabo

@@ -295,7 +295,7 @@ def test_device_solve_graph_plans_match_torch_path(strict):
         _, _, val, log = run_sweep(DEV, **kw, **extra)
         np.testing.assert_allclose(val, val_t, rtol=1e-9)
         np.testing.assert_array_equal(log["per_restart_iterations"].cpu().numpy(), ref_iters)
-        np.testing.assert_allclose(log["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(log["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-6, atol=1e-9)   # (stopped by |grad| < 1e-4: |grad|^2 / curvature)
 
 
 def test_fused_acquisition_on_trainable_surrogate():

@@ -6,9 +6,10 @@ from gabotorch_amd import ops, _lib
 from tools.dev_bench import spd_set, timeit
 from oracle import spd as ospd
 tag = sys.argv[1] if len(sys.argv) > 1 else "main"
+DIMS = (10,) if tag == "prof" else (5, 8, 9, 10, 12)
 ops.set_error_checking(False)
 n, beta = 4096, 0.2 + float(np.log(2.0))
-for d in (5, 8, 9, 10, 12):
+for d in DIMS:
     xs = spd_set(n, d)
     x = torch.tensor(xs, device="cuda")
     go = torch.ones(n, n, dtype=torch.float64, device="cuda")
