@@ -6,6 +6,25 @@
 #include <type_traits>
 #include <utility>
 
+// Development instrumentation (builds with -DGABO_TR_CLOCKS only; tools/tr_clocks.py): block 0 / lane 0 appends (tag, s_memtime) pairs
+// to a per-translation-unit buffer that the exported gabo_debug_clocks of that unit copies out.  Compiles to nothing otherwise.
+#ifdef GABO_TR_CLOCKS
+static __device__ long long gabo_clk_buf[8192];
+static __device__ int gabo_clk_n;
+#define GABO_TICK(tag)                                                          \
+    do {                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                              \
+            int k_ = gabo_clk_n++;                                              \
+            if (k_ < 4096) {                                                    \
+                gabo_clk_buf[2 * k_] = (tag);                                   \
+                gabo_clk_buf[2 * k_ + 1] = (long long)__builtin_amdgcn_s_memtime(); \
+            }                                                                   \
+        }                                                                       \
+    } while (0)
+#else
+#define GABO_TICK(tag) do { } while (0)
+#endif
+
 namespace gabo {
 
 // ---- compile-time loops: every index reaching a register array is a constant, so nothing lands in scratch -----

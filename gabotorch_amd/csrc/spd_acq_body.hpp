@@ -16,6 +16,30 @@ static __device__ __forceinline__ double wave_sum64(double v) {
 
 using AcqParams = gabo_spd_acq_params;   // include/gabo_hip.h
 
+// sum_{j < n} col[j * n] * x[j]: one output of the two triangular matrix-vector products of the exact-GP posterior per lane.  L^-1 is
+// stored dense with exact zeros above the diagonal, so the sum runs over ALL j (uniform trip count, nothing to mask); eight loads are
+// issued before the FMAs that use them and four partial sums keep the FMA chain short.  (The plain triangular loop with its lane-dependent
+// bound waited for one load per term: 300 cycles per term from L2, 150 once the factors were staged in LDS; a version that masked the
+// terms outside the triangle instead of using the zeros was slower still - tools/tr_clocks.py.)
+static __device__ __forceinline__ double strided_dot(const double* __restrict__ col, const double* __restrict__ x, int n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        double av[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = col[(j + u) * n];
+            xv[u] = x[j + u];
+        }
+        s0 = __builtin_fma(av[0], xv[0], s0); s1 = __builtin_fma(av[1], xv[1], s1);
+        s2 = __builtin_fma(av[2], xv[2], s2); s3 = __builtin_fma(av[3], xv[3], s3);
+        s0 = __builtin_fma(av[4], xv[4], s0); s1 = __builtin_fma(av[5], xv[5], s1);
+        s2 = __builtin_fma(av[6], xv[6], s2); s3 = __builtin_fma(av[7], xv[7], s3);
+    }
+    for (; j < n; ++j) s0 = __builtin_fma(col[j * n], x[j], s0);
+    return (s0 + s1) + (s2 + s3);
+}
+
 // LDS needed by acq_eval<D>: static part (doubles) + 3 n doubles of dynamic scratch
 template <int D>
 struct AcqLds {
@@ -52,6 +76,7 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
     const int lane = threadIdx.x;
     const int64_t i = index;
     const bool want_grad = grad_out != nullptr;
+    GABO_TICK(100);
     // ---- candidate side: W = chol(x*)^-1, computed by every lane (wave-uniform, a few hundred flops)
     // and kept in LDS (broadcast reads with compile-time offsets) so that it does not compete with M for registers
     {
@@ -64,6 +89,7 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
         if (lane == 0) static_for<T>([&](auto ee) { wl[decltype(ee)::value] = w[decltype(ee)::value]; });
     }
     __syncthreads();
+    GABO_TICK(101);
     const double* w = wl;
     for (int64_t j0 = 0; j0 < n; j0 += 64) {
         const int64_t j = j0 + lane;
@@ -144,6 +170,7 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
         }
     }
     __syncthreads();
+    GABO_TICK(102);
     // ---- exact-GP posterior + acquisition (same arithmetic as gp_acquisition.hip)
     double part = 0.0;
     for (int64_t j = lane; j < n; j += 64) part = __builtin_fma(ks[j], alpha[j], part);
@@ -156,10 +183,8 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
     } else {
         part = 0.0;
         for (int64_t r = lane; r < n; r += 64) {
-            double a = 0.0;
-            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(linv_t[j * n + r], ks[j], a);
-            vv[r] = a;
-            part = __builtin_fma(a, a, part);
+            vv[r] = strided_dot(linv_t + r, ks, (int)n);      // (L^-1 ks)_r = sum_j L^-T[j][r] ks[j]  (zero for j > r)
+            part = __builtin_fma(vv[r], vv[r], part);
         }
         const double var = os * kxx - wave_sum64(part);
         const bool clamped = !(var > 1e-9);
@@ -173,12 +198,12 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
     }
     if (!want_grad) return;
     __syncthreads();
+    GABO_TICK(103);
     // ---- weights w_j = d(out_sign acq)/d(d_j^2) and S = sum_j w_j logm(M_j), one accumulator column per lane
     static_for<T>([&](auto ee) { acc[decltype(ee)::value * LD + lane] = 0.0; });
     for (int64_t j = lane; j < n; j += 64) {
         double ws = 0.0;
-        if (kind != GABO_ACQ_POSTERIOR_MEAN)
-            for (int64_t r = j; r < n; ++r) ws = __builtin_fma(linv[r * n + j], vv[r], ws);
+        if (kind != GABO_ACQ_POSTERIOR_MEAN) ws = strided_dot(linv + j, vv, (int)n);     // (L^-T v)_j = sum_r L^-1[r][j] v[r]  (zero for r < j)
         const double gk = out_sign * os * (g_mean * alpha[j] - 2.0 * g_var * ws);
         const double wj = gk * kd[j];
         static_for<T>([&](auto ee) {
@@ -187,12 +212,14 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
         });
     }
     __syncthreads();
+    GABO_TICK(104);
     for (int e = lane; e < T; e += 64) {
         double t = 0.0;
         for (int l = 0; l < 64; ++l) t += acc[e * LD + ((l + e) & 63)];
         red[e] = t;
     }
     __syncthreads();
+    GABO_TICK(105);
     // grad = -2 W^T S W, Mandel  (as in spd_backward.hip)
     for (int e = lane; e < T; e += 64) {
         int a = 0;
@@ -284,10 +311,8 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
     } else {
         part = 0.0;
         for (int64_t r = lane; r < n; r += 64) {
-            double a = 0.0;
-            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(linv_t[j * n + r], ks[j], a);
-            vv[r] = a;
-            part = __builtin_fma(a, a, part);
+            vv[r] = strided_dot(linv_t + r, ks, (int)n);      // (L^-1 ks)_r = sum_j L^-T[j][r] ks[j]  (zero for j > r)
+            part = __builtin_fma(vv[r], vv[r], part);
         }
         const double var = os * kxx - wave_sum64(part);
         const bool clamped = !(var > 1e-9);
@@ -306,8 +331,7 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
     static_for<T>([&](auto ee) { gacc[decltype(ee)::value] = 0.0; });
     for (int64_t j = lane; j < n; j += 64) {
         double ws = 0.0;
-        if (kind != GABO_ACQ_POSTERIOR_MEAN)
-            for (int64_t r = j; r < n; ++r) ws = __builtin_fma(linv[r * n + j], vv[r], ws);
+        if (kind != GABO_ACQ_POSTERIOR_MEAN) ws = strided_dot(linv + j, vv, (int)n);     // (L^-T v)_j = sum_r L^-1[r][j] v[r]  (zero for r < j)
         const double gk = out_sign * os * (g_mean * alpha[j] - 2.0 * g_var * ws);
         const double wj = 2.0 * gk * kd[j];
         static_for<T>([&](auto ee) {

@@ -124,8 +124,10 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
     double* xfd = t.x_fd + i * T;
     double* egfd = t.eg_fd + i * T;
     double* F = t.F + i * T * P.n;
+    GABO_TICK(1);
     tcg_begin(x, g, gc, fc, true, delta, w, i, R, D, C, status, mats);
     __syncthreads();
+    GABO_TICK(2);
     if constexpr (D <= 8) {
         // (x_unchanged: the previous proposal of this launch was rejected, so the constraint values and whitened gradients in the
         // workspace are still those of x: skip the eigen-solve)
@@ -135,9 +137,11 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
         }
     }
     double* egfd0 = t.eg_fd0 + i * T;
+    GABO_TICK(3);
     for (int it = 0; it < maxinner; ++it) {
         tcg_fd_point(w, i, D, xfd, mats);
         __syncthreads();
+        GABO_TICK(4);
         // tCG restarts from eta = 0 with the same x, g and preconditioner after a rejected proposal (only the radius changed), so its
         // first direction, first FD point and the acquisition gradient there are bit for bit those of the previous iteration: keep
         // that gradient instead of evaluating the acquisition again (a restart that sits on a bound does one tCG step per
@@ -145,8 +149,10 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
         double* eg_it = (it == 0) ? egfd0 : egfd;
         if (!(it == 0 && x_unchanged)) acq_eval_any<D, METRIC>(xfd, P, t.val_fd + i, eg_it, F, acq, dyn, status, i);
         __syncthreads();
+        GABO_TICK(5);
         const bool running = tcg_step(w, i, R, D, C, eg_it, neq, delta_cons, theta, kappa, mininner, it, mats);
         __syncthreads();
+        GABO_TICK(6);
         if (!running) break;
     }
     // ---- proposal x+ = L expm(eta~) L^T and the model decrease -<g, eta> - 1/2 <eta, H eta> (whitened Frobenius dots)
@@ -201,7 +207,36 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
         xpm[e] = (k == 0) ? M1[r * D + cc] : kSqrt2 * M1[r * D + cc];
     }
     __syncthreads();
+    GABO_TICK(7);
     acq_eval_any<D, METRIC>(xpm, P, t.fx_prop + i, t.eg_prop + i * T, F, acq, dyn, status, i);
+    GABO_TICK(8);
+}
+
+// The exact-GP factors L^-1 and L^-T (n^2 doubles each) are read by every acquisition evaluation of the launch - two triangular
+// matrix-vector products whose per-lane loops wait for one L2 round trip per term (clock instrumentation, tools/tr_clocks.py: 15 k
+// + 16 k of the 55-64 k cycles of an evaluation at n = 50).  When they fit, the wave copies them into LDS once per launch and the
+// evaluations read them from there.  Dynamic LDS: 3 n doubles of scratch, then 2 n^2 doubles when `stage_gp`.
+static __device__ __forceinline__ AcqParams stage_gp_factors(const AcqParams& P, double* dyn, int stage_gp) {
+    AcqParams Ps = P;
+    if (stage_gp && P.linv && P.linv_t) {
+        const int64_t nn = P.n * P.n;
+        double* gl = dyn + 3 * P.n;
+        for (int64_t e = threadIdx.x; e < nn; e += blockDim.x) {
+            gl[e] = P.linv[e];
+            gl[nn + e] = P.linv_t[e];
+        }
+        __syncthreads();
+        Ps.linv = gl;
+        Ps.linv_t = gl + nn;
+    }
+    return Ps;
+}
+
+// dynamic LDS bytes of the trust-region kernels and whether the GP factors are staged (total LDS of a block stays below 64 KB)
+static inline size_t tr_dynamic_lds(int64_t n, int* stage_gp) {
+    const size_t base = (size_t)(3 * n) * sizeof(double), staged = (size_t)(2 * n * n) * sizeof(double);
+    *stage_gp = (base + staged <= 48 * 1024) ? 1 : 0;
+    return base + (*stage_gp ? staged : 0);
 }
 
 template <int D, int METRIC>
@@ -210,7 +245,8 @@ __global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __rest
                                                             const double* __restrict__ gc, const double* __restrict__ fc,
                                                             AcqParams P, void* wsbase, double* __restrict__ x_prop, int64_t R, int C,
                                                             int neq, double delta_cons, double theta, double kappa, int mininner,
-                                                            int maxinner, int* __restrict__ any_active, int* __restrict__ status) {
+                                                            int maxinner, int* __restrict__ any_active, int* __restrict__ status,
+                                                            int stage_gp) {
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
     __shared__ __attribute__((aligned(16))) double mats[5 * dd + kJacobiScratch];
@@ -219,7 +255,8 @@ __global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __rest
     if (i == 0 && threadIdx.x == 0) *any_active = 0;          // set again by the update kernel
     if (active[i] == 0) return;
     TrWs t = tr_layout(wsbase, R, D, C, P.n);
-    tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], gc, fc, P, t, x_prop + i * dd, i, R, C, neq, delta_cons, theta, kappa,
+    const AcqParams Ps = stage_gp_factors(P, dyn, stage_gp);
+    tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], gc, fc, Ps, t, x_prop + i * dd, i, R, C, neq, delta_cons, theta, kappa,
                                mininner, maxinner, acq, mats, dyn, status, nullptr);
 }
 
@@ -288,7 +325,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
                                                           BuiltinCons B, void* wsbase, int64_t R, double delta_cons, double theta,
                                                           double kappa, int mininner, int maxinner, double delta_bar, double rho_prime,
                                                           double rho_regularization, double mingradnorm, int64_t maxiter,
-                                                          int* __restrict__ status) {
+                                                          int* __restrict__ status, int stage_gp) {
     static_assert(D <= 8, "built-in constraints use the register eigen-solver");
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
@@ -299,15 +336,17 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     const int C = B.n;
     TrWs t = tr_layout(wsbase, R, D, C, P.n);
     double* xp = t.xp_mat + i * dd;
+    const AcqParams Ps = stage_gp_factors(P, dyn, stage_gp);
     bool cons_fresh = false;          // wave-uniform: the constraints in the workspace belong to the current x
     for (;;) {
-        tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, P, t, xp, i, R, C, 0, delta_cons, theta, kappa,
+        tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, i, R, C, 0, delta_cons, theta, kappa,
                                    mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh);
         __syncthreads();
         const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B) : false;
         bool accepted = false;
         const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, i, D, C, delta_bar,
                                           rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
+        GABO_TICK(9);
         if (!still) break;
         cons_fresh = !accepted;
     }
@@ -320,9 +359,10 @@ static int launch_propose_one(const double* x, const double* g, const double* de
                               const double* fc, const AcqParams& P, void* ws, double* x_prop, int64_t r, int c, int neq,
                               double delta_cons, double theta, double kappa, int mininner, int maxinner, int* any_active, int* status,
                               hipStream_t st) {
-    size_t lds = (size_t)(3 * P.n) * sizeof(double);
+    int stage_gp = 0;
+    size_t lds = tr_dynamic_lds(P.n, &stage_gp);
     hipLaunchKernelGGL((spd_tr_propose_kernel<D, METRIC>), dim3((unsigned)r), dim3(64), lds, st, x, g, delta_tr, active, gc, fc, P, ws,
-                       x_prop, r, c, neq, delta_cons, theta, kappa, mininner, maxinner, any_active, status);
+                       x_prop, r, c, neq, delta_cons, theta, kappa, mininner, maxinner, any_active, status, stage_gp);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
@@ -377,12 +417,13 @@ struct SolveArgs {
 
 template <int METRIC>
 static int dispatch_solve(const SolveArgs& a) {
-    size_t lds = (size_t)(3 * a.P->n) * sizeof(double);
+    int stage_gp = 0;
+    size_t lds = tr_dynamic_lds(a.P->n, &stage_gp);
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
         hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
                            a.active, a.iters, *a.P, a.B, a.ws, a.r, a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.delta_bar, \
-                           a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status);                               \
+                           a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp);                     \
         break;
     switch (a.d) {
         GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8)

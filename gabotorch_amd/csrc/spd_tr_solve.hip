@@ -4,3 +4,17 @@
 namespace gabo {
 int solve_affine_invariant(const SolveArgs& a) { return dispatch_solve<0>(a); }
 }  // namespace gabo
+
+#ifdef GABO_TR_CLOCKS
+// development only: copy out and reset the (tag, cycle) pairs recorded by block 0 of the kernels of THIS translation unit
+extern "C" int gabo_debug_clocks(long long* out, int max_pairs) {
+    int n = 0;
+    hipMemcpyFromSymbol(&n, HIP_SYMBOL(gabo_clk_n), sizeof(int));
+    if (n > max_pairs) n = max_pairs;
+    if (n > 4096) n = 4096;
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(gabo_clk_buf), (size_t)n * 2 * sizeof(long long));
+    int zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(gabo_clk_n), &zero, sizeof(int));
+    return n;
+}
+#endif

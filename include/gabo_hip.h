@@ -185,7 +185,8 @@ int gabo_frobenius_backward(const double* x1, const double* x2, const double* gr
  * K(X*, X_train) inside the acquisition maximiser (manifold_optimize.py:182-184; botorch ExpectedImprovement / PosteriorMean
  * over a gpytorch ExactGP, [3P] semantics in SURVEY App. B).  One launch replaces the posterior algebra and its autograd.
  *   kstar: r x n BASE kernel values k(x*_r, x_train_j) (before the outputscale); alpha = (K + noise I)^-1 (y - mean), n;
- *   linv = L^-1 and linv_t = L^-T (both n x n row-major, L = chol(K + noise I)); kxx = base kernel k(x*, x*).
+ *   linv = L^-1 and linv_t = L^-T (both n x n row-major DENSE, L = chol(K + noise I), with exact zeros outside their triangle: the
+ *   SPD kernels sum over whole rows / columns); kxx = base kernel k(x*, x*).
  *   value[r]      = out_sign * acquisition(x*_r)
  *   grad_kstar    = NULL or r x n: out_sign * d acquisition / d kstar   (chain it into gabo_spd_ai_backward / the sphere backward)
  *   kind GABO_ACQ_EXPECTED_IMPROVEMENT: sigma = sqrt(max(var, 1e-9)), u = +-(mean - best_f)/sigma, EI = sigma (phi(u) + u Phi(u))
@@ -254,8 +255,8 @@ typedef struct {
     const double* train_factors; /* affine-invariant: gabo_spd_acq_prepare_train output; log-Euclidean / Frobenius: the Mandel vectors of
                                     logm(X_j) / X_j; always entry-major d_vec x n */
     const double* alpha;         /* n */
-    const double* linv;          /* n x n */
-    const double* linv_t;        /* n x n */
+    const double* linv;          /* n x n dense, zeros above the diagonal */
+    const double* linv_t;        /* n x n dense, zeros below the diagonal */
     int64_t n;
     double beta;
     int flags;                   /* GABO_OUT_GAUSSIAN / GABO_OUT_LAPLACE | GABO_METRIC_* */

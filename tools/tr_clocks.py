@@ -1,0 +1,42 @@
+"""Where one trust-region iteration's cycles go (development; needs the library built by
+`python tools/ab_build.py clk spd_tr_solve.hip -DGABO_TR_CLOCKS` and GABO_HIP_LIB pointing at it): runs the config-4 single-launch solve
+and prints, for restart 0, the cycles between the instrumentation points of csrc/spd_tr_body.hpp / spd_acq_body.hpp."""
+import ctypes, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gabotorch_amd import _lib
+from tools.sweep_bench import run_sweep
+
+lib = ctypes.CDLL(_lib.LIB_PATH)
+lib.gabo_debug_clocks.restype = ctypes.c_int
+lib.gabo_debug_clocks.argtypes = [ctypes.c_void_p, ctypes.c_int]
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+run_sweep("cuda:0", num_restarts=R, batched_rand=True, builtin_constraint=True)
+buf = (ctypes.c_longlong * 8192)()
+lib.gabo_debug_clocks(buf, 4096)                       # drop the warm-up run
+run_sweep("cuda:0", num_restarts=R, batched_rand=True, builtin_constraint=True, maxiter=6)
+n = lib.gabo_debug_clocks(buf, 4096)
+ev = [(int(buf[2 * k]), int(buf[2 * k + 1])) for k in range(n)]
+names = {1: "iteration start", 2: "tcg_begin", 3: "builtin constraints", 4: "tcg_fd_point", 5: "acq_eval at the FD point", 6: "tcg_step",
+         7: "proposal: expm, congruence, Mandel", 8: "acq_eval at the proposal", 9: "update (rho test, state)",
+         100: "  acq: entry", 101: "  acq: chol + inverse of x", 102: "  acq: pairs (M, eigen, logs, F)", 103: "  acq: GP posterior + EI",
+         104: "  acq: weights + accumulate", 105: "  acq: reduce"}
+print(f"{n} events for restart 0")
+tot = collections.OrderedDict()
+prev_outer = None
+prev_any = None
+for tag, t in ev:
+    if prev_any is not None:
+        key = names.get(tag, str(tag)) if tag >= 100 else None
+        if tag >= 100 and prev_any[0] >= 100 and tag != 100:
+            tot.setdefault(key, []).append(t - prev_any[1])
+    if tag < 100:
+        if prev_outer is not None:
+            tot.setdefault(names.get(tag, str(tag)), []).append(t - prev_outer[1])
+        prev_outer = (tag, t)
+    prev_any = (tag, t)
+for k, v in tot.items():
+    print(f"{k:45s} n={len(v):3d}  mean {np.mean(v):9.0f} cycles   total {np.sum(v):10.0f}")
+its = [t for tag, t in ev if tag == 1]
+if len(its) > 1:
+    print("cycles per trust-region iteration:", [its[k + 1] - its[k] for k in range(len(its) - 1)])
