@@ -173,7 +173,11 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
 }  // namespace gabo
 
 namespace gabo {
-// dimensions 13..16 are instantiated in their own translation unit (spd_pairwise_wide.hip)
+// dimensions 13..16 are instantiated in their own translation unit (spd_pairwise_wide.hip), 17..20 in two more
+int launch_spd_ai_wide2(int d, const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
+                        int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st);
+int launch_spd_ai_wide3(int d, const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
+                        int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st);
 int launch_spd_ai_wide(int d, const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
                        int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st);
 }  // namespace gabo

@@ -1,5 +1,5 @@
 // SPD pairwise Gram, dimensions 13..16: the same register-resident lane-per-pair kernels, budgeted for ONE wave per SIMD (512 VGPRs
-// per lane).  (d = 17..20 also fit - a little scratch from d = 18, 4.7e8 pairs/s at d = 20 - but cost 2.5 minutes of compile time.)  Instantiations only; templates in spd_pairwise_body.hpp.
+// per lane); d = 17..20 in spd_pairwise_wide2.hip / spd_pairwise_wide3.hip.  Instantiations only; templates in spd_pairwise_body.hpp.
 #include "spd_pairwise_body.hpp"
 
 namespace gabo {
@@ -13,6 +13,8 @@ int launch_spd_ai_wide(int d, const double* x1, const double* x2, double* out, d
         GABO_CASE(13) GABO_CASE(14) GABO_CASE(15) GABO_CASE(16)
     }
 #undef GABO_CASE
+    if (d == 17 || d == 18) return launch_spd_ai_wide2(d, x1, x2, out, dist_out, batch, n1, n2, s1, s2, beta, flags, ws, status, st);
+    if (d == 19 || d == 20) return launch_spd_ai_wide3(d, x1, x2, out, dist_out, batch, n1, n2, s1, s2, beta, flags, ws, status, st);
     return GABO_ERR_DIM;
 }
 

@@ -232,10 +232,12 @@ static __device__ __forceinline__ AcqParams stage_gp_factors(const AcqParams& P,
     return Ps;
 }
 
-// dynamic LDS bytes of the trust-region kernels and whether the GP factors are staged (total LDS of a block stays below 64 KB)
-static inline size_t tr_dynamic_lds(int64_t n, int* stage_gp) {
+// dynamic LDS bytes of the trust-region kernels and whether the GP factors are staged: when they fit (total LDS of a block below 64 KB)
+// and the launch is in the latency regime.  With thousands of restarts the CUs are full and LDS capacity limits the blocks per CU:
+// measured per propose launch, staged vs not: 113 vs 137 us at 512 restarts, 242 vs 209 at 2048, 757 vs 689 at 8192.
+static inline size_t tr_dynamic_lds(int64_t n, int64_t restarts, int* stage_gp) {
     const size_t base = (size_t)(3 * n) * sizeof(double), staged = (size_t)(2 * n * n) * sizeof(double);
-    *stage_gp = (base + staged <= 48 * 1024) ? 1 : 0;
+    *stage_gp = (base + staged <= 48 * 1024 && restarts <= 1024) ? 1 : 0;
     return base + (*stage_gp ? staged : 0);
 }
 
@@ -360,7 +362,7 @@ static int launch_propose_one(const double* x, const double* g, const double* de
                               double delta_cons, double theta, double kappa, int mininner, int maxinner, int* any_active, int* status,
                               hipStream_t st) {
     int stage_gp = 0;
-    size_t lds = tr_dynamic_lds(P.n, &stage_gp);
+    size_t lds = tr_dynamic_lds(P.n, r, &stage_gp);
     hipLaunchKernelGGL((spd_tr_propose_kernel<D, METRIC>), dim3((unsigned)r), dim3(64), lds, st, x, g, delta_tr, active, gc, fc, P, ws,
                        x_prop, r, c, neq, delta_cons, theta, kappa, mininner, maxinner, any_active, status, stage_gp);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
@@ -418,7 +420,7 @@ struct SolveArgs {
 template <int METRIC>
 static int dispatch_solve(const SolveArgs& a) {
     int stage_gp = 0;
-    size_t lds = tr_dynamic_lds(a.P->n, &stage_gp);
+    size_t lds = tr_dynamic_lds(a.P->n, a.r, &stage_gp);
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
         hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \

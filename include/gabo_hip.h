@@ -47,7 +47,7 @@ typedef void* gabo_stream_t; /* hipStream_t */
  * the metric) up to GABO_SPD_FWD_REG_MAX_DIM; the closed-form backward and the fused acquisition kernels up to
  * GABO_SPD_REG_MAX_DIM; larger d falls back to one wave per pair with LDS tiles. */
 #define GABO_SPD_REG_MAX_DIM 12
-#define GABO_SPD_FWD_REG_MAX_DIM 16   /* the forward kernels stay register-resident up to here (one wave per SIMD above 12) */
+#define GABO_SPD_FWD_REG_MAX_DIM 20   /* the forward kernels stay register-resident up to here (one wave per SIMD above 12) */
 #define GABO_SPD_MAX_DIM 32
 
 int gabo_version(void);
