@@ -132,3 +132,39 @@ def test_gen_candidates_drives_a_foreign_solver_restart_by_restart():
     assert solver.calls == 4 and cand.shape == (4, 1, n) and val.shape == (4,)
     np.testing.assert_allclose(cand[:, 0].numpy(), np.tile(y, (4, 1)), atol=1e-7)
     np.testing.assert_allclose(val.numpy(), 1.0, atol=1e-12)
+
+
+def test_use_rand_start_reaches_the_same_optima(golden):
+    """use_rand=True (robust_trust_regions.py:173-219, 407-452): random tCG start without preconditioner + Cauchy-point safeguard.  The
+    random start cannot be pinned against the reference (pymanopt's randvec and numpy's global stream), so the property is checked:
+    every restart ends on a stationary point at least as good as its start, and from starts near an optimum it ends on that optimum."""
+    g = golden("trust_regions.npz")
+    cost = sphere_kernel_mean_cost(T(g["sph5_Y"]), T(g["sph5_w"]), float(g["sph5_beta"]))
+    torch.manual_seed(0)
+    x0 = T(g["sph5_x0"])
+    prob = BatchedProblem(CpuSphere(5), cost)
+    x = TrustRegions(use_rand=True).solve(prob, x0)
+    assert (cost(x) <= cost(x0) + 1e-12).all()
+    _, rg = prob.cost_grad(x)
+    assert float(rg.norm(dim=-1).max()) < 1e-5
+    near = T(g["sph5_exact_x"]) + 1e-3 * torch.randn(g["sph5_exact_x"].shape, dtype=torch.float64)
+    near = near / near.norm(dim=-1, keepdim=True)
+    y = TrustRegions(use_rand=True).solve(BatchedProblem(CpuSphere(5), cost), near)
+    np.testing.assert_allclose(y.numpy(), g["sph5_exact_x"], atol=1e-6)
+
+
+def test_plugin_api_namespaces_expose_the_names_the_examples_import():
+    from gabotorch_amd.plugin_api import botorch, gpytorch
+    import gabotorch_amd.plugin_api.pymanopt.manifolds as pyman_man
+    import gabotorch_amd.plugin_api.pymanopt.solvers as pyman_solvers
+    for obj in (gpytorch.kernels.ScaleKernel, gpytorch.kernels.Kernel, gpytorch.priors.torch_priors.GammaPrior,
+                gpytorch.likelihoods.gaussian_likelihood.GaussianLikelihood, gpytorch.constraints.GreaterThan,
+                gpytorch.mlls.ExactMarginalLogLikelihood, botorch.models.SingleTaskGP, botorch.fit_gpytorch_model,
+                botorch.acquisition.ExpectedImprovement, pyman_man.PositiveDefinite, pyman_man.Sphere, pyman_man.Grassmann,
+                pyman_man.Product, pyman_man.Euclidean, pyman_solvers.TrustRegions, pyman_solvers.ConjugateGradient):
+        assert callable(obj)
+    prior = gpytorch.priors.torch_priors.GammaPrior(1.1, 0.05)
+    assert abs((prior.concentration - 1) / prior.rate - 2.0) < 1e-12                     # examples/gabo_spd.py:168
+    lik = gpytorch.likelihoods.gaussian_likelihood.GaussianLikelihood(noise_prior=prior, noise_constraint=gpytorch.constraints.GreaterThan(1e-8),
+                                                                     initial_value=2.0)
+    assert lik.initial_value == 2.0
