@@ -16,6 +16,7 @@ struct TcgWs {
     double *chol, *g_w, *eta_w, *heta_w, *r_w, *delta_w, *expm, *w_ones, *scal, *gc_w, *fc, *fcg_pe;
     int *stop, *running, *counters;
     size_t bytes;
+    int64_t index_base;      // added to the restart index when an error is reported (a block-private workspace is indexed with 0)
 };
 
 static __host__ __device__ inline TcgWs tcg_layout(void* base, int64_t R, int d, int C) {
@@ -39,6 +40,7 @@ static __host__ __device__ inline TcgWs tcg_layout(void* base, int64_t R, int d,
     w.running = q;  q += R;
     w.counters = q; q += 4;
     w.bytes = (size_t)((char*)q - (char*)base);
+    w.index_base = 0;
     return w;
 }
 
@@ -88,7 +90,7 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
     bool ok = lds_cholesky(M0, d);
     lds_tri_inverse(M0, M1, d);
     if (!ok && threadIdx.x == 0 && status) {
-        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = (int)i;
+        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = (int)(i + w.index_base);
     }
     lds_load(g, M2, d);
     lds_symmetrize(M2, M4, d);

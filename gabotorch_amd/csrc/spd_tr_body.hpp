@@ -147,7 +147,7 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
         // that gradient instead of evaluating the acquisition again (a restart that sits on a bound does one tCG step per
         // iteration - this is half of its acquisition evaluations)
         double* eg_it = (it == 0) ? egfd0 : egfd;
-        if (!(it == 0 && x_unchanged)) acq_eval_any<D, METRIC>(xfd, P, t.val_fd + i, eg_it, F, acq, dyn, status, i);
+        if (!(it == 0 && x_unchanged)) acq_eval_any<D, METRIC>(xfd, P, t.val_fd + i, eg_it, F, acq, dyn, status, i + w.index_base);
         __syncthreads();
         GABO_TICK(5);
         const bool running = tcg_step(w, i, R, D, C, eg_it, neq, delta_cons, theta, kappa, mininner, it, mats);
@@ -208,7 +208,7 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
     }
     __syncthreads();
     GABO_TICK(7);
-    acq_eval_any<D, METRIC>(xpm, P, t.fx_prop + i, t.eg_prop + i * T, F, acq, dyn, status, i);
+    acq_eval_any<D, METRIC>(xpm, P, t.fx_prop + i, t.eg_prop + i * T, F, acq, dyn, status, i + w.index_base);
     GABO_TICK(8);
 }
 
@@ -239,6 +239,18 @@ static inline size_t tr_dynamic_lds(int64_t n, int64_t restarts, int* stage_gp) 
     const size_t base = (size_t)(3 * n) * sizeof(double), staged = (size_t)(2 * n * n) * sizeof(double);
     *stage_gp = (base + staged <= 48 * 1024 && restarts <= 1024) ? 1 : 0;
     return base + (*stage_gp ? staged : 0);
+}
+
+// The single-launch solve owns its restart from the first iteration to the last: nothing in the workspace has to survive the launch, so
+// the whole per-restart workspace (whitened tCG vectors, FD point, proposal, the logm spill: ~1 k doubles at d = 5, n = 50) can live in
+// the block's LDS instead of L2 - every phase of an iteration starts with dependent loads of that state.  Only in the latency regime and
+// when it fits next to the staged GP factors (static LDS of the kernel is below 12 KB for d <= 8).
+static inline size_t tr_solve_dynamic_lds(int64_t n, int64_t restarts, int d, int C, int* stage_gp, int* ws_lds) {
+    size_t bytes = tr_dynamic_lds(n, restarts, stage_gp);
+    bytes = (bytes + 15) & ~(size_t)15;
+    const size_t ws = tr_layout(nullptr, 1, d, C, n).bytes + 16;
+    *ws_lds = (restarts <= 1024 && bytes + ws <= 52 * 1024) ? 1 : 0;
+    return bytes + (*ws_lds ? ws : 0);
 }
 
 template <int D, int METRIC>
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
                                                           BuiltinCons B, void* wsbase, int64_t R, double delta_cons, double theta,
                                                           double kappa, int mininner, int maxinner, double delta_bar, double rho_prime,
                                                           double rho_regularization, double mingradnorm, int64_t maxiter,
-                                                          int* __restrict__ status, int stage_gp) {
+                                                          int* __restrict__ status, int stage_gp, int ws_lds) {
     static_assert(D <= 8, "built-in constraints use the register eigen-solver");
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
@@ -336,17 +348,32 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     const int64_t i = blockIdx.x;
     if (active[i] == 0) return;
     const int C = B.n;
-    TrWs t = tr_layout(wsbase, R, D, C, P.n);
-    double* xp = t.xp_mat + i * dd;
     const AcqParams Ps = stage_gp_factors(P, dyn, stage_gp);
+    // workspace: this block's slice of the caller's buffer, or (ws_lds) a private copy of the layout for ONE restart in LDS
+    TrWs t;
+    int64_t iw = i, Rw = R;
+    if (ws_lds) {
+        size_t off = (size_t)(3 * P.n + (stage_gp ? 2 * P.n * P.n : 0)) * sizeof(double);
+        off = (off + 15) & ~(size_t)15;
+        char* base = (char*)dyn + off;
+        t = tr_layout(base, 1, D, C, P.n);
+        for (size_t e = threadIdx.x; e < t.bytes / sizeof(double); e += blockDim.x) ((double*)base)[e] = 0.0;
+        t.tcg.index_base = i;
+        iw = 0;
+        Rw = 1;
+        __syncthreads();
+    } else {
+        t = tr_layout(wsbase, R, D, C, P.n);
+    }
+    double* xp = t.xp_mat + iw * dd;
     bool cons_fresh = false;          // wave-uniform: the constraints in the workspace belong to the current x
     for (;;) {
-        tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, i, R, C, 0, delta_cons, theta, kappa,
+        tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, iw, Rw, C, 0, delta_cons, theta, kappa,
                                    mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh);
         __syncthreads();
         const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B) : false;
         bool accepted = false;
-        const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, i, D, C, delta_bar,
+        const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, iw, D, C, delta_bar,
                                           rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
         GABO_TICK(9);
         if (!still) break;
@@ -419,13 +446,13 @@ struct SolveArgs {
 
 template <int METRIC>
 static int dispatch_solve(const SolveArgs& a) {
-    int stage_gp = 0;
-    size_t lds = tr_dynamic_lds(a.P->n, a.r, &stage_gp);
+    int stage_gp = 0, ws_lds = 0;
+    size_t lds = tr_solve_dynamic_lds(a.P->n, a.r, a.d, a.B.n, &stage_gp, &ws_lds);
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
         hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
                            a.active, a.iters, *a.P, a.B, a.ws, a.r, a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.delta_bar, \
-                           a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp);                     \
+                           a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds);             \
         break;
     switch (a.d) {
         GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8)
