@@ -189,7 +189,10 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
             double sigma = sa - copysign_d(root - __builtin_fabs(delta), delta);
             double gamma = nonzero(dg[D - 1] - sigma);
             double p = floor_p(gamma * gamma);
-            double c = 1.0, s = 0.0;
+            double s = 0.0;
+#ifdef GABO_QL_FORM1
+            double c = 1.0;
+#endif
             static_for_down<D - 2, l>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
 #ifdef GABO_QL_NO_LOOKAHEAD
@@ -199,28 +202,31 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
 #endif
                 double r = p + bb;
                 if constexpr (i != D - 2) e2[i + 1] = s * r;
-#ifdef GABO_QL_TWO_RCP
-                double ir = GABO_QL_RCP(r);
-                c = p * ir;
-                s = bb * ir;
-                double ic = GABO_QL_RCP(c);
-#else
-                // one reciprocal serves both divisions of the step: t = 1/(p r)  =>  1/r = t p,  and
-                // p' = gamma^2 / c = gamma^2 r / p = (gamma r)^2 t
+#ifdef GABO_QL_FORM1
+                // (round-1 form: c and s explicitly, gamma = c (a_i - sigma) - s gamma_old, p' = (gamma r)^2 t)
                 double t = GABO_QL_RCP(p * r);
                 double ir = t * p;
                 c = p * ir;
                 s = bb * ir;
-#endif
                 double oldgam = gamma;
                 double al = dg[i];
                 gamma = nonzero(__builtin_fma(c, al - sigma, -s * oldgam));
                 dg[i + 1] = oldgam + (al - gamma);
-#ifdef GABO_QL_TWO_RCP
-                p = gamma * gamma * ic;
-#else
                 double gr = gamma * r;
                 p = floor_p((gr * t) * gr);
+#else
+                // one reciprocal serves the step: t = 1/(p r)  =>  1/r = t p.  With f = p (a_i - sigma) - b gamma_old:
+                //   gamma' = c (a_i - sigma) - s gamma_old = f / r = f (t p),     p' = gamma'^2 / c = gamma'^2 r / p = f^2 t
+                // (c itself is never needed; two instructions less per step than forming c, gamma r and (gamma r)^2 t)
+                double t = GABO_QL_RCP(p * r);
+                double ir = t * p;
+                s = bb * ir;
+                double oldgam = gamma;
+                double al = dg[i];
+                double f = __builtin_fma(p, al - sigma, -(bb * oldgam));
+                gamma = ir * f;
+                dg[i + 1] = oldgam + (al - gamma);
+                p = floor_p((f * t) * f);
 #endif
             });
             e2[l] = s * p;

@@ -12,7 +12,9 @@ import numpy as np
 D = 10
 EPS2 = 1e-22
 ZERO = True
+RCPERR = 0.0       # relative error of the reciprocal inside a step (2^-47 = 7e-15 models the one-Newton reciprocal)
 PFLOOR = False
+FORM2 = False     # gamma = (p a - b gamma_old) / r and p' = f^2 t with t = 1/(p r): two instructions less per step
 
 
 def synth(n, d, seed):
@@ -111,16 +113,22 @@ def ql(dg, e2, lookahead, wave=64):
                 r = p + bb
                 if i != D - 2:
                     e2[idx, i + 1] = s * r
-                t = 1.0 / (p * r)
+                t = (1.0 / (p * r)) * (1.0 + RCPERR * np.random.default_rng(i).uniform(-1, 1, len(idx)))
                 ir = t * p
                 c = p * ir
                 s = bb * ir
                 oldgam = gamma
                 al = dg[idx, i]
-                gamma = (c * (al - sigma) - s * oldgam) if PFLOOR else nonzero(c * (al - sigma) - s * oldgam)
-                dg[idx, i + 1] = oldgam + (al - gamma)
-                gr = gamma * r
-                p = np.maximum((gr * t) * gr, 1e-150) if PFLOOR else (gr * t) * gr
+                if FORM2:
+                    f = p * (al - sigma) - bb * oldgam
+                    gamma = ir * f
+                    dg[idx, i + 1] = oldgam + (al - gamma)
+                    p = np.maximum((f * t) * f, 1e-150)
+                else:
+                    gamma = (c * (al - sigma) - s * oldgam) if PFLOOR else nonzero(c * (al - sigma) - s * oldgam)
+                    dg[idx, i + 1] = oldgam + (al - gamma)
+                    gr = gamma * r
+                    p = np.maximum((gr * t) * gr, 1e-150) if PFLOOR else (gr * t) * gr
             e2[idx, l] = s * p
             dg[idx, l] = sigma + gamma
     a, b2, cc = dg[:, D - 2].copy(), e2[:, D - 2].copy(), dg[:, D - 1].copy()
