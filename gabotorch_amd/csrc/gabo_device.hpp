@@ -205,6 +205,47 @@ __device__ __forceinline__ double exp_neg(double x, const MathRegs& t) {
     return __builtin_ldexp(p, (int)k);
 }
 
+// max(x, bound) for x known not to be a signalling NaN (hipcc otherwise canonicalises x with an extra v_max_f64 x, x first)
+__device__ __forceinline__ double max_raw(double x, double bound_uniform) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(bound_uniform));
+    return r;
+}
+
+// Table-assisted exp(x) for x <= 0 (kernel values of the write-bound Gram kernels): x = (64 e + j) ln2/64 + r, |r| <= ln2/128,
+// exp(x) = 2^e * 2^(j/64) * (1 + r + ... + r^5/120) (3.5e-17 truncation).  17 VALU instructions and one LDS read against ~37 for OCML's
+// exp (whose Horner steps each re-materialise a literal).  `tab`: the 64 entries of kExp2Tab copied to LDS by the kernel; `c`: kExpTabC
+// held in SGPRs ([0] ln2/64 high part with 33 bits so that k * hi is exact, [1] low part, [2] 64/ln2, [3..5] 1/120, 1/24, 1/6);
+// `c3_vgpr`: c[3] in a VGPR (a VALU instruction reads one scalar operand).
+static __constant__ double kExpTabC[6] = {0.010830424695086549, 1.162596423439437e-12, 92.33248261689366, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0};
+static __constant__ double kExp2Tab[64] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237,
+    1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916,
+    1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.202156731452703, 1.215247359980469,
+    1.22848053610687, 1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096,
+    1.3109612115247644, 1.3252366431597413, 1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832,
+    1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993,
+    1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837, 1.5759808451078865,
+    1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364, 1.681792830507429,
+    1.7001063537185235, 1.718619298122478, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072,
+    1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474,
+    1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+
+template <class C>
+__device__ __forceinline__ double exp_neg_tab(double x, const C& c, double c3_vgpr, const double* __restrict__ tab) {
+    x = max_raw(x, -800.0);
+    double k = __builtin_rint(x * c[2]);
+    double r = __builtin_fma(-k, c[1], __builtin_fma(-k, c[0], x));
+    double p = __builtin_fma(r, c3_vgpr, c[4]);
+    p = __builtin_fma(p, r, c[5]);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;                                                 // exp(r) - 1
+    int ki = (int)k;
+    double t = tab[ki & 63];
+    return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 6);   // (v_ldexp_f64 also does the gradual underflow)
+}
+
 // log(x) for positive normal x (eigenvalues of an SPD matrix), fdlibm e_log.c scheme: x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt 2,
 // s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2)), R a degree-7 minimax polynomial split into even and odd halves.
 // OCML's log is 98 VALU instructions (double-double arithmetic); this is ~35 at 1 ulp.  Coefficients pinned in registers.

@@ -71,6 +71,19 @@ __global__ __launch_bounds__(256, (D > 12 ? 1 : GABO_PAIR_WAVES)) void spd_ai_pa
                                                               int col_blocks, int row_chunks, int64_t sym_tiles, double beta, int flags) {
     constexpr int T = tri_size(D);
     const int mode = flags & GABO_OUT_MASK;
+    // small matrices (the latent spaces of the nested kernels: d = 2, 3): the finish is a visible part of a pair's ~140 instructions,
+    // so the Gaussian mode uses the table-assisted exp of the write-bound kernels (17 instead of ~37 instructions).  From d = 5 on the
+    // scalar registers are taken by the W row and OCML's exp measured faster than any variant with pinned coefficients.
+    constexpr bool kTabExp = D <= 4;
+    __shared__ double tab[kTabExp ? 64 : 1];
+    double ec[6], ec3 = 0.0;
+    if constexpr (kTabExp) {
+        if (threadIdx.x < 64) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+        __syncthreads();
+        static_for<6>([&](auto k) { ec[decltype(k)::value] = kExpTabC[decltype(k)::value]; });
+        ec3 = ec[3];
+        asm volatile("" : "+v"(ec3));
+    }
     int64_t cg, rc, b;
     if (flags & GABO_SYMMETRIC) {
         // Only tiles touching the upper triangle exist in the grid: column group cg owns row chunks
@@ -118,7 +131,8 @@ __global__ __launch_bounds__(256, (D > 12 ? 1 : GABO_PAIR_WAVES)) void spd_ai_pa
             // i.e. 1e-16 beta d^2 relative in K.  (OCML's exp stays: the register-table exp_neg of gabo_device.hpp measured 4 % SLOWER here,
             // 2.75 vs 2.63 ms - its 28 pinned coefficients cost more than the instructions they save once per pair.)
             dist = 0.0;
-            val = exp(-((s + 1e-15) * beta));
+            if constexpr (kTabExp) val = exp_neg_tab(-((s + 1e-15) * beta), ec, ec3, tab);
+            else val = exp(-((s + 1e-15) * beta));
         } else {
             dist = __builtin_sqrt(s + 1e-15);  // spd_utils_torch.py:120
             val = finish(dist, beta, mode);

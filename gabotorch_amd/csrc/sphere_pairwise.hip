@@ -26,21 +26,9 @@ __constant__ double kSphW[kSphWDeg + 1] = {
     0.9999999999999999, 0.166666666666762, 0.07499999997954958, 0.04464285887635292, 0.03038186720347429, 0.022374245713577247,
     0.01731559954431618, 0.014425198539078435, 0.007444628520337835, 0.03675841815436629, -0.12408231204352452, 0.4950065878219168,
     -1.3361380175788322, 2.733327968715509, -3.974232006625551, 3.9651660247789384, -2.4213345116985456, 0.7052735073244606};
-// [0] ln2/64 high part (33 bits: k * hi is exact), [1] low part, [2] 64/ln2, [3..5] 1/120, 1/24, 1/6, [6] pi, [7] z of the clamp
+// [6] pi, [7] z of the clamp (the exp constants [0..5] and the 2^(j/64) table are shared: gabo_device.hpp, kExpTabC / kExp2Tab)
 __constant__ double kSphC[8] = {0.010830424695086549, 1.162596423439437e-12, 92.33248261689366, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0,
                                 3.14159265358979311600e+00, 4.996003610813204e-16};
-__constant__ double kExp2Tab[64] = {
-    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237,
-    1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916,
-    1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.202156731452703, 1.215247359980469,
-    1.22848053610687, 1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096,
-    1.3109612115247644, 1.3252366431597413, 1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832,
-    1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993,
-    1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837, 1.5759808451078865,
-    1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364, 1.681792830507429,
-    1.7001063537185235, 1.718619298122478, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072,
-    1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474,
-    1.9360617934922943, 1.9571441241754002, 1.978456026387951};
 
 struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar cache, lives in SGPRs
     double w[kSphWDeg + 1], c[8], neg_beta, neg_4beta;
@@ -58,13 +46,6 @@ struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar
     }
 };
 
-// max(x, bound) for x known not to be a signalling NaN (hipcc otherwise canonicalises x with an extra v_max_f64 x, x first)
-__device__ __forceinline__ double max_raw(double x, double bound_uniform) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(bound_uniform));
-    return r;
-}
-
 __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss& g, const double* __restrict__ tab) {
     double z = max_raw(__builtin_fma(-0.5, __builtin_fabs(ip), 0.5), g.c[7]);
     double w = g.w_top;
@@ -72,17 +53,7 @@ __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss&
     double q = (z * w) * w;                                   // (phi / 2)^2
     double th = __builtin_fma(-2.0, sqrt_nz(q), g.c[6]);      // pi - phi
     double x = (ip < 0.0) ? (th * th) * g.neg_beta : q * g.neg_4beta;
-    x = max_raw(x, -800.0);
-    double k = __builtin_rint(x * g.c[2]);
-    double r = __builtin_fma(-k, g.c[1], __builtin_fma(-k, g.c[0], x));
-    double p = __builtin_fma(r, g.e_top, g.c[4]);
-    p = __builtin_fma(p, r, g.c[5]);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = p * r;                                                 // exp(r) - 1
-    int ki = (int)k;
-    double t = tab[ki & 63];
-    return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 6);   // (v_ldexp_f64 also does the gradual underflow)
+    return exp_neg_tab(x, g.c, g.e_top, tab);
 }
 
 template <int MODE>
