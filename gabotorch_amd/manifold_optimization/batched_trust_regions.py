@@ -243,7 +243,12 @@ class PointwiseProblemAdapter:
 
 class BatchedTrustRegions:
     """Riemannian trust regions with truncated CG, all restarts in lock step; optional equality / inequality constraints
-    handled as in ConstrainedTrustRegions (linearised constraints truncate the tCG step at distance Delta_cons)."""
+    handled as in ConstrainedTrustRegions (linearised constraints truncate the tCG step at distance Delta_cons).
+
+    Stopping criteria: `mingradnorm` and `maxiter` per restart on every path.  `maxtime` is checked once per outer iteration by the host-
+    driven paths; the single-launch device solve cannot look at a clock, so it is only taken when `maxtime` is at its default (>= 1000 s)
+    and a caller that lowers `maxtime` gets the launch-per-iteration plan instead.  pymanopt's underscored attribute names (`_maxiter`,
+    `_mingradnorm`, ...) are aliases of the plain ones, so outer solvers that tighten them between calls act on this object."""
 
     def __init__(self, miniter=3, kappa=0.1, theta=1.0, rho_prime=0.1, use_rand=False, rho_regularization=1e3, maxtime=1000,
                  maxiter=1000, mingradnorm=1e-6, minstepsize=1e-10, maxcostevals=5000, logverbosity=0, strict_constraints=False):
@@ -283,8 +288,10 @@ class BatchedTrustRegions:
                 try:
                     f = con(xx)
                     if f.shape != x.shape[:1]:
-                        raise RuntimeError
-                except Exception:   # noqa: BLE001  a user callable written for one point: evaluate restart by restart
+                        raise IndexError
+                except (IndexError, ValueError, TypeError, RuntimeError):
+                    # a user callable written for ONE point (the reference's convention): evaluate restart by restart - a genuine
+                    # error in the callable is raised again by this second call
                     f = torch.stack([con(xx[i]) for i in range(x.shape[0])])
                 (g,) = torch.autograd.grad(f.sum(), xx, allow_unused=True)
             if g is None:
@@ -302,8 +309,8 @@ class BatchedTrustRegions:
                 try:
                     f = con(x)
                     if f.shape != x.shape[:1]:
-                        raise RuntimeError
-                except Exception:   # noqa: BLE001  a user callable written for one point
+                        raise IndexError
+                except (IndexError, ValueError, TypeError, RuntimeError):      # a user callable written for one point (see above)
                     f = torch.stack([con(x[i]) for i in range(x.shape[0])])
                 vals.append(f.detach().to(x.dtype))
         return torch.stack(vals, dim=1)
