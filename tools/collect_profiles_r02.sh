@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/profiles_r02
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench command itself under the kernel trace (same flags as the graded run minus the CPU baseline and the side reports)
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sweep --no-symmetric > $OUT/bench_under_rocprof.json 2> /tmp/pk.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --no-symmetric > $OUT/bench_under_rocprof.json 2> /tmp/pk.err
 cp /tmp/pk/bench_kernel_stats.csv $OUT/bench_kernel_stats.csv
 cp /tmp/pk/bench_kernel_trace.csv $OUT/bench_kernel_trace.csv
 # 2. PMC passes on the Gram launch (FETCH_SIZE and WRITE_SIZE cannot share a pass; the mirror kernel of the symmetric build is the

@@ -39,7 +39,7 @@ def main():
         "round": 2, "kernel": kern,
         "workload": "N=4096, d=10, all N^2 pairs (bench.py `value` launches; tools/prof_spd.py 4096 10 x for the PMC passes)",
         "rocprof_kernel_trace_ms": {"avg": sum(durs) / len(durs), "median": statistics.median(durs), "min": min(durs), "max": max(durs),
-                                    "calls": len(durs), "note": "all dispatches of the bench command incl. its 3 warm-up steps"},
+                                    "calls": len(durs), "note": "all dispatches of the bench command: 60 disclosed preheat launches (the first ~20 at a lower clock), 5 warm-up steps, 20 timed steps"},
         "bench_hip_event_ms_per_step": line["roofline"]["kernel_ms"],
         "FETCH_SIZE_KB_raw": raw["full_fetch"][kern]["FETCH_SIZE"], "WRITE_SIZE_KB_raw": raw["full_write"][kern]["WRITE_SIZE"],
         "fetch_calibration": {"kernel": mirror + " (8 B/lane loads of a known byte count)", "known_bytes": known,
