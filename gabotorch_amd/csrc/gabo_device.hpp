@@ -281,4 +281,43 @@ __device__ __forceinline__ double log_pos(double x, const LogRegs& t) {
     return __builtin_fma(dk, t.ln2_hi, -((hfsq - __builtin_fma(s, hfsq + R, dk * t.ln2_lo)) - f));
 }
 
+
+// Table-assisted log(x) for positive normal x: k = exponent of x sqrt2, m = x 2^-k in [sqrt(1/2), sqrt 2), (c, l) = kLogTab[(exponent LSB, top 7
+// mantissa bits) of m] (gabo_log_tab.hpp: c ~ 1 / bucket centre, l = -log c; both buckets next to 1 hold (1, 0) so that log 1 = 0 exactly and the
+// logs of near-identity eigenvalues keep their relative accuracy), r = m c - 1 exactly (one FMA; |r| <= 2^-8, < 2^-7 next to 1),
+// log x = k ln2 + l + log1p(r) with the degree-7 series of log1p.  <= 2 ulp (tools/sim/gen_log_table.py models it in numpy); 20 VALU
+// instructions and one 16-byte LDS read, no reciprocal and no compare, against 35 with a quarter-rate v_rcp_f64 for log_pos.
+// `tab`: the 256 (c, l) pairs copied to LDS by the kernel.
+struct LogTabRegs {
+    double sqrt2, c7, c6, c5, c4, c3, ln2_hi, ln2_lo;
+    __device__ __forceinline__ static LogTabRegs load() {
+        LogTabRegs t;
+        t.sqrt2 = MathRegs::pin(1.41421356237309504880);
+        t.c7 = MathRegs::pin(1.0 / 7.0);
+        t.c6 = MathRegs::pin(-1.0 / 6.0);
+        t.c5 = MathRegs::pin(0.2);
+        t.c4 = MathRegs::pin(-0.25);
+        t.c3 = MathRegs::pin(1.0 / 3.0);
+        t.ln2_hi = MathRegs::pin(6.93147180369123816490e-01);
+        t.ln2_lo = MathRegs::pin(1.90821492927058770002e-10);
+        return t;
+    }
+};
+
+__device__ __forceinline__ double log_tab(double x, const LogTabRegs& t, const double* __restrict__ tab) {
+    const int ke = __builtin_amdgcn_frexp_exp(x * t.sqrt2);        // x sqrt2 = mant 2^ke, mant in [1/2, 1)
+    const double m = __builtin_ldexp(x, 1 - ke);                   // [sqrt(1/2), sqrt 2) (to a rounding of the product above: the table covers [1/2, 2))
+    const unsigned hi = (unsigned)__double2hiint(m);
+    const double2 cl = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + ((hi >> 9) & 0xff0u));
+    const double r = __builtin_fma(m, cl.x, -1.0);
+    double p = MathRegs::fmac(r, t.c7, t.c6);
+    p = MathRegs::fmac(p, r, t.c5);
+    p = MathRegs::fmac(p, r, t.c4);
+    p = MathRegs::fmac(p, r, t.c3);
+    p = __builtin_fma(p, r, -0.5);
+    const double lp = __builtin_fma(r * r, p, r);
+    const double dk = (double)(ke - 1);
+    return __builtin_fma(dk, t.ln2_hi, cl.y) + __builtin_fma(dk, t.ln2_lo, lp);
+}
+
 }  // namespace gabo

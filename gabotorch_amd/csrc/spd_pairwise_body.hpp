@@ -5,6 +5,7 @@
 #include "spd_prep.hpp"
 #include "gabo_mirror.hpp"
 #include "spd_generic.hpp"
+#include "gabo_log_tab.hpp"
 #include "../../include/gabo_hip.h"
 
 #ifndef GABO_PAIR_WAVES
@@ -15,7 +16,7 @@ namespace gabo {
 
 // sum_k log^2(lambda_k) of M = C C^T with C = W * G (both lower triangular, W wave-uniform, G per lane)
 template <int D>
-__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const double* __restrict__ Gj, int64_t gstride) {
+__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const double* __restrict__ Gj, int64_t gstride, const double* __restrict__ ltab) {
     constexpr int T = tri_size(D);
     // Column `col` of C = W G depends only on column `col` of G:  C[r][col] = sum_{k=col..r} W[r][k] G[k][col].
     // M = C C^T = sum_col C[:,col] C[:,col]^T, so M is accumulated by rank-1 updates and C is never held whole:
@@ -49,11 +50,34 @@ __device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const d
     double s = 0.0;
 #ifdef GABO_OCML_LOG
     static_for<D>([&](auto kk) { double lg = log(dg[decltype(kk)::value]); s = __builtin_fma(lg, lg, s); });
-#else
+#elif defined(GABO_LOG_FDLIBM)                /* A/B: the round-1 log (fdlibm scheme, 35 instructions with a v_rcp_f64) */
     const LogRegs lr = LogRegs::load();       // pinned here, after M and the tridiagonal are dead: no extra register pressure
     static_for<D>([&](auto kk) { double lg = log_pos(dg[decltype(kk)::value], lr); s = __builtin_fma(lg, lg, s); });
+#else
+    const LogTabRegs lr = LogTabRegs::load();
+    static_for<D>([&](auto kk) { double lg = log_tab(dg[decltype(kk)::value], lr, ltab); s = __builtin_fma(lg, lg, s); });
 #endif
     return s;
+}
+
+// d = 2 (the latent space of the nested kernels, config 5) in closed form with ONE logarithm per pair: M = C C^T, C = W G lower triangular, so
+// det M = (c00 c11)^2 exactly and log lambda_- = log det M - log lambda_+; log det M = 2 (log(w00 w11) + log(g00 g11)) is a per-POINT quantity
+// (`lw2`: the row's, wave-uniform; `lg2`: the lane's column's, computed once before the row loop).  lambda_+ = (tr + sqrt((m00 - m11)^2 + 4 m10^2)) / 2
+// has no cancellation.  ~45 instructions per pair against ~120 for the generic path (two logs, the 2x2 QL finish, three operand loads).
+struct Spd2Col {
+    double g00, g10, g11, lg;
+};
+__device__ __forceinline__ double ai_sumsq2(const double* __restrict__ W, const Spd2Col& g, double lw, const LogTabRegs& lr,
+                                            const double* __restrict__ ltab, double tiny) {
+    const double c00 = W[0] * g.g00, c11 = W[2] * g.g11;
+    const double c10 = __builtin_fma(W[1], g.g00, W[2] * g.g10);
+    const double m00 = c00 * c00, m10d = (c10 + c10) * c00, m11 = __builtin_fma(c10, c10, c11 * c11);
+    const double tr = m00 + m11, df = m00 - m11;
+    // (`tiny` = 1e-290 keeps the seed-based square root away from 0 when M is a multiple of the identity)
+    const double root = sqrt_nz(__builtin_fma(df, df, __builtin_fma(m10d, m10d, tiny)));
+    const double l1 = log_tab(0.5 * (tr + root), lr, ltab);
+    const double l2 = __builtin_fma(2.0, lw + g.lg, -l1);
+    return __builtin_fma(l1, l1, l2 * l2);
 }
 
 __device__ __forceinline__ double finish(double dist, double beta, int mode) {
@@ -76,10 +100,14 @@ __global__ __launch_bounds__(256, (D > 12 ? 1 : GABO_PAIR_WAVES)) void spd_ai_pa
     // scalar registers are taken by the W row and OCML's exp measured faster than any variant with pinned coefficients.
     constexpr bool kTabExp = D <= 4;
     __shared__ double tab[kTabExp ? 64 : 1];
+    __shared__ __attribute__((aligned(16))) double ltab[512];        // (c, -log c) pairs of log_tab
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) ltab[k] = kLogTab[k];
     double ec[6], ec3 = 0.0;
     if constexpr (kTabExp) {
         if (threadIdx.x < 64) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
-        __syncthreads();
+    }
+    __syncthreads();
+    if constexpr (kTabExp) {
         static_for<6>([&](auto k) { ec[decltype(k)::value] = kExpTabC[decltype(k)::value]; });
         ec3 = ec[3];
         asm volatile("" : "+v"(ec3));
@@ -118,13 +146,37 @@ __global__ __launch_bounds__(256, (D > 12 ? 1 : GABO_PAIR_WAVES)) void spd_ai_pa
     if ((flags & GABO_SYMMETRIC) && j0 + (int64_t)(threadIdx.x | 63) < i0) return;
     const double* Gj = G + b * g_batch_stride + jc;
     double* ob = out + b * n1 * n2;
+    // d = 2: the lane's column (3 numbers) and its log-determinant term stay in registers; lane r of every wave holds the term of row i0 + r
+    Spd2Col col2;
+    double lw_lane = 0.0, tiny = 1e-290;
+    LogTabRegs lr2;
+    if constexpr (D == 2) {
+        lr2 = LogTabRegs::load();
+        asm volatile("" : "+s"(tiny));
+        col2.g00 = Gj[0];
+        col2.g10 = Gj[n2];
+        col2.g11 = Gj[2 * n2];
+        col2.lg = log_tab(col2.g00 * col2.g11, lr2, ltab);
+        int64_t ir = i0 + (threadIdx.x & 63);
+        ir = ir < n1 ? ir : n1 - 1;
+        const double* Wr = Winv + b * w_batch_stride + ir * T;
+        lw_lane = log_tab(Wr[0] * Wr[2], lr2, ltab);
+    }
     for (int64_t i = i0; i < i1; ++i) {
         const double* W = Winv + b * w_batch_stride + i * T;
-        // Launder the column pointer so the 55 G loads are NOT hoisted out of the row loop: keeping G resident costs
-        // 110 VGPRs (one wave per SIMD less); re-reading it from L2 costs 28 KB per wave-row, which is noise here.
-        const double* Gp = Gj;
-        asm volatile("" : "+v"(Gp));
-        double s = ai_sumsq<D>(W, Gp, n2);
+        double s;
+        if constexpr (D == 2) {
+            const int lane = (int)(i - i0);
+            const double lw = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lw_lane), lane),
+                                               __builtin_amdgcn_readlane(__double2loint(lw_lane), lane));
+            s = ai_sumsq2(W, col2, lw, lr2, ltab, tiny);
+        } else {
+            // Launder the column pointer so the 55 G loads are NOT hoisted out of the row loop: keeping G resident costs
+            // 110 VGPRs (one wave per SIMD less); re-reading it from L2 costs 28 KB per wave-row, which is noise here.
+            const double* Gp = Gj;
+            asm volatile("" : "+v"(Gp));
+            s = ai_sumsq<D>(W, Gp, n2, ltab);
+        }
         double dist, val;
         if (mode == GABO_OUT_GAUSSIAN && !dist_out) {
             // exp(-beta sqrt(s + 1e-15)^2) (spd_utils_torch.py:120, kernels_spd.py:94-98) without the square root: sqrt(x)^2 = x to an ulp,
