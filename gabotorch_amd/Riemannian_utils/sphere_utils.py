@@ -29,3 +29,20 @@ def sphere_distance(x, y):
     X, _ = _rows(x)
     Y, _ = _rows(y)
     return ops.sphere_manifold_op(_lib.GABO_SPH_DIST, torch.as_tensor(X), torch.as_tensor(Y)).numpy()
+
+
+def rotation_from_sphere_points(x, y):
+    """The rotation matrix that carries the unit vector x to the unit vector y along their geodesic (sphere_utils.py:168-202; used by
+    `examples/bo_sphere/constrained_benchmark_examples/gabo_sphere_inequality_constraints.py`).  It acts in span{x, y} only: with t = <x, y>
+    (clipped to [-1, 1]), s = sin(acos t) and e the unit vector of that plane orthogonal to y,
+        R = I + s (y e^T - e y^T) + (t - 1) (y y^T + e e^T)
+    (Jung, Dryden & Marron 2012, appendix).  Host-side numpy: one d x d matrix per call, not on the device path (the batched, matrix-free
+    form the nested-sphere kernels use is `sphere_utils_torch.rotate_along_geodesic`)."""
+    x = np.asarray(x, dtype=float).reshape(-1)
+    y = np.asarray(y, dtype=float).reshape(-1)
+    t = float(np.clip(x @ y, -1.0, 1.0))
+    e = x - t * y
+    e = e / np.linalg.norm(e)
+    s = np.sqrt((1.0 - t) * (1.0 + t))
+    ye = np.outer(y, e)
+    return np.eye(x.size) + s * (ye - ye.T) + (t - 1.0) * (np.outer(y, y) + np.outer(e, e))
