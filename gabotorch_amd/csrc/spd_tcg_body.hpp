@@ -78,13 +78,28 @@ static __device__ double unwhitened_sum(const double* L, const double* rw, int d
 // lds: 5 d^2 doubles.  Every thread of the (one-wave) block calls it.
 static __device__ void tcg_begin(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ gc,
                                  const double* __restrict__ fc, bool active, double delta_tr, const TcgWs& w, int64_t i, int64_t R,
-                                 int d, int C, int* __restrict__ status, double* lds) {
+                                 int d, int C, int* __restrict__ status, double* lds, bool reuse = false) {
     const int dd = d * d;
     double* M0 = lds;          // L
     double* M1 = M0 + dd;      // W = L^-1
     double* M2 = M1 + dd;
     double* M3 = M2 + dd;
     double* M4 = M3 + dd;
+    double* gw = w.g_w + i * dd;
+    double* rw = w.r_w + i * dd;
+    if (reuse) {
+        // x and g are those of the previous call for this restart (its proposal was rejected): the factor, the whitened gradient,
+        // L^-1 1 and the whitened constraint gradients in the workspace are still valid - only the iteration state is reset.  M0 / M3
+        // are refilled with the stored values, so everything below sees bit for bit what the full path computes.
+        lds_load(w.chol + i * dd, M0, d);
+        lds_load(gw, M3, d);
+        for (int e = threadIdx.x; e < dd; e += 64) {
+            rw[e] = M3[e];
+            w.eta_w[i * dd + e] = 0.0;
+            w.heta_w[i * dd + e] = 0.0;
+        }
+        __syncthreads();
+    } else {
     lds_load(x, M0, d);
     lds_symmetrize(M0, M4, d);
     bool ok = lds_cholesky(M0, d);
@@ -96,8 +111,6 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
     lds_symmetrize(M2, M4, d);
     lds_congruence(M1, M2, M3, M4, d);      // g~ = W g W^T
     lds_symmetrize(M3, M4, d);
-    double* gw = w.g_w + i * dd;
-    double* rw = w.r_w + i * dd;
     for (int e = threadIdx.x; e < dd; e += 64) {
         w.chol[i * dd + e] = M0[e];
         gw[e] = M3[e];
@@ -111,6 +124,7 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
         w.w_ones[i * d + r] = s;
     }
     __syncthreads();
+    }
     const double rr = wave_dot(M3, M3, dd);
     const double usum = unwhitened_sum(M0, M3, d);
     const bool zero_sum = usum == 0.0;
@@ -121,7 +135,7 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
         zr = __builtin_fma(z, M3[e], zr);
     }
     zr = wave_sum(zr);
-    for (int k = 0; gc != nullptr && k < C; ++k) {
+    for (int k = 0; gc != nullptr && !reuse && k < C; ++k) {
         lds_load(gc + ((int64_t)k * R + i) * dd, M2, d);
         lds_symmetrize(M2, M4, d);
         lds_congruence(M1, M2, M3, M4, d);
@@ -138,7 +152,7 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
         sc[SC_Z_R] = zr;
         sc[SC_MODEL] = 0.0;
         sc[SC_NORM_R0] = __builtin_sqrt(rr > 0.0 ? rr : 0.0);
-        sc[SC_C_FD] = 0.0;
+        if (!reuse) sc[SC_C_FD] = 0.0;        // (reuse: the first FD point's c may be kept together with its E, see tr_propose_body)
         w.stop[i] = TCG_MAX_INNER_ITER;
         w.running[i] = active ? 1 : 0;
         for (int k = 0; k < C; ++k) { if (fc != nullptr) w.fc[i * C + k] = fc[i * C + k]; w.fcg_pe[i * C + k] = 0.0; }

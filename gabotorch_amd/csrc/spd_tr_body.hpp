@@ -111,13 +111,15 @@ __device__ __forceinline__ bool builtin_infeasible(const double* __restrict__ xp
 
 // tCG + proposal + acquisition at the proposal for restart i (one wave).  gc/fc: host-evaluated constraints, or null with
 // `builtin` set (then the wave evaluates them itself).  mats: 5 D^2 + kJacobiScratch doubles of LDS, dyn: 3 n doubles.
+// Returns the number of tCG iterations it ran.  x_unchanged: the previous call for this restart (same launch) ended in a rejected proposal;
+// fd0_kept: ... and ran exactly ONE tCG iteration, so the first FD point's E = expm(c delta~) and c are still in the workspace.
 template <int D, int METRIC>
-__device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta,
+__device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta,
                                                 const double* __restrict__ gc, const double* __restrict__ fc, const AcqParams& P,
                                                 const TrWs& t, double* __restrict__ x_prop, int64_t i, int64_t R, int C, int neq,
                                                 double delta_cons, double theta, double kappa, int mininner, int maxinner,
                                                 AcqLds<D>& acq, double* mats, double* dyn, int* __restrict__ status,
-                                                const BuiltinCons* builtin, bool x_unchanged = false) {
+                                                const BuiltinCons* builtin, bool x_unchanged = false, bool fd0_kept = false) {
     constexpr int T = tri_size(D);
     constexpr int dd = D * D;
     const TcgWs& w = t.tcg;
@@ -125,7 +127,7 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
     double* egfd = t.eg_fd + i * T;
     double* F = t.F + i * T * P.n;
     GABO_TICK(1);
-    tcg_begin(x, g, gc, fc, true, delta, w, i, R, D, C, status, mats);
+    tcg_begin(x, g, gc, fc, true, delta, w, i, R, D, C, status, mats, x_unchanged);
     __syncthreads();
     GABO_TICK(2);
     if constexpr (D <= 8) {
@@ -138,8 +140,12 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
     }
     double* egfd0 = t.eg_fd0 + i * T;
     GABO_TICK(3);
+    int inner = 0;
     for (int it = 0; it < maxinner; ++it) {
-        tcg_fd_point(w, i, D, xfd, mats);
+        ++inner;
+        // (same x, g, preconditioner => same first direction, same FD point: when nothing has overwritten E and c since, skip it - the
+        // acquisition gradient there is kept too, below)
+        if (!(it == 0 && x_unchanged && fd0_kept)) tcg_fd_point(w, i, D, xfd, mats);
         __syncthreads();
         GABO_TICK(4);
         // tCG restarts from eta = 0 with the same x, g and preconditioner after a rejected proposal (only the radius changed), so its
@@ -210,6 +216,7 @@ __device__ __forceinline__ void tr_propose_body(const double* __restrict__ x, co
     GABO_TICK(7);
     acq_eval_any<D, METRIC>(xpm, P, t.fx_prop + i, t.eg_prop + i * T, F, acq, dyn, status, i + w.index_base);
     GABO_TICK(8);
+    return inner;
 }
 
 // The exact-GP factors L^-1 and L^-T (n^2 doubles each) are read by every acquisition evaluation of the launch - two triangular
@@ -367,9 +374,10 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     }
     double* xp = t.xp_mat + iw * dd;
     bool cons_fresh = false;          // wave-uniform: the constraints in the workspace belong to the current x
+    int last_inner = 0;               // tCG iterations of the previous trust-region iteration
     for (;;) {
-        tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, iw, Rw, C, 0, delta_cons, theta, kappa,
-                                   mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh);
+        last_inner = tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, iw, Rw, C, 0, delta_cons, theta,
+                                                kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1);
         __syncthreads();
         const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B) : false;
         bool accepted = false;
