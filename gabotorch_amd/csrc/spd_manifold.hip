@@ -13,6 +13,7 @@
 // eigen-decomposition is cyclic Jacobi with the rotation applied in parallel over the row/column index.
 #include "gabo_device.hpp"
 #include "lds_linalg.hpp"
+#include "spd_eigvec.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
@@ -189,6 +190,87 @@ __global__ __launch_bounds__(64) void spd_project_kernel(const double* __restric
         }
         y[i * dv + e] = (k == 0) ? s1 : 0.5 * (kSqrt2 * s1 + kSqrt2 * s2);
     }
+}
+
+// The same projection for a small latent dimension (the nested kernels: dl = 2, 3, 4) as ONE matrix-vector product in Mandel coordinates:
+// y = P x with P (dl_vec x D_vec) a function of W only,
+//     y_ab = sum_r W_ra W_rb X_rr + sum_{r > c} (W_ra W_cb + W_ca W_rb) X_rc,     X_rc = x_k / sqrt2 (r != c),   y_e = sqrt2 y_ab (a != b).
+// Every block builds P in LDS (D_vec x dl_vec products: less than one matrix's worth of the old kernel's work), then each WAVE does one
+// matrix per step: a coalesced read of the D_vec entries, dl_vec FMAs per entry and dl_vec wave reductions.  The wave-per-matrix LDS
+// kernel above spends its time in barrier phases whose last one keeps dl_vec of 64 lanes busy: rocprofv3 kernel time at n = 4096, D = 20 -> 2:
+// 9 us against 14 (a 4096-element fill kernel takes 3-5 us on the same box).
+template <int DL>
+__global__ __launch_bounds__(256) void spd_project_small_kernel(const double* __restrict__ x, const double* __restrict__ w,
+                                                                double* __restrict__ y, int64_t n, int D) {
+    constexpr int DV = DL * (DL + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int Dv = D * (D + 1) / 2;
+    double* Wl = lds;                 // D x DL
+    double* P = Wl + D * DL;          // DV x Dv
+    for (int e = threadIdx.x; e < D * DL; e += blockDim.x) Wl[e] = w[e];
+    __syncthreads();
+    for (int t = threadIdx.x; t < D * D; t += blockDim.x) {
+        const int r = t / D, c = t - r * D;
+        if (r < c) continue;
+        const int k = r - c, idx = mandel_pos(D, r, c);      // input entry (r, c) sits on sub-diagonal k of the Mandel order
+        static_for<DL>([&](auto kk) {
+            constexpr int ko = decltype(kk)::value;
+            static_for<DL - ko>([&](auto bb) {
+                constexpr int b = decltype(bb)::value, a = b + ko;
+                double coef;
+                if (k == 0) coef = Wl[r * DL + a] * Wl[r * DL + b] * (ko == 0 ? 1.0 : kSqrt2);
+                else coef = __builtin_fma(Wl[r * DL + a], Wl[c * DL + b], Wl[c * DL + a] * Wl[r * DL + b]) * (ko == 0 ? kInvSqrt2 : 1.0);
+                P[mandel_pos(DL, a, b) * Dv + idx] = coef;
+            });
+        });
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    for (int64_t i = (int64_t)blockIdx.x * waves + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * waves) {
+        double acc[DV];
+        static_for<DV>([&](auto e) { acc[decltype(e)::value] = 0.0; });
+        const double* xi = x + i * Dv;
+        for (int k = lane; k < Dv; k += 64) {
+            const double xk = xi[k];
+            static_for<DV>([&](auto e) { acc[decltype(e)::value] = __builtin_fma(P[decltype(e)::value * Dv + k], xk, acc[decltype(e)::value]); });
+        }
+        static_for<DV>([&](auto e) {
+            double s = acc[decltype(e)::value];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == decltype(e)::value) y[i * DV + decltype(e)::value] = s;
+        });
+    }
+}
+
+// logm for d <= 8, one LANE per matrix: register eigen-decomposition (spd_eigvec.hpp), y = V diag(log lambda) V^T.  The wave-per-matrix
+// LDS Jacobi kernel below takes 13 us for 4096 2 x 2 matrices (64 blocks' worth of useful lanes spread over 4096 blocks).
+template <int D>
+__global__ __launch_bounds__(64) void spd_logm_mandel_reg_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+    constexpr int T = tri_size(D);
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t ic = i < n ? i : n - 1;             // every lane of the wave runs the eigen-solver (it leaves its stages by a wave vote)
+    double m[T], lam[D], v[D * D];
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<r + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const double e = x[ic * T + mandel_pos(D, r, c)];
+            m[tri(r, c)] = (r == c) ? e : e / kSqrt2;
+        });
+    });
+    sym_eig_reg<D>(m, lam, v);
+    double lg[D];
+    static_for<D>([&](auto kk) { lg[decltype(kk)::value] = log(lam[decltype(kk)::value]); });     // (OCML: NaN for a non-positive eigenvalue, like the reference)
+    if (i >= n) return;
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<r + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            double s = 0.0;
+            static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; s = __builtin_fma(v[r * D + k] * lg[k], v[c * D + k], s); });
+            y[i * T + mandel_pos(D, r, c)] = (r == c) ? s : kSqrt2 * s;
+        });
+    });
 }
 
 // logm of SPD matrices, Mandel in -> Mandel out (the per-point part of SpdLogEuclideanGaussianKernel, kernels_spd.py:289-305)
@@ -524,6 +606,16 @@ int gabo_spd_project(const double* x_mandel, const double* w, double* y_mandel, 
     if (D < 1 || D > 64 || dl < 1 || dl > 64) return GABO_ERR_DIM;
     if (n == 0) return GABO_OK;
     if (!x_mandel || !w || !y_mandel || n > 0x7fffffffLL) return GABO_ERR_ARG;
+    const size_t small_lds = (size_t)(D * dl + (dl * (dl + 1) / 2) * (D * (D + 1) / 2)) * sizeof(double);
+    if (dl >= 2 && dl <= 4 && small_lds <= 48 * 1024) {
+        const int64_t blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;      // one matrix per wave (two per wave measured slower: 10.6 vs 9.0 us at n = 4096)
+        switch (dl) {
+            case 2: hipLaunchKernelGGL(gabo::spd_project_small_kernel<2>, dim3((unsigned)blocks), dim3(256), small_lds, (hipStream_t)stream, x_mandel, w, y_mandel, n, D); break;
+            case 3: hipLaunchKernelGGL(gabo::spd_project_small_kernel<3>, dim3((unsigned)blocks), dim3(256), small_lds, (hipStream_t)stream, x_mandel, w, y_mandel, n, D); break;
+            default: hipLaunchKernelGGL(gabo::spd_project_small_kernel<4>, dim3((unsigned)blocks), dim3(256), small_lds, (hipStream_t)stream, x_mandel, w, y_mandel, n, D); break;
+        }
+        return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+    }
     size_t lds = (size_t)(D * D + 2 * D * dl) * sizeof(double);
     hipLaunchKernelGGL(gabo::spd_project_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel, w, y_mandel, n, D, dl);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
@@ -534,6 +626,14 @@ int gabo_spd_logm_mandel(const double* x_mandel, double* y_mandel, int64_t n, in
     if (d < 1 || d > 32) return GABO_ERR_DIM;
     if (n == 0) return GABO_OK;
     if (!x_mandel || !y_mandel || n > 0x7fffffffLL) return GABO_ERR_ARG;
+    if (d >= 2 && d <= 8) {
+        const unsigned blocks = (unsigned)((n + 63) / 64);
+#define GABO_CASE(DD) \
+    case DD: hipLaunchKernelGGL(gabo::spd_logm_mandel_reg_kernel<DD>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, x_mandel, y_mandel, n); break;
+        switch (d) { GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8) }
+#undef GABO_CASE
+        return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+    }
     size_t lds = (size_t)(3 * d * d + gabo::kJacobiScratch) * sizeof(double);
     hipLaunchKernelGGL(gabo::spd_logm_mandel_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel, y_mandel, n, d);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;

@@ -14,7 +14,8 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 run_sweep("cuda:0", num_restarts=R, batched_rand=True, builtin_constraint=True)
 buf = (ctypes.c_longlong * 8192)()
 lib.gabo_debug_clocks(buf, 4096)                       # drop the warm-up run
-run_sweep("cuda:0", num_restarts=R, batched_rand=True, builtin_constraint=True, maxiter=6)
+MAXIT = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+run_sweep("cuda:0", num_restarts=R, batched_rand=True, builtin_constraint=True, maxiter=MAXIT)
 n = lib.gabo_debug_clocks(buf, 4096)
 ev = [(int(buf[2 * k]), int(buf[2 * k + 1])) for k in range(n)]
 names = {1: "iteration start", 2: "tcg_begin", 3: "builtin constraints", 4: "tcg_fd_point", 5: "acq_eval at the FD point", 6: "tcg_step",
@@ -40,3 +41,20 @@ for k, v in tot.items():
 its = [t for tag, t in ev if tag == 1]
 if len(its) > 1:
     print("cycles per trust-region iteration:", [its[k + 1] - its[k] for k in range(len(its) - 1)])
+
+# per-iteration phase table (outer tags only): which phases ran and what they cost
+rows, cur, last = [], {}, None
+for tag, t in ev:
+    if tag >= 100:
+        continue
+    if tag == 1 and cur:
+        rows.append(cur)
+        cur = {}
+    if last is not None and tag != 1:
+        cur[tag] = cur.get(tag, 0) + (t - last)
+    last = t
+if cur:
+    rows.append(cur)
+print("iteration: " + "  ".join(f"{names[k][:14]:>14s}" for k in range(2, 10)))
+for k, r in enumerate(rows[:40]):
+    print(f"{k:9d}: " + "  ".join(f"{r.get(tag, 0):14d}" for tag in range(2, 10)) + f"   total {sum(r.values())}")
