@@ -197,8 +197,8 @@ __global__ __launch_bounds__(64) void spd_project_kernel(const double* __restric
 //     y_ab = sum_r W_ra W_rb X_rr + sum_{r > c} (W_ra W_cb + W_ca W_rb) X_rc,     X_rc = x_k / sqrt2 (r != c),   y_e = sqrt2 y_ab (a != b).
 // Every block builds P in LDS (D_vec x dl_vec products: less than one matrix's worth of the old kernel's work), then each WAVE does one
 // matrix per step: a coalesced read of the D_vec entries, dl_vec FMAs per entry and dl_vec wave reductions.  The wave-per-matrix LDS
-// kernel above spends its time in barrier phases whose last one keeps dl_vec of 64 lanes busy: rocprofv3 kernel time at n = 4096, D = 20 -> 2:
-// 9 us against 14 (a 4096-element fill kernel takes 3-5 us on the same box).
+// kernel above spends its time in barrier phases whose last one keeps dl_vec of 64 lanes busy: at n = 4096, D = 20 -> 2 a call
+// went from 16.5 to 13.6 us host-timed (most of it launch overhead); rocprofv3 kernel time of this kernel 9 us (a 4096-element fill kernel: 3-5 us).
 template <int DL>
 __global__ __launch_bounds__(256) void spd_project_small_kernel(const double* __restrict__ x, const double* __restrict__ w,
                                                                 double* __restrict__ y, int64_t n, int D) {
