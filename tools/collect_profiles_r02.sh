@@ -8,25 +8,28 @@ OUT=$R/gpurun_out/profiles_r02
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench command itself under the kernel trace (same flags as the graded run minus the CPU baseline and the side reports)
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --no-symmetric > $OUT/bench_under_rocprof.json 2> /tmp/pk.err
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --no-symmetric > $OUT/bench_under_rocprof.json 2> /tmp/pk.err
 cp /tmp/pk/bench_kernel_stats.csv $OUT/bench_kernel_stats.csv
 cp /tmp/pk/bench_kernel_trace.csv $OUT/bench_kernel_trace.csv
 # 2. PMC passes on the Gram launch (FETCH_SIZE and WRITE_SIZE cannot share a pass; the mirror kernel of the symmetric build is the
 #    known-byte-count calibration of FETCH_SIZE)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python $R/tools/prof_spd.py 4096 10 sym 2 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf2 -o f -- python $R/tools/prof_spd.py 4096 10 x 2 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw2 -o w -- python $R/tools/prof_spd.py 4096 10 x 2 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE --output-format csv -d /tmp/ps -o s -- python $R/tools/prof_spd.py 4096 10 x 2 > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python $R/tools/prof_spd.py 4096 10 sym 2 > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf2 -o f -- python $R/tools/prof_spd.py 4096 10 x 2 > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw2 -o w -- python $R/tools/prof_spd.py 4096 10 x 2 > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE --output-format csv -d /tmp/ps -o s -- python $R/tools/prof_spd.py 4096 10 x 2 > /dev/null 2>&1
 # 3. sphere Gram: kernel trace + instruction counters + write bytes
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/psph -o sph -- python $R/tools/prof_sphere.py > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/psph -o sph -- python $R/tools/prof_sphere.py > /dev/null 2>&1
 cp /tmp/psph/sph_kernel_stats.csv $OUT/sphere_kernel_stats.csv
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d /tmp/pss -o s -- python $R/tools/prof_sphere.py > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/psw -o w -- python $R/tools/prof_sphere.py > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d /tmp/pss -o s -- python $R/tools/prof_sphere.py > /dev/null 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/psw -o w -- python $R/tools/prof_sphere.py > /dev/null 2>&1
 # 4. backward (d = 10, N = 4096) and the config-4 sweep under the kernel trace
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python $R/tools/ab_backward.py prof > $OUT/backward.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python $R/tools/ab_backward.py prof > $OUT/backward.log 2>&1
 cp /tmp/pb/b_kernel_stats.csv $OUT/backward_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/psweep -o sw -- python $R/tools/sweep_bench.py 512 > $OUT/sweep.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/psweep -o sw -- python $R/tools/sweep_bench.py 512 > $OUT/sweep.log 2>&1
 cp /tmp/psweep/sw_kernel_stats.csv $OUT/sweep_kernel_stats.csv
+# 5. the config-5 pieces (projection, nested Gram, logm, log-Euclidean Gram) under the kernel trace
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc5 -o c5 -- python $R/tools/config5_profile.py > /dev/null 2>&1
+cp /tmp/pc5/c5_kernel_stats.csv $OUT/config5_kernel_stats.csv
 python - <<PY
 import csv, collections, json
 def load(path):

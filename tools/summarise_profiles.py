@@ -15,7 +15,7 @@ RND = "r02"
 
 def main():
     for name in ("bench_kernel_stats.csv", "sphere_kernel_stats.csv", "backward_kernel_stats.csv", "sweep_kernel_stats.csv",
-                 "bench_under_rocprof.json", "pmc_raw.json", "sweep.log", "backward.log"):
+                 "config5_kernel_stats.csv", "bench_under_rocprof.json", "pmc_raw.json", "sweep.log", "backward.log"):
         p = os.path.join(SRC, name)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(DST, f"{RND}_{name}"))
