@@ -1,0 +1,36 @@
+"""The (c, -log c) table of the table-assisted fp64 log of the SPD Gram kernels (gabotorch_amd/csrc/gabo_log_tab.hpp) is the output of its
+generator, and the routine built on it (modelled in numpy, same operation order as `log_tab` in gabo_device.hpp) is accurate to 2 ulp."""
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools.sim import gen_log_table as glt  # noqa: E402
+
+
+def test_committed_table_equals_generator_output():
+    text = open(os.path.join(ROOT, "gabotorch_amd", "csrc", "gabo_log_tab.hpp")).read()
+    body = text[text.index("{", text.index("kLogTab")) + 1:text.rindex("};")]
+    vals = [float.fromhex(v) for v in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+", body)]
+    assert len(vals) == 512
+    c, l = glt.table()
+    np.testing.assert_array_equal(np.array(vals[0::2]), c)
+    np.testing.assert_array_equal(np.array(vals[1::2]), l)
+    assert c[127] == 1.0 and l[127] == 0.0 and c[128] == 1.0 and l[128] == 0.0          # log is exact-in-form around 1
+
+
+def test_table_log_model_accuracy():
+    c, l = glt.table()
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.exp(rng.uniform(-30, 30, 200000)), 1.0 + rng.uniform(-2e-2, 2e-2, 100000), 1.0 + rng.uniform(-1e-9, 1e-9, 20000),
+                        np.array([1.0, 0.5, 2.0, 2.0 ** -0.5, 2.0 ** 0.5, 1e-300, 1e300, np.nextafter(1.0, 0.0), np.nextafter(1.0, 2.0)])])
+    got, rmax = glt.log_tab_model(x, c, l)
+    want = np.log(x.astype(np.longdouble))
+    err = np.abs(got - want.astype(np.float64))
+    ulp = np.spacing(np.abs(want.astype(np.float64)))
+    assert rmax < 2.0 ** -7
+    assert float(np.max(err / np.maximum(ulp, 5e-324))) <= 2.0
+    assert glt.log_tab_model(np.array([1.0]), c, l)[0][0] == 0.0
