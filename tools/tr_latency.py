@@ -15,7 +15,7 @@ ops.set_error_checking(False)
 np.random.seed(1); torch.manual_seed(1)
 opts = {"device": dev, "batched_rand": True}
 res = {}
-for R in (64, 512, 2048, 8192):
+for R in (64, 512, 2048, 4096, 8192):
     ic = mo.gen_batch_initial_conditions_manifold(acq, man, None, None, R, 4 * R, torch.float64, opts, to_vec)
     x = to_mat(ic[:, 0]).contiguous()
     fused = FusedAcquisition.build(acq, to_vec, torch.device(dev))
