@@ -210,8 +210,13 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
     // tile shape: 64..256 columns per block, `rows` rows per block; keep >= ~8 blocks per CU when the problem allows
     int threads = n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
     int64_t col_blocks = (n2 + threads - 1) / threads;
-    int rows = 16;
-    while (rows > 1 && col_blocks * ((n1 + rows - 1) / rows) * batch < 4096) rows >>= 1;
+    // rows per block: a wave's prologue (log table into LDS, for d = 2 the per-point log terms) is amortised over them; d = 2 pairs are ~75
+    // instructions; measured at N = 4096, d = 2: 64 / 32 / 16 / 8 / 4 rows per block = 66 / 61 / 59 / 63 / 71 us
+#ifndef GABO_PAIR_ROWS_D2
+#define GABO_PAIR_ROWS_D2 16
+#endif
+    int rows = D == 2 ? GABO_PAIR_ROWS_D2 : 16;
+    while (rows > 1 && col_blocks * ((n1 + rows - 1) / rows) * batch < (rows > 16 ? 1024 : 4096)) rows >>= 1;
     int64_t row_chunks = (n1 + rows - 1) / rows;
     int64_t sym_tiles = 0;
     if (flags & GABO_SYMMETRIC) {
