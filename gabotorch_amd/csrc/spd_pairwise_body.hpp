@@ -208,14 +208,23 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
     double* G = ws + b1 * n1 * T;
     launch_spd_prep<D>(x1, x2, W, G, b1, b2, n1, n2, s1, s2, status, st);
     // tile shape: 64..256 columns per block, `rows` rows per block; keep >= ~8 blocks per CU when the problem allows
-    int threads = n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
+    // (d = 10, N = 4096, 8 rows: 256 / 128 / 64 threads per block = 2.57 / 2.56 / 2.55 ms - one-wave blocks leave the shortest tail)
+#ifndef GABO_PAIR_THREADS
+#define GABO_PAIR_THREADS (D >= 9 ? 64 : 256)
+#endif
+    int threads = n2 >= 256 ? GABO_PAIR_THREADS : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
     int64_t col_blocks = (n2 + threads - 1) / threads;
     // rows per block: a wave's prologue (log table into LDS, for d = 2 the per-point log terms) is amortised over them; d = 2 pairs are ~75
     // instructions; measured at N = 4096, d = 2: 64 / 32 / 16 / 8 / 4 rows per block = 66 / 61 / 59 / 63 / 71 us
 #ifndef GABO_PAIR_ROWS_D2
 #define GABO_PAIR_ROWS_D2 16
 #endif
-    int rows = D == 2 ? GABO_PAIR_ROWS_D2 : 16;
+    // d = 10, N = 4096 (blocks vary in duration with their pairs' QL iteration counts: smaller blocks balance the tail, larger ones amortise
+    // the prologue): 64 / 32 / 16 / 8 / 4 / 2 rows = 2.72 / 2.64 / 2.60 / 2.58 / 2.58 / 2.62 ms
+#ifndef GABO_PAIR_ROWS
+#define GABO_PAIR_ROWS (D >= 9 ? 8 : 16)
+#endif
+    int rows = D == 2 ? GABO_PAIR_ROWS_D2 : GABO_PAIR_ROWS;
     while (rows > 1 && col_blocks * ((n1 + rows - 1) / rows) * batch < (rows > 16 ? 1024 : 4096)) rows >>= 1;
     int64_t row_chunks = (n1 + rows - 1) / rows;
     int64_t sym_tiles = 0;

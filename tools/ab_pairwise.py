@@ -10,7 +10,7 @@ from oracle import spd as ospd, sphere as osph
 tag = sys.argv[1] if len(sys.argv) > 1 else os.path.basename(_lib.LIB_PATH)
 ops.set_error_checking(False)
 n, beta = 4096, 0.2 + float(np.log(2.0))
-for d in (5, 10, 12):
+for d in tuple(int(v) for v in os.environ.get("GABO_AB_DIMS", "5,10,12").split(",")):
     xs = spd_set(n, d)
     x = torch.tensor(xs, device="cuda")
     ms = min(timeit(lambda: ops.spd_ai_pairwise(x, x, beta=beta), iters=10, warm=3) for _ in range(3))
@@ -19,6 +19,8 @@ for d in (5, 10, 12):
     want = ospd.affine_invariant_distance(m1, m2)
     err = float(np.max(np.abs(dist ** 2 - want ** 2) / want ** 2))
     print(f"[{tag}] SPD d={d} N={n}: {ms:.3f} ms  {n*n/ms*1e3:.3e} pairs/s   max rel err of d^2 vs oracle {err:.2e}")
+if os.environ.get("GABO_AB_DIMS"):
+    sys.exit(0)
 rng = np.random.default_rng(0)
 s = rng.standard_normal((n, 10)); s /= np.linalg.norm(s, axis=1, keepdims=True)
 st = torch.tensor(s, device="cuda")
