@@ -208,9 +208,9 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
     double* G = ws + b1 * n1 * T;
     launch_spd_prep<D>(x1, x2, W, G, b1, b2, n1, n2, s1, s2, status, st);
     // tile shape: 64..256 columns per block, `rows` rows per block; keep >= ~8 blocks per CU when the problem allows
-    // (d = 10, N = 4096, 8 rows: 256 / 128 / 64 threads per block = 2.57 / 2.56 / 2.55 ms - one-wave blocks leave the shortest tail)
+    // (d = 10, N = 4096, 8 rows: 256 / 128 / 64 threads per block = 2.57 / 2.56 / 2.55 ms - one-wave blocks: a block's slots are not held until its slowest wave ends; d = 7: 1.25 -> 1.23 ms, d <= 5: no gain)
 #ifndef GABO_PAIR_THREADS
-#define GABO_PAIR_THREADS (D >= 9 ? 64 : 256)
+#define GABO_PAIR_THREADS (D >= 7 ? 64 : 256)
 #endif
     int threads = n2 >= 256 ? GABO_PAIR_THREADS : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
     int64_t col_blocks = (n2 + threads - 1) / threads;
