@@ -22,12 +22,24 @@ __device__ __forceinline__ void tridiagonalize(double (&m)[tri_size(D)], double 
         double sig = 0.0;
         static_for<n - 1>([&](auto t) { double x = m[tri(k + 2 + decltype(t)::value, k)]; sig = __builtin_fma(x, x, sig); });
         double nn = __builtin_fma(alpha, alpha, sig);
+#ifdef GABO_TRIDIAG_ZERO_GUARDS       /* A/B: the round-1 form (two compares and four selects per column for the all-zero column) */
         double nrm = sqrt_pos(nn);
         double u[n];
         u[0] = alpha + copysign_d(nrm, alpha);
         static_for<n - 1>([&](auto t) { u[decltype(t)::value + 1] = m[tri(k + 2 + decltype(t)::value, k)]; });
         double hh = __builtin_fma(__builtin_fabs(alpha), nrm, nn);
         double inv_hh = hh == 0.0 ? 0.0 : rcp(hh);
+#else
+        // A column that is already zero needs no special case when |x| is floored at 1e-145 and hh is taken as |u|^2 / 2 from the u
+        // actually used: then u = 1e-145 e0 and H = I - 2 e0 e0^T, a reflection - still an orthogonal similarity, and every
+        // intermediate stays finite for |A| < 1e160 (p = A u / hh is 2 A[:, 0] 1e145).  e2[k] below keeps the unfloored value.
+        double nrm = sqrt_nz(max_raw(nn, 1e-290));
+        double u[n];
+        u[0] = alpha + copysign_d(nrm, alpha);
+        static_for<n - 1>([&](auto t) { u[decltype(t)::value + 1] = m[tri(k + 2 + decltype(t)::value, k)]; });
+        double ihalf = rcp(__builtin_fma(u[0], u[0], sig));       // 1 / |u|^2
+        double inv_hh = ihalf + ihalf;
+#endif
         // p = A22 u / hh   (A22 symmetric, lower stored)
         double p[n];
         static_for<n>([&](auto rr) {
