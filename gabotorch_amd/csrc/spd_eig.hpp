@@ -178,7 +178,13 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
             const bool done0 = e2[l] <= eps2 * __builtin_fabs(dg[l] * dg[l + 1]);
             // the WAVE leaves stage l when its last lane has deflated e2[l] (a per-lane `break` would keep the wave here until every lane
             // had finished its look-ahead work too, at stage l's longer sweep extent)
+#ifdef GABO_QL_BALLOT_NOT
             if (__builtin_amdgcn_ballot_w64(!done0) == 0) break;
+#else
+            // (every active lane done: the mask of `done0` against the mask of the active lanes - one vector compare; `ballot(!done0)`
+            // costs a second, NaN-aware one)
+            if (__builtin_amdgcn_ballot_w64(done0) == __builtin_amdgcn_ballot_w64(true)) break;
+#endif
             const double e2l = done0 ? 0.0 : e2[l];        // (e2[l] itself is rewritten at the end of the sweep: s p = 0 for these lanes)
             double sa = dg[l], sb = dg[l + 1], se = e2l;
             bool idle = false;
