@@ -113,6 +113,19 @@ __device__ __forceinline__ double floor_p(double p) {
     return r;
 #endif
 }
+// a * b + 1e-150: the same guarantee folded into the multiplication that produces p (p = a b >= 0 here) - one instruction instead of
+// the product and the maximum.  The addend only registers when p < 1e-134.
+__device__ __forceinline__ double mul_floor_p(double a, double b) {
+#if defined(GABO_QL_GAMMA_NUDGE)
+    return a * b;
+#elif defined(GABO_QL_FLOOR_MAX)          /* A/B: product, then v_max_f64 */
+    return floor_p(a * b);
+#else
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(1e-150));
+    return r;
+#endif
+}
 __device__ __forceinline__ double nonzero(double g) {
 #ifdef GABO_QL_GAMMA_NUDGE
     double a = __builtin_fmax(__builtin_fabs(g), 1e-75);
@@ -206,7 +219,7 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
             double root = sqrt_shift(__builtin_fma(delta, delta, se));
             double sigma = sa - copysign_d(root - __builtin_fabs(delta), delta);
             double gamma = nonzero(dg[D - 1] - sigma);
-            double p = floor_p(gamma * gamma);
+            double p = mul_floor_p(gamma, gamma);
             double s = 0.0;
 #ifdef GABO_QL_FORM1
             double c = 1.0;
@@ -244,7 +257,7 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
                 double f = __builtin_fma(p, al - sigma, -(bb * oldgam));
                 gamma = ir * f;
                 dg[i + 1] = oldgam + (al - gamma);
-                p = floor_p((f * t) * f);
+                p = mul_floor_p(f * t, f);
 #endif
             });
             e2[l] = s * p;
