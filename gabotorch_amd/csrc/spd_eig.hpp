@@ -90,8 +90,14 @@ __device__ __forceinline__ void tridiagonalize(double (&m)[tri_size(D)], double 
 // sqrt(x), x > 0, to ~2^-46: hardware seed + one coupled Goldschmidt step.  For the Wilkinson SHIFT only - its accuracy sets the
 // convergence rate of a sweep, never the eigenvalues (three instructions less per sweep than sqrt_nz).
 __device__ __forceinline__ double sqrt_shift(double x) {
-#ifdef GABO_QL_EXACT_SHIFT_SQRT
+#if defined(GABO_QL_EXACT_SHIFT_SQRT)
     return sqrt_nz(x);
+#elif !defined(GABO_QL_SHIFT_SQRT_GOLDSCHMIDT)
+    // the bare hardware seed (2^-24): the shift only sets the convergence RATE - a shift that misses the Wilkinson value by 1e-7 of the root
+    // still contracts e^2 by ~1e-14 per sweep once the cubic phase has brought it there.  Wave-level simulation (tools/sim/ql_lookahead_sim.py
+    // with the root perturbed): 124.3 -> 125.7 sweep steps and 19.3 -> 19.7 sweeps per wave for 4 instructions less per sweep; measured
+    // 2.455 -> 2.440 ms.  (-DGABO_QL_SHIFT_SQRT_GOLDSCHMIDT: seed + one coupled step, 2^-46.)
+    return x * __builtin_amdgcn_rsq(x);
 #else
     double y = __builtin_amdgcn_rsq(x);
     double g = x * y;
