@@ -107,7 +107,7 @@ __device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[
         for (int it = 0; it < 60; ++it) {
             const double s01 = __builtin_fabs(dg[l]) + __builtin_fabs(dg[l + 1]);
             const bool done0 = e[l] * e[l] <= eps2 * (s01 * s01);
-            if (__builtin_amdgcn_ballot_w64(!done0) == 0) break;          // the wave leaves the stage with its last lane
+            if (__builtin_amdgcn_ballot_w64(done0) == __builtin_amdgcn_ballot_w64(true)) break;   // the wave leaves the stage with its last lane (one compare: see spd_eig.hpp)
             const double el = done0 ? 0.0 : e[l];
             double sa = dg[l], sb = dg[l + 1], se = el;
             bool idle = done0;
