@@ -87,8 +87,14 @@ __device__ __forceinline__ double finish(double dist, double beta, int mode) {
 }
 
 // 1-D grid, block id -> (batch, row chunk of `rows` rows, column group of blockDim.x columns), column group fastest
+#ifndef GABO_PAIR_TWO_WAVE_MAX_DIM
+// Two waves per SIMD (256 VGPRs) up to d = 14: at d = 13 / 14 the compiler spills 10 / 24 doubles per lane to scratch, which costs far less than
+// the halved issue rate of a lone wave (8.5 instead of 4.5 cycles per instruction): N = 4096 Gram 5.92 -> 4.33 ms and 7.77 -> 5.87 ms; d = 15: 9.9 ->
+// 9.8, d = 16: 11.9 -> 14.1 (one wave per SIMD from 15 on).
+#define GABO_PAIR_TWO_WAVE_MAX_DIM 14
+#endif
 template <int D>
-__global__ __launch_bounds__(256, (D > 12 ? 1 : GABO_PAIR_WAVES)) void spd_ai_pairwise_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
+__global__ __launch_bounds__(256, (D > GABO_PAIR_TWO_WAVE_MAX_DIM ? 1 : GABO_PAIR_WAVES)) void spd_ai_pairwise_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
                                                               double* __restrict__ out, double* __restrict__ dist_out,
                                                               int64_t n1, int64_t n2,
                                                               int64_t w_batch_stride, int64_t g_batch_stride, int rows,

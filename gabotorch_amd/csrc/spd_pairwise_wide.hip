@@ -1,4 +1,4 @@
-// SPD pairwise Gram, dimensions 13..16: the same register-resident lane-per-pair kernels, budgeted for ONE wave per SIMD (512 VGPRs
+// SPD pairwise Gram, dimensions 13..16: the same register-resident lane-per-pair kernels, two waves per SIMD up to d = 14, ONE above (512 VGPRs
 // per lane); d = 17..20 in spd_pairwise_wide2.hip / spd_pairwise_wide3.hip.  Instantiations only; templates in spd_pairwise_body.hpp.
 #include "spd_pairwise_body.hpp"
 
