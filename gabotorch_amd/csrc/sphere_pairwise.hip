@@ -135,10 +135,11 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
         const int64_t ia = (i0 + li < n1) ? i0 + li : n1 - 1;
         const double* pa = x1 + b * s1 + ia * dim;
         sph_v4d acc[4];
-        static_for<4>([&](auto tt) { acc[decltype(tt)::value] = sph_v4d{0.0, 0.0, 0.0, 0.0}; });
         {
-            // K is padded to a multiple of 4 with zeros: the padded lanes load the last valid entry (no divergent load) and drop it
-            for (int k0 = 0; k0 < dim; k0 += 4) {
+            // K is padded to a multiple of 4 with zeros: the padded lanes load the last valid entry (no divergent load) and zero their x1
+            // operand - the x2 operand can stay (it is a genuine, finite entry of the same vector, or that column is NaN anyway), which
+            // saves its four selects per step.  The first step starts from a literal zero accumulator (no per-chunk clearing moves).
+            auto kstep = [&](int k0, auto first) {
                 const int kk = k0 + lk;
                 const bool ok = kk < dim;
                 const int kc = ok ? kk : dim - 1;
@@ -148,9 +149,12 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
                 a = ok ? a : 0.0;
                 static_for<4>([&](auto tt) {
                     constexpr int t = decltype(tt)::value;
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ok ? bv[t] : 0.0, acc[t], 0, 0, 0);
+                    if constexpr (decltype(first)::value) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[t], sph_v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+                    else acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[t], acc[t], 0, 0, 0);
                 });
-            }
+            };
+            kstep(0, std::true_type{});
+            for (int k0 = 4; k0 < dim; k0 += 4) kstep(k0, std::false_type{});
         }
         // Stores: wave-uniform base of the chunk + a 32-bit lane offset.  A chunk that lies fully inside the matrix (and, with
         // x1 is x2, fully above the diagonal) stores without predicates.
