@@ -46,6 +46,7 @@ struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar
     }
 };
 
+template <bool CLAMP>
 __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss& g, const double* __restrict__ tab) {
     double z = max_raw(__builtin_fma(-0.5, __builtin_fabs(ip), 0.5), g.c[7]);
     double w = g.w_top;
@@ -53,7 +54,7 @@ __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss&
     double q = (z * w) * w;                                   // (phi / 2)^2
     double th = __builtin_fma(-2.0, sqrt_nz(q), g.c[6]);      // pi - phi
     double x = (ip < 0.0) ? (th * th) * g.neg_beta : q * g.neg_4beta;
-    return exp_neg_tab(x, g.c, g.e_top, tab);
+    return exp_neg_tab<CLAMP>(x, g.c, g.e_top, tab);      // x >= -beta (pi^2 + eps): no clamp needed unless beta is astronomically large
 }
 
 template <int MODE>
@@ -77,7 +78,7 @@ typedef double sph_v4d __attribute__((ext_vector_type(4)));
 // What binds the kernel is fp64 issue: tools/ubench_mfma_f64.hip shows the f64 matrix pipe and the f64 vector pipe do NOT overlap
 // on gfx950 (MFMA alone 77.8, v_fma_f64 alone 60.6, both together 64.9 TFLOP/s), so per output the MFMA costs 12 issue slots beside
 // the ~56 instructions of the epilogue; what the MFMA form removes is the LDS staging and its index arithmetic.
-template <int MODE>
+template <int MODE, bool BIGBETA = true>
 __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks, int chunks,
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
 #if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 1     /* development probe: MFMA + stores only */
         return ip;
 #endif
-        if constexpr (MODE == GABO_OUT_GAUSSIAN) return sphere_gauss_finish(ip, g, tab);
+        if constexpr (MODE == GABO_OUT_GAUSSIAN) return sphere_gauss_finish<BIGBETA>(ip, g, tab);
         else return sphere_finish<MODE>(ip, beta, mt);
     };
     const uint32_t loff = (uint32_t)lk * (uint32_t)n2 + (uint32_t)li;
@@ -292,12 +293,13 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
         }
         if (tiles_x > 0x7fffffffLL) return GABO_ERR_ARG;
         const int mode = flags & GABO_OUT_MASK;
-#define GABO_SPH_LAUNCH(M)                                                                                                         \
-    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M>), dim3((unsigned)tiles_x, (unsigned)batch), dim3(threads), 0, st, x1, x2, out, \
+#define GABO_SPH_LAUNCH(M, BIG)                                                                                                    \
+    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M, BIG>), dim3((unsigned)tiles_x, (unsigned)batch), dim3(threads), 0, st, x1, x2, out, \
                        n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, chunks, beta, flags)
-        if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE);
-        else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE);
-        else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN);
+        if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE, true);
+        else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE, true);
+        else if (beta > -1000.0 && beta < 1000.0) GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, false);   // |x| < 1e4: inside the exact range of the argument reduction, no clamp
+        else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, true);
 #undef GABO_SPH_LAUNCH
         if (flags & GABO_SYMMETRIC) {
             int tiles = (int)((n1 + 31) / 32);
