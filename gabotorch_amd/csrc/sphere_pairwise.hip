@@ -16,11 +16,12 @@ namespace gabo {
 // With z = (1 - |c|) / 2 = sin^2(phi / 2), phi = acos|c|:  phi = 2 asin(sqrt z) = 2 sqrt(z) w(z),  w(z) = asin(sqrt z) / sqrt z analytic
 // on z in [0, 1/2] (degree-17 polynomial, 2.2e-16, tools/sim/fit_sphere_poly.py).  Then
 //     c >= 0:  theta^2 = phi^2 = 4 z w^2                      (no square root, no acos)
-//     c <  0:  theta   = pi - phi = pi - 2 sqrt(z w^2)
+//     c <  0:  theta   = pi - phi = pi - 2 sqrt(z w^2),  theta^2 = phi^2 - 4 pi sqrt(z w^2) + pi^2   (one FMA on top of the c >= 0 value)
 // and the reference's clamp of c to [-1+1e-15, 1-1e-15] (sphere_utils_torch.py:53) is the lower bound z >= kSphZmin.
 // exp(x), x <= 0: x = (64 e + j) ln2/64 + r, |r| <= ln2/128: 2^e * 2^(j/64) (LDS table) * (1 + r + ... + r^5/120)  (3.5e-17).
 // Against exp(-beta arccos(clip(c))^2) in 60-digit arithmetic this is as accurate as the numpy oracle itself (4e-15 vs 3e-15
-// relative at beta = 1.3: the conditioning of exp(-beta theta^2), not the approximation).
+// relative at beta = 1.3: the conditioning of exp(-beta theta^2), not the approximation); the three-term form of theta^2 for c < 0
+// costs up to two more bits there (7e-15 against the oracle).
 constexpr int kSphWDeg = 17;
 __constant__ double kSphW[kSphWDeg + 1] = {
     0.9999999999999999, 0.166666666666762, 0.07499999997954958, 0.04464285887635292, 0.03038186720347429, 0.022374245713577247,
@@ -31,7 +32,7 @@ __constant__ double kSphC[8] = {0.010830424695086549, 1.162596423439437e-12, 92.
                                 3.14159265358979311600e+00, 4.996003610813204e-16};
 
 struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar cache, lives in SGPRs
-    double w[kSphWDeg + 1], c[8], neg_beta, neg_4beta;
+    double w[kSphWDeg + 1], c[8], neg_beta, neg_4beta, four_pi_beta, neg_beta_pi2;
     double w_top, e_top;          // the leading coefficient of each Horner chain in a VGPR: a VALU instruction reads ONE scalar operand
     __device__ __forceinline__ static SphGauss load(double beta) {
         SphGauss t;
@@ -39,6 +40,8 @@ struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar
         static_for<8>([&](auto i) { t.c[decltype(i)::value] = kSphC[decltype(i)::value]; });
         t.neg_beta = -beta;
         t.neg_4beta = -4.0 * beta;
+        t.four_pi_beta = 4.0 * t.c[6] * beta;
+        t.neg_beta_pi2 = -beta * (t.c[6] * t.c[6]);
         t.w_top = t.w[kSphWDeg];
         t.e_top = t.c[3];
         asm volatile("" : "+v"(t.w_top), "+v"(t.e_top));
@@ -52,8 +55,9 @@ __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss&
     double w = g.w_top;
     static_for<kSphWDeg>([&](auto i) { w = __builtin_fma(w, z, g.w[kSphWDeg - 1 - decltype(i)::value]); });
     double q = (z * w) * w;                                   // (phi / 2)^2
-    double th = __builtin_fma(-2.0, sqrt_nz(q), g.c[6]);      // pi - phi
-    double x = (ip < 0.0) ? (th * th) * g.neg_beta : q * g.neg_4beta;
+    double x = q * g.neg_4beta;                               // c >= 0: -beta phi^2
+    // c < 0: -beta (pi - phi)^2 = -beta phi^2 + 4 pi beta sqrt(q) - beta pi^2 (theta >= pi/2 here: the sum loses at most two bits)
+    if (ip < 0.0) x = __builtin_fma(sqrt_nz(q), g.four_pi_beta, x + g.neg_beta_pi2);
     return exp_neg_tab<CLAMP>(x, g.c, g.e_top, tab);      // x >= -beta (pi^2 + eps): no clamp needed unless beta is astronomically large
 }
 
