@@ -248,6 +248,23 @@ __device__ __forceinline__ double exp_neg_tab(double x, const C& c, double c3_vg
     return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 6);   // (v_ldexp_f64 also does the gradual underflow)
 }
 
+// The same with a 256-entry table (2 KB of LDS): |r| <= ln2/512, so exp(r) - 1 = r (1 + r/2 + r^2/6 + r^3/24) leaves r^5/120 = 3.8e-17 - one FMA
+// less per value.  c: [0] ln2/256 head (k c[0] exact for |k| < 2^19), [1] tail, [2] 256/ln2, [3] 1/6; `c24_vgpr`: 1/24 in a VGPR.
+// tools/sim/gen_exp_table.py generates the table and models the routine (2.2e-16 on [-40, 0]).
+template <bool CLAMP = true, class C>
+__device__ __forceinline__ double exp_neg_tab256(double x, const C& c, double c24_vgpr, const double* __restrict__ tab) {
+    if constexpr (CLAMP) x = max_raw(x, -800.0);
+    double k = __builtin_rint(x * c[2]);
+    double r = __builtin_fma(-k, c[1], __builtin_fma(-k, c[0], x));
+    double p = __builtin_fma(r, c24_vgpr, c[3]);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;                                                 // exp(r) - 1
+    int ki = (int)k;
+    double t = tab[ki & 255];
+    return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 8);
+}
+
 // log(x) for positive normal x (eigenvalues of an SPD matrix), fdlibm e_log.c scheme: x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt 2,
 // s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2)), R a degree-7 minimax polynomial split into even and odd halves.
 // OCML's log is 98 VALU instructions (double-double arithmetic); this is ~35 at 1 ulp.  Coefficients pinned in registers.

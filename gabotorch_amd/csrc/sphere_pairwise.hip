@@ -7,6 +7,7 @@
 // everything but the stores 44 us, the kernel 47-50 us - bound by fp64 issue of the acos^2 + exp epilogue, not by the write.
 #include "gabo_device.hpp"
 #include "gabo_mirror.hpp"
+#include "gabo_exp_tab256.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
@@ -18,7 +19,7 @@ namespace gabo {
 //     c >= 0:  theta^2 = phi^2 = 4 z w^2                      (no square root, no acos)
 //     c <  0:  theta   = pi - phi = pi - 2 sqrt(z w^2),  theta^2 = phi^2 - 4 pi sqrt(z w^2) + pi^2   (one FMA on top of the c >= 0 value)
 // and the reference's clamp of c to [-1+1e-15, 1-1e-15] (sphere_utils_torch.py:53) is the lower bound z >= kSphZmin.
-// exp(x), x <= 0: x = (64 e + j) ln2/64 + r, |r| <= ln2/128: 2^e * 2^(j/64) (LDS table) * (1 + r + ... + r^5/120)  (3.5e-17).
+// exp(x), x <= 0: x = (256 e + j) ln2/256 + r, |r| <= ln2/512: 2^e * 2^(j/256) (LDS table) * (1 + r + ... + r^4/24)  (3.8e-17).
 // Against exp(-beta arccos(clip(c))^2) in 60-digit arithmetic this is as accurate as the numpy oracle itself (4e-15 vs 3e-15
 // relative at beta = 1.3: the conditioning of exp(-beta theta^2), not the approximation); the three-term form of theta^2 for c < 0
 // costs up to two more bits there (7e-15 against the oracle).
@@ -27,8 +28,8 @@ __constant__ double kSphW[kSphWDeg + 1] = {
     0.9999999999999999, 0.166666666666762, 0.07499999997954958, 0.04464285887635292, 0.03038186720347429, 0.022374245713577247,
     0.01731559954431618, 0.014425198539078435, 0.007444628520337835, 0.03675841815436629, -0.12408231204352452, 0.4950065878219168,
     -1.3361380175788322, 2.733327968715509, -3.974232006625551, 3.9651660247789384, -2.4213345116985456, 0.7052735073244606};
-// [6] pi, [7] z of the clamp (the exp constants [0..5] and the 2^(j/64) table are shared: gabo_device.hpp, kExpTabC / kExp2Tab)
-__constant__ double kSphC[8] = {0.010830424695086549, 1.162596423439437e-12, 92.33248261689366, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0,
+// [0..3] exp_neg_tab256: ln2/256 head and tail, 256/ln2, 1/6; [4] 1/24 (kept in a VGPR); [5] unused; [6] pi, [7] z of the clamp
+__constant__ double kSphC[8] = {0.010830424695086549 / 4, 1.162596423439437e-12 / 4, 92.33248261689366 * 4, 1.0 / 6.0, 1.0 / 24.0, 0.0,
                                 3.14159265358979311600e+00, 4.996003610813204e-16};
 
 struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar cache, lives in SGPRs
@@ -43,7 +44,7 @@ struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar
         t.four_pi_beta = 4.0 * t.c[6] * beta;
         t.neg_beta_pi2 = -beta * (t.c[6] * t.c[6]);
         t.w_top = t.w[kSphWDeg];
-        t.e_top = t.c[3];
+        t.e_top = t.c[4];
         asm volatile("" : "+v"(t.w_top), "+v"(t.e_top));
         return t;
     }
@@ -58,7 +59,7 @@ __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss&
     double x = q * g.neg_4beta;                               // c >= 0: -beta phi^2
     // c < 0: -beta (pi - phi)^2 = -beta phi^2 + 4 pi beta sqrt(q) - beta pi^2 (theta >= pi/2 here: the sum loses at most two bits)
     if (ip < 0.0) x = __builtin_fma(sqrt_nz(q), g.four_pi_beta, x + g.neg_beta_pi2);
-    return exp_neg_tab<CLAMP>(x, g.c, g.e_top, tab);      // x >= -beta (pi^2 + eps): no clamp needed unless beta is astronomically large
+    return exp_neg_tab256<CLAMP>(x, g.c, g.e_top, tab);      // x >= -beta (pi^2 + eps): no clamp needed unless beta is astronomically large
 }
 
 template <int MODE>
@@ -87,10 +88,10 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks, int chunks,
                                                               double beta, int flags) {
-    __shared__ double tab[64];
+    __shared__ double tab[256];
     const int tid = threadIdx.x;
     if constexpr (MODE == GABO_OUT_GAUSSIAN) {
-        if (tid < 64) tab[tid] = kExp2Tab[tid];
+        for (int k = tid; k < 256; k += blockDim.x) tab[k] = kExp2Tab256[k];
         __syncthreads();
     }
     const int rows = 16 * chunks;

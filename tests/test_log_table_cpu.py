@@ -34,3 +34,17 @@ def test_table_log_model_accuracy():
     assert rmax < 2.0 ** -7
     assert float(np.max(err / np.maximum(ulp, 5e-324))) <= 2.0
     assert glt.log_tab_model(np.array([1.0]), c, l)[0][0] == 0.0
+
+
+def test_exp_table_equals_generator_output_and_model_accuracy():
+    from tools.sim import gen_exp_table as get
+    text = open(os.path.join(ROOT, "gabotorch_amd", "csrc", "gabo_exp_tab256.hpp")).read()
+    body = text[text.index("{", text.index("kExp2Tab256")) + 1:text.rindex("};")]
+    vals = np.array([float.fromhex(v) for v in re.findall(r"0x[0-9a-f.]+p[+-]?\d+", body)])
+    tab = get.table()
+    np.testing.assert_array_equal(vals, tab)
+    assert tab[0] == 1.0 and abs(tab[128] - 2.0 ** 0.5) < 3e-16
+    x = -np.random.default_rng(2).uniform(0, 40, 200000)
+    got = get.exp_model(x, tab)
+    want = np.exp(x.astype(np.longdouble)).astype(np.float64)
+    assert float(np.max(np.abs(got - want) / want)) < 4.5e-16
