@@ -465,7 +465,7 @@ def main():
                                                 "frac": pairs_per_step * 8.04 / (sph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "model": "8.04 algorithmic B/pair (one fp64 output + amortised operand reads)"},
                                    "max_abs_err_vs_oracle_block": sph_err}
-            line["roofline_sphere"] = dict(line["sphere_gram"]["roofline"], kernel="gabo::sphere_pairwise_kernel<0, false>", kernel_ms=sph_ms,
+            line["roofline_sphere"] = dict(line["sphere_gram"]["roofline"], kernel="gabo::sphere_pairwise_kernel<0, true>", kernel_ms=sph_ms,
                                            binding_resource="fp64 issue of the acos^2 + exp epilogue (MFMA + stores alone: 26 us)")
             line["config5"] = config5_pieces(device)
             # the step before the sweep in a BO iteration: surrogate fit (fit_gpytorch_model), 50 observations on S^5_++

@@ -265,6 +265,22 @@ __device__ __forceinline__ double exp_neg_tab256(double x, const C& c, double c2
     return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 8);
 }
 
+// exp(-y) for y >= 0 given as y (the caller's quantity is naturally positive: beta d^2): the same routine with the sign folded into the
+// constants - c[2] = -256/ln2, and -y enters the reduction as a negated FMA addend - so that no instruction is spent on the negation.
+template <bool CLAMP = true, class C>
+__device__ __forceinline__ double exp_of_minus_tab256(double y, const C& c, double c24_vgpr, const double* __restrict__ tab) {
+    if constexpr (CLAMP) y = __builtin_fmin(y, 800.0);
+    double k = __builtin_rint(y * c[2]);                       // c[2] < 0: k = rint(-y 256 / ln2)
+    double r = __builtin_fma(-k, c[1], __builtin_fma(-k, c[0], -y));
+    double p = __builtin_fma(r, c24_vgpr, c[3]);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;
+    int ki = (int)k;
+    double t = tab[ki & 255];
+    return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 8);
+}
+
 // log(x) for positive normal x (eigenvalues of an SPD matrix), fdlibm e_log.c scheme: x = 2^k (1+f), sqrt(1/2) <= 1+f < sqrt 2,
 // s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2)), R a degree-7 minimax polynomial split into even and odd halves.
 // OCML's log is 98 VALU instructions (double-double arithmetic); this is ~35 at 1 ulp.  Coefficients pinned in registers.

@@ -32,17 +32,29 @@ __constant__ double kSphW[kSphWDeg + 1] = {
 __constant__ double kSphC[8] = {0.010830424695086549 / 4, 1.162596423439437e-12 / 4, 92.33248261689366 * 4, 1.0 / 6.0, 1.0 / 24.0, 0.0,
                                 3.14159265358979311600e+00, 4.996003610813204e-16};
 
+// Host-prepared coefficients of the usual case (0 < beta < 1000, `SCALED`): w~_k = 2 sqrt(beta) w_k, so that z w~(z)^2 IS beta phi^2 and the
+// multiplication by 4 beta disappears from the epilogue (passed by value: kernel arguments are read through the scalar cache like the
+// __constant__ table).  `a`, `b`: 2 pi sqrt(beta) and beta pi^2 of the c < 0 branch.
+struct SphPoly {
+    double w[kSphWDeg + 1], a, b;
+};
+static const double kSphWHost[kSphWDeg + 1] = {
+    0.9999999999999999, 0.166666666666762, 0.07499999997954958, 0.04464285887635292, 0.03038186720347429, 0.022374245713577247,
+    0.01731559954431618, 0.014425198539078435, 0.007444628520337835, 0.03675841815436629, -0.12408231204352452, 0.4950065878219168,
+    -1.3361380175788322, 2.733327968715509, -3.974232006625551, 3.9651660247789384, -2.4213345116985456, 0.7052735073244606};
+
 struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar cache, lives in SGPRs
-    double w[kSphWDeg + 1], c[8], neg_beta, neg_4beta, four_pi_beta, neg_beta_pi2;
+    double w[kSphWDeg + 1], c[8], neg_4beta, four_pi_beta, neg_beta_pi2;
     double w_top, e_top;          // the leading coefficient of each Horner chain in a VGPR: a VALU instruction reads ONE scalar operand
-    __device__ __forceinline__ static SphGauss load(double beta) {
+    template <bool SCALED>
+    __device__ __forceinline__ static SphGauss load(double beta, const SphPoly& P) {
         SphGauss t;
-        static_for<kSphWDeg + 1>([&](auto i) { t.w[decltype(i)::value] = kSphW[decltype(i)::value]; });
+        static_for<kSphWDeg + 1>([&](auto i) { t.w[decltype(i)::value] = SCALED ? P.w[decltype(i)::value] : kSphW[decltype(i)::value]; });
         static_for<8>([&](auto i) { t.c[decltype(i)::value] = kSphC[decltype(i)::value]; });
-        t.neg_beta = -beta;
+        if constexpr (SCALED) t.c[2] = -t.c[2];           // exp_of_minus_tab256
         t.neg_4beta = -4.0 * beta;
-        t.four_pi_beta = 4.0 * t.c[6] * beta;
-        t.neg_beta_pi2 = -beta * (t.c[6] * t.c[6]);
+        t.four_pi_beta = SCALED ? -P.a : 4.0 * t.c[6] * beta;
+        t.neg_beta_pi2 = SCALED ? P.b : -beta * (t.c[6] * t.c[6]);
         t.w_top = t.w[kSphWDeg];
         t.e_top = t.c[4];
         asm volatile("" : "+v"(t.w_top), "+v"(t.e_top));
@@ -50,16 +62,24 @@ struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar
     }
 };
 
-template <bool CLAMP>
+// SCALED = false: any beta (unscaled coefficients, exp with its argument clamp)
+template <bool SCALED>
 __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss& g, const double* __restrict__ tab) {
     double z = max_raw(__builtin_fma(-0.5, __builtin_fabs(ip), 0.5), g.c[7]);
     double w = g.w_top;
     static_for<kSphWDeg>([&](auto i) { w = __builtin_fma(w, z, g.w[kSphWDeg - 1 - decltype(i)::value]); });
-    double q = (z * w) * w;                                   // (phi / 2)^2
-    double x = q * g.neg_4beta;                               // c >= 0: -beta phi^2
-    // c < 0: -beta (pi - phi)^2 = -beta phi^2 + 4 pi beta sqrt(q) - beta pi^2 (theta >= pi/2 here: the sum loses at most two bits)
-    if (ip < 0.0) x = __builtin_fma(sqrt_nz(q), g.four_pi_beta, x + g.neg_beta_pi2);
-    return exp_neg_tab256<CLAMP>(x, g.c, g.e_top, tab);      // x >= -beta (pi^2 + eps): no clamp needed unless beta is astronomically large
+    double q = (z * w) * w;                                   // (phi / 2)^2, times 4 beta when SCALED
+    if constexpr (SCALED) {
+        // y = beta theta^2 >= 0:  c >= 0: beta phi^2 = q;  c < 0: beta (pi - phi)^2 = q - 2 pi sqrt(beta) sqrt(q) + beta pi^2
+        // (theta >= pi/2 there: the sum loses at most two bits).  y <= beta (pi^2 + eps) < 1e4: no clamp in the exp.
+        double y = q;
+        if (ip < 0.0) y = __builtin_fma(sqrt_nz(q), g.four_pi_beta, q + g.neg_beta_pi2);
+        return exp_of_minus_tab256<false>(y, g.c, g.e_top, tab);
+    } else {
+        double x = q * g.neg_4beta;                           // c >= 0: -beta phi^2
+        if (ip < 0.0) x = __builtin_fma(sqrt_nz(q), g.four_pi_beta, x + g.neg_beta_pi2);
+        return exp_neg_tab256<true>(x, g.c, g.e_top, tab);
+    }
 }
 
 template <int MODE>
@@ -83,11 +103,11 @@ typedef double sph_v4d __attribute__((ext_vector_type(4)));
 // What binds the kernel is fp64 issue: tools/ubench_mfma_f64.hip shows the f64 matrix pipe and the f64 vector pipe do NOT overlap
 // on gfx950 (MFMA alone 77.8, v_fma_f64 alone 60.6, both together 64.9 TFLOP/s), so per output the MFMA costs 12 issue slots beside
 // the ~56 instructions of the epilogue; what the MFMA form removes is the LDS staging and its index arithmetic.
-template <int MODE, bool BIGBETA = true>
+template <int MODE, bool SCALED = false>
 __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks, int chunks,
-                                                              double beta, int flags) {
+                                                              double beta, int flags, SphPoly poly) {
     __shared__ double tab[256];
     const int tid = threadIdx.x;
     if constexpr (MODE == GABO_OUT_GAUSSIAN) {
@@ -123,13 +143,13 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
     });
     SphGauss g;
     MathRegs mt;
-    if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load(beta);
+    if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load<SCALED>(beta, poly);
     else mt = MathRegs::load();
     auto finish = [&](double ip) {
 #if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 1     /* development probe: MFMA + stores only */
         return ip;
 #endif
-        if constexpr (MODE == GABO_OUT_GAUSSIAN) return sphere_gauss_finish<BIGBETA>(ip, g, tab);
+        if constexpr (MODE == GABO_OUT_GAUSSIAN) return sphere_gauss_finish<SCALED>(ip, g, tab);
         else return sphere_finish<MODE>(ip, beta, mt);
     };
     const uint32_t loff = (uint32_t)lk * (uint32_t)n2 + (uint32_t)li;
@@ -298,13 +318,21 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
         }
         if (tiles_x > 0x7fffffffLL) return GABO_ERR_ARG;
         const int mode = flags & GABO_OUT_MASK;
-#define GABO_SPH_LAUNCH(M, BIG)                                                                                                    \
-    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M, BIG>), dim3((unsigned)tiles_x, (unsigned)batch), dim3(threads), 0, st, x1, x2, out, \
-                       n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, chunks, beta, flags)
-        if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE, true);
-        else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE, true);
-        else if (beta > -1000.0 && beta < 1000.0) GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, false);   // |x| < 1e4: inside the exact range of the argument reduction, no clamp
-        else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, true);
+        gabo::SphPoly poly = {};
+        const bool scaled = mode == GABO_OUT_GAUSSIAN && beta > 1e-30 && beta < 1000.0;     // the usual case (see SphPoly)
+        if (scaled) {
+            const double sc = 2.0 * sqrt(beta), pi = 3.14159265358979311600e+00;
+            for (int k = 0; k <= gabo::kSphWDeg; ++k) poly.w[k] = gabo::kSphWHost[k] * sc;
+            poly.a = pi * sc;
+            poly.b = beta * (pi * pi);
+        }
+#define GABO_SPH_LAUNCH(M, SC)                                                                                                     \
+    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M, SC>), dim3((unsigned)tiles_x, (unsigned)batch), dim3(threads), 0, st, x1, x2, out, \
+                       n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, chunks, beta, flags, poly)
+        if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE, false);
+        else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE, false);
+        else if (scaled) GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, true);
+        else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, false);
 #undef GABO_SPH_LAUNCH
         if (flags & GABO_SYMMETRIC) {
             int tiles = (int)((n1 + 31) / 32);
