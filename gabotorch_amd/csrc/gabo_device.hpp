@@ -90,6 +90,17 @@ __device__ __forceinline__ double sqrt_nz(double x) {
     return __builtin_fma(dres, h, g);
 }
 
+// sqrt(x), x > 0, from the bare seed by ONE cubic correction: g0 = x y0, r = 1 - g0 y0 (|r| <= 2^-22), sqrt x = g0 (1 - r)^(-1/2) =
+// g0 (1 + r/2 + 3 r^2/8) + O(r^3): five instructions after the seed where the Goldschmidt form above takes seven; the rounding of g0 enters
+// r through the same FMA that uses it, so what is left is half an ulp of g0 and the final rounding.
+__device__ __forceinline__ double sqrt_nz_cubic(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double r = __builtin_fma(-g, y, 1.0);
+    double p = __builtin_fma(0.375, r, 0.5) * r;
+    return __builtin_fma(g, p, g);
+}
+
 // 1/sqrt(x), x > 0: e = 1 - x y0^2 (|e| <= 2^-23); y0 (1 + e/2 + 3e^2/8) leaves an e^3 error.
 __device__ __forceinline__ double rsqrt_nz(double x) {
     double y = __builtin_amdgcn_rsq(x);
@@ -277,6 +288,24 @@ __device__ __forceinline__ double exp_of_minus_tab256(double y, const C& c, doub
     p = __builtin_fma(p, r, 1.0);
     p = p * r;
     int ki = (int)k;
+    double t = tab[ki & 255];
+    return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 8);
+}
+
+// The same with the round-to-integer done by the FMA that scales the argument: km = y c[2] + 1.5 2^52 holds k = rint(y c[2]) in its low
+// mantissa bits (two's complement in the low word for |k| < 2^31), k = km - 1.5 2^52 is exact: v_fma + v_add replace v_mul + v_rndne + v_cvt_i32.
+// `magic_vgpr`: 1.5 2^52 in a VGPR (a VALU instruction reads one scalar operand, and c[2] is it).  |y| < 1e4 by construction: no clamp.
+template <class C>
+__device__ __forceinline__ double exp_of_minus_tab256_magic(double y, const C& c, double c24_vgpr, double magic_vgpr,
+                                                            const double* __restrict__ tab) {
+    double km = __builtin_fma(y, c[2], magic_vgpr);
+    double k = km - magic_vgpr;
+    double r = __builtin_fma(-k, c[1], __builtin_fma(-k, c[0], -y));
+    double p = __builtin_fma(r, c24_vgpr, c[3]);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;
+    int ki = __double2loint(km);
     double t = tab[ki & 255];
     return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 8);
 }

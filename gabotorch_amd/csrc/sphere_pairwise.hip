@@ -13,39 +13,39 @@
 namespace gabo {
 
 
-// ---- Gaussian epilogue: K = exp(-beta acos(c)^2) without acos, in ~55 fp64 VALU instructions ------------------------------
-// With z = (1 - |c|) / 2 = sin^2(phi / 2), phi = acos|c|:  phi = 2 asin(sqrt z) = 2 sqrt(z) w(z),  w(z) = asin(sqrt z) / sqrt z analytic
-// on z in [0, 1/2] (degree-17 polynomial, 2.2e-16, tools/sim/fit_sphere_poly.py).  Then
-//     c >= 0:  theta^2 = phi^2 = 4 z w^2                      (no square root, no acos)
-//     c <  0:  theta   = pi - phi = pi - 2 sqrt(z w^2),  theta^2 = phi^2 - 4 pi sqrt(z w^2) + pi^2   (one FMA on top of the c >= 0 value)
-// and the reference's clamp of c to [-1+1e-15, 1-1e-15] (sphere_utils_torch.py:53) is the lower bound z >= kSphZmin.
-// exp(x), x <= 0: x = (256 e + j) ln2/256 + r, |r| <= ln2/512: 2^e * 2^(j/256) (LDS table) * (1 + r + ... + r^4/24)  (3.8e-17).
-// Against exp(-beta arccos(clip(c))^2) in 60-digit arithmetic this is as accurate as the numpy oracle itself (4e-15 vs 3e-15
-// relative at beta = 1.3: the conditioning of exp(-beta theta^2), not the approximation); the three-term form of theta^2 for c < 0
-// costs up to two more bits there (7e-15 against the oracle).
+// ---- Gaussian epilogue: K = exp(-beta acos(c)^2) without acos, in ~45 fp64 VALU instructions ------------------------------
+// With z = (1 - |c|) / 2 = sin^2(phi / 2), phi = acos|c| = 2 asin(sqrt z):  (phi / 2)^2 = z P(z),  P(z) = asin(sqrt z)^2 / z analytic on
+// z in [0, 1/2] (degree-17 polynomial, 4.3e-16, tools/sim/fit_sphere_poly2.py - the same accuracy as squaring a 2.2e-16 fit of
+// asin(sqrt z) / sqrt z, one multiplication less).  Then
+//     c >= 0:  theta^2 = phi^2 = 4 z P                        (no square root, no acos)
+//     c <  0:  theta   = pi - phi,  theta^2 = phi^2 - 2 pi sqrt(phi^2) + pi^2   (the c >= 0 value + u t, u = 1, t = pi^2 - 2 pi phi)
+// with u = 0 / 1 built from the sign bit of c (two 32-bit instructions; a compare + 64-bit select costs 13 cycles), and the reference's clamp of c
+// to [-1+1e-15, 1-1e-15] (sphere_utils_torch.py:53) is the lower bound z >= kSphZmin.
+// exp(-y), y >= 0: -y = (256 e + j) ln2/256 + r, |r| <= ln2/512: 2^e * 2^(j/256) (LDS table) * (1 + r + ... + r^4/24)  (3.8e-17).
+// Against exp(-beta arccos(clip(c))^2) in 60-digit arithmetic this is as accurate as the numpy oracle itself (5e-15 vs 3.6e-15
+// relative at beta = 1.3: the conditioning of exp(-beta theta^2), not the approximation; model: fit_sphere_poly2.py model 17).
 constexpr int kSphWDeg = 17;
-__constant__ double kSphW[kSphWDeg + 1] = {
-    0.9999999999999999, 0.166666666666762, 0.07499999997954958, 0.04464285887635292, 0.03038186720347429, 0.022374245713577247,
-    0.01731559954431618, 0.014425198539078435, 0.007444628520337835, 0.03675841815436629, -0.12408231204352452, 0.4950065878219168,
-    -1.3361380175788322, 2.733327968715509, -3.974232006625551, 3.9651660247789384, -2.4213345116985456, 0.7052735073244606};
-// [0..3] exp_neg_tab256: ln2/256 head and tail, 256/ln2, 1/6; [4] 1/24 (kept in a VGPR); [5] unused; [6] pi, [7] z of the clamp
-__constant__ double kSphC[8] = {0.010830424695086549 / 4, 1.162596423439437e-12 / 4, 92.33248261689366 * 4, 1.0 / 6.0, 1.0 / 24.0, 0.0,
-                                3.14159265358979311600e+00, 4.996003610813204e-16};
+#define GABO_SPH_P_COEFFS                                                                                                              \
+    0.9999999999999998, 0.3333333333336239, 0.17777777771542846, 0.11428571957076086, 0.081269605781923, 0.061574423044727364,         \
+    0.048599889486560285, 0.04118585704847234, 0.02076148720348778, 0.11067290731777447, -0.3792345962104177, 1.5080499520508546,      \
+    -4.072870215777421, 8.329550989544446, -12.110677571177652, 12.080701723504074, -7.375868506853218, 2.1474532497337413
+__constant__ double kSphW[kSphWDeg + 1] = {GABO_SPH_P_COEFFS};
+// [0..3] exp_neg_tab256: ln2/256 head and tail, 256/ln2, 1/6; [4] 1/24 (kept in a VGPR); [5] 1.5 2^52 (VGPR); [6] pi, [7] z of the clamp
+__constant__ double kSphC[8] = {0.010830424695086549 / 4, 1.162596423439437e-12 / 4, 92.33248261689366 * 4, 1.0 / 6.0, 1.0 / 24.0,
+                                6755399441055744.0, 3.14159265358979311600e+00, 4.996003610813204e-16};
 
-// Host-prepared coefficients of the usual case (0 < beta < 1000, `SCALED`): w~_k = 2 sqrt(beta) w_k, so that z w~(z)^2 IS beta phi^2 and the
+// Host-prepared coefficients of the usual case (0 < beta < 1000, `SCALED`): P~_k = 4 beta P_k, so that z P~(z) IS beta phi^2 and the
 // multiplication by 4 beta disappears from the epilogue (passed by value: kernel arguments are read through the scalar cache like the
 // __constant__ table).  `a`, `b`: 2 pi sqrt(beta) and beta pi^2 of the c < 0 branch.
 struct SphPoly {
     double w[kSphWDeg + 1], a, b;
 };
-static const double kSphWHost[kSphWDeg + 1] = {
-    0.9999999999999999, 0.166666666666762, 0.07499999997954958, 0.04464285887635292, 0.03038186720347429, 0.022374245713577247,
-    0.01731559954431618, 0.014425198539078435, 0.007444628520337835, 0.03675841815436629, -0.12408231204352452, 0.4950065878219168,
-    -1.3361380175788322, 2.733327968715509, -3.974232006625551, 3.9651660247789384, -2.4213345116985456, 0.7052735073244606};
+static const double kSphWHost[kSphWDeg + 1] = {GABO_SPH_P_COEFFS};
 
 struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar cache, lives in SGPRs
     double w[kSphWDeg + 1], c[8], neg_4beta, four_pi_beta, neg_beta_pi2;
-    double w_top, e_top;          // the leading coefficient of each Horner chain in a VGPR: a VALU instruction reads ONE scalar operand
+    double w_top, e_top, magic, t0;   // VGPR copies: the leading coefficient of each Horner chain, 1.5 2^52 and the addend of `t` (a VALU
+                                      // instruction reads ONE scalar operand)
     template <bool SCALED>
     __device__ __forceinline__ static SphGauss load(double beta, const SphPoly& P) {
         SphGauss t;
@@ -57,10 +57,17 @@ struct SphGauss {     // wave-uniform: loaded once per kernel through the scalar
         t.neg_beta_pi2 = SCALED ? P.b : -beta * (t.c[6] * t.c[6]);
         t.w_top = t.w[kSphWDeg];
         t.e_top = t.c[4];
-        asm volatile("" : "+v"(t.w_top), "+v"(t.e_top));
+        t.magic = t.c[5];
+        t.t0 = t.neg_beta_pi2;
+        asm volatile("" : "+v"(t.w_top), "+v"(t.e_top), "+v"(t.magic), "+v"(t.t0));
         return t;
     }
 };
+
+// 1.0 where c < 0, 0.0 elsewhere, from the sign bit
+__device__ __forceinline__ double sph_neg_indicator(double ip) {
+    return __hiloint2double((__double2hiint(ip) >> 31) & 0x3FF00000, 0);
+}
 
 // SCALED = false: any beta (unscaled coefficients, exp with its argument clamp)
 template <bool SCALED>
@@ -68,17 +75,15 @@ __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss&
     double z = max_raw(__builtin_fma(-0.5, __builtin_fabs(ip), 0.5), g.c[7]);
     double w = g.w_top;
     static_for<kSphWDeg>([&](auto i) { w = __builtin_fma(w, z, g.w[kSphWDeg - 1 - decltype(i)::value]); });
-    double q = (z * w) * w;                                   // (phi / 2)^2, times 4 beta when SCALED
+    double q = z * w;                                         // (phi / 2)^2, times 4 beta when SCALED
+    // c < 0: t = +-(beta pi^2 - 2 pi beta phi) on top of the c >= 0 value (theta >= pi/2 there: the sum loses at most two bits)
+    double t = __builtin_fma(sqrt_nz_cubic(q), g.four_pi_beta, g.t0);
+    double u = sph_neg_indicator(ip);
     if constexpr (SCALED) {
-        // y = beta theta^2 >= 0:  c >= 0: beta phi^2 = q;  c < 0: beta (pi - phi)^2 = q - 2 pi sqrt(beta) sqrt(q) + beta pi^2
-        // (theta >= pi/2 there: the sum loses at most two bits).  y <= beta (pi^2 + eps) < 1e4: no clamp in the exp.
-        double y = q;
-        if (ip < 0.0) y = __builtin_fma(sqrt_nz(q), g.four_pi_beta, q + g.neg_beta_pi2);
-        return exp_of_minus_tab256<false>(y, g.c, g.e_top, tab);
+        // y = beta theta^2 >= 0; y <= beta (pi^2 + eps) < 1e4: no clamp in the exp
+        return exp_of_minus_tab256_magic(__builtin_fma(u, t, q), g.c, g.e_top, g.magic, tab);
     } else {
-        double x = q * g.neg_4beta;                           // c >= 0: -beta phi^2
-        if (ip < 0.0) x = __builtin_fma(sqrt_nz(q), g.four_pi_beta, x + g.neg_beta_pi2);
-        return exp_neg_tab256<true>(x, g.c, g.e_top, tab);
+        return exp_neg_tab256<true>(__builtin_fma(u, t, q * g.neg_4beta), g.c, g.e_top, tab);
     }
 }
 
@@ -103,17 +108,34 @@ typedef double sph_v4d __attribute__((ext_vector_type(4)));
 // What binds the kernel is fp64 issue: tools/ubench_mfma_f64.hip shows the f64 matrix pipe and the f64 vector pipe do NOT overlap
 // on gfx950 (MFMA alone 77.8, v_fma_f64 alone 60.6, both together 64.9 TFLOP/s), so per output the MFMA costs 12 issue slots beside
 // the ~56 instructions of the epilogue; what the MFMA form removes is the LDS staging and its index arithmetic.
-template <int MODE, bool SCALED = false>
-__global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
+// KS > 0: dim <= 4 KS <= 16 - the wave's x2 fragments stay in registers for all of its row chunks and the block's x1 rows are copied to
+// LDS once, so that the chunk loop contains NO global load.  This is about the memory counter, not about load latency: vmcnt retires in
+// issue order, loads and stores alike, so operand loads issued after a chunk's 16 stores cannot be waited for without also waiting for
+// those stores to be acknowledged by L2 - under a 3-5 TB/s write stream that stalled every wave once per chunk (measured at N = 16384:
+// 633 us with the loads behind the stores, 478 us with the stores removed, 369 us for the stores alone).  LDS reads count in lgkmcnt.
+// KS = 0: any dim, operands loaded per chunk.
+constexpr int kSphMaxChunks = 8;
+#ifdef GABO_SPH_CLOCKS     /* the timestamps must not cost the fourth wave per SIMD */
+#define GABO_SPH_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define GABO_SPH_BOUNDS __launch_bounds__(256)
+#endif
+template <int MODE, bool SCALED = false, int KS = 0, bool NT = false>
+__global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks, int chunks,
                                                               double beta, int flags, SphPoly poly) {
     __shared__ double tab[256];
+    __shared__ double xa[KS > 0 ? 16 * kSphMaxChunks * 4 * KS : 1];
     const int tid = threadIdx.x;
-    if constexpr (MODE == GABO_OUT_GAUSSIAN) {
-        for (int k = tid; k < 256; k += blockDim.x) tab[k] = kExp2Tab256[k];
-        __syncthreads();
-    }
+    SphGauss g;       // requested first: the scalar loads of the coefficients travel together with the kernel arguments
+    MathRegs mt;
+    if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load<SCALED>(beta, poly);
+    else mt = MathRegs::load();
+#ifdef GABO_SPH_CLOCKS    /* development: per-wave timestamps (100 MHz) into the output buffer; build with GABO_SPH_PROBE=2 (no result stores) */
+    const uint64_t clk_start = __builtin_amdgcn_s_memrealtime();
+    const uint64_t cyc_start = __builtin_amdgcn_s_memtime();
+#endif
     const int rows = 16 * chunks;
     uint32_t cg, rc;
     if (flags & GABO_SYMMETRIC) {       // x1 is x2: only tiles touching the upper triangle exist (see spd_pairwise.hip)
@@ -132,8 +154,7 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
     }
     const int64_t b = blockIdx.y;
     const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int64_t j0 = (int64_t)cg * blockDim.x + (tid & ~63);       // first column of this wave
-    if (j0 >= n2) return;
+    const int64_t j0 = (int64_t)cg * blockDim.x + (tid & ~63);       // first column of this wave (>= n2: the wave only helps with the copies)
     const double* pb[4];
     static_for<4>([&](auto tt) {
         constexpr int t = decltype(tt)::value;
@@ -141,10 +162,44 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
         jb = jb < n2 ? jb : n2 - 1;                   // out-of-range rows / columns recompute the last one and are not stored
         pb[t] = x2 + b * s2 + jb * dim;
     });
-    SphGauss g;
-    MathRegs mt;
-    if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load<SCALED>(beta, poly);
-    else mt = MathRegs::load();
+    constexpr int KSR = KS > 0 ? KS : 1;
+    double bfrag[KSR][4];
+    int kcs[KSR];
+    if constexpr (KS > 0) {
+        // every global load of the kernel is requested here, before anything waits: the wave's x2 fragments, then the block's rows of x1
+        // (rows * dim consecutive doubles; past the end of the set: its last entry, never stored) and the exp table on their way to LDS
+        static_for<KS>([&](auto ss) {
+            constexpr int sidx = decltype(ss)::value;
+            const int kk = 4 * sidx + lk;
+            kcs[sidx] = kk < dim ? kk : dim - 1;
+            static_for<4>([&](auto tt) { bfrag[sidx][decltype(tt)::value] = pb[decltype(tt)::value][kcs[sidx]]; });
+        });
+        const int64_t first = (int64_t)rc * rows * dim, last = n1 * dim - 1;
+        const double* src = x1 + b * s1;
+        const int total = rows * dim, step = (int)blockDim.x;
+        double tv = 0.0;
+        if constexpr (MODE == GABO_OUT_GAUSSIAN) tv = kExp2Tab256[tid];
+        for (int base = tid; base < total; base += 4 * step) {       // four loads in flight per thread (one round for 64 rows x dim <= 16)
+            double stage[4];
+            static_for<4>([&](auto ee) {
+                const int64_t k = first + base + decltype(ee)::value * step;
+                stage[decltype(ee)::value] = src[k < last ? k : last];
+            });
+            static_for<4>([&](auto ee) {
+                const int k = base + decltype(ee)::value * step;
+                if (k < total) xa[k] = stage[decltype(ee)::value];
+            });
+        }
+        if constexpr (MODE == GABO_OUT_GAUSSIAN) {
+            tab[tid] = tv;
+            for (int k = tid + step; k < 256; k += step) tab[k] = kExp2Tab256[k];
+        }
+        __syncthreads();
+    } else if constexpr (MODE == GABO_OUT_GAUSSIAN) {
+        for (int k = tid; k < 256; k += blockDim.x) tab[k] = kExp2Tab256[k];
+        __syncthreads();
+    }
+    if (j0 >= n2) return;
     auto finish = [&](double ip) {
 #if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 1     /* development probe: MFMA + stores only */
         return ip;
@@ -153,15 +208,36 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
         else return sphere_finish<MODE>(ip, beta, mt);
     };
     const uint32_t loff = (uint32_t)lk * (uint32_t)n2 + (uint32_t)li;
+#ifdef GABO_SPH_CLOCKS
+    const uint64_t clk_loop = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int ch = 0; ch < chunks; ++ch) {
         const int64_t i0 = (int64_t)rc * rows + 16 * ch;
         if (i0 >= n1) break;
         // x1 is x2, wave entirely left of the chunk's first row: i > j for every pair it would evaluate (and for every later chunk)
         if ((flags & GABO_SYMMETRIC) && j0 + 63 < i0) break;
-        const int64_t ia = (i0 + li < n1) ? i0 + li : n1 - 1;
-        const double* pa = x1 + b * s1 + ia * dim;
         sph_v4d acc[4];
-        {
+        if constexpr (KS > 0) {
+            // K is padded to 4 KS with zeros: the padded lanes hold the last valid entry and zero their x1 operand (the x2 operand can stay:
+            // a genuine, finite entry of the same vector, or that column is NaN anyway)
+            double a_cur[KS];
+            const double* xrow = xa + (16 * ch + li) * dim;
+            static_for<KS>([&](auto ss) {
+                constexpr int sidx = decltype(ss)::value;
+                a_cur[sidx] = xrow[kcs[sidx]];
+                if constexpr (sidx == KS - 1) a_cur[sidx] = 4 * sidx + lk >= dim ? 0.0 : a_cur[sidx];
+            });
+            static_for<KS>([&](auto ss) {
+                constexpr int sidx = decltype(ss)::value;
+                static_for<4>([&](auto tt) {
+                    constexpr int t = decltype(tt)::value;
+                    if constexpr (sidx == 0) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[0], bfrag[0][t], sph_v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+                    else acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[sidx], bfrag[sidx][t], acc[t], 0, 0, 0);
+                });
+            });
+        } else {
+            const int64_t ia = (i0 + li < n1) ? i0 + li : n1 - 1;
+            const double* pa = x1 + b * s1 + ia * dim;
             // K is padded to a multiple of 4 with zeros: the padded lanes load the last valid entry (no divergent load) and zero their x1
             // operand - the x2 operand can stay (it is a genuine, finite entry of the same vector, or that column is NaN anyway), which
             // saves its four selects per step.  The first step starts from a literal zero accumulator (no per-chunk clearing moves).
@@ -197,7 +273,8 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
                     double v_ = finish(acc[t][r]);
                     if (v_ == 12345.678) orow[loff + 16u * t] = v_;
 #else
-                    orow[loff + 16u * t] = finish(acc[t][r]);
+                    if constexpr (NT) __builtin_nontemporal_store(finish(acc[t][r]), &orow[loff + 16u * t]);
+                    else orow[loff + 16u * t] = finish(acc[t][r]);
 #endif
                 });
             });
@@ -214,6 +291,17 @@ __global__ __launch_bounds__(256) void sphere_pairwise_kernel(const double* __re
             });
         }
     }
+#ifdef GABO_SPH_CLOCKS
+    if ((tid & 63) == 0) {     // records live BEHIND the result matrix: the caller (tools/sphere_clocks.py) allocates 4 doubles per wave more
+        const uint64_t clk_end = __builtin_amdgcn_s_memrealtime();
+        const uint64_t cyc_end = __builtin_amdgcn_s_memtime();
+        double* rec = out + (int64_t)gridDim.y * n1 * n2 + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (tid >> 6)) * 4;
+        rec[0] = (double)clk_start;
+        rec[1] = (double)clk_loop;
+        rec[2] = (double)clk_end;
+        rec[3] = (double)(cyc_end - cyc_start);       // shader cycles entry -> exit
+    }
+#endif
 }
 
 // diag branch: row k of x1 with row k of x2 (sphere_utils_torch.py:45-49)
@@ -306,6 +394,7 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
 #ifndef GABO_SPH_CHUNKS
 #define GABO_SPH_CHUNKS 4
 #endif
+        static_assert(GABO_SPH_CHUNKS <= gabo::kSphMaxChunks, "LDS copy of the x1 rows");
         int chunks = GABO_SPH_CHUNKS;
         while (chunks > 1 && col_blocks * ((n1 + 16 * chunks - 1) / (16 * chunks)) * batch < 1024) chunks >>= 1;
         const int rows = 16 * chunks;
@@ -321,19 +410,42 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
         gabo::SphPoly poly = {};
         const bool scaled = mode == GABO_OUT_GAUSSIAN && beta > 1e-30 && beta < 1000.0;     // the usual case (see SphPoly)
         if (scaled) {
-            const double sc = 2.0 * sqrt(beta), pi = 3.14159265358979311600e+00;
+            const double sc = 4.0 * beta, pi = 3.14159265358979311600e+00;
             for (int k = 0; k <= gabo::kSphWDeg; ++k) poly.w[k] = gabo::kSphWHost[k] * sc;
-            poly.a = pi * sc;
+            poly.a = 2.0 * pi * sqrt(beta);
             poly.b = beta * (pi * pi);
         }
+        // results larger than the L2 caches (8 x 4 MB) are written with streaming stores: nothing of them would survive in L2 for a
+        // consumer anyway (N = 4096: 41.5 -> 40.3 us)
+#ifndef GABO_SPH_NT_BYTES
+#define GABO_SPH_NT_BYTES (32ll << 20)
+#endif
+        const bool streaming = batch * n1 * n2 * 8 > GABO_SPH_NT_BYTES && !(flags & GABO_SYMMETRIC);
+#define GABO_SPH_LAUNCH_NT(M, SC, K, NT_)                                                                                          \
+    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M, SC, K, NT_>), dim3((unsigned)tiles_x, (unsigned)batch), dim3(threads), 0, st, x1,  \
+                       x2, out, n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, chunks, beta, flags, poly)
+#define GABO_SPH_LAUNCH_KS(M, SC, K)                                                                                               \
+    do {                                                                                                                           \
+        if (streaming) GABO_SPH_LAUNCH_NT(M, SC, K, true);                                                                         \
+        else GABO_SPH_LAUNCH_NT(M, SC, K, false);                                                                                  \
+    } while (0)
 #define GABO_SPH_LAUNCH(M, SC)                                                                                                     \
-    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M, SC>), dim3((unsigned)tiles_x, (unsigned)batch), dim3(threads), 0, st, x1, x2, out, \
-                       n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, chunks, beta, flags, poly)
+    do {                                                                                                                           \
+        switch (dim <= 16 ? (dim + 3) / 4 : 0) {                                                                                   \
+            case 1: GABO_SPH_LAUNCH_KS(M, SC, 1); break;                                                                           \
+            case 2: GABO_SPH_LAUNCH_KS(M, SC, 2); break;                                                                           \
+            case 3: GABO_SPH_LAUNCH_KS(M, SC, 3); break;                                                                           \
+            case 4: GABO_SPH_LAUNCH_KS(M, SC, 4); break;                                                                           \
+            default: GABO_SPH_LAUNCH_KS(M, SC, 0); break;                                                                          \
+        }                                                                                                                          \
+    } while (0)
         if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE, false);
         else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE, false);
         else if (scaled) GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, true);
         else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, false);
 #undef GABO_SPH_LAUNCH
+#undef GABO_SPH_LAUNCH_KS
+#undef GABO_SPH_LAUNCH_NT
         if (flags & GABO_SYMMETRIC) {
             int tiles = (int)((n1 + 31) / 32);
             hipLaunchKernelGGL((gabo::mirror_upper_kernel<1>), dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch),

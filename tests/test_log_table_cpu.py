@@ -48,3 +48,27 @@ def test_exp_table_equals_generator_output_and_model_accuracy():
     got = get.exp_model(x, tab)
     want = np.exp(x.astype(np.longdouble)).astype(np.float64)
     assert float(np.max(np.abs(got - want) / want)) < 4.5e-16
+
+
+def test_sphere_polynomial_equals_generator_output_and_epilogue_model():
+    """asin(sqrt z)^2 / z of the sphere Gram epilogue (csrc/sphere_pairwise.hip): the committed coefficients are what
+    tools/sim/fit_sphere_poly2.py produces, and a numpy model of the epilogue (cubic square root from a 2^-24 seed, sign indicator,
+    magic-number rounding in the exp) stays within the conditioning of exp(-beta theta^2)."""
+    import mpmath as mp
+    sys.path.insert(0, os.path.join(ROOT, "tools", "sim"))
+    import fit_sphere_poly2 as fsp
+    text = open(os.path.join(ROOT, "gabotorch_amd", "csrc", "sphere_pairwise.hip")).read()
+    body = text[text.index("#define GABO_SPH_P_COEFFS") + len("#define GABO_SPH_P_COEFFS"):text.index("__constant__ double kSphW")]
+    vals = [float(v) for v in re.findall(r"-?\d+\.\d+(?:e-?\d+)?", body)]
+    coef = [float(c) for c in fsp.cheb_fit(fsp.p_true, mp.mpf(0), mp.mpf("0.5"), 17)]
+    assert vals == coef
+    z = np.linspace(0.0, 0.5, 2001)
+    want = np.array([float(fsp.p_true(mp.mpf(float(v)))) for v in z])
+    assert float(np.max(np.abs(fsp.horner64(coef, z) - want) / want)) < 5e-16
+    rng = np.random.default_rng(3)
+    c = np.concatenate([rng.uniform(-1, 1, 100000), 1 - 10.0 ** rng.uniform(-16, 0, 20000), -1 + 10.0 ** rng.uniform(-16, 0, 20000),
+                        np.array([1.0, -1.0, 0.0, 1 + 2e-16, -1 - 2e-16])])
+    for beta in (0.05, 1.2931471805599454, 40.0):
+        got = fsp.epilogue_model(c, beta, coef, rng)
+        want = np.exp(-beta * np.arccos(np.clip(c, -1.0 + 1e-15, 1.0 - 1e-15)) ** 2)
+        assert float(np.max(np.abs(got - want) / want)) < 2.5e-14 * max(1.0, beta)
