@@ -14,9 +14,19 @@
 
 namespace gabo {
 
+// The lane's column of G as a pointer into the GLOBAL address space.  The row loop launders this pointer (so that the G loads are not
+// hoisted); laundering a plain `const double*` makes it a generic pointer, the loads become flat_load - which count in vmcnt AND lgkmcnt and
+// may return out of order - and every wait in front of their uses becomes `s_waitcnt vmcnt(0) lgkmcnt(0)`, a full drain four times per row.
+// With the address space kept the loads are global_load and the waits are the partial vmcnt(N) of in-order returns.
+#ifdef GABO_PAIR_FLAT   /* A/B: the round-2 form */
+typedef const double* spd_gcol_ptr;
+#else
+typedef const double __attribute__((address_space(1)))* spd_gcol_ptr;
+#endif
+
 // sum_k log^2(lambda_k) of M = C C^T with C = W * G (both lower triangular, W wave-uniform, G per lane)
 template <int D>
-__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const double* __restrict__ Gj, int64_t gstride, const double* __restrict__ ltab) {
+__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, spd_gcol_ptr Gj, int64_t gstride, const double* __restrict__ ltab) {
     constexpr int T = tri_size(D);
     // Column `col` of C = W G depends only on column `col` of G:  C[r][col] = sum_{k=col..r} W[r][k] G[k][col].
     // M = C C^T = sum_col C[:,col] C[:,col]^T, so M is accumulated by rank-1 updates and C is never held whole:
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(256, (D > GABO_PAIR_TWO_WAVE_MAX_DIM ? 1 : GABO_PAI
         } else {
             // Launder the column pointer so the 55 G loads are NOT hoisted out of the row loop: keeping G resident costs
             // 110 VGPRs (one wave per SIMD less); re-reading it from L2 costs 28 KB per wave-row, which is noise here.
-            const double* Gp = Gj;
+            spd_gcol_ptr Gp = (spd_gcol_ptr)Gj;
             asm volatile("" : "+v"(Gp));
             s = ai_sumsq<D>(W, Gp, n2, ltab);
         }

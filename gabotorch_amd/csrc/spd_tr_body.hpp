@@ -339,7 +339,11 @@ static __device__ bool tr_update_body(double* __restrict__ x, double* __restrict
 
 // The whole trust-region solve of restart i in one launch: no host involvement between iterations.  Possible when the
 // constraints are the built-in eigenvalue bounds (or there are none); D <= 8.
-template <int D, int METRIC>
+// LAT (the latency regime: <= 1024 restarts, everything fits): the GP factors AND the workspace are in LDS, known at compile time.  With
+// the two as runtime flags every workspace / factor pointer is "LDS or global", i.e. a generic pointer, and its accesses are flat_load /
+// flat_store - which count in vmcnt and lgkmcnt at once, so each dependent access is a full `s_waitcnt vmcnt(0) lgkmcnt(0)` drain through
+// the memory pipeline (d = 5: 159 flat loads, 89 flat stores, 89 such drains in the kernel).  Specialised, they are ds_read / ds_write.
+template <int D, int METRIC, bool LAT = false>
 __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
                                                           double* __restrict__ ng, double* __restrict__ delta_tr,
                                                           uint8_t* __restrict__ active, int64_t* __restrict__ iters, AcqParams P,
@@ -355,7 +359,24 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     const int64_t i = blockIdx.x;
     if (active[i] == 0) return;
     const int C = B.n;
-    const AcqParams Ps = stage_gp_factors(P, dyn, stage_gp);
+    if constexpr (LAT) {
+        stage_gp = 1;
+        ws_lds = 1;
+    }
+    AcqParams Ps = P;
+    if constexpr (LAT) {          // (the dispatcher has checked that the factors exist)
+        const int64_t nn = P.n * P.n;
+        double* gl = dyn + 3 * P.n;
+        for (int64_t e = threadIdx.x; e < nn; e += blockDim.x) {
+            gl[e] = P.linv[e];
+            gl[nn + e] = P.linv_t[e];
+        }
+        __syncthreads();
+        Ps.linv = gl;
+        Ps.linv_t = gl + nn;
+    } else {
+        Ps = stage_gp_factors(P, dyn, stage_gp);
+    }
     // workspace: this block's slice of the caller's buffer, or (ws_lds) a private copy of the layout for ONE restart in LDS
     TrWs t;
     int64_t iw = i, Rw = R;
@@ -456,17 +477,26 @@ template <int METRIC>
 static int dispatch_solve(const SolveArgs& a) {
     int stage_gp = 0, ws_lds = 0;
     size_t lds = tr_solve_dynamic_lds(a.P->n, a.r, a.d, a.B.n, &stage_gp, &ws_lds);
+#ifdef GABO_TR_NO_LAT    /* A/B: the runtime-flag kernel everywhere */
+    const bool lat = false;
+#else
+    const bool lat = stage_gp && ws_lds && a.P->linv && a.P->linv_t;
+#endif
+#define GABO_SOLVE_LAUNCH(DD, LAT_)                                                                                                \
+    hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC, LAT_>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
+                       a.active, a.iters, *a.P, a.B, a.ws, a.r, a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.delta_bar, \
+                       a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds)
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
-        hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
-                           a.active, a.iters, *a.P, a.B, a.ws, a.r, a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.delta_bar, \
-                           a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds);             \
+        if (lat) GABO_SOLVE_LAUNCH(DD, true);                                                                                      \
+        else GABO_SOLVE_LAUNCH(DD, false);                                                                                         \
         break;
     switch (a.d) {
         GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8)
         default: return GABO_ERR_DIM;
     }
 #undef GABO_CASE
+#undef GABO_SOLVE_LAUNCH
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

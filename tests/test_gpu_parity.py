@@ -194,6 +194,24 @@ def test_sphere_vs_oracle(dim, n1, n2, batch):
         np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-13)
 
 
+@pytest.mark.parametrize("dim", [1, 2, 4, 5, 8, 12, 13, 16, 17])
+def test_sphere_every_k_step_count(dim):
+    """dim <= 16 runs with the x2 fragments in registers and the x1 rows in LDS (1..4 MFMA K steps, with and without K padding), dim > 16
+    with per-chunk operand loads; ragged sizes exercise the predicated edge tiles, beta >= 1000 the unscaled coefficients."""
+    rng = np.random.default_rng(100 + dim)
+    for n1, n2 in ((77, 333), (130, 64), (1, 1), (64, 257)):
+        x1 = rng.standard_normal((n1, dim)); x1 /= np.linalg.norm(x1, axis=-1, keepdims=True)
+        x2 = rng.standard_normal((n2, dim)); x2 /= np.linalg.norm(x2, axis=-1, keepdims=True)
+        if dim > 1 and n1 > 1:
+            x2[0] = x1[0]                       # an identical and an antipodal pair: the clamp at both ends
+            x2[-1] = -x1[1]
+        for beta in (0.37, 1500.0):
+            got = ops.sphere_pairwise(t(x1), t(x2), beta=beta).cpu().numpy()
+            np.testing.assert_allclose(got, osph.sphere_gaussian_kernel(x1, x2, beta), rtol=1e-11 * max(1.0, beta), atol=1e-300)
+        got = ops.sphere_pairwise(t(x1), t(x2), mode=_lib.GABO_OUT_DISTANCE).cpu().numpy()
+        np.testing.assert_allclose(got, osph.sphere_distance(x1, x2), rtol=1e-12, atol=3e-8)
+
+
 def test_sphere_symmetric_mode():
     rng = np.random.default_rng(8)
     for n in (1, 17, 256, 700):
