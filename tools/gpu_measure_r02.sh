@@ -11,7 +11,7 @@ timeout 900 python tools/config5_bench.py 2>&1 | grep -v amdgpu > $O/config5.txt
 timeout 900 python tools/sphere_sweep_bench.py 2>&1 | grep -v amdgpu > $O/sphere_sweep.txt
 timeout 900 python tools/bo_iteration_breakdown.py 2>&1 | grep -v amdgpu > $O/bo_iteration.txt
 timeout 600 python tools/sweep_bench.py 512 2>&1 | grep -v amdgpu > $O/sweep.txt
-timeout 600 python tools/ab_sphere.py main 2>&1 | grep -v amdgpu > $O/sphere.txt
+(timeout 600 python tools/ab_sphere.py main; timeout 300 python tools/ab_solve.py main) 2>&1 | grep -v amdgpu > $O/sphere.txt
 for f in dim_sweep tr_latency config5 sphere_sweep bo_iteration sweep sphere; do echo "== $f"; tail -25 $O/$f.txt | cut -c1-300; done
 python - <<PY
 import json
