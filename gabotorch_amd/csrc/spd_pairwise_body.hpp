@@ -6,6 +6,7 @@
 #include "gabo_mirror.hpp"
 #include "spd_generic.hpp"
 #include "gabo_log_tab.hpp"
+#include "gabo_exp_tab256.hpp"
 #include "../../include/gabo_hip.h"
 
 #ifndef GABO_PAIR_WAVES
@@ -214,6 +215,119 @@ __global__ __launch_bounds__(256, (D > GABO_PAIR_TWO_WAVE_MAX_DIM ? 1 : GABO_PAI
     }
 }
 
+// ---- d = 2, Gaussian kernel values only (no distance output): the Gram of the nested kernels' latent space (config 5) ----------------------
+// The same closed form as ai_sumsq2, in a kernel of its own so that the row loop contains nothing else: lane r of every wave holds row i0 + r
+// of W and its log-determinant term (read back with v_readlane: no scalar-memory round trip per row), the column in registers, log of
+// (tr + root) with the halving folded into the exponent, the cubic square root, exp with magic-number rounding on the 256-entry table
+// (sphere_pairwise.hip), beta folded into one FMA, streaming stores for results beyond L2.
+constexpr double kMagicRound = 6755399441055744.0;      // 1.5 2^52
+// [0..3] ln2/256 head and tail, -256/ln2, 1/6 (exp_of_minus_tab256_magic)
+__constant__ double kExpC256[4] = {0.010830424695086549 / 4, 1.162596423439437e-12 / 4, -92.33248261689366 * 4, 1.0 / 6.0};
+
+template <bool NT>
+__global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
+                                                            double* __restrict__ out, int64_t n1, int64_t n2, int64_t w_batch_stride,
+                                                            int64_t g_batch_stride, int rows, int col_blocks, int row_chunks,
+                                                            int64_t sym_tiles, double beta, int flags) {
+    __shared__ __attribute__((aligned(16))) double ltab[512];
+    __shared__ double etab[256];
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) ltab[k] = kLogTab[k];
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) etab[k] = kExp2Tab256[k];
+    int64_t cg, rc, b;
+    if (flags & GABO_SYMMETRIC) {       // see spd_ai_pairwise_kernel
+        const int64_t per_batch = sym_tiles;
+        b = blockIdx.x / per_batch;
+        int64_t t = blockIdx.x - b * per_batch;
+        cg = 0;
+        for (;;) {
+            int64_t cnt = ((cg + 1) * (int64_t)blockDim.x + rows - 1) / rows;
+            if (cnt > row_chunks) cnt = row_chunks;
+            if (t < cnt) break;
+            t -= cnt;
+            ++cg;
+        }
+        rc = t;
+    } else {
+        const int64_t bid = blockIdx.x;
+        cg = bid % col_blocks;
+        rc = (bid / col_blocks) % row_chunks;
+        b = bid / ((int64_t)col_blocks * row_chunks);
+    }
+    const int64_t j0 = cg * blockDim.x;
+    const int64_t j = j0 + threadIdx.x;
+    const int64_t jc = j < n2 ? j : n2 - 1;
+    const int64_t i0 = rc * rows;
+    const int64_t i1 = (i0 + rows < n1) ? i0 + rows : n1;
+    const double* Gj = G + b * g_batch_stride + jc;
+    const double g00 = Gj[0], g10 = Gj[n2], g11 = Gj[2 * n2];
+    const LogTabRegs lr = LogTabRegs::load();
+    // the block's rows of W and their log-determinant terms: thread r prepares row i0 + r (rows <= 64), everybody reads them back from LDS
+    // with a wave-uniform address (a broadcast: no VALU instruction, no scalar-memory round trip per row)
+    __shared__ __attribute__((aligned(16))) double wrow[64 * 4];
+    double w0l = 1.0, w1l = 0.0, w2l = 1.0;
+    if ((int)threadIdx.x < rows) {
+        int64_t ir = i0 + threadIdx.x;
+        ir = ir < n1 ? ir : n1 - 1;
+        const double* Wr = Winv + b * w_batch_stride + ir * 3;
+        w0l = Wr[0], w1l = Wr[1], w2l = Wr[2];
+    }
+    __syncthreads();                                     // the tables
+    if ((int)threadIdx.x < rows) {
+        wrow[4 * threadIdx.x + 0] = w0l;
+        wrow[4 * threadIdx.x + 1] = w1l;
+        wrow[4 * threadIdx.x + 2] = w2l;
+        wrow[4 * threadIdx.x + 3] = 2.0 * log_tab(w0l * w2l, lr, ltab);      // 2 log(w00 w11)
+    }
+    __syncthreads();
+    if ((flags & GABO_SYMMETRIC) && j0 + (int64_t)(threadIdx.x | 63) < i0) return;
+    double ec[4];
+    static_for<4>([&](auto k) { ec[decltype(k)::value] = kExpC256[decltype(k)::value]; });
+    double c24 = 1.0 / 24.0, magic = kMagicRound, tiny = 1e-290;
+    asm volatile("" : "+v"(c24), "+v"(magic));
+    asm volatile("" : "+s"(tiny));
+    // 2 (log(w00 w11) + log(g00 g11)) = log det M: the lane's column term and the row's term
+    const double lg2 = 2.0 * log_tab(g00 * g11, lr, ltab);
+    const double beta_eps = beta * 1e-15;
+    double* orow = out + b * n1 * n2 + i0 * n2 + j;
+    const int nrows = (int)(i1 - i0);
+    // x1 is x2: row r of the block is stored by the lanes with i0 + r <= j
+    const int64_t jrel = j - i0;
+    const int rmax = j >= n2 ? -1 : ((flags & GABO_SYMMETRIC) ? (jrel < 0 ? -1 : (jrel > 63 ? 63 : (int)jrel)) : 63);
+    for (int r = 0; r < nrows; ++r, orow += n2) {
+        const double2 wa = *reinterpret_cast<const double2*>(wrow + 4 * r);
+        const double2 wb = *reinterpret_cast<const double2*>(wrow + 4 * r + 2);
+        const double w0 = wa.x, w1 = wa.y, w2 = wb.x, lw2 = wb.y;
+        const double c00 = w0 * g00, c11 = w2 * g11;
+        const double c10 = __builtin_fma(w1, g00, w2 * g10);
+        const double m00 = c00 * c00, m10d = (c10 + c10) * c00, m11 = __builtin_fma(c10, c10, c11 * c11);
+        const double tr = m00 + m11, df = m00 - m11;
+        const double x2 = tr + sqrt_nz_cubic(__builtin_fma(df, df, __builtin_fma(m10d, m10d, tiny)));      // 2 lambda_+
+        // log(x2 / 2): log_tab with the halving folded into the exponent
+        const int ke = __builtin_amdgcn_frexp_exp(x2 * lr.sqrt2);
+        const double m = __builtin_ldexp(x2, 1 - ke);
+        const unsigned hi = (unsigned)__double2hiint(m);
+        const double2 cl = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(ltab) + ((hi >> 9) & 0xff0u));
+        const double rr = __builtin_fma(m, cl.x, -1.0);
+        double p = MathRegs::fmac(rr, lr.c7, lr.c6);
+        p = MathRegs::fmac(p, rr, lr.c5);
+        p = MathRegs::fmac(p, rr, lr.c4);
+        p = MathRegs::fmac(p, rr, lr.c3);
+        p = __builtin_fma(p, rr, -0.5);
+        const double lp = __builtin_fma(rr * rr, p, rr);
+        const double dk = (double)(ke - 2);
+        const double l1 = __builtin_fma(dk, lr.ln2_hi, cl.y) + __builtin_fma(dk, lr.ln2_lo, lp);
+        const double l2 = (lg2 - l1) + lw2;
+        const double sq = __builtin_fma(l1, l1, l2 * l2);
+        // exp(-beta (s + 1e-15)) (spd_utils_torch.py:120, kernels_spd.py:94-98; sqrt(x)^2 = x to an ulp)
+        const double y = __builtin_fmin(__builtin_fma(sq, beta, beta_eps), 800.0);
+        const double val = exp_of_minus_tab256_magic(y, ec, c24, magic, etab);
+        if (r <= rmax) {
+            if constexpr (NT) __builtin_nontemporal_store(val, orow);
+            else *orow = val;
+        }
+    }
+}
+
 template <int D>
 static int launch_spd_ai(const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
                          int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st) {
@@ -252,6 +366,21 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
     }
     int64_t nblocks = ((flags & GABO_SYMMETRIC) ? sym_tiles : col_blocks * row_chunks) * batch;
     if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
+    bool special2 = false;
+#ifndef GABO_PAIR_NO_GAUSS2
+    if constexpr (D == 2) special2 = (flags & GABO_OUT_MASK) == GABO_OUT_GAUSSIAN && !dist_out && rows <= 64 && beta >= 0.0;
+#endif
+    if (special2) {
+        const bool streaming = batch * n1 * n2 * 8 > (32ll << 20) && !(flags & GABO_SYMMETRIC);      // beyond the L2 caches (see sphere_pairwise.hip)
+        if (streaming)
+            hipLaunchKernelGGL((spd_ai_gauss2_kernel<true>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
+                               (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks, (int)row_chunks,
+                               sym_tiles, beta, flags);
+        else
+            hipLaunchKernelGGL((spd_ai_gauss2_kernel<false>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
+                               (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks, (int)row_chunks,
+                               sym_tiles, beta, flags);
+    } else
     hipLaunchKernelGGL((spd_ai_pairwise_kernel<D>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, dist_out, n1, n2,
                        (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks,
                        (int)row_chunks, sym_tiles, beta, flags);
