@@ -26,8 +26,25 @@ typedef const double __attribute__((address_space(1)))* spd_gcol_ptr;
 #endif
 
 // sum_k log^2(lambda_k) of M = C C^T with C = W * G (both lower triangular, W wave-uniform, G per lane)
-template <int D>
-__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, spd_gcol_ptr Gj, int64_t gstride, const double* __restrict__ ltab) {
+// The same column through a buffer descriptor: address = wave-uniform base (in the descriptor) + the lane's byte offset + a SCALAR offset per
+// entry.  The 55 entry offsets k * n2 * 8 are then computed on the scalar unit; with a vector pointer each load needs its own 64-bit vector
+// add (v_lshl_add_u64), 54 of them per pair at d = 10.  Usable while T * n2 * 8 < 2^31.
+struct SpdGcolBuffer {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;            // laundered once per row (keeps the loads inside the row loop)
+    int stride_bytes;    // n2 * 8
+    __device__ __forceinline__ double operator[](int k) const {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, k * stride_bytes, 0));
+    }
+};
+struct SpdGcolPointer {
+    spd_gcol_ptr p;
+    int64_t stride;
+    __device__ __forceinline__ double operator[](int k) const { return p[(int64_t)k * stride]; }
+};
+
+template <int D, class GCOL>
+__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const GCOL& Gj, const double* __restrict__ ltab) {
     constexpr int T = tri_size(D);
     // Column `col` of C = W G depends only on column `col` of G:  C[r][col] = sum_{k=col..r} W[r][k] G[k][col].
     // M = C C^T = sum_col C[:,col] C[:,col]^T, so M is accumulated by rank-1 updates and C is never held whole:
@@ -36,7 +53,7 @@ __device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, spd_gco
     static_for<D>([&](auto cc) {
         constexpr int col = decltype(cc)::value;
         double g[D - col], c[D - col];
-        static_for<D - col>([&](auto kk) { g[decltype(kk)::value] = Gj[(int64_t)tri(col + decltype(kk)::value, col) * gstride]; });
+        static_for<D - col>([&](auto kk) { g[decltype(kk)::value] = Gj[tri(col + decltype(kk)::value, col)]; });
         static_for<D - col>([&](auto rr) {
             constexpr int r = col + decltype(rr)::value;
             double acc = W[tri(r, col)] * g[0];
@@ -163,6 +180,18 @@ __global__ __launch_bounds__(256, (D > GABO_PAIR_TWO_WAVE_MAX_DIM ? 1 : GABO_PAI
     if ((flags & GABO_SYMMETRIC) && j0 + (int64_t)(threadIdx.x | 63) < i0) return;
     const double* Gj = G + b * g_batch_stride + jc;
     double* ob = out + b * n1 * n2;
+    // buffer form of the column loads (see SpdGcolBuffer): base = the wave's first column, lane offset = its (clamped) column
+    const int64_t jw = j0 + (threadIdx.x & ~63);
+    const bool use_buffer = D > 2 && (int64_t)T * n2 * 8 < (1ll << 31);
+    SpdGcolBuffer gbuf;
+    {
+        const double* gw = G + b * g_batch_stride + (jw < n2 ? jw : n2 - 1);
+        uint64_t a = (uint64_t)gw;
+        a = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+        gbuf.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0x7fffffff, 0x00020000);
+        gbuf.voff = (int)((jc - (jw < n2 ? jw : n2 - 1)) * 8);
+        gbuf.stride_bytes = (int)(n2 * 8);
+    }
     // d = 2: the lane's column (3 numbers) and its log-determinant term stay in registers; lane r of every wave holds the term of row i0 + r
     Spd2Col col2;
     double lw_lane = 0.0, tiny = 1e-290;
@@ -190,9 +219,19 @@ __global__ __launch_bounds__(256, (D > GABO_PAIR_TWO_WAVE_MAX_DIM ? 1 : GABO_PAI
         } else {
             // Launder the column pointer so the 55 G loads are NOT hoisted out of the row loop: keeping G resident costs
             // 110 VGPRs (one wave per SIMD less); re-reading it from L2 costs 28 KB per wave-row, which is noise here.
-            spd_gcol_ptr Gp = (spd_gcol_ptr)Gj;
-            asm volatile("" : "+v"(Gp));
-            s = ai_sumsq<D>(W, Gp, n2, ltab);
+#ifndef GABO_PAIR_NO_BUFFER
+            if (use_buffer) {
+                SpdGcolBuffer gb = gbuf;
+                asm volatile("" : "+v"(gb.voff));
+                asm volatile("" : "+s"(gb.stride_bytes));      // the entry offsets are recomputed per row on the scalar unit, not kept (the W row owns the SGPRs)
+                s = ai_sumsq<D>(W, gb, ltab);
+            } else
+#endif
+            {
+                SpdGcolPointer gp{(spd_gcol_ptr)Gj, n2};
+                asm volatile("" : "+v"(gp.p));
+                s = ai_sumsq<D>(W, gp, ltab);
+            }
         }
         double dist, val;
         if (mode == GABO_OUT_GAUSSIAN && !dist_out) {
