@@ -101,6 +101,33 @@ __device__ __forceinline__ double sqrt_nz_cubic(double x) {
     return __builtin_fma(g, p, g);
 }
 
+// Sum over the 64 lanes of a wave, the same bits in every lane.  __shfl_xor on a double is two ds_bpermute_b32 per step: six dependent
+// round trips through the LDS crossbar (~100 cycles each) in kernels whose every phase waits for such a sum.  Here the four steps inside a
+// row of 16 lanes are DPP moves on the vector pipe (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: each pairs lanes symmetrically, so
+// all 16 lanes of a row end with the same bits), the rows are combined with row_bcast15 / row_bcast31 (rows 1 and 3 += their lower
+// neighbour, then row 3 += row 1: lane 63 holds (r3 + r2) + (r1 + r0)) and lane 63 is broadcast through two v_readlane: ~21 instructions,
+// no LDS.  All 64 lanes must be active.  GABO_WAVE_SUM_SHFL: the butterfly (A/B).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_allsum(double v) {
+#ifdef GABO_WAVE_SUM_SHFL
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+#else
+    v += dpp_fetch<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]
+    v += dpp_fetch<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]
+    v += dpp_fetch<0x141, 0xf>(v);       // row_half_mirror
+    v += dpp_fetch<0x140, 0xf>(v);       // row_mirror
+    v += dpp_fetch<0x142, 0xa>(v);       // row_bcast15 into rows 1 and 3 (the other rows add the `old` operand: +0.0)
+    v += dpp_fetch<0x143, 0xc>(v);       // row_bcast31 into rows 2 and 3
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+#endif
+}
+
 // 1/sqrt(x), x > 0: e = 1 - x y0^2 (|e| <= 2^-23); y0 (1 + e/2 + 3e^2/8) leaves an e^3 error.
 __device__ __forceinline__ double rsqrt_nz(double x) {
     double y = __builtin_amdgcn_rsq(x);

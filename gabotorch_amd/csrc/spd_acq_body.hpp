@@ -9,10 +9,7 @@
 
 namespace gabo {
 
-static __device__ __forceinline__ double wave_sum64(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+static __device__ __forceinline__ double wave_sum64(double v) { return wave_allsum(v); }      // gabo_device.hpp
 
 using AcqParams = gabo_spd_acq_params;   // include/gabo_hip.h
 

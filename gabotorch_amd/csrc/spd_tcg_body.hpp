@@ -44,10 +44,7 @@ static __host__ __device__ inline TcgWs tcg_layout(void* base, int64_t R, int d,
     return w;
 }
 
-static __device__ __forceinline__ double wave_sum(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+static __device__ __forceinline__ double wave_sum(double v) { return wave_allsum(v); }      // gabo_device.hpp
 
 static __device__ __forceinline__ double wave_dot(const double* a, const double* b, int n) {
     double s = 0.0;
