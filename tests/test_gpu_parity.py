@@ -212,6 +212,18 @@ def test_sphere_every_k_step_count(dim):
         np.testing.assert_allclose(got, osph.sphere_distance(x1, x2), rtol=1e-12, atol=3e-8)
 
 
+def test_sphere_batched_register_path():
+    """leading batch dimensions (and a set shared by the whole batch: stride 0) through the dim <= 16 path"""
+    rng = np.random.default_rng(77)
+    x1 = rng.standard_normal((3, 2, 45, 10)); x1 /= np.linalg.norm(x1, axis=-1, keepdims=True)
+    x2 = rng.standard_normal((3, 2, 70, 10)); x2 /= np.linalg.norm(x2, axis=-1, keepdims=True)
+    got = ops.sphere_pairwise(t(x1), t(x2), beta=0.9).cpu().numpy()
+    np.testing.assert_allclose(got, osph.sphere_gaussian_kernel(x1, x2, 0.9), rtol=1e-11, atol=1e-14)
+    shared = t(x2[0, 0]).expand(3, 2, 70, 10)
+    got = ops.sphere_pairwise(t(x1), shared, beta=0.9).cpu().numpy()
+    np.testing.assert_allclose(got, osph.sphere_gaussian_kernel(x1, np.broadcast_to(x2[0, 0], x2.shape), 0.9), rtol=1e-11, atol=1e-14)
+
+
 def test_sphere_symmetric_mode():
     rng = np.random.default_rng(8)
     for n in (1, 17, 256, 700):
