@@ -89,6 +89,40 @@ def test_spd_ai_vs_oracle_all_dims(d):
     np.testing.assert_allclose(lap, np.exp(-0.7 * want), rtol=1e-10)
 
 
+def test_spd_ai_gaussian_d2_kernel():
+    """d = 2 Gaussian values without a distance output run in their own kernel (spd_ai_gauss2_kernel): ragged sizes, batches, a shared
+    set, the x1-is-x2 build, near-identical and badly conditioned pairs, and agreement with the general kernel's distance output."""
+    rng = np.random.default_rng(22)
+    for n1, n2 in [(1, 1), (3, 64), (17, 257), (70, 300), (130, 65)]:
+        x1 = np.stack([rand_spd_mandel(rng, n1, 2) for _ in range(2)])
+        x2 = np.stack([rand_spd_mandel(rng, n2, 2) for _ in range(2)])
+        got = ops.spd_ai_pairwise(t(x1), t(x2), beta=0.8).cpu().numpy()
+        np.testing.assert_allclose(got, ospd.spd_ai_gaussian_kernel(x1, x2, 0.8), rtol=1e-9, atol=1e-13)
+        dist = ops.spd_ai_pairwise(t(x1), t(x2), mode=_lib.GABO_OUT_DISTANCE).cpu().numpy()
+        np.testing.assert_allclose(got, np.exp(-0.8 * dist ** 2), rtol=1e-11, atol=1e-300)
+    x = rand_spd_mandel(rng, 333, 2)
+    X = t(x)
+    sym = ops.spd_ai_pairwise(X, X, beta=1.1, symmetric=True).cpu().numpy()
+    full = ops.spd_ai_pairwise(X, X.clone(), beta=1.1).cpu().numpy()
+    np.testing.assert_array_equal(sym, sym.T)
+    np.testing.assert_allclose(sym, full, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(sym, ospd.spd_ai_gaussian_kernel(x, x, 1.1), rtol=1e-9, atol=1e-13)
+    shared = t(x[:50]).expand(4, 50, 3)
+    cand = np.stack([rand_spd_mandel(rng, 1, 2) for _ in range(4)])
+    got = ops.spd_ai_pairwise(t(cand), shared, beta=0.5).cpu().numpy()
+    np.testing.assert_allclose(got, ospd.spd_ai_gaussian_kernel(cand, np.broadcast_to(x[:50], (4, 50, 3)), 0.5), rtol=1e-9, atol=1e-13)
+    # near-identical pairs (K -> 1) and condition numbers up to e^18
+    a = rand_spd_mandel(rng, 64, 2)
+    b = a * (1.0 + 1e-9 * np.arange(64))[:, None]
+    got = ops.spd_ai_pairwise(t(a), t(b), beta=2.0).cpu().numpy()
+    np.testing.assert_allclose(got, ospd.spd_ai_gaussian_kernel(a, b, 2.0), rtol=1e-12, atol=0)
+    q = np.linalg.qr(rng.standard_normal((32, 2, 2)))[0]
+    ill = np.einsum("nab,nb,ncb->nac", q, np.exp(rng.uniform(-9, 9, (32, 2))), q)
+    illv = ospd.symmetric_matrix_to_vector_mandel(0.5 * (ill + ill.transpose(0, 2, 1)))
+    got = ops.spd_ai_pairwise(t(a), t(illv), beta=0.01).cpu().numpy()
+    np.testing.assert_allclose(got, ospd.spd_ai_gaussian_kernel(a, illv, 0.01), rtol=1e-6, atol=1e-300)
+
+
 def test_spd_ai_shapes_batches_and_edges():
     rng = np.random.default_rng(5)
     d = 5
