@@ -2,9 +2,9 @@
 // replaces kernel_utils/kernels_sphere.py:71-94,118-134 + Riemannian_utils/sphere_utils_torch.py:12-55.
 //
 // The reference materialises two N1 x N2 x dim tensors and a degenerate bmm; here the inner products run as fp64 MFMA tiles
-// (16 x 16 x 4) on operands read straight from L2 and each lane finishes its 16 results in registers.  HBM traffic = the output
-// matrix (8 B per pair).  Measured at N = 4096, dim 10 (tools/ab_sphere.py, development probes): MFMA + stores alone 26 us (5.1 TB/s),
-// everything but the stores 44 us, the kernel 47-50 us - bound by fp64 issue of the acos^2 + exp epilogue, not by the write.
+// (16 x 16 x 4) and each lane finishes its 16 results in registers.  HBM traffic = the output matrix (8 B per pair).  Measured at
+// N = 4096, dim 10 (tools/ab_sphere.py, tools/sphere_clocks.py): 39-40 us; MFMA + stores alone 24 us, everything but the stores 38 us.
+// What bound the 43-us version was not the epilogue but the memory counter (operand loads waiting behind the result stores, see the kernel).
 #include "gabo_device.hpp"
 #include "gabo_mirror.hpp"
 #include "gabo_exp_tab256.hpp"
@@ -102,12 +102,12 @@ typedef double sph_v4d __attribute__((ext_vector_type(4)));
 // grid.x: (row chunk, column group), column group fastest; grid.y: batch.  A block owns `rows` = 16 * chunks rows x blockDim.x columns.
 // The inner products <x1_i, x2_j> are a GEMM with K = dim: v_mfma_f64_16x16x4_f64.  A wave owns 64 columns = four 16 x 16 MFMA tiles
 // per 16-row chunk and walks the block's row chunks; per K step of 4 a lane holds ONE double of x1 (A[i = lane & 15][k = lane >> 4])
-// and one of each x2 tile (B[k = lane >> 4][j = lane & 15]), loaded straight from L2 (the point sets are a few hundred KB) - no LDS
-// staging, no transposes (keeping the x2 fragments in registers across the chunks measured no gain: 50.7 vs 49.5 us).  Result layout of the f64 MFMA: register r of
-// lane l is row (l >> 4) + 4 r, column l & 15 - a wave store writes four full 128-byte lines.
-// What binds the kernel is fp64 issue: tools/ubench_mfma_f64.hip shows the f64 matrix pipe and the f64 vector pipe do NOT overlap
-// on gfx950 (MFMA alone 77.8, v_fma_f64 alone 60.6, both together 64.9 TFLOP/s), so per output the MFMA costs 12 issue slots beside
-// the ~56 instructions of the epilogue; what the MFMA form removes is the LDS staging and its index arithmetic.
+// and one of each x2 tile (B[k = lane >> 4][j = lane & 15]) - operands are read in exactly the fragment layout, no transposes (where they
+// come from: KS below).  Result layout of the f64 MFMA: register r of lane l is row (l >> 4) + 4 r, column l & 15 - a wave store writes
+// four full 128-byte lines.
+// Issue budget: tools/ubench_mfma_f64.hip shows the f64 matrix pipe and the f64 vector pipe do NOT overlap on gfx950 (MFMA alone 77.8,
+// v_fma_f64 alone 60.6, both together 64.9 TFLOP/s), so per output the MFMA costs 12 issue slots beside the ~48 instructions of the
+// epilogue (27.5 us of the 38-us kernel span; the rest is prologue, the lone-wave tail and store interference: tools/sphere_clocks.py).
 // KS > 0: dim <= 4 KS <= 16 - the wave's x2 fragments stay in registers for all of its row chunks and the block's x1 rows are copied to
 // LDS once, so that the chunk loop contains NO global load.  This is about the memory counter, not about load latency: vmcnt retires in
 // issue order, loads and stores alike, so operand loads issued after a chunk's 16 stores cannot be waited for without also waiting for
