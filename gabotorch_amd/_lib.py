@@ -68,6 +68,7 @@ SIGNATURES = {
     "gabo_spd_tcg_step": (_I, [_P, _P, _P, _I64, _I, _I, _I, _D, _D, _D, _I, _P]),
     "gabo_spd_tcg_end": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P]),
     "gabo_spd_sample": (_I, [_P, _I64, _I, _D, _D, _c.c_uint64, _I, _P]),
+    "gabo_spd_sample_range": (_I, [_P, _I64, _I64, _I, _D, _D, _c.c_uint64, _I, _P]),
     "gabo_nested_sphere_epilogue": (_I, [_P, _P, _I64, _I, _D, _I, _P]),
     "gabo_nested_sphere_epilogue_backward": (_I, [_P, _P, _P, _I64, _I, _D, _P]),
     "gabo_spd_tr_workspace_bytes": (_SZ, [_I64, _I, _I, _I64]),

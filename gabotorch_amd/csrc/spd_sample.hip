@@ -48,14 +48,14 @@ struct Philox {
 };
 
 // lane-private d x d scratch in LDS: element e of lane l at q[e * 64 + l] (bank-conflict free, dynamically indexable)
-__global__ __launch_bounds__(64) void spd_sample_kernel(double* __restrict__ out, int64_t n, int d, double min_eig, double max_eig,
-                                                        uint64_t seed, int mandel) {
+__global__ __launch_bounds__(64) void spd_sample_kernel(double* __restrict__ out, int64_t first, int64_t n, int d, double min_eig,
+                                                        double max_eig, uint64_t seed, int mandel) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     if (i >= n) return;
     double* q = lds + lane;
-    Philox rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint64_t)i, 0u};
+    Philox rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint64_t)(first + i), 0u};   // counter = GLOBAL sample index
     const int dd = d * d;
     for (int e = 0; e < dd; e += 2) {
         double z0, z1;
@@ -110,14 +110,19 @@ __global__ __launch_bounds__(64) void spd_sample_kernel(double* __restrict__ out
 
 }  // namespace gabo
 
-extern "C" int gabo_spd_sample(double* out, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, int mandel,
-                               gabo_stream_t stream) {
+extern "C" int gabo_spd_sample_range(double* out, int64_t first, int64_t n, int d, double min_eig, double max_eig, uint64_t seed,
+                                     int mandel, gabo_stream_t stream) {
     if (d < 1 || d > 16) return GABO_ERR_DIM;
-    if (n < 0 || !(min_eig > 0.0) || !(max_eig >= min_eig)) return GABO_ERR_ARG;
+    if (first < 0 || n < 0 || !(min_eig > 0.0) || !(max_eig >= min_eig)) return GABO_ERR_ARG;
     if (n == 0) return GABO_OK;
     if (!out) return GABO_ERR_ARG;
     size_t lds = (size_t)d * d * 64 * sizeof(double);
-    hipLaunchKernelGGL(gabo::spd_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream, out, n, d, min_eig,
-                       max_eig, seed, mandel);
+    hipLaunchKernelGGL(gabo::spd_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream, out, first, n, d,
+                       min_eig, max_eig, seed, mandel);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+extern "C" int gabo_spd_sample(double* out, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, int mandel,
+                               gabo_stream_t stream) {
+    return gabo_spd_sample_range(out, 0, n, d, min_eig, max_eig, seed, mandel, stream);
 }

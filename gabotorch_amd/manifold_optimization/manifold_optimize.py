@@ -1,7 +1,8 @@
 """Multi-start acquisition maximisation on a manifold - same entry points and keyword arguments as the reference
 (BoManifolds/manifold_optimization/manifold_optimize.py:36-321), re-organised for the MI355X:
 
-  * the `raw_samples` candidates are scored in one batched acquisition call (as the reference does, :297-309);
+  * the `raw_samples` candidates are scored in one batched acquisition call (as the reference does, :297-309); with
+    torch.distributed initialised they are drawn and scored sharded by sample index, one all_gather of (value, sample);
   * the `num_restarts` local solves run in LOCK STEP (BatchedTrustRegions) instead of the sequential loop at :207;
   * with torch.distributed initialised, restart r is owned by rank r % world (interleaved: trust-region iteration counts
     vary), each rank optimises its share on its own GPU, and ONE all_gather of (acquisition value, candidate) per restart
@@ -67,10 +68,7 @@ def joint_optimize_manifold(acq_function, manifold, solver, q, num_restarts, raw
         raw_samples=raw_samples, sample_type=sample_type, options=options, post_processing_manifold=post_processing_manifold)
     dist = _dist()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
-    if dist is not None and world > 1:
-        # every rank must start from the same initial conditions: rank 0's draw wins
-        batch_initial_conditions = batch_initial_conditions.contiguous()
-        dist.broadcast(batch_initial_conditions, src=0)
+    # (no broadcast: every rank selected the same initial conditions from the all_gathered raw samples)
     owned = shard_restarts(num_restarts, rank, world)
     batch_limit = options.get("batch_limit", num_restarts)
     cand_list, val_list = [], []
@@ -213,61 +211,107 @@ def _gen_candidates_pointwise(x0, acquisition_function, manifold, solver, post_p
     return candidates.detach(), batch_acquisition.detach()
 
 
+def _draw_raw_samples(manifold, total, first, count, options, sample_type):
+    """Raw samples first ... first + count - 1 of the `total` of one attempt, count x 1 x (point shape) (manifold_optimize.py:288).
+    `manifold.rand` stays a host callable (callers monkey-patch it); two opt-in faster routes draw the same distribution."""
+    device = options.get("device")
+    if options.get("device_rand") and device is not None and hasattr(manifold, "rand_batch_device"):
+        # drawn on the device, stream addressed by the global sample index: the shards of ranks with a common numpy seed are
+        # exactly the samples one rank would have drawn
+        return manifold.rand_batch_device(total, device, first=first, count=count)[:, None].to(sample_type)
+    if options.get("batched_rand") and hasattr(manifold, "rand_batch"):
+        # one vectorised host draw (same distribution, not numpy's draw order of `count` manifold.rand() calls)
+        pts = torch.as_tensor(np.asarray(manifold.rand_batch(count)))[:, None].to(sample_type)
+    elif count:
+        pts = torch.cat([torch.as_tensor(np.asarray(manifold.rand()))[None, None] for _ in range(count)]).to(sample_type)
+    else:
+        pts = torch.as_tensor(np.asarray(manifold.rand()))[None, None][:0].to(sample_type)
+    return pts if device is None else pts.to(device)
+
+
+def _score_raw_samples(acq_function, X_rnd, post_processing_manifold, options):
+    """(post-processed samples, acquisition values) of a block of raw samples, no gradients (manifold_optimize.py:291-309)."""
+    fused = None
+    if options.get("fused_acquisition", True) and X_rnd.is_cuda and X_rnd.shape[1] == 1:
+        fused = FusedAcquisition.build(acq_function, post_processing_manifold, X_rnd.device)
+    with torch.no_grad():
+        if fused is not None:          # built-in surrogate: one launch of the fused chain for the SPD kernels, same values
+            Y = -fused.cost(X_rnd[:, 0].contiguous()) if X_rnd.shape[0] else X_rnd.new_zeros(0, dtype=torch.float64)
+            X = X_rnd if post_processing_manifold is None else post_processing_manifold(X_rnd)
+            return X, Y
+        X = X_rnd if post_processing_manifold is None else post_processing_manifold(X_rnd)
+        step = options.get("batch_limit") or max(X.shape[0], 1)
+        parts = [acq_function(X[s:s + step]) for s in range(0, X.shape[0], step)]
+        Y = torch.cat(parts).to(X) if parts else X.new_zeros(0)
+    return X, Y
+
+
+def _gather_raw_samples(X_loc, Y_loc, total, seed):
+    """ONE all_gather that assembles the sample-index shards of every rank - rows [row_block(total, r, world)) from rank r - and
+    carries each rank's proposal for the selection seed; rank 0's is the one every rank uses.  Returns (X, Y, seed), identical on
+    every rank (raw-sample scoring sharded by sample index)."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return X_loc, Y_loc, seed
+    from ..distributed import row_block
+    world = dist.get_world_size()
+    per = (total + world - 1) // world
+    feat = X_loc[0].numel() if X_loc.shape[0] else int(np.prod(X_loc.shape[1:]))
+    packed = torch.zeros(per + 1, 1 + feat, dtype=torch.float64, device=X_loc.device)
+    packed[0, 0] = float(seed)                      # < 2^52: exact in a double
+    n = X_loc.shape[0]
+    packed[1:1 + n, 0] = Y_loc.reshape(-1).double()
+    packed[1:1 + n, 1:] = X_loc.reshape(n, -1).double()
+    parts = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(parts, packed)
+    counts = [row_block(total, r, world) for r in range(world)]
+    X = torch.cat([parts[r][1:1 + hi - lo, 1:] for r, (lo, hi) in enumerate(counts)]).reshape((total,) + tuple(X_loc.shape[1:])).to(X_loc.dtype)
+    Y = torch.cat([parts[r][1:1 + hi - lo, 0] for r, (lo, hi) in enumerate(counts)]).to(Y_loc.dtype)
+    if world > 1 and counts[1][1] - counts[1][0] == counts[0][1] and counts[0][1] > 0 and torch.equal(parts[0][1:], parts[1][1:]) \
+            and float(parts[0][0, 0]) == float(parts[1][0, 0]) and not getattr(_gather_raw_samples, "_warned", False):
+        _gather_raw_samples._warned = True
+        warnings.warn("ranks 0 and 1 drew identical raw samples: manifold.rand reads the global numpy RNG - seed it per rank "
+                      "(seed + rank), or draw on the device (options['device_rand']), whose stream is addressed by sample index")
+    return X, Y, int(parts[0][0, 0].item())
+
+
 def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num_restarts, raw_samples,
                                           sample_type=torch.float64, options=None, post_processing_manifold=None):
     """`num_restarts x q x d` initial conditions chosen among `raw_samples` random manifold points by the botorch
-    heuristics (manifold_optimize.py:232-321).  `manifold.rand` stays a host callable (callers monkey-patch it)."""
+    heuristics (manifold_optimize.py:232-321): up to four attempts with raw_samples, 2 raw_samples, ... as long as the heuristic
+    reports that it had to pick at random.
+
+    With torch.distributed initialised the raw samples are sharded BY SAMPLE INDEX: rank r draws and scores rows
+    row_block(total, r, world) only, one all_gather assembles (Y, X), and every rank runs the selection on identical data with an
+    identical random stream - so all ranks hold the same initial conditions without a broadcast."""
     options = options or {}
-    batch_limit = options.get("batch_limit")
-    factor, max_factor = 1, 5
-    init_kwargs = {}
-    if "eta" in options:
-        init_kwargs["eta"] = options.get("eta")
+    q = 1 if q is None else q
+    select = initialize_q_batch
+    select_kwargs = {"eta": options["eta"]} if "eta" in options else {}
     if options.get("nonnegative") or is_nonnegative(acq_function):
-        init_func = initialize_q_batch_nonneg
+        select = initialize_q_batch_nonneg
         if "alpha" in options:
-            init_kwargs["alpha"] = options.get("alpha")
-    else:
-        init_func = initialize_q_batch
-    if q is None:
-        q = 1
-    device = options.get("device")
-    while factor < max_factor:
-        with warnings.catch_warnings(record=True) as ws:
+            select_kwargs["alpha"] = options["alpha"]
+    dist = _dist()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    chosen = None
+    for attempt in range(1, 5):                     # the reference's factor = 1 ... max_factor - 1
+        total = raw_samples * attempt * q
+        lo, hi = (0, total)
+        if world > 1:
+            from ..distributed import row_block
+            lo, hi = row_block(total, rank, world)
+        X_loc, Y_loc = _score_raw_samples(acq_function, _draw_raw_samples(manifold, total, lo, hi - lo, options, sample_type),
+                                          post_processing_manifold, options)
+        seed = int(torch.randint(0, 2 ** 52, (1,)).item())      # from torch's global generator, like botorch's own multinomial draw
+        X_rnd, Y_rnd, seed = _gather_raw_samples(X_loc, Y_loc, total, seed)
+        gen = torch.Generator(device=X_rnd.device)
+        gen.manual_seed(seed)
+        with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
-            if options.get("device_rand") and device is not None and hasattr(manifold, "rand_batch_device"):
-                # opt-in: the raw samples are drawn on the device (same distribution as manifold.rand_batch, own random stream)
-                X_rnd = manifold.rand_batch_device(raw_samples * factor * q, device)[:, None].to(sample_type)
-            elif options.get("batched_rand") and hasattr(manifold, "rand_batch"):
-                # opt-in: one vectorised draw instead of raw_samples host calls of manifold.rand (same distribution, different
-                # order of draws from the global RNG, so not sample-for-sample identical to the reference)
-                X_rnd = torch.as_tensor(np.asarray(manifold.rand_batch(raw_samples * factor * q)))[:, None].to(sample_type)
-            else:
-                points = [torch.as_tensor(np.asarray(manifold.rand()))[None, None] for _ in range(raw_samples * factor * q)]
-                X_rnd = torch.cat(points).to(sample_type)
-            if device is not None:
-                X_rnd = X_rnd.to(device)
-            fused = None
-            if options.get("fused_acquisition", True) and X_rnd.is_cuda and q == 1:
-                fused = FusedAcquisition.build(acq_function, post_processing_manifold, X_rnd.device)
-            if fused is not None:
-                # built-in surrogate: the raw samples are scored by the fused chain (one launch for the SPD kernels); same values
-                with torch.no_grad():
-                    Y_rnd = -fused.cost(X_rnd[:, 0].contiguous())
-                if post_processing_manifold is not None:
-                    X_rnd = post_processing_manifold(X_rnd)
-            else:
-                if post_processing_manifold is not None:
-                    X_rnd = post_processing_manifold(X_rnd)
-                with torch.no_grad():
-                    bl = X_rnd.shape[0] if batch_limit is None else batch_limit
-                    Y = [acq_function(X_rnd[s:s + bl]) for s in range(0, X_rnd.shape[0], bl)]
-                    Y_rnd = torch.cat(Y).to(X_rnd)
-            batch_initial_conditions = init_func(X=X_rnd, Y=Y_rnd, n=num_restarts, **init_kwargs)
-            if not any(issubclass(w.category, BadInitialCandidatesWarning) for w in ws):
-                return batch_initial_conditions
-            if factor < max_factor:
-                factor += 1
+            chosen = select(X=X_rnd, Y=Y_rnd, n=num_restarts, generator=gen, **select_kwargs)
+        if not any(issubclass(w.category, BadInitialCandidatesWarning) for w in caught):
+            return chosen
     warnings.warn("Unable to find non-zero acquisition function values - initial conditions are being selected randomly.",
                   BadInitialCandidatesWarning)
-    return batch_initial_conditions
+    return chosen

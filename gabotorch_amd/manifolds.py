@@ -59,11 +59,13 @@ class PositiveDefinite:
         m = np.einsum("kab,kb,kcb->kac", q, lam, q)
         return 0.5 * (m + m.transpose(0, 2, 1))
 
-    def rand_batch_device(self, k, device):
+    def rand_batch_device(self, k, device, first=0, count=None):
         """k samples of the same distribution drawn on the device (gabo_spd_sample); the seed comes from numpy's global RNG, so
-        np.random.seed(...) makes the draw reproducible.  Used when the caller opts in (options={"device_rand": True})."""
+        np.random.seed(...) makes the draw reproducible.  Used when the caller opts in (options={"device_rand": True}).
+        `first` / `count`: only samples first ... first + count - 1 of the k are drawn (the stream is addressed by sample index, so the
+        shards of ranks that share the numpy seed add up to exactly the k samples one rank would draw: SURVEY 8e)."""
         seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
-        return ops.spd_sample(k, self._n, self.min_eig, self.max_eig, seed, device)
+        return ops.spd_sample(k - first if count is None else count, self._n, self.min_eig, self.max_eig, seed, device, first=first)
 
     exp = staticmethod(_wrap(lambda x, u: ops.spd_manifold_op(_lib.GABO_SPD_EXP, x, u)))
     retr = exp                                                                       # [3P] retr = exp

@@ -100,8 +100,9 @@ def is_nonnegative(acq_function):
     return bool(getattr(acq_function, "is_nonnegative", False))
 
 
-def initialize_q_batch(X, Y, n, eta=1.0):
-    """botorch.optim.initializers.initialize_q_batch [3P]: Boltzmann sampling on standardised values, argmax forced in."""
+def initialize_q_batch(X, Y, n, eta=1.0, generator=None):
+    """botorch.optim.initializers.initialize_q_batch [3P]: Boltzmann sampling on standardised values, argmax forced in.
+    `generator` (not in botorch): the random stream of the selection, so that every rank of a sharded sweep selects the same rows."""
     n_samples = X.shape[0]
     if n > n_samples:
         raise RuntimeError(f"n ({n}) cannot be larger than the number of provided samples ({n_samples})")
@@ -110,7 +111,7 @@ def initialize_q_batch(X, Y, n, eta=1.0):
     Ystd = Y.std()
     if Ystd == 0:
         warnings.warn("All acquisition values for raw samples points are the same.", BadInitialCandidatesWarning)
-        return X[torch.randperm(n=n_samples, device=X.device)][:n]
+        return X[torch.randperm(n=n_samples, device=X.device, generator=generator)][:n]
     max_val, max_idx = torch.max(Y, dim=0)
     Z = (Y - Y.mean()) / Ystd
     etaZ = eta * Z
@@ -118,14 +119,14 @@ def initialize_q_batch(X, Y, n, eta=1.0):
     while torch.isinf(weights).any():
         etaZ *= 0.5
         weights = torch.exp(etaZ)
-    idcs = torch.multinomial(weights, n)
+    idcs = torch.multinomial(weights, n, generator=generator)
     if max_idx not in idcs:
         idcs[-1] = max_idx
     return X[idcs]
 
 
-def initialize_q_batch_nonneg(X, Y, n, eta=1.0, alpha=1e-4):
-    """botorch.optim.initializers.initialize_q_batch_nonneg [3P]."""
+def initialize_q_batch_nonneg(X, Y, n, eta=1.0, alpha=1e-4, generator=None):
+    """botorch.optim.initializers.initialize_q_batch_nonneg [3P]; `generator` as in initialize_q_batch."""
     n_samples = X.shape[0]
     if n > n_samples:
         raise RuntimeError(f"n ({n}) cannot be larger than the number of provided samples ({n_samples})")
@@ -135,21 +136,21 @@ def initialize_q_batch_nonneg(X, Y, n, eta=1.0, alpha=1e-4):
     if torch.any(max_val <= 0):
         warnings.warn("All acquisition values for raw sampled points are nonpositive, so initial conditions are being "
                       "selected randomly.", BadInitialCandidatesWarning)
-        return X[torch.randperm(n=n_samples, device=X.device)][:n]
+        return X[torch.randperm(n=n_samples, device=X.device, generator=generator)][:n]
     pos = Y > 0
     num_pos = int(pos.sum().item())
     if num_pos < n:
         remaining = n - num_pos
-        rand_idx = torch.randperm(n_samples - num_pos, device=Y.device)[:remaining]
+        rand_idx = torch.randperm(n_samples - num_pos, device=Y.device, generator=generator)[:remaining]
         xpos, xneg = X[pos], X[~pos][rand_idx]
-        return torch.cat([xpos, xneg], dim=0)[torch.randperm(n, device=X.device)]
+        return torch.cat([xpos, xneg], dim=0)[torch.randperm(n, device=X.device, generator=generator)]
     alpha_pos = Y >= alpha * max_val
     while alpha_pos.sum() < n:
         alpha = 0.1 * alpha
         alpha_pos = Y >= alpha * max_val
     alpha_pos_idcs = torch.arange(len(Y), device=Y.device)[alpha_pos]
     weights = torch.exp(eta * (Y[alpha_pos] / max_val - 1))
-    idcs = alpha_pos_idcs[torch.multinomial(weights, n)]
+    idcs = alpha_pos_idcs[torch.multinomial(weights, n, generator=generator)]
     if max_idx not in idcs:
         idcs[-1] = max_idx
     return X[idcs]

@@ -684,14 +684,15 @@ def spd_acq_eval(x_mandel, train_factors, alpha, linv, linv_t, beta, mode, mean,
     return value, grad
 
 
-def spd_sample(n, d, min_eig, max_eig, seed, device, mandel=False):
-    """n random SPD matrices (n, d, d) - or Mandel vectors (n, d_vec) - drawn on the device with spd_sample's distribution."""
+def spd_sample(n, d, min_eig, max_eig, seed, device, mandel=False, first=0):
+    """n random SPD matrices (n, d, d) - or Mandel vectors (n, d_vec) - drawn on the device with spd_sample's distribution: samples
+    first ... first + n - 1 of the stream keyed by `seed` (a rank's shard of the raw samples when first > 0)."""
     lib = _lib.load()
     dev = torch.device(device)
     out = torch.empty((n, d * (d + 1) // 2) if mandel else (n, d, d), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.gabo_spd_sample(out.data_ptr(), n, d, float(min_eig), float(max_eig), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                       1 if mandel else 0, _stream_ptr(dev)), "gabo_spd_sample")
+        _lib.check(lib.gabo_spd_sample_range(out.data_ptr(), int(first), n, d, float(min_eig), float(max_eig), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                             1 if mandel else 0, _stream_ptr(dev)), "gabo_spd_sample_range")
     return out
 
 

@@ -225,6 +225,10 @@ int gabo_gp_mll_gram(const double* k, const double* y, int64_t n, double outputs
  * factor of a Gaussian matrix.  out: n x d x d (mandel == 0) or n x d_vec Mandel vectors.  Counter-based stream (Philox4x32-10,
  * key = seed, counter = matrix index): reproducible for a seed, independent of the launch geometry, NOT numpy's stream. d <= 16. */
 int gabo_spd_sample(double* out, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, int mandel, gabo_stream_t stream);
+/* Samples first ... first + n - 1 of the same stream (out holds n of them): the raw samples of one acquisition sweep sharded by sample
+ * index over the GPUs of a node - the union over the ranks is bit-identical to one gabo_spd_sample call of the total. */
+int gabo_spd_sample_range(double* out, int64_t first, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, int mandel,
+                          gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Nested-sphere projection S^(d-1) c R^d -> next subsphere, per-point part.

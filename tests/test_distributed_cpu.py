@@ -33,39 +33,101 @@ def _problem():
     return acq, CpuSphere(3)
 
 
-def _run(seed, num_restarts):
+class _IndexedSphere:
+    """CpuSphere + a sampler addressed by the global sample index (the protocol of manifolds.PositiveDefinite.rand_batch_device /
+    gabo_spd_sample_range): sample i depends on (numpy seed, i) only.  Records which index ranges it was asked for."""
+
+    def __new__(cls, n):
+        from tests._cpu_manifolds import CpuSphere
+
+        class Indexed(CpuSphere):
+            def __init__(self, n):
+                super().__init__(n)
+                self.calls = []
+
+            def rand_batch_device(self, k, device, first=0, count=None):
+                count = k - first if count is None else count
+                self.calls.append((k, first, count))
+                key = int(np.random.randint(0, 2 ** 31 - 1))
+                x = np.stack([np.random.default_rng([key, first + i]).standard_normal(self._n) for i in range(count)]) \
+                    if count else np.zeros((0, self._n))
+                return torch.as_tensor(x / np.linalg.norm(x, axis=1, keepdims=True)) if count else torch.as_tensor(x)
+        return Indexed(n)
+
+
+def _run(seed, num_restarts, indexed=False, raw_samples=40):
     from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions
-    from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold
+    from gabotorch_amd.manifold_optimization import manifold_optimize as mo
     acq, man = _problem()
+    options = {}
+    if indexed:
+        man = _IndexedSphere(3)
+        options = {"device": "cpu", "device_rand": True}
     np.random.seed(seed)
     torch.manual_seed(seed)
-    best = joint_optimize_manifold(acq, man, BatchedTrustRegions(), q=1, num_restarts=num_restarts, raw_samples=40, bounds=None)
-    return best, acq(best[None])
+    ic = mo.gen_batch_initial_conditions_manifold(acq, man, None, None, num_restarts, raw_samples, options=options)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    best = mo.joint_optimize_manifold(acq, man, BatchedTrustRegions(), q=1, num_restarts=num_restarts, raw_samples=raw_samples, bounds=None,
+                                      options=options)
+    return best, acq(best[None]), ic, getattr(man, "calls", None)
 
 
-def _worker(rank, world, port, num_restarts, out_dir):
+def _worker(rank, world, port, num_restarts, out_dir, indexed, seeds):
     sys.path.insert(0, ROOT)
+    import warnings
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        best, val = _run(100 + rank, num_restarts)      # different seeds per rank: rank 0's initial conditions must win
-        torch.save({"best": best, "val": val}, os.path.join(out_dir, f"r{rank}.pt"))
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            best, val, ic, calls = _run(seeds[rank], num_restarts, indexed=indexed)
+        torch.save({"best": best, "val": val, "ic": ic, "calls": calls,
+                    "identical_warning": any("identical raw samples" in str(w.message) for w in caught)}, os.path.join(out_dir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
+def _two_ranks(tmp_path, num_restarts, indexed, seeds):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, num_restarts, str(tmp_path), indexed, seeds), nprocs=2, join=True)
+    return [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(2)]
+
+
 def test_two_rank_sharding_matches_single_process(tmp_path):
+    """Raw samples sharded by sample index + restarts sharded r % P.  With a sampler addressed by the global sample index
+    and a common seed the two-rank sweep IS the single-process sweep: same raw samples, same selection, same candidate."""
     sys.path.insert(0, ROOT)
-    for num_restarts in (5, 2):       # 5: uneven shards (3 + 2);  2: one restart per rank
-        port = _free_port()
-        mp.spawn(_worker, args=(2, port, num_restarts, str(tmp_path)), nprocs=2, join=True)
-        r0 = torch.load(os.path.join(tmp_path, "r0.pt"))
-        r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
-        assert torch.equal(r0["best"], r1["best"])                         # every rank returns the same candidate
-        single, sval = _run(100, num_restarts)                              # same seed as rank 0 -> same initial conditions
+    for num_restarts in (5, 2):       # 5: uneven restart shards (3 + 2);  2: one restart per rank
+        r0, r1 = _two_ranks(tmp_path, num_restarts, True, (100, 100))
+        assert torch.equal(r0["best"], r1["best"]) and torch.equal(r0["ic"], r1["ic"])     # every rank: same starts, same candidate
+        # each rank drew (and scored) only its own half of the 40 raw samples - twice: once for `ic`, once inside the sweep
+        assert r0["calls"] == [(40, 0, 20)] * 2 and r1["calls"] == [(40, 20, 20)] * 2
+        single, sval, sic, scalls = _run(100, num_restarts, indexed=True)
+        assert scalls == [(40, 0, 40)] * 2
+        assert torch.equal(r0["ic"], sic)                                                   # identical initial conditions, bit for bit
         np.testing.assert_allclose(r0["best"].numpy(), single.numpy(), rtol=0, atol=1e-12)
         np.testing.assert_allclose(r0["val"].numpy(), sval.numpy(), rtol=1e-12)
-        assert r0["best"].shape == (1, 3)
+        assert r0["best"].shape == (1, 3) and not r0["identical_warning"]
+
+
+def test_two_rank_host_sampler_shards(tmp_path):
+    """manifold.rand as a host callable (the reference's contract): rank r draws its shard from ITS numpy stream, the all_gather makes the
+    union common, every rank selects the same rows.  Identically seeded ranks are told that their shards are duplicates."""
+    sys.path.insert(0, ROOT)
+    r0, r1 = _two_ranks(tmp_path, 6, False, (100, 101))
+    assert torch.equal(r0["ic"], r1["ic"]) and torch.equal(r0["best"], r1["best"]) and not r0["identical_warning"]
+    shards = []
+    for seed in (100, 101):            # what each rank drew: 20 calls of manifold.rand() from its own stream
+        np.random.seed(seed)
+        x = np.random.randn(20, 3)
+        shards.append(x / np.linalg.norm(x, axis=1, keepdims=True))
+    ic = r0["ic"][:, 0].numpy()
+    member = [[bool(np.any(np.all(np.abs(sh - row) < 1e-15, axis=1))) for sh in shards] for row in ic]
+    assert all(a or b for a, b in member)                                                    # every start is one of the gathered samples
+    assert any(a for a, _ in member) and any(b for _, b in member)                           # and both shards contribute
+    d0, d1 = _two_ranks(tmp_path, 6, False, (100, 100))
+    assert d0["identical_warning"] and d1["identical_warning"] and torch.equal(d0["best"], d1["best"])
 
 
 def test_shard_and_gather_helpers_single_process():

@@ -1,0 +1,46 @@
+"""The multi-rank branch of bench.py executed on ONE GPU: `python bench.py --gpus 2` starts its own two ranks through
+torch.distributed.run; with GABO_BENCH_ONE_DEVICE set both ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+device) - every other statement of the multi-rank path is the one the driver's 8-GPU run executes: self-launch, per-rank Gram builds,
+row-block sharded Gram (left sharded / all_gathered), raw samples sharded by sample index + restarts sharded r % P with their two
+all_gathers, the weak-scaling sweep, max-over-ranks timing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    env = dict(os.environ, GABO_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--preheat", "5",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+    log = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(log, exist_ok=True)
+    with open(os.path.join(log, "bench_two_ranks_one_device.log"), "w") as f:
+        f.write(r.stdout + "\n--- stderr ---\n" + r.stderr[-20000:])
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE JSON line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["parity"]["max_rel_err_vs_oracle_256x256"] < 1e-9
+    sg = line["sharded_gram"]
+    assert sg["left_sharded"]["ms"] > 0 and sg["all_gathered"]["ms"] >= sg["left_sharded"]["ms"] * 0.5
+    assert sg["parity_max_abs_vs_unsharded"] < 1e-12              # the assembled Gram is the single-launch Gram
+    sw = line["acq_sweep"]
+    weak = sw["weak_scaling_512_restarts_per_gpu"]
+    assert weak["restarts"] == 1024 and weak["restarts_per_s"] > 0
+    assert "expected_scaling" in line and "cpu_baseline" not in line
+
+    # the sweep whose raw samples come from the index-addressed device stream does not depend on the number of ranks: same
+    # raw samples (shards of one stream), same selection, same restarts -> the best acquisition value of a single-rank run
+    sys.path.insert(0, ROOT)
+    from tools.sweep_bench import run_sweep
+    single = run_sweep("cuda:0", num_restarts=512, device_rand=True, builtin_constraint=True)[2]
+    assert abs(sw["best_acq_single_launch_solve_device_rand"] - single) <= 1e-9 * abs(single), (sw["best_acq_single_launch_solve_device_rand"], single)

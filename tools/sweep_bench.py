@@ -42,7 +42,11 @@ def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=
         return u @ np.diag(lam) @ u.T
     man.rand = rand
     man.rand_batch = lambda k: np.stack([rand() for _ in range(0)]) if k == 0 else manifolds.PositiveDefinite.rand_batch(man, k)
-    np.random.seed(seed); torch.manual_seed(seed)
+    # host samplers read numpy's global stream: one stream per rank (seed + rank); the device sampler is addressed by the global sample
+    # index, so there every rank keeps the SAME seed and the shards add up to exactly the single-rank draw
+    import torch.distributed as _dist
+    _rank = _dist.get_rank() if (_dist.is_available() and _dist.is_initialized()) else 0
+    np.random.seed(seed + (0 if device_rand else _rank)); torch.manual_seed(seed)
     ops.set_error_checking(False)
     device = str(device)
     solver = BatchedTrustRegions(mingradnorm=1e-4, maxiter=maxiter, strict_constraints=strict)
