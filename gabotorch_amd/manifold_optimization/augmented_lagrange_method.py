@@ -22,10 +22,40 @@ class _Constraint:
         return self.manifold.egrad2rgrad(x, self._vg(x)[1])
 
 
+def _as_constraint_problems(manifold, constraints, verbosity):
+    """None / one constraint / a list of them -> a list of objects with .cost(x) and .grad(x).  A bare callable on torch tensors is
+    wrapped the way the reference wraps it, `Problem(manifold, g, arg=torch.Tensor())` (augmented_Lagrange_method.py:133-136)."""
+    import torch
+
+    from ..pymanopt_addons.problem import Problem
+    if constraints is None:
+        return []
+    if not isinstance(constraints, (list, tuple)):
+        constraints = [constraints]
+    return [c if hasattr(c, "cost") and hasattr(c, "grad") else Problem(manifold, c, arg=torch.Tensor(), verbosity=verbosity)
+            for c in constraints]
+
+
+def _axpy(g, a, cg):
+    """g + a cg for a gradient that is an array or, on product manifolds, a list of arrays"""
+    if isinstance(g, (list, tuple)):
+        return [gi + a * ci for gi, ci in zip(g, cg)]
+    return g + a * cg
+
+
 class _Subproblem:
+    """The unconstrained subproblem (:226-326) with pymanopt's problem attributes: cost, grad, the finite-difference hess the reference
+    binds (:324 `get_hessianfd`), precon, verbosity."""
+
     def __init__(self, problem, eqs, ineqs, lambdas, gammas, rho):
         self.manifold = problem.manifold
         self.problem, self.eqs, self.ineqs, self.lambdas, self.gammas, self.rho = problem, eqs, ineqs, lambdas, gammas, rho
+        self.verbosity = getattr(problem, "verbosity", 0)
+        self.precon = getattr(problem, "precon", None) or (lambda x, d: d)
+
+    def hess(self, x, a):
+        from .approximate_hessian import get_hessianfd
+        return get_hessianfd(self, x, a)
 
     def cost(self, x):                                       # (:273-288)
         c = self.problem.cost(x)
@@ -36,37 +66,36 @@ class _Subproblem:
         return c
 
     def grad(self, x):                                       # (:290-317)
-        g = [gi.copy() for gi in self.problem.grad(x)]
+        g = self.problem.grad(x)
+        g = [np.array(gi, dtype=float) for gi in g] if isinstance(g, (list, tuple)) else np.array(g, dtype=float)
         for k, con in enumerate(self.ineqs):
             v = con.cost(x)
             if self.lambdas[k] / self.rho - v > 0:
-                cg = con.grad(x)
-                for i in range(len(g)):
-                    g[i] += (v * self.rho - self.lambdas[k]) * cg[i]
+                g = _axpy(g, v * self.rho - self.lambdas[k], con.grad(x))
         for k, con in enumerate(self.eqs):
-            v = con.cost(x)
-            cg = con.grad(x)
-            for i in range(len(g)):
-                g[i] += (v * self.rho + self.gammas[k]) * cg[i]
+            g = _axpy(g, con.cost(x) * self.rho + self.gammas[k], con.grad(x))
         return g
 
 
 class AugmentedLagrangeMethod:
     def __init__(self, inner_solver, bound=20, rho_init=1, thetarho=0.3, tau=0.8, starting_tolgradnorm=1e-3, ending_tolgradnorm=1e-6,
-                 lambdas_fact=1.0, gammas_fact=1.0, maxiter=1000, maxtime=1000, minstepsize=1e-10):
+                 lambdas_fact=1.0, gammas_fact=1.0, maxiter=1000, maxtime=1000, minstepsize=1e-10, logverbosity=0, **_solver_kwargs):
         self.inner_solver = inner_solver
         self._bound, self._rho_init, self._thetarho, self._tau = bound, rho_init, thetarho, tau
         self._starting_tolgradnorm, self._ending_tolgradnorm = starting_tolgradnorm, ending_tolgradnorm
         self._lambdas_fact, self._gammas_fact = lambdas_fact, gammas_fact
         self._maxiter, self._maxtime, self._minstepsize = maxiter, maxtime, minstepsize
+        self._logverbosity = logverbosity
         self.log = {}
 
     def solve(self, problem, x=None, eq_constraints=None, ineq_constraints=None, lambdas=None, gammas=None, rho=None):
-        """problem: .manifold (a Product of host manifolds: points are lists), .cost(x) -> float, .grad(x) -> Riemannian gradient.
-        Constraints: objects with .cost / .grad (see _Constraint).  Returns the final point."""
+        """problem: .manifold, .cost(x) -> float, .grad(x) -> Riemannian gradient (points are arrays, or lists of arrays on a Product of
+        manifolds).  Constraints, as in the reference (:72-136): one or a list of callables on torch tensors (each wrapped in a
+        `Problem(manifold, g, arg=torch.Tensor())`) - or objects that already have .cost / .grad (see _Constraint).  The inner solver may
+        return the point or (point, log).  Returns the final point, (point, log) when logverbosity >= 1 (:222-225)."""
         man = problem.manifold
-        eqs = list(eq_constraints or [])
-        ineqs = list(ineq_constraints or [])
+        eqs = _as_constraint_problems(man, eq_constraints, getattr(problem, "verbosity", 0))
+        ineqs = _as_constraint_problems(man, ineq_constraints, getattr(problem, "verbosity", 0))
         xbest = man.rand() if x is None else x
         xprev = xbest
         lambdas = self._lambdas_fact * np.ones(len(ineqs)) if lambdas is None else np.asarray(lambdas, dtype=float)
@@ -81,7 +110,8 @@ class AugmentedLagrangeMethod:
         while True:
             sub = _Subproblem(problem, eqs, ineqs, lambdas, gammas, rho)
             self.inner_solver._mingradnorm = tol
-            xbest, _ = self.inner_solver.solve(sub, xbest)
+            res = self.inner_solver.solve(sub, xbest)
+            xbest = res[0] if isinstance(res, tuple) and len(res) == 2 and isinstance(res[1], dict) else res
             newacc = 0.0
             # (:179-183) NOTE the reference raises an inequality multiplier by + rho g(x) although its constraints are satisfied at
             # g >= 0 (the usual update is max(lambda - rho g, 0)): restated as written; its own callers only pass equalities
@@ -113,4 +143,4 @@ class AugmentedLagrangeMethod:
             break
         self.log = {"iterations": k, "stop_reason": reason, "violation": oldacc, "rho": rho, "time": time.time() - time0,
                     "lambdas": lambdas, "gammas": gammas}
-        return xbest
+        return (xbest, self.log) if self._logverbosity >= 1 else xbest

@@ -31,7 +31,7 @@ def _randvec(man, x):
     """unit-norm random tangent vectors at the R points x ([3P] pymanopt `randvec`: a normal draw pushed into the tangent space and
     normalised in the manifold's metric); drawn from torch's global generator on x's device"""
     h = torch.randn_like(x)
-    if hasattr(man, "proj"):
+    if hasattr(getattr(man, "base", man), "proj"):        # (_PointwiseManifold always has `proj`: ask the manifold it wraps)
         h = man.proj(x, h)
     else:
         h = man.egrad2rgrad(x, h)
@@ -330,12 +330,18 @@ class BatchedTrustRegions:
             problem = PointwiseProblemAdapter(problem)
         if x is None:
             x = problem.manifold.rand()
-        single = not batched or not torch.is_tensor(x) or x.dim() == len(getattr(problem.manifold, "_shape", (0,) * (x.dim() - 1)))
+        # ONE point: always for a pymanopt-style problem or numpy input; for a batched problem only when the tensor has exactly the
+        # manifold's point shape (an R x d_vec batch of Mandel rows on S^n_++ has the RANK of one n x n point, not its shape)
+        shape = getattr(problem.manifold, "_shape", None)
+        single = not batched or not torch.is_tensor(x) or (shape is not None and tuple(x.shape) == tuple(shape)) \
+            or (shape is None and x.dim() == 1)
         if single:
             was_numpy = not torch.is_tensor(x)
             xt = torch.as_tensor(np.asarray(x, dtype=np.float64)) if was_numpy else x.detach().double()
             out = self._solve(problem, xt[None], eq_constraints, ineq_constraints, mininner, maxinner, Delta_bar, Delta0, Delta_cons)[0]
-            return out.cpu().numpy() if was_numpy else out
+            out = out.cpu().numpy() if was_numpy else out
+            # pymanopt's contract (robust_trust_regions.py:393-398): (x, optlog) when logverbosity >= 1
+            return (out, self.log) if (self.logverbosity >= 1 and not batched) else out
         return self._solve(problem, x, eq_constraints, ineq_constraints, mininner, maxinner, Delta_bar, Delta0, Delta_cons)
 
     def _solve(self, problem, x, eq_constraints, ineq_constraints, mininner, maxinner, Delta_bar, Delta0, Delta_cons):

@@ -62,6 +62,9 @@ class _TorchEvaluator:
             raise ValueError("Incompatible lists in ehess")
         df = self._gradient(seq)
         r = sum((d.reshape(-1) * torch.as_tensor(np.asarray(ui)).to(d).reshape(-1)).sum() for d, ui in zip(df, us) if d is not None)
+        if not (torch.is_tensor(r) and r.requires_grad):          # a gradient that does not depend on x (linear cost): zero Hessian
+            out = [np.zeros_like(k) for k in self._key]
+            return out if seq else out[0]
         h = torch.autograd.grad(r, self._x, retain_graph=True, allow_unused=True)
         out = [(torch.zeros_like(xi) if hi is None else hi).detach().cpu().numpy() for hi, xi in zip(h, self._x)]
         return out if seq else out[0]

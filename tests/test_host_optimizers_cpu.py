@@ -120,3 +120,35 @@ def test_library_constraints_are_recognised_for_graph_capture():
     assert not _library_constraint(lambda x: min_eigenvalue_constraint_torch(x, 0.1))
     assert not _library_constraint(functools.partial(lambda x, b: x.sum() - b, b=1.0))
     assert builtin_constraint(plain) is not None and builtin_constraint(nested) is None      # only the plain ones run inside the kernel
+
+
+def test_alm_with_trust_regions_and_callable_constraints():
+    """The reference's own use of the method (examples/bo_sphere/constrained_benchmark_examples/gabo_sphere_equality_constraints.py:200-203):
+    `AugmentedLagrangeMethod(inner_solver=TrustRegions(...))` with the constraints given as bare torch callables - one callable or a list -
+    on a pymanopt-style `Problem`.  min <c, x> on S^3 subject to x_0 = 0.3 (equality) and x_1 >= -2 (inequality, never active)."""
+    import torch
+    from gabotorch_amd.manifold_optimization.augmented_Lagrange_method import AugmentedLagrangeMethod
+    from gabotorch_amd.manifold_optimization.robust_trust_regions import TrustRegions
+    from gabotorch_amd.pymanopt_addons.problem import Problem
+    c = np.array([0.5, -1.0, 2.0, 0.7])
+    ct = torch.tensor(c)
+    man = Sphere(4)
+    man.egrad2rgrad = man.proj
+    man.ehess2rhess = lambda x, eg, eh, u: man.proj(x, eh) - float(x @ eg) * u
+    man.typicaldist = np.pi
+    problem = Problem(man, lambda x: (ct * x).sum(), arg=torch.Tensor(), verbosity=0)
+    x0 = np.array([0.5, 0.5, 0.5, 0.5])
+    # closed form: x_0 = 0.3, the rest antiparallel to c[1:] with norm sqrt(1 - 0.09)
+    want = np.concatenate([[0.3], -c[1:] / np.linalg.norm(c[1:]) * np.sqrt(1 - 0.09)])
+    for eqs, ineqs in ((lambda x: x[0] - 0.3, None), ([lambda x: x[0] - 0.3], [lambda x: x[1] + 2.0])):
+        solver = AugmentedLagrangeMethod(maxiter=40, inner_solver=TrustRegions(maxiter=200), gammas_fact=0.05)
+        x = solver.solve(problem, x=x0.copy(), eq_constraints=eqs, ineq_constraints=ineqs)
+        assert isinstance(x, np.ndarray) and abs(np.linalg.norm(x) - 1) < 1e-12
+        np.testing.assert_allclose(x, want, atol=2e-3)
+    # logverbosity >= 1: (x, log), as pymanopt's solvers return it - for the trust regions on ONE point and for the method itself
+    xt, log = TrustRegions(maxiter=50, logverbosity=2).solve(problem, x=x0.copy())
+    assert isinstance(xt, np.ndarray) and isinstance(log, dict)
+    np.testing.assert_allclose(xt, -c / np.linalg.norm(c), atol=1e-6)
+    xa, alog = AugmentedLagrangeMethod(maxiter=5, inner_solver=TrustRegions(maxiter=50, logverbosity=1), logverbosity=1).solve(
+        problem, x=x0.copy(), eq_constraints=lambda x: x[0] - 0.3)
+    assert isinstance(xa, np.ndarray) and "iterations" in alog

@@ -17,7 +17,9 @@ def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrain
     gp = models.ExactGP(torch.tensor(X, device=device), torch.tensor(y, device=device), SphereGaussianKernel(beta_min=0.6), outputscale=1.0, noise=1e-2)
     acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
     man = manifolds.Sphere(dim)
-    np.random.seed(5); torch.manual_seed(5)
+    import torch.distributed as _dist
+    _rank = _dist.get_rank() if (_dist.is_available() and _dist.is_initialized()) else 0
+    np.random.seed(5 + _rank); torch.manual_seed(5)      # host sampler: one numpy stream per rank (the raw samples are sharded by index)
     cons = [lambda x: x[..., 0] - 0.1] if constrained else None
     solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=maxiter)
     torch.cuda.synchronize(); t0 = time.perf_counter()
