@@ -8,6 +8,7 @@
 #include "gabo_device.hpp"
 #include "gabo_mirror.hpp"
 #include "gabo_exp_tab256.hpp"
+#include "gabo_sphere_pw_table.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
@@ -87,6 +88,80 @@ __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss&
     }
 }
 
+// ---- round 3: the same value from a piecewise table, 35 instead of 46 issue slots per output ------------------------------------
+// s = sqrt((1 - |c|) / 4) in [1.6e-8, 1/2] serves BOTH signs of c (sin(theta/2) = sqrt2 s for c >= 0, cos(theta/2) = sqrt2 s for c < 0), and
+// theta^2 is analytic in s on all of [0, 1/2] for either sign: no square-root singularity is left at c = -1, so one short polynomial per
+// slot replaces the degree-17 chain AND the c < 0 correction.  Slot = round(64 s) by the magic-number FMA; the addend's low word carries
+// + 40 for c < 0 (two 32-bit instructions from the sign bit), so the right branch's table row index simply appears in the low mantissa word.
+// The block's copy of the table (LDS, 80 rows x 10 doubles) is pre-multiplied by -beta 256 / ln2: the Horner chain (7 FMAs, coefficients by
+// four ds_read_b128 - the LDS pipe, not the vector pipe) delivers Y = -beta theta^2 in units of ln2/256, the exp argument reduction is the exact
+// subtraction Y - rint(Y) (no head/tail product), and exp(r ln2/256) - 1 is a degree-4 polynomial with the scale inside its coefficients.
+// Instructions per output: 2 (clamped q) + 8 issue slots (v_rsq_f64 + 5) + 2 + 3 (slot, t) + 1 (address) + 7 + 12 (exp) = 35 (+ 12 of MFMA).
+// Accuracy: tools/sim/fit_sphere_piecewise.py model 7 - 3.8e-15 against 60-digit arithmetic at beta = 1.29 (numpy's own 3.4e-15).
+// A NaN inner product does not propagate (v_max_f64 returns the bound): a corrupted input row shows up as K = 1 / exp(-beta pi^2) entries,
+// as in the polynomial form below; the distance / Laplace modes propagate it.
+struct SphPwRegs {
+    double qmin, scale, c1, c2, c3, magic;    // SGPRs
+    double c4;                                // VGPR (the one FMA of the exp tail whose other operands are both vector registers is fine with
+                                              // a scalar c3; c4 starts the chain together with r)
+    __device__ __forceinline__ static SphPwRegs load();
+};
+// from constant memory (scalar loads -> SGPRs; as literals the compiler keeps them in VGPRs and copies one per v_fmac):
+// [0] (1 - (1 - 1e-15)) / 4, the reference's clamp of c (sphere_utils_torch.py:53); [1] slots per unit of s; [2..5] l^k / k!, l = ln2 / 256;
+// [6] 1.5 2^52
+#define GABO_SPH_L 0.0027076061740622863
+__constant__ double kSphPwC[7] = {0.25 * 9.992007221626409e-16, 64.0, GABO_SPH_L, GABO_SPH_L* GABO_SPH_L / 2.0,
+                                  GABO_SPH_L* GABO_SPH_L* GABO_SPH_L / 6.0, GABO_SPH_L* GABO_SPH_L* GABO_SPH_L* GABO_SPH_L / 24.0,
+                                  6755399441055744.0};
+__device__ __forceinline__ SphPwRegs SphPwRegs::load() {
+    SphPwRegs t;
+    t.qmin = kSphPwC[0];
+    t.scale = kSphPwC[1];
+    t.c1 = kSphPwC[2];
+    t.c2 = kSphPwC[3];
+    t.c3 = kSphPwC[4];
+    t.c4 = kSphPwC[5];
+    t.magic = kSphPwC[6];
+    asm volatile("" : "+s"(t.qmin), "+s"(t.scale), "+s"(t.c1), "+s"(t.c2), "+s"(t.c3), "+s"(t.magic));
+    asm volatile("" : "+v"(t.c4));
+    return t;
+}
+
+__device__ __forceinline__ double sphere_gauss_finish_pw(double ip, const SphPwRegs& g, const double* __restrict__ pw,
+                                                         const double* __restrict__ tab) {
+    const double q = max_raw(__builtin_fma(-0.25, __builtin_fabs(ip), 0.25), g.qmin);
+    const double s = sqrt_nz_cubic(q);
+    const double magic = __hiloint2double(0x43380000, (__double2hiint(ip) >> 31) & kSphPwNeg);     // 1.5 2^52 (+ 40 for c < 0)
+    const double kf = __builtin_fma(s, g.scale, magic);
+    const double kd = kf - magic;
+    const double t = __builtin_fma(s, g.scale, -kd);
+    // the slot's eight coefficients: four ds_read_b128 (conflict-free 4 LDS cycles each; the two-address ds_read2st64_b64 the compiler
+    // merges a [coefficient][slot] layout into runs at half that rate and made the LDS pipe the bottleneck: 49 instead of 41 us)
+    typedef double pw_v2d __attribute__((ext_vector_type(2)));
+    // (byte offset by the 24-bit multiply: v_mul_lo_u32, which a plain `slot * 10` compiles to, is a quarter-rate instruction)
+    const pw_v2d* row = reinterpret_cast<const pw_v2d*>(reinterpret_cast<const char*>(pw) +
+                                                        __umul24((unsigned)__double2loint(kf), (unsigned)(kSphPwStride * sizeof(double))));
+    static_assert(kSphPwDeg == 7, "four coefficient pairs");
+    const pw_v2d c67 = row[3], c45 = row[2], c23 = row[1], c01 = row[0];
+    double w = __builtin_fma(c67[1], t, c67[0]);
+    w = __builtin_fma(w, t, c45[1]);
+    w = __builtin_fma(w, t, c45[0]);
+    w = __builtin_fma(w, t, c23[1]);
+    w = __builtin_fma(w, t, c23[0]);
+    w = __builtin_fma(w, t, c01[1]);
+    w = __builtin_fma(w, t, c01[0]);
+    const double km = w + g.magic;
+    const double k = km - g.magic;
+    const double r = w - k;
+    double p = __builtin_fma(r, g.c4, g.c3);
+    p = __builtin_fma(p, r, g.c2);
+    p = __builtin_fma(p, r, g.c1);
+    p = p * r;                                                 // exp(r ln2/256) - 1
+    const int ki = __double2loint(km);
+    const double e = tab[ki & 255];
+    return __builtin_ldexp(__builtin_fma(e, p, e), ki >> 8);
+}
+
 template <int MODE>
 __device__ __forceinline__ double sphere_finish(double ip, double beta, const MathRegs& mt) {
     const double lo = -1.0 + 1e-15, hi = 1.0 - 1e-15;  // sphere_utils_torch.py:53
@@ -115,23 +190,56 @@ typedef double sph_v4d __attribute__((ext_vector_type(4)));
 // 633 us with the loads behind the stores, 478 us with the stores removed, 369 us for the stores alone).  LDS reads count in lgkmcnt.
 // KS = 0: any dim, operands loaded per chunk.
 constexpr int kSphMaxChunks = 8;
-#ifdef GABO_SPH_CLOCKS     /* the timestamps must not cost the fourth wave per SIMD */
+// four waves per SIMD (128 VGPRs): neither the timestamps of the development build nor the 16 independent table-driven epilogues of a
+// chunk (which the scheduler would otherwise interleave into 160 registers) may cost the fourth wave
+#ifndef GABO_SPH_PW_WAVES
+#define GABO_SPH_PW_WAVES 4
+#endif
+#ifndef GABO_SPH_PW_GROUP
+#define GABO_SPH_PW_GROUP 1
+#endif
+#ifndef GABO_SPH_PW_BARRIER
+#define GABO_SPH_PW_BARRIER 1
+#endif
+#ifdef GABO_SPH_CLOCKS
 #define GABO_SPH_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #else
-#define GABO_SPH_BOUNDS __launch_bounds__(256)
+#define GABO_SPH_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW ? GABO_SPH_PW_WAVES : 1, 4)))
 #endif
-template <int MODE, bool SCALED = false, int KS = 0, bool NT = false>
+template <int MODE, bool SCALED = false, int KS = 0, bool NT = false, bool PW = false>
 __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks, int chunks,
                                                               double beta, int flags, SphPoly poly) {
     __shared__ double tab[256];
     __shared__ double xa[KS > 0 ? 16 * kSphMaxChunks * 4 * KS : 1];
+    __shared__ __attribute__((aligned(16))) double pw[PW ? kSphPwSlots * kSphPwStride : 2];
     const int tid = threadIdx.x;
     SphGauss g;       // requested first: the scalar loads of the coefficients travel together with the kernel arguments
+    SphPwRegs gp;
     MathRegs mt;
-    if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load<SCALED>(beta, poly);
+    if constexpr (PW) gp = SphPwRegs::load();
+    else if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load<SCALED>(beta, poly);
     else mt = MathRegs::load();
+    constexpr int kPwN = kSphPwSlots * kSphPwStride, kPwFirst = (kPwN + 255) / 256;       // 800 entries: four per thread of a 256-thread block
+    double pwv[kPwFirst];
+    if constexpr (PW) {
+        // the piecewise table: its first round of loads (all of it for a 256-thread block) is requested with everything else
+        static_for<kPwFirst>([&](auto ee) {
+            const int k = tid + decltype(ee)::value * (int)blockDim.x;
+            pwv[decltype(ee)::value] = kSphPwTab[k < kPwN ? k : kPwN - 1];
+        });
+    }
+    auto pw_store = [&]() {      // ... and scaled by -beta 256 / ln2 on its way to LDS
+        if constexpr (PW) {
+            const double sc = beta * -369.3299304675746;
+            static_for<kPwFirst>([&](auto ee) {
+                const int k = tid + decltype(ee)::value * (int)blockDim.x;
+                if (k < kPwN) pw[k] = pwv[decltype(ee)::value] * sc;
+            });
+            for (int k = kPwFirst * (int)blockDim.x + tid; k < kPwN; k += (int)blockDim.x) pw[k] = kSphPwTab[k] * sc;      // blocks of < 256 threads
+        }
+    };
 #ifdef GABO_SPH_CLOCKS    /* development: per-wave timestamps (100 MHz) into the output buffer; build with GABO_SPH_PROBE=2 (no result stores) */
     const uint64_t clk_start = __builtin_amdgcn_s_memrealtime();
     const uint64_t cyc_start = __builtin_amdgcn_s_memtime();
@@ -154,7 +262,10 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
     }
     const int64_t b = blockIdx.y;
     const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
-    const int64_t j0 = (int64_t)cg * blockDim.x + (tid & ~63);       // first column of this wave (>= n2: the wave only helps with the copies)
+    // first column of this wave (>= n2: the wave only helps with the copies).  The wave index goes through v_readfirstlane so that the
+    // compiler KNOWS j0 is wave-uniform: the result stores then take their row base from SGPRs (`global_store ... v_off, v_data, s[base]`)
+    // instead of one 64-bit vector addition per store
+    const int64_t j0 = (int64_t)cg * blockDim.x + 64 * __builtin_amdgcn_readfirstlane(tid >> 6);
     const double* pb[4];
     static_for<4>([&](auto tt) {
         constexpr int t = decltype(tt)::value;
@@ -194,9 +305,11 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
             tab[tid] = tv;
             for (int k = tid + step; k < 256; k += step) tab[k] = kExp2Tab256[k];
         }
+        pw_store();
         __syncthreads();
     } else if constexpr (MODE == GABO_OUT_GAUSSIAN) {
         for (int k = tid; k < 256; k += blockDim.x) tab[k] = kExp2Tab256[k];
+        pw_store();
         __syncthreads();
     }
     if (j0 >= n2) return;
@@ -204,10 +317,11 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
 #if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 1     /* development probe: MFMA + stores only */
         return ip;
 #endif
-        if constexpr (MODE == GABO_OUT_GAUSSIAN) return sphere_gauss_finish<SCALED>(ip, g, tab);
+        if constexpr (PW) return sphere_gauss_finish_pw(ip, gp, pw, tab);
+        else if constexpr (MODE == GABO_OUT_GAUSSIAN) return sphere_gauss_finish<SCALED>(ip, g, tab);
         else return sphere_finish<MODE>(ip, beta, mt);
     };
-    const uint32_t loff = (uint32_t)lk * (uint32_t)n2 + (uint32_t)li;
+    const uint32_t loff = ((uint32_t)lk * (uint32_t)n2 + (uint32_t)li) * 8u;       // byte offset of the lane inside a 4-row group (n2 < 2^27)
 #ifdef GABO_SPH_CLOCKS
     const uint64_t clk_loop = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -217,6 +331,46 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
         // x1 is x2, wave entirely left of the chunk's first row: i > j for every pair it would evaluate (and for every later chunk)
         if ((flags & GABO_SYMMETRIC) && j0 + 63 < i0) break;
         sph_v4d acc[4];
+        // Stores: wave-uniform base of the chunk + a 32-bit lane offset.  A chunk that lies fully inside the matrix (and, with
+        // x1 is x2, fully above the diagonal) stores without predicates.
+        double* ob = out + b * n1 * n2 + i0 * n2 + j0;
+        const bool inside = i0 + 16 <= n1 && j0 + 64 <= n2 && (uint64_t)n2 < (1ull << 27) &&
+                            (!(flags & GABO_SYMMETRIC) || i0 + 15 <= j0);
+        // finish and store tiles T0 ... T0 + NTILE - 1 of the chunk
+        auto store_tiles = [&](auto t0_, auto ntile_) {
+            constexpr int T0 = decltype(t0_)::value, NTILE = decltype(ntile_)::value;
+            if (inside) {
+                static_for<4>([&](auto rr) {
+                    constexpr int r = decltype(rr)::value;
+                    double* orow = ob + (int64_t)(4 * r) * n2;       // wave-uniform
+                    static_for<NTILE>([&](auto tt) {
+                        constexpr int t = T0 + decltype(tt)::value;
+#if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 2     /* development probe: everything but the stores */
+                        double v_ = finish(acc[t][r]);
+                        if (v_ == 12345.678) *reinterpret_cast<double*>(reinterpret_cast<char*>(orow) + loff + 128u * t) = v_;
+#else
+                        double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(orow) + loff + 128u * t);
+                        if constexpr (NT) __builtin_nontemporal_store(finish(acc[t][r]), dst);
+                        else *dst = finish(acc[t][r]);
+#endif
+                        // one table-driven epilogue at a time: left alone the scheduler interleaves the whole chunk (8 table reads and ~35
+                        // registers per output) and the kernel no longer fits the 128 registers of four waves per SIMD
+                        if constexpr (PW && GABO_SPH_PW_BARRIER) __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            } else {
+                static_for<NTILE>([&](auto tt) {
+                    constexpr int t = T0 + decltype(tt)::value;
+                    const int64_t j = j0 + 16 * t + li;
+                    static_for<4>([&](auto rr) {
+                        constexpr int r = decltype(rr)::value;
+                        const int64_t i = i0 + lk + 4 * r;
+                        double val = finish(acc[t][r]);
+                        if (i < n1 && j < n2 && (!(flags & GABO_SYMMETRIC) || i <= j)) ob[(int64_t)(lk + 4 * r) * n2 + 16 * t + li] = val;
+                    });
+                });
+            }
+        };
         if constexpr (KS > 0) {
             // K is padded to 4 KS with zeros: the padded lanes hold the last valid entry and zero their x1 operand (the x2 operand can stay:
             // a genuine, finite entry of the same vector, or that column is NaN anyway)
@@ -227,13 +381,20 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
                 a_cur[sidx] = xrow[kcs[sidx]];
                 if constexpr (sidx == KS - 1) a_cur[sidx] = 4 * sidx + lk >= dim ? 0.0 : a_cur[sidx];
             });
-            static_for<KS>([&](auto ss) {
-                constexpr int sidx = decltype(ss)::value;
-                static_for<4>([&](auto tt) {
-                    constexpr int t = decltype(tt)::value;
-                    if constexpr (sidx == 0) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[0], bfrag[0][t], sph_v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-                    else acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[sidx], bfrag[sidx][t], acc[t], 0, 0, 0);
+            // PW: two tiles at a time (their MFMAs, then their eight epilogues) - 16 accumulator registers live instead of 32
+            constexpr int GROUP = (PW && GABO_SPH_PW_BARRIER) ? GABO_SPH_PW_GROUP : 4;
+            static_for<4 / GROUP>([&](auto gg) {
+                constexpr int T0 = decltype(gg)::value * GROUP;
+                static_for<KS>([&](auto ss) {
+                    constexpr int sidx = decltype(ss)::value;
+                    static_for<GROUP>([&](auto tt) {
+                        constexpr int t = T0 + decltype(tt)::value;
+                        if constexpr (sidx == 0) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[0], bfrag[0][t], sph_v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+                        else acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[sidx], bfrag[sidx][t], acc[t], 0, 0, 0);
+                    });
                 });
+                store_tiles(std::integral_constant<int, T0>{}, std::integral_constant<int, GROUP>{});
+                if constexpr (PW && GABO_SPH_PW_BARRIER) __builtin_amdgcn_sched_barrier(0);
             });
         } else {
             const int64_t ia = (i0 + li < n1) ? i0 + li : n1 - 1;
@@ -257,38 +418,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
             };
             kstep(0, std::true_type{});
             for (int k0 = 4; k0 < dim; k0 += 4) kstep(k0, std::false_type{});
-        }
-        // Stores: wave-uniform base of the chunk + a 32-bit lane offset.  A chunk that lies fully inside the matrix (and, with
-        // x1 is x2, fully above the diagonal) stores without predicates.
-        double* ob = out + b * n1 * n2 + i0 * n2 + j0;
-        const bool inside = i0 + 16 <= n1 && j0 + 64 <= n2 && (uint64_t)n2 < (1ull << 27) &&
-                            (!(flags & GABO_SYMMETRIC) || i0 + 15 <= j0);
-        if (inside) {
-            static_for<4>([&](auto rr) {
-                constexpr int r = decltype(rr)::value;
-                double* orow = ob + (int64_t)(4 * r) * n2;       // wave-uniform
-                static_for<4>([&](auto tt) {
-                    constexpr int t = decltype(tt)::value;
-#if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 2     /* development probe: everything but the stores */
-                    double v_ = finish(acc[t][r]);
-                    if (v_ == 12345.678) orow[loff + 16u * t] = v_;
-#else
-                    if constexpr (NT) __builtin_nontemporal_store(finish(acc[t][r]), &orow[loff + 16u * t]);
-                    else orow[loff + 16u * t] = finish(acc[t][r]);
-#endif
-                });
-            });
-        } else {
-            static_for<4>([&](auto tt) {
-                constexpr int t = decltype(tt)::value;
-                const int64_t j = j0 + 16 * t + li;
-                static_for<4>([&](auto rr) {
-                    constexpr int r = decltype(rr)::value;
-                    const int64_t i = i0 + lk + 4 * r;
-                    double val = finish(acc[t][r]);
-                    if (i < n1 && j < n2 && (!(flags & GABO_SYMMETRIC) || i <= j)) ob[(int64_t)(lk + 4 * r) * n2 + 16 * t + li] = val;
-                });
-            });
+            store_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
         }
     }
 #ifdef GABO_SPH_CLOCKS
@@ -408,7 +538,8 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
         if (tiles_x > 0x7fffffffLL) return GABO_ERR_ARG;
         const int mode = flags & GABO_OUT_MASK;
         gabo::SphPoly poly = {};
-        const bool scaled = mode == GABO_OUT_GAUSSIAN && beta > 1e-30 && beta < 1000.0;     // the usual case (see SphPoly)
+        // the usual case: piecewise-table epilogue (sphere_gauss_finish_pw); outside it the global polynomial with the clamped exp
+        const bool scaled = mode == GABO_OUT_GAUSSIAN && beta > 1e-30 && beta < 1000.0;
         if (scaled) {
             const double sc = 4.0 * beta, pi = 3.14159265358979311600e+00;
             for (int k = 0; k <= gabo::kSphWDeg; ++k) poly.w[k] = gabo::kSphWHost[k] * sc;
@@ -421,9 +552,15 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
 #define GABO_SPH_NT_BYTES (32ll << 20)
 #endif
         const bool streaming = batch * n1 * n2 * 8 > GABO_SPH_NT_BYTES && !(flags & GABO_SYMMETRIC);
+#ifdef GABO_SPH_NO_PW      /* A/B: the round-2 epilogue (global degree-17 polynomial) for the usual range of beta too */
+#define GABO_SPH_PW_OF(SC) false
+#else
+#define GABO_SPH_PW_OF(SC) SC
+#endif
 #define GABO_SPH_LAUNCH_NT(M, SC, K, NT_)                                                                                          \
-    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M, SC, K, NT_>), dim3((unsigned)tiles_x, (unsigned)batch), dim3(threads), 0, st, x1,  \
-                       x2, out, n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, chunks, beta, flags, poly)
+    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M, SC, K, NT_, GABO_SPH_PW_OF(SC)>), dim3((unsigned)tiles_x, (unsigned)batch),     \
+                       dim3(threads), 0, st, x1, x2, out, n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, \
+                       chunks, beta, flags, poly)
 #define GABO_SPH_LAUNCH_KS(M, SC, K)                                                                                               \
     do {                                                                                                                           \
         if (streaming) GABO_SPH_LAUNCH_NT(M, SC, K, true);                                                                         \
