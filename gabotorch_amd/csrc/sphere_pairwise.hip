@@ -88,63 +88,69 @@ __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss&
     }
 }
 
-// ---- round 3: the same value from a piecewise table, 35 instead of 46 issue slots per output ------------------------------------
-// s = sqrt((1 - |c|) / 4) in [1.6e-8, 1/2] serves BOTH signs of c (sin(theta/2) = sqrt2 s for c >= 0, cos(theta/2) = sqrt2 s for c < 0), and
-// theta^2 is analytic in s on all of [0, 1/2] for either sign: no square-root singularity is left at c = -1, so one short polynomial per
-// slot replaces the degree-17 chain AND the c < 0 correction.  Slot = round(64 s) by the magic-number FMA; the addend's low word carries
-// + 40 for c < 0 (two 32-bit instructions from the sign bit), so the right branch's table row index simply appears in the low mantissa word.
-// The block's copy of the table (LDS, 80 rows x 10 doubles) is pre-multiplied by -beta 256 / ln2: the Horner chain (7 FMAs, coefficients by
-// four ds_read_b128 - the LDS pipe, not the vector pipe) delivers Y = -beta theta^2 in units of ln2/256, the exp argument reduction is the exact
-// subtraction Y - rint(Y) (no head/tail product), and exp(r ln2/256) - 1 is a degree-4 polynomial with the scale inside its coefficients.
-// Instructions per output: 2 (clamped q) + 8 issue slots (v_rsq_f64 + 5) + 2 + 3 (slot, t) + 1 (address) + 7 + 12 (exp) = 35 (+ 12 of MFMA).
-// Accuracy: tools/sim/fit_sphere_piecewise.py model 7 - 3.8e-15 against 60-digit arithmetic at beta = 1.29 (numpy's own 3.4e-15).
-// A NaN inner product does not propagate (v_max_f64 returns the bound): a corrupted input row shows up as K = 1 / exp(-beta pi^2) entries,
-// as in the polynomial form below; the distance / Laplace modes propagate it.
+// ---- round 3: the same value from a piecewise table, 31 + v_rsq_f64 instead of 45 + v_rsq_f64 instructions per output -----------------
+// v = sqrt((1 + c) / 2) = cos(theta / 2) in [2.2e-8, 1] serves BOTH signs of c: theta^2 = 4 acos(v)^2 is analytic on all of [0, 1] (acos^2 is
+// regular at v = 1, and c = -1, where theta^2 has a square-root singularity as a function of c, is the ordinary point v = 0; the only
+// singularity, v = -1, is a full unit away).  So there is no c < 0 correction, no sign handling, and a degree-6 polynomial per slot of width
+// 1/64 replaces the degree-17 chain.  Slot = round(64 v) by the magic-number FMA (the index appears in the low mantissa word).
+// The block's copy of the table (LDS, 65 rows x 10 doubles) is pre-multiplied by -beta 256 / ln2: the Horner chain (6 FMAs, coefficients by
+// three ds_read_b128 and one ds_read_b64 - the LDS pipe, not the vector pipe) delivers Y = -beta theta^2 in units of ln2/256, the exp argument
+// reduction is the exact subtraction Y - rint(Y) (no head/tail product), and exp(r ln2/256) - 1 is a degree-4 polynomial with the scale inside its
+// coefficients.  Instructions per output: 3 (clamped q) + v_rsq_f64 + 5 + 3 (slot, t) + 1 (address) + 6 + 12 (exp) = 30 + v_rsq_f64 (13.7 cycles).
+// Accuracy: tools/sim/fit_sphere_piecewise.py model 6 - 2.9e-15 against 60-digit arithmetic at beta = 1.29 (numpy's own 3.1e-15).
+// A NaN inner product does not propagate (v_max_f64 / v_min_f64 return the bound): a corrupted input row shows up as K = 1 entries, as
+// in the polynomial form above (exp(-beta pi^2) there for a negative sign bit); the distance / Laplace modes propagate it.
 struct SphPwRegs {
-    double qmin, scale, c1, c2, c3, magic;    // SGPRs
-    double c4;                                // VGPR (the one FMA of the exp tail whose other operands are both vector registers is fine with
-                                              // a scalar c3; c4 starts the chain together with r)
+    double qmin, qmax, c1, c2, c3, magic;    // SGPRs
+    double c4, scale;                        // VGPRs (a VALU instruction reads ONE scalar operand: these share an FMA with c3 resp. the magic number;
+                                             // as the scalar one of its FMA the magic number is an addend the compiler cannot turn into v_mov + v_fmac)
     __device__ __forceinline__ static SphPwRegs load();
 };
 // from constant memory (scalar loads -> SGPRs; as literals the compiler keeps them in VGPRs and copies one per v_fmac):
-// [0] (1 - (1 - 1e-15)) / 4, the reference's clamp of c (sphere_utils_torch.py:53); [1] slots per unit of s; [2..5] l^k / k!, l = ln2 / 256;
-// [6] 1.5 2^52
+// [0], [1] the reference's clamp of c to [-1 + 1e-15, 1 - 1e-15] (sphere_utils_torch.py:53) stated for q = (1 + c) / 2; [2] slots per unit
+// of v; [3..6] l^k / k!, l = ln2 / 256; [7] 1.5 2^52
 #define GABO_SPH_L 0.0027076061740622863
-__constant__ double kSphPwC[7] = {0.25 * 9.992007221626409e-16, 64.0, GABO_SPH_L, GABO_SPH_L* GABO_SPH_L / 2.0,
+__constant__ double kSphPwC[8] = {4.996003610813204e-16, 1.0 - 4.996003610813204e-16, kSphPwScale, GABO_SPH_L, GABO_SPH_L* GABO_SPH_L / 2.0,
                                   GABO_SPH_L* GABO_SPH_L* GABO_SPH_L / 6.0, GABO_SPH_L* GABO_SPH_L* GABO_SPH_L* GABO_SPH_L / 24.0,
                                   6755399441055744.0};
 __device__ __forceinline__ SphPwRegs SphPwRegs::load() {
     SphPwRegs t;
     t.qmin = kSphPwC[0];
-    t.scale = kSphPwC[1];
-    t.c1 = kSphPwC[2];
-    t.c2 = kSphPwC[3];
-    t.c3 = kSphPwC[4];
-    t.c4 = kSphPwC[5];
-    t.magic = kSphPwC[6];
-    asm volatile("" : "+s"(t.qmin), "+s"(t.scale), "+s"(t.c1), "+s"(t.c2), "+s"(t.c3), "+s"(t.magic));
-    asm volatile("" : "+v"(t.c4));
+    t.qmax = kSphPwC[1];
+    t.scale = kSphPwC[2];
+    t.c1 = kSphPwC[3];
+    t.c2 = kSphPwC[4];
+    t.c3 = kSphPwC[5];
+    t.c4 = kSphPwC[6];
+    t.magic = kSphPwC[7];
+    asm volatile("" : "+s"(t.qmin), "+s"(t.qmax), "+s"(t.c1), "+s"(t.c2), "+s"(t.c3), "+s"(t.magic));
+    asm volatile("" : "+v"(t.c4), "+v"(t.scale));
     return t;
+}
+
+__device__ __forceinline__ double min_raw(double x, double bound_uniform) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(bound_uniform));
+    return r;
 }
 
 __device__ __forceinline__ double sphere_gauss_finish_pw(double ip, const SphPwRegs& g, const double* __restrict__ pw,
                                                          const double* __restrict__ tab) {
-    const double q = max_raw(__builtin_fma(-0.25, __builtin_fabs(ip), 0.25), g.qmin);
-    const double s = sqrt_nz_cubic(q);
-    const double magic = __hiloint2double(0x43380000, (__double2hiint(ip) >> 31) & kSphPwNeg);     // 1.5 2^52 (+ 40 for c < 0)
-    const double kf = __builtin_fma(s, g.scale, magic);
-    const double kd = kf - magic;
-    const double t = __builtin_fma(s, g.scale, -kd);
-    // the slot's eight coefficients: four ds_read_b128 (conflict-free 4 LDS cycles each; the two-address ds_read2st64_b64 the compiler
-    // merges a [coefficient][slot] layout into runs at half that rate and made the LDS pipe the bottleneck: 49 instead of 41 us)
+    const double q = min_raw(max_raw(__builtin_fma(0.5, ip, 0.5), g.qmin), g.qmax);
+    const double v = sqrt_nz_cubic(q);
+    const double kf = __builtin_fma(v, g.scale, g.magic);
+    const double kd = kf - g.magic;
+    const double t = __builtin_fma(v, g.scale, -kd);
+    // the slot's seven coefficients: three ds_read_b128 + one ds_read_b64 (conflict-free 4 / 2 LDS cycles each; the two-address
+    // ds_read2st64_b64 the compiler merges a [coefficient][slot] layout into runs at half that rate and made the LDS pipe the bottleneck:
+    // 49 instead of 41 us).  Byte offset by the 24-bit multiply: v_mul_lo_u32, which a plain `slot * 10` compiles to, is quarter rate.
     typedef double pw_v2d __attribute__((ext_vector_type(2)));
-    // (byte offset by the 24-bit multiply: v_mul_lo_u32, which a plain `slot * 10` compiles to, is a quarter-rate instruction)
-    const pw_v2d* row = reinterpret_cast<const pw_v2d*>(reinterpret_cast<const char*>(pw) +
-                                                        __umul24((unsigned)__double2loint(kf), (unsigned)(kSphPwStride * sizeof(double))));
-    static_assert(kSphPwDeg == 7, "four coefficient pairs");
-    const pw_v2d c67 = row[3], c45 = row[2], c23 = row[1], c01 = row[0];
-    double w = __builtin_fma(c67[1], t, c67[0]);
-    w = __builtin_fma(w, t, c45[1]);
+    const char* rowb = reinterpret_cast<const char*>(pw) + __umul24((unsigned)__double2loint(kf), (unsigned)(kSphPwStride * sizeof(double)));
+    const pw_v2d* row = reinterpret_cast<const pw_v2d*>(rowb);
+    static_assert(kSphPwDeg == 6, "three coefficient pairs and one single");
+    const double c6 = reinterpret_cast<const double*>(rowb)[6];
+    const pw_v2d c45 = row[2], c23 = row[1], c01 = row[0];
+    double w = __builtin_fma(c6, t, c45[1]);
     w = __builtin_fma(w, t, c45[0]);
     w = __builtin_fma(w, t, c23[1]);
     w = __builtin_fma(w, t, c23[0]);
@@ -221,7 +227,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
     if constexpr (PW) gp = SphPwRegs::load();
     else if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load<SCALED>(beta, poly);
     else mt = MathRegs::load();
-    constexpr int kPwN = kSphPwSlots * kSphPwStride, kPwFirst = (kPwN + 255) / 256;       // 800 entries: four per thread of a 256-thread block
+    constexpr int kPwN = kSphPwSlots * kSphPwStride, kPwFirst = (kPwN + 255) / 256;       // 650 entries: three per thread of a 256-thread block
     double pwv[kPwFirst];
     if constexpr (PW) {
         // the piecewise table: its first round of loads (all of it for a 256-thread block) is requested with everything else
