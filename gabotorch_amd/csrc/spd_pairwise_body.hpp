@@ -7,6 +7,7 @@
 #include "spd_generic.hpp"
 #include "gabo_log_tab.hpp"
 #include "gabo_exp_tab256.hpp"
+#include "gabo_acosh2_table.hpp"
 #include "../../include/gabo_hip.h"
 
 #ifndef GABO_PAIR_WAVES
@@ -263,8 +264,9 @@ constexpr double kMagicRound = 6755399441055744.0;      // 1.5 2^52
 // [0..3] ln2/256 head and tail, -256/ln2, 1/6 (exp_of_minus_tab256_magic)
 __constant__ double kExpC256[4] = {0.010830424695086549 / 4, 1.162596423439437e-12 / 4, -92.33248261689366 * 4, 1.0 / 6.0};
 
+// (round 2: the sqrt + log form, kept for A/B builds: -DGABO_GAUSS2_LOG)
 template <bool NT>
-__global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
+__global__ __launch_bounds__(256) void spd_ai_gauss2_log_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
                                                             double* __restrict__ out, int64_t n1, int64_t n2, int64_t w_batch_stride,
                                                             int64_t g_batch_stride, int rows, int col_blocks, int row_chunks,
                                                             int64_t sym_tiles, double beta, int flags) {
@@ -367,6 +369,159 @@ __global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __rest
     }
 }
 
+// ---- round 3: d = 2 Gaussian values without a square root or a logarithm per pair --------------------------------------------------
+// M = C C^T, C = W G lower triangular:  log lambda_+- = s +- delta  with  s = log sqrt(det M) = log(c00 c11) = log(w00 w11) + log(g00 g11)
+// (a sum of per-POINT terms) and delta = acosh(tau),  tau = tr M / (2 sqrt(det M)) = 1 + ((c00 - c11)^2 + c10^2) / (2 c00 c11)  (sqrt(det M) =
+// c00 c11 exactly; the numerator has no cancellation; 1 / (c00 c11) is again a product of per-point terms).  Hence
+//     d^2 = log^2 lambda_+ + log^2 lambda_- = 2 s^2 + 2 A(tau),   A(tau) = acosh(tau)^2,
+// and A is analytic on all of [1, inf) (the square removes acosh's square-root singularity at 1: A = 2u - u^2/3 + ..., u = tau - 1), so it
+// comes from a table: slot = low exponent bits + top 4 mantissa bits of tau (one bit-field extract), local variable t = tau minus tau with its lower bits cleared (exact),
+// degree 7, coefficients by four ds_read_b128 (csrc/gabo_acosh2_table.hpp, tools/sim/fit_acosh2_table.py: as accurate as the sqrt + log form,
+// 2e-15 of max(1, d^2) on the benchmark distribution).  The block's copy of the table is pre-multiplied by -512 beta / ln2 (and carries the
+// 1e-15 of spd_utils_torch.py:120 in its constant terms), the per-point logarithms by sqrt(512 beta / ln2): Y = -s'^2 + Y_A is -beta (d^2 +
+// 1e-15) in units of ln2/256, whose exp needs no argument reduction products (Y - rint(Y) is exact).  ~36 instructions per pair where the
+// sqrt + log form had ~64.  tau >= 2^12 (eigenvalue ratio of M beyond e^18) or NaN: those lanes take acosh = log(tau + sqrt(tau^2 - 1)) from OCML
+// behind a wave-uniform branch.
+constexpr double kGauss2L = 0.0027076061740622863;      // ln2 / 256
+// [0..3] l^k / k! (k = 1..4), [4] 1.5 2^52, [5] 2^12
+__constant__ double kGauss2C[6] = {kGauss2L, kGauss2L * kGauss2L / 2.0, kGauss2L * kGauss2L * kGauss2L / 6.0,
+                                   kGauss2L * kGauss2L * kGauss2L * kGauss2L / 24.0, 6755399441055744.0, 4096.0};
+
+template <bool NT>
+__global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
+                                                            double* __restrict__ out, int64_t n1, int64_t n2, int64_t w_batch_stride,
+                                                            int64_t g_batch_stride, int rows, int col_blocks, int row_chunks,
+                                                            int64_t sym_tiles, double beta, int flags) {
+    __shared__ __attribute__((aligned(16))) double ltab[512];
+    __shared__ double etab[256];
+    __shared__ __attribute__((aligned(16))) double atab[kAcosh2Slots * kAcosh2Stride];
+    __shared__ __attribute__((aligned(16))) double wrow[64 * 6];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 512; k += blockDim.x) ltab[k] = kLogTab[k];
+    for (int k = tid; k < 256; k += blockDim.x) etab[k] = kExp2Tab256[k];
+    {
+        const double sc = beta * (-512.0 / 0.69314718055994530942), eps = beta * (-256.0 / 0.69314718055994530942) * 1e-15;
+        // (rows 176..239 of the table are unused - binades 12..15 - and never read by a lane whose value is kept)
+        constexpr int kUsedLo = (kAcosh2Binades - 1) * 16 * kAcosh2Stride, kUsedHi = 240 * kAcosh2Stride;
+        for (int k = tid; k < kAcosh2Slots * kAcosh2Stride - (kUsedHi - kUsedLo); k += blockDim.x) {
+            const int kk = k < kUsedLo ? k : k + (kUsedHi - kUsedLo);
+            const double v = kAcosh2Tab[kk] * sc;
+            atab[kk] = (kk % kAcosh2Stride == 0) ? v + eps : v;
+        }
+    }
+    int64_t cg, rc, b;
+    if (flags & GABO_SYMMETRIC) {       // see spd_ai_pairwise_kernel
+        const int64_t per_batch = sym_tiles;
+        b = blockIdx.x / per_batch;
+        int64_t t = blockIdx.x - b * per_batch;
+        cg = 0;
+        for (;;) {
+            int64_t cnt = ((cg + 1) * (int64_t)blockDim.x + rows - 1) / rows;
+            if (cnt > row_chunks) cnt = row_chunks;
+            if (t < cnt) break;
+            t -= cnt;
+            ++cg;
+        }
+        rc = t;
+    } else {
+        const int64_t bid = blockIdx.x;
+        cg = bid % col_blocks;
+        rc = (bid / col_blocks) % row_chunks;
+        b = bid / ((int64_t)col_blocks * row_chunks);
+    }
+    const int64_t j0 = cg * blockDim.x;
+    const int64_t j = j0 + tid;
+    const int64_t jc = j < n2 ? j : n2 - 1;
+    const int64_t i0 = rc * rows;
+    const int64_t i1 = (i0 + rows < n1) ? i0 + rows : n1;
+    const double* Gj = G + b * g_batch_stride + jc;
+    const double g00 = Gj[0], g10 = Gj[n2], g11 = Gj[2 * n2];
+    const LogTabRegs lr = LogTabRegs::load();
+    const double sscale = __builtin_sqrt(beta * (512.0 / 0.69314718055994530942));
+    // the block's rows of W with their per-point terms: thread r prepares row i0 + r (rows <= 64), everybody reads them back from LDS with a
+    // wave-uniform address (a broadcast: no VALU instruction, no scalar-memory round trip per row)
+    double w0l = 1.0, w1l = 0.0, w2l = 1.0;
+    if (tid < rows) {
+        int64_t ir = i0 + tid;
+        ir = ir < n1 ? ir : n1 - 1;
+        const double* Wr = Winv + b * w_batch_stride + ir * 3;
+        w0l = Wr[0], w1l = Wr[1], w2l = Wr[2];
+    }
+    __syncthreads();                                     // the tables
+    if (tid < rows) {
+        const double dw = w0l * w2l;
+        wrow[6 * tid + 0] = w0l;
+        wrow[6 * tid + 1] = w1l;
+        wrow[6 * tid + 2] = w2l;
+        wrow[6 * tid + 3] = sscale * log_tab(dw, lr, ltab);      // sqrt(512 beta / ln2) log(w00 w11)
+        wrow[6 * tid + 4] = rcp(dw);                             // 1 / (w00 w11)
+    }
+    __syncthreads();
+    if ((flags & GABO_SYMMETRIC) && j0 + (int64_t)(tid | 63) < i0) return;
+    double ec[6];
+    static_for<6>([&](auto k) { ec[decltype(k)::value] = kGauss2C[decltype(k)::value]; });
+    double c4v = ec[3];
+    asm volatile("" : "+v"(c4v));
+    const double dg = g00 * g11;
+    const double bcol = sscale * log_tab(dg, lr, ltab);       // the lane's column terms
+    const double icol = 0.5 * rcp(dg);
+    double* orow = out + b * n1 * n2 + i0 * n2 + j;
+    const int nrows = (int)(i1 - i0);
+    // x1 is x2: row r of the block is stored by the lanes with i0 + r <= j
+    const int64_t jrel = j - i0;
+    const int rmax = j >= n2 ? -1 : ((flags & GABO_SYMMETRIC) ? (jrel < 0 ? -1 : (jrel > 63 ? 63 : (int)jrel)) : 63);
+    typedef double g2_v2d __attribute__((ext_vector_type(2)));
+    for (int r = 0; r < nrows; ++r, orow += n2) {
+        const g2_v2d wa = *reinterpret_cast<const g2_v2d*>(wrow + 6 * r);
+        const g2_v2d wb = *reinterpret_cast<const g2_v2d*>(wrow + 6 * r + 2);
+        const double irow = wrow[6 * r + 4];
+        const double w0 = wa[0], w1 = wa[1], w2 = wb[0], arow = wb[1];
+        const double c00 = w0 * g00, c11 = w2 * g11;
+        const double c10 = __builtin_fma(w1, g00, w2 * g10);
+        const double dd = c00 - c11;
+        const double num = __builtin_fma(dd, dd, c10 * c10);
+        const double tau = __builtin_fma(num, irow * icol, 1.0);
+        const unsigned hi = (unsigned)__double2hiint(tau);
+        // row of the table: bits 16..23 of the high word (in range by construction: one v_bfe_u32, no bias subtraction, and the four reads
+        // share one address register with immediate offsets)
+        static_assert(kAcosh2MBits == 4 && kAcosh2Slots == 256, "row index = 8 bits");
+        const unsigned off = __umul24((hi >> 16) & 0xffu, (unsigned)(kAcosh2Stride * sizeof(double)));
+        const double t = tau - __hiloint2double((int)(hi & ~((1u << (20 - kAcosh2MBits)) - 1u)), 0);
+        const g2_v2d* row = reinterpret_cast<const g2_v2d*>(reinterpret_cast<const char*>(atab) + off);
+        static_assert(kAcosh2Deg == 7, "four coefficient pairs");
+        const g2_v2d c67 = row[3], c45 = row[2], c23 = row[1], c01 = row[0];
+        double ya = __builtin_fma(c67[1], t, c67[0]);
+        ya = __builtin_fma(ya, t, c45[1]);
+        ya = __builtin_fma(ya, t, c45[0]);
+        ya = __builtin_fma(ya, t, c23[1]);
+        ya = __builtin_fma(ya, t, c23[0]);
+        ya = __builtin_fma(ya, t, c01[1]);
+        ya = __builtin_fma(ya, t, c01[0]);
+        if (__builtin_expect(__any(!(tau < ec[5])), 0)) {
+            if (!(tau < ec[5])) {       // beyond the table (or NaN): acosh from OCML
+                const double dl = log(tau + __builtin_sqrt(__builtin_fma(tau, tau, -1.0)));
+                ya = -(sscale * sscale) * __builtin_fma(dl, dl, 0.5e-15);
+            }
+        }
+        const double sp = arow + bcol;
+        const double y = __builtin_fma(-sp, sp, ya);           // -beta (d^2 + 1e-15) 256 / ln2  (spd_utils_torch.py:120, kernels_spd.py:94-98)
+        const double km = y + ec[4];
+        const double kk = km - ec[4];
+        const double rr = y - kk;
+        double p = __builtin_fma(rr, c4v, ec[2]);
+        p = __builtin_fma(p, rr, ec[1]);
+        p = __builtin_fma(p, rr, ec[0]);
+        p = p * rr;
+        const int ki = __double2loint(km);
+        const double e = etab[ki & 255];
+        const double val = __builtin_ldexp(__builtin_fma(e, p, e), ki >> 8);
+        if (r <= rmax) {
+            if constexpr (NT) __builtin_nontemporal_store(val, orow);
+            else *orow = val;
+        }
+    }
+}
+
 template <int D>
 static int launch_spd_ai(const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
                          int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st) {
@@ -393,7 +548,13 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
 #ifndef GABO_PAIR_ROWS
 #define GABO_PAIR_ROWS (D >= 9 ? 8 : 16)
 #endif
-    int rows = D == 2 ? GABO_PAIR_ROWS_D2 : GABO_PAIR_ROWS;
+    // the d = 2 Gaussian kernel copies a 20 KB table into LDS per block: 64 rows per block amortise it (N = 4096: 16 / 32 / 64 rows = 46.5 / 42.4 /
+    // 40.7 us including the prep launch)
+#ifndef GABO_PAIR_ROWS_GAUSS2
+#define GABO_PAIR_ROWS_GAUSS2 64
+#endif
+    const bool gauss2 = D == 2 && (flags & GABO_OUT_MASK) == GABO_OUT_GAUSSIAN && !dist_out && beta >= 0.0;
+    int rows = D == 2 ? (gauss2 ? GABO_PAIR_ROWS_GAUSS2 : GABO_PAIR_ROWS_D2) : GABO_PAIR_ROWS;
     while (rows > 1 && col_blocks * ((n1 + rows - 1) / rows) * batch < (rows > 16 ? 1024 : 4096)) rows >>= 1;
     int64_t row_chunks = (n1 + rows - 1) / rows;
     int64_t sym_tiles = 0;
@@ -407,16 +568,21 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
     if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
     bool special2 = false;
 #ifndef GABO_PAIR_NO_GAUSS2
-    if constexpr (D == 2) special2 = (flags & GABO_OUT_MASK) == GABO_OUT_GAUSSIAN && !dist_out && rows <= 64 && beta >= 0.0;
+    if constexpr (D == 2) special2 = gauss2 && rows <= 64;
 #endif
     if (special2) {
         const bool streaming = batch * n1 * n2 * 8 > (32ll << 20) && !(flags & GABO_SYMMETRIC);      // beyond the L2 caches (see sphere_pairwise.hip)
+#ifdef GABO_GAUSS2_LOG
+#define GABO_GAUSS2_KERNEL spd_ai_gauss2_log_kernel
+#else
+#define GABO_GAUSS2_KERNEL spd_ai_gauss2_kernel
+#endif
         if (streaming)
-            hipLaunchKernelGGL((spd_ai_gauss2_kernel<true>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
+            hipLaunchKernelGGL((GABO_GAUSS2_KERNEL<true>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
                                (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks, (int)row_chunks,
                                sym_tiles, beta, flags);
         else
-            hipLaunchKernelGGL((spd_ai_gauss2_kernel<false>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
+            hipLaunchKernelGGL((GABO_GAUSS2_KERNEL<false>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
                                (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks, (int)row_chunks,
                                sym_tiles, beta, flags);
     } else

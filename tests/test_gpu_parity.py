@@ -121,6 +121,18 @@ def test_spd_ai_gaussian_d2_kernel():
     illv = ospd.symmetric_matrix_to_vector_mandel(0.5 * (ill + ill.transpose(0, 2, 1)))
     got = ops.spd_ai_pairwise(t(a), t(illv), beta=0.01).cpu().numpy()
     np.testing.assert_allclose(got, ospd.spd_ai_gaussian_kernel(a, illv, 0.01), rtol=1e-6, atol=1e-300)
+    # tau = cosh(delta) beyond the kernel's acosh^2 table (eigenvalue ratio of M beyond e^18: tau >= 2^12) - the lanes that leave the table take
+    # acosh from log + sqrt behind a wave-uniform branch; mixed with ordinary pairs in the same wave.  Well-conditioned by construction
+    # (diagonal matrices: the Cholesky factors are exact), so the comparison is tight
+    lam = np.exp(np.concatenate([rng.uniform(-14, 14, (40, 2)), rng.uniform(-1, 1, (40, 2))]))
+    far = np.zeros((80, 3))
+    far[:, 0], far[:, 1] = lam[:, 0], lam[:, 1]
+    eye = np.tile(np.array([[1.0, 1.0, 0.0]]), (5, 1))
+    want = np.exp(-0.003 * (np.log(lam[:, 0]) ** 2 + np.log(lam[:, 1]) ** 2 + 1e-15))
+    assert float(np.max(np.abs(np.log(lam[:40, 0] / lam[:40, 1])))) > 20          # delta > 10: far outside the table
+    got = ops.spd_ai_pairwise(t(eye), t(far), beta=0.003).cpu().numpy()
+    np.testing.assert_allclose(got, np.broadcast_to(want, (5, 80)), rtol=1e-12, atol=0)
+    np.testing.assert_allclose(got, ospd.spd_ai_gaussian_kernel(eye, far, 0.003), rtol=1e-9, atol=0)
 
 
 def test_spd_ai_shapes_batches_and_edges():
