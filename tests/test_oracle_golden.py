@@ -180,3 +180,20 @@ def test_nested_sphere_reconstruction_cost(golden):
     h = 1e-6
     num = [(cost(g["ns_r"] + h * np.eye(2)[k]) - cost(g["ns_r"] - h * np.eye(2)[k])) / (2 * h) for k in range(2)]
     np.testing.assert_allclose(num, g["ns_grad"], rtol=1e-6)
+
+
+def test_gp_oracle_against_the_ei_fixture(golden):
+    """oracle/gp.py (GP posterior + expected improvement) on oracle/spd.py's kernel against -EI as make_golden_ei_optimum.py states it in torch
+    on the reference's `affine_invariant_distance_torch`: at the 32 starts and at the reference solver's 32 end points."""
+    from oracle import gp as ogp
+    g = golden("ei_optimum.npz")
+    beta = float(g["beta"])
+    np.testing.assert_allclose(g["mandel_check"], ospd.symmetric_matrix_to_vector_mandel(g["X"][:1])[0], rtol=0, atol=1e-15)
+    kxx = ospd.spd_ai_gaussian_kernel(g["Xv"], g["Xv"], beta)
+    for pts, want in ((g["x0"], g["f0"]), (g["x"], g["f"])):
+        v = ospd.symmetric_matrix_to_vector_mandel(pts)
+        ks = ospd.spd_ai_gaussian_kernel(v, g["Xv"], beta)
+        ei = ogp.expected_improvement(*ogp.gp_posterior(kxx, ks, np.exp(-beta * 1e-15) * np.ones(len(v)), g["y"], float(g["mean"]),
+                                                        float(g["outputscale"]), float(g["noise"])), best_f=float(g["best_f"]), maximize=False)
+        np.testing.assert_allclose(-ei, want, rtol=2e-7, atol=1e-12)
+    assert int(g["best"]) == int(np.argmin(g["f"])) and (g["nit"] == 100).sum() == 1
