@@ -11,7 +11,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
 from gabotorch_amd import manifolds, models, ops
 from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel
 from gabotorch_amd.manifold_optimization import manifold_optimize as mo
@@ -44,10 +43,10 @@ PLANS = {"single_launch_solve": ("partial", {}),
          "generic_lockstep_autograd": ("opaque", {"fused_acquisition": False})}
 
 
-def test_surrogate_matches_the_reference_cost_at_the_starts_and_optima():
+def test_surrogate_matches_the_reference_cost_at_the_starts_and_optima(golden):
     """-EI of the fixture (torch on the reference's distance function) = the acquisition through the HIP kernels, at the 32 starts and at the
     reference's 32 end points; and the numpy oracle agrees (botorch's EI formula is restated in all three places: [3P], unpinned)."""
-    g = load_golden("ei_optimum.npz")
+    g = golden("ei_optimum.npz")
     gp, acq, man = _problem(g)
     beta = float(gp.base_kernel.beta)
     assert abs(beta - float(g["beta"])) < 1e-7                           # the kernel's fp32 softplus(0) + beta_min against 0.25 + ln 2 in double
@@ -65,8 +64,8 @@ def test_surrogate_matches_the_reference_cost_at_the_starts_and_optima():
 
 
 @pytest.mark.parametrize("plan", list(PLANS))
-def test_returned_candidate_is_the_reference_best_of_restarts(plan, monkeypatch):
-    g = load_golden("ei_optimum.npz")
+def test_returned_candidate_is_the_reference_best_of_restarts(plan, monkeypatch, golden):
+    g = golden("ei_optimum.npz")
     gp, acq, man = _problem(g)
     gp.base_kernel.beta = float(g["beta"])
     R = g["x0"].shape[0]
