@@ -12,6 +12,7 @@ GABO_OK = 0
 GABO_ERR_DIM, GABO_ERR_ARG, GABO_ERR_NOT_SPD, GABO_ERR_LAUNCH = -1, -2, -3, -4
 GABO_OUT_GAUSSIAN, GABO_OUT_DISTANCE, GABO_OUT_LAPLACE, GABO_SYMMETRIC = 0, 1, 2, 4
 GABO_SPD_REG_MAX_DIM = 12
+GABO_SPD_BWD_REG_MAX_DIM = 16
 GABO_SPD_FWD_REG_MAX_DIM = 20
 GABO_SPD_MAX_DIM = 32
 (GABO_SPD_EXP, GABO_SPD_LOG, GABO_SPD_INNER, GABO_SPD_NORM, GABO_SPD_DIST, GABO_SPD_EGRAD2RGRAD, GABO_SPD_EHESS2RHESS,

@@ -170,7 +170,16 @@ static int launch_spd_ai_backward(const double* x1, const double* x2, const doub
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
+// d = 12 ... 16: two lanes per pair (spd_backward_duo.hip)
+int launch_spd_ai_backward_duo(int d, const double* x1, const double* x2, const double* gout, double* gx, int64_t batch, int64_t n1, int64_t n2,
+                               int64_t s1, int64_t s2, int64_t go_sb, int64_t go_si, int64_t go_sj, double beta, int flags, double* ws, int* status,
+                               hipStream_t st);
+
 }  // namespace gabo
+
+#ifndef GABO_BWD_DUO_MIN_DIM
+#define GABO_BWD_DUO_MIN_DIM 12    /* two lanes per pair from here (d = 12: 22.9 against 24.3 ms; below, the one-lane kernel is faster: spd_backward_duo.hip) */
+#endif
 
 extern "C" int gabo_spd_ai_backward(const double* x1, const double* x2, const double* grad_out, double* grad_x1, int64_t batch,
                                     int64_t n1, int64_t n2, int d, int64_t x1_batch_stride, int64_t x2_batch_stride,
@@ -185,6 +194,11 @@ extern "C" int gabo_spd_ai_backward(const double* x1, const double* x2, const do
     if (flags & GABO_SYMMETRIC) return GABO_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     double* ws = (double*)workspace;
+#ifndef GABO_ONLY_DIM
+    if (d >= GABO_BWD_DUO_MIN_DIM && d <= GABO_SPD_BWD_REG_MAX_DIM)
+        return gabo::launch_spd_ai_backward_duo(d, x1, x2, grad_out, grad_x1, batch, n1, n2, x1_batch_stride, x2_batch_stride, go_batch_stride,
+                                                go_row_stride, go_col_stride, beta, flags, ws, status, st);
+#endif
     if (d > GABO_SPD_REG_MAX_DIM)
         return gabo::launch_spd_ai_backward_generic(x1, x2, grad_out, grad_x1, batch, n1, n2, d, x1_batch_stride, x2_batch_stride,
                                                     go_batch_stride, go_row_stride, go_col_stride, beta, flags, ws, status, st);

@@ -16,9 +16,10 @@ namespace gabo {
 
 // m: packed lower triangle (destroyed).  Out: dg (diagonal), e (signed sub-diagonal, e[D-1] = 0) of T = Q^T M Q and z = Q
 // (row-major D x D), Q = H_0 H_1 ... H_{D-3}.
+// First half: T = Q^T M Q with the reflectors left in the columns of m (u_k in m[k+1.., k]) and 1 / hh_k in ihh.
 template <int D>
-__device__ __forceinline__ void tridiagonalize_q(double (&m)[tri_size(D)], double (&dg)[D], double (&e)[D], double (&z)[D * D]) {
-    double ihh[D >= 3 ? D - 2 : 1];
+__device__ __forceinline__ void tridiagonalize_reflectors(double (&m)[tri_size(D)], double (&dg)[D], double (&e)[D],
+                                                          double (&ihh)[D >= 3 ? D - 2 : 1]) {
     static_for<D - 2>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
         constexpr int n = D - k - 1;  // order of the trailing block; the column below the diagonal is x_0..x_{n-1}
@@ -69,6 +70,12 @@ __device__ __forceinline__ void tridiagonalize_q(double (&m)[tri_size(D)], doubl
     }
     dg[D - 1] = m[tri(D - 1, D - 1)];
     e[D - 1] = 0.0;
+}
+
+template <int D>
+__device__ __forceinline__ void tridiagonalize_q(double (&m)[tri_size(D)], double (&dg)[D], double (&e)[D], double (&z)[D * D]) {
+    double ihh[D >= 3 ? D - 2 : 1];
+    tridiagonalize_reflectors<D>(m, dg, e, ihh);
     // z = H_0 ... H_{D-3}: identity, then the reflectors from the last to the first; H_k touches rows k+1.. only, and what has been
     // built so far is non-trivial in rows / columns >= k+2, so each step fills the block [k+1.., k+1..] (everything else stays 0 / 1
     // and folds away at compile time)
@@ -95,9 +102,10 @@ __device__ __forceinline__ void tridiagonalize_q(double (&m)[tri_size(D)], doubl
 }
 
 // Eigen-decomposition of the symmetric tridiagonal (dg, e) with the rotations accumulated into z (columns become the eigenvectors of
-// the ORIGINAL matrix when z enters as the Q of tridiagonalize_q).  Eigenvalues in dg, unordered.
-template <int D>
-__device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[D], double (&z)[D * D]) {
+// the ORIGINAL matrix when z enters as the Q of tridiagonalize_q).  Eigenvalues in dg, unordered.  ROWS: the rows of z this lane holds (all D
+// of them, or its share when several lanes split one matrix by rows: a rotation acts on two COLUMNS, so it never mixes rows).
+template <int D, int ROWS = D>
+__device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[D], double (&z)[ROWS * D]) {
     // dropping an off-diagonal e perturbs a matrix FUNCTION to first order in e / gap (the eigenvalue-only solver can be looser: a
     // symmetric function of the eigenvalues moves only to second order): |e| <= eps (|d_l| + |d_{l+1}|), the EISPACK / LAPACK
     // criterion in the form that also terminates on indefinite input (tangent vectors) with zeros on the diagonal
@@ -146,7 +154,7 @@ __device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[
                 p = s * r;
                 dg[i + 1] = g + p;
                 g = __builtin_fma(c, r, -b);
-                static_for<D>([&](auto kk) {
+                static_for<ROWS>([&](auto kk) {
                     constexpr int k = decltype(kk)::value;
                     double zi = z[k * D + i], zj = z[k * D + i + 1];
                     z[k * D + i + 1] = __builtin_fma(s, zi, c * zj);
@@ -167,6 +175,73 @@ __device__ __forceinline__ void sym_eig_reg(double (&m)[tri_size(D)], double (&l
     double sub[D];
     tridiagonalize_q<D>(m, lam, sub, v);
     tridiag_ql_vectors<D>(lam, sub, v);
+}
+
+// ---- two lanes per matrix ("duo") ----------------------------------------------------------------------------------------------------
+// Lanes 2p and 2p + 1 hold the same matrix; each keeps HALF the rows of Z (lane parity h owns rows 2 lr + h, lr = 0 .. HR - 1, HR = ceil(D / 2);
+// for odd D the last row of the odd lane is padding and stays zero).  Z is what makes the one-lane solver a 512-register kernel (D^2 doubles:
+// 200 VGPRs at d = 10, one wave per SIMD, every instruction at 8.5 instead of 4.5 cycles); halved it fits 256 registers up to d = 12 (two waves
+// per SIMD) and 512 up to d = 16.  The QL rotations - two thirds of the work - act on two columns of Z row by row, so they need no exchange at all:
+// a lane simply applies them to its rows.  The tridiagonalisation and the scalar QL recurrence run redundantly (bit-identically) in both lanes; the
+// accumulation of the reflectors needs one partner sum per (reflector, column) through a DPP swap.
+template <int D>
+struct DuoShape {
+    static constexpr int HR = (D + 1) / 2;
+};
+
+// the partner lane's value (lane ^ 1)
+__device__ __forceinline__ double duo_swap(double v) { return dpp_fetch<0xB1, 0xf>(v); }
+
+// zh[lr * D + c] = Z[2 lr + h][c]
+template <int D>
+__device__ __forceinline__ void tridiagonalize_q_duo(double (&m)[tri_size(D)], double (&dg)[D], double (&e)[D],
+                                                     double (&zh)[DuoShape<D>::HR * D], bool h) {
+    constexpr int HR = DuoShape<D>::HR;
+    double ihh[D >= 3 ? D - 2 : 1];
+    tridiagonalize_reflectors<D>(m, dg, e, ihh);
+    const double one_odd = h ? 1.0 : 0.0, one_even = h ? 0.0 : 1.0;
+    static_for<HR>([&](auto rr) {
+        constexpr int lr = decltype(rr)::value;
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            zh[lr * D + c] = (c == 2 * lr) ? one_even : ((c == 2 * lr + 1) ? one_odd : 0.0);
+        });
+    });
+    static_for_down<D - 3, 0>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int lr0 = k / 2;                      // local rows below it belong to global rows <= k for either parity
+        // this lane's entries of the reflector (zero above row k + 1: compile-time zeros fold the products away)
+        double um[HR];
+        static_for<HR - lr0>([&](auto rr) {
+            constexpr int lr = lr0 + decltype(rr)::value;
+            constexpr int re = 2 * lr, ro = 2 * lr + 1;
+            const double ue = (re >= k + 1 && re < D) ? m[tri(re < D ? re : D - 1, k)] : 0.0;
+            const double uo = (ro >= k + 1 && ro < D) ? m[tri(ro < D ? ro : D - 1, k)] : 0.0;
+            um[lr] = h ? uo : ue;
+        });
+        static_for<D - k - 1>([&](auto cc) {
+            constexpr int c = k + 1 + decltype(cc)::value;
+            double t = 0.0;
+            static_for<HR - lr0>([&](auto rr) {
+                constexpr int lr = lr0 + decltype(rr)::value;
+                t = __builtin_fma(um[lr], zh[lr * D + c], t);
+            });
+            t = (t + duo_swap(t)) * ihh[k];
+            static_for<HR - lr0>([&](auto rr) {
+                constexpr int lr = lr0 + decltype(rr)::value;
+                zh[lr * D + c] = __builtin_fma(-um[lr], t, zh[lr * D + c]);
+            });
+        });
+    });
+}
+
+// m (packed lower triangle, the same in both lanes of a pair, destroyed) = V diag(lam) V^T: eigenvalues (unordered, in both lanes) and this
+// lane's rows of V.  Every lane of the wave must call it.
+template <int D>
+__device__ __forceinline__ void sym_eig_duo(double (&m)[tri_size(D)], double (&lam)[D], double (&vh)[DuoShape<D>::HR * D], bool h) {
+    double sub[D];
+    tridiagonalize_q_duo<D>(m, lam, sub, vh, h);
+    tridiag_ql_vectors<D, DuoShape<D>::HR>(lam, sub, vh);
 }
 
 }  // namespace gabo

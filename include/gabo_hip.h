@@ -44,9 +44,10 @@ typedef void* gabo_stream_t; /* hipStream_t */
 #define GABO_METRIC_MASK 24
 
 /* SPD pairwise kernels: 2 <= d <= GABO_SPD_MAX_DIM.  The forward runs the register-resident lane-per-pair kernels (the fast path,
- * the metric) up to GABO_SPD_FWD_REG_MAX_DIM; the closed-form backward and the fused acquisition kernels up to
- * GABO_SPD_REG_MAX_DIM; larger d falls back to one wave per pair with LDS tiles. */
+ * the metric) up to GABO_SPD_FWD_REG_MAX_DIM; the closed-form backward up to GABO_SPD_BWD_REG_MAX_DIM, the fused acquisition kernels
+ * up to GABO_SPD_REG_MAX_DIM; larger d falls back to one wave per pair with LDS tiles. */
 #define GABO_SPD_REG_MAX_DIM 12
+#define GABO_SPD_BWD_REG_MAX_DIM 16   /* the closed-form backward stays register-resident up to here (two lanes per pair from d = 12) */
 #define GABO_SPD_FWD_REG_MAX_DIM 20   /* the forward kernels stay register-resident up to here (one wave per SIMD above 12) */
 #define GABO_SPD_MAX_DIM 32
 

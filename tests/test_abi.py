@@ -78,7 +78,7 @@ def test_acquisition_and_trust_region_entry_points_validate_on_the_host():
 def test_workspace_covers_both_layouts_between_the_register_limits():
     """12 < d <= 16: the forward kernels use the packed layout, the backward the wave-per-pair one - the workspace must fit either."""
     lib = _lib.load()
-    assert _lib.GABO_SPD_REG_MAX_DIM == 12 and _lib.GABO_SPD_FWD_REG_MAX_DIM == 20
+    assert _lib.GABO_SPD_REG_MAX_DIM == 12 and _lib.GABO_SPD_FWD_REG_MAX_DIM == 20 and _lib.GABO_SPD_BWD_REG_MAX_DIM == 16
     for d in (13, 16):
         t = d * (d + 1) // 2
         assert lib.gabo_spd_ai_workspace_bytes(1, 3, 50, d) == max((3 + 50) * t, 2 * 3 * d * d) * 8

@@ -41,11 +41,13 @@ def test_spd_grads_golden(golden):
         np.testing.assert_allclose(x2.grad.cpu().numpy(), o2, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(o2).max()))
 
 
-@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_REG_MAX_DIM + 1)) + [13, 16, 20])
+@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_BWD_REG_MAX_DIM + 1)) + [17, 20])
 def test_spd_backward_all_dims_vs_oracle(d):
+    """d <= 11: one lane per pair; 12 ... 16: two lanes per pair (odd d: a padded half row in the odd lane; 70 and 33 columns: a ragged last chunk of the
+    32-pair waves); above: the wave-per-pair fallback"""
     rng = np.random.default_rng(40 + d)
-    x1, x2 = rand_spd_mandel(rng, 5, d), rand_spd_mandel(rng, 70, d)
-    gup = rng.standard_normal((5, 70))
+    x1, x2 = rand_spd_mandel(rng, 5, d), rand_spd_mandel(rng, 70 if d % 3 else 33, d)
+    gup = rng.standard_normal((5, x2.shape[0]))
     got = ops.spd_ai_backward(t(x1), t(x2), t(gup), 0.8, _lib.GABO_OUT_GAUSSIAN, wrt=1).cpu().numpy()
     want, want2 = ospd.spd_ai_gaussian_kernel_grads(x1, x2, 0.8, gup)
     np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-10 * np.abs(want).max())

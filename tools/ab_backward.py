@@ -6,7 +6,7 @@ from gabotorch_amd import ops, _lib
 from tools.dev_bench import spd_set, timeit
 from oracle import spd as ospd
 tag = sys.argv[1] if len(sys.argv) > 1 else "main"
-DIMS = (10,) if tag == "prof" else (5, 8, 9, 10, 12)
+DIMS = tuple(int(v) for v in os.environ["GABO_AB_DIMS"].split(",")) if "GABO_AB_DIMS" in os.environ else ((10,) if tag == "prof" else (8, 9, 10, 11, 12))
 ops.set_error_checking(False)
 n, beta = 4096, 0.2 + float(np.log(2.0))
 for d in DIMS:

@@ -6,11 +6,11 @@ from gabotorch_amd import ops
 from tools.dev_bench import spd_set, timeit
 ops.set_error_checking(False)
 n = 4096
-for d in (2, 3, 5, 7, 10, 12, 13, 16, 20):
+for d in (2, 3, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20):
     nn = n if d <= 16 else 512          # the wave-per-pair fallback (forward d > 16, backward d > 12) is a correctness path
     x = torch.tensor(spd_set(nn, d), device="cuda")
     ms = timeit(lambda: ops.spd_ai_pairwise(x, x, beta=0.5), 5 if d > 12 else 10)
-    nb = nn if d <= 12 else 512
+    nb = nn if d <= 16 else 512      # (register-resident backward up to d = 16: two lanes per pair from d = 12)
     xb = x[:nb]
     go = torch.ones(nb, nb, dtype=torch.float64, device="cuda")
     msb = timeit(lambda: ops.spd_ai_backward(xb, xb, go, 0.5), 3)
