@@ -645,21 +645,27 @@ int gabo_frobenius_pairwise(const double* x1, const double* x2, double* out, int
     if (d < 1 || d > 64) return GABO_ERR_DIM;
     if (batch == 0 || n1 == 0 || n2 == 0) return GABO_OK;
     if (!x1 || !x2 || !out) return GABO_ERR_ARG;
-    if (batch > 65535) return GABO_ERR_ARG;
     const int threads = n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
     const int64_t col_blocks = (n2 + threads - 1) / threads;
     int rows = 64;                                    // rows per block: as many as keep >= ~2048 blocks in flight
     while (rows > 1 && col_blocks * ((n1 + rows - 1) / rows) * batch < 2048) rows >>= 1;
     const int64_t blocks = col_blocks * ((n1 + rows - 1) / rows);
     if (blocks > 0x7fffffffLL) return GABO_ERR_ARG;
-    const dim3 grid((unsigned)blocks, (unsigned)batch);
-#define GABO_FROB_LAUNCH(DS)                                                                                                     \
-    hipLaunchKernelGGL(gabo::frobenius_pairwise_kernel<DS>, grid, dim3(threads), 0, (hipStream_t)stream, x1, x2, out, n1, n2, d, \
+    // the batch rides in grid.y (<= 65535): larger t-batches (raw_samples x 1 x d candidates against one training set) go out in slices
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+        const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        const dim3 grid((unsigned)blocks, (unsigned)nb);
+        const double* x1b = x1 + b0 * x1_batch_stride;
+        const double* x2b = x2 + b0 * x2_batch_stride;
+        double* outb = out + b0 * n1 * n2;
+#define GABO_FROB_LAUNCH(DS)                                                                                                       \
+    hipLaunchKernelGGL(gabo::frobenius_pairwise_kernel<DS>, grid, dim3(threads), 0, (hipStream_t)stream, x1b, x2b, outb, n1, n2, d, \
                        x1_batch_stride, x2_batch_stride, (int)col_blocks, rows, beta, flags)
-    if (d == 1) GABO_FROB_LAUNCH(1);
-    else if (d == 2) GABO_FROB_LAUNCH(2);
-    else if (d == 3) GABO_FROB_LAUNCH(3);
-    else GABO_FROB_LAUNCH(0);
+        if (d == 1) GABO_FROB_LAUNCH(1);
+        else if (d == 2) GABO_FROB_LAUNCH(2);
+        else if (d == 3) GABO_FROB_LAUNCH(3);
+        else GABO_FROB_LAUNCH(0);
+    }
 #undef GABO_FROB_LAUNCH
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }

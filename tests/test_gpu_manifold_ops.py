@@ -89,6 +89,12 @@ def test_projection_and_log_euclid_golden(golden):
         np.testing.assert_allclose(ops.frobenius_pairwise(t(a), t(b), mode=_lib.GABO_OUT_DISTANCE).cpu().numpy(), gm[f"d{d}_frob"], rtol=1e-12)
         k = ops.frobenius_pairwise(t(a), t(b), beta=0.37).cpu().numpy()
         np.testing.assert_allclose(k, np.exp(-0.37 * gm[f"d{d}_frob"] ** 2), rtol=1e-12)
+    # a t-batch beyond the 65535 slices one launch carries (raw_samples x 1 x d candidates against a shared training set)
+    rng = np.random.default_rng(8)
+    cand, train = rng.standard_normal((70000, 1, 3)), rng.standard_normal((4, 3))
+    got = ops.frobenius_pairwise(t(cand), t(train).expand(70000, 4, 3), beta=0.5).cpu().numpy()
+    want = np.exp(-0.5 * ((cand - train[None] + 1e-15) ** 2).sum(-1))[:, None, :]
+    np.testing.assert_allclose(got, want, rtol=1e-12)
 
 
 def test_sphere_manifold_ops(golden):
