@@ -3,6 +3,7 @@
 // (spd_pairwise_generic.hip).  Every function is called by all threads of the block and ends with a barrier.
 #pragma once
 #include "gabo_device.hpp"
+#include "wave_eigh.hpp"
 
 namespace gabo {
 
@@ -96,8 +97,9 @@ static __device__ void lds_congruence(const double* A, const double* B, double* 
     lds_mm(T, A, C, d, false, true);
 }
 
-// LDS scratch (doubles) lds_jacobi needs next to the matrices: (c, s) and the index pair of up to 16 concurrent rotations (d <= 32)
-constexpr int kJacobiScratch = 48;
+// LDS scratch (doubles) the eigen-solvers need next to the matrices: lds_jacobi keeps (c, s) and the index pair of up to 16 concurrent
+// rotations there (48 doubles), wave_eigh the (u, q) pairs of a Householder step (kWaveEighScratch = 64)
+constexpr int kJacobiScratch = kWaveEighScratch;
 
 // pair (p < q) of slot s in round r of the circle-method schedule over np + 1 players (np odd); q may be the padding player
 static __device__ __forceinline__ void jacobi_pair(int r, int s, int np, int& p, int& q) {
@@ -211,6 +213,20 @@ static __device__ void lds_jacobi(double* A, double* V, double* cs, int d) {
     }
 }
 
+// Eigen-decomposition with the contract of lds_jacobi (eigenvalues on the diagonal of A, eigenvectors in the columns of V, V may be
+// null), by the faster method for the order: Jacobi up to d = 8 (QL = false), Householder + QL in the registers of the block's first
+// wave above (QL = true, kWaveEighMinDim <= d <= 32: wave_eigh.hpp).  Called by all threads of the block; ends with a barrier.
+// QL is a template parameter of the calling KERNEL (chosen by its launcher from d): wave_eigh is a 289-register function, and a kernel
+// that can reach it is allocated for it even when d is small.
+template <bool QL>
+static __device__ void lds_eigh(double* A, double* V, double* cs, int d) {
+    if constexpr (QL) {
+        if (threadIdx.x < 64) wave_eigh_any(A, V, cs, d);
+        wsync();
+    } else {
+        lds_jacobi(A, V, cs, d);
+    }
+}
 
 // F = V f(diag(A)) V^T
 static __device__ void lds_fun_from_eig(const double* A, const double* V, double* F, int d, int fn) {

@@ -9,8 +9,9 @@
 //   ehess2rhess  X sym(H) X + sym(U sym(G) X)         [3P] (problem.py:156)
 //   logm / expm / sqrtm of a symmetric matrix         spd_utils_torch.py:13-50 ; tools/multi.py:55-75
 //   lambda_max / lambda_min and their gradients       spd_constraints_utils_torch.py:17-50
-// R restarts are R independent blocks; inside a block the 64 lanes share the O(d^3) loops element-wise and the
-// eigen-decomposition is cyclic Jacobi with the rotation applied in parallel over the row/column index.
+// R restarts are R independent blocks; inside a block the lanes share the O(d^3) loops element-wise; the eigen-decomposition is the
+// parallel-ordering Jacobi of lds_linalg.hpp up to d = 4 and Householder + QL with one matrix row per lane above (wave_eigh.hpp:
+// 118 k against 634 k shader cycles at d = 20, tools/ubench_eigh.hip).
 #include "gabo_device.hpp"
 #include "lds_linalg.hpp"
 #include "spd_eigvec.hpp"
@@ -25,8 +26,9 @@ enum {
 };
 
 // a, b, c: up to three input matrix batches (n x d x d, row-major); out: n x d x d or n scalars (+ n x d x d gradient in out2)
-// THREADS = 64: one wave per matrix (the compiler drops the barriers of a single-wave workgroup); 256: four waves for d > 12
-template <int THREADS>
+// THREADS = 64: one wave per matrix (the compiler drops the barriers of a single-wave workgroup); 256: four waves for d > 12 and a
+// small batch.  QL: the eigen-solver this instantiation links (lds_eigh<QL>).
+template <int THREADS, bool QL>
 __global__ __launch_bounds__(THREADS) void spd_manifold_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
                                                           const double* __restrict__ c, const double* __restrict__ e,
                                                           double* __restrict__ out, double* __restrict__ out2, int64_t n, int d,
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(THREADS) void spd_manifold_kernel(int op, const dou
             lds_tri_inverse(M0, M2, d);          // M2 = W
             lds_congruence(M2, M1, M3, M4, d);   // M3 = W B W^T
             lds_symmetrize(M3, M5, d);
-            lds_jacobi(M3, M4, cs, d);           // M3 diag, M4 = V
+            lds_eigh<QL>(M3, M4, cs, d);           // M3 diag, M4 = V
             lds_fun_from_eig(M3, M4, M1, d, op == OP_EXP ? FN_EXP : FN_LOG);
             lds_congruence(M0, M1, M3, M4, d);   // L F L^T
             lds_symmetrize(M3, M5, d);
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(THREADS) void spd_manifold_kernel(int op, const dou
             lds_tri_inverse(M0, M2, d);
             lds_congruence(M2, M1, M3, M4, d);
             lds_symmetrize(M3, M5, d);
-            lds_jacobi(M3, M4, cs, d);
+            lds_eigh<QL>(M3, M4, cs, d);
             if (threadIdx.x == 0) {
                 double s = 0.0;
                 for (int k = 0; k < d; ++k) { double lg = log(M3[k * d + k]); s = __builtin_fma(lg, lg, s); }
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(THREADS) void spd_manifold_kernel(int op, const dou
         case OP_SQRTM: {
             lds_load(A, M0, d);
             lds_symmetrize(M0, M5, d);
-            lds_jacobi(M0, M1, cs, d);
+            lds_eigh<QL>(M0, M1, cs, d);
             lds_fun_from_eig(M0, M1, M2, d, op == OP_LOGM ? FN_LOG : (op == OP_EXPM ? FN_EXP : FN_SQRT));
             lds_store(M2, out + i * dd, d);
             if (out2) {          // hand the eigen-decomposition to gabo_spd_matfun_backward_eig: V (d x d), then the d eigenvalues
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(THREADS) void spd_manifold_kernel(int op, const dou
         case OP_EIGMIN: {  // out[i] = extreme eigenvalue, out2 = v v^T (its Euclidean gradient w.r.t. the symmetric matrix)
             lds_load(A, M0, d);
             lds_symmetrize(M0, M5, d);
-            lds_jacobi(M0, M1, cs, d);
+            lds_eigh<QL>(M0, M1, cs, d);
             int best = 0;
             for (int k = 1; k < d; ++k) {
                 bool better = op == OP_EIGMAX ? (M0[k * d + k] > M0[best * d + best]) : (M0[k * d + k] < M0[best * d + best]);
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_reg_kernel(const double* _
 }
 
 // logm of SPD matrices, Mandel in -> Mandel out (the per-point part of SpdLogEuclideanGaussianKernel, kernels_spd.py:289-305)
+template <bool QL>
 __global__ __launch_bounds__(64) void spd_logm_mandel_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t n, int d) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int dd = d * d;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_kernel(const double* __res
     const int64_t i = blockIdx.x;
     const int dv = d * (d + 1) / 2;
     lds_from_mandel(x + i * dv, M0, d);
-    lds_jacobi(M0, M1, cs, d);
+    lds_eigh<QL>(M0, M1, cs, d);
     lds_fun_from_eig(M0, M1, M2, d, FN_LOG);
     for (int e = threadIdx.x; e < dv; e += blockDim.x) {
         int k = 0;
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(256) void frobenius_pairwise_kernel(const double* _
 // F_kk = 1/l_k, Mandel in / out.  The Mandel map is an isometry, so gx is the gradient of the loss w.r.t. the Mandel
 // vector x when g is its gradient w.r.t. the Mandel vector of logm(X): what autograd through logm_torch
 // (spd_utils_torch.py:13-30) produces, without its 1/(l_k - l_l) singularity at repeated eigenvalues.
+template <bool QL>
 __global__ __launch_bounds__(64) void spd_logm_mandel_backward_kernel(const double* __restrict__ x, const double* __restrict__ g,
                                                                       double* __restrict__ gx, int64_t n, int d) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_backward_kernel(const doub
     const int dv = d * (d + 1) / 2;
     lds_from_mandel(x + i * dv, M0, d);
     lds_from_mandel(g + i * dv, M2, d);
-    lds_jacobi(M0, M1, cs, d);                  // M0 = diag(lambda), M1 = V
+    lds_eigh<QL>(M0, M1, cs, d);                  // M0 = diag(lambda), M1 = V
     lds_mm(M1, M2, M3, d, true, false);         // V^T G
     lds_mm(M3, M1, M2, d, false, false);        // V^T G V
     for (int e = threadIdx.x; e < dd; e += blockDim.x) {
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_backward_kernel(const doub
 // through logm_torch / sqrtm_torch (spd_utils_torch.py:13-50) computes, in the form that stays finite at repeated eigenvalues.
 // eig != nullptr: the eigen-decomposition saved by the forward launch (n x (d^2 + d): V, then the eigenvalues) replaces the Jacobi
 // solve of `a`, which is most of this kernel's time.
-template <int THREADS>
+template <int THREADS, bool QL>
 __global__ __launch_bounds__(THREADS) void spd_matfun_backward_kernel(const double* __restrict__ a, const double* __restrict__ eig,
                                                                  const double* __restrict__ g, double* __restrict__ out, int64_t n,
                                                                  int d, int fn) {
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(THREADS) void spd_matfun_backward_kernel(const doub
     } else {
         lds_load(a + i * dd, M0, d);
         lds_symmetrize(M0, M3, d);
-        lds_jacobi(M0, M1, cs, d);              // M0 = diag(lambda), M1 = V
+        lds_eigh<QL>(M0, M1, cs, d);              // M0 = diag(lambda), M1 = V
     }
     lds_mm(M1, M2, M3, d, true, false);         // V^T G
     lds_mm(M3, M1, M2, d, false, false);        // V^T G V
@@ -592,11 +596,15 @@ int gabo_spd_manifold_op(int op, const double* a, const double* b, const double*
     if (op == gabo::OP_EHESS2RHESS && !e) return GABO_ERR_ARG;
     if (n > 0x7fffffffLL) return GABO_ERR_ARG;
     size_t lds = (size_t)(6 * d * d + gabo::kJacobiScratch) * sizeof(double);
-    if (d > 12)
-        hipLaunchKernelGGL(gabo::spd_manifold_kernel<256>, dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
+    // four waves per matrix only share the O(d^3) products (the eigen-solve is one wave's): worth it for a few matrices, not for thousands
+    if (d > 12 && n < 1024)
+        hipLaunchKernelGGL((gabo::spd_manifold_kernel<256, true>), dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
+                       d, status);
+    else if (d >= gabo::kWaveEighMinDim)
+        hipLaunchKernelGGL((gabo::spd_manifold_kernel<64, true>), dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
                        d, status);
     else
-        hipLaunchKernelGGL(gabo::spd_manifold_kernel<64>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
+        hipLaunchKernelGGL((gabo::spd_manifold_kernel<64, false>), dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, op, a, b, c, e, out, out2, n,
                        d, status);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
@@ -635,7 +643,10 @@ int gabo_spd_logm_mandel(const double* x_mandel, double* y_mandel, int64_t n, in
         return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
     }
     size_t lds = (size_t)(3 * d * d + gabo::kJacobiScratch) * sizeof(double);
-    hipLaunchKernelGGL(gabo::spd_logm_mandel_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel, y_mandel, n, d);
+    if (d >= gabo::kWaveEighMinDim)
+        hipLaunchKernelGGL(gabo::spd_logm_mandel_kernel<true>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel, y_mandel, n, d);
+    else
+        hipLaunchKernelGGL(gabo::spd_logm_mandel_kernel<false>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel, y_mandel, n, d);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
@@ -676,8 +687,12 @@ int gabo_spd_logm_mandel_backward(const double* x_mandel, const double* grad_y, 
     if (n < 0 || (n > 0 && (!x_mandel || !grad_y || !grad_x))) return GABO_ERR_ARG;
     if (n == 0) return GABO_OK;
     size_t lds = (size_t)(4 * d * d + gabo::kJacobiScratch) * sizeof(double);
-    hipLaunchKernelGGL(gabo::spd_logm_mandel_backward_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel,
-                       grad_y, grad_x, n, d);
+    if (d >= gabo::kWaveEighMinDim)
+        hipLaunchKernelGGL(gabo::spd_logm_mandel_backward_kernel<true>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel,
+                           grad_y, grad_x, n, d);
+    else
+        hipLaunchKernelGGL(gabo::spd_logm_mandel_backward_kernel<false>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_mandel,
+                           grad_y, grad_x, n, d);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
@@ -688,11 +703,14 @@ int gabo_spd_matfun_backward(int op, const double* a, const double* grad_out, do
     if (n == 0) return GABO_OK;
     const int fn = op == GABO_SPD_LOGM ? gabo::FN_LOG : (op == GABO_SPD_EXPM ? gabo::FN_EXP : gabo::FN_SQRT);
     size_t lds = (size_t)(4 * d * d + gabo::kJacobiScratch) * sizeof(double);
-    if (d > 12)
-        hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel<256>, dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, a, (const double*)nullptr,
+    if (d > 12 && n < 1024)
+        hipLaunchKernelGGL((gabo::spd_matfun_backward_kernel<256, true>), dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, a, (const double*)nullptr,
+                       grad_out, grad_a, n, d, fn);
+    else if (d >= gabo::kWaveEighMinDim)
+        hipLaunchKernelGGL((gabo::spd_matfun_backward_kernel<64, true>), dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, a, (const double*)nullptr,
                        grad_out, grad_a, n, d, fn);
     else
-        hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel<64>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, a, (const double*)nullptr,
+        hipLaunchKernelGGL((gabo::spd_matfun_backward_kernel<64, false>), dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, a, (const double*)nullptr,
                        grad_out, grad_a, n, d, fn);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
@@ -705,11 +723,12 @@ int gabo_spd_matfun_backward_eig(int op, const double* eig, const double* grad_o
     if (n == 0) return GABO_OK;
     const int fn = op == GABO_SPD_LOGM ? gabo::FN_LOG : (op == GABO_SPD_EXPM ? gabo::FN_EXP : gabo::FN_SQRT);
     size_t lds = (size_t)(4 * d * d + gabo::kJacobiScratch) * sizeof(double);
+    // (the eigen-decomposition is handed over: no solver in this launch, the Jacobi instantiation is the small one)
     if (d > 12)
-        hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel<256>, dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, (const double*)nullptr,
+        hipLaunchKernelGGL((gabo::spd_matfun_backward_kernel<256, false>), dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, (const double*)nullptr,
                        eig, grad_out, grad_a, n, d, fn);
     else
-        hipLaunchKernelGGL(gabo::spd_matfun_backward_kernel<64>, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, (const double*)nullptr,
+        hipLaunchKernelGGL((gabo::spd_matfun_backward_kernel<64, false>), dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, (const double*)nullptr,
                        eig, grad_out, grad_a, n, d, fn);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }

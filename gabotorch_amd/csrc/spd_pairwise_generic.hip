@@ -34,7 +34,7 @@ __device__ __forceinline__ double pair_weight(double d2, double go, double beta,
 }
 
 // block = one pair (b, i, j).  BWD = false: out/dist_out.  BWD = true: atomically accumulates w_ij logm(M_ij) into S[b,i].
-template <bool BWD>
+template <bool BWD, bool QL>
 __global__ __launch_bounds__(64) void spd_pair_generic_kernel(const double* __restrict__ Wg, const double* __restrict__ x2,
                                                               double* __restrict__ out, double* __restrict__ dist_out,
                                                               const double* __restrict__ gout, double* __restrict__ S, int64_t n1,
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void spd_pair_generic_kernel(const double* __re
     lds_from_mandel(x2 + b * x2_bs + j * dv, B, d);
     lds_congruence(Wl, B, M, T, d);
     lds_symmetrize(M, T, d);
-    lds_jacobi(M, BWD ? V : nullptr, cs, d);
+    lds_eigh<QL>(M, BWD ? V : nullptr, cs, d);
     double s = 0.0;
     for (int k = 0; k < d; ++k) { double lg = log(M[k * d + k]); s = __builtin_fma(lg, lg, s); }
     const double d2 = s + 1e-15;
@@ -113,9 +113,13 @@ int launch_spd_ai_generic(const double* x1, const double* x2, double* out, doubl
     const int64_t dd = (int64_t)d * d;
     if (b1 * n1 > 0x7fffffffLL || batch * n1 * n2 > 0x7fffffffLL) return GABO_ERR_ARG;
     hipLaunchKernelGGL(spd_prep_generic_kernel, dim3((unsigned)(b1 * n1)), dim3(64), (size_t)(2 * dd) * 8, st, x1, ws, n1, s1, d, status);
-    hipLaunchKernelGGL((spd_pair_generic_kernel<false>), dim3((unsigned)(batch * n1 * n2)), dim3(64), (size_t)(5 * dd + kJacobiScratch) * 8, st, ws, x2,
-                       out, dist_out, (const double*)nullptr, (double*)nullptr, n1, n2, d, (s1 == 0) ? (int64_t)0 : n1 * dd, s2,
-                       (int64_t)0, (int64_t)0, (int64_t)0, beta, flags & ~GABO_SYMMETRIC);
+#define GABO_GENERIC_FWD(QL)                                                                                                          \
+    hipLaunchKernelGGL((spd_pair_generic_kernel<false, QL>), dim3((unsigned)(batch * n1 * n2)), dim3(64), (size_t)(5 * dd + kJacobiScratch) * 8, \
+                       st, ws, x2, out, dist_out, (const double*)nullptr, (double*)nullptr, n1, n2, d, (s1 == 0) ? (int64_t)0 : n1 * dd, \
+                       s2, (int64_t)0, (int64_t)0, (int64_t)0, beta, flags & ~GABO_SYMMETRIC)
+    if (d >= kWaveEighMinDim) GABO_GENERIC_FWD(true);
+    else GABO_GENERIC_FWD(false);
+#undef GABO_GENERIC_FWD
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
@@ -129,10 +133,15 @@ int launch_spd_ai_backward_generic(const double* x1, const double* x2, const dou
     double* S = ws + b1 * n1 * dd;
     hipLaunchKernelGGL(spd_prep_generic_kernel, dim3((unsigned)(b1 * n1)), dim3(64), (size_t)(2 * dd) * 8, st, x1, W, n1, s1, d, status);
     hipMemsetAsync(S, 0, (size_t)(batch * n1 * dd) * 8, st);
-    if (n2 > 0)
-        hipLaunchKernelGGL((spd_pair_generic_kernel<true>), dim3((unsigned)(batch * n1 * n2)), dim3(64), (size_t)(5 * dd + kJacobiScratch) * 8, st, W,
-                           x2, (double*)nullptr, (double*)nullptr, gout, S, n1, n2, d, (s1 == 0) ? (int64_t)0 : n1 * dd, s2, go_sb,
-                           go_si, go_sj, beta, flags);
+#define GABO_GENERIC_BWD(QL)                                                                                                          \
+    hipLaunchKernelGGL((spd_pair_generic_kernel<true, QL>), dim3((unsigned)(batch * n1 * n2)), dim3(64), (size_t)(5 * dd + kJacobiScratch) * 8, \
+                       st, W, x2, (double*)nullptr, (double*)nullptr, gout, S, n1, n2, d, (s1 == 0) ? (int64_t)0 : n1 * dd, s2, go_sb,    \
+                       go_si, go_sj, beta, flags)
+    if (n2 > 0) {
+        if (d >= kWaveEighMinDim) GABO_GENERIC_BWD(true);
+        else GABO_GENERIC_BWD(false);
+    }
+#undef GABO_GENERIC_BWD
     hipLaunchKernelGGL(spd_bwd_finalize_generic_kernel, dim3((unsigned)(batch * n1)), dim3(64), (size_t)(4 * dd) * 8, st, W, S, gx, d,
                        (s1 == 0) ? (int64_t)0 : n1 * dd, n1);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Wave-per-matrix eigen-solver (lds_jacobi) timings: logm of N SPD matrices by dimension.   python tools/lds_eig_bench.py"""
+"""Wave-per-matrix eigen-solver (lds_jacobi up to d = 8, wave_eigh above) timings: logm of N SPD matrices by dimension.   python tools/lds_eig_bench.py"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ from gabotorch_amd import _lib, ops                                             
 def main():
     dev = "cuda:0"
     rng = np.random.default_rng(0)
-    for d in (2, 5, 10, 16, 20, 32):
+    for d in (2, 5, 8, 9, 10, 12, 13, 16, 17, 18, 20, 21, 24, 28, 29, 32):
         for n in (32, 4096):
             q = np.linalg.qr(rng.standard_normal((n, d, d)))[0]
             m = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.1, 5.0, (n, d)), q)
