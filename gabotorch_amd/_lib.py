@@ -21,6 +21,7 @@ GABO_ACQ_EXPECTED_IMPROVEMENT, GABO_ACQ_POSTERIOR_MEAN = 0, 1
 GABO_GP_MLL_MAX_N = 160
 GABO_METRIC_AFFINE_INVARIANT, GABO_METRIC_LOG_EUCLIDEAN, GABO_METRIC_FROBENIUS = 0, 8, 16
 GABO_CONSTRAINT_MAX_EIGENVALUE, GABO_CONSTRAINT_MIN_EIGENVALUE = 0, 1
+GABO_RECON_AFFINE_INVARIANT, GABO_RECON_LOG_EUCLIDEAN = 0, 1
 GABO_SPH_PROJ, GABO_SPH_RETR, GABO_SPH_EXP, GABO_SPH_LOG, GABO_SPH_DIST, GABO_SPH_EHESS2RHESS = range(6)
 
 _ERR = {GABO_ERR_DIM: "unsupported dimension", GABO_ERR_ARG: "bad argument", GABO_ERR_NOT_SPD: "input is not SPD",
@@ -88,6 +89,9 @@ SIGNATURES = {
     "gabo_sphere_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _I64, _I, _P]),
     "gabo_mandel_to_matrix": (_I, [_P, _P, _I64, _I, _P]),
     "gabo_matrix_to_mandel": (_I, [_P, _P, _I64, _I, _P]),
+    "gabo_nested_spd_reconstruction_workspace_bytes": (_SZ, [_I64, _I64, _I, _I]),
+    "gabo_nested_spd_reconstruction_prepare": (_I, [_P, _P, _I64, _I, _I, _P, _P]),
+    "gabo_nested_spd_reconstruction": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _SZ, _P]),
 }
 
 _lib = None

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(THREADS) void spd_manifold_kernel(int op, const dou
             lds_congruence(M2, M1, M3, M4, d);   // M3 = W B W^T
             lds_symmetrize(M3, M5, d);
             lds_eigh<QL>(M3, M4, cs, d);           // M3 diag, M4 = V
-            lds_fun_from_eig(M3, M4, M1, d, op == OP_EXP ? FN_EXP : FN_LOG);
+            lds_fun_from_eig(M3, M4, M1, d, op == OP_EXP ? FN_EXP : FN_LOG, cs);
             lds_congruence(M0, M1, M3, M4, d);   // L F L^T
             lds_symmetrize(M3, M5, d);
             lds_store(M3, out + i * dd, d);
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(THREADS) void spd_manifold_kernel(int op, const dou
             lds_load(A, M0, d);
             lds_symmetrize(M0, M5, d);
             lds_eigh<QL>(M0, M1, cs, d);
-            lds_fun_from_eig(M0, M1, M2, d, op == OP_LOGM ? FN_LOG : (op == OP_EXPM ? FN_EXP : FN_SQRT));
+            lds_fun_from_eig(M0, M1, M2, d, op == OP_LOGM ? FN_LOG : (op == OP_EXPM ? FN_EXP : FN_SQRT), cs);
             lds_store(M2, out + i * dd, d);
             if (out2) {          // hand the eigen-decomposition to gabo_spd_matfun_backward_eig: V (d x d), then the d eigenvalues
                 double* eg = out2 + i * (dd + d);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_kernel(const double* __res
     const int dv = d * (d + 1) / 2;
     lds_from_mandel(x + i * dv, M0, d);
     lds_eigh<QL>(M0, M1, cs, d);
-    lds_fun_from_eig(M0, M1, M2, d, FN_LOG);
+    lds_fun_from_eig(M0, M1, M2, d, FN_LOG, cs);
     for (int e = threadIdx.x; e < dv; e += blockDim.x) {
         int k = 0;
         while (k + 1 < d && (k + 1) * d - (k + 1) * k / 2 <= e) ++k;

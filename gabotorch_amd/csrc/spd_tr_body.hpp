@@ -199,7 +199,7 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
     } else {
         lds_load(etaw, M1, D);
         lds_jacobi(M1, M2, cs, D);
-        lds_fun_from_eig(M1, M2, M3, D, FN_EXP);
+        lds_fun_from_eig(M1, M2, M3, D, FN_EXP, cs);
     }
     lds_congruence(M0, M3, M1, M2, D);
     lds_symmetrize(M1, M2, D);

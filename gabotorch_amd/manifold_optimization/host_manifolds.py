@@ -12,7 +12,7 @@ class Euclidean:
         self.typicaldist = float(np.sqrt(self.dim))
 
     def inner(self, x, u, v):
-        return float(np.tensordot(u, v, axes=u.ndim))
+        return float(np.vdot(u, v))
 
     def norm(self, x, u):
         return float(np.linalg.norm(u))
@@ -87,7 +87,7 @@ class Grassmann:
         self.typicaldist = float(np.sqrt(p))
 
     def inner(self, x, u, v):
-        return float(np.tensordot(u, v, axes=2))
+        return float(np.vdot(u, v))
 
     def norm(self, x, u):
         return float(np.linalg.norm(u))
@@ -126,13 +126,24 @@ class PositiveDefinite:
         self._shape = (n, n)
         self.dim = n * (n + 1) // 2
         self.typicaldist = float(np.sqrt(self.dim))
+        self._inv = []                 # (bytes of x, x^-1) of the last base points: a solver asks for many inner products at one point
 
     @staticmethod
     def _sym(a):
         return 0.5 * (a + a.T)
 
+    def _inverse(self, x):
+        key = x.tobytes()
+        for k, xi in self._inv:
+            if k == key:
+                return xi
+        xi = np.linalg.inv(x)
+        self._inv = [(key, xi)] + self._inv[:2]
+        return xi
+
     def inner(self, x, u, v):
-        return float(np.tensordot(np.linalg.solve(x, u), np.linalg.solve(x, v).T, axes=2))
+        xi = self._inverse(x)                                        # tr(X^-1 U X^-1 V)
+        return float(np.vdot((xi @ u).T, xi @ v))
 
     def norm(self, x, u):
         return float(np.sqrt(max(self.inner(x, u, u), 0.0)))

@@ -1,78 +1,54 @@
 """Reconstruction parameters of the nested-SPD mapping, with the reference's names and signatures
 (BoManifolds/nested_mappings/nested_spd_optimization.py:23-186): the costs are sums of squared affine-invariant or log-Euclidean
-distances between the data and their reconstructions (HIP kernels, differentiable through the closed-form backward kernels and the
-matrix-function adjoint), minimised over  V in G(D, D-d),  C in S^(D-d)_++,  K = t * unit vector reshaped, t = sigmoid(.) in (0, 1),
-under W^T V = 0 by the augmented Lagrangian method."""
+distances between the data and their reconstructions, minimised over  V in G(D, D-d),  C in S^(D-d)_++,  K = t * unit vector reshaped,
+t = sigmoid(.) in (0, 1), under W^T V = 0 by the augmented Lagrangian method.  Both built-in costs are ONE HIP launch per evaluation,
+value and gradient together (gabo_nested_spd_reconstruction: csrc/nested_spd_reconstruction.hip)."""
 import numpy as np
 import torch
 
+from .. import _lib, ops
 from ..manifold_optimization.augmented_lagrange_method import AugmentedLagrangeMethod, _Constraint
 from ..manifold_optimization.host_manifolds import Euclidean, Grassmann, PositiveDefinite, Product, Sphere
-from ..Riemannian_utils.spd_utils_torch import affine_invariant_distance_torch, logm_torch
-from .nested_spd_utils import projection_from_nested_spd_to_spd
+
+
+def _fused_cost(metric, x_data, x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix, contraction_matrix):
+    rec = ops.NestedSpdReconstruction(x_data, x_data_projected, projection_matrix, metric)
+    return rec(projection_complement_matrix, bottom_spd_matrix, contraction_matrix)
 
 
 def min_affine_invariant_distance_reconstruction_cost(x_data, x_data_projected, projection_matrix, projection_complement_matrix,
                                                       bottom_spd_matrix, contraction_matrix):
-    """sum_n d_AI(X_n, reconstruction(Y_n))^2   (nested_spd_optimization.py:23-56).  One batched launch for the N distances."""
-    x_rec = projection_from_nested_spd_to_spd(x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix,
-                                              contraction_matrix)
-    dist = affine_invariant_distance_torch(x_data.to(x_rec.device)[:, None], x_rec[:, None])        # batch N of 1 x 1 problems
-    return torch.sum(dist * dist)
+    """sum_n d_AI(X_n, reconstruction(Y_n))^2   (nested_spd_optimization.py:23-56); differentiable in V, C, K."""
+    return _fused_cost(_lib.GABO_RECON_AFFINE_INVARIANT, x_data, x_data_projected, projection_matrix, projection_complement_matrix,
+                       bottom_spd_matrix, contraction_matrix)
 
 
 def min_log_euclidean_distance_reconstruction_cost(x_data, x_data_projected, projection_matrix, projection_complement_matrix,
                                                    bottom_spd_matrix, contraction_matrix):
-    """sum_n ||logm X_n - logm reconstruction(Y_n) + 1e-15||_F^2   (nested_spd_optimization.py:59-92)."""
-    x_rec = projection_from_nested_spd_to_spd(x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix,
-                                              contraction_matrix)
-    diff = logm_torch(x_data.to(x_rec.device)) - logm_torch(x_rec) + 1e-15
-    return torch.sum(diff * diff)
+    """sum_n ||logm X_n - logm reconstruction(Y_n) + 1e-15||_F^2   (nested_spd_optimization.py:59-92); differentiable in V, C, K."""
+    return _fused_cost(_lib.GABO_RECON_LOG_EUCLIDEAN, x_data, x_data_projected, projection_matrix, projection_complement_matrix,
+                       bottom_spd_matrix, contraction_matrix)
 
 
 def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, projection_matrix, inner_solver,
                                                   cost_function=min_affine_invariant_distance_reconstruction_cost,
                                                   nb_init_candidates=100, maxiter=50, hip_graphs=True):
     """-> (projection_complement_matrix D x (D-d), bottom_spd_matrix (D-d) x (D-d), contraction_matrix d x (D-d))
-    (nested_spd_optimization.py:95-186).  hip_graphs (extension): replay the evaluations of the two built-in costs from hipGraphs."""
+    (nested_spd_optimization.py:95-186).  The two built-in costs are served by the fused launch (the parameters stay host-resident numpy
+    arrays as in the reference; an evaluation is one pinned copy in, one launch, one copy out; the nb_init_candidates start points are ONE
+    launch); any other cost_function is differentiated by autograd, evaluation by evaluation.  hip_graphs: kept for signature compatibility."""
     dev, dt = x_data.device, torch.float64
     x_data, x_data_projected, W = x_data.to(dt), x_data_projected.to(dev, dt), projection_matrix.to(dev, dt)
     dim, latent = x_data.shape[1], W.shape[1]
-    manifold = Product([Grassmann(dim, dim - latent), PositiveDefinite(dim - latent), Sphere(latent * (dim - latent)), Euclidean(1)])
-
-    shapes = [(dim, dim - latent), (dim - latent, dim - latent), (latent * (dim - latent),), (1,)]
+    comp = dim - latent
+    manifold = Product([Grassmann(dim, comp), PositiveDefinite(comp), Sphere(latent * comp), Euclidean(1)])
+    shapes = [(dim, comp), (comp, comp), (latent * comp,), (1,)]
     sizes = [int(np.prod(sh)) for sh in shapes]
-
-    # what does not depend on the parameters is evaluated once: logm of the data (log-Euclidean cost) and sqrtm of the latent points
-    from .. import _lib, ops
-    sqrt_low = ops.spd_matrix_function(x_data_projected, _lib.GABO_SPD_SQRTM).to(dt)
-    if cost_function is min_log_euclidean_distance_reconstruction_cost:
-        log_data = logm_torch(x_data)
-
-        def data_cost(V, C, K):
-            x_rec = projection_from_nested_spd_to_spd(x_data_projected, W, V, C, K, sqrt_low=sqrt_low)
-            diff = log_data - logm_torch(x_rec) + 1e-15
-            return torch.sum(diff * diff)
-    elif cost_function is min_affine_invariant_distance_reconstruction_cost:
-        def data_cost(V, C, K):
-            x_rec = projection_from_nested_spd_to_spd(x_data_projected, W, V, C, K, sqrt_low=sqrt_low)
-            dist = affine_invariant_distance_torch(x_data[:, None], x_rec[:, None])
-            return torch.sum(dist * dist)
-    else:
-        def data_cost(V, C, K):
-            return cost_function(x_data, x_data_projected, W, V, C, K)
-
-    def cost_torch(p):
-        norm = torch.sigmoid(p[3])                                       # gpytorch Interval(0, 1).transform   (:139,155)
-        K = norm * p[2].reshape(latent, dim - latent)
-        return data_cost(p[0], p[1], K)
-
     W_host = W.cpu().numpy()
 
     class _OrthogonalityConstraint:
         """||V^T W||_F = 0 (W^T V = 0, :142-147) and its Euclidean gradient W (W^T V) / ||V^T W||_F with respect to V, in numpy: a
-        few hundred flops on a host-resident parameter (a torch CPU call here costs milliseconds of thread-pool wake-up on a
-        many-core host, a device launch a round trip)."""
+        few hundred flops on a host-resident parameter."""
 
         @staticmethod
         def cost(x):
@@ -85,92 +61,100 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
             gV = (W_host @ wtv) / value if value > 0.0 else np.zeros_like(V)
             return value, [gV] + [np.zeros(np.shape(xi)) for xi in x[1:]]
 
-    class _Evaluator:
-        """value / (value, Euclidean gradient) of fn at a point, remembering the last point: the augmented Lagrangian asks for the
-        cost and the gradient of the same point separately, and line searches only need values (no autograd graph).
-        graphs=True: an evaluation is a fixed sequence of ~40 small launches on fixed shapes (two eigen-solves, a dozen products,
-        their adjoints), so both variants are captured once into hipGraphs (torch.cuda.CUDAGraph) on a static parameter buffer and
-        replayed: one host-to-device copy, one graph launch and one read-back per evaluation instead of ~40 eager launches."""
+    def contraction(x):
+        """K = sigmoid(x[3]) * x[2] reshaped (gpytorch Interval(0, 1).transform, :139, 155) -> (K, t, unit matrix)"""
+        t = 1.0 / (1.0 + np.exp(-float(np.asarray(x[3]).reshape(-1)[0])))
+        unit = np.asarray(x[2], dtype=np.float64).reshape(latent, comp)
+        return t * unit, t, unit
 
-        def __init__(self, fn, device, graphs=False):
-            self.fn, self.device, self.key, self.value, self.grads = fn, device, None, None, None
-            self.graphs = bool(graphs) and torch.device(device).type == "cuda"
-            self._captured = {}
+    class _FusedEvaluator:
+        """value / (value, Euclidean gradient) at a point through gabo_nested_spd_reconstruction, remembering the last point (the
+        augmented Lagrangian asks for the cost and the gradient of the same point separately; line searches only need values)."""
+
+        def __init__(self, metric):
+            self.rec = ops.NestedSpdReconstruction(x_data, x_data_projected, W, metric)
+            self.key, self.value, self.grads = None, None, None
 
         def _at(self, x):
             key = b"".join(np.ascontiguousarray(p, dtype=np.float64).tobytes() for p in x)
             if key != self.key:
                 self.key, self.value, self.grads = key, None, None
 
-        def _eval(self, flat, with_grad):
-            parts = [t.reshape(sh) for t, sh in zip(torch.split(flat, sizes), shapes)]
-            if not with_grad:
-                with torch.no_grad():
-                    return self.fn(parts).reshape(1)
-            parts = [t.requires_grad_(True) for t in parts]
-            v = self.fn(parts)
-            grads = torch.autograd.grad(v, parts, allow_unused=True)
-            return torch.cat([v.detach().reshape(1)] + [torch.zeros_like(pi).reshape(-1) if g is None else g.reshape(-1)
-                                                        for g, pi in zip(grads, parts)])
-
-        def _run(self, x, with_grad):
-            host = torch.from_numpy(np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1) for p in x]))
-            if not self.graphs:
-                return self._eval(host.to(self.device), with_grad).cpu().numpy()
-            ent = self._captured.get(with_grad)
-            if ent is None:
-                previous = ops.set_error_checking(False)          # the status read-back would synchronise inside the capture
-                try:
-                    static_in = host.to(self.device)
-                    side = torch.cuda.Stream(device=self.device)
-                    side.wait_stream(torch.cuda.current_stream(self.device))
-                    with torch.cuda.stream(side):
-                        for _ in range(3):                          # warm-up outside capture (lazy caches, allocator)
-                            self._eval(static_in, with_grad)
-                    torch.cuda.current_stream(self.device).wait_stream(side)
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        out = self._eval(static_in, with_grad)
-                finally:
-                    ops.set_error_checking(previous)
-                ent = self._captured[with_grad] = (graph, static_in, out)
-            graph, static_in, out = ent
-            static_in.copy_(host)
-            graph.replay()
-            return out.cpu().numpy()
+        def many(self, xs):
+            ks = [contraction(x)[0] for x in xs]
+            return self.rec.evaluate_host(np.stack([x[0] for x in xs]), np.stack([x[1] for x in xs]), np.stack(ks), grad=False)
 
         def cost(self, x):
             self._at(x)
             if self.value is None:
-                self.value = float(self._run(x, False)[0])
+                self.value = float(self.rec.evaluate_host(x[0], x[1], contraction(x)[0], grad=False))
             return self.value
 
         def __call__(self, x):
             self._at(x)
             if self.grads is None:
-                flat = self._run(x, True)
-                self.value = float(flat[0])
-                self.grads = [a.reshape(np.shape(xi)) for a, xi in zip(np.split(flat[1:], np.cumsum(sizes)[:-1]), x)]
+                K, t, unit = contraction(x)
+                value, gV, gC, gK = self.rec.evaluate_host(x[0], x[1], K, grad=True)
+                self.value = float(value)
+                self.grads = [gV, gC, (t * gK).reshape(np.shape(x[2])), np.full(np.shape(x[3]), float(np.sum(gK * unit)) * t * (1.0 - t))]
             return self.value, self.grads
+
+    class _AutogradEvaluator:
+        """the same for a user-supplied cost_function(x_data, x_data_projected, W, V, C, K) -> 0-dim tensor: torch autograd, eager"""
+
+        def __init__(self):
+            self.key, self.value, self.grads = None, None, None
+
+        _at = _FusedEvaluator._at
+
+        def _eval(self, x, with_grad):
+            parts = [torch.tensor(np.asarray(p, dtype=np.float64).reshape(sh), device=dev, requires_grad=with_grad) for p, sh in zip(x, shapes)]
+            with torch.set_grad_enabled(with_grad):
+                K = torch.sigmoid(parts[3]) * parts[2].reshape(latent, comp)
+                v = cost_function(x_data, x_data_projected, W, parts[0], parts[1], K)
+            if not with_grad:
+                return float(v), None
+            grads = torch.autograd.grad(v, parts, allow_unused=True)
+            return float(v), [np.zeros(sh) if g is None else g.cpu().numpy().reshape(np.shape(xi)) for g, sh, xi in zip(grads, shapes, x)]
+
+        def many(self, xs):
+            return np.array([self._eval(x, False)[0] for x in xs])
+
+        def cost(self, x):
+            self._at(x)
+            if self.value is None:
+                self.value = self._eval(x, False)[0]
+            return self.value
+
+        def __call__(self, x):
+            self._at(x)
+            if self.grads is None:
+                self.value, self.grads = self._eval(x, True)
+            return self.value, self.grads
+
+    if cost_function is min_log_euclidean_distance_reconstruction_cost:
+        cost_vg = _FusedEvaluator(_lib.GABO_RECON_LOG_EUCLIDEAN)
+    elif cost_function is min_affine_invariant_distance_reconstruction_cost:
+        cost_vg = _FusedEvaluator(_lib.GABO_RECON_AFFINE_INVARIANT)
+    else:
+        cost_vg = _AutogradEvaluator()
 
     class _Problem:
         pass
     problem = _Problem()
     problem.manifold = manifold
-    builtin_cost = cost_function in (min_log_euclidean_distance_reconstruction_cost, min_affine_invariant_distance_reconstruction_cost)
-    cost_vg = _Evaluator(cost_torch, dev, graphs=hip_graphs and builtin_cost)      # (a user cost may synchronise: eager)
     problem.cost = cost_vg.cost
     problem.grad = lambda x: manifold.egrad2rgrad(x, cost_vg(x)[1])
     con_vg = _OrthogonalityConstraint()
     constraint = _Constraint(manifold, con_vg)
     constraint.cost = con_vg.cost
     cands = [manifold.rand() for _ in range(nb_init_candidates)]
-    vals = [cost_vg.cost(c) for c in cands]
+    vals = cost_vg.many(cands)                                           # best of the random starts (:158-166): one launch
     x0 = cands[int(np.argmin(vals))]
     solver = AugmentedLagrangeMethod(maxiter=maxiter, inner_solver=inner_solver, lambdas_fact=0.05)
     opt = solver.solve(problem, x=x0, eq_constraints=[constraint])
     V = torch.tensor(opt[0], dtype=dt, device=dev)
     C = torch.tensor(opt[1], dtype=dt, device=dev)
-    K = torch.sigmoid(torch.tensor(opt[3], dtype=dt, device=dev)) * torch.tensor(opt[2], dtype=dt, device=dev).reshape(latent, dim - latent)
+    K = torch.tensor(contraction(opt)[0], dtype=dt, device=dev)
     optimize_reconstruction_parameters_nested_spd.last_log = dict(solver.log, init_cost=float(np.min(vals)), final_cost=problem.cost(opt))
     return V, C, K

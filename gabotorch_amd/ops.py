@@ -405,6 +405,117 @@ def spd_matrix_function(a, op):
     return _SpdMatFun.apply(a, int(op)) if a.requires_grad else spd_manifold_op(int(op), a)
 
 
+class NestedSpdReconstruction:
+    """Reconstruction cost of the nested-SPD mapping for a FIXED data set, value and gradient in one launch
+    (gabo_nested_spd_reconstruction; nested_spd_optimization.py:23-92).  metric: _lib.GABO_RECON_LOG_EUCLIDEAN / _AFFINE_INVARIANT.
+    Built once per optimisation: logm X_n (or chol(X_n)^-1), Y_n^1/2 and the staging buffers stay on the device."""
+
+    def __init__(self, x_data, x_data_projected, projection_matrix, metric, sqrt_low=None):
+        lib = _lib.load()
+        self.metric = int(metric)
+        dev = self.device = _device_for(x_data, x_data_projected, projection_matrix)
+        X = _prep(x_data, dev).contiguous()
+        self.y = _prep(x_data_projected, dev).contiguous()
+        self.w = _prep(projection_matrix, dev).contiguous()
+        self.N, self.D, self.d = int(X.shape[0]), int(X.shape[-1]), int(self.w.shape[1])
+        self.m = self.D - self.d
+        if X.dim() != 3 or X.shape[1] != self.D or tuple(self.y.shape) != (self.N, self.d, self.d) or self.w.shape[0] != self.D:
+            raise RuntimeError(f"shapes: x_data {tuple(X.shape)}, x_data_projected {tuple(self.y.shape)}, projection_matrix {tuple(self.w.shape)}")
+        self.sqrt_y = (spd_manifold_op(_lib.GABO_SPD_SQRTM, self.y) if sqrt_low is None else _prep(sqrt_low, dev)).contiguous()
+        self.data = torch.empty_like(X)
+        status = torch.zeros(2, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.gabo_nested_spd_reconstruction_prepare(X.data_ptr(), self.data.data_ptr(), self.N, self.D, self.metric,
+                                                                  status.data_ptr(), _stream_ptr(dev)), "gabo_nested_spd_reconstruction_prepare")
+        _raise_if_not_spd(status, "gabo_nested_spd_reconstruction_prepare")
+        self.sizes = (self.D * self.m, self.m * self.m, self.d * self.m)
+        self._buffers = {}
+
+    def _staging(self, P):
+        ent = self._buffers.get(P)
+        if ent is None:
+            lib = _lib.load()
+            npar = sum(self.sizes)
+            ws = max(int(lib.gabo_nested_spd_reconstruction_workspace_bytes(P, max(self.N, 1), self.D, self.d)), 16)
+            ent = self._buffers[P] = dict(
+                host_in=torch.empty(P * npar, dtype=torch.float64).pin_memory(), dev_in=torch.empty(P * npar, dtype=torch.float64, device=self.device),
+                host_out=torch.empty(P * (1 + npar), dtype=torch.float64).pin_memory(),
+                dev_out=torch.empty(P * (1 + npar), dtype=torch.float64, device=self.device),
+                ws=torch.empty(ws, dtype=torch.uint8, device=self.device))
+        return ent
+
+    def launch(self, v, c, k, cost, gv, gc, gk, P, ws):
+        """Raw launch on contiguous fp64 device tensors (gv = gc = gk = None: values only)."""
+        lib = _lib.load()
+        ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+        with torch.cuda.device(self.device):
+            _lib.check(lib.gabo_nested_spd_reconstruction(self.data.data_ptr(), self.y.data_ptr(), self.sqrt_y.data_ptr(), self.w.data_ptr(),
+                                                          v.data_ptr(), c.data_ptr(), k.data_ptr(), cost.data_ptr(), ptr(gv), ptr(gc), ptr(gk), P,
+                                                          self.N, self.D, self.d, self.metric, ws.data_ptr(), ws.numel(), _stream_ptr(self.device)),
+                       "gabo_nested_spd_reconstruction")
+
+    def evaluate_host(self, V, C, K, grad=True):
+        """numpy in, numpy out: V (P, D, m) or (D, m), C, K likewise -> cost (P,) [, gV, gC, gK].  One pinned host-to-device copy, one
+        launch, one copy back: what an evaluation of the augmented-Lagrangian line search costs."""
+        import numpy as np
+        V, C, K = (np.asarray(a, dtype=np.float64) for a in (V, C, K))
+        single = V.ndim == 2
+        P = 1 if single else V.shape[0]
+        ent = self._staging(P)
+        nV, nC, nK = self.sizes
+        hin = ent["host_in"].numpy()
+        hin[:P * nV] = V.reshape(-1)
+        hin[P * nV:P * (nV + nC)] = C.reshape(-1)
+        hin[P * (nV + nC):] = K.reshape(-1)
+        ent["dev_in"].copy_(ent["host_in"], non_blocking=True)
+        din, dout = ent["dev_in"], ent["dev_out"]
+        v, c, k = din[:P * nV], din[P * nV:P * (nV + nC)], din[P * (nV + nC):]
+        cost = dout[:P]
+        if grad:
+            gv, gc, gk = dout[P:P + P * nV], dout[P + P * nV:P + P * (nV + nC)], dout[P + P * (nV + nC):]
+        else:
+            gv = gc = gk = None
+        self.launch(v, c, k, cost, gv, gc, gk, P, ent["ws"])
+        nout = P * (1 + nV + nC + nK) if grad else P
+        ent["host_out"][:nout].copy_(dout[:nout], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        hout = ent["host_out"].numpy()
+        costs = hout[:P].copy()
+        if not grad:
+            return costs[0] if single else costs
+        gV = hout[P:P + P * nV].reshape(V.shape).copy()
+        gC = hout[P + P * nV:P + P * (nV + nC)].reshape(C.shape).copy()
+        gK = hout[P + P * (nV + nC):nout].reshape(K.shape).copy()
+        return (costs[0] if single else costs), gV, gC, gK
+
+    def __call__(self, V, C, K):
+        """Differentiable (first order) torch form: V (D, m), C (m, m), K (d, m) tensors -> 0-dim cost."""
+        return _NestedSpdReconstructionFn.apply(self, V, C, K)
+
+
+class _NestedSpdReconstructionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rec, V, C, K):
+        dev = rec.device
+        v, c, k = (_prep(t_.detach(), dev).contiguous() for t_ in (V, C, K))
+        need = any(t_.requires_grad for t_ in (V, C, K))
+        cost = torch.empty(1, dtype=torch.float64, device=dev)
+        gv, gc, gk = (torch.empty_like(t_) for t_ in (v, c, k)) if need else (None, None, None)
+        rec.launch(v, c, k, cost, gv, gc, gk, 1, rec._staging(1)["ws"])
+        if need:
+            ctx.save_for_backward(gv, gc, gk)
+        ctx.meta = [(t_.device, t_.dtype) for t_ in (V, C, K)]
+        return cost[0].to(V.device, V.dtype)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        out = [None]
+        for grad, (dev, dt), need in zip(ctx.saved_tensors, ctx.meta, ctx.needs_input_grad[1:]):
+            out.append((grad * g.to(grad.device)).to(dev, dt) if need else None)
+        return tuple(out)
+
+
 def spd_project(x_mandel, w):
     """(..., D_vec) Mandel, w (D, dl) -> (..., dl_vec) Mandel of W^T X W."""
     lib = _lib.load()

@@ -399,6 +399,30 @@ int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm,
 int gabo_sphere_manifold_op(int op, const double* x, const double* u, const double* v, const double* w, double* out, int64_t n,
                             int dim, gabo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Reconstruction cost of the nested-SPD mapping, with its gradient, in one launch (HD-GaBO: the objective of
+ * optimize_reconstruction_parameters_nested_spd, nested_mappings/nested_spd_optimization.py:95-186).
+ * Replaces  min_affine_invariant_distance_reconstruction_cost   nested_spd_optimization.py:23-56   (metric 0)
+ *           min_log_euclidean_distance_reconstruction_cost      nested_spd_optimization.py:59-92   (metric 1)
+ *           projection_from_nested_spd_to_spd                    nested_mappings/nested_spd_utils.py:51-118
+ *           and the reference's autograd pass through them (sqrtm_torch / logm_torch: spd_utils_torch.py:13-50; symeig).
+ *
+ * cost[p] = sum_n dist(X_n, R_p [[Y_n, B_pn], [B_pn^T, C_p]] R_p^T)^2,  R_p = [W, V_p],  B_pn = Y_n^1/2 K_p C_p^1/2, with
+ *   metric 1: dist^2 = ||logm X_n - logm Xrec + 1e-15||_F^2 (the 1e-15 on every matrix entry, spd_utils_torch.py:156),
+ *   metric 0: dist^2 = sum_k log^2 lambda_k(L_n^-1 Xrec L_n^-T) + 1e-15, L_n = chol(X_n)      (spd_utils_torch.py:120).
+ * data: N x D x D, what the metric needs of the FIXED data, written by gabo_nested_spd_reconstruction_prepare from X (N x D x D):
+ *   logm X_n (metric 1) or L_n^-1 (metric 0).  y, sqrt_y: N x d x d (Y_n = W^T X_n W and its square root, e.g. GABO_SPD_SQRTM);
+ * w: D x d;  v: P x D x (D-d), c: P x (D-d) x (D-d), k: P x d x (D-d): P parameter sets evaluated by one launch (the optimiser's
+ * initial candidates; P = 1 inside the line searches).  cost: P.  grad_v / grad_c / grad_k: the Euclidean partial derivatives, same
+ * shapes as v / c / k, or all three NULL (values only).  2 <= D <= GABO_SPD_MAX_DIM, 1 <= d < D.  status: as above (prepare, metric 0).
+ */
+size_t gabo_nested_spd_reconstruction_workspace_bytes(int64_t P, int64_t N, int D, int d);
+int gabo_nested_spd_reconstruction_prepare(const double* x, double* data, int64_t N, int D, int metric, int* status, gabo_stream_t stream);
+int gabo_nested_spd_reconstruction(const double* data, const double* y, const double* sqrt_y, const double* w, const double* v,
+                                   const double* c, const double* k, double* cost, double* grad_v, double* grad_c, double* grad_k,
+                                   int64_t P, int64_t N, int D, int d, int metric, void* workspace, size_t workspace_bytes,
+                                   gabo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -346,3 +346,53 @@ def test_one_launch_likelihood_reports_indefinite_gram_matrices_as_minus_infinit
     assert float(ll) == -np.inf
     ll.backward()
     assert float(k.grad.abs().max()) == 0.0
+
+
+def test_fused_reconstruction_launch_at_config5_size():
+    """gabo_nested_spd_reconstruction at D = 20 -> d = 2 (config 5): values against the numpy oracle, gradients against the composition of
+    the separate HIP launches it replaces (projection_from_nested_spd_to_spd + logm_torch / affine_invariant_distance_torch under autograd),
+    a batch of parameter sets in one launch, and the host (numpy in / numpy out) form the optimiser uses."""
+    from gabotorch_amd import _lib, ops
+    from gabotorch_amd.nested_mappings.nested_spd_utils import projection_from_nested_spd_to_spd
+    from gabotorch_amd.Riemannian_utils import spd_utils_torch as sut
+    from oracle import spd as ospd
+    rng = np.random.default_rng(21)
+    D, d, N, P = 20, 2, 13, 3
+    m = D - d
+    X = _rand_spd(rng, N, D)
+    Rm = np.linalg.qr(rng.standard_normal((D, D)))[0]
+    W = Rm[:, :d]
+    Y = np.einsum("ab,nac,cd->nbd", W, X, W)
+    Vs = np.stack([np.linalg.qr(Rm[:, d:] + 0.05 * rng.standard_normal((D, m)))[0] for _ in range(P)])
+    Cs = _rand_spd(rng, P, m)
+    Ks = rng.standard_normal((P, d, m))
+    Ks *= (0.3 + 0.5 * rng.uniform(size=(P, 1, 1))) / np.linalg.norm(Ks, axis=(1, 2), keepdims=True)
+    T = lambda a, grad=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV, requires_grad=grad)   # noqa: E731
+    for metric, name in ((_lib.GABO_RECON_LOG_EUCLIDEAN, "le"), (_lib.GABO_RECON_AFFINE_INVARIANT, "ai")):
+        rec = ops.NestedSpdReconstruction(T(X), T(Y), T(W), metric)
+        costs, gV, gC, gK = rec.evaluate_host(Vs, Cs, Ks, grad=True)
+        np.testing.assert_allclose(rec.evaluate_host(Vs, Cs, Ks, grad=False), costs, rtol=1e-14)
+        for p in range(P):
+            np.testing.assert_allclose(costs[p], ospd.reconstruction_cost(X, Y, W, Vs[p], Cs[p], Ks[p], metric=name), rtol=1e-10)
+            V, C, K = T(Vs[p], True), T(Cs[p], True), T(Ks[p], True)
+            xr = projection_from_nested_spd_to_spd(T(Y), T(W), V, C, K)
+            if name == "le":
+                diff = sut.logm_torch(T(X)) - sut.logm_torch(xr) + 1e-15
+                ref = torch.sum(diff * diff)
+            else:
+                dist = sut.affine_invariant_distance_torch(T(X)[:, None], xr[:, None])
+                ref = torch.sum(dist * dist)
+            ref.backward()
+            np.testing.assert_allclose(costs[p], ref.item(), rtol=1e-11)
+            scale = max(float(V.grad.abs().max()), float(C.grad.abs().max()), float(K.grad.abs().max()))
+            np.testing.assert_allclose(gV[p], V.grad.cpu().numpy(), rtol=1e-8, atol=1e-9 * scale)
+            np.testing.assert_allclose(gC[p], C.grad.cpu().numpy(), rtol=1e-8, atol=1e-9 * scale)
+            np.testing.assert_allclose(gK[p], K.grad.cpu().numpy(), rtol=1e-8, atol=1e-9 * scale)
+            # single parameter set, host form and autograd form
+            c1, v1, c1g, k1 = rec.evaluate_host(Vs[p], Cs[p], Ks[p], grad=True)
+            np.testing.assert_allclose([c1], [costs[p]], rtol=1e-14)
+            np.testing.assert_allclose(v1, gV[p], rtol=1e-13, atol=1e-13 * scale)
+            V2, C2, K2 = T(Vs[p], True), T(Cs[p], True), T(Ks[p], True)
+            (3.0 * rec(V2, C2, K2)).backward()
+            np.testing.assert_allclose(K2.grad.cpu().numpy(), 3.0 * gK[p], rtol=1e-13, atol=1e-13 * scale)
+            np.testing.assert_allclose(C2.grad.cpu().numpy(), 3.0 * gC[p], rtol=1e-13, atol=1e-13 * scale)
