@@ -21,6 +21,7 @@ GABO_ACQ_EXPECTED_IMPROVEMENT, GABO_ACQ_POSTERIOR_MEAN = 0, 1
 GABO_GP_MLL_MAX_N = 160
 GABO_METRIC_AFFINE_INVARIANT, GABO_METRIC_LOG_EUCLIDEAN, GABO_METRIC_FROBENIUS = 0, 8, 16
 GABO_CONSTRAINT_MAX_EIGENVALUE, GABO_CONSTRAINT_MIN_EIGENVALUE = 0, 1
+GABO_CONSTRAINT_MAX_EIGENVALUE_NESTED, GABO_CONSTRAINT_MIN_EIGENVALUE_NESTED = 2, 3
 GABO_RECON_AFFINE_INVARIANT, GABO_RECON_LOG_EUCLIDEAN = 0, 1
 GABO_SPH_PROJ, GABO_SPH_RETR, GABO_SPH_EXP, GABO_SPH_LOG, GABO_SPH_DIST, GABO_SPH_EHESS2RHESS = range(6)
 
@@ -76,7 +77,8 @@ SIGNATURES = {
     "gabo_spd_tr_workspace_bytes": (_SZ, [_I64, _I, _I, _I64]),
     "gabo_spd_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
     "gabo_spd_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I64, _D, _D, _D, _D, _I64, _P, _P]),
-    "gabo_spd_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _SZ, _I64, _I, _D, _D, _D, _I, _I, _D, _D, _D, _D, _I64, _P, _P]),
+    "gabo_spd_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _SZ, _I64, _I, _D, _D, _D, _I, _I, _D, _D, _D, _D, _I64,
+                               _P, _P, _P, _I, _P, _P]),
     "gabo_spd_matfun_backward": (_I, [_I, _P, _P, _P, _I64, _I, _P]),
     "gabo_spd_matfun_backward_eig": (_I, [_I, _P, _P, _P, _I64, _I, _P]),
     "gabo_sphere_acq_eval": (_I, [_P, _P, _P, _P, _I64, _P]),
@@ -91,6 +93,8 @@ SIGNATURES = {
     "gabo_matrix_to_mandel": (_I, [_P, _P, _I64, _I, _P]),
     "gabo_nested_spd_reconstruction_workspace_bytes": (_SZ, [_I64, _I64, _I, _I]),
     "gabo_nested_spd_reconstruction_prepare": (_I, [_P, _P, _I64, _I, _I, _P, _P]),
+    "gabo_nested_spd_lift_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "gabo_nested_spd_extreme_eigenvalues": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _I, _P]),
     "gabo_nested_spd_reconstruction": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _SZ, _P]),
 }
 

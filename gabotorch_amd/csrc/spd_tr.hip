@@ -93,7 +93,8 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
                       const gabo_spd_acq_params* acq, int n_constraints, const int* constraint_kind, const double* constraint_bound,
                       int strict, void* workspace, size_t workspace_bytes, int64_t r, int d, double delta_cons, double theta, double kappa,
                       int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
-                      int64_t maxiter, int* status, gabo_stream_t stream) {
+                      int64_t maxiter, const double* lift_w, const double* lift_p, const double* lift_x0, int lift_dim, int* status,
+                      gabo_stream_t stream) {
     if (d < 2 || d > 8) return GABO_ERR_DIM;
     if (r < 0 || r > 0x7fffffffLL || n_constraints < 0 || n_constraints > gabo::kMaxCons || maxinner < 1 || maxiter < 1 || !acq)
         return GABO_ERR_ARG;
@@ -107,10 +108,19 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
     gabo::BuiltinCons B;
     B.n = n_constraints;
     B.strict = strict ? 1 : 0;
+    B.big_dim = lift_dim;
+    B.lift_w = lift_w;
+    B.lift_p = lift_p;
+    B.lift_x0 = lift_x0;
     for (int k = 0; k < gabo::kMaxCons; ++k) {
         B.kind[k] = k < n_constraints ? constraint_kind[k] : 0;
         B.bound[k] = k < n_constraints ? constraint_bound[k] : 0.0;
-        if (k < n_constraints && B.kind[k] != GABO_CONSTRAINT_MAX_EIGENVALUE && B.kind[k] != GABO_CONSTRAINT_MIN_EIGENVALUE) return GABO_ERR_ARG;
+        if (k < n_constraints && (B.kind[k] < GABO_CONSTRAINT_MAX_EIGENVALUE || B.kind[k] > GABO_CONSTRAINT_MIN_EIGENVALUE_NESTED)) return GABO_ERR_ARG;
+    }
+    if (gabo::builtin_has_kind(B, true)) {
+        // (the lifted dimension goes through the wave eigen-solver: kWaveEighMinDim <= lift_dim)
+        if (!lift_w || !lift_p || !lift_x0) return GABO_ERR_ARG;
+        if (lift_dim <= d || lift_dim < 5 || lift_dim > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
     }
     gabo::SolveArgs a{x, fx, grad, grad_norm, trust_radius, active, iters, acq, B, workspace, r, d, delta_cons, theta, kappa, mininner,
                       maxinner, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter, status, (hipStream_t)stream};

@@ -2,6 +2,7 @@
 #pragma once
 #include "spd_acq_body.hpp"
 #include "spd_tcg_body.hpp"
+#include "nested_spd_lift.hpp"
 
 namespace gabo {
 
@@ -32,13 +33,24 @@ static __host__ __device__ inline TrWs tr_layout(void* base, int64_t R, int d, i
 }
 
 // The constraints the library can evaluate itself (no host callable needed): extreme eigenvalues of the iterate
-// (max/min_eigenvalue_constraint_torch, spd_constraints_utils_torch.py:17-50).  kind 0: bound - lambda_max(x) >= 0, 1: lambda_min(x) - bound >= 0.
+// (max/min_eigenvalue_constraint_torch, spd_constraints_utils_torch.py:17-50) - kind 0: bound - lambda_max(x) >= 0, 1: lambda_min(x) - bound >= 0 -
+// and of the iterate LIFTED to the original space of a nested SPD mapping (max/min_eigenvalue_nested_spd_constraint,
+// nested_spd_constraints_utils.py:14-73) - kinds 2 / 3, with lift_w, lift_p (big_dim x d) and lift_x0 (big_dim x big_dim) from
+// gabo_nested_spd_lift_prepare; the wave evaluates those through nested_extremes_body in `nlds` (dynamic LDS).
 struct BuiltinCons {
     int n;
     int strict;
     int kind[kMaxCons];
     double bound[kMaxCons];
+    int big_dim;
+    const double *lift_w, *lift_p, *lift_x0;
 };
+
+static __host__ __device__ inline bool builtin_has_kind(const BuiltinCons& B, bool nested) {
+    for (int k = 0; k < B.n; ++k)
+        if ((B.kind[k] >= 2) == nested) return true;
+    return false;
+}
 
 // extreme eigenpair of the symmetric D x D matrix at `a` (row-major, global or LDS), every lane redundantly (D <= 8)
 template <int D>
@@ -53,15 +65,40 @@ __device__ __forceinline__ void eig_extremes(const double* __restrict__ a, doubl
 }
 
 // values and WHITENED Riemannian gradients of the built-in constraints at x (L = chol x already in the workspace):
-// f = bound - lambda_max: egrad = -v v^T, rgrad = x egrad x, whitened L^-1 rgrad L^-T = -(L^T v)(L^T v)^T  (and + for lambda_min - bound)
+// f = bound - lambda_max: egrad = -v v^T, rgrad = x egrad x, whitened L^-1 rgrad L^-T = -(L^T v)(L^T v)^T  (and + for lambda_min - bound);
+// nested kinds: egrad = -+ G (G = d lambda / d x from nested_extremes_body), whitened = L^T egrad L.
 template <int D>
 __device__ __forceinline__ void builtin_constraints(const double* __restrict__ x, const TcgWs& w, int64_t i, int64_t R,
-                                                    const BuiltinCons& B) {
+                                                    const BuiltinCons& B, double* nlds) {
     constexpr int dd = D * D;
+    const double* L = w.chol + i * dd;
+    if (builtin_has_kind(B, true)) {
+        const NestedExtremesOut ne = nested_extremes_body<true, (D >= kWaveEighMinDim)>(x, B.lift_w, B.lift_p, B.lift_x0, B.big_dim, D, nlds, true);
+        for (int k = 0; k < B.n; ++k) {
+            if (B.kind[k] < 2) continue;
+            const bool want_max = B.kind[k] == 2;
+            const double* G = ne.grad + (want_max ? 0 : dd);
+            const double sign = want_max ? -1.0 : 1.0;
+            if (threadIdx.x == 0) w.fc[i * B.n + k] = want_max ? B.bound[k] - ne.lam[0] : ne.lam[1] - B.bound[k];
+            double* out = w.gc_w + ((int64_t)k * R + i) * dd;
+            for (int e = threadIdx.x; e < dd; e += 64) {
+                const int r = e / D, c = e - r * D;
+                double s = 0.0;
+                for (int a = 0; a < D; ++a) {
+                    double t = 0.0;
+                    for (int b = 0; b < D; ++b) t = __builtin_fma(G[a * D + b], L[b * D + c], t);
+                    s = __builtin_fma(L[a * D + r], t, s);
+                }
+                out[e] = sign * s;
+            }
+        }
+        __syncthreads();
+    }
+    if (!builtin_has_kind(B, false)) return;
     double lam[D], v[dd];
     eig_extremes<D>(x, lam, v);
-    const double* L = w.chol + i * dd;
     for (int k = 0; k < B.n; ++k) {
+        if (B.kind[k] >= 2) continue;
         const bool want_max = B.kind[k] == 0;
         double best = lam[0];
         double vec[D];
@@ -92,7 +129,19 @@ __device__ __forceinline__ void builtin_constraints(const double* __restrict__ x
 
 // strict variant: does the proposal violate a built-in constraint?  (constrained_trust_regions.py:932-951)
 template <int D>
-__device__ __forceinline__ bool builtin_infeasible(const double* __restrict__ xp, const BuiltinCons& B) {
+__device__ __forceinline__ bool builtin_infeasible(const double* __restrict__ xp, const BuiltinCons& B, double* nlds) {
+    bool bad = false;
+    if (builtin_has_kind(B, true)) {
+        const NestedExtremesOut ne = nested_extremes_body<true, (D >= kWaveEighMinDim)>(xp, B.lift_w, B.lift_p, B.lift_x0, B.big_dim, D, nlds, false);
+        const double nmax = ne.lam[0], nmin = ne.lam[1];
+        for (int k = 0; k < B.n; ++k) {
+            if (B.kind[k] < 2) continue;
+            const double f = B.kind[k] == 2 ? B.bound[k] - nmax : nmin - B.bound[k];
+            bad = bad || (f < 0.0);
+        }
+        __syncthreads();
+    }
+    if (!builtin_has_kind(B, false)) return bad;
     double lam[D], v[D * D];
     eig_extremes<D>(xp, lam, v);
     double lmax = lam[0], lmin = lam[0];
@@ -101,8 +150,8 @@ __device__ __forceinline__ bool builtin_infeasible(const double* __restrict__ xp
         lmax = lam[c] > lmax ? lam[c] : lmax;
         lmin = lam[c] < lmin ? lam[c] : lmin;
     });
-    bool bad = false;
     for (int k = 0; k < B.n; ++k) {
+        if (B.kind[k] >= 2) continue;
         const double f = B.kind[k] == 0 ? B.bound[k] - lmax : lmin - B.bound[k];
         bad = bad || (f < 0.0);
     }
@@ -119,7 +168,8 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
                                                 const TrWs& t, double* __restrict__ x_prop, int64_t i, int64_t R, int C, int neq,
                                                 double delta_cons, double theta, double kappa, int mininner, int maxinner,
                                                 AcqLds<D>& acq, double* mats, double* dyn, int* __restrict__ status,
-                                                const BuiltinCons* builtin, bool x_unchanged = false, bool fd0_kept = false) {
+                                                const BuiltinCons* builtin, bool x_unchanged = false, bool fd0_kept = false,
+                                                double* nlds = nullptr) {
     constexpr int T = tri_size(D);
     constexpr int dd = D * D;
     const TcgWs& w = t.tcg;
@@ -134,7 +184,7 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
         // (x_unchanged: the previous proposal of this launch was rejected, so the constraint values and whitened gradients in the
         // workspace are still those of x: skip the eigen-solve)
         if (builtin != nullptr && builtin->n > 0 && !x_unchanged) {
-            builtin_constraints<D>(x, w, i, R, *builtin);
+            builtin_constraints<D>(x, w, i, R, *builtin, nlds);
             __syncthreads();
         }
     }
@@ -252,12 +302,17 @@ static inline size_t tr_dynamic_lds(int64_t n, int64_t restarts, int* stage_gp) 
 // the whole per-restart workspace (whitened tCG vectors, FD point, proposal, the logm spill: ~1 k doubles at d = 5, n = 50) can live in
 // the block's LDS instead of L2 - every phase of an iteration starts with dependent loads of that state.  Only in the latency regime and
 // when it fits next to the staged GP factors (static LDS of the kernel is below 12 KB for d <= 8).
-static inline size_t tr_solve_dynamic_lds(int64_t n, int64_t restarts, int d, int C, int* stage_gp, int* ws_lds) {
+// nested_bytes: LDS of the nested eigenvalue constraints (nested_extremes_lds_doubles), placed last; *nested_off receives its offset.
+static inline size_t tr_solve_dynamic_lds(int64_t n, int64_t restarts, int d, int C, int* stage_gp, int* ws_lds, size_t nested_bytes = 0,
+                                          int* nested_off = nullptr) {
     size_t bytes = tr_dynamic_lds(n, restarts, stage_gp);
     bytes = (bytes + 15) & ~(size_t)15;
     const size_t ws = tr_layout(nullptr, 1, d, C, n).bytes + 16;
-    *ws_lds = (restarts <= 1024 && bytes + ws <= 52 * 1024) ? 1 : 0;
-    return bytes + (*ws_lds ? ws : 0);
+    *ws_lds = (restarts <= 1024 && bytes + ws + nested_bytes <= 52 * 1024) ? 1 : 0;
+    bytes += (*ws_lds ? ws : 0);
+    bytes = (bytes + 15) & ~(size_t)15;
+    if (nested_off) *nested_off = (int)bytes;
+    return bytes + nested_bytes;
 }
 
 template <int D, int METRIC>
@@ -350,7 +405,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
                                                           BuiltinCons B, void* wsbase, int64_t R, double delta_cons, double theta,
                                                           double kappa, int mininner, int maxinner, double delta_bar, double rho_prime,
                                                           double rho_regularization, double mingradnorm, int64_t maxiter,
-                                                          int* __restrict__ status, int stage_gp, int ws_lds) {
+                                                          int* __restrict__ status, int stage_gp, int ws_lds, int nested_off) {
     static_assert(D <= 8, "built-in constraints use the register eigen-solver");
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
@@ -394,13 +449,14 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
         t = tr_layout(wsbase, R, D, C, P.n);
     }
     double* xp = t.xp_mat + iw * dd;
+    double* nlds = reinterpret_cast<double*>(reinterpret_cast<char*>(dyn) + nested_off);      // (used by nested constraint kinds only)
     bool cons_fresh = false;          // wave-uniform: the constraints in the workspace belong to the current x
     int last_inner = 0;               // tCG iterations of the previous trust-region iteration
     for (;;) {
         last_inner = tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, iw, Rw, C, 0, delta_cons, theta,
-                                                kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1);
+                                                kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1, nlds);
         __syncthreads();
-        const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B) : false;
+        const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B, nlds) : false;
         bool accepted = false;
         const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, iw, D, C, delta_bar,
                                           rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
@@ -475,8 +531,10 @@ struct SolveArgs {
 
 template <int METRIC>
 static int dispatch_solve(const SolveArgs& a) {
-    int stage_gp = 0, ws_lds = 0;
-    size_t lds = tr_solve_dynamic_lds(a.P->n, a.r, a.d, a.B.n, &stage_gp, &ws_lds);
+    int stage_gp = 0, ws_lds = 0, nested_off = 0;
+    const size_t nested_bytes = builtin_has_kind(a.B, true) ? nested_extremes_lds_doubles(a.B.big_dim, a.d) * sizeof(double) : 0;
+    size_t lds = tr_solve_dynamic_lds(a.P->n, a.r, a.d, a.B.n, &stage_gp, &ws_lds, nested_bytes, &nested_off);
+    if (lds > 64 * 1024) return GABO_ERR_ARG;
 #ifdef GABO_TR_NO_LAT    /* A/B: the runtime-flag kernel everywhere */
     const bool lat = false;
 #else
@@ -485,7 +543,7 @@ static int dispatch_solve(const SolveArgs& a) {
 #define GABO_SOLVE_LAUNCH(DD, LAT_)                                                                                                \
     hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC, LAT_>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
                        a.active, a.iters, *a.P, a.B, a.ws, a.r, a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.delta_bar, \
-                       a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds)
+                       a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds, nested_off)
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
         if (lat) GABO_SOLVE_LAUNCH(DD, true);                                                                                      \

@@ -44,11 +44,12 @@ __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// A (d x d, symmetric, row-major, LDS): on return its DIAGONAL holds the eigenvalues (unordered; the rest of A is left as it was);
-// V (d x d, LDS, may be null: eigenvalues only): eigenvectors in columns; bc: kWaveEighScratch doubles of LDS.  DP - 3 <= d <= DP.
-// Called by all 64 lanes of one wave (any other waves of the block wait at the caller's barrier).
+// Householder reduction of the padded matrix to tridiagonal form, the first half of both solvers below.  Lane r keeps row r in a[];
+// out: the tridiagonal (dg, e: wave-uniform), 1 / hh_k of the reflectors (ihh) and, when refl != null, the reflectors themselves
+// (u_k, k >= pad, entry j at refl[(k - pad) d + (j - pad)]: at most (d - 2)(d - 1) doubles of a d x d LDS matrix).
 template <int DP>
-__device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_f64* bc, int d) {
+__device__ __forceinline__ void wave_tridiagonalize(lds_f64* A, lds_f64* refl, lds_f64* bc, int d, double (&dg)[DP], double (&e)[DP],
+                                                    double (&ihh)[DP >= 3 ? DP - 2 : 1]) {
     const int lane = threadIdx.x & 63;
     const int pad = DP - d;
     const int ra = lane - pad;                           // the row of A this lane owns (lanes < pad: identity rows; lanes >= DP: idle)
@@ -60,9 +61,6 @@ __device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_
         if (own && c >= pad) v = A[ra * d + (c - pad)];
         a[c] = v;
     });
-    GABO_EIGH_TICK(0);
-    double dg[DP], e[DP], ihh[DP >= 3 ? DP - 2 : 1];
-    lds_f64* refl = V;                                    // u_k (k >= pad), entry j at refl[(k - pad) d + (j - pad)]; overwritten by Z at the end
     static_for<DP - 2>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
         if (k < pad) {                                   // wave-uniform: the identity block needs no reflector
@@ -80,7 +78,7 @@ __device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_
         const double inv_hh = hh == 0.0 ? 0.0 : rcp(hh);
         const double u = (lane == k + 1) ? alpha + copysign_d(nrm, alpha) : x;
         if (lane < DP) bc[2 * lane] = u;
-        if (V != nullptr && below) refl[(k - pad) * d + (lane - pad)] = u;
+        if (refl != nullptr && below) refl[(k - pad) * d + (lane - pad)] = u;
         wave_lds_order();
         double p = 0.0;
         static_for<DP - k - 1>([&](auto jj) {
@@ -106,6 +104,21 @@ __device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_
     e[DP - 2] = lane_value(a[DP - 2], DP - 1);
     dg[DP - 1] = lane_value(a[DP - 1], DP - 1);
     e[DP - 1] = 0.0;
+}
+
+// A (d x d, symmetric, row-major, LDS): on return its DIAGONAL holds the eigenvalues (unordered; the rest of A is left as it was);
+// V (d x d, LDS, may be null: eigenvalues only): eigenvectors in columns; bc: kWaveEighScratch doubles of LDS.  DP - 3 <= d <= DP.
+// Called by all 64 lanes of one wave (any other waves of the block wait at the caller's barrier).
+template <int DP>
+__device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_f64* bc, int d) {
+    const int lane = threadIdx.x & 63;
+    const int pad = DP - d;
+    const int ra = lane - pad;
+    const bool own = ra >= 0 && lane < DP;
+    GABO_EIGH_TICK(0);
+    double dg[DP], e[DP], ihh[DP >= 3 ? DP - 2 : 1];
+    lds_f64* refl = V;                                    // overwritten by Z at the end
+    wave_tridiagonalize<DP>(A, refl, bc, d, dg, e, ihh);
     GABO_EIGH_TICK(1);
     // row `lane` of Q = H_pad ... H_{DP-3}: e_lane^T pushed through the reflectors in order
     double z[DP];
@@ -142,6 +155,158 @@ __device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_
         if (lane == c && c >= pad) A[(c - pad) * d + (c - pad)] = dg[c];
     });
     wave_lds_order();
+}
+
+// Sum over each half of the wave (lanes 0..31, lanes 32..63), the half's total in every lane of that half.  All 64 lanes active.
+__device__ __forceinline__ double half_wave_allsum(double v) {
+    v += dpp_fetch<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]
+    v += dpp_fetch<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]
+    v += dpp_fetch<0x141, 0xf>(v);       // row_half_mirror
+    v += dpp_fetch<0x140, 0xf>(v);       // row_mirror: every lane of a row of 16 holds the row's sum
+    v += dpp_fetch<0x142, 0xa>(v);       // row_bcast15 into rows 1 and 3: they now hold the sums of their halves
+    const double lo = lane_value(v, 31), hi = lane_value(v, 63);
+    return (threadIdx.x & 32) ? hi : lo;
+}
+
+// The two EXTREME eigenpairs of one d x d symmetric matrix by one wave, for callers that bound lambda_max / lambda_min and differentiate
+// them (eigenvalue constraints stated in the original space of a nested SPD mapping: nested_spd_constraints_utils.py:14-73).  Householder
+// reduction as above, then - instead of the QL iteration over the whole spectrum, 70 % of wave_eigh -
+//   * both eigenvalues by multisection on the Sturm count of T - x I: lanes 0..31 work on lambda_max and lanes 32..63 on lambda_min, each lane
+//     counts at its own abscissa, so one pass of the d-step recurrence cuts both brackets 33-fold (12 passes: 2^-60 of the Gershgorin width);
+//   * both eigenvectors of T by three steps of inverse iteration on the pivoted LU factors of T - lambda I (each half of the wave for its
+//     own lambda, the recurrences run redundantly in the lanes of the half);
+//   * the reflectors applied to both vectors at once (lane = (half, component), dot products by a half-wave DPP sum).
+// A: in: the matrix; out: A[0..d) = eigenvector of lambda_max, A[d..2d) = eigenvector of lambda_min (unit norm, sign arbitrary).
+// W: d x d of LDS scratch (the reflectors).  bc: kWaveEighScratch doubles; out: bc[0] = lambda_max, bc[1] = lambda_min.  DP - 3 <= d <= DP.
+template <int DP>
+__device__ __attribute__((noinline)) void wave_eig_extremes(lds_f64* A, lds_f64* W, lds_f64* bc, int d) {
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, r = lane & 31;
+    const int pad = DP - d;
+    double dg[DP], e[DP], ihh[DP >= 3 ? DP - 2 : 1];
+    wave_tridiagonalize<DP>(A, W, bc, d, dg, e, ihh);
+    // ---- Gershgorin bracket of the spectrum of the active block, off-diagonal squares
+    double e2[DP];
+    double gl = 0.0, gu = 0.0;
+    static_for<DP>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        e2[i] = e[i] * e[i];
+        if (i < pad) return;
+        const double off = __builtin_fabs(e[i]) + (i > 0 ? __builtin_fabs(e[i > 0 ? i - 1 : 0]) : 0.0);     // (e[pad - 1] = 0)
+        const double lo_i = dg[i] - off, hi_i = dg[i] + off;
+        gl = (i == pad || lo_i < gl) ? lo_i : gl;
+        gu = (i == pad || hi_i > gu) ? hi_i : gu;
+    });
+    const double tnorm = __builtin_fmax(__builtin_fabs(gl), __builtin_fabs(gu));
+    const double pivmin = __builtin_fmax(tnorm * tnorm * 1e-290, 1e-300);
+    double lo = gl - 1e-15 * tnorm - pivmin, hi = gu + 1e-15 * tnorm + pivmin;         // per half: the bracket of its eigenvalue
+    const double frac = (double)(r + 1) * (1.0 / 33.0);
+    const int target = half ? 1 : d;                     // count(x) >= target  <=>  x is above the eigenvalue this half looks for
+    for (int pass = 0; pass < 12; ++pass) {
+        const double w = hi - lo;
+        const double x = __builtin_fma(w, frac, lo);
+        int cnt = 0;
+        double q = 1.0;
+        static_for<DP>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            if (i < pad) return;
+            const double t = (i == 0) ? 0.0 : e2[i > 0 ? i - 1 : 0] * rcp(q);
+            q = (dg[i] - x) - t;
+            q = (__builtin_fabs(q) < pivmin) ? -pivmin : q;
+            cnt += q < 0.0 ? 1 : 0;
+        });
+        const unsigned long long above = __builtin_amdgcn_ballot_w64(cnt >= target);
+        const unsigned mine = half ? (unsigned)(above >> 32) : (unsigned)above;
+        const int first = mine ? __builtin_ctz(mine) : 32;                               // first abscissa above the eigenvalue
+        const double nlo = first == 0 ? lo : __builtin_fma(w, (double)first * (1.0 / 33.0), lo);
+        const double nhi = first == 32 ? hi : __builtin_fma(w, (double)(first + 1) * (1.0 / 33.0), lo);
+        lo = nlo;
+        hi = nhi;
+    }
+    const double lam = 0.5 * (lo + hi);
+    // ---- pivoted LU of T - lam I (rows of U: 1 / u0, u1, u2; multipliers ml; interchanges sw)
+    const double tiny = __builtin_fmax(2.3e-16 * tnorm, 1e-300);
+    double iu0[DP], u1[DP], ml[DP];                       // (the second super-diagonal of U is e[k + 1] where rows were interchanged, 0 elsewhere)
+    bool sw[DP];
+    double cu = dg[0] - lam, cv = e[0];
+    static_for<DP - 1>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        const double ck = e[k];
+        const double an = dg[k + 1] - lam, bn = (k + 1 < DP - 1) ? e[k + 1 < DP - 1 ? k + 1 : 0] : 0.0;
+        const bool swp = __builtin_fabs(ck) > __builtin_fabs(cu);
+        double piv = swp ? ck : cu;
+        const double other = swp ? cu : ck;
+        piv = (__builtin_fabs(piv) < tiny) ? copysign_d(tiny, piv) : piv;
+        const double ip = rcp(piv);
+        const double mult = other * ip;
+        iu0[k] = ip;
+        u1[k] = swp ? an : cv;
+        ml[k] = mult;
+        sw[k] = swp;
+        const double ncu = swp ? __builtin_fma(-mult, an, cv) : __builtin_fma(-mult, cv, an);
+        cv = swp ? -mult * bn : bn;
+        cu = ncu;
+    });
+    cu = (__builtin_fabs(cu) < tiny) ? copysign_d(tiny, cu) : cu;
+    iu0[DP - 1] = rcp(cu);
+    u1[DP - 1] = 0.0;
+    sw[DP - 1] = false;
+    // ---- inverse iteration: U z = b first (a start vector with the L-solve already "applied"), then two full solves
+    double z[DP];
+    static_for<DP>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        z[i] = (i < pad) ? 0.0 : 1.0 + 0.25 * (double)((i * 7) % 5);
+    });
+    for (int it = 0; it < 3; ++it) {
+        if (it > 0) {
+            static_for<DP - 1>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                const double yk = z[k], yn = z[k + 1];
+                z[k] = sw[k] ? yn : yk;
+                z[k + 1] = sw[k] ? __builtin_fma(-ml[k], yn, yk) : __builtin_fma(-ml[k], yk, yn);
+            });
+        }
+        static_for_down<DP - 1, 0>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            double acc = z[k];
+            if constexpr (k + 1 < DP) acc = __builtin_fma(-u1[k], z[k + 1 < DP ? k + 1 : k], acc);
+            if constexpr (k + 2 < DP) acc = __builtin_fma(sw[k] ? -e[k + 1 < DP ? k + 1 : k] : 0.0, z[k + 2 < DP ? k + 2 : k], acc);
+            z[k] = acc * iu0[k];
+        });
+        double nn = 0.0, big = 0.0;
+        static_for<DP>([&](auto ii) { big = __builtin_fmax(big, __builtin_fabs(z[decltype(ii)::value])); });
+        const double sc = rcp(big);                                                      // (against overflow of the squares)
+        static_for<DP>([&](auto ii) { z[decltype(ii)::value] *= sc; nn = __builtin_fma(z[decltype(ii)::value], z[decltype(ii)::value], nn); });
+        const double inr = rsqrt_nz(nn);
+        static_for<DP>([&](auto ii) { z[decltype(ii)::value] *= inr; });
+    }
+    // ---- back to the original basis: y = H_pad ... H_{DP-3} z, component r of this half's vector in lane (half, r)
+    double zr = 0.0;
+    static_for<DP>([&](auto cc) { zr = (r == decltype(cc)::value) ? z[decltype(cc)::value] : zr; });
+    static_for_down<DP - 3, 0>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        if (k < pad) return;
+        const double u = (r > k && r < DP) ? W[(k - pad) * d + (r - pad)] : 0.0;
+        const double dot = half_wave_allsum(u * zr) * ihh[k];
+        zr = __builtin_fma(-dot, u, zr);
+    });
+    wave_lds_order();
+    if (r >= pad && r < DP) A[half * d + (r - pad)] = zr;
+    if (r == 0) bc[half] = lam;
+    wave_lds_order();
+}
+
+__device__ __forceinline__ void wave_eig_extremes_any(double* A, double* W, double* bc, int d) {
+    lds_f64* a = (lds_f64*)A;
+    lds_f64* w = (lds_f64*)W;
+    lds_f64* b = (lds_f64*)bc;
+    if (d <= 8) wave_eig_extremes<8>(a, w, b, d);
+    else if (d <= 12) wave_eig_extremes<12>(a, w, b, d);
+    else if (d <= 16) wave_eig_extremes<16>(a, w, b, d);
+    else if (d <= 20) wave_eig_extremes<20>(a, w, b, d);
+    else if (d <= 24) wave_eig_extremes<24>(a, w, b, d);
+    else if (d <= 28) wave_eig_extremes<28>(a, w, b, d);
+    else wave_eig_extremes<32>(a, w, b, d);
 }
 
 // dispatch on the padded order; d in [kWaveEighMinDim, 32]

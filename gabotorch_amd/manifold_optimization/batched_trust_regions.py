@@ -558,14 +558,17 @@ class BatchedTrustRegions:
 
             # no constraint needs a host callable (none, or eigenvalue bounds built with functools.partial as in the reference
             # examples): the whole solve is ONE launch, every wave iterating its restart to the end
-            from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint
+            from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint, builtin_lift
             builtins = [builtin_constraint(c) for c in cons]
             solve_ok = (ncons == 0) if sphere else (d <= 8 and neq == 0 and all(b is not None for b in builtins)
                                                     and fused.metric != _lib_frobenius())
+            lift = builtin_lift(builtins) if (solve_ok and not sphere) else None      # the nested kinds' mapping (one for all of them)
+            solve_ok = solve_ok and lift is not False
             if solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000:
+                extra = {} if sphere else {"lift": lift}
                 TR.solve(S.x, S.fx, S.g, S.ng, S.Delta, S.active_u8, S.iters, [b[0] for b in builtins], [b[1] for b in builtins], strict,
                           Delta_cons, self.theta, self.kappa, mininner, maxinner, Delta_bar, self.rho_prime, self.rho_regularization,
-                          self.mingradnorm, self.maxiter)
+                          self.mingradnorm, self.maxiter, **extra)
                 if hasattr(TR, "status"):
                     ops._raise_if_not_spd(TR.status, "gabo_spd_tr_solve")       # (when error checking is on: one read-back per solve)
                 k = int(S.iters.max().item())

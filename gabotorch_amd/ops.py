@@ -516,6 +516,63 @@ class _NestedSpdReconstructionFn(torch.autograd.Function):
         return tuple(out)
 
 
+def nested_spd_lift_prepare(w, v, c, k):
+    """(x0, p) of gabo_nested_spd_lift_prepare for the mapping (W, V, C, K) on w's device (detached fp64)."""
+    lib = _lib.load()
+    dev = _device_for(w, v, c, k)
+    W, V, C, K = (_prep(t_.detach(), dev).contiguous() for t_ in (w, v, c, k))
+    D, d = int(W.shape[0]), int(W.shape[1])
+    if tuple(V.shape) != (D, D - d) or tuple(C.shape) != (D - d, D - d) or tuple(K.shape) != (d, D - d):
+        raise RuntimeError(f"nested SPD mapping shapes: W {tuple(W.shape)}, V {tuple(V.shape)}, C {tuple(C.shape)}, K {tuple(K.shape)}")
+    x0 = torch.empty(D, D, dtype=torch.float64, device=dev)
+    p = torch.empty(D, d, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_nested_spd_lift_prepare(V.data_ptr(), C.data_ptr(), K.data_ptr(), x0.data_ptr(), p.data_ptr(), D, d, _stream_ptr(dev)),
+                   "gabo_nested_spd_lift_prepare")
+    return W, x0, p
+
+
+def nested_spd_extreme_eigenvalues(y, w, p, x0, want_grad=False):
+    """y (..., d, d) latent points -> lam (..., 2) = (lambda_max, lambda_min) of the lifted points [, grad (..., 2, d, d)]."""
+    lib = _lib.load()
+    dev = w.device
+    Y = _prep(y, dev).contiguous()
+    D, d = int(w.shape[0]), int(w.shape[1])
+    if Y.shape[-2:] != (d, d):
+        raise RuntimeError(f"latent points must be (..., {d}, {d}), got {tuple(Y.shape)}")
+    R = Y.numel() // (d * d)
+    lam = torch.empty(Y.shape[:-2] + (2,), dtype=torch.float64, device=dev)
+    grad = torch.empty(Y.shape[:-2] + (2, d, d), dtype=torch.float64, device=dev) if want_grad else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_nested_spd_extreme_eigenvalues(Y.data_ptr(), w.data_ptr(), p.data_ptr(), x0.data_ptr(), lam.data_ptr(),
+                                                           None if grad is None else grad.data_ptr(), R, D, d, _stream_ptr(dev)),
+                   "gabo_nested_spd_extreme_eigenvalues")
+    return (lam, grad) if want_grad else lam
+
+
+class _NestedSpdExtremes(torch.autograd.Function):
+    """(lambda_max, lambda_min) of the lifted latent point, differentiable (first order) in the latent point."""
+
+    @staticmethod
+    def forward(ctx, y, w, p, x0):
+        if not y.requires_grad:
+            return nested_spd_extreme_eigenvalues(y, w, p, x0).to(y.device, y.dtype)
+        lam, grad = nested_spd_extreme_eigenvalues(y, w, p, x0, want_grad=True)
+        ctx.save_for_backward(grad)
+        return lam.to(y.device, y.dtype)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        gy = (g.to(grad.device)[..., None, None] * grad).sum(-3)
+        return gy.to(g.device, g.dtype), None, None, None
+
+
+def nested_spd_extremes(y, w, p, x0):
+    return _NestedSpdExtremes.apply(y, w, p, x0)
+
+
 def spd_project(x_mandel, w):
     """(..., D_vec) Mandel, w (D, dl) -> (..., dl_vec) Mandel of W^T X W."""
     lib = _lib.load()
@@ -932,20 +989,28 @@ class SpdTr:
         return self.x_prop
 
     def solve(self, x, fx, g, ng, Delta, active, iters, kinds, bounds, strict, delta_cons, theta, kappa, mininner, maxinner, delta_bar,
-              rho_prime, rho_regularization, mingradnorm, maxiter):
-        """The whole solve in one launch (built-in eigenvalue constraints `kinds`/`bounds`, or none)."""
+              rho_prime, rho_regularization, mingradnorm, maxiter, lift=None):
+        """The whole solve in one launch (built-in eigenvalue constraints `kinds`/`bounds`, or none).  lift: the (w, x0, p) of
+        nested_spd_lift_prepare when some kinds are the nested ones (bounds stated in the original space of a nested SPD mapping)."""
         _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters)
         import ctypes
         nc = len(kinds)
         ck = (ctypes.c_int * max(nc, 1))(*kinds)
         cb = (ctypes.c_double * max(nc, 1))(*bounds)
+        if lift is not None:
+            lw, lx0, lp = lift                         # (the order nested_spd_lift_prepare returns them in)
+            _require(self.dev, lift_w=lw, lift_p=lp, lift_x0=lx0)
+            self._lift_ref = lift                      # (keeps the buffers alive until the next solve)
+            lift_args = (lw.data_ptr(), lp.data_ptr(), lx0.data_ptr(), int(lw.shape[0]))
+        else:
+            lift_args = (None, None, None, 0)
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.gabo_spd_tr_solve(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
                                                   active.data_ptr(), iters.data_ptr(), self.acq_ref, nc, ck, cb, 1 if strict else 0,
                                                   self.ws.data_ptr(), self.wsb, self.r, self.d, float(delta_cons), float(theta),
                                                   float(kappa), int(mininner), int(maxinner), float(delta_bar), float(rho_prime),
-                                                  float(rho_regularization), float(mingradnorm), int(maxiter), self.status.data_ptr(),
-                                                  _stream_ptr(self.dev)), "gabo_spd_tr_solve")
+                                                  float(rho_regularization), float(mingradnorm), int(maxiter), *lift_args,
+                                                  self.status.data_ptr(), _stream_ptr(self.dev)), "gabo_spd_tr_solve")
 
     def update(self, x, fx, g, ng, Delta, active, iters, invalid, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter):
         _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters, invalid=invalid)

@@ -330,16 +330,23 @@ int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, d
 
 /* The whole solve in ONE launch: every wave iterates propose/update for its restart until its gradient norm or iteration limit is
  * reached.  Possible when the constraints need no host callable: none, or bounds on the extreme eigenvalues of the iterate
- * (max_eigenvalue_constraint_torch / min_eigenvalue_constraint_torch, spd_constraints_utils_torch.py:17-50), all inequalities;
+ * (max_eigenvalue_constraint_torch / min_eigenvalue_constraint_torch, spd_constraints_utils_torch.py:17-50) or of the iterate lifted
+ * to the original space of a nested SPD mapping (max/min_eigenvalue_nested_spd_constraint, nested_spd_constraints_utils.py:14-73: the
+ * constraints of HD-GaBO's latent sweep, examples/hd_bo_spd/benchmark_examples/hd_gabo_spd.py:244-257), all inequalities;
  * strict != 0 rejects infeasible proposals (StrictConstrainedTrustRegions).  2 <= d <= 8; affine-invariant and log-Euclidean
- * surrogates.  State arrays as in gabo_spd_tr_update, updated in place; active[i] is 0 for every restart on return. */
-#define GABO_CONSTRAINT_MAX_EIGENVALUE 0   /* bound - lambda_max(x) >= 0 */
-#define GABO_CONSTRAINT_MIN_EIGENVALUE 1   /* lambda_min(x) - bound >= 0 */
+ * surrogates.  State arrays as in gabo_spd_tr_update, updated in place; active[i] is 0 for every restart on return.
+ * lift_w, lift_p (lift_dim x d), lift_x0 (lift_dim x lift_dim): the mapping of the nested kinds (gabo_nested_spd_lift_prepare;
+ * 5 <= lift_dim <= GABO_SPD_MAX_DIM), NULL / 0 without them. */
+#define GABO_CONSTRAINT_MAX_EIGENVALUE 0          /* bound - lambda_max(x) >= 0 */
+#define GABO_CONSTRAINT_MIN_EIGENVALUE 1          /* lambda_min(x) - bound >= 0 */
+#define GABO_CONSTRAINT_MAX_EIGENVALUE_NESTED 2   /* bound - lambda_max(lift(x)) >= 0 */
+#define GABO_CONSTRAINT_MIN_EIGENVALUE_NESTED 3   /* lambda_min(lift(x)) - bound >= 0 */
 int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
                       const gabo_spd_acq_params* acq, int n_constraints, const int* constraint_kind, const double* constraint_bound,
                       int strict, void* workspace, size_t workspace_bytes, int64_t r, int d, double delta_cons, double theta, double kappa,
                       int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
-                      int64_t maxiter, int* status, gabo_stream_t stream);
+                      int64_t maxiter, const double* lift_w, const double* lift_p, const double* lift_x0, int lift_dim, int* status,
+                      gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Acquisition maximisation on the sphere S^(dim-1) (the sphere twins of gabo_spd_acq_eval / gabo_spd_tr_*): kernel strip of
@@ -422,6 +429,20 @@ int gabo_nested_spd_reconstruction(const double* data, const double* y, const do
                                    const double* c, const double* k, double* cost, double* grad_v, double* grad_c, double* grad_k,
                                    int64_t P, int64_t N, int D, int d, int metric, void* workspace, size_t workspace_bytes,
                                    gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Eigenvalue bounds of a latent (nested) SPD point stated in the original space (HD-GaBO's acquisition constraints).
+ * Replaces  max_eigenvalue_nested_spd_constraint / min_eigenvalue_nested_spd_constraint   nested_mappings/nested_spd_constraints_utils.py:14-73
+ *           (projection_from_nested_spd_to_spd, nested_spd_utils.py:51-118, followed by symeig(eigenvectors=True) and autograd).
+ * gabo_nested_spd_lift_prepare, once per mapping (W, V, C, K):  x0 = V sym(C) V^T (D x D),  p = V (K C^1/2)^T (D x d), so that
+ *   Xrec(Y) = x0 + W Y W^T + (W Y^1/2) p^T + p (W Y^1/2)^T.    v: D x (D-d), c: (D-d) x (D-d), k: d x (D-d).
+ * gabo_nested_spd_extreme_eigenvalues: y: R x d x d latent points; lam: R x 2 = (lambda_max, lambda_min) of Xrec(Y_r);
+ *   grad: R x 2 x d x d = their gradients with respect to the (symmetric) Y_r, or NULL.  One wave per point, both eigenpairs from one
+ *   Householder reduction.  2 <= D <= GABO_SPD_MAX_DIM, 1 <= d < D.
+ */
+int gabo_nested_spd_lift_prepare(const double* v, const double* c, const double* k, double* x0, double* p, int D, int d, gabo_stream_t stream);
+int gabo_nested_spd_extreme_eigenvalues(const double* y, const double* w, const double* p, const double* x0, double* lam, double* grad,
+                                        int64_t R, int D, int d, gabo_stream_t stream);
 
 #ifdef __cplusplus
 }

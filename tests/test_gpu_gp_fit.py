@@ -396,3 +396,40 @@ def test_fused_reconstruction_launch_at_config5_size():
             (3.0 * rec(V2, C2, K2)).backward()
             np.testing.assert_allclose(K2.grad.cpu().numpy(), 3.0 * gK[p], rtol=1e-13, atol=1e-13 * scale)
             np.testing.assert_allclose(C2.grad.cpu().numpy(), 3.0 * gC[p], rtol=1e-13, atol=1e-13 * scale)
+
+
+def test_nested_spd_eigenvalue_constraints_one_launch_at_config5_size():
+    """gabo_nested_spd_extreme_eigenvalues (both extreme eigenpairs of the lifted point from one Householder reduction: multisection +
+    inverse iteration) at D = 20 -> d = 2 and D = 12 -> d = 3, 6: values against numpy on the oracle's lift, gradients against the composed
+    differentiable path (projection_from_nested_spd_to_spd + the eigenvalue op under autograd) that it replaces."""
+    from gabotorch_amd.nested_mappings import nested_spd_constraints_utils as nscu
+    from gabotorch_amd.nested_mappings.nested_spd_utils import projection_from_nested_spd_to_spd
+    from gabotorch_amd.Riemannian_utils.spd_constraints_utils_torch import max_eigenvalue_constraint_torch, min_eigenvalue_constraint_torch
+    from oracle import spd as ospd
+    rng = np.random.default_rng(5)
+    T = lambda a, grad=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV, requires_grad=grad)   # noqa: E731
+    for D, d, R in ((20, 2, 9), (12, 3, 4), (12, 6, 3), (7, 2, 5)):
+        m = D - d
+        Rm = np.linalg.qr(rng.standard_normal((D, D)))[0]
+        W, V = Rm[:, :d], np.linalg.qr(Rm[:, d:] + 0.02 * rng.standard_normal((D, m)))[0]      # W^T V only approximately 0, as after the ALM
+        C = _rand_spd(rng, 1, m)[0]
+        K = rng.standard_normal((d, m))
+        K *= 0.6 / np.linalg.norm(K)
+        Y = _rand_spd(rng, R, d)
+        args = [T(W), T(V), T(C), T(K)]
+        lifted = ospd.projection_from_nested_spd_to_spd(Y, W, V, C, K)
+        lam = np.linalg.eigvalsh(0.5 * (lifted + lifted.transpose(0, 2, 1)))
+        y1, y2 = T(Y, True), T(Y, True)
+        fmax = nscu.max_eigenvalue_nested_spd_constraint(y1, 5.0, *args)
+        fmin = nscu.min_eigenvalue_nested_spd_constraint(y1, 0.1, *args)
+        np.testing.assert_allclose(fmax.detach().cpu().numpy(), 5.0 - lam[:, -1], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(fmin.detach().cpu().numpy(), lam[:, 0] - 0.1, rtol=1e-12, atol=1e-13)
+        wts = T(rng.standard_normal((2, R)))
+        (wts[0] * fmax + wts[1] * fmin).sum().backward()
+        xs = projection_from_nested_spd_to_spd(y2, *args)
+        (wts[0] * max_eigenvalue_constraint_torch(xs, 5.0) + wts[1] * min_eigenvalue_constraint_torch(xs, 0.1)).sum().backward()
+        g1, g2 = y1.grad.cpu().numpy(), y2.grad.cpu().numpy()
+        np.testing.assert_allclose(0.5 * (g1 + g1.transpose(0, 2, 1)), 0.5 * (g2 + g2.transpose(0, 2, 1)), rtol=1e-9, atol=1e-11)
+        # values only (the strict solver's feasibility test) and a single point
+        with torch.no_grad():
+            np.testing.assert_allclose(nscu.max_eigenvalue_nested_spd_constraint(T(Y[0]), 5.0, *args).item(), 5.0 - lam[0, -1], rtol=1e-12)

@@ -744,3 +744,84 @@ def test_device_solvers_at_the_smallest_sizes():
         np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-8)
         np.testing.assert_allclose(out[1][0], out[0][0], atol=1e-6)
         np.testing.assert_allclose(out[1][0][0, 0], [0.6, 0.8], atol=1e-5)          # the posterior mean peaks at the training point
+
+
+@pytest.mark.parametrize("case", ["D20_d2_strict", "D12_d3", "D20_d2_max_only_strict"])
+def test_single_launch_solve_with_nested_eigenvalue_constraints(case):
+    """Config 5's latent sweep: log-Euclidean surrogate on S^d_++, eigenvalue bounds stated in the original space S^D_++ of a nested SPD mapping
+    (functools.partial over max/min_eigenvalue_nested_spd_constraint with the mapping bound by keyword, hd_gabo_spd.py:244-257).  The
+    single-launch solve evaluates them inside the kernel (nested_extremes_body: lift, both extreme eigenpairs from one Householder
+    reduction, gradient through sqrtm); checked against the same constraints as opaque callables on the torch lock-step solver and on the
+    propose / update plan."""
+    import functools
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdLogEuclideanGaussianKernel
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    from gabotorch_amd.nested_mappings import nested_spd_constraints_utils as nscu
+    D, d = (12, 3) if case.startswith("D12") else (20, 2)
+    strict = case.endswith("strict")
+    n_train, R = 15, 64
+    rng, X, y = _spd_gp(d, n_train=n_train, seed=43)
+    kern = SpdLogEuclideanGaussianKernel().double()
+    kern.lengthscale = torch.tensor(1.4, dtype=torch.float64)
+    gp = models.ExactGP(t(X), t(y), kern, outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    m = D - d
+    Rm = np.linalg.qr(rng.standard_normal((D, D)))[0]
+    W, V = t(Rm[:, :d]), t(np.linalg.qr(Rm[:, d:] + 0.01 * rng.standard_normal((D, m)))[0])
+    qc = np.linalg.qr(rng.standard_normal((m, m)))[0]
+    C = t((qc * rng.uniform(0.6, 1.8, m)) @ qc.T)
+    K0 = rng.standard_normal((d, m))
+    K = t(0.5 * K0 / np.linalg.norm(K0))
+    mapping = dict(projection_matrix=W, projection_complement_matrix=V, bottom_spd_matrix=C, contraction_matrix=K)
+    lift = lambda mats: np.linalg.eigvalsh(ospd.projection_from_nested_spd_to_spd(mats, *(a.cpu().numpy() for a in (W, V, C, K))))   # noqa: E731
+    q = np.linalg.qr(rng.standard_normal((4 * R, d, d)))[0]
+    P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.5, 2.2, (4 * R, d)), q)
+    P = 0.5 * (P + P.transpose(0, 2, 1))
+    man = manifolds.PositiveDefinite(d)
+    ops.set_error_checking(False)
+    # bounds that the unconstrained optimum of a good part of the restarts violates, starts that satisfy them
+    free = BatchedTrustRegions(mingradnorm=1e-5, maxiter=25)
+    c_free, v_free = gen_candidates_manifold(ops.matrix_to_mandel(t(P))[:, None], acq, man, free, vector_to_symmetric_matrix_mandel_torch,
+                                        symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
+    lam_free, lam_start = lift(ospd.vector_to_symmetric_matrix_mandel(c_free.cpu().numpy()[:, 0])), lift(P)
+    steer = case.startswith("D20")             # (at D = 12 -> 3 the unconstrained optima move inwards: the bounds are evaluated but rarely bind)
+    if steer:
+        hi, lo = float(np.quantile(lam_free[:, -1], 0.5)), float(np.quantile(lam_free[:, 0], 0.3))
+    else:
+        hi, lo = float(np.quantile(lam_start[:, -1], 0.8)), float(np.quantile(lam_start[:, 0], 0.2))
+    ok = (lam_start[:, -1] < hi - 0.05) & (lam_start[:, 0] > lo + 0.02)
+    keep = np.concatenate([np.flatnonzero(ok & (lam_free[:, -1] > hi + 0.05))[:R // 2], np.flatnonzero(ok & (lam_free[:, -1] <= hi + 0.05))])[:R]
+    assert len(keep) >= 24 and (not steer or (lam_free[keep, -1] > hi + 0.05).sum() >= 5), (hi, lo, len(keep))
+    x0 = ops.matrix_to_mandel(t(P[keep]))[:, None]
+    partials = [functools.partial(nscu.max_eigenvalue_nested_spd_constraint, maximum_eigenvalue=hi, **mapping)]
+    lambdas = [lambda z: nscu.max_eigenvalue_nested_spd_constraint(z, hi, W, V, C, K)]
+    if "max_only" not in case:
+        partials.append(functools.partial(nscu.min_eigenvalue_nested_spd_constraint, minimum_eigenvalue=lo, **mapping))
+        lambdas.append(lambda z: nscu.min_eigenvalue_nested_spd_constraint(z, lo, W, V, C, K))
+    b = scut.builtin_constraint(partials[0])
+    assert b is not None and b[0] == _lib.GABO_CONSTRAINT_MAX_EIGENVALUE_NESTED and b[1] == hi and scut.builtin_constraint(lambdas[0]) is None
+    out = {}
+    for maxiter in (1, 25):
+        for name, cons, opts in (("torch", lambdas, {"device_tcg": False}), ("plan", lambdas, {}), ("solve", partials, {})):
+            solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=maxiter, strict_constraints=strict)
+            c, v = gen_candidates_manifold(x0, acq, man, solver, vector_to_symmetric_matrix_mandel_torch, symmetric_matrix_to_vector_mandel_torch,
+                                           inequality_constraints=cons, approx_hessian=True, options=opts)
+            out[name, maxiter] = (c.cpu().numpy(), v.cpu().numpy(), solver.log["per_restart_iterations"].cpu().numpy())
+    ops.set_error_checking(True)
+    # ONE trust-region iteration (constraint values, whitened gradients, tCG with the constraint stop, proposal, strict feasibility test,
+    # rho test): the three drivers agree restart by restart
+    for name in ("plan", "solve"):
+        np.testing.assert_allclose(out[name, 1][1], out["torch", 1][1], rtol=5e-5, atol=1e-13)       # (device tCG vs torch tCG: the tolerance of the tests above)
+    np.testing.assert_allclose(out["solve", 1][1], out["plan", 1][1], rtol=1e-9, atol=1e-14)         # same device arithmetic, two drivers
+    np.testing.assert_allclose(out["solve", 1][0], out["plan", 1][0], rtol=0, atol=1e-9)
+    # The whole solve.  A restart that crawls along a bound takes accept / reject decisions that rounding can flip (the drivers whiten the
+    # constraint gradients in different orders), after which its trajectory parts by a step - the effect the reference itself shows between
+    # its f32 and f64 runs (DESIGN 2).  So: most restarts end on the torch path's value, all of them near it, none of them outside the
+    # bounds (strict), and the bounds did steer restarts whose unconstrained optimum lies outside.
+    lam = lift(ospd.vector_to_symmetric_matrix_mandel(out["solve", 25][0][:, 0]))
+    if strict:
+        assert lam[:, -1].max() < hi + 1e-9 and ("max_only" in case or lam[:, 0].min() > lo - 1e-9), (hi, lo, lam[:, -1].max(), lam[:, 0].min())
+    assert not steer or (np.abs(out["solve", 25][1] - v_free.cpu().numpy()[keep]) > 1e-6 * np.abs(out["solve", 25][1])).sum() >= 5
+    for name in ("plan", "solve"):
+        rel = np.abs(out[name, 25][1] - out["torch", 25][1]) / np.maximum(np.abs(out["torch", 25][1]), 1e-12)
+        assert (rel < 2e-5).mean() >= 0.7 and rel.max() < 5e-2, (name, np.sort(rel)[-8:])

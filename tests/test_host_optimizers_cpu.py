@@ -119,7 +119,7 @@ def test_library_constraints_are_recognised_for_graph_capture():
     assert _library_constraint(plain) and _library_constraint(nested)
     assert not _library_constraint(lambda x: min_eigenvalue_constraint_torch(x, 0.1))
     assert not _library_constraint(functools.partial(lambda x, b: x.sum() - b, b=1.0))
-    assert builtin_constraint(plain) is not None and builtin_constraint(nested) is None      # only the plain ones run inside the kernel
+    assert builtin_constraint(plain) is not None and builtin_constraint(nested) is None      # (a nested one needs its mapping as tensors)
 
 
 def test_alm_with_trust_regions_and_callable_constraints():

@@ -28,6 +28,22 @@ __global__ __launch_bounds__(64) void eig_kernel(const double* __restrict__ a, d
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// extreme eigenpairs only (wave_eig_extremes): lam[0] = max, lam[1] = min, v rows 0 / 1 the vectors
+__global__ __launch_bounds__(64) void ext_kernel(const double* __restrict__ a, double* __restrict__ lam, double* __restrict__ v,
+                                                 long long* __restrict__ cycles, int d) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* A = lds;
+    double* V = A + d * d;
+    double* cs = V + d * d;
+    gabo::lds_load(a + (size_t)blockIdx.x * d * d, A, d);
+    const long long t0 = __builtin_readcyclecounter();
+    gabo::wave_eig_extremes_any(A, V, cs, d);
+    const long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x < 2) lam[blockIdx.x * 2 + threadIdx.x] = cs[threadIdx.x];
+    for (int k = threadIdx.x; k < 2 * d; k += 64) v[(size_t)blockIdx.x * 2 * d + k] = A[k];
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
 int main() {
     std::mt19937_64 rng(7);
     std::normal_distribution<double> nd;
@@ -82,6 +98,35 @@ int main() {
             }
         }
         printf("%4d %14.0f %14.0f %12.1e %12.1e", d, cyc[0], cyc[1], resid, orth);
+        if (d >= gabo::kWaveEighMinDim) {
+            // extremes against the full solve
+            std::vector<double> lamq(nmat * d), lam2(nmat * 2), v2((size_t)nmat * 2 * d);
+            std::vector<long long> c2(nmat);
+            hipMemcpy(lamq.data(), dl, nmat * d * 8, hipMemcpyDeviceToHost);       // (the QL eigenvalues of the last launch above)
+            for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(ext_kernel, dim3(nmat), dim3(64), lds, 0, da, dl, dv, dc, d);
+            hipDeviceSynchronize();
+            hipMemcpy(lam2.data(), dl, nmat * 2 * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(v2.data(), dv, (size_t)nmat * 2 * d * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(c2.data(), dc, nmat * 8, hipMemcpyDeviceToHost);
+            double ce = 0, dlam = 0, res2 = 0, nrm2 = 0;
+            for (int m = 0; m < nmat; ++m) {
+                ce += (double)c2[m] / nmat;
+                double mx = lamq[m * d], mn = lamq[m * d];
+                for (int k = 1; k < d; ++k) { mx = fmax(mx, lamq[m * d + k]); mn = fmin(mn, lamq[m * d + k]); }
+                dlam = fmax(dlam, fmax(fabs(lam2[2 * m] - mx) / mx, fabs(lam2[2 * m + 1] - mn) / mx));
+                for (int h = 0; h < 2; ++h) {
+                    double nn = 0;
+                    for (int r = 0; r < d; ++r) {
+                        double av = 0;
+                        for (int c2i = 0; c2i < d; ++c2i) av += a[(size_t)m * d * d + r * d + c2i] * v2[(size_t)m * 2 * d + h * d + c2i];
+                        res2 = fmax(res2, fabs(av - lam2[2 * m + h] * v2[(size_t)m * 2 * d + h * d + r]));
+                        nn += v2[(size_t)m * 2 * d + h * d + r] * v2[(size_t)m * 2 * d + h * d + r];
+                    }
+                    nrm2 = fmax(nrm2, fabs(nn - 1.0));
+                }
+            }
+            printf("   extremes: %8.0f cycles, |dlam|/lmax %.1e, resid %.1e, |v|^2-1 %.1e", ce, dlam, res2, nrm2);
+        }
 #ifdef GABO_EIGH_CLOCKS
         long long ph[8];
         hipMemcpyFromSymbol(ph, HIP_SYMBOL(gabo_eigh_clk), sizeof(ph));
