@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
 from gabotorch_amd.nested_mappings import nested_spd_optimization as nso
 from gabotorch_amd.manifold_optimization.conjugate_gradient import ConjugateGradient
 rng = np.random.default_rng(3)
-D, d, N = 20, 2, 10
+D, d, N = int(os.environ.get("RECON_D", "20")), 2, 10
 q = np.linalg.qr(rng.standard_normal((N, D, D)))[0]
 X = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.1, 5.0, (N, D)), q); X = 0.5*(X+X.transpose(0,2,1))
 W = np.linalg.qr(rng.standard_normal((D, D)))[0][:, :d]
