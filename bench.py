@@ -140,7 +140,7 @@ def cpu_baseline(x):
 def config5_pieces(device):
     """BASELINE.json config 5 at its stated size: N = 4096 points of S^20_++ projected to S^2_++ (Y = W^T X W, nested_spd_utils.py:13-48)
     followed by the nested affine-invariant Gram and the log-Euclidean Gram of the latent points; parity of a block against the oracle."""
-    from gabotorch_amd import ops as _ops
+    from gabotorch_amd import _lib, ops as _ops
     from oracle import spd as ospd
     n, D, d = N_POINTS, 20, 2
     xm = synthetic_spd_mandel(n, D, 1234)
@@ -202,6 +202,33 @@ def config5_pieces(device):
     e_le = float(np.max(np.abs(kle - ospd.log_euclidean_gaussian_kernel(yo, yo, 1.0))))
     if not (e_p < 1e-10 and e_ai < 1e-9 and e_le < 1e-9):
         raise RuntimeError(f"config 5 parity gate failed: {e_p} {e_ai} {e_le}")
+    # the latent loop of an HD-GaBO iteration at D = 20: one reconstruction evaluation (value + gradients, 13 data points: the fused
+    # launch of nested_spd_optimization.py:23-92) and the original-space eigenvalue constraints of 512 latent points (one launch:
+    # nested_spd_constraints_utils.py:14-73), each checked against the oracle
+    nd = 13
+    xd = ospd.vector_to_symmetric_matrix_mandel(xm[:nd])
+    Rm = np.linalg.qr(rng.standard_normal((D, D)))[0]
+    Wl, Vl = np.ascontiguousarray(Rm[:, :d]), np.ascontiguousarray(Rm[:, d:])
+    qc = np.linalg.qr(rng.standard_normal((D - d, D - d)))[0]
+    Cl = (qc * rng.uniform(0.5, 2.0, D - d)) @ qc.T
+    Kl = rng.standard_normal((d, D - d))
+    Kl *= 0.4 / np.linalg.norm(Kl)
+    yd = np.einsum("ab,nac,cd->nbd", Wl, xd, Wl)
+    T64 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)   # noqa: E731
+    rec = _ops.NestedSpdReconstruction(T64(xd), T64(yd), T64(Wl), _lib.GABO_RECON_LOG_EUCLIDEAN)
+    vt, ct, kt = T64(Vl), T64(Cl), T64(Kl)
+    cost_t, gv_t, gc_t, gk_t = torch.empty(1, dtype=torch.float64, device=device), torch.empty_like(vt), torch.empty_like(ct), torch.empty_like(kt)
+    ws_rec = rec._staging(1)["ws"]
+    ms_rec = graph_ms(lambda: rec.launch(vt, ct, kt, cost_t, gv_t, gc_t, gk_t, 1, ws_rec), reps=5)
+    e_rec = abs(float(cost_t[0]) - ospd.reconstruction_cost(xd, yd, Wl, Vl, Cl, Kl, metric="le")) / abs(float(cost_t[0]))
+    lw, lx0, lp = _ops.nested_spd_lift_prepare(T64(Wl), vt, ct, kt)
+    ylat = _ops.mandel_to_matrix(y[:512])
+    ms_nc = graph_ms(lambda: _ops.nested_spd_extreme_eigenvalues(ylat, lw, lp, lx0, want_grad=True), reps=5)
+    lam_nc = _ops.nested_spd_extreme_eigenvalues(ylat[:64], lw, lp, lx0).cpu().numpy()
+    lam_o = np.linalg.eigvalsh(ospd.projection_from_nested_spd_to_spd(ylat[:64].cpu().numpy(), Wl, Vl, Cl, Kl))
+    e_nc = float(max(np.abs(lam_nc[:, 0] - lam_o[:, -1]).max(), np.abs(lam_nc[:, 1] - lam_o[:, 0]).max()))
+    if not (e_rec < 1e-10 and e_nc < 1e-11):
+        raise RuntimeError(f"config 5 latent-loop parity gate failed: {e_rec} {e_nc}")
     pairs = n * n
     hbm = lambda nbytes, ms: {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",   # noqa: E731
                               "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -217,6 +244,13 @@ def config5_pieces(device):
             "log_euclidean_gram_roofline": dict(hbm(pairs * 8.0, ms_le), model="8 algorithmic B/pair: one fp64 output"),
             "device_ms_in_a_hip_graph": dict(dev_ms, note="the *_ms figures above are HIP events around 20 calls issued from the host: for the "
                                              "5-10 us kernels that is the host's launch rate; these are the same calls captured in one hipGraph"),
+            "latent_loop": {"workload": "D = 20 -> 2: one reconstruction evaluation (value + gradients w.r.t. V, C, K; 13 data points, log-Euclidean "
+                                        "cost; gabo_nested_spd_reconstruction) and lambda_max / lambda_min of 512 lifted latent points with their "
+                                        "gradients (gabo_nested_spd_extreme_eigenvalues); device ms per launch inside a hipGraph",
+                            "reconstruction_evaluation_ms": ms_rec, "nested_eigenvalue_constraints_512_points_ms": ms_nc,
+                            "bound": "latency: two dependent eigen-solves of order 18 and 20 per block (wave_eigh: one wave, ~2.1e5 shader cycles); "
+                                     "one Householder reduction + multisection per lifted point (~6e4 cycles)",
+                            "parity": {"reconstruction_cost_rel": e_rec, "extreme_eigenvalues_max_abs": e_nc}},
             "parity": {"projection_max_abs": e_p, "nested_ai_gram_max_abs": e_ai, "log_euclidean_gram_max_abs": e_le, "block": "96 x 96"}}
 
 

@@ -37,6 +37,10 @@ def test_sphere_hip_path_matches_reference_optima(golden, n, approx):
 
 @pytest.mark.parametrize("d", [2, 3])
 def test_spd_hip_path_matches_reference_optima(golden, d):
+    """SECONDARY check against the reference AS IT IS (trust_regions.npz: its solvers with the float32 eigenvalue buffer of
+    spd_utils_torch.py:108, so its own costs / FD Hessians carry 1e-7 / 1e-3 relative noise - DESIGN 2): 2e-3 on the points and on the
+    constrained costs is the reference's own f32-vs-f64 distance, not this solver's accuracy.  The primary, tight comparison is against the
+    reference's float64 traces: tests/test_gpu_tr_traces.py (every iterate, 1e-6) and tests/test_gpu_ei_optimum.py (best-of-restarts, 1e-5)."""
     g = golden("trust_regions.npz")
     Ym = t(ospd.symmetric_matrix_to_vector_mandel(g[f"spd{d}_Y"]))
     w, beta = t(g[f"spd{d}_w"]), float(g[f"spd{d}_beta"])
@@ -534,7 +538,9 @@ def test_device_solve_matches_reference_solver_optima(golden, d):
     """The golden trust-region problems (tests/golden/make_golden_tr.py: the REFERENCE's TrustRegions / ConstrainedTrustRegions /
     StrictConstrainedTrustRegions run on cost(x) = -sum_j w_j exp(-beta d_AI(x, Y_j)^2) with get_hessianfd) are posterior-mean
     acquisitions of a GP with alpha = w: the device-resident solve - propose/update plan and gabo_spd_tr_solve - must land on the
-    reference's optima from the same starting points."""
+    reference's optima from the same starting points.  SECONDARY check: these fixtures are the reference as it is (float32 eigenvalue
+    buffer), hence the 2e-3 on the constrained costs (its own f32-vs-f64 distance); the float64 traces of
+    tests/test_gpu_tr_traces.py and the EI optimum of tests/test_gpu_ei_optimum.py are the tight ones."""
     import functools
     from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
     g = golden("trust_regions.npz")
@@ -698,6 +704,9 @@ def test_sphere_device_solve_matches_reference_solver_optima(golden, n):
         c, v = gen_candidates_manifold(t(g[f"sph{n}_x0"])[:, None], acq, man, BatchedTrustRegions(), approx_hessian=approx)
         np.testing.assert_allclose(-v.cpu().numpy(), g[f"sph{n}_{key}_f"], rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(c[:, 0].cpu().numpy(), g[f"sph{n}_{key}_x"], rtol=0, atol=1e-4)
+    # (constrained runs: a restart that ends on the bound x_0 = 0.3 stops where its last accepted step happened to land along the bound; the
+    # reference's own runs differ by this much between float32 and float64 eigen-buffers - a secondary check, the tight one is
+    # tests/test_gpu_tr_traces.py against the float64 traces)
     cons = [lambda p: p[..., 0] - 0.3]
     x0c = t(g[f"sph{n}_con_x0"])[:, None]
     c, v = gen_candidates_manifold(x0c, acq, man, BatchedTrustRegions(mingradnorm=1e-6, maxiter=200), inequality_constraints=cons)
