@@ -246,14 +246,14 @@ class SingleTaskGP(torch.nn.Module):
 
     def marginal_log_likelihood(self):
         """(log p(y | X) + log priors) / n, the quantity gpytorch's ExactMarginalLogLikelihood returns [3P].
-        Up to GABO_GP_MLL_MAX_N training points the likelihood and its gradient with respect to the Gram matrix, outputscale, noise
+        Up to GABO_GP_MLL_LARGE_MAX_N training points the likelihood and its gradient with respect to the Gram matrix, outputscale, noise
         and mean are ONE launch (gabo_gp_mll_gram) behind a custom autograd node, so autograd only has to differentiate the kernel
         itself (its own HIP backward); above that, torch's Cholesky / solve."""
         from . import _lib
         cm = self.covar_module
         scaled = hasattr(cm, "base_kernel") and type(cm).__name__ == "ScaleKernel" and cm.raw_outputscale.numel() == 1
         kb = (cm.base_kernel if scaled else cm).forward(self.train_x, self.train_x)
-        if kb.is_cuda and kb.dim() == 2 and kb.shape[-1] <= _lib.GABO_GP_MLL_MAX_N:
+        if kb.is_cuda and kb.dim() == 2 and kb.shape[-1] <= _lib.GABO_GP_MLL_LARGE_MAX_N:
             os_ = cm.outputscale.double().reshape(()) if scaled else torch.ones((), dtype=torch.float64)
             ll = _ExactMll.apply(kb.double(), self.train_y.to(kb.device), os_, self.noise.reshape(()), self.mean_constant.reshape(()))
             pri = self._priors()
@@ -291,7 +291,7 @@ class SingleTaskGP(torch.nn.Module):
     def _stationary_form(self):
         """(E, theta_fn, outputscale_fn) when the covariance is [ScaleKernel of] one of the path's plain kernels, all of which
         are exp(-theta * E) with E = d^2 or d fixed during a fit; None for anything else (nested kernels carry extra
-        parameters inside the distance, batched hyper-parameters, more than GABO_GP_MLL_MAX_N points)."""
+        parameters inside the distance, batched hyper-parameters, more than GABO_GP_MLL_LARGE_MAX_N points)."""
         from . import _lib, ops
         from .kernel_utils import kernels_sphere as ksph
         from .kernel_utils import kernels_spd as kspd
@@ -304,7 +304,7 @@ class SingleTaskGP(torch.nn.Module):
         else:
             return None
         x = self.train_x
-        if x.dim() != 2 or not 1 <= x.shape[0] <= _lib.GABO_GP_MLL_MAX_N:
+        if x.dim() != 2 or not 1 <= x.shape[0] <= _lib.GABO_GP_MLL_LARGE_MAX_N:
             return None
         kind = type(base)
         dist_mode = _lib.GABO_OUT_DISTANCE

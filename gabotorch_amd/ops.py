@@ -776,15 +776,39 @@ def gp_acquisition(kstar, alpha, linv, linv_t, mean, outputscale, kxx, best_f, k
     return value, grad
 
 
+_mll_large_ws = {}
+
+
+def _gp_mll_large(e, y, theta, outputscale, noise, mean, gram, want_w):
+    """gabo_gp_mll_large on contiguous device tensors -> (out (6,) device tensor, W or None); the workspace is kept per (device, n)."""
+    lib = _lib.load()
+    dev, n = e.device, e.shape[-1]
+    key = (dev, n)
+    ws = _mll_large_ws.get(key)
+    if ws is None:
+        if len(_mll_large_ws) > 4:
+            _mll_large_ws.clear()
+        ws = _mll_large_ws[key] = torch.empty(int(lib.gabo_gp_mll_large_workspace_bytes(n)) // 8 + 1, dtype=torch.float64, device=dev)
+    out = torch.empty(6, dtype=torch.float64, device=dev)
+    w = torch.empty(n, n, dtype=torch.float64, device=dev) if want_w else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_gp_mll_large(e.data_ptr(), y.data_ptr(), n, float(theta), float(outputscale), float(noise), float(mean),
+                                         1 if gram else 0, out.data_ptr(), None if w is None else w.data_ptr(), ws.data_ptr(),
+                                         ws.numel() * 8, _stream_ptr(dev)), "gabo_gp_mll_large")
+    return out, w
+
+
 def gp_mll(e, y, theta, outputscale, noise, mean):
-    """One evaluation of the exact-GP marginal log likelihood with K = outputscale * exp(-theta * e) + noise * I (gabo_gp_mll):
-    -> [ll, dll/dtheta, dll/doutputscale, dll/dnoise, dll/dmean, not_positive_definite] as Python floats (one device->host copy).
-    e: n x n fp64 on a HIP device (n <= GABO_GP_MLL_MAX_N), y: n."""
+    """One evaluation of the exact-GP marginal log likelihood with K = outputscale * exp(-theta * e) + noise * I (gabo_gp_mll; the tiled
+    gabo_gp_mll_large beyond GABO_GP_MLL_MAX_N points): -> [ll, dll/dtheta, dll/doutputscale, dll/dnoise, dll/dmean,
+    not_positive_definite] as Python floats (one device->host copy).  e: n x n fp64 on a HIP device (n <= GABO_GP_MLL_LARGE_MAX_N), y: n."""
     lib = _lib.load()
     dev = e.device
     n = e.shape[-1]
     if e.dim() != 2 or e.shape[0] != n or y.numel() != n or not e.is_contiguous() or not y.is_contiguous():
         raise RuntimeError("gp_mll: e must be a contiguous n x n matrix and y a contiguous vector of n targets")
+    if n > _lib.GABO_GP_MLL_MAX_N:
+        return _gp_mll_large(e, y, theta, outputscale, noise, mean, False, False)[0].tolist()
     out = torch.empty(6, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.gabo_gp_mll(e.data_ptr(), y.data_ptr(), n, float(theta), float(outputscale), float(noise), float(mean),
@@ -794,14 +818,16 @@ def gp_mll(e, y, theta, outputscale, noise, mean):
 
 def gp_mll_gram(k, y, outputscale, noise, mean, want_w=True):
     """gabo_gp_mll_gram: exact-GP marginal log likelihood for Ky = outputscale * k + noise * I with k an arbitrary base Gram matrix
-    (n x n fp64 on a HIP device, n <= GABO_GP_MLL_MAX_N).  -> (out (6,) device tensor: ll, 0, dll/doutputscale, dll/dnoise, dll/dmean,
-    not-positive-definite flag;  W = alpha alpha^T - Ky^-1 (n x n) or None).  No host synchronisation."""
+    (n x n fp64 on a HIP device, n <= GABO_GP_MLL_LARGE_MAX_N).  -> (out (6,) device tensor: ll, 0, dll/doutputscale, dll/dnoise,
+    dll/dmean, not-positive-definite flag;  W = alpha alpha^T - Ky^-1 (n x n) or None).  No host synchronisation."""
     lib = _lib.load()
     dev = k.device
     n = k.shape[-1]
     if k.dim() != 2 or k.shape[0] != n or y.numel() != n:
         raise RuntimeError("gp_mll_gram: k must be an n x n matrix and y a vector of n targets")
     k, y = k.contiguous(), y.contiguous()
+    if n > _lib.GABO_GP_MLL_MAX_N:
+        return _gp_mll_large(k, y, 0.0, outputscale, noise, mean, True, want_w)
     out = torch.empty(6, dtype=torch.float64, device=dev)
     w = torch.empty(n, n, dtype=torch.float64, device=dev) if want_w else None
     with torch.cuda.device(dev):

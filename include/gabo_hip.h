@@ -219,6 +219,14 @@ int gabo_gp_mll(const double* e, const double* y, int64_t n, double theta, doubl
  * d out[0] / d k = outputscale * W / 2 chains into the kernel's own backward - no Cholesky / solve / log-det autograd. */
 int gabo_gp_mll_gram(const double* k, const double* y, int64_t n, double outputscale, double noise, double mean, double* out, double* w,
                      gabo_stream_t stream);
+/* Both of the above for larger training sets, n <= GABO_GP_MLL_LARGE_MAX_N: the same sweep operator on 32 x 32 tiles of the bordered
+ * matrix in the caller's workspace, two launches per block of 32 pivots (csrc/gp_mll_large.hip).  gram = 0: e as in gabo_gp_mll;
+ * gram != 0: e is the base Gram matrix as in gabo_gp_mll_gram (theta unused, out[1] = 0).  w: NULL or n x n as above.  Both triangles
+ * of e are read. */
+#define GABO_GP_MLL_LARGE_MAX_N 2048
+size_t gabo_gp_mll_large_workspace_bytes(int64_t n);
+int gabo_gp_mll_large(const double* e, const double* y, int64_t n, double theta, double outputscale, double noise, double mean, int gram,
+                      double* out, double* w, void* workspace, size_t workspace_bytes, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * n random SPD matrices with the distribution of spd_sample (Riemannian_utils/spd_utils.py:290-306; the raw samples of

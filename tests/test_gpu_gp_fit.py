@@ -219,9 +219,38 @@ def test_gp_mll_kernel_reports_indefinite_matrices_and_sizes():
     e = torch.zeros(3, 3, dtype=torch.float64, device=DEV)       # K = os * ones + noise I with a negative "noise": indefinite
     out = ops.gp_mll(e, torch.ones(3, dtype=torch.float64, device=DEV), 1.0, 1.0, -0.5, 0.0)
     assert out[5] == 1.0 and out[:5] == [0.0] * 5
-    n = _lib.GABO_GP_MLL_MAX_N + 1
+    n = _lib.GABO_GP_MLL_LARGE_MAX_N + 1
     with pytest.raises(RuntimeError):
         ops.gp_mll(torch.zeros(n, n, dtype=torch.float64, device=DEV), torch.zeros(n, dtype=torch.float64, device=DEV), 1.0, 1.0, 0.1, 0.0)
+    n = _lib.GABO_GP_MLL_MAX_N + 40                                # the tiled path reports an indefinite matrix the same way
+    out = ops.gp_mll(torch.zeros(n, n, dtype=torch.float64, device=DEV), torch.ones(n, dtype=torch.float64, device=DEV), 1.0, 1.0, -0.5, 0.0)
+    assert out[5] == 1.0 and out[:5] == [0.0] * 5
+
+
+@pytest.mark.parametrize("n", [161, 200, 256, 512, 1024])
+def test_gp_mll_beyond_one_workgroup_against_the_oracle(n):
+    """gabo_gp_mll_large (the sweep operator on 32 x 32 tiles, two launches per pivot block) against oracle/gp.py: likelihood, its four
+    analytic derivatives, and W = alpha alpha^T - Ky^-1 of the Gram form."""
+    from gabotorch_amd import ops
+    from oracle import gp as ogp
+    rng = np.random.default_rng(n)
+    X = _rand_spd(rng, n, 3)
+    e = ospd.affine_invariant_distance(X, X) ** 2
+    y = rng.standard_normal(n)
+    theta, os_, noise, mean = 0.8, 1.3, 0.05, 0.2
+    want_ll, want_grad = ogp.marginal_log_likelihood(e, y, theta, os_, noise, mean)
+    out = ops.gp_mll(torch.tensor(e, device=DEV), torch.tensor(y, device=DEV), theta, os_, noise, mean)
+    assert out[5] == 0.0
+    np.testing.assert_allclose(out[0], want_ll, rtol=1e-10)
+    np.testing.assert_allclose(out[1:5], want_grad, rtol=1e-8, atol=1e-9 * abs(want_ll))
+    kb = np.exp(-theta * e)
+    o6, W = ops.gp_mll_gram(torch.tensor(kb, device=DEV), torch.tensor(y, device=DEV), os_, noise, mean)
+    o6 = o6.tolist()
+    np.testing.assert_allclose(o6[0], out[0], rtol=1e-12)
+    np.testing.assert_allclose([o6[2], o6[3], o6[4]], [out[2], out[3], out[4]], rtol=1e-8)       # (exp(-theta e) formed on the host here, on the device there)
+    ky = os_ * kb + noise * np.eye(n)
+    alpha = np.linalg.solve(ky, y - mean)
+    np.testing.assert_allclose(W.cpu().numpy(), np.outer(alpha, alpha) - np.linalg.inv(ky), rtol=1e-8, atol=1e-8 * np.abs(alpha).max() ** 2)
 
 
 def _plain_models(rng, n=17):
