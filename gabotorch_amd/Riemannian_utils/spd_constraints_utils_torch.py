@@ -85,6 +85,6 @@ def builtin_lift(builtins):
         if any(a is not b and (a.shape != b.shape or a.data_ptr() != b.data_ptr()) for a, b in zip(first, other)):
             return False
     w, v, c, k = first
-    if not (5 <= w.shape[0] <= _lib.GABO_SPD_MAX_DIM):
+    if not (5 <= w.shape[0] <= _lib.GABO_TR_NESTED_MAX_DIM):
         return False
     return ops.nested_spd_lift_prepare(w, v, c, k)

@@ -15,6 +15,7 @@ GABO_SPD_REG_MAX_DIM = 12
 GABO_SPD_BWD_REG_MAX_DIM = 16
 GABO_SPD_FWD_REG_MAX_DIM = 20
 GABO_SPD_MAX_DIM = 32
+GABO_TR_NESTED_MAX_DIM = 24
 (GABO_SPD_EXP, GABO_SPD_LOG, GABO_SPD_INNER, GABO_SPD_NORM, GABO_SPD_DIST, GABO_SPD_EGRAD2RGRAD, GABO_SPD_EHESS2RHESS,
  GABO_SPD_LOGM, GABO_SPD_EXPM, GABO_SPD_SQRTM, GABO_SPD_EIGMAX, GABO_SPD_EIGMIN) = range(12)
 GABO_ACQ_EXPECTED_IMPROVEMENT, GABO_ACQ_POSTERIOR_MEAN = 0, 1

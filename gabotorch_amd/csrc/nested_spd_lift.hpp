@@ -19,7 +19,8 @@ struct NestedExtremesOut {
     const double* grad;
 };
 
-template <bool QLD, bool QLd>
+// MAXDP: see wave_eig_extremes_any (D <= MAXDP is the caller's to check)
+template <bool QLD, bool QLd, int MAXDP = 32>
 __device__ __forceinline__ NestedExtremesOut nested_extremes_body(const double* __restrict__ y, const double* __restrict__ w,
                                                                   const double* __restrict__ p, const double* __restrict__ x0, int D, int d,
                                                                   double* lds, bool want_grad) {
@@ -73,7 +74,7 @@ __device__ __forceinline__ NestedExtremesOut nested_extremes_body(const double* 
     }
     __syncthreads();
     if constexpr (QLD) {
-        wave_eig_extremes_any(M0, M1, cs, D);            // M0[0..D) = v_max, M0[D..2D) = v_min, cs[0..1] = lambda_max, lambda_min
+        wave_eig_extremes_any<MAXDP>(M0, M1, cs, D);     // M0[0..D) = v_max, M0[D..2D) = v_min, cs[0..1] = lambda_max, lambda_min
         __syncthreads();
     } else {                                             // D < 5: the Jacobi solver, then pick
         lds_jacobi(M0, M1, cs, D);

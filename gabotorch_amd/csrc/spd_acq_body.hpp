@@ -88,6 +88,7 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
     __syncthreads();
     GABO_TICK(101);
     const double* w = wl;
+    const LogRegs logc = LogRegs::load();
     for (int64_t j0 = 0; j0 < n; j0 += 64) {
         const int64_t j = j0 + lane;
         const bool live = j < n;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
         double s = 0.0;
         static_for<D>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
-            lg[k] = log(lam[k]);
+            lg[k] = log_pos(lam[k], logc);                // (fdlibm scheme, 1 ulp, ~35 instructions; OCML's log is ~100: D of them per pair)
             s = __builtin_fma(lg[k], lg[k], s);
         });
         const double d2 = s + 1e-15;                      // spd_utils_torch.py:120
@@ -211,9 +212,17 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
     __syncthreads();
     GABO_TICK(104);
     for (int e = lane; e < T; e += 64) {
-        double t = 0.0;
-        for (int l = 0; l < 64; ++l) t += acc[e * LD + ((l + e) & 63)];
-        red[e] = t;
+        // four partial sums, the loop unrolled: the 64 LDS reads are independent and go out back to back (as one running sum the loop
+        // waited for each read: 75 cycles per term, 4.8 k of an evaluation's 42 k - tools/tr_clocks.py)
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+        for (int l = 0; l < 64; l += 4) {
+            t0 += acc[e * LD + ((l + e) & 63)];
+            t1 += acc[e * LD + ((l + 1 + e) & 63)];
+            t2 += acc[e * LD + ((l + 2 + e) & 63)];
+            t3 += acc[e * LD + ((l + 3 + e) & 63)];
+        }
+        red[e] = (t0 + t1) + (t2 + t3);
     }
     __syncthreads();
     GABO_TICK(105);

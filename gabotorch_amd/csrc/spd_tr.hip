@@ -120,7 +120,7 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
     if (gabo::builtin_has_kind(B, true)) {
         // (the lifted dimension goes through the wave eigen-solver: kWaveEighMinDim <= lift_dim)
         if (!lift_w || !lift_p || !lift_x0) return GABO_ERR_ARG;
-        if (lift_dim <= d || lift_dim < 5 || lift_dim > GABO_SPD_MAX_DIM) return GABO_ERR_DIM;
+        if (lift_dim <= d || lift_dim < 5 || lift_dim > gabo::kTrNestedMaxDim) return GABO_ERR_DIM;
     }
     gabo::SolveArgs a{x, fx, grad, grad_norm, trust_radius, active, iters, acq, B, workspace, r, d, delta_cons, theta, kappa, mininner,
                       maxinner, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter, status, (hipStream_t)stream};

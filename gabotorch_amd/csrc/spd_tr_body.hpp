@@ -37,6 +37,7 @@ static __host__ __device__ inline TrWs tr_layout(void* base, int64_t R, int d, i
 // and of the iterate LIFTED to the original space of a nested SPD mapping (max/min_eigenvalue_nested_spd_constraint,
 // nested_spd_constraints_utils.py:14-73) - kinds 2 / 3, with lift_w, lift_p (big_dim x d) and lift_x0 (big_dim x big_dim) from
 // gabo_nested_spd_lift_prepare; the wave evaluates those through nested_extremes_body in `nlds` (dynamic LDS).
+constexpr int kTrNestedMaxDim = 24;      // largest original dimension of the nested kinds inside the solve kernel (gabo_spd_tr_solve checks it)
 struct BuiltinCons {
     int n;
     int strict;
@@ -73,7 +74,7 @@ __device__ __forceinline__ void builtin_constraints(const double* __restrict__ x
     constexpr int dd = D * D;
     const double* L = w.chol + i * dd;
     if (builtin_has_kind(B, true)) {
-        const NestedExtremesOut ne = nested_extremes_body<true, (D >= kWaveEighMinDim)>(x, B.lift_w, B.lift_p, B.lift_x0, B.big_dim, D, nlds, true);
+        const NestedExtremesOut ne = nested_extremes_body<true, (D >= kWaveEighMinDim), kTrNestedMaxDim>(x, B.lift_w, B.lift_p, B.lift_x0, B.big_dim, D, nlds, true);
         for (int k = 0; k < B.n; ++k) {
             if (B.kind[k] < 2) continue;
             const bool want_max = B.kind[k] == 2;
@@ -132,7 +133,7 @@ template <int D>
 __device__ __forceinline__ bool builtin_infeasible(const double* __restrict__ xp, const BuiltinCons& B, double* nlds) {
     bool bad = false;
     if (builtin_has_kind(B, true)) {
-        const NestedExtremesOut ne = nested_extremes_body<true, (D >= kWaveEighMinDim)>(xp, B.lift_w, B.lift_p, B.lift_x0, B.big_dim, D, nlds, false);
+        const NestedExtremesOut ne = nested_extremes_body<true, (D >= kWaveEighMinDim), kTrNestedMaxDim>(xp, B.lift_w, B.lift_p, B.lift_x0, B.big_dim, D, nlds, false);
         const double nmax = ne.lam[0], nmin = ne.lam[1];
         for (int k = 0; k < B.n; ++k) {
             if (B.kind[k] < 2) continue;

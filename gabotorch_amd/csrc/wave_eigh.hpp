@@ -296,6 +296,9 @@ __device__ __attribute__((noinline)) void wave_eig_extremes(lds_f64* A, lds_f64*
     wave_lds_order();
 }
 
+// MAXDP: the largest padded order the caller links (a kernel that can reach an instantiation is allocated for its registers: the
+// single-launch trust-region solve stops at 24)
+template <int MAXDP = 32>
 __device__ __forceinline__ void wave_eig_extremes_any(double* A, double* W, double* bc, int d) {
     lds_f64* a = (lds_f64*)A;
     lds_f64* w = (lds_f64*)W;
@@ -304,9 +307,11 @@ __device__ __forceinline__ void wave_eig_extremes_any(double* A, double* W, doub
     else if (d <= 12) wave_eig_extremes<12>(a, w, b, d);
     else if (d <= 16) wave_eig_extremes<16>(a, w, b, d);
     else if (d <= 20) wave_eig_extremes<20>(a, w, b, d);
-    else if (d <= 24) wave_eig_extremes<24>(a, w, b, d);
-    else if (d <= 28) wave_eig_extremes<28>(a, w, b, d);
-    else wave_eig_extremes<32>(a, w, b, d);
+    else if (d <= 24 || MAXDP <= 24) wave_eig_extremes<24>(a, w, b, d);
+    else if constexpr (MAXDP > 24) {
+        if (d <= 28) wave_eig_extremes<28>(a, w, b, d);
+        else wave_eig_extremes<32>(a, w, b, d);
+    }
 }
 
 // dispatch on the padded order; d in [kWaveEighMinDim, 32]

@@ -344,7 +344,8 @@ int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, d
  * strict != 0 rejects infeasible proposals (StrictConstrainedTrustRegions).  2 <= d <= 8; affine-invariant and log-Euclidean
  * surrogates.  State arrays as in gabo_spd_tr_update, updated in place; active[i] is 0 for every restart on return.
  * lift_w, lift_p (lift_dim x d), lift_x0 (lift_dim x lift_dim): the mapping of the nested kinds (gabo_nested_spd_lift_prepare;
- * 5 <= lift_dim <= GABO_SPD_MAX_DIM), NULL / 0 without them. */
+ * 5 <= lift_dim <= GABO_TR_NESTED_MAX_DIM), NULL / 0 without them. */
+#define GABO_TR_NESTED_MAX_DIM 24
 #define GABO_CONSTRAINT_MAX_EIGENVALUE 0          /* bound - lambda_max(x) >= 0 */
 #define GABO_CONSTRAINT_MIN_EIGENVALUE 1          /* lambda_min(x) - bound >= 0 */
 #define GABO_CONSTRAINT_MAX_EIGENVALUE_NESTED 2   /* bound - lambda_max(lift(x)) >= 0 */

@@ -1,5 +1,6 @@
-"""Turns the raw outputs of tools/collect_profiles_r02.sh (gpurun_out/profiles_r02/) into the files committed under profiles/:
-rNN_* copies of the rocprofv3 summaries and profiles/pmc_summary.json (what bench.py's `roofline.traffic` reads)."""
+"""Turns the raw outputs of tools/collect_profiles_rNN.sh (gpurun_out/profiles_rNN/) into the files committed under profiles/:
+rNN_* copies of the rocprofv3 summaries and profiles/pmc_summary.json (what bench.py's `roofline.traffic` reads).
+    python tools/summarise_profiles.py [r03]"""
 import csv
 import json
 import os
@@ -8,14 +9,15 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "profiles_r02")
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", "profiles_" + RND)
 DST = os.path.join(ROOT, "profiles")
-RND = "r02"
 
 
 def main():
     for name in ("bench_kernel_stats.csv", "sphere_kernel_stats.csv", "backward_kernel_stats.csv", "sweep_kernel_stats.csv",
-                 "config5_kernel_stats.csv", "bench_under_rocprof.json", "pmc_raw.json", "sweep.log", "backward.log"):
+                 "config5_kernel_stats.csv", "bench_under_rocprof.json", "pmc_raw.json", "sweep.log", "backward.log",
+                 "recon_kernel_stats.csv", "recon.log", "hd_gabo_kernel_stats.csv", "hd_gabo.log", "gp_mll_kernel_stats.csv", "gp_mll.log"):
         p = os.path.join(SRC, name)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(DST, f"{RND}_{name}"))
@@ -36,7 +38,7 @@ def main():
     sq = raw["full_sq"][kern]
     pairs = n * n
     out = {
-        "round": 2, "kernel": kern,
+        "round": int(RND[1:]), "kernel": kern,
         "workload": "N=4096, d=10, all N^2 pairs (bench.py `value` launches; tools/prof_spd.py 4096 10 x for the PMC passes)",
         "rocprof_kernel_trace_ms": {"avg": sum(durs) / len(durs), "median": statistics.median(durs), "min": min(durs), "max": max(durs),
                                     "calls": len(durs), "note": "all dispatches of the bench command: 60 disclosed preheat launches (the first ~20 at a lower clock), 5 warm-up steps, 20 timed steps"},
@@ -58,6 +60,16 @@ def main():
         out["sphere"] = {"kernel": sph[0], "sq": s, "valu_insts_per_output": s["SQ_INSTS_VALU"] / (pairs / 64.0),
                          "valu_insts_per_output_round1": 102,
                          "hbm_write_bytes_per_launch": raw["sphere_write"][sph[0]]["WRITE_SIZE"] * 1024.0}
+    # the write-bound Gram kernels of config 5 (N = 4096 latent 2 x 2 points): instructions per output and write bytes
+    for key, name in (("nested_ai_gram", "spd_ai_gauss2_kernel"), ("log_euclidean_gram", "frobenius_pairwise_kernel")):
+        ks = [k for k in raw.get("config5_sq", {}) if name in k] if isinstance(raw.get("config5_sq"), dict) else []
+        if ks:
+            s = raw["config5_sq"][ks[0]]
+            row = {"kernel": ks[0], "sq": s, "valu_insts_per_output": s["SQ_INSTS_VALU"] / (pairs / 64.0)}
+            kw = [k for k in raw.get("config5_write", {}) if name in k] if isinstance(raw.get("config5_write"), dict) else []
+            if kw:
+                row["hbm_write_bytes_per_launch"] = raw["config5_write"][kw[0]]["WRITE_SIZE"] * 1024.0
+            out[key] = row
     json.dump(out, open(os.path.join(DST, "pmc_summary.json"), "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
