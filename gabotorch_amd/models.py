@@ -356,20 +356,24 @@ class SingleTaskGP(torch.nn.Module):
 
         return evaluate
 
-    def _fast_scalar_objective(self, params):
+    def _fast_scalar_objective(self, params, evaluator=None):
         """v -> (loss, gradient) in plain Python floats for the layout every reference example uses (stand-in ScaleKernel / kernel
         classes with softplus constraints, Gamma priors): the chain rule through softplus and the priors costs microseconds, so an
         L-BFGS evaluation is the gabo_gp_mll launch and its 48-byte read-back.  None when the model is laid out differently (the
-        caller then lets autograd do the chain rule)."""
+        caller then lets autograd do the chain rule).
+        evaluator(theta, outputscale, noise, mean) -> (ll, d theta, d outputscale, d noise, d mean, not_pd): replaces the launch on the
+        fixed distance matrix for kernels with further parameters inside the distance (the nested kernels: manifold_gp_fit.py); `params`
+        then lists the SCALAR hyper-parameters only."""
         import numpy as np
 
         from . import _compat, ops
         if _compat.HAVE_GPYTORCH:
             return None
-        form = self._stationary_form()
-        if form is None:
-            return None
-        e = form[0]
+        if evaluator is None:
+            form = self._stationary_form()
+            if form is None:
+                return None
+            e = form[0]
         cm = self.covar_module
         base = getattr(cm, "base_kernel", cm)
         index = {id(p): i for i, p in enumerate(params)}
@@ -405,8 +409,10 @@ class SingleTaskGP(torch.nn.Module):
             if type(self.noise_prior) is not GammaPrior:
                 return None
             priors.append(("noise", self.noise_prior.concentration, self.noise_prior.rate))
-        y = self.train_y.to(e.device).contiguous()
-        n = y.numel()
+        n = self.train_y.numel()
+        if evaluator is None:
+            y = self.train_y.to(e.device).contiguous()
+            evaluator = lambda theta, os_, noise, mean: ops.gp_mll(e, y, theta, os_, noise, mean)      # noqa: E731
 
         def objective(v):
             val, dval = {}, {}
@@ -416,7 +422,7 @@ class SingleTaskGP(torch.nn.Module):
                 dval[name] = 1.0 / (1.0 + math.exp(-raw)) if raw >= 0 else math.exp(raw) / (1.0 + math.exp(raw))
             positive = val["theta"]                       # beta, or the lengthscale l with theta = l^-2
             theta, dtheta = (positive, 1.0) if uses_beta else (positive ** -2, -2.0 * positive ** -3)
-            ll, g_theta, g_os, g_noise, g_mean, bad = ops.gp_mll(e, y, theta, val.get("os", 1.0), val["noise"], float(v[i_mean]))
+            ll, g_theta, g_os, g_noise, g_mean, bad = evaluator(theta, val.get("os", 1.0), val["noise"], float(v[i_mean]))
             grad = np.zeros_like(v)
             if bad:
                 return 1e10, grad

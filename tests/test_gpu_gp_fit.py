@@ -462,3 +462,40 @@ def test_nested_spd_eigenvalue_constraints_one_launch_at_config5_size():
         # values only (the strict solver's feasibility test) and a single point
         with torch.no_grad():
             np.testing.assert_allclose(nscu.max_eigenvalue_nested_spd_constraint(T(Y[0]), 5.0, *args).item(), 5.0 - lam[0, -1], rtol=1e-12)
+
+
+@pytest.mark.parametrize("flavour", ["log_euclidean", "affine_invariant"])
+def test_nested_spd_fit_objective_without_autograd_matches_the_autograd_objective(flavour):
+    """fit_gpytorch_manifold's objective for ScaleKernel(NestedSpd*GaussianKernel) - HD-GaBO's surrogate - as a chain of HIP launches
+    with the backward launches called directly (_NestedSpdMllProblem) against the same marginal likelihood differentiated by torch
+    autograd (_MllProblem): value and Euclidean gradients w.r.t. the projection matrix, lengthscale / beta, outputscale, noise and mean."""
+    from gabotorch_amd.kernel_utils.kernels_spd import NestedSpdAffineInvariantGaussianKernel
+    from gabotorch_amd.manifold_optimization import manifold_gp_fit as mgf
+    from gabotorch_amd.manifold_optimization.host_manifolds import Euclidean, Product
+    rng = np.random.default_rng(11)
+    D, dl, n = 8, 2, 12
+    X = torch.tensor(ospd.symmetric_matrix_to_vector_mandel(_rand_spd(rng, n, D)), device=DEV)
+    y = torch.tensor(rng.standard_normal(n), device=DEV)
+    torch.manual_seed(2)
+    base = NestedSpdLogEuclideanGaussianKernel(D, dl) if flavour == "log_euclidean" else NestedSpdAffineInvariantGaussianKernel(D, dl, beta_min=0.3)
+    kern = ScaleKernel(base, outputscale_prior=models.GammaPrior(2.0, 0.15)).double()
+    gp = models.SingleTaskGP(X, y, kern, noise_prior=models.GammaPrior(1.1, 0.05))
+    named = list(gp.named_parameters())
+    params = [p for _, p in named]
+    factors = []
+    for name, p in named:
+        man = getattr(base, "raw_projection_matrix_manifold") if p is base.raw_projection_matrix else Euclidean(int(p.numel()))
+        factors.append(man)
+    manifold = Product(factors)
+    fast = mgf._NestedSpdMllProblem.build(gp, [nm for nm, _ in named], params, manifold)
+    assert fast is not None
+    slow = mgf._MllProblem(gp, [nm for nm, _ in named], params, manifold)
+    for trial in range(3):
+        x = []
+        for p, man in zip(params, factors):
+            x.append(man.rand() if p is base.raw_projection_matrix else rng.normal(0.3, 0.5, size=(int(p.numel()),)))
+        c_fast, c_slow = fast.cost(x), slow.cost(x)
+        np.testing.assert_allclose(c_fast, c_slow, rtol=1e-10)
+        g_fast, g_slow = fast.egrad(x), slow.egrad(x)
+        for a, b, (nm, _) in zip(g_fast, g_slow, named):
+            np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-9, err_msg=nm)
