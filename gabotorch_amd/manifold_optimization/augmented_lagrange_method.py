@@ -57,6 +57,11 @@ class _Subproblem:
         from .approximate_hessian import get_hessianfd
         return get_hessianfd(self, x, a)
 
+    @property
+    def prefetch(self):
+        """the wrapped problem's batched look-ahead (see LineSearchAdaptive.search), when it has one"""
+        return getattr(self.problem, "prefetch", None)
+
     def cost(self, x):                                       # (:273-288)
         c = self.problem.cost(x)
         for k, con in enumerate(self.ineqs):

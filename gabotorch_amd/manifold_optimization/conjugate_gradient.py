@@ -24,16 +24,24 @@ class LineSearchAdaptive:
         self.contraction_factor, self.suff_decr, self.maxiter, self.initial_stepsize = contraction_factor, suff_decr, maxiter, initial_stepsize
         self._oldalpha = None
 
-    def search(self, objective, man, x, d, f0, df0):
+    def search(self, objective, man, x, d, f0, df0, prefetch=None):
+        """prefetch (optional): callable taking a list of points whose objective values will be asked for next - a problem whose
+        evaluations are device launches evaluates them together (the first trial step and the first contraction in one launch: about
+        half of the searches contract once).  It changes which launches compute the values, never the values or the steps taken."""
         norm_d = man.norm(x, d)
         alpha = self._oldalpha if self._oldalpha is not None else self.initial_stepsize / norm_d
         alpha = float(alpha)
         newx = man.retr(x, _scale(alpha, d))
+        nextx = None
+        if prefetch is not None:
+            nextx = man.retr(x, _scale(alpha * self.contraction_factor, d))
+            prefetch([newx, nextx])
         newf = objective(newx)
         evals = 1
         while newf > f0 + self.suff_decr * alpha * df0 and evals <= self.maxiter:
             alpha *= self.contraction_factor
-            newx = man.retr(x, _scale(alpha, d))
+            newx = nextx if nextx is not None else man.retr(x, _scale(alpha, d))
+            nextx = None
             newf = objective(newx)
             evals += 1
         if newf > f0:
@@ -86,7 +94,7 @@ class ConjugateGradient:
             if df0 >= 0:                              # not a descent direction: restart from steepest descent
                 desc = _scale(-1.0, grad)
                 df0 = -grad_grad
-            stepsize, newx, newcost = linesearch.search(problem.cost, man, x, desc, cost, df0)
+            stepsize, newx, newcost = linesearch.search(problem.cost, man, x, desc, cost, df0, prefetch=getattr(problem, "prefetch", None))
             newgrad = problem.grad(newx)
             newgradnorm = man.norm(newx, newgrad)
             new_gg = man.inner(newx, newgrad, newgrad)

@@ -81,16 +81,36 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
             ks = [contraction(x)[0] for x in xs]
             return self.rec.evaluate_host(np.stack([x[0] for x in xs]), np.stack([x[1] for x in xs]), np.stack(ks), grad=False)
 
+        @staticmethod
+        def _key(x):
+            return b"".join(np.ascontiguousarray(p, dtype=np.float64).tobytes() for p in x)
+
+        @staticmethod
+        def _chain(x, t, unit, gV, gC, gK):
+            return [gV, gC, (t * gK).reshape(np.shape(x[2])), np.full(np.shape(x[3]), float(np.sum(gK * unit)) * t * (1.0 - t))]
+
         def __call__(self, x):
-            key = b"".join(np.ascontiguousarray(p, dtype=np.float64).tobytes() for p in x)
+            key = self._key(x)
             for k, value, grads in self.recent:
                 if k == key:
                     return value, grads
             K, t, unit = contraction(x)
             value, gV, gC, gK = self.rec.evaluate_host(x[0], x[1], K, grad=True)
-            grads = [gV, gC, (t * gK).reshape(np.shape(x[2])), np.full(np.shape(x[3]), float(np.sum(gK * unit)) * t * (1.0 - t))]
-            self.recent = [(key, float(value), grads)] + self.recent[:1]
+            grads = self._chain(x, t, unit, gV, gC, gK)
+            self.recent = [(key, float(value), grads)] + self.recent[:3]
             return float(value), grads
+
+        def prefetch(self, xs):
+            """the points a line search will ask for next, in ONE launch (blocks of different parameter sets run side by side: the
+            launch takes as long as a single evaluation)"""
+            xs = [x for x in xs if all(self._key(x) != k for k, _, _ in self.recent)]
+            if len(xs) < 2:
+                return
+            parts = [contraction(x) for x in xs]
+            values, gV, gC, gK = self.rec.evaluate_host(np.stack([x[0] for x in xs]), np.stack([x[1] for x in xs]),
+                                                        np.stack([pt[0] for pt in parts]), grad=True)
+            new = [(self._key(x), float(values[i]), self._chain(x, parts[i][1], parts[i][2], gV[i], gC[i], gK[i])) for i, x in enumerate(xs)]
+            self.recent = new + self.recent[:4 - len(new)]
 
         def cost(self, x):
             return self(x)[0]
@@ -144,6 +164,8 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
     problem.manifold = manifold
     problem.cost = cost_vg.cost
     problem.grad = lambda x: manifold.egrad2rgrad(x, cost_vg(x)[1])
+    if hasattr(cost_vg, "prefetch"):
+        problem.prefetch = cost_vg.prefetch
     con_vg = _OrthogonalityConstraint()
     constraint = _Constraint(manifold, con_vg)
     constraint.cost = con_vg.cost
