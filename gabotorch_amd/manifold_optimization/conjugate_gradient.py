@@ -31,11 +31,16 @@ class LineSearchAdaptive:
         norm_d = man.norm(x, d)
         alpha = self._oldalpha if self._oldalpha is not None else self.initial_stepsize / norm_d
         alpha = float(alpha)
-        newx = man.retr(x, _scale(alpha, d))
         nextx = None
         if prefetch is not None:
-            nextx = man.retr(x, _scale(alpha * self.contraction_factor, d))
+            steps = (alpha, alpha * self.contraction_factor)
+            if hasattr(man, "retr_steps"):
+                newx, nextx = man.retr_steps(x, d, steps)
+            else:
+                newx, nextx = (man.retr(x, _scale(t, d)) for t in steps)
             prefetch([newx, nextx])
+        else:
+            newx = man.retr(x, _scale(alpha, d))
         newf = objective(newx)
         evals = 1
         while newf > f0 + self.suff_decr * alpha * df0 and evals <= self.maxiter:

@@ -155,12 +155,18 @@ class PositiveDefinite:
         return x @ self._sym(g) @ x
 
     def retr(self, x, u):          # retr = exp = L expm(L^-1 U L^-T) L^T
+        return self.retr_steps(x, u, (1.0,))[0]
+
+    exp = retr
+
+    def retr_steps(self, x, u, steps):
+        """[retr(x, t u) for t in steps]: one Cholesky factor and one eigen-decomposition serve every step length (a line search asks for
+        several along one direction): L expm(t S) L^T = (L Q) e^(t w) (L Q)^T with S = L^-1 U L^-T = Q diag(w) Q^T."""
         L = np.linalg.cholesky(x)
         Li = np.linalg.inv(L)
         w, q = np.linalg.eigh(self._sym(Li @ u @ Li.T))
-        return self._sym(L @ (q * np.exp(w)) @ q.T @ L.T)
-
-    exp = retr
+        lq = L @ q
+        return [self._sym((lq * np.exp(t * w)) @ lq.T) for t in steps]
 
     def transp(self, x1, x2, u):
         return u
@@ -204,6 +210,16 @@ class Product:
 
     def retr(self, x, u):
         return self._map("retr", x, u)
+
+    def retr_steps(self, x, u, steps):
+        """[retr(x, t u) for t in steps] (factors that can share work between the steps do: see PositiveDefinite.retr_steps)"""
+        per = []
+        for k, m in enumerate(self._manifolds):
+            if hasattr(m, "retr_steps"):
+                per.append(m.retr_steps(x[k], u[k], steps))
+            else:
+                per.append([m.retr(x[k], t * u[k]) for t in steps])
+        return [[per[k][i] for k in range(len(self._manifolds))] for i in range(len(steps))]
 
     def transp(self, x1, x2, u):
         return self._map("transp", x1, x2, u)

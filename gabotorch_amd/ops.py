@@ -435,13 +435,19 @@ class NestedSpdReconstruction:
         ent = self._buffers.get(P)
         if ent is None:
             lib = _lib.load()
-            npar = sum(self.sizes)
+            nV, nC, nK = self.sizes
+            npar = nV + nC + nK
             ws = max(int(lib.gabo_nested_spd_reconstruction_workspace_bytes(P, max(self.N, 1), self.D, self.d)), 16)
+            host_in, host_out = torch.empty(P * npar, dtype=torch.float64).pin_memory(), torch.empty(P * (1 + npar), dtype=torch.float64).pin_memory()
+            dev_in = torch.empty(P * npar, dtype=torch.float64, device=self.device)
+            dev_out = torch.empty(P * (1 + npar), dtype=torch.float64, device=self.device)
+            o1, o2, o3 = P, P + P * nV, P + P * (nV + nC)
             ent = self._buffers[P] = dict(
-                host_in=torch.empty(P * npar, dtype=torch.float64).pin_memory(), dev_in=torch.empty(P * npar, dtype=torch.float64, device=self.device),
-                host_out=torch.empty(P * (1 + npar), dtype=torch.float64).pin_memory(),
-                dev_out=torch.empty(P * (1 + npar), dtype=torch.float64, device=self.device),
-                ws=torch.empty(ws, dtype=torch.uint8, device=self.device))
+                host_in=host_in, dev_in=dev_in, host_out=host_out, dev_out=dev_out, ws=torch.empty(ws, dtype=torch.uint8, device=self.device),
+                # views made once: an evaluation is host-bound (one launch of ~0.14 ms), every Python-level slice on its path counts
+                hin=host_in.numpy(), hout=host_out.numpy(), v=dev_in[:P * nV], c=dev_in[P * nV:P * (nV + nC)], k=dev_in[P * (nV + nC):],
+                cost=dev_out[:P], gv=dev_out[o1:o2], gc=dev_out[o2:o3], gk=dev_out[o3:], ho_cost=host_out[:P], do_cost=dev_out[:P],
+                stream=torch.cuda.current_stream(self.device))
         return ent
 
     def launch(self, v, c, k, cost, gv, gc, gk, P, ws):
@@ -463,29 +469,26 @@ class NestedSpdReconstruction:
         P = 1 if single else V.shape[0]
         ent = self._staging(P)
         nV, nC, nK = self.sizes
-        hin = ent["host_in"].numpy()
-        hin[:P * nV] = V.reshape(-1)
-        hin[P * nV:P * (nV + nC)] = C.reshape(-1)
-        hin[P * (nV + nC):] = K.reshape(-1)
+        hin = ent["hin"]
+        hin[:P * nV] = V.ravel()
+        hin[P * nV:P * (nV + nC)] = C.ravel()
+        hin[P * (nV + nC):] = K.ravel()
         ent["dev_in"].copy_(ent["host_in"], non_blocking=True)
-        din, dout = ent["dev_in"], ent["dev_out"]
-        v, c, k = din[:P * nV], din[P * nV:P * (nV + nC)], din[P * (nV + nC):]
-        cost = dout[:P]
         if grad:
-            gv, gc, gk = dout[P:P + P * nV], dout[P + P * nV:P + P * (nV + nC)], dout[P + P * (nV + nC):]
+            self.launch(ent["v"], ent["c"], ent["k"], ent["cost"], ent["gv"], ent["gc"], ent["gk"], P, ent["ws"])
+            ent["host_out"].copy_(ent["dev_out"], non_blocking=True)
         else:
-            gv = gc = gk = None
-        self.launch(v, c, k, cost, gv, gc, gk, P, ent["ws"])
-        nout = P * (1 + nV + nC + nK) if grad else P
-        ent["host_out"][:nout].copy_(dout[:nout], non_blocking=True)
+            self.launch(ent["v"], ent["c"], ent["k"], ent["cost"], None, None, None, P, ent["ws"])
+            ent["ho_cost"].copy_(ent["do_cost"], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
-        hout = ent["host_out"].numpy()
+        hout = ent["hout"]
         costs = hout[:P].copy()
         if not grad:
             return costs[0] if single else costs
-        gV = hout[P:P + P * nV].reshape(V.shape).copy()
-        gC = hout[P + P * nV:P + P * (nV + nC)].reshape(C.shape).copy()
-        gK = hout[P + P * (nV + nC):nout].reshape(K.shape).copy()
+        o1, o2, o3 = P, P + P * nV, P + P * (nV + nC)
+        gV = hout[o1:o2].reshape(V.shape).copy()
+        gC = hout[o2:o3].reshape(C.shape).copy()
+        gK = hout[o3:].reshape(K.shape).copy()
         return (costs[0] if single else costs), gV, gC, gK
 
     def __call__(self, V, C, K):
