@@ -82,7 +82,11 @@ def build(force=False, extra_flags=(), verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     if force:
         for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+            path = os.path.join(OBJ, f)
+            if os.path.isdir(path):                    # (tools/ab_build.py keeps its variant objects in sub-directories)
+                shutil.rmtree(path)
+            else:
+                os.remove(path)
     srcs = sources()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, list(extra_flags)), srcs))

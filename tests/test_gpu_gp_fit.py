@@ -386,7 +386,15 @@ def test_fused_reconstruction_launch_at_config5_size():
     from gabotorch_amd.Riemannian_utils import spd_utils_torch as sut
     from oracle import spd as ospd
     rng = np.random.default_rng(21)
-    D, d, N, P = 20, 2, 13, 3
+    _fused_reconstruction_case(rng, 20, 2, 13, 3)
+    _fused_reconstruction_case(rng, 9, 3, 5, 2)              # complement of order 6: the padded order 8 of the wave eigen-solver; D = 9 -> 12
+
+
+def _fused_reconstruction_case(rng, D, d, N, P):
+    from gabotorch_amd import _lib, ops
+    from gabotorch_amd.nested_mappings.nested_spd_utils import projection_from_nested_spd_to_spd
+    from gabotorch_amd.Riemannian_utils import spd_utils_torch as sut
+    from oracle import spd as ospd
     m = D - d
     X = _rand_spd(rng, N, D)
     Rm = np.linalg.qr(rng.standard_normal((D, D)))[0]

@@ -242,3 +242,38 @@ def test_device_spd_sampler_distribution_and_reproducibility():
     big = ops.spd_sample(64, 16, lo, hi, seed=5, device=DEV).cpu().numpy()
     lam16 = np.linalg.eigvalsh(big)
     assert lam16.min() >= lo - 1e-10 and lam16.max() <= hi + 1e-10
+
+
+@pytest.mark.parametrize("d", [5, 8, 9, 12, 13, 20, 21, 32])
+def test_wave_eigen_solver_on_degenerate_and_scaled_inputs(d):
+    """The wave-per-matrix Householder + QL solver (csrc/wave_eigh.hpp: every padded order and its padding cases) through the matrix
+    functions and the extreme-eigenvalue op: identity, repeated eigenvalues, an exactly tridiagonal and an exactly diagonal matrix, the zero
+    matrix (expm), a clustered spectrum, scales 1e-8 and 1e8, an indefinite input (expm of a tangent vector)."""
+    rng = np.random.default_rng(100 + d)
+    q = np.linalg.qr(rng.standard_normal((d, d)))[0]
+    spectra = [np.ones(d), np.repeat([0.5, 2.0], [d // 2, d - d // 2]), np.linspace(0.3, 3.0, d),
+               1.0 + 1e-9 * np.arange(d), np.concatenate([[1e-3], np.full(d - 1, 4.0)])]
+    mats = [(q * lam) @ q.T for lam in spectra]
+    mats.append(np.diag(np.linspace(0.2, 2.0, d)))
+    tri = np.diag(np.linspace(1.0, 2.0, d)) + np.diag(np.full(d - 1, 0.3), 1) + np.diag(np.full(d - 1, 0.3), -1)
+    mats += [tri, 1e-8 * mats[2], 1e8 * mats[2]]
+    mats = np.stack([0.5 * (m + m.T) for m in mats])
+    lam, vec = np.linalg.eigh(mats)
+    fun = lambda f: np.einsum("nab,nb,ncb->nac", vec, f(lam), vec)      # noqa: E731
+    def worst(got, want, scale):            # per matrix: max abs error in units of `scale`
+        return np.abs(got - want).max(axis=(1, 2)) / scale
+    err = worst(ops.spd_manifold_op(_lib.GABO_SPD_LOGM, t(mats)).cpu().numpy(), fun(np.log), np.abs(np.log(lam)).max(axis=1) + 0.1)
+    assert err.max() < 1e-12, err
+    err = worst(ops.spd_manifold_op(_lib.GABO_SPD_SQRTM, t(mats)).cpu().numpy(), fun(np.sqrt), np.sqrt(lam.max(axis=1)))
+    assert err.max() < 1e-13, err
+    for op, pick in ((_lib.GABO_SPD_EIGMAX, -1), (_lib.GABO_SPD_EIGMIN, 0)):
+        val, vv = ops.spd_manifold_op(op, t(mats), want_grad=True)
+        assert (np.abs(val.cpu().numpy() - lam[:, pick]) <= 1e-14 * np.abs(lam).max(axis=1)).all()      # (absolute accuracy eps |A|: the small end of a wide spectrum keeps fewer digits)
+        vv = vv.cpu().numpy()                                           # v v^T of SOME unit vector of the (possibly degenerate) eigenspace
+        np.testing.assert_allclose(np.trace(vv, axis1=1, axis2=2), 1.0, rtol=1e-12)
+        resid = np.einsum("nab,nbc->nac", mats, vv) - lam[:, pick, None, None] * vv
+        np.testing.assert_array_less(np.abs(resid).max(axis=(1, 2)), 1e-11 * np.abs(lam).max(axis=1) + 1e-300)
+    tangent = np.stack([np.zeros((d, d)), 0.5 * (mats[2] - 1.5 * np.eye(d))])       # zero and an indefinite symmetric matrix
+    lt, vt = np.linalg.eigh(tangent)
+    err = worst(ops.spd_manifold_op(_lib.GABO_SPD_EXPM, t(tangent)).cpu().numpy(), np.einsum("nab,nb,ncb->nac", vt, np.exp(lt), vt), np.exp(lt.max(axis=1)))
+    assert err.max() < 1e-13, err
