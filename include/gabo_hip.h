@@ -220,7 +220,7 @@ int gabo_gp_mll(const double* e, const double* y, int64_t n, double theta, doubl
 int gabo_gp_mll_gram(const double* k, const double* y, int64_t n, double outputscale, double noise, double mean, double* out, double* w,
                      gabo_stream_t stream);
 /* Both of the above for larger training sets, n <= GABO_GP_MLL_LARGE_MAX_N: the same sweep operator on 32 x 32 tiles of the bordered
- * matrix in the caller's workspace, two launches per block of 32 pivots (csrc/gp_mll_large.hip).  gram = 0: e as in gabo_gp_mll;
+ * matrix in the caller's workspace, one launch per block of 32 pivots (csrc/gp_mll_large.hip).  gram = 0: e as in gabo_gp_mll;
  * gram != 0: e is the base Gram matrix as in gabo_gp_mll_gram (theta unused, out[1] = 0).  w: NULL or n x n as above.  Both triangles
  * of e are read. */
 #define GABO_GP_MLL_LARGE_MAX_N 2048
