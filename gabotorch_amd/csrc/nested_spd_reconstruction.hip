@@ -40,25 +40,30 @@ static __device__ void lds_gemm(const double* A, int ai, int ak, const double* B
     __syncthreads();
 }
 
-// divided differences of log / sqrt at two eigenvalues (the diagonal gives the derivative); the same expressions as
-// spd_matfun_backward_kernel (spd_manifold.hip)
-static __device__ __forceinline__ double divided_difference(double lr, double lc, int fn) {
-    const double mean = 0.5 * (lr + lc), dl = lr - lc;
+// divided differences of log / sqrt at two eigenvalues (the diagonal gives the derivative) from the eigenvalues and f at them; the same
+// expressions as spd_matfun_backward_kernel (spd_manifold.hip)
+static __device__ __forceinline__ double divided_difference(double lr, double lc, double fr, double fc, int fn) {
     if (fn == FN_LOG) {
+        const double mean = 0.5 * (lr + lc), dl = lr - lc;
         const double z = dl / (2.0 * mean), z2 = z * z;
-        return (__builtin_fabs(z) < 1e-3) ? (1.0 + z2 * (1.0 / 3.0 + z2 * (0.2 + z2 * (1.0 / 7.0)))) / mean : (log(lr) - log(lc)) / dl;
+        return (__builtin_fabs(z) < 1e-3) ? (1.0 + z2 * (1.0 / 3.0 + z2 * (0.2 + z2 * (1.0 / 7.0)))) / mean : (fr - fc) / dl;
     }
-    return 1.0 / (__builtin_sqrt(lr) + __builtin_sqrt(lc));
+    return 1.0 / (fr + fc);
 }
 
-// out = U ((U^T sym(G) U) o F) U^T, symmetrised; lam on the diagonal of Lam.  G is overwritten; T scratch.  n x n matrices in LDS.
-static __device__ void lds_matfun_adjoint(const double* Lam, const double* U, double* G, double* T, double* out, int n, int fn) {
+// out = U ((U^T sym(G) U) o F) U^T, symmetrised; lam on the diagonal of Lam.  G is overwritten; T scratch; fl: n doubles of scratch for f(lambda).
+// n x n matrices in LDS.
+static __device__ void lds_matfun_adjoint(const double* Lam, const double* U, double* G, double* T, double* out, int n, int fn, double* fl) {
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const double lam = Lam[k * n + k];
+        fl[k] = fn == FN_LOG ? log(lam) : __builtin_sqrt(lam);
+    }
     lds_symmetrize(G, T, n);
     lds_mm(U, G, T, n, true, false);          // U^T G
     lds_mm(T, U, G, n, false, false);         // U^T G U
     for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
         const int r = e / n, c = e - r * n;
-        G[e] *= divided_difference(Lam[r * n + r], Lam[c * n + c], fn);
+        G[e] *= divided_difference(Lam[r * n + r], Lam[c * n + c], fl[r], fl[c], fn);
     }
     __syncthreads();
     lds_mm(U, G, T, n, false, false);
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256) void nested_spd_reconstruction_kernel(const do
         }
         __syncthreads();
         if (want_grad) {
-            lds_matfun_adjoint(M0, M1, M2, M3, M4, D, FN_LOG);
+            lds_matfun_adjoint(M0, M1, M2, M3, M4, D, FN_LOG, cs);
             for (int e = threadIdx.x; e < DD; e += blockDim.x) M2[e] = M4[e];   // M2 = G
             __syncthreads();
         }
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void nested_spd_reconstruction_kernel(const do
         gk[(size_t)p * d * m + e] = s;
     }
     lds_gemm(Kl, 1, m, SumT, m, 1, M2, m, m, d);          // K^T G_T
-    lds_matfun_adjoint(Lc, Uc, M2, M3, M4, m, FN_SQRT);
+    lds_matfun_adjoint(Lc, Uc, M2, M3, M4, m, FN_SQRT, cs);
     for (int e = threadIdx.x; e < mm; e += blockDim.x) gc[(size_t)p * mm + e] = SumBB[e] + M4[e];
     GABO_RECON_TICK(7);
 }

@@ -380,6 +380,8 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_backward_kernel(const doub
     lds_eigh<QL>(M0, M1, cs, d);                  // M0 = diag(lambda), M1 = V
     lds_mm(M1, M2, M3, d, true, false);         // V^T G
     lds_mm(M3, M1, M2, d, false, false);        // V^T G V
+    for (int k = threadIdx.x; k < d; k += blockDim.x) cs[k] = log(M0[k * d + k]);     // (d logarithms, not 2 d^2: the eigen-solver's scratch is free)
+    wsync();
     for (int e = threadIdx.x; e < dd; e += blockDim.x) {
         int r = e / d, c = e - r * d;
         double lr = M0[r * d + r], lc = M0[c * d + c];
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(64) void spd_logm_mandel_backward_kernel(const doub
         // log(lr/lc)/(lr-lc) = atanh(z)/(z mean) with z = dl/(2 mean): series near z = 0 keeps full precision
         double z = dl / (2.0 * mean), z2 = z * z;
         double f = (__builtin_fabs(z) < 1e-3) ? (1.0 + z2 * (1.0 / 3.0 + z2 * (0.2 + z2 * (1.0 / 7.0)))) / mean
-                                              : (log(lr) - log(lc)) / dl;
+                                              : (cs[r] - cs[c]) / dl;
         M2[e] *= f;
     }
     wsync();
@@ -433,6 +435,11 @@ __global__ __launch_bounds__(THREADS) void spd_matfun_backward_kernel(const doub
     }
     lds_mm(M1, M2, M3, d, true, false);         // V^T G
     lds_mm(M3, M1, M2, d, false, false);        // V^T G V
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {                       // f(lambda_k) once per eigenvalue (the eigen-solver's scratch is free)
+        const double lam = M0[k * d + k];
+        cs[k] = fn == FN_LOG ? log(lam) : (fn == FN_SQRT ? __builtin_sqrt(lam) : 0.0);
+    }
+    wsync();
     for (int e = threadIdx.x; e < dd; e += blockDim.x) {
         int r = e / d, c = e - r * d;
         const double lr = M0[r * d + r], lc = M0[c * d + c];
@@ -440,9 +447,9 @@ __global__ __launch_bounds__(THREADS) void spd_matfun_backward_kernel(const doub
         double f;
         if (fn == FN_LOG) {
             const double z = dl / (2.0 * mean), z2 = z * z;
-            f = (__builtin_fabs(z) < 1e-3) ? (1.0 + z2 * (1.0 / 3.0 + z2 * (0.2 + z2 * (1.0 / 7.0)))) / mean : (log(lr) - log(lc)) / dl;
+            f = (__builtin_fabs(z) < 1e-3) ? (1.0 + z2 * (1.0 / 3.0 + z2 * (0.2 + z2 * (1.0 / 7.0)))) / mean : (cs[r] - cs[c]) / dl;
         } else if (fn == FN_SQRT) {
-            f = 1.0 / (__builtin_sqrt(lr) + __builtin_sqrt(lc));          // (sqrt lr - sqrt lc)/(lr - lc), exact and stable
+            f = 1.0 / (cs[r] + cs[c]);                                      // (sqrt lr - sqrt lc)/(lr - lc), exact and stable
         } else {
             const double h = 0.5 * dl, h2 = h * h;                         // (e^lr - e^lc)/(lr - lc) = e^mean sinh(h)/h
             const double sh = (__builtin_fabs(h) < 1e-2) ? 1.0 + h2 * (1.0 / 6.0 + h2 * (1.0 / 120.0 + h2 / 5040.0)) : sinh(h) / h;
