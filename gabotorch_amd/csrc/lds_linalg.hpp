@@ -17,7 +17,7 @@ static __device__ void lds_from_mandel(const double* __restrict__ v, double* A, 
         int r = e / d, c = e - r * d;
         int hi = r > c ? r : c, lo = r > c ? c : r;
         double x = v[mandel_pos(d, hi, lo)];
-        A[e] = (r == c) ? x : x / kSqrt2;
+        A[e] = (r == c) ? x : x * kInvSqrt2;
     }
     wsync();
 }
@@ -45,7 +45,8 @@ static __device__ bool lds_cholesky(double* A, int d) {
         double piv = A[c * d + c];
         for (int k = 0; k < c; ++k) piv -= A[c * d + k] * A[c * d + k];
         if (!(piv > 0.0)) ok = false;
-        double lcc = __builtin_sqrt(piv);
+        const double inv = rsqrt_nz(piv);           // (see mandel_cholesky, spd_prep.hpp)
+        const double lcc = piv * inv;
         wsync();
         for (int r = c + threadIdx.x; r < d; r += blockDim.x) {
             if (r == c) {
@@ -53,7 +54,7 @@ static __device__ bool lds_cholesky(double* A, int d) {
             } else {
                 double s = A[r * d + c];
                 for (int k = 0; k < c; ++k) s -= A[r * d + k] * A[c * d + k];
-                A[r * d + c] = s / lcc;
+                A[r * d + c] = s * inv;
             }
         }
         for (int r = threadIdx.x; r < c; r += blockDim.x) A[r * d + c] = 0.0;
@@ -66,11 +67,11 @@ static __device__ bool lds_cholesky(double* A, int d) {
 static __device__ void lds_tri_inverse(const double* L, double* W, int d) {
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         for (int r = 0; r < c; ++r) W[r * d + c] = 0.0;
-        W[c * d + c] = 1.0 / L[c * d + c];
+        W[c * d + c] = rcp(L[c * d + c]);
         for (int r = c + 1; r < d; ++r) {
             double s = 0.0;
             for (int k = c; k < r; ++k) s += L[r * d + k] * W[k * d + c];
-            W[r * d + c] = -s / L[r * d + r];
+            W[r * d + c] = -s * rcp(L[r * d + r]);
         }
     }
     wsync();

@@ -17,7 +17,9 @@ __device__ __forceinline__ bool mandel_cholesky(const double* __restrict__ v, do
         static_for<r + 1>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             double e = v[mandel_pos(D, r, c)];
-            a[tri(r, c)] = (r == c) ? e : e / kSqrt2;  // spd_utils_torch.py:186-187 divides by 2**0.5
+            // (spd_utils_torch.py:186-187 divides by 2**0.5; the product with 1/sqrt2 differs from the quotient by at most one ulp of an entry that
+            // only feeds the factorisation, and an fp64 division is ~35 instructions: T of them per matrix were the larger part of this function)
+            a[tri(r, c)] = (r == c) ? e : e * kInvSqrt2;
         });
     });
     bool bad = false;
@@ -26,8 +28,10 @@ __device__ __forceinline__ bool mandel_cholesky(const double* __restrict__ v, do
         double piv = a[tri(c, c)];
         static_for<c>([&](auto kk) { constexpr int k = decltype(kk)::value; piv = __builtin_fma(-a[tri(c, k)], a[tri(c, k)], piv); });
         if (!(piv > 0.0)) bad = true;
-        double lcc = __builtin_sqrt(piv);
-        double inv = 1.0 / lcc;
+        // 1 / sqrt(piv) by seed + cubic correction, L_cc = piv / sqrt(piv): 8 instructions for the IEEE sqrt and division's ~50 (a non-positive
+        // pivot - flagged above - still yields NaN / inf here, as the square root did)
+        double inv = rsqrt_nz(piv);
+        double lcc = piv * inv;
         a[tri(c, c)] = lcc;
         static_for<D - c - 1>([&](auto rr) {
             constexpr int r = c + 1 + decltype(rr)::value;
@@ -44,7 +48,7 @@ template <int D>
 __device__ __forceinline__ void lower_inverse(const double (&a)[tri_size(D)], double (&w)[tri_size(D)]) {
     static_for<D>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        w[tri(c, c)] = 1.0 / a[tri(c, c)];
+        w[tri(c, c)] = rcp(a[tri(c, c)]);
     });
     static_for<D>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
