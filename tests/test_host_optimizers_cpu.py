@@ -152,3 +152,66 @@ def test_alm_with_trust_regions_and_callable_constraints():
     xa, alog = AugmentedLagrangeMethod(maxiter=5, inner_solver=TrustRegions(maxiter=50, logverbosity=1), logverbosity=1).solve(
         problem, x=x0.copy(), eq_constraints=lambda x: x[0] - 0.3)
     assert isinstance(xa, np.ndarray) and "iterations" in alog
+
+
+def test_retr_steps_and_line_search_prefetch_change_no_step():
+    """Product.retr_steps (one Cholesky + eigh of the SPD factor shared by the step lengths of a line search) equals separate retractions, and a
+    problem that offers `prefetch` (batched look-ahead of the line search: the first trial step and its first contraction) is driven through
+    exactly the same iterates as one that does not - prefetch only changes which evaluations compute the values."""
+    import numpy as np
+    from gabotorch_amd.manifold_optimization.conjugate_gradient import ConjugateGradient
+    from gabotorch_amd.manifold_optimization.host_manifolds import Euclidean, Grassmann, PositiveDefinite, Product, Sphere
+    np.random.seed(3)
+    man = Product([Grassmann(6, 4), PositiveDefinite(4), Sphere(8), Euclidean(1)])
+    x = man.rand()
+    u = man.proj(x, [0.2 * np.random.randn(*np.shape(xi)) for xi in x])
+    for got, t in zip(man.retr_steps(x, u, (0.7, 0.35, 0.0)), (0.7, 0.35, 0.0)):
+        want = man.retr(x, [t * ui for ui in u])
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-13)
+    target = man.rand()
+
+    class Problem:
+        manifold = man
+        asked = 0
+
+        def cost(self, p):
+            Problem.asked += 1
+            return float(sum(np.sum((a - b) ** 2) for a, b in zip(p, target)))
+
+        def grad(self, p):
+            return man.egrad2rgrad(p, [2.0 * (a - b) for a, b in zip(p, target)])
+
+    class Prefetching(Problem):
+        seen = []
+
+        def prefetch(self, points):
+            Prefetching.seen.append(len(points))
+
+    plain, _ = ConjugateGradient(maxiter=15).solve(Problem(), x=x)
+    ahead, log = ConjugateGradient(maxiter=15).solve(Prefetching(), x=x)
+    assert Prefetching.seen and all(k == 2 for k in Prefetching.seen)
+    for a, b in zip(plain, ahead):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+    assert log["final_cost"] < 0.5 * Problem().cost(x)
+
+
+def test_nested_eigenvalue_partials_are_recognised_with_their_mapping():
+    """builtin_constraint on functools.partial(max/min_eigenvalue_nested_spd_constraint, bound=..., <the four mapping tensors by keyword>) - the
+    form examples/hd_bo_spd/benchmark_examples/hd_gabo_spd.py:244-257 builds - returns the nested kind, the bound and the mapping tensors;
+    positional mappings, missing tensors or a mapping that requires a gradient stay host callables."""
+    import functools
+    import torch
+    from gabotorch_amd import _lib
+    from gabotorch_amd.nested_mappings import nested_spd_constraints_utils as nscu
+    from gabotorch_amd.Riemannian_utils.spd_constraints_utils_torch import builtin_constraint
+    W, V, C, K = torch.zeros(6, 2, dtype=torch.float64), torch.zeros(6, 4, dtype=torch.float64), torch.eye(4, dtype=torch.float64), torch.zeros(2, 4, dtype=torch.float64)
+    mapping = dict(projection_matrix=W, projection_complement_matrix=V, bottom_spd_matrix=C, contraction_matrix=K)
+    b = builtin_constraint(functools.partial(nscu.max_eigenvalue_nested_spd_constraint, maximum_eigenvalue=5.0, **mapping))
+    assert b[0] == _lib.GABO_CONSTRAINT_MAX_EIGENVALUE_NESTED and b[1] == 5.0 and all(x is y for x, y in zip(b[2], (W, V, C, K)))
+    b = builtin_constraint(functools.partial(nscu.min_eigenvalue_nested_spd_constraint, minimum_eigenvalue=torch.tensor(1e-4, dtype=torch.float64), **mapping))
+    assert b[0] == _lib.GABO_CONSTRAINT_MIN_EIGENVALUE_NESTED and abs(b[1] - 1e-4) < 1e-18
+    assert builtin_constraint(functools.partial(nscu.max_eigenvalue_nested_spd_constraint, 5.0, W, V, C, K)) is None
+    grad_map = dict(mapping, bottom_spd_matrix=C.clone().requires_grad_(True))
+    assert builtin_constraint(functools.partial(nscu.max_eigenvalue_nested_spd_constraint, maximum_eigenvalue=5.0, **grad_map)) is None
+    assert builtin_constraint(functools.partial(nscu.max_eigenvalue_nested_spd_constraint, maximum_eigenvalue=5.0, projection_matrix=W)) is None
