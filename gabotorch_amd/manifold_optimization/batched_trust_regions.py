@@ -279,8 +279,43 @@ class BatchedTrustRegions:
 
     # ------------------------------------------------------------------------------------------------- constraints
     @staticmethod
+    def _nested_group(x, constraints):
+        """(is_max, bounds, (w, x0, p)) when EVERY constraint is a functools.partial over max/min_eigenvalue_nested_spd_constraint with
+        one common mapping (HD-GaBO's bounds in the original space): one launch of gabo_nested_spd_extreme_eigenvalues then serves them
+        all - both extreme eigenpairs come out of the same Householder reduction - with their gradients, no autograd graph.  None
+        otherwise (the callables are called one by one)."""
+        if not constraints or not torch.is_tensor(x) or not x.is_cuda:
+            return None
+        from .. import _lib
+        from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint
+        info = [builtin_constraint(c) for c in constraints]
+        if any(b is None or len(b) != 3 for b in info):
+            return None
+        first = info[0][2]
+        if any(any(s is not t for s, t in zip(first, b[2])) for b in info[1:]):
+            return None
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in first)
+        memo = getattr(first[2], "_gabo_lift", None)         # (the memo nested_spd_constraints_utils._lifted_extremes keeps)
+        if memo is None or memo[0] != key:
+            from .. import ops
+            memo = (key, ops.nested_spd_lift_prepare(*first))
+            try:
+                first[2]._gabo_lift = memo
+            except AttributeError:
+                pass
+        return [b[0] == _lib.GABO_CONSTRAINT_MAX_EIGENVALUE_NESTED for b in info], [b[1] for b in info], memo[1]
+
+    @staticmethod
     def _constraint_values_grads(problem, x, constraints):
         """-> fc (R, C), rgrad (C tensors of shape R x *shape)"""
+        group = BatchedTrustRegions._nested_group(x, constraints)
+        if group is not None:
+            from .. import ops
+            is_max, bounds, (w, x0, p) = group
+            lam, grad = ops.nested_spd_extreme_eigenvalues(x.detach(), w, p, x0, want_grad=True)
+            vals = [(b - lam[:, 0]) if mx else (lam[:, 1] - b) for mx, b in zip(is_max, bounds)]
+            grads = [problem.manifold.egrad2rgrad(x, (-grad[:, 0]) if mx else grad[:, 1]) for mx in is_max]
+            return torch.stack(vals, dim=1).to(x.dtype), grads
         vals, grads = [], []
         for con in constraints:
             xx = x.detach().clone().requires_grad_(True)
@@ -303,6 +338,12 @@ class BatchedTrustRegions:
     @staticmethod
     def _constraint_values(x, constraints):
         """-> fc (R, C) only (the strict variant's feasibility test of a proposal needs no gradients)"""
+        group = BatchedTrustRegions._nested_group(x, constraints)
+        if group is not None:
+            from .. import ops
+            is_max, bounds, (w, x0, p) = group
+            lam = ops.nested_spd_extreme_eigenvalues(x.detach(), w, p, x0)
+            return torch.stack([(b - lam[:, 0]) if mx else (lam[:, 1] - b) for mx, b in zip(is_max, bounds)], dim=1).to(x.dtype)
         vals = []
         with torch.no_grad():
             for con in constraints:
