@@ -25,6 +25,7 @@ GABO_METRIC_AFFINE_INVARIANT, GABO_METRIC_LOG_EUCLIDEAN, GABO_METRIC_FROBENIUS =
 GABO_CONSTRAINT_MAX_EIGENVALUE, GABO_CONSTRAINT_MIN_EIGENVALUE = 0, 1
 GABO_CONSTRAINT_MAX_EIGENVALUE_NESTED, GABO_CONSTRAINT_MIN_EIGENVALUE_NESTED = 2, 3
 GABO_RECON_AFFINE_INVARIANT, GABO_RECON_LOG_EUCLIDEAN = 0, 1
+GABO_RECON_STOP = ("max iterations", "max time", "min step size", "min grad norm")     # GABO_RECON_STOP_* of the header, by code
 GABO_SPH_PROJ, GABO_SPH_RETR, GABO_SPH_EXP, GABO_SPH_LOG, GABO_SPH_DIST, GABO_SPH_EHESS2RHESS = range(6)
 
 _ERR = {GABO_ERR_DIM: "unsupported dimension", GABO_ERR_ARG: "bad argument", GABO_ERR_NOT_SPD: "input is not SPD",
@@ -48,6 +49,22 @@ class SphereAcqParams(_c.Structure):
                 ("outputscale", _c.c_double), ("kxx", _c.c_double), ("best_f", _c.c_double), ("kind", _c.c_int), ("maximize", _c.c_int),
                 ("out_sign", _c.c_double)]
 
+
+class ReconSolveOptions(_c.Structure):
+    """gabo_recon_solve_options of include/gabo_hip.h"""
+    _fields_ = [(k, _c.c_double) for k in ("bound", "rho_init", "thetarho", "tau", "starting_tolgradnorm", "ending_tolgradnorm", "gammas_fact",
+                                          "minstepsize", "maxtime")] + [("maxiter", _c.c_int64)] + \
+               [(k, _c.c_double) for k in ("cg_minstepsize", "cg_maxtime", "cg_orth_value")] + [("cg_maxiter", _c.c_int64)]
+
+
+class ReconSolveLog(_c.Structure):
+    """gabo_recon_solve_log of include/gabo_hip.h"""
+    _fields_ = [(k, _c.c_int64) for k in ("outer_iterations", "inner_iterations", "evaluations", "launches")] + [("stop_reason", _c.c_int)] + \
+               [(k, _c.c_double) for k in ("violation", "rho", "gamma", "final_cost", "seconds")]
+
+
+# gabo_recon_eval_fn: int (void* ctx, int64 P, const double* v, c, k, double* cost, grad_v, grad_c, grad_k)
+ReconEvalFn = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_int64, *([_c.POINTER(_c.c_double)] * 7))
 
 SIGNATURES = {
     "gabo_version": (_I, []),
@@ -99,7 +116,10 @@ SIGNATURES = {
     "gabo_nested_spd_reconstruction_prepare": (_I, [_P, _P, _I64, _I, _I, _P, _P]),
     "gabo_nested_spd_lift_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "gabo_nested_spd_extreme_eigenvalues": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _I, _P]),
-    "gabo_nested_spd_reconstruction": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _SZ, _P]),
+    "gabo_nested_spd_reconstruction": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _SZ, _P]),
+    "gabo_nested_spd_reconstruction_solve_workspace_bytes": (None, [_I64, _I, _I, _P, _P]),
+    "gabo_nested_spd_reconstruction_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _P, _SZ, _P, _SZ, _P, _P, _P]),
+    "gabo_nested_spd_reconstruction_solve_with": (_I, [ReconEvalFn, _P, _P, _P, _P, _P, _P, _I, _I, _P, _SZ, _P, _P]),
 }
 
 _lib = None

@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void nested_spd_reconstruction_kernel(const do
                                                                         const double* __restrict__ v, const double* __restrict__ c,
                                                                         const double* __restrict__ k, double* __restrict__ cost,
                                                                         double* __restrict__ gv, double* __restrict__ gc,
-                                                                        double* __restrict__ gk, int P, int N, int D, int d, int metric,
-                                                                        int* __restrict__ counters, double* __restrict__ records) {
+                                                                        double* __restrict__ gk, const double* __restrict__ c_lam,
+                                                                        const double* __restrict__ c_vec, int P, int N, int D, int d,
+                                                                        int metric, int* __restrict__ counters, double* __restrict__ records) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = D - d, DD = D * D, mm = m * m;
     const ReconLayout lay{D, d, m};
@@ -133,13 +134,22 @@ __global__ __launch_bounds__(256) void nested_spd_reconstruction_kernel(const do
         Sl[e] = 0.5 * (sy[(size_t)n * d * d + r * d + cc] + sy[(size_t)n * d * d + cc * d + r]);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < mm; e += blockDim.x) Lc[e] = Cl[e];
-    __syncthreads();
-
-    // ---- C^1/2 = Uc sqrt(Lc) Uc^T
+    // ---- C^1/2 = Uc sqrt(Lc) Uc^T: from the caller's eigen-decomposition of C when it has one (the native optimisation loop factors
+    // each iterate on the host in ~5 us; here it is a lone wave's ~50 us on the critical path of every block), else factored here
     GABO_RECON_TICK(1);
-    if (m >= kWaveEighMinDim) lds_eigh<true>(Lc, Uc, cs, m);
-    else lds_eigh<false>(Lc, Uc, cs, m);
+    if (c_lam != nullptr) {
+        for (int e = threadIdx.x; e < mm; e += blockDim.x) {
+            const int r = e / m, cc = e - r * m;
+            Lc[e] = r == cc ? c_lam[(size_t)p * m + r] : 0.0;
+            Uc[e] = c_vec[(size_t)p * mm + e];
+        }
+        __syncthreads();
+    } else {
+        for (int e = threadIdx.x; e < mm; e += blockDim.x) Lc[e] = Cl[e];
+        __syncthreads();
+        if (m >= kWaveEighMinDim) lds_eigh<true>(Lc, Uc, cs, m);
+        else lds_eigh<false>(Lc, Uc, cs, m);
+    }
     GABO_RECON_TICK(2);
     lds_fun_from_eig(Lc, Uc, Cs, m, FN_SQRT, cs);
     lds_gemm(Kl, m, 1, Cs, m, 1, Tl, d, m, m);            // T = K C^1/2
@@ -350,10 +360,10 @@ int gabo_nested_spd_reconstruction_prepare(const double* x, double* out, int64_t
 
 int gabo_nested_spd_reconstruction(const double* data, const double* y, const double* sqrt_y, const double* w, const double* v,
                                    const double* c, const double* k, double* cost, double* grad_v, double* grad_c, double* grad_k,
-                                   int64_t P, int64_t N, int D, int d, int metric, void* workspace, size_t workspace_bytes,
-                                   gabo_stream_t stream) {
+                                   const double* c_eigenvalues, const double* c_eigenvectors, int64_t P, int64_t N, int D, int d, int metric,
+                                   void* workspace, size_t workspace_bytes, gabo_stream_t stream) {
     if (D < 2 || D > GABO_SPD_MAX_DIM || d < 1 || d >= D) return GABO_ERR_DIM;
-    if (P < 0 || N < 0 || (metric != 0 && metric != 1)) return GABO_ERR_ARG;
+    if (P < 0 || N < 0 || (metric != 0 && metric != 1) || ((c_eigenvalues == nullptr) != (c_eigenvectors == nullptr))) return GABO_ERR_ARG;
     if (P == 0) return GABO_OK;
     if (!cost) return GABO_ERR_ARG;
     const bool grads = grad_v || grad_c || grad_k;
@@ -381,7 +391,7 @@ int gabo_nested_spd_reconstruction(const double* data, const double* y, const do
             return GABO_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(gabo::nested_spd_reconstruction_kernel, dim3((unsigned)(P * N)), dim3(256), lds, (hipStream_t)stream, data, y, sqrt_y, w, v,
-                       c, k, cost, grad_v, grad_c, grad_k, (int)P, (int)N, D, d, metric, cnt, records);
+                       c, k, cost, grad_v, grad_c, grad_k, c_eigenvalues, c_eigenvectors, (int)P, (int)N, D, d, metric, cnt, records);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 }

@@ -8,6 +8,7 @@ import torch
 
 from .. import _lib, ops
 from ..manifold_optimization.augmented_lagrange_method import AugmentedLagrangeMethod, _Constraint
+from ..manifold_optimization.conjugate_gradient import ConjugateGradient
 from ..manifold_optimization.host_manifolds import Euclidean, Grassmann, PositiveDefinite, Product, Sphere
 
 
@@ -32,11 +33,15 @@ def min_log_euclidean_distance_reconstruction_cost(x_data, x_data_projected, pro
 
 def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, projection_matrix, inner_solver,
                                                   cost_function=min_affine_invariant_distance_reconstruction_cost,
-                                                  nb_init_candidates=100, maxiter=50, hip_graphs=True):
+                                                  nb_init_candidates=100, maxiter=50, hip_graphs=True, native=True, alm_options=None):
     """-> (projection_complement_matrix D x (D-d), bottom_spd_matrix (D-d) x (D-d), contraction_matrix d x (D-d))
     (nested_spd_optimization.py:95-186).  The two built-in costs are served by the fused launch (the parameters stay host-resident numpy
     arrays as in the reference; an evaluation is one pinned copy in, one launch, one copy out; the nb_init_candidates start points are ONE
-    launch); any other cost_function is differentiated by autograd, evaluation by evaluation.  hip_graphs: kept for signature compatibility."""
+    launch); any other cost_function is differentiated by autograd, evaluation by evaluation.  hip_graphs: kept for signature compatibility.
+    native: with a built-in cost and this package's ConjugateGradient as the inner solver (what the HD-GaBO example passes), the whole
+    augmented-Lagrangian run is one call of the native host loop (gabo_nested_spd_reconstruction_solve: the same algorithm in C++ around
+    the same launch - the numpy bookkeeping between two launches cost as much as the launches); False keeps the Python loop.
+    alm_options: further keyword arguments of AugmentedLagrangeMethod (the reference fixes them: lambdas_fact = 0.05 and the defaults)."""
     dev, dt = x_data.device, torch.float64
     x_data, x_data_projected, W = x_data.to(dt), x_data_projected.to(dev, dt), projection_matrix.to(dev, dt)
     dim, latent = x_data.shape[1], W.shape[1]
@@ -172,7 +177,18 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
     cands = [manifold.rand() for _ in range(nb_init_candidates)]
     vals = cost_vg.many(cands)                                           # best of the random starts (:158-166): one launch
     x0 = cands[int(np.argmin(vals))]
-    solver = AugmentedLagrangeMethod(maxiter=maxiter, inner_solver=inner_solver, lambdas_fact=0.05)
+    solver = AugmentedLagrangeMethod(**dict(dict(maxiter=maxiter, inner_solver=inner_solver, lambdas_fact=0.05), **(alm_options or {})))
+    if native and isinstance(cost_vg, _FusedEvaluator) and type(inner_solver) is ConjugateGradient:
+        options = _lib.ReconSolveOptions(
+            bound=solver._bound, rho_init=solver._rho_init, thetarho=solver._thetarho, tau=solver._tau,
+            starting_tolgradnorm=solver._starting_tolgradnorm, ending_tolgradnorm=solver._ending_tolgradnorm, gammas_fact=solver._gammas_fact,
+            minstepsize=solver._minstepsize, maxtime=solver._maxtime, maxiter=solver._maxiter, cg_minstepsize=inner_solver.minstepsize,
+            cg_maxtime=inner_solver.maxtime, cg_orth_value=inner_solver.orth_value, cg_maxiter=inner_solver.maxiter)
+        v, c, unit, raw, log = cost_vg.rec.solve_host(x0[0], x0[1], x0[2], x0[3], options)
+        opt = [v, c, unit, raw]
+        optimize_reconstruction_parameters_nested_spd.last_log = dict(log, init_cost=float(np.min(vals)), native=True)
+        return (torch.tensor(v, dtype=dt, device=dev), torch.tensor(c, dtype=dt, device=dev),
+                torch.tensor(contraction(opt)[0], dtype=dt, device=dev))
     opt = solver.solve(problem, x=x0, eq_constraints=[constraint])
     V = torch.tensor(opt[0], dtype=dt, device=dev)
     C = torch.tensor(opt[1], dtype=dt, device=dev)

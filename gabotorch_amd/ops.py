@@ -456,8 +456,9 @@ class NestedSpdReconstruction:
         ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
         with torch.cuda.device(self.device):
             _lib.check(lib.gabo_nested_spd_reconstruction(self.data.data_ptr(), self.y.data_ptr(), self.sqrt_y.data_ptr(), self.w.data_ptr(),
-                                                          v.data_ptr(), c.data_ptr(), k.data_ptr(), cost.data_ptr(), ptr(gv), ptr(gc), ptr(gk), P,
-                                                          self.N, self.D, self.d, self.metric, ws.data_ptr(), ws.numel(), _stream_ptr(self.device)),
+                                                          v.data_ptr(), c.data_ptr(), k.data_ptr(), cost.data_ptr(), ptr(gv), ptr(gc), ptr(gk), None,
+                                                          None, P, self.N, self.D, self.d, self.metric, ws.data_ptr(), ws.numel(),
+                                                          _stream_ptr(self.device)),
                        "gabo_nested_spd_reconstruction")
 
     def evaluate_host(self, V, C, K, grad=True):
@@ -494,6 +495,79 @@ class NestedSpdReconstruction:
     def __call__(self, V, C, K):
         """Differentiable (first order) torch form: V (D, m), C (m, m), K (d, m) tensors -> 0-dim cost."""
         return _NestedSpdReconstructionFn.apply(self, V, C, K)
+
+    def solve_host(self, V, C, unit, raw, options):
+        """The augmented-Lagrangian / conjugate-gradient run from the start point (V, C, unit, raw) as ONE call of the native host loop
+        (gabo_nested_spd_reconstruction_solve): numpy in, numpy out -> (V, C, unit, raw, log dict).  options: _lib.ReconSolveOptions."""
+        import ctypes
+
+        import numpy as np
+        lib = _lib.load()
+        ent = self._buffers.get("solve")
+        if ent is None:
+            dev_bytes, pin_doubles = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            lib.gabo_nested_spd_reconstruction_solve_workspace_bytes(self.N, self.D, self.d, ctypes.byref(dev_bytes), ctypes.byref(pin_doubles))
+            ent = self._buffers["solve"] = dict(ws=torch.empty(max(dev_bytes.value, 16), dtype=torch.uint8, device=self.device),
+                                                pinned=torch.empty(pin_doubles.value, dtype=torch.float64).pin_memory(),
+                                                w_host=np.ascontiguousarray(self.w.cpu().numpy(), dtype=np.float64))
+        v, c, u = (np.array(a, dtype=np.float64, order="C") for a in (V, C, unit))
+        r = np.array([float(np.asarray(raw).reshape(-1)[0])], dtype=np.float64)
+        if v.shape != (self.D, self.m) or c.shape != (self.m, self.m) or u.size != self.d * self.m:
+            raise RuntimeError(f"start point shapes: V {v.shape}, C {c.shape}, unit {u.shape}")
+        log = _lib.ReconSolveLog()
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+        with torch.cuda.device(self.device):
+            code = lib.gabo_nested_spd_reconstruction_solve(
+                self.data.data_ptr(), self.y.data_ptr(), self.sqrt_y.data_ptr(), self.w.data_ptr(), ptr(ent["w_host"]), ptr(v), ptr(c), ptr(u),
+                ptr(r), self.N, self.D, self.d, self.metric, ent["ws"].data_ptr(), ent["ws"].numel(), ent["pinned"].data_ptr(),
+                ent["pinned"].numel(), ctypes.byref(options), ctypes.byref(log), _stream_ptr(self.device))
+        _lib.check(code, "gabo_nested_spd_reconstruction_solve")
+        return v, c, u, r, _recon_log(log)
+
+
+def _recon_log(log):
+    return {"iterations": int(log.outer_iterations), "inner_iterations": int(log.inner_iterations), "evaluations": int(log.evaluations),
+            "launches": int(log.launches), "stop_reason": _lib.GABO_RECON_STOP[log.stop_reason], "violation": float(log.violation),
+            "rho": float(log.rho), "gammas": [float(log.gamma)], "final_cost": float(log.final_cost), "time": float(log.seconds)}
+
+
+def nested_spd_reconstruction_solve_with(evaluate, w_host, V, C, unit, raw, options):
+    """The same native loop around a host callable  evaluate(V (P, D, m), C (P, m, m), K (P, d, m)) -> (cost (P,), gV, gC, gK)  in numpy
+    (gabo_nested_spd_reconstruction_solve_with): a user-supplied cost function, or a test's.  -> (V, C, unit, raw, log dict)."""
+    import ctypes
+
+    import numpy as np
+    lib = _lib.load()
+    w = np.ascontiguousarray(w_host, dtype=np.float64)
+    D, d = w.shape
+    m = D - d
+    v, c, u = (np.array(a, dtype=np.float64, order="C") for a in (V, C, unit))
+    r = np.array([float(np.asarray(raw).reshape(-1)[0])], dtype=np.float64)
+    npar = D * m + m * m + d * m
+    staging = np.empty(2 * (npar + m + m * m) + 2 * (1 + npar))
+    failure = []
+
+    def trampoline(_ctx, P, pv, pc, pk, pcost, pgv, pgc, pgk):
+        try:
+            as_np = lambda q, *shape: np.ctypeslib.as_array(q, shape=(int(np.prod(shape)),)).reshape(shape)   # noqa: E731
+            cost, gv, gc, gk = evaluate(as_np(pv, P, D, m).copy(), as_np(pc, P, m, m).copy(), as_np(pk, P, d, m).copy())
+            as_np(pcost, P)[:] = np.asarray(cost, dtype=np.float64).reshape(P)
+            as_np(pgv, P, D, m)[:] = gv
+            as_np(pgc, P, m, m)[:] = gc
+            as_np(pgk, P, d, m)[:] = gk
+            return _lib.GABO_OK
+        except Exception as exc:          # nothing may propagate through the C frames: the loop stops on the code, the error is raised below
+            failure.append(exc)
+            return _lib.GABO_ERR_ARG
+
+    log = _lib.ReconSolveLog()
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    code = lib.gabo_nested_spd_reconstruction_solve_with(_lib.ReconEvalFn(trampoline), None, ptr(w), ptr(v), ptr(c), ptr(u), ptr(r), D, d,
+                                                         ptr(staging), staging.size, ctypes.byref(options), ctypes.byref(log))
+    if failure:
+        raise failure[0]
+    _lib.check(code, "gabo_nested_spd_reconstruction_solve_with")
+    return v, c, u, r, _recon_log(log)
 
 
 class _NestedSpdReconstructionFn(torch.autograd.Function):

@@ -431,13 +431,58 @@ int gabo_sphere_manifold_op(int op, const double* x, const double* u, const doub
  * w: D x d;  v: P x D x (D-d), c: P x (D-d) x (D-d), k: P x d x (D-d): P parameter sets evaluated by one launch (the optimiser's
  * initial candidates; P = 1 inside the line searches).  cost: P.  grad_v / grad_c / grad_k: the Euclidean partial derivatives, same
  * shapes as v / c / k, or all three NULL (values only).  2 <= D <= GABO_SPD_MAX_DIM, 1 <= d < D.  status: as above (prepare, metric 0).
+ * c_eigenvalues: P x (D-d), c_eigenvectors: P x (D-d) x (D-d) with the vectors in the COLUMNS (row-major), or both NULL: the
+ *   eigen-decomposition of sym(C_p), when the caller has it (the kernel then skips its own - a lone wave's ~50 us at D = 20).
  */
 size_t gabo_nested_spd_reconstruction_workspace_bytes(int64_t P, int64_t N, int D, int d);
 int gabo_nested_spd_reconstruction_prepare(const double* x, double* data, int64_t N, int D, int metric, int* status, gabo_stream_t stream);
 int gabo_nested_spd_reconstruction(const double* data, const double* y, const double* sqrt_y, const double* w, const double* v,
                                    const double* c, const double* k, double* cost, double* grad_v, double* grad_c, double* grad_k,
-                                   int64_t P, int64_t N, int D, int d, int metric, void* workspace, size_t workspace_bytes,
-                                   gabo_stream_t stream);
+                                   const double* c_eigenvalues, const double* c_eigenvectors, int64_t P, int64_t N, int D, int d, int metric,
+                                   void* workspace, size_t workspace_bytes, gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The optimisation of the reconstruction parameters itself, as a native host loop around the launch above.
+ * Replaces  optimize_reconstruction_parameters_nested_spd            nested_mappings/nested_spd_optimization.py:168-186 (the run from the
+ *             chosen start point; the random candidates of :158-166 stay with the caller: one launch with P = nb_init_candidates)
+ *           AugmentedLagrangeMethod.solve with one equality constraint  manifold_optimization/augmented_Lagrange_method.py:72-326
+ *           [3P] pymanopt ConjugateGradient + LineSearchAdaptive         (the inner_solver of examples/hd_bo_spd/.../hd_gabo_spd.py)
+ * on  V in G(D, D-d) x C in S^(D-d)_++ x unit vector of R^(d (D-d)) x raw in R,  K = sigmoid(raw) * unit reshaped d x (D-d)  (:139, 155),
+ * under ||V^T W||_F = 0 (:142-147).  HOST function: it returns when the optimisation has ended (every evaluation waits for its launch).
+ * v, c, unit, raw: HOST arrays, in: the start point, out: the optimum.  w_host: D x d host copy of w.
+ * gabo_nested_spd_reconstruction_solve: data / y / sqrt_y / w as for gabo_nested_spd_reconstruction (device); workspace: device memory,
+ *   pinned: page-locked host memory (hipHostMalloc / torch pin_memory), sizes from ..._solve_workspace_bytes (pinned counted in doubles).
+ * gabo_nested_spd_reconstruction_solve_with: the same loop around ANY evaluator (a user-supplied cost_function, :98) - called with
+ *   P <= 2 parameter sets, v: P x D x (D-d), c: P x (D-d)^2, k: P x d x (D-d), it fills cost[P] and the Euclidean partial derivatives
+ *   grad_v / grad_c / grad_k (same shapes) and returns GABO_OK; staging: >= 2 (2 npar + 1 + (D-d) + (D-d)^2) doubles of host memory,
+ *   npar = D (D-d) + (D-d)^2 + d (D-d).
+ * Returns GABO_OK, an argument error, GABO_ERR_NOT_SPD when an iterate left the cone (never in exact arithmetic), or the evaluator's code.
+ */
+typedef struct {
+    double bound, rho_init, thetarho, tau, starting_tolgradnorm, ending_tolgradnorm, gammas_fact, minstepsize, maxtime; /* augmented_Lagrange_method.py:36-70 */
+    int64_t maxiter;
+    double cg_minstepsize, cg_maxtime, cg_orth_value;   /* [3P] pymanopt ConjugateGradient(minstepsize, maxtime, orth_value) */
+    int64_t cg_maxiter;
+} gabo_recon_solve_options;
+#define GABO_RECON_STOP_MAXITER 0
+#define GABO_RECON_STOP_MAXTIME 1
+#define GABO_RECON_STOP_MINSTEP 2
+#define GABO_RECON_STOP_MINGRAD 3
+typedef struct {
+    int64_t outer_iterations, inner_iterations, evaluations, launches;
+    int stop_reason;                                     /* GABO_RECON_STOP_* */
+    double violation, rho, gamma, final_cost, seconds;
+} gabo_recon_solve_log;
+typedef int (*gabo_recon_eval_fn)(void* ctx, int64_t P, const double* v, const double* c, const double* k, double* cost, double* grad_v,
+                                  double* grad_c, double* grad_k);
+void gabo_nested_spd_reconstruction_solve_workspace_bytes(int64_t N, int D, int d, size_t* device_bytes, size_t* pinned_doubles);
+int gabo_nested_spd_reconstruction_solve(const double* data, const double* y, const double* sqrt_y, const double* w, const double* w_host,
+                                         double* v, double* c, double* unit, double* raw, int64_t N, int D, int d, int metric,
+                                         void* workspace, size_t workspace_bytes, double* pinned, size_t pinned_doubles,
+                                         const gabo_recon_solve_options* options, gabo_recon_solve_log* log, gabo_stream_t stream);
+int gabo_nested_spd_reconstruction_solve_with(gabo_recon_eval_fn evaluate, void* ctx, const double* w_host, double* v, double* c,
+                                              double* unit, double* raw, int D, int d, double* staging, size_t staging_doubles,
+                                              const gabo_recon_solve_options* options, gabo_recon_solve_log* log);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Eigenvalue bounds of a latent (nested) SPD point stated in the original space (HD-GaBO's acquisition constraints).

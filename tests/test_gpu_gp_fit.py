@@ -146,6 +146,38 @@ def test_optimize_reconstruction_parameters_nested_spd():
     assert np.linalg.eigvalsh(Xr.cpu().numpy()).min() > 0
 
 
+@pytest.mark.parametrize("D,d,N,metric", [(4, 2, 8, "ai"), (9, 3, 6, "le"), (20, 2, 12, "le"), (20, 2, 12, "ai")])
+def test_native_reconstruction_loop_follows_the_python_loop(D, d, N, metric):
+    """gabo_nested_spd_reconstruction_solve (augmented Lagrangian + conjugate gradients in C++ around the fused launch) against the Python
+    statement of the same algorithm (augmented_lagrange_method.py + conjugate_gradient.py + host_manifolds.py, themselves checked against
+    analytic optima in tests/test_host_optimizers_cpu.py) from the same start: same iterates.  Short runs (rounding differences between the
+    two eigen-solvers grow by a decade every ~5 conjugate-gradient iterations on this non-convex cost); the outer `min step size` test is
+    switched off in both (it compares a Grassmann distance that is 1e-8-noise of the eigen-solver with 1e-10)."""
+    from gabotorch_amd.nested_mappings import nested_spd_optimization as nso
+    from gabotorch_amd.nested_mappings.nested_spd_utils import projection_from_spd_to_nested_spd
+    rng = np.random.default_rng(100 + D)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV)   # noqa: E731
+    X = T(_rand_spd(rng, N, D))
+    W = T(np.linalg.qr(rng.standard_normal((D, d)))[0])
+    Y = projection_from_spd_to_nested_spd(X, W)
+    cost = nso.min_log_euclidean_distance_reconstruction_cost if metric == "le" else nso.min_affine_invariant_distance_reconstruction_cost
+    out = {}
+    for native in (False, True):
+        np.random.seed(11)
+        V, C, K = nso.optimize_reconstruction_parameters_nested_spd(X, Y, W, ConjugateGradient(maxiter=8), cost_function=cost, nb_init_candidates=10,
+                                                                    maxiter=4, native=native, alm_options=dict(minstepsize=0.0))
+        out[native] = (V.cpu().numpy(), C.cpu().numpy(), K.cpu().numpy(), dict(nso.optimize_reconstruction_parameters_nested_spd.last_log))
+    py, nat = out[False], out[True]
+    assert nat[3].get("native") and not py[3].get("native")
+    assert nat[3]["iterations"] == py[3]["iterations"] == 4
+    np.testing.assert_allclose(nat[3]["final_cost"], py[3]["final_cost"], rtol=1e-6)
+    np.testing.assert_allclose(nat[3]["violation"], py[3]["violation"], rtol=1e-3, atol=1e-9)
+    np.testing.assert_allclose(nat[3]["rho"], py[3]["rho"], rtol=1e-12)
+    for a, b in zip(nat[:3], py[:3]):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert nat[3]["launches"] <= nat[3]["evaluations"] <= 2 * nat[3]["launches"]
+
+
 def test_nested_sphere_reconstruction_cost_and_optimiser(golden):
     from gabotorch_amd.nested_mappings import nested_spheres_optimization as nsso
     from gabotorch_amd.nested_mappings.nested_spheres_utils import projection_from_sphere_to_subsphere

@@ -1,6 +1,7 @@
 """Host-side pieces of the surrogate fit (manifold_gp_fit.py in the reference): numpy manifolds and Riemannian conjugate gradients.
 No GPU needed: they only ever move hyper-parameters."""
 import numpy as np
+import pytest
 
 from gabotorch_amd.manifold_optimization.conjugate_gradient import ConjugateGradient
 from gabotorch_amd.manifold_optimization.host_manifolds import Euclidean, Grassmann, Product, Sphere
@@ -215,3 +216,72 @@ def test_nested_eigenvalue_partials_are_recognised_with_their_mapping():
     grad_map = dict(mapping, bottom_spd_matrix=C.clone().requires_grad_(True))
     assert builtin_constraint(functools.partial(nscu.max_eigenvalue_nested_spd_constraint, maximum_eigenvalue=5.0, **grad_map)) is None
     assert builtin_constraint(functools.partial(nscu.max_eigenvalue_nested_spd_constraint, maximum_eigenvalue=5.0, projection_matrix=W)) is None
+
+
+@pytest.mark.parametrize("D,d,seed", [(5, 2, 0), (10, 2, 1), (20, 2, 2), (8, 3, 3)])
+def test_native_reconstruction_loop_against_the_python_solvers(D, d, seed):
+    """gabo_nested_spd_reconstruction_solve_with - the augmented Lagrangian + conjugate-gradient loop of HD-GaBO's reconstruction
+    parameters in C++ (csrc/nested_spd_reconstruction_solve.hip: own eigen-solver, Cholesky, retractions, transports) - driven by a numpy
+    cost through its evaluator callback (no GPU involved), against AugmentedLagrangeMethod + ConjugateGradient + host_manifolds on the
+    same cost from the same start: the iterates agree to rounding, so do the multiplier and the penalty.  (Short runs: on a non-convex
+    cost the rounding differences of two eigen-solvers grow by about a decade every 5 conjugate-gradient iterations - 1e-16 after one,
+    1e-8 after 50 - so a long run is compared by the quality of its optimum, below.)"""
+    from gabotorch_amd import _lib, ops
+    from gabotorch_amd.manifold_optimization.augmented_lagrange_method import AugmentedLagrangeMethod, _Constraint
+    from gabotorch_amd.manifold_optimization.host_manifolds import PositiveDefinite
+    rng = np.random.RandomState(seed)
+    np.random.seed(seed)
+    m = D - d
+    W = np.linalg.qr(rng.randn(D, d))[0]
+    man = Product([Grassmann(D, m), PositiveDefinite(m), Sphere(d * m), Euclidean(1)])
+    V0 = np.linalg.qr(rng.randn(D, m))[0]
+    A = rng.randn(m, m)
+    C0 = A @ A.T / m + np.eye(m)
+    K0 = 0.3 * rng.randn(d, m)
+
+    def evaluate(V, C, K):          # P parameter sets at once: a smooth cost with a non-quadratic term in C
+        logdet = np.log(np.linalg.det(C))
+        cost = 0.5 * ((V - V0) ** 2).sum((1, 2)) + 0.5 * ((C - C0) ** 2).sum((1, 2)) + 0.5 * ((K - K0) ** 2).sum((1, 2)) + 0.1 * logdet ** 2
+        return cost, V - V0, (C - C0) + 0.2 * logdet[:, None, None] * np.linalg.inv(C).transpose(0, 2, 1), K - K0
+
+    def value_and_egrad(x):         # the chain through K = sigmoid(raw) * unit, as nested_spd_optimization.py states it
+        t = 1.0 / (1.0 + np.exp(-float(x[3][0])))
+        unit = x[2].reshape(d, m)
+        c, gV, gC, gK = evaluate(x[0][None], x[1][None], (t * unit)[None])
+        return float(c[0]), [gV[0], gC[0], (t * gK[0]).reshape(-1), np.array([float(np.sum(gK[0] * unit)) * t * (1 - t)])]
+
+    class Objective:
+        manifold = man
+        cost = staticmethod(lambda x: value_and_egrad(x)[0])
+        grad = staticmethod(lambda x: man.egrad2rgrad(x, value_and_egrad(x)[1]))
+
+    def orthogonality(x):
+        wtv = W.T @ x[0]
+        v = float(np.linalg.norm(wtv))
+        return v, [W @ wtv / v] + [np.zeros(np.shape(xi)) for xi in x[1:]]
+
+    x0 = man.rand()
+    def both(outer, inner):
+        alm = AugmentedLagrangeMethod(maxiter=outer, inner_solver=ConjugateGradient(maxiter=inner), gammas_fact=1.0, minstepsize=0.0)
+        ref = alm.solve(Objective(), x=[a.copy() for a in x0], eq_constraints=[_Constraint(man, orthogonality)])
+        options = _lib.ReconSolveOptions(bound=20, rho_init=1, thetarho=0.3, tau=0.8, starting_tolgradnorm=1e-3, ending_tolgradnorm=1e-6,
+                                         gammas_fact=1.0, minstepsize=0.0, maxtime=1000, maxiter=outer, cg_minstepsize=1e-10, cg_maxtime=1000,
+                                         cg_orth_value=np.inf, cg_maxiter=inner)
+        return ref, alm.log, options, ops.nested_spd_reconstruction_solve_with(evaluate, W, x0[0], x0[1], x0[2], x0[3], options)
+
+    ref, ref_log, options, (v, c, u, r, log) = both(4, 8)
+    assert log["iterations"] == ref_log["iterations"] == 4 and log["stop_reason"] == ref_log["stop_reason"] == "max iterations"
+    np.testing.assert_allclose(log["rho"], ref_log["rho"], rtol=1e-12)
+    np.testing.assert_allclose(log["gammas"], ref_log["gammas"], rtol=1e-8)
+    np.testing.assert_allclose(log["violation"], ref_log["violation"], rtol=1e-6, atol=1e-12)
+    for got, want in zip((v, c, u, r), ref):
+        np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-9)
+    assert np.abs(v.T @ v - np.eye(m)).max() < 1e-12 and np.linalg.eigvalsh(c).min() > 0 and abs(np.linalg.norm(u) - 1) < 1e-12
+    assert log["launches"] < log["evaluations"] <= 2 * log["launches"]          # the look-ahead: two step lengths per evaluator call
+    # the full-length run: an optimum of the same quality
+    ref, ref_log, options, (v, c, u, r, log) = both(6, 50)
+    np.testing.assert_allclose(log["final_cost"], value_and_egrad(ref)[0], rtol=2e-2)
+    assert log["violation"] < max(2.0 * ref_log["violation"], 1e-3)
+    # an evaluator that raises stops the loop and the error reaches the caller
+    with pytest.raises(ZeroDivisionError):
+        ops.nested_spd_reconstruction_solve_with(lambda V, C, K: 1 / 0, W, x0[0], x0[1], x0[2], x0[3], options)
