@@ -117,6 +117,8 @@ SIGNATURES = {
     "gabo_nested_spd_lift_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "gabo_nested_spd_extreme_eigenvalues": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _I, _P]),
     "gabo_nested_spd_reconstruction": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _SZ, _P]),
+    "gabo_nested_spd_fit_workspace_bytes": (_SZ, [_I64, _I, _I]),
+    "gabo_nested_spd_fit_evaluate": (_I, [_P, _P, _P, _P, _I64, _I, _I, _D, _D, _D, _D, _I, _P, _P, _SZ, _P, _SZ, _P]),
     "gabo_nested_spd_reconstruction_solve_workspace_bytes": (None, [_I64, _I, _I, _P, _P]),
     "gabo_nested_spd_reconstruction_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _P, _SZ, _P, _SZ, _P, _P, _P]),
     "gabo_nested_spd_reconstruction_solve_with": (_I, [ReconEvalFn, _P, _P, _P, _P, _P, _P, _I, _I, _P, _SZ, _P, _P]),

@@ -86,12 +86,43 @@ class _NestedSpdMllProblem(_MllProblem):
         self.W = None
         self.want_grad = False
         self.grad_w = None
+        self.native, self.values_only, self.W_host, self._native_buffers, self._recent = True, False, None, None, []
         self.scalar = model._fast_scalar_objective([params[k] for k in self.scalar_idx], evaluator=self._evaluate)
         return self if self.scalar is not None else None
+
+    def _native(self, theta, outputscale, noise, mean):
+        """The log-Euclidean kernel's chain as ONE host call (gabo_nested_spd_fit_evaluate: the same launches issued from C++, one pinned
+        copy in and one out) - always with the gradient: a line search asks for the value at a point and the solver for the gradient at the
+        point it accepted, so the last results are remembered and that second request costs nothing."""
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        n, D, d = self.x.shape[0], self.W_host.shape[0], self.W_host.shape[1]
+        if self._native_buffers is None:
+            ws = torch.empty(max(int(lib.gabo_nested_spd_fit_workspace_bytes(n, D, d)), 16), dtype=torch.uint8, device=self.x.device)
+            self._native_buffers = (ws, torch.empty(2 * D * d + 7, dtype=torch.float64).pin_memory(), np.empty(7 + D * d))
+        ws, pinned, out = self._native_buffers
+        key = (self.W_host.tobytes(), theta, outputscale, noise, mean)
+        for k, res in self._recent:
+            if k == key and (res[2] or not self.want_grad):
+                self.grad_w = res[1]
+                return res[0]
+        want = self.want_grad or not self.values_only
+        with torch.cuda.device(self.x.device):
+            _lib.check(lib.gabo_nested_spd_fit_evaluate(
+                self.x.data_ptr(), self.xm.data_ptr(), self.y.data_ptr(), self.W_host.ctypes.data_as(ctypes.c_void_p), n, D, d, float(theta),
+                float(outputscale), float(noise), float(mean), 1 if want else 0, out.ctypes.data_as(ctypes.c_void_p), ws.data_ptr(), ws.numel(),
+                pinned.data_ptr(), pinned.numel(), self.ops._stream_ptr(self.x.device)), "gabo_nested_spd_fit_evaluate")
+        res = ((float(out[0]), float(out[6]), float(out[2]), float(out[3]), float(out[4]), float(out[5])), out[7:].reshape(D, d).copy(), want)
+        self._recent = [(key, res)] + self._recent[:3]
+        self.grad_w = res[1]
+        return res[0]
 
     def _evaluate(self, theta, outputscale, noise, mean):
         from .. import _lib
         ops = self.ops
+        if self.log_euclidean and self.native:
+            return self._native(theta, outputscale, noise, mean)
         z = ops.spd_project(self.x, self.W)
         if self.log_euclidean:
             feat = ops.spd_logm_mandel(z)
@@ -117,7 +148,10 @@ class _NestedSpdMllProblem(_MllProblem):
         return flat[0], flat[6], flat[2], flat[3], flat[4], flat[5]
 
     def _run(self, x, want_grad):
-        self.W = torch.as_tensor(np.asarray(x[self.iw], dtype=np.float64), device=self.x.device).reshape(self.params[self.iw].shape).contiguous()
+        if self.log_euclidean and self.native:
+            self.W_host = np.ascontiguousarray(np.asarray(x[self.iw], dtype=np.float64).reshape(self.params[self.iw].shape))
+        else:
+            self.W = torch.as_tensor(np.asarray(x[self.iw], dtype=np.float64), device=self.x.device).reshape(self.params[self.iw].shape).contiguous()
         self.want_grad = want_grad
         v = np.array([float(np.asarray(x[k]).reshape(-1)[0]) for k in self.scalar_idx])
         return self.scalar(v)
@@ -171,7 +205,9 @@ def fit_gpytorch_manifold(model, solver=None, nb_init_candidates=200, last_x_as_
         for i in range(int(3 * nb_init_candidates / 4)):
             for k in eucl:
                 cands[i][k] = x0[k].copy()
+    problem.values_only = True           # (the candidates are only ranked: no gradient behind these values)
     costs = [problem.cost(c) for c in cands]
+    problem.values_only = False
     x_init = cands[int(np.argmin(costs))]
     opt_x, log = solver.solve(problem, x=x_init)
     problem._set(opt_x)

@@ -229,6 +229,26 @@ int gabo_gp_mll_large(const double* e, const double* y, int64_t n, double theta,
                       double* out, double* w, void* workspace, size_t workspace_bytes, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * One evaluation of the surrogate-fit objective of HD-GaBO with its gradient, as one HOST call (it returns with the numbers):
+ * the marginal log likelihood of ScaleKernel(NestedSpdLogEuclideanGaussianKernel) at a projection matrix W and scalar hyper-parameters.
+ * Replaces the closure fit_gpytorch_manifold differentiates by autograd   manifold_optimization/manifold_gp_fit.py:54-222
+ *   kernel: NestedSpdLogEuclideanGaussianKernel.forward                    kernel_utils/kernels_nested_spd.py:139-250
+ *           = projection_from_spd_to_nested_spd (nested_spd_utils.py:20-48) -> logm_torch (spd_utils_torch.py:13-30) -> exp(-theta ||.||_F^2)
+ *   likelihood: [3P] gpytorch ExactMarginalLogLikelihood.
+ * It issues gabo_spd_project, gabo_spd_logm_mandel, gabo_frobenius_pairwise, gabo_gp_mll_gram (gabo_gp_mll_large above GABO_GP_MLL_MAX_N) and
+ * their backward launches back to back on `stream`, and waits.
+ * x_mandel: n x D(D+1)/2 training points, x_matrices: the same as n x D x D, y: n targets (device); w_host: D x d (host).
+ * out_host (host, 7 + D d doubles): [ll, 0, d ll/d outputscale, d ll/d noise, d ll/d mean, not-positive-definite flag, d ll/d theta,
+ *   d ll / d W (D x d, Euclidean)]; want_grad = 0: only the first six are computed (the rest zero).  theta = 1 / lengthscale^2.
+ * workspace: device, gabo_nested_spd_fit_workspace_bytes(n, D, d); pinned: >= 2 D d + 7 doubles of page-locked host memory.
+ * 1 <= n <= GABO_GP_MLL_LARGE_MAX_N, 1 <= d < D <= GABO_SPD_MAX_DIM.
+ */
+size_t gabo_nested_spd_fit_workspace_bytes(int64_t n, int D, int d);
+int gabo_nested_spd_fit_evaluate(const double* x_mandel, const double* x_matrices, const double* y, const double* w_host, int64_t n, int D,
+                                 int d, double theta, double outputscale, double noise, double mean, int want_grad, double* out_host,
+                                 void* workspace, size_t workspace_bytes, double* pinned, size_t pinned_doubles, gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * n random SPD matrices with the distribution of spd_sample (Riemannian_utils/spd_utils.py:290-306; the raw samples of
  * gen_batch_initial_conditions_manifold, manifold_optimize.py:288): eigenvalues U[min_eig, max_eig], eigenvectors = orthogonal
  * factor of a Gaussian matrix.  out: n x d x d (mandel == 0) or n x d_vec Mandel vectors.  Counter-based stream (Philox4x32-10,

@@ -539,3 +539,44 @@ def test_nested_spd_fit_objective_without_autograd_matches_the_autograd_objectiv
         g_fast, g_slow = fast.egrad(x), slow.egrad(x)
         for a, b, (nm, _) in zip(g_fast, g_slow, named):
             np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-9, err_msg=nm)
+        if flavour == "log_euclidean":
+            # the same chain issued launch by launch from Python (what gabo_nested_spd_fit_evaluate replaces)
+            assert fast.native and fast._recent
+            fast.native = False
+            c_chain, g_chain = fast.cost(x), fast.egrad(x)
+            fast.native = True
+            np.testing.assert_allclose(c_fast, c_chain, rtol=1e-13)
+            for a, b, (nm, _) in zip(g_fast, g_chain, named):
+                np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12, err_msg=nm)
+
+
+@pytest.mark.parametrize("n", [40, 200])
+def test_native_fit_evaluation_at_larger_training_sets(n):
+    """gabo_nested_spd_fit_evaluate (one host call per evaluation of the HD-GaBO surrogate objective) against the launch-by-launch chain
+    at training-set sizes on both sides of the one-workgroup likelihood limit (GABO_GP_MLL_MAX_N = 160), values only and with gradients."""
+    from gabotorch_amd.manifold_optimization import manifold_gp_fit as mgf
+    from gabotorch_amd.manifold_optimization.host_manifolds import Euclidean, Product
+    rng = np.random.default_rng(n)
+    D, dl = 10, 3
+    X = torch.tensor(ospd.symmetric_matrix_to_vector_mandel(_rand_spd(rng, n, D)), device=DEV)
+    y = torch.tensor(rng.standard_normal(n), device=DEV)
+    torch.manual_seed(3)
+    base = NestedSpdLogEuclideanGaussianKernel(D, dl)
+    gp = models.SingleTaskGP(X, y, ScaleKernel(base, outputscale_prior=models.GammaPrior(2.0, 0.15)).double(), noise_prior=models.GammaPrior(1.1, 0.05))
+    named = list(gp.named_parameters())
+    params = [p for _, p in named]
+    factors = [getattr(base, "raw_projection_matrix_manifold") if p is base.raw_projection_matrix else Euclidean(int(p.numel())) for _, p in named]
+    prob = mgf._NestedSpdMllProblem.build(gp, [nm for nm, _ in named], params, Product(factors))
+    assert prob is not None and prob.native
+    x = [man.rand() if p is base.raw_projection_matrix else rng.normal(0.3, 0.4, size=(int(p.numel()),)) for p, man in zip(params, factors)]
+    prob.values_only = True
+    c_values_only = prob.cost(x)
+    prob.values_only = False
+    prob._recent = []
+    c_native, g_native = prob.cost(x), prob.egrad(x)
+    prob.native = False
+    c_chain, g_chain = prob.cost(x), prob.egrad(x)
+    assert np.isfinite(c_chain)
+    np.testing.assert_allclose([c_values_only, c_native], c_chain, rtol=1e-12)
+    for a, b, (nm, _) in zip(g_native, g_chain, named):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11, err_msg=nm)
