@@ -229,6 +229,26 @@ def config5_pieces(device):
     e_nc = float(max(np.abs(lam_nc[:, 0] - lam_o[:, -1]).max(), np.abs(lam_nc[:, 1] - lam_o[:, 0]).max()))
     if not (e_rec < 1e-10 and e_nc < 1e-11):
         raise RuntimeError(f"config 5 latent-loop parity gate failed: {e_rec} {e_nc}")
+    # the whole optimisation of the reconstruction parameters from this start (augmented Lagrangian + conjugate gradients as a native host
+    # loop around the launch above: gabo_nested_spd_reconstruction_solve), the example's settings (6 outer iterations, 100 inner)
+    opts = _lib.ReconSolveOptions(bound=20, rho_init=1, thetarho=0.3, tau=0.8, starting_tolgradnorm=1e-3, ending_tolgradnorm=1e-6, gammas_fact=1.0,
+                                  minstepsize=1e-10, maxtime=1000, maxiter=6, cg_minstepsize=1e-10, cg_maxtime=1000, cg_orth_value=float("inf"),
+                                  cg_maxiter=100)
+    unit0 = Kl.reshape(-1) / np.linalg.norm(Kl)
+    raw0 = float(np.log(0.4 / 0.6))                                     # sigmoid(raw) = 0.4 = ||K||
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        v_o, c_o, u_o, r_o, slog = rec.solve_host(Vl, Cl, unit0, raw0, opts)
+        wall = time.perf_counter() - t0
+        best = wall if best is None else min(best, wall)
+    k_o = u_o.reshape(d, D - d) / (1.0 + np.exp(-r_o[0]))
+    e_sol = abs(slog["final_cost"] - ospd.reconstruction_cost(xd, yd, Wl, v_o, c_o, k_o, metric="le")) / abs(slog["final_cost"])
+    if not (e_sol < 1e-9 and slog["final_cost"] <= float(cost_t[0]) and np.linalg.eigvalsh(c_o).min() > 0):
+        raise RuntimeError(f"config 5 reconstruction-loop gate failed: {e_sol} {slog}")
+    solve = {"wall_ms": best * 1e3, "launches": slog["launches"], "evaluations": slog["evaluations"], "inner_iterations": slog["inner_iterations"],
+             "us_per_launch": best * 1e6 / max(slog["launches"], 1), "start_cost": float(cost_t[0]), "final_cost": slog["final_cost"],
+             "constraint_violation": slog["violation"], "final_cost_vs_oracle_rel": e_sol}
     pairs = n * n
     hbm = lambda nbytes, ms: {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",   # noqa: E731
                               "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -248,6 +268,7 @@ def config5_pieces(device):
                                         "cost; gabo_nested_spd_reconstruction) and lambda_max / lambda_min of 512 lifted latent points with their "
                                         "gradients (gabo_nested_spd_extreme_eigenvalues); device ms per launch inside a hipGraph",
                             "reconstruction_evaluation_ms": ms_rec, "nested_eigenvalue_constraints_512_points_ms": ms_nc,
+                            "reconstruction_optimisation": solve,
                             "bound": "latency: two dependent eigen-solves of order 18 and 20 per block (wave_eigh: one wave, ~2.1e5 shader cycles); "
                                      "one Householder reduction + multisection per lifted point (~6e4 cycles)",
                             "parity": {"reconstruction_cost_rel": e_rec, "extreme_eigenvalues_max_abs": e_nc}},

@@ -25,6 +25,7 @@ GABO_METRIC_AFFINE_INVARIANT, GABO_METRIC_LOG_EUCLIDEAN, GABO_METRIC_FROBENIUS =
 GABO_CONSTRAINT_MAX_EIGENVALUE, GABO_CONSTRAINT_MIN_EIGENVALUE = 0, 1
 GABO_CONSTRAINT_MAX_EIGENVALUE_NESTED, GABO_CONSTRAINT_MIN_EIGENVALUE_NESTED = 2, 3
 GABO_RECON_AFFINE_INVARIANT, GABO_RECON_LOG_EUCLIDEAN = 0, 1
+GABO_RECON_MAX_LOOKAHEAD = 4
 GABO_RECON_STOP = ("max iterations", "max time", "min step size", "min grad norm")     # GABO_RECON_STOP_* of the header, by code
 GABO_SPH_PROJ, GABO_SPH_RETR, GABO_SPH_EXP, GABO_SPH_LOG, GABO_SPH_DIST, GABO_SPH_EHESS2RHESS = range(6)
 
@@ -54,13 +55,13 @@ class ReconSolveOptions(_c.Structure):
     """gabo_recon_solve_options of include/gabo_hip.h"""
     _fields_ = [(k, _c.c_double) for k in ("bound", "rho_init", "thetarho", "tau", "starting_tolgradnorm", "ending_tolgradnorm", "gammas_fact",
                                           "minstepsize", "maxtime")] + [("maxiter", _c.c_int64)] + \
-               [(k, _c.c_double) for k in ("cg_minstepsize", "cg_maxtime", "cg_orth_value")] + [("cg_maxiter", _c.c_int64)]
+               [(k, _c.c_double) for k in ("cg_minstepsize", "cg_maxtime", "cg_orth_value")] + [("cg_maxiter", _c.c_int64), ("lookahead", _c.c_int64)]
 
 
 class ReconSolveLog(_c.Structure):
     """gabo_recon_solve_log of include/gabo_hip.h"""
     _fields_ = [(k, _c.c_int64) for k in ("outer_iterations", "inner_iterations", "evaluations", "launches")] + [("stop_reason", _c.c_int)] + \
-               [(k, _c.c_double) for k in ("violation", "rho", "gamma", "final_cost", "seconds")]
+               [(k, _c.c_double) for k in ("violation", "rho", "gamma", "final_cost", "seconds", "seconds_evaluator")]
 
 
 # gabo_recon_eval_fn: int (void* ctx, int64 P, const double* v, c, k, double* cost, grad_v, grad_c, grad_k)

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void nested_spd_reconstruction_kernel(const do
     __threadfence();
     const double* Rp = records + (size_t)p * N * rec;
     if (threadIdx.x == 0) {
+        counters[p] = 0;                  // every block of this parameter set has drawn its ticket: the next launch finds it at zero
         double s = 0.0;
         for (int q = 0; q < N; ++q) s += Rp[(size_t)q * rec];
         cost[p] = s;
@@ -330,6 +331,11 @@ __global__ __launch_bounds__(64) void nested_spd_reconstruction_prepare_kernel(c
     }
 }
 
+int nested_spd_reconstruction_launch(const double* data, const double* y, const double* sqrt_y, const double* w, const double* v,
+                                     const double* c, const double* k, double* cost, double* grad_v, double* grad_c, double* grad_k,
+                                     const double* c_eigenvalues, const double* c_eigenvectors, int64_t P, int64_t N, int D, int d, int metric,
+                                     void* workspace, size_t workspace_bytes, bool clear_tickets, gabo_stream_t stream);
+
 }  // namespace gabo
 
 extern "C" {
@@ -362,6 +368,20 @@ int gabo_nested_spd_reconstruction(const double* data, const double* y, const do
                                    const double* c, const double* k, double* cost, double* grad_v, double* grad_c, double* grad_k,
                                    const double* c_eigenvalues, const double* c_eigenvectors, int64_t P, int64_t N, int D, int d, int metric,
                                    void* workspace, size_t workspace_bytes, gabo_stream_t stream) {
+    return gabo::nested_spd_reconstruction_launch(data, y, sqrt_y, w, v, c, k, cost, grad_v, grad_c, grad_k, c_eigenvalues, c_eigenvectors, P, N, D,
+                                                  d, metric, workspace, workspace_bytes, true, stream);
+}
+}
+
+namespace gabo {
+
+// The launch behind gabo_nested_spd_reconstruction.  clear_tickets = false: the caller guarantees that the tickets at the head of the
+// workspace are zero (they are after every completed launch: the last block of a parameter set puts its ticket back) - the native
+// optimisation loop clears them once and saves a memset node per evaluation.
+int nested_spd_reconstruction_launch(const double* data, const double* y, const double* sqrt_y, const double* w, const double* v,
+                                     const double* c, const double* k, double* cost, double* grad_v, double* grad_c, double* grad_k,
+                                     const double* c_eigenvalues, const double* c_eigenvectors, int64_t P, int64_t N, int D, int d, int metric,
+                                     void* workspace, size_t workspace_bytes, bool clear_tickets, gabo_stream_t stream) {
     if (D < 2 || D > GABO_SPD_MAX_DIM || d < 1 || d >= D) return GABO_ERR_DIM;
     if (P < 0 || N < 0 || (metric != 0 && metric != 1) || ((c_eigenvalues == nullptr) != (c_eigenvectors == nullptr))) return GABO_ERR_ARG;
     if (P == 0) return GABO_OK;
@@ -379,19 +399,20 @@ int gabo_nested_spd_reconstruction(const double* data, const double* y, const do
     }
     if (!data || !y || !sqrt_y || !w || !v || !c || !k || !workspace) return GABO_ERR_ARG;
     if (P * N > 0x7fffffffLL || workspace_bytes < gabo_nested_spd_reconstruction_workspace_bytes(P, N, D, d)) return GABO_ERR_ARG;
-    const gabo::ReconLayout lay{D, d, D - d};
+    const ReconLayout lay{D, d, D - d};
     const size_t counters = ((size_t)P * sizeof(int) + 15) / 16 * 16;
     int* cnt = static_cast<int*>(workspace);
     double* records = reinterpret_cast<double*>(static_cast<char*>(workspace) + counters);
-    hipMemsetAsync(cnt, 0, counters, (hipStream_t)stream);
+    if (clear_tickets) hipMemsetAsync(cnt, 0, counters, (hipStream_t)stream);
     const size_t lds = lay.lds_doubles() * sizeof(double);
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gabo::nested_spd_reconstruction_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nested_spd_reconstruction_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return GABO_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(gabo::nested_spd_reconstruction_kernel, dim3((unsigned)(P * N)), dim3(256), lds, (hipStream_t)stream, data, y, sqrt_y, w, v,
+    hipLaunchKernelGGL(nested_spd_reconstruction_kernel, dim3((unsigned)(P * N)), dim3(256), lds, (hipStream_t)stream, data, y, sqrt_y, w, v,
                        c, k, cost, grad_v, grad_c, grad_k, c_eigenvalues, c_eigenvectors, (int)P, (int)N, D, d, metric, cnt, records);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
-}
+
+}  // namespace gabo

@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -26,6 +28,12 @@
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
+
+int nested_spd_reconstruction_launch(const double* data, const double* y, const double* sqrt_y, const double* w, const double* v,
+                                     const double* c, const double* k, double* cost, double* grad_v, double* grad_c, double* grad_k,
+                                     const double* c_eigenvalues, const double* c_eigenvectors, int64_t P, int64_t N, int D, int d, int metric,
+                                     void* workspace, size_t workspace_bytes, bool clear_tickets, gabo_stream_t stream);     // nested_spd_reconstruction.hip
+
 namespace host {
 
 typedef std::vector<double> vec;
@@ -199,6 +207,8 @@ static void lower_inverse(const double* L, double* Li, int n) {
     }
 }
 
+enum { kMaxLookahead = GABO_RECON_MAX_LOOKAHEAD };
+
 struct Dims {
     int D, d, m;
     int nV, nC, nU, n;          // sizes of the factors and of a point / tangent vector [V | C | unit | raw]
@@ -225,11 +235,13 @@ struct Driver {
     const double* W;                                   // D x d, host
     gabo_recon_eval_fn eval;
     void* ctx;
-    double* stage_in;                                  // 2 * (nV + nC + nU): [V x P | C x P | K x P]
-    double* stage_out;                                 // 2 * (1 + nV + nC + nU): [cost x P | gV x P | gC x P | gK x P]
+    double* stage_in;                                  // kMaxLookahead * (nV + nC + nU + factors): [V x P | C x P | K x P]
+    double* stage_out;                                 // kMaxLookahead * (1 + nV + nC + nU): [cost x P | gV x P | gC x P | gK x P]
     gabo_recon_solve_options opt;
     double rho = 1.0, gamma = 1.0;
+    int lookahead = 2;
     int64_t evaluations = 0, launches = 0, inner_iterations = 0;
+    double seconds_evaluator = 0.0;
     int error = GABO_OK;
     vec t0, t1, t2, t3, t4, ew, ee;                    // scratch
 
@@ -241,10 +253,10 @@ struct Driver {
     }
 
     // ---------------------------------------------------------------------------------------------- the evaluator
-    // reconstruction cost + Euclidean gradient (and the constraint value) at P <= 2 points, ONE call of the evaluator
+    // reconstruction cost + Euclidean gradient (and the constraint value) at P <= kMaxLookahead points, ONE call of the evaluator
     void evaluate(Point** pts, int P) {
         const int npar = dm.nV + dm.nC + dm.nU;
-        double ts[2];
+        double ts[kMaxLookahead];
         for (int p = 0; p < P; ++p) {
             const double* x = pts[p]->x.data();
             ts[p] = 1.0 / (1.0 + std::exp(-x[dm.oS]));                                  // gpytorch Interval(0, 1).transform (:139, 155)
@@ -257,7 +269,9 @@ struct Driver {
         double* gv = stage_out + P;
         double* gc = gv + (size_t)P * dm.nV;
         double* gk = gc + (size_t)P * dm.nC;
+        const auto t_eval = std::chrono::steady_clock::now();
         const int rc = eval(ctx, P, stage_in, stage_in + (size_t)P * dm.nV, stage_in + (size_t)P * (dm.nV + dm.nC), cost, gv, gc, gk);
+        seconds_evaluator += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_eval).count();
         if (rc != GABO_OK && error == GABO_OK) error = rc;
         (void)npar;
         launches += 1;
@@ -482,7 +496,7 @@ struct Driver {
     // [3P] pymanopt ConjugateGradient with LineSearchAdaptive (Hestenes-Stiefel beta clipped at 0; sufficient decrease 1/2, contraction
     // 1/2, at most 10 cost evaluations; next initial step = last accepted, doubled unless it took exactly one contraction).
     // cur: in = start (evaluated), out = result (evaluated).  Returns the number of iterations.
-    int64_t cg(Point& cur, double tolgradnorm, Point& c1, Point& c2) {
+    int64_t cg(Point& cur, double tolgradnorm, std::vector<Point>& cands) {
         using clock = std::chrono::steady_clock;
         const auto time0 = clock::now();
         const int n = dm.n;
@@ -506,25 +520,28 @@ struct Driver {
                 for (int i = 0; i < n; ++i) desc[i] = -grad[i];
                 df0 = -grad_grad;
             }
-            // ---- line search: the first trial step and its first contraction in one launch
+            // ---- line search: the first trial step and its first `look - 1` contractions in one launch (the blocks of different
+            // parameter sets run side by side: the launch takes as long as a single evaluation)
             const double norm_d = norm(cur, desc.data());
             double alpha = oldalpha >= 0.0 ? oldalpha : 1.0 / norm_d;
-            const double steps[2] = {alpha, 0.5 * alpha};
-            Point* both[2] = {&c1, &c2};
-            retr_steps(cur.x.data(), desc.data(), steps, 2, both);
-            evaluate(both, 2);
-            Point* cand = &c1;
+            const int look = (int)cands.size();
+            double steps[kMaxLookahead];
+            Point* ahead[kMaxLookahead];
+            for (int i = 0; i < look; ++i) { steps[i] = i == 0 ? alpha : 0.5 * steps[i - 1]; ahead[i] = &cands[i]; }
+            retr_steps(cur.x.data(), desc.data(), steps, look, ahead);
+            evaluate(ahead, look);
+            Point* cand = &cands[0];
             double newf = sub_cost(*cand);
             int evals = 1;
             while (newf > cost + 0.5 * alpha * df0 && evals <= 10) {
                 alpha *= 0.5;
-                if (evals == 1) {
-                    cand = &c2;
+                if (evals < look) {
+                    cand = &cands[evals];
                 } else {
-                    Point* one[1] = {&c1};
+                    Point* one[1] = {&cands[0]};
                     retr_steps(cur.x.data(), desc.data(), &alpha, 1, one);
                     evaluate(one, 1);
-                    cand = &c1;
+                    cand = &cands[0];
                 }
                 newf = sub_cost(*cand);
                 evals += 1;
@@ -568,7 +585,8 @@ struct Driver {
     void solve(Point& best, gabo_recon_solve_log* log) {
         using clock = std::chrono::steady_clock;
         const auto time0 = clock::now();
-        Point c1(dm), c2(dm), prev(dm);
+        Point prev(dm);
+        std::vector<Point> cands((size_t)lookahead, Point(dm));
         rho = opt.rho_init;
         gamma = opt.gammas_fact;
         double oldacc = std::numeric_limits<double>::infinity();
@@ -580,7 +598,7 @@ struct Driver {
         evaluate(start, 1);
         prev.x = best.x;
         while (error == GABO_OK) {
-            inner_iterations += cg(best, tol, c1, c2);
+            inner_iterations += cg(best, tol, cands);
             const double v = best.g;                            // (:185-188) the one equality constraint
             const double newacc = std::fabs(v);
             gamma = std::min(opt.bound, std::max(-opt.bound, gamma + rho * v));
@@ -606,6 +624,7 @@ struct Driver {
             log->gamma = gamma;
             log->final_cost = best.f;
             log->seconds = std::chrono::duration<double>(clock::now() - time0).count();
+            log->seconds_evaluator = seconds_evaluator;
         }
     }
 };
@@ -615,8 +634,11 @@ static bool options_ok(const gabo_recon_solve_options* o) {
            o->ending_tolgradnorm > 0.0;
 }
 
-// the built-in evaluator: pinned staging -> device, one launch, device -> pinned staging, wait.  The eigen-decomposition of each C goes
-// along with the parameters: ~5 us of host arithmetic here against a lone wave's ~50 us on the critical path of every block there.
+// The built-in evaluator: pinned staging -> device, one launch, device -> pinned staging, wait.  (Letting the kernel read and write the
+// page-locked staging memory directly instead of the two small copies was measured: no difference, 45.3 against 45.8 ms per optimisation
+// at D = 20 - the copies are not what the ~30 us between the end of the kernel and the host's next instruction are made of.)
+// The eigen-decomposition of each C goes along with the parameters: ~5 us of host arithmetic here against a lone wave's ~50 us on
+// the critical path of every block there.
 struct HipEvaluator {
     const double *data, *y, *sqrt_y, *w;
     int64_t N;
@@ -626,6 +648,7 @@ struct HipEvaluator {
     size_t recon_ws_bytes;
     hipStream_t stream;
     vec a, q, lam, e;
+    double t_factor = 0.0, t_enqueue = 0.0, t_wait = 0.0;     // where an evaluation's wall-clock goes (reported with GABO_RECON_TIMING set)
 };
 
 static int hip_evaluate(void* ctx, int64_t P, const double* v, const double* c, const double* k, double* cost, double* gv, double* gc,
@@ -634,6 +657,7 @@ static int hip_evaluate(void* ctx, int64_t P, const double* v, const double* c, 
     const int m = ev.D - ev.d;
     const size_t nV = (size_t)ev.D * m, nC = (size_t)m * m, nK = (size_t)ev.d * m, npar = nV + nC + nK;
     (void)k; (void)gv; (void)gc; (void)gk;                      // (contiguous behind v / cost: the driver's staging layout)
+    const auto t0 = std::chrono::steady_clock::now();
     double* h_lam = const_cast<double*>(v) + P * npar;          // the staging buffer continues behind the P parameter sets
     double* h_vec = h_lam + P * m;
     for (int64_t p = 0; p < P; ++p) {
@@ -645,22 +669,30 @@ static int hip_evaluate(void* ctx, int64_t P, const double* v, const double* c, 
         for (int i = 0; i < m; ++i)
             for (int j = 0; j < m; ++j) out[i * m + j] = ev.q[j * m + i];          // vectors into the columns
     }
-    const size_t in_doubles = P * (npar + m + nC);
-    if (hipMemcpyAsync(ev.dev_in, v, sizeof(double) * in_doubles, hipMemcpyHostToDevice, ev.stream) != hipSuccess) return GABO_ERR_LAUNCH;
-    double* dv = ev.dev_in;
+    const auto t1 = std::chrono::steady_clock::now();
+    double* in = ev.dev_in;
+    double* out = ev.dev_out;
+    if (hipMemcpyAsync(ev.dev_in, v, sizeof(double) * P * (npar + m + nC), hipMemcpyHostToDevice, ev.stream) != hipSuccess) return GABO_ERR_LAUNCH;
+    double* dv = in;
     double* dc = dv + P * nV;
     double* dk = dc + P * nC;
     double* dlam = dk + P * nK;
     double* dvec = dlam + P * m;
-    double* dcost = ev.dev_out;
+    double* dcost = out;
     double* dgv = dcost + P;
     double* dgc = dgv + P * nV;
     double* dgk = dgc + P * nC;
-    const int rc = gabo_nested_spd_reconstruction(ev.data, ev.y, ev.sqrt_y, ev.w, dv, dc, dk, dcost, dgv, dgc, dgk, dlam, dvec, P, ev.N, ev.D,
-                                                  ev.d, ev.metric, ev.recon_ws, ev.recon_ws_bytes, (gabo_stream_t)ev.stream);
+    const int rc = nested_spd_reconstruction_launch(ev.data, ev.y, ev.sqrt_y, ev.w, dv, dc, dk, dcost, dgv, dgc, dgk, dlam, dvec, P, ev.N, ev.D, ev.d,
+                                                    ev.metric, ev.recon_ws, ev.recon_ws_bytes, false, (gabo_stream_t)ev.stream);
     if (rc != GABO_OK) return rc;
     if (hipMemcpyAsync(cost, ev.dev_out, sizeof(double) * P * (1 + npar), hipMemcpyDeviceToHost, ev.stream) != hipSuccess) return GABO_ERR_LAUNCH;
-    return hipStreamSynchronize(ev.stream) == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+    const auto t2 = std::chrono::steady_clock::now();
+    const bool ok = hipStreamSynchronize(ev.stream) == hipSuccess;
+    const auto t3 = std::chrono::steady_clock::now();
+    ev.t_factor += std::chrono::duration<double>(t1 - t0).count();
+    ev.t_enqueue += std::chrono::duration<double>(t2 - t1).count();
+    ev.t_wait += std::chrono::duration<double>(t3 - t2).count();
+    return ok ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -679,9 +711,11 @@ int gabo_nested_spd_reconstruction_solve_with(gabo_recon_eval_fn evaluate, void*
     if (!evaluate || !w_host || !v || !c || !unit || !raw || !staging || !options_ok(options)) return GABO_ERR_ARG;
     Dims dm(D, d);
     const size_t npar = (size_t)dm.nV + dm.nC + dm.nU;
-    const size_t in_doubles = 2 * (npar + dm.m + dm.nC);       // two parameter sets + room for an evaluator's factors of the two C
-    if (staging_doubles < in_doubles + 2 * (1 + npar)) return GABO_ERR_ARG;
+    const size_t in_doubles = kMaxLookahead * (npar + dm.m + dm.nC);       // the parameter sets + room for an evaluator's factors of their C
+    if (staging_doubles < in_doubles + kMaxLookahead * (1 + npar)) return GABO_ERR_ARG;
     Driver drv(D, d, w_host, evaluate, ctx, staging, staging + in_doubles, *options);
+    // default: four step lengths per launch while the extra retractions are cheap (measured: -22 % / -13 % / -3 % wall-clock at D = 5 / 10 / 20)
+    drv.lookahead = options->lookahead < 1 ? (dm.m <= 16 ? 4 : 2) : (options->lookahead > kMaxLookahead ? (int)kMaxLookahead : (int)options->lookahead);
     Point best(dm);
     std::memcpy(best.x.data(), v, sizeof(double) * dm.nV);
     std::memcpy(best.x.data() + dm.oC, c, sizeof(double) * dm.nC);
@@ -697,11 +731,11 @@ int gabo_nested_spd_reconstruction_solve_with(gabo_recon_eval_fn evaluate, void*
 
 void gabo_nested_spd_reconstruction_solve_workspace_bytes(int64_t N, int D, int d, size_t* device_bytes, size_t* pinned_doubles) {
     const size_t m = (size_t)(D - d), npar = (size_t)D * m + m * m + (size_t)d * m;
-    const size_t in_doubles = 2 * (npar + m + m * m);
+    const size_t in_doubles = kMaxLookahead * (npar + m + m * m);
     if (device_bytes)
-        *device_bytes = align256(sizeof(double) * in_doubles) + align256(sizeof(double) * 2 * (1 + npar)) +
-                        align256(gabo_nested_spd_reconstruction_workspace_bytes(2, N < 1 ? 1 : N, D, d));
-    if (pinned_doubles) *pinned_doubles = in_doubles + 2 * (1 + npar);
+        *device_bytes = align256(sizeof(double) * in_doubles) + align256(sizeof(double) * kMaxLookahead * (1 + npar)) +
+                        align256(gabo_nested_spd_reconstruction_workspace_bytes(kMaxLookahead, N < 1 ? 1 : N, D, d));
+    if (pinned_doubles) *pinned_doubles = in_doubles + kMaxLookahead * (1 + npar);
 }
 
 int gabo_nested_spd_reconstruction_solve(const double* data, const double* y, const double* sqrt_y, const double* w, const double* w_host,
@@ -719,13 +753,19 @@ int gabo_nested_spd_reconstruction_solve(const double* data, const double* y, co
     e.N = N; e.D = D; e.d = d; e.metric = metric;
     char* base = static_cast<char*>(workspace);
     e.dev_in = reinterpret_cast<double*>(base);
-    const size_t in_doubles = 2 * (npar + m + m * m);
+    const size_t in_doubles = kMaxLookahead * (npar + m + m * m);
     e.dev_out = reinterpret_cast<double*>(base + align256(sizeof(double) * in_doubles));
-    e.recon_ws = base + align256(sizeof(double) * in_doubles) + align256(sizeof(double) * 2 * (1 + npar));
+    e.recon_ws = base + align256(sizeof(double) * in_doubles) + align256(sizeof(double) * kMaxLookahead * (1 + npar));
     e.a.resize(m * m); e.q.resize(m * m); e.lam.resize(m); e.e.resize(3 * m);
-    e.recon_ws_bytes = gabo_nested_spd_reconstruction_workspace_bytes(2, N < 1 ? 1 : N, D, d);
+    // the tickets at the head of the launch workspace: cleared once, every launch leaves them at zero
+    if (hipMemsetAsync(e.recon_ws, 0, 256, (hipStream_t)stream) != hipSuccess) return GABO_ERR_LAUNCH;
+    e.recon_ws_bytes = gabo_nested_spd_reconstruction_workspace_bytes(kMaxLookahead, N < 1 ? 1 : N, D, d);
     e.stream = (hipStream_t)stream;
-    return gabo_nested_spd_reconstruction_solve_with(hip_evaluate, &e, w_host, v, c, unit, raw, D, d, pinned, pinned_doubles, options, log);
+    const int rc = gabo_nested_spd_reconstruction_solve_with(hip_evaluate, &e, w_host, v, c, unit, raw, D, d, pinned, pinned_doubles, options, log);
+    if (getenv("GABO_RECON_TIMING") && log)
+        fprintf(stderr, "gabo_nested_spd_reconstruction_solve D=%d: %.2f ms = manifold arithmetic %.2f + factor C %.2f + enqueue %.2f + wait %.2f (%ld launches)\n", D,
+                1e3 * log->seconds, 1e3 * (log->seconds - log->seconds_evaluator), 1e3 * e.t_factor, 1e3 * e.t_enqueue, 1e3 * e.t_wait, (long)log->launches);
+    return rc;
 }
 
 }  // extern "C"

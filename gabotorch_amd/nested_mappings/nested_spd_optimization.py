@@ -3,6 +3,8 @@
 distances between the data and their reconstructions, minimised over  V in G(D, D-d),  C in S^(D-d)_++,  K = t * unit vector reshaped,
 t = sigmoid(.) in (0, 1), under W^T V = 0 by the augmented Lagrangian method.  Both built-in costs are ONE HIP launch per evaluation,
 value and gradient together (gabo_nested_spd_reconstruction: csrc/nested_spd_reconstruction.hip)."""
+import os
+
 import numpy as np
 import torch
 
@@ -183,7 +185,8 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
             bound=solver._bound, rho_init=solver._rho_init, thetarho=solver._thetarho, tau=solver._tau,
             starting_tolgradnorm=solver._starting_tolgradnorm, ending_tolgradnorm=solver._ending_tolgradnorm, gammas_fact=solver._gammas_fact,
             minstepsize=solver._minstepsize, maxtime=solver._maxtime, maxiter=solver._maxiter, cg_minstepsize=inner_solver.minstepsize,
-            cg_maxtime=inner_solver.maxtime, cg_orth_value=inner_solver.orth_value, cg_maxiter=inner_solver.maxiter)
+            cg_maxtime=inner_solver.maxtime, cg_orth_value=inner_solver.orth_value, cg_maxiter=inner_solver.maxiter,
+            lookahead=int(os.environ.get("GABO_RECON_LOOKAHEAD", "0")))
         v, c, unit, raw, log = cost_vg.rec.solve_host(x0[0], x0[1], x0[2], x0[3], options)
         opt = [v, c, unit, raw]
         optimize_reconstruction_parameters_nested_spd.last_log = dict(log, init_cost=float(np.min(vals)), native=True)

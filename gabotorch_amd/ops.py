@@ -528,7 +528,8 @@ class NestedSpdReconstruction:
 def _recon_log(log):
     return {"iterations": int(log.outer_iterations), "inner_iterations": int(log.inner_iterations), "evaluations": int(log.evaluations),
             "launches": int(log.launches), "stop_reason": _lib.GABO_RECON_STOP[log.stop_reason], "violation": float(log.violation),
-            "rho": float(log.rho), "gammas": [float(log.gamma)], "final_cost": float(log.final_cost), "time": float(log.seconds)}
+            "rho": float(log.rho), "gammas": [float(log.gamma)], "final_cost": float(log.final_cost), "time": float(log.seconds),
+            "time_in_evaluator": float(log.seconds_evaluator)}
 
 
 def nested_spd_reconstruction_solve_with(evaluate, w_host, V, C, unit, raw, options):
@@ -544,7 +545,7 @@ def nested_spd_reconstruction_solve_with(evaluate, w_host, V, C, unit, raw, opti
     v, c, u = (np.array(a, dtype=np.float64, order="C") for a in (V, C, unit))
     r = np.array([float(np.asarray(raw).reshape(-1)[0])], dtype=np.float64)
     npar = D * m + m * m + d * m
-    staging = np.empty(2 * (npar + m + m * m) + 2 * (1 + npar))
+    staging = np.empty(_lib.GABO_RECON_MAX_LOOKAHEAD * (2 * npar + 1 + m + m * m))
     failure = []
 
     def trampoline(_ctx, P, pv, pc, pk, pcost, pgv, pgc, pgk):

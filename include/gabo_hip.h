@@ -473,8 +473,8 @@ int gabo_nested_spd_reconstruction(const double* data, const double* y, const do
  * gabo_nested_spd_reconstruction_solve: data / y / sqrt_y / w as for gabo_nested_spd_reconstruction (device); workspace: device memory,
  *   pinned: page-locked host memory (hipHostMalloc / torch pin_memory), sizes from ..._solve_workspace_bytes (pinned counted in doubles).
  * gabo_nested_spd_reconstruction_solve_with: the same loop around ANY evaluator (a user-supplied cost_function, :98) - called with
- *   P <= 2 parameter sets, v: P x D x (D-d), c: P x (D-d)^2, k: P x d x (D-d), it fills cost[P] and the Euclidean partial derivatives
- *   grad_v / grad_c / grad_k (same shapes) and returns GABO_OK; staging: >= 2 (2 npar + 1 + (D-d) + (D-d)^2) doubles of host memory,
+ *   P <= GABO_RECON_MAX_LOOKAHEAD parameter sets, v: P x D x (D-d), c: P x (D-d)^2, k: P x d x (D-d), it fills cost[P] and the Euclidean partial derivatives
+ *   grad_v / grad_c / grad_k (same shapes) and returns GABO_OK; staging: >= GABO_RECON_MAX_LOOKAHEAD (2 npar + 1 + (D-d) + (D-d)^2) doubles of host memory,
  *   npar = D (D-d) + (D-d)^2 + d (D-d).
  * Returns GABO_OK, an argument error, GABO_ERR_NOT_SPD when an iterate left the cone (never in exact arithmetic), or the evaluator's code.
  */
@@ -483,7 +483,11 @@ typedef struct {
     int64_t maxiter;
     double cg_minstepsize, cg_maxtime, cg_orth_value;   /* [3P] pymanopt ConjugateGradient(minstepsize, maxtime, orth_value) */
     int64_t cg_maxiter;
+    int64_t lookahead;   /* step lengths alpha, alpha/2, ... evaluated by the first launch of a line search: 1..GABO_RECON_MAX_LOOKAHEAD,
+                            0 = default (4 up to D - d = 16, else 2).
+                            It changes which launch computes a value, never the values or the steps taken. */
 } gabo_recon_solve_options;
+#define GABO_RECON_MAX_LOOKAHEAD 4
 #define GABO_RECON_STOP_MAXITER 0
 #define GABO_RECON_STOP_MAXTIME 1
 #define GABO_RECON_STOP_MINSTEP 2
@@ -492,6 +496,7 @@ typedef struct {
     int64_t outer_iterations, inner_iterations, evaluations, launches;
     int stop_reason;                                     /* GABO_RECON_STOP_* */
     double violation, rho, gamma, final_cost, seconds;
+    double seconds_evaluator;                            /* of `seconds`, inside the evaluator (enqueue + wait); the rest is host arithmetic */
 } gabo_recon_solve_log;
 typedef int (*gabo_recon_eval_fn)(void* ctx, int64_t P, const double* v, const double* c, const double* k, double* cost, double* grad_v,
                                   double* grad_c, double* grad_k);

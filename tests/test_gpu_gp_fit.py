@@ -175,7 +175,7 @@ def test_native_reconstruction_loop_follows_the_python_loop(D, d, N, metric):
     np.testing.assert_allclose(nat[3]["rho"], py[3]["rho"], rtol=1e-12)
     for a, b in zip(nat[:3], py[:3]):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
-    assert nat[3]["launches"] <= nat[3]["evaluations"] <= 2 * nat[3]["launches"]
+    assert nat[3]["launches"] <= nat[3]["evaluations"] <= 4 * nat[3]["launches"]          # (up to GABO_RECON_MAX_LOOKAHEAD step lengths per launch)
 
 
 def test_nested_sphere_reconstruction_cost_and_optimiser(golden):

@@ -30,6 +30,8 @@ cp /tmp/psweep/sw_kernel_stats.csv $OUT/sweep_kernel_stats.csv
 # 4b. config 5's latent loop: the reconstruction optimiser (fused launch) and the HD-GaBO example under the kernel trace; the tiled likelihood
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prec -o rec -- python $R/tools/recon_profile.py > $OUT/recon.log 2>&1
 cp /tmp/prec/rec_kernel_stats.csv $OUT/recon_kernel_stats.csv
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/precn -o recn -- python $R/tools/recon_native_probe.py 20 > $OUT/recon_native.log 2>&1
+cp /tmp/precn/recn_kernel_stats.csv $OUT/recon_native_kernel_stats.csv
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/phd -o hd -- python $R/tools/hd_gabo_breakdown.py --dims 20 --iters 4 > $OUT/hd_gabo.log 2>&1
 cp /tmp/phd/hd_kernel_stats.csv $OUT/hd_gabo_kernel_stats.csv
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pmll -o mll -- python $R/tools/gp_mll_bench.py > $OUT/gp_mll.log 2>&1

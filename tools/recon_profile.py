@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Host-side profile (cProfile) of optimize_reconstruction_parameters_nested_spd at D = 20 -> 2, N = 10: where an augmented-Lagrangian
-run spends its wall-clock between the fused launch, the pinned copies and the numpy manifold arithmetic.   python tools/recon_profile.py"""
+"""Host-side profile (cProfile) of the PYTHON loop of optimize_reconstruction_parameters_nested_spd (native=False) at D = 20 -> 2, N = 10:
+where an augmented-Lagrangian run spends its wall-clock between the fused launch, the pinned copies and the numpy manifold arithmetic - the
+measurement that motivated the native loop (tools/recon_native_probe.py times that one).   python tools/recon_profile.py"""
 import os, sys, cProfile, pstats, time
 import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -16,7 +17,7 @@ Y = np.einsum("ab,nac,cd->nbd", W, X, W)
 T = lambda a: torch.tensor(a, dtype=torch.float64, device="cuda:0")
 np.random.seed(0)
 def go():
-    return nso.optimize_reconstruction_parameters_nested_spd(T(X), T(Y), T(W), ConjugateGradient(maxiter=100), cost_function=nso.min_log_euclidean_distance_reconstruction_cost, nb_init_candidates=20, maxiter=6)
+    return nso.optimize_reconstruction_parameters_nested_spd(T(X), T(Y), T(W), ConjugateGradient(maxiter=100), cost_function=nso.min_log_euclidean_distance_reconstruction_cost, nb_init_candidates=20, maxiter=6, native=False)
 go()
 t=time.perf_counter(); go(); print("wall", time.perf_counter()-t)
 pr = cProfile.Profile(); pr.enable(); go(); pr.disable()
