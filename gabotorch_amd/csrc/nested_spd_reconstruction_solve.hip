@@ -46,12 +46,15 @@ typedef std::vector<double> vec;
 #define GABO_HOST_CLONES __attribute__((target_clones("avx2", "default")))
 #endif
 
-GABO_HOST_CLONES
-static double dot(const double* a, const double* b, int n) {
+// (inlined into each clone of its callers: a call through the ifunc table per 18-element product would cost more than the product)
+__attribute__((always_inline)) static inline double dot_inl(const double* a, const double* b, int n) {
     double s = 0.0;
     for (int i = 0; i < n; ++i) s += a[i] * b[i];
     return s;
 }
+
+GABO_HOST_CLONES
+static double dot(const double* a, const double* b, int n) { return dot_inl(a, b, n); }
 
 // C (M x N) = A (M x K) B (K x N), row-major
 GABO_HOST_CLONES
@@ -86,7 +89,7 @@ static void mtm(const double* A, const double* B, double* C, int K, int M, int N
 GABO_HOST_CLONES
 static void mmt(const double* A, const double* B, double* C, int M, int K, int N) {
     for (int i = 0; i < M; ++i)
-        for (int j = 0; j < N; ++j) C[(size_t)i * N + j] = dot(A + (size_t)i * K, B + (size_t)j * K, K);
+        for (int j = 0; j < N; ++j) C[(size_t)i * N + j] = dot_inl(A + (size_t)i * K, B + (size_t)j * K, K);
 }
 
 static void symmetrize(double* A, int n) {
@@ -118,8 +121,8 @@ static bool sym_eig(int n, double* a, double* w, double* q, double* e) {
         if (vnorm2 == 0.0) continue;
         const double inv = 1.0 / vnorm2;                 // H = I - v v^T / vnorm2
         // trailing block B (rows / columns k+1..n-1): B <- H B H
-        for (int i = 0; i < len; ++i) p[i] = inv * dot(a + (size_t)(k + 1 + i) * n + k + 1, v, len);
-        const double kk = 0.5 * inv * dot(p, v, len);
+        for (int i = 0; i < len; ++i) p[i] = inv * dot_inl(a + (size_t)(k + 1 + i) * n + k + 1, v, len);
+        const double kk = 0.5 * inv * dot_inl(p, v, len);
         for (int i = 0; i < len; ++i) p[i] -= kk * v[i];
         for (int i = 0; i < len; ++i) {
             double* row = a + (size_t)(k + 1 + i) * n + k + 1;
@@ -128,12 +131,18 @@ static bool sym_eig(int n, double* a, double* w, double* q, double* e) {
         }
         a[(k + 1) * n + k] = a[k * n + k + 1] = alpha * scale;
         for (int i = 1; i < len; ++i) a[(k + 1 + i) * n + k] = a[k * n + k + 1 + i] = 0.0;
-        // rows k+1.. of q: q <- H q
-        for (int j = 0; j < n; ++j) {
-            double s = 0.0;
-            for (int i = 0; i < len; ++i) s += v[i] * q[(size_t)(k + 1 + i) * n + j];
-            s *= inv;
-            for (int i = 0; i < len; ++i) q[(size_t)(k + 1 + i) * n + j] -= s * v[i];
+        // rows k+1.. of q: q <- H q  (row by row: contiguous, vectorisable; p is free again and holds v^T q / vnorm2)
+        for (int j = 0; j < n; ++j) p[j] = 0.0;
+        for (int i = 0; i < len; ++i) {
+            const double vi = v[i];
+            const double* row = q + (size_t)(k + 1 + i) * n;
+            for (int j = 0; j < n; ++j) p[j] += vi * row[j];
+        }
+        for (int j = 0; j < n; ++j) p[j] *= inv;
+        for (int i = 0; i < len; ++i) {
+            const double vi = v[i];
+            double* row = q + (size_t)(k + 1 + i) * n;
+            for (int j = 0; j < n; ++j) row[j] -= vi * p[j];
         }
     }
     for (int i = 0; i < n; ++i) w[i] = a[i * n + i];

@@ -52,7 +52,8 @@ int main(int argc, char** argv) {
     const std::vector<double> v_start = v, c_start = c, u_start = u;
     double sec = 1e30;
     int rc = 0;
-    for (int rep = 0; rep < 30; ++rep) {                  // best of 30 identical runs
+    const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 30;
+    for (int rep = 0; rep < reps; ++rep) {                  // best of 30 identical runs
         v = v_start; c = c_start; u = u_start; raw[0] = 0.3;
         const auto t0 = std::chrono::steady_clock::now();
         rc = gabo_nested_spd_reconstruction_solve_with(quad, &x, w.data(), v.data(), c.data(), u.data(), raw.data(), D, d, staging.data(),
