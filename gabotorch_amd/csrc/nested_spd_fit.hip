@@ -105,6 +105,13 @@ __global__ __launch_bounds__(256) void fit_projection_adjoint_kernel(const doubl
     }
 }
 
+// (for the nested-sphere chain in nested_sphere_chain.hip: the same adjoint of the Gram matrix)
+int fit_gram_adjoint_launch(const double* kb, const double* wm, double* gs, double* out, double* partial, int* counter, int64_t n, double half_os,
+                            double theta, unsigned blocks, hipStream_t s) {
+    hipLaunchKernelGGL(fit_gram_adjoint_kernel, dim3(blocks), dim3(256), 0, s, kb, wm, gs, out, partial, counter, n, half_os, theta);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
 namespace {
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }

@@ -171,6 +171,98 @@ class _NestedSpdMllProblem(_MllProblem):
         return out
 
 
+class _NestedSphereMllProblem(_MllProblem):
+    """The same objective for ScaleKernel(NestedSphereGaussianKernel) - the surrogate of HD-GaBO on the sphere
+    (examples/hd_bo_sphere/benchmark_examples/hd_gabo_sphere.py:150-180): the axes of the nested spheres are learnt on their spheres together
+    with the scalar hyper-parameters.  One evaluation is ONE host call (gabo_nested_sphere_fit_evaluate: every level of the projection for
+    every training point in one launch, the Gram matrix, the likelihood, and their adjoints back to the axes); torch autograd through the
+    level-by-level Python statement of the projection needed ~50 launches per level."""
+
+    @staticmethod
+    def build(model, names, params, manifold):
+        from .. import _compat, ops
+        from ..kernel_utils.kernels_nested_sphere import NestedSphereGaussianKernel
+        cm = model.covar_module
+        base = getattr(cm, "base_kernel", None)
+        if _compat.HAVE_GPYTORCH or base is None or type(base) is not NestedSphereGaussianKernel:
+            return None
+        if not model.train_x.is_cuda and not torch.cuda.is_available():
+            return None
+        axis_idx = []
+        for a in base.axes:
+            hits = [k for k, p in enumerate(params) if p is a]
+            if len(hits) != 1:
+                return None
+            axis_idx.append(hits[0])
+        self = _NestedSphereMllProblem(model, names, params, manifold)
+        self.axis_idx = axis_idx
+        self.scalar_idx = [k for k in range(len(params)) if k not in axis_idx]
+        if any(params[k].numel() != 1 for k in self.scalar_idx) or base.dim - base.latent_dim != len(axis_idx) or base.latent_dim > 64:
+            return None
+        self.ops = ops
+        dev = ops._device_for(model.train_x)
+        self.x = model.train_x.to(dev).double().contiguous()
+        self.y = model.train_y.to(dev).double().contiguous()
+        if self.x.dim() != 2 or self.x.shape[1] != base.dim:
+            return None
+        self.D, self.L = int(base.dim), len(axis_idx)
+        self.dists = np.array([float(d.reshape(-1)[0]) for d in base.distances_to_axis], dtype=np.float64)
+        self.total = sum(self.D - k for k in range(self.L))
+        self.want_grad, self.values_only, self.axes_host, self.grad_axes, self._buffers, self._recent = False, False, None, None, None, []
+        self.scalar = model._fast_scalar_objective([params[k] for k in self.scalar_idx], evaluator=self._evaluate)
+        return self if self.scalar is not None else None
+
+    def _evaluate(self, theta, outputscale, noise, mean):
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        n = self.x.shape[0]
+        if self._buffers is None:
+            ws = torch.empty(max(int(lib.gabo_nested_sphere_fit_workspace_bytes(n, self.D, self.L)), 16), dtype=torch.uint8, device=self.x.device)
+            self._buffers = (ws, torch.empty(2 * self.total + self.L + 7, dtype=torch.float64).pin_memory(), np.empty(7 + self.total))
+        ws, pinned, out = self._buffers
+        key = (self.axes_host.tobytes(), theta, outputscale, noise, mean)
+        for k, res in self._recent:
+            if k == key and (res[2] or not self.want_grad):
+                self.grad_axes = res[1]
+                return res[0]
+        want = self.want_grad or not self.values_only
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+        with torch.cuda.device(self.x.device):
+            _lib.check(lib.gabo_nested_sphere_fit_evaluate(
+                self.x.data_ptr(), self.y.data_ptr(), ptr(self.axes_host), ptr(self.dists), n, self.D, self.L, float(theta), float(outputscale),
+                float(noise), float(mean), 1 if want else 0, ptr(out), ws.data_ptr(), ws.numel(), pinned.data_ptr(), pinned.numel(),
+                self.ops._stream_ptr(self.x.device)), "gabo_nested_sphere_fit_evaluate")
+        res = ((float(out[0]), float(out[6]), float(out[2]), float(out[3]), float(out[4]), float(out[5])), out[7:].copy(), want)
+        self._recent = [(key, res)] + self._recent[:3]
+        self.grad_axes = res[1]
+        return res[0]
+
+    def _run(self, x, want_grad):
+        self.axes_host = np.ascontiguousarray(np.concatenate([np.asarray(x[k], dtype=np.float64).reshape(-1) for k in self.axis_idx]))
+        self.want_grad = want_grad
+        v = np.array([float(np.asarray(x[k]).reshape(-1)[0]) for k in self.scalar_idx])
+        return self.scalar(v)
+
+    def cost(self, x):
+        self.n_evals += 1
+        loss, _ = self._run(x, False)
+        return float("inf") if loss >= 1e10 else float(loss)
+
+    def egrad(self, x):
+        loss, g = self._run(x, True)
+        n = self.y.numel()
+        out = [None] * len(self.params)
+        for pos, k in enumerate(self.scalar_idx):
+            out[k] = np.full(np.shape(x[k]), g[pos])
+        off = 0
+        for level, k in enumerate(self.axis_idx):
+            d = self.D - level
+            out[k] = np.zeros(np.shape(x[k])) if loss >= 1e10 else (-self.grad_axes[off:off + d] / n).reshape(np.shape(x[k]))
+            off += d
+        return out
+
+
 def fit_gpytorch_manifold(model, solver=None, nb_init_candidates=200, last_x_as_candidate_prob=0.9, exclude=None,
                           keep_first_euclidean=True):
     """Fits `model` (gabotorch_amd.models.SingleTaskGP) in place; returns (model, info).
@@ -196,7 +288,8 @@ def fit_gpytorch_manifold(model, solver=None, nb_init_candidates=200, last_x_as_
         factors.append(man)
         x0.append(p.detach().cpu().double().numpy().reshape(shape).copy())
     manifold = Product(factors)
-    problem = _NestedSpdMllProblem.build(model, names, params, manifold) or _MllProblem(model, names, params, manifold)
+    problem = (_NestedSpdMllProblem.build(model, names, params, manifold) or _NestedSphereMllProblem.build(model, names, params, manifold)
+               or _MllProblem(model, names, params, manifold))
     t1 = time.time()
     cands = [x0] if np.random.rand() < last_x_as_candidate_prob else []
     cands += [manifold.rand() for _ in range(nb_init_candidates - len(cands))]

@@ -20,37 +20,40 @@ def min_error_reconstruction_cost(x_data, x_subsphere, sphere_axes, sphere_dista
 
 
 def optimize_reconstruction_parameters_nested_sphere(x_data, x_subsphere, sphere_axes, solver, nb_init_candidates=100):
-    """-> list of distances to the axes [S^d, ..., S^(d-r+1)] (1 x 1 tensors)   (nested_spheres_optimization.py:41-100)."""
+    """-> list of distances to the axes [S^d, ..., S^(d-r+1)] (1 x 1 tensors)   (nested_spheres_optimization.py:41-100).
+    One launch per evaluation (gabo_nested_sphere_reconstruction: every level of the lift, the distance to the data and the gradient with
+    respect to the distances; the start candidates are ONE launch); the chain through r = pi * sigmoid(.) is host arithmetic."""
+    from .. import ops
     dev, dt = x_data.device, torch.float64
-    x_data, x_subsphere = x_data.to(dt), x_subsphere.to(dev, dt)
-    axes = [a.detach().to(dev, dt) for a in sphere_axes]
-    n_levels = x_data.shape[1] - x_subsphere.shape[1]
+    rec = ops.NestedSphereReconstruction(x_data.to(dt), x_subsphere.to(dev, dt), [a.detach() for a in sphere_axes])
+    n_levels = rec.L
     manifold = Product([Euclidean(1) for _ in range(n_levels)])
 
-    def radii(params):
-        return [math.pi * torch.sigmoid(p).reshape(1, 1) for p in params]          # gpytorch Interval(0, pi).transform
+    def sigmoid(x):
+        v = np.array([float(np.asarray(xi).reshape(-1)[0]) for xi in x])
+        return 1.0 / (1.0 + np.exp(-v))
 
-    def cost_torch(params):
-        return min_error_reconstruction_cost(x_data, x_subsphere, axes, radii(params))
+    recent = []                        # (key, value, gradient): a line search asks for the value, the solver then for the gradient there
 
     def value_and_egrad(x):
-        p = [torch.tensor(np.asarray(xi), dtype=dt, device=dev, requires_grad=True) for xi in x]
-        v = cost_torch(p)
-        grads = torch.autograd.grad(v, p, allow_unused=True)
-        return float(v.detach()), [np.zeros(1) if g is None else g.detach().cpu().numpy().reshape(1) for g in grads]
+        sg = sigmoid(x)                                                # gpytorch Interval(0, pi).transform
+        key = sg.tobytes()
+        for k, v, g in recent:
+            if k == key:
+                return v, g
+        v, g = rec.evaluate(math.pi * sg, grad=True)
+        out = (float(v), [np.array([gi]) for gi in g * math.pi * sg * (1.0 - sg)])
+        recent[:] = [(key,) + out] + recent[:3]
+        return out
 
     class _Problem:
         pass
     problem = _Problem()
     problem.manifold = manifold
-
-    def value_only(x):                 # line searches and the candidate screening need no autograd graph
-        with torch.no_grad():
-            return float(cost_torch([torch.tensor(np.asarray(xi), dtype=dt, device=dev) for xi in x]))
-    problem.cost = value_only
+    problem.cost = lambda x: value_and_egrad(x)[0]
     problem.grad = lambda x: manifold.egrad2rgrad(x, value_and_egrad(x)[1])
     cands = [manifold.rand() for _ in range(nb_init_candidates)]
-    vals = [problem.cost(c) for c in cands]
+    vals = rec.evaluate(math.pi * np.stack([sigmoid(c) for c in cands]), grad=False)          # the candidate screening: one launch
     opt, log = solver.solve(problem, x=cands[int(np.argmin(vals))])
     optimize_reconstruction_parameters_nested_sphere.last_log = dict(log, init_cost=float(np.min(vals)))
-    return [r.detach() for r in radii([torch.tensor(o, dtype=dt, device=dev) for o in opt])]
+    return [torch.tensor([[ri]], dtype=dt, device=dev) for ri in math.pi * sigmoid(opt)]

@@ -1013,6 +1013,72 @@ class _NestedSphereEpilogue(torch.autograd.Function):
         return nested_sphere_epilogue_backward(u, g, ctx.dist).to(u.dtype), None
 
 
+def pack_nested_sphere_axes(sphere_axes, dim):
+    """[axis of S^(dim-1) (dim entries), axis of the next subsphere (dim - 1 entries), ...] -> one float64 numpy vector, level after level
+    (the layout of gabo_nested_sphere_frames / _reconstruction / _fit_evaluate)."""
+    import numpy as np
+    parts = []
+    for k, a in enumerate(sphere_axes):
+        v = (a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)).reshape(-1)
+        if v.size != dim - k:
+            raise RuntimeError(f"nested-sphere axis of level {k} must have {dim - k} entries, got {v.size}")
+        parts.append(v)
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+class NestedSphereReconstruction:
+    """min_error_reconstruction_cost (nested_spheres_optimization.py:20-38) for FIXED data, subsphere points and axes, as a function of the
+    distances to the axes: value and gradient of P parameter sets in one launch (gabo_nested_sphere_reconstruction)."""
+
+    def __init__(self, x_data, x_subsphere, sphere_axes):
+        lib = _lib.load()
+        dev = self.device = _device_for(x_data, x_subsphere)
+        self.x = _prep(x_data, dev).contiguous()
+        self.z = _prep(x_subsphere, dev).contiguous()
+        self.N, self.D = int(self.x.shape[0]), int(self.x.shape[1])
+        self.L = self.D - int(self.z.shape[1])
+        if self.x.dim() != 2 or self.z.dim() != 2 or self.z.shape[0] != self.N or self.L < 1 or len(sphere_axes) != self.L:
+            raise RuntimeError(f"shapes: x_data {tuple(self.x.shape)}, x_subsphere {tuple(self.z.shape)}, {len(sphere_axes)} axes")
+        axes = torch.as_tensor(pack_nested_sphere_axes(sphere_axes, self.D), device=dev)
+        self.frames = torch.empty(axes.numel() + 2 * self.L, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.gabo_nested_sphere_frames(axes.data_ptr(), self.frames.data_ptr(), self.D, self.L, _stream_ptr(dev)), "gabo_nested_sphere_frames")
+        self._buffers = {}
+
+    def evaluate(self, distances, grad=True):
+        """distances: (P, L) or (L,) numpy -> cost (P,) [, d cost / d distances (P, L)] as numpy (one copy in, one launch, one copy out)."""
+        import numpy as np
+        lib = _lib.load()
+        r = np.asarray(distances, dtype=np.float64)
+        single = r.ndim == 1
+        r = np.ascontiguousarray(r.reshape(-1, self.L))
+        P = r.shape[0]
+        ent = self._buffers.get(P)
+        if ent is None:
+            ws = max(int(lib.gabo_nested_sphere_reconstruction_workspace_bytes(P, max(self.N, 1), self.D, self.L)), 16)
+            ent = self._buffers[P] = dict(hin=torch.empty(P * self.L, dtype=torch.float64).pin_memory(),
+                                          hout=torch.empty(P * (1 + self.L), dtype=torch.float64).pin_memory(),
+                                          din=torch.empty(P * self.L, dtype=torch.float64, device=self.device),
+                                          dout=torch.empty(P * (1 + self.L), dtype=torch.float64, device=self.device),
+                                          ws=torch.empty(ws, dtype=torch.uint8, device=self.device))
+        ent["hin"].numpy()[:] = r.ravel()
+        ent["din"].copy_(ent["hin"], non_blocking=True)
+        dout = ent["dout"]
+        with torch.cuda.device(self.device):
+            _lib.check(lib.gabo_nested_sphere_reconstruction(self.x.data_ptr(), self.z.data_ptr(), self.frames.data_ptr(), ent["din"].data_ptr(),
+                                                             dout.data_ptr(), dout[P:].data_ptr() if grad else None, P, self.N, self.D, self.L,
+                                                             ent["ws"].data_ptr(), ent["ws"].numel(), _stream_ptr(self.device)),
+                       "gabo_nested_sphere_reconstruction")
+        ent["hout"].copy_(dout, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        out = ent["hout"].numpy()
+        cost = out[:P].copy()
+        if not grad:
+            return cost[0] if single else cost
+        g = out[P:].reshape(P, self.L).copy()
+        return (cost[0], g[0]) if single else (cost, g)
+
+
 def nested_sphere_next(rotated, dist_to_axis):
     """Differentiable mode-0 epilogue."""
     if rotated.requires_grad:

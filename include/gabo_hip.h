@@ -249,6 +249,33 @@ int gabo_nested_spd_fit_evaluate(const double* x_mandel, const double* x_matrice
                                  void* workspace, size_t workspace_bytes, double* pinned, size_t pinned_doubles, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Nested-sphere mappings over all their levels in one launch (HD-GaBO on the sphere, examples/hd_bo_sphere/benchmark_examples/hd_gabo_sphere.py).
+ * Level k = 0 .. levels-1 has the axis a_k on S^(D-k-1) (dimension D - k) and the distance r_k; `axes` are packed level after level
+ * (sum_k (D - k) doubles).  frames: the rotation frames of the axes, sum_k (D - k) + 2 levels doubles, written by gabo_nested_sphere_frames
+ *   (rotation_from_sphere_points_torch(axis, north pole), Riemannian_utils/sphere_utils_torch.py:58-93, as a rank-2 update).
+ * gabo_nested_sphere_reconstruction replaces  min_error_reconstruction_cost   nested_mappings/nested_spheres_optimization.py:20-38
+ *   = projection_from_subsphere_to_sphere (nested_spheres_utils.py:149-218) + sphere_distance_torch(diag) (sphere_utils_torch.py:12-55) + autograd:
+ *   x_data: N x D, x_subsphere: N x (D - levels), distances: P x levels (P parameter sets in one launch: the optimiser's start candidates);
+ *   cost[p] = sum_n acos(clamp(<x_n, reconstruction_p(z_n)>))^2, grad: P x levels = d cost / d distances, or NULL.
+ * gabo_nested_sphere_fit_evaluate: one evaluation of the surrogate-fit objective of the same example with its gradient, one HOST call
+ *   (fit_gpytorch_manifold's closure, manifold_optimization/manifold_gp_fit.py:54-222, for ScaleKernel(NestedSphereGaussianKernel),
+ *   kernel_utils/kernels_nested_sphere.py:19-152 = projection_from_sphere_to_subsphere (nested_spheres_utils.py:68-146) -> Gaussian sphere kernel;
+ *   [3P] gpytorch ExactMarginalLogLikelihood): x: n x D training points, y: n targets (device); axes_host (packed), distances_host (levels): host.
+ *   out_host (7 + sum_k (D - k) doubles): [ll, 0, d/d outputscale, d/d noise, d/d mean, not-positive-definite flag, d/d beta, d ll / d axes
+ *   (packed, Euclidean)]; want_grad = 0: the first six only.  workspace: device, ..._fit_workspace_bytes; pinned: >= 2 sum_k (D - k) + levels + 7
+ *   doubles of page-locked host memory.  D - levels <= 64, n <= GABO_GP_MLL_LARGE_MAX_N.
+ */
+int gabo_nested_sphere_frames(const double* axes, double* frames, int D, int levels, gabo_stream_t stream);
+size_t gabo_nested_sphere_reconstruction_workspace_bytes(int64_t P, int64_t N, int D, int levels);
+int gabo_nested_sphere_reconstruction(const double* x_data, const double* x_subsphere, const double* frames, const double* distances,
+                                      double* cost, double* grad, int64_t P, int64_t N, int D, int levels, void* workspace,
+                                      size_t workspace_bytes, gabo_stream_t stream);
+size_t gabo_nested_sphere_fit_workspace_bytes(int64_t n, int D, int levels);
+int gabo_nested_sphere_fit_evaluate(const double* x, const double* y, const double* axes_host, const double* distances_host, int64_t n, int D,
+                                    int levels, double beta, double outputscale, double noise, double mean, int want_grad, double* out_host,
+                                    void* workspace, size_t workspace_bytes, double* pinned, size_t pinned_doubles, gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * n random SPD matrices with the distribution of spd_sample (Riemannian_utils/spd_utils.py:290-306; the raw samples of
  * gen_batch_initial_conditions_manifold, manifold_optimize.py:288): eigenvalues U[min_eig, max_eig], eigenvectors = orthogonal
  * factor of a Gaussian matrix.  out: n x d x d (mandel == 0) or n x d_vec Mandel vectors.  Counter-based stream (Philox4x32-10,

@@ -204,6 +204,82 @@ def test_nested_sphere_reconstruction_cost_and_optimiser(golden):
     assert projection_from_sphere_to_subsphere(x, axes, found)[-1].shape == (20, 3)
 
 
+@pytest.mark.parametrize("D,lat,N", [(5, 3, 9), (21, 3, 14), (51, 3, 11), (70, 2, 5)])
+def test_fused_nested_sphere_reconstruction_launch(golden, D, lat, N):
+    """gabo_nested_sphere_reconstruction (all levels of the lift, the distance to the data and the gradient w.r.t. the distances to the axes,
+    P parameter sets per launch) against the level-by-level torch statement under autograd (min_error_reconstruction_cost, itself pinned on
+    the reference's values in reconstruction.npz above), and on the golden fixture directly."""
+    from gabotorch_amd import ops
+    from gabotorch_amd.nested_mappings import nested_spheres_optimization as nsso
+    T = lambda a, grad=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV, requires_grad=grad)   # noqa: E731
+    g = golden("reconstruction.npz")
+    rec = ops.NestedSphereReconstruction(T(g["ns_x"]), T(g["ns_sub"]), [T(g["ns_axis0"]), T(g["ns_axis1"])])
+    c, gr = rec.evaluate(np.asarray(g["ns_r"], dtype=np.float64))
+    np.testing.assert_allclose(c, g["ns_cost"], rtol=1e-10)
+    np.testing.assert_allclose(gr, g["ns_grad"], rtol=1e-8)
+    rng = np.random.default_rng(D)
+    L = D - lat
+    axes = []
+    for k in range(L):
+        a = rng.standard_normal(D - k)
+        axes.append(T(a / np.linalg.norm(a)))
+    x = rng.standard_normal((N, D))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    z = rng.standard_normal((N, lat))
+    z /= np.linalg.norm(z, axis=1, keepdims=True)
+    rec = ops.NestedSphereReconstruction(T(x), T(z), axes)
+    P = 3
+    r = rng.uniform(0.3, 2.8, size=(P, L))
+    costs, grads = rec.evaluate(r)
+    np.testing.assert_allclose(rec.evaluate(r, grad=False), costs, rtol=0, atol=0)
+    for p in range(P):
+        rt = [T([[v]], True) for v in r[p]]
+        want = nsso.min_error_reconstruction_cost(T(x), T(z), axes, rt)
+        want.backward()
+        np.testing.assert_allclose(costs[p], float(want), rtol=1e-11)
+        np.testing.assert_allclose(grads[p], [float(t_.grad) for t_ in rt], rtol=1e-8, atol=1e-10)
+    c1, g1 = rec.evaluate(r[1])
+    assert c1 == costs[1] and np.array_equal(g1, grads[1])
+
+
+@pytest.mark.parametrize("D,lat,n", [(5, 3, 12), (21, 3, 30), (51, 4, 20), (12, 2, 190)])
+def test_nested_sphere_fit_objective_in_one_host_call_matches_autograd(D, lat, n):
+    """fit_gpytorch_manifold's objective for ScaleKernel(NestedSphereGaussianKernel) - the surrogate of HD-GaBO on the sphere - as ONE host call
+    (gabo_nested_sphere_fit_evaluate: projection through all levels, Gram, likelihood and the adjoints back to the axes) against the same
+    marginal likelihood differentiated by torch autograd through the level-by-level statement (_MllProblem): value, the gradients w.r.t.
+    every axis, beta, outputscale, noise and mean.  (The autograd gradients of the axes pass through their float32 parameters: 1e-6.)"""
+    from gabotorch_amd.manifold_optimization import manifold_gp_fit as mgf
+    from gabotorch_amd.manifold_optimization.host_manifolds import Euclidean, Product
+    rng = np.random.default_rng(D + n)
+    x = rng.standard_normal((n, D))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    X = torch.tensor(x, device=DEV)
+    y = torch.tensor(rng.standard_normal(n), device=DEV)
+    torch.manual_seed(4)
+    base = NestedSphereGaussianKernel(D, lat, beta_min=0.6)
+    gp = models.SingleTaskGP(X, y, ScaleKernel(base, outputscale_prior=models.GammaPrior(2.0, 0.15)).double(), noise_prior=models.GammaPrior(1.1, 0.05))
+    named = list(gp.named_parameters())
+    params = [p for _, p in named]
+    axis_ids = {id(a) for a in base.axes}
+    factors = [getattr(base, nm.split(".")[-1] + "_manifold") if id(p) in axis_ids else Euclidean(int(p.numel())) for nm, p in named]
+    manifold = Product(factors)
+    fast = mgf._NestedSphereMllProblem.build(gp, [nm for nm, _ in named], params, manifold)
+    assert fast is not None
+    slow = mgf._MllProblem(gp, [nm for nm, _ in named], params, manifold)
+    for trial in range(2):
+        pt = [man.rand() if id(p) in axis_ids else rng.normal(0.3, 0.4, size=(int(p.numel()),)) for p, man in zip(params, factors)]
+        fast.values_only = True
+        c_values = fast.cost(pt)
+        fast.values_only = False
+        fast._recent = []
+        c_fast, c_slow = fast.cost(pt), slow.cost(pt)
+        np.testing.assert_allclose([c_values, c_fast], c_slow, rtol=1e-9)
+        g_fast, g_slow = fast.egrad(pt), slow.egrad(pt)
+        for a, b, (nm, p) in zip(g_fast, g_slow, named):
+            tol = 2e-5 if id(p) in axis_ids else 1e-7
+            np.testing.assert_allclose(np.ravel(a), np.ravel(b), rtol=tol, atol=tol * max(1e-3, float(np.abs(b).max())), err_msg=nm)
+
+
 def test_nested_spd_eigenvalue_constraints_golden(golden):
     """max/min_eigenvalue_nested_spd_constraint (bounds in the original space, hd_gabo_spd.py:245-256) with their gradients w.r.t.
     the nested point, single points and a batch, against the reference."""
