@@ -119,6 +119,8 @@ SIGNATURES = {
     "gabo_nested_spd_extreme_eigenvalues": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I, _I, _P]),
     "gabo_nested_spd_reconstruction": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _SZ, _P]),
     "gabo_nested_sphere_frames": (_I, [_P, _P, _I, _I, _P]),
+    "gabo_nested_sphere_project": (_I, [_P, _P, _P, _P, _P, _I64, _I, _I, _P]),
+    "gabo_nested_sphere_lift": (_I, [_P, _P, _P, _P, _P, _I64, _I, _I, _P]),
     "gabo_nested_sphere_reconstruction_workspace_bytes": (_SZ, [_I64, _I64, _I, _I]),
     "gabo_nested_sphere_reconstruction": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _P, _SZ, _P]),
     "gabo_nested_sphere_fit_workspace_bytes": (_SZ, [_I64, _I, _I]),

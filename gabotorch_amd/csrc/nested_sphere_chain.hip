@@ -205,6 +205,40 @@ __global__ __launch_bounds__(64) void nested_sphere_project_kernel(const double*
     for (int i = lane; i < D - L; i += 64) z[(size_t)n * (D - L) + i] = cur[i];
 }
 
+// Lift S^(D-L-1) -> S^(D-1) through all levels (projection_from_subsphere_to_sphere, nested_spheres_utils.py:182-218), one wave per point:
+// level k (applied from k = L-1 down to 0) maps x in S^(d-2) to R(north -> axis_k) [sin r_k x, cos r_k] in S^(d-1), d = D - k.
+// levels_out != NULL keeps every level's output (packed like the axes: level 0's, the final point, first).
+__global__ __launch_bounds__(64) void nested_sphere_lift_kernel(const double* __restrict__ z, const double* __restrict__ frames,
+                                                               const double* __restrict__ dists, double* __restrict__ xout,
+                                                               double* __restrict__ levels_out, int D, int L) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* cur = lds;                // D
+    const int n = blockIdx.x, lane = threadIdx.x, lat = D - L;
+    const int total = chain_offset(D, L);
+    const double* stv = frames + total;
+    for (int i = lane; i < lat; i += 64) cur[i] = z[(size_t)n * lat + i];
+    __syncthreads();
+    for (int k = L - 1; k >= 0; --k) {
+        const int d = D - k;
+        const double* e = frames + chain_offset(D, k);
+        const double s = stv[2 * k], t = stv[2 * k + 1];
+        const double r = dists[k];
+        const double sr = sin(r), cr = cos(r);
+        double dot = 0.0;
+        for (int i = lane; i < d - 1; i += 64) dot = __builtin_fma(cur[i], e[i], dot);
+        dot = wave_sum(dot);
+        const double el = e[d - 1];
+        const double b = sr * dot + cr * el;
+        const double cy = -s * b + (t - 1.0) * cr, ce = s * cr + (t - 1.0) * b;
+        __syncthreads();
+        for (int i = lane; i < d - 1; i += 64) cur[i] = sr * cur[i] + ce * e[i];
+        if (lane == 0) cur[d - 1] = cr + cy + ce * el;
+        __syncthreads();
+        if (levels_out) for (int i = lane; i < d; i += 64) levels_out[(size_t)n * total + chain_offset(D, k) + i] = cur[i];
+    }
+    if (xout) for (int i = lane; i < D; i += 64) xout[(size_t)n * D + i] = cur[i];
+}
+
 // Adjoint of the projection with respect to the frames: gz (n x (D-L)) -> per-point partials [g_e (packed like the axes) | (g_s, g_t) per level]
 __global__ __launch_bounds__(64) void nested_sphere_project_backward_kernel(const double* __restrict__ store, const double* __restrict__ frames,
                                                                            const double* __restrict__ dists, const double* __restrict__ gz,
@@ -375,6 +409,28 @@ int gabo_nested_sphere_frames(const double* axes, double* frames, int D, int lev
     if (D < 2 || D > 4096 || levels < 1 || levels > D - 1) return GABO_ERR_DIM;
     if (!axes || !frames) return GABO_ERR_ARG;
     hipLaunchKernelGGL(gabo::nested_sphere_frames_kernel, dim3((unsigned)levels), dim3(64), 0, (hipStream_t)stream, axes, frames, D, levels);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_nested_sphere_project(const double* x, const double* frames, const double* distances, double* z, double* levels_in, int64_t n, int D,
+                               int levels, gabo_stream_t stream) {
+    if (D < 2 || D > 4096 || levels < 1 || levels > D - 1) return GABO_ERR_DIM;
+    if (n < 0) return GABO_ERR_ARG;
+    if (n == 0) return GABO_OK;
+    if (!x || !frames || !distances || !z || n > 0x7fffffffLL) return GABO_ERR_ARG;
+    hipLaunchKernelGGL(gabo::nested_sphere_project_kernel, dim3((unsigned)n), dim3(64), (size_t)D * sizeof(double), (hipStream_t)stream, x, frames,
+                       distances, z, levels_in, D, levels);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_nested_sphere_lift(const double* x_subsphere, const double* frames, const double* distances, double* x, double* levels_out, int64_t n,
+                            int D, int levels, gabo_stream_t stream) {
+    if (D < 2 || D > 4096 || levels < 1 || levels > D - 1) return GABO_ERR_DIM;
+    if (n < 0) return GABO_ERR_ARG;
+    if (n == 0) return GABO_OK;
+    if (!x_subsphere || !frames || !distances || (!x && !levels_out) || n > 0x7fffffffLL) return GABO_ERR_ARG;
+    hipLaunchKernelGGL(gabo::nested_sphere_lift_kernel, dim3((unsigned)n), dim3(64), (size_t)D * sizeof(double), (hipStream_t)stream, x_subsphere,
+                       frames, distances, x, levels_out, D, levels);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .conjugate_gradient import ConjugateGradient
-from .host_manifolds import Euclidean, Product
+from .host_manifolds import Euclidean, PackedEuclideanSpheres, Product, Sphere
 
 
 class _MllProblem:
@@ -302,7 +302,18 @@ def fit_gpytorch_manifold(model, solver=None, nb_init_candidates=200, last_x_as_
     costs = [problem.cost(c) for c in cands]
     problem.values_only = False
     x_init = cands[int(np.argmin(costs))]
-    opt_x, log = solver.solve(problem, x=x_init)
+    if isinstance(problem, _NestedSphereMllProblem) and all(type(m) in (Euclidean, Sphere) for m in factors):
+        # one axis per nested level: the same product geometry on one flat vector (no Python loop over ~D factors per manifold operation)
+        packed = PackedEuclideanSpheres(factors)
+
+        class _Packed:
+            manifold = packed
+            cost = staticmethod(lambda v: problem.cost(packed.unpack(v)))
+            grad = staticmethod(lambda v: packed.egrad2rgrad(v, packed.pack(problem.egrad(packed.unpack(v)))))
+        opt_v, log = solver.solve(_Packed, x=packed.pack(x_init))
+        opt_x = [np.array(a) for a in packed.unpack(opt_v)]
+    else:
+        opt_x, log = solver.solve(problem, x=x_init)
     problem._set(opt_x)
     for p in params:
         p.grad = None

@@ -7,7 +7,7 @@ import math
 import numpy as np
 import torch
 
-from ..manifold_optimization.host_manifolds import Euclidean, Product
+from ..manifold_optimization.host_manifolds import Euclidean
 from ..Riemannian_utils.sphere_utils_torch import sphere_distance_torch
 from .nested_spheres_utils import projection_from_subsphere_to_sphere
 
@@ -27,11 +27,11 @@ def optimize_reconstruction_parameters_nested_sphere(x_data, x_subsphere, sphere
     dev, dt = x_data.device, torch.float64
     rec = ops.NestedSphereReconstruction(x_data.to(dt), x_subsphere.to(dev, dt), [a.detach() for a in sphere_axes])
     n_levels = rec.L
-    manifold = Product([Euclidean(1) for _ in range(n_levels)])
+    # the reference's product of n_levels Euclidean lines (:62-63) IS R^n_levels: one vector, no Python loop over the factors per operation
+    manifold = Euclidean(n_levels)
 
     def sigmoid(x):
-        v = np.array([float(np.asarray(xi).reshape(-1)[0]) for xi in x])
-        return 1.0 / (1.0 + np.exp(-v))
+        return 1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64).reshape(-1)))
 
     recent = []                        # (key, value, gradient): a line search asks for the value, the solver then for the gradient there
 
@@ -42,7 +42,7 @@ def optimize_reconstruction_parameters_nested_sphere(x_data, x_subsphere, sphere
             if k == key:
                 return v, g
         v, g = rec.evaluate(math.pi * sg, grad=True)
-        out = (float(v), [np.array([gi]) for gi in g * math.pi * sg * (1.0 - sg)])
+        out = (float(v), g * math.pi * sg * (1.0 - sg))
         recent[:] = [(key,) + out] + recent[:3]
         return out
 

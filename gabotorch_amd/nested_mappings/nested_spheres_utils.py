@@ -12,6 +12,15 @@ from .. import ops
 from ..Riemannian_utils.sphere_utils_torch import rotate_along_geodesic
 
 
+def _no_graph(points, sphere_axes, sphere_distances):
+    """True when no autograd graph is wanted through the mapping (then the fused all-levels launches serve) and a HIP device is there"""
+    if not (points.is_cuda or torch.cuda.is_available()):
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    return not (points.requires_grad or any(torch.is_tensor(t) and t.requires_grad for t in list(sphere_axes) + list(sphere_distances)))
+
+
 def _dist_value(sphere_distance_to_axis):
     return float(sphere_distance_to_axis.reshape(-1)[0]) if torch.is_tensor(sphere_distance_to_axis) else float(sphere_distance_to_axis)
 
@@ -55,6 +64,9 @@ def projection_from_sphere_to_subsphere(x, sphere_axes, sphere_distances_to_axes
         sphere_axes = [sphere_axes]
     if not isinstance(sphere_distances_to_axes, list):
         sphere_distances_to_axes = [sphere_distances_to_axes]
+    if _no_graph(x, sphere_axes, sphere_distances_to_axes) and x.dim() == 2 and len(sphere_axes) >= 1:
+        # nothing to differentiate: every level for every point in ONE launch (gabo_nested_sphere_project)
+        return [t.to(x.device, x.dtype) for t in ops.nested_sphere_project_all(x, sphere_axes, sphere_distances_to_axes)]
     x_subsphere = [x]
     for axis, dist in zip(sphere_axes, sphere_distances_to_axes):
         x_subsphere.append(projection_from_sphere_to_next_subsphere(x_subsphere[-1], axis, dist))
@@ -80,6 +92,8 @@ def projection_from_subsphere_to_sphere(x_subsphere, sphere_axes, sphere_distanc
         sphere_axes = [sphere_axes]
     if not isinstance(sphere_distances_to_axes, list):
         sphere_distances_to_axes = [sphere_distances_to_axes]
+    if _no_graph(x_subsphere, sphere_axes, sphere_distances_to_axes) and x_subsphere.dim() == 2 and len(sphere_axes) >= 1:
+        return [t.to(x_subsphere.device, x_subsphere.dtype) for t in ops.nested_sphere_lift_all(x_subsphere, sphere_axes, sphere_distances_to_axes)]
     x = [x_subsphere]
     nb = len(sphere_axes)
     for s in range(nb):

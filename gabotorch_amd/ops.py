@@ -1026,6 +1026,60 @@ def pack_nested_sphere_axes(sphere_axes, dim):
     return np.ascontiguousarray(np.concatenate(parts))
 
 
+def _nested_sphere_frames(sphere_axes, sphere_distances, dim, dev):
+    """(frames, distances) device tensors of the fused nested-sphere launches from the lists the reference's functions take."""
+    lib = _lib.load()
+    levels = len(sphere_axes)
+    axes = torch.cat([a.detach().reshape(-1).to(dev, torch.float64) for a in sphere_axes])
+    if axes.numel() != levels * dim - levels * (levels - 1) // 2:
+        raise RuntimeError("nested-sphere axes: level k must have dim - k entries")
+    dists = torch.cat([(d.detach().reshape(-1)[:1].to(dev, torch.float64) if torch.is_tensor(d)
+                        else torch.tensor([float(d)], dtype=torch.float64, device=dev)) for d in sphere_distances])
+    frames = torch.empty(axes.numel() + 2 * levels, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_nested_sphere_frames(axes.data_ptr(), frames.data_ptr(), dim, levels, _stream_ptr(dev)), "gabo_nested_sphere_frames")
+    return frames, dists
+
+
+def _level_offsets(dim, levels):
+    return [k * dim - k * (k - 1) // 2 for k in range(levels + 1)]
+
+
+def nested_sphere_project_all(x, sphere_axes, sphere_distances):
+    """projection_from_sphere_to_subsphere (nested_spheres_utils.py:117-146) in one launch, no autograd: x (N, D) -> the list
+    [x, x_{D-1}, ..., x_{D-levels}] of the points on every nested subsphere."""
+    lib = _lib.load()
+    dev = _device_for(x)
+    X = _prep(x, dev).contiguous()
+    n, dim = int(X.shape[0]), int(X.shape[1])
+    levels = len(sphere_axes)
+    frames, dists = _nested_sphere_frames(sphere_axes, sphere_distances, dim, dev)
+    off = _level_offsets(dim, levels)
+    z = torch.empty(n, dim - levels, dtype=torch.float64, device=dev)
+    store = torch.empty(n, off[-1], dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_nested_sphere_project(X.data_ptr(), frames.data_ptr(), dists.data_ptr(), z.data_ptr(), store.data_ptr(), n, dim, levels,
+                                                  _stream_ptr(dev)), "gabo_nested_sphere_project")
+    return [store[:, off[k]:off[k + 1]] for k in range(levels)] + [z]
+
+
+def nested_sphere_lift_all(x_subsphere, sphere_axes, sphere_distances):
+    """projection_from_subsphere_to_sphere (nested_spheres_utils.py:182-218) in one launch, no autograd: x_subsphere (N, D - levels) -> the
+    list [x_subsphere, x_{D-levels+1}, ..., x_D] (the axes are used in reverse order, as in the reference)."""
+    lib = _lib.load()
+    dev = _device_for(x_subsphere)
+    Z = _prep(x_subsphere, dev).contiguous()
+    levels = len(sphere_axes)
+    n, dim = int(Z.shape[0]), int(Z.shape[1]) + levels
+    frames, dists = _nested_sphere_frames(sphere_axes, sphere_distances, dim, dev)
+    off = _level_offsets(dim, levels)
+    store = torch.empty(n, off[-1], dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gabo_nested_sphere_lift(Z.data_ptr(), frames.data_ptr(), dists.data_ptr(), None, store.data_ptr(), n, dim, levels,
+                                               _stream_ptr(dev)), "gabo_nested_sphere_lift")
+    return [Z] + [store[:, off[k]:off[k + 1]] for k in range(levels - 1, -1, -1)]
+
+
 class NestedSphereReconstruction:
     """min_error_reconstruction_cost (nested_spheres_optimization.py:20-38) for FIXED data, subsphere points and axes, as a function of the
     distances to the axes: value and gradient of P parameter sets in one launch (gabo_nested_sphere_reconstruction)."""

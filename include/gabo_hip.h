@@ -266,6 +266,14 @@ int gabo_nested_spd_fit_evaluate(const double* x_mandel, const double* x_matrice
  *   doubles of page-locked host memory.  D - levels <= 64, n <= GABO_GP_MLL_LARGE_MAX_N.
  */
 int gabo_nested_sphere_frames(const double* axes, double* frames, int D, int levels, gabo_stream_t stream);
+/* gabo_nested_sphere_project: x (n x D) through every level -> z (n x (D - levels));  levels_in (or NULL): n x sum_k (D - k), the input of
+ *   every level - the list projection_from_sphere_to_subsphere returns, without its last entry z (nested_spheres_utils.py:117-146).
+ * gabo_nested_sphere_lift: x_subsphere (n x (D - levels)) back up -> x (n x D, or NULL); levels_out (or NULL): n x sum_k (D - k), the output of
+ *   every level, level 0 (the final point) first - the list of projection_from_subsphere_to_sphere reversed (:182-218).  distances: `levels` doubles on the device. */
+int gabo_nested_sphere_project(const double* x, const double* frames, const double* distances, double* z, double* levels_in, int64_t n, int D,
+                               int levels, gabo_stream_t stream);
+int gabo_nested_sphere_lift(const double* x_subsphere, const double* frames, const double* distances, double* x, double* levels_out, int64_t n,
+                            int D, int levels, gabo_stream_t stream);
 size_t gabo_nested_sphere_reconstruction_workspace_bytes(int64_t P, int64_t N, int D, int levels);
 int gabo_nested_sphere_reconstruction(const double* x_data, const double* x_subsphere, const double* frames, const double* distances,
                                       double* cost, double* grad, int64_t P, int64_t N, int D, int levels, void* workspace,

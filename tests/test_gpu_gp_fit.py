@@ -242,6 +242,38 @@ def test_fused_nested_sphere_reconstruction_launch(golden, D, lat, N):
     assert c1 == costs[1] and np.array_equal(g1, grads[1])
 
 
+@pytest.mark.parametrize("D,lat,N", [(5, 3, 7), (21, 3, 40), (51, 2, 9)])
+def test_nested_sphere_projections_in_one_launch_match_the_level_by_level_path(D, lat, N):
+    """projection_from_sphere_to_subsphere / projection_from_subsphere_to_sphere without an autograd graph (gabo_nested_sphere_project /
+    _lift: every level in one launch) against the differentiable level-by-level statement of the same functions (pinned on the reference's
+    values by test_gpu_parity's nested-sphere goldens): every entry of the returned lists."""
+    from gabotorch_amd.nested_mappings.nested_spheres_utils import projection_from_sphere_to_subsphere, projection_from_subsphere_to_sphere
+    rng = np.random.default_rng(3 * D)
+    T = lambda a, grad=False: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV, requires_grad=grad)   # noqa: E731
+    L = D - lat
+    axes = []
+    for k in range(L):
+        a = rng.standard_normal(D - k)
+        axes.append(T(a / np.linalg.norm(a)))
+    dists = [torch.tensor([[v]], dtype=torch.float64) for v in rng.uniform(0.4, 2.6, L)]
+    x = rng.standard_normal((N, D))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    fused = projection_from_sphere_to_subsphere(T(x), axes, dists)
+    stepwise = projection_from_sphere_to_subsphere(T(x, True), axes, dists)
+    assert len(fused) == len(stepwise) == L + 1
+    for a, b in zip(fused, stepwise):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a.cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-11, atol=1e-13)
+    z = fused[-1].contiguous()
+    up_fused = projection_from_subsphere_to_sphere(z, axes, dists)
+    up_stepwise = projection_from_subsphere_to_sphere(z.clone().requires_grad_(True), axes, dists)
+    assert len(up_fused) == len(up_stepwise) == L + 1
+    for a, b in zip(up_fused, up_stepwise):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a.cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(np.linalg.norm(up_fused[-1].cpu().numpy(), axis=1), 1.0, atol=1e-4)      # (the reference's + 1e-6 in the normalisations)
+
+
 @pytest.mark.parametrize("D,lat,n", [(5, 3, 12), (21, 3, 30), (51, 4, 20), (12, 2, 190)])
 def test_nested_sphere_fit_objective_in_one_host_call_matches_autograd(D, lat, n):
     """fit_gpytorch_manifold's objective for ScaleKernel(NestedSphereGaussianKernel) - the surrogate of HD-GaBO on the sphere - as ONE host call

@@ -290,3 +290,39 @@ def test_native_reconstruction_loop_against_the_python_solvers(D, d, seed):
     # an evaluator that raises stops the loop and the error reaches the caller
     with pytest.raises(ZeroDivisionError):
         ops.nested_spd_reconstruction_solve_with(lambda V, C, K: 1 / 0, W, x0[0], x0[1], x0[2], x0[3], options)
+
+
+def test_packed_product_of_spheres_and_lines_is_the_product_manifold():
+    """PackedEuclideanSpheres (one flat vector, segment sums) against Product([...]) of the same Euclidean / Sphere factors: every operation
+    the conjugate-gradient solver uses, and the same minimiser from the same start."""
+    from gabotorch_amd.manifold_optimization.host_manifolds import PackedEuclideanSpheres
+    np.random.seed(4)
+    factors = [Euclidean(1), Euclidean(1), Sphere(7), Sphere(6), Sphere(5), Euclidean(1), Euclidean(3)]
+    prod, packed = Product(factors), PackedEuclideanSpheres(factors)
+    assert packed.dim == prod.dim and packed.typicaldist == prod.typicaldist
+    x, y = prod.rand(), prod.rand()
+    u, v = prod.proj(x, [np.random.randn(*m._shape) for m in factors]), prod.proj(x, [np.random.randn(*m._shape) for m in factors])
+    px, py, pu, pv = (packed.pack(a) for a in (x, y, u, v))
+    for got, want in zip(packed.unpack(px), x):
+        np.testing.assert_array_equal(got, want)
+    np.testing.assert_allclose(packed.inner(px, pu, pv), prod.inner(x, u, v), rtol=1e-13)
+    np.testing.assert_allclose(packed.norm(px, pu), prod.norm(x, u), rtol=1e-13)
+    np.testing.assert_allclose(packed.dist(px, py), prod.dist(x, y), rtol=1e-12)
+    ambient = [np.random.randn(*m._shape) for m in factors]
+    np.testing.assert_allclose(packed.proj(px, packed.pack(ambient)), packed.pack(prod.proj(x, ambient)), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(packed.retr(px, 0.3 * pu), packed.pack(prod.retr(x, [0.3 * a for a in u])), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(packed.transp(px, py, pu), packed.pack(prod.transp(x, y, u)), rtol=1e-13, atol=1e-15)
+    target = prod.rand()
+
+    def cost_parts(z):
+        return float(sum(np.sum((a - b) ** 2) for a, b in zip(z, target)))
+
+    def egrad_parts(z):
+        return [2.0 * (a - b) for a, b in zip(z, target)]
+
+    a, log_a = ConjugateGradient(maxiter=60).solve(_Problem(prod, cost_parts, egrad_parts), x=[p.copy() for p in x])
+    b, log_b = ConjugateGradient(maxiter=60).solve(
+        _Problem(packed, lambda z: cost_parts(packed.unpack(z)), lambda z: packed.pack(egrad_parts(packed.unpack(z)))), x=px.copy())
+    assert log_a["iterations"] == log_b["iterations"]
+    np.testing.assert_allclose(b, packed.pack(a), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(b, packed.pack(target), atol=1e-5)
