@@ -1,18 +1,50 @@
-import sys, time, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/examples")
-import numpy as np, torch
-import hd_gabo_sphere as ex
-import gabotorch_amd.manifold_optimization.manifold_gp_fit as mgf
-import gabotorch_amd.nested_mappings.nested_spheres_optimization as nso
-import gabotorch_amd.manifold_optimization.manifold_optimize as mo
-T = {"fit": [], "recon": [], "sweep": []}
+#!/usr/bin/env python3
+"""Wall-clock phases of one HD-GaBO iteration on the sphere (examples/hd_gabo_sphere.py: surrogate fit with the nested-sphere axes learnt on
+their spheres, reconstruction distances, latent acquisition sweep) by ambient dimension; medians over the iterations after the first.
+   python tools/hd_gabo_sphere_breakdown.py [D ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+import hd_gabo_sphere as ex                                                                      # noqa: E402
+import gabotorch_amd.manifold_optimization.manifold_gp_fit as mgf                                 # noqa: E402
+import gabotorch_amd.manifold_optimization.manifold_optimize as mo                                # noqa: E402
+import gabotorch_amd.nested_mappings.nested_spheres_optimization as nso                           # noqa: E402
+
+T = {"fit": [], "reconstruction": [], "sweep": []}
+starts = []
+
+
 def wrap(mod, name, key):
     f = getattr(mod, name)
+
     def g(*a, **k):
-        torch.cuda.synchronize(); t = time.perf_counter(); r = f(*a, **k); torch.cuda.synchronize(); T[key].append(time.perf_counter() - t); return r
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        if key == "fit":
+            starts.append(t)
+        r = f(*a, **k)
+        torch.cuda.synchronize()
+        T[key].append(time.perf_counter() - t)
+        return r
     setattr(ex, name, g)
-wrap(mgf, "fit_gpytorch_manifold", "fit"); wrap(nso, "optimize_reconstruction_parameters_nested_sphere", "recon"); wrap(mo, "joint_optimize_manifold", "sweep")
-for dim, latent in ((5, 3), (21, 3), (51, 3)):
-    for k in T: T[k].clear()
-    t = time.perf_counter(); ex.run(dim, latent, 8, verbose=False); tot = time.perf_counter() - t
-    print(dim, latent, {k: round(1e3 * float(np.median(v[1:])), 1) for k, v in T.items()}, "total/iter", round(1e3 * tot / 8, 1))
+
+
+wrap(mgf, "fit_gpytorch_manifold", "fit")
+wrap(nso, "optimize_reconstruction_parameters_nested_sphere", "reconstruction")
+wrap(mo, "joint_optimize_manifold", "sweep")
+for dim in [int(a) for a in sys.argv[1:]] or [5, 21, 51]:
+    for k in T:
+        T[k].clear()
+    starts.clear()
+    ex.run(dim, 3, 9, verbose=False)
+    med = {k: 1e3 * float(np.median(v[1:])) for k, v in T.items()}
+    iteration = 1e3 * float(np.median(np.diff(starts)[1:]))
+    print(f"HD-GaBO sphere D={dim:2d} -> 3, n = 6..13: " + ", ".join(f"{k} {v:.1f} ms" for k, v in med.items()) + f"; iteration {iteration:.1f} ms")
