@@ -275,6 +275,64 @@ def config5_pieces(device):
             "parity": {"projection_max_abs": e_p, "nested_ai_gram_max_abs": e_ai, "log_euclidean_gram_max_abs": e_le, "block": "96 x 96"}}
 
 
+def hd_sphere_pieces(device):
+    """The nested-sphere chain of HD-GaBO on the sphere (examples/hd_bo_sphere/benchmark_examples/hd_gabo_sphere.py) at D = 51 -> 3 (48 levels):
+    all levels of the projection for N = 4096 points in one launch, and one reconstruction evaluation (lift + geodesic distance + gradient
+    w.r.t. the 48 distances) of 64 data points; each checked against the oracle."""
+    from gabotorch_amd import _lib, ops as _ops
+    from oracle import sphere as osph
+    lib = _lib.load()
+    D, lat, n = 51, 3, N_POINTS
+    L = D - lat
+    rng = np.random.default_rng(5151)
+    axes_np = []
+    for k in range(L):
+        a = rng.standard_normal(D - k)
+        axes_np.append(a / np.linalg.norm(a))
+    r_np = rng.uniform(0.8, 2.2, L)
+    x = rng.standard_normal((n, D))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    xt = torch.tensor(x, device=device)
+    axes = [torch.tensor(a, device=device) for a in axes_np]
+    frames, dists = _ops._nested_sphere_frames(axes, list(r_np), D, device)
+    z = torch.empty(n, lat, dtype=torch.float64, device=device)
+    stream = _ops._stream_ptr(device)
+
+    def ev_ms(fn, iters=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    ms_proj = ev_ms(lambda: lib.gabo_nested_sphere_project(xt.data_ptr(), frames.data_ptr(), dists.data_ptr(), z.data_ptr(), None, n, D, L, stream))
+    e_proj = float(np.max(np.abs(z[:64].cpu().numpy() - osph.projection_from_sphere_to_subsphere(x[:64], axes_np, r_np)[-1])))
+    nd = 64
+    rec = _ops.NestedSphereReconstruction(xt[:nd], z[:nd], axes)
+    rd = torch.tensor(r_np, device=device)
+    out = torch.empty(1 + L, dtype=torch.float64, device=device)
+    ws = torch.empty(max(int(lib.gabo_nested_sphere_reconstruction_workspace_bytes(1, nd, D, L)), 16), dtype=torch.uint8, device=device)
+    ms_rec = ev_ms(lambda: lib.gabo_nested_sphere_reconstruction(rec.x.data_ptr(), rec.z.data_ptr(), rec.frames.data_ptr(), rd.data_ptr(), out.data_ptr(),
+                                                                 out[1:].data_ptr(), 1, nd, D, L, ws.data_ptr(), ws.numel(), stream))
+    want = osph.nested_sphere_reconstruction_cost(x[:nd], z[:nd].cpu().numpy(), axes_np, r_np)
+    e_rec = abs(float(out[0]) - want) / abs(want)
+    if not (e_proj < 1e-9 and e_rec < 1e-9):
+        raise RuntimeError(f"nested-sphere parity gate failed: {e_proj} {e_rec}")
+    # algorithmic traffic of the projection: one read of the point, one write of the latent point; the frames (10 KB) stay in L2
+    nbytes = n * (D + lat) * 8
+    return {"workload": "hd_gabo_sphere pieces, D = 51 -> 3 (48 nested levels): projection of N=4096 points through all levels (one wave per point); "
+                        "one reconstruction evaluation with its gradient w.r.t. the 48 distances, 64 data points",
+            "projection_ms": ms_proj, "projection_points_per_s": n / (ms_proj * 1e-3),
+            "projection_roofline": {"bound": "latency: 48 dependent levels per wave (one inner product, one acos / sin, one norm each)",
+                                    "achieved": nbytes / (ms_proj * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": nbytes / (ms_proj * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "reconstruction_evaluation_ms": ms_rec,
+            "parity": {"projection_max_abs": e_proj, "reconstruction_cost_rel": e_rec}}
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks (one process per GPU, RCCL over
     xGMI) and relay their output - rank 0 prints the JSON line."""
@@ -550,6 +608,7 @@ def main():
             line["roofline_sphere"] = dict(line["sphere_gram"]["roofline"], kernel="gabo::sphere_pairwise_kernel<0, true>", kernel_ms=sph_ms,
                                            binding_resource="fp64 issue of the acos^2 + exp epilogue (MFMA + stores alone: 26 us)")
             line["config5"] = config5_pieces(device)
+            line["hd_sphere"] = hd_sphere_pieces(device)
             # the step before the sweep in a BO iteration: surrogate fit (fit_gpytorch_model), 50 observations on S^5_++
             import time as _time
             from gabotorch_amd import models as _models

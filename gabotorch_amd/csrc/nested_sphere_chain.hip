@@ -24,10 +24,7 @@ constexpr double kChainClamp = 1.0 - 1e-15;       // sphere_utils_torch.py:53,78
 
 __host__ __device__ inline int chain_offset(int D, int k) { return k * D - k * (k - 1) / 2; }      // sum_{j<k} (D - j)
 
-static __device__ __forceinline__ double wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+static __device__ __forceinline__ double wave_sum(double v) { return wave_allsum(v); }      // DPP row operations + two v_readlane (gabo_device.hpp)
 
 // frames of the L levels from their axes: one wave per level
 __global__ __launch_bounds__(64) void nested_sphere_frames_kernel(const double* __restrict__ axes, double* __restrict__ frames, int D, int L) {
@@ -62,19 +59,28 @@ __global__ __launch_bounds__(64) void nested_sphere_reconstruction_kernel(const 
     const int total_in = L * lat + L * (L - 1) / 2;           // sum_{k=0}^{L-1} (D - k - 1)
     double* cur = xin + total_in;                             // D
     double* g = cur + D;                                      // D
+    double* srt = g + D;                                      // L : sin r_k, then L : cos r_k (one level per lane, once)
+    double* crt = srt + L;
+    double* fr = crt + L;                                     // the frames: every level reads its e from LDS, not from L2 (48 dependent round trips)
     const int p = blockIdx.x / N, n = blockIdx.x - p * N;
     const int lane = threadIdx.x;
-    const double* stv = frames + chain_offset(D, L);
+    const int nframes = chain_offset(D, L) + 2 * L;
+    for (int i = lane; i < nframes; i += 64) fr[i] = frames[i];
+    const double* stv = fr + chain_offset(D, L);
     const bool want_grad = grad != nullptr;
     for (int i = lane; i < lat; i += 64) cur[i] = z[(size_t)n * lat + i];
+    for (int k = lane; k < L; k += 64) {
+        const double r = dists[(size_t)p * L + k];
+        srt[k] = sin(r);
+        crt[k] = cos(r);
+    }
     __syncthreads();
     int in_off = 0;
     for (int k = L - 1; k >= 0; --k) {                        // level k: S^(d-2) -> S^(d-1), d = D - k
         const int d = D - k;
-        const double* e = frames + chain_offset(D, k);
+        const double* e = fr + chain_offset(D, k);
         const double s = stv[2 * k], t = stv[2 * k + 1];
-        const double r = dists[(size_t)p * L + k];
-        const double sr = sin(r), cr = cos(r);
+        const double sr = srt[k], cr = crt[k];
         double dot = 0.0;
         for (int i = lane; i < d - 1; i += 64) {
             const double xi = cur[i];
@@ -107,10 +113,9 @@ __global__ __launch_bounds__(64) void nested_sphere_reconstruction_kernel(const 
         for (int k = 0; k < L; ++k) {                         // back through the levels, last applied first
             const int d = D - k;
             in_off -= d - 1;
-            const double* e = frames + chain_offset(D, k);
+            const double* e = fr + chain_offset(D, k);
             const double s = stv[2 * k], t = stv[2 * k + 1];
-            const double r = dists[(size_t)p * L + k];
-            const double sr = sin(r), cr = cos(r);
+            const double sr = srt[k], cr = crt[k];
             double ge = 0.0;
             for (int i = lane; i < d; i += 64) ge = __builtin_fma(g[i], e[i], ge);
             ge = wave_sum(ge);                                 // g_ce
@@ -154,11 +159,13 @@ __global__ __launch_bounds__(64) void nested_sphere_reconstruction_kernel(const 
 // (the mode-0 epilogue of nested_sphere.hip behind the rank-2 rotation).  store != NULL keeps the level inputs (n x sum_k d_k, packed
 // like the axes) for the backward pass.
 struct ChainLevel {
-    double a_, b, cy, ce, tc, theta, st, sr, A;
+    double a_, b, cy, ce, tc, st, sr, A;
     bool inside;
 };
 
-static __device__ __forceinline__ ChainLevel chain_level_forward(const double* p, const double* e, double s, double t, double r, int d, int lane) {
+// (sin theta of theta = acos(tc) is sqrt(1 - tc^2): no inverse trigonometric function on the 48-level critical path; sr = sin r_k is the
+// same for every point and comes from a table the wave fills once, one level per lane)
+static __device__ __forceinline__ ChainLevel chain_level_forward(const double* p, const double* e, double s, double t, double sr, int d, int lane) {
     ChainLevel lv;
     double dot = 0.0;
     for (int i = lane; i < d; i += 64) dot = __builtin_fma(p[i], e[i], dot);
@@ -169,9 +176,8 @@ static __device__ __forceinline__ ChainLevel chain_level_forward(const double* p
     const double tl = lv.a_ + lv.cy + lv.ce * e[d - 1];
     lv.inside = tl < kChainClamp && tl > -kChainClamp;
     lv.tc = tl > kChainClamp ? kChainClamp : (tl < -kChainClamp ? -kChainClamp : tl);
-    lv.theta = acos(lv.tc);
-    lv.st = sin(lv.theta);
-    lv.sr = sin(r);
+    lv.st = __builtin_sqrt((1.0 - lv.tc) * (1.0 + lv.tc));
+    lv.sr = sr;
     lv.A = lv.sr / ((lv.st + kChainEps) * (lv.sr + kChainEps));
     return lv;
 }
@@ -181,16 +187,21 @@ __global__ __launch_bounds__(64) void nested_sphere_project_kernel(const double*
                                                                   double* __restrict__ store, int D, int L) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* cur = lds;                // D
+    double* srt = cur + D;            // L : sin r_k
+    // (the frames are read from L2 here: staging their 10 KB in LDS per block pays for the few blocks of a reconstruction launch, not for
+    // thousands of points - measured 74 -> 98 us for 4096 points at D = 51)
+    const double* fr = frames;
     const int n = blockIdx.x, lane = threadIdx.x;
-    const double* stv = frames + chain_offset(D, L);
     const int total = chain_offset(D, L);
+    const double* stv = fr + total;
     for (int i = lane; i < D; i += 64) cur[i] = x[(size_t)n * D + i];
+    for (int k = lane; k < L; k += 64) srt[k] = sin(dists[k]);
     __syncthreads();
     for (int k = 0; k < L; ++k) {
         const int d = D - k;
-        const double* e = frames + chain_offset(D, k);
+        const double* e = fr + chain_offset(D, k);
         if (store) for (int i = lane; i < d; i += 64) store[(size_t)n * total + chain_offset(D, k) + i] = cur[i];
-        const ChainLevel lv = chain_level_forward(cur, e, stv[2 * k], stv[2 * k + 1], dists[k], d, lane);
+        const ChainLevel lv = chain_level_forward(cur, e, stv[2 * k], stv[2 * k + 1], srt[k], d, lane);
         double nn = 0.0;
         __syncthreads();
         for (int i = lane; i < d - 1; i += 64) {
@@ -213,17 +224,20 @@ __global__ __launch_bounds__(64) void nested_sphere_lift_kernel(const double* __
                                                                double* __restrict__ levels_out, int D, int L) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* cur = lds;                // D
+    double* srt = cur + D;            // L, L : sin r_k, cos r_k
+    double* crt = srt + L;
+    const double* fr = frames;
     const int n = blockIdx.x, lane = threadIdx.x, lat = D - L;
     const int total = chain_offset(D, L);
-    const double* stv = frames + total;
+    const double* stv = fr + total;
     for (int i = lane; i < lat; i += 64) cur[i] = z[(size_t)n * lat + i];
+    for (int k = lane; k < L; k += 64) { srt[k] = sin(dists[k]); crt[k] = cos(dists[k]); }
     __syncthreads();
     for (int k = L - 1; k >= 0; --k) {
         const int d = D - k;
-        const double* e = frames + chain_offset(D, k);
+        const double* e = fr + chain_offset(D, k);
         const double s = stv[2 * k], t = stv[2 * k + 1];
-        const double r = dists[k];
-        const double sr = sin(r), cr = cos(r);
+        const double sr = srt[k], cr = crt[k];
         double dot = 0.0;
         for (int i = lane; i < d - 1; i += 64) dot = __builtin_fma(cur[i], e[i], dot);
         dot = wave_sum(dot);
@@ -246,18 +260,22 @@ __global__ __launch_bounds__(64) void nested_sphere_project_backward_kernel(cons
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* G = lds;                  // D : gradient with respect to the current level's output, then input
     double* U = G + D;                // D
+    double* srt = U + D;              // L : sin r_k
+    double* fr = srt + L;             // the frames
     const int n = blockIdx.x, lane = threadIdx.x;
     const int total = chain_offset(D, L);
-    const double* stv = frames + total;
+    for (int i = lane; i < total + 2 * L; i += 64) fr[i] = frames[i];
+    const double* stv = fr + total;
     double* out = partial + (size_t)n * (total + 2 * L);
     for (int i = lane; i < D - L; i += 64) G[i] = gz[(size_t)n * (D - L) + i];
+    for (int k = lane; k < L; k += 64) srt[k] = sin(dists[k]);
     __syncthreads();
     for (int k = L - 1; k >= 0; --k) {
         const int d = D - k;
-        const double* e = frames + chain_offset(D, k);
+        const double* e = fr + chain_offset(D, k);
         const double* p = store + (size_t)n * total + chain_offset(D, k);
         const double s = stv[2 * k], t = stv[2 * k + 1];
-        const ChainLevel lv = chain_level_forward(p, e, s, t, dists[k], d, lane);
+        const ChainLevel lv = chain_level_forward(p, e, s, t, srt[k], d, lane);
         // recompute U[0:d-1], w = A U, |w|
         double nn = 0.0, gw_dot = 0.0;
         for (int i = lane; i < d - 1; i += 64) {
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(64) void nested_sphere_project_backward_kernel(cons
         }
         gA = wave_sum(gA);
         gce = wave_sum(gce);
-        const double gu_last = lv.inside ? gA * lv.A * cos(lv.theta) / ((lv.st + kChainEps) * __builtin_sqrt((1.0 - lv.tc) * (1.0 + lv.tc))) : 0.0;
+        const double gu_last = lv.inside ? gA * lv.A * lv.tc / ((lv.st + kChainEps) * lv.st) : 0.0;      // cos theta = tc, dtheta/dt = -1 / sin theta
         gce += gu_last * e[d - 1];
         const double gcy = gu_last;
         const double gs = gcy * lv.b - gce * lv.a_, gt = gcy * lv.a_ + gce * lv.b;
@@ -366,6 +384,14 @@ __global__ __launch_bounds__(64) void sphere_gram_adjoint_kernel(const double* _
     }
 }
 
+// dynamic LDS of a chain kernel beyond the 64 KB default needs the attribute (D >~ 90)
+template <typename K>
+static bool chain_lds_ok(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return false;
+    return bytes <= 64 * 1024 ||
+           hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
 int fit_gram_adjoint_launch(const double* kb, const double* wm, double* gs, double* out, double* partial, int* counter, int64_t n, double half_os,
                             double theta, unsigned blocks, hipStream_t s);      // nested_spd_fit.hip
 
@@ -418,7 +444,8 @@ int gabo_nested_sphere_project(const double* x, const double* frames, const doub
     if (n < 0) return GABO_ERR_ARG;
     if (n == 0) return GABO_OK;
     if (!x || !frames || !distances || !z || n > 0x7fffffffLL) return GABO_ERR_ARG;
-    hipLaunchKernelGGL(gabo::nested_sphere_project_kernel, dim3((unsigned)n), dim3(64), (size_t)D * sizeof(double), (hipStream_t)stream, x, frames,
+    const size_t lds = (size_t)(D + levels) * sizeof(double);
+    hipLaunchKernelGGL(gabo::nested_sphere_project_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x, frames,
                        distances, z, levels_in, D, levels);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
@@ -429,7 +456,8 @@ int gabo_nested_sphere_lift(const double* x_subsphere, const double* frames, con
     if (n < 0) return GABO_ERR_ARG;
     if (n == 0) return GABO_OK;
     if (!x_subsphere || !frames || !distances || (!x && !levels_out) || n > 0x7fffffffLL) return GABO_ERR_ARG;
-    hipLaunchKernelGGL(gabo::nested_sphere_lift_kernel, dim3((unsigned)n), dim3(64), (size_t)D * sizeof(double), (hipStream_t)stream, x_subsphere,
+    const size_t lds = (size_t)(D + 2 * levels) * sizeof(double);
+    hipLaunchKernelGGL(gabo::nested_sphere_lift_kernel, dim3((unsigned)n), dim3(64), lds, (hipStream_t)stream, x_subsphere,
                        frames, distances, x, levels_out, D, levels);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
@@ -445,7 +473,7 @@ int gabo_nested_sphere_reconstruction(const double* x_data, const double* x_subs
                                       size_t workspace_bytes, gabo_stream_t stream) {
     if (D < 2 || levels < 1 || levels > D - 1) return GABO_ERR_DIM;
     const int lat = D - levels;
-    const size_t lds = ((size_t)levels * lat + (size_t)levels * (levels - 1) / 2 + 2 * (size_t)D) * sizeof(double);
+    const size_t lds = ((size_t)levels * lat + (size_t)levels * (levels - 1) / 2 + 2 * (size_t)D + 2 * (size_t)levels + ((size_t)gabo::chain_offset(D, levels) + 2 * (size_t)levels)) * sizeof(double);
     if (lds > 160 * 1024) return GABO_ERR_DIM;
     if (P < 0 || N < 0) return GABO_ERR_ARG;
     if (P == 0) return GABO_OK;
@@ -496,7 +524,10 @@ int gabo_nested_sphere_fit_evaluate(const double* x, const double* y, const doub
     std::memcpy(pinned + total, distances_host, sizeof(double) * levels);
     if (hipMemcpyAsync(d_axes, pinned, sizeof(double) * (total + levels), hipMemcpyHostToDevice, s) != hipSuccess) return GABO_ERR_LAUNCH;
     hipLaunchKernelGGL(gabo::nested_sphere_frames_kernel, dim3((unsigned)levels), dim3(64), 0, s, d_axes, at(lay.frames), D, levels);
-    hipLaunchKernelGGL(gabo::nested_sphere_project_kernel, dim3((unsigned)n), dim3(64), (size_t)D * sizeof(double), s, x, at(lay.frames), d_dists,
+    const size_t nfr = ((size_t)gabo::chain_offset(D, levels) + 2 * (size_t)levels);
+    const size_t lds_fwd = (size_t)(D + levels) * sizeof(double), lds_bwd = ((size_t)(2 * D + levels) + nfr) * sizeof(double);
+    if (!gabo::chain_lds_ok(gabo::nested_sphere_project_backward_kernel, lds_bwd)) return GABO_ERR_DIM;
+    hipLaunchKernelGGL(gabo::nested_sphere_project_kernel, dim3((unsigned)n), dim3(64), lds_fwd, s, x, at(lay.frames), d_dists,
                        at(lay.z), want_grad ? at(lay.store) : nullptr, D, levels);
     if (hipGetLastError() != hipSuccess) return GABO_ERR_LAUNCH;
     int rc = gabo_sphere_pairwise(at(lay.z), at(lay.z), at(lay.kb), 1, n, n, lat, 0, 0, beta, GABO_OUT_GAUSSIAN, 0, stream);
@@ -514,7 +545,7 @@ int gabo_nested_sphere_fit_evaluate(const double* x, const double* y, const doub
         if (rc != GABO_OK) return rc;
         hipLaunchKernelGGL(gabo::sphere_gram_adjoint_kernel, dim3((unsigned)n), dim3(64), (size_t)(65 * lat) * sizeof(double), s, at(lay.z), at(lay.gs),
                            at(lay.gz), (int)n, lat, beta);
-        hipLaunchKernelGGL(gabo::nested_sphere_project_backward_kernel, dim3((unsigned)n), dim3(64), (size_t)(2 * D) * sizeof(double), s, at(lay.store),
+        hipLaunchKernelGGL(gabo::nested_sphere_project_backward_kernel, dim3((unsigned)n), dim3(64), lds_bwd, s, at(lay.store),
                            at(lay.frames), d_dists, at(lay.gz), at(lay.partial), D, levels);
         hipLaunchKernelGGL(gabo::nested_sphere_axes_adjoint_kernel, dim3((unsigned)levels), dim3(64), (size_t)D * sizeof(double), s, d_axes, at(lay.frames),
                            at(lay.partial), d_out + 7, (int)n, D, levels);

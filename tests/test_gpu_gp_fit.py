@@ -242,6 +242,58 @@ def test_fused_nested_sphere_reconstruction_launch(golden, D, lat, N):
     assert c1 == costs[1] and np.array_equal(g1, grads[1])
 
 
+@pytest.mark.parametrize("D,lat,N", [(5, 3, 11), (21, 3, 16), (51, 3, 13), (101, 3, 4)])
+def test_nested_sphere_chain_against_the_oracle(D, lat, N):
+    """The all-levels launches against oracle/sphere.py (the numpy restatement of nested_spheres_utils.py with full rotation matrices, pinned on
+    the reference's goldens by tests/test_oracle_golden.py): every level of the projection and of the lift, the reconstruction cost, and the
+    nested kernel's Gram matrix through the surrogate objective's launch chain (its likelihood against oracle/gp.py)."""
+    from gabotorch_amd import ops
+    from gabotorch_amd.nested_mappings.nested_spheres_utils import projection_from_sphere_to_subsphere, projection_from_subsphere_to_sphere
+    from oracle import gp as ogp
+    from oracle import sphere as osph
+    rng = np.random.default_rng(7 * D)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV)   # noqa: E731
+    L = D - lat
+    axes_np = []
+    for k in range(L):
+        a = rng.standard_normal(D - k)
+        axes_np.append(a / np.linalg.norm(a))
+    r_np = rng.uniform(0.5, 2.5, L)
+    x = rng.standard_normal((N, D))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    axes, dists = [T(a) for a in axes_np], [torch.tensor([[v]], dtype=torch.float64) for v in r_np]
+    down = projection_from_sphere_to_subsphere(T(x), axes, dists)
+    want_down = osph.projection_from_sphere_to_subsphere(x, axes_np, r_np)
+    for a, b in zip(down, want_down):
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=1e-9, atol=1e-11)
+    z = want_down[-1]
+    up = projection_from_subsphere_to_sphere(T(z), axes, dists)
+    for a, b in zip(up, osph.projection_from_subsphere_to_sphere(z, axes_np, r_np)):
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=1e-9, atol=1e-11)
+    rec = ops.NestedSphereReconstruction(T(x), T(z), axes)
+    np.testing.assert_allclose(rec.evaluate(r_np, grad=False), osph.nested_sphere_reconstruction_cost(x, z, axes_np, r_np), rtol=1e-9)
+    # the fit objective's chain: log likelihood of the nested kernel's Gram matrix at these axes
+    import ctypes
+    from gabotorch_amd import _lib
+    lib = _lib.load()
+    y = rng.standard_normal(N)
+    beta, os_, noise, mean = 1.3, 0.8, 0.05, 0.1
+    packed = ops.pack_nested_sphere_axes(axes_np, D)
+    ws = torch.empty(lib.gabo_nested_sphere_fit_workspace_bytes(N, D, L), dtype=torch.uint8, device=DEV)
+    pinned = torch.empty(2 * packed.size + L + 7, dtype=torch.float64).pin_memory()
+    out = np.empty(7 + packed.size)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    xt, yt = T(x), T(y)
+    _lib.check(lib.gabo_nested_sphere_fit_evaluate(xt.data_ptr(), yt.data_ptr(), ptr(packed), ptr(np.ascontiguousarray(r_np)), N, D, L, beta, os_, noise,
+                                                   mean, 0, ptr(out), ws.data_ptr(), ws.numel(), pinned.data_ptr(), pinned.numel(), None), "fit_evaluate")
+    gram = osph.nested_sphere_gaussian_kernel(x, x, axes_np, r_np, beta)
+    ky = os_ * gram + noise * np.eye(N)
+    resid = y - mean
+    want_ll = -0.5 * resid @ np.linalg.solve(ky, resid) - 0.5 * np.linalg.slogdet(ky)[1] - 0.5 * N * np.log(2.0 * np.pi)
+    np.testing.assert_allclose(out[0], want_ll, rtol=1e-9)
+    assert out[5] == 0.0 and ogp is not None
+
+
 @pytest.mark.parametrize("D,lat,N", [(5, 3, 7), (21, 3, 40), (51, 2, 9)])
 def test_nested_sphere_projections_in_one_launch_match_the_level_by_level_path(D, lat, N):
     """projection_from_sphere_to_subsphere / projection_from_subsphere_to_sphere without an autograd graph (gabo_nested_sphere_project /
