@@ -244,6 +244,30 @@ class _NestedSphereMllProblem(_MllProblem):
         v = np.array([float(np.asarray(x[k]).reshape(-1)[0]) for k in self.scalar_idx])
         return self.scalar(v)
 
+    # the same objective on ONE flat vector (the factors' entries one after the other, PackedEuclideanSpheres): no list of ~50 arrays is
+    # taken apart and put together again around every evaluation
+    def flat_layout(self, bounds):
+        self._axes_pos = np.concatenate([np.arange(bounds[k], bounds[k + 1]) for k in self.axis_idx])
+        self._scalar_pos = np.array([bounds[k] for k in self.scalar_idx])
+
+    def _run_flat(self, v, want_grad):
+        self.axes_host = np.ascontiguousarray(v[self._axes_pos])
+        self.want_grad = want_grad
+        return self.scalar(v[self._scalar_pos])
+
+    def cost_flat(self, v):
+        self.n_evals += 1
+        loss, _ = self._run_flat(v, False)
+        return float("inf") if loss >= 1e10 else float(loss)
+
+    def egrad_flat(self, v):
+        loss, g = self._run_flat(v, True)
+        out = np.zeros(v.shape[0])
+        out[self._scalar_pos] = g
+        if loss < 1e10:
+            out[self._axes_pos] = -self.grad_axes / self.y.numel()
+        return out
+
     def cost(self, x):
         self.n_evals += 1
         loss, _ = self._run(x, False)
@@ -306,10 +330,12 @@ def fit_gpytorch_manifold(model, solver=None, nb_init_candidates=200, last_x_as_
         # one axis per nested level: the same product geometry on one flat vector (no Python loop over ~D factors per manifold operation)
         packed = PackedEuclideanSpheres(factors)
 
+        problem.flat_layout(packed._bounds)
+
         class _Packed:
             manifold = packed
-            cost = staticmethod(lambda v: problem.cost(packed.unpack(v)))
-            grad = staticmethod(lambda v: packed.egrad2rgrad(v, packed.pack(problem.egrad(packed.unpack(v)))))
+            cost = staticmethod(problem.cost_flat)
+            grad = staticmethod(lambda v: packed.egrad2rgrad(v, problem.egrad_flat(v)))
         opt_v, log = solver.solve(_Packed, x=packed.pack(x_init))
         opt_x = [np.array(a) for a in packed.unpack(opt_v)]
     else:

@@ -362,6 +362,14 @@ def test_nested_sphere_fit_objective_in_one_host_call_matches_autograd(D, lat, n
         for a, b, (nm, p) in zip(g_fast, g_slow, named):
             tol = 2e-5 if id(p) in axis_ids else 1e-7
             np.testing.assert_allclose(np.ravel(a), np.ravel(b), rtol=tol, atol=tol * max(1e-3, float(np.abs(b).max())), err_msg=nm)
+        # the flat-vector form the fit actually drives (PackedEuclideanSpheres): same numbers, no lists
+        from gabotorch_amd.manifold_optimization.host_manifolds import PackedEuclideanSpheres
+        packed = PackedEuclideanSpheres(factors)
+        fast.flat_layout(packed._bounds)
+        fast._recent = []
+        v = packed.pack(pt)
+        assert fast.cost_flat(v) == c_fast
+        np.testing.assert_array_equal(fast.egrad_flat(v), packed.pack(g_fast))
 
 
 def test_nested_spd_eigenvalue_constraints_golden(golden):
