@@ -31,7 +31,7 @@ def optimize_reconstruction_parameters_nested_sphere(x_data, x_subsphere, sphere
     manifold = Euclidean(n_levels)
 
     def sigmoid(x):
-        return 1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64).reshape(-1)))
+        return 0.5 * (1.0 + np.tanh(0.5 * np.asarray(x, dtype=np.float64).reshape(-1)))      # = 1 / (1 + exp(-x)), without the overflow of exp far out
 
     recent = []                        # (key, value, gradient): a line search asks for the value, the solver then for the gradient there
 
