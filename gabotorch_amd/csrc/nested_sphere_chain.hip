@@ -176,9 +176,9 @@ static __device__ __forceinline__ ChainLevel chain_level_forward(const double* p
     const double tl = lv.a_ + lv.cy + lv.ce * e[d - 1];
     lv.inside = tl < kChainClamp && tl > -kChainClamp;
     lv.tc = tl > kChainClamp ? kChainClamp : (tl < -kChainClamp ? -kChainClamp : tl);
-    lv.st = __builtin_sqrt((1.0 - lv.tc) * (1.0 + lv.tc));
+    lv.st = sqrt_nz((1.0 - lv.tc) * (1.0 + lv.tc));             // (> 0 inside the clamp; seed + Goldschmidt: ~1 ulp, a third of the IEEE sequence)
     lv.sr = sr;
-    lv.A = lv.sr / ((lv.st + kChainEps) * (lv.sr + kChainEps));
+    lv.A = lv.sr * rcp((lv.st + kChainEps) * (lv.sr + kChainEps));
     return lv;
 }
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void nested_sphere_project_kernel(const double*
             cur[i] = w;
             nn = __builtin_fma(w, w, nn);
         }
-        const double inv = 1.0 / (__builtin_sqrt(wave_sum(nn)) + kChainEps);
+        const double inv = rcp(sqrt_pos(wave_sum(nn)) + kChainEps);
         for (int i = lane; i < d - 1; i += 64) cur[i] *= inv;
         __syncthreads();
     }
@@ -287,13 +287,13 @@ __global__ __launch_bounds__(64) void nested_sphere_project_backward_kernel(cons
         }
         nn = wave_sum(nn);
         gw_dot = wave_sum(gw_dot);
-        const double nrm = __builtin_sqrt(nn), den = nrm + kChainEps;
-        const double coef = nrm > 0.0 ? gw_dot / (nrm * den * den) : 0.0;
+        const double nrm = sqrt_pos(nn), den = nrm + kChainEps, iden = rcp(den);
+        const double coef = nrm > 0.0 ? gw_dot * rcp(nrm * den * den) : 0.0;
         // z = w / den:  g_w = g_z / den - (g_z . w) w / (|w| den^2);  g_U = A g_w;  g_A = sum g_w U
         double gA = 0.0, gce = 0.0;
         __syncthreads();
         for (int i = lane; i < d - 1; i += 64) {
-            const double gw = G[i] / den - coef * (lv.A * U[i]);
+            const double gw = G[i] * iden - coef * (lv.A * U[i]);
             gA = __builtin_fma(gw, U[i], gA);
             const double gu = lv.A * gw;
             G[i] = gu;                                        // g_U
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void nested_sphere_project_backward_kernel(cons
         }
         gA = wave_sum(gA);
         gce = wave_sum(gce);
-        const double gu_last = lv.inside ? gA * lv.A * lv.tc / ((lv.st + kChainEps) * lv.st) : 0.0;      // cos theta = tc, dtheta/dt = -1 / sin theta
+        const double gu_last = lv.inside ? gA * lv.A * lv.tc * rcp((lv.st + kChainEps) * lv.st) : 0.0;      // cos theta = tc, dtheta/dt = -1 / sin theta
         gce += gu_last * e[d - 1];
         const double gcy = gu_last;
         const double gs = gcy * lv.b - gce * lv.a_, gt = gcy * lv.a_ + gce * lv.b;
