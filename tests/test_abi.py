@@ -84,3 +84,41 @@ def test_workspace_covers_both_layouts_between_the_register_limits():
         assert lib.gabo_spd_ai_workspace_bytes(1, 3, 50, d) == max((3 + 50) * t, 2 * 3 * d * d) * 8
         assert lib.gabo_spd_ai_workspace_bytes(1, 50, 3, d) == max((3 + 50) * t, 2 * 50 * d * d) * 8
     assert lib.gabo_spd_ai_workspace_bytes(1, 3, 50, 21) == 2 * 3 * 21 * 21 * 8
+
+
+def test_round3_host_loops_and_nested_sphere_entries_validate_on_the_host():
+    """The entry points added for the HD-GaBO loops: argument validation and workspace sizes need no GPU."""
+    import ctypes
+    lib = _lib.load()
+    # nested-sphere chain
+    assert lib.gabo_nested_sphere_frames(None, None, 1, 1, None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_nested_sphere_frames(None, None, 5, 5, None) == _lib.GABO_ERR_DIM            # levels <= D - 1
+    assert lib.gabo_nested_sphere_frames(None, None, 5, 2, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_nested_sphere_project(None, None, None, None, None, 0, 5, 2, None) == _lib.GABO_OK
+    assert lib.gabo_nested_sphere_project(None, None, None, None, None, 3, 5, 2, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_nested_sphere_lift(None, None, None, None, None, 3, 5, 0, None) == _lib.GABO_ERR_DIM
+    w1 = lib.gabo_nested_sphere_reconstruction_workspace_bytes(1, 10, 21, 18)
+    assert 0 < w1 < lib.gabo_nested_sphere_reconstruction_workspace_bytes(3, 10, 21, 18) and w1 >= 16 + 10 * 19 * 8
+    assert lib.gabo_nested_sphere_reconstruction(None, None, None, None, None, None, 0, 4, 21, 18, None, 0, None) == _lib.GABO_OK
+    assert lib.gabo_nested_sphere_reconstruction(None, None, None, None, None, None, 1, 4, 21, 18, None, 0, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_nested_sphere_reconstruction(None, None, None, None, None, None, 1, 4, 300, 298, None, 0, None) == _lib.GABO_ERR_DIM   # LDS
+    assert lib.gabo_nested_sphere_fit_workspace_bytes(12, 51, 48) > 12 * (51 * 48 - 48 * 47 // 2) * 8
+    assert lib.gabo_nested_sphere_fit_evaluate(None, None, None, None, 12, 51, 48, 1.0, 1.0, 0.1, 0.0, 1, None, None, 0, None, 0, None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_nested_sphere_fit_evaluate(None, None, None, None, 12, 80, 10, 1.0, 1.0, 0.1, 0.0, 1, None, None, 0, None, 0, None) == _lib.GABO_ERR_DIM  # latent > 64
+    # nested-SPD fit evaluation and the native reconstruction loop
+    assert lib.gabo_nested_spd_fit_workspace_bytes(12, 20, 2) > 3 * 12 * 12 * 8
+    assert lib.gabo_nested_spd_fit_evaluate(None, None, None, None, 12, 40, 2, 1.0, 1.0, 0.1, 0.0, 1, None, None, 0, None, 0, None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_nested_spd_fit_evaluate(None, None, None, None, 12, 20, 2, 1.0, 1.0, 0.1, 0.0, 1, None, None, 0, None, 0, None) == _lib.GABO_ERR_ARG
+    dev, pin = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    lib.gabo_nested_spd_reconstruction_solve_workspace_bytes(10, 20, 2, ctypes.byref(dev), ctypes.byref(pin))
+    npar = 20 * 18 + 18 * 18 + 2 * 18
+    assert pin.value == _lib.GABO_RECON_MAX_LOOKAHEAD * (2 * npar + 1 + 18 + 18 * 18) and dev.value > pin.value * 8
+    opts = _lib.ReconSolveOptions(bound=20, rho_init=1, thetarho=0.3, tau=0.8, starting_tolgradnorm=1e-3, ending_tolgradnorm=1e-6, gammas_fact=1.0,
+                                  minstepsize=1e-10, maxtime=10, maxiter=2, cg_minstepsize=1e-10, cg_maxtime=10, cg_orth_value=1e300, cg_maxiter=3)
+    log = _lib.ReconSolveLog()
+    assert lib.gabo_nested_spd_reconstruction_solve(None, None, None, None, None, None, None, None, None, 4, 40, 2, 1, None, 0, None, 0,
+                                                    ctypes.byref(opts), ctypes.byref(log), None) == _lib.GABO_ERR_DIM
+    assert lib.gabo_nested_spd_reconstruction_solve(None, None, None, None, None, None, None, None, None, 4, 20, 2, 1, None, 0, None, 0,
+                                                    ctypes.byref(opts), ctypes.byref(log), None) == _lib.GABO_ERR_ARG
+    assert lib.gabo_nested_spd_reconstruction(None, None, None, None, None, None, None, None, None, None, None, None, None, 0, 4, 20, 2, 1, None, 0,
+                                              None) == _lib.GABO_OK
