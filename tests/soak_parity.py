@@ -99,6 +99,40 @@ def main():
         Y = torch.tensor(rand_spd(rng, (5,), d), device=dev)
         U = ops.spd_manifold_op(_lib.GABO_SPD_LOG, M, Y)
         note("exp_log_map_roundtrip", (ops.spd_manifold_op(_lib.GABO_SPD_EXP, M, U) - Y).abs().max() / Y.abs().max())
+        # nested-sphere chain: every level of the projection and of the lift, reconstruction cost, its gradient by finite differences,
+        # and the nested SPD reconstruction cost
+        if case % 3 == 0:
+            from gabotorch_amd.nested_mappings.nested_spheres_utils import projection_from_sphere_to_subsphere, projection_from_subsphere_to_sphere
+            Dn = int(rng.integers(3, 90))
+            lat = int(rng.integers(2, min(Dn, 8)))
+            L = Dn - lat
+            npts = int(rng.integers(1, 40))
+            axes_np = []
+            for k in range(L):
+                ax = rng.standard_normal(Dn - k)
+                axes_np.append(ax / np.linalg.norm(ax))
+            r_np = rng.uniform(0.4, 2.7, L)
+            xs = rng.standard_normal((npts, Dn))
+            xs /= np.linalg.norm(xs, axis=1, keepdims=True)
+            axes_t = [torch.tensor(ax, device=dev) for ax in axes_np]
+            dists_t = [torch.tensor([[v]], dtype=torch.float64) for v in r_np]
+            down = projection_from_sphere_to_subsphere(torch.tensor(xs, device=dev), axes_t, dists_t)
+            want_down = osph.projection_from_sphere_to_subsphere(xs, axes_np, r_np)
+            note("nested_sphere_project", max(np.max(np.abs(g_.cpu().numpy() - w_)) for g_, w_ in zip(down, want_down)))
+            zs = want_down[-1]
+            up = projection_from_subsphere_to_sphere(torch.tensor(zs, device=dev), axes_t, dists_t)
+            note("nested_sphere_lift", max(np.max(np.abs(g_.cpu().numpy() - w_)) for g_, w_ in zip(up, osph.projection_from_subsphere_to_sphere(zs, axes_np, r_np))))
+            rec = ops.NestedSphereReconstruction(torch.tensor(xs, device=dev), torch.tensor(zs, device=dev), axes_t)
+            c0, g0 = rec.evaluate(r_np)
+            want_c = osph.nested_sphere_reconstruction_cost(xs, zs, axes_np, r_np)
+            note("nested_sphere_recon_cost", abs(c0 - want_c) / max(1.0, abs(want_c)))
+            kk = int(rng.integers(0, L))
+            hh = 1e-6
+            rp, rm = r_np.copy(), r_np.copy()
+            rp[kk] += hh
+            rm[kk] -= hh
+            fdv = (osph.nested_sphere_reconstruction_cost(xs, zs, axes_np, rp) - osph.nested_sphere_reconstruction_cost(xs, zs, axes_np, rm)) / (2 * hh)
+            note("nested_sphere_recon_fd", abs(g0[kk] - fdv) / max(1.0, abs(fdv)))
     for k in sorted(worst):
         print(f"{k:28s} worst {worst[k]:.2e}")
     bad = {k: v for k, v in worst.items() if v > (1e-5 if "fd" in k else (1e-7 if "gp_mll" in k else 1e-9))}
