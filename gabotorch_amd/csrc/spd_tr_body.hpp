@@ -48,6 +48,9 @@ struct BuiltinCons {
 };
 
 static __host__ __device__ inline bool builtin_has_kind(const BuiltinCons& B, bool nested) {
+#ifdef GABO_TR_NO_NESTED    /* A/B: the solve kernels without the nested kinds (their eigen-solver of order 24 sets the register budget) */
+    if (nested) return false;
+#endif
     for (int k = 0; k < B.n; ++k)
         if ((B.kind[k] >= 2) == nested) return true;
     return false;
