@@ -55,13 +55,13 @@ class ReconSolveOptions(_c.Structure):
     """gabo_recon_solve_options of include/gabo_hip.h"""
     _fields_ = [(k, _c.c_double) for k in ("bound", "rho_init", "thetarho", "tau", "starting_tolgradnorm", "ending_tolgradnorm", "gammas_fact",
                                           "minstepsize", "maxtime")] + [("maxiter", _c.c_int64)] + \
-               [(k, _c.c_double) for k in ("cg_minstepsize", "cg_maxtime", "cg_orth_value")] + [("cg_maxiter", _c.c_int64), ("lookahead", _c.c_int64)]
+               [(k, _c.c_double) for k in ("cg_minstepsize", "cg_maxtime", "cg_orth_value")] + [("cg_maxiter", _c.c_int64), ("lookahead", _c.c_int64), ("host_threads", _c.c_int64)]
 
 
 class ReconSolveLog(_c.Structure):
     """gabo_recon_solve_log of include/gabo_hip.h"""
     _fields_ = [(k, _c.c_int64) for k in ("outer_iterations", "inner_iterations", "evaluations", "launches")] + [("stop_reason", _c.c_int)] + \
-               [(k, _c.c_double) for k in ("violation", "rho", "gamma", "final_cost", "seconds", "seconds_evaluator")]
+               [(k, _c.c_double) for k in ("violation", "rho", "gamma", "final_cost", "seconds", "seconds_evaluator")] + [("host_threads", _c.c_int64)]
 
 
 # gabo_recon_eval_fn: int (void* ctx, int64 P, const double* v, c, k, double* cost, grad_v, grad_c, grad_k)

@@ -17,12 +17,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../include/gabo_hip.h"
@@ -236,7 +239,68 @@ struct Point {
     double g = 0.0;             // constraint ||V^T W||_F
     vec cinv;                   // C^-1, made when the first inner product at this point asks for it
     bool has_cinv = false;
-    explicit Point(const Dims& dm) : x(dm.n), egrad(dm.n), cinv(dm.nC) {}
+    vec c_lam, c_vec;           // eigenvalues / eigenvectors (in the columns) of sym(C), for evaluators that take them along (the HIP launch)
+    bool has_factors = false;
+    explicit Point(const Dims& dm) : x(dm.n), egrad(dm.n), cinv(dm.nC), c_lam(dm.m), c_vec(dm.nC) {}
+};
+
+// Scratch of one line-search candidate: the candidates of a launch are retracted (and their C factored) side by side on the pool's threads.
+struct StepScratch {
+    vec a, m0, m1, m2, w, e;
+    int error = GABO_OK;
+    explicit StepScratch(const Dims& dm) : a(dm.nV), m0(dm.nC), m1(dm.nC), m2(dm.nC), w(dm.m), e(3 * dm.m) {}
+};
+
+// A handful of worker threads that spin between the launches of ONE optimisation (tens of milliseconds): task 0 runs on the caller,
+// tasks 1.. on the workers; every worker answers every run (no straggler can meet the next run's job).
+class StepPool {
+    std::vector<std::thread> workers;
+    std::atomic<unsigned> generation{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> stop{false};
+    const std::function<void(int)>* job = nullptr;
+    int ntasks = 0;
+
+    static void relax() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        __builtin_ia32_pause();
+#endif
+    }
+
+ public:
+    explicit StepPool(int nworkers) {
+        for (int w = 0; w < nworkers; ++w)
+            workers.emplace_back([this, w] {
+                unsigned seen = 0;
+                while (true) {
+                    while (generation.load(std::memory_order_acquire) == seen) {
+                        if (stop.load(std::memory_order_relaxed)) return;
+                        relax();
+                    }
+                    seen += 1;
+                    if (w + 1 < ntasks) (*job)(w + 1);
+                    pending.fetch_sub(1, std::memory_order_release);
+                }
+            });
+    }
+    int threads() const { return (int)workers.size() + 1; }
+    void run(int n, const std::function<void(int)>& f) {
+        if (workers.empty() || n <= 1) {
+            for (int i = 0; i < n; ++i) f(i);
+            return;
+        }
+        job = &f;
+        ntasks = n;
+        pending.store((int)workers.size(), std::memory_order_relaxed);
+        generation.fetch_add(1, std::memory_order_release);
+        f(0);
+        for (int i = (int)workers.size() + 1; i < n; ++i) f(i);          // (more tasks than threads: the rest here)
+        while (pending.load(std::memory_order_acquire) > 0) relax();
+    }
+    ~StepPool() {
+        stop.store(true);
+        for (auto& t : workers) t.join();
+    }
 };
 
 struct Driver {
@@ -253,12 +317,29 @@ struct Driver {
     double seconds_evaluator = 0.0;
     int error = GABO_OK;
     vec t0, t1, t2, t3, t4, ew, ee;                    // scratch
+    bool stage_factors = false;                        // the evaluator takes the eigen-decomposition of every C behind the parameter sets
+    std::vector<StepScratch> steps_scratch;
+    StepPool* pool = nullptr;
 
     Driver(int D, int d, const double* w, gabo_recon_eval_fn fn, void* c, double* in, double* out, const gabo_recon_solve_options& o)
         : dm(D, d), W(w), eval(fn), ctx(c), stage_in(in), stage_out(out), opt(o) {
         const int big = std::max(dm.nV, dm.nC) + dm.D * dm.D;
         t0.resize(big); t1.resize(big); t2.resize(big); t3.resize(big); t4.resize(big);
         ew.resize(dm.D); ee.resize(3 * dm.D);
+        for (int i = 0; i < kMaxLookahead; ++i) steps_scratch.emplace_back(dm);
+    }
+
+    // eigen-decomposition of sym(C) of a point (vectors in the columns), with the scratch of one candidate slot
+    bool factor_point(Point& pt, StepScratch& sc) {
+        const int m = dm.m;
+        const double* cp = pt.x.data() + dm.oC;
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) sc.m0[i * m + j] = 0.5 * (cp[i * m + j] + cp[j * m + i]);
+        if (!sym_eig(m, sc.m0.data(), pt.c_lam.data(), sc.m1.data(), sc.e.data())) return false;
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) pt.c_vec[i * m + j] = sc.m1[j * m + i];
+        pt.has_factors = true;
+        return true;
     }
 
     // ---------------------------------------------------------------------------------------------- the evaluator
@@ -273,6 +354,11 @@ struct Driver {
             std::memcpy(stage_in + (size_t)P * dm.nV + (size_t)p * dm.nC, x + dm.oC, sizeof(double) * dm.nC);
             double* k = stage_in + (size_t)P * (dm.nV + dm.nC) + (size_t)p * dm.nU;
             for (int i = 0; i < dm.nU; ++i) k[i] = ts[p] * x[dm.oU + i];
+            if (stage_factors) {
+                if (!pts[p]->has_factors && !factor_point(*pts[p], steps_scratch[0]) && error == GABO_OK) error = GABO_ERR_NOT_SPD;
+                std::memcpy(stage_in + (size_t)P * npar + (size_t)p * dm.m, pts[p]->c_lam.data(), sizeof(double) * dm.m);
+                std::memcpy(stage_in + (size_t)P * (npar + dm.m) + (size_t)p * dm.nC, pts[p]->c_vec.data(), sizeof(double) * dm.nC);
+            }
         }
         double* cost = stage_out;
         double* gv = stage_out + P;
@@ -282,7 +368,6 @@ struct Driver {
         const int rc = eval(ctx, P, stage_in, stage_in + (size_t)P * dm.nV, stage_in + (size_t)P * (dm.nV + dm.nC), cost, gv, gc, gk);
         seconds_evaluator += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_eval).count();
         if (rc != GABO_OK && error == GABO_OK) error = rc;
-        (void)npar;
         launches += 1;
         evaluations += P;
         for (int p = 0; p < P; ++p) {
@@ -397,50 +482,55 @@ struct Driver {
             mmt(L, Q, LQ, m, m, m);                             // LQ[i][k] = sum_j L[i][j] Q[k][j] = (L Qcols)[i][k]
         }
         if (!ok && error == GABO_OK) error = GABO_ERR_NOT_SPD;
-        for (int s = 0; s < nsteps; ++s) {
-            double* C2 = outs[s]->x.data() + dm.oC;
+        // every step length: its SPD point, its Grassmann point (polar factor: A (A^T A)^-1/2), sphere / Euclidean factors and - for the
+        // evaluators that take it - the eigen-decomposition of the new C; independent of each other: one task each on the pool's threads
+        const double* LQc = LQ;
+        const double* ews = ew.data();
+        const std::function<void(int)> task = [&, LQc, ews, ok](int s) {
+            StepScratch& sc = steps_scratch[s];
+            Point& out = *outs[s];
+            double* y = out.x.data();
+            double* C2 = y + dm.oC;
             if (!ok) {
                 for (int i = 0; i < m * m; ++i) C2[i] = std::numeric_limits<double>::quiet_NaN();
-                continue;
+            } else {
+                double* scaled = sc.m0.data();                   // LQ diag(exp(t w))
+                for (int i = 0; i < m; ++i)
+                    for (int k = 0; k < m; ++k) scaled[i * m + k] = LQc[i * m + k] * std::exp(steps[s] * ews[k]);
+                mmt(scaled, LQc, C2, m, m, m);
+                symmetrize(C2, m);
             }
-            double* sc = S;                                     // LQ diag(exp(t w))
-            for (int i = 0; i < m; ++i)
-                for (int k = 0; k < m; ++k) sc[i * m + k] = LQ[i * m + k] * std::exp(steps[s] * ew[k]);
-            mmt(sc, LQ, C2, m, m, m);
-            symmetrize(C2, m);
-        }
-        // Grassmann factor: A (A^T A)^-1/2
-        for (int s = 0; s < nsteps; ++s) {
-            double* A = t0.data();
+            double* A = sc.a.data();
             for (int i = 0; i < dm.nV; ++i) A[i] = x[i] + steps[s] * u[i];
-            double* M = t1.data();
+            double* M = sc.m0.data();
             mtm(A, A, M, D, m, m);
             symmetrize(M, m);
-            double* Qm = t2.data();
-            const bool conv = sym_eig(m, M, ew.data(), Qm, ee.data());
-            if (!conv && error == GABO_OK) error = GABO_ERR_NOT_SPD;
-            double* R = t3.data();                              // (A^T A)^-1/2 = sum_k w_k^-1/2 q_k q_k^T
+            double* Qm = sc.m1.data();
+            if (!sym_eig(m, M, sc.w.data(), Qm, sc.e.data())) sc.error = GABO_ERR_NOT_SPD;
+            double* R = sc.m2.data();                            // (A^T A)^-1/2 = sum_k w_k^-1/2 q_k q_k^T
             for (int i = 0; i < m * m; ++i) R[i] = 0.0;
             for (int k = 0; k < m; ++k) {
-                const double f = 1.0 / std::sqrt(ew[k]);
+                const double f = 1.0 / std::sqrt(sc.w[k]);
                 const double* qk = Qm + (size_t)k * m;
                 for (int i = 0; i < m; ++i) {
                     const double fi = f * qk[i];
                     for (int j = 0; j < m; ++j) R[i * m + j] += fi * qk[j];
                 }
             }
-            mm(A, R, outs[s]->x.data(), D, m, m);
-        }
-        // sphere and Euclidean factors
-        for (int s = 0; s < nsteps; ++s) {
-            double* y = outs[s]->x.data();
+            mm(A, R, y, D, m, m);
             double nn = 0.0;
             for (int i = 0; i < dm.nU; ++i) { y[dm.oU + i] = x[dm.oU + i] + steps[s] * u[dm.oU + i]; nn += y[dm.oU + i] * y[dm.oU + i]; }
             nn = std::sqrt(nn);
             for (int i = 0; i < dm.nU; ++i) y[dm.oU + i] /= nn;
             y[dm.oS] = x[dm.oS] + steps[s] * u[dm.oS];
-            outs[s]->has_cinv = false;
-        }
+            out.has_cinv = false;
+            out.has_factors = false;
+            if (stage_factors && ok && !factor_point(out, sc)) sc.error = GABO_ERR_NOT_SPD;
+        };
+        if (pool) pool->run(nsteps, task);
+        else for (int s = 0; s < nsteps; ++s) task(s);
+        for (int s = 0; s < nsteps; ++s)
+            if (steps_scratch[s].error != GABO_OK && error == GABO_OK) error = steps_scratch[s].error;
     }
 
     // geodesic distance on the product (the augmented Lagrangian's step length between outer iterations, :199)
@@ -579,7 +669,9 @@ struct Driver {
                 std::swap(cur.x, cand->x);
                 std::swap(cur.egrad, cand->egrad);
                 std::swap(cur.cinv, cand->cinv);
-                cur.f = cand->f; cur.g = cand->g; cur.has_cinv = cand->has_cinv;
+                std::swap(cur.c_lam, cand->c_lam);
+                std::swap(cur.c_vec, cand->c_vec);
+                cur.f = cand->f; cur.g = cand->g; cur.has_cinv = cand->has_cinv; cur.has_factors = cand->has_factors;
             }
             cost = newf;
             grad.swap(newgrad);
@@ -656,6 +748,7 @@ struct HipEvaluator {
     void* recon_ws;
     size_t recon_ws_bytes;
     hipStream_t stream;
+    bool factors_staged = false;          // the driver put the eigen-decomposition of every C behind the parameter sets already
     vec a, q, lam, e;
     double t_factor = 0.0, t_enqueue = 0.0, t_wait = 0.0;     // where an evaluation's wall-clock goes (reported with GABO_RECON_TIMING set)
 };
@@ -669,7 +762,7 @@ static int hip_evaluate(void* ctx, int64_t P, const double* v, const double* c, 
     const auto t0 = std::chrono::steady_clock::now();
     double* h_lam = const_cast<double*>(v) + P * npar;          // the staging buffer continues behind the P parameter sets
     double* h_vec = h_lam + P * m;
-    for (int64_t p = 0; p < P; ++p) {
+    for (int64_t p = 0; p < P && !ev.factors_staged; ++p) {
         const double* cp = c + p * nC;
         for (int i = 0; i < m; ++i)
             for (int j = 0; j < m; ++j) ev.a[i * m + j] = 0.5 * (cp[i * m + j] + cp[j * m + i]);
@@ -713,9 +806,9 @@ using namespace gabo::host;
 
 extern "C" {
 
-int gabo_nested_spd_reconstruction_solve_with(gabo_recon_eval_fn evaluate, void* ctx, const double* w_host, double* v, double* c,
-                                              double* unit, double* raw, int D, int d, double* staging, size_t staging_doubles,
-                                              const gabo_recon_solve_options* options, gabo_recon_solve_log* log) {
+static int solve_impl(gabo_recon_eval_fn evaluate, void* ctx, const double* w_host, double* v, double* c, double* unit, double* raw, int D, int d,
+                      double* staging, size_t staging_doubles, const gabo_recon_solve_options* options, gabo_recon_solve_log* log,
+                      bool stage_factors) {
     if (D < 2 || D > GABO_SPD_MAX_DIM || d < 1 || d >= D) return GABO_ERR_DIM;
     if (!evaluate || !w_host || !v || !c || !unit || !raw || !staging || !options_ok(options)) return GABO_ERR_ARG;
     Dims dm(D, d);
@@ -723,8 +816,19 @@ int gabo_nested_spd_reconstruction_solve_with(gabo_recon_eval_fn evaluate, void*
     const size_t in_doubles = kMaxLookahead * (npar + dm.m + dm.nC);       // the parameter sets + room for an evaluator's factors of their C
     if (staging_doubles < in_doubles + kMaxLookahead * (1 + npar)) return GABO_ERR_ARG;
     Driver drv(D, d, w_host, evaluate, ctx, staging, staging + in_doubles, *options);
-    // default: four step lengths per launch while the extra retractions are cheap (measured: -22 % / -13 % / -3 % wall-clock at D = 5 / 10 / 20)
-    drv.lookahead = options->lookahead < 1 ? (dm.m <= 16 ? 4 : 2) : (options->lookahead > kMaxLookahead ? (int)kMaxLookahead : (int)options->lookahead);
+    drv.stage_factors = stage_factors;
+    // host threads for the candidates of a line search (each candidate's retraction and factorisation is one task): default one per
+    // candidate when the matrices are large enough for a task to outweigh the hand-off (~1 us) and the machine has the cores
+    const int hw = (int)std::thread::hardware_concurrency();
+    int threads = options->host_threads > 0 ? (int)options->host_threads : (dm.m >= 8 && hw >= 8 ? (int)kMaxLookahead : 1);
+    threads = std::max(1, std::min(threads, (int)kMaxLookahead));
+    StepPool pool(threads - 1);
+    drv.pool = &pool;
+    // default look-ahead: four step lengths per launch while the extra retractions are cheap - small matrices (measured single-threaded:
+    // -22 % / -13 % / -3 % wall-clock at D = 5 / 10 / 20) or one thread per candidate
+    drv.lookahead = options->lookahead < 1 ? ((dm.m <= 16 || threads >= 4) ? 4 : 2)
+                                           : (options->lookahead > kMaxLookahead ? (int)kMaxLookahead : (int)options->lookahead);
+    if (log) log->host_threads = threads;
     Point best(dm);
     std::memcpy(best.x.data(), v, sizeof(double) * dm.nV);
     std::memcpy(best.x.data() + dm.oC, c, sizeof(double) * dm.nC);
@@ -736,6 +840,12 @@ int gabo_nested_spd_reconstruction_solve_with(gabo_recon_eval_fn evaluate, void*
     std::memcpy(unit, best.x.data() + dm.oU, sizeof(double) * dm.nU);
     *raw = best.x[dm.oS];
     return drv.error;
+}
+
+int gabo_nested_spd_reconstruction_solve_with(gabo_recon_eval_fn evaluate, void* ctx, const double* w_host, double* v, double* c,
+                                              double* unit, double* raw, int D, int d, double* staging, size_t staging_doubles,
+                                              const gabo_recon_solve_options* options, gabo_recon_solve_log* log) {
+    return solve_impl(evaluate, ctx, w_host, v, c, unit, raw, D, d, staging, staging_doubles, options, log, false);
 }
 
 void gabo_nested_spd_reconstruction_solve_workspace_bytes(int64_t N, int D, int d, size_t* device_bytes, size_t* pinned_doubles) {
@@ -770,7 +880,8 @@ int gabo_nested_spd_reconstruction_solve(const double* data, const double* y, co
     if (hipMemsetAsync(e.recon_ws, 0, 256, (hipStream_t)stream) != hipSuccess) return GABO_ERR_LAUNCH;
     e.recon_ws_bytes = gabo_nested_spd_reconstruction_workspace_bytes(kMaxLookahead, N < 1 ? 1 : N, D, d);
     e.stream = (hipStream_t)stream;
-    const int rc = gabo_nested_spd_reconstruction_solve_with(hip_evaluate, &e, w_host, v, c, unit, raw, D, d, pinned, pinned_doubles, options, log);
+    e.factors_staged = true;
+    const int rc = solve_impl(hip_evaluate, &e, w_host, v, c, unit, raw, D, d, pinned, pinned_doubles, options, log, true);
     if (getenv("GABO_RECON_TIMING") && log)
         fprintf(stderr, "gabo_nested_spd_reconstruction_solve D=%d: %.2f ms = manifold arithmetic %.2f + factor C %.2f + enqueue %.2f + wait %.2f (%ld launches)\n", D,
                 1e3 * log->seconds, 1e3 * (log->seconds - log->seconds_evaluator), 1e3 * e.t_factor, 1e3 * e.t_enqueue, 1e3 * e.t_wait, (long)log->launches);

@@ -186,7 +186,7 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
             starting_tolgradnorm=solver._starting_tolgradnorm, ending_tolgradnorm=solver._ending_tolgradnorm, gammas_fact=solver._gammas_fact,
             minstepsize=solver._minstepsize, maxtime=solver._maxtime, maxiter=solver._maxiter, cg_minstepsize=inner_solver.minstepsize,
             cg_maxtime=inner_solver.maxtime, cg_orth_value=inner_solver.orth_value, cg_maxiter=inner_solver.maxiter,
-            lookahead=int(os.environ.get("GABO_RECON_LOOKAHEAD", "0")))
+            lookahead=int(os.environ.get("GABO_RECON_LOOKAHEAD", "0")), host_threads=int(os.environ.get("GABO_RECON_THREADS", "0")))
         v, c, unit, raw, log = cost_vg.rec.solve_host(x0[0], x0[1], x0[2], x0[3], options)
         opt = [v, c, unit, raw]
         optimize_reconstruction_parameters_nested_spd.last_log = dict(log, init_cost=float(np.min(vals)), native=True)

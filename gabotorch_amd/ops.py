@@ -529,7 +529,7 @@ def _recon_log(log):
     return {"iterations": int(log.outer_iterations), "inner_iterations": int(log.inner_iterations), "evaluations": int(log.evaluations),
             "launches": int(log.launches), "stop_reason": _lib.GABO_RECON_STOP[log.stop_reason], "violation": float(log.violation),
             "rho": float(log.rho), "gammas": [float(log.gamma)], "final_cost": float(log.final_cost), "time": float(log.seconds),
-            "time_in_evaluator": float(log.seconds_evaluator)}
+            "time_in_evaluator": float(log.seconds_evaluator), "host_threads": int(log.host_threads)}
 
 
 def nested_spd_reconstruction_solve_with(evaluate, w_host, V, C, unit, raw, options):

@@ -521,6 +521,8 @@ typedef struct {
     int64_t lookahead;   /* step lengths alpha, alpha/2, ... evaluated by the first launch of a line search: 1..GABO_RECON_MAX_LOOKAHEAD,
                             0 = default (4 up to D - d = 16, else 2).
                             It changes which launch computes a value, never the values or the steps taken. */
+    int64_t host_threads; /* threads that retract / factor the candidates of a line search side by side: 1..GABO_RECON_MAX_LOOKAHEAD,
+                             0 = default (one per candidate from D - d = 8 on a machine with >= 8 cores, else 1).  Same results either way. */
 } gabo_recon_solve_options;
 #define GABO_RECON_MAX_LOOKAHEAD 4
 #define GABO_RECON_STOP_MAXITER 0
@@ -532,6 +534,7 @@ typedef struct {
     int stop_reason;                                     /* GABO_RECON_STOP_* */
     double violation, rho, gamma, final_cost, seconds;
     double seconds_evaluator;                            /* of `seconds`, inside the evaluator (enqueue + wait); the rest is host arithmetic */
+    int64_t host_threads;                                /* threads used (see the options) */
 } gabo_recon_solve_log;
 typedef int (*gabo_recon_eval_fn)(void* ctx, int64_t P, const double* v, const double* c, const double* k, double* cost, double* grad_v,
                                   double* grad_c, double* grad_k);

@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     double nn = 0.0;
     for (auto& t : u) { t = rnd(); nn += t * t; }
     for (auto& t : u) t /= std::sqrt(nn);
-    gabo_recon_solve_options o{20, 1, 0.3, 0.8, 1e-3, 1e-6, 0.05, 1e-10, 1000, 6, 1e-10, 1000, INFINITY, 100, argc > 3 ? atoi(argv[3]) : 2};
+    gabo_recon_solve_options o{20, 1, 0.3, 0.8, 1e-3, 1e-6, 0.05, 1e-10, 1000, 6, 1e-10, 1000, INFINITY, 100, argc > 3 ? atoi(argv[3]) : 2, argc > 4 ? atoi(argv[4]) : 0};
     gabo_recon_solve_log log;
     const size_t npar = (size_t)D * m + m * m + d * m;
     std::vector<double> staging(GABO_RECON_MAX_LOOKAHEAD * (2 * npar + 1 + m + m * m));
