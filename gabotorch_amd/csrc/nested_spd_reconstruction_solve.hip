@@ -15,6 +15,7 @@
 // statement (same iterates up to the rounding of the eigen-solvers), including the look-ahead of the line search: the first trial step
 // and its first contraction are evaluated by one launch.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -261,9 +262,11 @@ class StepPool {
     const std::function<void(int)>* job = nullptr;
     int ntasks = 0;
 
-    static void relax() {
+    // spin politely; on an oversubscribed machine (fewer runnable cores than threads) give the time slice away instead of burning it
+    static void relax(unsigned& spins) {
 #if !defined(__HIP_DEVICE_COMPILE__)
-        __builtin_ia32_pause();
+        if (++spins < (1u << 20)) __builtin_ia32_pause();      // (~tens of ms: longer than any wait inside one optimisation)
+        else std::this_thread::yield();
 #endif
     }
 
@@ -273,9 +276,10 @@ class StepPool {
             workers.emplace_back([this, w] {
                 unsigned seen = 0;
                 while (true) {
+                    unsigned spins = 0;
                     while (generation.load(std::memory_order_acquire) == seen) {
                         if (stop.load(std::memory_order_relaxed)) return;
-                        relax();
+                        relax(spins);
                     }
                     seen += 1;
                     if (w + 1 < ntasks) (*job)(w + 1);
@@ -295,7 +299,8 @@ class StepPool {
         generation.fetch_add(1, std::memory_order_release);
         f(0);
         for (int i = (int)workers.size() + 1; i < n; ++i) f(i);          // (more tasks than threads: the rest here)
-        while (pending.load(std::memory_order_acquire) > 0) relax();
+        unsigned spins = 0;
+        while (pending.load(std::memory_order_acquire) > 0) relax(spins);
     }
     ~StepPool() {
         stop.store(true);
@@ -818,9 +823,14 @@ static int solve_impl(gabo_recon_eval_fn evaluate, void* ctx, const double* w_ho
     Driver drv(D, d, w_host, evaluate, ctx, staging, staging + in_doubles, *options);
     drv.stage_factors = stage_factors;
     // host threads for the candidates of a line search (each candidate's retraction and factorisation is one task): default one per
-    // candidate when the matrices are large enough for a task to outweigh the hand-off (~1 us) and the machine has the cores
-    const int hw = (int)std::thread::hardware_concurrency();
-    int threads = options->host_threads > 0 ? (int)options->host_threads : (dm.m >= 8 && hw >= 8 ? (int)kMaxLookahead : 1);
+    // candidate when the matrices are large enough for a task to outweigh the hand-off (~1 us) and the process may run on >= 16 cores (the
+    // workers spin: on a small or busy machine they cost more than they bring - 8 shared vCPUs: 2.9 -> 3.6 ms per optimisation)
+    int hw = (int)std::thread::hardware_concurrency();
+#if !defined(__HIP_DEVICE_COMPILE__)
+    cpu_set_t mask;                                    // the cores this process may actually run on (containers, taskset)
+    if (sched_getaffinity(0, sizeof(mask), &mask) == 0) hw = std::min(hw, (int)CPU_COUNT(&mask));
+#endif
+    int threads = options->host_threads > 0 ? (int)options->host_threads : (dm.m >= 8 && hw >= 16 ? (int)kMaxLookahead : 1);
     threads = std::max(1, std::min(threads, (int)kMaxLookahead));
     StepPool pool(threads - 1);
     drv.pool = &pool;

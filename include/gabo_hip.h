@@ -522,7 +522,7 @@ typedef struct {
                             0 = default (4 up to D - d = 16, else 2).
                             It changes which launch computes a value, never the values or the steps taken. */
     int64_t host_threads; /* threads that retract / factor the candidates of a line search side by side: 1..GABO_RECON_MAX_LOOKAHEAD,
-                             0 = default (one per candidate from D - d = 8 on a machine with >= 8 cores, else 1).  Same results either way. */
+                             0 = default (one per candidate from D - d = 8 when the process may run on >= 16 cores, else 1).  Same results either way. */
 } gabo_recon_solve_options;
 #define GABO_RECON_MAX_LOOKAHEAD 4
 #define GABO_RECON_STOP_MAXITER 0

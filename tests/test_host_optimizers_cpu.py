@@ -261,12 +261,12 @@ def test_native_reconstruction_loop_against_the_python_solvers(D, d, seed):
         return v, [W @ wtv / v] + [np.zeros(np.shape(xi)) for xi in x[1:]]
 
     x0 = man.rand()
-    def both(outer, inner, lookahead=2):
+    def both(outer, inner, lookahead=2, host_threads=1):
         alm = AugmentedLagrangeMethod(maxiter=outer, inner_solver=ConjugateGradient(maxiter=inner), gammas_fact=1.0, minstepsize=0.0)
         ref = alm.solve(Objective(), x=[a.copy() for a in x0], eq_constraints=[_Constraint(man, orthogonality)])
         options = _lib.ReconSolveOptions(bound=20, rho_init=1, thetarho=0.3, tau=0.8, starting_tolgradnorm=1e-3, ending_tolgradnorm=1e-6,
                                          gammas_fact=1.0, minstepsize=0.0, maxtime=1000, maxiter=outer, cg_minstepsize=1e-10, cg_maxtime=1000,
-                                         cg_orth_value=np.inf, cg_maxiter=inner, lookahead=lookahead)
+                                         cg_orth_value=np.inf, cg_maxiter=inner, lookahead=lookahead, host_threads=host_threads)
         return ref, alm.log, options, ops.nested_spd_reconstruction_solve_with(evaluate, W, x0[0], x0[1], x0[2], x0[3], options)
 
     ref, ref_log, options, (v, c, u, r, log) = both(4, 8)
@@ -282,6 +282,11 @@ def test_native_reconstruction_loop_against_the_python_solvers(D, d, seed):
     _, _, _, (v4, c4, u4, r4, log4) = both(4, 8, lookahead=4)
     assert log4["launches"] <= log["launches"] and log4["inner_iterations"] == log["inner_iterations"]
     for got, want in zip((v4, c4, u4, r4), (v, c, u, r)):
+        np.testing.assert_array_equal(got, want)
+    # ... and so do host threads (one candidate of a line search per thread)
+    _, _, _, (vt, ct, ut, rt, logt) = both(4, 8, lookahead=4, host_threads=3)
+    assert logt["host_threads"] == 3 and logt["launches"] == log4["launches"]
+    for got, want in zip((vt, ct, ut, rt), (v, c, u, r)):
         np.testing.assert_array_equal(got, want)
     # the full-length run: an optimum of the same quality
     ref, ref_log, options, (v, c, u, r, log) = both(6, 50)
