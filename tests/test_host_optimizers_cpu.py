@@ -284,8 +284,8 @@ def test_native_reconstruction_loop_against_the_python_solvers(D, d, seed):
     for got, want in zip((v4, c4, u4, r4), (v, c, u, r)):
         np.testing.assert_array_equal(got, want)
     # ... and so do host threads (one candidate of a line search per thread)
-    _, _, _, (vt, ct, ut, rt, logt) = both(4, 8, lookahead=4, host_threads=3)
-    assert logt["host_threads"] == 3 and logt["launches"] == log4["launches"]
+    _, _, _, (vt, ct, ut, rt, logt) = both(4, 8, lookahead=4, host_threads=2)
+    assert logt["host_threads"] == 2 and logt["launches"] == log4["launches"]
     for got, want in zip((vt, ct, ut, rt), (v, c, u, r)):
         np.testing.assert_array_equal(got, want)
     # the full-length run: an optimum of the same quality
