@@ -333,6 +333,49 @@ def hd_sphere_pieces(device):
             "parity": {"projection_max_abs": e_proj, "reconstruction_cost_rel": e_rec}}
 
 
+def _collective_selfcheck(dist, device, world, rank):
+    """The collectives of the data path executed once each on the initialised backend with the shapes the path uses, results
+    checked, durations reported: the row-block slab of the sharded Gram (all_gather_into_tensor), the packed (value, candidate) rows of the
+    restarts and of the raw samples (all_gather into a list), the max-over-ranks reduction of the timings, the barrier."""
+    out = {}
+
+    def timed_ms(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    per = (N_POINTS + world - 1) // world
+    slab = torch.full((per, N_POINTS), float(rank), dtype=torch.float64, device=device)
+    full = torch.empty(world * per, N_POINTS, dtype=torch.float64, device=device)
+    try:
+        out["all_gather_into_tensor_gram_slab_ms"] = timed_ms(lambda: dist.all_gather_into_tensor(full, slab))
+    except (RuntimeError, NotImplementedError, AttributeError):      # gloo (the one-device test hook): the list form, as distributed.sharded_gram does
+        slabs = [torch.empty_like(slab) for _ in range(world)]
+        out["all_gather_into_tensor_gram_slab_ms"] = timed_ms(lambda: dist.all_gather(slabs, slab))
+        out["gram_slab_collective"] = "all_gather (list form)"
+        full = torch.cat(slabs)
+    want = torch.arange(world, dtype=torch.float64, device=device).repeat_interleave(per)
+    ok = bool(torch.equal(full[:, 0], want) and torch.equal(full[:, -1], want))
+    packed = torch.full((512 // world + 1, 16), float(rank), dtype=torch.float64, device=device)
+    parts = [torch.empty_like(packed) for _ in range(world)]
+    out["all_gather_restart_rows_ms"] = timed_ms(lambda: dist.all_gather(parts, packed))
+    ok = ok and all(bool((parts[r] == float(r)).all()) for r in range(world))
+    t = torch.tensor([float(rank)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = ok and float(t.item()) == float(world - 1)
+    dist.barrier()
+    out["bytes_gram_slab_per_rank"] = per * N_POINTS * 8
+    out["ok"] = ok
+    if not ok:
+        raise RuntimeError(f"collective self-check failed on backend {dist.get_backend()}")
+    return out
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks (one process per GPU, RCCL over
     xGMI) and relay their output - rank 0 prints the JSON line."""
@@ -384,6 +427,8 @@ def main():
         _self_launch(args)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    backend = "none" if dist is None else str(dist.get_backend())
+    collectives = None if dist is None else _collective_selfcheck(dist, device, world, rank)
 
     x = synthetic_spd_mandel(N_POINTS, DIM, 1234 + rank)      # one independent point set per rank
     job = GramJob(x, device, symmetric=False)
@@ -527,7 +572,7 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {
             "metric": "SPD affine-invariant kernel-matrix build, pairs/sec (N=4096,d=10)",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "pairs/s", "n_gpus": world, "world_size": world, "backend": backend, "steps": args.steps, "warmup": args.warmup,
             "untimed_preheat_steps": max(args.preheat, 0),
             "ms_per_step": wall_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -573,6 +618,8 @@ def main():
                                                            "(2048 x 16 doubles per rank) and one of (value, candidate) per restart (512 x 16 doubles per rank)",
             "measured_single_gpu_latencies_us": {"tr_iteration_launch_64_restarts": 86, "tr_iteration_launch_512_restarts": 113,
                                                  "tr_iteration_launch_2048_restarts": 182, "tr_iteration_launch_8192_restarts": 597}}
+        if collectives is not None:
+            line["collectives"] = collectives
         if sweep is not None:
             line["acq_sweep"] = sweep
         if sharded is not None:

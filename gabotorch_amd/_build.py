@@ -1,4 +1,4 @@
-"""Builds gabotorch_amd/libgabo_hip.so from csrc/*.hip with hipcc for gfx950 (cross-compiles without a GPU).
+"""Builds gabotorch_amd/libgabo_hip.so from csrc/*.hip (device code, hipcc for gfx950: cross-compiles without a GPU) and host/*.cpp (host-only C++).
 
 In-tree on purpose: the .so travels to the GPU box with the repository snapshot.  `python -m gabotorch_amd._build`
 rebuilds; `__graft_entry__.build()` calls `build()`.
@@ -10,7 +10,8 @@ import subprocess
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(PKG, "csrc")
+CSRC = os.path.join(PKG, "csrc")          # device code (*.hip) and its headers
+HOST = os.path.join(PKG, "host")          # host-only C++ above the launches (*.cpp): compiled as plain C++ against the HIP runtime API
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libgabo_hip.so")
 ARCH = "gfx950"
@@ -36,7 +37,15 @@ _HEAVY = ["spd_backward_duo.hip", "spd_pairwise_wide3.hip", "spd_pairwise_wide2.
 def sources():
     names = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     names.sort(key=lambda f: _HEAVY.index(f) if f in _HEAVY else len(_HEAVY))
-    return [os.path.join(CSRC, f) for f in names]
+    host = sorted(f for f in os.listdir(HOST) if f.endswith(".cpp")) if os.path.isdir(HOST) else []
+    return [os.path.join(CSRC, f) for f in names] + [os.path.join(HOST, f) for f in host]
+
+
+def _rocm_include():
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "include")
+
+
+HOST_FLAGS = ["-x", "c++", "-O3", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-Wall", "-D__HIP_PLATFORM_AMD__"]
 
 
 def _deps():
@@ -64,13 +73,16 @@ def _recorded_deps(depfile):
 
 
 def _compile(src, extra):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
     depfile = obj[:-2] + ".d"
     known = _recorded_deps(depfile)
     deps = ([src, os.path.abspath(__file__)] + known) if known is not None else ([src] + _deps())
     if not _stale(obj, deps):
         return obj, False
-    cmd = [_hipcc()] + FLAGS + extra + ["-MD", "-MF", depfile, "-c", src, "-o", obj]
+    if src.endswith(".cpp"):       # host-only translation unit: the same clang, no offload pass
+        cmd = [_hipcc()] + HOST_FLAGS + ["-I", _rocm_include()] + [f for f in extra if f.startswith("-D")] + ["-MD", "-MF", depfile, "-c", src, "-o", obj]
+    else:
+        cmd = [_hipcc()] + FLAGS + extra + ["-MD", "-MF", depfile, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -78,7 +90,7 @@ def _compile(src, extra):
 
 
 def build(force=False, extra_flags=(), verbose=False):
-    """Compile every csrc/*.hip for gfx950 and link libgabo_hip.so.  Returns the library path."""
+    """Compile every csrc/*.hip for gfx950 and every host/*.cpp, link libgabo_hip.so.  Returns the library path."""
     os.makedirs(OBJ, exist_ok=True)
     if force:
         for f in os.listdir(OBJ):

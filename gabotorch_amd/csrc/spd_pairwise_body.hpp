@@ -530,7 +530,7 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
     const int64_t b2 = (s2 == 0) ? 1 : batch;
     double* W = ws;
     double* G = ws + b1 * n1 * T;
-    launch_spd_prep<D>(x1, x2, W, G, b1, b2, n1, n2, s1, s2, status, st);
+    launch_spd_prep<D>(x1, x2, W, G, b1, b2, n1, n2, s1, s2, status, st, /*lenient2=*/1);
     // tile shape: 64..256 columns per block, `rows` rows per block; keep >= ~8 blocks per CU when the problem allows
     // (d = 10, N = 4096, 8 rows: 256 / 128 / 64 threads per block = 2.57 / 2.56 / 2.55 ms - one-wave blocks: a block's slots are not held until its slowest wave ends; d = 7: 1.25 -> 1.23 ms, d <= 5: no gain)
 #ifndef GABO_PAIR_THREADS

@@ -3,6 +3,9 @@
 //   x2 side: G = chol(B), entry-major "SoA"           [b][T][n2]   (lane j reads G[e][j]: fully coalesced)
 // A non-positive pivot (input not SPD; the reference raises from torch.cholesky, spd_utils_torch.py:87) sets
 // status[0] = GABO_ERR_NOT_SPD and status[1] = index of the first offender (x1 set first, then x2).
+// `lenient2` (the forward Gram): the reference factors x1 only - a matrix of x2 that is not positive definite but free of NaN goes through its
+// symeig and log and gives a NaN column (spd_utils_torch.py:109-120), no exception; NaN entries in x2 make its eigen-solver raise.  With the flag
+// such a matrix of x2 is not reported: its factor carries the NaN of the failed pivot into every entry of its column of the result.
 #pragma once
 #include "gabo_device.hpp"
 #include "../../include/gabo_hip.h"
@@ -70,7 +73,7 @@ template <int D>
 __global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                       double* __restrict__ W, double* __restrict__ G, int64_t b1, int64_t b2,
                                                       int64_t n1, int64_t n2, int64_t s1, int64_t s2, unsigned blocks1,
-                                                      int* __restrict__ status) {
+                                                      int* __restrict__ status, int lenient2) {
     constexpr int T = tri_size(D);
     const bool second = blockIdx.x >= blocks1;
     const int64_t g = (int64_t)(second ? blockIdx.x - blocks1 : blockIdx.x) * blockDim.x + threadIdx.x;
@@ -79,7 +82,14 @@ __global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__
     const int64_t b = g / n, i = g - b * n;
     const double* v = (second ? x2 + b * s2 : x1 + b * s1) + i * T;
     double a[T];
-    const bool bad = mandel_cholesky<D>(v, a);
+    bool bad = mandel_cholesky<D>(v, a);
+    if (bad && second && lenient2) {
+        bool has_nan = false;
+        static_for<T>([&](auto ee) { const double e = v[decltype(ee)::value]; has_nan |= e != e; });
+        bad = has_nan;
+        // every entry of the factor NaN (a failed LAST pivot alone would leave the other columns of the factor finite)
+        if (!has_nan) static_for<T>([&](auto ee) { a[decltype(ee)::value] = __builtin_nan(""); });
+    }
     if (bad) {
         if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = (second ? (int)(b1 * n1) : 0) + (int)g;
     }
@@ -96,11 +106,11 @@ __global__ __launch_bounds__(64) void spd_prep_kernel(const double* __restrict__
 
 template <int D>
 static void launch_spd_prep(const double* x1, const double* x2, double* W, double* G, int64_t b1, int64_t b2, int64_t n1,
-                            int64_t n2, int64_t s1, int64_t s2, int* status, hipStream_t st) {
+                            int64_t n2, int64_t s1, int64_t s2, int* status, hipStream_t st, int lenient2 = 0) {
     const unsigned blocks1 = (unsigned)((b1 * n1 + 63) / 64), blocks2 = (unsigned)((b2 * n2 + 63) / 64);
     if (blocks1 + blocks2 == 0) return;
     hipLaunchKernelGGL((spd_prep_kernel<D>), dim3(blocks1 + blocks2), dim3(64), 0, st, x1, x2, W, G, b1, b2, n1, n2, s1, s2, blocks1,
-                       status);
+                       status, lenient2);
 }
 
 }  // namespace gabo

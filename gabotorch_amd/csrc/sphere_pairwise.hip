@@ -98,8 +98,9 @@ __device__ __forceinline__ double sphere_gauss_finish(double ip, const SphGauss&
 // reduction is the exact subtraction Y - rint(Y) (no head/tail product), and exp(r ln2/256) - 1 is a degree-4 polynomial with the scale inside its
 // coefficients.  Instructions per output: 3 (clamped q) + v_rsq_f64 + 5 + 3 (slot, t) + 1 (address) + 6 + 12 (exp) = 30 + v_rsq_f64 (13.7 cycles).
 // Accuracy: tools/sim/fit_sphere_piecewise.py model 6 - 2.9e-15 against 60-digit arithmetic at beta = 1.29 (numpy's own 3.1e-15).
-// A NaN inner product does not propagate (v_max_f64 / v_min_f64 return the bound): a corrupted input row shows up as K = 1 entries, as
-// in the polynomial form above (exp(-beta pi^2) there for a negative sign bit); the distance / Laplace modes propagate it.
+// A NaN inner product does not propagate through this chain (v_max_f64 / v_min_f64 return the bound), nor through the clamp of the other
+// epilogues; the reference's clamp -> acos -> exp returns NaN (sphere_utils_torch.py:53-55).  The pair kernel therefore repairs such
+// entries behind the epilogue (`nan_fixup` below), at the price of one compare per operand and chunk instead of two instructions per output.
 struct SphPwRegs {
     double qmin, qmax, c1, c2, c3, magic;    // SGPRs
     double c4, scale;                        // VGPRs (a VALU instruction reads ONE scalar operand: these share an FMA with c3 resp. the magic number;
@@ -167,6 +168,9 @@ __device__ __forceinline__ double sphere_gauss_finish_pw(double ip, const SphPwR
     const double e = tab[ki & 255];
     return __builtin_ldexp(__builtin_fma(e, p, e), ki >> 8);
 }
+
+// true for NaN, +-inf and magnitudes whose products could overflow: operands of an inner product that may come out NaN
+__device__ __forceinline__ bool sph_suspect(double v) { return !(__builtin_fabs(v) < 1e150); }
 
 template <int MODE>
 __device__ __forceinline__ double sphere_finish(double ip, double beta, const MathRegs& mt) {
@@ -291,6 +295,11 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
             kcs[sidx] = kk < dim ? kk : dim - 1;
             static_for<4>([&](auto tt) { bfrag[sidx][decltype(tt)::value] = pb[decltype(tt)::value][kcs[sidx]]; });
         });
+        // K is padded to 4 KS with zeros on BOTH sides (0 * 0: an infinite entry of the last valid column must not meet the zero of the other
+        // operand); once per wave
+        static_for<4>([&](auto tt) {
+            bfrag[KS - 1][decltype(tt)::value] = 4 * (KS - 1) + lk >= dim ? 0.0 : bfrag[KS - 1][decltype(tt)::value];
+        });
         const int64_t first = (int64_t)rc * rows * dim, last = n1 * dim - 1;
         const double* src = x1 + b * s1;
         const int total = rows * dim, step = (int)blockDim.x;
@@ -319,7 +328,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
         __syncthreads();
     }
     if (j0 >= n2) return;
-    auto finish = [&](double ip) {
+    auto finish_raw = [&](double ip) {
 #if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 1     /* development probe: MFMA + stores only */
         return ip;
 #endif
@@ -327,6 +336,22 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
         else if constexpr (MODE == GABO_OUT_GAUSSIAN) return sphere_gauss_finish<SCALED>(ip, g, tab);
         else return sphere_finish<MODE>(ip, beta, mt);
     };
+    // NaN inner products come out NaN, as the reference's clamp -> acos -> exp does (sphere_utils_torch.py:53-55), although the clamps of the
+    // epilogues above return their bound for a NaN.  KS > 0: the operands are in registers - one compare each per chunk decides, wave-uniformly,
+    // whether any inner product of the chunk CAN be NaN (NaN / inf operand, or magnitudes whose products overflow); only then the chunk's
+    // tiles are formed once more and their NaN entries stored over the epilogue's values (`nan_fixup`).  KS = 0: a select per output.
+    auto finish = [&](double ip) {
+        const double v = finish_raw(ip);
+        if constexpr (KS > 0) return v;
+        else return ip != ip ? ip : v;
+    };
+    bool suspect_b = false;
+    if constexpr (KS > 0) {
+        static_for<KS>([&](auto ss) {
+            static_for<4>([&](auto tt) { suspect_b |= sph_suspect(bfrag[decltype(ss)::value][decltype(tt)::value]); });
+        });
+        suspect_b = __builtin_amdgcn_ballot_w64(suspect_b) != 0;
+    }
     const uint32_t loff = ((uint32_t)lk * (uint32_t)n2 + (uint32_t)li) * 8u;       // byte offset of the lane inside a 4-row group (n2 < 2^27)
 #ifdef GABO_SPH_CLOCKS
     const uint64_t clk_loop = __builtin_amdgcn_s_memrealtime();
@@ -378,8 +403,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
             }
         };
         if constexpr (KS > 0) {
-            // K is padded to 4 KS with zeros: the padded lanes hold the last valid entry and zero their x1 operand (the x2 operand can stay:
-            // a genuine, finite entry of the same vector, or that column is NaN anyway)
+            // K is padded to 4 KS with zeros: the padded lanes hold the last valid entry and zero it (the x2 operand was zeroed once per wave)
             double a_cur[KS];
             const double* xrow = xa + (16 * ch + li) * dim;
             static_for<KS>([&](auto ss) {
@@ -389,25 +413,50 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
             });
             // PW: two tiles at a time (their MFMAs, then their eight epilogues) - 16 accumulator registers live instead of 32
             constexpr int GROUP = (PW && GABO_SPH_PW_BARRIER) ? GABO_SPH_PW_GROUP : 4;
-            static_for<4 / GROUP>([&](auto gg) {
-                constexpr int T0 = decltype(gg)::value * GROUP;
+            auto form_tiles = [&](auto t0_, auto ntile_) {
+                constexpr int T0 = decltype(t0_)::value, NTILE = decltype(ntile_)::value;
                 static_for<KS>([&](auto ss) {
                     constexpr int sidx = decltype(ss)::value;
-                    static_for<GROUP>([&](auto tt) {
+                    static_for<NTILE>([&](auto tt) {
                         constexpr int t = T0 + decltype(tt)::value;
                         if constexpr (sidx == 0) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[0], bfrag[0][t], sph_v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
                         else acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[sidx], bfrag[sidx][t], acc[t], 0, 0, 0);
                     });
                 });
+            };
+            static_for<4 / GROUP>([&](auto gg) {
+                constexpr int T0 = decltype(gg)::value * GROUP;
+                form_tiles(std::integral_constant<int, T0>{}, std::integral_constant<int, GROUP>{});
                 store_tiles(std::integral_constant<int, T0>{}, std::integral_constant<int, GROUP>{});
                 if constexpr (PW && GABO_SPH_PW_BARRIER) __builtin_amdgcn_sched_barrier(0);
             });
+            bool suspect = false;
+            static_for<KS>([&](auto ss) { suspect |= sph_suspect(a_cur[decltype(ss)::value]); });
+            if (__builtin_expect(suspect_b || __builtin_amdgcn_ballot_w64(suspect) != 0, 0)) {
+                // nan_fixup (rare): the chunk's inner products once more, tile by tile; their NaN entries replace what the epilogue stored
+                // (same lane, same address, program order)
+                static_for<4>([&](auto tt) {
+                    constexpr int t = decltype(tt)::value;
+                    form_tiles(std::integral_constant<int, t>{}, std::integral_constant<int, 1>{});
+                    const int64_t j = j0 + 16 * t + li;
+                    static_for<4>([&](auto rr) {
+                        constexpr int r = decltype(rr)::value;
+                        const int64_t i = i0 + lk + 4 * r;
+                        const double ipn = acc[t][r];
+                        if (ipn != ipn && i < n1 && j < n2 && (!(flags & GABO_SYMMETRIC) || i <= j)) {
+                            double* dst = ob + (int64_t)(lk + 4 * r) * n2 + 16 * t + li;
+                            if constexpr (NT) __builtin_nontemporal_store(ipn, dst);
+                            else *dst = ipn;
+                        }
+                    });
+                });
+            }
         } else {
             const int64_t ia = (i0 + li < n1) ? i0 + li : n1 - 1;
             const double* pa = x1 + b * s1 + ia * dim;
-            // K is padded to a multiple of 4 with zeros: the padded lanes load the last valid entry (no divergent load) and zero their x1
-            // operand - the x2 operand can stay (it is a genuine, finite entry of the same vector, or that column is NaN anyway), which
-            // saves its four selects per step.  The first step starts from a literal zero accumulator (no per-chunk clearing moves).
+            // K is padded to a multiple of 4 with zeros: the padded lanes load the last valid entry (no divergent load) and zero both
+            // operands (0 * 0: an infinite entry must not meet the zero of the other side).  The first step starts from a literal zero
+            // accumulator (no per-chunk clearing moves).
             auto kstep = [&](int k0, auto first) {
                 const int kk = k0 + lk;
                 const bool ok = kk < dim;
@@ -416,6 +465,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
                 double bv[4];
                 static_for<4>([&](auto tt) { bv[decltype(tt)::value] = pb[decltype(tt)::value][kc]; });
                 a = ok ? a : 0.0;
+                static_for<4>([&](auto tt) { bv[decltype(tt)::value] = ok ? bv[decltype(tt)::value] : 0.0; });
                 static_for<4>([&](auto tt) {
                     constexpr int t = decltype(tt)::value;
                     if constexpr (decltype(first)::value) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[t], sph_v4d{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
@@ -453,9 +503,10 @@ __global__ __launch_bounds__(256) void sphere_diag_kernel(const double* __restri
     for (int k = 0; k < dim; ++k) acc = __builtin_fma(p[k], q[k], acc);
     const MathRegs mt = MathRegs::load();
     const int mode = flags & GABO_OUT_MASK;
-    out[g] = mode == GABO_OUT_DISTANCE ? sphere_finish<GABO_OUT_DISTANCE>(acc, beta, mt)
-                                       : (mode == GABO_OUT_LAPLACE ? sphere_finish<GABO_OUT_LAPLACE>(acc, beta, mt)
-                                                                   : sphere_finish<GABO_OUT_GAUSSIAN>(acc, beta, mt));
+    const double v = mode == GABO_OUT_DISTANCE ? sphere_finish<GABO_OUT_DISTANCE>(acc, beta, mt)
+                                               : (mode == GABO_OUT_LAPLACE ? sphere_finish<GABO_OUT_LAPLACE>(acc, beta, mt)
+                                                                           : sphere_finish<GABO_OUT_GAUSSIAN>(acc, beta, mt));
+    out[g] = acc != acc ? acc : v;      // the clamp inside sphere_finish returns its bound for a NaN; the reference's returns NaN
 }
 
 // Element-wise f^(order)(c) on a precomputed inner-product matrix c = <x1_i, x2_j>, f(c) = g(clamp(c)):

@@ -14,8 +14,11 @@
 // The algorithm is gabotorch_amd/manifold_optimization/{augmented_lagrange_method,conjugate_gradient,host_manifolds}.py statement by
 // statement (same iterates up to the rounding of the eigen-solvers), including the look-ahead of the line search: the first trial step
 // and its first contraction are evaluated by one launch.
-#include <hip/hip_runtime.h>
+// Host C++ only (no device code): compiled by the host compiler against the HIP runtime API (gabotorch_amd/_build.py, host/*.cpp).
+#include <hip/hip_runtime_api.h>
+#if defined(__linux__)
 #include <sched.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -36,7 +39,7 @@ namespace gabo {
 int nested_spd_reconstruction_launch(const double* data, const double* y, const double* sqrt_y, const double* w, const double* v,
                                      const double* c, const double* k, double* cost, double* grad_v, double* grad_c, double* grad_k,
                                      const double* c_eigenvalues, const double* c_eigenvectors, int64_t P, int64_t N, int D, int d, int metric,
-                                     void* workspace, size_t workspace_bytes, bool clear_tickets, gabo_stream_t stream);     // nested_spd_reconstruction.hip
+                                     void* workspace, size_t workspace_bytes, bool clear_tickets, gabo_stream_t stream);     // csrc/nested_spd_reconstruction.hip
 
 namespace host {
 
@@ -44,10 +47,10 @@ typedef std::vector<double> vec;
 
 // The dense helpers below are compiled twice - baseline x86-64 and AVX2 - and the loader picks by the CPU it runs on (GNU ifunc): the
 // loops are m^3-sized with m = D - d <= 31, the compiler's vectoriser is all they need.
-#if defined(__HIP_DEVICE_COMPILE__) || defined(GABO_HOST_NO_CLONES)
-#define GABO_HOST_CLONES                                 // (the device pass parses this file too: nothing here is device code)
-#else
+#if defined(__x86_64__) && defined(__gnu_linux__) && !defined(GABO_HOST_NO_CLONES)
 #define GABO_HOST_CLONES __attribute__((target_clones("avx2", "default")))
+#else
+#define GABO_HOST_CLONES                                 // (no ifunc dispatch outside x86-64 glibc: one baseline build)
 #endif
 
 // (inlined into each clone of its callers: a call through the ifunc table per 18-element product would cost more than the product)
@@ -264,9 +267,12 @@ class StepPool {
 
     // spin politely; on an oversubscribed machine (fewer runnable cores than threads) give the time slice away instead of burning it
     static void relax(unsigned& spins) {
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(__x86_64__)
         if (++spins < (1u << 20)) __builtin_ia32_pause();      // (~tens of ms: longer than any wait inside one optimisation)
         else std::this_thread::yield();
+#else
+        ++spins;
+        std::this_thread::yield();
 #endif
     }
 
@@ -826,7 +832,7 @@ static int solve_impl(gabo_recon_eval_fn evaluate, void* ctx, const double* w_ho
     // candidate when the matrices are large enough for a task to outweigh the hand-off (~1 us) and the process may run on >= 16 cores (the
     // workers spin: on a small or busy machine they cost more than they bring - 8 shared vCPUs: 2.9 -> 3.6 ms per optimisation)
     int hw = (int)std::thread::hardware_concurrency();
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(__gnu_linux__)
     cpu_set_t mask;                                    // the cores this process may actually run on (containers, taskset)
     if (sched_getaffinity(0, sizeof(mask), &mask) == 0) hw = std::min(hw, (int)CPU_COUNT(&mask));
 #endif

@@ -72,6 +72,10 @@ class _NestedSpdMllProblem(_MllProblem):
         iw = [k for k, p in enumerate(params) if p is base.raw_projection_matrix]
         if len(iw) != 1 or base.raw_projection_matrix.dim() != 2 or not model.train_x.is_cuda and not torch.cuda.is_available():
             return None
+        from .. import _lib
+        # beyond what the one-call evaluators take (tiled likelihood: n <= 2048; projection kernels: D <= 32) the generic autograd problem is used
+        if model.train_x.shape[0] > _lib.GABO_GP_MLL_LARGE_MAX_N or base.raw_projection_matrix.shape[0] > _lib.GABO_SPD_MAX_DIM:
+            return None
         self = _NestedSpdMllProblem(model, names, params, manifold)
         self.iw = iw[0]
         self.scalar_idx = [k for k in range(len(params)) if k != self.iw]
@@ -187,6 +191,9 @@ class _NestedSphereMllProblem(_MllProblem):
         if _compat.HAVE_GPYTORCH or base is None or type(base) is not NestedSphereGaussianKernel:
             return None
         if not model.train_x.is_cuda and not torch.cuda.is_available():
+            return None
+        from .. import _lib
+        if model.train_x.shape[0] > _lib.GABO_GP_MLL_LARGE_MAX_N:       # beyond the tiled likelihood: the generic autograd problem
             return None
         axis_idx = []
         for a in base.axes:

@@ -211,7 +211,30 @@ def _gen_candidates_pointwise(x0, acquisition_function, manifold, solver, post_p
     return candidates.detach(), batch_acquisition.detach()
 
 
-def _draw_raw_samples(manifold, total, first, count, options, sample_type):
+class _rank_stream:
+    """Host draws of one rank's shard of the raw samples.  Single process: numpy's global stream as it is (the reference's draw order,
+    pinned by golden vectors).  Several ranks: every rank takes ONE integer from the global stream - identically seeded ranks stay in
+    step, which the GP fit's numpy candidates and every later draw rely on - and draws its shard from a temporary state seeded with
+    (that integer, rank); the global state is put back afterwards.  The shards of different ranks are then distinct streams whatever the
+    seeding of the processes, and nobody has to reseed numpy per rank."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.saved = rank, world, None
+
+    def __enter__(self):
+        if self.world > 1:
+            base = int(np.random.randint(0, 2 ** 31 - 1))
+            self.saved = np.random.get_state()
+            np.random.seed([base, self.rank])
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            np.random.set_state(self.saved)
+        return False
+
+
+def _draw_raw_samples(manifold, total, first, count, options, sample_type, rank=0, world=1):
     """Raw samples first ... first + count - 1 of the `total` of one attempt, count x 1 x (point shape) (manifold_optimize.py:288).
     `manifold.rand` stays a host callable (callers monkey-patch it); two opt-in faster routes draw the same distribution."""
     device = options.get("device")
@@ -219,13 +242,14 @@ def _draw_raw_samples(manifold, total, first, count, options, sample_type):
         # drawn on the device, stream addressed by the global sample index: the shards of ranks with a common numpy seed are
         # exactly the samples one rank would have drawn
         return manifold.rand_batch_device(total, device, first=first, count=count)[:, None].to(sample_type)
-    if options.get("batched_rand") and hasattr(manifold, "rand_batch"):
-        # one vectorised host draw (same distribution, not numpy's draw order of `count` manifold.rand() calls)
-        pts = torch.as_tensor(np.asarray(manifold.rand_batch(count)))[:, None].to(sample_type)
-    elif count:
-        pts = torch.cat([torch.as_tensor(np.asarray(manifold.rand()))[None, None] for _ in range(count)]).to(sample_type)
-    else:
-        pts = torch.as_tensor(np.asarray(manifold.rand()))[None, None][:0].to(sample_type)
+    with _rank_stream(rank, world):
+        if options.get("batched_rand") and hasattr(manifold, "rand_batch"):
+            # one vectorised host draw (same distribution, not numpy's draw order of `count` manifold.rand() calls)
+            pts = torch.as_tensor(np.asarray(manifold.rand_batch(count)))[:, None].to(sample_type)
+        elif count:
+            pts = torch.cat([torch.as_tensor(np.asarray(manifold.rand()))[None, None] for _ in range(count)]).to(sample_type)
+        else:
+            pts = torch.as_tensor(np.asarray(manifold.rand()))[None, None][:0].to(sample_type)
     return pts if device is None else pts.to(device)
 
 
@@ -270,8 +294,9 @@ def _gather_raw_samples(X_loc, Y_loc, total, seed):
     if world > 1 and counts[1][1] - counts[1][0] == counts[0][1] and counts[0][1] > 0 and torch.equal(parts[0][1:], parts[1][1:]) \
             and float(parts[0][0, 0]) == float(parts[1][0, 0]) and not getattr(_gather_raw_samples, "_warned", False):
         _gather_raw_samples._warned = True
-        warnings.warn("ranks 0 and 1 drew identical raw samples: manifold.rand reads the global numpy RNG - seed it per rank "
-                      "(seed + rank), or draw on the device (options['device_rand']), whose stream is addressed by sample index")
+        warnings.warn("ranks 0 and 1 drew identical raw samples: manifold.rand does not read numpy's global generator (whose per-rank "
+                      "streams are derived internally) - make the sampler rank-aware, or draw on the device (options['device_rand']), "
+                      "whose stream is addressed by sample index.  Do NOT reseed numpy per rank: the GP fit draws from it on every rank")
     return X, Y, int(parts[0][0, 0].item())
 
 
@@ -301,7 +326,7 @@ def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num
         if world > 1:
             from ..distributed import row_block
             lo, hi = row_block(total, rank, world)
-        X_loc, Y_loc = _score_raw_samples(acq_function, _draw_raw_samples(manifold, total, lo, hi - lo, options, sample_type),
+        X_loc, Y_loc = _score_raw_samples(acq_function, _draw_raw_samples(manifold, total, lo, hi - lo, options, sample_type, rank, world),
                                           post_processing_manifold, options)
         seed = int(torch.randint(0, 2 ** 52, (1,)).item())      # from torch's global generator, like botorch's own multinomial draw
         X_rnd, Y_rnd, seed = _gather_raw_samples(X_loc, Y_loc, total, seed)

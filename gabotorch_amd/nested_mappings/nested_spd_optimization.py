@@ -14,8 +14,43 @@ from ..manifold_optimization.conjugate_gradient import ConjugateGradient
 from ..manifold_optimization.host_manifolds import Euclidean, Grassmann, PositiveDefinite, Product, Sphere
 
 
+def _default_threads():
+    """0 = the native loop decides (spinning helper threads on hosts with >= 16 runnable cores); 1 when several ranks share the host: the
+    spinning workers of every rank would compete for the same cores."""
+    import torch.distributed as dist
+    return "1" if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else "0"
+
+
+def _composed_cost(metric, x_data, x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix, contraction_matrix):
+    """The same cost as a composition of this package's differentiable operations (lift, then N distances / matrix logarithms): gradients
+    with respect to EVERY argument, the data, the latent points and W included, as the reference's torch statement gives them."""
+    from ..Riemannian_utils.spd_utils_torch import affine_invariant_distance_torch, logm_torch
+    from .nested_spd_utils import projection_from_nested_spd_to_spd
+    x_rec = projection_from_nested_spd_to_spd(x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix,
+                                              contraction_matrix)
+    if metric == _lib.GABO_RECON_AFFINE_INVARIANT:
+        dist = affine_invariant_distance_torch(x_data.to(x_rec.device)[:, None], x_rec[:, None])        # batch N of 1 x 1 problems
+        return torch.sum(dist * dist)
+    diff = logm_torch(x_data.to(x_rec.device)) - logm_torch(x_rec) + 1e-15
+    return torch.sum(diff * diff)
+
+
+_prepared = {}      # (metric, data pointers / versions) -> NestedSpdReconstruction of the most recent data set
+
+
 def _fused_cost(metric, x_data, x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix, contraction_matrix):
-    rec = ops.NestedSpdReconstruction(x_data, x_data_projected, projection_matrix, metric)
+    # the fused launch propagates gradients to V, C and K only: with a gradient requested for the data side, the composed path
+    if torch.is_grad_enabled() and any(torch.is_tensor(a) and a.requires_grad for a in (x_data, x_data_projected, projection_matrix)):
+        return _composed_cost(metric, x_data, x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix,
+                              contraction_matrix)
+    # the prepared object (logm / inverse factors of the data, square roots of the latent points: two launches and a status read-back) is
+    # kept for as long as the caller comes back with the same, unmodified tensors
+    key = (int(metric),) + tuple((a.data_ptr(), a._version, tuple(a.shape), str(a.device)) for a in (x_data, x_data_projected, projection_matrix))
+    rec = _prepared.get("rec") if _prepared.get("key") == key else None
+    if rec is None:
+        rec = ops.NestedSpdReconstruction(x_data, x_data_projected, projection_matrix, metric)
+        _prepared["key"], _prepared["rec"] = key, rec
+        _prepared["hold"] = (x_data, x_data_projected, projection_matrix)      # (keeps the pointers of the key from being recycled)
     return rec(projection_complement_matrix, bottom_spd_matrix, contraction_matrix)
 
 
@@ -179,20 +214,28 @@ def optimize_reconstruction_parameters_nested_spd(x_data, x_data_projected, proj
     cands = [manifold.rand() for _ in range(nb_init_candidates)]
     vals = cost_vg.many(cands)                                           # best of the random starts (:158-166): one launch
     x0 = cands[int(np.argmin(vals))]
-    solver = AugmentedLagrangeMethod(**dict(dict(maxiter=maxiter, inner_solver=inner_solver, lambdas_fact=0.05), **(alm_options or {})))
-    if native and isinstance(cost_vg, _FusedEvaluator) and type(inner_solver) is ConjugateGradient:
+    alm_options = dict(alm_options or {})
+    logverbosity = int(alm_options.get("logverbosity", 0) or 0)
+    solver = AugmentedLagrangeMethod(**dict(dict(maxiter=maxiter, inner_solver=inner_solver, lambdas_fact=0.05), **alm_options))
+    # the native loop implements the algorithm with the options below; anything else in alm_options (multiplier update factor, logging, line
+    # search settings of another inner solver ...) is served by the Python loop
+    _NATIVE_KEYS = {"maxiter", "bound", "rho_init", "thetarho", "tau", "starting_tolgradnorm", "ending_tolgradnorm", "gammas_fact", "minstepsize",
+                    "maxtime"}
+    if native and isinstance(cost_vg, _FusedEvaluator) and type(inner_solver) is ConjugateGradient and set(alm_options) <= _NATIVE_KEYS:
         options = _lib.ReconSolveOptions(
             bound=solver._bound, rho_init=solver._rho_init, thetarho=solver._thetarho, tau=solver._tau,
             starting_tolgradnorm=solver._starting_tolgradnorm, ending_tolgradnorm=solver._ending_tolgradnorm, gammas_fact=solver._gammas_fact,
             minstepsize=solver._minstepsize, maxtime=solver._maxtime, maxiter=solver._maxiter, cg_minstepsize=inner_solver.minstepsize,
             cg_maxtime=inner_solver.maxtime, cg_orth_value=inner_solver.orth_value, cg_maxiter=inner_solver.maxiter,
-            lookahead=int(os.environ.get("GABO_RECON_LOOKAHEAD", "0")), host_threads=int(os.environ.get("GABO_RECON_THREADS", "0")))
+            lookahead=int(os.environ.get("GABO_RECON_LOOKAHEAD", "0")), host_threads=int(os.environ.get("GABO_RECON_THREADS", _default_threads())))
         v, c, unit, raw, log = cost_vg.rec.solve_host(x0[0], x0[1], x0[2], x0[3], options)
         opt = [v, c, unit, raw]
         optimize_reconstruction_parameters_nested_spd.last_log = dict(log, init_cost=float(np.min(vals)), native=True)
         return (torch.tensor(v, dtype=dt, device=dev), torch.tensor(c, dtype=dt, device=dev),
                 torch.tensor(contraction(opt)[0], dtype=dt, device=dev))
     opt = solver.solve(problem, x=x0, eq_constraints=[constraint])
+    if logverbosity >= 1:                                                # pymanopt convention: (x, log) with logverbosity >= 1
+        opt = opt[0]
     V = torch.tensor(opt[0], dtype=dt, device=dev)
     C = torch.tensor(opt[1], dtype=dt, device=dev)
     K = torch.tensor(contraction(opt)[0], dtype=dt, device=dev)

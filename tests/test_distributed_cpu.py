@@ -82,7 +82,7 @@ def _worker(rank, world, port, num_restarts, out_dir, indexed, seeds):
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
             best, val, ic, calls = _run(seeds[rank], num_restarts, indexed=indexed)
-        torch.save({"best": best, "val": val, "ic": ic, "calls": calls,
+        torch.save({"best": best, "val": val, "ic": ic, "calls": calls, "np_after": float(np.random.rand()),
                     "identical_warning": any("identical raw samples" in str(w.message) for w in caught)}, os.path.join(out_dir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -112,22 +112,44 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
 
 
 def test_two_rank_host_sampler_shards(tmp_path):
-    """manifold.rand as a host callable (the reference's contract): rank r draws its shard from ITS numpy stream, the all_gather makes the
-    union common, every rank selects the same rows.  Identically seeded ranks are told that their shards are duplicates."""
+    """manifold.rand as a host callable (the reference's contract): every rank takes one integer from numpy's global stream and draws its
+    shard from a temporary state seeded with (that integer, rank) - distinct shards whether the processes were seeded alike or not - the
+    all_gather makes the union common, every rank selects the same rows, and the global stream is left where that one integer put it, so
+    identically seeded ranks stay in step (the GP fit draws from numpy on every rank)."""
     sys.path.insert(0, ROOT)
-    r0, r1 = _two_ranks(tmp_path, 6, False, (100, 101))
-    assert torch.equal(r0["ic"], r1["ic"]) and torch.equal(r0["best"], r1["best"]) and not r0["identical_warning"]
-    shards = []
-    for seed in (100, 101):            # what each rank drew: 20 calls of manifold.rand() from its own stream
-        np.random.seed(seed)
-        x = np.random.randn(20, 3)
-        shards.append(x / np.linalg.norm(x, axis=1, keepdims=True))
-    ic = r0["ic"][:, 0].numpy()
-    member = [[bool(np.any(np.all(np.abs(sh - row) < 1e-15, axis=1))) for sh in shards] for row in ic]
-    assert all(a or b for a, b in member)                                                    # every start is one of the gathered samples
-    assert any(a for a, _ in member) and any(b for _, b in member)                           # and both shards contribute
-    d0, d1 = _two_ranks(tmp_path, 6, False, (100, 100))
-    assert d0["identical_warning"] and d1["identical_warning"] and torch.equal(d0["best"], d1["best"])
+    for seeds in ((100, 100), (100, 101)):
+        r0, r1 = _two_ranks(tmp_path, 6, False, seeds)
+        assert torch.equal(r0["ic"], r1["ic"]) and torch.equal(r0["best"], r1["best"])
+        assert not r0["identical_warning"] and not r1["identical_warning"]
+        shards = []
+        for rank, seed in enumerate(seeds):            # what each rank drew: 20 calls of manifold.rand() from its derived stream
+            np.random.seed(seed)
+            base = int(np.random.randint(0, 2 ** 31 - 1))
+            np.random.seed([base, rank])
+            x = np.random.randn(20, 3)
+            shards.append(x / np.linalg.norm(x, axis=1, keepdims=True))
+        assert not np.allclose(shards[0], shards[1])
+        ic = r0["ic"][:, 0].numpy()
+        member = [[bool(np.any(np.all(np.abs(sh - row) < 1e-15, axis=1))) for sh in shards] for row in ic]
+        assert all(a or b for a, b in member)                                                    # every start is one of the gathered samples
+        assert any(a for a, _ in member) and any(b for _, b in member)                           # and both shards contribute
+        # the global numpy stream after the sweep: advanced by the one integer only, hence common to identically seeded ranks
+        if seeds[0] == seeds[1]:
+            assert r0["np_after"] == r1["np_after"]
+        np.random.seed(seeds[0])
+        np.random.randint(0, 2 ** 31 - 1)
+        assert r0["np_after"] == float(np.random.rand())
+
+
+def test_single_process_host_draw_order_is_numpys():
+    """One process: manifold.rand() reads numpy's global stream call by call, as in the reference (manifold_optimize.py:288)."""
+    from gabotorch_amd.manifold_optimization import manifold_optimize as mo
+    acq, man = _problem()
+    np.random.seed(5)
+    pts = mo._draw_raw_samples(man, 7, 0, 7, {}, torch.float64)
+    np.random.seed(5)
+    want = np.stack([np.asarray(man.rand()) for _ in range(7)])
+    assert torch.equal(pts[:, 0], torch.as_tensor(want))
 
 
 def test_shard_and_gather_helpers_single_process():

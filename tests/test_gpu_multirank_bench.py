@@ -29,6 +29,7 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE JSON line
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["backend"] == "gloo" and line["world_size"] == 2 and line["collectives"]["ok"]
     assert line["value"] > 0 and line["parity"]["max_rel_err_vs_oracle_256x256"] < 1e-9
     sg = line["sharded_gram"]
     assert sg["left_sharded"]["ms"] > 0 and sg["all_gathered"]["ms"] >= sg["left_sharded"]["ms"] * 0.5
@@ -44,3 +45,30 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     from tools.sweep_bench import run_sweep
     single = run_sweep("cuda:0", num_restarts=512, device_rand=True, builtin_constraint=True)[2]
     assert abs(sw["best_acq_single_launch_solve_device_rand"] - single) <= 1e-9 * abs(single), (sw["best_acq_single_launch_solve_device_rand"], single)
+
+
+def test_bench_one_rank_through_rccl(tmp_path):
+    """The RCCL branch itself on hardware: bench.py under torch.distributed.run with ONE rank initialises the `nccl` backend on cuda:0 (device_id
+    set) and executes every collective of the data path once - all_gather_into_tensor of the Gram slab, all_gather of the packed restart
+    rows, all_reduce(MAX), barrier - before the timed region; the line names the backend it used."""
+    import socket
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GABO_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--preheat", "5", "--no-cpu-baseline", "--no-sweep"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    log = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(log, exist_ok=True)
+    with open(os.path.join(log, "bench_one_rank_rccl.log"), "w") as f:
+        f.write(r.stdout + "\n--- stderr ---\n" + r.stderr[-20000:])
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["backend"] == "nccl" and line["world_size"] == 1 and line["n_gpus"] == 1
+    assert line["collectives"]["ok"] and line["collectives"]["all_gather_into_tensor_gram_slab_ms"] > 0
+    assert line["value"] > 0 and line["parity"]["max_rel_err_vs_oracle_256x256"] < 1e-9
