@@ -240,8 +240,12 @@ __global__ __launch_bounds__(256, (D > GABO_PAIR_TWO_WAVE_MAX_DIM ? 1 : GABO_PAI
             // i.e. 1e-16 beta d^2 relative in K.  (OCML's exp stays: the register-table exp_neg of gabo_device.hpp measured 4 % SLOWER here,
             // 2.75 vs 2.63 ms - its 28 pinned coefficients cost more than the instructions they save once per pair.)
             dist = 0.0;
-            if constexpr (kTabExp) val = exp_neg_tab(-((s + 1e-15) * beta), ec, ec3, tab);
-            else val = exp(-((s + 1e-15) * beta));
+            if constexpr (kTabExp) {
+                val = exp_neg_tab(-((s + 1e-15) * beta), ec, ec3, tab);
+                val = s != s ? s : val;        // (the argument clamp of the table exp returns its bound for a NaN: a NaN column of x2 must stay NaN)
+            } else {
+                val = exp(-((s + 1e-15) * beta));
+            }
         } else {
             dist = __builtin_sqrt(s + 1e-15);  // spd_utils_torch.py:120
             val = finish(dist, beta, mode);

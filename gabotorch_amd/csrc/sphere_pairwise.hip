@@ -211,6 +211,9 @@ constexpr int kSphMaxChunks = 8;
 #ifndef GABO_SPH_PW_BARRIER
 #define GABO_SPH_PW_BARRIER 1
 #endif
+#ifndef GABO_SPH_PW_EVERY      /* epilogues the scheduler may interleave between two scheduling barriers */
+#define GABO_SPH_PW_EVERY 1
+#endif
 #ifdef GABO_SPH_CLOCKS
 #define GABO_SPH_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #else
@@ -346,12 +349,14 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
         else return ip != ip ? ip : v;
     };
     bool suspect_b = false;
+#ifndef GABO_SPH_NO_NAN_FIXUP
     if constexpr (KS > 0) {
         static_for<KS>([&](auto ss) {
             static_for<4>([&](auto tt) { suspect_b |= sph_suspect(bfrag[decltype(ss)::value][decltype(tt)::value]); });
         });
         suspect_b = __builtin_amdgcn_ballot_w64(suspect_b) != 0;
     }
+#endif
     const uint32_t loff = ((uint32_t)lk * (uint32_t)n2 + (uint32_t)li) * 8u;       // byte offset of the lane inside a 4-row group (n2 < 2^27)
 #ifdef GABO_SPH_CLOCKS
     const uint64_t clk_loop = __builtin_amdgcn_s_memrealtime();
@@ -386,7 +391,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
 #endif
                         // one table-driven epilogue at a time: left alone the scheduler interleaves the whole chunk (8 table reads and ~35
                         // registers per output) and the kernel no longer fits the 128 registers of four waves per SIMD
-                        if constexpr (PW && GABO_SPH_PW_BARRIER) __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (PW && GABO_SPH_PW_BARRIER && ((r * NTILE + decltype(tt)::value + 1) % GABO_SPH_PW_EVERY == 0)) __builtin_amdgcn_sched_barrier(0);
                     });
                 });
             } else {
@@ -431,7 +436,9 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
                 if constexpr (PW && GABO_SPH_PW_BARRIER) __builtin_amdgcn_sched_barrier(0);
             });
             bool suspect = false;
+#ifndef GABO_SPH_NO_NAN_FIXUP     /* A/B: the round-3 kernel (NaN inner products not repaired) */
             static_for<KS>([&](auto ss) { suspect |= sph_suspect(a_cur[decltype(ss)::value]); });
+#endif
             if (__builtin_expect(suspect_b || __builtin_amdgcn_ballot_w64(suspect) != 0, 0)) {
                 // nan_fixup (rare): the chunk's inner products once more, tile by tile; their NaN entries replace what the epilogue stored
                 // (same lane, same address, program order)

@@ -153,9 +153,76 @@ def spd_ai_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, wrt
     return gx.to(out_device)
 
 
+def spd_ai_backward2(x1, x2, grad_out, u, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, want_dgrad_out=True, want_mixed=False):
+    """Second-order terms of the kernel (gabo_spd_ai_backward2): with grad_out fixed and u a direction shaped like x1, returns (hv, dg, mixed):
+    hv = d/dt spd_ai_backward(x1 + t u, x2, grad_out)|_0 (shaped like x1), dg[..., i, j] = <u_i, dK_ij/dx1_i> (or None) and
+    mixed = d <spd_ai_backward(x1, x2, grad_out), u> / d x2 (shaped like x2, or None)."""
+    lib = _lib.load()
+    out_device = x1.device
+    dev = _device_for(x1, x2, grad_out, u)
+    a, b = _prep(x1, dev), _prep(x2, dev)
+    g, uu = _prep(grad_out, dev).contiguous(), _prep(u, dev).contiguous()
+    if uu.shape != a.shape:
+        raise RuntimeError(f"direction {tuple(uu.shape)} is not shaped like x1 {tuple(a.shape)}")
+    d = _mandel_dim(a.shape[-1])
+    n1, n2 = a.shape[-2], b.shape[-2]
+    bshape = a.shape[:-2]
+    a2, nb, s1 = _flatten_batch(a, 2)
+    b2, _, s2 = _flatten_batch(b, 2)
+    if s1 == 0 and nb > 1:                       # an expand()ed x1 with per-batch directions: give every batch its own copy
+        a2, s1 = a.contiguous().reshape(nb, n1, -1), n1 * a.shape[-1]
+    hv = torch.zeros(bshape + (n1, a.shape[-1]), dtype=torch.float64, device=dev)
+    dg = torch.zeros(bshape + (n1, n2), dtype=torch.float64, device=dev) if want_dgrad_out else None
+    mx = torch.zeros(bshape + (n2, a.shape[-1]), dtype=torch.float64, device=dev) if want_mixed else None
+    if hv.numel() == 0 or n2 == 0:
+        return hv.to(out_device), (None if dg is None else dg.to(out_device)), (None if mx is None else mx.to(x2.device))
+    wsb = lib.gabo_spd_ai_backward2_workspace_bytes(nb, n1, n2, d)
+    ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gabo_spd_ai_backward2(a2.data_ptr(), b2.data_ptr(), g.data_ptr(), uu.data_ptr(), hv.data_ptr(), None if dg is None else dg.data_ptr(),
+                                       None if mx is None else mx.data_ptr(), nb, n1, n2, d, s1, s2, n1 * n2, n2, 1, float(beta), int(mode),
+                                       ws.data_ptr(), wsb, status.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "gabo_spd_ai_backward2")
+    _raise_if_not_spd(status, "gabo_spd_ai_backward2")
+    if mx is not None and s2 == 0 and nb > 1:   # x2 was one expand()ed set: its derivative is the sum over the batch
+        mx = mx.reshape(nb, n2, -1).sum(0).expand(bshape + (n2, a.shape[-1]))
+    return hv.to(out_device), (None if dg is None else dg.to(out_device)), (None if mx is None else mx.to(x2.device))
+
+
+class _SpdAiGradFunction(torch.autograd.Function):
+    """The first-order gradient of sum(grad_out * K(x1, x2)) with respect to x1 (wrt = 1) or x2 (wrt = 2) as a differentiable function of
+    (x1, x2, grad_out): the node a second autograd pass runs through (create_graph=True; pymanopt_addons/tools/autodiff/_pytorch.py:103-116
+    builds exact Hessian-vector products that way).  Its own backward is gabo_spd_ai_backward2: the diagonal block of the Hessian, the mixed
+    block and the directional derivative of K for grad_out; for wrt = 2 the same call with the two sets exchanged (d(A, B) = d(B, A)).  Mixed
+    second derivatives with beta are not provided (None)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, grad_out, bval, mode, wrt):
+        ctx.save_for_backward(x1, x2, grad_out)
+        ctx.bval, ctx.mode, ctx.wrt = bval, mode, wrt
+        return spd_ai_backward(x1, x2, grad_out, bval, mode, wrt=wrt).to((x1 if wrt == 1 else x2).dtype)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u):
+        x1, x2, grad_out = ctx.saved_tensors
+        need1, need2, needg = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if ctx.wrt == 1:
+            hv, dg, mx = spd_ai_backward2(x1, x2, grad_out, u, ctx.bval, ctx.mode, want_dgrad_out=needg, want_mixed=need2)
+            d1, d2 = hv, mx
+        else:
+            hv, dg, mx = spd_ai_backward2(x2, x1, grad_out.transpose(-1, -2), u, ctx.bval, ctx.mode, want_dgrad_out=needg, want_mixed=need1)
+            d1, d2 = mx, hv
+            dg = None if dg is None else dg.transpose(-1, -2)
+        return (d1.to(x1.dtype) if need1 else None), (d2.to(x2.dtype) if need2 else None), (dg.to(grad_out.dtype) if needg else None), None, None, None
+
+
 class _SpdAiKernelFunction(torch.autograd.Function):
-    """K(x1, x2; beta) with the HIP forward and the HIP closed-form backward.  First order only (the reference runs
-    the SPD maximiser with approx_hessian=True for the same reason: manifold_optimize.py:198-202)."""
+    """K(x1, x2; beta) with the HIP forward and the HIP closed-form backward.  The gradient with respect to x1 is itself differentiable
+    and so is the one with respect to x2 (in x1, x2 and the upstream gradient: _SpdAiGradFunction), which is what exact Hessian-vector
+    products of a cost built on the kernel need (approx_hessian=False; the reference's SPD examples run with approx_hessian=True,
+    manifold_optimize.py:198-202); the gradient with respect to beta is first order."""
 
     @staticmethod
     def forward(ctx, x1, x2, beta, mode):
@@ -173,14 +240,22 @@ class _SpdAiKernelFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         x1, x2, out, dist = ctx.saved_tensors
         g1 = g2 = gb = None
+        second = torch.is_grad_enabled()              # create_graph=True: this pass is being recorded
+        second = second and (x1.requires_grad or x2.requires_grad or grad_out.requires_grad)
         if ctx.needs_input_grad[0]:
-            g1 = spd_ai_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=1).to(x1.dtype)
+            if second:
+                g1 = _SpdAiGradFunction.apply(x1, x2, grad_out, ctx.bval, ctx.mode, 1)
+            else:
+                g1 = spd_ai_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=1).to(x1.dtype)
         if ctx.needs_input_grad[1]:
-            g2 = spd_ai_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=2).to(x2.dtype)
+            if second:
+                g2 = _SpdAiGradFunction.apply(x1, x2, grad_out, ctx.bval, ctx.mode, 2)
+            else:
+                g2 = spd_ai_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=2).to(x2.dtype)
+        grad_out = grad_out.detach()
         if ctx.needs_input_grad[2]:
             if ctx.mode == _lib.GABO_OUT_GAUSSIAN:
                 gb = -(grad_out * out * dist * dist).sum()      # dK/dbeta = -d^2 K

@@ -84,6 +84,24 @@ int gabo_spd_ai_backward(const double* x1, const double* x2, const double* grad_
                          int64_t go_row_stride, int64_t go_col_stride, double beta, int flags, void* workspace,
                          size_t workspace_bytes, int* status, gabo_stream_t stream);
 
+/* Second-order term of the same kernels with respect to x1: what a SECOND autograd pass through the reference's chain returns
+ * (pymanopt_addons/tools/autodiff/_pytorch.py:103-116 asks torch.autograd.grad of <gradient, vector> for exact Hessian-vector products; the chain
+ * is Riemannian_utils/spd_utils_torch.py:87-120 with symeig(eigenvectors=True) at :110).  With grad_out held fixed and u (batch x n1 x d_vec,
+ * Mandel) a direction for x1:
+ *   hv_x1[b,i,:]       = d/dt grad_x1(x1 + t u)[b,i,:] at t = 0     (the Hessian of sum(grad_out * out) is block diagonal in i)
+ *   d_grad_out[b,i,j]  = <u[b,i,:], d out[b,i,j] / d x1[b,i,:]>     (derivative of <grad_x1, u> with respect to grad_out; NULL to skip; dense)
+ *   mixed_x2[b,j,:]    = d <grad_x1[b], u[b]> / d x2[b,j,:]          (the mixed block; NULL to skip; batch x n2 x d_vec dense - with x2 shared across
+ *                        the batch, stride 0, the caller sums over the batch)
+ * Closed form through second divided differences of t log t on the eigen-decomposition of each pair (csrc/spd_backward2.hip); every
+ * 2 <= d <= GABO_SPD_MAX_DIM, one wave per pair.  grad_out strides as in gabo_spd_ai_backward; x1 is per batch (x1_batch_stride >= n1 * d_vec, or 0
+ * with batch = 1).  The second derivative with respect to x2 alone is this call with the two sets exchanged (the distance is symmetric in its
+ * arguments); mixed derivatives with beta are not provided. */
+size_t gabo_spd_ai_backward2_workspace_bytes(int64_t batch, int64_t n1, int64_t n2, int d);
+int gabo_spd_ai_backward2(const double* x1, const double* x2, const double* grad_out, const double* u, double* hv_x1, double* d_grad_out,
+                          double* mixed_x2, int64_t batch, int64_t n1, int64_t n2, int d, int64_t x1_batch_stride, int64_t x2_batch_stride,
+                          int64_t go_batch_stride, int64_t go_row_stride, int64_t go_col_stride, double beta, int flags, void* workspace,
+                          size_t workspace_bytes, int* status, gabo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Sphere pairwise kernel matrix.
  * Replaces  SphereGaussianKernel.forward / SphereLaplaceKernel.forward   kernel_utils/kernels_sphere.py:71-94,118-134

@@ -44,16 +44,6 @@ def test_c_abi_argument_errors_on_device():
     assert lib.gabo_sphere_from_inner(x.data_ptr(), out.data_ptr(), 4, 1.0, 0, 3, None) == _lib.GABO_ERR_ARG
 
 
-def test_second_derivative_of_spd_kernel_is_refused():
-    """The SPD kernels are first-order only (the reference uses approx_hessian=True for them): asking autograd for a second
-    derivative must fail loudly, not silently return zeros."""
-    x = (torch.rand(3, 3, dtype=torch.float64, device=DEV) + torch.tensor([2., 2, 0], dtype=torch.float64, device=DEV)).requires_grad_(True)
-    k = SpdAffineInvariantGaussianKernel(beta_min=0.5).forward(x, x.detach())
-    (g,) = torch.autograd.grad(k.sum(), x, create_graph=True)
-    with pytest.raises(RuntimeError):
-        torch.autograd.grad(g.sum(), x)
-
-
 def test_device_solve_reports_a_non_spd_start():
     """The single-launch solve writes the device status word like every other entry point: a non-SPD starting matrix raises."""
     from gabotorch_amd import manifolds, models

@@ -21,11 +21,11 @@ def main():
     for src in _build.sources():
         name = os.path.basename(src)
         if name in units:
-            obj = os.path.join(outdir, name[:-4] + ".o")
+            obj = os.path.join(outdir, os.path.splitext(name)[0] + ".o")
             cmd = [_build._hipcc()] + _build.FLAGS + flags + ["-c", src, "-o", obj]
             subprocess.run(cmd, check=True)
         else:
-            obj = os.path.join(_build.OBJ, name[:-4] + ".o")
+            obj = os.path.join(_build.OBJ, os.path.splitext(name)[0] + ".o")
         objs.append(obj)
     lib = os.path.join(_build.PKG, f"libgabo_hip_{tag}.so")
     subprocess.run([_build._hipcc(), "-shared", "-fPIC", f"--offload-arch={_build.ARCH}"] + objs + ["-o", lib], check=True)
