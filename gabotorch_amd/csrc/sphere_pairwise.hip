@@ -9,6 +9,7 @@
 #include "gabo_mirror.hpp"
 #include "gabo_exp_tab256.hpp"
 #include "gabo_sphere_pw_table.hpp"
+#include "gabo_sphere_ktab.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
@@ -169,6 +170,77 @@ __device__ __forceinline__ double sphere_gauss_finish_pw(double ip, const SphPwR
     return __builtin_ldexp(__builtin_fma(e, p, e), ki >> 8);
 }
 
+// ---- round 4: the KERNEL VALUE itself from a piecewise table: no exp per output, 17 + v_rsq_f64 instructions instead of 31 + v_rsq_f64 -------
+// K(v) = exp(-beta Theta(v)), Theta = 4 acos^2, is as smooth in v = cos(theta / 2) as Theta (the only singularity, v = -1, is a unit away from
+// [0, 1]); with 1024 slots of width 1/1024 a degree-5 polynomial per slot reproduces it to the accuracy of the inputs for beta <= 4
+// (tools/sim/gen_sphere_ktab.py: 2.0e-15 against 60-digit arithmetic at beta = 1.29, numpy's own acos^2 / exp chain 3.4e-15).  The table depends on
+// beta, so every block builds its copy at launch (49 KB of LDS, one slot per thread of a 1024-thread block): from the beta-independent Taylor
+// coefficients theta_k(s) of Theta at the slot centres (csrc/gabo_sphere_ktab.hpp, 60-digit generation) by the power-series recurrence of
+// exp(polynomial),  e_0 = exp(p_0),  e_m = (1/m) sum_k k p_k e_(m-k),  p_k = -beta theta_k,  to degree 6, the t^6 term folded into the lower ones
+// by Chebyshev economisation on [-1/2, 1/2] (t^6 ~ (768 t^4 - 72 t^2 + 1) / 2048).  ~75 instructions per thread once, against 14 saved on each of
+// its 64 outputs.  The clamp, the square root and the magic-number slot selection are those of the round-3 epilogue.
+constexpr int kSphKtStride = 6;      // doubles per LDS row: three ds_read_b128 (48 bytes; rows s and s + 16 k share LDS banks)
+constexpr double kSphKtMaxBeta = 4.0;
+struct SphKtRegs {
+    double qmin, qmax, magic;     // SGPRs
+    double scale;                 // VGPR (shares an FMA with the magic number)
+    __device__ __forceinline__ static SphKtRegs load() {
+        SphKtRegs t;
+        t.qmin = kSphPwC[0];
+        t.qmax = kSphPwC[1];
+        t.magic = kSphPwC[7];
+        t.scale = (double)kSphKtScale;
+        asm volatile("" : "+s"(t.qmin), "+s"(t.qmax), "+s"(t.magic));
+        asm volatile("" : "+v"(t.scale));
+        return t;
+    }
+};
+
+// the six coefficients of slot s (one thread): see above.  The base row is loaded separately (the first one at the very top of the kernel,
+// together with the operands: a second dependent round trip to L2 / HBM in front of the block's barrier was a third of the prologue)
+typedef double kt_v2d __attribute__((ext_vector_type(2)));
+struct SphKtBaseRow {
+    kt_v2d b01, b23, b45, b67;
+    __device__ __forceinline__ static SphKtBaseRow load(int s) {
+        const kt_v2d* b = reinterpret_cast<const kt_v2d*>(kSphKtBase + s * kSphKtBaseStride);
+        return SphKtBaseRow{b[0], b[1], b[2], b[3]};
+    }
+};
+__device__ __forceinline__ void sphere_kt_build_row(int s, const SphKtBaseRow& br, double beta, double* __restrict__ kt) {
+    const kt_v2d b01 = br.b01, b23 = br.b23, b45 = br.b45, b67 = br.b67;
+    const double nb = -beta;
+    const double p0 = nb * b01[0];
+    const double q1 = nb * b01[1], q2 = (2.0 * nb) * b23[0], q3 = (3.0 * nb) * b23[1], q4 = (4.0 * nb) * b45[0], q5 = (5.0 * nb) * b45[1],
+                 q6 = (6.0 * nb) * b67[0];
+    const double e0 = exp(p0);
+    const double e1 = q1 * e0;
+    const double e2 = 0.5 * __builtin_fma(q1, e1, q2 * e0);
+    const double e3 = (1.0 / 3.0) * __builtin_fma(q1, e2, __builtin_fma(q2, e1, q3 * e0));
+    const double e4 = 0.25 * __builtin_fma(q1, e3, __builtin_fma(q2, e2, __builtin_fma(q3, e1, q4 * e0)));
+    const double e5 = 0.2 * __builtin_fma(q1, e4, __builtin_fma(q2, e3, __builtin_fma(q3, e2, __builtin_fma(q4, e1, q5 * e0))));
+    const double e6 = (1.0 / 6.0) * __builtin_fma(q1, e5, __builtin_fma(q2, e4, __builtin_fma(q3, e3, __builtin_fma(q4, e2, __builtin_fma(q5, e1, q6 * e0)))));
+    kt_v2d* row = reinterpret_cast<kt_v2d*>(kt + s * kSphKtStride);
+    row[0] = kt_v2d{__builtin_fma(e6, 1.0 / 2048.0, e0), e1};
+    row[1] = kt_v2d{__builtin_fma(e6, -72.0 / 2048.0, e2), e3};
+    row[2] = kt_v2d{__builtin_fma(e6, 768.0 / 2048.0, e4), e5};
+}
+
+__device__ __forceinline__ double sphere_gauss_finish_kt(double ip, const SphKtRegs& g, const double* __restrict__ kt) {
+    const double q = min_raw(max_raw(__builtin_fma(0.5, ip, 0.5), g.qmin), g.qmax);
+    const double v = sqrt_nz_cubic(q);
+    const double kf = __builtin_fma(v, g.scale, g.magic);
+    const double kd = kf - g.magic;
+    const double t = __builtin_fma(v, g.scale, -kd);
+    const char* rowb = reinterpret_cast<const char*>(kt) + __umul24((unsigned)__double2loint(kf), (unsigned)(kSphKtStride * sizeof(double)));
+    const kt_v2d* row = reinterpret_cast<const kt_v2d*>(rowb);
+    const kt_v2d c45 = row[2], c23 = row[1], c01 = row[0];
+    double w = __builtin_fma(c45[1], t, c45[0]);
+    w = __builtin_fma(w, t, c23[1]);
+    w = __builtin_fma(w, t, c23[0]);
+    w = __builtin_fma(w, t, c01[1]);
+    return __builtin_fma(w, t, c01[0]);
+}
+
 // true for NaN, +-inf and magnitudes whose products could overflow: operands of an inner product that may come out NaN
 __device__ __forceinline__ bool sph_suspect(double v) { return !(__builtin_fabs(v) < 1e150); }
 
@@ -215,25 +287,35 @@ constexpr int kSphMaxChunks = 8;
 #define GABO_SPH_PW_EVERY 1
 #endif
 #ifdef GABO_SPH_CLOCKS
-#define GABO_SPH_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#define GABO_SPH_BOUNDS __launch_bounds__(KT ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #else
-#define GABO_SPH_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW ? GABO_SPH_PW_WAVES : 1, 4)))
+#define GABO_SPH_BOUNDS __launch_bounds__(KT ? 1024 : 256) __attribute__((amdgpu_waves_per_eu((PW || KT) ? GABO_SPH_PW_WAVES : 1, 4)))
 #endif
-template <int MODE, bool SCALED = false, int KS = 0, bool NT = false, bool PW = false>
+#ifndef GABO_SPH_KT_EVERY      /* epilogues of the kernel-value table the scheduler may interleave between two scheduling barriers */
+#define GABO_SPH_KT_EVERY 2
+#endif
+constexpr int kSphKtChunks = 4;      // 16-row chunks per block of the KT variant (its LDS copy of the x1 rows)
+template <int MODE, bool SCALED = false, int KS = 0, bool NT = false, bool PW = false, bool KT = false>
 __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks, int chunks,
                                                               double beta, int flags, SphPoly poly) {
-    __shared__ double tab[256];
-    __shared__ double xa[KS > 0 ? 16 * kSphMaxChunks * 4 * KS : 1];
+    static_assert(!KT || (KS > 0 && !PW && MODE == GABO_OUT_GAUSSIAN), "the kernel-value table serves the Gaussian mode with the operands in registers");
+    __shared__ double tab[KT ? 1 : 256];
+    __shared__ double xa[KS > 0 ? 16 * (KT ? kSphKtChunks : kSphMaxChunks) * 4 * KS : 1];
     __shared__ __attribute__((aligned(16))) double pw[PW ? kSphPwSlots * kSphPwStride : 2];
+    __shared__ __attribute__((aligned(16))) double kt[KT ? kSphKtSlots * kSphKtStride : 2];
     const int tid = threadIdx.x;
     SphGauss g;       // requested first: the scalar loads of the coefficients travel together with the kernel arguments
     SphPwRegs gp;
+    SphKtRegs gk;
     MathRegs mt;
-    if constexpr (PW) gp = SphPwRegs::load();
+    if constexpr (KT) gk = SphKtRegs::load();
+    else if constexpr (PW) gp = SphPwRegs::load();
     else if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load<SCALED>(beta, poly);
     else mt = MathRegs::load();
+    SphKtBaseRow kbase;
+    if constexpr (KT) kbase = SphKtBaseRow::load(tid < kSphKtSlots ? tid : kSphKtSlots - 1);       // (blocks are at most kSphKtSlots threads)
     constexpr int kPwN = kSphPwSlots * kSphPwStride, kPwFirst = (kPwN + 255) / 256;       // 650 entries: three per thread of a 256-thread block
     double pwv[kPwFirst];
     if constexpr (PW) {
@@ -307,7 +389,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
         const double* src = x1 + b * s1;
         const int total = rows * dim, step = (int)blockDim.x;
         double tv = 0.0;
-        if constexpr (MODE == GABO_OUT_GAUSSIAN) tv = kExp2Tab256[tid];
+        if constexpr (MODE == GABO_OUT_GAUSSIAN && !KT) tv = kExp2Tab256[tid];
         for (int base = tid; base < total; base += 4 * step) {       // four loads in flight per thread (one round for 64 rows x dim <= 16)
             double stage[4];
             static_for<4>([&](auto ee) {
@@ -319,7 +401,11 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
                 if (k < total) xa[k] = stage[decltype(ee)::value];
             });
         }
-        if constexpr (MODE == GABO_OUT_GAUSSIAN) {
+        if constexpr (KT) {
+            // the block's table of kernel values for this beta: one slot per thread (see sphere_kt_build_row)
+            sphere_kt_build_row(tid, kbase, beta, kt);
+            for (int sl = tid + step; sl < kSphKtSlots; sl += step) sphere_kt_build_row(sl, SphKtBaseRow::load(sl), beta, kt);
+        } else if constexpr (MODE == GABO_OUT_GAUSSIAN) {
             tab[tid] = tv;
             for (int k = tid + step; k < 256; k += step) tab[k] = kExp2Tab256[k];
         }
@@ -335,7 +421,8 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
 #if defined(GABO_SPH_PROBE) && GABO_SPH_PROBE == 1     /* development probe: MFMA + stores only */
         return ip;
 #endif
-        if constexpr (PW) return sphere_gauss_finish_pw(ip, gp, pw, tab);
+        if constexpr (KT) return sphere_gauss_finish_kt(ip, gk, kt);
+        else if constexpr (PW) return sphere_gauss_finish_pw(ip, gp, pw, tab);
         else if constexpr (MODE == GABO_OUT_GAUSSIAN) return sphere_gauss_finish<SCALED>(ip, g, tab);
         else return sphere_finish<MODE>(ip, beta, mt);
     };
@@ -392,6 +479,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
                         // one table-driven epilogue at a time: left alone the scheduler interleaves the whole chunk (8 table reads and ~35
                         // registers per output) and the kernel no longer fits the 128 registers of four waves per SIMD
                         if constexpr (PW && GABO_SPH_PW_BARRIER && ((r * NTILE + decltype(tt)::value + 1) % GABO_SPH_PW_EVERY == 0)) __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (KT && ((r * NTILE + decltype(tt)::value + 1) % GABO_SPH_KT_EVERY == 0)) __builtin_amdgcn_sched_barrier(0);
                     });
                 });
             } else {
@@ -417,7 +505,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
                 if constexpr (sidx == KS - 1) a_cur[sidx] = 4 * sidx + lk >= dim ? 0.0 : a_cur[sidx];
             });
             // PW: two tiles at a time (their MFMAs, then their eight epilogues) - 16 accumulator registers live instead of 32
-            constexpr int GROUP = (PW && GABO_SPH_PW_BARRIER) ? GABO_SPH_PW_GROUP : 4;
+            constexpr int GROUP = ((PW && GABO_SPH_PW_BARRIER) || KT) ? GABO_SPH_PW_GROUP : 4;
             auto form_tiles = [&](auto t0_, auto ntile_) {
                 constexpr int T0 = decltype(t0_)::value, NTILE = decltype(ntile_)::value;
                 static_for<KS>([&](auto ss) {
@@ -433,7 +521,7 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
                 constexpr int T0 = decltype(gg)::value * GROUP;
                 form_tiles(std::integral_constant<int, T0>{}, std::integral_constant<int, GROUP>{});
                 store_tiles(std::integral_constant<int, T0>{}, std::integral_constant<int, GROUP>{});
-                if constexpr (PW && GABO_SPH_PW_BARRIER) __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((PW && GABO_SPH_PW_BARRIER) || KT) __builtin_amdgcn_sched_barrier(0);
             });
             bool suspect = false;
 #ifndef GABO_SPH_NO_NAN_FIXUP     /* A/B: the round-3 kernel (NaN inner products not repaired) */
@@ -582,15 +670,31 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
                            dim, x1_batch_stride, x2_batch_stride, beta, flags);
     } else {
         if (batch > 65535) return GABO_ERR_ARG;
-        int threads = n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64));
+        const int mode = flags & GABO_OUT_MASK;
+        // the usual case: table-driven epilogues; outside it the global polynomial with the clamped exp
+        const bool scaled = mode == GABO_OUT_GAUSSIAN && beta > 1e-30 && beta < 1000.0;
+        // large Gram matrices with beta <= 4: the kernel-value table (sphere_gauss_finish_kt), blocks of 1024 threads that build it once each
+#ifdef GABO_SPH_NO_KT      /* A/B: the round-3 epilogue everywhere */
+        const bool kt = false;
+#else
+        const bool kt = scaled && beta <= gabo::kSphKtMaxBeta && dim <= 16 && n2 >= 1024 && (double)batch * (double)n1 * (double)n2 >= (double)(1 << 22);
+#endif
+        // blocks of the kernel-value table: 1024 threads (one table slot per thread, one block per CU) while the grid is about one round of
+        // the 256 CUs; beyond that two co-resident 512-thread blocks per CU, whose prologues (table build, no stores in flight) overlap each
+        // other's loops (measured, 1024 / 512 threads: N = 4096: 31.1 / 33.0 us, 8192: 142 / 131, 16384: 525 / 470; round-3 epilogue: 36.4 / 141 / 516)
+#ifndef GABO_SPH_KT_THREADS
+#define GABO_SPH_KT_THREADS ((((n2 + 1023) / 1024) * ((n1 + 16 * gabo::kSphKtChunks - 1) / (16 * gabo::kSphKtChunks)) * batch <= 320) ? 1024 : 512)
+#endif
+        const int kt_threads = GABO_SPH_KT_THREADS;
+        int threads = kt ? kt_threads : (n2 >= 256 ? 256 : (n2 > 128 ? 192 : (n2 > 64 ? 128 : 64)));
         int64_t col_blocks = (n2 + threads - 1) / threads;
         // 16-row chunks per block: as many as keep >= 1024 blocks in flight (each wave re-uses its x2 fragments across the chunks)
 #ifndef GABO_SPH_CHUNKS
 #define GABO_SPH_CHUNKS 4
 #endif
         static_assert(GABO_SPH_CHUNKS <= gabo::kSphMaxChunks, "LDS copy of the x1 rows");
-        int chunks = GABO_SPH_CHUNKS;
-        while (chunks > 1 && col_blocks * ((n1 + 16 * chunks - 1) / (16 * chunks)) * batch < 1024) chunks >>= 1;
+        int chunks = kt ? gabo::kSphKtChunks : GABO_SPH_CHUNKS;
+        while (chunks > 1 && col_blocks * ((n1 + 16 * chunks - 1) / (16 * chunks)) * batch < (kt ? 256 * (1024 / kt_threads) : 1024)) chunks >>= 1;
         const int rows = 16 * chunks;
         int64_t row_chunks = (n1 + rows - 1) / rows;
         int64_t tiles_x = col_blocks * row_chunks;
@@ -600,10 +704,7 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
             for (int64_t cg = 0; cg < col_blocks; ++cg) tiles_x += gabo::sym_chunks_of(cg, threads, rows, row_chunks);
         }
         if (tiles_x > 0x7fffffffLL) return GABO_ERR_ARG;
-        const int mode = flags & GABO_OUT_MASK;
         gabo::SphPoly poly = {};
-        // the usual case: piecewise-table epilogue (sphere_gauss_finish_pw); outside it the global polynomial with the clamped exp
-        const bool scaled = mode == GABO_OUT_GAUSSIAN && beta > 1e-30 && beta < 1000.0;
         if (scaled) {
             const double sc = 4.0 * beta, pi = 3.14159265358979311600e+00;
             for (int k = 0; k <= gabo::kSphWDeg; ++k) poly.w[k] = gabo::kSphWHost[k] * sc;
@@ -625,6 +726,20 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
     hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M, SC, K, NT_, GABO_SPH_PW_OF(SC)>), dim3((unsigned)tiles_x, (unsigned)batch),     \
                        dim3(threads), 0, st, x1, x2, out, n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, \
                        chunks, beta, flags, poly)
+#define GABO_SPH_LAUNCH_KT(K, NT_)                                                                                                 \
+    hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<GABO_OUT_GAUSSIAN, true, K, NT_, false, true>), dim3((unsigned)tiles_x, (unsigned)batch), \
+                       dim3(threads), 0, st, x1, x2, out, n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, \
+                       chunks, beta, flags, poly)
+    // (the kernel-value table makes the kernel store-bound, and under the resulting back-pressure streaming stores measured far slower than
+    // plain ones: N = 4096: 43.9 us with `nt`, 31.6 without - tools/ab_sphere.py, round 4)
+#ifndef GABO_SPH_KT_NT
+#define GABO_SPH_KT_NT 0
+#endif
+#define GABO_SPH_LAUNCH_KT_KS(K)                                                                                                   \
+    do {                                                                                                                           \
+        if (streaming && GABO_SPH_KT_NT) GABO_SPH_LAUNCH_KT(K, (GABO_SPH_KT_NT != 0));                                             \
+        else GABO_SPH_LAUNCH_KT(K, false);                                                                                         \
+    } while (0)
 #define GABO_SPH_LAUNCH_KS(M, SC, K)                                                                                               \
     do {                                                                                                                           \
         if (streaming) GABO_SPH_LAUNCH_NT(M, SC, K, true);                                                                         \
@@ -640,13 +755,22 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
             default: GABO_SPH_LAUNCH_KS(M, SC, 0); break;                                                                          \
         }                                                                                                                          \
     } while (0)
-        if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE, false);
+        if (kt) {
+            switch ((dim + 3) / 4) {
+                case 1: GABO_SPH_LAUNCH_KT_KS(1); break;
+                case 2: GABO_SPH_LAUNCH_KT_KS(2); break;
+                case 3: GABO_SPH_LAUNCH_KT_KS(3); break;
+                default: GABO_SPH_LAUNCH_KT_KS(4); break;
+            }
+        } else if (mode == GABO_OUT_DISTANCE) GABO_SPH_LAUNCH(GABO_OUT_DISTANCE, false);
         else if (mode == GABO_OUT_LAPLACE) GABO_SPH_LAUNCH(GABO_OUT_LAPLACE, false);
         else if (scaled) GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, true);
         else GABO_SPH_LAUNCH(GABO_OUT_GAUSSIAN, false);
 #undef GABO_SPH_LAUNCH
 #undef GABO_SPH_LAUNCH_KS
 #undef GABO_SPH_LAUNCH_NT
+#undef GABO_SPH_LAUNCH_KT_KS
+#undef GABO_SPH_LAUNCH_KT
         if (flags & GABO_SYMMETRIC) {
             int tiles = (int)((n1 + 31) / 32);
             hipLaunchKernelGGL((gabo::mirror_upper_kernel<1>), dim3((unsigned)((int64_t)tiles * (tiles + 1) / 2), (unsigned)batch),

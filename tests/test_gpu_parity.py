@@ -169,8 +169,11 @@ def test_spd_not_spd_is_reported():
     good = ospd.symmetric_matrix_to_vector_mandel(np.eye(2)[None])
     with pytest.raises(RuntimeError, match="not positive definite"):
         ops.spd_ai_pairwise(t(bad), t(good))
+    # an indefinite matrix in the SECOND set: the reference factors x1 only - the pair goes through symeig and log and comes out NaN, without an
+    # exception (spd_utils_torch.py:87, 109-120; tests/test_gpu_nan.py)
+    assert bool(torch.isnan(ops.spd_ai_pairwise(t(good), t(bad))).all())
     with pytest.raises(RuntimeError, match="not positive definite"):
-        ops.spd_ai_pairwise(t(good), t(bad))
+        ops.spd_ai_pairwise(t(good), t(np.array([[1.0, float("nan"), 0.0]])))
     with pytest.raises(RuntimeError, match="unsupported dimension"):
         ops.spd_ai_pairwise(t(np.ones((2, 33 * 34 // 2))), t(np.ones((2, 33 * 34 // 2))))
 
@@ -319,3 +322,36 @@ def test_baseline_config2_full_size_properties():
     np.testing.assert_allclose(torch.diagonal(K).cpu().numpy(), np.exp(-(0.6 + np.log(2)) * np.arccos(1 - 1e-15) ** 2), rtol=1e-9)
     np.testing.assert_allclose(K[100:164, 4000:4096].cpu().numpy(), osph.sphere_gaussian_kernel(x[100:164], x[4000:4096], 0.6 + np.log(2)),
                                rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("dim", [3, 7, 10, 16])
+@pytest.mark.parametrize("beta", [0.2, 1.2931471805599454, 4.0, 4.5])
+def test_sphere_large_gram_kernel_value_table(dim, beta):
+    """Gram matrices of >= 4 M outputs with beta <= 4 take the kernel-value table (sphere_gauss_finish_kt: blocks of 1024 threads, no exp per
+    output); beta = 4.5 the round-3 epilogue on the same inputs.  Ragged sizes (partial column block, partial row chunk), the clamp edge
+    cases (identical / antipodal / nearly identical points, kernels_sphere.py:90-94 with sphere_utils_torch.py:53) and the x1-is-x2 build."""
+    rng = np.random.default_rng(dim)
+    n1, n2 = 2050, 2100
+    x1 = rng.standard_normal((n1, dim)); x1 /= np.linalg.norm(x1, axis=1, keepdims=True)
+    x2 = rng.standard_normal((n2, dim)); x2 /= np.linalg.norm(x2, axis=1, keepdims=True)
+    x2[:40] = x1[:40]                                   # identical: d = 4.47e-8
+    x2[40:80] = -x1[40:80]                              # antipodal
+    y = x1[80:120] + 1e-9 * rng.standard_normal((40, dim))
+    x2[80:120] = y / np.linalg.norm(y, axis=1, keepdims=True)
+    want = osph.sphere_gaussian_kernel(x1, x2, beta)
+    got = ops.sphere_pairwise(t(x1), t(x2), beta=beta).cpu().numpy()
+    # (relative to K: at theta -> pi the conditioning of exp(-beta theta^2) in c is 2 beta pi / sqrt(1 - c^2) - numpy's own arccos / exp chain
+    # is only this good there, tools/sim/gen_sphere_ktab.py)
+    np.testing.assert_allclose(got, want, rtol=5e-12, atol=1e-300)
+    ws = osph.sphere_gaussian_kernel(x2, x2, beta)
+    gs = ops.sphere_pairwise(t(x2), t(x2), beta=beta, symmetric=True).cpu().numpy()
+    np.testing.assert_allclose(gs, ws, rtol=5e-12, atol=1e-300)
+    np.testing.assert_array_equal(gs, gs.T)
+    # a NaN row / column in the large build (the repair path of tests/test_gpu_nan.py inside the 1024-thread blocks)
+    x1[1000, dim - 1] = np.nan
+    x2[2000, 0] = np.nan
+    with np.errstate(all="ignore"):
+        wn = osph.sphere_gaussian_kernel(x1, x2, beta)
+    gn = ops.sphere_pairwise(t(x1), t(x2), beta=beta).cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(gn), np.isnan(wn))
+    np.testing.assert_allclose(gn[~np.isnan(wn)], wn[~np.isnan(wn)], rtol=5e-12, atol=1e-300)
