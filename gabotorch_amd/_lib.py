@@ -74,6 +74,8 @@ SIGNATURES = {
     "gabo_spd_ai_backward": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _D, _I, _P, _SZ, _P, _P]),
     "gabo_spd_ai_backward2_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
     "gabo_spd_ai_backward2": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _D, _I, _P, _SZ, _P, _P]),
+    "gabo_nested_spd_gram_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
+    "gabo_nested_spd_gram": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _D, _I, _P, _SZ, _P, _P]),
     "gabo_sphere_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _I, _P]),
     "gabo_sphere_from_inner": (_I, [_P, _P, _I64, _D, _I, _I, _P]),
     "gabo_spd_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P]),

@@ -15,6 +15,7 @@
 #include "gabo_device.hpp"
 #include "lds_linalg.hpp"
 #include "spd_eigvec.hpp"
+#include "spd_project_operator.hpp"
 #include "../../include/gabo_hip.h"
 
 namespace gabo {
@@ -209,24 +210,7 @@ __global__ __launch_bounds__(256) void spd_project_small_kernel(const double* __
     const int Dv = D * (D + 1) / 2;
     double* Wl = lds;                 // D x DL
     double* P = Wl + D * DL;          // DV x Dv
-    for (int e = threadIdx.x; e < D * DL; e += blockDim.x) Wl[e] = w[e];
-    __syncthreads();
-    for (int t = threadIdx.x; t < D * D; t += blockDim.x) {
-        const int r = t / D, c = t - r * D;
-        if (r < c) continue;
-        const int k = r - c, idx = mandel_pos(D, r, c);      // input entry (r, c) sits on sub-diagonal k of the Mandel order
-        static_for<DL>([&](auto kk) {
-            constexpr int ko = decltype(kk)::value;
-            static_for<DL - ko>([&](auto bb) {
-                constexpr int b = decltype(bb)::value, a = b + ko;
-                double coef;
-                if (k == 0) coef = Wl[r * DL + a] * Wl[r * DL + b] * (ko == 0 ? 1.0 : kSqrt2);
-                else coef = __builtin_fma(Wl[r * DL + a], Wl[c * DL + b], Wl[c * DL + a] * Wl[r * DL + b]) * (ko == 0 ? kInvSqrt2 : 1.0);
-                P[mandel_pos(DL, a, b) * Dv + idx] = coef;
-            });
-        });
-    }
-    __syncthreads();
+    build_projection_operator<DL>(w, D, Wl, P);
     const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
     for (int64_t i = (int64_t)blockIdx.x * waves + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * waves) {
         double acc[DV];

@@ -15,6 +15,19 @@
 #include "spd_pairwise_body.hpp"
 
 
+namespace gabo {
+int launch_spd_ai_prepared(int d, double* out, int64_t batch, int64_t n1, int64_t n2, bool shared1, bool shared2, double beta, int flags,
+                           double* ws, hipStream_t st) {
+    const int64_t s1 = shared1 ? 0 : 1, s2 = shared2 ? 0 : 1;
+    switch (d) {
+        case 2: return launch_spd_ai<2>(nullptr, nullptr, out, nullptr, batch, n1, n2, s1, s2, beta, flags, ws, nullptr, st, true);
+        case 3: return launch_spd_ai<3>(nullptr, nullptr, out, nullptr, batch, n1, n2, s1, s2, beta, flags, ws, nullptr, st, true);
+        case 4: return launch_spd_ai<4>(nullptr, nullptr, out, nullptr, batch, n1, n2, s1, s2, beta, flags, ws, nullptr, st, true);
+    }
+    return GABO_ERR_DIM;
+}
+}  // namespace gabo
+
 extern "C" {
 
 size_t gabo_spd_ai_workspace_bytes(int64_t batch, int64_t n1, int64_t n2, int d) {

@@ -526,15 +526,17 @@ __global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __rest
     }
 }
 
+// prepared: the workspace already holds the factors (W for b1 * n1 matrices, then G: the fused projection of the nested kernels wrote them,
+// nested_spd_gram.hip); s1 / s2 then only say whether a set is shared across the batch (0) or not
 template <int D>
 static int launch_spd_ai(const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
-                         int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st) {
+                         int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st, bool prepared = false) {
     constexpr int T = tri_size(D);
     const int64_t b1 = (s1 == 0) ? 1 : batch;  // a shared set is factored once
     const int64_t b2 = (s2 == 0) ? 1 : batch;
     double* W = ws;
     double* G = ws + b1 * n1 * T;
-    launch_spd_prep<D>(x1, x2, W, G, b1, b2, n1, n2, s1, s2, status, st, /*lenient2=*/1);
+    if (!prepared) launch_spd_prep<D>(x1, x2, W, G, b1, b2, n1, n2, s1, s2, status, st, /*lenient2=*/1);
     // tile shape: 64..256 columns per block, `rows` rows per block; keep >= ~8 blocks per CU when the problem allows
     // (d = 10, N = 4096, 8 rows: 256 / 128 / 64 threads per block = 2.57 / 2.56 / 2.55 ms - one-wave blocks: a block's slots are not held until its slowest wave ends; d = 7: 1.25 -> 1.23 ms, d <= 5: no gain)
 #ifndef GABO_PAIR_THREADS
@@ -607,6 +609,9 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
 }  // namespace gabo
 
 namespace gabo {
+// the pairwise launch alone on factors already in the workspace, d = 2 ... 4 (spd_pairwise.hip; called by nested_spd_gram.hip)
+int launch_spd_ai_prepared(int d, double* out, int64_t batch, int64_t n1, int64_t n2, bool shared1, bool shared2, double beta, int flags,
+                           double* ws, hipStream_t st);
 // dimensions 13..16 are instantiated in their own translation unit (spd_pairwise_wide.hip), 17..20 in two more
 int launch_spd_ai_wide2(int d, const double* x1, const double* x2, double* out, double* dist_out, int64_t batch, int64_t n1, int64_t n2,
                         int64_t s1, int64_t s2, double beta, int flags, double* ws, int* status, hipStream_t st);

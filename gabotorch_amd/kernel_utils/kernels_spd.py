@@ -119,9 +119,12 @@ class NestedSpdAffineInvariantGaussianKernel(_BetaKernel):
         if diagonal_distance is True:
             return _diag_ones(x2)
         w = self.projection_matrix.double()
+        beta = self.beta.double()
+        if ops.nested_spd_gram_applicable(x1, x2, w, beta):      # nobody differentiates this evaluation: projection + factorisation in one launch
+            return ops.nested_spd_gram(x1, x2, w, float(beta), _lib.GABO_METRIC_AFFINE_INVARIANT)
         p1 = ops.spd_project_diff(x1, w)
         p2 = p1 if x2 is x1 else ops.spd_project_diff(x2, w)
-        return ops.spd_ai_kernel(p1, p2, self.beta.double(), _lib.GABO_OUT_GAUSSIAN)
+        return ops.spd_ai_kernel(p1, p2, beta, _lib.GABO_OUT_GAUSSIAN)
 
 
 class NestedSpdLogEuclideanGaussianKernel(SpdLogEuclideanGaussianKernel):
@@ -147,6 +150,8 @@ class NestedSpdLogEuclideanGaussianKernel(SpdLogEuclideanGaussianKernel):
         if diagonal_distance is True:
             return _diag_ones(x2)
         w = self.projection_matrix.double()
+        if ops.nested_spd_gram_applicable(x1, x2, w, self.lengthscale):      # projection + logm in one launch, then the Frobenius Gram
+            return ops.nested_spd_gram(x1, x2, w, float(_beta_from_lengthscale(self.lengthscale)), _lib.GABO_METRIC_LOG_EUCLIDEAN)
         p1 = ops.spd_project_diff(x1, w)
         p2 = p1 if x2 is x1 else ops.spd_project_diff(x2, w)
         return super().forward(p1, p2)

@@ -17,6 +17,9 @@ def set_error_checking(flag):
     global _check_errors
     prev = _check_errors
     _check_errors = bool(flag)
+    if _check_errors and not prev:
+        for w in _status_words.values():
+            w.zero_()
     return prev
 
 
@@ -71,6 +74,21 @@ def _require(dev, **tensors):
                             f"{'' if not torch.is_tensor(t) or t.is_contiguous() else ' (not contiguous)'}")
 
 
+_status_words = {}
+
+
+def _status_word(dev):
+    """The device status word of the entry points (two int32: error code, index of the offender), one cached buffer per device: the kernels
+    only ever write it on an error, so it is zeroed when created and again after an error has been raised - not by a fill launch in front
+    of every call (4 us of GPU time next to a 6 us projection, profiles/r03_config5_kernel_stats.csv).  With error checking off nobody
+    reads it; set_error_checking(True) starts from a clean word."""
+    key = (dev.type, dev.index)
+    w = _status_words.get(key)
+    if w is None:
+        w = _status_words[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+    return w
+
+
 def _mandel_dim(dv):
     d = int((-1.0 + (1.0 + 8.0 * dv) ** 0.5) / 2.0)
     if d * (d + 1) // 2 != dv:
@@ -82,6 +100,7 @@ def _raise_if_not_spd(status, what):
     if _check_errors:
         st = status.tolist()
         if st[0] != 0:
+            status.zero_()
             raise RuntimeError(f"{what}: input matrix #{st[1]} is not positive definite (Cholesky pivot <= 0)")
 
 
@@ -105,7 +124,7 @@ def spd_ai_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, symmetric=Fal
         return (out.to(out_device), dist.to(out_device)) if return_dist else out.to(out_device)
     wsb = lib.gabo_spd_ai_workspace_bytes(nb, n1, n2, d)
     ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
-    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    status = _status_word(dev)
     flags = int(mode) | (_lib.GABO_SYMMETRIC if symmetric else 0)
     with torch.cuda.device(dev):
         rc = lib.gabo_spd_ai_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), dist.data_ptr() if return_dist else None,
@@ -772,6 +791,55 @@ def spd_project_diff(x_mandel, w):
     if x_mandel.requires_grad or w.requires_grad:
         return _SpdProject.apply(x_mandel, w)
     return spd_project(x_mandel, w)
+
+
+def nested_spd_gram(x1, x2, w, beta, metric=_lib.GABO_METRIC_AFFINE_INVARIANT, mode=_lib.GABO_OUT_GAUSSIAN):
+    """Gram matrix of the nested SPD kernels in two launches, no gradient (gabo_nested_spd_gram): x1 (..., N1, D_vec), x2 (..., N2, D_vec) Mandel
+    vectors of the ORIGINAL space, w (D, d_latent) with 2 <= d_latent <= 4 -> (..., N1, N2).  metric: _lib.GABO_METRIC_AFFINE_INVARIANT
+    (exp(-beta d_AI^2) of the projected points) or _lib.GABO_METRIC_LOG_EUCLIDEAN (exp(-beta ||logm - logm + 1e-15||_F^2))."""
+    lib = _lib.load()
+    if x1.shape[:-2] != x2.shape[:-2] or x1.shape[-1] != x2.shape[-1]:
+        raise RuntimeError(f"batch/feature shapes differ: {tuple(x1.shape)} vs {tuple(x2.shape)} (no broadcasting, as in the reference)")
+    out_device = x1.device
+    dev = _device_for(x1, x2, w)
+    same = x2 is x1
+    a = _prep(x1, dev).contiguous()
+    b = a if same else _prep(x2, dev).contiguous()
+    W = _prep(w, dev).contiguous()
+    D = _mandel_dim(a.shape[-1])
+    if W.dim() != 2 or W.shape[0] != D:
+        raise RuntimeError(f"projection matrix must be ({D}, d_latent), got {tuple(W.shape)}")
+    dl = int(W.shape[1])
+    n1, n2 = a.shape[-2], b.shape[-2]
+    bshape = a.shape[:-2]
+    nb = 1
+    for k in bshape:
+        nb *= int(k)
+    out = torch.empty(bshape + (n1, n2), dtype=torch.float64, device=dev)
+    if out.numel() == 0:
+        return out.to(out_device)
+    wsb = lib.gabo_nested_spd_gram_workspace_bytes(nb, n1, n2, dl)
+    ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
+    status = _status_word(dev)
+    with torch.cuda.device(dev):
+        rc = lib.gabo_nested_spd_gram(a.data_ptr(), b.data_ptr(), W.data_ptr(), out.data_ptr(), nb, n1, n2, D, dl, int(metric), float(beta), int(mode),
+                                      ws.data_ptr(), wsb, status.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "gabo_nested_spd_gram")
+    _raise_if_not_spd(status, "gabo_nested_spd_gram")
+    return out.to(out_device)
+
+
+def nested_spd_gram_applicable(x1, x2, w, *params):
+    """the fused two-launch Gram serves evaluations that nobody differentiates, latent dimensions 2 ... 4 and dense, equally batched inputs"""
+    if torch.is_grad_enabled() and any(torch.is_tensor(t_) and t_.requires_grad for t_ in (x1, x2, w) + params):
+        return False
+    if w.dim() != 2 or not (2 <= w.shape[1] <= 4) or w.shape[0] > _lib.GABO_SPD_MAX_DIM or x1.dim() < 2 or x1.shape[:-2] != x2.shape[:-2]:
+        return False
+    D = w.shape[0]
+    if x1.shape[-1] != D * (D + 1) // 2 or x2.shape[-1] != x1.shape[-1]:
+        return False
+    dv = w.shape[1] * (w.shape[1] + 1) // 2
+    return (D * w.shape[1] + dv * x1.shape[-1]) * 8 <= 48 * 1024 and (x1.is_cuda or torch.cuda.is_available())
 
 
 def spd_logm_mandel(x_mandel):

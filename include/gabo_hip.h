@@ -177,6 +177,18 @@ int gabo_spd_logm_mandel(const double* x_mandel, double* y_mandel, int64_t n, in
 int gabo_frobenius_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2, int d,
                             int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, gabo_stream_t stream);
 
+/* Gram matrix of the nested SPD kernels in two launches (no gradient): project both point sets (Y = W^T X W, nested_spd_utils.py:13-48) and finish
+ * every latent matrix in the same launch - Cholesky factor / inverse for the affine-invariant kernel, Mandel vector of logm for the log-Euclidean
+ * one - then the Gram launch.  Replaces NestedSpdAffineInvariantGaussianKernel.forward / NestedSpdLogEuclideanGaussianKernel.forward
+ * (kernel_utils/kernels_nested_spd.py:104-136, 191-246) when no gradient is requested.
+ *   x1: batch x n1 x D_vec, x2: batch x n2 x D_vec (Mandel, dense), w: D x dl (row-major), out: batch x n1 x n2; 2 <= dl <= 4, dl <= D <= 32.
+ *   metric: GABO_METRIC_AFFINE_INVARIANT (out = exp(-beta d_AI^2), Laplace / distance with `flags` as in gabo_spd_ai_pairwise, GABO_SYMMETRIC when
+ *           x1 is x2) or GABO_METRIC_LOG_EUCLIDEAN (out = exp(-beta ||logm Y1 - logm Y2 + 1e-15||_F^2), beta = 1 / lengthscale^2).
+ *   x1 == x2 (same pointer, n1 == n2): the set is projected once.  status as in gabo_spd_ai_pairwise (a latent matrix of x1 that is not SPD is reported). */
+size_t gabo_nested_spd_gram_workspace_bytes(int64_t batch, int64_t n1, int64_t n2, int dl);
+int gabo_nested_spd_gram(const double* x1, const double* x2, const double* w, double* out, int64_t batch, int64_t n1, int64_t n2, int D, int dl,
+                         int metric, double beta, int flags, void* workspace, size_t workspace_bytes, int* status, gabo_stream_t stream);
+
 /* Gradients of the two calls above (the reference differentiates them by autograd; kernels_spd.py:238-240,305-311).
  * gabo_spd_logm_mandel_backward: grad_x = Mandel( V ((V^T G V) o F) V^T ), the adjoint Frechet derivative of logm at X applied
  *   to G = grad_y (Mandel), F the divided differences of log at the eigenvalues of X.
