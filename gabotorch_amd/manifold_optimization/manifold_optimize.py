@@ -330,11 +330,17 @@ def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num
                                           post_processing_manifold, options)
         seed = int(torch.randint(0, 2 ** 52, (1,)).item())      # from torch's global generator, like botorch's own multinomial draw
         X_rnd, Y_rnd, seed = _gather_raw_samples(X_loc, Y_loc, total, seed)
-        gen = torch.Generator(device=X_rnd.device)
+        # The selection heuristic is a dozen data-dependent decisions on `total` scalars: on the device every one of them is a launch and a
+        # read-back (0.85 ms of the 4.4-ms config-4 sweep, tools/sweep_phases2.py); here the values come to the host in ONE copy, the heuristic
+        # selects ROW INDICES there (same functions, host generator with the common seed: identical on every rank) and the rows are gathered
+        # on the device.
+        gen = torch.Generator()
         gen.manual_seed(seed)
+        rows = torch.arange(X_rnd.shape[0]).reshape(-1, 1, 1)
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
-            chosen = select(X=X_rnd, Y=Y_rnd, n=num_restarts, generator=gen, **select_kwargs)
+            picked = select(X=rows, Y=Y_rnd.detach().cpu(), n=num_restarts, generator=gen, **select_kwargs)
+        chosen = X_rnd.index_select(0, picked.reshape(-1).to(X_rnd.device))
         if not any(issubclass(w.category, BadInitialCandidatesWarning) for w in caught):
             return chosen
     warnings.warn("Unable to find non-zero acquisition function values - initial conditions are being selected randomly.",
