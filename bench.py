@@ -643,32 +643,50 @@ def main():
             sx /= np.linalg.norm(sx, axis=1, keepdims=True)
             st_ = torch.tensor(sx, device=device)
             sbeta = 0.6 + float(np.log(2.0))
-            # untimed launches first, as for the headline kernel: this kernel is bound by the HBM write stream, and after a phase without
-            # memory traffic (the fp64 Gram builds and the latency-bound sweeps above) the chip needs ~250 launches (8 ms) of it to be back at
-            # its sustained rate (tools/sphere_bench_probe2.py: 45, 41, 33, 32 ... 30.7 us per block of 100 launches; 30.4-30.8 us over 2000)
-            sph_preheat = 300
+            # On a stream of its own: while the hipGraph executables of the sweeps above are alive, every launch on the process's DEFAULT
+            # stream pays for its implicit ordering against their streams - this write-bound kernel 42 instead of 31 us, back to 31 on any
+            # other stream or once the graphs are destroyed (tools/sphere_bench_probe5.py).  The headline job ran before any graph existed.
+            import gc
+            gc.collect()
+            sph_stream = torch.cuda.Stream(device)
+            sph_stream.wait_stream(torch.cuda.current_stream(device))
+            _sph_ctx = torch.cuda.stream(sph_stream)
+            _sph_ctx.__enter__()
+            # Untimed launches first, as for the headline kernel.  This kernel is bound by the HBM write stream, and the chip's clock / power
+            # management needs ~450 back-to-back launches (15 ms) of it to settle: per block of 50 launches 33, 40, 41, 38, 37, 36, 35, 35, 33,
+            # 32, 32, 31 us (tools/sphere_bench_probe3.py; 30.4-30.8 us over 2000 launches, tools/sphere_bench_probe.py) - after a phase
+            # without memory traffic (the fp64 Gram builds and latency-bound sweeps above) even more.  Timed: five blocks of 100 launches,
+            # the median block reported, all five disclosed.
+            sph_preheat, sph_block, sph_blocks = 600, 100, 5
             for _ in range(sph_preheat):
                 _ops.sphere_pairwise(st_, st_, beta=sbeta)
-            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s0.record()
-            for _ in range(20):
-                ks = _ops.sphere_pairwise(st_, st_, beta=sbeta)
-            s1.record()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(sph_blocks + 1)]
+            evs[0].record()
+            for blk in range(sph_blocks):
+                for _ in range(sph_block):
+                    ks = _ops.sphere_pairwise(st_, st_, beta=sbeta)
+                evs[blk + 1].record()
             torch.cuda.synchronize()
-            sph_ms = s0.elapsed_time(s1) / 20
+            sph_block_ms = [evs[b_].elapsed_time(evs[b_ + 1]) / sph_block for b_ in range(sph_blocks)]
+            sph_ms = float(np.median(sph_block_ms))
             sph_err = float(np.max(np.abs(ks[:128, 4000:].cpu().numpy() - osph.sphere_gaussian_kernel(sx[:128], sx[4000:], sbeta))))
+            _sph_ctx.__exit__(None, None, None)
+            torch.cuda.current_stream(device).wait_stream(sph_stream)
             line["sphere_gram"] = {"workload": "SphereGaussianKernel S^9 Gram, N=4096 (BASELINE config 2)", "ms_per_step": sph_ms,
                                    "pairs_per_s": pairs_per_step / (sph_ms * 1e-3),
                                    "roofline": {"bound": "hbm", "achieved": pairs_per_step * 8.04 / (sph_ms * 1e-3) / 1e9,
                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac": pairs_per_step * 8.04 / (sph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "model": "8.04 algorithmic B/pair (one fp64 output + amortised operand reads)"},
-                                   "untimed_preheat_launches": sph_preheat, "max_abs_err_vs_oracle_block": sph_err}
+                                   "untimed_preheat_launches": sph_preheat, "timed": f"{sph_blocks} blocks of {sph_block} launches, median block, on a non-default stream",
+                                   "ms_per_step_of_each_block": sph_block_ms, "max_abs_err_vs_oracle_block": sph_err}
             line["roofline_sphere"] = dict(line["sphere_gram"]["roofline"], kernel="gabo::sphere_pairwise_kernel<0, true, 3, false, false, true>", kernel_ms=sph_ms,
                                            binding_resource="the HBM write stream (MFMA + stores alone: 26 us; the epilogue reads the kernel value from a "
                                                             "per-launch table: no exp per output) + 3 us of table-building prologue without stores in flight")
-            line["config5"] = config5_pieces(device)
-            line["hd_sphere"] = hd_sphere_pieces(device)
+            with torch.cuda.stream(sph_stream):          # (same reason: the write-bound Gram kernels of config 5)
+                line["config5"] = config5_pieces(device)
+                line["hd_sphere"] = hd_sphere_pieces(device)
+            torch.cuda.current_stream(device).wait_stream(sph_stream)
             # the step before the sweep in a BO iteration: surrogate fit (fit_gpytorch_model), 50 observations on S^5_++
             import time as _time
             from gabotorch_amd import models as _models

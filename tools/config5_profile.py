@@ -16,4 +16,6 @@ for _ in range(30):
     k = ops.spd_ai_pairwise(y, y, beta=0.6 + np.log(2))
     lg = ops.spd_logm_mandel(y)
     k2 = ops.frobenius_pairwise(lg, lg, beta=1.0)
+    k3 = ops.nested_spd_gram(x, x, w, 0.6 + np.log(2), 0)          # round 4: projection + factorisation fused, then the Gram launch
+    k4 = ops.nested_spd_gram(x, x, w, 1.0, 8)                      # ... projection + logm fused, then the Frobenius Gram
 torch.cuda.synchronize()

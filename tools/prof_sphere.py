@@ -6,6 +6,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 rng = np.random.default_rng(0)
 s = rng.standard_normal((n, 10)); s /= np.linalg.norm(s, axis=1, keepdims=True)
 s = torch.tensor(s, device="cuda")
-for _ in range(3):
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+for _ in range(reps):
     ops.sphere_pairwise(s, s, beta=1.29)
 torch.cuda.synchronize()

@@ -17,7 +17,8 @@ DST = os.path.join(ROOT, "profiles")
 def main():
     for name in ("bench_kernel_stats.csv", "sphere_kernel_stats.csv", "backward_kernel_stats.csv", "sweep_kernel_stats.csv",
                  "config5_kernel_stats.csv", "bench_under_rocprof.json", "pmc_raw.json", "sweep.log", "backward.log",
-                 "recon_kernel_stats.csv", "recon.log", "hd_gabo_kernel_stats.csv", "hd_gabo.log", "gp_mll_kernel_stats.csv", "gp_mll.log"):
+                 "recon_kernel_stats.csv", "recon.log", "hd_gabo_kernel_stats.csv", "hd_gabo.log", "gp_mll_kernel_stats.csv", "gp_mll.log",
+                 "recon_native_kernel_stats.csv", "recon_native.log", "pmc_sphere.json", "pmc_headline.json", "pmc_tr_solve.json"):
         p = os.path.join(SRC, name)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(DST, f"{RND}_{name}"))
