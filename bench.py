@@ -132,8 +132,9 @@ def cpu_baseline(x):
                             "sample": f"first {rows_all} Gram rows ({rows_all * x.shape[0]} pairs, {dta:.1f} s)"},
             "vectorised_numpy_pairs_per_s": vrows * x.shape[0] / dtv,
             "sample": f"first {rows} of {x.shape[0]} Gram rows x all {x.shape[0]} columns ({rows * x.shape[0]} pairs, {dt:.1f} s): "
-                      "oracle.spd.affine_invariant_distance_faithful = the reference's op sequence (Mandel->matrix, Cholesky, "
-                      "inverse, two bmm, one torch.linalg.eigh per pair in a Python loop, exp), torch CPU fp64, one thread (the loop is scalar)",
+                      "oracle.spd.affine_invariant_distance_faithful = the reference's op sequence (Mandel->matrix by its per-vector Python loop, "
+                      "Cholesky, inverse, two bmm, one torch.linalg.eigh per pair in a Python loop, exp), torch CPU fp64, one thread (the loop is "
+                      "scalar); the reference itself on this input, build container, 8 threads: 3.74e4 pairs/s (profiles/r04_reference_cpu.json)",
             "host_cpus": ncpu}, k
 
 

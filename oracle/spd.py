@@ -41,6 +41,27 @@ def vector_to_symmetric_matrix_mandel(v):
     return m
 
 
+def vector_to_symmetric_matrix_mandel_faithful(v):
+    """The same map with the reference's OP SEQUENCE (spd_utils_torch.py:172-194): a Python loop over the vectors, each matrix assembled
+    from its diagonals (one diagonal-matrix construction and addition per off-diagonal, above and below).  Used by the `cpu_baseline` leg of
+    bench.py only, so that the timed port spends its time where the reference does; same values as the vectorised
+    statement above (tests/test_oracle_properties.py)."""
+    import torch
+    vectors = torch.as_tensor(np.asarray(v, dtype=np.float64)).reshape(-1, np.shape(v)[-1])
+    d = mandel_dim(vectors.shape[1])
+    bounds = np.cumsum(range(d, 0, -1))
+    out = torch.zeros(vectors.shape[0], d, d, dtype=torch.float64)
+    for n in range(vectors.shape[0]):
+        row = vectors[n]
+        mat = torch.diag(row[0:d])
+        for i in range(d - 1):
+            seg = row[int(bounds[i]):int(bounds[i + 1])]
+            mat = mat + torch.diag(seg, i + 1) / SQRT2
+            mat = mat + torch.diag(seg, -i - 1) / SQRT2
+        out[n] = mat
+    return out.numpy().reshape(tuple(np.shape(v)[:-1]) + (d, d))
+
+
 def symmetric_matrix_to_vector_mandel(m):
     """(..., d, d) -> (..., d_vec); off-diagonals sqrt(2) * mean(upper, lower)   (spd_utils_torch.py:197-226, :219)."""
     m = np.asarray(m, dtype=np.float64)
@@ -103,8 +124,9 @@ def affine_invariant_distance_faithful(x1, x2):
 
 def spd_ai_gaussian_kernel(x1_mandel, x2_mandel, beta, diagonal_distance=False, faithful=False):
     """K = exp(-beta d^2) from Mandel inputs   (kernel_utils/kernels_spd.py:72-100)."""
-    m1 = vector_to_symmetric_matrix_mandel(x1_mandel)
-    m2 = vector_to_symmetric_matrix_mandel(x2_mandel)
+    to_matrix = vector_to_symmetric_matrix_mandel_faithful if faithful else vector_to_symmetric_matrix_mandel
+    m1 = to_matrix(x1_mandel)
+    m2 = to_matrix(x2_mandel)
     if faithful and not diagonal_distance:
         dist = affine_invariant_distance_faithful(m1, m2)
     else:

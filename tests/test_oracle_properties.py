@@ -89,3 +89,14 @@ def test_gp_mll_oracle_known_answers():
             dn[k] -= h
             fd = (ogp.marginal_log_likelihood(e, y, *up)[0] - ogp.marginal_log_likelihood(e, y, *dn)[0]) / (2 * h)
             np.testing.assert_allclose(g[k], fd, rtol=2e-6, atol=1e-7)
+
+
+def test_faithful_mandel_loop_equals_the_vectorised_map():
+    """the per-vector loop the cpu_baseline leg times (spd_utils_torch.py:172-194: it DIVIDES by 2**0.5) and the vectorised statement (which
+    multiplies by the reciprocal): the same matrices to an ulp"""
+    rng = np.random.default_rng(11)
+    for d in (2, 5, 10):
+        v = rng.standard_normal((7, d * (d + 1) // 2))
+        np.testing.assert_allclose(ospd.vector_to_symmetric_matrix_mandel_faithful(v), ospd.vector_to_symmetric_matrix_mandel(v), rtol=3e-16, atol=0)
+    vb = rng.standard_normal((2, 3, 6))
+    assert ospd.vector_to_symmetric_matrix_mandel_faithful(vb).shape == (2, 3, 3, 3)
