@@ -106,11 +106,304 @@ __device__ __forceinline__ void wave_tridiagonalize(lds_f64* A, lds_f64* refl, l
     e[DP - 1] = 0.0;
 }
 
+// ---- round 4: one LANE GROUP per eigenvalue instead of the wave-serial QL recurrence ---------------------------------------------------------
+// The QL phase of wave_eigh is one dependent chain (~19 instructions per rotation, ~1.7 d^2 / 2 rotations: 81 k of the 118 k cycles at d = 20)
+// executed redundantly by every lane.  Here the d eigenpairs of the tridiagonal matrix T are found side by side:
+//   0. T is scaled by a power of two (exactly) to |T| in [1/2, 1): the thresholds below are plain numbers and the Sturm sequence cannot overflow;
+//   1. every eigenvalue gets m = 64 / d lanes; a few passes of multisection on the Sturm count of T - x I (each lane counts at its own abscissa:
+//      one pass cuts every bracket (m + 1)-fold; the count is the number of sign changes of the three-term recurrence of the leading minors -
+//      ONE dependent FMA per row, no division) put eigenvalue k into a bracket of <= 6e-5;
+//   2. brackets that are not separated from their neighbours by their own width get up to 8 more passes; what is still crowded then (repeated
+//      eigenvalues, clusters below 2e-9) sends the whole matrix to the QL path - one wave holds one matrix, so the decision is wave-uniform;
+//   3. Rayleigh-quotient iteration per lane from the bracket's midpoint (pivoted LU of T - mu I with the forward substitution fused in, back
+//      substitution, Rayleigh quotient).  A lane is done when the residual |T z - rq z| of its pair, computed explicitly, is below 2^-50
+//      (floor of the fp64 evaluation: ~3e-16).  Typically 3 solves.  Safety net, independent of every count above: the brackets are disjoint (step 2), every quotient ends INSIDE its
+//      own bracket and every pair has a rounding-level residual - d such pairs are all the eigenpairs; anything else falls back to QL;
+//   4. each lane pushes ITS vector through the reflectors (wave-uniform LDS reads), the vectors go to V;
+//   5. eigenvectors computed independently are orthogonal to eps / gap only, and a matrix FUNCTION sum f_k v_k v_k^T does not forgive that:
+//      one Newton-Schulz step of the polar decomposition, V <- V (3 I - V^T V) / 2, restricted to the columns whose eigenvalues lie within
+//      GABO_EIGH_RQI_ORTH_GAP of each other (a wave-uniform window of the sorted spectrum), squares the defect; two steps below a gap of 1e-6.
+//      (The residual of a corrected vector stays at rounding level: the admixture of a neighbour is eps / gap, its residual against the
+//      other eigenvalue is the gap.)
+// Returns false when the QL path has to take over (V and the diagonal of A are untouched then; td holds T * scale, `unscale` = 1 / scale).
+#ifndef GABO_EIGH_RQI_MAX_DP
+#define GABO_EIGH_RQI_MAX_DP 24     /* above: the per-lane state no longer fits the register file (and the compile time explodes) */
+#endif
+#ifndef GABO_EIGH_RQI_EXTRA_PASSES
+#define GABO_EIGH_RQI_EXTRA_PASSES 1      /* one more pass (~1 k cycles) usually saves the fourth solve (~4 k): tools/ubench_eigh.hip */
+#endif
+#ifndef GABO_EIGH_RQI_ORTH_GAP
+#define GABO_EIGH_RQI_ORTH_GAP 0.03
+#endif
+template <int DP>
+__device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_f64* refl, lds_f64* td, int d, const double (&ihh)[DP >= 3 ? DP - 2 : 1],
+                                              double& unscale) {
+    // td: the tridiagonal matrix in LDS (td[i] = diagonal, td[DP + i] = off-diagonal e_i between i and i + 1; wave-uniform broadcast reads: the
+    // per-lane state below - the vector and the LU factors of T - mu I - is what the registers are for)
+    lds_f64* te = td + DP;
+    const int lane = threadIdx.x & 63;
+    const int pad = DP - d;                                // 0 ... 3 leading identity rows, decoupled (e[pad - 1] = 0): skipped below
+    const int m = 64 / d;                                  // lanes per eigenvalue, 2 ... 7 (d >= 9)
+    const int graw = lane / m;
+    const bool spare = graw >= d;                          // lanes beyond the last group compute along with it; their votes are outside every group's mask
+    const int grp = spare ? d - 1 : graw;
+    const int j = spare ? 0 : lane - grp * m;
+    const int leader = grp * m;
+    unscale = 1.0;
+    // ---- Gershgorin bracket of the active block
+    double gl = 0.0, gu = 0.0;
+    static_for<DP>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const double off = __builtin_fabs(te[i]) + (i > 0 ? __builtin_fabs(te[i > 0 ? i - 1 : 0]) : 0.0);     // (e[pad - 1] = 0, e[DP - 1] = 0)
+        const double di = td[i];
+        const double lo_i = di - off, hi_i = di + off;
+        gl = (i == pad || (i > pad && lo_i < gl)) ? lo_i : gl;
+        gu = (i == pad || (i > pad && hi_i > gu)) ? hi_i : gu;
+    });
+    const double tnorm = __builtin_fmax(__builtin_fabs(gl), __builtin_fabs(gu));
+    if (!(tnorm > 1e-290) || !(tnorm < 1e290)) return false;         // zero matrix, NaN, extreme scales: the QL path
+    int ex;
+    (void)frexp(tnorm, &ex);
+    const double scale = ldexp(1.0, -ex);
+    unscale = ldexp(1.0, ex);
+    wave_lds_order();
+    if (lane < DP) {
+        // (the identity rows in front of the matrix become eigenvalues 4 above the scaled spectrum: the loops below run over all DP rows
+        // without a branch, the counts below x < 1 and the vectors - zero in those rows - do not see them)
+        td[lane] = lane < pad ? 4.0 : td[lane] * scale;
+        te[lane] = lane < pad ? 0.0 : te[lane] * scale;
+    }
+    wave_lds_order();
+    // T in registers from here on (wave-uniform values in vector registers: left to the scheduler, every row of the loops below would
+    // wait for its own LDS read)
+    double ta[DP], tb[DP], tb2[DP];
+    static_for<DP>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        ta[i] = td[i];
+        tb[i] = te[i];
+    });
+    static_for<DP>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        tb2[i] = (i == 0) ? 0.0 : -(tb[i > 0 ? i - 1 : 0] * tb[i > 0 ? i - 1 : 0]);
+    });
+    double lo = gl * scale - 2e-15, hi = gu * scale + 2e-15;
+    const double inv = 1.0 / (double)(m + 1);
+    const double frac = (double)(j + 1) * inv;
+    const unsigned long long gmask = (1ull << m) - 1ull;
+    const int passes = (m == 2 ? 9 : (m == 3 ? 7 : (m <= 5 ? 6 : 5))) + GABO_EIGH_RQI_EXTRA_PASSES;       // (m + 1)^passes >= 15625
+    const int nxt = (grp + 1 < d ? grp + 1 : grp) * m;
+    bool isolated = false;
+    int npass = 0, nsolve = 0;        // (instrumentation: tools/ubench_eigh.hip)
+    // (no bracket narrower than ~2e-9: eigenvalues closer than that are left to the QL path - their computed vectors mix by residual / gap,
+    // more than the two Newton-Schulz steps of step 5 take out)
+    const int pass_cap = m == 2 ? 19 : (m == 3 ? 15 : (m == 4 ? 13 : (m <= 6 ? 11 : 10)));
+    const int pass_end = passes + 8 < pass_cap ? passes + 8 : pass_cap;
+    for (int pass = 0; pass < pass_end; ++pass) {
+        ++npass;
+        const double w = hi - lo;
+        const double x = __builtin_fma(w, frac, lo);
+        // sign changes of p_0 = 1, p_i = (a_i - x) p_(i-1) - e_(i-1)^2 p_(i-2) = eigenvalues below x; |p_i| <= 5^i.  The signs are shifted
+        // into one word, newest at bit 0: four instructions per row.  (A p_i that is exactly zero should take the sign opposite to its
+        // predecessor's; it takes the sign of its zero instead - a count that is off by one misplaces a bracket, which step 3's safety net
+        // catches.)
+        double pm2 = 1.0, pm1 = 1.0;
+        unsigned signs = 0u;
+        static_for<DP>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const double p = __builtin_fma(ta[i] - x, pm1, tb2[i] * pm2);
+            signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(p), 31);
+            pm2 = pm1;
+            pm1 = p;
+        });
+        const int cnt = __builtin_popcount(signs ^ (signs >> 1));       // (bit DP would be the sign of p_0: 0)
+        const unsigned long long above = __builtin_amdgcn_ballot_w64(cnt >= grp + 1);      // x lies above eigenvalue `grp` (0-based, ascending)
+        const unsigned mine = (unsigned)((above >> leader) & gmask);
+        const int first = mine ? __builtin_ctz(mine) : m;
+        const double nlo = first == 0 ? lo : __builtin_fma(w, (double)first * inv, lo);
+        const double nhi = first == m ? hi : __builtin_fma(w, (double)(first + 1) * inv, lo);
+        lo = nlo;
+        hi = nhi;
+        if (pass + 1 >= passes) {
+            const double lo_next = __shfl(lo, nxt, 64);
+            const bool crowded = !spare && grp + 1 < d && !(lo_next - hi >= hi - lo);
+            if (__builtin_amdgcn_ballot_w64(crowded) == 0) { isolated = true; break; }
+        }
+    }
+    GABO_EIGH_TICK(4);
+    if (!isolated) return false;
+    // ---- Rayleigh-quotient iteration on T (every lane for the eigenvalue of its group)
+    constexpr double tiny = 1.2e-16;
+    double z[DP];
+    static_for<DP>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        z[i] = (i < pad) ? 0.0 : 1.0 + 0.25 * (double)((i * 7) % 5);
+    });
+    double mu = 0.5 * (lo + hi), rho = mu;
+    bool done = false, conv = false;
+    for (int it = 0; it < 7; ++it) {
+        ++nsolve;
+        // pivoted LU of T - mu I, the forward substitution applied to z on the way (rows of U: 1 / u0, u1, [e_(k+1) where rows were interchanged])
+        double iu0[DP], u1[DP];
+        unsigned swm = 0u;
+        double cu = ta[0] - mu, cv = tb[0];
+        static_for<DP - 1>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const double ck = tb[k];
+            const double an = ta[k + 1] - mu, bn = tb[k + 1];         // (e[DP - 1] = 0)
+            const bool swp = __builtin_fabs(ck) > __builtin_fabs(cu);
+            double piv = swp ? ck : cu;
+            const double other = swp ? cu : ck;
+            piv = (__builtin_fabs(piv) < tiny) ? copysign_d(tiny, piv) : piv;
+            const double ip = rcp(piv);
+            const double mult = other * ip;
+            const double ux = swp ? an : cv, uy = swp ? cv : an;      // the pivot row's superdiagonal entry and the entry below it
+            iu0[k] = ip;
+            u1[k] = ux;
+            swm |= swp ? (1u << k) : 0u;
+            cu = __builtin_fma(-mult, ux, uy);
+            cv = (swp ? -mult : 1.0) * bn;
+            const double yk = z[k], yn = z[k + 1];
+            const double zx = swp ? yn : yk, zy = swp ? yk : yn;
+            z[k] = zx;
+            z[k + 1] = __builtin_fma(-mult, zx, zy);
+        });
+        cu = (__builtin_fabs(cu) < tiny) ? copysign_d(tiny, cu) : cu;
+        iu0[DP - 1] = rcp(cu);
+        static_for_down<DP - 1, 0>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            double acc = z[k];
+            if constexpr (k + 1 < DP) acc = __builtin_fma(-u1[k + 1 < DP ? k : 0], z[k + 1 < DP ? k + 1 : k], acc);
+            if constexpr (k + 2 < DP) acc = __builtin_fma(((swm >> k) & 1u) ? -tb[k + 1 < DP ? k + 1 : k] : 0.0, z[k + 2 < DP ? k + 2 : k], acc);
+            z[k] = acc * iu0[k];
+        });
+        double nn = 0.0, big = 0.0;
+        static_for<DP>([&](auto ii) { big = __builtin_fmax(big, __builtin_fabs(z[decltype(ii)::value])); });
+        const double sc = rcp(big);                                                      // (against overflow of the squares)
+        static_for<DP>([&](auto ii) { z[decltype(ii)::value] *= sc; nn = __builtin_fma(z[decltype(ii)::value], z[decltype(ii)::value], nn); });
+        const double inr = rsqrt_nz(nn);
+        static_for<DP>([&](auto ii) { z[decltype(ii)::value] *= inr; });
+        // Rayleigh quotient of the normalised vector - the eigenvalue, and the next shift while it stays with its bracket - and the residual
+        // |T z - rq z| of the pair: a lane is done when that is at rounding level (|T| < 1)
+        double tz[DP];
+        double rq0 = 0.0, rq1 = 0.0;
+        static_for<DP>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            double acc = ta[i] * z[i];
+            if constexpr (i > 0) acc = __builtin_fma(tb[i > 0 ? i - 1 : 0], z[i > 0 ? i - 1 : 0], acc);
+            if constexpr (i + 1 < DP) acc = __builtin_fma(tb[i], z[i + 1 < DP ? i + 1 : i], acc);
+            tz[i] = acc;
+            if constexpr (i % 2 == 0) rq0 = __builtin_fma(acc, z[i], rq0); else rq1 = __builtin_fma(acc, z[i], rq1);
+        });
+        const double rq = rq0 + rq1;
+        double rs0 = 0.0, rs1 = 0.0;
+        static_for<DP>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const double ri = __builtin_fma(-rq, z[i], tz[i]);
+            if constexpr (i % 2 == 0) rs0 = __builtin_fma(ri, ri, rs0); else rs1 = __builtin_fma(ri, ri, rs1);
+        });
+        done = done || (rs0 + rs1 <= 0x1p-100);
+        rho = rq;
+        mu = (rho >= lo && rho <= hi) ? rho : mu;
+        if (__builtin_amdgcn_ballot_w64(!done && !spare) == 0) { conv = true; break; }
+    }
+    GABO_EIGH_TICK(5);
+    if (!conv || __builtin_amdgcn_ballot_w64(!spare && !(rho >= lo && rho <= hi)) != 0) return false;
+    // ---- back to the original basis: this lane's vector through H_pad ... H_(DP-3), last reflector first
+    static_for_down<DP - 3, 0>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        if constexpr (k < 3) { if (k < pad) return; }
+        const lds_f64* uk = refl + ((k - pad) * d - pad);
+        double u[DP - k - 1];
+        static_for<DP - k - 1>([&](auto jj) { u[decltype(jj)::value] = uk[k + 1 + decltype(jj)::value]; });
+        __builtin_amdgcn_sched_barrier(0);
+        double t0 = 0.0, t1 = 0.0;
+        static_for<DP - k - 1>([&](auto jj) {
+            constexpr int q = decltype(jj)::value;
+            if constexpr (q % 2 == 0) t0 = __builtin_fma(z[k + 1 + q], u[q], t0); else t1 = __builtin_fma(z[k + 1 + q], u[q], t1);
+        });
+        const double t = (t0 + t1) * ihh[k];
+        static_for<DP - k - 1>([&](auto jj) {
+            constexpr int q = decltype(jj)::value;
+            z[k + 1 + q] = __builtin_fma(-t, u[q], z[k + 1 + q]);
+        });
+    });
+    GABO_EIGH_TICK(6);
+    wave_lds_order();                                       // every lane is done with the reflectors: V may be overwritten
+    const bool writer = !spare && j == 0;
+    if (writer) {
+        static_for<DP>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if (c >= pad) V[(c - pad) * d + grp] = z[c];
+        });
+        A[grp * d + grp] = rho * unscale;
+    }
+    wave_lds_order();
+    // ---- Newton-Schulz step(s) against the columns whose eigenvalues are close: a window of the sorted spectrum, the same for every group
+    int win = 0;
+    double gap_min = 1.0;
+    for (int k = 1; k < d; ++k) {
+        const bool has = !spare && grp + k < d;
+        const double other = __shfl(rho, (has ? grp + k : grp) * m, 64);
+        const bool near = has && other - rho < GABO_EIGH_RQI_ORTH_GAP;
+        if (k == 1) gap_min = has ? other - rho : 1.0;
+        if (__builtin_amdgcn_ballot_w64(near) == 0) break;
+        win = k;
+    }
+#ifdef GABO_EIGH_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.x == 0) gabo_eigh_clk[7] = npass * 10000 + nsolve * 100 + win;
+#endif
+    const int ns_steps = win == 0 ? 0 : (__builtin_amdgcn_ballot_w64(gap_min < 1e-6) != 0 ? 2 : 1);
+    for (int ns = 0; ns < ns_steps; ++ns) {
+        double zn[DP];
+        {
+            double g0 = 0.0, g1 = 0.0;
+            static_for<DP>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                if constexpr (r % 2 == 0) g0 = __builtin_fma(z[r], z[r], g0); else g1 = __builtin_fma(z[r], z[r], g1);
+            });
+            const double cf = 0.5 * (3.0 - (g0 + g1));
+            static_for<DP>([&](auto rr) { zn[decltype(rr)::value] = cf * z[decltype(rr)::value]; });
+        }
+        for (int o = -win; o <= win; ++o) {
+            if (o == 0) continue;
+            const int col = grp + o;
+            const bool ok = col >= 0 && col < d;
+            const lds_f64* vc = V + (ok ? col : grp);
+            double cv[DP];
+            static_for<DP>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                cv[r] = 0.0;
+                if constexpr (r < 3) { if (r < pad) return; }
+                cv[r] = vc[(r - pad) * d];
+            });
+            __builtin_amdgcn_sched_barrier(0);      // (all reads of the column in flight before the first use: the scheduler would pair each with its FMA)
+            double g0 = 0.0, g1 = 0.0;
+            static_for<DP>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                if constexpr (r % 2 == 0) g0 = __builtin_fma(z[r], cv[r], g0); else g1 = __builtin_fma(z[r], cv[r], g1);
+            });
+            const double cf = ok ? -0.5 * (g0 + g1) : 0.0;
+            static_for<DP>([&](auto rr) { zn[decltype(rr)::value] = __builtin_fma(cf, cv[decltype(rr)::value], zn[decltype(rr)::value]); });
+        }
+        static_for<DP>([&](auto rr) { z[decltype(rr)::value] = zn[decltype(rr)::value]; });
+        wave_lds_order();                                   // all reads of the old columns are done
+        if (writer) {
+            static_for<DP>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if (c >= pad) V[(c - pad) * d + grp] = z[c];
+            });
+        }
+        wave_lds_order();
+    }
+    return true;
+}
+
 // A (d x d, symmetric, row-major, LDS): on return its DIAGONAL holds the eigenvalues (unordered; the rest of A is left as it was);
-// V (d x d, LDS, may be null: eigenvalues only): eigenvectors in columns; bc: kWaveEighScratch doubles of LDS.  DP - 3 <= d <= DP.
+// V (d x d, LDS, may be null: eigenvalues only): eigenvectors in columns; bc: kWaveEighScratch doubles of LDS.  DP - 3 <= d <= DP (DP = 8: 2 <= d <= 8).
 // Called by all 64 lanes of one wave (any other waves of the block wait at the caller's barrier).
 template <int DP>
-__device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_f64* bc, int d) {
+__device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_f64* bc, int d_arg) {
+    const int d = __builtin_amdgcn_readfirstlane(d_arg);      // (arguments of a function arrive in vector registers: every branch on the padding would be an exec-mask branch)
     const int lane = threadIdx.x & 63;
     const int pad = DP - d;
     const int ra = lane - pad;
@@ -120,6 +413,34 @@ __device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_
     lds_f64* refl = V;                                    // overwritten by Z at the end
     wave_tridiagonalize<DP>(A, refl, bc, d, dg, e, ihh);
     GABO_EIGH_TICK(1);
+#ifndef GABO_EIGH_NO_RQI
+    // (d <= 8: the QL chain is short - 17 k cycles at d = 5 against 26 k for this route, tools/ubench_eigh.hip)
+    if constexpr (DP >= 12 && DP <= GABO_EIGH_RQI_MAX_DP) {
+        if (V != nullptr) {
+            // the tridiagonal matrix goes to the (now free) scratch in LDS: the lane-group solver reads it from there, its registers hold per-lane
+            // state; on the way back to the QL path it is read again
+            if (lane < DP) {
+                double dv = 0.0, ev = 0.0;
+                static_for<DP>([&](auto cc) { dv = (lane == decltype(cc)::value) ? dg[decltype(cc)::value] : dv; ev = (lane == decltype(cc)::value) ? e[decltype(cc)::value] : ev; });
+                bc[lane] = dv;
+                bc[DP + lane] = ev;
+            }
+            wave_lds_order();
+            double unscale;
+            if (wave_eigh_rqi<DP>(A, V, refl, bc, d, ihh, unscale)) {
+                GABO_EIGH_TICK(2);
+                GABO_EIGH_TICK(3);
+                return;
+            }
+            // (the scaling is a power of two: exact both ways)
+            static_for<DP>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                dg[c] = c < pad ? 1.0 : bc[c] * unscale;
+                e[c] = c < pad ? 0.0 : bc[DP + c] * unscale;
+            });
+        }
+    }
+#endif
     // row `lane` of Q = H_pad ... H_{DP-3}: e_lane^T pushed through the reflectors in order
     double z[DP];
     static_for<DP>([&](auto cc) { z[decltype(cc)::value] = (lane == decltype(cc)::value) ? 1.0 : 0.0; });
@@ -141,7 +462,35 @@ __device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_
         });
     }
     GABO_EIGH_TICK(2);
+    // The QL iteration deflates from the top of T and wants the SMALL end of a graded matrix there (LAPACK's dsteqr picks QL or QR by the same
+    // comparison of the two ends); with the large end on top, a cluster of small eigenvalues exhausts the 60 iterations of a stage
+    // (tests/test_gpu_manifold_ops.py::test_lane_group_eigen_solver_on_many_spectra, graded matrices: 5e-10 |A| before).  T is reversed
+    // then - J T J, the columns of Q with it - and the result reversed back.
+    constexpr int kMaxPad = DP == 8 ? 6 : 3;             // (wave_eigh_any: the smallest padded order; orders 2 ... 4 come from spd_backward2.hip)
+    double d_top = dg[0];
+    static_for<kMaxPad>([&](auto ii) { d_top = (pad == decltype(ii)::value + 1) ? dg[decltype(ii)::value + 1] : d_top; });
+    const bool reversed = __builtin_fabs(d_top) > __builtin_fabs(dg[DP - 1]);
+    // (only the active block is reversed: the identity rows of the padding stay in front, where their stages deflate at once)
+    auto flip = [&](auto pp, bool with_e) {
+        constexpr int P = decltype(pp)::value;
+        static_for<(DP - P) / 2>([&](auto ii) {
+            constexpr int i = P + decltype(ii)::value, j = DP - 1 - decltype(ii)::value;
+            const double t0 = dg[i]; dg[i] = dg[j]; dg[j] = t0;
+            const double t1 = z[i]; z[i] = z[j]; z[j] = t1;
+        });
+        if (with_e) {
+            static_for<(DP - 1 - P) / 2>([&](auto ii) {
+                constexpr int i = P + decltype(ii)::value, j = DP - 2 - decltype(ii)::value;
+                const double t0 = e[i]; e[i] = e[j]; e[j] = t0;
+            });
+        }
+    };
+    auto flip_any = [&](bool with_e) {
+        static_for<kMaxPad + 1>([&](auto pp) { if (pad == decltype(pp)::value) flip(pp, with_e); });
+    };
+    if (reversed) flip_any(true);
     tridiag_ql_vectors<DP, 1>(dg, e, z);
+    if (reversed) flip_any(false);
     GABO_EIGH_TICK(3);
     wave_lds_order();
     if (V != nullptr && own) {

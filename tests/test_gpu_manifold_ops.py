@@ -277,3 +277,47 @@ def test_wave_eigen_solver_on_degenerate_and_scaled_inputs(d):
     lt, vt = np.linalg.eigh(tangent)
     err = worst(ops.spd_manifold_op(_lib.GABO_SPD_EXPM, t(tangent)).cpu().numpy(), np.einsum("nab,nb,ncb->nac", vt, np.exp(lt), vt), np.exp(lt.max(axis=1)))
     assert err.max() < 1e-13, err
+
+
+@pytest.mark.parametrize("d", [5, 8, 9, 12, 14, 16, 17, 20, 23, 24, 28, 32])
+def test_lane_group_eigen_solver_on_many_spectra(d):
+    """Round 4: for orders 9 ... 24 the eigenpairs come from the lane-group solver of csrc/wave_eigh.hpp (multisection on Sturm counts,
+    Rayleigh-quotient iteration per lane, windowed Newton-Schulz step), with the QL path as its fallback.  1200 matrices per order: Wishart
+    spectra (crowded small end), spectra over 8 decades, pairs of eigenvalues 1e-3 ... 1e-12 apart (in and below the solver's isolation
+    threshold: both routes), a cluster of five, graded tridiagonal-like matrices; matrix square root and logarithm against numpy's eigh,
+    and sqrtm(A)^2 = A."""
+    rng = np.random.default_rng(500 + d)
+    n = 200
+    mats = []
+    g = rng.standard_normal((n, d, d))
+    mats.append(np.einsum("nab,ncb->nac", g, g) / d + 0.1 * np.eye(d))
+    def with_spectrum(lam):
+        q = np.linalg.qr(rng.standard_normal((lam.shape[0], d, d)))[0]
+        return np.einsum("nab,nb,ncb->nac", q, lam, q)
+    mats.append(with_spectrum(10.0 ** rng.uniform(-4, 4, (n, d))))
+    lam = rng.uniform(0.5, 3.0, (n, d))
+    lam[:, 1] = lam[:, 0] * (1.0 + 10.0 ** rng.uniform(-12, -3, n))
+    mats.append(with_spectrum(lam))
+    lam = rng.uniform(0.5, 3.0, (n, d))
+    lam[:, :5] = lam[:, :1] * (1.0 + 10.0 ** rng.uniform(-9, -4, (n, 1)) * np.arange(5))
+    mats.append(with_spectrum(lam))
+    grade = 10.0 ** (-np.arange(d) * rng.uniform(0.05, 0.25, (n, 1)))          # (entries down to 1e-11 of the largest)
+    mats.append(np.einsum("na,nab,nb->nab", grade, mats[0], grade) + 1e-9 * np.eye(d))
+    mats.append(with_spectrum(rng.uniform(0.2, 5.0, (n, d))) * 10.0 ** rng.uniform(-6, 6, (n, 1, 1)))
+    mats = np.concatenate(mats)
+    mats = 0.5 * (mats + mats.transpose(0, 2, 1))
+    lam, vec = np.linalg.eigh(mats)
+    assert lam.min() > 0
+    fun = lambda f: np.einsum("nab,nb,ncb->nac", vec, f(lam), vec)      # noqa: E731
+    root = ops.spd_manifold_op(_lib.GABO_SPD_SQRTM, t(mats)).cpu().numpy()
+    scale = np.sqrt(lam.max(axis=1))
+    err = np.abs(root - fun(np.sqrt)).max(axis=(1, 2)) / scale
+    # (the small eigenvalues are known to eps |A|, their square roots to eps sqrt(cond) / 2 of sqrt |A| - in either solver)
+    cond = lam.max(axis=1) / lam.min(axis=1)
+    assert (err < 2e-13 + 1e-15 * np.sqrt(cond)).all(), (err / (2e-13 + 1e-15 * np.sqrt(cond))).max()
+    back = np.abs(np.einsum("nab,nbc->nac", root, root) - mats).max(axis=(1, 2)) / lam.max(axis=1)
+    assert back.max() < 2e-13, (back.max(), back.argmax())
+    logm = ops.spd_manifold_op(_lib.GABO_SPD_LOGM, t(mats)).cpu().numpy()
+    err = np.abs(logm - fun(np.log)).max(axis=(1, 2)) / (np.abs(np.log(lam)).max(axis=1) + 0.1)
+    # (log of a spectrum over many decades: the small eigenvalues are known to eps |A| only, their logarithms to eps cond(A))
+    assert (err < 1e-13 + 4e-16 * cond).all(), (err / (1e-13 + 4e-16 * cond)).max()

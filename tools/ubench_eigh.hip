@@ -131,7 +131,8 @@ int main() {
         long long ph[8];
         hipMemcpyFromSymbol(ph, HIP_SYMBOL(gabo_eigh_clk), sizeof(ph));
         if (d >= gabo::kWaveEighMinDim)
-            printf("   block 0: tridiagonalise %lld, accumulate Q %lld, QL %lld", ph[1] - ph[0], ph[2] - ph[1], ph[3] - ph[2]);
+            printf("   block 0: tridiagonalise %lld, accumulate Q %lld, QL %lld | lane-group solver: multisection %lld, RQI %lld, back-transform %lld, rest %lld, [passes, solves, window] = %lld",
+                   ph[1] - ph[0], ph[2] - ph[1], ph[3] - ph[2], ph[4] - ph[1], ph[5] - ph[4], ph[6] - ph[5], ph[2] - ph[6], ph[7]);
 #endif
         printf("\n");
         hipFree(da); hipFree(dl); hipFree(dv); hipFree(dc);
