@@ -63,12 +63,52 @@ __device__ __forceinline__ void wave_tridiagonalize(lds_f64* A, lds_f64* refl, l
     });
     static_for<DP - 2>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
+        constexpr int n = DP - k - 1;                    // entries of column k below the diagonal
         if (k < pad) {                                   // wave-uniform: the identity block needs no reflector
             dg[k] = 1.0;
             e[k] = 0.0;
             ihh[k] = 0.0;
             return;
         }
+#ifndef GABO_EIGH_LDS_REDUCTION
+        // Round 4: no exchange through LDS.  Column k below the diagonal is ONE register pair spread over the lanes k+1 ... DP-1: v_readlane
+        // with constant lane indices puts it into scalar registers, where every lane forms |x|^2 and the reflector redundantly (no
+        // wave-wide sum) and uses the entries as the scalar operand of its FMAs; q comes back the same way.  One wave-wide sum per column
+        // (u . p) is left.  Before: two sums and two LDS round trips per column, 27 k of the 75 k cycles at d = 20.
+        const bool below = lane > k && lane < DP;
+        const double x = below ? a[k] : 0.0;             // column k below the diagonal = entry k of the rows below (symmetry)
+        double us[n];
+        static_for<n>([&](auto ii) { us[decltype(ii)::value] = lane_value(a[k], k + 1 + decltype(ii)::value); });
+        const double alpha = us[0];
+        double n0 = 0.0, n1 = 0.0;
+        static_for<n>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            if constexpr (i % 2 == 0) n0 = __builtin_fma(us[i], us[i], n0); else n1 = __builtin_fma(us[i], us[i], n1);
+        });
+        const double nn = n0 + n1;
+        const double nrm = sqrt_pos(nn);
+        const double hh = __builtin_fma(__builtin_fabs(alpha), nrm, nn);      // u = x + sign(x0)|x| e0, H = I - u u^T / hh
+        const double inv_hh = hh == 0.0 ? 0.0 : rcp(hh);
+        us[0] = alpha + copysign_d(nrm, alpha);
+        const double u = (lane == k + 1) ? us[0] : x;
+        if (refl != nullptr && below) refl[(k - pad) * d + (lane - pad)] = u;
+        double p0 = 0.0, p1 = 0.0;
+        static_for<n>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            if constexpr (i % 2 == 0) p0 = __builtin_fma(a[k + 1 + i], us[i], p0); else p1 = __builtin_fma(a[k + 1 + i], us[i], p1);
+        });
+        const double p = below ? (p0 + p1) * inv_hh : 0.0;
+        const double kap = 0.5 * wave_allsum(u * p) * inv_hh;
+        const double q = __builtin_fma(-kap, u, p);
+        static_for<n>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const double qb = lane_value(q, k + 1 + i);
+            a[k + 1 + i] = __builtin_fma(-q, us[i], __builtin_fma(-u, qb, a[k + 1 + i]));
+        });
+        dg[k] = lane_value(a[k], k);
+        e[k] = hh == 0.0 ? alpha : -copysign_d(nrm, alpha);
+        ihh[k] = inv_hh;
+#else
         const bool below = lane > k && lane < DP;
         const double x = below ? a[k] : 0.0;             // column k below the diagonal = entry k of the rows below (symmetry)
         const double alpha = lane_value(a[k], k + 1);
@@ -99,6 +139,7 @@ __device__ __forceinline__ void wave_tridiagonalize(lds_f64* A, lds_f64* refl, l
         e[k] = hh == 0.0 ? alpha : -copysign_d(nrm, alpha);
         ihh[k] = inv_hh;
         wave_lds_order();                                // the next step rewrites bc
+#endif
     });
     dg[DP - 2] = lane_value(a[DP - 2], DP - 2);
     e[DP - 2] = lane_value(a[DP - 2], DP - 1);
