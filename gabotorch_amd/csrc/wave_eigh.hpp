@@ -10,6 +10,9 @@
 // dependent chain (angle: rsq + rcp + ~20 fp64 instructions), ~130 rounds per 20 x 20 matrix = 0.21 ms measured.
 // Here the chain is the QL recurrence alone (13 instructions per rotation, ~1.7 (d^2 / 2) rotations) and the O(d^3) work is d-way
 // lane-parallel: ~8e3 wave instructions at d = 20.  A lone wave issues one fp64 instruction per 8.5 cycles (profiles/r02_ubench_issue.txt).
+// Round 4: the reduction exchanges its column through v_readlane instead of LDS (wave_tridiagonalize), orders 9 ... 24 find the eigenpairs of T
+// with one lane GROUP per eigenvalue (wave_eigh_rqi: multisection on Sturm counts + Rayleigh-quotient iteration + windowed Newton-Schulz
+// step; QL is its fallback), and the QL path reverses T when its large end is on top.  DESIGN 4.9b, tools/ubench_eigh.hip.
 #pragma once
 #include "gabo_device.hpp"
 #include "spd_eigvec.hpp"
@@ -168,7 +171,7 @@ __device__ __forceinline__ void wave_tridiagonalize(lds_f64* A, lds_f64* refl, l
 //      other eigenvalue is the gap.)
 // Returns false when the QL path has to take over (V and the diagonal of A are untouched then; td holds T * scale, `unscale` = 1 / scale).
 #ifndef GABO_EIGH_RQI_MAX_DP
-#define GABO_EIGH_RQI_MAX_DP 24     /* above: the per-lane state no longer fits the register file (and the compile time explodes) */
+#define GABO_EIGH_RQI_MAX_DP 32
 #endif
 #ifndef GABO_EIGH_RQI_EXTRA_PASSES
 #define GABO_EIGH_RQI_EXTRA_PASSES 1      /* one more pass (~1 k cycles) usually saves the fourth solve (~4 k): tools/ubench_eigh.hip */
@@ -192,14 +195,18 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
     const int leader = grp * m;
     unscale = 1.0;
     // ---- Gershgorin bracket of the active block
-    double gl = 0.0, gu = 0.0;
+    double gl = 1e300, gu = -1e300;
     static_for<DP>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         const double off = __builtin_fabs(te[i]) + (i > 0 ? __builtin_fabs(te[i > 0 ? i - 1 : 0]) : 0.0);     // (e[pad - 1] = 0, e[DP - 1] = 0)
         const double di = td[i];
-        const double lo_i = di - off, hi_i = di + off;
-        gl = (i == pad || (i > pad && lo_i < gl)) ? lo_i : gl;
-        gu = (i == pad || (i > pad && hi_i > gu)) ? hi_i : gu;
+        double lo_i = di - off, hi_i = di + off;
+        if constexpr (i < 3) {                            // (the identity rows of the padding do not take part; pad <= 3 here)
+            lo_i = i < pad ? 1e300 : lo_i;
+            hi_i = i < pad ? -1e300 : hi_i;
+        }
+        gl = __builtin_fmin(gl, lo_i);
+        gu = __builtin_fmax(gu, hi_i);
     });
     const double tnorm = __builtin_fmax(__builtin_fabs(gl), __builtin_fabs(gu));
     if (!(tnorm > 1e-290) || !(tnorm < 1e290)) return false;         // zero matrix, NaN, extreme scales: the QL path
@@ -271,6 +278,9 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
         }
     }
     GABO_EIGH_TICK(4);
+#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 1
+    return lo < hi;
+#endif
     if (!isolated) return false;
     // ---- Rayleigh-quotient iteration on T (every lane for the eigenvalue of its group)
     constexpr double tiny = 1.2e-16;
@@ -285,7 +295,6 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
         ++nsolve;
         // pivoted LU of T - mu I, the forward substitution applied to z on the way (rows of U: 1 / u0, u1, [e_(k+1) where rows were interchanged])
         double iu0[DP], u1[DP];
-        unsigned swm = 0u;
         double cu = ta[0] - mu, cv = tb[0];
         static_for<DP - 1>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
@@ -298,9 +307,10 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
             const double ip = rcp(piv);
             const double mult = other * ip;
             const double ux = swp ? an : cv, uy = swp ? cv : an;      // the pivot row's superdiagonal entry and the entry below it
-            iu0[k] = ip;
+            // (the interchange flag rides in the last mantissa bit of the stored reciprocal - a perturbation of U by half an ulp - instead of
+            // a register of its own per row)
+            iu0[k] = __hiloint2double(__double2hiint(ip), (__double2loint(ip) & ~1) | (swp ? 1 : 0));
             u1[k] = ux;
-            swm |= swp ? (1u << k) : 0u;
             cu = __builtin_fma(-mult, ux, uy);
             cv = (swp ? -mult : 1.0) * bn;
             const double yk = z[k], yn = z[k + 1];
@@ -309,12 +319,12 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
             z[k + 1] = __builtin_fma(-mult, zx, zy);
         });
         cu = (__builtin_fabs(cu) < tiny) ? copysign_d(tiny, cu) : cu;
-        iu0[DP - 1] = rcp(cu);
+        iu0[DP - 1] = rcp(cu);      // (no row below: its flag is never read)
         static_for_down<DP - 1, 0>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             double acc = z[k];
             if constexpr (k + 1 < DP) acc = __builtin_fma(-u1[k + 1 < DP ? k : 0], z[k + 1 < DP ? k + 1 : k], acc);
-            if constexpr (k + 2 < DP) acc = __builtin_fma(((swm >> k) & 1u) ? -tb[k + 1 < DP ? k + 1 : k] : 0.0, z[k + 2 < DP ? k + 2 : k], acc);
+            if constexpr (k + 2 < DP) acc = __builtin_fma((__double2loint(iu0[k]) & 1) ? -tb[k + 1 < DP ? k + 1 : k] : 0.0, z[k + 2 < DP ? k + 2 : k], acc);
             z[k] = acc * iu0[k];
         });
         double nn = 0.0, big = 0.0;
@@ -348,6 +358,9 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
         if (__builtin_amdgcn_ballot_w64(!done && !spare) == 0) { conv = true; break; }
     }
     GABO_EIGH_TICK(5);
+#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 2
+    V[lane] = z[0] + z[DP - 1] + rho; return conv;
+#endif
     if (!conv || __builtin_amdgcn_ballot_w64(!spare && !(rho >= lo && rho <= hi)) != 0) return false;
     // ---- back to the original basis: this lane's vector through H_pad ... H_(DP-3), last reflector first
     static_for_down<DP - 3, 0>([&](auto kk) {
@@ -369,6 +382,9 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
         });
     });
     GABO_EIGH_TICK(6);
+#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 3
+    V[lane] = z[0] + z[DP - 1] + rho; return conv;
+#endif
     wave_lds_order();                                       // every lane is done with the reflectors: V may be overwritten
     const bool writer = !spare && j == 0;
     if (writer) {
@@ -379,19 +395,30 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
         A[grp * d + grp] = rho * unscale;
     }
     wave_lds_order();
+#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 4
+    return conv;
+#endif
     // ---- Newton-Schulz step(s) against the columns whose eigenvalues are close: a window of the sorted spectrum, the same for every group
+    // (the sorted eigenvalues go through the scratch that held T; the spectrum is ascending, so the largest offset at which ANY group still
+    // has a neighbour within the threshold is the window.  Written without a run-time loop: the loop form with __shfl and an early exit
+    // took InstCombine four minutes per instantiation)
+    if (writer) td[grp] = rho;
+    wave_lds_order();
     int win = 0;
     double gap_min = 1.0;
-    for (int k = 1; k < d; ++k) {
+    static_for<DP - 1>([&](auto kk) {
+        constexpr int k = decltype(kk)::value + 1;
         const bool has = !spare && grp + k < d;
-        const double other = __shfl(rho, (has ? grp + k : grp) * m, 64);
+        const double other = td[has ? grp + k : grp];
         const bool near = has && other - rho < GABO_EIGH_RQI_ORTH_GAP;
-        if (k == 1) gap_min = has ? other - rho : 1.0;
-        if (__builtin_amdgcn_ballot_w64(near) == 0) break;
-        win = k;
-    }
+        if constexpr (k == 1) gap_min = has ? other - rho : 1.0;
+        win = __builtin_amdgcn_ballot_w64(near) != 0 ? k : win;
+    });
 #ifdef GABO_EIGH_CLOCKS
     if (threadIdx.x == 0 && blockIdx.x == 0) gabo_eigh_clk[7] = npass * 10000 + nsolve * 100 + win;
+#endif
+#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 5
+    V[lane] = (double)win + gap_min; return conv;
 #endif
     const int ns_steps = win == 0 ? 0 : (__builtin_amdgcn_ballot_w64(gap_min < 1e-6) != 0 ? 2 : 1);
     for (int ns = 0; ns < ns_steps; ++ns) {
