@@ -278,9 +278,6 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
         }
     }
     GABO_EIGH_TICK(4);
-#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 1
-    return lo < hi;
-#endif
     if (!isolated) return false;
     // ---- Rayleigh-quotient iteration on T (every lane for the eigenvalue of its group)
     constexpr double tiny = 1.2e-16;
@@ -358,9 +355,6 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
         if (__builtin_amdgcn_ballot_w64(!done && !spare) == 0) { conv = true; break; }
     }
     GABO_EIGH_TICK(5);
-#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 2
-    V[lane] = z[0] + z[DP - 1] + rho; return conv;
-#endif
     if (!conv || __builtin_amdgcn_ballot_w64(!spare && !(rho >= lo && rho <= hi)) != 0) return false;
     // ---- back to the original basis: this lane's vector through H_pad ... H_(DP-3), last reflector first
     static_for_down<DP - 3, 0>([&](auto kk) {
@@ -382,9 +376,6 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
         });
     });
     GABO_EIGH_TICK(6);
-#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 3
-    V[lane] = z[0] + z[DP - 1] + rho; return conv;
-#endif
     wave_lds_order();                                       // every lane is done with the reflectors: V may be overwritten
     const bool writer = !spare && j == 0;
     if (writer) {
@@ -395,9 +386,6 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
         A[grp * d + grp] = rho * unscale;
     }
     wave_lds_order();
-#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 4
-    return conv;
-#endif
     // ---- Newton-Schulz step(s) against the columns whose eigenvalues are close: a window of the sorted spectrum, the same for every group
     // (the sorted eigenvalues go through the scratch that held T; the spectrum is ascending, so the largest offset at which ANY group still
     // has a neighbour within the threshold is the window.  Written without a run-time loop: the loop form with __shfl and an early exit
@@ -416,9 +404,6 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
     });
 #ifdef GABO_EIGH_CLOCKS
     if (threadIdx.x == 0 && blockIdx.x == 0) gabo_eigh_clk[7] = npass * 10000 + nsolve * 100 + win;
-#endif
-#if defined(GABO_EIGH_BISECT) && GABO_EIGH_BISECT == 5
-    V[lane] = (double)win + gap_min; return conv;
 #endif
     const int ns_steps = win == 0 ? 0 : (__builtin_amdgcn_ballot_w64(gap_min < 1e-6) != 0 ? 2 : 1);
     for (int ns = 0; ns < ns_steps; ++ns) {
