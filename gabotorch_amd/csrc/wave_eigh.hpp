@@ -581,18 +581,17 @@ __device__ __forceinline__ double half_wave_allsum(double v) {
 // A: in: the matrix; out: A[0..d) = eigenvector of lambda_max, A[d..2d) = eigenvector of lambda_min (unit norm, sign arbitrary).
 // W: d x d of LDS scratch (the reflectors).  bc: kWaveEighScratch doubles; out: bc[0] = lambda_max, bc[1] = lambda_min.  DP - 3 <= d <= DP.
 template <int DP>
-__device__ __attribute__((noinline)) void wave_eig_extremes(lds_f64* A, lds_f64* W, lds_f64* bc, int d) {
+__device__ __attribute__((noinline)) void wave_eig_extremes(lds_f64* A, lds_f64* W, lds_f64* bc, int d_arg) {
+    const int d = __builtin_amdgcn_readfirstlane(d_arg);      // (see wave_eigh)
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5, r = lane & 31;
     const int pad = DP - d;
     double dg[DP], e[DP], ihh[DP >= 3 ? DP - 2 : 1];
     wave_tridiagonalize<DP>(A, W, bc, d, dg, e, ihh);
-    // ---- Gershgorin bracket of the spectrum of the active block, off-diagonal squares
-    double e2[DP];
+    // ---- Gershgorin bracket of the spectrum of the active block
     double gl = 0.0, gu = 0.0;
     static_for<DP>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        e2[i] = e[i] * e[i];
         if (i < pad) return;
         const double off = __builtin_fabs(e[i]) + (i > 0 ? __builtin_fabs(e[i > 0 ? i - 1 : 0]) : 0.0);     // (e[pad - 1] = 0)
         const double lo_i = dg[i] - off, hi_i = dg[i] + off;
@@ -600,23 +599,39 @@ __device__ __attribute__((noinline)) void wave_eig_extremes(lds_f64* A, lds_f64*
         gu = (i == pad || hi_i > gu) ? hi_i : gu;
     });
     const double tnorm = __builtin_fmax(__builtin_fabs(gl), __builtin_fabs(gu));
-    const double pivmin = __builtin_fmax(tnorm * tnorm * 1e-290, 1e-300);
-    double lo = gl - 1e-15 * tnorm - pivmin, hi = gu + 1e-15 * tnorm + pivmin;         // per half: the bracket of its eigenvalue
+    // Sturm counts as in wave_eigh_rqi (round 4): T scaled by a power of two to |T| in [1/2, 1), the count = sign changes of the minors'
+    // three-term recurrence - one dependent FMA per row, no division (a corrected reciprocal per row before: 12 instructions instead of 4);
+    // the identity rows of the padding become eigenvalues 4, above every abscissa
+    int ex = 0;
+    double scale = 1.0, unscale = 1.0;
+    if (tnorm > 0.0 && tnorm < 1e300) {
+        (void)frexp(tnorm, &ex);
+        scale = ldexp(1.0, -ex);
+        unscale = ldexp(1.0, ex);
+    }
+    double ta[DP], tb2[DP];
+    static_for<DP>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        ta[i] = i < pad ? 4.0 : dg[i] * scale;
+        const double es = (i == 0) ? 0.0 : e[i > 0 ? i - 1 : 0] * scale;
+        tb2[i] = -(es * es);
+    });
+    double lo = gl * scale - 2e-15, hi = gu * scale + 2e-15;         // per half: the bracket of its eigenvalue
     const double frac = (double)(r + 1) * (1.0 / 33.0);
     const int target = half ? 1 : d;                     // count(x) >= target  <=>  x is above the eigenvalue this half looks for
     for (int pass = 0; pass < 12; ++pass) {
         const double w = hi - lo;
         const double x = __builtin_fma(w, frac, lo);
-        int cnt = 0;
-        double q = 1.0;
+        double pm2 = 1.0, pm1 = 1.0;
+        unsigned signs = 0u;
         static_for<DP>([&](auto ii) {
             constexpr int i = decltype(ii)::value;
-            if (i < pad) return;
-            const double t = (i == 0) ? 0.0 : e2[i > 0 ? i - 1 : 0] * rcp(q);
-            q = (dg[i] - x) - t;
-            q = (__builtin_fabs(q) < pivmin) ? -pivmin : q;
-            cnt += q < 0.0 ? 1 : 0;
+            const double p = __builtin_fma(ta[i] - x, pm1, tb2[i] * pm2);
+            signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(p), 31);
+            pm2 = pm1;
+            pm1 = p;
         });
+        const int cnt = __builtin_popcount(signs ^ (signs >> 1));
         const unsigned long long above = __builtin_amdgcn_ballot_w64(cnt >= target);
         const unsigned mine = half ? (unsigned)(above >> 32) : (unsigned)above;
         const int first = mine ? __builtin_ctz(mine) : 32;                               // first abscissa above the eigenvalue
@@ -625,7 +640,7 @@ __device__ __attribute__((noinline)) void wave_eig_extremes(lds_f64* A, lds_f64*
         lo = nlo;
         hi = nhi;
     }
-    const double lam = 0.5 * (lo + hi);
+    const double lam = 0.5 * (lo + hi) * unscale;
     // ---- pivoted LU of T - lam I (rows of U: 1 / u0, u1, u2; multipliers ml; interchanges sw)
     const double tiny = __builtin_fmax(2.3e-16 * tnorm, 1e-300);
     double iu0[DP], u1[DP], ml[DP];                       // (the second super-diagonal of U is e[k + 1] where rows were interchanged, 0 elsewhere)

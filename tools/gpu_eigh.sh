@@ -4,5 +4,5 @@ cd $R
 for b in ${BINS:-build/ubench_eigh_*}; do
   echo "== $b"
   timeout 300 $b | awk '$1>=9' > gpurun_out/$(basename $b).txt
-  cut -c1-8,20-64,150-400 gpurun_out/$(basename $b).txt
+  cut -c1-8,20-64,65-150 gpurun_out/$(basename $b).txt
 done
