@@ -78,16 +78,38 @@ static __device__ void lds_tri_inverse(const double* L, double* W, int d) {
 }
 
 // C = op(A) op(B), thread per output element; C must not alias A or B
-static __device__ void lds_mm(const double* A, const double* B, double* C, int d, bool ta, bool tb) {
+// (round 4: four products in flight per thread, the transposition flags resolved outside the loop.  Worth ~7 % of a product phase only
+// (tools/recon_clocks.py: 17.1 k -> 15.9 k cycles for the five products of "C^1/2, B, Xrec" at D = 20): a 20 x 20 product on 256 threads is
+// 320 ds_read_b64 wave instructions through one CU's LDS pipe, ~1.3 k cycles of bandwidth before any latency - a 2 x 2 register tile per
+// thread would halve that)
+template <bool TA, bool TB>
+static __device__ __forceinline__ void lds_mm_body(const double* A, const double* B, double* C, int d) {
     for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
-        int r = e / d, c = e - r * d;
-        double s = 0.0;
-        for (int k = 0; k < d; ++k) {
-            double a = ta ? A[k * d + r] : A[r * d + k];
-            double b = tb ? B[c * d + k] : B[k * d + c];
-            s = __builtin_fma(a, b, s);
+        const int r = e / d, c = e - r * d;
+        const double* ap = TA ? A + r : A + r * d;
+        const double* bp = TB ? B + c * d : B + c;
+        const int as = TA ? d : 1, bs = TB ? 1 : d;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = 0;
+        for (; k + 4 <= d; k += 4) {
+            const double a0 = ap[k * as], a1 = ap[(k + 1) * as], a2 = ap[(k + 2) * as], a3 = ap[(k + 3) * as];
+            const double b0 = bp[k * bs], b1 = bp[(k + 1) * bs], b2 = bp[(k + 2) * bs], b3 = bp[(k + 3) * bs];
+            s0 = __builtin_fma(a0, b0, s0);
+            s1 = __builtin_fma(a1, b1, s1);
+            s2 = __builtin_fma(a2, b2, s2);
+            s3 = __builtin_fma(a3, b3, s3);
         }
-        C[e] = s;
+        for (; k < d; ++k) s0 = __builtin_fma(ap[k * as], bp[k * bs], s0);
+        C[e] = (s0 + s1) + (s2 + s3);
+    }
+}
+static __device__ void lds_mm(const double* A, const double* B, double* C, int d, bool ta, bool tb) {
+    if (ta) {
+        if (tb) lds_mm_body<true, true>(A, B, C, d);
+        else lds_mm_body<true, false>(A, B, C, d);
+    } else {
+        if (tb) lds_mm_body<false, true>(A, B, C, d);
+        else lds_mm_body<false, false>(A, B, C, d);
     }
     wsync();
 }
@@ -239,9 +261,17 @@ static __device__ void lds_fun_from_eig(const double* A, const double* V, double
     wsync();
     for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
         int r = e / d, c = e - r * d;
-        double s = 0.0;
-        for (int k = 0; k < d; ++k) s = __builtin_fma(V[r * d + k] * fl[k], V[c * d + k], s);
-        F[e] = s;
+        const double* vr = V + r * d;
+        const double* vc = V + c * d;
+        double s0 = 0.0, s1 = 0.0;                    // (two products in flight: see lds_mm)
+        int k = 0;
+        for (; k + 2 <= d; k += 2) {
+            const double a0 = vr[k], a1 = vr[k + 1], f0 = fl[k], f1 = fl[k + 1], b0 = vc[k], b1 = vc[k + 1];
+            s0 = __builtin_fma(a0 * f0, b0, s0);
+            s1 = __builtin_fma(a1 * f1, b1, s1);
+        }
+        if (k < d) s0 = __builtin_fma(vr[k] * fl[k], vc[k], s0);
+        F[e] = s0 + s1;
     }
     wsync();
 }

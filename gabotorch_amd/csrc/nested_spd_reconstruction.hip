@@ -33,9 +33,20 @@ static __device__ void lds_gemm(const double* A, int ai, int ak, const double* B
                                 double scale = 1.0) {
     for (int e = threadIdx.x; e < M * N; e += blockDim.x) {
         const int i = e / N, j = e - i * N;
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s = __builtin_fma(A[i * ai + k * ak], B[k * bk + j * bj], s);
-        C[e] = s * scale;
+        const double* ap = A + i * ai;
+        const double* bp = B + j * bj;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;          // (four products in flight: see lds_mm)
+        int k = 0;
+        for (; k + 4 <= K; k += 4) {
+            const double a0 = ap[k * ak], a1 = ap[(k + 1) * ak], a2 = ap[(k + 2) * ak], a3 = ap[(k + 3) * ak];
+            const double b0 = bp[k * bk], b1 = bp[(k + 1) * bk], b2 = bp[(k + 2) * bk], b3 = bp[(k + 3) * bk];
+            s0 = __builtin_fma(a0, b0, s0);
+            s1 = __builtin_fma(a1, b1, s1);
+            s2 = __builtin_fma(a2, b2, s2);
+            s3 = __builtin_fma(a3, b3, s3);
+        }
+        for (; k < K; ++k) s0 = __builtin_fma(ap[k * ak], bp[k * bk], s0);
+        C[e] = ((s0 + s1) + (s2 + s3)) * scale;
     }
     __syncthreads();
 }
