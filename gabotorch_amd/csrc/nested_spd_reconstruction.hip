@@ -295,8 +295,20 @@ __global__ __launch_bounds__(256) void nested_spd_reconstruction_kernel(const do
     double* SumBB = M0;               // m x m
     double* SumT = M1;                // d x m
     for (int e = threadIdx.x; e < D * m + mm + d * m; e += blockDim.x) {
-        double s = 0.0;
-        for (int q = 0; q < N; ++q) s += Rp[(size_t)q * rec + 1 + e];
+        // (four records in flight: one dependent global load per record was ~2 k cycles each on the tail of every gradient launch; the order
+        // of the additions is fixed - it does not depend on the order in which the blocks finished)
+        const double* rp = Rp + 1 + e;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int q = 0;
+        for (; q + 4 <= N; q += 4) {
+            const double v0 = rp[(size_t)q * rec], v1 = rp[(size_t)(q + 1) * rec], v2 = rp[(size_t)(q + 2) * rec], v3 = rp[(size_t)(q + 3) * rec];
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
+        }
+        for (; q < N; ++q) s0 += rp[(size_t)q * rec];
+        const double s = (s0 + s1) + (s2 + s3);
         if (e < D * m) gv[(size_t)p * D * m + e] = s;
         else if (e < D * m + mm) SumBB[e - D * m] = s;
         else SumT[e - D * m - mm] = s;
