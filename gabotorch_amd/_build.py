@@ -7,6 +7,7 @@ import concurrent.futures
 import os
 import shutil
 import subprocess
+import time
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
@@ -83,9 +84,12 @@ def _compile(src, extra):
         cmd = [_hipcc()] + HOST_FLAGS + ["-I", _rocm_include()] + [f for f in extra if f.startswith("-D")] + ["-MD", "-MF", depfile, "-c", src, "-o", obj]
     else:
         cmd = [_hipcc()] + FLAGS + extra + ["-MD", "-MF", depfile, "-c", src, "-o", obj]
+    t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if os.environ.get("GABO_BUILD_TIMES"):
+        print(f"{time.time() - t0:7.1f} s  {os.path.basename(src)}", flush=True)
     return obj, True
 
 
