@@ -5,7 +5,8 @@ import torch
 from gabotorch_amd import _lib, ops
 
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 9
-rng = np.random.default_rng(500 + d)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(500 + d + 1000 * seed)
 n = 200
 mats = []
 g = rng.standard_normal((n, d, d))
@@ -30,7 +31,9 @@ fun = lambda f: np.einsum("nab,nb,ncb->nac", vec, f(lam), vec)
 root = ops.spd_manifold_op(_lib.GABO_SPD_SQRTM, torch.tensor(mats, device="cuda:0")).cpu().numpy()
 err = np.abs(root - fun(np.sqrt)).max(axis=(1, 2)) / np.sqrt(lam.max(axis=1))
 back = np.abs(np.einsum("nab,nbc->nac", root, root) - mats).max(axis=(1, 2)) / lam.max(axis=1)
-for k in range(6):
+bad = (back > 2e-13).sum()
+print(f"d {d} seed {seed}: max back error {back.max():.2e}, matrices above 2e-13: {bad}")
+for k in range(6 if "-v" in sys.argv else 0):
     sl = slice(k * n, (k + 1) * n)
     i = k * n + int(np.argmax(err[sl]))
     sp = lam[i] / lam[i].max()
