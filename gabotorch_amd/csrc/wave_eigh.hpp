@@ -181,10 +181,9 @@ __device__ __forceinline__ void wave_tridiagonalize(lds_f64* A, lds_f64* refl, l
 #endif
 template <int DP>
 __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_f64* refl, lds_f64* td, int d, const double (&ihh)[DP >= 3 ? DP - 2 : 1],
-                                              double& unscale) {
-    // td: the tridiagonal matrix in LDS (td[i] = diagonal, td[DP + i] = off-diagonal e_i between i and i + 1; wave-uniform broadcast reads: the
-    // per-lane state below - the vector and the LU factors of T - mu I - is what the registers are for)
-    lds_f64* te = td + DP;
+                                              double (&ta)[DP], double (&tb)[DP], double& unscale) {
+    // ta / tb: the tridiagonal matrix (diagonal, off-diagonal e_i between i and i + 1) in registers, wave-uniform; SCALED IN PLACE (the caller
+    // undoes it with `unscale` when the QL path has to take over).  td: kWaveEighScratch doubles of LDS scratch (the sorted eigenvalues, step 5)
     const int lane = threadIdx.x & 63;
     const int pad = DP - d;                                // 0 ... 3 leading identity rows, decoupled (e[pad - 1] = 0): skipped below
     const int m = 64 / d;                                  // lanes per eigenvalue, 2 ... 7 (d >= 9)
@@ -198,8 +197,8 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
     double gl = 1e300, gu = -1e300;
     static_for<DP>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        const double off = __builtin_fabs(te[i]) + (i > 0 ? __builtin_fabs(te[i > 0 ? i - 1 : 0]) : 0.0);     // (e[pad - 1] = 0, e[DP - 1] = 0)
-        const double di = td[i];
+        const double off = __builtin_fabs(tb[i]) + (i > 0 ? __builtin_fabs(tb[i > 0 ? i - 1 : 0]) : 0.0);     // (e[pad - 1] = 0, e[DP - 1] = 0)
+        const double di = ta[i];
         double lo_i = di - off, hi_i = di + off;
         if constexpr (i < 3) {                            // (the identity rows of the padding do not take part; pad <= 3 here)
             lo_i = i < pad ? 1e300 : lo_i;
@@ -214,22 +213,15 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
     (void)frexp(tnorm, &ex);
     const double scale = ldexp(1.0, -ex);
     unscale = ldexp(1.0, ex);
-    wave_lds_order();
-    if (lane < DP) {
-        // (the identity rows in front of the matrix become eigenvalues 4 above the scaled spectrum: the loops below run over all DP rows
-        // without a branch, the counts below x < 1 and the vectors - zero in those rows - do not see them)
-        td[lane] = lane < pad ? 4.0 : td[lane] * scale;
-        te[lane] = lane < pad ? 0.0 : te[lane] * scale;
-    }
-    wave_lds_order();
-    // T in registers from here on (wave-uniform values in vector registers: left to the scheduler, every row of the loops below would
-    // wait for its own LDS read)
-    double ta[DP], tb[DP], tb2[DP];
+    // (the identity rows in front of the matrix become eigenvalues 4 above the scaled spectrum: the loops below run over all DP rows without a
+    // branch, the counts below x < 1 and the vectors - zero in those rows - do not see them)
     static_for<DP>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        ta[i] = td[i];
-        tb[i] = te[i];
+        ta[i] *= scale;
+        tb[i] *= scale;                                   // (zero in the padding rows already)
+        if constexpr (i < 3) ta[i] = i < pad ? 4.0 : ta[i];
     });
+    double tb2[DP];
     static_for<DP>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         tb2[i] = (i == 0) ? 0.0 : -(tb[i > 0 ? i - 1 : 0] * tb[i > 0 ? i - 1 : 0]);
@@ -470,26 +462,17 @@ __device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_
     // (d <= 8: the QL chain is short - 17 k cycles at d = 5 against 26 k for this route, tools/ubench_eigh.hip)
     if constexpr (DP >= 12 && DP <= GABO_EIGH_RQI_MAX_DP) {
         if (V != nullptr) {
-            // the tridiagonal matrix goes to the (now free) scratch in LDS: the lane-group solver reads it from there, its registers hold per-lane
-            // state; on the way back to the QL path it is read again
-            if (lane < DP) {
-                double dv = 0.0, ev = 0.0;
-                static_for<DP>([&](auto cc) { dv = (lane == decltype(cc)::value) ? dg[decltype(cc)::value] : dv; ev = (lane == decltype(cc)::value) ? e[decltype(cc)::value] : ev; });
-                bc[lane] = dv;
-                bc[DP + lane] = ev;
-            }
-            wave_lds_order();
+            // T stays in the registers it is in (scaled in place by the lane-group solver: a power of two, exact both ways)
             double unscale;
-            if (wave_eigh_rqi<DP>(A, V, refl, bc, d, ihh, unscale)) {
+            if (wave_eigh_rqi<DP>(A, V, refl, bc, d, ihh, dg, e, unscale)) {
                 GABO_EIGH_TICK(2);
                 GABO_EIGH_TICK(3);
                 return;
             }
-            // (the scaling is a power of two: exact both ways)
             static_for<DP>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                dg[c] = c < pad ? 1.0 : bc[c] * unscale;
-                e[c] = c < pad ? 0.0 : bc[DP + c] * unscale;
+                dg[c] = c < pad ? 1.0 : dg[c] * unscale;
+                e[c] = c < pad ? 0.0 : e[c] * unscale;
             });
         }
     }
