@@ -170,6 +170,9 @@ __device__ __forceinline__ void wave_tridiagonalize(lds_f64* A, lds_f64* refl, l
 //      (The residual of a corrected vector stays at rounding level: the admixture of a neighbour is eps / gap, its residual against the
 //      other eigenvalue is the gap.)
 // Returns false when the QL path has to take over (V and the diagonal of A are untouched then; td holds T * scale, `unscale` = 1 / scale).
+#ifndef GABO_EIGH_RQI_MIN_DP
+#define GABO_EIGH_RQI_MIN_DP 8      /* with d >= 7 (below: the QL chain is as short as the fixed costs of the lane groups: 15.1 k against 15.4 k cycles at d = 5) */
+#endif
 #ifndef GABO_EIGH_RQI_MAX_DP
 #define GABO_EIGH_RQI_MAX_DP 32
 #endif
@@ -446,7 +449,8 @@ __device__ __forceinline__ bool wave_eigh_rqi(lds_f64* A, lds_f64* V, const lds_
 // A (d x d, symmetric, row-major, LDS): on return its DIAGONAL holds the eigenvalues (unordered; the rest of A is left as it was);
 // V (d x d, LDS, may be null: eigenvalues only): eigenvectors in columns; bc: kWaveEighScratch doubles of LDS.  DP - 3 <= d <= DP (DP = 8: 2 <= d <= 8).
 // Called by all 64 lanes of one wave (any other waves of the block wait at the caller's barrier).
-template <int DP>
+// LANE_GROUPS = false: the QL path only (orders up to 6: the lane-group code would only cost them its callee-saved registers)
+template <int DP, bool LANE_GROUPS = true>
 __device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_f64* bc, int d_arg) {
     const int d = __builtin_amdgcn_readfirstlane(d_arg);      // (arguments of a function arrive in vector registers: every branch on the padding would be an exec-mask branch)
     const int lane = threadIdx.x & 63;
@@ -459,9 +463,9 @@ __device__ __attribute__((noinline)) void wave_eigh(lds_f64* A, lds_f64* V, lds_
     wave_tridiagonalize<DP>(A, refl, bc, d, dg, e, ihh);
     GABO_EIGH_TICK(1);
 #ifndef GABO_EIGH_NO_RQI
-    // (d <= 8: the QL chain is short - 17 k cycles at d = 5 against 26 k for this route, tools/ubench_eigh.hip)
-    if constexpr (DP >= 12 && DP <= GABO_EIGH_RQI_MAX_DP) {
-        if (V != nullptr) {
+    // (d = 7, 8: 21.4 k -> 18.9 k, 25.2 k -> 20.6 k cycles; d <= 6: no gain, the QL path stays - tools/ubench_eigh.hip)
+    if constexpr (LANE_GROUPS && DP >= GABO_EIGH_RQI_MIN_DP && DP <= GABO_EIGH_RQI_MAX_DP) {
+        if (V != nullptr && (DP > 8 || d >= 7)) {
             // T stays in the registers it is in (scaled in place by the lane-group solver: a power of two, exact both ways)
             double unscale;
             if (wave_eigh_rqi<DP>(A, V, refl, bc, d, ihh, dg, e, unscale)) {
@@ -719,7 +723,8 @@ __device__ __forceinline__ void wave_eigh_any(double* A, double* V, double* bc, 
     lds_f64* a = (lds_f64*)A;
     lds_f64* v = (lds_f64*)V;
     lds_f64* b = (lds_f64*)bc;
-    if (d <= 8) wave_eigh<8>(a, v, b, d);
+    if (d <= 6) wave_eigh<8, false>(a, v, b, d);
+    else if (d <= 8) wave_eigh<8>(a, v, b, d);
     else if (d <= 12) wave_eigh<12>(a, v, b, d);
     else if (d <= 16) wave_eigh<16>(a, v, b, d);
     else if (d <= 20) wave_eigh<20>(a, v, b, d);
