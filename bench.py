@@ -127,7 +127,17 @@ def cpu_baseline(x):
     kv = ospd.spd_ai_gaussian_kernel(x[:vrows], x, BETA, faithful=False)
     dtv = time.perf_counter() - t1
     assert np.allclose(kv, k[:vrows], rtol=1e-9, atol=1e-14)
+    ref_proper = None
+    try:
+        rp = json.load(open(os.path.join(ROOT, "profiles", "r04_reference_cpu.json")))
+        ref_proper = {"pairs_per_s": rp["spd_config3"]["pairs_per_s"], "cores": rp["host"]["cores"], "kind": "reference",
+                      "where": "the reference ITSELF (its Mandel loop + affine_invariant_distance_torch + exp) on the config-3 input in the build container, "
+                               "8 vCPU / 8 torch threads, tools/time_reference_cpu.py -> profiles/r04_reference_cpu.json; /root/reference does not travel to the "
+                               "GPU box, so this figure is not re-timed here"}
+    except Exception:       # noqa: BLE001
+        pass
     return {"value": rows * x.shape[0] / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "reference_proper_pairs_per_s": None if ref_proper is None else ref_proper["pairs_per_s"], "reference_proper": ref_proper,
             "all_threads": {"value": rows_all * x.shape[0] / dta, "unit": "pairs/s", "cores": ncpu, "torch_threads": ncpu,
                             "sample": f"first {rows_all} Gram rows ({rows_all * x.shape[0]} pairs, {dta:.1f} s)"},
             "vectorised_numpy_pairs_per_s": vrows * x.shape[0] / dtv,
@@ -136,6 +146,56 @@ def cpu_baseline(x):
                       "Cholesky, inverse, two bmm, one torch.linalg.eigh per pair in a Python loop, exp), torch CPU fp64, one thread (the loop is "
                       "scalar); the reference itself on this input, build container, 8 threads: 3.74e4 pairs/s (profiles/r04_reference_cpu.json)",
             "host_cpus": ncpu}, k
+
+
+def measure_hbm_traffic(timeout_s=150):
+    """HBM bytes per launch of the headline kernel from the PMC counters, measured in THIS run: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do
+    not fit one pass: MI355X_MICROARCH.md, counter table) over three launches of the same N = 4096, d = 10 Gram build (tools/prof_spd.py), only
+    --kernel-trace next to --pmc.  Units and gfx950 corrections as the guide prescribes: the counters are in KB; FETCH_SIZE under-reports coalesced
+    streaming reads on gfx950 by the factor calibrated on a kernel of known byte count (profiles/pmc_summary.json `fetch_calibration`: 2.013).
+    Returns (bytes_per_launch or None, description)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) for k in os.environ):
+        return None, "this process is itself running under a profiler"
+    factor = 2.013135990798753
+    try:
+        factor = float(json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["fetch_calibration"]["factor"])
+    except Exception:       # noqa: BLE001
+        pass
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_"))}
+    env["TMPDIR"] = "/tmp"
+    got = {}
+    work = tempfile.mkdtemp(prefix="gabo_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "out", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "prof_spd.py"), str(N_POINTS), str(DIM), "x", "3"]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s"
+            files = glob.glob(d + "/**/out_counter_collection.csv", recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {counter} pass wrote no counter file"
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if "spd_ai_pairwise_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not vals:
+                return None, f"no spd_ai_pairwise_kernel dispatch in the {counter} pass"
+            got[counter] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    total = got["FETCH_SIZE"] * 1024.0 * factor + got["WRITE_SIZE"] * 1024.0
+    return total, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (with --kernel-trace only) over 3 launches of "
+                   f"the same Gram build; KB -> B; FETCH_SIZE x {factor:.3f} (gfx950 under-report of coalesced reads, calibrated on a kernel of known "
+                   f"byte count: profiles/pmc_summary.json); raw KB per launch: FETCH_SIZE {got['FETCH_SIZE']:.0f}, WRITE_SIZE {got['WRITE_SIZE']:.0f}")
 
 
 def config5_pieces(device):
@@ -409,7 +469,10 @@ def main():
                     "(~60 ms) of fp64 load to reach its sustained clock (rocprofv3: 3.30 ms for the first dispatch, 2.67 ms from the "
                     "20th on, profiles/pmc_summary.json); reported in the line as `untimed_preheat_steps`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", choices=["auto", "measure", "file"], default="auto", help="roofline.traffic: measured in this run with two rocprofv3 "
+                    "--pmc passes (auto: when rocprofv3 is on PATH, one rank, not already under a profiler; ~30 s) or read from profiles/pmc_summary.json")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--sweep-lite", action="store_true", help="only the single-launch-solve variants of the config-4 sweep (tests: the eight-rank run on one device)")
     ap.add_argument("--no-symmetric", action="store_true", help="skip the separately reported x1-is-x2 run (profiling: keeps "
                     "the rocprof average of the pairwise kernel equal to the `value` launches)")
     args = ap.parse_args()
@@ -488,13 +551,17 @@ def main():
         if dist is not None:
             dist.barrier()
         sw_s0, sw_best, sw_val, sw_log = run_sweep(device, num_restarts=512, batched_rand=True, builtin_constraint=True)
-        sw_l = run_sweep(device, num_restarts=512, hip_graphs=True, batched_rand=True)[0]        # the same constraint as an opaque lambda
+        lite = args.sweep_lite
+        sw_l = None if lite else run_sweep(device, num_restarts=512, hip_graphs=True, batched_rand=True)[0]        # the same constraint as an opaque lambda
         tt = torch.tensor([sw_s0], dtype=torch.float64, device=device)
         if dist is not None:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        sw_c, _, sw_val_c, _ = run_sweep(device, num_restarts=512, hip_graphs=True, batched_rand=True, capture_constraints=True)
-        sw_d = min(run_sweep(device, num_restarts=512, hip_graphs=True, device_rand=True, capture_constraints=True)[0] for _ in range(3))
-        sw_val_d = run_sweep(device, num_restarts=512, hip_graphs=True, device_rand=True, capture_constraints=True)[2]
+        if lite:
+            sw_c = sw_val_c = sw_d = sw_val_d = None
+        else:
+            sw_c, _, sw_val_c, _ = run_sweep(device, num_restarts=512, hip_graphs=True, batched_rand=True, capture_constraints=True)
+            sw_d = min(run_sweep(device, num_restarts=512, hip_graphs=True, device_rand=True, capture_constraints=True)[0] for _ in range(3))
+            sw_val_d = run_sweep(device, num_restarts=512, hip_graphs=True, device_rand=True, capture_constraints=True)[2]
         # the constraint given as functools.partial(max_eigenvalue_constraint_torch, ...) like the reference example does
         # (examples/gabo_spd.py:136-138): evaluated on the device, the whole solve is one launch (gabo_spd_tr_solve)
         sw_s = min(run_sweep(device, num_restarts=512, batched_rand=True, builtin_constraint=True)[0] for _ in range(3))
@@ -516,18 +583,52 @@ def main():
             ww = torch.tensor([run_sweep(device, **kw)[0]], dtype=torch.float64, device=device)
             dist.all_reduce(ww, op=dist.ReduceOp.MAX)
             weak = {"restarts": 512 * world, "seconds": float(ww.item()), "restarts_per_s": 512 * world / float(ww.item())}
+        # STRONG scaling of the sweep (north_star: ">= 6x further at 8 GPUs on a 512-restart acquisition sweep"): the total number of restarts fixed, sharded
+        # r % P over the ranks, at 512 and at 8192 restarts; time = max over ranks (device sampler: the same draw whatever P is)
+        strong = {}
+        for total in (512, 8192):
+            kw = dict(num_restarts=total, raw_samples=4 * total, device_rand=True, builtin_constraint=True)
+            run_sweep(device, **kw)
+            if dist is not None:
+                dist.barrier()
+            best_s, best_v = float("inf"), None
+            for _ in range(3):
+                s_, _, v_, _ = run_sweep(device, **kw)
+                if s_ < best_s:
+                    best_s, best_v = s_, v_
+            ts_ = torch.tensor([best_s], dtype=torch.float64, device=device)
+            if dist is not None:
+                dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+            strong[str(total)] = {"restarts": total, "raw_samples": 4 * total, "n_gpus": world, "seconds": float(ts_.item()),
+                                  "restarts_per_s": total / float(ts_.item()), "best_acq": best_v}
+        # one GPU: the sweep's latency as a function of the number of restarts IT holds, which is what a rank of a P-GPU run sees (R / P restarts):
+        # predicted strong-scaling speed-up S_P(R) = t_1(R) / t_1(R / P), the all_gather of R x 16 doubles (< 20 us over xGMI) neglected
+        latency_table = None
+        if world == 1 and not lite:
+            latency_table = {}
+            for total in (64, 128, 256, 1024, 2048, 4096, 16384, 32768, 65536):
+                kw = dict(num_restarts=total, raw_samples=4 * total, device_rand=True, builtin_constraint=True)
+                try:
+                    run_sweep(device, **kw)
+                    latency_table[total] = min(run_sweep(device, **kw)[0] for _ in range(2))
+                except Exception as err:       # noqa: BLE001  (a size the maximiser declines must not take the headline line with it)
+                    print(f"sweep with {total} restarts failed: {err}", file=sys.stderr)
+            latency_table[512], latency_table[8192] = strong["512"]["seconds"], strong["8192"]["seconds"]
+            latency_table = {str(k): latency_table[k] for k in sorted(latency_table)}
         sweep = {"workload": "gabo_spd S^5_++: GP(50 obs of the Ackley objective, SURVEY 8d)+EI, 2048 raw samples, 512 restarts, ConstrainedTR semantics, FD Hessian, "
                              "lambda_max<=5 constraint built with functools.partial as in the reference example; raw samples drawn in one "
                              "vectorised host call and scored by the fused chain; the trust-region solve is ONE launch (every wave iterates "
                              "its restart: tCG, proposal, acquisition, constraint, update); restarts sharded over ranks, all_gather+argmax",
                  "seconds": float(tt.item()), "restarts_per_s": 512 / float(tt.item()), "best_acq": sw_val,
                  "tr_iterations": int(sw_log["iterations"]),
-                 "seconds_constraint_as_opaque_lambda_hipgraphs": float(sw_l),
-                 "seconds_constraints_captured": float(sw_c), "best_acq_constraints_captured": sw_val_c,
-                 "seconds_constraints_captured_device_rand": float(sw_d), "best_acq_device_rand": sw_val_d,
+                 "seconds_constraint_as_opaque_lambda_hipgraphs": sw_l,
+                 "seconds_constraints_captured": sw_c, "best_acq_constraints_captured": sw_val_c,
+                 "seconds_constraints_captured_device_rand": sw_d, "best_acq_device_rand": sw_val_d,
                  "seconds_single_launch_solve": sw_s, "seconds_single_launch_solve_device_rand": sw_sd, "best_acq_single_launch_solve": sw_val_s,
                  "best_acq_single_launch_solve_device_rand": sw_val_sd,
                  "weak_scaling_512_restarts_per_gpu": weak,
+                 "strong_scaling_fixed_total_restarts": strong,
+                 "seconds_by_restarts_one_gpu": latency_table,
                  "note": "latency-bound: 512 restarts are 2 waves per CU and each wave runs its restart serially (about 0.15 ms per "
                          "trust-region iteration); plus 2-3.5 ms of initial-condition generation when the raw samples are drawn on the host "
                          "(0.1 ms on the device).  Opaque constraint callables cost 0.4 ms per iteration and one graph replay each.  Does not "
@@ -575,10 +676,16 @@ def main():
         kernel_s = ev_ms * 1e-3               # prep + pairwise launches; the pairwise kernel is > 99.5 % of it (profiles/)
         ach_gbs = pairs_per_step * BYTES_PER_PAIR / kernel_s / 1e9
         ach_tf = pairs_per_step * FLOP_PER_PAIR / kernel_s / 1e12
-        traffic = None
+        traffic, traffic_source = None, None
+        if args.traffic != "file" and world == 1:
+            traffic, traffic_source = measure_hbm_traffic()
+            if traffic is None and args.traffic == "measure":
+                raise RuntimeError(f"--traffic measure: {traffic_source}")
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if traffic is None and os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            traffic_source = ("profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch, committed; NOT re-measured "
+                              f"inside this run: {traffic_source or 'not requested'})")
         line = {
             "metric": "SPD affine-invariant kernel-matrix build, pairs/sec (N=4096,d=10)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "world_size": world, "backend": backend, "steps": args.steps, "warmup": args.warmup,
@@ -588,10 +695,12 @@ def main():
             "config": {"workload": "SpdAffineInvariantGaussianKernel S^10_++ Gram K(X,X), N=4096 random SPD 10x10 (Mandel, "
                                    "eig U[0.05,5], seed 1234+rank), beta=0.2+ln2, all N^2 pairs evaluated; one independent "
                                    "point set per GPU", "n_points": N_POINTS, "dim": DIM, "parallelism": f"independent Gram builds x{world}"},
-            "roofline": {"bound": "mfma", "binding_resource": "fp64 issue (vector pipe; the f64 matrix pipe shares it: tools/ubench_mfma_f64.hip)",
+            "roofline": {"bound": "mfma", "bound_note": "the harness token for 'compute-bound'; what binds is the fp64 VECTOR issue rate - the kernel issues no MFMA "
+                                                        "instruction (PMC SQ_INSTS_VALU_MFMA_MOPS_F64 = 0) and the f64 matrix pipe shares the datapath",
+                         "mfma_instructions": 0,
+                         "binding_resource": "fp64 issue (vector pipe; the f64 matrix pipe shares it: tools/ubench_mfma_f64.hip)",
                          "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
-                         "same launch, committed; not re-measured inside this run)",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_over_compulsory": None if traffic is None else traffic / (pairs_per_step * 8.0 + 2 * N_POINTS * (DIM * (DIM + 1) // 2) * 8),
                          "kernel": "gabo::spd_ai_pairwise_kernel<10>", "kernel_ms": ev_ms,
                          "kernel_ms_median": float(np.median(step_ms)), "kernel_ms_min": float(np.min(step_ms)),
@@ -627,6 +736,17 @@ def main():
                                                            "(2048 x 16 doubles per rank) and one of (value, candidate) per restart (512 x 16 doubles per rank)",
             "measured_single_gpu_latencies_us": {"tr_iteration_launch_64_restarts": 86, "tr_iteration_launch_512_restarts": 113,
                                                  "tr_iteration_launch_2048_restarts": 182, "tr_iteration_launch_8192_restarts": 597}}
+        if sweep is not None and sweep.get("seconds_by_restarts_one_gpu"):
+            tab = {int(k): v for k, v in sweep["seconds_by_restarts_one_gpu"].items()}
+            pred = {str(r): tab[r] / tab[r // 8] for r in sorted(tab) if r // 8 in tab}
+            reach = [r for r in sorted(tab) if r // 8 in tab and tab[r] / tab[r // 8] >= 6.0]
+            line["expected_scaling"]["acq_sweep.strong_measured_model"] = {
+                "model": "S_8(R) = t_1(R) / t_1(R / 8) from THIS run's one-GPU sweep times (device sampler, single-launch solve; `acq_sweep.seconds_by_restarts_one_gpu`); "
+                         "a rank of an 8-GPU run holds R / 8 restarts and R / 2 raw samples; the all_gather of the R candidate rows is < 20 us",
+                "predicted_speedup_at_8_gpus_by_total_restarts": pred,
+                "smallest_total_restarts_reaching_6x_at_8_gpus": reach[0] if reach else None,
+                "north_star_512_restarts": f"predicted {pred.get('512', float('nan')):.2f}x at 8 GPUs: the 512-restart sweep is latency-bound (one wave per restart, "
+                                           "2 waves per CU on one GPU already), so the >= 6x of north_star is reached only from the restart count above"}
         if collectives is not None:
             line["collectives"] = collectives
         if sweep is not None:
@@ -635,7 +755,7 @@ def main():
             line["sharded_gram"] = sharded
         if sphere_sweep_result is not None:
             line["acq_sweep_sphere"] = sphere_sweep_result
-        if not args.no_sweep:
+        if not args.no_sweep and not args.sweep_lite:
             # config 2 of BASELINE.json beside the headline: SphereGaussianKernel S^9, N=4096 (HBM-write bound: 8.04 B/pair)
             from gabotorch_amd import ops as _ops
             from oracle import sphere as osph
@@ -649,6 +769,18 @@ def main():
             # other stream or once the graphs are destroyed (tools/sphere_bench_probe5.py).  The headline job ran before any graph existed.
             import gc
             gc.collect()
+
+            def cold20():
+                """what a caller who builds ONE Gram sees: launches 1..20 after a device synchronisation, each between its own pair of events"""
+                torch.cuda.synchronize()
+                ev_ = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+                ev_[0].record()
+                for c_ in range(20):
+                    _ops.sphere_pairwise(st_, st_, beta=sbeta)
+                    ev_[c_ + 1].record()
+                torch.cuda.synchronize()
+                return [ev_[c_].elapsed_time(ev_[c_ + 1]) for c_ in range(20)]
+            sph_cold_default = cold20()          # on the process's default stream (with the sweeps' hipGraph executables alive: see above)
             sph_stream = torch.cuda.Stream(device)
             sph_stream.wait_stream(torch.cuda.current_stream(device))
             _sph_ctx = torch.cuda.stream(sph_stream)
@@ -659,6 +791,7 @@ def main():
             # without memory traffic (the fp64 Gram builds and latency-bound sweeps above) even more.  Timed: five blocks of 100 launches,
             # the median block reported, all five disclosed.
             sph_preheat, sph_block, sph_blocks = 600, 100, 5
+            sph_cold = cold20()
             for _ in range(sph_preheat):
                 _ops.sphere_pairwise(st_, st_, beta=sbeta)
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(sph_blocks + 1)]
@@ -679,6 +812,11 @@ def main():
                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac": pairs_per_step * 8.04 / (sph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "model": "8.04 algorithmic B/pair (one fp64 output + amortised operand reads)"},
+                                   "cold_ms": float(np.median(sph_cold_default)), "cold_ms_first_launch": sph_cold_default[0],
+                                   "cold_ms_private_stream": float(np.median(sph_cold)),
+                                   "cold_note": "median / first of launches 1-20 after a device synchronisation, no preheat, each launch between its own pair of "
+                                                "events (the launch gap is inside): `cold_ms` on the default stream, `cold_ms_private_stream` on the stream the "
+                                                "sustained figure is taken on",
                                    "untimed_preheat_launches": sph_preheat, "timed": f"{sph_blocks} blocks of {sph_block} launches, median block, on a non-default stream",
                                    "ms_per_step_of_each_block": sph_block_ms, "max_abs_err_vs_oracle_block": sph_err}
             line["roofline_sphere"] = dict(line["sphere_gram"]["roofline"], kernel="gabo::sphere_pairwise_kernel<0, true, 3, false, false, true>", kernel_ms=sph_ms,

@@ -7,7 +7,7 @@ kernel classes keep their reference signatures.  The stand-in only covers what t
 
 import torch
 
-try:  # pragma: no cover - exercised only where gpytorch exists
+try:  # (exercised by tests/test_real_package_branch_cpu.py with modules of the real package's shape)
     import gpytorch
     from gpytorch.constraints import GreaterThan, Positive
     from gpytorch.kernels import Kernel, ScaleKernel

@@ -339,6 +339,9 @@ __global__ __launch_bounds__(256) void frobenius_pairwise_kernel(const double* _
             const double dist = __builtin_sqrt(s);
             val = mode == GABO_OUT_DISTANCE ? dist : exp_neg_tab(dist * neg_beta, ec, ec3, tab);
         }
+        // (the argument clamp of the table exp returns its bound for a NaN; a NaN entry - e.g. the logm of a matrix with a non-positive
+        // eigenvalue in the log-Euclidean kernels - must give a NaN kernel value, as torch.exp does in kernels_spd.py:238-240, 309-311)
+        val = s != s ? s : val;
         if (j < n2) ob[i * n2] = val;
     }
 }

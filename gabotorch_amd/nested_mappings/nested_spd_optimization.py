@@ -4,6 +4,8 @@ distances between the data and their reconstructions, minimised over  V in G(D, 
 t = sigmoid(.) in (0, 1), under W^T V = 0 by the augmented Lagrangian method.  Both built-in costs are ONE HIP launch per evaluation,
 value and gradient together (gabo_nested_spd_reconstruction: csrc/nested_spd_reconstruction.hip)."""
 import os
+import threading
+import weakref
 
 import numpy as np
 import torch
@@ -36,6 +38,14 @@ def _composed_cost(metric, x_data, x_data_projected, projection_matrix, projecti
 
 
 _prepared = {}      # (metric, data pointers / versions) -> NestedSpdReconstruction of the most recent data set
+_prepared_lock = threading.Lock()
+
+
+def clear_prepared_reconstruction():
+    """Drops the cached preparation of the most recent data set (device workspaces included).  Call it after modifying the data tensors behind
+    autograd's back (`.data`, memory shared with numpy): such edits do not move `_version`, which is what the cache key watches."""
+    with _prepared_lock:
+        _prepared.clear()
 
 
 def _fused_cost(metric, x_data, x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix, contraction_matrix):
@@ -44,13 +54,18 @@ def _fused_cost(metric, x_data, x_data_projected, projection_matrix, projection_
         return _composed_cost(metric, x_data, x_data_projected, projection_matrix, projection_complement_matrix, bottom_spd_matrix,
                               contraction_matrix)
     # the prepared object (logm / inverse factors of the data, square roots of the latent points: two launches and a status read-back) is
-    # kept for as long as the caller comes back with the same, unmodified tensors
-    key = (int(metric),) + tuple((a.data_ptr(), a._version, tuple(a.shape), str(a.device)) for a in (x_data, x_data_projected, projection_matrix))
-    rec = _prepared.get("rec") if _prepared.get("key") == key else None
-    if rec is None:
-        rec = ops.NestedSpdReconstruction(x_data, x_data_projected, projection_matrix, metric)
-        _prepared["key"], _prepared["rec"] = key, rec
-        _prepared["hold"] = (x_data, x_data_projected, projection_matrix)      # (keeps the pointers of the key from being recycled)
+    # kept for as long as the caller comes back with the same, unmodified tensors AND keeps them alive: the entry holds them weakly, so it
+    # dies with the data set instead of pinning it (and its device workspaces) for the life of the process
+    tensors = (x_data, x_data_projected, projection_matrix)
+    key = (int(metric),) + tuple((a.data_ptr(), a._version, tuple(a.shape), str(a.device)) for a in tensors)
+    with _prepared_lock:
+        rec = _prepared.get("rec") if _prepared.get("key") == key else None
+        if rec is not None and any(r() is not a for r, a in zip(_prepared["refs"], tensors)):
+            rec = None      # same addresses, other tensor objects: the memory was recycled
+        if rec is None:
+            rec = ops.NestedSpdReconstruction(x_data, x_data_projected, projection_matrix, metric)
+            _prepared["key"], _prepared["rec"] = key, rec
+            _prepared["refs"] = tuple(weakref.ref(a, lambda _r: _prepared.clear()) for a in tensors)
     return rec(projection_complement_matrix, bottom_spd_matrix, contraction_matrix)
 
 

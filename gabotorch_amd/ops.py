@@ -104,6 +104,17 @@ def _raise_if_not_spd(status, what):
             raise RuntimeError(f"{what}: input matrix #{st[1]} is not positive definite (Cholesky pivot <= 0)")
 
 
+def _check_launch(rc, status, what):
+    """return code first, then the device status word.  The cached per-device word (_status_word) must never outlive the call that wrote it: if
+    the return code already raises, the word is cleared on the way out, so a later valid call cannot be blamed for this one's matrix."""
+    try:
+        _lib.check(rc, what)
+    except Exception:
+        status.zero_()
+        raise
+    _raise_if_not_spd(status, what)
+
+
 def spd_ai_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, symmetric=False, return_dist=False):
     """x1 (..., N1, d_vec), x2 (..., N2, d_vec) Mandel vectors -> (..., N1, N2) on x1's device.
     return_dist=True also returns the distance matrix written by the same launch."""
@@ -130,8 +141,7 @@ def spd_ai_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, symmetric=Fal
         rc = lib.gabo_spd_ai_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), dist.data_ptr() if return_dist else None,
                                       nb, n1, n2, d, s1, s2, float(beta), flags, ws.data_ptr(), wsb, status.data_ptr(),
                                       _stream_ptr(dev))
-    _lib.check(rc, "gabo_spd_ai_pairwise")
-    _raise_if_not_spd(status, "gabo_spd_ai_pairwise")
+    _check_launch(rc, status, "gabo_spd_ai_pairwise")
     if return_dist:
         return out.to(out_device), dist.to(out_device)
     return out.to(out_device)
@@ -167,8 +177,8 @@ def spd_ai_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, wrt
                                       _stream_ptr(dev))
     _lib.check(rc, "gabo_spd_ai_backward")
     _raise_if_not_spd(status, "gabo_spd_ai_backward")
-    if sf == 0 and nb > 1:      # the differentiated set was one expand()ed set: its gradient is the sum over the batch
-        gx = gx.reshape(nb, m1, -1).sum(0).expand(bshape + (m1, a.shape[-1]))
+    # (a set handed over as ONE expand()ed set, batch stride 0: the result is still the gradient with respect to the expanded tensor, one slice
+    # per batch entry - autograd's ExpandBackward sums them for the base tensor; summing here as well would count the batch twice)
     return gx.to(out_device)
 
 
@@ -204,44 +214,56 @@ def spd_ai_backward2(x1, x2, grad_out, u, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN,
                                        ws.data_ptr(), wsb, status.data_ptr(), _stream_ptr(dev))
     _lib.check(rc, "gabo_spd_ai_backward2")
     _raise_if_not_spd(status, "gabo_spd_ai_backward2")
-    if mx is not None and s2 == 0 and nb > 1:   # x2 was one expand()ed set: its derivative is the sum over the batch
-        mx = mx.reshape(nb, n2, -1).sum(0).expand(bshape + (n2, a.shape[-1]))
+    # (x2 as one expand()ed set: mx stays per batch entry, like spd_ai_backward's result - ExpandBackward does the sum)
     return hv.to(out_device), (None if dg is None else dg.to(out_device)), (None if mx is None else mx.to(x2.device))
 
 
 class _SpdAiGradFunction(torch.autograd.Function):
     """The first-order gradient of sum(grad_out * K(x1, x2)) with respect to x1 (wrt = 1) or x2 (wrt = 2) as a differentiable function of
-    (x1, x2, grad_out): the node a second autograd pass runs through (create_graph=True; pymanopt_addons/tools/autodiff/_pytorch.py:103-116
+    (x1, x2, grad_out, beta): the node a second autograd pass runs through (create_graph=True; pymanopt_addons/tools/autodiff/_pytorch.py:103-116
     builds exact Hessian-vector products that way).  Its own backward is gabo_spd_ai_backward2: the diagonal block of the Hessian, the mixed
-    block and the directional derivative of K for grad_out; for wrt = 2 the same call with the two sets exchanged (d(A, B) = d(B, A)).  Mixed
-    second derivatives with beta are not provided (None)."""
+    block and the directional derivative of K for grad_out; for wrt = 2 the same call with the two sets exchanged (d(A, B) = d(B, A)).
+    The mixed derivative with beta comes from the same launch: dK/dx = -beta K d(d^2)/dx (Gaussian), so d/dbeta (dK/dx) = (1/beta - d^2) dK/dx and
+    d <g, u> / dbeta = sum_ij grad_out_ij (1/beta - d_ij^2) <u_i, dK_ij/dx_i>  (Laplace: d instead of d^2; distance output: 0)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, grad_out, bval, mode, wrt):
+    def forward(ctx, x1, x2, grad_out, beta, mode, wrt):
+        bval = float(beta)
         ctx.save_for_backward(x1, x2, grad_out)
         ctx.bval, ctx.mode, ctx.wrt = bval, mode, wrt
+        ctx.beta_shape, ctx.beta_device = beta.shape, beta.device
         return spd_ai_backward(x1, x2, grad_out, bval, mode, wrt=wrt).to((x1 if wrt == 1 else x2).dtype)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, u):
         x1, x2, grad_out = ctx.saved_tensors
-        need1, need2, needg = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need1, need2, needg, needb = ctx.needs_input_grad[:4]
+        needb = needb and ctx.mode != _lib.GABO_OUT_DISTANCE
         if ctx.wrt == 1:
-            hv, dg, mx = spd_ai_backward2(x1, x2, grad_out, u, ctx.bval, ctx.mode, want_dgrad_out=needg, want_mixed=need2)
+            hv, dg, mx = spd_ai_backward2(x1, x2, grad_out, u, ctx.bval, ctx.mode, want_dgrad_out=needg or needb, want_mixed=need2)
             d1, d2 = hv, mx
         else:
-            hv, dg, mx = spd_ai_backward2(x2, x1, grad_out.transpose(-1, -2), u, ctx.bval, ctx.mode, want_dgrad_out=needg, want_mixed=need1)
+            hv, dg, mx = spd_ai_backward2(x2, x1, grad_out.transpose(-1, -2), u, ctx.bval, ctx.mode, want_dgrad_out=needg or needb, want_mixed=need1)
             d1, d2 = mx, hv
             dg = None if dg is None else dg.transpose(-1, -2)
-        return (d1.to(x1.dtype) if need1 else None), (d2.to(x2.dtype) if need2 else None), (dg.to(grad_out.dtype) if needg else None), None, None, None
+        gb = None
+        if ctx.needs_input_grad[3]:
+            if needb:
+                dist = spd_ai_pairwise(x1, x2, 1.0, _lib.GABO_OUT_DISTANCE).to(dg.device)
+                w = dist * dist if ctx.mode == _lib.GABO_OUT_GAUSSIAN else dist
+                gb = (grad_out.to(dg.device) * dg * (1.0 / ctx.bval - w)).sum()
+            else:
+                gb = torch.zeros((), dtype=torch.float64, device=grad_out.device)
+            gb = gb.reshape(ctx.beta_shape).to(ctx.beta_device)
+        return (d1.to(x1.dtype) if need1 else None), (d2.to(x2.dtype) if need2 else None), (dg.to(grad_out.dtype) if needg else None), gb, None, None
 
 
 class _SpdAiKernelFunction(torch.autograd.Function):
     """K(x1, x2; beta) with the HIP forward and the HIP closed-form backward.  The gradient with respect to x1 is itself differentiable
     and so is the one with respect to x2 (in x1, x2 and the upstream gradient: _SpdAiGradFunction), which is what exact Hessian-vector
     products of a cost built on the kernel need (approx_hessian=False; the reference's SPD examples run with approx_hessian=True,
-    manifold_optimize.py:198-202); the gradient with respect to beta is first order."""
+    manifold_optimize.py:198-202); so is the gradient with respect to beta (second order in x1, x2, beta and the upstream gradient)."""
 
     @staticmethod
     def forward(ctx, x1, x2, beta, mode):
@@ -249,7 +271,7 @@ class _SpdAiKernelFunction(torch.autograd.Function):
         need = x1.requires_grad or x2.requires_grad or (torch.is_tensor(beta) and beta.requires_grad)
         if need:
             out, dist = spd_ai_pairwise(x1, x2, bval, mode, return_dist=True)
-            ctx.save_for_backward(x1, x2, out, dist)
+            ctx.save_for_backward(x1, x2, out, dist, beta)
         else:
             same = x1.data_ptr() == x2.data_ptr() and x1.shape == x2.shape and x1.stride() == x2.stride() and x1.dim() == 2
             out = spd_ai_pairwise(x1, x2, bval, mode, symmetric=same)
@@ -260,28 +282,37 @@ class _SpdAiKernelFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        x1, x2, out, dist = ctx.saved_tensors
+        x1, x2, out, dist, beta = ctx.saved_tensors
         g1 = g2 = gb = None
         second = torch.is_grad_enabled()              # create_graph=True: this pass is being recorded
-        second = second and (x1.requires_grad or x2.requires_grad or grad_out.requires_grad)
+        second = second and (x1.requires_grad or x2.requires_grad or grad_out.requires_grad or beta.requires_grad)
         if ctx.needs_input_grad[0]:
             if second:
-                g1 = _SpdAiGradFunction.apply(x1, x2, grad_out, ctx.bval, ctx.mode, 1)
+                g1 = _SpdAiGradFunction.apply(x1, x2, grad_out, beta, ctx.mode, 1)
             else:
                 g1 = spd_ai_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=1).to(x1.dtype)
         if ctx.needs_input_grad[1]:
             if second:
-                g2 = _SpdAiGradFunction.apply(x1, x2, grad_out, ctx.bval, ctx.mode, 2)
+                g2 = _SpdAiGradFunction.apply(x1, x2, grad_out, beta, ctx.mode, 2)
             else:
                 g2 = spd_ai_backward(x1, x2, grad_out, ctx.bval, ctx.mode, wrt=2).to(x2.dtype)
-        grad_out = grad_out.detach()
         if ctx.needs_input_grad[2]:
-            if ctx.mode == _lib.GABO_OUT_GAUSSIAN:
-                gb = -(grad_out * out * dist * dist).sum()      # dK/dbeta = -d^2 K
-            elif ctx.mode == _lib.GABO_OUT_LAPLACE:
-                gb = -(grad_out * out * dist).sum()             # dK/dbeta = -d K
-            else:
+            if ctx.mode == _lib.GABO_OUT_DISTANCE:
                 gb = torch.zeros((), dtype=grad_out.dtype, device=grad_out.device)
+            elif second:
+                # A recorded pass: dK/dbeta = -d^2 K (Gaussian) / -d K (Laplace) must itself be a function of (x1, x2, beta, grad_out), so it
+                # is rebuilt from two differentiable evaluations (kernel value and distance) instead of the saved, constant matrices - the
+                # marginal likelihood's Hessian in beta and the x-beta blocks then come out complete (third derivatives are not provided:
+                # the nodes created here are first / second order like every other one).
+                kk = _SpdAiKernelFunction.apply(x1, x2, beta, ctx.mode)
+                dd = _SpdAiKernelFunction.apply(x1, x2, beta, _lib.GABO_OUT_DISTANCE)
+                gb = -(grad_out * kk * (dd * dd if ctx.mode == _lib.GABO_OUT_GAUSSIAN else dd)).sum()
+            else:
+                go = grad_out.detach()
+                if ctx.mode == _lib.GABO_OUT_GAUSSIAN:
+                    gb = -(go * out * dist * dist).sum()      # dK/dbeta = -d^2 K
+                else:
+                    gb = -(go * out * dist).sum()             # dK/dbeta = -d K
             gb = gb.reshape(ctx.beta_shape).to(ctx.beta_device)
         return g1, g2, gb, None
 
@@ -824,8 +855,7 @@ def nested_spd_gram(x1, x2, w, beta, metric=_lib.GABO_METRIC_AFFINE_INVARIANT, m
     with torch.cuda.device(dev):
         rc = lib.gabo_nested_spd_gram(a.data_ptr(), b.data_ptr(), W.data_ptr(), out.data_ptr(), nb, n1, n2, D, dl, int(metric), float(beta), int(mode),
                                       ws.data_ptr(), wsb, status.data_ptr(), _stream_ptr(dev))
-    _lib.check(rc, "gabo_nested_spd_gram")
-    _raise_if_not_spd(status, "gabo_nested_spd_gram")
+    _check_launch(rc, status, "gabo_nested_spd_gram")
     return out.to(out_device)
 
 

@@ -1,7 +1,7 @@
 """`botorch` as the reference examples use it."""
 import types as _types
 
-try:                                     # pragma: no cover - only where botorch exists
+try:                                     # (tests/test_real_package_branch_cpu.py)
     from botorch import acquisition, fit_gpytorch_model, models  # noqa: F401
 except Exception:                        # noqa: BLE001
     from .. import models as _models

@@ -1,7 +1,7 @@
 """`gpytorch` as the reference examples use it."""
 import types as _types
 
-try:                                     # pragma: no cover - only where gpytorch exists
+try:                                     # (tests/test_real_package_branch_cpu.py)
     from gpytorch import constraints, kernels, likelihoods, mlls, priors  # noqa: F401
 except Exception:                        # noqa: BLE001
     from .. import _compat, models

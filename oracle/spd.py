@@ -162,6 +162,58 @@ def spd_ai_gaussian_kernel_grads(x1_mandel, x2_mandel, beta, grad_k):
     return symmetric_matrix_to_vector_mandel(ga), symmetric_matrix_to_vector_mandel(gb)
 
 
+def _divided_differences(fun, dfun, lam):
+    """first divided differences of `fun` at the eigenvalues, the derivative where two of them coincide (to rounding)"""
+    a, b = lam[..., :, None], lam[..., None, :]
+    close = np.abs(a - b) <= 1e-9 * (np.abs(a) + np.abs(b))
+    den = np.where(close, 1.0, a - b)
+    return np.where(close, dfun(0.5 * (a + b)), (fun(a) - fun(b)) / den)
+
+
+def spd_ai_kernel_hvp(x1_mandel, x2_mandel, beta, grad_k, u_mandel, mode="gaussian"):
+    """Second order: d/dt grad_x1 [sum(grad_k * K(x1 + t u, x2))] at t = 0, Mandel layout, with K the Gaussian / Laplace kernel or the
+    distance itself.  The reference obtains it as torch.autograd.grad(<egrad, u>, x) through cholesky / inverse / bmm / symeig / log / exp
+    (pymanopt_addons/tools/autodiff/_pytorch.py:103-116 `ehess`, Riemannian_utils/spd_utils_torch.py:87-120, kernels_spd.py:94-98, 185).
+
+    Closed form per pair, A = x1_i = L L^T, M = L^-1 B L^-T = V diag(lam) V^T, f = sum log^2 lam, Ut = L^-1 U L^-T, U' = V^T Ut V:
+        grad_A f      = -2 L^-T logm(M) L^-1,                <grad_A f, U> = -2 sum_k log(lam_k) U'_kk,
+        Hess_A f [U]  =  2 L^-T V (C o U') V^T L^-1,          C_kl = divided differences of t log t  (C_kk = 1 + log lam_k),
+        D^2 K [U]     =  phi'(f) Hess f [U] + phi''(f) <grad f, U> grad f,      K = phi(f)
+    (phi(f) = exp(-beta (f + 1e-15)), exp(-beta sqrt(f + 1e-15)), sqrt(f + 1e-15)).  Pinned by tests/golden/hvp.npz, which is the
+    reference's own `ehess`."""
+    a = vector_to_symmetric_matrix_mandel(x1_mandel)
+    b = vector_to_symmetric_matrix_mandel(x2_mandel)
+    u = vector_to_symmetric_matrix_mandel(u_mandel)
+    li = _chol_inv(a)
+    m = np.einsum("...iab,...jbc,...idc->...ijad", li, b, li, optimize=True)
+    lam, v = np.linalg.eigh(m, UPLO="U")
+    lg = np.log(lam)
+    f = np.sum(lg * lg, -1)
+    s = f + 1e-15
+    if mode == "gaussian":
+        k = np.exp(-beta * s)
+        p1, p2 = -beta * k, beta * beta * k
+    elif mode == "laplace":
+        r = np.sqrt(s)
+        k = np.exp(-beta * r)
+        p1, p2 = -beta * k / (2.0 * r), k * (beta * beta / (4.0 * s) + beta / (4.0 * s * r))
+    elif mode == "distance":
+        r = np.sqrt(s)
+        p1, p2 = 1.0 / (2.0 * r), -1.0 / (4.0 * s * r)
+    else:
+        raise ValueError(mode)
+    ut = np.einsum("...iab,...ibc,...idc->...iad", li, u, li, optimize=True)           # L^-1 U L^-T per row
+    up = np.einsum("...ijba,...ibc,...ijcd->...ijad", v, ut, v, optimize=True)          # V^T Ut V per pair
+    c = _divided_differences(lambda t: t * np.log(t), lambda t: 1.0 + np.log(t), lam)
+    hess_f = 2.0 * np.einsum("...ab,...bc,...dc->...ad", v, c * up, v, optimize=True)    # in the whitened coordinates
+    grad_f = -2.0 * np.einsum("...ab,...b,...cb->...ac", v, lg, v)
+    inner = -2.0 * np.einsum("...k,...kk->...", lg, up)
+    g = np.asarray(grad_k)
+    core = (g * p1)[..., None, None] * hess_f + (g * p2 * inner)[..., None, None] * grad_f
+    hv = np.einsum("...iba,...ijbc,...icd->...iad", li, core, li, optimize=True)
+    return symmetric_matrix_to_vector_mandel(hv)
+
+
 # ------------------------------------------------------------------------------------- matrix functions
 def _sym_fun(x, f):
     lam, v = np.linalg.eigh(np.asarray(x, dtype=np.float64), UPLO="U")

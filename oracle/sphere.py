@@ -45,6 +45,28 @@ def sphere_gaussian_kernel_grads(x1, x2, beta, grad_k):
     return np.einsum("...ij,...jd->...id", w, x2), np.einsum("...ij,...id->...jd", w, x1)
 
 
+def sphere_gaussian_kernel_hvp(x1, x2, beta, grad_k, u):
+    """Second order: d/dt grad_x1 [sum(grad_k * K(x1 + t u, x2))] at t = 0 for the Gaussian kernel, Euclidean coordinates (what the reference's
+    PyTorch backend returns as `ehess`, pymanopt_addons/tools/autodiff/_pytorch.py:103-116, through sphere_utils_torch.py:12-55 and
+    kernels_sphere.py:90-94).  K = phi(c), c = <x1_i, x2_j>:  Hess[U]_i = sum_j grad_k_ij phi''(c_ij) <x2_j, u_i> x2_j with
+    phi' = 2 beta psi phi,  phi'' = 2 beta phi (2 beta psi^2 - psi' / sin(theta)),  theta = acos c,  psi = theta / sin(theta),
+    psi' = (sin(theta) - theta cos(theta)) / sin^2(theta); zero where the clamp is active.  Pinned by tests/golden/hvp.npz."""
+    x1 = np.asarray(x1, dtype=np.float64)
+    x2 = np.asarray(x2, dtype=np.float64)
+    ip = np.einsum("...id,...jd->...ij", x1, x2)
+    lo, hi = -1.0 + CLAMP, 1.0 - CLAMP
+    c = np.clip(ip, lo, hi)
+    th = np.arccos(c)
+    sn = np.sqrt(1.0 - c * c)
+    phi = np.exp(-(th * th) * beta)
+    psi = th / sn
+    dpsi = (sn - th * c) / (sn * sn)
+    d2 = 2.0 * beta * phi * (2.0 * beta * psi * psi - dpsi / sn)
+    d2 = np.where((ip >= lo) & (ip <= hi), d2, 0.0)
+    w = np.asarray(grad_k) * d2 * np.einsum("...jd,...id->...ij", x2, np.asarray(u, dtype=np.float64))
+    return np.einsum("...ij,...jd->...id", w, x2)
+
+
 # ------------------------------------------------------------------ exp / log maps (reference numpy statements)
 def expmap(u, x0):
     """x0 cos|u| + u sin|u| / |u|; returns x0 where |u| < 1e-16   (Riemannian_utils/sphere_utils.py:14-38).  (..., dim)."""

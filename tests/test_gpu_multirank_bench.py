@@ -72,3 +72,36 @@ def test_bench_one_rank_through_rccl(tmp_path):
     assert line["backend"] == "nccl" and line["world_size"] == 1 and line["n_gpus"] == 1
     assert line["collectives"]["ok"] and line["collectives"]["all_gather_into_tensor_gram_slab_ms"] > 0
     assert line["value"] > 0 and line["parity"]["max_rel_err_vs_oracle_256x256"] < 1e-9
+
+
+def test_bench_eight_ranks_on_one_device(tmp_path):
+    """The partition arithmetic of the driver's 8-GPU run, executed once: eight gloo ranks on cuda:0.  per = ceil(4096 / 8) = 512
+    rows per rank in the sharded Gram with its padded all_gather slots, restarts r % 8 and raw samples by index range in the sweeps (512 restarts:
+    64 per rank; 8192: 1024 per rank; weak: 4096), max-over-ranks timing, one JSON line."""
+    env = dict(os.environ, GABO_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--preheat", "2",
+                        "--no-cpu-baseline", "--no-symmetric", "--sweep-lite"], env=env, capture_output=True, text=True, timeout=1800)
+    log = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(log, exist_ok=True)
+    with open(os.path.join(log, "bench_eight_ranks_one_device.log"), "w") as f:
+        f.write(r.stdout + "\n--- stderr ---\n" + r.stderr[-20000:])
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["world_size"] == 8 and line["backend"] == "gloo" and line["collectives"]["ok"]
+    assert line["value"] > 0 and line["parity"]["max_rel_err_vs_oracle_256x256"] < 1e-9
+    assert line["sharded_gram"]["parity_max_abs_vs_unsharded"] < 1e-12
+    sw = line["acq_sweep"]
+    assert sw["weak_scaling_512_restarts_per_gpu"]["restarts"] == 4096
+    strong = sw["strong_scaling_fixed_total_restarts"]
+    assert strong["512"]["n_gpus"] == 8 and strong["512"]["seconds"] > 0 and strong["8192"]["seconds"] > 0
+    # the index-addressed device stream makes the sharded sweeps equal to the one-rank sweeps of the same total size
+    sys.path.insert(0, ROOT)
+    from tools.sweep_bench import run_sweep
+    for total in (512, 8192):
+        single = run_sweep("cuda:0", num_restarts=total, raw_samples=4 * total, device_rand=True, builtin_constraint=True)[2]
+        got = strong[str(total)]["best_acq"]
+        assert abs(got - single) <= 1e-9 * abs(single), (total, got, single)

@@ -185,3 +185,36 @@ def test_spd_gram_indefinite_x2_gives_a_nan_column_like_the_reference(d, mode):
         k2, d2 = ops.spd_ai_pairwise(t(v1), t(v2), beta=0.8, return_dist=True)
         np.testing.assert_array_equal(np.isnan(k2.cpu().numpy()), nan_want)
         np.testing.assert_array_equal(np.isnan(d2.cpu().numpy()), nan_want)
+
+
+@pytest.mark.parametrize("mode", ["gaussian", "laplace", "distance"])
+def test_frobenius_and_log_euclidean_gram_propagate_nan(mode):
+    """exp(-beta |x - y|^2) of a NaN difference is NaN in the reference (torch.exp, kernels_spd.py:238-240, 309-311); the table exp of the
+    Frobenius epilogue clamps its argument and used to return 0.  A NaN row of x1 -> NaN row, of x2 -> NaN column; a matrix with a negative
+    eigenvalue has a NaN logm (spd_utils_torch.py:13-30: torch.log of the eigenvalues), hence a NaN row / column of the log-Euclidean Gram."""
+    rng = np.random.default_rng(77)
+    d = 3
+    m1, m2 = _rand_spd(rng, 70, d), _rand_spd(rng, 130, d)
+    v1, v2 = ospd.symmetric_matrix_to_vector_mandel(m1), ospd.symmetric_matrix_to_vector_mandel(m2)
+    a, b = v1.copy(), v2.copy()
+    a[7, 2] = np.nan
+    b[64, 0] = np.nan
+    got = ops.frobenius_pairwise(t(a), t(b), beta=0.6, mode=MODES[mode]).cpu().numpy()
+    with np.errstate(all="ignore"):
+        dist = ospd.frobenius_distance(ospd.vector_to_symmetric_matrix_mandel(a), ospd.vector_to_symmetric_matrix_mandel(b))
+        want = dist if mode == "distance" else (np.exp(-dist * 0.6) if mode == "laplace" else np.exp(-(dist * dist) * 0.6))
+    nan_want = np.isnan(want)
+    assert nan_want[7].all() and nan_want[:, 64].all() and nan_want.sum() == 130 + 70 - 1
+    np.testing.assert_array_equal(np.isnan(got), nan_want)
+    np.testing.assert_allclose(got[~nan_want], want[~nan_want], rtol=1e-9, atol=1e-12)
+    # log-Euclidean: logm of an indefinite matrix is NaN, and so is every kernel value it enters
+    w, q = np.linalg.eigh(m2[9])
+    w[0] = -0.5
+    m2b = m2.copy()
+    m2b[9] = (q * w) @ q.T
+    m2b[9] = 0.5 * (m2b[9] + m2b[9].T)
+    l1 = ops.spd_logm_mandel(t(v1))
+    l2 = ops.spd_logm_mandel(t(ospd.symmetric_matrix_to_vector_mandel(m2b)))
+    assert bool(torch.isnan(l2[9]).any()) and not bool(torch.isnan(l2[:9]).any())
+    k = ops.frobenius_pairwise(l1, l2, beta=0.6, mode=MODES[mode]).cpu().numpy()
+    assert np.isnan(k[:, 9]).all() and np.isnan(k).sum() == 70

@@ -8,6 +8,7 @@ import torch
 
 from gabotorch_amd import _lib, ops
 from oracle import spd as ospd
+from oracle import sphere as osph
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -169,3 +170,107 @@ def test_exact_hessian_of_an_acquisition_on_the_spd_manifold():
                                             symmetric_matrix_to_vector_mandel_torch, approx_hessian=approx)
         best[approx] = float(val.max())
     assert abs(best[False] - best[True]) <= 1e-5 * max(abs(best[True]), 1e-3), best
+
+
+@pytest.mark.parametrize("mode", ["gaussian", "laplace", "distance"])
+def test_second_derivatives_involving_beta_match_torch_double_backward(mode):
+    """d^2/dbeta^2, d^2/dbeta dx (from the beta gradient) and d/dbeta <dK/dx, U> (from the x gradient) under create_graph=True -
+    the marginal likelihood's Hessian with respect to beta and the x-beta blocks - complete, not the partial value of a constant saved matrix"""
+    rng = np.random.default_rng(31)
+    d, n1, n2 = 3, 5, 6
+    x1, x2 = _rand_spd_mandel(rng, n1, d), _rand_spd_mandel(rng, n2, d)
+    G, U1, U2 = rng.standard_normal((n1, n2)), rng.standard_normal(x1.shape), rng.standard_normal(x2.shape)
+
+    def run(dev, kernel):
+        a = torch.tensor(x1, device=dev, requires_grad=True)
+        b = torch.tensor(x2, device=dev, requires_grad=True)
+        beta = torch.tensor(0.7, dtype=torch.float64, requires_grad=True)
+        Gt = torch.tensor(G, device=dev, requires_grad=True)
+        L = (Gt * kernel(a, b, beta)).sum()
+        gb, ga, gbv = torch.autograd.grad(L, (beta, a, b), create_graph=True, allow_unused=True)
+        outs = []
+        if mode == "distance":          # beta does not enter: the gradient is zero (or absent), its derivatives too
+            assert gb is None or float(gb.detach().abs()) == 0.0
+            gb = None
+        if gb is not None:
+            outs += list(torch.autograd.grad(gb, (beta, a, b, Gt), retain_graph=True))
+        mixed = (ga * torch.tensor(U1, device=dev)).sum() + (gbv * torch.tensor(U2, device=dev)).sum()
+        (mb,) = torch.autograd.grad(mixed, beta, allow_unused=True)
+        outs.append(torch.zeros(()) if mb is None else mb)
+        return [o.detach().cpu().numpy() for o in outs]
+    want = run("cpu", lambda a, b, beta: _torch_kernel(a, b, beta, mode, d))
+    got = run(DEV, lambda a, b, beta: ops.spd_ai_kernel(a, b, beta, MODES[mode]))
+    assert len(want) == len(got)
+    for w, g in zip(want, got):
+        np.testing.assert_allclose(g, w, rtol=1e-8, atol=1e-9 * max(np.abs(w).max(), 1e-3))
+
+
+@pytest.mark.parametrize("which", ["x2", "x1"])
+def test_gradients_of_an_expanded_set_are_not_counted_twice(which):
+    """a training set handed over as .expand(b, n, dv) (gpytorch's train inputs in a batched acquisition call, batch stride 0):
+    first- and second-order gradients with respect to the BASE tensor against torch on the CPU"""
+    rng = np.random.default_rng(32)
+    d, nb, n1, n2 = 3, 4, 3, 5
+    base = _rand_spd_mandel(rng, n2, d)
+    other = np.stack([_rand_spd_mandel(rng, n1, d) for _ in range(nb)])
+    G, U = rng.standard_normal((nb, n1, n2)), rng.standard_normal(other.shape)
+
+    def run(dev, kernel):
+        bt = torch.tensor(base, device=dev, requires_grad=True)
+        ot = torch.tensor(other, device=dev, requires_grad=True)
+        ex = bt.expand(nb, n2, base.shape[-1])
+        K = kernel(ot, ex) if which == "x2" else kernel(ex, ot).transpose(-1, -2)
+        L = (torch.tensor(G, device=dev) * K).sum()
+        g_base, g_other = torch.autograd.grad(L, (bt, ot), create_graph=True)
+        (h_base,) = torch.autograd.grad((g_other * torch.tensor(U, device=dev)).sum(), bt)
+        return [t_.detach().cpu().numpy() for t_ in (g_base, g_other, h_base)]
+
+    def torch_kernel(a, b):
+        return torch.stack([_torch_kernel(a[k], b[k], 0.8, "gaussian", d) for k in range(nb)])
+    want = run("cpu", torch_kernel)
+    got = run(DEV, lambda a, b: ops.spd_ai_kernel(a, b, 0.8, _lib.GABO_OUT_GAUSSIAN))
+    for w, g in zip(want, got):
+        np.testing.assert_allclose(g, w, rtol=1e-8, atol=1e-9 * np.abs(w).max())
+
+
+# ---- pinned to the reference: `ehess` of its own PytorchBackend (tests/golden/make_golden_hvp.py -> hvp.npz) ----------------------------------
+def _mandel(m):
+    return ospd.symmetric_matrix_to_vector_mandel(0.5 * (m + np.swapaxes(m, -1, -2)))
+
+
+@pytest.mark.parametrize("mode", ["gaussian", "laplace", "distance"])
+@pytest.mark.parametrize("d", [2, 3, 5, 10])
+def test_hessian_vector_product_against_the_reference_backend(golden, d, mode):
+    """gabo_spd_ai_backward2 (directly and through two autograd passes) against the Hessian-vector products the reference's PyTorch backend
+    returns (pymanopt_addons/tools/autodiff/_pytorch.py:103-116) and against the oracle's closed form; the set includes a pair whose M has a
+    spectrum repeated to 1e-4"""
+    z = golden("hvp.npz")
+    x1, x2, G, U, beta = (z[f"spd{d}_{k}"] for k in ("x1", "x2", "G", "U", "beta"))
+    want = _mandel(z[f"spd{d}_{mode}_ehess"])
+    want_g = _mandel(z[f"spd{d}_{mode}_egrad"])
+    t = lambda a: torch.tensor(a, device=DEV)       # noqa: E731
+    hv = ops.spd_ai_backward2(t(_mandel(x1)), t(_mandel(x2)), t(G), t(_mandel(U)), float(beta), MODES[mode])[0].cpu().numpy()
+    np.testing.assert_allclose(hv, want, rtol=0, atol=1e-9 * np.abs(want).max())
+    np.testing.assert_allclose(hv, ospd.spd_ai_kernel_hvp(_mandel(x1), _mandel(x2), float(beta), G, _mandel(U), mode), rtol=0, atol=1e-9 * np.abs(want).max())
+    a = t(_mandel(x1)).requires_grad_()
+    K = ops.spd_ai_kernel(a, t(_mandel(x2)), float(beta), MODES[mode])
+    (g,) = torch.autograd.grad((t(G) * K).sum(), a, create_graph=True)
+    np.testing.assert_allclose(g.detach().cpu().numpy(), want_g, rtol=0, atol=1e-9 * np.abs(want_g).max())
+    (h,) = torch.autograd.grad((g * t(_mandel(U))).sum(), a)
+    np.testing.assert_allclose(h.cpu().numpy(), want, rtol=0, atol=1e-9 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("dim", [3, 5, 10])
+def test_sphere_hessian_vector_product_against_the_reference_backend(golden, dim):
+    """the sphere kernel's second autograd pass (gabo_sphere_from_inner, order 2) against the reference backend's `ehess` and the oracle"""
+    z = golden("hvp.npz")
+    x1, x2, G, U, beta = (z[f"sph{dim}_{k}"] for k in ("x1", "x2", "G", "U", "beta"))
+    t = lambda a: torch.tensor(a, device=DEV)       # noqa: E731
+    a = t(x1).requires_grad_()
+    K = ops.sphere_kernel(a, t(x2), float(beta), _lib.GABO_OUT_GAUSSIAN)
+    (g,) = torch.autograd.grad((t(G) * K).sum(), a, create_graph=True)
+    np.testing.assert_allclose(g.detach().cpu().numpy(), z[f"sph{dim}_egrad"], rtol=0, atol=1e-10 * np.abs(z[f"sph{dim}_egrad"]).max())
+    (h,) = torch.autograd.grad((g * t(U)).sum(), a)
+    want = z[f"sph{dim}_ehess"]
+    np.testing.assert_allclose(h.cpu().numpy(), want, rtol=0, atol=1e-10 * np.abs(want).max())
+    np.testing.assert_allclose(osph.sphere_gaussian_kernel_hvp(x1, x2, float(beta), G, U), want, rtol=0, atol=1e-12 * np.abs(want).max())

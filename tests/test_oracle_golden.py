@@ -197,3 +197,25 @@ def test_gp_oracle_against_the_ei_fixture(golden):
                                                         float(g["outputscale"]), float(g["noise"])), best_f=float(g["best_f"]), maximize=False)
         np.testing.assert_allclose(-ei, want, rtol=2e-7, atol=1e-12)
     assert int(g["best"]) == int(np.argmin(g["f"])) and (g["nit"] == 100).sum() == 1
+
+
+def test_second_order_statements_against_the_reference_backend(golden):
+    """oracle.spd.spd_ai_kernel_hvp / oracle.sphere.sphere_gaussian_kernel_hvp against `ehess` of the reference's own PytorchBackend
+    (pymanopt_addons/tools/autodiff/_pytorch.py:103-116) on costs built from its distance functions (tests/golden/make_golden_hvp.py)"""
+    z = golden("hvp.npz")
+
+    def mandel(m):
+        return ospd.symmetric_matrix_to_vector_mandel(0.5 * (m + np.swapaxes(m, -1, -2)))
+    assert not bool(z["exact_repeat_is_finite"])       # (the reference itself returns NaN at an exactly repeated eigenvalue of M)
+    for d in z["spd_dims"]:
+        x1, x2, G, U, beta = (z[f"spd{d}_{k}"] for k in ("x1", "x2", "G", "U", "beta"))
+        for mode in ("gaussian", "laplace", "distance"):
+            want = mandel(z[f"spd{d}_{mode}_ehess"])       # chain rule through the (isometric) Mandel map: P^T vec(ehess)
+            got = ospd.spd_ai_kernel_hvp(mandel(x1), mandel(x2), float(beta), G, mandel(U), mode)
+            np.testing.assert_allclose(got, want, rtol=0, atol=5e-12 * np.abs(want).max())
+        ga, _ = ospd.spd_ai_gaussian_kernel_grads(mandel(x1), mandel(x2), float(beta), G)
+        np.testing.assert_allclose(ga, mandel(z[f"spd{d}_gaussian_egrad"]), rtol=0, atol=5e-12 * np.abs(ga).max())
+    for dim in z["sphere_dims"]:
+        x1, x2, G, U, beta = (z[f"sph{dim}_{k}"] for k in ("x1", "x2", "G", "U", "beta"))
+        got = osph.sphere_gaussian_kernel_hvp(x1, x2, float(beta), G, U)
+        np.testing.assert_allclose(got, z[f"sph{dim}_ehess"], rtol=0, atol=1e-12 * np.abs(got).max())
