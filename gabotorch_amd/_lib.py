@@ -20,6 +20,7 @@ GABO_TR_NESTED_MAX_DIM = 24
  GABO_SPD_LOGM, GABO_SPD_EXPM, GABO_SPD_SQRTM, GABO_SPD_EIGMAX, GABO_SPD_EIGMIN) = range(12)
 GABO_ACQ_EXPECTED_IMPROVEMENT, GABO_ACQ_POSTERIOR_MEAN = 0, 1
 GABO_GP_MLL_MAX_N = 160
+GABO_GP_FACTOR_MAX_N = 96
 GABO_GP_MLL_LARGE_MAX_N = 2048
 GABO_METRIC_AFFINE_INVARIANT, GABO_METRIC_LOG_EUCLIDEAN, GABO_METRIC_FROBENIUS = 0, 8, 16
 GABO_CONSTRAINT_MAX_EIGENVALUE, GABO_CONSTRAINT_MIN_EIGENVALUE = 0, 1
@@ -85,6 +86,7 @@ SIGNATURES = {
     "gabo_gp_acquisition": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _D, _D, _D, _D, _I, _I, _D, _P]),
     "gabo_gp_mll": (_I, [_P, _P, _I64, _D, _D, _D, _D, _P, _P]),
     "gabo_gp_mll_gram": (_I, [_P, _P, _I64, _D, _D, _D, _P, _P, _P]),
+    "gabo_gp_factor": (_I, [_P, _P, _I64, _D, _D, _D, _P, _P, _P, _P, _P]),
     "gabo_gp_mll_large_workspace_bytes": (_SZ, [_I64]),
     "gabo_gp_mll_large": (_I, [_P, _P, _I64, _D, _D, _D, _D, _I, _P, _P, _P, _SZ, _P]),
     "gabo_spd_acq_max_train": (_I64, [_I]),

@@ -39,7 +39,12 @@ class FusedAcquisition:
         self.best_f = float(getattr(acq, "best_f", 0.0))
         self.mean, self.outputscale = mean, outputscale
         self.linv = linv.to(device).contiguous()
-        self.linv_t = self.linv.t().contiguous()
+        # (gabo_gp_factor wrote L^-T next to L^-1: models.*._cache_linv_t, valid for exactly that cache object)
+        held = getattr(acq.model, "_cache_linv_t", None)
+        if held is not None and held[0] is getattr(acq.model, "_cache", None) and held[1].device == self.linv.device:
+            self.linv_t = held[1]
+        else:
+            self.linv_t = self.linv.t().contiguous()
         self.alpha = alpha.to(device).contiguous()
         self.train = train_x.to(device).contiguous()
         # d <= 12: value + gradient in ONE launch per evaluation (csrc/spd_acq.hip); the training side is factored once here

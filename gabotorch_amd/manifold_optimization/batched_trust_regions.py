@@ -498,9 +498,22 @@ class BatchedTrustRegions:
         ncons, neq = len(cons), len(eqs)
         graphs = bool(getattr(problem, "use_hip_graphs", False))
         sphere = fused.family == "sphere"
-        T = None if sphere else ops.SpdTcg(R, d, ncons, dev)
-        val_buf = torch.zeros(R, dtype=dt, device=dev)
-        eg_buf = torch.zeros(R, d * (d + 1) // 2, dtype=dt, device=dev)
+        # Will the whole solve be ONE launch (decided below by the same tests)?  Then the tCG handle, the evaluation buffers and the
+        # constraint buffers of the multi-launch plans are never touched: not creating them takes ~10 allocations and fill launches
+        # (~0.1 ms of host time) off the front of a 4-ms sweep.
+        one_launch = False
+        builtins, lift = None, None
+        if getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True):
+            from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint, builtin_lift
+            builtins = [builtin_constraint(c) for c in cons]
+            solve_ok = (ncons == 0) if sphere else (d <= 8 and neq == 0 and all(b is not None for b in builtins)
+                                                    and fused.metric != _lib_frobenius())
+            lift = builtin_lift(builtins) if (solve_ok and not sphere) else None      # the nested kinds' mapping (one for all of them)
+            solve_ok = solve_ok and lift is not False
+            one_launch = bool(solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000)
+        T = None if (sphere or one_launch) else ops.SpdTcg(R, d, ncons, dev)
+        val_buf = None if one_launch else torch.zeros(R, dtype=dt, device=dev)
+        eg_buf = None if one_launch else torch.zeros(R, d * (d + 1) // 2, dtype=dt, device=dev)
         eps = torch.finfo(dt).eps
         time0 = time.time()
         fx, eg = fused.cost_egrad(x)
@@ -514,12 +527,12 @@ class BatchedTrustRegions:
         S.Delta = torch.full((R,), float(Delta0), dtype=dt, device=dev)
         S.active = torch.ones(R, dtype=torch.bool, device=dev)
         S.iters = torch.zeros(R, dtype=torch.long, device=dev)
-        S.any_active = torch.ones((), dtype=torch.bool, device=dev)
+        S.any_active = None if one_launch else torch.ones((), dtype=torch.bool, device=dev)
         step_args = (neq, Delta_cons, self.theta, self.kappa, mininner)
 
-        fc_buf = torch.zeros(R, ncons, dtype=dt, device=dev) if ncons else None
-        gc_buf = torch.zeros((ncons,) + tuple(x.shape), dtype=dt, device=dev) if ncons else None
-        invalid_buf = torch.zeros(R, dtype=torch.bool, device=dev)
+        fc_buf = torch.zeros(R, ncons, dtype=dt, device=dev) if (ncons and not one_launch) else None
+        gc_buf = torch.zeros((ncons,) + tuple(x.shape), dtype=dt, device=dev) if (ncons and not one_launch) else None
+        invalid_buf = None if one_launch else torch.zeros(R, dtype=torch.bool, device=dev)
         strict = bool(ncons and self.strict_constraints)
 
         def constraints_at_x():                      # user callables (torch): captured only on request, see below
@@ -585,7 +598,7 @@ class BatchedTrustRegions:
             else:
                 TR = ops.SpdTr(R, d, ncons, fused.acq_params(), fused.train.shape[0], dev)
             S.active_u8 = S.active.view(torch.uint8)
-            inv_u8 = invalid_buf.view(torch.uint8)
+            inv_u8 = None if invalid_buf is None else invalid_buf.view(torch.uint8)
 
             def part_a(sync):       # noqa: F811
                 xp = TR.propose(S.x, S.g, S.Delta, S.active_u8, gc_buf, fc_buf, neq, Delta_cons, self.theta, self.kappa, mininner,
@@ -599,13 +612,7 @@ class BatchedTrustRegions:
 
             # no constraint needs a host callable (none, or eigenvalue bounds built with functools.partial as in the reference
             # examples): the whole solve is ONE launch, every wave iterating its restart to the end
-            from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint, builtin_lift
-            builtins = [builtin_constraint(c) for c in cons]
-            solve_ok = (ncons == 0) if sphere else (d <= 8 and neq == 0 and all(b is not None for b in builtins)
-                                                    and fused.metric != _lib_frobenius())
-            lift = builtin_lift(builtins) if (solve_ok and not sphere) else None      # the nested kinds' mapping (one for all of them)
-            solve_ok = solve_ok and lift is not False
-            if solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000:
+            if one_launch:
                 extra = {} if sphere else {"lift": lift}
                 TR.solve(S.x, S.fx, S.g, S.ng, S.Delta, S.active_u8, S.iters, [b[0] for b in builtins], [b[1] for b in builtins], strict,
                           Delta_cons, self.theta, self.kappa, mininner, maxinner, Delta_bar, self.rho_prime, self.rho_regularization,
@@ -613,6 +620,7 @@ class BatchedTrustRegions:
                 if hasattr(TR, "status"):
                     ops._raise_if_not_spd(TR.status, "gabo_spd_tr_solve")       # (when error checking is on: one read-back per solve)
                 k = int(S.iters.max().item())
+                ops.check_deferred()
                 self.log = {"iterations": k, "per_restart_iterations": S.iters, "final_cost": S.fx, "final_gradnorm": S.ng,
                             "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0}
                 return S.x

@@ -164,6 +164,9 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
             batch_acquisition = -fused.cost(opt_x)          # same values through the fused chain (one launch for the SPD kernels)
         else:
             batch_acquisition = acquisition_function(candidates)
+    if candidates.is_cuda:
+        from .. import ops as _ops
+        _ops.check_deferred()          # (no-op unless a deferred launch check is still queued: then one 8-byte read-back)
     return candidates.detach(), batch_acquisition.detach()
 
 
@@ -339,7 +342,11 @@ def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num
         rows = torch.arange(X_rnd.shape[0]).reshape(-1, 1, 1)
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
-            picked = select(X=rows, Y=Y_rnd.detach().cpu(), n=num_restarts, generator=gen, **select_kwargs)
+            y_host = Y_rnd.detach().cpu()          # (the host waits for the scores here anyway: deferred launch checks cost nothing now)
+            if Y_rnd.is_cuda:
+                from .. import ops as _ops
+                _ops.check_deferred()
+            picked = select(X=rows, Y=y_host, n=num_restarts, generator=gen, **select_kwargs)
         chosen = X_rnd.index_select(0, picked.reshape(-1).to(X_rnd.device))
         if not any(issubclass(w.category, BadInitialCandidatesWarning) for w in caught):
             return chosen

@@ -35,6 +35,16 @@ class ExactGP(torch.nn.Module):
 
     def _train_cache(self):
         if self._cache is None:
+            from . import _lib as _l, ops as _ops
+            n = self.train_x.shape[-2]
+            if self.train_x.is_cuda and 0 < n <= _l.GABO_GP_FACTOR_MAX_N:
+                # one launch instead of Cholesky (+ its info read-back), cholesky_solve and a triangular solve (csrc/gp_factor.hip)
+                with torch.no_grad():
+                    kb = self.base_kernel.forward(self.train_x, self.train_x).double()
+                    Linv, Linv_t, alpha = _ops.gp_factor(kb, self.train_y, float(self.outputscale), float(self.noise), float(self.mean), defer_check=True)
+                self._cache = (Linv, alpha)
+                self._cache_linv_t = (self._cache, Linv_t)
+                return self._cache
             with torch.no_grad():
                 k = self.outputscale * self.base_kernel.forward(self.train_x, self.train_x)
                 n = k.shape[-1]
@@ -53,6 +63,8 @@ class ExactGP(torch.nn.Module):
             X = X.unsqueeze(-2)
         b = X.shape[0]
         Linv, alpha = self._train_cache()
+        from . import ops as _ops
+        _ops.check_deferred()
         xt = self.train_x.to(X.device).expand(b, *self.train_x.shape)           # stride-0 batch: factored once by the kernel
         ks = self.outputscale * self.base_kernel.forward(X, xt)                 # b x 1 x n   (candidates first)
         kss = self.outputscale * self.base_kernel.forward(X, X)                 # b x 1 x 1
@@ -442,6 +454,8 @@ class SingleTaskGP(torch.nn.Module):
     def _ensure_cache(self):
         """(L^-1, alpha, mean) of the fitted model; freezes the kernel hyper-parameters (prediction mode)."""
         if self._cache is None:
+            self._factor_in_one_launch()
+        if self._cache is None:
             with torch.no_grad():
                 L = torch.linalg.cholesky(self._kxx())
                 mu = self.mean_constant.detach().to(L.device)
@@ -452,11 +466,34 @@ class SingleTaskGP(torch.nn.Module):
             p.requires_grad_(False)
         return self._cache
 
+    def _factor_in_one_launch(self):
+        """gabo_gp_factor for the plain ScaleKernel(base) / base covariance modules on a HIP device (csrc/gp_factor.hip); leaves the cache
+        empty otherwise (the torch route below then fills it)."""
+        from . import _compat, _lib as _l, ops as _ops
+        cm = self.covar_module
+        n = self.train_x.shape[-2]
+        if not (self.train_x.is_cuda and 0 < n <= _l.GABO_GP_FACTOR_MAX_N):
+            return
+        if type(cm) is _compat.ScaleKernel and not _compat.HAVE_GPYTORCH:
+            base, outputscale = cm.base_kernel, float(cm.outputscale.detach())
+        else:
+            return
+        with torch.no_grad():
+            kb = base.forward(self.train_x, self.train_x)
+            if kb.dim() != 2:
+                return
+            mu = self.mean_constant.detach().to(kb.device)
+            Linv, Linv_t, alpha = _ops.gp_factor(kb.double(), self.train_y, outputscale, float(self.noise.detach()), float(mu), defer_check=True)
+        self._cache = (Linv, alpha, mu)
+        self._cache_linv_t = (self._cache, Linv_t)
+
     def posterior(self, X):
         if X.dim() == 2:
             X = X.unsqueeze(-2)
         b = X.shape[0]
         Linv, alpha, mu = self._ensure_cache()
+        from . import ops as _ops
+        _ops.check_deferred()
         xt = self.train_x.to(X.device).expand(b, *self.train_x.shape)
         ks = self.covar_module.forward(X, xt).squeeze(-2)
         kss = self.covar_module.forward(X, X).reshape(b)

@@ -1027,6 +1027,47 @@ def gp_acquisition(kstar, alpha, linv, linv_t, mean, outputscale, kxx, best_f, k
     return value, grad
 
 
+_deferred = []
+
+
+def check_deferred():
+    """Reads the status words queued by launches whose error check was deferred (gp_factor) and raises for the first failure.  Called at
+    the natural host synchronisation points of a sweep; cheap when the queue is empty."""
+    while _deferred:
+        status, message = _deferred.pop(0)
+        if status.tolist()[0] != 0:
+            _deferred.clear()
+            raise RuntimeError(message)
+
+
+def gp_factor(kbase, y, outputscale, noise, mean, defer_check=False):
+    """Prediction cache of the exact GP in one launch (gabo_gp_factor): kbase n x n BASE kernel matrix of the training set, y its targets ->
+    (L^-1, L^-T, alpha) with L = chol(outputscale kbase + noise I), alpha = (outputscale kbase + noise I)^-1 (y - mean); n <= GABO_GP_FACTOR_MAX_N.
+    Raises like torch.linalg.cholesky when the matrix is not positive definite - at once, or (defer_check=True) at the next check_deferred().
+    All tensors fp64 on one HIP device."""
+    lib = _lib.load()
+    dev = kbase.device
+    kb, yy = kbase.contiguous(), y.to(dev, torch.float64).contiguous()
+    n = kb.shape[-1]
+    _require(dev, kbase=kb, y=yy)
+    linv = torch.empty(n, n, dtype=torch.float64, device=dev)
+    linv_t = torch.empty(n, n, dtype=torch.float64, device=dev)
+    alpha = torch.empty(n, dtype=torch.float64, device=dev)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)        # (a word of its own: it is read later, see below)
+    with torch.cuda.device(dev):
+        rc = lib.gabo_gp_factor(kb.data_ptr(), yy.data_ptr(), n, float(outputscale), float(noise), float(mean), linv.data_ptr(), linv_t.data_ptr(),
+                                alpha.data_ptr(), status.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "gabo_gp_factor")
+    # The status is read back whatever set_error_checking says (torch.linalg.cholesky would raise here too, and a silent garbage factor would
+    # poison every acquisition value) - but not HERE: the read-back would park the host behind the launch (~0.1 ms of a 4-ms sweep) while it
+    # has the rest of the sweep's launches to issue.  It is queued and checked at the caller's next natural synchronisation point
+    # (check_deferred: after the raw samples' scores have been copied to the host, after a solve, or whenever error checking reads a status).
+    _deferred.append((status, "gabo_gp_factor: the training covariance outputscale * K + noise * I is not positive definite (Cholesky pivot <= 0)"))
+    if defer_check is False:
+        check_deferred()
+    return linv, linv_t, alpha
+
+
 _mll_large_ws = {}
 
 

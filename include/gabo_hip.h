@@ -228,6 +228,16 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
                         double* grad_kstar, int64_t r, int64_t n, double mean, double outputscale, double kxx, double best_f,
                         int kind, int maximize, double out_sign, gabo_stream_t stream);
 
+/* The prediction cache those two entry points read, in one launch: L = chol(outputscale * k + noise * I) (k: n x n BASE kernel matrix of the
+ * training set, row-major, lower triangle read), linv = L^-1 and linv_t = L^-T (n x n row-major, exact zeros outside their triangle) and
+ * alpha = (outputscale * k + noise * I)^-1 (y - mean).  Replaces the Cholesky / cholesky_solve / triangular solve a fitted [3P] gpytorch
+ * ExactGP runs when it is first asked for a posterior (behind manifold_optimize.py:182-184).  One workgroup, both factors in LDS:
+ * n <= GABO_GP_FACTOR_MAX_N (GABO_ERR_DIM beyond: factor with a library call instead).  status = {GABO_ERR_NOT_SPD, 0} when a pivot is
+ * not positive (outputs then unspecified). */
+#define GABO_GP_FACTOR_MAX_N 96
+int gabo_gp_factor(const double* k, const double* y, int64_t n, double outputscale, double noise, double mean, double* linv,
+                   double* linv_t, double* alpha, int* status, gabo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Exact-GP marginal log likelihood and its analytic gradient, one launch per evaluation of the surrogate fit
  * (fit_gpytorch_model(mll) at examples/bo_spd/benchmark_examples/gabo_spd.py:194 and its siblings; [3P] gpytorch

@@ -193,7 +193,8 @@ def install():
 
         def forward(self, X):
             post = self.model.posterior(X)
-            mean, sigma = post.mean.reshape(X.shape[:-2]), post.variance.clamp_min(1e-18).sqrt().reshape(X.shape[:-2])
+            mean, var = (post.mean, post.variance) if hasattr(post, "mean") else post      # (this package's GP returns the pair)
+            mean, sigma = mean.reshape(X.shape[:-2]), var.clamp_min(1e-18).sqrt().reshape(X.shape[:-2])
             u = (mean - self.best_f) / sigma
             u = u if self.maximize else -u
             normal = torch.distributions.Normal(torch.zeros_like(u), torch.ones_like(u))

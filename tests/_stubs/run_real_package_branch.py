@@ -44,11 +44,11 @@ for cls, kw in classes:
     rec = {"params": sorted(n for n, _ in k.named_parameters())}
     if hasattr(k, "beta"):
         k.beta = 1.5
-        rec["beta"] = float(k.beta)
+        rec["beta"] = float(k.beta.detach())
         assert isinstance(k.raw_beta_constraint, gp.constraints.GreaterThan)
     if getattr(k, "has_lengthscale", False):
         k.lengthscale = 0.8
-        rec["lengthscale"] = float(k.lengthscale)
+        rec["lengthscale"] = float(k.lengthscale.detach())
     made[cls.__name__] = rec
 out["kernels"] = made
 scaled = gp.kernels.ScaleKernel(kernels_spd.SpdAffineInvariantGaussianKernel(beta_min=0.25), outputscale_prior=prior)
@@ -69,13 +69,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "gpu":
     k = kernels_spd.SpdAffineInvariantGaussianKernel(beta_min=0.25)
     k.beta = 0.9
     got = k(torch.tensor(xv, device=dev), torch.tensor(xv[:5], device=dev))        # gpytorch.kernels.Kernel.__call__ of the stand-in -> forward -> HIP
-    out["spd_forward_err"] = float(np.abs(got.detach().cpu().numpy() - ospd.spd_ai_gaussian_kernel(xv, xv[:5], 0.9)).max())
+    out["spd_forward_err"] = float(np.abs(got.detach().cpu().numpy() - ospd.spd_ai_gaussian_kernel(xv, xv[:5], float(k.beta.detach().double()))).max())
     sx = rng.standard_normal((9, 4))
     sx /= np.linalg.norm(sx, axis=1, keepdims=True)
     ks = kernels_sphere.SphereGaussianKernel(beta_min=0.6)
     ks.beta = 1.1
-    out["sphere_forward_err"] = float(np.abs(ks(torch.tensor(sx, device=dev)).detach().cpu().numpy() - osph.sphere_gaussian_kernel(sx, sx, 1.1)).max())
-    out["scaled_forward_ratio"] = float((scaled(torch.tensor(xv, device=dev)) / scaled.base_kernel(torch.tensor(xv, device=dev))).mean() / scaled.outputscale)
+    out["sphere_forward_err"] = float(np.abs(ks(torch.tensor(sx, device=dev)).detach().cpu().numpy() - osph.sphere_gaussian_kernel(sx, sx, float(ks.beta.detach().double()))).max())
+    out["scaled_forward_ratio"] = float(((scaled(torch.tensor(xv, device=dev)) / scaled.base_kernel(torch.tensor(xv, device=dev))).mean() / scaled.outputscale).detach())
     # the maximiser driven by a FOREIGN acquisition object (the stand-in botorch's ExpectedImprovement over this package's GP posterior)
     y = rng.standard_normal(12)
     gpm = models.ExactGP(torch.tensor(xv, device=dev), torch.tensor(y, device=dev), k, outputscale=1.0, noise=1e-2)

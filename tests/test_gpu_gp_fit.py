@@ -748,3 +748,68 @@ def test_native_fit_evaluation_at_larger_training_sets(n):
     np.testing.assert_allclose([c_values_only, c_native], c_chain, rtol=1e-12)
     for a, b, (nm, _) in zip(g_native, g_chain, named):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11, err_msg=nm)
+
+
+@pytest.mark.parametrize("n", [1, 7, 50, 64, 96])
+def test_gp_factor_matches_lapack(n):
+    """gabo_gp_factor (csrc/gp_factor.hip): L^-1, L^-T and alpha of outputscale K + noise I in one launch, against numpy's LAPACK factorisation
+    of the same matrix - the quantities [3P] gpytorch caches for an ExactGP's posterior (behind manifold_optimize.py:182-184)."""
+    import numpy as np
+    import torch
+    from gabotorch_amd import ops
+    rng = np.random.default_rng(n)
+    z = rng.standard_normal((n, 4))
+    kb = np.exp(-0.7 * ((z[:, None] - z[None]) ** 2).sum(-1))
+    y = rng.standard_normal(n)
+    os_, noise, mean = 1.7, 1e-2, 0.3
+    linv, linv_t, alpha = ops.gp_factor(torch.tensor(kb, device="cuda:0"), torch.tensor(y, device="cuda:0"), os_, noise, mean)
+    K = os_ * kb + noise * np.eye(n)
+    L = np.linalg.cholesky(K)
+    want = np.linalg.inv(L)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(linv.cpu().numpy(), want, rtol=0, atol=1e-10 * scale)
+    np.testing.assert_array_equal(linv_t.cpu().numpy(), linv.cpu().numpy().T)
+    assert np.all(np.triu(linv.cpu().numpy(), 1) == 0.0)          # exact zeros above the diagonal (the SPD kernels sum whole rows)
+    a_want = np.linalg.solve(K, y - mean)
+    np.testing.assert_allclose(alpha.cpu().numpy(), a_want, rtol=0, atol=1e-9 * np.abs(a_want).max())
+
+
+def test_gp_factor_refuses_what_it_cannot_factor():
+    import numpy as np
+    import torch
+    from gabotorch_amd import _lib, ops
+    bad = np.array([[1.0, 2.0], [2.0, 1.0]])
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        ops.gp_factor(torch.tensor(bad, device="cuda:0"), torch.zeros(2, dtype=torch.float64, device="cuda:0"), 1.0, 0.0, 0.0)
+    ops.gp_factor(torch.eye(3, dtype=torch.float64, device="cuda:0"), torch.zeros(3, dtype=torch.float64, device="cuda:0"), 1.0, 0.0, 0.0)   # the status word is clean again
+    n = _lib.GABO_GP_FACTOR_MAX_N + 1
+    with pytest.raises(RuntimeError):
+        ops.gp_factor(torch.eye(n, dtype=torch.float64, device="cuda:0"), torch.zeros(n, dtype=torch.float64, device="cuda:0"), 1.0, 0.0, 0.0)
+
+
+def test_exact_gp_prediction_cache_through_gp_factor_equals_the_torch_route():
+    """models.ExactGP / SingleTaskGP fill their prediction cache with ONE launch on the device; the posterior is the one the torch route gives"""
+    import numpy as np
+    import torch
+    from gabotorch_amd import models
+    from gabotorch_amd._compat import ScaleKernel
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel
+    from oracle import spd as ospd
+    rng = np.random.default_rng(5)
+    q = np.linalg.qr(rng.standard_normal((30, 3, 3)))[0]
+    X = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.3, 3.0, (30, 3)), q)
+    xv = torch.tensor(ospd.symmetric_matrix_to_vector_mandel(0.5 * (X + X.transpose(0, 2, 1))), device="cuda:0")
+    y = torch.tensor(rng.standard_normal(30), device="cuda:0")
+    k = SpdAffineInvariantGaussianKernel(beta_min=0.25)
+    gp = models.ExactGP(xv, y, k, outputscale=1.3, noise=1e-2)
+    linv, alpha = gp._train_cache()
+    assert getattr(gp, "_cache_linv_t", None) is not None          # the one-launch route ran
+    kb = k.forward(xv, xv).detach().cpu().numpy()
+    K = 1.3 * kb + 1e-2 * np.eye(30)
+    np.testing.assert_allclose(linv.cpu().numpy(), np.linalg.inv(np.linalg.cholesky(K)), rtol=0, atol=1e-9 * np.abs(linv.cpu().numpy()).max())
+    np.testing.assert_allclose(alpha.cpu().numpy(), np.linalg.solve(K, y.cpu().numpy() - gp.mean), rtol=1e-8, atol=1e-10)
+    st = models.SingleTaskGP(xv, y, ScaleKernel(SpdAffineInvariantGaussianKernel(beta_min=0.25)))
+    li2, al2, mu2 = st._ensure_cache()
+    assert getattr(st, "_cache_linv_t", None) is not None
+    K2 = st._kxx().detach().cpu().numpy()
+    np.testing.assert_allclose(al2.cpu().numpy(), np.linalg.solve(K2, y.cpu().numpy() - float(mu2)), rtol=1e-8, atol=1e-10)
