@@ -78,6 +78,10 @@ SIGNATURES = {
     "gabo_nested_spd_gram_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
     "gabo_nested_spd_gram": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _D, _I, _P, _SZ, _P, _P]),
     "gabo_sphere_pairwise": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _I, _P]),
+    "gabo_sphere_ktable_doubles": (_I64, []),
+    "gabo_sphere_pairwise_uses_ktable": (_I, [_I64, _I64, _I64, _I, _D, _I, _I]),
+    "gabo_sphere_ktable_build": (_I, [_D, _P, _P]),
+    "gabo_sphere_pairwise_cached": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _I64, _I64, _D, _I, _I, _P, _P]),
     "gabo_sphere_from_inner": (_I, [_P, _P, _I64, _D, _I, _I, _P]),
     "gabo_spd_manifold_op": (_I, [_I, _P, _P, _P, _P, _P, _P, _I64, _I, _P, _P]),
     "gabo_spd_project": (_I, [_P, _P, _P, _I64, _I, _I, _P]),

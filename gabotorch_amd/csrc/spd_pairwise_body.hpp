@@ -391,17 +391,21 @@ constexpr double kGauss2L = 0.0027076061740622863;      // ln2 / 256
 __constant__ double kGauss2C[6] = {kGauss2L, kGauss2L * kGauss2L / 2.0, kGauss2L * kGauss2L * kGauss2L / 6.0,
                                    kGauss2L * kGauss2L * kGauss2L * kGauss2L / 24.0, 6755399441055744.0, 4096.0};
 
-template <bool NT>
+template <bool NT, bool SYM>
 __global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __restrict__ Winv, const double* __restrict__ G,
                                                             double* __restrict__ out, int64_t n1, int64_t n2, int64_t w_batch_stride,
                                                             int64_t g_batch_stride, int rows, int col_blocks, int row_chunks,
                                                             int64_t sym_tiles, double beta, int flags) {
+#ifndef GABO_GAUSS2_OCML_LOG
     __shared__ __attribute__((aligned(16))) double ltab[512];
+#endif
     __shared__ double etab[256];
     __shared__ __attribute__((aligned(16))) double atab[kAcosh2Slots * kAcosh2Stride];
-    __shared__ __attribute__((aligned(16))) double wrow[64 * 6];
+    __shared__ __attribute__((aligned(16))) double wrow[64 * 4];
     const int tid = threadIdx.x;
+#ifndef GABO_GAUSS2_OCML_LOG
     for (int k = tid; k < 512; k += blockDim.x) ltab[k] = kLogTab[k];
+#endif
     for (int k = tid; k < 256; k += blockDim.x) etab[k] = kExp2Tab256[k];
     {
         const double sc = beta * (-512.0 / 0.69314718055994530942), eps = beta * (-256.0 / 0.69314718055994530942) * 1e-15;
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __rest
         }
     }
     int64_t cg, rc, b;
-    if (flags & GABO_SYMMETRIC) {       // see spd_ai_pairwise_kernel
+    if constexpr (SYM) {       // see spd_ai_pairwise_kernel
         const int64_t per_batch = sym_tiles;
         b = blockIdx.x / per_batch;
         int64_t t = blockIdx.x - b * per_batch;
@@ -440,7 +444,12 @@ __global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __rest
     const int64_t i1 = (i0 + rows < n1) ? i0 + rows : n1;
     const double* Gj = G + b * g_batch_stride + jc;
     const double g00 = Gj[0], g10 = Gj[n2], g11 = Gj[2 * n2];
+#ifndef GABO_GAUSS2_OCML_LOG
     const LogTabRegs lr = LogTabRegs::load();
+#define GABO_G2_LOG(x) log_tab((x), lr, ltab)
+#else
+#define GABO_G2_LOG(x) log(x)      /* two logarithms per thread, once: no table to copy into LDS for them */
+#endif
     const double sscale = __builtin_sqrt(beta * (512.0 / 0.69314718055994530942));
     // the block's rows of W with their per-point terms: thread r prepares row i0 + r (rows <= 64), everybody reads them back from LDS with a
     // wave-uniform address (a broadcast: no VALU instruction, no scalar-memory round trip per row)
@@ -452,39 +461,42 @@ __global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __rest
         w0l = Wr[0], w1l = Wr[1], w2l = Wr[2];
     }
     __syncthreads();                                     // the tables
+    // tau = tr M / (2 sqrt(det M)) with M = C C^T, C = W G = [[a, 0], [c, b]]:  tau = 1 + ((a - b)^2 + c^2) / (2 a b)  (no cancellation in the numerator).
+    // The quotient is folded into the operands: rows scaled by 1 / sqrt(2 w00 w11), columns by 1 / sqrt(g00 g11) - per-POINT factors - so that
+    // with the scaled entries  tau = 1 + (a' - b')^2 + c'^2:  six instructions per pair (round 4: nine, with the product of the two reciprocals
+    // formed per pair), tau >= 1 by construction (two FMAs onto 1.0) and NaN operands stay NaN.
     if (tid < rows) {
         const double dw = w0l * w2l;
-        wrow[6 * tid + 0] = w0l;
-        wrow[6 * tid + 1] = w1l;
-        wrow[6 * tid + 2] = w2l;
-        wrow[6 * tid + 3] = sscale * log_tab(dw, lr, ltab);      // sqrt(512 beta / ln2) log(w00 w11)
-        wrow[6 * tid + 4] = rcp(dw);                             // 1 / (w00 w11)
+        const double sw = rsqrt_nz(dw + dw);
+        wrow[4 * tid + 0] = w0l * sw;
+        wrow[4 * tid + 1] = w1l * sw;
+        wrow[4 * tid + 2] = w2l * sw;
+        wrow[4 * tid + 3] = sscale * GABO_G2_LOG(dw);      // sqrt(512 beta / ln2) log(w00 w11)
     }
     __syncthreads();
-    if ((flags & GABO_SYMMETRIC) && j0 + (int64_t)(tid | 63) < i0) return;
+    if (SYM && j0 + (int64_t)(tid | 63) < i0) return;
     double ec[6];
     static_for<6>([&](auto k) { ec[decltype(k)::value] = kGauss2C[decltype(k)::value]; });
     double c4v = ec[3];
     asm volatile("" : "+v"(c4v));
     const double dg = g00 * g11;
-    const double bcol = sscale * log_tab(dg, lr, ltab);       // the lane's column terms
-    const double icol = 0.5 * rcp(dg);
+    const double bcol = sscale * GABO_G2_LOG(dg);       // the lane's column terms
+    const double sg = rsqrt_nz(dg);
+    const double q00 = g00 * sg, q10 = g10 * sg, q11 = g11 * sg;       // the column's factor scaled by 1 / sqrt(g00 g11)
     double* orow = out + b * n1 * n2 + i0 * n2 + j;
-    const int nrows = (int)(i1 - i0);
+    const int nrows = __builtin_amdgcn_readfirstlane((int)(i1 - i0));      // (wave-uniform: the loop counter and its compare stay on the scalar unit)
     // x1 is x2: row r of the block is stored by the lanes with i0 + r <= j
     const int64_t jrel = j - i0;
-    const int rmax = j >= n2 ? -1 : ((flags & GABO_SYMMETRIC) ? (jrel < 0 ? -1 : (jrel > 63 ? 63 : (int)jrel)) : 63);
+    const int rmax = j >= n2 ? -1 : (SYM ? (jrel < 0 ? -1 : (jrel > 63 ? 63 : (int)jrel)) : 63);
     typedef double g2_v2d __attribute__((ext_vector_type(2)));
+    if (!SYM && j >= n2) return;       // (no barrier below; the full build then stores without a per-row predicate)
     for (int r = 0; r < nrows; ++r, orow += n2) {
-        const g2_v2d wa = *reinterpret_cast<const g2_v2d*>(wrow + 6 * r);
-        const g2_v2d wb = *reinterpret_cast<const g2_v2d*>(wrow + 6 * r + 2);
-        const double irow = wrow[6 * r + 4];
+        const g2_v2d wa = *reinterpret_cast<const g2_v2d*>(wrow + 4 * r);
+        const g2_v2d wb = *reinterpret_cast<const g2_v2d*>(wrow + 4 * r + 2);
         const double w0 = wa[0], w1 = wa[1], w2 = wb[0], arow = wb[1];
-        const double c00 = w0 * g00, c11 = w2 * g11;
-        const double c10 = __builtin_fma(w1, g00, w2 * g10);
-        const double dd = c00 - c11;
-        const double num = __builtin_fma(dd, dd, c10 * c10);
-        const double tau = __builtin_fma(num, irow * icol, 1.0);
+        const double hh = __builtin_fma(w0, q00, -(w2 * q11));          // a' - b'
+        const double cc = __builtin_fma(w1, q00, w2 * q10);             // c'
+        const double tau = __builtin_fma(cc, cc, __builtin_fma(hh, hh, 1.0));
         const unsigned hi = (unsigned)__double2hiint(tau);
         // row of the table: bits 16..23 of the high word (in range by construction: one v_bfe_u32, no bias subtraction, and the four reads
         // share one address register with immediate offsets)
@@ -519,12 +531,13 @@ __global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __rest
         const int ki = __double2loint(km);
         const double e = etab[ki & 255];
         const double val = __builtin_ldexp(__builtin_fma(e, p, e), ki >> 8);
-        if (r <= rmax) {
+        if (!SYM || r <= rmax) {
             if constexpr (NT) __builtin_nontemporal_store(val, orow);
             else *orow = val;
         }
     }
 }
+#undef GABO_G2_LOG
 
 // prepared: the workspace already holds the factors (W for b1 * n1 matrices, then G: the fused projection of the nested kernels wrote them,
 // nested_spd_gram.hip); s1 / s2 then only say whether a set is shared across the batch (0) or not
@@ -577,20 +590,29 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
     if constexpr (D == 2) special2 = gauss2 && rows <= 64;
 #endif
     if (special2) {
+#ifdef GABO_GAUSS2_NO_NT      /* A/B: plain stores whatever the size */
+        const bool streaming = false;
+#else
         const bool streaming = batch * n1 * n2 * 8 > (32ll << 20) && !(flags & GABO_SYMMETRIC);      // beyond the L2 caches (see sphere_pairwise.hip)
+#endif
 #ifdef GABO_GAUSS2_LOG
 #define GABO_GAUSS2_KERNEL spd_ai_gauss2_log_kernel
 #else
 #define GABO_GAUSS2_KERNEL spd_ai_gauss2_kernel
 #endif
-        if (streaming)
-            hipLaunchKernelGGL((GABO_GAUSS2_KERNEL<true>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
-                               (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks, (int)row_chunks,
-                               sym_tiles, beta, flags);
-        else
-            hipLaunchKernelGGL((GABO_GAUSS2_KERNEL<false>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,
-                               (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks, (int)row_chunks,
-                               sym_tiles, beta, flags);
+#define GABO_GAUSS2_LAUNCH(...)                                                                                                     \
+        hipLaunchKernelGGL((GABO_GAUSS2_KERNEL<__VA_ARGS__>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, n1, n2,             \
+                           (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks, (int)row_chunks,       \
+                           sym_tiles, beta, flags)
+#ifdef GABO_GAUSS2_LOG
+        if (streaming) GABO_GAUSS2_LAUNCH(true);
+        else GABO_GAUSS2_LAUNCH(false);
+#else
+        if (flags & GABO_SYMMETRIC) GABO_GAUSS2_LAUNCH(false, true);        // (never streamed: see `streaming`)
+        else if (streaming) GABO_GAUSS2_LAUNCH(true, false);
+        else GABO_GAUSS2_LAUNCH(false, false);
+#endif
+#undef GABO_GAUSS2_LAUNCH
     } else
     hipLaunchKernelGGL((spd_ai_pairwise_kernel<D>), dim3((unsigned)nblocks), dim3(threads), 0, st, W, G, out, dist_out, n1, n2,
                        (s1 == 0) ? (int64_t)0 : n1 * T, (s2 == 0) ? (int64_t)0 : n2 * T, rows, (int)col_blocks,

@@ -299,7 +299,7 @@ template <int MODE, bool SCALED = false, int KS = 0, bool NT = false, bool PW = 
 __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                               double* __restrict__ out, int64_t n1, int64_t n2, int dim,
                                                               int64_t s1, int64_t s2, int col_blocks, int row_chunks, int chunks,
-                                                              double beta, int flags, SphPoly poly) {
+                                                              double beta, int flags, SphPoly poly, const double* __restrict__ ktab_g) {
     static_assert(!KT || (KS > 0 && !PW && MODE == GABO_OUT_GAUSSIAN), "the kernel-value table serves the Gaussian mode with the operands in registers");
     __shared__ double tab[KT ? 1 : 256];
     __shared__ double xa[KS > 0 ? 16 * (KT ? kSphKtChunks : kSphMaxChunks) * 4 * KS : 1];
@@ -315,7 +315,18 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
     else if constexpr (MODE == GABO_OUT_GAUSSIAN) g = SphGauss::load<SCALED>(beta, poly);
     else mt = MathRegs::load();
     SphKtBaseRow kbase;
-    if constexpr (KT) kbase = SphKtBaseRow::load(tid < kSphKtSlots ? tid : kSphKtSlots - 1);       // (blocks are at most kSphKtSlots threads)
+    kt_v2d krow[3];
+    if constexpr (KT) {
+        // the caller's table for this beta (gabo_sphere_ktable_build), if any: the thread's row travels with the operands and goes to LDS as it
+        // is - no exp, no recurrence in the prologue; otherwise the beta-independent base row the table is built from
+        const int srow = tid < kSphKtSlots ? tid : kSphKtSlots - 1;       // (blocks are at most kSphKtSlots threads)
+        if (ktab_g) {
+            const kt_v2d* src = reinterpret_cast<const kt_v2d*>(ktab_g + srow * kSphKtStride);
+            krow[0] = src[0], krow[1] = src[1], krow[2] = src[2];
+        } else {
+            kbase = SphKtBaseRow::load(srow);
+        }
+    }
     constexpr int kPwN = kSphPwSlots * kSphPwStride, kPwFirst = (kPwN + 255) / 256;       // 650 entries: three per thread of a 256-thread block
     double pwv[kPwFirst];
     if constexpr (PW) {
@@ -403,8 +414,18 @@ __global__ GABO_SPH_BOUNDS void sphere_pairwise_kernel(const double* __restrict_
         }
         if constexpr (KT) {
             // the block's table of kernel values for this beta: one slot per thread (see sphere_kt_build_row)
-            sphere_kt_build_row(tid, kbase, beta, kt);
-            for (int sl = tid + step; sl < kSphKtSlots; sl += step) sphere_kt_build_row(sl, SphKtBaseRow::load(sl), beta, kt);
+            if (ktab_g) {
+                kt_v2d* dst = reinterpret_cast<kt_v2d*>(kt + tid * kSphKtStride);
+                dst[0] = krow[0], dst[1] = krow[1], dst[2] = krow[2];
+                for (int sl = tid + step; sl < kSphKtSlots; sl += step) {
+                    const kt_v2d* src = reinterpret_cast<const kt_v2d*>(ktab_g + sl * kSphKtStride);
+                    kt_v2d* d2 = reinterpret_cast<kt_v2d*>(kt + sl * kSphKtStride);
+                    d2[0] = src[0], d2[1] = src[1], d2[2] = src[2];
+                }
+            } else {
+                sphere_kt_build_row(tid, kbase, beta, kt);
+                for (int sl = tid + step; sl < kSphKtSlots; sl += step) sphere_kt_build_row(sl, SphKtBaseRow::load(sl), beta, kt);
+            }
         } else if constexpr (MODE == GABO_OUT_GAUSSIAN) {
             tab[tid] = tv;
             for (int k = tid + step; k < 256; k += step) tab[k] = kExp2Tab256[k];
@@ -655,9 +676,48 @@ extern "C" int gabo_sphere_from_inner(const double* inner, double* out, int64_t 
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
+namespace gabo {
+// the launch condition of the kernel-value table path (sphere_gauss_finish_kt), in one place
+static bool sphere_uses_ktable(int64_t batch, int64_t n1, int64_t n2, int dim, double beta, int flags) {
+#ifdef GABO_SPH_NO_KT      /* A/B: the round-3 epilogue everywhere */
+    return false;
+#else
+    const bool scaled = (flags & GABO_OUT_MASK) == GABO_OUT_GAUSSIAN && beta > 1e-30 && beta < 1000.0;
+    return scaled && beta <= kSphKtMaxBeta && dim <= 16 && n2 >= 1024 && (double)batch * (double)n1 * (double)n2 >= (double)(1 << 22);
+#endif
+}
+
+__global__ __launch_bounds__(256) void sphere_ktable_kernel(double beta, double* __restrict__ table) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < kSphKtSlots) sphere_kt_build_row(s, SphKtBaseRow::load(s), beta, table);
+}
+}  // namespace gabo
+
+extern "C" int64_t gabo_sphere_ktable_doubles(void) { return (int64_t)gabo::kSphKtSlots * gabo::kSphKtStride; }
+
+extern "C" int gabo_sphere_pairwise_uses_ktable(int64_t batch, int64_t n1, int64_t n2, int dim, double beta, int flags, int diag) {
+    return (!diag && gabo::sphere_uses_ktable(batch, n1, n2, dim, beta, flags)) ? 1 : 0;
+}
+
+extern "C" int gabo_sphere_ktable_build(double beta, double* table, gabo_stream_t stream) {
+    if (!table || !(beta > 1e-30) || beta > gabo::kSphKtMaxBeta) return GABO_ERR_ARG;
+    hipLaunchKernelGGL(gabo::sphere_ktable_kernel, dim3((gabo::kSphKtSlots + 255) / 256), dim3(256), 0, (hipStream_t)stream, beta, table);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+extern "C" int gabo_sphere_pairwise_cached(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
+                                           int dim, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags,
+                                           int diag, const double* ktable, gabo_stream_t stream);
+
 extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
                                     int dim, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags,
                                     int diag, gabo_stream_t stream) {
+    return gabo_sphere_pairwise_cached(x1, x2, out, batch, n1, n2, dim, x1_batch_stride, x2_batch_stride, beta, flags, diag, nullptr, stream);
+}
+
+extern "C" int gabo_sphere_pairwise_cached(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
+                                           int dim, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags,
+                                           int diag, const double* ktable, gabo_stream_t stream) {
     if (batch < 0 || n1 < 0 || n2 < 0 || x1_batch_stride < 0 || x2_batch_stride < 0) return GABO_ERR_ARG;
     if (dim < 1) return GABO_ERR_DIM;
     if (batch == 0 || n1 == 0 || n2 == 0) return GABO_OK;
@@ -674,11 +734,7 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
         // the usual case: table-driven epilogues; outside it the global polynomial with the clamped exp
         const bool scaled = mode == GABO_OUT_GAUSSIAN && beta > 1e-30 && beta < 1000.0;
         // large Gram matrices with beta <= 4: the kernel-value table (sphere_gauss_finish_kt), blocks of 1024 threads that build it once each
-#ifdef GABO_SPH_NO_KT      /* A/B: the round-3 epilogue everywhere */
-        const bool kt = false;
-#else
-        const bool kt = scaled && beta <= gabo::kSphKtMaxBeta && dim <= 16 && n2 >= 1024 && (double)batch * (double)n1 * (double)n2 >= (double)(1 << 22);
-#endif
+        const bool kt = gabo::sphere_uses_ktable(batch, n1, n2, dim, beta, flags);
         // blocks of the kernel-value table: 1024 threads (one table slot per thread, one block per CU) while the grid is about one round of
         // the 256 CUs; beyond that two co-resident 512-thread blocks per CU, whose prologues (table build, no stores in flight) overlap each
         // other's loops (measured, 1024 / 512 threads: N = 4096: 31.1 / 33.0 us, 8192: 142 / 131, 16384: 525 / 470; round-3 epilogue: 36.4 / 141 / 516)
@@ -725,11 +781,11 @@ extern "C" int gabo_sphere_pairwise(const double* x1, const double* x2, double* 
 #define GABO_SPH_LAUNCH_NT(M, SC, K, NT_)                                                                                          \
     hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<M, SC, K, NT_, GABO_SPH_PW_OF(SC)>), dim3((unsigned)tiles_x, (unsigned)batch),     \
                        dim3(threads), 0, st, x1, x2, out, n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, \
-                       chunks, beta, flags, poly)
+                       chunks, beta, flags, poly, (const double*)nullptr)
 #define GABO_SPH_LAUNCH_KT(K, NT_)                                                                                                 \
     hipLaunchKernelGGL((gabo::sphere_pairwise_kernel<GABO_OUT_GAUSSIAN, true, K, NT_, false, true>), dim3((unsigned)tiles_x, (unsigned)batch), \
                        dim3(threads), 0, st, x1, x2, out, n1, n2, dim, x1_batch_stride, x2_batch_stride, (int)col_blocks, (int)row_chunks, \
-                       chunks, beta, flags, poly)
+                       chunks, beta, flags, poly, ktable)
     // (the kernel-value table makes the kernel store-bound, and under the resulting back-pressure streaming stores measured far slower than
     // plain ones: N = 4096: 43.9 us with `nt`, 31.6 without - tools/ab_sphere.py, round 4)
 #ifndef GABO_SPH_KT_NT

@@ -346,12 +346,36 @@ def sphere_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, diag=False, s
     out = torch.empty(bshape + ((n1, 1) if diag else (n1, n2)), dtype=torch.float64, device=dev)
     if out.numel() == 0:
         return out.to(out_device)
+    flags = int(mode) | (_lib.GABO_SYMMETRIC if symmetric and not diag else 0)
     with torch.cuda.device(dev):
-        rc = lib.gabo_sphere_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), nb, n1, n2, dim, s1, s2, float(beta),
-                                      int(mode) | (_lib.GABO_SYMMETRIC if symmetric and not diag else 0), 1 if diag else 0,
-                                      _stream_ptr(dev))
+        stream = _stream_ptr(dev)
+        ktable = None
+        # (not while a hipGraph is being captured: a build recorded into the graph would not have run for eager launches that find it cached)
+        if lib.gabo_sphere_pairwise_uses_ktable(nb, n1, n2, dim, float(beta), flags, 1 if diag else 0) and not torch.cuda.is_current_stream_capturing():
+            ktable = _sphere_ktable(lib, dev, stream, float(beta))
+        rc = lib.gabo_sphere_pairwise_cached(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), nb, n1, n2, dim, s1, s2, float(beta), flags,
+                                             1 if diag else 0, None if ktable is None else ktable.data_ptr(), stream)
     _lib.check(rc, "gabo_sphere_pairwise")
     return out.to(out_device)
+
+
+_sphere_ktables = {}
+
+
+def _sphere_ktable(lib, dev, stream, beta):
+    """The kernel-value table of the large sphere Gram launches for this beta, built once per (device, stream, beta) by gabo_sphere_ktable_build
+    and handed to gabo_sphere_pairwise_cached: a BO iteration evaluates every kernel matrix with the one fitted beta, so the 3-us table build
+    leaves the prologue of each launch.  Keyed by the stream the build was enqueued on (stream order makes it visible to the launches behind it)."""
+    key = (dev.type, dev.index, stream if isinstance(stream, int) else getattr(stream, "value", stream))
+    ent = _sphere_ktables.get(key)
+    if ent is None or ent[0] != beta:
+        table = ent[1] if ent is not None else torch.empty(int(lib.gabo_sphere_ktable_doubles()), dtype=torch.float64, device=dev)
+        if len(_sphere_ktables) > 16 and ent is None:
+            _sphere_ktables.clear()
+        _lib.check(lib.gabo_sphere_ktable_build(beta, table.data_ptr(), stream), "gabo_sphere_ktable_build")
+        _sphere_ktables[key] = (beta, table)
+        return table
+    return ent[1]
 
 
 def sphere_from_inner(inner, beta, mode, order):

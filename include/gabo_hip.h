@@ -112,6 +112,19 @@ int gabo_spd_ai_backward2(const double* x1, const double* x2, const double* grad
 int gabo_sphere_pairwise(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
                          int dim, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, int diag,
                          gabo_stream_t stream);
+/* The same launch for a caller that evaluates many Gram matrices with ONE beta (every kernel matrix of a BO iteration after the fit:
+ * kernels_sphere.py:90-94 is called with the fitted beta throughout).  Large Gaussian Gram matrices read the kernel VALUE from a table that
+ * depends on beta only (csrc/sphere_pairwise.hip); built inside every launch it is a prologue without stores in flight.  The caller may
+ * build it once - gabo_sphere_ktable_build into a buffer of gabo_sphere_ktable_doubles() doubles, on the stream of the launches that use
+ * it - and hand it over as `ktable` (NULL: built in the launch, exactly gabo_sphere_pairwise).  The table must belong to the `beta`
+ * passed here; it is ignored when the launch does not take the table path (gabo_sphere_pairwise_uses_ktable == 0).  Results are
+ * bit-identical with and without it. */
+int64_t gabo_sphere_ktable_doubles(void);
+int gabo_sphere_pairwise_uses_ktable(int64_t batch, int64_t n1, int64_t n2, int dim, double beta, int flags, int diag);
+int gabo_sphere_ktable_build(double beta, double* table, gabo_stream_t stream);
+int gabo_sphere_pairwise_cached(const double* x1, const double* x2, double* out, int64_t batch, int64_t n1, int64_t n2,
+                                int dim, int64_t x1_batch_stride, int64_t x2_batch_stride, double beta, int flags, int diag,
+                                const double* ktable, gabo_stream_t stream);
 
 /* Element-wise value (order 0), first (1) or second (2) derivative, with respect to the inner product c, of
  * f(c) = g(acos(clamp(c, -1+1e-15, 1-1e-15))) with g chosen by `flags` as above; derivatives are 0 where the clamp is active.

@@ -355,3 +355,32 @@ def test_sphere_large_gram_kernel_value_table(dim, beta):
     gn = ops.sphere_pairwise(t(x1), t(x2), beta=beta).cpu().numpy()
     np.testing.assert_array_equal(np.isnan(gn), np.isnan(wn))
     np.testing.assert_allclose(gn[~np.isnan(wn)], wn[~np.isnan(wn)], rtol=5e-12, atol=1e-300)
+
+
+def test_sphere_gram_with_a_cached_kernel_value_table_is_bit_identical():
+    """gabo_sphere_pairwise_cached with a table from gabo_sphere_ktable_build against the launch that builds the table itself (ktable = NULL):
+    the same bits; the ops layer keeps one table per (device, stream) and rebuilds it when beta changes."""
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n, dim = 2304, 10
+    x = rng.standard_normal((n, dim))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    X = t(x)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.gabo_sphere_pairwise_uses_ktable(1, n, n, dim, 1.29, _lib.GABO_OUT_GAUSSIAN, 0) == 1
+    assert lib.gabo_sphere_pairwise_uses_ktable(1, 100, 100, dim, 1.29, _lib.GABO_OUT_GAUSSIAN, 0) == 0
+    assert lib.gabo_sphere_pairwise_uses_ktable(1, n, n, dim, 1.29, _lib.GABO_OUT_LAPLACE, 0) == 0
+    table = torch.empty(int(lib.gabo_sphere_ktable_doubles()), dtype=torch.float64, device="cuda:0")
+    outs = []
+    for beta in (1.29, 0.4):
+        _lib.check(lib.gabo_sphere_ktable_build(beta, table.data_ptr(), stream), "build")
+        a, b = torch.empty(n, n, dtype=torch.float64, device="cuda:0"), torch.empty(n, n, dtype=torch.float64, device="cuda:0")
+        _lib.check(lib.gabo_sphere_pairwise_cached(X.data_ptr(), X.data_ptr(), a.data_ptr(), 1, n, n, dim, 0, 0, beta, _lib.GABO_OUT_GAUSSIAN, 0, table.data_ptr(), stream), "cached")
+        _lib.check(lib.gabo_sphere_pairwise(X.data_ptr(), X.data_ptr(), b.data_ptr(), 1, n, n, dim, 0, 0, beta, _lib.GABO_OUT_GAUSSIAN, 0, stream), "plain")
+        assert torch.equal(a, b)
+        outs.append(a.cpu().numpy())
+        np.testing.assert_allclose(outs[-1], osph.sphere_gaussian_kernel(x, x, beta), rtol=5e-12, atol=1e-300)
+    # the ops layer: the cache follows beta
+    for beta, want in zip((1.29, 0.4, 1.29), (outs[0], outs[1], outs[0])):
+        np.testing.assert_array_equal(ops.sphere_pairwise(X, X, beta=beta).cpu().numpy(), want)
+    assert lib.gabo_sphere_ktable_build(9.0, table.data_ptr(), stream) != 0       # beyond the table's range of beta
