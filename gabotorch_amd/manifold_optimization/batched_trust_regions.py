@@ -622,7 +622,7 @@ class BatchedTrustRegions:
                 k = int(S.iters.max().item())
                 ops.check_deferred()
                 self.log = {"iterations": k, "per_restart_iterations": S.iters, "final_cost": S.fx, "final_gradnorm": S.ng,
-                            "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0}
+                            "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0, "one_launch_solve": True}
                 return S.x
 
         # Execution plan.  Eager: the parts in order, with the inner loop leaving as soon as no restart runs.  hipGraphs: the

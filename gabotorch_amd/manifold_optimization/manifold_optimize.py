@@ -160,7 +160,12 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
         candidates = post_processing_manifold(candidates)
     candidates = candidates[:, None]
     with torch.no_grad():
-        if fused is not None:
+        final = getattr(solver, "log", None) or {}
+        if fused is not None and final.get("one_launch_solve") and final.get("final_cost") is not None and final["final_cost"].shape[0] == opt_x.shape[0]:
+            # the single-launch solve ended with the cost of every restart's final iterate in its state (evaluated by the same device
+            # function the fused chain calls): no further launch
+            batch_acquisition = -final["final_cost"]
+        elif fused is not None:
             batch_acquisition = -fused.cost(opt_x)          # same values through the fused chain (one launch for the SPD kernels)
         else:
             batch_acquisition = acquisition_function(candidates)

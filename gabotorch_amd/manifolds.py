@@ -23,23 +23,21 @@ def _wrap(fn):
     return inner
 
 
-def _householder_q(a):
-    """The orthogonal factor of qr(a) for a batch of small square matrices, by n - 1 Householder reflections VECTORISED over the batch:
-    a is n x n x k (batch LAST, so that every numpy operation below runs over a contiguous axis of length k), the result has the same layout.
-    numpy's batched `np.linalg.qr` is one LAPACK call per matrix (2-3 ms for 2048 5 x 5 matrices, the largest host item of a sweep with
-    host-drawn raw samples).  Column signs may differ from LAPACK's; Q diag(lam) Q^T does not see them."""
-    a = np.array(a, dtype=np.float64, copy=True)
-    n, k = a.shape[0], a.shape[-1]
+def _haar_q(n, k, gen):
+    """k Haar-distributed orthogonal n x n matrices (up to column signs), laid out n x n x k (batch LAST: every numpy operation below runs
+    over a contiguous axis of length k).  The Q of qr(randn(n, n)) - what the reference's sampler uses (spd_utils.py:290-306) - is the product of
+    n - 1 Householder reflections whose vectors are, by the rotation invariance of the Gaussian, independent Gaussian vectors of lengths
+    n, n - 1, ..., 2 (the subgroup algorithm of Diaconis and Shahshahani); drawing those vectors directly gives the same distribution without
+    factoring anything: n (n + 1) / 2 - 1 normals per matrix instead of n^2, and no LAPACK call per matrix (numpy's batched qr takes 2-3 ms for
+    2048 5 x 5 matrices - the largest host item of a sweep with host-drawn raw samples).  Q diag(lam) Q^T does not see the column signs."""
     q = np.zeros((n, n, k))
     q[np.arange(n), np.arange(n)] = 1.0
     for j in range(n - 1):
-        x = a[j:, j]
-        v = x.copy()
-        nrm = np.sqrt((x * x).sum(0))
-        v[0] += np.where(x[0] >= 0, nrm, -nrm)
+        v = gen.standard_normal((n - j, k))
+        nrm = np.sqrt((v * v).sum(0))
+        v[0] += np.where(v[0] >= 0, nrm, -nrm)
         vn = (v * v).sum(0)
         v *= np.sqrt(2.0) / np.sqrt(np.where(vn > 0, vn, 1.0))             # H = I - v v^T with |v|^2 = 2
-        a[j:, j:] -= v[:, None] * (v[:, None] * a[j:, j:]).sum(0)[None]
         q[:, j:] -= (q[:, j:] * v[None]).sum(1)[:, None] * v[None]
     return q
 
@@ -79,7 +77,7 @@ class PositiveDefinite:
         # the normals from a PCG64 / ziggurat stream seeded from the GLOBAL stream (np.random.seed still fixes the draw): 0.25 ms for
         # 2048 5 x 5 matrices where the global stream's polar method takes 0.75
         gen = np.random.Generator(np.random.PCG64(int(np.random.randint(0, 2 ** 31 - 1))))
-        q = _householder_q(gen.standard_normal((self._n, self._n, k)))               # n x n x k: batch last
+        q = _haar_q(self._n, k, gen)                                                  # n x n x k: batch last
         m = np.einsum("ick,jck->ijk", q * lam.T[None], q)                             # Q diag(lam) Q^T
         m = np.ascontiguousarray(m.transpose(2, 0, 1))
         return 0.5 * (m + m.transpose(0, 2, 1))
