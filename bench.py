@@ -566,11 +566,14 @@ def main():
         # (examples/gabo_spd.py:136-138): evaluated on the device, the whole solve is one launch (gabo_spd_tr_solve)
         sw_s = min(run_sweep(device, num_restarts=512, batched_rand=True, builtin_constraint=True)[0] for _ in range(3))
         sw_sd = min(run_sweep(device, num_restarts=512, device_rand=True, builtin_constraint=True)[0] for _ in range(3))
+        # (the same sweep with the native host driver switched off: joint_optimize_manifold's Python path, launch for launch the same work)
+        sw_sd_py = min(run_sweep(device, num_restarts=512, device_rand=True, builtin_constraint=True, native_sweep=False)[0] for _ in range(3))
+        sw_val_sd_py = run_sweep(device, num_restarts=512, device_rand=True, builtin_constraint=True, native_sweep=False)[2]
         sw_val_s = run_sweep(device, num_restarts=512, batched_rand=True, builtin_constraint=True)[2]
-        ts = torch.tensor([sw_s, sw_sd], dtype=torch.float64, device=device)
+        ts = torch.tensor([sw_s, sw_sd, sw_sd_py], dtype=torch.float64, device=device)
         if dist is not None:
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        sw_s, sw_sd = float(ts[0]), float(ts[1])
+        sw_s, sw_sd, sw_sd_py = float(ts[0]), float(ts[1]), float(ts[2])
         # (device sampler: every rank holds the same seed and draws its index range of the SAME stream, so this value does not
         # depend on the number of ranks - tests/test_gpu_multirank_bench.py compares it with the single-rank run)
         sw_val_sd = run_sweep(device, num_restarts=512, device_rand=True, builtin_constraint=True)[2]
@@ -626,6 +629,11 @@ def main():
                  "seconds_constraints_captured_device_rand": sw_d, "best_acq_device_rand": sw_val_d,
                  "seconds_single_launch_solve": sw_s, "seconds_single_launch_solve_device_rand": sw_sd, "best_acq_single_launch_solve": sw_val_s,
                  "best_acq_single_launch_solve_device_rand": sw_val_sd,
+                 "seconds_single_launch_solve_device_rand_python_path": sw_sd_py, "best_acq_single_launch_solve_device_rand_python_path": sw_val_sd_py,
+                 "native_host_driver": "with one process the device-sampled sweep runs through gabo_spd_sweep_score / gabo_spd_sweep_solve (csrc/spd_sweep.hip): the "
+                                       "launches of the Python path enqueued from C++, the selection heuristic still on torch's generator between the two calls; the "
+                                       "two paths return the same candidate bit for bit (tests/test_gpu_native_sweep.py); with several ranks the Python path runs "
+                                       "(its all_gathers sit between the launches)",
                  "weak_scaling_512_restarts_per_gpu": weak,
                  "strong_scaling_fixed_total_restarts": strong,
                  "seconds_by_restarts_one_gpu": latency_table,

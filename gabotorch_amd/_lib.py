@@ -44,6 +44,15 @@ class AcqParams(_c.Structure):
                 ("kxx", _c.c_double), ("best_f", _c.c_double), ("kind", _c.c_int), ("maximize", _c.c_int), ("out_sign", _c.c_double)]
 
 
+class SweepConfig(_c.Structure):
+    """gabo_spd_sweep_config of include/gabo_hip.h"""
+    _fields_ = [("acq", AcqParams), ("d", _c.c_int), ("min_eig", _c.c_double), ("max_eig", _c.c_double), ("n_constraints", _c.c_int),
+                ("constraint_kind", _c.c_int * 8), ("constraint_bound", _c.c_double * 8), ("strict", _c.c_int),
+                ("delta_bar", _c.c_double), ("delta0", _c.c_double), ("delta_cons", _c.c_double), ("theta", _c.c_double), ("kappa", _c.c_double),
+                ("mininner", _c.c_int), ("maxinner", _c.c_int), ("rho_prime", _c.c_double), ("rho_regularization", _c.c_double),
+                ("mingradnorm", _c.c_double), ("maxiter", _c.c_int64)]
+
+
 class SphereAcqParams(_c.Structure):
     """gabo_sphere_acq_params of include/gabo_hip.h"""
     _fields_ = [("train", _c.c_void_p), ("train_t", _c.c_void_p), ("alpha", _c.c_void_p), ("linv", _c.c_void_p), ("linv_t", _c.c_void_p),
@@ -109,6 +118,9 @@ SIGNATURES = {
     "gabo_spd_tr_workspace_bytes": (_SZ, [_I64, _I, _I, _I64]),
     "gabo_spd_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
     "gabo_spd_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I64, _D, _D, _D, _D, _I64, _P, _P]),
+    "gabo_spd_sweep_workspace_bytes": (_SZ, [_I64, _I, _I64, _I64, _I]),
+    "gabo_spd_sweep_score": (_I, [_P, _I64, _I64, _I64, _c.c_uint64, _P, _P, _SZ, _P, _P]),
+    "gabo_spd_sweep_solve": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "gabo_spd_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _SZ, _I64, _I, _D, _D, _D, _I, _I, _D, _D, _D, _D, _I64,
                                _P, _P, _P, _I, _P, _P]),
     "gabo_spd_matfun_backward": (_I, [_I, _P, _P, _P, _I64, _I, _P]),

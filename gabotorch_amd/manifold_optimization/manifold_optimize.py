@@ -63,6 +63,11 @@ def joint_optimize_manifold(acq_function, manifold, solver, q, num_restarts, raw
     """Returns the `q x d` best candidate (manifold_optimize.py:36-120)."""
     options = options or {}
     analytic = getattr(acq_function, "is_analytic", True)
+    plan = _native_sweep_plan(acq_function, manifold, solver, q if not analytic else 1, num_restarts, raw_samples, bounds, sample_type, options,
+                              inequality_constraints, equality_constraints, pre_processing_manifold, post_processing_manifold, approx_hessian,
+                              solver_init_conds)
+    if plan is not None:
+        return _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options)
     batch_initial_conditions = gen_batch_initial_conditions_manifold(
         acq_function=acq_function, manifold=manifold, bounds=bounds, q=None if analytic else q, num_restarts=num_restarts,
         raw_samples=raw_samples, sample_type=sample_type, options=options, post_processing_manifold=post_processing_manifold)
@@ -308,6 +313,133 @@ def _gather_raw_samples(X_loc, Y_loc, total, seed):
     return X, Y, int(parts[0][0, 0].item())
 
 
+def _selection(acq_function, options):
+    """the botorch heuristic gen_batch_initial_conditions_manifold applies to the scored raw samples, with its keyword arguments"""
+    select = initialize_q_batch
+    select_kwargs = {"eta": options["eta"]} if "eta" in options else {}
+    if options.get("nonnegative") or is_nonnegative(acq_function):
+        select = initialize_q_batch_nonneg
+        if "alpha" in options:
+            select_kwargs["alpha"] = options["alpha"]
+    return select, select_kwargs
+
+
+def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samples, bounds, sample_type, options, inequality_constraints,
+                       equality_constraints, pre_processing_manifold, post_processing_manifold, approx_hessian, solver_init_conds):
+    """The sweep as two native host calls (csrc/spd_sweep.hip: gabo_spd_sweep_score / gabo_spd_sweep_solve) when EVERY launch of it would be
+    one the native driver issues - built-in SPD surrogate evaluated in one launch, raw samples drawn on the device, eigenvalue bounds built
+    with functools.partial (or no constraints), FD Hessian, the whole solve one launch, one process.  Returns what the driver needs, or None:
+    then the Python path below runs, launch for launch the same work.  options={"native_sweep": False} keeps the Python path."""
+    from ..manifolds import PositiveDefinite
+    from ..Riemannian_utils import spd_utils_torch
+    from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint
+    from .. import _lib
+    device = options.get("device")
+    if not (options.get("native_sweep", True) and options.get("device_rand") and device is not None and _dist() is None):
+        return None
+    if not (q == 1 and bounds is None and not solver_init_conds and approx_hessian and sample_type == torch.float64
+            and isinstance(solver, BatchedTrustRegions) and not solver.use_rand and solver.maxtime >= 1000
+            and solver.trace is None and not equality_constraints):
+        return None
+    if any(options.get(k, True) is False for k in ("fused_acquisition", "device_tcg", "device_outer", "device_iteration", "device_solve")):
+        return None
+    if options.get("batch_limit", num_restarts) < num_restarts or num_restarts < 1 or raw_samples < 1:
+        return None
+    if not (isinstance(manifold, PositiveDefinite) and type(manifold).rand_batch_device is PositiveDefinite.rand_batch_device
+            and "rand_batch_device" not in vars(manifold) and hasattr(manifold, "min_eig") and hasattr(manifold, "max_eig") and 2 <= manifold._n <= 8):
+        return None
+    if pre_processing_manifold is not spd_utils_torch.vector_to_symmetric_matrix_mandel_torch:
+        return None
+    cons = list(inequality_constraints or [])
+    builtins = [builtin_constraint(c) for c in cons]
+    if len(cons) > 8 or any(b is None or len(b) != 2 or b[0] not in (_lib.GABO_CONSTRAINT_MAX_EIGENVALUE, _lib.GABO_CONSTRAINT_MIN_EIGENVALUE)
+                            for b in builtins):
+        return None
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return None
+    fused = FusedAcquisition.build(acq_function, post_processing_manifold, dev)
+    if fused is None or not (fused.family == "spd" and fused.flavour == "ai" and fused.single_launch and fused.matrix_input):
+        return None
+    return {"fused": fused, "device": dev, "manifold": manifold, "builtins": builtins}
+
+
+_sweep_workspaces = {}
+
+
+def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options):
+    """joint_optimize_manifold through gabo_spd_sweep_score / gabo_spd_sweep_solve: the draws from numpy's and torch's generators, the
+    selection heuristic and every device launch are those of the Python path (same order, same operands), so the candidate returned is the
+    same, bit for bit (tests/test_gpu_native_sweep.py)."""
+    import ctypes
+
+    from .. import _lib, ops
+    lib = _lib.load()
+    fused, dev, man = plan["fused"], plan["device"], plan["manifold"]
+    d, dv, R = man._n, man._n * (man._n + 1) // 2, int(num_restarts)
+    cfg = _lib.SweepConfig()
+    cfg.acq = fused.acq_params()
+    cfg.d, cfg.min_eig, cfg.max_eig = d, float(man.min_eig), float(man.max_eig)
+    cfg.n_constraints = len(plan["builtins"])
+    for k, b in enumerate(plan["builtins"]):
+        cfg.constraint_kind[k], cfg.constraint_bound[k] = int(b[0]), float(b[1])
+    cfg.strict = 1 if solver.strict_constraints else 0
+    delta_bar = getattr(man, "typicaldist", None) or float(man.dim) ** 0.5          # (BatchedTrustRegions._solve's defaults)
+    cfg.delta_bar, cfg.delta0, cfg.delta_cons = float(delta_bar), float(delta_bar) / 8, 1e-6
+    cfg.theta, cfg.kappa, cfg.mininner, cfg.maxinner = float(solver.theta), float(solver.kappa), 1, int(man.dim)
+    cfg.rho_prime, cfg.rho_regularization = float(solver.rho_prime), float(solver.rho_regularization)
+    cfg.mingradnorm, cfg.maxiter = float(solver.mingradnorm), int(solver.maxiter)
+    select, select_kwargs = _selection(acq_function, options)
+    status = ops._status_word(dev)
+    import time
+    time0 = time.time()
+    with torch.cuda.device(dev):
+        stream = ops._stream_ptr(dev)
+        picked = None
+        for attempt in range(1, 5):                     # the reference's factor = 1 ... max_factor - 1 (manifold_optimize.py:283-320)
+            total = raw_samples * attempt
+            wsb = int(lib.gabo_spd_sweep_workspace_bytes(int(fused.train.shape[0]), d, total, R, cfg.n_constraints))
+            key = (dev.index, stream)
+            ws = _sweep_workspaces.get(key)
+            if ws is None or ws.numel() < wsb:
+                ws = _sweep_workspaces[key] = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))           # (the draw of manifolds.PositiveDefinite.rand_batch_device)
+            y = np.empty(total, dtype=np.float64)
+            rc = lib.gabo_spd_sweep_score(ctypes.byref(cfg), total, total, R, seed & 0xFFFFFFFFFFFFFFFF, y.ctypes.data, ws.data_ptr(), wsb,
+                                          status.data_ptr(), stream)
+            ops._check_launch(rc, status, "gabo_spd_sweep_score")
+            ops.check_deferred()
+            sel_seed = int(torch.randint(0, 2 ** 52, (1,)).item())
+            gen = torch.Generator()
+            gen.manual_seed(sel_seed)
+            rows = torch.arange(total).reshape(-1, 1, 1)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                picked = select(X=rows, Y=torch.from_numpy(y), n=R, generator=gen, **select_kwargs)
+            if not any(issubclass(w_.category, BadInitialCandidatesWarning) for w_ in caught):
+                break
+        else:
+            warnings.warn("Unable to find non-zero acquisition function values - initial conditions are being selected randomly.",
+                          BadInitialCandidatesWarning)
+        idx = np.ascontiguousarray(picked.reshape(-1).numpy(), dtype=np.int64)
+        best, iters = ctypes.c_int64(0), ctypes.c_int64(0)
+        value = ctypes.c_double(0.0)
+        cand_p, cost_p, it_p = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        rc = lib.gabo_spd_sweep_solve(ctypes.byref(cfg), idx.ctypes.data, R, total, ctypes.byref(best), ctypes.byref(value), ctypes.byref(iters),
+                                      ctypes.byref(cand_p), ctypes.byref(cost_p), ctypes.byref(it_p), ws.data_ptr(), wsb, status.data_ptr(), stream)
+        ops._check_launch(rc, status, "gabo_spd_sweep_solve")
+    base = ws.data_ptr()
+
+    def view(ptr, count, dtype):
+        off = int(ptr.value) - base
+        return ws[off:off + 8 * count].view(dtype)
+    cands = view(cand_p, R * dv, torch.float64).reshape(R, dv)
+    solver.log = {"iterations": int(iters.value), "per_restart_iterations": view(it_p, R, torch.int64).clone(),
+                  "final_cost": view(cost_p, R, torch.float64).clone(), "final_gradnorm": None, "cost_evals": 0, "grad_evals": 0,
+                  "time": time.time() - time0, "one_launch_solve": True, "native_sweep": True}
+    return cands[int(best.value)].reshape(1, dv).clone()
+
+
 def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num_restarts, raw_samples,
                                           sample_type=torch.float64, options=None, post_processing_manifold=None):
     """`num_restarts x q x d` initial conditions chosen among `raw_samples` random manifold points by the botorch
@@ -319,12 +451,7 @@ def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num
     identical random stream - so all ranks hold the same initial conditions without a broadcast."""
     options = options or {}
     q = 1 if q is None else q
-    select = initialize_q_batch
-    select_kwargs = {"eta": options["eta"]} if "eta" in options else {}
-    if options.get("nonnegative") or is_nonnegative(acq_function):
-        select = initialize_q_batch_nonneg
-        if "alpha" in options:
-            select_kwargs["alpha"] = options["alpha"]
+    select, select_kwargs = _selection(acq_function, options)
     dist = _dist()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     chosen = None

@@ -40,7 +40,14 @@ class ExactGP(torch.nn.Module):
             if self.train_x.is_cuda and 0 < n <= _l.GABO_GP_FACTOR_MAX_N:
                 # one launch instead of Cholesky (+ its info read-back), cholesky_solve and a triangular solve (csrc/gp_factor.hip)
                 with torch.no_grad():
-                    kb = self.base_kernel.forward(self.train_x, self.train_x).double()
+                    from .kernel_utils import kernels_spd as _ks
+                    bk = self.base_kernel
+                    if type(bk) in (_ks.SpdAffineInvariantGaussianKernel, _ks.SpdAffineInvariantLaplaceKernel) and self.train_x.dim() == 2:
+                        # (what bk.forward launches - the x1-is-x2 build - without the autograd wrapper around it)
+                        mode = _l.GABO_OUT_GAUSSIAN if type(bk) is _ks.SpdAffineInvariantGaussianKernel else _l.GABO_OUT_LAPLACE
+                        kb = _ops.spd_ai_pairwise(self.train_x, self.train_x, float(bk.beta.double()), mode, symmetric=True)
+                    else:
+                        kb = bk.forward(self.train_x, self.train_x).double()
                     Linv, Linv_t, alpha = _ops.gp_factor(kb, self.train_y, float(self.outputscale), float(self.noise), float(self.mean), defer_check=True)
                 self._cache = (Linv, alpha)
                 self._cache_linv_t = (self._cache, Linv_t)

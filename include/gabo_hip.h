@@ -466,6 +466,45 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
                       gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * One multi-start acquisition sweep on S^d_++ as TWO HOST CALLS (they return with the numbers): the device work of
+ *   gen_batch_initial_conditions_manifold   manifold_optimize.py:232-321  (raw samples drawn on the device and scored)
+ *   gen_candidates_manifold + get_best_candidates   :124-228, :118-120   (initial value / gradient, the whole trust-region solve, argmax)
+ * enqueued from C++ through the entry points above (gabo_spd_sample_range, the Mandel maps, gabo_spd_acq_eval, gabo_spd_manifold_op,
+ * gabo_spd_tr_solve) - the same launches, in the same order, as this package's Python path, minus ~1 ms of interpreter time around a
+ * 2.7-ms solve.  The selection of the restarts among the raw samples (botorch's initialize_q_batch heuristics [3P], driven by the caller's
+ * random generator) happens between the two calls, on the host, in the caller's language.  Conditions of gabo_spd_tr_solve (2 <= d <= 8,
+ * constraints = bounds on the extreme eigenvalues of the iterate or none); `acq` as for gabo_spd_acq_eval.
+ *   score: raw samples 0 ... count - 1 of the stream `seed` -> workspace, their acquisition values -> values_host (count doubles).
+ *   solve: restarts from the raw samples picked_host[0 ... restarts - 1] of the LAST score call on this workspace; *best_index_host = the
+ *          restart with the largest final acquisition value (first on ties, NaN wins: torch.argmax), *best_value_host its value,
+ *          *max_iterations_host the largest iteration count; candidates_dev / cost_dev / iterations_dev (NULL to skip) receive DEVICE
+ *          pointers into the workspace: the final iterates as Mandel vectors (restarts x d_vec), their costs (= -acquisition) and
+ *          iteration counts - valid until the workspace is reused.
+ * workspace: gabo_spd_sweep_workspace_bytes(n_train, d, max_raw, restarts, n_constraints) bytes, the same (max_raw, restarts) in both
+ * calls; status: device int[2], zeroed by the caller. */
+#define GABO_SWEEP_MAX_CONSTRAINTS 8
+typedef struct {
+    gabo_spd_acq_params acq;
+    int d;
+    double min_eig, max_eig;                       /* the sampler: eigenvalues U[min_eig, max_eig] (spd_utils.py:290-306) */
+    int n_constraints;
+    int constraint_kind[GABO_SWEEP_MAX_CONSTRAINTS];        /* GABO_CONSTRAINT_MAX_EIGENVALUE / _MIN_EIGENVALUE */
+    double constraint_bound[GABO_SWEEP_MAX_CONSTRAINTS];
+    int strict;
+    double delta_bar, delta0, delta_cons, theta, kappa;     /* robust_trust_regions.py:111-160 / constrained_trust_regions.py:120-190 */
+    int mininner, maxinner;
+    double rho_prime, rho_regularization, mingradnorm;
+    int64_t maxiter;
+} gabo_spd_sweep_config;
+size_t gabo_spd_sweep_workspace_bytes(int64_t n_train, int d, int64_t max_raw, int64_t restarts, int n_constraints);
+int gabo_spd_sweep_score(const gabo_spd_sweep_config* cfg, int64_t count, int64_t max_raw, int64_t restarts, uint64_t seed, double* values_host,
+                         void* workspace, size_t workspace_bytes, int* status, gabo_stream_t stream);
+int gabo_spd_sweep_solve(const gabo_spd_sweep_config* cfg, const int64_t* picked_host, int64_t restarts, int64_t max_raw,
+                         int64_t* best_index_host, double* best_value_host, int64_t* max_iterations_host, double** candidates_dev,
+                         double** cost_dev, int64_t** iterations_dev, void* workspace, size_t workspace_bytes, int* status,
+                         gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Acquisition maximisation on the sphere S^(dim-1) (the sphere twins of gabo_spd_acq_eval / gabo_spd_tr_*): kernel strip of
  * SphereGaussianKernel / SphereLaplaceKernel (kernels_sphere.py:71-94,118-134) + exact-GP posterior + EI / posterior mean + gradient
  * in one launch, and the trust-region iteration of robust_trust_regions.py / constrained_trust_regions.py with the finite-difference

@@ -1,0 +1,47 @@
+"""The config-4 sweep as two native host calls (gabo_spd_sweep_score / gabo_spd_sweep_solve, csrc/spd_sweep.hip) against the Python path of
+joint_optimize_manifold (manifold_optimize.py:36-120 of the reference: initial conditions, the restarts' solves, argmax): the native driver
+enqueues the same launches in the same order and leaves the selection heuristic and both random generators where they are, so the returned
+candidate is the same BIT FOR BIT."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _both(**kw):
+    from tools.sweep_bench import run_sweep
+    _, best_n, val_n, log_n = run_sweep("cuda:0", device_rand=True, builtin_constraint=True, native_sweep=True, **kw)
+    _, best_p, val_p, log_p = run_sweep("cuda:0", device_rand=True, builtin_constraint=True, native_sweep=False, **kw)
+    assert log_n.get("native_sweep") and not log_p.get("native_sweep")
+    return (best_n, val_n, log_n), (best_p, val_p, log_p)
+
+
+@pytest.mark.parametrize("restarts,raw", [(512, 2048), (64, 256), (7, 50), (1, 3)])
+def test_native_sweep_returns_the_python_path_candidate_bit_for_bit(restarts, raw):
+    (bn, vn, ln), (bp, vp, lp) = _both(num_restarts=restarts, raw_samples=raw)
+    assert torch.equal(bn, bp) and vn == vp
+    assert ln["iterations"] == lp["iterations"]
+    assert torch.equal(ln["per_restart_iterations"].cpu(), lp["per_restart_iterations"].cpu())
+    np.testing.assert_array_equal(ln["final_cost"].cpu().numpy(), lp["final_cost"].cpu().numpy())
+
+
+def test_native_sweep_without_constraints_and_with_the_strict_solver():
+    (bn, vn, _), (bp, vp, _) = _both(num_restarts=96, raw_samples=384, constraint=False)
+    assert torch.equal(bn, bp) and vn == vp
+    (bn, vn, _), (bp, vp, _) = _both(num_restarts=96, raw_samples=384, strict=True, maxiter=30)
+    assert torch.equal(bn, bp) and vn == vp
+
+
+def test_native_sweep_declines_what_it_does_not_cover():
+    """an opaque constraint callable, host-drawn raw samples, hipGraph plans: the Python path runs (and says so in the solver's log)"""
+    from tools.sweep_bench import run_sweep
+    for kw in (dict(device_rand=True, builtin_constraint=False), dict(batched_rand=True, builtin_constraint=True),
+               dict(device_rand=True, builtin_constraint=True, device_solve=False)):
+        log = run_sweep("cuda:0", num_restarts=32, raw_samples=128, maxiter=10, **kw)[3]
+        assert not log.get("native_sweep")

@@ -2,7 +2,7 @@
 import cProfile, os, pstats, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools import sweep_bench
-kw = dict(builtin_constraint=True, device_rand=True)
+kw = dict(builtin_constraint=True, device_rand=True, native_sweep="--python" not in sys.argv)
 for _ in range(5):
     sweep_bench.run_sweep("cuda:0", **kw)
 pr = cProfile.Profile()
