@@ -119,7 +119,7 @@ SIGNATURES = {
     "gabo_spd_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
     "gabo_spd_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I64, _D, _D, _D, _D, _I64, _P, _P]),
     "gabo_spd_sweep_workspace_bytes": (_SZ, [_I64, _I, _I64, _I64, _I]),
-    "gabo_spd_sweep_score": (_I, [_P, _I64, _I64, _I64, _c.c_uint64, _P, _P, _SZ, _P, _P]),
+    "gabo_spd_sweep_score": (_I, [_P, _I64, _I64, _I64, _c.c_uint64, _P, _P, _P, _SZ, _P, _P]),
     "gabo_spd_sweep_solve": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "gabo_spd_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _SZ, _I64, _I, _D, _D, _D, _I, _I, _D, _D, _D, _D, _I64,
                                _P, _P, _P, _I, _P, _P]),

@@ -88,7 +88,8 @@ extern "C" size_t gabo_spd_sweep_workspace_bytes(int64_t n_train, int d, int64_t
 }
 
 extern "C" int gabo_spd_sweep_score(const gabo_spd_sweep_config* cfg, int64_t count, int64_t max_raw, int64_t restarts, uint64_t seed,
-                                    double* values_host, void* workspace, size_t workspace_bytes, int* status, gabo_stream_t stream) {
+                                    const double* raw_matrices_host, double* values_host, void* workspace, size_t workspace_bytes, int* status,
+                                    gabo_stream_t stream) {
     if (!cfg || !values_host || !workspace || !status || count < 1 || count > max_raw || restarts < 1) return GABO_ERR_ARG;
     const int d = cfg->d;
     if (d < 2 || d > 8 || cfg->n_constraints < 0 || cfg->n_constraints > GABO_SWEEP_MAX_CONSTRAINTS) return GABO_ERR_DIM;
@@ -99,7 +100,12 @@ extern "C" int gabo_spd_sweep_score(const gabo_spd_sweep_config* cfg, int64_t co
     int rc;
     // spd_sample on the device (manifolds.PositiveDefinite.rand_batch_device), the Mandel map of the post-processing (manifold_optimize.py:291),
     // the acquisition value of every raw sample (the fused chain's cost, sign -1: `values` below are the acquisition values themselves)
-    if ((rc = gabo_spd_sample_range(w.raw_mat, 0, count, d, cfg->min_eig, cfg->max_eig, seed, 0, stream)) != GABO_OK) return rc;
+    if (raw_matrices_host) {
+        // the caller's own sampler (`manifold.rand` is user code: the reference binds spd_sample to it, examples/gabo_spd.py:102) drew them on the host
+        if (hipMemcpyAsync(w.raw_mat, raw_matrices_host, (size_t)count * d * d * 8, hipMemcpyHostToDevice, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    } else if ((rc = gabo_spd_sample_range(w.raw_mat, 0, count, d, cfg->min_eig, cfg->max_eig, seed, 0, stream)) != GABO_OK) {
+        return rc;
+    }
     if ((rc = gabo_matrix_to_mandel(w.raw_mat, w.raw_mandel, count, d, stream)) != GABO_OK) return rc;
     if ((rc = gabo_spd_acq_eval(w.raw_mandel, a.train_factors, a.alpha, a.linv, a.linv_t, w.raw_val, nullptr, nullptr, count, a.n, d, a.beta, a.flags,
                                 a.mean, a.outputscale, a.kxx, a.best_f, a.kind, a.maximize, 1.0, nullptr, status, stream)) != GABO_OK)

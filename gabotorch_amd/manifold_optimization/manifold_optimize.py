@@ -335,7 +335,7 @@ def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samp
     from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint
     from .. import _lib
     device = options.get("device")
-    if not (options.get("native_sweep", True) and options.get("device_rand") and device is not None and _dist() is None):
+    if not (options.get("native_sweep", True) and device is not None and _dist() is None):
         return None
     if not (q == 1 and bounds is None and not solver_init_conds and approx_hessian and sample_type == torch.float64
             and isinstance(solver, BatchedTrustRegions) and not solver.use_rand and solver.maxtime >= 1000
@@ -345,9 +345,12 @@ def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samp
         return None
     if options.get("batch_limit", num_restarts) < num_restarts or num_restarts < 1 or raw_samples < 1:
         return None
-    if not (isinstance(manifold, PositiveDefinite) and type(manifold).rand_batch_device is PositiveDefinite.rand_batch_device
-            and "rand_batch_device" not in vars(manifold) and hasattr(manifold, "min_eig") and hasattr(manifold, "max_eig") and 2 <= manifold._n <= 8):
+    if not (isinstance(manifold, PositiveDefinite) and 2 <= manifold._n <= 8):
         return None
+    device_rand = bool(options.get("device_rand")) and hasattr(manifold, "rand_batch_device")
+    if device_rand and not (type(manifold).rand_batch_device is PositiveDefinite.rand_batch_device and "rand_batch_device" not in vars(manifold)
+                            and hasattr(manifold, "min_eig") and hasattr(manifold, "max_eig")):
+        return None       # (a sampler of the caller's own on the device: the Python path calls it)
     if pre_processing_manifold is not spd_utils_torch.vector_to_symmetric_matrix_mandel_torch:
         return None
     cons = list(inequality_constraints or [])
@@ -361,7 +364,7 @@ def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samp
     fused = FusedAcquisition.build(acq_function, post_processing_manifold, dev)
     if fused is None or not (fused.family == "spd" and fused.flavour == "ai" and fused.single_launch and fused.matrix_input):
         return None
-    return {"fused": fused, "device": dev, "manifold": manifold, "builtins": builtins}
+    return {"fused": fused, "device": dev, "manifold": manifold, "builtins": builtins, "device_rand": device_rand}
 
 
 _sweep_workspaces = {}
@@ -379,7 +382,8 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
     d, dv, R = man._n, man._n * (man._n + 1) // 2, int(num_restarts)
     cfg = _lib.SweepConfig()
     cfg.acq = fused.acq_params()
-    cfg.d, cfg.min_eig, cfg.max_eig = d, float(man.min_eig), float(man.max_eig)
+    cfg.d = d
+    cfg.min_eig, cfg.max_eig = (float(man.min_eig), float(man.max_eig)) if plan["device_rand"] else (0.0, 0.0)
     cfg.n_constraints = len(plan["builtins"])
     for k, b in enumerate(plan["builtins"]):
         cfg.constraint_kind[k], cfg.constraint_bound[k] = int(b[0]), float(b[1])
@@ -403,10 +407,18 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
             ws = _sweep_workspaces.get(key)
             if ws is None or ws.numel() < wsb:
                 ws = _sweep_workspaces[key] = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))           # (the draw of manifolds.PositiveDefinite.rand_batch_device)
+            seed, raw = 0, None
+            if plan["device_rand"]:
+                seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))       # (the draw of manifolds.PositiveDefinite.rand_batch_device)
+            elif options.get("batched_rand") and hasattr(man, "rand_batch"):       # the host samplers of _draw_raw_samples, same draws
+                raw = np.ascontiguousarray(man.rand_batch(total), dtype=np.float64)
+            else:
+                raw = np.ascontiguousarray(np.stack([np.asarray(man.rand()) for _ in range(total)]), dtype=np.float64)
+            if raw is not None and raw.shape != (total, d, d):
+                raise RuntimeError(f"manifold.rand returned points of shape {raw.shape[1:]}, expected ({d}, {d})")
             y = np.empty(total, dtype=np.float64)
-            rc = lib.gabo_spd_sweep_score(ctypes.byref(cfg), total, total, R, seed & 0xFFFFFFFFFFFFFFFF, y.ctypes.data, ws.data_ptr(), wsb,
-                                          status.data_ptr(), stream)
+            rc = lib.gabo_spd_sweep_score(ctypes.byref(cfg), total, total, R, seed & 0xFFFFFFFFFFFFFFFF, None if raw is None else raw.ctypes.data,
+                                          y.ctypes.data, ws.data_ptr(), wsb, status.data_ptr(), stream)
             ops._check_launch(rc, status, "gabo_spd_sweep_score")
             ops.check_deferred()
             sel_seed = int(torch.randint(0, 2 ** 52, (1,)).item())

@@ -474,7 +474,8 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
  * 2.7-ms solve.  The selection of the restarts among the raw samples (botorch's initialize_q_batch heuristics [3P], driven by the caller's
  * random generator) happens between the two calls, on the host, in the caller's language.  Conditions of gabo_spd_tr_solve (2 <= d <= 8,
  * constraints = bounds on the extreme eigenvalues of the iterate or none); `acq` as for gabo_spd_acq_eval.
- *   score: raw samples 0 ... count - 1 of the stream `seed` -> workspace, their acquisition values -> values_host (count doubles).
+ *   score: raw samples 0 ... count - 1 of the stream `seed` (gabo_spd_sample) - or, raw_matrices_host != NULL, the count x d x d matrices the
+ *          caller's own sampler drew on the host (`manifold.rand` is user code) - -> workspace, their acquisition values -> values_host.
  *   solve: restarts from the raw samples picked_host[0 ... restarts - 1] of the LAST score call on this workspace; *best_index_host = the
  *          restart with the largest final acquisition value (first on ties, NaN wins: torch.argmax), *best_value_host its value,
  *          *max_iterations_host the largest iteration count; candidates_dev / cost_dev / iterations_dev (NULL to skip) receive DEVICE
@@ -497,8 +498,9 @@ typedef struct {
     int64_t maxiter;
 } gabo_spd_sweep_config;
 size_t gabo_spd_sweep_workspace_bytes(int64_t n_train, int d, int64_t max_raw, int64_t restarts, int n_constraints);
-int gabo_spd_sweep_score(const gabo_spd_sweep_config* cfg, int64_t count, int64_t max_raw, int64_t restarts, uint64_t seed, double* values_host,
-                         void* workspace, size_t workspace_bytes, int* status, gabo_stream_t stream);
+int gabo_spd_sweep_score(const gabo_spd_sweep_config* cfg, int64_t count, int64_t max_raw, int64_t restarts, uint64_t seed,
+                         const double* raw_matrices_host, double* values_host, void* workspace, size_t workspace_bytes, int* status,
+                         gabo_stream_t stream);
 int gabo_spd_sweep_solve(const gabo_spd_sweep_config* cfg, const int64_t* picked_host, int64_t restarts, int64_t max_raw,
                          int64_t* best_index_host, double* best_value_host, int64_t* max_iterations_host, double** candidates_dev,
                          double** cost_dev, int64_t** iterations_dev, void* workspace, size_t workspace_bytes, int* status,

@@ -14,10 +14,10 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-def _both(**kw):
+def _both(device_rand=True, **kw):
     from tools.sweep_bench import run_sweep
-    _, best_n, val_n, log_n = run_sweep("cuda:0", device_rand=True, builtin_constraint=True, native_sweep=True, **kw)
-    _, best_p, val_p, log_p = run_sweep("cuda:0", device_rand=True, builtin_constraint=True, native_sweep=False, **kw)
+    _, best_n, val_n, log_n = run_sweep("cuda:0", device_rand=device_rand, builtin_constraint=True, native_sweep=True, **kw)
+    _, best_p, val_p, log_p = run_sweep("cuda:0", device_rand=device_rand, builtin_constraint=True, native_sweep=False, **kw)
     assert log_n.get("native_sweep") and not log_p.get("native_sweep")
     return (best_n, val_n, log_n), (best_p, val_p, log_p)
 
@@ -38,10 +38,18 @@ def test_native_sweep_without_constraints_and_with_the_strict_solver():
     assert torch.equal(bn, bp) and vn == vp
 
 
+@pytest.mark.parametrize("batched", [True, False])
+def test_native_sweep_with_raw_samples_drawn_by_the_callers_host_sampler(batched):
+    """`manifold.rand` is user code (the reference binds spd_sample to it, examples/gabo_spd.py:102): its draws - one by one from numpy's global
+    stream, or the vectorised rand_batch - are handed to the native driver as they are"""
+    (bn, vn, ln), (bp, vp, lp) = _both(device_rand=False, batched_rand=batched, num_restarts=24, raw_samples=96, maxiter=25)
+    assert torch.equal(bn, bp) and vn == vp
+    np.testing.assert_array_equal(ln["final_cost"].cpu().numpy(), lp["final_cost"].cpu().numpy())
+
+
 def test_native_sweep_declines_what_it_does_not_cover():
-    """an opaque constraint callable, host-drawn raw samples, hipGraph plans: the Python path runs (and says so in the solver's log)"""
+    """an opaque constraint callable, a plan without the one-launch solve: the Python path runs (and says so in the solver's log)"""
     from tools.sweep_bench import run_sweep
-    for kw in (dict(device_rand=True, builtin_constraint=False), dict(batched_rand=True, builtin_constraint=True),
-               dict(device_rand=True, builtin_constraint=True, device_solve=False)):
+    for kw in (dict(device_rand=True, builtin_constraint=False), dict(device_rand=True, builtin_constraint=True, device_solve=False)):
         log = run_sweep("cuda:0", num_restarts=32, raw_samples=128, maxiter=10, **kw)[3]
         assert not log.get("native_sweep")
