@@ -533,7 +533,7 @@ struct SolveArgs {
     hipStream_t st;
 };
 
-template <int METRIC>
+template <int METRIC, int DMIN = 2, int DMAX = 8>
 static int dispatch_solve(const SolveArgs& a) {
     int stage_gp = 0, ws_lds = 0, nested_off = 0;
     const size_t nested_bytes = builtin_has_kind(a.B, true) ? nested_extremes_lds_doubles(a.B.big_dim, a.d) * sizeof(double) : 0;
@@ -550,8 +550,12 @@ static int dispatch_solve(const SolveArgs& a) {
                        a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds, nested_off)
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
-        if (lat) GABO_SOLVE_LAUNCH(DD, true);                                                                                      \
-        else GABO_SOLVE_LAUNCH(DD, false);                                                                                         \
+        if constexpr (DD >= DMIN && DD <= DMAX) {                                                                                  \
+            if (lat) GABO_SOLVE_LAUNCH(DD, true);                                                                                  \
+            else GABO_SOLVE_LAUNCH(DD, false);                                                                                     \
+        } else {                                                                                                                   \
+            return GABO_ERR_DIM;                                                                                                   \
+        }                                                                                                                          \
         break;
     switch (a.d) {
         GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8)

@@ -1,8 +1,10 @@
-// Single-launch trust-region solve, affine-invariant surrogate (instantiations only; templates in spd_tr_body.hpp).
+// Single-launch trust-region solve, affine-invariant surrogate, d = 2 ... 6 (instantiations only; templates in spd_tr_body.hpp); d = 7, 8 in
+// spd_tr_solve_hi.hip.
 #include "spd_tr_body.hpp"
 
 namespace gabo {
-int solve_affine_invariant(const SolveArgs& a) { return dispatch_solve<0>(a); }
+int solve_affine_invariant_hi(const SolveArgs& a);
+int solve_affine_invariant(const SolveArgs& a) { return a.d >= 7 ? solve_affine_invariant_hi(a) : dispatch_solve<0, 2, 6>(a); }
 }  // namespace gabo
 
 #ifdef GABO_TR_CLOCKS
