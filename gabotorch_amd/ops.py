@@ -1094,7 +1094,7 @@ def gp_factor(kbase, y, outputscale, noise, mean, defer_check=False):
     # has the rest of the sweep's launches to issue.  It is queued and checked at the caller's next natural synchronisation point
     # (check_deferred: after the raw samples' scores have been copied to the host, after a solve, or whenever error checking reads a status).
     _deferred.append((status, "gabo_gp_factor: the training covariance outputscale * K + noise * I is not positive definite (Cholesky pivot <= 0)"))
-    if defer_check is False:
+    if defer_check is False or len(_deferred) > 32:       # (never an unbounded queue: a caller that only ever factors is checked every 32 launches)
         check_deferred()
     return linv, linv_t, alpha
 
