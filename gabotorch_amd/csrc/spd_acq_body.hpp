@@ -125,7 +125,9 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
         double vreg[kRegV ? D * D : 1];
         double lam[D];
         if constexpr (kRegV) {
-            sym_eig_reg<D>(m, lam, vreg);
+            // (value only: the same eigenvalues, bit for bit, without the eigenvectors - a third of the eigen-solver's instructions)
+            if (want_grad) sym_eig_reg<D>(m, lam, vreg);
+            else sym_eig_reg_values<D>(m, lam);
         } else {
             jacobi_eig<D>(m, vl);
             static_for<D>([&](auto kk) { lam[decltype(kk)::value] = m[tri(decltype(kk)::value, decltype(kk)::value)]; });

@@ -104,7 +104,9 @@ __device__ __forceinline__ void tridiagonalize_q(double (&m)[tri_size(D)], doubl
 // Eigen-decomposition of the symmetric tridiagonal (dg, e) with the rotations accumulated into z (columns become the eigenvectors of
 // the ORIGINAL matrix when z enters as the Q of tridiagonalize_q).  Eigenvalues in dg, unordered.  ROWS: the rows of z this lane holds (all D
 // of them, or its share when several lanes split one matrix by rows: a rotation acts on two COLUMNS, so it never mixes rows).
-template <int D, int ROWS = D>
+// VEC = false: the same recurrence on (dg, e) without touching z - the eigenvalues come out with the SAME BITS as with the vectors (the
+// rotations never feed back into dg / e), at about a third of the instructions.
+template <int D, int ROWS = D, bool VEC = true>
 __device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[D], double (&z)[ROWS * D]) {
     // dropping an off-diagonal e perturbs a matrix FUNCTION to first order in e / gap (the eigenvalue-only solver can be looser: a
     // symmetric function of the eigenvalues moves only to second order): |e| <= eps (|d_l| + |d_{l+1}|), the EISPACK / LAPACK
@@ -154,12 +156,14 @@ __device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[
                 p = s * r;
                 dg[i + 1] = g + p;
                 g = __builtin_fma(c, r, -b);
-                static_for<ROWS>([&](auto kk) {
-                    constexpr int k = decltype(kk)::value;
-                    double zi = z[k * D + i], zj = z[k * D + i + 1];
-                    z[k * D + i + 1] = __builtin_fma(s, zi, c * zj);
-                    z[k * D + i] = __builtin_fma(c, zi, -s * zj);
-                });
+                if constexpr (VEC) {
+                    static_for<ROWS>([&](auto kk) {
+                        constexpr int k = decltype(kk)::value;
+                        double zi = z[k * D + i], zj = z[k * D + i + 1];
+                        z[k * D + i + 1] = __builtin_fma(s, zi, c * zj);
+                        z[k * D + i] = __builtin_fma(c, zi, -s * zj);
+                    });
+                }
             });
             dg[l] -= p;
             e[l] = g;
@@ -175,6 +179,16 @@ __device__ __forceinline__ void sym_eig_reg(double (&m)[tri_size(D)], double (&l
     double sub[D];
     tridiagonalize_q<D>(m, lam, sub, v);
     tridiag_ql_vectors<D>(lam, sub, v);
+}
+
+// The eigenvalues alone, bit-identical to the `lam` of sym_eig_reg on the same input (same tridiagonalisation, same QL recurrence; the
+// reflectors are not accumulated and the rotations not applied): for callers that need the VALUE of a spectral function now and its
+// gradient only sometimes (the trust-region solve evaluates a proposal's acquisition value first, spd_tr_body.hpp).
+template <int D>
+__device__ __forceinline__ void sym_eig_reg_values(double (&m)[tri_size(D)], double (&lam)[D]) {
+    double sub[D], ihh[D >= 3 ? D - 2 : 1], none[D];
+    tridiagonalize_reflectors<D>(m, lam, sub, ihh);
+    tridiag_ql_vectors<D, 1, false>(lam, sub, none);
 }
 
 // ---- two lanes per matrix ("duo") ----------------------------------------------------------------------------------------------------

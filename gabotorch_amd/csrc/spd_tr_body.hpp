@@ -173,7 +173,7 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
                                                 double delta_cons, double theta, double kappa, int mininner, int maxinner,
                                                 AcqLds<D>& acq, double* mats, double* dyn, int* __restrict__ status,
                                                 const BuiltinCons* builtin, bool x_unchanged = false, bool fd0_kept = false,
-                                                double* nlds = nullptr) {
+                                                double* nlds = nullptr, bool value_only = false) {
     constexpr int T = tri_size(D);
     constexpr int dd = D * D;
     const TcgWs& w = t.tcg;
@@ -268,7 +268,9 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
     }
     __syncthreads();
     GABO_TICK(7);
-    acq_eval_any<D, METRIC>(xpm, P, t.fx_prop + i, t.eg_prop + i * T, F, acq, dyn, status, i + w.index_base);
+    // value_only: the acquisition VALUE at the proposal now, its gradient only if the proposal is accepted (tr_solve: a restart that has just
+    // had a proposal rejected will most likely have the next one rejected too, and a rejected proposal's gradient is never looked at)
+    acq_eval_any<D, METRIC>(xpm, P, t.fx_prop + i, value_only ? nullptr : t.eg_prop + i * T, F, acq, dyn, status, i + w.index_base);
     GABO_TICK(8);
     return inner;
 }
@@ -338,6 +340,19 @@ __global__ __launch_bounds__(64) void spd_tr_propose_kernel(const double* __rest
     const AcqParams Ps = stage_gp_factors(P, dyn, stage_gp);
     tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], gc, fc, Ps, t, x_prop + i * dd, i, R, C, neq, delta_cons, theta, kappa,
                                mininner, maxinner, acq, mats, dyn, status, nullptr);
+}
+
+// the acceptance test of the update below on its own (robust_trust_regions.py:236-300): model decrease and rho > rho_prime, with the
+// regularisation of rho (robust_trust_regions.py:262-271).  The same statements as in tr_update_body, so that the two agree bit for bit.
+static __device__ __forceinline__ bool tr_would_accept(double fx0, double fx_prop, double rhoden_raw, bool inval, double rho_prime,
+                                                       double rho_regularization) {
+    const double fxp = inval ? __builtin_inf() : fx_prop;
+    const double rho_reg = (__builtin_fabs(fx0) > 1.0 ? __builtin_fabs(fx0) : 1.0) * 2.220446049250313e-16 * rho_regularization;
+    const double rhonum = (fx0 - fxp) + rho_reg;
+    const double rhoden = rhoden_raw + rho_reg;
+    const bool model_decreased = rhoden >= 0.0;
+    const double rho = rhoden == 0.0 ? __builtin_nan("") : rhonum / rhoden;
+    return model_decreased && rho > rho_prime;
 }
 
 // rho test and state update of restart i (robust_trust_regions.py:236-330; same algebra as BatchedTrustRegions.solve).
@@ -456,11 +471,28 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     double* nlds = reinterpret_cast<double*>(reinterpret_cast<char*>(dyn) + nested_off);      // (used by nested constraint kinds only)
     bool cons_fresh = false;          // wave-uniform: the constraints in the workspace belong to the current x
     int last_inner = 0;               // tCG iterations of the previous trust-region iteration
+    constexpr int T_ = tri_size(D);
     for (;;) {
+        // Value first after a rejection.  The restarts that set this launch's duration are the ones whose proposals are rejected again and again
+        // (config 4: 4 of 512 restarts sit on the eigenvalue bound and have 99 of their 100 proposals rejected, the radius ending at 2.4e-60, while
+        // the other 508 finish within 12 iterations - tools/tr_accept_stats.py): their iteration is tCG (cached begin), proposal, acquisition at the
+        // proposal, update - and the acquisition GRADIENT there, a third of that evaluation (eigenvectors, logm of every pair, the second
+        // triangular product, the adjoint chain), is never used.  So the iteration after a rejected one evaluates the value alone (with the
+        // eigenvalue recurrence of the full evaluation: the same bits, sym_eig_reg_values) and the gradient only if the acceptance test passes.
+#ifdef GABO_TR_NO_LAZY_GRADIENT      /* A/B: value and gradient together in every iteration (rounds 1-4) */
+        const bool lazy = false;
+#else
+        const bool lazy = cons_fresh;
+#endif
         last_inner = tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, iw, Rw, C, 0, delta_cons, theta,
-                                                kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1, nlds);
+                                                kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1, nlds, lazy);
         __syncthreads();
         const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B, nlds) : false;
+        if (lazy && tr_would_accept(fx[i], t.fx_prop[iw], t.rhoden[iw], inval, rho_prime, rho_regularization)) {
+            acq_eval_any<D, METRIC>(t.xp_mandel + iw * T_, Ps, t.fx_prop + iw, t.eg_prop + iw * T_, t.F + iw * T_ * Ps.n, acq, dyn, status,
+                                    iw + t.tcg.index_base);
+            __syncthreads();
+        }
         bool accepted = false;
         const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, iw, D, C, delta_bar,
                                           rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
