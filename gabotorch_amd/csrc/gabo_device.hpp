@@ -9,11 +9,14 @@
 // Development instrumentation (builds with -DGABO_TR_CLOCKS only; tools/tr_clocks.py): block 0 / lane 0 appends (tag, s_memtime) pairs
 // to a per-translation-unit buffer that the exported gabo_debug_clocks of that unit copies out.  Compiles to nothing otherwise.
 #ifdef GABO_TR_CLOCKS
+#ifndef GABO_TR_CLOCKS_BLOCK
+#define GABO_TR_CLOCKS_BLOCK 0      /* the restart (block) whose waves record: -DGABO_TR_CLOCKS_BLOCK=<index of a restart that runs to maxiter> */
+#endif
 static __device__ long long gabo_clk_buf[8192];
 static __device__ int gabo_clk_n;
 #define GABO_TICK(tag)                                                          \
     do {                                                                        \
-        if (threadIdx.x == 0 && blockIdx.x == 0) {                              \
+        if (threadIdx.x == 0 && blockIdx.x == GABO_TR_CLOCKS_BLOCK) {           \
             int k_ = gabo_clk_n++;                                              \
             if (k_ < 4096) {                                                    \
                 gabo_clk_buf[2 * k_] = (tag);                                   \

@@ -173,7 +173,7 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
                                                 double delta_cons, double theta, double kappa, int mininner, int maxinner,
                                                 AcqLds<D>& acq, double* mats, double* dyn, int* __restrict__ status,
                                                 const BuiltinCons* builtin, bool x_unchanged = false, bool fd0_kept = false,
-                                                double* nlds = nullptr, bool value_only = false) {
+                                                double* nlds = nullptr, bool value_only = false, double* step_cache = nullptr) {
     constexpr int T = tri_size(D);
     constexpr int dd = D * D;
     const TcgWs& w = t.tcg;
@@ -225,6 +225,35 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
     const double ge = wave_dot(w.g_w + i * dd, etaw, dd);
     const double ehe = wave_dot(etaw, w.heta_w + i * dd, dd);
     if (threadIdx.x == 0) t.rhoden[i] = -ge - 0.5 * ehe;
+    // The same step again.  A restart that sits on a constraint bound can have its tCG step set by the LINEARISED CONSTRAINT (stop reason
+    // "reached constraints"), whatever the trust radius: the rejected proposal quarters the radius, tCG runs again from the same x, gradient and
+    // constraints and returns the SAME eta, bit for bit - for every one of the remaining iterations (config 4: 4 of 512 restarts do this 98 times
+    // in a row, tools/tr_eta_probe.py; they were the whole duration of the launch).  With x unchanged and eta~ identical the proposal, its
+    // acquisition value and therefore the rho test are those of the previous iteration, which are still in the workspace: skip the matrix
+    // exponential, the congruence and the evaluation.  `step_cache`: T + 1 doubles of LDS (the last eta~ as a packed triangle, a valid flag).
+    if (step_cache != nullptr) {
+        bool same = x_unchanged && step_cache[T] != 0.0;
+        for (int e = threadIdx.x; e < dd; e += 64) {
+            const int r = e / D, c = e - r * D;
+            const double sym = 0.5 * (etaw[r * D + c] + etaw[c * D + r]);
+            if (r >= c) {
+                same = same && (sym == step_cache[tri(r, c)]);
+            }
+        }
+        same = __builtin_amdgcn_ballot_w64(!same) == 0;       // every lane agrees (lanes beyond D^2 vote with the flag alone)
+        __syncthreads();                                        // all compares done before the cache is rewritten
+        for (int e = threadIdx.x; e < dd; e += 64) {
+            const int r = e / D, c = e - r * D;
+            if (r >= c) step_cache[tri(r, c)] = 0.5 * (etaw[r * D + c] + etaw[c * D + r]);
+        }
+        if (threadIdx.x == 0) step_cache[T] = 1.0;
+        if (same) {
+            __syncthreads();
+            GABO_TICK(7);
+            GABO_TICK(8);
+            return inner;
+        }
+    }
     lds_load(w.chol + i * dd, M0, D);
     if constexpr (D <= 8) {
         // expm(eta~) from the register eigen-decomposition (every lane redundantly, no barriers); lane 0 publishes E
@@ -472,6 +501,14 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     bool cons_fresh = false;          // wave-uniform: the constraints in the workspace belong to the current x
     int last_inner = 0;               // tCG iterations of the previous trust-region iteration
     constexpr int T_ = tri_size(D);
+#ifndef GABO_TR_NO_STEP_CACHE
+    __shared__ double step_cache_store[T_ + 1];     // the last proposal's eta~ and a valid flag: see "The same step again" in tr_propose_body
+    if (threadIdx.x == 0) step_cache_store[T_] = 0.0;
+    __syncthreads();
+    double* const step_cache = step_cache_store;
+#else
+    double* const step_cache = nullptr;
+#endif
     for (;;) {
         // Value first after a rejection.  The restarts that set this launch's duration are the ones whose proposals are rejected again and again
         // (config 4: 4 of 512 restarts sit on the eigenvalue bound and have 99 of their 100 proposals rejected, the radius ending at 2.4e-60, while
@@ -485,7 +522,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
         const bool lazy = cons_fresh;
 #endif
         last_inner = tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, iw, Rw, C, 0, delta_cons, theta,
-                                                kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1, nlds, lazy);
+                                                kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1, nlds, lazy, step_cache);
         __syncthreads();
         const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B, nlds) : false;
         if (lazy && tr_would_accept(fx[i], t.fx_prop[iw], t.rhoden[iw], inval, rho_prime, rho_regularization)) {

@@ -28,4 +28,4 @@ print("all restarts: accepted total", int(a.sum()), "rejected total", int(r.sum(
 top = torch.argsort(it, descending=True)[:12]
 print("final trust radius of the top restarts:", [float(acc["delta"][i]) for i in top[:6]], " (Delta0 = sqrt(15)/8 = 0.484; a rejection quarters it)")
 print("final gradient norms:", [float(log["final_gradnorm"][i]) for i in top[:6]])
-print("top restarts (iters, accepted, rejected):", [(int(it[i]), int(a[i]), int(r[i])) for i in top])
+print("top restarts (index, iters, accepted, rejected):", [(int(i), int(it[i]), int(a[i]), int(r[i])) for i in top])

@@ -11,11 +11,11 @@ lib = ctypes.CDLL(_lib.LIB_PATH)
 lib.gabo_debug_clocks.restype = ctypes.c_int
 lib.gabo_debug_clocks.argtypes = [ctypes.c_void_p, ctypes.c_int]
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-run_sweep("cuda:0", num_restarts=R, batched_rand=True, builtin_constraint=True)
+run_sweep("cuda:0", num_restarts=R, device_rand=True, builtin_constraint=True, native_sweep=False)
 buf = (ctypes.c_longlong * 8192)()
 lib.gabo_debug_clocks(buf, 4096)                       # drop the warm-up run
 MAXIT = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-run_sweep("cuda:0", num_restarts=R, batched_rand=True, builtin_constraint=True, maxiter=MAXIT)
+run_sweep("cuda:0", num_restarts=R, device_rand=True, builtin_constraint=True, maxiter=MAXIT, native_sweep=False)
 n = lib.gabo_debug_clocks(buf, 4096)
 ev = [(int(buf[2 * k]), int(buf[2 * k + 1])) for k in range(n)]
 names = {1: "iteration start", 2: "tcg_begin", 3: "builtin constraints", 4: "tcg_fd_point", 5: "acq_eval at the FD point", 6: "tcg_step",
