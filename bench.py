@@ -637,10 +637,13 @@ def main():
                  "weak_scaling_512_restarts_per_gpu": weak,
                  "strong_scaling_fixed_total_restarts": strong,
                  "seconds_by_restarts_one_gpu": latency_table,
-                 "note": "latency-bound: 512 restarts are 2 waves per CU and each wave runs its restart serially (about 0.15 ms per "
-                         "trust-region iteration); plus 2-3.5 ms of initial-condition generation when the raw samples are drawn on the host "
-                         "(0.1 ms on the device).  Opaque constraint callables cost 0.4 ms per iteration and one graph replay each.  Does not "
-                         "speed up with more GPUs at this size (weak scaling only)"}
+                 "note": "latency-bound: 512 restarts are 2 waves per CU and each wave runs its restart serially (about 0.065 ms per full "
+                         "trust-region iteration).  Round 5: the restarts that sit on the eigenvalue bound (4 of 512: 99 of their 100 proposals rejected) "
+                         "no longer set the launch's duration - the solve evaluates a proposal's value before its gradient after a rejection and reuses the "
+                         "previous proposal when tCG returns the same step again (bit-identical results) - so the kernel lasts as long as the longest chain "
+                         "of accepted iterations (12).  Around it: ~0.3 ms per-GP set-up, ~0.25 ms selection heuristic, two host synchronisations; 1-2 ms "
+                         "more when the raw samples are drawn by the host sampler.  Opaque constraint callables cost 0.4 ms per iteration and one graph "
+                         "replay each.  Does not speed up with more GPUs at this size (weak scaling only)"}
 
 
     sphere_sweep_result = None
@@ -736,10 +739,10 @@ def main():
             "sharded_gram.all_gathered": "strong, ~3x at P = 8: each rank receives (P-1)/P of the 134 MB result, 16.8 MB from each of 7 peers over its own "
                                          "xGMI link (76.8 GB/s per direction peak, ~50 GB/s assumed): 0.34 ms on top of the 0.31 ms of compute; leave the "
                                          "Gram sharded when the consumer is sharded",
-            "acq_sweep.strong_512_restarts": "<= 1.3x at any P: a restart is ONE wave that runs its trust-region iterations serially; measured on one GPU "
-                                             "the iteration launch takes 86 us at 64 restarts against 113 us at 512 (tools/tr_latency.py, DESIGN 4.6), and "
-                                             "the 512-restart sweep is 2 waves per CU already. north_star's >= 6x at 8 GPUs is NOT reachable for a sweep of this size with a "
-                                             "wave-per-restart solver; sharding raw-sample drawing + scoring removes the replicated part of the initial conditions",
+            "acq_sweep.strong_512_restarts": "~1.0x at any P (see acq_sweep.strong_measured_model for this run's table): a restart is ONE wave that runs its "
+                                             "trust-region iterations serially, and the 512-restart sweep is 2 waves per CU already. north_star's >= 6x at 8 GPUs is "
+                                             "NOT reachable for a sweep of this size with a wave-per-restart solver; what round 5 did instead is cut the one-GPU time "
+                                             "of this sweep 2.8x (4.2-4.6 -> 1.5 ms)",
             "acq_sweep.weak_scaling_512_restarts_per_gpu": "~P x restarts/s: per-rank work unchanged, one all_gather of (value, sample) rows for the raw samples "
                                                            "(2048 x 16 doubles per rank) and one of (value, candidate) per restart (512 x 16 doubles per rank)",
             "measured_single_gpu_latencies_us": {"tr_iteration_launch_64_restarts": 86, "tr_iteration_launch_512_restarts": 113,
