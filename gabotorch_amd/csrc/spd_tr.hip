@@ -8,6 +8,8 @@
 // acquisition behind pymanopt_addons/problem.py; here restarts never interact, so each wave runs its whole inner loop alone
 // and the host only supplies what is user code: the constraint callables, evaluated between the two launches when strict.
 // The building blocks are the device functions of spd_tcg_body.hpp and spd_acq_body.hpp.
+#include <cstdlib>
+
 #include "spd_tr_body.hpp"
 
 namespace gabo {
@@ -124,6 +126,9 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
     }
     gabo::SolveArgs a{x, fx, grad, grad_norm, trust_radius, active, iters, acq, B, workspace, r, d, delta_cons, theta, kappa, mininner,
                       maxinner, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter, status, (hipStream_t)stream};
+    // test hook: GABO_TR_NO_SHORTCUTS in the environment runs every iteration in full (no value-first evaluation after a rejection, no reuse of
+    // an identical step's proposal): the two forms must agree bit for bit (tests/test_gpu_native_sweep.py)
+    a.shortcuts = getenv("GABO_TR_NO_SHORTCUTS") ? 0 : 1;
     switch (acq->flags & GABO_METRIC_MASK) {
         case GABO_METRIC_AFFINE_INVARIANT: return gabo::solve_affine_invariant(a);
         case GABO_METRIC_LOG_EUCLIDEAN: return gabo::solve_log_euclidean(a);

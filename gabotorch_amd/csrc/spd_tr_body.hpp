@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
                                                           BuiltinCons B, void* wsbase, int64_t R, double delta_cons, double theta,
                                                           double kappa, int mininner, int maxinner, double delta_bar, double rho_prime,
                                                           double rho_regularization, double mingradnorm, int64_t maxiter,
-                                                          int* __restrict__ status, int stage_gp, int ws_lds, int nested_off) {
+                                                          int* __restrict__ status, int stage_gp, int ws_lds, int nested_off, int shortcuts) {
     static_assert(D <= 8, "built-in constraints use the register eigen-solver");
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     __shared__ double step_cache_store[T_ + 1];     // the last proposal's eta~ and a valid flag: see "The same step again" in tr_propose_body
     if (threadIdx.x == 0) step_cache_store[T_] = 0.0;
     __syncthreads();
-    double* const step_cache = step_cache_store;
+    double* const step_cache = shortcuts != 0 ? step_cache_store : nullptr;
 #else
     double* const step_cache = nullptr;
 #endif
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
 #ifdef GABO_TR_NO_LAZY_GRADIENT      /* A/B: value and gradient together in every iteration (rounds 1-4) */
         const bool lazy = false;
 #else
-        const bool lazy = cons_fresh;
+        const bool lazy = cons_fresh && shortcuts != 0;
 #endif
         last_inner = tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, iw, Rw, C, 0, delta_cons, theta,
                                                 kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1, nlds, lazy, step_cache);
@@ -600,6 +600,7 @@ struct SolveArgs {
     int64_t maxiter;
     int* status;
     hipStream_t st;
+    int shortcuts = 1;      // 0: every iteration computes its proposal and the full evaluation (the environment variable GABO_TR_NO_SHORTCUTS: tests)
 };
 
 template <int METRIC, int DMIN = 2, int DMAX = 8>
@@ -616,7 +617,7 @@ static int dispatch_solve(const SolveArgs& a) {
 #define GABO_SOLVE_LAUNCH(DD, LAT_)                                                                                                \
     hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC, LAT_>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
                        a.active, a.iters, *a.P, a.B, a.ws, a.r, a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.delta_bar, \
-                       a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds, nested_off)
+                       a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds, nested_off, a.shortcuts)
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
         if constexpr (DD >= DMIN && DD <= DMAX) {                                                                                  \

@@ -53,3 +53,23 @@ def test_native_sweep_declines_what_it_does_not_cover():
     for kw in (dict(device_rand=True, builtin_constraint=False), dict(device_rand=True, builtin_constraint=True, device_solve=False)):
         log = run_sweep("cuda:0", num_restarts=32, raw_samples=128, maxiter=10, **kw)[3]
         assert not log.get("native_sweep")
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(strict=True), dict(constraint=False), dict(maxiter=250)])
+def test_one_launch_solve_shortcuts_do_not_change_a_bit(kw, monkeypatch):
+    """The single-launch solve evaluates a proposal's value before its gradient after a rejection and reuses the previous proposal when tCG returns
+    the same step again (csrc/spd_tr_body.hpp).  With GABO_TR_NO_SHORTCUTS in the environment the same kernel runs every iteration in full (the form of
+    rounds 1-4): final iterates, costs and iteration counts of all 512 restarts must agree bit for bit - including the restarts that sit on the
+    eigenvalue bound and have every proposal but one rejected (radius down to 1e-150 at 250 iterations)."""
+    from tools.sweep_bench import run_sweep
+    monkeypatch.delenv("GABO_TR_NO_SHORTCUTS", raising=False)
+    _, b1, v1, l1 = run_sweep("cuda:0", device_rand=True, builtin_constraint=True, native_sweep=False, **kw)
+    monkeypatch.setenv("GABO_TR_NO_SHORTCUTS", "1")
+    _, b2, v2, l2 = run_sweep("cuda:0", device_rand=True, builtin_constraint=True, native_sweep=False, **kw)
+    monkeypatch.delenv("GABO_TR_NO_SHORTCUTS")
+    assert l1.get("one_launch_solve") and l2.get("one_launch_solve")
+    assert torch.equal(l1["per_restart_iterations"].cpu(), l2["per_restart_iterations"].cpu())
+    np.testing.assert_array_equal(l1["final_cost"].cpu().numpy(), l2["final_cost"].cpu().numpy())
+    assert torch.equal(b1, b2) and v1 == v2
+    if kw.get("constraint", True) and not kw.get("strict"):
+        assert int(l1["per_restart_iterations"].max()) == kw.get("maxiter", 100)       # (the restarts on the bound are in the set)
