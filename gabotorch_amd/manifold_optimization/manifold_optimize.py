@@ -362,8 +362,8 @@ def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samp
     if dev.type != "cuda":
         return None
     fused = FusedAcquisition.build(acq_function, post_processing_manifold, dev)
-    if fused is None or not (fused.family == "spd" and fused.flavour == "ai" and fused.single_launch and fused.matrix_input):
-        return None
+    if fused is None or not (fused.family == "spd" and fused.flavour in ("ai", "le") and fused.single_launch and fused.matrix_input):
+        return None       # (affine-invariant and log-Euclidean surrogates: the metrics gabo_spd_tr_solve iterates)
     return {"fused": fused, "device": dev, "manifold": manifold, "builtins": builtins, "device_rand": device_rand}
 
 

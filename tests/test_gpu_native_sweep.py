@@ -73,3 +73,42 @@ def test_one_launch_solve_shortcuts_do_not_change_a_bit(kw, monkeypatch):
     assert torch.equal(b1, b2) and v1 == v2
     if kw.get("constraint", True) and not kw.get("strict"):
         assert int(l1["per_restart_iterations"].max()) == kw.get("maxiter", 100)       # (the restarts on the bound are in the set)
+
+
+def test_native_sweep_on_the_log_euclidean_surrogate_of_config_5():
+    """config 5's latent sweep: S^2_++, SpdLogEuclideanGaussianKernel, StrictConstrainedTrustRegions semantics, an eigenvalue box built with
+    functools.partial (hd_gabo_spd.py:244-257 without the nested lift): native driver against the Python path, bit for bit"""
+    import functools
+
+    from gabotorch_amd import manifolds, models
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdLogEuclideanGaussianKernel
+    from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions
+    from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold
+    from gabotorch_amd.Riemannian_utils import spd_constraints_utils_torch as scut
+    from gabotorch_amd.Riemannian_utils.spd_utils_torch import symmetric_matrix_to_vector_mandel_torch as to_vec, vector_to_symmetric_matrix_mandel_torch as to_mat
+    from oracle import spd as ospd
+    rng = np.random.default_rng(11)
+    q = np.linalg.qr(rng.standard_normal((30, 2, 2)))[0]
+    X = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.1, 4.0, (30, 2)), q)
+    z = torch.tensor(ospd.symmetric_matrix_to_vector_mandel(0.5 * (X + X.transpose(0, 2, 1))), device="cuda:0")
+    f = torch.tensor((np.log(np.linalg.eigvalsh(X) / 2.0) ** 2).sum(1), device="cuda:0")
+    outs = []
+    for native in (True, False):
+        kern = SpdLogEuclideanGaussianKernel().double()
+        kern.lengthscale = torch.tensor(1.5, dtype=torch.float64)
+        gp = models.ExactGP(z, f, kern, outputscale=1.0, noise=1e-2)
+        acq = models.ExpectedImprovement(gp, best_f=float(f.min()), maximize=False)
+        man = manifolds.PositiveDefinite(2)
+        man.min_eig, man.max_eig = 0.05, 5.0
+        cons = [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=5.0),
+                functools.partial(scut.min_eigenvalue_constraint_torch, minimum_eigenvalue=0.05)]
+        np.random.seed(7)
+        torch.manual_seed(7)
+        solver = BatchedTrustRegions(mingradnorm=2e-4, maxiter=60, strict_constraints=True)
+        best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=48, raw_samples=192, bounds=None,
+                                       options={"device": "cuda:0", "batched_rand": True, "native_sweep": native}, inequality_constraints=cons,
+                                       pre_processing_manifold=to_mat, post_processing_manifold=to_vec, approx_hessian=True)
+        assert bool(solver.log.get("native_sweep")) == native and solver.log.get("one_launch_solve")
+        outs.append((best.clone(), solver.log["final_cost"].clone(), solver.log["per_restart_iterations"].clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2].cpu(), outs[1][2].cpu())
