@@ -663,7 +663,8 @@ def main():
             dist.all_reduce(tsw, op=dist.ReduceOp.MAX)
         ssw = float(tsw.item())
         sphere_sweep_result = {"workload": "SphereGaussianKernel GP(50 obs)+EI on S^9, 2048 raw samples, 512 restarts, stock trust regions "
-                                           "with exact Hessian-vector products (closed form on the device)",
+                                           "with exact Hessian-vector products (closed form on the device); one process: through the native host driver "
+                                           "gabo_sphere_sweep_score / gabo_sphere_sweep_solve",
                                "seconds": ssw, "restarts_per_s": 512 / ssw, "best_acq": sval}
 
     t = torch.tensor([wall], dtype=torch.float64, device=device)

@@ -61,6 +61,13 @@ class SphereAcqParams(_c.Structure):
                 ("out_sign", _c.c_double)]
 
 
+class SphereSweepConfig(_c.Structure):
+    """gabo_sphere_sweep_config of include/gabo_hip.h"""
+    _fields_ = [("acq", SphereAcqParams), ("delta_bar", _c.c_double), ("delta0", _c.c_double), ("theta", _c.c_double), ("kappa", _c.c_double),
+                ("mininner", _c.c_int), ("maxinner", _c.c_int), ("exact_hessian", _c.c_int), ("rho_prime", _c.c_double),
+                ("rho_regularization", _c.c_double), ("mingradnorm", _c.c_double), ("maxiter", _c.c_int64)]
+
+
 class ReconSolveOptions(_c.Structure):
     """gabo_recon_solve_options of include/gabo_hip.h"""
     _fields_ = [(k, _c.c_double) for k in ("bound", "rho_init", "thetarho", "tau", "starting_tolgradnorm", "ending_tolgradnorm", "gammas_fact",
@@ -118,6 +125,9 @@ SIGNATURES = {
     "gabo_spd_tr_workspace_bytes": (_SZ, [_I64, _I, _I, _I64]),
     "gabo_spd_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _I, _D, _D, _D, _I, _I, _P, _P, _P]),
     "gabo_spd_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I64, _D, _D, _D, _D, _I64, _P, _P]),
+    "gabo_sphere_sweep_workspace_bytes": (_SZ, [_I, _I64, _I64]),
+    "gabo_sphere_sweep_score": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _SZ, _P]),
+    "gabo_sphere_sweep_solve": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gabo_spd_sweep_workspace_bytes": (_SZ, [_I64, _I, _I64, _I64, _I]),
     "gabo_spd_sweep_score": (_I, [_P, _I64, _I64, _I64, _c.c_uint64, _P, _P, _P, _SZ, _P, _P]),
     "gabo_spd_sweep_solve": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),

@@ -175,3 +175,123 @@ extern "C" int gabo_spd_sweep_solve(const gabo_spd_sweep_config* cfg, const int6
     if (iterations_dev) *iterations_dev = w.iters;
     return GABO_OK;
 }
+
+// ---- the sphere twin: gen_batch_initial_conditions_manifold + gen_candidates_manifold + get_best_candidates on S^(dim-1) ----------------------------
+// The reference's gabo_sphere examples (examples/bo_sphere/benchmark_examples/gabo_sphere.py:151-175): stock TrustRegions, no constraints, exact or
+// finite-difference Hessian-vector products.  Same two-call shape as above; the raw samples always come from the caller's host sampler (`manifold.rand`).
+namespace gabo {
+
+struct SphSweepWs {
+    double *raw, *raw_val, *x, *fx, *eg, *g, *ng, *delta;
+    int64_t *picked, *iters;
+    uint8_t* active;
+    void* tr;
+    size_t tr_bytes, bytes;
+};
+
+static SphSweepWs sph_sweep_layout(void* base, int dim, int64_t max_raw, int64_t r) {
+    SphSweepWs w;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) {
+        char* q = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return q;
+    };
+    w.raw = (double*)take((size_t)max_raw * dim * 8);
+    w.raw_val = (double*)take((size_t)max_raw * 8);
+    w.x = (double*)take((size_t)r * dim * 8);
+    w.fx = (double*)take((size_t)r * 8);
+    w.eg = (double*)take((size_t)r * dim * 8);
+    w.g = (double*)take((size_t)r * dim * 8);
+    w.ng = (double*)take((size_t)r * 8);
+    w.delta = (double*)take((size_t)r * 8);
+    w.picked = (int64_t*)take((size_t)r * 8);
+    w.iters = (int64_t*)take((size_t)r * 8);
+    w.active = (uint8_t*)take((size_t)r);
+    w.tr_bytes = gabo_sphere_tr_workspace_bytes(r, dim, 0);
+    w.tr = take(w.tr_bytes + 8);
+    w.bytes = (size_t)(p - (char*)base);
+    return w;
+}
+
+// ||g_i|| of r tangent vectors ([3P] pymanopt Sphere.norm = the Euclidean norm)
+__global__ __launch_bounds__(256) void sweep_rownorm_kernel(const double* __restrict__ g, double* __restrict__ out, int64_t r, int dim) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r) return;
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) s += g[i * dim + k] * g[i * dim + k];
+    out[i] = __builtin_sqrt(s);
+}
+
+}  // namespace gabo
+
+extern "C" size_t gabo_sphere_sweep_workspace_bytes(int dim, int64_t max_raw, int64_t restarts) {
+    if (dim < 2 || max_raw < 0 || restarts < 0) return 0;
+    return gabo::sph_sweep_layout(nullptr, dim, max_raw, restarts).bytes;
+}
+
+extern "C" int gabo_sphere_sweep_score(const gabo_sphere_sweep_config* cfg, int64_t count, int64_t max_raw, int64_t restarts,
+                                       const double* raw_points_host, double* values_host, void* workspace, size_t workspace_bytes,
+                                       gabo_stream_t stream) {
+    if (!cfg || !raw_points_host || !values_host || !workspace || count < 1 || count > max_raw || restarts < 1) return GABO_ERR_ARG;
+    const int dim = cfg->acq.dim;
+    if (dim < 2) return GABO_ERR_DIM;
+    const gabo::SphSweepWs w = gabo::sph_sweep_layout(workspace, dim, max_raw, restarts);
+    if (w.bytes > workspace_bytes) return GABO_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(w.raw, raw_points_host, (size_t)count * dim * 8, hipMemcpyHostToDevice, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    gabo_sphere_acq_params acq = cfg->acq;
+    acq.out_sign = 1.0;
+    int rc;
+    if ((rc = gabo_sphere_acq_eval(w.raw, &acq, w.raw_val, nullptr, count, stream)) != GABO_OK) return rc;
+    if (hipMemcpyAsync(values_host, w.raw_val, (size_t)count * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return GABO_ERR_LAUNCH;
+    return GABO_OK;
+}
+
+extern "C" int gabo_sphere_sweep_solve(const gabo_sphere_sweep_config* cfg, const int64_t* picked_host, int64_t restarts, int64_t max_raw,
+                                       int64_t* best_index_host, double* best_value_host, int64_t* max_iterations_host, double** candidates_dev,
+                                       double** cost_dev, int64_t** iterations_dev, void* workspace, size_t workspace_bytes,
+                                       gabo_stream_t stream) {
+    if (!cfg || !picked_host || !best_index_host || !best_value_host || !workspace || restarts < 1) return GABO_ERR_ARG;
+    const int dim = cfg->acq.dim;
+    if (dim < 2) return GABO_ERR_DIM;
+    const int64_t r = restarts;
+    for (int64_t k = 0; k < r; ++k)
+        if (picked_host[k] < 0 || picked_host[k] >= max_raw) return GABO_ERR_ARG;
+    const gabo::SphSweepWs w = gabo::sph_sweep_layout(workspace, dim, max_raw, r);
+    if (w.bytes > workspace_bytes) return GABO_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (hipMemcpyAsync(w.picked, picked_host, (size_t)r * 8, hipMemcpyHostToDevice, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    hipLaunchKernelGGL(gabo::sweep_gather_kernel, dim3((unsigned)((r * dim + 255) / 256)), dim3(256), 0, st, w.raw, w.picked, w.x, r, dim);
+    gabo_sphere_acq_params acq = cfg->acq;
+    acq.out_sign = -1.0;
+    if ((rc = gabo_sphere_acq_eval(w.x, &acq, w.fx, w.eg, r, stream)) != GABO_OK) return rc;
+    if ((rc = gabo_sphere_manifold_op(GABO_SPH_PROJ, w.x, w.eg, nullptr, nullptr, w.g, r, dim, stream)) != GABO_OK) return rc;
+    hipLaunchKernelGGL(gabo::sweep_rownorm_kernel, dim3((unsigned)((r + 255) / 256)), dim3(256), 0, st, w.g, w.ng, r, dim);
+    hipLaunchKernelGGL(gabo::sweep_init_kernel, dim3((unsigned)((r + 255) / 256)), dim3(256), 0, st, w.delta, w.active, w.iters, r, cfg->delta0);
+    if (hipMemsetAsync(w.tr, 0, w.tr_bytes, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    if ((rc = gabo_sphere_tr_solve(w.x, w.fx, w.g, w.ng, w.delta, w.active, w.iters, &acq, w.tr, w.tr_bytes, r, cfg->theta, cfg->kappa, cfg->mininner,
+                                   cfg->maxinner, cfg->exact_hessian, cfg->delta_bar, cfg->rho_prime, cfg->rho_regularization, cfg->mingradnorm,
+                                   cfg->maxiter, stream)) != GABO_OK)
+        return rc;
+    std::vector<double> fx((size_t)r);
+    std::vector<int64_t> it((size_t)r);
+    if (hipMemcpyAsync(fx.data(), w.fx, (size_t)r * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    if (hipMemcpyAsync(it.data(), w.iters, (size_t)r * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return GABO_ERR_LAUNCH;
+    int64_t best = 0, maxit = 0;
+    for (int64_t k = 0; k < r; ++k) {
+        const double v = -fx[(size_t)k], b = -fx[(size_t)best];
+        if ((v > b && b == b) || (v != v && b == b)) best = k;
+        if (it[(size_t)k] > maxit) maxit = it[(size_t)k];
+    }
+    *best_index_host = best;
+    *best_value_host = -fx[(size_t)best];
+    if (max_iterations_host) *max_iterations_host = maxit;
+    if (candidates_dev) *candidates_dev = w.x;
+    if (cost_dev) *cost_dev = w.fx;
+    if (iterations_dev) *iterations_dev = w.iters;
+    return GABO_OK;
+}

@@ -330,13 +330,31 @@ def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samp
     one the native driver issues - built-in SPD surrogate evaluated in one launch, raw samples drawn on the device, eigenvalue bounds built
     with functools.partial (or no constraints), FD Hessian, the whole solve one launch, one process.  Returns what the driver needs, or None:
     then the Python path below runs, launch for launch the same work.  options={"native_sweep": False} keeps the Python path."""
-    from ..manifolds import PositiveDefinite
+    from ..manifolds import PositiveDefinite, Sphere
     from ..Riemannian_utils import spd_utils_torch
     from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint
     from .. import _lib
     device = options.get("device")
     if not (options.get("native_sweep", True) and device is not None and _dist() is None):
         return None
+    if isinstance(manifold, Sphere):
+        # the sphere twin (gabo_sphere_sweep_score / _solve): stock trust regions without constraints, exact or FD Hessian, host sampler
+        if not (q == 1 and bounds is None and not solver_init_conds and sample_type == torch.float64 and isinstance(solver, BatchedTrustRegions)
+                and not solver.use_rand and solver.maxtime >= 1000 and solver.trace is None and not equality_constraints
+                and not inequality_constraints and pre_processing_manifold is None and post_processing_manifold is None):
+            return None
+        if any(options.get(k, True) is False for k in ("fused_acquisition", "device_tcg", "device_outer", "device_iteration", "device_solve")):
+            return None
+        if options.get("batch_limit", num_restarts) < num_restarts or num_restarts < 1 or raw_samples < 1:
+            return None
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            return None
+        fused = FusedAcquisition.build(acq_function, None, dev)
+        if fused is None or not (fused.family == "sphere" and fused.single_launch):
+            return None
+        return {"fused": fused, "device": dev, "manifold": manifold, "builtins": [], "device_rand": False, "sphere": True,
+                "exact_hessian": not approx_hessian}
     if not (q == 1 and bounds is None and not solver_init_conds and approx_hessian and sample_type == torch.float64
             and isinstance(solver, BatchedTrustRegions) and not solver.use_rand and solver.maxtime >= 1000
             and solver.trace is None and not equality_constraints):
@@ -377,6 +395,8 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
     import ctypes
 
     from .. import _lib, ops
+    if plan.get("sphere"):
+        return _native_sweep_sphere(plan, acq_function, solver, num_restarts, raw_samples, options)
     lib = _lib.load()
     fused, dev, man = plan["fused"], plan["device"], plan["manifold"]
     d, dv, R = man._n, man._n * (man._n + 1) // 2, int(num_restarts)
@@ -450,6 +470,76 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
                   "final_cost": view(cost_p, R, torch.float64).clone(), "final_gradnorm": None, "cost_evals": 0, "grad_evals": 0,
                   "time": time.time() - time0, "one_launch_solve": True, "native_sweep": True}
     return cands[int(best.value)].reshape(1, dv).clone()
+
+
+def _native_sweep_sphere(plan, acq_function, solver, num_restarts, raw_samples, options):
+    """the sphere twin of _native_sweep: gabo_sphere_sweep_score / gabo_sphere_sweep_solve around the same selection heuristic and host sampler"""
+    import ctypes
+    import time
+
+    from .. import _lib, ops
+    lib = _lib.load()
+    fused, dev, man = plan["fused"], plan["device"], plan["manifold"]
+    dim, R = int(man._n), int(num_restarts)
+    cfg = _lib.SphereSweepConfig()
+    cfg.acq = fused.sphere_acq_params()
+    delta_bar = getattr(man, "typicaldist", None) or float(man.dim) ** 0.5
+    cfg.delta_bar, cfg.delta0 = float(delta_bar), float(delta_bar) / 8
+    cfg.theta, cfg.kappa, cfg.mininner, cfg.maxinner = float(solver.theta), float(solver.kappa), 1, int(man.dim)
+    cfg.exact_hessian = 1 if plan["exact_hessian"] else 0
+    cfg.rho_prime, cfg.rho_regularization = float(solver.rho_prime), float(solver.rho_regularization)
+    cfg.mingradnorm, cfg.maxiter = float(solver.mingradnorm), int(solver.maxiter)
+    select, select_kwargs = _selection(acq_function, options)
+    time0 = time.time()
+    with torch.cuda.device(dev):
+        stream = ops._stream_ptr(dev)
+        picked = None
+        for attempt in range(1, 5):
+            total = raw_samples * attempt
+            wsb = int(lib.gabo_sphere_sweep_workspace_bytes(dim, total, R))
+            key = ("sphere", dev.index, stream)
+            ws = _sweep_workspaces.get(key)
+            if ws is None or ws.numel() < wsb:
+                ws = _sweep_workspaces[key] = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            if options.get("batched_rand") and hasattr(man, "rand_batch"):           # the host samplers of _draw_raw_samples, same draws
+                raw = np.ascontiguousarray(man.rand_batch(total), dtype=np.float64)
+            else:
+                raw = np.ascontiguousarray(np.stack([np.asarray(man.rand()) for _ in range(total)]), dtype=np.float64)
+            if raw.shape != (total, dim):
+                raise RuntimeError(f"manifold.rand returned points of shape {raw.shape[1:]}, expected ({dim},)")
+            y = np.empty(total, dtype=np.float64)
+            _lib.check(lib.gabo_sphere_sweep_score(ctypes.byref(cfg), total, total, R, raw.ctypes.data, y.ctypes.data, ws.data_ptr(), wsb, stream),
+                       "gabo_sphere_sweep_score")
+            ops.check_deferred()
+            sel_seed = int(torch.randint(0, 2 ** 52, (1,)).item())
+            gen = torch.Generator()
+            gen.manual_seed(sel_seed)
+            rows = torch.arange(total).reshape(-1, 1, 1)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                picked = select(X=rows, Y=torch.from_numpy(y), n=R, generator=gen, **select_kwargs)
+            if not any(issubclass(w_.category, BadInitialCandidatesWarning) for w_ in caught):
+                break
+        else:
+            warnings.warn("Unable to find non-zero acquisition function values - initial conditions are being selected randomly.",
+                          BadInitialCandidatesWarning)
+        idx = np.ascontiguousarray(picked.reshape(-1).numpy(), dtype=np.int64)
+        best, iters = ctypes.c_int64(0), ctypes.c_int64(0)
+        value = ctypes.c_double(0.0)
+        cand_p, cost_p, it_p = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.gabo_sphere_sweep_solve(ctypes.byref(cfg), idx.ctypes.data, R, total, ctypes.byref(best), ctypes.byref(value), ctypes.byref(iters),
+                                               ctypes.byref(cand_p), ctypes.byref(cost_p), ctypes.byref(it_p), ws.data_ptr(), wsb, stream),
+                   "gabo_sphere_sweep_solve")
+    base = ws.data_ptr()
+
+    def view(ptr, count, dtype):
+        off = int(ptr.value) - base
+        return ws[off:off + 8 * count].view(dtype)
+    cands = view(cand_p, R * dim, torch.float64).reshape(R, dim)
+    solver.log = {"iterations": int(iters.value), "per_restart_iterations": view(it_p, R, torch.int64).clone(),
+                  "final_cost": view(cost_p, R, torch.float64).clone(), "final_gradnorm": None, "cost_evals": 0, "grad_evals": 0,
+                  "time": time.time() - time0, "one_launch_solve": True, "native_sweep": True}
+    return cands[int(best.value)].reshape(1, dim).clone()
 
 
 def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num_restarts, raw_samples,

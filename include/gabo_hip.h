@@ -547,6 +547,24 @@ int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm,
                          int mininner, int maxinner, int exact_hessian, double delta_bar, double rho_prime, double rho_regularization,
                          double mingradnorm, int64_t maxiter, gabo_stream_t stream);
 
+/* The sphere twin of gabo_spd_sweep_score / gabo_spd_sweep_solve: one multi-start acquisition sweep of the reference's gabo_sphere examples
+ * (examples/bo_sphere/benchmark_examples/gabo_sphere.py:151-175: stock TrustRegions, no constraints; manifold_optimize.py:36-321) as two host
+ * calls around the caller's selection heuristic.  The raw samples are the caller's (count x dim points drawn by `manifold.rand` on the host).
+ * Launches: gabo_sphere_acq_eval, gabo_sphere_manifold_op (proj), gabo_sphere_tr_solve.  candidates_dev: the final iterates, restarts x dim. */
+typedef struct {
+    gabo_sphere_acq_params acq;
+    double delta_bar, delta0, theta, kappa;
+    int mininner, maxinner, exact_hessian;
+    double rho_prime, rho_regularization, mingradnorm;
+    int64_t maxiter;
+} gabo_sphere_sweep_config;
+size_t gabo_sphere_sweep_workspace_bytes(int dim, int64_t max_raw, int64_t restarts);
+int gabo_sphere_sweep_score(const gabo_sphere_sweep_config* cfg, int64_t count, int64_t max_raw, int64_t restarts, const double* raw_points_host,
+                            double* values_host, void* workspace, size_t workspace_bytes, gabo_stream_t stream);
+int gabo_sphere_sweep_solve(const gabo_sphere_sweep_config* cfg, const int64_t* picked_host, int64_t restarts, int64_t max_raw,
+                            int64_t* best_index_host, double* best_value_host, int64_t* max_iterations_host, double** candidates_dev,
+                            double** cost_dev, int64_t** iterations_dev, void* workspace, size_t workspace_bytes, gabo_stream_t stream);
+
 /* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
  *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)
  *   GABO_SPH_RETR   out = (X+U)/|X+U|        [3P] Sphere.retr  (robust_trust_regions.py:228)

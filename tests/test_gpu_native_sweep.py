@@ -112,3 +112,21 @@ def test_native_sweep_on_the_log_euclidean_surrogate_of_config_5():
         outs.append((best.clone(), solver.log["final_cost"].clone(), solver.log["per_restart_iterations"].clone()))
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2].cpu(), outs[1][2].cpu())
+
+
+@pytest.mark.parametrize("approx", [False, True])
+def test_native_sphere_sweep_returns_the_python_path_candidate(approx):
+    """gabo_sphere_sweep_score / gabo_sphere_sweep_solve (the reference's gabo_sphere setting: stock trust regions, no constraints, exact or FD
+    Hessian-vector products) against the Python path: same candidate, costs and iteration counts.  (The initial gradient NORM is a torch
+    reduction in one path and a plain loop in the other; it only enters the stopping test, so the comparison stays bitwise.)"""
+    from tools.sphere_sweep_bench import run
+    outs = []
+    for native in (True, False):
+        dt, val, its, log = run(approx=approx, constrained=False, device="cuda:0", native=native, R=96, raw=384)
+        assert bool(log.get("native_sweep")) == native and log.get("one_launch_solve")
+        outs.append((val, its, log["final_cost"].cpu().numpy(), log["per_restart_iterations"].cpu().numpy()))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    np.testing.assert_array_equal(outs[0][3], outs[1][3])
+    # a constrained sphere sweep (constraints on the sphere are user callables) stays on the Python path
+    assert not run(approx=True, constrained=True, device="cuda:0", R=16, raw=64, maxiter=5)[3].get("native_sweep")
