@@ -149,7 +149,7 @@ __device__ __forceinline__ double nonzero(double g) {
 // simply swept through: the recurrence restarts by itself there (c -> 1, s -> 0).  p > 0 is an invariant (see
 // `floor_p`), hence r = p + bb > 0 and c = p / r > 0: no division can see a zero.  The last 2x2 block is closed form.
 template <int D>
-__device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2)[D]) {
+__device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2)[D], const double eps2_arg = 0.0) {
     // Deflation threshold on e2[l] / |d[l] d[l+1]|.  LAPACK uses eps^2 (4.9e-32); 1e-20 is enough here: dropping an
     // off-diagonal e perturbs a SYMMETRIC function of the eigenvalues (sum log^2) only to second order, ~e^2 f'' <= 1e-20,
     // whatever the gap, and the iteration converges cubically, so the looser test saves the last sweep of many stages
@@ -158,7 +158,11 @@ __device__ __forceinline__ void tridiag_eigenvalues(double (&dg)[D], double (&e2
 #ifndef GABO_QL_EPS2
 #define GABO_QL_EPS2 1e-20
 #endif
-    constexpr double eps2 = GABO_QL_EPS2;
+    // eps2_arg > 0: the caller's threshold (wave-uniform).  The Gaussian kernel VALUE without a distance output tolerates a looser one: dropping
+    // an off-diagonal e^2 <= eps2 |d d'| perturbs sum log^2 lambda by ~eps2 in ABSOLUTE terms (second order), i.e. K = exp(-beta d^2) by
+    // beta eps2 relative - far below its rounding at 1e-16; what the strict 1e-20 protects is the RELATIVE accuracy of a tiny distance
+    // (nearly identical pairs: d ~ 1e-5, d^2 ~ 1e-10), which only the distance and Laplace outputs expose (spd_pairwise_body.hpp).
+    const double eps2 = eps2_arg > 0.0 ? eps2_arg : GABO_QL_EPS2;
 #ifndef GABO_QL_NOFLIP
     // QL deflates at the top (index 0) and converges fastest when the small end of a graded matrix sits there (LAPACK's
     // dsterf chooses QL vs QR on the same criterion): reverse the arrays per lane when |d[0]| > |d[D-1]|.  Measured on the

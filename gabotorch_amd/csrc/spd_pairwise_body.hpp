@@ -45,7 +45,7 @@ struct SpdGcolPointer {
 };
 
 template <int D, class GCOL>
-__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const GCOL& Gj, const double* __restrict__ ltab) {
+__device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const GCOL& Gj, const double* __restrict__ ltab, const double eps2 = 0.0) {
     constexpr int T = tri_size(D);
     // Column `col` of C = W G depends only on column `col` of G:  C[r][col] = sum_{k=col..r} W[r][k] G[k][col].
     // M = C C^T = sum_col C[:,col] C[:,col]^T, so M is accumulated by rank-1 updates and C is never held whole:
@@ -75,7 +75,7 @@ __device__ __forceinline__ double ai_sumsq(const double* __restrict__ W, const G
     });
     double dg[D], e2[D];
     tridiagonalize<D>(m, dg, e2);
-    tridiag_eigenvalues<D>(dg, e2);
+    tridiag_eigenvalues<D>(dg, e2, eps2);
     double s = 0.0;
 #ifdef GABO_OCML_LOG
     static_for<D>([&](auto kk) { double lg = log(dg[decltype(kk)::value]); s = __builtin_fma(lg, lg, s); });
@@ -209,6 +209,13 @@ __global__ __launch_bounds__(256, (D > GABO_PAIR_TWO_WAVE_MAX_DIM ? 1 : GABO_PAI
         const double* Wr = Winv + b * w_batch_stride + ir * T;
         lw_lane = log_tab(Wr[0] * Wr[2], lr2, ltab);
     }
+    // deflation threshold of the QL iteration: 1e-20 where a distance leaves the kernel (distance and Laplace modes, or a distance output next to the
+    // Gaussian values); GABO_QL_EPS2_GAUSS for Gaussian values alone (see tridiag_eigenvalues)
+#ifndef GABO_QL_EPS2_GAUSS
+#define GABO_QL_EPS2_GAUSS 1e-15
+#endif
+    double eps2 = (mode == GABO_OUT_GAUSSIAN && !dist_out) ? GABO_QL_EPS2_GAUSS : 0.0;
+    asm volatile("" : "+s"(eps2));
     for (int64_t i = i0; i < i1; ++i) {
         const double* W = Winv + b * w_batch_stride + i * T;
         double s;
@@ -225,13 +232,13 @@ __global__ __launch_bounds__(256, (D > GABO_PAIR_TWO_WAVE_MAX_DIM ? 1 : GABO_PAI
                 SpdGcolBuffer gb = gbuf;
                 asm volatile("" : "+v"(gb.voff));
                 asm volatile("" : "+s"(gb.stride_bytes));      // the entry offsets are recomputed per row on the scalar unit, not kept (the W row owns the SGPRs)
-                s = ai_sumsq<D>(W, gb, ltab);
+                s = ai_sumsq<D>(W, gb, ltab, eps2);
             } else
 #endif
             {
                 SpdGcolPointer gp{(spd_gcol_ptr)Gj, n2};
                 asm volatile("" : "+v"(gp.p));
-                s = ai_sumsq<D>(W, gp, ltab);
+                s = ai_sumsq<D>(W, gp, ltab, eps2);
             }
         }
         double dist, val;
