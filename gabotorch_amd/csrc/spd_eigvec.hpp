@@ -107,11 +107,13 @@ __device__ __forceinline__ void tridiagonalize_q(double (&m)[tri_size(D)], doubl
 // VEC = false: the same recurrence on (dg, e) without touching z - the eigenvalues come out with the SAME BITS as with the vectors (the
 // rotations never feed back into dg / e), at about a third of the instructions.
 template <int D, int ROWS = D, bool VEC = true>
-__device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[D], double (&z)[ROWS * D]) {
+__device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[D], double (&z)[ROWS * D], const double eps2_arg = 0.0) {
     // dropping an off-diagonal e perturbs a matrix FUNCTION to first order in e / gap (the eigenvalue-only solver can be looser: a
     // symmetric function of the eigenvalues moves only to second order): |e| <= eps (|d_l| + |d_{l+1}|), the EISPACK / LAPACK
     // criterion in the form that also terminates on indefinite input (tangent vectors) with zeros on the diagonal
-    constexpr double eps2 = 1.2e-32;
+    // (eps2_arg > 0: the caller's threshold on e^2 / (|d_l| + |d_l+1|)^2.  A dropped off-diagonal e changes a matrix function by e f[lambda_l, lambda_l+1] - a divided
+    // difference, bounded by e f' even where the gap closes - so a caller that needs the function to 1e-12 can stop at |e| <= 1e-13 (|d| + |d'|))
+    const double eps2 = eps2_arg > 0.0 ? eps2_arg : 1.2e-32;
     static_for<D - 1>([&](auto ll) {
         constexpr int l = decltype(ll)::value;
         for (int it = 0; it < 60; ++it) {
@@ -175,10 +177,10 @@ __device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[
 // m (packed lower triangle, destroyed) = V diag(lam) V^T: eigenvalues (unordered) and eigenvectors (columns of v, row-major D x D).
 // Every lane of the wave must call it (the iteration leaves a stage by a wave-wide vote).
 template <int D>
-__device__ __forceinline__ void sym_eig_reg(double (&m)[tri_size(D)], double (&lam)[D], double (&v)[D * D]) {
+__device__ __forceinline__ void sym_eig_reg(double (&m)[tri_size(D)], double (&lam)[D], double (&v)[D * D], const double eps2 = 0.0) {
     double sub[D];
     tridiagonalize_q<D>(m, lam, sub, v);
-    tridiag_ql_vectors<D>(lam, sub, v);
+    tridiag_ql_vectors<D>(lam, sub, v, eps2);
 }
 
 // The eigenvalues alone, bit-identical to the `lam` of sym_eig_reg on the same input (same tridiagonalisation, same QL recurrence; the
