@@ -101,11 +101,26 @@ __global__ __launch_bounds__(64, (D > GABO_BWD_TWO_WAVE_MAX_DIM ? 1 : 2)) void s
         auto Vat = [&](int r, int c) -> double { return vreg[r * D + c]; };
         double lg[D];
         double s = 0.0;
+#ifdef GABO_BWD_OCML_LOG       /* A/B: OCML's log (98 instructions, double-double) as in rounds 1-4 */
         static_for<D>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             lg[k] = log(lam[k]);
             s = __builtin_fma(lg[k], lg[k], s);
         });
+#else
+        {
+            // the fdlibm-scheme log of the acquisition kernels (gabo_device.hpp: ~35 instructions at 1 ulp) instead of OCML's 98: D of them per pair.
+            // An eigenvalue that is not positive (M = C C^T is positive semi-definite by construction: rounding of a singular pair, or NaN factors of
+            // a matrix of x2 that is not positive definite) gives NaN, as torch.log does in spd_utils_torch.py:115.
+            const LogRegs logc = LogRegs::load();
+            static_for<D>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                const double l = log_pos(lam[k], logc);
+                lg[k] = lam[k] > 0.0 ? l : __builtin_nan("");
+                s = __builtin_fma(lg[k], lg[k], s);
+            });
+        }
+#endif
         // w = dLoss/d(d^2)
         double d2 = s + 1e-15;
         double go = live ? gout[b * go_sb + i * go_si + j * go_sj] : 0.0;

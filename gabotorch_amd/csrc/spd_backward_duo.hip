@@ -77,9 +77,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((D > 12 ? 1 
         sym_eig_duo<D>(m, lam, vh, h);
         // logarithms: each lane takes every other eigenvalue, the partner's come through the swap
         double lg[D];
+        const LogRegs logc = LogRegs::load();
         static_for<HR>([&](auto kk) {
             constexpr int ke = 2 * decltype(kk)::value, ko = ke + 1 < D ? ke + 1 : ke;
-            const double mine = log(h ? lam[ko] : lam[ke]);
+            const double lsel = h ? lam[ko] : lam[ke];
+            const double mine = lsel > 0.0 ? log_pos(lsel, logc) : __builtin_nan("");   // (as spd_backward.hip: 35 instructions instead of OCML's 98)
             const double other = duo_swap(mine);
             lg[ke] = h ? other : mine;
             if constexpr (ke + 1 < D) lg[ke + 1] = h ? mine : other;
