@@ -115,6 +115,7 @@ SIGNATURES = {
     "gabo_spd_tcg_workspace_bytes": (_SZ, [_I64, _I, _I]),
     "gabo_spd_tcg_running_offset": (_SZ, [_I64, _I, _I]),
     "gabo_spd_tcg_begin": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ, _I64, _I, _I, _P, _P]),
+    "gabo_spd_tcg_begin_rand": (_I, [_P, _P, _P, _I64, _I, _I, _P]),
     "gabo_spd_tcg_fd_point": (_I, [_P, _P, _I64, _I, _I, _P]),
     "gabo_spd_tcg_step": (_I, [_P, _P, _P, _I64, _I, _I, _I, _D, _D, _D, _I, _P]),
     "gabo_spd_tcg_end": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P]),
@@ -137,6 +138,7 @@ SIGNATURES = {
     "gabo_spd_matfun_backward_eig": (_I, [_I, _P, _P, _P, _I64, _I, _P]),
     "gabo_sphere_acq_eval": (_I, [_P, _P, _P, _P, _I64, _P]),
     "gabo_sphere_tr_workspace_bytes": (_SZ, [_I64, _I, _I]),
+    "gabo_sphere_tr_stop_offset": (_SZ, [_I64, _I, _I]),
     "gabo_sphere_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _D, _D, _D, _I, _I, _I, _P, _P]),
     "gabo_sphere_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _D, _D, _D, _D, _I64, _P, _P]),
     "gabo_sphere_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I64, _D, _D, _I, _I, _I, _D, _D, _D, _D, _I64, _P]),

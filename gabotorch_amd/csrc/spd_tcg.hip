@@ -18,8 +18,18 @@ __global__ __launch_bounds__(64) void spd_tcg_begin_kernel(const double* __restr
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int64_t i = blockIdx.x;
     TcgWs w = tcg_layout(wsbase, R, d, C);
-    if (i == 0 && threadIdx.x == 0) { w.counters[0] = 0; w.counters[1] = 0; }
+    if (i == 0 && threadIdx.x == 0) { w.counters[0] = 0; w.counters[1] = 0; w.counters[3] = 0; }
     tcg_begin(x + i * d * d, g + i * d * d, gc, fc, active[i] != 0, delta_tr[i], w, i, R, d, C, status, lds);
+}
+
+// counters[3] = 1: the steps that follow run without the preconditioner (use_rand)
+__global__ __launch_bounds__(64) void spd_tcg_begin_rand_kernel(void* wsbase, const double* __restrict__ eta0, const double* __restrict__ heta0,
+                                                                int64_t R, int d, int C) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t i = blockIdx.x;
+    TcgWs w = tcg_layout(wsbase, R, d, C);
+    if (i == 0 && threadIdx.x == 0) w.counters[3] = 1;
+    tcg_begin_rand(w, i, d, eta0 + i * d * d, heta0 + i * d * d, lds);
 }
 
 __global__ __launch_bounds__(64) void spd_tcg_fd_point_kernel(void* wsbase, double* __restrict__ x_fd, int64_t R, int d, int C) {
@@ -38,7 +48,7 @@ __global__ __launch_bounds__(64) void spd_tcg_step_kernel(void* wsbase, const do
     const int iter = w.counters[1];
     if (i == 0 && threadIdx.x == 0) w.counters[2] = iter + 1;   // published to counters[1] by spd_tcg_advance_kernel
     const bool running = tcg_step(w, i, R, d, C, egrad_fd + i * (int64_t)(d * (d + 1) / 2), neq, delta_cons, theta, kappa, mininner,
-                                  iter, lds);
+                                  iter, lds, w.counters[3] != 0);
     if (running && threadIdx.x == 0) atomicOr(w.counters, 1);
 }
 
@@ -90,6 +100,18 @@ int gabo_spd_tcg_begin(const double* x, const double* grad, const double* cons_g
     size_t lds = (size_t)(5 * d * d) * sizeof(double);
     hipLaunchKernelGGL(gabo::spd_tcg_begin_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, grad, cons_grads,
                        cons_values, active, trust_radius, workspace, r, d, n_constraints, status);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_spd_tcg_begin_rand(void* workspace, const double* eta0, const double* heta0, int64_t r, int d, int n_constraints,
+                            gabo_stream_t stream) {
+    int rc = tcg_args_ok(r, d, n_constraints);
+    if (rc != GABO_OK) return rc;
+    if (r == 0) return GABO_OK;
+    if (!workspace || !eta0 || !heta0) return GABO_ERR_ARG;
+    size_t lds = (size_t)(5 * d * d) * sizeof(double);
+    hipLaunchKernelGGL(gabo::spd_tcg_begin_rand_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, workspace, eta0, heta0, r, d,
+                       n_constraints);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

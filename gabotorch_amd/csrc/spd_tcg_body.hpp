@@ -11,6 +11,9 @@ enum { TCG_NEGATIVE_CURVATURE = 0, TCG_EXCEEDED_TR, TCG_REACHED_TARGET_LINEAR, T
        TCG_MODEL_INCREASED, TCG_REACHED_CONSTRAINTS };
 enum { SC_DELTA = 0, SC_E_PE, SC_E_PD, SC_D_PD, SC_Z_R, SC_MODEL, SC_NORM_R0, SC_C_FD, SC_COUNT };
 constexpr int kMaxCons = 8;
+#ifndef GABO_FD_EPS
+#define GABO_FD_EPS 6.103515625e-05    /* "how far do we look": 2^-14, approximate_hessian.py:40 (rounds 2-4 had 2^-13 here; A/B: tools/ab_build.py) */
+#endif
 
 struct TcgWs {
     double *chol, *g_w, *eta_w, *heta_w, *r_w, *delta_w, *expm, *w_ones, *scal, *gc_w, *fc, *fcg_pe;
@@ -156,6 +159,66 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
     }
 }
 
+// use_rand (robust_trust_regions.py:176-181, 407-452): tCG starts from a tiny random tangent vector eta0 instead of zero, with
+// Heta0 = hess(x, eta0) given by the caller, r = g + Heta0, no preconditioner (z = r), delta = -r, e_Pe = <eta0, eta0>,
+// e_Pd = <eta0, delta>, model = <eta0, g> + <eta0, Heta0> / 2.  Called after tcg_begin for the same restart (which left the factor,
+// the whitened gradient and the constraints' state in the workspace); eta0, heta0: this restart's d x d tangent vectors at x.
+// lds: 5 d^2 doubles.
+static __device__ void tcg_begin_rand(const TcgWs& w, int64_t i, int d, const double* __restrict__ eta0, const double* __restrict__ heta0,
+                                      double* lds) {
+    const int dd = d * d;
+    double* M0 = lds;          // L
+    double* M1 = M0 + dd;      // W = L^-1
+    double* M2 = M1 + dd;
+    double* M3 = M2 + dd;      // eta~
+    double* M4 = M3 + dd;
+    lds_load(w.chol + i * dd, M0, d);
+    lds_tri_inverse(M0, M1, d);
+    lds_load(heta0, M2, d);
+    lds_symmetrize(M2, M4, d);
+    lds_congruence(M1, M2, M3, M4, d);      // Heta~ = W Heta0 W^T
+    lds_symmetrize(M3, M4, d);
+    const double* gw = w.g_w + i * dd;
+    double* rw = w.r_w + i * dd;
+    double rr = 0.0;
+    for (int e = threadIdx.x; e < dd; e += 64) {
+        const double h = M3[e], r = gw[e] + h;
+        w.heta_w[i * dd + e] = h;
+        M0[e] = h;                          // (L is not needed any more)
+        rw[e] = r;
+        w.delta_w[i * dd + e] = -r;
+        rr = __builtin_fma(r, r, rr);
+    }
+    rr = wave_sum(rr);
+    __syncthreads();
+    lds_load(eta0, M2, d);
+    lds_symmetrize(M2, M4, d);
+    lds_congruence(M1, M2, M3, M4, d);      // eta~ = W eta0 W^T
+    lds_symmetrize(M3, M4, d);
+    double ee = 0.0, er = 0.0, eg = 0.0, eh = 0.0;
+    for (int e = threadIdx.x; e < dd; e += 64) {
+        const double a = M3[e];
+        w.eta_w[i * dd + e] = a;
+        ee = __builtin_fma(a, a, ee);
+        er = __builtin_fma(a, rw[e], er);
+        eg = __builtin_fma(a, gw[e], eg);
+        eh = __builtin_fma(a, M0[e], eh);
+    }
+    ee = wave_sum(ee);
+    er = wave_sum(er);
+    eg = wave_sum(eg);
+    eh = wave_sum(eh);
+    if (threadIdx.x == 0) {
+        double* sc = w.scal + i * SC_COUNT;
+        sc[SC_E_PE] = ee;
+        sc[SC_E_PD] = -er;
+        sc[SC_D_PD] = rr;
+        sc[SC_Z_R] = rr;
+        sc[SC_MODEL] = eg + 0.5 * eh;
+        sc[SC_NORM_R0] = __builtin_sqrt(rr > 0.0 ? rr : 0.0);
+    }
+}
+
 // FD point of get_hessianfd (approximate_hessian.py:30-47): c = 2^-14 / ||delta||_x, x1 = retr(x, c delta) = L expm(c delta~) L^T.
 // Restarts that are not running get x1 = x (their gradient is evaluated but not used).
 // x_fd: this restart's Mandel row (global or LDS).  lds: 4 d^2 + 2 doubles.
@@ -174,7 +237,7 @@ static __device__ void tcg_fd_point(const TcgWs& w, int64_t i, int d, double* __
         const double* dl = w.delta_w + i * dd;
         const double nrm = __builtin_sqrt(wave_dot(dl, dl, dd));
         tiny = nrm < 1e-15;
-        c = 0.0001220703125 / (tiny ? 1.0 : nrm);             // 2^-14
+        c = GABO_FD_EPS / (tiny ? 1.0 : nrm);
         for (int e = threadIdx.x; e < dd; e += 64) M1[e] = c * dl[e];
         __syncthreads();
         // E = expm(A), ||A||_F = 2^-14 by construction: I + A + A^2/2 + A^3/6 leaves ||A||^4/24 < 6e-19 (the eigen-decomposition
@@ -370,7 +433,9 @@ struct SpdPrecon {
     const double* chol;     // global
     const double* w1;       // row sums of L^-1
     int d;
+    bool off;               // use_rand: "and therefore, no preconditioner" (robust_trust_regions.py:411, 424-427): z = r
     __device__ bool zero_sum(const double* rn) const {
+        if (off) return false;
         lds_load(chol, Lbuf, d);
         return unwhitened_sum(Lbuf, rn, d) == 0.0;
     }
@@ -380,7 +445,7 @@ struct SpdPrecon {
 // egrad_fd: this restart's Euclidean gradient at the FD point (Mandel row, global or LDS).  lds: 5 d^2 doubles.
 // Returns true while the restart keeps running.  `iter` = index of this inner iteration (0-based).
 static __device__ bool tcg_step(const TcgWs& w, int64_t i, int64_t R, int d, int C, const double* __restrict__ egrad_fd, int neq,
-                                double delta_cons, double theta, double kappa, int mininner, int iter, double* lds) {
+                                double delta_cons, double theta, double kappa, int mininner, int iter, double* lds, bool no_precon = false) {
     const int dd = d * d;
     double* M0 = lds;
     double* M1 = M0 + dd;
@@ -411,7 +476,7 @@ static __device__ bool tcg_step(const TcgWs& w, int64_t i, int64_t R, int d, int
     __syncthreads();
     TcgVecs v{gw, w.eta_w + i * dd, w.heta_w + i * dd, w.r_w + i * dd, w.delta_w + i * dd, w.gc_w + i * dd, (int64_t)R * dd, sc,
               w.fc + i * C, w.fcg_pe + i * C, w.stop + i, w.running + i};
-    SpdPrecon pc{M0, w.chol + i * dd, w.w_ones + i * d, d};
+    SpdPrecon pc{M0, w.chol + i * dd, w.w_ones + i * d, d, no_precon};
     return tcg_step_core(v, dd, C, Hd, dl, M0, M1, M3, neq, delta_cons, theta, kappa, mininner, iter, pc);
 }
 

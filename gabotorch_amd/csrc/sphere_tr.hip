@@ -358,7 +358,7 @@ static __device__ void sph_propose_body(const double* __restrict__ x, const doub
         // FD point (approximate_hessian.py:30-47): c = 2^-14 / |delta|, x1 = retr(x, c delta)
         const double nrm = __builtin_sqrt(dotg(dl, dl, dim));
         const bool tiny = nrm < 1e-15;
-        const double c = 0.0001220703125 / (tiny ? 1.0 : nrm);
+        const double c = 6.103515625e-05 / (tiny ? 1.0 : nrm);      // 2^-14 (rounds 2-4 had 2^-13 here)
         double yy = 0.0;
         for (int e = threadIdx.x; e < dim; e += 64) { const double y = xs[e] + c * dl[e]; s0[e] = y; yy = __builtin_fma(y, y, yy); }
         const double inv = 1.0 / __builtin_sqrt(wave_sum(yy));
@@ -536,6 +536,11 @@ int gabo_sphere_acq_eval(const double* x, const gabo_sphere_acq_params* acq, dou
 size_t gabo_sphere_tr_workspace_bytes(int64_t r, int dim, int n_constraints) {
     if (r < 0 || dim < 1 || n_constraints < 0) return 0;
     return gabo::sph_layout(nullptr, r, dim, n_constraints).bytes;
+}
+
+size_t gabo_sphere_tr_stop_offset(int64_t r, int dim, int n_constraints) {
+    if (r < 0 || dim < 1 || n_constraints < 0) return 0;
+    return (size_t)((char*)gabo::sph_layout(nullptr, r, dim, n_constraints).stop - (char*)nullptr);
 }
 
 int gabo_sphere_tr_propose(const double* x, const double* grad, const double* trust_radius, const uint8_t* active,

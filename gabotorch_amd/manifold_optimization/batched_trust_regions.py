@@ -22,6 +22,11 @@ NEGATIVE_CURVATURE, EXCEEDED_TR, REACHED_TARGET_LINEAR, REACHED_TARGET_SUPERLINE
     REACHED_CONSTRAINTS = range(7)
 
 
+def self_lib():
+    from .. import _lib
+    return _lib.load()
+
+
 def _bm(mask, like):
     """broadcast a (R,) mask / scalar-per-restart tensor against (R, ...)"""
     return mask.reshape(mask.shape + (1,) * (like.dim() - mask.dim()))
@@ -256,7 +261,8 @@ class BatchedTrustRegions:
         # violates a constraint is rejected outright (cost = +inf) and the radius shrinks; everything else is identical.
         self.strict_constraints = strict_constraints
         # use_rand=True (robust_trust_regions.py:173-219, 407-452): tCG starts from a tiny random tangent vector instead of zero, runs
-        # without the preconditioner, and its result is compared with the Cauchy point.  Served by the generic lock-step path only.
+        # without the preconditioner, and its result is compared with the Cauchy point.  On S^d_++ with the fused acquisition the
+        # device-resident tCG launches take it (gabo_spd_tcg_begin_rand); everywhere else the generic lock-step path.
         self.use_rand = bool(use_rand)
         self.miniter, self.kappa, self.theta, self.rho_prime = miniter, kappa, theta, rho_prime
         self.rho_regularization = rho_regularization
@@ -404,7 +410,10 @@ class BatchedTrustRegions:
         neq = len(eqs)
         constrained = bool(eqs or ineqs)
 
-        if not self.use_rand and self._device_tcg_applies(problem, x, len(eqs) + len(ineqs)) and getattr(problem, "device_outer", True):
+        # use_rand: the SPD plan of device-resident tCG launches takes it (gabo_spd_tcg_begin_rand); the single-launch kernels and
+        # the sphere's do not - no reference caller sets it - and fall through to the generic lock-step code below
+        rand_ok = not self.use_rand or getattr(getattr(problem, "fused", None), "family", None) == "spd"
+        if rand_ok and self._device_tcg_applies(problem, x, len(eqs) + len(ineqs)) and getattr(problem, "device_outer", True):
             return self._solve_device(problem, x, eqs, ineqs, mininner, maxinner, Delta_bar, Delta0, Delta_cons)
         time0 = time.time()
         fx, g = problem.cost_grad(x)
@@ -496,21 +505,24 @@ class BatchedTrustRegions:
         dt, dev = x.dtype, x.device
         cons = eqs + ineqs
         ncons, neq = len(cons), len(eqs)
-        graphs = bool(getattr(problem, "use_hip_graphs", False))
         sphere = fused.family == "sphere"
+        # (the random start is drawn between the launches; a trace clones the state between them)
+        graphs = bool(getattr(problem, "use_hip_graphs", False)) and not self.use_rand and self.trace is None
         # Will the whole solve be ONE launch (decided below by the same tests)?  Then the tCG handle, the evaluation buffers and the
         # constraint buffers of the multi-launch plans are never touched: not creating them takes ~10 allocations and fill launches
         # (~0.1 ms of host time) off the front of a 4-ms sweep.
         one_launch = False
         builtins, lift = None, None
-        if getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True):
+        fused_iteration = getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True) and not self.use_rand
+        if fused_iteration:
             from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint, builtin_lift
             builtins = [builtin_constraint(c) for c in cons]
             solve_ok = (ncons == 0) if sphere else (d <= 8 and neq == 0 and all(b is not None for b in builtins)
                                                     and fused.metric != _lib_frobenius())
             lift = builtin_lift(builtins) if (solve_ok and not sphere) else None      # the nested kinds' mapping (one for all of them)
             solve_ok = solve_ok and lift is not False
-            one_launch = bool(solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000)
+            # (a requested trace is recorded between the launches of the multi-launch plans: iterate, radius, tCG stop reason)
+            one_launch = bool(solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000 and self.trace is None)
         T = None if (sphere or one_launch) else ops.SpdTcg(R, d, ncons, dev)
         val_buf = None if one_launch else torch.zeros(R, dtype=dt, device=dev)
         eg_buf = None if one_launch else torch.zeros(R, d * (d + 1) // 2, dtype=dt, device=dev)
@@ -548,12 +560,33 @@ class BatchedTrustRegions:
 
         def part_a(sync):
             T.begin(S.x, S.g, gc_buf, fc_buf, S.active, S.Delta)
+            if self.use_rand:                                             # (robust_trust_regions.py:176-181, 411-415: as _solve / _tcg_begin)
+                eta0 = 1e-6 * _randvec(man, S.x)
+                for _ in range(64):
+                    big = man.norm(S.x, eta0) > S.Delta
+                    if not bool(big.any()):
+                        break
+                    eta0 = torch.where(_bm(big, eta0), eta0 * float(eps) ** 0.25, eta0)
+                T.begin_rand(eta0, problem.hess(S.x, eta0, grad_x=S.g))
             for _ in range(int(maxinner)):
                 T.step(fused.egrad_mandel(T.fd_point(), active_ptr=T.running_ptr, out=(val_buf, eg_buf)), *step_args)
                 problem.n_grad += 1
                 if sync and not bool(T.any_running.item()):
                     break
             eta, Heta, stop_inner = T.end()
+            if self.use_rand:
+                # keep the better of the tCG step and the Cauchy point (:196-219), the statements of _solve
+                Hg = problem.hess(S.x, S.g, grad_x=S.g)
+                g_Hg = man.inner(S.x, S.g, Hg)
+                safe = torch.where(g_Hg > 0, g_Hg, torch.ones_like(g_Hg))
+                tau_c = torch.where(g_Hg <= 0, torch.ones_like(S.ng), torch.clamp(S.ng ** 3 / (S.Delta * safe), max=1.0))
+                scale = -tau_c * S.Delta / torch.where(S.ng > 0, S.ng, torch.ones_like(S.ng))
+                eta_c, Heta_c = _bm(scale, S.g) * S.g, _bm(scale, Hg) * Hg
+                mdle = S.fx + man.inner(S.x, S.g, eta) + 0.5 * man.inner(S.x, Heta, eta)
+                mdlec = S.fx + man.inner(S.x, S.g, eta_c) + 0.5 * man.inner(S.x, Heta_c, eta_c)
+                cauchy = mdlec < mdle
+                eta = torch.where(_bm(cauchy, eta), eta_c, eta)
+                Heta = torch.where(_bm(cauchy, Heta), Heta_c, Heta)
             x_prop = man.retr(S.x, eta)
             fx_prop, eg_prop = fused.cost_egrad(x_prop)
             problem.n_grad += 1
@@ -578,8 +611,11 @@ class BatchedTrustRegions:
                 boundary = boundary | (stop_inner == REACHED_CONSTRAINTS)
             grow = ~shrink & (rho > 0.75) & boundary
             newDelta = torch.where(shrink, S.Delta / 4, torch.where(grow, torch.clamp(2 * S.Delta, max=float(Delta_bar)), S.Delta))
-            S.Delta.copy_(torch.where(S.active, newDelta, S.Delta))
             accept = S.active & model_decreased & (rho > self.rho_prime)
+            if self.trace is not None:                                  # (the record of _solve, same keys)
+                self.trace.append({"x": S.x.clone(), "Delta": S.Delta.clone(), "eta": eta.clone(), "stop_inner": stop_inner.clone(),
+                                   "rho": rho.clone(), "accept": accept.clone(), "active": S.active.clone(), "fx": S.fx.clone()})
+            S.Delta.copy_(torch.where(S.active, newDelta, S.Delta))
             gnew = man.egrad2rgrad(x_prop, eg_prop)                 # the gradient at the proposal IS the gradient at the new x
             S.x.copy_(torch.where(_bm(accept, S.x), x_prop, S.x))
             S.fx.copy_(torch.where(accept, fx_prop, S.fx))
@@ -592,7 +628,7 @@ class BatchedTrustRegions:
 
         # d <= 12: the two parts are ONE launch each (csrc/spd_tr.hip: every wave runs its restart's whole tCG loop, proposal and
         # acquisition evaluations by itself)
-        if getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True):
+        if fused_iteration:
             if sphere:
                 TR = ops.SphereTr(R, d, ncons, fused.sphere_acq_params(), dev, exact_hessian=not problem.approx_hessian)
             else:
@@ -605,7 +641,14 @@ class BatchedTrustRegions:
                                 maxinner)
                 return {"x_prop": xp}
 
+            # (where the record below finds the stop reasons of the last tCG run; TcgWs: stop, then running)
+            stop_off = (self_lib().gabo_sphere_tr_stop_offset(R, d, ncons) // 4 if sphere
+                        else self_lib().gabo_spd_tcg_running_offset(R, d, ncons) // 4 - R)
+
             def part_b(A):          # noqa: F811
+                if self.trace is not None:
+                    self.trace.append({"x": S.x.clone(), "Delta": S.Delta.clone(), "active": S.active.clone(), "fx": S.fx.clone(),
+                                       "stop_inner": TR.ws.view(torch.int32)[stop_off:stop_off + R].clone().long()})
                 TR.update(S.x, S.fx, S.g, S.ng, S.Delta, S.active_u8, S.iters, inv_u8 if strict else None, Delta_bar, self.rho_prime,
                           self.rho_regularization, self.mingradnorm, self.maxiter)
                 S.any_active.copy_(TR.any_active[0] != 0)
@@ -840,7 +883,7 @@ class BatchedTrustRegions:
         S.running.copy_(running)
         S.any_running.copy_(running.any())
 
-    def _tcg_device(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons):
+    def _tcg_device(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons, eta0=None):
         """The tCG loop on the device-resident state machine (csrc/spd_tcg.hip): per inner iteration one FD-point launch, the
         fused acquisition-gradient chain and one step launch; with hipGraphs the three are one replay."""
         from .. import ops
@@ -859,7 +902,13 @@ class BatchedTrustRegions:
         def one_step():
             T.step(fused.egrad_mandel(T.fd_point()), *args)
 
-        T.begin(x, g, torch.stack(gc) if ncons else None, fc, active, Delta)
+        def begin():
+            T.begin(x, g, torch.stack(gc) if ncons else None, fc, active, Delta)
+            if eta0 is not None:                                    # use_rand (robust_trust_regions.py:411-415)
+                T.begin_rand(eta0, heta0)
+
+        heta0 = None if eta0 is None else problem.hess(x, eta0, grad_x=g)
+        begin()
         graphs = bool(getattr(problem, "use_hip_graphs", False))
         if graphs and ent["graph"] is None:
             side = torch.cuda.Stream(device=x.device)
@@ -871,7 +920,7 @@ class BatchedTrustRegions:
             with torch.cuda.graph(graph):
                 one_step()
             ent["graph"] = graph
-            T.begin(x, g, torch.stack(gc) if ncons else None, fc, active, Delta)      # the warm-up and capture advanced the state
+            begin()                                                 # the warm-up and capture advanced the state
         for _ in range(int(maxinner)):
             if graphs:
                 ent["graph"].replay()
@@ -884,8 +933,8 @@ class BatchedTrustRegions:
 
     def _tcg(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons, eta0=None):
         ncons = 0 if fc is None else fc.shape[1]
-        if eta0 is None and self._device_tcg_applies(problem, x, ncons):
-            return self._tcg_device(problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons)
+        if (eta0 is None or getattr(getattr(problem, "fused", None), "family", None) == "spd") and self._device_tcg_applies(problem, x, ncons):
+            return self._tcg_device(problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons, eta0=eta0)
         graphs = bool(getattr(problem, "use_hip_graphs", False)) and x.is_cuda and eta0 is None
         key = (tuple(x.shape), x.device, ncons, neq, float(Delta_cons), int(mininner))
         cache = problem.__dict__.setdefault("_tcg_cache", {})

@@ -1408,6 +1408,14 @@ class SpdTcg:
                                                    self.ws.data_ptr(), self.wsb, self.r, self.d, self.c, self.status.data_ptr(),
                                                    _stream_ptr(self.dev)), "gabo_spd_tcg_begin")
 
+    def begin_rand(self, eta0, heta0):
+        """use_rand (robust_trust_regions.py:173-181, 407-452), after begin(): start from eta0 with heta0 = hess(x, eta0), no preconditioner."""
+        self._keep_rand = (eta0.contiguous(), heta0.contiguous())
+        _require(self.dev, eta0=self._keep_rand[0], heta0=self._keep_rand[1])
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gabo_spd_tcg_begin_rand(self.ws.data_ptr(), self._keep_rand[0].data_ptr(), self._keep_rand[1].data_ptr(),
+                                                        self.r, self.d, self.c, _stream_ptr(self.dev)), "gabo_spd_tcg_begin_rand")
+
     def fd_point(self):
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.gabo_spd_tcg_fd_point(self.ws.data_ptr(), self.x_fd.data_ptr(), self.r, self.d, self.c,

@@ -405,6 +405,10 @@ int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const
  *   begin:    x, grad (Riemannian gradient at x): r x d x d; cons_grads: n_constraints x r x d x d Riemannian gradients of the
  *             constraints (equalities first), cons_values: r x n_constraints; active: r bytes (0 = restart already converged);
  *             trust_radius: r.  Non-SPD x is reported through `status` like the other entry points.
+ *   begin_rand (optional, after begin): `use_rand=True` of the reference (robust_trust_regions.py:173-181, 407-452) - the iteration starts
+ *             from the caller's tiny random tangent vectors eta0 (r x d x d) with heta0 = hess(x, eta0) instead of zero, and the steps
+ *             that follow run without the preconditioner (":411 and therefore, no preconditioner").  The comparison with the Cauchy
+ *             point after `end` (:196-219) is the caller's.
  *   fd_point: writes the points x1 = retr(x, 2^-14 delta / ||delta||_x) as Mandel vectors (r x d_vec).
  *   step:     consumes the Euclidean gradient at those points (Mandel, r x d_vec) and advances every running restart;
  *             *any_running (device int) = 1 while at least one restart continues.  `mininner`: no residual test before.
@@ -417,6 +421,8 @@ size_t gabo_spd_tcg_running_offset(int64_t r, int d, int n_constraints);
 int gabo_spd_tcg_begin(const double* x, const double* grad, const double* cons_grads, const double* cons_values,
                        const uint8_t* active, const double* trust_radius, void* workspace, size_t workspace_bytes, int64_t r, int d,
                        int n_constraints, int* status, gabo_stream_t stream);
+int gabo_spd_tcg_begin_rand(void* workspace, const double* eta0, const double* heta0, int64_t r, int d, int n_constraints,
+                            gabo_stream_t stream);
 int gabo_spd_tcg_fd_point(void* workspace, double* x_fd_mandel, int64_t r, int d, int n_constraints, gabo_stream_t stream);
 int gabo_spd_tcg_step(void* workspace, const double* egrad_fd_mandel, int* any_running, int64_t r, int d, int n_constraints,
                       int n_equalities, double delta_cons, double theta, double kappa, int mininner, gabo_stream_t stream);
@@ -534,6 +540,9 @@ typedef struct {
 int gabo_sphere_acq_eval(const double* x, const gabo_sphere_acq_params* acq, double* value, double* grad, int64_t r,
                          gabo_stream_t stream);
 size_t gabo_sphere_tr_workspace_bytes(int64_t r, int dim, int n_constraints);
+/* byte offset, inside the workspace, of the r ints "stop reason of the last truncated-CG run" (codes as gabo_spd_tcg_end): what a
+ * per-iteration record of the solver reads between gabo_sphere_tr_propose and gabo_sphere_tr_update (robust_trust_regions.py:190 `srstr`) */
+size_t gabo_sphere_tr_stop_offset(int64_t r, int dim, int n_constraints);
 int gabo_sphere_tr_propose(const double* x, const double* grad, const double* trust_radius, const uint8_t* active,
                            const double* cons_grads, const double* cons_values, const gabo_sphere_acq_params* acq, void* workspace,
                            size_t workspace_bytes, double* x_prop, int64_t r, int n_constraints, int n_equalities, double delta_cons,

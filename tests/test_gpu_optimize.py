@@ -286,6 +286,88 @@ def test_device_tcg_matches_torch_tcg():
     np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("constraint", [True, False])
+def test_use_rand_on_the_device_tcg_plan_follows_the_torch_path(constraint):
+    """use_rand=True (robust_trust_regions.py:173-219, 407-452): random tCG start (torch's generator, the same draws on both sides),
+    no preconditioner, comparison with the Cauchy point.  The plan of device-resident tCG launches (gabo_spd_tcg_begin_rand + the steps
+    without the preconditioner) against the generic torch lock-step statement of the same solver: same trajectory restart for restart."""
+    from tools.sweep_bench import run_sweep
+    from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions
+    kw = dict(num_restarts=40, raw_samples=256, use_rand=True, constraint=constraint)
+    taken = []
+    real = BatchedTrustRegions._solve_device
+
+    def spy(self, *a, **k):
+        taken.append(self.use_rand)
+        return real(self, *a, **k)
+    _, best_t, val_t, log_t = run_sweep(DEV, device_tcg=False, **kw)
+    BatchedTrustRegions._solve_device = spy
+    try:
+        _, best_d, val_d, log_d = run_sweep(DEV, **kw)
+    finally:
+        BatchedTrustRegions._solve_device = real
+    assert taken == [True]                                   # (the device plan ran, with use_rand)
+    assert "one_launch_solve" not in log_d
+    np.testing.assert_array_equal(log_d["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
+    np.testing.assert_allclose(val_d, val_t, rtol=1e-9)
+    np.testing.assert_allclose(best_d.cpu().numpy(), best_t.cpu().numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-6, atol=1e-9)
+    # and the random start changes nothing about where the sweep ends (the plain solver, same seeds)
+    _, _, val_p, log_p = run_sweep(DEV, num_restarts=40, raw_samples=256, constraint=constraint)
+    np.testing.assert_allclose(val_d, val_p, rtol=1e-6)
+    # The reference's start is 1e-6 of a unit vector - a device plan that ignored it would pass the comparison above.  With the draw
+    # amplified to 0.05 on both sides the start decides the first steps.  (a) one tCG call, same inputs: the device launches against
+    # the generic torch statement - step, Hessian applied to it, stop reason; (b) whole sweeps: the plans end where the generic one does.
+    from gabotorch_amd.manifold_optimization import batched_trust_regions as btr
+    real_rv, real_tcg = btr._randvec, BatchedTrustRegions._tcg
+    seen = {}
+
+    def spy_tcg(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons, eta0=None):
+        if not seen:
+            seen.update(solver=self, problem=problem, eta0=eta0,
+                        args=(x.clone(), g.clone(), Delta.clone(), active.clone(), mininner, maxinner, None if fc is None else fc.clone(),
+                              [c.clone() for c in gc], neq, Delta_cons))
+        return real_tcg(self, problem, x, g, Delta, active, mininner, maxinner, fc, gc, neq, Delta_cons, eta0=eta0)
+    btr._randvec = lambda man, x: 5e4 * real_rv(man, x)
+    BatchedTrustRegions._tcg = spy_tcg
+    try:
+        _, _, val_i5, log_i5 = run_sweep(DEV, device_outer=False, **kw)          # generic outer loop around the device tCG
+        BatchedTrustRegions._tcg = real_tcg
+        _, _, val_t5, log_t5 = run_sweep(DEV, device_tcg=False, **kw)
+        _, _, val_d5, log_d5 = run_sweep(DEV, **kw)
+    finally:
+        btr._randvec, BatchedTrustRegions._tcg = real_rv, real_tcg
+    prob, eta0 = seen["problem"], seen["eta0"]
+    assert eta0 is not None and 0.04 < float(prob.manifold.norm(seen["args"][0], eta0).max()) < 0.06
+    out = {}
+    for name, flag in (("torch", False), ("device", True)):
+        prob.device_tcg = flag
+        out[name] = real_tcg(seen["solver"], prob, *seen["args"], eta0=eta0.clone())
+    (eta_t, heta_t, stop_t), (eta_d, heta_d, stop_d) = out["torch"], out["device"]
+    np.testing.assert_array_equal(stop_d.cpu().numpy(), stop_t.cpu().numpy())
+    # (finite differences of the gradient at c = 2^-14 / |delta| amplify the rounding difference of the two evaluation orders by 1 / c:
+    # 2e-10 / 4e-10 measured.  This comparison is what found the 2^-13 the device kernels had carried as their step since round 2 -
+    # 1e-4 of H delta, invisible in optima and iteration counts)
+    def rel_err(a_d, a_t):
+        return ((a_d - a_t).flatten(1).abs().amax(1) / a_t.flatten(1).abs().amax(1).clamp(min=1e-300)).cpu().numpy()
+    for a_d, a_t in ((eta_d, eta_t), (heta_d, heta_t)):
+        assert rel_err(a_d, a_t).max() < 2e-8, rel_err(a_d, a_t).max()
+    assert float((eta_t - eta0).abs().max()) > 1e-3                         # (tCG moved away from its start)
+    prob.device_tcg = False
+    plain = real_tcg(seen["solver"], prob, *seen["args"], eta0=None)
+    assert float((plain[0] - eta_t).abs().max()) > 1e-3                     # (and the start matters at this size)
+    prob.device_tcg = True
+    plain_d = real_tcg(seen["solver"], prob, *seen["args"], eta0=None)      # the same for the zero start: step and H step of the device tCG
+    np.testing.assert_array_equal(plain_d[2].cpu().numpy(), plain[2].cpu().numpy())
+    assert rel_err(plain_d[0], plain[0]).max() < 2e-8 and rel_err(plain_d[1], plain[1]).max() < 2e-8
+    it_t5 = log_t5["per_restart_iterations"].cpu().numpy()
+    for log5, val5 in ((log_d5, val_d5), (log_i5, val_i5)):
+        # (iteration counts: a restart whose gradient norm passes 1e-4 within rounding of an iteration boundary may stop one later)
+        it5 = log5["per_restart_iterations"].cpu().numpy()
+        assert np.abs(it5 - it_t5).max() <= 1 and (it5 == it_t5).mean() >= 0.9
+        np.testing.assert_allclose(val5, val_t5, rtol=1e-8)
+
+
 @pytest.mark.parametrize("strict", [False, True])
 def test_device_solve_graph_plans_match_torch_path(strict):
     """Every execution plan of the device-resident solve (eager; graphs with the constraint callables between replays; graphs
