@@ -39,6 +39,18 @@ int propose_affine_invariant(const ProposeArgs& a) { return a.d <= 8 ? dispatch_
 
 }  // namespace gabo
 
+namespace gabo {
+// gabo_tr_solve_record: one pending buffer per process, consumed by the next single-launch solve (a parity / debugging facility, not thread-safe)
+static double* g_tr_record = nullptr;
+static int64_t g_tr_record_cap = 0;
+void tr_record_take(double** buffer, int64_t* capacity) {
+    *buffer = g_tr_record;
+    *capacity = g_tr_record_cap;
+    g_tr_record = nullptr;
+    g_tr_record_cap = 0;
+}
+}  // namespace gabo
+
 extern "C" {
 
 size_t gabo_spd_tr_workspace_bytes(int64_t r, int d, int n_constraints, int64_t n_train) {
@@ -91,6 +103,13 @@ int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, d
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
+int gabo_tr_solve_record(double* buffer, int64_t max_iterations) {
+    if (max_iterations < 0 || (max_iterations > 0 && !buffer)) return GABO_ERR_ARG;
+    gabo::g_tr_record = max_iterations > 0 ? buffer : nullptr;
+    gabo::g_tr_record_cap = max_iterations;
+    return GABO_OK;
+}
+
 int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
                       const gabo_spd_acq_params* acq, int n_constraints, const int* constraint_kind, const double* constraint_bound,
                       int strict, void* workspace, size_t workspace_bytes, int64_t r, int d, double delta_cons, double theta, double kappa,
@@ -129,6 +148,7 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
     // test hook: GABO_TR_NO_SHORTCUTS in the environment runs every iteration in full (no value-first evaluation after a rejection, no reuse of
     // an identical step's proposal): the two forms must agree bit for bit (tests/test_gpu_native_sweep.py)
     a.shortcuts = getenv("GABO_TR_NO_SHORTCUTS") ? 0 : 1;
+    gabo::tr_record_take(&a.rec, &a.rec_cap);
     switch (acq->flags & GABO_METRIC_MASK) {
         case GABO_METRIC_AFFINE_INVARIANT: return gabo::solve_affine_invariant(a);
         case GABO_METRIC_LOG_EUCLIDEAN: return gabo::solve_log_euclidean(a);

@@ -453,7 +453,8 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
                                                           BuiltinCons B, void* wsbase, int64_t R, double delta_cons, double theta,
                                                           double kappa, int mininner, int maxinner, double delta_bar, double rho_prime,
                                                           double rho_regularization, double mingradnorm, int64_t maxiter,
-                                                          int* __restrict__ status, int stage_gp, int ws_lds, int nested_off, int shortcuts) {
+                                                          int* __restrict__ status, int stage_gp, int ws_lds, int nested_off, int shortcuts,
+                                                          double* __restrict__ rec, int64_t rec_cap) {
     static_assert(D <= 8, "built-in constraints use the register eigen-solver");
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
 #else
     double* const step_cache = nullptr;
 #endif
+    int64_t rec_k = rec != nullptr ? iters[i] : 0;      // gabo_tr_solve_record: index of the outer iteration being recorded
     for (;;) {
         // Value first after a rejection.  The restarts that set this launch's duration are the ones whose proposals are rejected again and again
         // (config 4: 4 of 512 restarts sit on the eigenvalue bound and have 99 of their 100 proposals rejected, the radius ending at 2.4e-60, while
@@ -524,6 +526,15 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
         last_inner = tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, iw, Rw, C, 0, delta_cons, theta,
                                                 kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1, nlds, lazy, step_cache);
         __syncthreads();
+        if (rec != nullptr && rec_k < rec_cap) {          // (the iterate, its radius and the stop reason of the tCG run that made the proposal)
+            double* rr = rec + (rec_k * R + i) * (dd + 2);
+            for (int e = threadIdx.x; e < dd; e += 64) rr[e] = x[i * dd + e];
+            if (threadIdx.x == 0) {
+                rr[dd] = delta_tr[i];
+                rr[dd + 1] = (double)t.tcg.stop[iw];
+            }
+        }
+        ++rec_k;
         const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B, nlds) : false;
         if (lazy && tr_would_accept(fx[i], t.fx_prop[iw], t.rhoden[iw], inval, rho_prime, rho_regularization)) {
             acq_eval_any<D, METRIC>(t.xp_mandel + iw * T_, Ps, t.fx_prop + iw, t.eg_prop + iw * T_, t.F + iw * T_ * Ps.n, acq, dyn, status,
@@ -600,6 +611,8 @@ struct SolveArgs {
     int64_t maxiter;
     int* status;
     hipStream_t st;
+    double* rec = nullptr;  // gabo_tr_solve_record: per-iteration record of this call, or null
+    int64_t rec_cap = 0;
     int shortcuts = 1;      // 0: every iteration computes its proposal and the full evaluation (the environment variable GABO_TR_NO_SHORTCUTS: tests)
 };
 
@@ -617,7 +630,7 @@ static int dispatch_solve(const SolveArgs& a) {
 #define GABO_SOLVE_LAUNCH(DD, LAT_)                                                                                                \
     hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC, LAT_>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
                        a.active, a.iters, *a.P, a.B, a.ws, a.r, a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.delta_bar, \
-                       a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds, nested_off, a.shortcuts)
+                       a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds, nested_off, a.shortcuts, a.rec, a.rec_cap)
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
         if constexpr (DD >= DMIN && DD <= DMAX) {                                                                                  \
@@ -635,6 +648,9 @@ static int dispatch_solve(const SolveArgs& a) {
 #undef GABO_SOLVE_LAUNCH
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
+
+// gabo_tr_solve_record (spd_tr.hip): hands the pending record buffer to the solve that is being launched and clears it
+void tr_record_take(double** buffer, int64_t* capacity);
 
 // defined in spd_tr.hip / spd_tr_le.hip / spd_tr_frob.hip / spd_tr_solve.hip / spd_tr_solve_le.hip
 int solve_affine_invariant(const SolveArgs& a);

@@ -488,16 +488,27 @@ __global__ __launch_bounds__(64) void sphere_tr_solve_kernel(double* __restrict_
                                                              uint8_t* __restrict__ active, int64_t* __restrict__ iters, SphAcq P,
                                                              void* wsbase, int64_t R, double theta, double kappa, int mininner,
                                                              int maxinner, double delta_bar, double rho_prime, double rho_regularization,
-                                                             double mingradnorm, int64_t maxiter, int exact_hessian) {
+                                                             double mingradnorm, int64_t maxiter, int exact_hessian,
+                                                             double* __restrict__ rec, int64_t rec_cap) {
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
     if (active[i] == 0) return;
     SphWs w = sph_layout(wsbase, R, P.dim, 0);
     bool x_unchanged = false;         // wave-uniform: the previous proposal of this launch was rejected
+    int64_t rec_k = rec != nullptr ? iters[i] : 0;      // gabo_tr_solve_record: index of the outer iteration being recorded
     for (;;) {
         sph_propose_body(x + i * P.dim, g + i * P.dim, delta_tr[i], nullptr, nullptr, P, w, i, R, 0, 0, 1e-6, theta, kappa, mininner,
                          maxinner, dyn + 7 * P.n, dyn, exact_hessian, x_unchanged);
         __syncthreads();
+        if (rec != nullptr && rec_k < rec_cap) {          // (the iterate, its radius and the stop reason of the tCG run that made the proposal)
+            double* rr = rec + (rec_k * R + i) * (P.dim + 2);
+            for (int e = threadIdx.x; e < P.dim; e += 64) rr[e] = x[i * P.dim + e];
+            if (threadIdx.x == 0) {
+                rr[P.dim] = delta_tr[i];
+                rr[P.dim + 1] = (double)w.stop[i];
+            }
+        }
+        ++rec_k;
         bool accepted = false;
         const bool still = sph_update_body(x + i * P.dim, fx + i, g + i * P.dim, ng + i, delta_tr + i, iters + i, false, w, i, P.dim, 0,
                                            delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter, &accepted);
@@ -506,6 +517,8 @@ __global__ __launch_bounds__(64) void sphere_tr_solve_kernel(double* __restrict_
     }
     if (threadIdx.x == 0) active[i] = 0;
 }
+
+void tr_record_take(double** buffer, int64_t* capacity);      // spd_tr.hip
 
 static int sph_acq_ok(const SphAcq* a) {
     if (!a || a->n < 1 || a->n > 4096 || a->dim < 2 || a->dim > 512 || !a->train || !a->train_t || !a->alpha) return GABO_ERR_ARG;
@@ -589,9 +602,12 @@ int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm,
     if (!x || !fx || !grad || !grad_norm || !trust_radius || !active || !iters || !workspace) return GABO_ERR_ARG;
     if (workspace_bytes < gabo_sphere_tr_workspace_bytes(r, acq->dim, 0)) return GABO_ERR_ARG;
     size_t lds = (size_t)(7 * acq->n + 6 * acq->dim) * sizeof(double);
+    double* rec = nullptr;
+    int64_t rec_cap = 0;
+    gabo::tr_record_take(&rec, &rec_cap);                 // gabo_tr_solve_record (spd_tr.hip)
     hipLaunchKernelGGL(gabo::sphere_tr_solve_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, fx, grad, grad_norm,
                        trust_radius, active, iters, *acq, workspace, r, theta, kappa, mininner, maxinner, delta_bar, rho_prime,
-                       rho_regularization, mingradnorm, maxiter, exact_hessian);
+                       rho_regularization, mingradnorm, maxiter, exact_hessian, rec, rec_cap);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

@@ -521,8 +521,7 @@ class BatchedTrustRegions:
                                                     and fused.metric != _lib_frobenius())
             lift = builtin_lift(builtins) if (solve_ok and not sphere) else None      # the nested kinds' mapping (one for all of them)
             solve_ok = solve_ok and lift is not False
-            # (a requested trace is recorded between the launches of the multi-launch plans: iterate, radius, tCG stop reason)
-            one_launch = bool(solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000 and self.trace is None)
+            one_launch = bool(solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000)
         T = None if (sphere or one_launch) else ops.SpdTcg(R, d, ncons, dev)
         val_buf = None if one_launch else torch.zeros(R, dtype=dt, device=dev)
         eg_buf = None if one_launch else torch.zeros(R, d * (d + 1) // 2, dtype=dt, device=dev)
@@ -657,12 +656,22 @@ class BatchedTrustRegions:
             # examples): the whole solve is ONE launch, every wave iterating its restart to the end
             if one_launch:
                 extra = {} if sphere else {"lift": lift}
+                if self.trace is not None:
+                    # the launch writes its own record (gabo_tr_solve_record): iterate, radius, tCG stop reason per outer iteration
+                    L = d if sphere else d * d
+                    extra["record"] = torch.full((int(min(self.maxiter, 1 << 14)), R, L + 2), float("nan"), dtype=dt, device=dev)
                 TR.solve(S.x, S.fx, S.g, S.ng, S.Delta, S.active_u8, S.iters, [b[0] for b in builtins], [b[1] for b in builtins], strict,
                           Delta_cons, self.theta, self.kappa, mininner, maxinner, Delta_bar, self.rho_prime, self.rho_regularization,
                           self.mingradnorm, self.maxiter, **extra)
                 if hasattr(TR, "status"):
                     ops._raise_if_not_spd(TR.status, "gabo_spd_tr_solve")       # (when error checking is on: one read-back per solve)
                 k = int(S.iters.max().item())
+                if self.trace is not None:
+                    rec = extra["record"]
+                    for kk in range(min(k, rec.shape[0])):
+                        ran = ~torch.isnan(rec[kk, :, L])
+                        self.trace.append({"x": rec[kk, :, :L].reshape(x.shape).clone(), "Delta": rec[kk, :, L].clone(), "active": ran,
+                                           "stop_inner": torch.where(ran, rec[kk, :, L + 1], torch.full_like(rec[kk, :, L], -1.0)).long()})
                 ops.check_deferred()
                 self.log = {"iterations": k, "per_restart_iterations": S.iters, "final_cost": S.fx, "final_gradnorm": S.ng,
                             "cost_evals": problem.n_cost, "grad_evals": problem.n_grad, "time": time.time() - time0, "one_launch_solve": True}

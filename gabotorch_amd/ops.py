@@ -1466,10 +1466,11 @@ class SpdTr:
         return self.x_prop
 
     def solve(self, x, fx, g, ng, Delta, active, iters, kinds, bounds, strict, delta_cons, theta, kappa, mininner, maxinner, delta_bar,
-              rho_prime, rho_regularization, mingradnorm, maxiter, lift=None):
+              rho_prime, rho_regularization, mingradnorm, maxiter, lift=None, record=None):
         """The whole solve in one launch (built-in eigenvalue constraints `kinds`/`bounds`, or none).  lift: the (w, x0, p) of
-        nested_spd_lift_prepare when some kinds are the nested ones (bounds stated in the original space of a nested SPD mapping)."""
-        _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters)
+        nested_spd_lift_prepare when some kinds are the nested ones (bounds stated in the original space of a nested SPD mapping).
+        record: (K, r, d*d + 2) tensor pre-filled with NaN -> per-iteration record of the launch (gabo_tr_solve_record)."""
+        _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters, record=record)
         import ctypes
         nc = len(kinds)
         ck = (ctypes.c_int * max(nc, 1))(*kinds)
@@ -1482,6 +1483,9 @@ class SpdTr:
         else:
             lift_args = (None, None, None, 0)
         with torch.cuda.device(self.dev):
+            if record is not None:
+                assert tuple(record.shape[1:]) == (self.r, self.d * self.d + 2)
+                _lib.check(self.lib.gabo_tr_solve_record(record.data_ptr(), int(record.shape[0])), "gabo_tr_solve_record")
             _lib.check(self.lib.gabo_spd_tr_solve(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
                                                   active.data_ptr(), iters.data_ptr(), self.acq_ref, nc, ck, cb, 1 if strict else 0,
                                                   self.ws.data_ptr(), self.wsb, self.r, self.d, float(delta_cons), float(theta),
@@ -1550,10 +1554,13 @@ class SphereTr:
                                                       self.any_active.data_ptr(), _stream_ptr(self.dev)), "gabo_sphere_tr_update")
 
     def solve(self, x, fx, g, ng, Delta, active, iters, kinds, bounds, strict, delta_cons, theta, kappa, mininner, maxinner, delta_bar,
-              rho_prime, rho_regularization, mingradnorm, maxiter):
-        _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters)
+              rho_prime, rho_regularization, mingradnorm, maxiter, record=None):
+        _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters, record=record)
         assert not kinds, "the sphere has no built-in constraints"
         with torch.cuda.device(self.dev):
+            if record is not None:                     # (K, r, dim + 2), pre-filled with NaN: gabo_tr_solve_record
+                assert tuple(record.shape[1:]) == (self.r, self.d + 2)
+                _lib.check(self.lib.gabo_tr_solve_record(record.data_ptr(), int(record.shape[0])), "gabo_tr_solve_record")
             _lib.check(self.lib.gabo_sphere_tr_solve(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
                                                      active.data_ptr(), iters.data_ptr(), self.acq_ref, self.ws.data_ptr(), self.wsb, self.r,
                                                      float(theta), float(kappa), int(mininner), int(maxinner), self.exact, float(delta_bar),

@@ -543,6 +543,13 @@ size_t gabo_sphere_tr_workspace_bytes(int64_t r, int dim, int n_constraints);
 /* byte offset, inside the workspace, of the r ints "stop reason of the last truncated-CG run" (codes as gabo_spd_tcg_end): what a
  * per-iteration record of the solver reads between gabo_sphere_tr_propose and gabo_sphere_tr_update (robust_trust_regions.py:190 `srstr`) */
 size_t gabo_sphere_tr_stop_offset(int64_t r, int dim, int n_constraints);
+/* Per-iteration record of the single-launch solves - what the reference's solvers keep in their optlog (robust_trust_regions.py:300-340:
+ * iterate, radius, `srstr`) and tests/golden/tr_traces.npz holds for them.  The NEXT call of gabo_spd_tr_solve or gabo_sphere_tr_solve of
+ * this process (one pending buffer; not thread-safe: a parity / debugging facility) writes, for outer iteration k < max_iterations of restart
+ * i, buffer[(k * r + i) * (L + 2) + ...] = the iterate (L = d * d doubles, or dim for the sphere), the trust radius and the stop reason of the
+ * truncated-CG run that made the proposal judged in that iteration.  buffer: device memory of max_iterations * r * (L + 2) doubles that the
+ * caller pre-fills (NaN: iterations a restart did not run stay NaN).  max_iterations = 0 withdraws a pending buffer. */
+int gabo_tr_solve_record(double* buffer, int64_t max_iterations);
 int gabo_sphere_tr_propose(const double* x, const double* grad, const double* trust_radius, const uint8_t* active,
                            const double* cons_grads, const double* cons_values, const gabo_sphere_acq_params* acq, void* workspace,
                            size_t workspace_bytes, double* x_prop, int64_t r, int n_constraints, int n_equalities, double delta_cons,

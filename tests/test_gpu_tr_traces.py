@@ -152,16 +152,17 @@ def test_device_resident_plans_reach_the_reference_fp64_optima(golden, name):
         ops.set_error_checking(True)
 
 
-@pytest.mark.parametrize("plan", ["tcg_launches", "propose_update_launches"])
+@pytest.mark.parametrize("plan", ["tcg_launches", "propose_update_launches", "single_launch_solve"])
 @pytest.mark.parametrize("name,run", [("spd3", "tr_fd"), ("spd5", "tr_fd"), ("spd2", "tr_fd"), ("spd3", "con"), ("spd5c", "con"),
                                       ("spd3", "strict"), ("spd5c", "strict")])
 def test_device_plans_follow_the_reference_trace(golden, name, run, plan):
     """The device-resident plans - the tCG launches (gabo_spd_tcg_begin / _fd_point / _step / _end around the fused acquisition evaluation)
     and the two launches per iteration (gabo_spd_tr_propose / _update: whitened coordinates, another eigen-solver, another summation order
     than the reference's numpy) - walked against the REFERENCE solver's own fp64 record iteration by iteration: radius (exact), tCG stop
-    reason, iterate within 1e-6, like the generic path above.  (The single-launch solve runs the propose / update bodies in one kernel and
-    keeps no record; tests/test_gpu_optimize.py ties it to these plans.)  Round 5: the kernels' finite-difference step had been 2^-13
-    instead of approximate_hessian.py:40's 2^-14 - 1e-4 of H delta, enough to reach the same optima by other iterates."""
+    reason, iterate within 1e-6, like the generic path above - and the single-launch solve (gabo_spd_tr_solve with the eigenvalue bound
+    built by functools.partial as in examples/gabo_spd.py:136-138, evaluated inside the kernel), which writes its own record
+    (gabo_tr_solve_record).  Round 5: the kernels' finite-difference step had been 2^-13 instead of approximate_hessian.py:40's 2^-14 -
+    1e-4 of H delta, enough to reach the same optima by other iterates."""
     g = golden("tr_traces.npz")
     d = int(name.rstrip("c")[3:])
     Y = ospd.symmetric_matrix_to_vector_mandel(g[f"{name}_Y"])
@@ -180,14 +181,17 @@ def test_device_plans_follow_the_reference_trace(golden, name, run, plan):
     else:
         solver = (ConstrainedTrustRegions if constrained else TrustRegions)(mingradnorm=1e-4, maxiter=100)
     solver.trace = []
-    cons = [lambda m: scut.max_eigenvalue_constraint_torch(m, mx)] if constrained else None
+    if plan == "single_launch_solve":
+        cons = [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=mx)] if constrained else None
+    else:
+        cons = [lambda m: scut.max_eigenvalue_constraint_torch(m, mx)] if constrained else None
+    options = {"tcg_launches": {"device_iteration": False}, "propose_update_launches": {"device_solve": False}, "single_launch_solve": {}}[plan]
     ops.set_error_checking(False)
     try:
-        gen_candidates_manifold(x0, acq, man, solver, pre, post, inequality_constraints=cons, approx_hessian=True,
-                                options={"device_iteration": plan != "tcg_launches"})
+        gen_candidates_manifold(x0, acq, man, solver, pre, post, inequality_constraints=cons, approx_hessian=True, options=options)
     finally:
         ops.set_error_checking(True)
-    assert solver.trace and "one_launch_solve" not in solver.log
+    assert solver.trace and ("one_launch_solve" in solver.log) == (plan == "single_launch_solve")
     assert ("eta" in solver.trace[0]) == (plan == "tcg_launches")                      # (which plan recorded it)
     ok = g[f"{name}_{run}_f64_ok"]
     res = compare_with_reference_trace(solver.trace, g, f"{name}_{run}_f64", atol_x=1e-6)
@@ -202,9 +206,13 @@ def test_device_plans_follow_the_reference_trace(golden, name, run, plan):
                                          ("sph5", "con", {"mingradnorm": 1e-6, "maxiter": 100}),
                                          ("sph3", "strict", {"mingradnorm": 1e-6, "maxiter": 100}),
                                          ("sph5", "strict", {"mingradnorm": 1e-6, "maxiter": 100})])
-def test_sphere_device_plan_follows_the_reference_trace(golden, name, run, kw):
+@pytest.mark.parametrize("plan", ["propose_update_launches", "single_launch_solve"])
+def test_sphere_device_plan_follows_the_reference_trace(golden, name, run, kw, plan):
     """The same for the sphere: gabo_sphere_tr_propose / _update (closed-form exact Hessian-vector products or the finite-difference ones,
-    the constraint callable evaluated between the launches) against the reference solvers' fp64 record."""
+    the constraint callable evaluated between the launches) and the single-launch gabo_sphere_tr_solve (unconstrained runs; its own
+    record, gabo_tr_solve_record) against the reference solvers' fp64 record."""
+    if plan == "single_launch_solve" and run in ("con", "strict"):
+        pytest.skip("the sphere has no built-in constraints: constrained sweeps run the propose / update launches")
     from gabotorch_amd.kernel_utils.kernels_sphere import SphereGaussianKernel
     g = golden("tr_traces.npz")
     if f"{name}_{run}_f64_xs" not in g:
@@ -221,10 +229,11 @@ def test_sphere_device_plan_follows_the_reference_trace(golden, name, run, kw):
     solver.trace = []
     x0 = t(g[f"{name}_con_x0"] if constrained else g[f"{name}_x0"])[:, None]
     cons = [lambda p: p[..., 0] - 0.3] if constrained else None
-    gen_candidates_manifold(x0, acq, manifolds.Sphere(n), solver, inequality_constraints=cons, approx_hessian=(run == "tr_fd"))
-    assert solver.trace and "one_launch_solve" not in solver.log and "eta" not in solver.trace[0]
+    gen_candidates_manifold(x0, acq, manifolds.Sphere(n), solver, inequality_constraints=cons, approx_hessian=(run == "tr_fd"),
+                            options={} if plan == "single_launch_solve" else {"device_solve": False})
+    assert solver.trace and ("one_launch_solve" in solver.log) == (plan == "single_launch_solve") and "eta" not in solver.trace[0]
     ok = g[f"{name}_{run}_f64_ok"]
     res = compare_with_reference_trace(solver.trace, g, f"{name}_{run}_f64", atol_x=1e-6)
     whole = [agree == nit or (run == "strict" and agree >= 30 and drift < 1e-6) for s, (agree, nit, worst, parted_at, drift) in enumerate(res) if ok[s]]
-    print(name, run, "restarts followed to the end:", sum(whole), "of", len(whole), [r[:2] for s, r in enumerate(res) if ok[s] and r[0] != r[1]])
+    print(name, run, plan, "restarts followed to the end:", sum(whole), "of", len(whole), [r[:2] for s, r in enumerate(res) if ok[s] and r[0] != r[1]])
     assert all(whole), [(s,) + r for s, r in enumerate(res) if ok[s] and r[0] != r[1]]
