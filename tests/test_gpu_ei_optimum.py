@@ -85,20 +85,21 @@ def test_returned_candidate_is_the_reference_best_of_restarts(plan, monkeypatch,
         f_star = -float(acq(best[None]).item())
     ref_best = int(g["best"])
     f_ref = float(g["f"][ref_best])
-    # THE statement: the returned optimum against the reference's best of restarts, 1e-5 relative
-    assert abs(f_star - f_ref) <= 1e-5 * abs(f_ref), (plan, f_star, f_ref)
-    # and the candidate itself is the reference's (both stop at |grad| < 1e-4: the points agree to that tolerance, not to rounding)
+    # THE statement: the returned optimum against the reference's best of restarts: 1e-8 relative (north_star asks for 1e-5; 2e-9 is what the
+    # reference's own evaluation of EI differs from every plan here by, the autograd path included)
+    assert abs(f_star - f_ref) <= 1e-8 * abs(f_ref), (plan, f_star, f_ref)
+    # and the candidate itself is the reference's
     x_star = ospd.vector_to_symmetric_matrix_mandel(best.cpu().numpy())[0]
-    assert np.linalg.norm(x_star - g["x"][ref_best]) <= 2e-3 * np.linalg.norm(g["x"][ref_best]), plan
+    assert np.linalg.norm(x_star - g["x"][ref_best]) <= 1e-7 * np.linalg.norm(g["x"][ref_best]), plan
 
-    # restart by restart (the values behind the arg max): restarts the reference ends by its gradient / step criteria within 1e-5 relative;
-    # the one it stops at maxiter - crawling along the bound, its iterates decided by rounding - within 2e-3
+    # restart by restart (the values behind the arg max): restarts the reference ends by its gradient / step criteria within 1e-8 relative;
+    # the one it stops at maxiter - crawling along the bound, |f| = 6e-4 - within 1e-7 (rounds 3-4: 1e-5 and 2e-3)
     cands, vals = mo.gen_candidates_manifold(ic, acq, man, ConstrainedTrustRegions(mingradnorm=1e-4, maxiter=100), to_mat, to_vec,
                                              inequality_constraints=cons, approx_hessian=True, options=opts)
     f = -vals.cpu().numpy()
     conv = g["nit"] < 100
     assert conv.sum() >= R - 2
-    np.testing.assert_allclose(f[conv], g["f"][conv], rtol=1e-5, atol=0, err_msg=plan)
-    np.testing.assert_allclose(f[~conv], g["f"][~conv], rtol=2e-3, atol=0, err_msg=plan)
+    np.testing.assert_allclose(f[conv], g["f"][conv], rtol=1e-8, atol=0, err_msg=plan)
+    np.testing.assert_allclose(f[~conv], g["f"][~conv], rtol=1e-7, atol=0, err_msg=plan)
     assert int(np.argmin(f)) == int(np.argmin(np.where(np.isclose(g["f"], f_ref, rtol=1e-9), g["f"], np.inf))) or \
         abs(f.min() - f_ref) <= 1e-5 * abs(f_ref)

@@ -283,7 +283,7 @@ def test_device_tcg_matches_torch_tcg():
     np.testing.assert_array_equal(log_d["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
     # (two evaluation orders - the device kernels use the Householder/QL eigen-solver - stopped by |grad| < 1e-4: values agree to
     # |grad|^2 / curvature, ~1e-10 absolute)
-    np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.parametrize("constraint", [True, False])
@@ -311,7 +311,7 @@ def test_use_rand_on_the_device_tcg_plan_follows_the_torch_path(constraint):
     np.testing.assert_array_equal(log_d["per_restart_iterations"].cpu().numpy(), log_t["per_restart_iterations"].cpu().numpy())
     np.testing.assert_allclose(val_d, val_t, rtol=1e-9)
     np.testing.assert_allclose(best_d.cpu().numpy(), best_t.cpu().numpy(), rtol=0, atol=1e-7)
-    np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(log_d["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-9, atol=1e-12)
     # and the random start changes nothing about where the sweep ends (the plain solver, same seeds)
     _, _, val_p, log_p = run_sweep(DEV, num_restarts=40, raw_samples=256, constraint=constraint)
     np.testing.assert_allclose(val_d, val_p, rtol=1e-6)
@@ -381,7 +381,7 @@ def test_device_solve_graph_plans_match_torch_path(strict):
         _, _, val, log = run_sweep(DEV, **kw, **extra)
         np.testing.assert_allclose(val, val_t, rtol=1e-9)
         np.testing.assert_array_equal(log["per_restart_iterations"].cpu().numpy(), ref_iters)
-        np.testing.assert_allclose(log["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-6, atol=1e-9)   # (stopped by |grad| < 1e-4: |grad|^2 / curvature)
+        np.testing.assert_allclose(log["final_cost"].cpu().numpy(), log_t["final_cost"].cpu().numpy(), rtol=1e-9, atol=1e-12)   # (stopped by |grad| < 1e-4: |grad|^2 / curvature)
 
 
 def test_fused_acquisition_on_trainable_surrogate():
@@ -508,11 +508,11 @@ def test_single_launch_acquisition_at_the_lds_limits():
 
 
 def test_device_trust_region_iteration_at_d12():
-    """the propose/update kernels at the largest supported dimension against the torch lock-step solver.  Three iterations agree
-    to rounding; later ones only approximately: at d = 12 the tCG runs up to 78 inner iterations on a finite-difference Hessian
-    (1/c = 2^14 ||delta|| amplifies the last bits of the gradient), so one exit test decided differently moves a restart by 1e-6."""
+    """the propose/update kernels at the largest supported dimension against the torch lock-step solver: three and six iterations (at
+    d = 12 the tCG runs up to 78 inner iterations on a finite-difference Hessian) agree to 1e-9.  (Rounds 2-4 compared the six-iteration
+    run at 1e-4 and blamed the amplification of the last bits by 1 / c; it was the kernels' step, 2^-13 instead of 2^-14: DESIGN 0.)"""
     from tools.sweep_bench import run_sweep
-    for maxiter, tol in ((3, 1e-9), (6, 1e-4)):
+    for maxiter, tol in ((3, 1e-9), (6, 1e-9)):
         kw = dict(num_restarts=12, raw_samples=64, d=12, n_train=30, maxiter=maxiter)
         _, _, val_t, log_t = run_sweep(DEV, device_tcg=False, **kw)
         _, _, val_d, log_d = run_sweep(DEV, **kw)
@@ -556,9 +556,9 @@ def test_device_solve_variants_match_torch_path(case):
                                        inequality_constraints=cons, approx_hessian=True, options=opts)
         out[name] = (c.cpu().numpy(), v.cpu().numpy(), solver.log["per_restart_iterations"].cpu().numpy())
     ops.set_error_checking(True)
-    # smooth unconstrained cases agree to 1e-7; with the kinked Laplace surrogate or with constraints (exit tests against
-    # Delta_cons^2 = 1e-12) single restarts can take a rounding-decided branch differently: BASELINE.json's 1e-5 on the optimum
-    tol = 1e-7 if case in ("unconstrained_ei", "posterior_mean") else 2e-5
+    # (until round 5 the constrained and Laplace cases were compared at 2e-5, attributed to rounding-decided branches: it was the
+    # finite-difference step of the device kernels)
+    tol = 1e-7 if case in ("unconstrained_ei", "posterior_mean") else 1e-9
     for name in ("device", "graphs", "two_launch_off"):
         np.testing.assert_array_equal(out[name][2], out["torch"][2])
         np.testing.assert_allclose(out[name][1], out["torch"][1], rtol=tol, atol=1e-12)
@@ -607,11 +607,11 @@ def test_single_launch_solve_matches_torch_path(case):
     ops.set_error_checking(True)
     for name in ("plan", "solve", "solve_off"):
         np.testing.assert_array_equal(out[name][2], out["torch"][2])
-        np.testing.assert_allclose(out[name][1], out["torch"][1], rtol=2e-5, atol=1e-12)
+        np.testing.assert_allclose(out[name][1], out["torch"][1], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(out["solve"][1], out["plan"][1], rtol=1e-9, atol=1e-13)       # same device arithmetic, two drivers
-    # (with constraints the two drivers evaluate lambda_max/min with different eigen-solvers - the wave's register Jacobi against
-    # the torch callable's launch - and a restart that sits on the bound can end a rounding error apart along a flat direction)
-    np.testing.assert_allclose(out["solve"][0], out["plan"][0], rtol=0, atol=1e-8 if lambdas is None else 1e-4)
+    # (with constraints the two drivers evaluate lambda_max/min with different eigen-solvers - the wave's register solver against
+    # the torch callable's launch - and a restart that sits on the bound can end a rounding error apart along a flat direction: 9e-8)
+    np.testing.assert_allclose(out["solve"][0], out["plan"][0], rtol=0, atol=1e-8 if lambdas is None else 1e-6)
     assert scut.builtin_constraint(lambdas[0]) is None if lambdas else True
 
 
@@ -760,7 +760,7 @@ def test_sphere_device_solve_matches_torch_path(case):
         solver = BatchedTrustRegions(mingradnorm=1e-6, maxiter=maxiter)
         c, v = gen_candidates_manifold(x[:, None], acq, man, solver, inequality_constraints=cons, approx_hessian=approx, options=opts)
         out[name] = (c.cpu().numpy(), v.cpu().numpy(), solver.log["per_restart_iterations"].cpu().numpy())
-    tol = 2e-5 if cons is not None else 1e-7
+    tol = 1e-9 if cons is not None else 1e-7
     for name in ("device", "graphs", "graphs_captured"):
         np.testing.assert_array_equal(out[name][2], out["torch"][2])
         np.testing.assert_allclose(out[name][1], out["torch"][1], rtol=tol, atol=1e-12)
@@ -902,17 +902,16 @@ def test_single_launch_solve_with_nested_eigenvalue_constraints(case):
     # ONE trust-region iteration (constraint values, whitened gradients, tCG with the constraint stop, proposal, strict feasibility test,
     # rho test): the three drivers agree restart by restart
     for name in ("plan", "solve"):
-        np.testing.assert_allclose(out[name, 1][1], out["torch", 1][1], rtol=5e-5, atol=1e-13)       # (device tCG vs torch tCG: the tolerance of the tests above)
+        np.testing.assert_allclose(out[name, 1][1], out["torch", 1][1], rtol=1e-10, atol=1e-13)       # (device tCG vs torch tCG)
     np.testing.assert_allclose(out["solve", 1][1], out["plan", 1][1], rtol=1e-9, atol=1e-14)         # same device arithmetic, two drivers
     np.testing.assert_allclose(out["solve", 1][0], out["plan", 1][0], rtol=0, atol=1e-9)
-    # The whole solve.  A restart that crawls along a bound takes accept / reject decisions that rounding can flip (the drivers whiten the
-    # constraint gradients in different orders), after which its trajectory parts by a step - the effect the reference itself shows between
-    # its f32 and f64 runs.  So: most restarts end on the torch path's value, all of them near it, none of them outside the
-    # bounds (strict), and the bounds did steer restarts whose unconstrained optimum lies outside.
+    # The whole solve: nine restarts in ten end on the torch path's value to 1e-8, all of them within 1e-6 (a restart that crawls along a
+    # bound takes accept / reject decisions that rounding can flip: the drivers whiten the constraint gradients in different orders), none
+    # of them outside the bounds (strict), and the bounds did steer restarts whose unconstrained optimum lies outside.
     lam = lift(ospd.vector_to_symmetric_matrix_mandel(out["solve", 25][0][:, 0]))
     if strict:
         assert lam[:, -1].max() < hi + 1e-9 and ("max_only" in case or lam[:, 0].min() > lo - 1e-9), (hi, lo, lam[:, -1].max(), lam[:, 0].min())
     assert not steer or (np.abs(out["solve", 25][1] - v_free.cpu().numpy()[keep]) > 1e-6 * np.abs(out["solve", 25][1])).sum() >= 5
     for name in ("plan", "solve"):
         rel = np.abs(out[name, 25][1] - out["torch", 25][1]) / np.maximum(np.abs(out["torch", 25][1]), 1e-12)
-        assert (rel < 2e-5).mean() >= 0.7 and rel.max() < 5e-2, (name, np.sort(rel)[-8:])
+        assert (rel < 1e-8).mean() >= 0.9 and rel.max() < 1e-6, (name, np.sort(rel)[-8:])

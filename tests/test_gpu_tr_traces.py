@@ -3,8 +3,9 @@ tests/test_tr_traces_cpu.py for what the fixture holds and how "f32" / "f64" dif
 
   * Hessian-vector products: autograd through the HIP kernels + HIP manifold operations, <= 1e-8 of the reference's fp64 run;
   * the generic lock-step path with HIP kernels and HIP manifold operations follows the reference iterate by iterate;
-  * the device-resident plans (propose/update launches, single-launch solve) end on the reference's fp64 optima within 1e-5
-    relative (north_star tolerance) at the size of config 4 (S^5_++, 50 terms, lambda_max bound), unconstrained and constrained."""
+  * the device-resident plans (tCG launches, propose/update launches, single-launch solve) follow the reference iterate by iterate as
+    well (round 5, after their finite-difference step was corrected to the reference's 2^-14) and end on its fp64 optima within 1e-8
+    relative at the size of config 4 (S^5_++, 50 terms, lambda_max bound), unconstrained and constrained."""
 import functools
 
 import numpy as np
@@ -123,19 +124,18 @@ def test_device_resident_plans_reach_the_reference_fp64_optima(golden, name):
             c, v = gen_candidates_manifold(x0, acq, man, TrustRegions(mingradnorm=1e-4, maxiter=100), pre, post, approx_hessian=True,
                                            options=opts)
             ok = g[f"{name}_tr_fd_f64_ok"]
-            assert rel(-v.cpu().numpy()[ok], g[f"{name}_tr_fd_f64_f"][ok]) < 1e-5, (name, opts)
+            assert rel(-v.cpu().numpy()[ok], g[f"{name}_tr_fd_f64_f"][ok]) < 1e-8, (name, opts)
         ok = g[f"{name}_con_f64_ok"]
-        # restarts the reference brought to |grad| < mingradnorm: 1e-5.  Restarts it stopped at maxiter = 100 while they crawl along the
-        # bound are compared mid-trajectory; the device kernels evaluate the same formulas in another order (whitened tCG, register Jacobi),
-        # and a hundred steps later the two trajectories are 1e-4 apart in cost - the generic path on the same HIP kernels follows the
-        # reference through all 100 iterations (test_generic_path_on_hip_kernels_follows_the_reference_trace)
+        # restarts the reference brought to |grad| < mingradnorm and restarts it stopped at maxiter = 100 while they crawl along the bound
+        # (compared mid-trajectory) alike: 1e-8.  (Rounds 1-4: 1e-5 and 1e-3, "the device kernels evaluate the same formulas in another
+        # order" - they evaluated the finite differences at twice the reference's step.)
         conv = ok & (g[f"{name}_con_f64_nit"] < 100)
         for cons in (partial, opaque):
             c, v = gen_candidates_manifold(x0, acq, man, ConstrainedTrustRegions(mingradnorm=1e-4, maxiter=100), pre, post,
                                            inequality_constraints=cons, approx_hessian=True)
             if conv.any():
-                assert rel(-v.cpu().numpy()[conv], g[f"{name}_con_f64_f"][conv]) < 1e-5, (name, "con", cons is partial)
-            assert rel(-v.cpu().numpy()[ok], g[f"{name}_con_f64_f"][ok]) < 1e-3, (name, "con at maxiter", cons is partial)
+                assert rel(-v.cpu().numpy()[conv], g[f"{name}_con_f64_f"][conv]) < 1e-8, (name, "con", cons is partial)
+            assert rel(-v.cpu().numpy()[ok], g[f"{name}_con_f64_f"][ok]) < 1e-8, (name, "con at maxiter", cons is partial)
         ok = g[f"{name}_strict_f64_ok"]
         for cons in (partial, opaque):
             strict = StrictConstrainedTrustRegions(mingradnorm=2e-4, maxiter=100, minstepsize=1e-4)
