@@ -45,7 +45,7 @@ def _axpy(g, a, cg):
 
 class _Subproblem:
     """The unconstrained subproblem (:226-326) with pymanopt's problem attributes: cost, grad, the finite-difference hess the reference
-    binds (:324 `get_hessianfd`), precon, verbosity."""
+    binds (:324 `get_hessianfd` - of the ORIGINAL problem, see hess below), precon, verbosity."""
 
     def __init__(self, problem, eqs, ineqs, lambdas, gammas, rho):
         self.manifold = problem.manifold
@@ -54,8 +54,13 @@ class _Subproblem:
         self.precon = getattr(problem, "precon", None) or (lambda x, d: d)
 
     def hess(self, x, a):
+        # The reference binds `types.MethodType(get_hessianfd, problem)` (:324) - to the ORIGINAL problem, not to the subproblem it has just
+        # built: the finite differences are those of the objective's gradient alone, the penalty terms contribute nothing to the model's
+        # curvature.  Restated as written (tests/golden/alm.npz: with it every outer iterate of the reference's runs is reproduced to
+        # 1e-8; with the subproblem's own gradient - rounds 2-4 - the first inner solve already lands 1e-3 away and single starts end in
+        # another local optimum).  Inner solvers without a Hessian (the reconstruction's conjugate gradients) never call this.
         from .approximate_hessian import get_hessianfd
-        return get_hessianfd(self, x, a)
+        return get_hessianfd(self.problem, x, a)
 
     @property
     def prefetch(self):

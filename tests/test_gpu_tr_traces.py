@@ -237,3 +237,36 @@ def test_sphere_device_plan_follows_the_reference_trace(golden, name, run, kw, p
     whole = [agree == nit or (run == "strict" and agree >= 30 and drift < 1e-6) for s, (agree, nit, worst, parted_at, drift) in enumerate(res) if ok[s]]
     print(name, run, plan, "restarts followed to the end:", sum(whole), "of", len(whole), [r[:2] for s, r in enumerate(res) if ok[s] and r[0] != r[1]])
     assert all(whole), [(s,) + r for s, r in enumerate(res) if ok[s] and r[0] != r[1]]
+
+
+@pytest.mark.parametrize("plan", ["generic_on_hip_kernels", "propose_update_launches"])
+@pytest.mark.parametrize("name,run", [("sph3", "eq"), ("sph5", "eq"), ("sph3", "eq_fd"), ("sph5", "eq_fd"), ("sph3", "eqoff"), ("sph5", "eqoff"),
+                                      ("sph3", "eq_strict"), ("sph5", "eq_strict")])
+def test_equality_constraints_follow_the_reference_trace(golden, name, run, plan):
+    """EQUALITY constraints on the sphere (gabo_sphere_equality_constraints.py:100-118: the great circle x[1] = yc; tests/golden/
+    tr_traces_eq.npz holds the reference's ConstrainedTrustRegions / StrictConstrainedTrustRegions records, 100 outer iterations each, from
+    starts on the constraint and off it): the generic lock-step path on the HIP kernels and the device plan (gabo_sphere_tr_propose /
+    _update, the constraint callable evaluated between the launches, neq = 1 inside the tCG) against them iteration by iteration."""
+    from gabotorch_amd.kernel_utils.kernels_sphere import SphereGaussianKernel
+    from tests.test_tr_traces_cpu import eq_run_setup
+    g, ge = golden("tr_traces.npz"), golden("tr_traces_eq.npz")
+    cls, kw, x0, cons, fd = eq_run_setup(ge, name, run)
+    solver = cls(**kw)
+    solver.trace = []
+    n = int(name[3:])
+    if plan == "generic_on_hip_kernels":
+        solver.solve(_problem(g, name, approx=fd), t(x0), eq_constraints=cons)
+    else:
+        kern = SphereGaussianKernel(beta_min=0.1).double()
+        kern.beta = torch.tensor(float(g[f"{name}_beta"]), dtype=torch.float64)
+        w = g[f"{name}_w"]
+        gp = models.ExactGP(t(g[f"{name}_Y"]), t(np.zeros(len(w))), kern, outputscale=1.0, noise=1.0, mean=0.0)
+        gp._cache = (torch.eye(len(w), dtype=torch.float64, device=DEV), t(w))
+        acq = models.PosteriorMean(gp, maximize=True)
+        gen_candidates_manifold(t(x0)[:, None], acq, manifolds.Sphere(n), solver, equality_constraints=cons, approx_hessian=fd)
+        assert "eta" not in solver.trace[0] and "one_launch_solve" not in solver.log       # (recorded between the two launches)
+    res = compare_with_reference_trace(solver.trace, ge, f"{name}_{run}_f64", atol_x=1e-6)
+    ok = ge[f"{name}_{run}_f64_ok"]
+    whole = [agree == nit or (run == "eq_strict" and agree >= 30 and drift < 1e-6) for s, (agree, nit, worst, parted_at, drift) in enumerate(res) if ok[s]]
+    print(name, run, plan, "restarts followed to the end:", sum(whole), "of", len(whole), [r[:2] for s, r in enumerate(res) if ok[s] and r[0] != r[1]])
+    assert all(whole), [(s,) + r for s, r in enumerate(res) if ok[s] and r[0] != r[1]]

@@ -331,3 +331,68 @@ def test_packed_product_of_spheres_and_lines_is_the_product_manifold():
     assert log_a["iterations"] == log_b["iterations"]
     np.testing.assert_allclose(b, packed.pack(a), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(b, packed.pack(target), atol=1e-5)
+
+
+def alm_reference_walk(solve_one, ga, name, rname):
+    """Shared by the CPU and GPU tests: runs `solve_one(s, x0, record)` for every start of tests/golden/alm.npz (record: list that receives the
+    point every inner solve returns) and walks the reference's outer iterates.  The method ends when the step between two outer iterates
+    is below 1e-10 in pymanopt's `dist` = arccos<x, y> - a quantity that is 0 or 1.5e-8 depending on the last bit of the inner product - so
+    the NUMBER of outer iterations is rounding-decided; every iterate both runs have is compared."""
+    import numpy as np
+    for s, x0 in enumerate(ga[f"{name}_{rname}_x0"]):
+        rec = []
+        x = solve_one(s, x0.copy(), rec)
+        nit, xs = int(ga[f"{name}_{rname}_nit"][s]), ga[f"{name}_{rname}_xs"][s]
+        m = min(nit, len(rec))
+        assert m >= 5 and abs(np.linalg.norm(x) - 1) < 1e-12
+        err = max(float(np.abs(rec[k] - xs[k]).max()) for k in range(m))
+        assert err < 1e-6, (name, rname, s, err, len(rec), nit)
+        if len(rec) == nit:
+            np.testing.assert_allclose(x, ga[f"{name}_{rname}_x"][s], rtol=0, atol=1e-6)
+
+
+def recording(inner, rec):
+    import numpy as np
+    real = inner.solve
+
+    def solve(problem, x=None, **kw):
+        r = real(problem, x=x, **kw)
+        rec.append(np.array(r[0] if isinstance(r, tuple) else r, dtype=float, copy=True))
+        return r
+    inner.solve = solve
+    return inner
+
+
+@pytest.mark.parametrize("name", ["sph3", "sph5"])
+@pytest.mark.parametrize("rname", ["eq", "ineq"])
+def test_alm_with_trust_regions_follows_the_reference_outer_iterates(golden, name, rname):
+    """`AugmentedLagrangeMethod(maxiter=200, inner_solver=TrustRegions(maxiter=200), gammas_fact=0.05)` - the DEFAULT solver of the reference's
+    constrained sphere examples (gabo_sphere_equality_constraints.py:95,200-203; gabo_sphere_inequality_constraints.py:97,238-241) - against
+    the record of the reference's own classes (tests/golden/make_golden_alm.py): every outer iterate.  What this pins: the multiplier and
+    penalty updates, the tolerance schedule, and the subproblem's Hessian, which the reference takes from the ORIGINAL problem
+    (augmented_Lagrange_method.py:324) - with the subproblem's own finite differences the first outer iterate is already 1e-3 away."""
+    import torch
+    from gabotorch_amd.manifold_optimization.augmented_Lagrange_method import AugmentedLagrangeMethod
+    from gabotorch_amd.manifold_optimization.robust_trust_regions import TrustRegions
+    from gabotorch_amd.pymanopt_addons.problem import Problem
+    g, ga = golden("tr_traces.npz"), golden("alm.npz")
+    n = int(name[3:])
+    Yt, wt, beta = torch.tensor(g[f"{name}_Y"]), torch.tensor(g[f"{name}_w"]), float(g[f"{name}_beta"])
+
+    def cost(x):
+        d = torch.acos((x.double()[None] @ Yt.T).clamp(-1 + 1e-15, 1 - 1e-15))
+        return -(wt * torch.exp(-beta * d * d)).sum()
+    man = Sphere(n)
+    man.egrad2rgrad = man.proj
+    man.ehess2rhess = lambda x, eg, eh, u: man.proj(x, eh) - float(x @ eg) * u
+    man.typicaldist = np.pi
+    center = torch.zeros(n, dtype=torch.float64)
+    center[0] = 1.0
+    cons = (dict(eq_constraints=[lambda x: x[1] - 0.0]) if rname == "eq"
+            else dict(ineq_constraints=[lambda x: np.pi / 4 - torch.acos(torch.clamp((x * center).sum(), -1.0, 1.0))]))
+
+    def solve_one(s, x0, rec):
+        problem = Problem(man, cost, arg=torch.Tensor(), verbosity=0)
+        solver = AugmentedLagrangeMethod(maxiter=200, inner_solver=recording(TrustRegions(maxiter=200), rec), gammas_fact=0.05)
+        return solver.solve(problem, x=x0, **cons)
+    alm_reference_walk(solve_one, ga, name, rname)

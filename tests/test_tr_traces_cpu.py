@@ -117,3 +117,35 @@ def test_distance_to_the_reference_as_is_is_the_references_own_noise(golden, nam
         assert own_noise < 5e-2, (name, run, own_noise)                 # (1.6e-2 on S^3_++ strict: |f| ~ 3e-3 at a maxiter end point)
         assert to_f64 < 1e-5, (name, run, to_f64)               # north_star: acquisition optima within 1e-5 relative fp64
         assert to_f32 < 2 * own_noise + 1e-9, (name, run, to_f32, own_noise)
+
+
+EQ_RUNS = [("sph3", "eq"), ("sph5", "eq"), ("sph3", "eq_fd"), ("sph5", "eq_fd"), ("sph3", "eqoff"), ("sph5", "eqoff"),
+           ("sph3", "eq_strict"), ("sph5", "eq_strict")]
+
+
+def eq_run_setup(ge, name, run):
+    """(solver class, keyword arguments, starts, equality constraints, FD Hessian?) of a run of tests/golden/make_golden_tr_traces_eq.py"""
+    cls = StrictConstrainedTrustRegions if run == "eq_strict" else ConstrainedTrustRegions
+    level = 0.2 if run == "eqoff" else 0.0
+    x0 = ge[f"{name}_eqoff_x0"] if run == "eqoff" else ge[f"{name}_eq_x0"]
+    return cls, {"mingradnorm": 1e-6, "maxiter": 100}, x0, [lambda x, level=level: x[..., 1] - level], run == "eq_fd"
+
+
+@pytest.mark.parametrize("name,run", EQ_RUNS)
+def test_equality_constrained_iterates_follow_the_reference_fp64_trace(golden, name, run):
+    """EQUALITY constraints (the great circle of gabo_sphere_equality_constraints.py:100-118; constrained_trust_regions.py:530-732 with
+    neq > 0): every one of the reference's 100 outer iterations reproduced - radius, tCG stop reason, iterate within 1e-6 - from starts on
+    the constraint and (eqoff) off it."""
+    g, ge = golden("tr_traces.npz"), golden("tr_traces_eq.npz")
+    cls, kw, x0, cons, fd = eq_run_setup(ge, name, run)
+    prob = _problem(g, name, approx=fd)
+    solver = cls(**kw)
+    solver.trace = []
+    x = solver.solve(prob, T(x0), eq_constraints=cons)
+    res = compare_with_reference_trace(solver.trace, ge, f"{name}_{run}_f64", atol_x=1e-6)
+    ok = ge[f"{name}_{run}_f64_ok"]
+    for s, (agree, nit, worst, parted_at, drift) in enumerate(res):
+        if ok[s]:
+            assert agree == nit or (run == "eq_strict" and agree >= 30 and drift < 1e-6), (name, run, s, agree, nit, worst, parted_at, drift)
+    np.testing.assert_allclose(x.numpy()[ok], ge[f"{name}_{run}_f64_x"][ok], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(prob.cost(x).numpy()[ok], ge[f"{name}_{run}_f64_f"][ok], rtol=1e-8, atol=1e-12)
