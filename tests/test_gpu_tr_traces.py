@@ -270,3 +270,33 @@ def test_equality_constraints_follow_the_reference_trace(golden, name, run, plan
     whole = [agree == nit or (run == "eq_strict" and agree >= 30 and drift < 1e-6) for s, (agree, nit, worst, parted_at, drift) in enumerate(res) if ok[s]]
     print(name, run, plan, "restarts followed to the end:", sum(whole), "of", len(whole), [r[:2] for s, r in enumerate(res) if ok[s] and r[0] != r[1]])
     assert all(whole), [(s,) + r for s, r in enumerate(res) if ok[s] and r[0] != r[1]]
+
+
+@pytest.mark.parametrize("plan", ["generic_on_hip_kernels", "propose_update_launches"])
+@pytest.mark.parametrize("run", ["box", "box_strict", "box2", "box2_strict"])
+def test_five_bound_constraints_follow_the_reference_trace(golden, run, plan):
+    """Several inequality constraints at once - the five bound constraints of gabo_sphere_bound_constraints.py:94-121, and a tighter box with
+    two bounds active at the solution (tests/golden/tr_traces_box.npz) - on the generic path over the HIP kernels and on the sphere's device
+    plan (five callables evaluated between the launches, the violated subset selected inside the tCG kernel)."""
+    from gabotorch_amd.kernel_utils.kernels_sphere import SphereGaussianKernel
+    from tests.test_tr_traces_cpu import box_run_setup
+    g, gb = golden("tr_traces.npz"), golden("tr_traces_box.npz")
+    cls, x0, cons = box_run_setup(gb, run)
+    solver = cls(maxiter=100)
+    solver.trace = []
+    if plan == "generic_on_hip_kernels":
+        solver.solve(_problem(g, "sph3", approx=False), t(x0), ineq_constraints=cons)
+    else:
+        kern = SphereGaussianKernel(beta_min=0.1).double()
+        kern.beta = torch.tensor(float(g["sph3_beta"]), dtype=torch.float64)
+        w = g["sph3_w"]
+        gp = models.ExactGP(t(g["sph3_Y"]), t(np.zeros(len(w))), kern, outputscale=1.0, noise=1.0, mean=0.0)
+        gp._cache = (torch.eye(len(w), dtype=torch.float64, device=DEV), t(w))
+        gen_candidates_manifold(t(x0)[:, None], models.PosteriorMean(gp, maximize=True), manifolds.Sphere(3), solver, inequality_constraints=cons,
+                                approx_hessian=False)
+        assert "eta" not in solver.trace[0] and "one_launch_solve" not in solver.log
+    res = compare_with_reference_trace(solver.trace, gb, f"sph3_{run}_f64", atol_x=1e-6)
+    ok = gb[f"sph3_{run}_f64_ok"]
+    whole = [agree == nit or (run.endswith("strict") and agree >= 30 and drift < 1e-6) for s, (agree, nit, worst, parted_at, drift) in enumerate(res) if ok[s]]
+    print(run, plan, "restarts followed to the end:", sum(whole), "of", len(whole), [r[:2] for s, r in enumerate(res) if ok[s] and r[0] != r[1]])
+    assert all(whole), [(s,) + r for s, r in enumerate(res) if ok[s] and r[0] != r[1]]

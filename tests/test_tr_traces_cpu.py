@@ -149,3 +149,34 @@ def test_equality_constrained_iterates_follow_the_reference_fp64_trace(golden, n
             assert agree == nit or (run == "eq_strict" and agree >= 30 and drift < 1e-6), (name, run, s, agree, nit, worst, parted_at, drift)
     np.testing.assert_allclose(x.numpy()[ok], ge[f"{name}_{run}_f64_x"][ok], rtol=0, atol=1e-6)
     np.testing.assert_allclose(prob.cost(x).numpy()[ok], ge[f"{name}_{run}_f64_f"][ok], rtol=1e-8, atol=1e-12)
+
+
+def box_run_setup(gb, run):
+    """(solver class, starts, the five bound constraints) of a run of tests/golden/make_golden_tr_traces_box.py
+    (gabo_sphere_bound_constraints.py:94-121)"""
+    b = dict(xl=0.0, yl=-0.6, yu=0.6, zl=-0.6, zu=0.6)
+    if run.startswith("box2"):
+        b.update(yu=0.3, zu=0.05)
+    cons = [lambda x: x[..., 0] - b["xl"], lambda x: x[..., 1] - b["yl"], lambda x: b["yu"] - x[..., 1], lambda x: x[..., 2] - b["zl"],
+            lambda x: b["zu"] - x[..., 2]]
+    cls = StrictConstrainedTrustRegions if run.endswith("strict") else ConstrainedTrustRegions
+    return cls, gb["sph3_box2_x0" if run.startswith("box2") else "sph3_box_x0"], cons
+
+
+@pytest.mark.parametrize("run", ["box", "box_strict", "box2", "box2_strict"])
+def test_five_bound_constraints_follow_the_reference_fp64_trace(golden, run):
+    """Several inequality constraints at once (the bound constraints of gabo_sphere_bound_constraints.py:94-121, ConstrainedTrustRegions(
+    maxiter=200) there): the step to the linearised constraints runs over the violated subset (constrained_trust_regions.py:569-590).
+    Both boxes - the example's, whose bounds rarely bind, and a tighter one with two bounds active at the solution."""
+    g, gb = golden("tr_traces.npz"), golden("tr_traces_box.npz")
+    cls, x0, cons = box_run_setup(gb, run)
+    prob = _problem(g, "sph3", approx=False)
+    solver = cls(maxiter=100)
+    solver.trace = []
+    x = solver.solve(prob, T(x0), ineq_constraints=cons)
+    res = compare_with_reference_trace(solver.trace, gb, f"sph3_{run}_f64", atol_x=1e-6)
+    ok = gb[f"sph3_{run}_f64_ok"]
+    for s, (agree, nit, worst, parted_at, drift) in enumerate(res):
+        if ok[s]:
+            assert agree == nit or (run.endswith("strict") and agree >= 30 and drift < 1e-6), (run, s, agree, nit, worst, parted_at, drift)
+    np.testing.assert_allclose(prob.cost(x).numpy()[ok], gb[f"sph3_{run}_f64_f"][ok], rtol=1e-8, atol=1e-12)
