@@ -48,3 +48,16 @@ def test_hd_gabo_sphere_loop():
     assert x.shape == (8, 5)
     np.testing.assert_allclose(np.linalg.norm(x.cpu().numpy(), axis=1), 1.0, atol=1e-12)
     assert all(b2 <= b1 + 1e-12 for b1, b2 in zip(best, best[1:])) and np.isfinite(best[-1])
+
+
+@pytest.mark.parametrize("kind,solver", [("equality", None), ("equality", "CTR"), ("inequality", None), ("bounds", None)])
+def test_constrained_sphere_loops(kind, solver):
+    """The reference's constrained sphere examples (examples/bo_sphere/constrained_benchmark_examples/*.py) in miniature: their constraint
+    callables, their constrained `manifold.rand`, their solvers (AugmentedLagrangeMethod around TrustRegions by default, ConstrainedTrustRegions
+    for the bounds).  Every candidate the maximiser returns satisfies the constraints (to the method's tolerance)."""
+    import gabo_sphere_constraints as ex
+    x, y, best, feasible = ex.run(kind, solver, iters=3, verbose=False, alm_maxiter=60)
+    xs = x.cpu().numpy()
+    assert xs.shape == (8, 3) and np.allclose(np.linalg.norm(xs, axis=1), 1.0, atol=1e-12)
+    assert all(feasible(p) for p in xs), [p for p in xs if not feasible(p)]
+    assert all(b2 <= b1 + 1e-12 for b1, b2 in zip(best, best[1:])) and np.isfinite(best[-1])
