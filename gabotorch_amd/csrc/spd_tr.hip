@@ -58,6 +58,13 @@ size_t gabo_spd_tr_workspace_bytes(int64_t r, int d, int n_constraints, int64_t 
     return gabo::tr_layout(nullptr, r, d, n_constraints, n_train).bytes;
 }
 
+int gabo_spd_tr_propose_supported(int flags, int d) {
+    const int metric = flags & GABO_METRIC_MASK;
+    if (metric == GABO_METRIC_AFFINE_INVARIANT) return d >= 2 && d <= GABO_SPD_REG_MAX_DIM;
+    if (metric == GABO_METRIC_LOG_EUCLIDEAN) return d >= 2 && d <= 7;       /* (d = 8: spd_tr_le_hi.hip) */
+    return 0;
+}
+
 int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust_radius, const uint8_t* active,
                         const double* cons_grads, const double* cons_values, const gabo_spd_acq_params* acq, void* workspace,
                         size_t workspace_bytes, double* x_prop, int64_t r, int d, int n_constraints, int n_equalities, double delta_cons,
@@ -75,7 +82,7 @@ int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust
     {
         const int metric = acq->flags & GABO_METRIC_MASK;
         if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN) return GABO_ERR_ARG;
-        if (metric != GABO_METRIC_AFFINE_INVARIANT && d > 8) return GABO_ERR_DIM;
+        if (!gabo_spd_tr_propose_supported(acq->flags, d)) return GABO_ERR_DIM;
     }
     if (workspace_bytes < gabo_spd_tr_workspace_bytes(r, d, n_constraints, acq->n)) return GABO_ERR_ARG;
     gabo::ProposeArgs a{x, grad, trust_radius, active, cons_grads, cons_values, acq, workspace, x_prop, r, d, n_constraints, n_equalities,
@@ -101,6 +108,20 @@ int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, d
                        trust_radius, active, iters, invalid, x_prop, workspace, r, d, n_constraints, n_train, delta_bar, rho_prime,
                        rho_regularization, mingradnorm, maxiter, any_active);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+
+int gabo_spd_tr_solve_supported(const gabo_spd_acq_params* acq, int64_t r, int d, int n_constraints, int lift_dim) {
+    if (!acq || d < 2 || d > 8 || r < 1 || n_constraints < 0 || n_constraints > gabo::kMaxCons) return 0;
+    const int metric = acq->flags & GABO_METRIC_MASK;
+    if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN) return 0;
+    if (acq->n < 1 || acq->n > gabo_spd_acq_max_train(d)) return 0;
+    const size_t nested_bytes = lift_dim > 0 ? gabo::nested_extremes_lds_doubles(lift_dim, d) * sizeof(double) : 0;
+#ifdef GABO_TR_NO_LAT
+    const bool has_factors = false;
+#else
+    const bool has_factors = acq->linv && acq->linv_t;
+#endif
+    return gabo::solve_supported(metric == GABO_METRIC_LOG_EUCLIDEAN ? 1 : 0, acq->n, r, d, n_constraints, has_factors, nested_bytes) ? 1 : 0;
 }
 
 int gabo_tr_solve_record(double* buffer, int64_t max_iterations) {

@@ -616,6 +616,22 @@ struct SolveArgs {
     int shortcuts = 1;      // 0: every iteration computes its proposal and the full evaluation (the environment variable GABO_TR_NO_SHORTCUTS: tests)
 };
 
+// The log-Euclidean solve at d = 7, 8 exists in its LDS-resident form only (workspace and GP factors in the block's LDS, pointers
+// specialised at compile time).  The generic-pointer instantiation of those two - 256 VGPRs + 256 AGPRs, ~3700 vector and ~880 scalar
+// registers spilled - faults on a null address at its first launch whatever its inputs (tools/soak_tr.py found it; every other
+// instantiation, d = 2 ... 8 of both metrics, runs: tools/repro_solve_fault.py over the whole table), so it is not built:
+// gabo_spd_tr_solve_supported says no and the caller iterates through gabo_spd_tr_propose / gabo_spd_tr_update.
+static constexpr bool solve_needs_lds_workspace(int metric, int d) { return metric == 1 && d >= 7; }
+
+// whether dispatch_solve would launch for this problem (the same sizing decisions)
+static inline bool solve_supported(int metric, int64_t n, int64_t r, int d, int C, bool has_factors, size_t nested_bytes) {
+    int stage_gp = 0, ws_lds = 0;
+    const size_t lds = tr_solve_dynamic_lds(n, r, d, C, &stage_gp, &ws_lds, nested_bytes);
+    if (lds > 64 * 1024 || d < 2 || d > 8) return false;
+    const bool lat = stage_gp && ws_lds && has_factors;
+    return lat || !solve_needs_lds_workspace(metric, d);
+}
+
 template <int METRIC, int DMIN = 2, int DMAX = 8>
 static int dispatch_solve(const SolveArgs& a) {
     int stage_gp = 0, ws_lds = 0, nested_off = 0;
@@ -635,6 +651,7 @@ static int dispatch_solve(const SolveArgs& a) {
     case DD:                                                                                                                       \
         if constexpr (DD >= DMIN && DD <= DMAX) {                                                                                  \
             if (lat) GABO_SOLVE_LAUNCH(DD, true);                                                                                  \
+            else if constexpr (solve_needs_lds_workspace(METRIC, DD)) return GABO_ERR_DIM;                                         \
             else GABO_SOLVE_LAUNCH(DD, false);                                                                                     \
         } else {                                                                                                                   \
             return GABO_ERR_DIM;                                                                                                   \

@@ -513,15 +513,24 @@ class BatchedTrustRegions:
         # (~0.1 ms of host time) off the front of a 4-ms sweep.
         one_launch = False
         builtins, lift = None, None
-        fused_iteration = getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True) and not self.use_rand
-        if fused_iteration:
+        fused_kernels = getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True) and not self.use_rand
+        # (the library says which of its iteration kernels exist for this surrogate: e.g. no propose / update pair for the log-Euclidean
+        # surrogate at d = 8, csrc/spd_tr_le_hi.hip, and no generic-workspace single launch for it at d = 7, 8, csrc/spd_tr_body.hpp)
+        propose_ok = bool(fused_kernels and (sphere or self_lib().gabo_spd_tr_propose_supported(int(fused.mode) | int(fused.metric), d)))
+        if fused_kernels:
             from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint, builtin_lift
             builtins = [builtin_constraint(c) for c in cons]
             solve_ok = (ncons == 0) if sphere else (d <= 8 and neq == 0 and all(b is not None for b in builtins)
                                                     and fused.metric != _lib_frobenius())
             lift = builtin_lift(builtins) if (solve_ok and not sphere) else None      # the nested kinds' mapping (one for all of them)
             solve_ok = solve_ok and lift is not False
+            if solve_ok and not sphere:
+                # (the library's own word: e.g. no single-launch form of the log-Euclidean surrogate at d = 7, 8 beyond what its LDS holds)
+                import ctypes
+                solve_ok = bool(self_lib().gabo_spd_tr_solve_supported(ctypes.byref(fused.acq_params()), R, d, ncons,
+                                                                       0 if lift is None else int(lift[0].shape[0])))
             one_launch = bool(solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000)
+        fused_iteration = propose_ok or one_launch
         T = None if (sphere or one_launch) else ops.SpdTcg(R, d, ncons, dev)
         val_buf = None if one_launch else torch.zeros(R, dtype=dt, device=dev)
         eg_buf = None if one_launch else torch.zeros(R, d * (d + 1) // 2, dtype=dt, device=dev)

@@ -382,6 +382,9 @@ def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samp
     fused = FusedAcquisition.build(acq_function, post_processing_manifold, dev)
     if fused is None or not (fused.family == "spd" and fused.flavour in ("ai", "le") and fused.single_launch and fused.matrix_input):
         return None       # (affine-invariant and log-Euclidean surrogates: the metrics gabo_spd_tr_solve iterates)
+    import ctypes
+    if not _lib.load().gabo_spd_tr_solve_supported(ctypes.byref(fused.acq_params()), int(num_restarts), int(manifold._n), len(builtins), 0):
+        return None       # (e.g. the log-Euclidean surrogate at d = 7, 8 beyond its LDS-resident form: the propose / update launches run)
     return {"fused": fused, "device": dev, "manifold": manifold, "builtins": builtins, "device_rand": device_rand}
 
 

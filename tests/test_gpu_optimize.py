@@ -615,6 +615,49 @@ def test_single_launch_solve_matches_torch_path(case):
     assert scut.builtin_constraint(lambdas[0]) is None if lambdas else True
 
 
+@pytest.mark.parametrize("d,n_train", [(8, 47), (7, 60), (8, 20)])
+def test_log_euclidean_sweep_at_d7_d8_beyond_the_lds_resident_solve(d, n_train):
+    """Two instantiations of the trust-region kernels for the log-Euclidean surrogate were wrong as compiled and are no longer built
+    (found by tools/soak_tr.py): the generic-workspace single-launch solve at d = 7, 8 faulted on a null address, and the propose kernel at
+    d = 8 returned wrong proposals.  The library now says what it has (gabo_spd_tr_solve_supported, gabo_spd_tr_propose_supported) and the
+    sweep takes the next plan: LDS-resident single launch where it fits ((8, 20)), else propose / update launches (d = 7), else the tCG
+    launches (d = 8) - every choice with the torch path's results."""
+    import ctypes
+    import functools
+    from gabotorch_amd.fused_acquisition import FusedAcquisition
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdLogEuclideanGaussianKernel
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    rng, X, y = _spd_gp(d, n_train=n_train, seed=47)
+    kern = SpdLogEuclideanGaussianKernel().double()
+    kern.lengthscale = torch.tensor(1.4, dtype=torch.float64)
+    gp = models.ExactGP(t(X), t(y), kern, outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    R = 24
+    q = np.linalg.qr(rng.standard_normal((R, d, d)))[0]
+    P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.5, 2.2, (R, d)), q)
+    x0 = ops.matrix_to_mandel(t(0.5 * (P + P.transpose(0, 2, 1))))[:, None]
+    cons = [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=2.6),
+            functools.partial(scut.min_eigenvalue_constraint_torch, minimum_eigenvalue=0.3)]
+    fused = FusedAcquisition.build(acq, symmetric_matrix_to_vector_mandel_torch, torch.device(DEV))
+    supported = bool(_lib.load().gabo_spd_tr_solve_supported(ctypes.byref(fused.acq_params()), R, d, 2, 0))
+    assert supported == (n_train == 20)
+    out = {}
+    ops.set_error_checking(False)
+    try:
+        for name, opts in (("torch", {"device_tcg": False}), ("device", {}), ("no_solve", {"device_solve": False}), ("graphs", {"hip_graphs": True})):
+            solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=12, strict_constraints=True)
+            c, v = gen_candidates_manifold(x0, acq, manifolds.PositiveDefinite(d), solver, vector_to_symmetric_matrix_mandel_torch,
+                                           symmetric_matrix_to_vector_mandel_torch, inequality_constraints=cons, approx_hessian=True, options=opts)
+            out[name] = (v.cpu().numpy(), solver.log["per_restart_iterations"].cpu().numpy(), "one_launch_solve" in solver.log)
+    finally:
+        ops.set_error_checking(True)
+    assert bool(_lib.load().gabo_spd_tr_propose_supported(int(fused.mode) | int(fused.metric), d)) == (d == 7)
+    assert out["device"][2] == supported and out["graphs"][2] == supported and not out["torch"][2] and not out["no_solve"][2]
+    for name in ("device", "no_solve", "graphs"):
+        np.testing.assert_array_equal(out[name][1], out["torch"][1])
+        np.testing.assert_allclose(out[name][0], out["torch"][0], rtol=1e-8, atol=1e-12)
+
+
 @pytest.mark.parametrize("d", [2, 3])
 def test_device_solve_matches_reference_solver_optima(golden, d):
     """The golden trust-region problems (tests/golden/make_golden_tr.py: the REFERENCE's TrustRegions / ConstrainedTrustRegions /
