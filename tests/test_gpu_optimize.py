@@ -958,3 +958,50 @@ def test_single_launch_solve_with_nested_eigenvalue_constraints(case):
     for name in ("plan", "solve"):
         rel = np.abs(out[name, 25][1] - out["torch", 25][1]) / np.maximum(np.abs(out["torch", 25][1]), 1e-12)
         assert (rel < 1e-8).mean() >= 0.9 and rel.max() < 1e-6, (name, np.sort(rel)[-8:])
+
+
+@pytest.mark.parametrize("n_train", [12, 60])
+@pytest.mark.parametrize("flavour,d", [(f, d) for f in ("ai", "le") for d in range(2, 9)] + [("ai", d) for d in (9, 10, 11, 12)]
+                         + [("frob", d) for d in (2, 5, 8)])
+def test_every_trust_region_kernel_instantiation_against_the_torch_solver(flavour, d, n_train):
+    """One small constrained (eigenvalue box, strict) EI sweep per surrogate metric and dimension, on every execution plan the library offers
+    for it - the single launch (LDS-resident with 12 training points; generic workspace with 60, whose GP factors do not fit beside it), the
+    propose / update launches, the tCG launches - against the torch lock-step solver: same iteration counts, same values.  Every
+    (dimension, metric, workspace) instantiation of the trust-region kernels is launched here once; two of them were wrong as compiled
+    until round 5 and no test had run them."""
+    import functools
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdFrobeniusGaussianKernel, SpdLogEuclideanGaussianKernel
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    if n_train > int(_lib.load().gabo_spd_acq_max_train(d)):
+        pytest.skip("more training points than the fused evaluation holds at this dimension")
+    rng, X, y = _spd_gp(d, n_train=n_train, seed=100 + d)
+    if flavour == "ai":
+        kern = SpdAffineInvariantGaussianKernel(beta_min=0.5)
+    else:
+        kern = (SpdLogEuclideanGaussianKernel if flavour == "le" else SpdFrobeniusGaussianKernel)().double()
+        kern.lengthscale = torch.tensor(1.4, dtype=torch.float64)
+    gp = models.ExactGP(t(X), t(y), kern, outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()), maximize=False)
+    R = 16
+    q = np.linalg.qr(rng.standard_normal((R, d, d)))[0]
+    P = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.5, 2.2, (R, d)), q)
+    x0 = ops.matrix_to_mandel(t(0.5 * (P + P.transpose(0, 2, 1))))[:, None]
+    cons = [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=2.6),
+            functools.partial(scut.min_eigenvalue_constraint_torch, minimum_eigenvalue=0.3)]
+    out = {}
+    ops.set_error_checking(False)
+    try:
+        for name, opts in (("torch", {"device_tcg": False}), ("default", {}), ("no_solve", {"device_solve": False}),
+                           ("tcg_launches", {"device_iteration": False})):
+            solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=8, strict_constraints=True)
+            c, v = gen_candidates_manifold(x0, acq, manifolds.PositiveDefinite(d), solver, vector_to_symmetric_matrix_mandel_torch,
+                                           symmetric_matrix_to_vector_mandel_torch, inequality_constraints=cons, approx_hessian=True, options=opts)
+            out[name] = (v.cpu().numpy(), solver.log["per_restart_iterations"].cpu().numpy(), "one_launch_solve" in solver.log)
+    finally:
+        ops.set_error_checking(True)
+    assert not out["torch"][2] and not out["no_solve"][2] and not out["tcg_launches"][2]
+    if flavour != "frob" and d <= 6:
+        assert out["default"][2]                     # (a single launch exists for every size up to d = 6)
+    for name in ("default", "no_solve", "tcg_launches"):
+        np.testing.assert_array_equal(out[name][1], out["torch"][1], err_msg=name)
+        np.testing.assert_allclose(out[name][0], out["torch"][0], rtol=1e-7, atol=1e-12, err_msg=name)
