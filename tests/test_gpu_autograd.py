@@ -41,7 +41,7 @@ def test_spd_grads_golden(golden):
         np.testing.assert_allclose(x2.grad.cpu().numpy(), o2, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(o2).max()))
 
 
-@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_BWD_REG_MAX_DIM + 1)) + [17, 20])
+@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_BWD_REG_MAX_DIM + 1)) + [17, 20, 24, 32])
 def test_spd_backward_all_dims_vs_oracle(d):
     """d <= 11: one lane per pair; 12 ... 16: two lanes per pair (odd d: a padded half row in the odd lane; 70 and 33 columns: a ragged last chunk of the
     32-pair waves); above: the wave-per-pair fallback"""

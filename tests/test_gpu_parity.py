@@ -76,7 +76,7 @@ def test_letters_fixture(golden):
     np.testing.assert_array_equal(ks, ks.T)
 
 
-@pytest.mark.parametrize("d", list(range(2, _lib.GABO_SPD_REG_MAX_DIM + 1)) + [13, 16, 17, 18, 19, 20, 24])
+@pytest.mark.parametrize("d", list(range(2, 33)))          # (every dimension the library takes: each is its own kernel instantiation up to 20)
 def test_spd_ai_vs_oracle_all_dims(d):
     rng = np.random.default_rng(d)
     x1 = rand_spd_mandel(rng, 37, d)
