@@ -82,8 +82,8 @@ def spd_case(rng):
 
 
 def sphere_case(rng):
-    dim = int(rng.choice([3, 4, 6, 10]))
-    n = int(rng.integers(4, 60))
+    dim = int(rng.choice([3, 4, 6, 10, 21, 51, 101]))            # (the reference's gabo_sphere.py runs up to dim = 100)
+    n = int(rng.integers(4, 300 if rng.integers(0, 4) == 0 else 60))
     X = rng.standard_normal((n, dim)); X /= np.linalg.norm(X, axis=1, keepdims=True)
     y = np.sin(3 * X[:, 0]) + X[:, 1] ** 2 + 0.05 * rng.standard_normal(n)
     gp = models.ExactGP(t(X), t(y), SphereGaussianKernel(beta_min=float(rng.uniform(0.5, 6.5))), outputscale=float(rng.uniform(0.5, 2.0)), noise=1e-2)
