@@ -269,6 +269,10 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
     double* vv = kd + n;
     const int lane = threadIdx.x;
     const bool want_grad = grad_out != nullptr;
+    // the wave's scratch for the adjoint of dlogm (log-Euclidean only): eigenvectors, eigenvalues and their logarithms of the candidate,
+    // the gradient with respect to logm(x) as a full matrix, the inner matrix of the Daleckii-Krein formula
+    struct FrobLds { double v[D * D], gm[D * D], inner[D * D], lam[D], lg[D]; };
+    __shared__ FrobLds sh;
     // ---- candidate features (Mandel order), wave-uniform
     double fx[T];
     double m[T], v[D * D], lam[D], lg[D];
@@ -292,6 +296,12 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
                 fx[mandel_pos(D, r, c)] = (r == c) ? f : f * kSqrt2;
             });
         });
+#ifndef GABO_FROB_REGISTER_ADJOINT
+        if (want_grad && lane == 0) {          // (every lane holds the same decomposition; the registers are free from here on)
+            static_for<D * D>([&](auto ee) { sh.v[decltype(ee)::value] = v[decltype(ee)::value]; });
+            static_for<D>([&](auto kk) { sh.lam[decltype(kk)::value] = lam[decltype(kk)::value]; sh.lg[decltype(kk)::value] = lg[decltype(kk)::value]; });
+        }
+#endif
     } else {
         static_for<T>([&](auto ee) { fx[decltype(ee)::value] = xrow[decltype(ee)::value]; });
     }
@@ -352,6 +362,7 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
     if constexpr (METRIC == 2) {
         if (lane == 0) static_for<T>([&](auto ee) { grad_out[decltype(ee)::value] = gacc[decltype(ee)::value]; });
     } else {
+#ifdef GABO_FROB_REGISTER_ADJOINT      /* rounds 2-5a: the adjoint unrolled in every lane's registers (D^4 products inline, 512-register kernels at D = 7, 8) */
         // adjoint of dlogm at x:  V ((V^T Gm V) o Fdd) V^T,  Fdd_kl = (log l_k - log l_l)/(l_k - l_l), Fdd_kk = 1/l_k
         double inner[D * D];
         static_for<D>([&](auto aa) {
@@ -396,6 +407,53 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
                 });
             });
         }
+#else
+        // adjoint of dlogm at x:  V ((V^T Gm V) o Fdd) V^T,  Fdd_kl = (log l_k - log l_l)/(l_k - l_l), Fdd_kk = 1/l_k - shared by the wave through
+        // LDS (round 5): lane a D + b forms entry (a, b) of the inner matrix, lane k entry k of the result.  The same products in the same
+        // order as the register form above (which every lane evaluated in full, D^4 of them inline: the source of the 512-register, 4 k-spill
+        // instantiations at D = 7, 8 - two of which were wrong as compiled): bit-identical results.
+        if (lane == 0) {
+            static_for<D>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                static_for<D>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    constexpr int hi = r > c ? r : c, lo = r > c ? c : r;
+                    sh.gm[r * D + c] = (r == c) ? gacc[mandel_pos(D, hi, lo)] : gacc[mandel_pos(D, hi, lo)] / kSqrt2;
+                });
+            });
+        }
+        __syncthreads();
+        for (int idx = lane; idx < D * D; idx += 64) {
+            const int a = idx / D, b = idx - a * D;
+            double sacc = 0.0;
+            for (int r = 0; r < D; ++r) {
+                double t = 0.0;      // (Gm V)[r][b]
+                for (int c = 0; c < D; ++c) t = __builtin_fma(sh.gm[r * D + c], sh.v[c * D + b], t);
+                sacc = __builtin_fma(sh.v[r * D + a], t, sacc);
+            }
+            const double la = sh.lam[a], lb = sh.lam[b];
+            const double meanl = 0.5 * (la + lb), dl = la - lb;
+            const double z = dl / (2.0 * meanl), z2 = z * z;
+            const double fdd = (__builtin_fabs(z) < 1e-3) ? (1.0 + z2 * (1.0 / 3.0 + z2 * (0.2 + z2 * (1.0 / 7.0)))) / meanl
+                                                           : (sh.lg[a] - sh.lg[b]) / dl;
+            sh.inner[idx] = sacc * fdd;
+        }
+        __syncthreads();
+        for (int k = lane; k < T; k += 64) {
+            int r = 0;
+            while (tri(r + 1, 0) <= k) ++r;
+            const int c = k - tri(r, 0);
+            double f1 = 0.0, f2 = 0.0;       // (r, c) and (c, r): averaged like symmetric_matrix_to_vector_mandel
+            for (int a = 0; a < D; ++a) {
+                for (int b = 0; b < D; ++b) {
+                    f1 = __builtin_fma(sh.v[r * D + a] * sh.inner[a * D + b], sh.v[c * D + b], f1);
+                    f2 = __builtin_fma(sh.v[c * D + a] * sh.inner[a * D + b], sh.v[r * D + b], f2);
+                }
+            }
+            grad_out[mandel_pos(D, r, c)] = (r == c) ? f1 : 0.5 * (kSqrt2 * f1 + kSqrt2 * f2);
+        }
+        __syncthreads();         // (the scratch is reused by the next evaluation of this wave)
+#endif
     }
 }
 

@@ -61,7 +61,7 @@ size_t gabo_spd_tr_workspace_bytes(int64_t r, int d, int n_constraints, int64_t 
 int gabo_spd_tr_propose_supported(int flags, int d) {
     const int metric = flags & GABO_METRIC_MASK;
     if (metric == GABO_METRIC_AFFINE_INVARIANT) return d >= 2 && d <= GABO_SPD_REG_MAX_DIM;
-    if (metric == GABO_METRIC_LOG_EUCLIDEAN) return d >= 2 && d <= 7;       /* (d = 8: spd_tr_le_hi.hip) */
+    if (metric == GABO_METRIC_LOG_EUCLIDEAN) return d >= 2 && d <= (GABO_LE_MAX_GENERIC_DIM >= 8 ? 8 : 7);       /* (d = 8: spd_tr_le_hi.hip) */
     return 0;
 }
 

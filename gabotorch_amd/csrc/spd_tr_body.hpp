@@ -616,12 +616,17 @@ struct SolveArgs {
     int shortcuts = 1;      // 0: every iteration computes its proposal and the full evaluation (the environment variable GABO_TR_NO_SHORTCUTS: tests)
 };
 
-// The log-Euclidean solve at d = 7, 8 exists in its LDS-resident form only (workspace and GP factors in the block's LDS, pointers
-// specialised at compile time).  The generic-pointer instantiation of those two - 256 VGPRs + 256 AGPRs, ~3700 vector and ~880 scalar
-// registers spilled - faults on a null address at its first launch whatever its inputs (tools/soak_tr.py found it; every other
-// instantiation, d = 2 ... 8 of both metrics, runs: tools/repro_solve_fault.py over the whole table), so it is not built:
-// gabo_spd_tr_solve_supported says no and the caller iterates through gabo_spd_tr_propose / gabo_spd_tr_update.
-static constexpr bool solve_needs_lds_workspace(int metric, int d) { return metric == 1 && d >= 7; }
+// Round 5 history of two instantiations (tools/soak_tr.py found them; tools/repro_solve_fault.py walks the whole table): with the
+// log-Euclidean evaluation's adjoint unrolled in every lane's registers (spd_acq_body.hpp, -DGABO_FROB_REGISTER_ADJOINT) the kernels of that
+// surrogate at d = 7, 8 were 512-register functions with ~3700 vector and ~880 scalar registers spilled, and two of them were wrong AS COMPILED:
+// the generic-workspace solve faulted on a null address at its first launch, the d = 8 propose kernel returned wrong proposals - while the
+// LDS-resident solve of the same source was right.  The adjoint is now shared by the wave through LDS (bit-identical results, 233 registers
+// at d = 8, no spills to speak of) and both instantiations are right again (the same table, the soak).  GABO_LE_MAX_GENERIC_DIM = 6 builds the
+// library without them, as the first fix did; gabo_spd_tr_solve_supported / gabo_spd_tr_propose_supported answer for whatever was built.
+#ifndef GABO_LE_MAX_GENERIC_DIM
+#define GABO_LE_MAX_GENERIC_DIM 8
+#endif
+static constexpr bool solve_needs_lds_workspace(int metric, int d) { return metric == 1 && d > GABO_LE_MAX_GENERIC_DIM; }
 
 // whether dispatch_solve would launch for this problem (the same sizing decisions)
 static inline bool solve_supported(int metric, int64_t n, int64_t r, int d, int C, bool has_factors, size_t nested_bytes) {

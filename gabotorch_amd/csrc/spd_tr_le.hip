@@ -1,5 +1,5 @@
-// Trust-region proposal kernels for the log-Euclidean surrogate, d = 2 ... 6 (instantiations only; templates in spd_tr_body.hpp); d = 7 in
-// spd_tr_le_hi.hip (d = 8: none, see there).
+// Trust-region proposal kernels for the log-Euclidean surrogate, d = 2 ... 6 (instantiations only; templates in spd_tr_body.hpp); d = 7, 8 in
+// spd_tr_le_hi.hip.
 #include "spd_tr_body.hpp"
 
 namespace gabo {

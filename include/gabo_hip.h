@@ -446,7 +446,7 @@ int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust
                         size_t workspace_bytes, double* x_prop, int64_t r, int d, int n_constraints, int n_equalities, double delta_cons,
                         double theta, double kappa, int mininner, int maxinner, int* any_active, int* status, gabo_stream_t stream);
 /* 1 when gabo_spd_tr_propose / gabo_spd_tr_update iterate a surrogate with these GABO_METRIC_* / GABO_OUT_* flags at dimension d:
- * affine-invariant 2 ... 12, log-Euclidean 2 ... 7.  Otherwise the caller composes the iteration from gabo_spd_tcg_* and gabo_spd_acq_eval
+ * affine-invariant 2 ... 12, log-Euclidean 2 ... 8.  Otherwise the caller composes the iteration from gabo_spd_tcg_* and gabo_spd_acq_eval
  * (or, where gabo_spd_tr_solve_supported, runs the single launch). */
 int gabo_spd_tr_propose_supported(int flags, int d);
 int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
@@ -476,8 +476,8 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
                       gabo_stream_t stream);
 /* 1 when gabo_spd_tr_solve runs this problem in its single launch, 0 when the caller has to iterate through gabo_spd_tr_propose /
  * gabo_spd_tr_update instead (same results, two launches per iteration): d outside 2 ... 8, a surrogate metric other than the
- * affine-invariant / log-Euclidean ones, or the log-Euclidean surrogate at d = 7, 8 with more training points / restarts than its
- * LDS-resident form holds (that form is the only one built for those two sizes).  lift_dim: as in gabo_spd_tr_solve, 0 without nested kinds. */
+ * affine-invariant / log-Euclidean ones, more dynamic LDS than a block has - or an instantiation this build of the library leaves out
+ * (-DGABO_LE_MAX_GENERIC_DIM, csrc/spd_tr_body.hpp).  lift_dim: as in gabo_spd_tr_solve, 0 without nested kinds. */
 int gabo_spd_tr_solve_supported(const gabo_spd_acq_params* acq, int64_t r, int d, int n_constraints, int lift_dim);
 
 /* ------------------------------------------------------------------------------------------------------------
