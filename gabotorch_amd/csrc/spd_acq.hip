@@ -59,7 +59,7 @@ int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const
     {
         const int out = flags & GABO_OUT_MASK, metric = flags & GABO_METRIC_MASK;
         if ((flags & ~(GABO_OUT_MASK | GABO_METRIC_MASK)) || (out != GABO_OUT_GAUSSIAN && out != GABO_OUT_LAPLACE)) return GABO_ERR_ARG;
-        if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN) return GABO_ERR_ARG;
+        if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN && metric != GABO_METRIC_FROBENIUS) return GABO_ERR_ARG;
         if (metric != GABO_METRIC_AFFINE_INVARIANT && (out != GABO_OUT_GAUSSIAN || d > 8)) return d > 8 ? GABO_ERR_DIM : GABO_ERR_ARG;
     }
     if (kind != GABO_ACQ_EXPECTED_IMPROVEMENT && kind != GABO_ACQ_POSTERIOR_MEAN) return GABO_ERR_ARG;
@@ -73,6 +73,7 @@ int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const
     switch (flags & GABO_METRIC_MASK) {
         case GABO_METRIC_AFFINE_INVARIANT: return gabo::acq_affine_invariant(a);
         case GABO_METRIC_LOG_EUCLIDEAN: return gabo::acq_log_euclidean(a);
+        case GABO_METRIC_FROBENIUS: return gabo::acq_frobenius(a);
     }
     return GABO_ERR_DIM;
 }

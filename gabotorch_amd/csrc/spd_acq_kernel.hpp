@@ -49,5 +49,6 @@ static int dispatch_acq(const AcqLaunch& a) {
 
 int acq_affine_invariant(const AcqLaunch& a);
 int acq_log_euclidean(const AcqLaunch& a);
+int acq_frobenius(const AcqLaunch& a);
 
 }  // namespace gabo

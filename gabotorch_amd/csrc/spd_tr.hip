@@ -62,6 +62,7 @@ int gabo_spd_tr_propose_supported(int flags, int d) {
     const int metric = flags & GABO_METRIC_MASK;
     if (metric == GABO_METRIC_AFFINE_INVARIANT) return d >= 2 && d <= GABO_SPD_REG_MAX_DIM;
     if (metric == GABO_METRIC_LOG_EUCLIDEAN) return d >= 2 && d <= (GABO_LE_MAX_GENERIC_DIM >= 8 ? 8 : 7);       /* (d = 8: spd_tr_le_hi.hip) */
+    if (metric == GABO_METRIC_FROBENIUS) return d >= 2 && d <= 8;
     return 0;
 }
 
@@ -81,7 +82,7 @@ int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust
     if (acq->kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!acq->linv || !acq->linv_t)) return GABO_ERR_ARG;
     {
         const int metric = acq->flags & GABO_METRIC_MASK;
-        if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN) return GABO_ERR_ARG;
+        if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN && metric != GABO_METRIC_FROBENIUS) return GABO_ERR_ARG;
         if (!gabo_spd_tr_propose_supported(acq->flags, d)) return GABO_ERR_DIM;
     }
     if (workspace_bytes < gabo_spd_tr_workspace_bytes(r, d, n_constraints, acq->n)) return GABO_ERR_ARG;
@@ -90,6 +91,7 @@ int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust
     switch (acq->flags & GABO_METRIC_MASK) {
         case GABO_METRIC_AFFINE_INVARIANT: return gabo::propose_affine_invariant(a);
         case GABO_METRIC_LOG_EUCLIDEAN: return gabo::propose_log_euclidean(a);
+        case GABO_METRIC_FROBENIUS: return gabo::propose_frobenius(a);
     }
     return GABO_ERR_DIM;
 }
@@ -113,7 +115,7 @@ int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, d
 int gabo_spd_tr_solve_supported(const gabo_spd_acq_params* acq, int64_t r, int d, int n_constraints, int lift_dim) {
     if (!acq || d < 2 || d > 8 || r < 1 || n_constraints < 0 || n_constraints > gabo::kMaxCons) return 0;
     const int metric = acq->flags & GABO_METRIC_MASK;
-    if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN) return 0;
+    if (metric != GABO_METRIC_AFFINE_INVARIANT && metric != GABO_METRIC_LOG_EUCLIDEAN && metric != GABO_METRIC_FROBENIUS) return 0;
     if (acq->n < 1 || acq->n > gabo_spd_acq_max_train(d)) return 0;
     const size_t nested_bytes = lift_dim > 0 ? gabo::nested_extremes_lds_doubles(lift_dim, d) * sizeof(double) : 0;
 #ifdef GABO_TR_NO_LAT
@@ -121,7 +123,7 @@ int gabo_spd_tr_solve_supported(const gabo_spd_acq_params* acq, int64_t r, int d
 #else
     const bool has_factors = acq->linv && acq->linv_t;
 #endif
-    return gabo::solve_supported(metric == GABO_METRIC_LOG_EUCLIDEAN ? 1 : 0, acq->n, r, d, n_constraints, has_factors, nested_bytes) ? 1 : 0;
+    return gabo::solve_supported(metric == GABO_METRIC_LOG_EUCLIDEAN ? 1 : metric == GABO_METRIC_FROBENIUS ? 2 : 0, acq->n, r, d, n_constraints, has_factors, nested_bytes) ? 1 : 0;
 }
 
 int gabo_tr_solve_record(double* buffer, int64_t max_iterations) {
@@ -173,8 +175,9 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
     switch (acq->flags & GABO_METRIC_MASK) {
         case GABO_METRIC_AFFINE_INVARIANT: return gabo::solve_affine_invariant(a);
         case GABO_METRIC_LOG_EUCLIDEAN: return gabo::solve_log_euclidean(a);
+        case GABO_METRIC_FROBENIUS: return gabo::solve_frobenius(a);
     }
-    return GABO_ERR_ARG;      /* (the Frobenius surrogate iterates through gabo_spd_tr_propose / gabo_spd_tr_update) */
+    return GABO_ERR_ARG;
 }
 
 }  // extern "C"

@@ -680,5 +680,7 @@ int solve_log_euclidean(const SolveArgs& a);
 int propose_affine_invariant(const ProposeArgs& a);
 int propose_affine_invariant_wide(const ProposeArgs& a);      // d = 9..12 (spd_tr_wide.hip)
 int propose_log_euclidean(const ProposeArgs& a);
+int propose_frobenius(const ProposeArgs& a);                  // spd_tr_frob.hip
+int solve_frobenius(const SolveArgs& a);                      // spd_tr_solve_frob.hip
 
 }  // namespace gabo

@@ -65,8 +65,7 @@ class FusedAcquisition:
             self.kxx = 1.0
             self.train_feat = ops.spd_logm_mandel(self.train) if flavour == "le" else self.train
             d_spd = ops._mandel_dim(self.train.shape[-1])
-            if (flavour == "le" and d_spd <= 8 and self.train.shape[0] <= _lib.load().gabo_spd_acq_max_train(d_spd)
-                    and mode == _lib.GABO_OUT_GAUSSIAN):
+            if (d_spd <= 8 and self.train.shape[0] <= _lib.load().gabo_spd_acq_max_train(d_spd) and mode == _lib.GABO_OUT_GAUSSIAN):
                 # one launch per evaluation for these too: the "factors" are the training features, entry-major
                 self.single_launch = True
                 self.train_factors = self.train_feat.t().contiguous()

@@ -520,8 +520,7 @@ class BatchedTrustRegions:
         if fused_kernels:
             from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint, builtin_lift
             builtins = [builtin_constraint(c) for c in cons]
-            solve_ok = (ncons == 0) if sphere else (d <= 8 and neq == 0 and all(b is not None for b in builtins)
-                                                    and fused.metric != _lib_frobenius())
+            solve_ok = (ncons == 0) if sphere else (d <= 8 and neq == 0 and all(b is not None for b in builtins))
             lift = builtin_lift(builtins) if (solve_ok and not sphere) else None      # the nested kinds' mapping (one for all of them)
             solve_ok = solve_ok and lift is not False
             if solve_ok and not sphere:

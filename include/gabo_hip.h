@@ -39,8 +39,9 @@ typedef void* gabo_stream_t; /* hipStream_t */
 /* distance used by the fused acquisition kernels (gabo_spd_acq_params.flags, OR-ed with GABO_OUT_GAUSSIAN / GABO_OUT_LAPLACE) */
 #define GABO_METRIC_AFFINE_INVARIANT 0
 #define GABO_METRIC_LOG_EUCLIDEAN 8   /* kernels_spd.py:244-313; Gaussian only, d <= 8 */
-#define GABO_METRIC_FROBENIUS 16      /* kernels_spd.py:190-241: reserved - this surrogate is served by the separate-launch chain
-                                         (gabo_frobenius_pairwise -> gabo_gp_acquisition -> gabo_frobenius_backward) */
+#define GABO_METRIC_FROBENIUS 16      /* kernels_spd.py:190-241; Gaussian only, d <= 8 in the fused acquisition / trust-region kernels (round 5; larger d
+                                         and the Laplace form: the separate-launch chain gabo_frobenius_pairwise -> gabo_gp_acquisition ->
+                                         gabo_frobenius_backward); train_factors = the Mandel vectors of the training points, entry-major */
 #define GABO_METRIC_MASK 24
 
 /* SPD pairwise kernels: 2 <= d <= GABO_SPD_MAX_DIM.  The forward runs the register-resident lane-per-pair kernels (the fast path,
@@ -446,7 +447,7 @@ int gabo_spd_tr_propose(const double* x, const double* grad, const double* trust
                         size_t workspace_bytes, double* x_prop, int64_t r, int d, int n_constraints, int n_equalities, double delta_cons,
                         double theta, double kappa, int mininner, int maxinner, int* any_active, int* status, gabo_stream_t stream);
 /* 1 when gabo_spd_tr_propose / gabo_spd_tr_update iterate a surrogate with these GABO_METRIC_* / GABO_OUT_* flags at dimension d:
- * affine-invariant 2 ... 12, log-Euclidean 2 ... 8.  Otherwise the caller composes the iteration from gabo_spd_tcg_* and gabo_spd_acq_eval
+ * affine-invariant 2 ... 12, log-Euclidean and Frobenius 2 ... 8.  Otherwise the caller composes the iteration from gabo_spd_tcg_* and gabo_spd_acq_eval
  * (or, where gabo_spd_tr_solve_supported, runs the single launch). */
 int gabo_spd_tr_propose_supported(int flags, int d);
 int gabo_spd_tr_update(double* x, double* fx, double* grad, double* grad_norm, double* trust_radius, uint8_t* active, int64_t* iters,
@@ -475,8 +476,7 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
                       int64_t maxiter, const double* lift_w, const double* lift_p, const double* lift_x0, int lift_dim, int* status,
                       gabo_stream_t stream);
 /* 1 when gabo_spd_tr_solve runs this problem in its single launch, 0 when the caller has to iterate through gabo_spd_tr_propose /
- * gabo_spd_tr_update instead (same results, two launches per iteration): d outside 2 ... 8, a surrogate metric other than the
- * affine-invariant / log-Euclidean ones, more dynamic LDS than a block has - or an instantiation this build of the library leaves out
+ * gabo_spd_tr_update instead (same results, two launches per iteration): d outside 2 ... 8, an unknown surrogate metric, more dynamic LDS than a block has - or an instantiation this build of the library leaves out
  * (-DGABO_LE_MAX_GENERIC_DIM, csrc/spd_tr_body.hpp).  lift_dim: as in gabo_spd_tr_solve, 0 without nested kinds. */
 int gabo_spd_tr_solve_supported(const gabo_spd_acq_params* acq, int64_t r, int d, int n_constraints, int lift_dim);
 

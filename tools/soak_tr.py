@@ -16,7 +16,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gabotorch_amd import manifolds, models, ops                                                       # noqa: E402
-from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel, SpdLogEuclideanGaussianKernel   # noqa: E402
+from gabotorch_amd.kernel_utils.kernels_spd import (SpdAffineInvariantGaussianKernel, SpdFrobeniusGaussianKernel,  # noqa: E402
+                                                    SpdLogEuclideanGaussianKernel)
 from gabotorch_amd.kernel_utils.kernels_sphere import SphereGaussianKernel                             # noqa: E402
 from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions              # noqa: E402
 from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold              # noqa: E402
@@ -54,13 +55,14 @@ def walk(ref, got, atol):
 def spd_case(rng):
     d = int(rng.choice([2, 3, 4, 5, 6, 7, 8]))
     n = int(rng.integers(4, 60))
-    le = bool(rng.integers(0, 2))
+    flav = int(rng.integers(0, 5))          # 0, 1: affine-invariant; 2, 3: log-Euclidean; 4: Frobenius
+    le, frob = flav in (2, 3), flav == 4
     q = np.linalg.qr(rng.standard_normal((n, d, d)))[0]
     Xm = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (n, d)), q)
     X = ospd.symmetric_matrix_to_vector_mandel(0.5 * (Xm + Xm.transpose(0, 2, 1)))
     y = np.log(np.linalg.eigvalsh(Xm)).sum(1) ** 2 + 0.1 * rng.standard_normal(n)
-    if le:
-        kern = SpdLogEuclideanGaussianKernel().double()
+    if le or frob:
+        kern = (SpdLogEuclideanGaussianKernel if le else SpdFrobeniusGaussianKernel)().double()
         kern.lengthscale = torch.tensor(float(rng.uniform(0.8, 2.0)), dtype=torch.float64)
     else:
         kern = SpdAffineInvariantGaussianKernel(beta_min=float(rng.uniform(0.2, 0.8)))
@@ -77,7 +79,7 @@ def spd_case(rng):
         cons = [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=float(rng.uniform(2.3, 3.0)))]
     if kind == 2:
         cons.append(functools.partial(scut.min_eigenvalue_constraint_torch, minimum_eigenvalue=float(rng.uniform(0.2, 0.45))))
-    desc = f"S^{d}_++ {'LE' if le else 'AI'} n={n} {type(acq).__name__} cons={kind} strict={strict}"
+    desc = f"S^{d}_++ {'LE' if le else 'Frob' if frob else 'AI'} n={n} {type(acq).__name__} cons={kind} strict={strict}"
     return desc, acq, manifolds.PositiveDefinite(d), x0, cons, strict, dict(pre_processing_manifold=to_mat, post_processing_manifold=to_vec, approx_hessian=True)
 
 
