@@ -13,7 +13,6 @@ from gabotorch_amd import models, ops
 from gabotorch_amd.fused_acquisition import FusedAcquisition
 from gabotorch_amd.kernel_utils.kernels_spd import SpdLogEuclideanGaussianKernel
 from gabotorch_amd.Riemannian_utils.spd_utils_torch import symmetric_matrix_to_vector_mandel_torch as to_vec
-from oracle import spd as ospd
 DEV = "cuda:0"
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV)
 out = {}
@@ -22,7 +21,7 @@ for d in range(2, 9):
     n = 40
     q = np.linalg.qr(rng.standard_normal((n, d, d)))[0]
     Xm = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (n, d)), q)
-    X = ospd.symmetric_matrix_to_vector_mandel(0.5 * (Xm + Xm.transpose(0, 2, 1)))
+    X = ops.matrix_to_mandel(t(0.5 * (Xm + Xm.transpose(0, 2, 1)))).cpu().numpy()
     y = np.log(np.linalg.eigvalsh(Xm)).sum(1) ** 2 + 0.1 * rng.standard_normal(n)
     kern = SpdLogEuclideanGaussianKernel().double(); kern.lengthscale = torch.tensor(1.4, dtype=torch.float64)
     gp = models.ExactGP(t(X), t(y), kern, outputscale=1.0, noise=1e-2)

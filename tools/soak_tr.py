@@ -24,7 +24,6 @@ from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates
 from gabotorch_amd.Riemannian_utils import spd_constraints_utils_torch as scut                         # noqa: E402
 from gabotorch_amd.Riemannian_utils.spd_utils_torch import (symmetric_matrix_to_vector_mandel_torch as to_vec,  # noqa: E402
                                                             vector_to_symmetric_matrix_mandel_torch as to_mat)
-from oracle import spd as ospd                                                                         # noqa: E402  (tools/: a checker, not the product)
 
 DEV = "cuda:0"
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV)      # noqa: E731
@@ -59,7 +58,7 @@ def spd_case(rng):
     le, frob = flav in (2, 3), flav == 4
     q = np.linalg.qr(rng.standard_normal((n, d, d)))[0]
     Xm = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.2, 3.0, (n, d)), q)
-    X = ospd.symmetric_matrix_to_vector_mandel(0.5 * (Xm + Xm.transpose(0, 2, 1)))
+    X = ops.matrix_to_mandel(t(0.5 * (Xm + Xm.transpose(0, 2, 1)))).cpu().numpy()
     y = np.log(np.linalg.eigvalsh(Xm)).sum(1) ** 2 + 0.1 * rng.standard_normal(n)
     if le or frob:
         kern = (SpdLogEuclideanGaussianKernel if le else SpdFrobeniusGaussianKernel)().double()
