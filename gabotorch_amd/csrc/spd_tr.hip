@@ -139,6 +139,11 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
                       int mininner, int maxinner, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
                       int64_t maxiter, const double* lift_w, const double* lift_p, const double* lift_x0, int lift_dim, int* status,
                       gabo_stream_t stream) {
+    // (a pending record buffer belongs to THIS call whether it launches or not: taken before any early return, so that a call refused for its
+    // arguments cannot leave the pointer to a later, unrelated solve)
+    double* rec = nullptr;
+    int64_t rec_cap = 0;
+    gabo::tr_record_take(&rec, &rec_cap);
     if (d < 2 || d > 8) return GABO_ERR_DIM;
     if (r < 0 || r > 0x7fffffffLL || n_constraints < 0 || n_constraints > gabo::kMaxCons || maxinner < 1 || maxiter < 1 || !acq)
         return GABO_ERR_ARG;
@@ -171,7 +176,8 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
     // test hook: GABO_TR_NO_SHORTCUTS in the environment runs every iteration in full (no value-first evaluation after a rejection, no reuse of
     // an identical step's proposal): the two forms must agree bit for bit (tests/test_gpu_native_sweep.py)
     a.shortcuts = getenv("GABO_TR_NO_SHORTCUTS") ? 0 : 1;
-    gabo::tr_record_take(&a.rec, &a.rec_cap);
+    a.rec = rec;
+    a.rec_cap = rec_cap;
     switch (acq->flags & GABO_METRIC_MASK) {
         case GABO_METRIC_AFFINE_INVARIANT: return gabo::solve_affine_invariant(a);
         case GABO_METRIC_LOG_EUCLIDEAN: return gabo::solve_log_euclidean(a);

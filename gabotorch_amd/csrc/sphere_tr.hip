@@ -595,6 +595,9 @@ int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm,
                          const gabo_sphere_acq_params* acq, void* workspace, size_t workspace_bytes, int64_t r, double theta, double kappa,
                          int mininner, int maxinner, int exact_hessian, double delta_bar, double rho_prime, double rho_regularization,
                          double mingradnorm, int64_t maxiter, gabo_stream_t stream) {
+    double* rec = nullptr;
+    int64_t rec_cap = 0;
+    gabo::tr_record_take(&rec, &rec_cap);                 // gabo_tr_solve_record (spd_tr.hip): consumed by this call whether it launches or not
     int rc = gabo::sph_acq_ok(acq);
     if (rc != GABO_OK) return rc;
     if (r < 0 || r > 0x7fffffffLL || maxinner < 1 || maxiter < 1) return GABO_ERR_ARG;
@@ -602,9 +605,6 @@ int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm,
     if (!x || !fx || !grad || !grad_norm || !trust_radius || !active || !iters || !workspace) return GABO_ERR_ARG;
     if (workspace_bytes < gabo_sphere_tr_workspace_bytes(r, acq->dim, 0)) return GABO_ERR_ARG;
     size_t lds = (size_t)(7 * acq->n + 6 * acq->dim) * sizeof(double);
-    double* rec = nullptr;
-    int64_t rec_cap = 0;
-    gabo::tr_record_take(&rec, &rec_cap);                 // gabo_tr_solve_record (spd_tr.hip)
     hipLaunchKernelGGL(gabo::sphere_tr_solve_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, fx, grad, grad_norm,
                        trust_radius, active, iters, *acq, workspace, r, theta, kappa, mininner, maxinner, delta_bar, rho_prime,
                        rho_regularization, mingradnorm, maxiter, exact_hessian, rec, rec_cap);

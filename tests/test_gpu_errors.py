@@ -62,3 +62,35 @@ def test_device_solve_reports_a_non_spd_start():
     with pytest.raises(RuntimeError, match="not positive definite"):
         gen_candidates_manifold(bad[:, None], acq, manifolds.PositiveDefinite(3), BatchedTrustRegions(maxiter=3),
                                 vector_to_symmetric_matrix_mandel_torch, symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
+
+
+def test_a_refused_solve_consumes_its_record_buffer():
+    """gabo_tr_solve_record hands ONE pending buffer to the next single-launch solve.  A solve that is refused for its arguments must still
+    consume it - otherwise the pointer would be written by a later, unrelated solve (possibly after the tensor is gone)."""
+    from gabotorch_amd import manifolds, models
+    from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions
+    from gabotorch_amd.manifold_optimization.manifold_optimize import gen_candidates_manifold
+    from gabotorch_amd.Riemannian_utils.spd_utils_torch import symmetric_matrix_to_vector_mandel_torch, vector_to_symmetric_matrix_mandel_torch
+    lib = _lib.load()
+    buf = torch.full((4, 3, 11), float("nan"), dtype=torch.float64, device=DEV)
+    assert lib.gabo_tr_solve_record(buf.data_ptr(), 4) == _lib.GABO_OK
+    # refused: d = 1
+    assert lib.gabo_spd_tr_solve(None, None, None, None, None, None, None, None, 0, None, None, 0, None, 0, 3, 1, 1e-6, 1.0, 0.1, 1, 3, 1.0, 0.1,
+                                 1e3, 1e-6, 10, None, None, None, 0, None, None) == _lib.GABO_ERR_DIM
+    rng = np.random.default_rng(0)
+    q = np.linalg.qr(rng.standard_normal((8, 3, 3)))[0]
+    Xm = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.5, 2.0, (8, 3)), q)
+    xv = symmetric_matrix_to_vector_mandel_torch(torch.tensor(Xm, device=DEV))
+    gp = models.ExactGP(xv, torch.tensor(rng.standard_normal(8), device=DEV), SpdAffineInvariantGaussianKernel(beta_min=0.5), outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=0.0, maximize=False)
+    solver = BatchedTrustRegions(maxiter=3)
+    gen_candidates_manifold(xv[:3, None], acq, manifolds.PositiveDefinite(3), solver, vector_to_symmetric_matrix_mandel_torch,
+                            symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
+    torch.cuda.synchronize()
+    assert "one_launch_solve" in solver.log and bool(torch.isnan(buf).all())
+    # and withdrawing a pending buffer works
+    assert lib.gabo_tr_solve_record(buf.data_ptr(), 4) == _lib.GABO_OK and lib.gabo_tr_solve_record(None, 0) == _lib.GABO_OK
+    gen_candidates_manifold(xv[:3, None], acq, manifolds.PositiveDefinite(3), solver, vector_to_symmetric_matrix_mandel_torch,
+                            symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(buf).all())
