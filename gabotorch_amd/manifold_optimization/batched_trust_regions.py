@@ -13,16 +13,11 @@ import time
 
 import torch
 
-def _lib_frobenius():
-    from .. import _lib
-    return _lib.GABO_METRIC_FROBENIUS
-
-
 NEGATIVE_CURVATURE, EXCEEDED_TR, REACHED_TARGET_LINEAR, REACHED_TARGET_SUPERLINEAR, MAX_INNER_ITER, MODEL_INCREASED, \
     REACHED_CONSTRAINTS = range(7)
 
 
-def self_lib():
+def _library():
     from .. import _lib
     return _lib.load()
 
@@ -516,7 +511,7 @@ class BatchedTrustRegions:
         fused_kernels = getattr(fused, "single_launch", False) and getattr(problem, "device_iteration", True) and not self.use_rand
         # (the library says which of its iteration kernels exist for this surrogate: e.g. no propose / update pair for the log-Euclidean
         # surrogate at d = 8, csrc/spd_tr_le_hi.hip, and no generic-workspace single launch for it at d = 7, 8, csrc/spd_tr_body.hpp)
-        propose_ok = bool(fused_kernels and (sphere or self_lib().gabo_spd_tr_propose_supported(int(fused.mode) | int(fused.metric), d)))
+        propose_ok = bool(fused_kernels and (sphere or _library().gabo_spd_tr_propose_supported(int(fused.mode) | int(fused.metric), d)))
         if fused_kernels:
             from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint, builtin_lift
             builtins = [builtin_constraint(c) for c in cons]
@@ -526,7 +521,7 @@ class BatchedTrustRegions:
             if solve_ok and not sphere:
                 # (the library's own word: e.g. no single-launch form of the log-Euclidean surrogate at d = 7, 8 beyond what its LDS holds)
                 import ctypes
-                solve_ok = bool(self_lib().gabo_spd_tr_solve_supported(ctypes.byref(fused.acq_params()), R, d, ncons,
+                solve_ok = bool(_library().gabo_spd_tr_solve_supported(ctypes.byref(fused.acq_params()), R, d, ncons,
                                                                        0 if lift is None else int(lift[0].shape[0])))
             one_launch = bool(solve_ok and getattr(problem, "device_solve", True) and self.maxtime >= 1000)
         fused_iteration = propose_ok or one_launch
@@ -649,8 +644,8 @@ class BatchedTrustRegions:
                 return {"x_prop": xp}
 
             # (where the record below finds the stop reasons of the last tCG run; TcgWs: stop, then running)
-            stop_off = (self_lib().gabo_sphere_tr_stop_offset(R, d, ncons) // 4 if sphere
-                        else self_lib().gabo_spd_tcg_running_offset(R, d, ncons) // 4 - R)
+            stop_off = (_library().gabo_sphere_tr_stop_offset(R, d, ncons) // 4 if sphere
+                        else _library().gabo_spd_tcg_running_offset(R, d, ncons) // 4 - R)
 
             def part_b(A):          # noqa: F811
                 if self.trace is not None:
