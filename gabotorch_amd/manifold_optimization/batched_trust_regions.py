@@ -22,6 +22,16 @@ def _library():
     return _lib.load()
 
 
+def _library_constraint_quick(con):
+    """this package's own eigenvalue constraints bound by functools.partial: batch-safe by construction (and possibly under graph capture,
+    where a host-side comparison could not run)"""
+    try:
+        from .manifold_optimize import _library_constraint
+        return bool(_library_constraint(con))
+    except Exception:       # noqa: BLE001
+        return False
+
+
 def _bm(mask, like):
     """broadcast a (R,) mask / scalar-per-restart tensor against (R, ...)"""
     return mask.reshape(mask.shape + (1,) * (like.dim() - mask.dim()))
@@ -307,6 +317,30 @@ class BatchedTrustRegions:
         return [b[0] == _lib.GABO_CONSTRAINT_MAX_EIGENVALUE_NESTED for b in info], [b[1] for b in info], memo[1]
 
     @staticmethod
+    def _call_constraint(con, x):
+        """Values (R,) of one user constraint at the R points x.  The reference's convention is a callable of ONE point (`x[1] - yc`,
+        gabo_sphere_equality_constraints.py:106-107); a callable written for a batch (`x[..., 1] - yc`) saves R - 1 calls.  The batched call is
+        accepted only if it has the batch's shape AND agrees with the single-point call at the first and the last restart: a one-point
+        callable applied to the batch can return the right SHAPE with the wrong meaning (`x[1] - yc` on an R x dim batch is row 1, of length
+        dim - which passes a shape test whenever the number of restarts equals the dimension)."""
+        R = x.shape[0]
+        try:
+            f = con(x)
+            ok = torch.is_tensor(f) and f.shape == x.shape[:1]
+        except (IndexError, ValueError, TypeError, RuntimeError):
+            ok = False
+        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()      # (capture_constraints=True: the caller vouches for the callable)
+        if ok and not capturing and not _library_constraint_quick(con):
+            with torch.no_grad():
+                ends = torch.stack([torch.as_tensor(con(x[i])).reshape(()) for i in sorted({0, R - 1})]).to(f.dtype)
+                got = f.detach()[sorted({0, R - 1})]
+                ok = bool(torch.allclose(got, ends, rtol=1e-9, atol=1e-12, equal_nan=True))
+        if not ok:
+            # one point at a time (a genuine error in the callable is raised again by these calls)
+            f = torch.stack([torch.as_tensor(con(x[i])).reshape(()) for i in range(R)])
+        return f
+
+    @staticmethod
     def _constraint_values_grads(problem, x, constraints):
         """-> fc (R, C), rgrad (C tensors of shape R x *shape)"""
         group = BatchedTrustRegions._nested_group(x, constraints)
@@ -321,14 +355,7 @@ class BatchedTrustRegions:
         for con in constraints:
             xx = x.detach().clone().requires_grad_(True)
             with torch.enable_grad():
-                try:
-                    f = con(xx)
-                    if f.shape != x.shape[:1]:
-                        raise IndexError
-                except (IndexError, ValueError, TypeError, RuntimeError):
-                    # a user callable written for ONE point (the reference's convention): evaluate restart by restart - a genuine
-                    # error in the callable is raised again by this second call
-                    f = torch.stack([con(xx[i]) for i in range(x.shape[0])])
+                f = BatchedTrustRegions._call_constraint(con, xx)
                 (g,) = torch.autograd.grad(f.sum(), xx, allow_unused=True)
             if g is None:
                 g = torch.zeros_like(x)
@@ -348,13 +375,7 @@ class BatchedTrustRegions:
         vals = []
         with torch.no_grad():
             for con in constraints:
-                try:
-                    f = con(x)
-                    if f.shape != x.shape[:1]:
-                        raise IndexError
-                except (IndexError, ValueError, TypeError, RuntimeError):      # a user callable written for one point (see above)
-                    f = torch.stack([con(x[i]) for i in range(x.shape[0])])
-                vals.append(f.detach().to(x.dtype))
+                vals.append(BatchedTrustRegions._call_constraint(con, x).detach().to(x.dtype))
         return torch.stack(vals, dim=1)
 
     # ------------------------------------------------------------------------------------------------- solve

@@ -168,3 +168,32 @@ def test_plugin_api_namespaces_expose_the_names_the_examples_import():
     lik = gpytorch.likelihoods.gaussian_likelihood.GaussianLikelihood(noise_prior=prior, noise_constraint=gpytorch.constraints.GreaterThan(1e-8),
                                                                      initial_value=2.0)
     assert lik.initial_value == 2.0
+
+
+def test_one_point_constraint_callables_when_restarts_equal_dimension(golden):
+    """The reference's constraint callables take ONE point (`x[1] - yc`, gabo_sphere_equality_constraints.py:106-107).  Applied to the
+    R x dim batch of the lock-step solver such a callable returns row 1 - a vector of length dim, which has the batch's shape exactly when
+    the number of restarts equals the dimension (5 restarts on S^4: the examples' num_restarts with dim = 5 of their beta_min ladder).  A shape
+    test alone accepted that until round 5; the batched call is now also compared with the single-point call at both ends of the batch."""
+    g = golden("tr_traces.npz")
+    n = 5
+    Y, w, beta = T_(g["sph5_Y"]), T_(g["sph5_w"]), float(g["sph5_beta"])
+    rng = np.random.default_rng(8)
+    x0 = rng.standard_normal((n, n))                 # R = dim = 5
+    x0[:, 1] = 0.0
+    x0 /= np.linalg.norm(x0, axis=1, keepdims=True)
+    out = {}
+    for name, con in (("one_point", lambda x: x[1] - 0.0), ("batch_safe", lambda x: x[..., 1] - 0.0)):
+        prob = BatchedProblem(CpuSphere(n), sphere_kernel_mean_cost(Y, w, beta), approx_hessian=False)
+        solver = ConstrainedTrustRegions(mingradnorm=1e-6, maxiter=25)
+        x = solver.solve(prob, T_(x0), eq_constraints=[con])
+        out[name] = (x.numpy(), solver.log["per_restart_iterations"].numpy())
+        vals = BatchedTrustRegions._constraint_values(T_(x0 + 0.01), [con]).numpy()[:, 0]
+        np.testing.assert_allclose(vals, (x0 + 0.01)[:, 1], rtol=0, atol=1e-15)          # each restart's OWN coordinate 1
+    np.testing.assert_array_equal(out["one_point"][1], out["batch_safe"][1])
+    np.testing.assert_allclose(out["one_point"][0], out["batch_safe"][0], rtol=0, atol=1e-12)
+    assert np.abs(out["one_point"][0][:, 1]).max() < 1e-5                                 # the equality holds at the end (to Delta_cons)
+
+
+def T_(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64)
