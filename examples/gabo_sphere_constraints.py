@@ -7,8 +7,9 @@ selects - AugmentedLagrangeMethod(maxiter=200, inner_solver=TrustRegions(maxiter
 
     python examples/gabo_sphere_constraints.py --kind equality|inequality|bounds [--solver ALM|CTR] [--iters 10]
 
-The augmented-Lagrangian method is driven restart by restart on the host, as the reference drives it (manifold_optimize.py:207-220): the
-acquisition it evaluates is still the HIP kernels'.  ConstrainedTrustRegions runs all restarts in lock step on the device.
+The augmented-Lagrangian method runs on all restarts in lock step (its inner trust-region solves batched, the acquisition through the fused
+HIP evaluation; `options={"batched_alm": False}`: restart by restart on the host, as the reference drives it, manifold_optimize.py:207-220) -
+both reproduce the reference's own outer iterates (tests/test_gpu_alm.py).  ConstrainedTrustRegions runs all restarts in lock step on the device.
 """
 import argparse
 import os

@@ -154,3 +154,136 @@ class AugmentedLagrangeMethod:
         self.log = {"iterations": k, "stop_reason": reason, "violation": oldacc, "rho": rho, "time": time.time() - time0,
                     "lambdas": lambdas, "gammas": gammas}
         return (xbest, self.log) if self._logverbosity >= 1 else xbest
+
+
+class _BatchedSubproblem:
+    """The subproblem of every restart at once, for the lock-step trust regions: cost and gradient of the wrapped batched problem (the fused
+    acquisition evaluation when it has one) plus the penalty terms (:273-317, autograd through the constraint callables), and - as the
+    reference binds it (:324) - the finite-difference Hessian of the ORIGINAL problem.  lambdas: R x n_ineq, gammas: R x n_eq, rho: R."""
+    approx_hessian = True
+    fused = None
+    use_hip_graphs = False
+
+    def __init__(self, problem, eqs, ineqs, lambdas, gammas, rho):
+        self.problem, self.eqs, self.ineqs, self.lambdas, self.gammas, self.rho = problem, eqs, ineqs, lambdas, gammas, rho
+        self.manifold, self.precon = problem.manifold, problem.precon
+        self.n_cost = self.n_grad = 0
+
+    def _penalty(self, x, need_grad):
+        """-> (penalty R, its Euclidean gradient or None).  The gradient is assembled per constraint as the reference does (:290-317) - an
+        inequality contributes (g rho - lambda) grad g ONLY where lambda / rho - g > 0 - and not by differentiating the clamped square: where
+        a constraint is inactive its gradient is never looked at, and it may be infinite there (the cap constraint angle - acos<x, c> at its
+        own centre: 0 x inf inside autograd would be NaN)."""
+        import torch
+
+        from .batched_trust_regions import BatchedTrustRegions
+        R = x.shape[0]
+        bm = lambda m: m.reshape((R,) + (1,) * (x.dim() - 1))      # noqa: E731
+        p = torch.zeros(R, dtype=x.dtype, device=x.device)
+        g = torch.zeros_like(x) if need_grad else None
+
+        def value_and_grad(con):
+            xx = x.detach().clone().requires_grad_(need_grad)
+            with torch.set_grad_enabled(need_grad):
+                v = BatchedTrustRegions._call_constraint(con, xx).to(x.dtype)
+                gv = None
+                if need_grad:
+                    (gv,) = torch.autograd.grad(v.sum(), xx, allow_unused=True)
+                    gv = torch.zeros_like(x) if gv is None else gv
+            return v.detach(), gv
+        for k, con in enumerate(self.ineqs):           # (:279-282, :295-307: g >= 0 is satisfied)
+            v, gv = value_and_grad(con)
+            slack = self.lambdas[:, k] / self.rho - v
+            act = slack > 0
+            p = p + torch.where(act, self.rho / 2.0 * slack ** 2, torch.zeros_like(p))
+            if need_grad:
+                g = g + torch.where(bm(act), bm(v * self.rho - self.lambdas[:, k]) * gv, torch.zeros_like(gv))
+        for k, con in enumerate(self.eqs):             # (:284-287, :309-317)
+            v, gv = value_and_grad(con)
+            p = p + self.rho / 2.0 * (self.gammas[:, k] / self.rho + v) ** 2
+            if need_grad:
+                g = g + bm(v * self.rho + self.gammas[:, k]) * gv
+        return p, g
+
+    def cost(self, x):
+        self.n_cost += 1
+        return self.problem.cost(x) + self._penalty(x, False)[0]
+
+    def cost_egrad(self, x, create_graph=False):
+        self.n_grad += 1
+        f, eg, xx = self.problem.cost_egrad(x)
+        p, g = self._penalty(x, True)
+        return f + p, eg.detach() + g, xx
+
+    def cost_grad(self, x):
+        f, eg, _ = self.cost_egrad(x)
+        return f, self.manifold.egrad2rgrad(x, eg)
+
+    def grad(self, x):
+        return self.cost_grad(x)[1]
+
+    def hess(self, x, u, grad_x=None):
+        return self.problem.hess(x, u)              # (the original problem's own gradient differences: `grad_x` is the subproblem's)
+
+
+def _solve_batched(self, problem, x, eq_constraints=None, ineq_constraints=None):
+    """The method on ALL restarts in lock step (R x point tensors, the inner solver one of this package's trust regions): the same updates
+    per restart as `solve` - which is the reference's loop (:66-225) and stays the statement tests pin to the reference's record - with the
+    inner solves batched.  A restart that has met its stopping criterion keeps its point while the others go on.  problem: BatchedProblem."""
+    import torch
+    man = problem.manifold
+    eqs = [] if eq_constraints is None else (list(eq_constraints) if isinstance(eq_constraints, (list, tuple)) else [eq_constraints])
+    ineqs = [] if ineq_constraints is None else (list(ineq_constraints) if isinstance(ineq_constraints, (list, tuple)) else [ineq_constraints])
+    from .batched_trust_regions import BatchedTrustRegions
+    R, dt, dev = x.shape[0], x.dtype, x.device
+    full = lambda cols, v: torch.full((R, cols), float(v), dtype=dt, device=dev)      # noqa: E731
+    lambdas, gammas = full(len(ineqs), self._lambdas_fact), full(len(eqs), self._gammas_fact)
+    rho = torch.full((R,), float(self._rho_init), dtype=dt, device=dev)
+    oldacc = torch.full((R,), float("inf"), dtype=dt, device=dev)
+    tol = self._starting_tolgradnorm
+    theta_tol = (self._ending_tolgradnorm / self._starting_tolgradnorm) ** (1.0 / self._maxiter)
+    active = torch.ones(R, dtype=torch.bool, device=dev)
+    xbest = x.detach().clone()
+    xprev = xbest
+    bm = lambda m: m.reshape((R,) + (1,) * (xbest.dim() - 1))      # noqa: E731
+    time0 = time.time()
+    k = 0
+    outer = torch.zeros(R, dtype=torch.long, device=dev)
+    while True:
+        sub = _BatchedSubproblem(problem, eqs, ineqs, lambdas, gammas, rho)
+        self.inner_solver._mingradnorm = tol
+        xnew = self.inner_solver.solve(sub, xbest)
+        xbest = torch.where(bm(active), xnew, xbest)
+        newacc = torch.zeros(R, dtype=dt, device=dev)
+        with torch.no_grad():
+            for c, con in enumerate(ineqs):                     # (:179-183, restated as written: see `solve`)
+                v = BatchedTrustRegions._call_constraint(con, xbest).to(dt)
+                newacc = torch.maximum(newacc, torch.maximum(-lambdas[:, c] / rho, v).abs())
+                lambdas[:, c] = torch.where(active, torch.clamp(lambdas[:, c] + rho * v, min=0.0, max=float(self._bound)), lambdas[:, c])
+            for c, con in enumerate(eqs):                       # (:185-188)
+                v = BatchedTrustRegions._call_constraint(con, xbest).to(dt)
+                newacc = torch.maximum(newacc, v.abs())
+                gammas[:, c] = torch.where(active, torch.clamp(gammas[:, c] + rho * v, min=-float(self._bound), max=float(self._bound)), gammas[:, c])
+        grow = active & ((newacc > self._tau * oldacc) if k > 0 else torch.ones_like(active))       # (:191-193)
+        rho = torch.where(grow, rho / self._thetarho, rho)
+        oldacc = torch.where(active, newacc, oldacc)
+        tol = max(self._ending_tolgradnorm, tol * theta_tol)
+        k += 1
+        outer += active.long()
+        # pymanopt's dist on the sphere is arccos<x, y>; elsewhere the manifold's own, or the chordal distance
+        if hasattr(man, "dist"):
+            step = torch.as_tensor(man.dist(xbest, xprev), dtype=dt, device=dev).reshape(R)
+        elif xbest.dim() == 2:
+            step = torch.acos(torch.clamp((xbest * xprev).sum(-1), -1.0, 1.0))
+        else:
+            step = (xbest - xprev).flatten(1).norm(dim=1)
+        active = active & ~(step < self._minstepsize)
+        if (time.time() - time0 >= self._maxtime or k >= self._maxiter or tol <= self._ending_tolgradnorm or not bool(active.any())):
+            break
+        xprev = xbest
+    self.log = {"iterations": k, "per_restart_iterations": outer, "violation": oldacc, "rho": rho, "time": time.time() - time0,
+                "lambdas": lambdas, "gammas": gammas, "batched": True}
+    return xbest
+
+
+AugmentedLagrangeMethod.solve_batched = _solve_batched

@@ -136,6 +136,21 @@ def gen_candidates_manifold(initial_conditions, acquisition_function, manifold, 
         zero = flat.sum(1) == 0
         return torch.where(zero.reshape((-1,) + (1,) * (d.dim() - 1)), d + 1e-30, d)
 
+    from .augmented_lagrange_method import AugmentedLagrangeMethod
+    if (isinstance(solver, AugmentedLagrangeMethod) and isinstance(getattr(solver, "inner_solver", None), BatchedTrustRegions)
+            and not solver_init_conds and (equality_constraints is not None or inequality_constraints is not None)
+            and (options or {}).get("batched_alm", True) and getattr(solver, "_logverbosity", 0) <= 0):
+        # The augmented-Lagrangian method around this package's trust regions - the default solver of the reference's constrained sphere
+        # examples - on all restarts in lock step: the per-restart updates of the reference's loop with the inner solves batched
+        # (augmented_lagrange_method.py: solve_batched; options={"batched_alm": False} drives it restart by restart as the reference does).
+        fused = FusedAcquisition.build(acquisition_function, post_processing_manifold, x0.device) if (x0.is_cuda and (options or {}).get("fused_acquisition", True)) else None
+        problem = BatchedProblem(manifold, cost, approx_hessian=True, precon=precon, fused=fused)
+        opt_x = solver.solve_batched(problem, x0.double(), eq_constraints=equality_constraints, ineq_constraints=inequality_constraints)
+        candidates = opt_x if post_processing_manifold is None else post_processing_manifold(opt_x)
+        candidates = candidates[:, None]
+        with torch.no_grad():
+            batch_acquisition = -problem.cost(opt_x) if fused is not None else acquisition_function(candidates)
+        return candidates.detach(), batch_acquisition.detach()
     if not isinstance(solver, BatchedTrustRegions):
         return _gen_candidates_pointwise(x0, acquisition_function, manifold, solver, post_processing_manifold, inequality_constraints,
                                          equality_constraints, approx_hessian, solver_init_conds)
