@@ -300,3 +300,42 @@ def test_five_bound_constraints_follow_the_reference_trace(golden, run, plan):
     whole = [agree == nit or (run.endswith("strict") and agree >= 30 and drift < 1e-6) for s, (agree, nit, worst, parted_at, drift) in enumerate(res) if ok[s]]
     print(run, plan, "restarts followed to the end:", sum(whole), "of", len(whole), [r[:2] for s, r in enumerate(res) if ok[s] and r[0] != r[1]])
     assert all(whole), [(s,) + r for s, r in enumerate(res) if ok[s] and r[0] != r[1]]
+
+
+@pytest.mark.parametrize("plan", ["generic_on_hip_kernels", "device_tcg_launches"])
+@pytest.mark.parametrize("name,run,kw", [("sph3", "rand_exact", {}), ("sph5", "rand_exact", {}), ("sph3", "rand_fd", {}),
+                                         ("spd3", "rand_fd", {"mingradnorm": 1e-4, "maxiter": 100})])
+def test_use_rand_follows_the_reference_trace(golden, name, run, kw, plan):
+    """`use_rand=True` against the reference's own record (tests/golden/tr_traces_rand.npz; the random tCG starts the reference drew are
+    replayed): the generic path on the HIP kernels and, on S^d_++, the plan of device-resident tCG launches (gabo_spd_tcg_begin_rand, steps
+    without the preconditioner, the Cauchy-point comparison)."""
+    from tests.test_tr_traces_cpu import replay_random_starts
+    g, gr = golden("tr_traces.npz"), golden("tr_traces_rand.npz")
+    solver = TrustRegions(use_rand=True, **kw)
+    solver.trace = []
+    eta_in = gr[f"{name}_{run}_f64_eta_in"]
+    if plan == "generic_on_hip_kernels":
+        with replay_random_starts(eta_in, t):
+            solver.solve(_problem(g, name, approx=(run == "rand_fd")), t(g[f"{name}_x0"]))
+    else:
+        if not name.startswith("spd"):
+            pytest.skip("use_rand has a device plan on S^d_++ only")
+        d = int(name[3:])
+        w = g[f"{name}_w"]
+        kern = SpdAffineInvariantGaussianKernel(beta_min=0.1).double()
+        kern.beta = torch.tensor(float(g[f"{name}_beta"]), dtype=torch.float64)
+        gp = models.ExactGP(t(ospd.symmetric_matrix_to_vector_mandel(g[f"{name}_Y"])), t(np.zeros(len(w))), kern, outputscale=1.0, noise=1.0, mean=0.0)
+        gp._cache = (torch.eye(len(w), dtype=torch.float64, device=DEV), t(w))
+        acq = models.PosteriorMean(gp, maximize=True)
+        x0 = ops.matrix_to_mandel(t(g[f"{name}_x0"]))[:, None]
+        ops.set_error_checking(False)
+        try:
+            with replay_random_starts(eta_in, t):
+                gen_candidates_manifold(x0, acq, manifolds.PositiveDefinite(d), solver, vector_to_symmetric_matrix_mandel_torch,
+                                        symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
+        finally:
+            ops.set_error_checking(True)
+        assert solver.trace and "eta" in solver.trace[0]                       # (recorded by the plan of tCG launches)
+    res = compare_with_reference_trace(solver.trace, gr, f"{name}_{run}_f64", atol_x=1e-6)
+    bad = [(s,) + r for s, r in enumerate(res) if r[0] != r[1]]
+    assert not bad, bad

@@ -180,3 +180,46 @@ def test_five_bound_constraints_follow_the_reference_fp64_trace(golden, run):
         if ok[s]:
             assert agree == nit or (run.endswith("strict") and agree >= 30 and drift < 1e-6), (run, s, agree, nit, worst, parted_at, drift)
     np.testing.assert_allclose(prob.cost(x).numpy()[ok], gb[f"sph3_{run}_f64_f"][ok], rtol=1e-8, atol=1e-12)
+
+
+class replay_random_starts:
+    """Context manager: `_randvec` of the lock-step solver returns, outer iteration by outer iteration, the random tCG starts the REFERENCE
+    drew in its own run (tests/golden/tr_traces_rand.npz: `eta_in`, divided by the 1e-6 the solver multiplies them with)."""
+
+    def __init__(self, eta_in, to_tensor):
+        self.eta, self.k, self.to_tensor = np.nan_to_num(eta_in, nan=0.0) / 1e-6, 0, to_tensor
+
+    def __enter__(self):
+        from gabotorch_amd.manifold_optimization import batched_trust_regions as btr
+        self.btr, self.real = btr, btr._randvec
+
+        def replay(man, x):
+            k = min(self.k, self.eta.shape[1] - 1)
+            self.k += 1
+            return self.to_tensor(self.eta[:, k]).to(x)
+        btr._randvec = replay
+        return self
+
+    def __exit__(self, *exc):
+        self.btr._randvec = self.real
+        return False
+
+
+RAND_RUNS = [("sph3", "rand_exact", {}), ("sph5", "rand_exact", {}), ("sph3", "rand_fd", {}), ("spd3", "rand_fd", {"mingradnorm": 1e-4, "maxiter": 100})]
+
+
+@pytest.mark.parametrize("name,run,kw", RAND_RUNS)
+def test_use_rand_iterates_follow_the_reference_fp64_trace(golden, name, run, kw):
+    """`use_rand=True` (robust_trust_regions.py:173-219, 407-452) pinned to the reference: its own random tCG starts are replayed (the
+    fixture stores the vector handed to tCG at every outer iteration), everything else - the start's Hessian, no preconditioner, the
+    comparison with the Cauchy point, acceptance - is this package's: every outer iteration of the reference reproduced."""
+    g, gr = golden("tr_traces.npz"), golden("tr_traces_rand.npz")
+    prob = _problem(g, name, approx=(run == "rand_fd"))
+    solver = TrustRegions(use_rand=True, **kw)
+    solver.trace = []
+    with replay_random_starts(gr[f"{name}_{run}_f64_eta_in"], T):
+        x = solver.solve(prob, T(g[f"{name}_x0"]))
+    res = compare_with_reference_trace(solver.trace, gr, f"{name}_{run}_f64", atol_x=1e-6)
+    for s, (agree, nit, worst, parted_at, drift) in enumerate(res):
+        assert agree == nit, (name, run, s, agree, nit, worst, parted_at, drift)
+    np.testing.assert_allclose(prob.cost(x).numpy(), gr[f"{name}_{run}_f64_f"], rtol=1e-8, atol=1e-11)
