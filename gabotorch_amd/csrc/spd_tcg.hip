@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64) void spd_tcg_begin_rand_kernel(void* wsbase, co
     const int64_t i = blockIdx.x;
     TcgWs w = tcg_layout(wsbase, R, d, C);
     if (i == 0 && threadIdx.x == 0) w.counters[3] = 1;
-    tcg_begin_rand(w, i, d, eta0 + i * d * d, heta0 + i * d * d, lds);
+    tcg_begin_rand(w, i, R, d, C, eta0 + i * d * d, heta0 + i * d * d, lds);
 }
 
 __global__ __launch_bounds__(64) void spd_tcg_fd_point_kernel(void* wsbase, double* __restrict__ x_fd, int64_t R, int d, int C) {

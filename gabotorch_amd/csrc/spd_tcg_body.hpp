@@ -164,8 +164,8 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
 // e_Pd = <eta0, delta>, model = <eta0, g> + <eta0, Heta0> / 2.  Called after tcg_begin for the same restart (which left the factor,
 // the whitened gradient and the constraints' state in the workspace); eta0, heta0: this restart's d x d tangent vectors at x.
 // lds: 5 d^2 doubles.
-static __device__ void tcg_begin_rand(const TcgWs& w, int64_t i, int d, const double* __restrict__ eta0, const double* __restrict__ heta0,
-                                      double* lds) {
+static __device__ void tcg_begin_rand(const TcgWs& w, int64_t i, int64_t R, int d, int C, const double* __restrict__ eta0,
+                                      const double* __restrict__ heta0, double* lds) {
     const int dd = d * d;
     double* M0 = lds;          // L
     double* M1 = M0 + dd;      // W = L^-1
@@ -208,6 +208,13 @@ static __device__ void tcg_begin_rand(const TcgWs& w, int64_t i, int d, const do
     er = wave_sum(er);
     eg = wave_sum(eg);
     eh = wave_sum(eh);
+    // the linearised constraints start from <grad c_k, eta0>, not from zero (constrained_trust_regions.py:512-516: `fcgradx_Pe[c] = inner(x,
+    // fgradx_cons[c], eta)`) - of the order of Delta_cons = 1e-6 for the 1e-6 start
+    __syncthreads();
+    for (int k = 0; k < C; ++k) {
+        const double ge = wave_dot(w.gc_w + ((int64_t)k * R + i) * dd, M3, dd);
+        if (threadIdx.x == 0) w.fcg_pe[i * C + k] = ge;
+    }
     if (threadIdx.x == 0) {
         double* sc = w.scal + i * SC_COUNT;
         sc[SC_E_PE] = ee;

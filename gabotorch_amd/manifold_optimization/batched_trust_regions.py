@@ -818,7 +818,10 @@ class BatchedTrustRegions:
         S.stop.fill_(MAX_INNER_ITER)
         S.running.copy_(S.active)
         if S.fcg_Pe is not None:
-            S.fcg_Pe.zero_()
+            if eta0 is None:
+                S.fcg_Pe.zero_()
+            else:                                   # (constrained_trust_regions.py:512-516: <grad c_k, eta0>, not zero)
+                S.fcg_Pe.copy_(torch.stack([man.inner(S.x, gci, S.eta) for gci in S.gc], dim=1))
 
     def _tcg_step(self, problem, S, neq, Delta_cons, check_residual):
         """One truncated-CG iteration for every restart (robust_trust_regions.py:476-568, constrained_trust_regions.py:530-732)."""

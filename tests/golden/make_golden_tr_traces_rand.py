@@ -6,6 +6,8 @@ formula [3P], from numpy's seeded global stream); what makes the record reproduc
 tCG is stored with every iteration (`eta_in`), so a test can replay it instead of drawing.  Same costs as tr_traces.npz (read from it), float64.
 
   * sph3, sph5: exact Hessian;  sph3 also with get_hessianfd;  spd3: get_hessianfd (the reference's SPD setting)
+  * ConstrainedTrustRegions(use_rand=True) (constrained_trust_regions.py:207-262, 512-516: the linearised constraints start from
+    <grad c, eta0>): sph3 with x[0] - 0.3 >= 0 from the starts of tr_traces.npz's constrained runs
 -> tests/golden/tr_traces_rand.npz
 """
 import os
@@ -35,7 +37,8 @@ def spd_randvec(x, man=None):
 
 
 def traced_rand(cls):
-    name = "_truncated_conjugate_gradient"
+    name = "_constrained_truncated_conjugate_gradient" if hasattr(cls, "_constrained_truncated_conjugate_gradient") \
+        else "_truncated_conjugate_gradient"
     inner = getattr(cls, name)
 
     def wrapper(self, problem, x, fgradx, eta, Delta, *rest):
@@ -92,6 +95,50 @@ def main():
         for k, v in packed.items():
             out[f"{name}_{rname}_f64_{k}"] = v
         print(name, rname, "iterations", packed["nit"], "f", np.array(costs).round(6), "|eta_in|", [float(np.linalg.norm(tr[0][5])) for tr in traces][:3], flush=True)
+    # ---- constrained runs (drawn after all the unconstrained ones: their records above do not depend on these)
+    from BoManifolds.Riemannian_utils.spd_constraints_utils_torch import max_eigenvalue_constraint_torch
+    # (spd3 with the lambda_max bound is not recorded: a restart on the bound shrinks its radius below the 1e-6 of the random start and the
+    # reference's `while man.norm(x, eta) > Delta: eta = np.sqrt(np.sqrt(np.spacing(1)))` (:214-215) replaces the tangent vector by a SCALAR -
+    # its next `man.norm(x, eta)` raises; this package scales the vector by that factor instead)
+    for name, kind in (("sph3", "sphere"),):
+        n = int(name[3:])
+        Yt, wt, beta = torch.tensor(g[f"{name}_Y"]), torch.tensor(g[f"{name}_w"]), float(g[f"{name}_beta"])
+        if kind == "sphere":
+            man = base.SphereMan(n)
+            man.randvec = sphere_randvec
+
+            def cost(x, Yt=Yt, wt=wt, beta=beta):
+                dd = base.sphere_distance_torch(x[None].double(), Yt)
+                return -(wt * torch.exp(-beta * dd * dd)).sum()
+            shape, x0, cons, fd, kw = (n,), g[f"{name}_con_x0"], [lambda x: x[0] - 0.3], False, {"mingradnorm": 1e-6, "maxiter": MAXIT}
+        else:
+            man = base.SpdMan(n)
+            man.randvec = types.MethodType(lambda self, x: spd_randvec(x, self), man)
+
+            def cost(x, Yt=Yt, wt=wt, beta=beta):
+                dist = base.affine_invariant_distance_torch(x[None].double(), Yt)
+                return -(wt * torch.exp(-beta * dist * dist)).sum()
+            mx = float(g[f"{name}_maxeig"])
+            shape, x0, cons, fd, kw = (n, n), g[f"{name}_x0"], [lambda x, m=mx: max_eigenvalue_constraint_torch(x, m)], True, {"mingradnorm": 1e-4, "maxiter": MAXIT}
+        traces, finals, costs = [], [], []
+        for xs in x0:
+            prob = base.Problem(manifold=man, cost=cost, verbosity=0, arg=torch.Tensor())
+            if fd:
+                prob._hess = types.MethodType(base.get_hessianfd, prob)
+            solver = traced_rand(base.ConstrainedTrustRegions)(use_rand=True, **kw)
+            solver.trace = []
+            x = solver.solve(prob, x=xs.copy(), ineq_constraints=cons)
+            traces.append(solver.trace); finals.append(np.asarray(x)); costs.append(prob.cost(x))
+        packed = T.pack([[t[:5] for t in tr] for tr in traces], finals, shape)
+        S = len(traces)
+        eta_in = np.full((S, MAXIT) + shape, np.nan)
+        for s, tr in enumerate(traces):
+            for k, t in enumerate(tr[:MAXIT]):
+                eta_in[s, k] = t[5]
+        packed["eta_in"], packed["x"], packed["f"], packed["ok"] = eta_in, np.stack(finals), np.array(costs), np.ones(S, dtype=bool)
+        for k, v in packed.items():
+            out[f"{name}_rand_con_f64_{k}"] = v
+        print(name, "rand_con", "iterations", packed["nit"], "f", np.array(costs).round(6), flush=True)
     torch.set_default_dtype(torch.float32)
     np.savez_compressed(os.path.join(HERE, "tr_traces_rand.npz"), **out)
     print("wrote tr_traces_rand.npz:", sum(v.nbytes for v in out.values()) // 1024, "KiB uncompressed")

@@ -223,3 +223,18 @@ def test_use_rand_iterates_follow_the_reference_fp64_trace(golden, name, run, kw
     for s, (agree, nit, worst, parted_at, drift) in enumerate(res):
         assert agree == nit, (name, run, s, agree, nit, worst, parted_at, drift)
     np.testing.assert_allclose(prob.cost(x).numpy(), gr[f"{name}_{run}_f64_f"], rtol=1e-8, atol=1e-11)
+
+
+def test_constrained_use_rand_iterates_follow_the_reference_fp64_trace(golden):
+    """ConstrainedTrustRegions(use_rand=True) (constrained_trust_regions.py:207-262) against the reference's record with its random starts
+    replayed.  (The linearised constraints start from <grad c, eta0> as in :512-516 since round 5 - read off the reference's code; on this
+    record's four restarts the old start from zero follows it as well, the term being 1e-6 |grad c| against steps of 0.1.)"""
+    g, gr = golden("tr_traces.npz"), golden("tr_traces_rand.npz")
+    prob = _problem(g, "sph3", approx=False)
+    solver = ConstrainedTrustRegions(use_rand=True, mingradnorm=1e-6, maxiter=100)
+    solver.trace = []
+    with replay_random_starts(gr["sph3_rand_con_f64_eta_in"], T):
+        x = solver.solve(prob, T(g["sph3_con_x0"]), ineq_constraints=[lambda x: x[..., 0] - 0.3])
+    res = compare_with_reference_trace(solver.trace, gr, "sph3_rand_con_f64", atol_x=1e-6)
+    assert all(agree == nit for agree, nit, *_ in res), res
+    np.testing.assert_allclose(prob.cost(x).numpy(), gr["sph3_rand_con_f64_f"], rtol=1e-8, atol=1e-11)
