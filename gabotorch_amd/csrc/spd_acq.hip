@@ -16,6 +16,15 @@ namespace gabo {
 
 int acq_affine_invariant(const AcqLaunch& a) { return dispatch_acq<0, 12>(a); }
 
+int acq_launch(const AcqLaunch& a) {
+    switch (a.P.flags & GABO_METRIC_MASK) {
+        case GABO_METRIC_AFFINE_INVARIANT: return acq_affine_invariant(a);
+        case GABO_METRIC_LOG_EUCLIDEAN: return acq_log_euclidean(a);
+        case GABO_METRIC_FROBENIUS: return acq_frobenius(a);
+    }
+    return GABO_ERR_DIM;
+}
+
 template <int D>
 static int launch_prepare_train(const double* x, double* G, int64_t n, int* status, hipStream_t st) {
     launch_spd_prep<D>(nullptr, x, nullptr, G, 0, 1, 0, n, 0, 0, status, st);          // only the second (entry-major Cholesky) set
@@ -70,12 +79,7 @@ int gabo_spd_acq_eval(const double* x_mandel, const double* train_factors, const
     gabo::AcqLaunch a{x_mandel, gabo::AcqParams{train_factors, alpha, linv, linv_t, n, beta, flags, mean, outputscale, kxx, best_f, kind,
                                                 maximize, out_sign},
                       value, grad_mandel, scratch, r, d, active, status, (hipStream_t)stream};
-    switch (flags & GABO_METRIC_MASK) {
-        case GABO_METRIC_AFFINE_INVARIANT: return gabo::acq_affine_invariant(a);
-        case GABO_METRIC_LOG_EUCLIDEAN: return gabo::acq_log_euclidean(a);
-        case GABO_METRIC_FROBENIUS: return gabo::acq_frobenius(a);
-    }
-    return GABO_ERR_DIM;
+    return gabo::acq_launch(a);
 }
 
 }  // extern "C"

@@ -48,8 +48,9 @@ struct Philox {
 };
 
 // lane-private d x d scratch in LDS: element e of lane l at q[e * 64 + l] (bank-conflict free, dynamically indexable)
+// out_stride: doubles between consecutive samples in `out` (the sweep driver writes them into rows [value, Mandel vector]: spd_sweep.hip)
 __global__ __launch_bounds__(64) void spd_sample_kernel(double* __restrict__ out, int64_t first, int64_t n, int d, double min_eig,
-                                                        double max_eig, uint64_t seed, int mandel) {
+                                                        double max_eig, uint64_t seed, int mandel, int64_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(64) void spd_sample_kernel(double* __restrict__ out
         }
     }
     if (mandel) {
-        double* o = out + i * (int64_t)(d * (d + 1) / 2);
+        double* o = out + i * out_stride;
         for (int r = 0; r < d; ++r)
             for (int c = 0; c <= r; ++c) {
                 double s = 0.0;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64) void spd_sample_kernel(double* __restrict__ out
                 o[mandel_pos(d, r, c)] = (r == c) ? s : s * kSqrt2;
             }
     } else {
-        double* o = out + i * (int64_t)dd;
+        double* o = out + i * out_stride;
         for (int r = 0; r < d; ++r)
             for (int c = 0; c <= r; ++c) {
                 double s = 0.0;
@@ -110,6 +111,15 @@ __global__ __launch_bounds__(64) void spd_sample_kernel(double* __restrict__ out
 
 }  // namespace gabo
 
+namespace gabo {
+// samples first ... first + n - 1 as Mandel vectors at out + i * out_stride (arguments checked by the caller)
+int spd_sample_rows(double* out, int64_t out_stride, int64_t first, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, hipStream_t st) {
+    size_t lds = (size_t)d * d * 64 * sizeof(double);
+    hipLaunchKernelGGL(spd_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, out, first, n, d, min_eig, max_eig, seed, 1, out_stride);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
+}  // namespace gabo
+
 extern "C" int gabo_spd_sample_range(double* out, int64_t first, int64_t n, int d, double min_eig, double max_eig, uint64_t seed,
                                      int mandel, gabo_stream_t stream) {
     if (d < 1 || d > 16) return GABO_ERR_DIM;
@@ -118,7 +128,7 @@ extern "C" int gabo_spd_sample_range(double* out, int64_t first, int64_t n, int 
     if (!out) return GABO_ERR_ARG;
     size_t lds = (size_t)d * d * 64 * sizeof(double);
     hipLaunchKernelGGL(gabo::spd_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream, out, first, n, d,
-                       min_eig, max_eig, seed, mandel);
+                       min_eig, max_eig, seed, mandel, (int64_t)(mandel ? d * (d + 1) / 2 : d * d));
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

@@ -18,8 +18,12 @@
 #include <vector>
 
 #include "../../include/gabo_hip.h"
+#include "spd_tr_body.hpp"
+#include "spd_acq_kernel.hpp"
 
 namespace gabo {
+
+int spd_sample_rows(double* out, int64_t out_stride, int64_t first, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, hipStream_t st);   // spd_sample.hip
 
 struct SweepWs {
     double *raw_mat, *raw_mandel, *raw_val;          // max_raw x d x d, max_raw x dv, max_raw
@@ -173,6 +177,217 @@ extern "C" int gabo_spd_sweep_solve(const gabo_spd_sweep_config* cfg, const int6
     if (candidates_dev) *candidates_dev = w.cand;
     if (cost_dev) *cost_dev = w.fx;
     if (iterations_dev) *iterations_dev = w.iters;
+    return GABO_OK;
+}
+
+// ---- round 6: the same sweep with its set-up, start and end inside the launches ------------------------------------------------------------------
+// gabo_spd_gp_prepare:       Gram of the training set -> Cholesky factor, its inverse, alpha -> entry-major training factors: four launches from ONE host
+//                            call (rounds 4-5: ~0.24 ms of Python around them, the GPU waiting for the next launch most of that time)
+// gabo_spd_sweep_score_rows: samples [first, first + count) of the stream (or the caller's host draws) as rows [value, Mandel vector] of ONE table, their
+//                            acquisition values into the table and, densely, into MAPPED HOST memory: two launches, no copy
+// gabo_spd_sweep_solve_rows: ONE launch - every wave starts its restart from its picked row (pre- / post-processing maps, value, gradient, Riemannian
+//                            gradient and norm: tr_start_body), iterates to the end and leaves [cost, iterations, Mandel vector] in a result row, on the
+//                            device and in mapped host memory.
+// Rows, because a multi-GPU sweep all_gathers exactly two things: the scored raw-sample rows and the result rows - the caller does that on
+// the tables themselves between / after the calls (manifold_optimize.py of this package), the driver has no collective of its own.
+namespace gabo {
+
+struct RowsWs {
+    double *raw_rows, *res_rows, *raw_mat;
+    double *x, *fx, *g, *ng, *delta;
+    int64_t* iters;
+    uint8_t* active;
+    void* tr;
+    size_t tr_bytes, bytes;
+};
+
+static RowsWs rows_layout(void* base, int64_t n, int d, int64_t max_raw, int64_t r, int c) {
+    RowsWs w;
+    const int64_t dv = (int64_t)d * (d + 1) / 2, dd = (int64_t)d * d;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) {
+        char* q = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return q;
+    };
+    w.raw_rows = (double*)take((size_t)max_raw * (1 + dv) * 8);
+    w.res_rows = (double*)take((size_t)r * (2 + dv) * 8);
+    w.raw_mat = (double*)take((size_t)max_raw * dd * 8);        // staging of host-drawn matrices
+    w.x = (double*)take((size_t)r * dd * 8);
+    w.fx = (double*)take((size_t)r * 8);
+    w.g = (double*)take((size_t)r * dd * 8);
+    w.ng = (double*)take((size_t)r * 8);
+    w.delta = (double*)take((size_t)r * 8);
+    w.iters = (int64_t*)take((size_t)r * 8);
+    w.active = (uint8_t*)take((size_t)r);
+    w.tr_bytes = gabo_spd_tr_workspace_bytes(r, d, c, n);
+    w.tr = take(w.tr_bytes + 8);
+    w.bytes = (size_t)(p - (char*)base);
+    return w;
+}
+
+// rows [., Mandel vector] from d x d matrices: matrix_to_mandel_kernel's statement (mandel.hip), strided output
+__global__ __launch_bounds__(256) void sweep_rows_from_matrices_kernel(const double* __restrict__ mat, double* __restrict__ rows, int64_t n, int d,
+                                                                       int64_t row_stride) {
+    const int64_t dd = (int64_t)d * d;
+    const int dv = d * (d + 1) / 2;
+    const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gidx >= n * dv) return;
+    const int64_t q = gidx / dv;
+    const int e = (int)(gidx - q * dv);
+    int k = 0;
+    while (k + 1 < d && (k + 1) * d - (k + 1) * k / 2 <= e) ++k;
+    const int c = e - (k * d - k * (k - 1) / 2);
+    const int r = c + k;
+    const double* m = mat + q * dd;
+    rows[q * row_stride + 1 + e] = (k == 0) ? m[r * d + c] : 0.5 * (kSqrt2 * m[c * d + r] + kSqrt2 * m[r * d + c]);
+}
+
+// The address the DEVICE uses for memory the host reads or writes directly: device memory as it is; page-locked host memory through its mapping.
+// Anything else (pageable host memory) is refused - a kernel that dereferenced it would fault.
+static void* device_visible(const void* p) {
+    if (!p) return nullptr;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (attr.type == hipMemoryTypeHost) return attr.devicePointer;
+    if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) return const_cast<void*>(p);
+    return nullptr;
+}
+
+}  // namespace gabo
+
+extern "C" size_t gabo_spd_gp_prepare_workspace_bytes(int64_t n, int d) {
+    if (n < 1 || d < 2) return 0;
+    return (((size_t)n * n * 8 + 255) & ~(size_t)255) + gabo_spd_ai_workspace_bytes(1, n, n, d);
+}
+
+extern "C" int gabo_spd_gp_prepare(const double* train_mandel, const double* y, int64_t n, int d, double beta, int flags, double outputscale, double noise,
+                                   double mean, double* linv, double* linv_t, double* alpha, double* train_factors, void* workspace,
+                                   size_t workspace_bytes, int* status, int* factor_status, gabo_stream_t stream) {
+    if (!train_mandel || !y || !linv || !linv_t || !alpha || !workspace || !status || !factor_status || n < 1) return GABO_ERR_ARG;
+    if (d < 2 || d > GABO_SPD_REG_MAX_DIM) return GABO_ERR_DIM;
+    if (n > GABO_GP_FACTOR_MAX_N) return GABO_ERR_DIM;
+    const int out = flags & GABO_OUT_MASK;
+    if ((flags & ~GABO_OUT_MASK) || (out != GABO_OUT_GAUSSIAN && out != GABO_OUT_LAPLACE)) return GABO_ERR_ARG;
+    if (workspace_bytes < gabo_spd_gp_prepare_workspace_bytes(n, d)) return GABO_ERR_ARG;
+    double* kb = (double*)workspace;
+    char* pw = (char*)workspace + (((size_t)n * n * 8 + 255) & ~(size_t)255);
+    int rc;
+    // what SpdAffineInvariant{Gaussian,Laplace}Kernel.forward(X, X) launches for the training set (the x1-is-x2 build), then models.ExactGP's cache
+    if ((rc = gabo_spd_ai_pairwise(train_mandel, train_mandel, kb, nullptr, 1, n, n, d, 0, 0, beta, out | GABO_SYMMETRIC, pw,
+                                   gabo_spd_ai_workspace_bytes(1, n, n, d), status, stream)) != GABO_OK)
+        return rc;
+    if ((rc = gabo_gp_factor(kb, y, n, outputscale, noise, mean, linv, linv_t, alpha, factor_status, stream)) != GABO_OK) return rc;
+    if (train_factors && (rc = gabo_spd_acq_prepare_train(train_mandel, train_factors, n, d, status, stream)) != GABO_OK) return rc;
+    return GABO_OK;
+}
+
+extern "C" size_t gabo_spd_sweep_rows_workspace_bytes(int64_t n_train, int d, int64_t max_raw, int64_t restarts, int n_constraints) {
+    if (n_train < 1 || d < 2 || max_raw < 0 || restarts < 0 || n_constraints < 0) return 0;
+    return gabo::rows_layout(nullptr, n_train, d, max_raw, restarts, n_constraints).bytes;
+}
+
+extern "C" int gabo_spd_sweep_rows_tables(void* workspace, int64_t n_train, int d, int64_t max_raw, int64_t restarts, int n_constraints, double** raw_rows,
+                                          double** result_rows) {
+    if (!workspace || n_train < 1 || d < 2 || max_raw < 0 || restarts < 0 || n_constraints < 0) return GABO_ERR_ARG;
+    const gabo::RowsWs w = gabo::rows_layout(workspace, n_train, d, max_raw, restarts, n_constraints);
+    if (raw_rows) *raw_rows = w.raw_rows;
+    if (result_rows) *result_rows = w.res_rows;
+    return GABO_OK;
+}
+
+extern "C" int gabo_spd_sweep_score_rows(const gabo_spd_sweep_config* cfg, int64_t first_sample, int64_t first_row, int64_t count, int64_t max_raw,
+                                         int64_t restarts, uint64_t seed, const double* raw_matrices_host, double* values_mapped, void* workspace,
+                                         size_t workspace_bytes, int* status, int* status_mapped, int synchronize, gabo_stream_t stream) {
+    if (!cfg || !workspace || !status || first_sample < 0 || first_row < 0 || count < 1 || first_row + count > max_raw || restarts < 1) return GABO_ERR_ARG;
+    const int d = cfg->d;
+    if (d < 2 || d > 8 || cfg->n_constraints < 0 || cfg->n_constraints > GABO_SWEEP_MAX_CONSTRAINTS) return GABO_ERR_DIM;
+    const gabo_spd_acq_params& a = cfg->acq;
+    if (a.n < 1 || a.n > gabo_spd_acq_max_train(d) || !a.train_factors || !a.alpha) return GABO_ERR_ARG;
+    if (a.kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!a.linv || !a.linv_t)) return GABO_ERR_ARG;
+    const gabo::RowsWs w = gabo::rows_layout(workspace, a.n, d, max_raw, restarts, cfg->n_constraints);
+    if (w.bytes > workspace_bytes) return GABO_ERR_ARG;
+    double* mirror = nullptr;
+    if (values_mapped && !(mirror = (double*)gabo::device_visible(values_mapped))) return GABO_ERR_ARG;
+    int* smirror = nullptr;
+    if (status_mapped && !(smirror = (int*)gabo::device_visible(status_mapped))) return GABO_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t dv = (int64_t)d * (d + 1) / 2, stride = 1 + dv;
+    double* rows = w.raw_rows + first_row * stride;
+    int rc;
+    if (raw_matrices_host) {
+        // the caller's own sampler (`manifold.rand` is user code: the reference binds spd_sample to it, examples/gabo_spd.py:102) drew them on the host
+        if (hipMemcpyAsync(w.raw_mat, raw_matrices_host, (size_t)count * d * d * 8, hipMemcpyHostToDevice, st) != hipSuccess) return GABO_ERR_LAUNCH;
+        hipLaunchKernelGGL(gabo::sweep_rows_from_matrices_kernel, dim3((unsigned)((count * dv + 255) / 256)), dim3(256), 0, st, w.raw_mat, rows, count, d,
+                           stride);
+        if (hipGetLastError() != hipSuccess) return GABO_ERR_LAUNCH;
+    } else {
+        if (!(cfg->min_eig > 0.0) || !(cfg->max_eig >= cfg->min_eig)) return GABO_ERR_ARG;
+        // (Mandel output of the sampler: kSqrt2 * s, the bits matrix_to_mandel gives for the symmetric matrix it would have written)
+        if ((rc = gabo::spd_sample_rows(rows + 1, stride, first_sample, count, d, cfg->min_eig, cfg->max_eig, seed, st)) != GABO_OK) return rc;
+    }
+    gabo_spd_acq_params acq = a;
+    acq.out_sign = 1.0;              // (`values` are the acquisition values themselves)
+    gabo::AcqLaunch al{rows + 1, acq, rows, nullptr, nullptr, count, d, nullptr, status, st};
+    al.x_stride = stride;
+    al.value_stride = stride;
+    al.value_mirror = mirror;
+    al.status_mirror = smirror;
+    if ((rc = gabo::acq_launch(al)) != GABO_OK) return rc;
+    if (synchronize && hipStreamSynchronize(st) != hipSuccess) return GABO_ERR_LAUNCH;
+    return GABO_OK;
+}
+
+extern "C" int gabo_spd_sweep_solve_rows(const gabo_spd_sweep_config* cfg, const int64_t* picked_mapped, int64_t restarts, int64_t max_raw,
+                                         double* results_mapped, void* workspace, size_t workspace_bytes, int* status, int* status_mapped,
+                                         int synchronize, gabo_stream_t stream) {
+    if (!cfg || !picked_mapped || !workspace || !status || restarts < 1 || restarts > 0x7fffffffLL) return GABO_ERR_ARG;
+    const int d = cfg->d, c = cfg->n_constraints;
+    if (d < 2 || d > 8 || c < 0 || c > GABO_SWEEP_MAX_CONSTRAINTS) return GABO_ERR_DIM;
+    const gabo_spd_acq_params& a = cfg->acq;
+    if (a.n < 1 || a.n > gabo_spd_acq_max_train(d) || !a.train_factors || !a.alpha || cfg->maxinner < 1 || cfg->maxiter < 1) return GABO_ERR_ARG;
+    if (a.kind == GABO_ACQ_EXPECTED_IMPROVEMENT && (!a.linv || !a.linv_t)) return GABO_ERR_ARG;
+    if (!gabo_spd_tr_solve_supported(&a, restarts, d, c, 0)) return GABO_ERR_DIM;
+    const int64_t r = restarts;
+    const gabo::RowsWs w = gabo::rows_layout(workspace, a.n, d, max_raw, r, c);
+    if (w.bytes > workspace_bytes) return GABO_ERR_ARG;
+    const int64_t* picked = (const int64_t*)gabo::device_visible(picked_mapped);
+    if (!picked) return GABO_ERR_ARG;
+    double* res_host = nullptr;
+    if (results_mapped && !(res_host = (double*)gabo::device_visible(results_mapped))) return GABO_ERR_ARG;
+    int* smirror = nullptr;
+    if (status_mapped && !(smirror = (int*)gabo::device_visible(status_mapped))) return GABO_ERR_ARG;
+    {
+        // (the indices are read here only when the host can: mapped host memory; device-resident indices are the caller's responsibility)
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, picked_mapped) == hipSuccess && attr.type == hipMemoryTypeHost) {
+            for (int64_t k = 0; k < r; ++k)
+                if (picked_mapped[k] < 0 || picked_mapped[k] >= max_raw) return GABO_ERR_ARG;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    gabo_spd_acq_params acq = a;
+    acq.out_sign = -1.0;             // cost = -acquisition
+    gabo::BuiltinCons B;
+    B.n = c;
+    B.strict = cfg->strict ? 1 : 0;
+    B.big_dim = 0;
+    B.lift_w = B.lift_p = B.lift_x0 = nullptr;
+    for (int k = 0; k < gabo::kMaxCons; ++k) {
+        B.kind[k] = k < c ? cfg->constraint_kind[k] : 0;
+        B.bound[k] = k < c ? cfg->constraint_bound[k] : 0.0;
+        if (k < c && B.kind[k] != GABO_CONSTRAINT_MAX_EIGENVALUE && B.kind[k] != GABO_CONSTRAINT_MIN_EIGENVALUE) return GABO_ERR_ARG;
+    }
+    if (gabo::tr_solve_uses_global_workspace(acq, r, d, c, 0) && hipMemsetAsync(w.tr, 0, w.tr_bytes, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    gabo::SolveArgs sa{w.x, w.fx, w.g, w.ng, w.delta, w.active, w.iters, &acq, B, w.tr, r, d, cfg->delta_cons, cfg->theta, cfg->kappa, cfg->mininner,
+                       cfg->maxinner, cfg->delta_bar, cfg->rho_prime, cfg->rho_regularization, cfg->mingradnorm, cfg->maxiter, status, st};
+    sa.start = gabo::TrStart{w.raw_rows, 1 + (int64_t)d * (d + 1) / 2, picked, cfg->delta0, w.res_rows, res_host, smirror};
+    int rc;
+    if ((rc = gabo::tr_solve_dispatch(sa)) != GABO_OK) return rc;
+    if (synchronize && hipStreamSynchronize(st) != hipSuccess) return GABO_ERR_LAUNCH;
     return GABO_OK;
 }
 

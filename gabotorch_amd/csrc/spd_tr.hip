@@ -49,6 +49,26 @@ void tr_record_take(double** buffer, int64_t* capacity) {
     g_tr_record = nullptr;
     g_tr_record_cap = 0;
 }
+
+int tr_solve_dispatch(const SolveArgs& a0) {
+    SolveArgs a = a0;
+    // test hook: GABO_TR_NO_SHORTCUTS in the environment runs every iteration in full (no value-first evaluation after a rejection, no reuse of
+    // an identical step's proposal): the two forms must agree bit for bit (tests/test_gpu_native_sweep.py).  Read once per process.
+    static const int shortcuts = getenv("GABO_TR_NO_SHORTCUTS") ? 0 : 1;
+    a.shortcuts = shortcuts;
+    switch (a.P->flags & GABO_METRIC_MASK) {
+        case GABO_METRIC_AFFINE_INVARIANT: return solve_affine_invariant(a);
+        case GABO_METRIC_LOG_EUCLIDEAN: return solve_log_euclidean(a);
+        case GABO_METRIC_FROBENIUS: return solve_frobenius(a);
+    }
+    return GABO_ERR_ARG;
+}
+
+bool tr_solve_uses_global_workspace(const AcqParams& P, int64_t r, int d, int C, size_t nested_bytes) {
+    int stage_gp = 0, ws_lds = 0;
+    tr_solve_dynamic_lds(P.n, r, d, C, &stage_gp, &ws_lds, nested_bytes);
+    return !ws_lds;
+}
 }  // namespace gabo
 
 extern "C" {
@@ -173,17 +193,9 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
     }
     gabo::SolveArgs a{x, fx, grad, grad_norm, trust_radius, active, iters, acq, B, workspace, r, d, delta_cons, theta, kappa, mininner,
                       maxinner, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter, status, (hipStream_t)stream};
-    // test hook: GABO_TR_NO_SHORTCUTS in the environment runs every iteration in full (no value-first evaluation after a rejection, no reuse of
-    // an identical step's proposal): the two forms must agree bit for bit (tests/test_gpu_native_sweep.py)
-    a.shortcuts = getenv("GABO_TR_NO_SHORTCUTS") ? 0 : 1;
     a.rec = rec;
     a.rec_cap = rec_cap;
-    switch (acq->flags & GABO_METRIC_MASK) {
-        case GABO_METRIC_AFFINE_INVARIANT: return gabo::solve_affine_invariant(a);
-        case GABO_METRIC_LOG_EUCLIDEAN: return gabo::solve_log_euclidean(a);
-        case GABO_METRIC_FROBENIUS: return gabo::solve_frobenius(a);
-    }
-    return GABO_ERR_ARG;
+    return gabo::tr_solve_dispatch(a);
 }
 
 }  // extern "C"

@@ -440,6 +440,100 @@ static __device__ bool tr_update_body(double* __restrict__ x, double* __restrict
     return !(ngi < mingradnorm || it >= maxiter);
 }
 
+// The sweep's own start and end of a restart (gabo_spd_sweep_solve_picked, spd_sweep.hip): restart i begins at raw sample picked[i] of the scored
+// table and the kernel itself does what gen_candidates_manifold does around the solver (manifold_optimize.py:170-205) - pre_processing_manifold
+// (Mandel -> matrix), post_processing_manifold inside the cost (matrix -> Mandel), cost and Euclidean gradient at the start, [3P] egrad2rgrad and
+// norm of pymanopt's PositiveDefinite (robust_trust_regions.py:148-158), radius and counters - and, after the last iteration, the Mandel vector of
+// the final iterate.  Rounds 4-5 issued these as ten launches in front of the solve and three behind it (85 + 15 us of a 1.4-ms sweep); the
+// statements below are THOSE kernels' statements in the same order (mandel.hip, spd_acq_kernel, spd_manifold.hip OP_EGRAD2RGRAD / OP_NORM), so the
+// bits are the ones the separate launches give.
+struct TrStart {
+    const double* raw_rows;     // null: the caller filled x, fx, g, ng, delta_tr, active, iters (gabo_spd_tr_solve)
+    int64_t raw_stride;         // doubles per row of the table: [value, Mandel vector ...]
+    const int64_t* picked;      // row index of every restart (device-visible: device memory or mapped host memory)
+    double delta0;
+    double* res_rows;           // restarts x (2 + T): final cost, iterations, final iterate as a Mandel vector
+    double* res_host;           // the same rows in mapped host memory, or null
+    int* status_host;           // mapped host copy of an error this launch reports, or null
+};
+
+template <int D, int METRIC>
+__device__ __forceinline__ void tr_start_body(const TrStart& S, double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
+                                              double* __restrict__ ng, const AcqParams& P, const TrWs& t, int64_t iw, AcqLds<D>& acq,
+                                              double* mats, double* dyn, int* __restrict__ status) {
+    constexpr int T = tri_size(D);
+    constexpr int dd = D * D;
+    double* M0 = mats;
+    double* M1 = M0 + dd;
+    double* M2 = M1 + dd;
+    double* M3 = M2 + dd;
+    double* M4 = M3 + dd;
+    const double* row = S.raw_rows + S.picked[blockIdx.x] * S.raw_stride + 1;
+    for (int e = threadIdx.x; e < dd; e += 64) {          // mandel_to_matrix_kernel
+        const int r = e / D, c = e - r * D;
+        const int hi = r > c ? r : c, lo = r > c ? c : r;
+        const double v = row[mandel_pos(D, hi, lo)];
+        const double m = (r == c) ? v : v / kSqrt2;
+        M0[e] = m;
+        x[e] = m;
+    }
+    __syncthreads();
+    double* xm = t.xp_mandel + iw * T;
+    for (int e = threadIdx.x; e < T; e += 64) {           // matrix_to_mandel_kernel
+        int k = 0;
+        while (k + 1 < D && (k + 1) * D - (k + 1) * k / 2 <= e) ++k;
+        const int c = e - (k * D - k * (k - 1) / 2);
+        const int r = c + k;
+        xm[e] = (k == 0) ? M0[r * D + c] : 0.5 * (kSqrt2 * M0[c * D + r] + kSqrt2 * M0[r * D + c]);
+    }
+    __syncthreads();
+    double* egm = t.eg_prop + iw * T;
+    acq_eval_any<D, METRIC>(xm, P, fx, egm, t.F + iw * T * P.n, acq, dyn, status, iw + t.tcg.index_base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < dd; e += 64) {          // mandel_to_matrix_kernel on the gradient
+        const int r = e / D, c = e - r * D;
+        const int hi = r > c ? r : c, lo = r > c ? c : r;
+        const double v = egm[mandel_pos(D, hi, lo)];
+        M1[e] = (r == c) ? v : v / kSqrt2;
+    }
+    __syncthreads();
+    lds_symmetrize(M1, M2, D);                             // OP_EGRAD2RGRAD: X sym(G) X
+    lds_congruence(M0, M1, M3, M4, D);
+    lds_store(M3, g, D);
+    for (int e = threadIdx.x; e < dd; e += 64) M1[e] = M3[e];
+    __syncthreads();
+    lds_cholesky(M0, D);                                   // OP_NORM: ||g||_x^2 = ||L^-1 g L^-T||_F^2
+    lds_tri_inverse(M0, M2, D);
+    lds_congruence(M2, M1, M3, M4, D);
+    if (threadIdx.x == 0) {
+        double sacc = 0.0;
+        for (int k = 0; k < dd; ++k) sacc = __builtin_fma(M3[k], M3[k], sacc);
+        *ng = __builtin_sqrt(sacc > 0.0 ? sacc : 0.0);
+    }
+    __syncthreads();
+}
+
+template <int D>
+__device__ __forceinline__ void tr_finish_body(const TrStart& S, const double* __restrict__ x, double fx, int64_t iters) {
+    constexpr int T = tri_size(D);
+    double* row = S.res_rows + (int64_t)blockIdx.x * (2 + T);
+    double* hrow = S.res_host ? S.res_host + (int64_t)blockIdx.x * (2 + T) : nullptr;
+    for (int e = threadIdx.x; e < T; e += 64) {           // matrix_to_mandel_kernel
+        int k = 0;
+        while (k + 1 < D && (k + 1) * D - (k + 1) * k / 2 <= e) ++k;
+        const int c = e - (k * D - k * (k - 1) / 2);
+        const int r = c + k;
+        const double v = (k == 0) ? x[r * D + c] : 0.5 * (kSqrt2 * x[c * D + r] + kSqrt2 * x[r * D + c]);
+        row[2 + e] = v;
+        if (hrow) hrow[2 + e] = v;
+    }
+    if (threadIdx.x == 0) {
+        row[0] = fx;
+        row[1] = (double)iters;
+        if (hrow) { hrow[0] = fx; hrow[1] = (double)iters; }
+    }
+}
+
 // The whole trust-region solve of restart i in one launch: no host involvement between iterations.  Possible when the
 // constraints are the built-in eigenvalue bounds (or there are none); D <= 8.
 // LAT (the latency regime: <= 1024 restarts, everything fits): the GP factors AND the workspace are in LDS, known at compile time.  With
@@ -454,14 +548,15 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
                                                           double kappa, int mininner, int maxinner, double delta_bar, double rho_prime,
                                                           double rho_regularization, double mingradnorm, int64_t maxiter,
                                                           int* __restrict__ status, int stage_gp, int ws_lds, int nested_off, int shortcuts,
-                                                          double* __restrict__ rec, int64_t rec_cap) {
+                                                          double* __restrict__ rec, int64_t rec_cap, TrStart S) {
     static_assert(D <= 8, "built-in constraints use the register eigen-solver");
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
     __shared__ __attribute__((aligned(16))) double mats[5 * dd + kJacobiScratch];
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
-    if (active[i] == 0) return;
+    const bool own_start = S.raw_rows != nullptr;            // (uniform over the launch)
+    if (!own_start && active[i] == 0) return;
     const int C = B.n;
     if constexpr (LAT) {
         stage_gp = 1;
@@ -499,6 +594,14 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     }
     double* xp = t.xp_mat + iw * dd;
     double* nlds = reinterpret_cast<double*>(reinterpret_cast<char*>(dyn) + nested_off);      // (used by nested constraint kinds only)
+    if (own_start) {
+        tr_start_body<D, METRIC>(S, x + i * dd, fx + i, g + i * dd, ng + i, Ps, t, iw, acq, mats, dyn, status);
+        if (threadIdx.x == 0) {
+            delta_tr[i] = S.delta0;
+            iters[i] = 0;
+        }
+        __syncthreads();
+    }
     bool cons_fresh = false;          // wave-uniform: the constraints in the workspace belong to the current x
     int last_inner = 0;               // tCG iterations of the previous trust-region iteration
     constexpr int T_ = tri_size(D);
@@ -549,6 +652,17 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
         cons_fresh = !accepted;
     }
     if (threadIdx.x == 0) active[i] = 0;
+    if (own_start) {
+        __syncthreads();
+        tr_finish_body<D>(S, x + i * dd, fx[i], iters[i]);
+        if (S.status_host != nullptr && threadIdx.x == 0) {          // (mirror_status of spd_acq_kernel.hpp)
+            const int e = __atomic_load_n(status, __ATOMIC_RELAXED);
+            if (e != 0) {
+                S.status_host[1] = __atomic_load_n(status + 1, __ATOMIC_RELAXED);
+                S.status_host[0] = e;
+            }
+        }
+    }
 }
 
 // one translation unit per metric (spd_tr.hip, spd_tr_le.hip, spd_tr_frob.hip) so that the instantiations compile in parallel
@@ -614,6 +728,7 @@ struct SolveArgs {
     double* rec = nullptr;  // gabo_tr_solve_record: per-iteration record of this call, or null
     int64_t rec_cap = 0;
     int shortcuts = 1;      // 0: every iteration computes its proposal and the full evaluation (the environment variable GABO_TR_NO_SHORTCUTS: tests)
+    TrStart start = {nullptr, 0, nullptr, 0.0, nullptr, nullptr, nullptr};      // the sweep driver's start / end inside the launch (spd_sweep.hip)
 };
 
 // Round 5 history of two instantiations (tools/soak_tr.py found them; tools/repro_solve_fault.py walks the whole table): with the
@@ -651,7 +766,8 @@ static int dispatch_solve(const SolveArgs& a) {
 #define GABO_SOLVE_LAUNCH(DD, LAT_)                                                                                                \
     hipLaunchKernelGGL((spd_tr_solve_kernel<DD, METRIC, LAT_>), dim3((unsigned)a.r), dim3(64), lds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
                        a.active, a.iters, *a.P, a.B, a.ws, a.r, a.delta_cons, a.theta, a.kappa, a.mininner, a.maxinner, a.delta_bar, \
-                       a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds, nested_off, a.shortcuts, a.rec, a.rec_cap)
+                       a.rho_prime, a.rho_regularization, a.mingradnorm, a.maxiter, a.status, stage_gp, ws_lds, nested_off, a.shortcuts, a.rec, a.rec_cap, \
+                       a.start)
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
         if constexpr (DD >= DMIN && DD <= DMAX) {                                                                                  \
@@ -682,5 +798,10 @@ int propose_affine_invariant_wide(const ProposeArgs& a);      // d = 9..12 (spd_
 int propose_log_euclidean(const ProposeArgs& a);
 int propose_frobenius(const ProposeArgs& a);                  // spd_tr_frob.hip
 int solve_frobenius(const SolveArgs& a);                      // spd_tr_solve_frob.hip
+
+// what gabo_spd_tr_solve does behind its argument checks (spd_tr.hip); spd_sweep.hip calls it with `start` set.  *needs_zeroed_workspace (may be
+// null): whether this problem runs with the caller's workspace (which must then be zeroed) instead of the block-private LDS copy.
+int tr_solve_dispatch(const SolveArgs& a);
+bool tr_solve_uses_global_workspace(const AcqParams& P, int64_t r, int d, int C, size_t nested_bytes);
 
 }  // namespace gabo

@@ -11,6 +11,8 @@ another kernel, user pre/post-processing callables, second derivatives) stays on
 """
 import math
 
+import torch
+
 from . import _lib, models, ops
 from .kernel_utils import kernels_spd, kernels_sphere
 from .Riemannian_utils import spd_utils_torch
@@ -30,23 +32,25 @@ def _surrogate_view(gp):
 
 
 class FusedAcquisition:
-    def __init__(self, acq, family, mode, beta, matrix_input, device, flavour="ai"):
-        base, outputscale, mean, (linv, alpha), train_x = _surrogate_view(acq.model)
+    def __init__(self, acq, family, mode, beta, matrix_input, device, flavour="ai", view=None):
+        base, outputscale, mean, (linv, alpha), train_x = view if view is not None else _surrogate_view(acq.model)
         self.family, self.mode, self.beta, self.matrix_input = family, mode, beta, matrix_input
         self.flavour = flavour          # SPD kernels: "ai" affine-invariant, "le" log-Euclidean, "frob" Frobenius
         self.kind = _lib.GABO_ACQ_EXPECTED_IMPROVEMENT if isinstance(acq, models.ExpectedImprovement) else _lib.GABO_ACQ_POSTERIOR_MEAN
         self.maximize = bool(acq.maximize)
         self.best_f = float(getattr(acq, "best_f", 0.0))
         self.mean, self.outputscale = mean, outputscale
-        self.linv = linv.to(device).contiguous()
+        device = torch.device(device)
+        on = lambda t_: t_ if (t_.device == device and t_.is_contiguous()) else t_.to(device).contiguous()    # noqa: E731
+        self.linv = on(linv)
         # (gabo_gp_factor wrote L^-T next to L^-1: models.*._cache_linv_t, valid for exactly that cache object)
         held = getattr(acq.model, "_cache_linv_t", None)
         if held is not None and held[0] is getattr(acq.model, "_cache", None) and held[1].device == self.linv.device:
             self.linv_t = held[1]
         else:
             self.linv_t = self.linv.t().contiguous()
-        self.alpha = alpha.to(device).contiguous()
-        self.train = train_x.to(device).contiguous()
+        self.alpha = on(alpha)
+        self.train = on(train_x)
         # d <= 12: value + gradient in ONE launch per evaluation (csrc/spd_acq.hip); the training side is factored once here
         self.single_launch = False
         if family == "spd" and flavour == "ai":
@@ -59,7 +63,14 @@ class FusedAcquisition:
             self.single_launch = (7 * n_tr + 6 * dim_tr) * 8 <= 150 * 1024 and n_tr <= 4096 and 2 <= dim_tr <= 512
             self.train_t = self.train.t().contiguous() if self.single_launch else None
         self.metric = {"ai": _lib.GABO_METRIC_AFFINE_INVARIANT, "le": _lib.GABO_METRIC_LOG_EUCLIDEAN, "frob": _lib.GABO_METRIC_FROBENIUS}[flavour]
-        self.train_factors = ops.spd_acq_prepare_train(self.train) if (self.single_launch and family == "spd") else None
+        self.train_factors = None
+        if self.single_launch and family == "spd":
+            # (gabo_spd_gp_prepare wrote them next to the factor: models.ExactGP._cache_factors, valid for exactly that cache object)
+            heldf = getattr(acq.model, "_cache_factors", None)
+            if heldf is not None and heldf[0] is getattr(acq.model, "_cache", None) and heldf[1] is not None and heldf[1].device == self.linv.device:
+                self.train_factors = heldf[1]
+            else:
+                self.train_factors = ops.spd_acq_prepare_train(self.train)
         if family == "spd" and flavour != "ai":
             # ||0 + 1e-15||_F^2 = d^2 1e-30 (spd_utils_torch.py:156): k(x, x) = 1 to the last bit; logm of the training set once
             self.kxx = 1.0
@@ -110,7 +121,7 @@ class FusedAcquisition:
             if post_processing is not spd_utils_torch.symmetric_matrix_to_vector_mandel_torch:
                 return None
             mode = _lib.GABO_OUT_GAUSSIAN if type(k) is kernels_spd.SpdAffineInvariantGaussianKernel else _lib.GABO_OUT_LAPLACE
-            return FusedAcquisition(acq, "spd", mode, float(k.beta.double()), True, device)
+            return FusedAcquisition(acq, "spd", mode, k.beta_float(), True, device, view=view)
         if type(k) in (kernels_spd.SpdLogEuclideanGaussianKernel, kernels_spd.SpdFrobeniusGaussianKernel):
             if post_processing is not spd_utils_torch.symmetric_matrix_to_vector_mandel_torch:
                 return None

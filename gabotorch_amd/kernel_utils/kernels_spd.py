@@ -29,6 +29,18 @@ class _BetaKernel(Kernel):
     def beta(self, value):
         self._set_beta(value)
 
+    def beta_float(self):
+        """beta as a Python float (the fp64 value of the parameter), for the launch arguments of the fused paths.  The constraint's transform is
+        four small tensor operations (25 us of a sweep's set-up); the result is remembered per raw value."""
+        raw = self.raw_beta
+        if raw.numel() != 1:
+            return float(self.beta.double())
+        key = (raw.item(), id(self.raw_beta_constraint))
+        held = self.__dict__.get("_beta_float_held")
+        if held is None or held[0] != key:
+            held = self.__dict__["_beta_float_held"] = (key, float(self.beta.double()))
+        return held[1]
+
     def _set_beta(self, value):
         if not torch.is_tensor(value):
             value = torch.as_tensor(value).to(self.raw_beta)

@@ -25,6 +25,14 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
+def _mark(options, label):
+    """development hook: options["timeline"] = [] collects (label, perf_counter) pairs of the sweep's host phases (tools/sweep_native_phases.py)"""
+    tl = options.get("timeline")
+    if tl is not None:
+        import time
+        tl.append((label, time.perf_counter()))
+
+
 def shard_restarts(num_restarts, rank, world):
     """Indices of the restarts rank `rank` owns (interleaved)."""
     return list(range(rank, num_restarts, world))
@@ -63,9 +71,11 @@ def joint_optimize_manifold(acq_function, manifold, solver, q, num_restarts, raw
     """Returns the `q x d` best candidate (manifold_optimize.py:36-120)."""
     options = options or {}
     analytic = getattr(acq_function, "is_analytic", True)
+    _mark(options, "-> plan")
     plan = _native_sweep_plan(acq_function, manifold, solver, q if not analytic else 1, num_restarts, raw_samples, bounds, sample_type, options,
                               inequality_constraints, equality_constraints, pre_processing_manifold, post_processing_manifold, approx_hessian,
                               solver_init_conds)
+    _mark(options, "<- plan")
     if plan is not None:
         return _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options)
     batch_initial_conditions = gen_batch_initial_conditions_manifold(
@@ -329,14 +339,63 @@ def _gather_raw_samples(X_loc, Y_loc, total, seed):
 
 
 def _selection(acq_function, options):
-    """the botorch heuristic gen_batch_initial_conditions_manifold applies to the scored raw samples, with its keyword arguments"""
-    select = initialize_q_batch
-    select_kwargs = {"eta": options["eta"]} if "eta" in options else {}
-    if options.get("nonnegative") or is_nonnegative(acq_function):
-        select = initialize_q_batch_nonneg
-        if "alpha" in options:
-            select_kwargs["alpha"] = options["alpha"]
-    return select, select_kwargs
+    """(nonneg, eta, alpha) of the botorch heuristic gen_batch_initial_conditions_manifold applies to the scored raw samples:
+    initialize_q_batch_nonneg for acquisition functions that are non-negative (or options["nonnegative"]), initialize_q_batch otherwise
+    (manifold_optimize.py:296-317), with their keyword arguments from `options`."""
+    nonneg = bool(options.get("nonnegative") or is_nonnegative(acq_function))
+    return nonneg, float(options.get("eta", 1.0)), float(options.get("alpha", 1e-4))
+
+
+def select_rows(y, n, generator, nonneg, eta=1.0, alpha=1e-4):
+    """Which n of the scored raw samples become restarts: models.initialize_q_batch_nonneg / initialize_q_batch ([3P] botorch.optim.initializers)
+    stated on ROW INDICES, for values that are already on the host.  y: (total,) float64 numpy array.  Returns (int64 index array of length n,
+    bad) - bad: the heuristic had to pick at random (botorch's BadInitialCandidatesWarning; the caller retries with more samples).
+    The comparisons and index bookkeeping are numpy; everything that feeds the random draw (the weights, torch.multinomial / torch.randperm on
+    `generator`) is the torch arithmetic of the functions it restates, so the rows picked are theirs, draw for draw (tests/test_selection_cpu.py).
+    Rounds 4-5 called those functions on torch tensors: a dozen tiny CPU-tensor operations, 0.16-0.25 ms of a 1.4-ms sweep."""
+    total = int(y.shape[0])
+    if n > total:
+        raise RuntimeError(f"n ({n}) cannot be larger than the number of provided samples ({total})")
+    if n == total:
+        return np.arange(total, dtype=np.int64), False
+    if not nonneg:
+        Y = torch.from_numpy(y)
+        Ystd = Y.std()
+        if Ystd == 0:
+            return torch.randperm(n=total, generator=generator)[:n].numpy().astype(np.int64), True
+        max_idx = int(torch.max(Y, dim=0)[1])
+        etaZ = eta * ((Y - Y.mean()) / Ystd)
+        weights = torch.exp(etaZ)
+        while torch.isinf(weights).any():
+            etaZ *= 0.5
+            weights = torch.exp(etaZ)
+        idcs = torch.multinomial(weights, n, generator=generator).numpy().astype(np.int64)
+        if max_idx not in idcs:
+            idcs[-1] = max_idx
+        return idcs, False
+    max_idx = int(np.argmax(y))                 # (first maximum; a NaN wins, as in torch.max)
+    max_val = float(y[max_idx])
+    if max_val != max_val:
+        raise RuntimeError("select_rows: the acquisition values of the raw samples contain NaN")       # (botorch's loop below would never end)
+    if max_val <= 0:
+        return torch.randperm(n=total, generator=generator)[:n].numpy().astype(np.int64), True
+    pos = y > 0
+    num_pos = int(pos.sum())
+    if num_pos < n:
+        remaining = n - num_pos
+        rand_idx = torch.randperm(total - num_pos, generator=generator)[:remaining].numpy()
+        both = np.concatenate([np.nonzero(pos)[0], np.nonzero(~pos)[0][rand_idx]])
+        return both[torch.randperm(n, generator=generator).numpy()].astype(np.int64), False
+    alpha_pos = y >= alpha * max_val
+    while alpha_pos.sum() < n:
+        alpha = 0.1 * alpha
+        alpha_pos = y >= alpha * max_val
+    pool = np.nonzero(alpha_pos)[0]
+    weights = torch.exp(eta * (torch.from_numpy(y[alpha_pos]) / max_val - 1))
+    idcs = pool[torch.multinomial(weights, n, generator=generator).numpy()].astype(np.int64)
+    if max_idx not in idcs:
+        idcs[-1] = max_idx
+    return idcs, False
 
 
 def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samples, bounds, sample_type, options, inequality_constraints,
@@ -350,9 +409,11 @@ def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samp
     from ..Riemannian_utils.spd_constraints_utils_torch import builtin_constraint
     from .. import _lib
     device = options.get("device")
-    if not (options.get("native_sweep", True) and device is not None and _dist() is None):
+    if not (options.get("native_sweep", True) and device is not None):
         return None
     if isinstance(manifold, Sphere):
+        if _dist() is not None:
+            return None       # (the sphere twin has no sharded form: the Python path below shards it)
         # the sphere twin (gabo_sphere_sweep_score / _solve): stock trust regions without constraints, exact or FD Hessian, host sampler
         if not (q == 1 and bounds is None and not solver_init_conds and sample_type == torch.float64 and isinstance(solver, BatchedTrustRegions)
                 and not solver.use_rand and solver.maxtime >= 1000 and solver.trace is None and not equality_constraints
@@ -406,11 +467,76 @@ def _native_sweep_plan(acq_function, manifold, solver, q, num_restarts, raw_samp
 _sweep_workspaces = {}
 
 
+def _all_gather_rows(dist, full, block):
+    """full (world * rows, width) <- every rank's block (rows, width): ONE collective; backends without all_gather_into_tensor take the list form"""
+    try:
+        dist.all_gather_into_tensor(full, block)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        parts = [torch.empty_like(block) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, block)
+        full.copy_(torch.cat(parts))
+
+
+class _RowsState:
+    """What one (device, stream) keeps between sweeps: the device workspace of the native driver (its two tables as tensors) and a block of PAGE-LOCKED
+    host memory the kernels write straight into (scores, result rows) and read from (picked rows) - no copy launch, no pageable staging; the host
+    looks at it through numpy once the stream has drained."""
+
+    def __init__(self, lib, dev, n_train, d, max_rows, restarts, n_constraints):
+        import ctypes
+        self.key = (n_train, d, max_rows, restarts, n_constraints)
+        dv = d * (d + 1) // 2
+        self.wsb = int(lib.gabo_spd_sweep_rows_workspace_bytes(n_train, d, max_rows, restarts, n_constraints))
+        self.ws = torch.empty(self.wsb // 8 + 1, dtype=torch.float64, device=dev)
+        raw_p, res_p = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib_check = lib.gabo_spd_sweep_rows_tables(self.ws.data_ptr(), n_train, d, max_rows, restarts, n_constraints, ctypes.byref(raw_p), ctypes.byref(res_p))
+        if _lib_check != 0:
+            raise RuntimeError("gabo_spd_sweep_rows_tables refused the workspace")
+        o_raw, o_res = (raw_p.value - self.ws.data_ptr()) // 8, (res_p.value - self.ws.data_ptr()) // 8
+        self.raw = self.ws[o_raw:o_raw + max_rows * (1 + dv)].view(max_rows, 1 + dv)
+        self.res = self.ws[o_res:o_res + restarts * (2 + dv)].view(restarts, 2 + dv)
+        self.pinned = torch.zeros(2 + max_rows + restarts + restarts * (2 + dv), dtype=torch.float64).pin_memory()
+        host = self.pinned.numpy()
+        self.err = host[:2].view(np.int32)                  # two status mirrors (score, solve): int32[2] each, written by a failing launch only
+        self.values = host[2:2 + max_rows]
+        self.picked = host[2 + max_rows:2 + max_rows + restarts].view(np.int64)
+        self.results = host[2 + max_rows + restarts:].reshape(restarts, 2 + dv)
+        base = self.pinned.data_ptr()
+        self.err_ptr = (base, base + 8)
+        self.values_ptr, self.picked_ptr, self.results_ptr = base + 16, base + 8 * (2 + max_rows), base + 8 * (2 + max_rows + restarts)
+        self.status = torch.zeros(2, 2, dtype=torch.int32, device=dev)      # the device words behind the mirrors (only a failing launch writes them)
+        self.status_ptr = (self.status.data_ptr(), self.status.data_ptr() + 8)
+
+    def raise_if_failed(self, which, what):
+        """after the stream has drained: did a launch of call `which` (0 score, 1 solve) report a non-SPD matrix?  Host memory only."""
+        e = self.err[2 * which:2 * which + 2]
+        if e[0] != 0:
+            idx = int(e[1])
+            e[:] = 0
+            self.status[which].zero_()
+            raise RuntimeError(f"{what}: input matrix #{idx} is not positive definite (Cholesky pivot <= 0)")
+
+
+def _rows_state(lib, dev, stream, n_train, d, max_rows, restarts, n_constraints):
+    key = (dev.index, stream)
+    st = _sweep_workspaces.get(key)
+    if st is None or st.key != (n_train, d, max_rows, restarts, n_constraints):
+        st = _sweep_workspaces[key] = _RowsState(lib, dev, n_train, d, max_rows, restarts, n_constraints)
+    return st
+
+
 def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options):
-    """joint_optimize_manifold through gabo_spd_sweep_score / gabo_spd_sweep_solve: the draws from numpy's and torch's generators, the
-    selection heuristic and every device launch are those of the Python path (same order, same operands), so the candidate returned is the
-    same, bit for bit (tests/test_gpu_native_sweep.py)."""
+    """joint_optimize_manifold through the native driver (csrc/spd_sweep.hip): gabo_spd_sweep_score_rows -> selection on the host ->
+    gabo_spd_sweep_solve_rows -> argmax - three launches and two waits per sweep on one GPU.  The draws from numpy's and torch's generators, the
+    selection heuristic and every statement executed on the device are those of the Python path, so the candidate returned is the same, bit for bit
+    (tests/test_gpu_native_sweep.py).
+
+    With torch.distributed initialised: rank r draws and scores raw samples [r * per, (r + 1) * per) into its block of the raw-row table,
+    ONE all_gather assembles the table (each block led by a header row that carries the rank's proposal for the selection seed; rank 0's is used),
+    every rank selects the same rows, solves restarts r, r + P, r + 2P, ... and ONE all_gather of the result rows followed by an argmax in restart
+    order (first index on ties) replaces get_best_candidates (manifold_optimize.py:118-120).  Exactly two collectives, none inside the driver."""
     import ctypes
+    import time
 
     from .. import _lib, ops
     if plan.get("sphere"):
@@ -418,6 +544,8 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
     lib = _lib.load()
     fused, dev, man = plan["fused"], plan["device"], plan["manifold"]
     d, dv, R = man._n, man._n * (man._n + 1) // 2, int(num_restarts)
+    dist = _dist()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     cfg = _lib.SweepConfig()
     cfg.acq = fused.acq_params()
     cfg.d = d
@@ -431,63 +559,96 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
     cfg.theta, cfg.kappa, cfg.mininner, cfg.maxinner = float(solver.theta), float(solver.kappa), 1, int(man.dim)
     cfg.rho_prime, cfg.rho_regularization = float(solver.rho_prime), float(solver.rho_regularization)
     cfg.mingradnorm, cfg.maxiter = float(solver.mingradnorm), int(solver.maxiter)
-    select, select_kwargs = _selection(acq_function, options)
-    status = ops._status_word(dev)
-    import time
+    nonneg, eta, alpha = _selection(acq_function, options)
+    cfg_ref = ctypes.byref(cfg)
+    checking = ops._check_errors is not False
+    r_loc, r_per = len(range(rank, R, world)), (R + world - 1) // world
+    n_train = int(fused.train.shape[0])
     time0 = time.time()
     with torch.cuda.device(dev):
         stream = ops._stream_ptr(dev)
         picked = None
         for attempt in range(1, 5):                     # the reference's factor = 1 ... max_factor - 1 (manifold_optimize.py:283-320)
             total = raw_samples * attempt
-            wsb = int(lib.gabo_spd_sweep_workspace_bytes(int(fused.train.shape[0]), d, total, R, cfg.n_constraints))
-            key = (dev.index, stream)
-            ws = _sweep_workspaces.get(key)
-            if ws is None or ws.numel() < wsb:
-                ws = _sweep_workspaces[key] = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            per = (total + world - 1) // world          # samples per rank; a rank's block of the table = one header row + per sample rows
+            lo = min(rank * per, total)
+            cnt = min(lo + per, total) - lo
+            st = _rows_state(lib, dev, stream, n_train, d, world * (per + 1), max(r_per, 1), cfg.n_constraints)
+            row0 = rank * (per + 1) + 1
             seed, raw = 0, None
-            if plan["device_rand"]:
-                seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))       # (the draw of manifolds.PositiveDefinite.rand_batch_device)
-            elif options.get("batched_rand") and hasattr(man, "rand_batch"):       # the host samplers of _draw_raw_samples, same draws
-                raw = np.ascontiguousarray(man.rand_batch(total), dtype=np.float64)
-            else:
-                raw = np.ascontiguousarray(np.stack([np.asarray(man.rand()) for _ in range(total)]), dtype=np.float64)
-            if raw is not None and raw.shape != (total, d, d):
+            with _rank_stream(rank, world if not plan["device_rand"] else 1):
+                if plan["device_rand"]:
+                    seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))       # (the draw of manifolds.PositiveDefinite.rand_batch_device)
+                elif options.get("batched_rand") and hasattr(man, "rand_batch"):       # the host samplers of _draw_raw_samples, same draws
+                    raw = np.ascontiguousarray(man.rand_batch(cnt), dtype=np.float64)
+                else:
+                    raw = np.ascontiguousarray(np.stack([np.asarray(man.rand()) for _ in range(cnt)]), dtype=np.float64) if cnt else np.zeros((0, d, d))
+            if raw is not None and raw.shape != (cnt, d, d):
                 raise RuntimeError(f"manifold.rand returned points of shape {raw.shape[1:]}, expected ({d}, {d})")
-            y = np.empty(total, dtype=np.float64)
-            rc = lib.gabo_spd_sweep_score(ctypes.byref(cfg), total, total, R, seed & 0xFFFFFFFFFFFFFFFF, None if raw is None else raw.ctypes.data,
-                                          y.ctypes.data, ws.data_ptr(), wsb, status.data_ptr(), stream)
-            ops._check_launch(rc, status, "gabo_spd_sweep_score")
-            ops.check_deferred()
+            _mark(options, "-> score")
+            pending = ops.prefetch_deferred()           # (the GP's set-up launches: their status words travel while the scoring launches run)
+            if cnt:
+                rc = lib.gabo_spd_sweep_score_rows(cfg_ref, lo, row0, cnt, world * (per + 1), max(r_per, 1), seed & 0xFFFFFFFFFFFFFFFF,
+                                                   None if raw is None else raw.ctypes.data, st.values_ptr if world == 1 else None, st.ws.data_ptr(),
+                                                   st.wsb, st.status_ptr[0], st.err_ptr[0], 1 if world == 1 else 0, stream)
+                if rc != 0:
+                    _lib.check(rc, "gabo_spd_sweep_score_rows")
+            _mark(options, "<- score")
             sel_seed = int(torch.randint(0, 2 ** 52, (1,)).item())
+            if world == 1:
+                y = st.values[:total]
+            else:
+                # the ONE collective of this stage: every rank's block (header + rows) -> the whole table, in place on every rank
+                block = st.raw[rank * (per + 1):(rank + 1) * (per + 1)]
+                block[0, 0] = float(sel_seed)           # < 2^52: exact in a double
+                _all_gather_rows(dist, st.raw, block.clone())
+                col = st.raw[:, 0].cpu().numpy().reshape(world, per + 1)         # (this copy waits for the stream)
+                sel_seed = int(col[0, 0])
+                y = np.ascontiguousarray(col[:, 1:].reshape(-1)[:total])
+            ops.check_prefetched(pending)
+            if checking:
+                st.raise_if_failed(0, "gabo_spd_sweep_score_rows")
+            _mark(options, "<- checks")
             gen = torch.Generator()
             gen.manual_seed(sel_seed)
-            rows = torch.arange(total).reshape(-1, 1, 1)
-            with warnings.catch_warnings(record=True) as caught:
-                warnings.simplefilter("always")
-                picked = select(X=rows, Y=torch.from_numpy(y), n=R, generator=gen, **select_kwargs)
-            if not any(issubclass(w_.category, BadInitialCandidatesWarning) for w_ in caught):
+            picked, bad = select_rows(y, R, gen, nonneg, eta, alpha)
+            if not bad:
                 break
         else:
             warnings.warn("Unable to find non-zero acquisition function values - initial conditions are being selected randomly.",
                           BadInitialCandidatesWarning)
-        idx = np.ascontiguousarray(picked.reshape(-1).numpy(), dtype=np.int64)
-        best, iters = ctypes.c_int64(0), ctypes.c_int64(0)
-        value = ctypes.c_double(0.0)
-        cand_p, cost_p, it_p = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
-        rc = lib.gabo_spd_sweep_solve(ctypes.byref(cfg), idx.ctypes.data, R, total, ctypes.byref(best), ctypes.byref(value), ctypes.byref(iters),
-                                      ctypes.byref(cand_p), ctypes.byref(cost_p), ctypes.byref(it_p), ws.data_ptr(), wsb, status.data_ptr(), stream)
-        ops._check_launch(rc, status, "gabo_spd_sweep_solve")
-    base = ws.data_ptr()
-
-    def view(ptr, count, dtype):
-        off = int(ptr.value) - base
-        return ws[off:off + 8 * count].view(dtype)
-    cands = view(cand_p, R * dv, torch.float64).reshape(R, dv)
-    solver.log = {"iterations": int(iters.value), "per_restart_iterations": view(it_p, R, torch.int64).clone(),
-                  "final_cost": view(cost_p, R, torch.float64).clone(), "final_gradnorm": None, "cost_evals": 0, "grad_evals": 0,
-                  "time": time.time() - time0, "one_launch_solve": True, "native_sweep": True}
-    return cands[int(best.value)].reshape(1, dv).clone()
+        _mark(options, "<- selection")
+        mine = picked[rank::world]                       # restart k belongs to rank k % world (trust-region iteration counts vary: interleaved)
+        st.picked[:r_loc] = (mine // per) * (per + 1) + 1 + mine % per          # sample index -> row of the table
+        if world > 1 and r_loc < r_per:
+            st.res[r_loc:, 0] = float("inf")             # (a rank with one restart fewer: its padding row loses every argmax)
+        if r_loc:
+            rc = lib.gabo_spd_sweep_solve_rows(cfg_ref, st.picked_ptr, r_loc, world * (per + 1), st.results_ptr if world == 1 else None,
+                                               st.ws.data_ptr(), st.wsb, st.status_ptr[1], st.err_ptr[1], 1 if world == 1 else 0, stream)
+            if rc != 0:
+                _lib.check(rc, "gabo_spd_sweep_solve_rows")
+        _mark(options, "<- solve")
+        if world == 1:
+            rows = st.results[:R]
+        else:
+            gathered = torch.empty(world * r_per, 2 + dv, dtype=torch.float64, device=dev)
+            _all_gather_rows(dist, gathered, st.res[:r_per].clone())
+            # rank r's row j is restart j * world + r           (the copy to the host waits for the stream)
+            rows = gathered.cpu().numpy().reshape(world, r_per, 2 + dv).transpose(1, 0, 2).reshape(world * r_per, 2 + dv)[:R]
+        if checking:
+            st.raise_if_failed(1, "gabo_spd_sweep_solve_rows")
+    cost = rows[:, 0]
+    nan = np.isnan(cost)
+    best = int(np.argmax(nan)) if nan.any() else int(np.argmin(cost))         # torch.argmax(-cost): a NaN wins, the first of equal values
+    solver.log = {"iterations": int(rows[:, 1].max()), "per_restart_iterations": torch.from_numpy(rows[:, 1].astype(np.int64)),
+                  "final_cost": torch.from_numpy(cost.copy()), "final_gradnorm": None, "cost_evals": 0, "grad_evals": 0,
+                  "time": time.time() - time0, "one_launch_solve": True, "native_sweep": True, "world_size": world}
+    if world == 1:
+        out = st.res[best, 2:].clone().reshape(1, dv)          # (the winner's row of the device table: no host -> device copy)
+    else:
+        out = torch.from_numpy(rows[best, 2:].copy()).reshape(1, dv).to(dev)
+    _mark(options, "<- result")
+    return out
 
 
 def _native_sweep_sphere(plan, acq_function, solver, num_restarts, raw_samples, options):
@@ -507,7 +668,7 @@ def _native_sweep_sphere(plan, acq_function, solver, num_restarts, raw_samples, 
     cfg.exact_hessian = 1 if plan["exact_hessian"] else 0
     cfg.rho_prime, cfg.rho_regularization = float(solver.rho_prime), float(solver.rho_regularization)
     cfg.mingradnorm, cfg.maxiter = float(solver.mingradnorm), int(solver.maxiter)
-    select, select_kwargs = _selection(acq_function, options)
+    nonneg, eta, alpha = _selection(acq_function, options)
     time0 = time.time()
     with torch.cuda.device(dev):
         stream = ops._stream_ptr(dev)
@@ -532,16 +693,13 @@ def _native_sweep_sphere(plan, acq_function, solver, num_restarts, raw_samples, 
             sel_seed = int(torch.randint(0, 2 ** 52, (1,)).item())
             gen = torch.Generator()
             gen.manual_seed(sel_seed)
-            rows = torch.arange(total).reshape(-1, 1, 1)
-            with warnings.catch_warnings(record=True) as caught:
-                warnings.simplefilter("always")
-                picked = select(X=rows, Y=torch.from_numpy(y), n=R, generator=gen, **select_kwargs)
-            if not any(issubclass(w_.category, BadInitialCandidatesWarning) for w_ in caught):
+            picked, bad = select_rows(y, R, gen, nonneg, eta, alpha)
+            if not bad:
                 break
         else:
             warnings.warn("Unable to find non-zero acquisition function values - initial conditions are being selected randomly.",
                           BadInitialCandidatesWarning)
-        idx = np.ascontiguousarray(picked.reshape(-1).numpy(), dtype=np.int64)
+        idx = np.ascontiguousarray(picked, dtype=np.int64)
         best, iters = ctypes.c_int64(0), ctypes.c_int64(0)
         value = ctypes.c_double(0.0)
         cand_p, cost_p, it_p = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
@@ -571,7 +729,7 @@ def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num
     identical random stream - so all ranks hold the same initial conditions without a broadcast."""
     options = options or {}
     q = 1 if q is None else q
-    select, select_kwargs = _selection(acq_function, options)
+    nonneg, eta, alpha = _selection(acq_function, options)
     dist = _dist()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     chosen = None
@@ -587,20 +745,17 @@ def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num
         X_rnd, Y_rnd, seed = _gather_raw_samples(X_loc, Y_loc, total, seed)
         # The selection heuristic is a dozen data-dependent decisions on `total` scalars: on the device every one of them is a launch and a
         # read-back (0.85 ms of the 4.4-ms config-4 sweep, tools/sweep_phases2.py); here the values come to the host in ONE copy, the heuristic
-        # selects ROW INDICES there (same functions, host generator with the common seed: identical on every rank) and the rows are gathered
+        # selects ROW INDICES there (select_rows; host generator with the common seed: identical on every rank) and the rows are gathered
         # on the device.
         gen = torch.Generator()
         gen.manual_seed(seed)
-        rows = torch.arange(X_rnd.shape[0]).reshape(-1, 1, 1)
-        with warnings.catch_warnings(record=True) as caught:
-            warnings.simplefilter("always")
-            y_host = Y_rnd.detach().cpu()          # (the host waits for the scores here anyway: deferred launch checks cost nothing now)
-            if Y_rnd.is_cuda:
-                from .. import ops as _ops
-                _ops.check_deferred()
-            picked = select(X=rows, Y=y_host, n=num_restarts, generator=gen, **select_kwargs)
-        chosen = X_rnd.index_select(0, picked.reshape(-1).to(X_rnd.device))
-        if not any(issubclass(w.category, BadInitialCandidatesWarning) for w in caught):
+        y_host = Y_rnd.detach().double().cpu().numpy()          # (the host waits for the scores here anyway: deferred launch checks cost nothing now)
+        if Y_rnd.is_cuda:
+            from .. import ops as _ops
+            _ops.check_deferred()
+        picked, bad = select_rows(np.ascontiguousarray(y_host.reshape(-1)), num_restarts, gen, nonneg, eta, alpha)
+        chosen = X_rnd.index_select(0, torch.from_numpy(picked).to(X_rnd.device))
+        if not bad:
             return chosen
     warnings.warn("Unable to find non-zero acquisition function values - initial conditions are being selected randomly.",
                   BadInitialCandidatesWarning)

@@ -39,16 +39,27 @@ class ExactGP(torch.nn.Module):
             n = self.train_x.shape[-2]
             if self.train_x.is_cuda and 0 < n <= _l.GABO_GP_FACTOR_MAX_N:
                 # one launch instead of Cholesky (+ its info read-back), cholesky_solve and a triangular solve (csrc/gp_factor.hip)
+                def drop(model=self):
+                    # (the factor this cache was to hold does not exist: ops.check_deferred calls this before it raises)
+                    model._cache = None
+                    model._cache_linv_t = None
+                    model._cache_factors = None
                 with torch.no_grad():
                     from .kernel_utils import kernels_spd as _ks
                     bk = self.base_kernel
-                    if type(bk) in (_ks.SpdAffineInvariantGaussianKernel, _ks.SpdAffineInvariantLaplaceKernel) and self.train_x.dim() == 2:
-                        # (what bk.forward launches - the x1-is-x2 build - without the autograd wrapper around it)
+                    if type(bk) in (_ks.SpdAffineInvariantGaussianKernel, _ks.SpdAffineInvariantLaplaceKernel) and self.train_x.dim() == 2 \
+                            and self.train_x.shape[-1] <= _l.GABO_SPD_REG_MAX_DIM * (_l.GABO_SPD_REG_MAX_DIM + 1) // 2:
+                        # (what bk.forward launches - the x1-is-x2 build - then the factor and the fused evaluators' training factors: one host call)
                         mode = _l.GABO_OUT_GAUSSIAN if type(bk) is _ks.SpdAffineInvariantGaussianKernel else _l.GABO_OUT_LAPLACE
-                        kb = _ops.spd_ai_pairwise(self.train_x, self.train_x, float(bk.beta.double()), mode, symmetric=True)
-                    else:
-                        kb = bk.forward(self.train_x, self.train_x).double()
-                    Linv, Linv_t, alpha = _ops.gp_factor(kb, self.train_y, float(self.outputscale), float(self.noise), float(self.mean), defer_check=True)
+                        Linv, Linv_t, alpha, factors = _ops.spd_gp_prepare(self.train_x, self.train_y, bk.beta_float(), mode, float(self.outputscale),
+                                                                           float(self.noise), float(self.mean), on_fail=drop)
+                        self._cache = (Linv, alpha)
+                        self._cache_linv_t = (self._cache, Linv_t)
+                        self._cache_factors = (self._cache, factors)
+                        return self._cache
+                    kb = bk.forward(self.train_x, self.train_x).double()
+                    Linv, Linv_t, alpha = _ops.gp_factor(kb, self.train_y, float(self.outputscale), float(self.noise), float(self.mean), defer_check=True,
+                                                         on_fail=drop)
                 self._cache = (Linv, alpha)
                 self._cache_linv_t = (self._cache, Linv_t)
                 return self._cache
@@ -490,7 +501,10 @@ class SingleTaskGP(torch.nn.Module):
             if kb.dim() != 2:
                 return
             mu = self.mean_constant.detach().to(kb.device)
-            Linv, Linv_t, alpha = _ops.gp_factor(kb.double(), self.train_y, outputscale, float(self.noise.detach()), float(mu), defer_check=True)
+            def drop(model=self):
+                model._cache = None
+                model._cache_linv_t = None
+            Linv, Linv_t, alpha = _ops.gp_factor(kb.double(), self.train_y, outputscale, float(self.noise.detach()), float(mu), defer_check=True, on_fail=drop)
         self._cache = (Linv, alpha, mu)
         self._cache_linv_t = (self._cache, Linv_t)
 

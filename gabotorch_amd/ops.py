@@ -8,18 +8,28 @@ import torch
 
 from . import _lib
 
-_check_errors = True
+_check_errors = "deferred"
 
 
 def set_error_checking(flag):
-    """Device-side data errors (non-SPD input) are read back after each call when enabled (costs a stream sync).
-    The reference raises from torch.cholesky in that case; disable inside latency-critical loops."""
+    """How device-side data errors (a non-SPD input matrix, a NaN entry) reach the caller.  The reference raises from torch.cholesky at the call
+    (spd_utils_torch.py:87); a launch is asynchronous, so raising AT the call costs a stream synchronisation per call.
+      "deferred" (default): every launch gets a status word of its own; the words are read back - ONE copy for all pending launches of a stream -
+                 at the next synchronisation point: check_deferred(), which the acquisition sweep, the GP posterior and the solvers call where
+                 they wait for the device anyway, or when 63 launches are pending on one stream.  The RuntimeError names the launch that failed.
+      True / "sync": read back after every call (one stream synchronisation per call): the reference's behaviour to the statement.
+      False:     never read.
+    Returns the previous setting."""
     global _check_errors
     prev = _check_errors
-    _check_errors = bool(flag)
-    if _check_errors and not prev:
-        for w in _status_words.values():
-            w.zero_()
+    if flag == "sync":
+        flag = True
+    if flag not in (True, False, "deferred"):
+        raise ValueError("set_error_checking: True / 'sync', 'deferred' or False")
+    if prev is False and flag is not False:
+        for ring in _status_rings.values():       # (nobody looked at the words while checking was off: start from clean ones)
+            ring.reset()
+    _check_errors = flag
     return prev
 
 
@@ -33,7 +43,26 @@ def _device_for(*tensors):
 
 
 def _stream_ptr(device):
-    return torch.cuda.current_stream(device).cuda_stream
+    """raw hipStream_t of torch's current stream on `device` (torch.cuda.current_stream builds a Stream object around the same call: 4 us a time)"""
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+
+
+class _NoCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CTX = _NoCtx()
+
+
+def _on(device):
+    """`with _on(dev):` = `with _on(dev):` when dev is not the current device, nothing otherwise (the guard object costs ~8 us)"""
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+    return _NO_CTX if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(idx)
 
 
 def _flatten_batch(x, tail_dims):
@@ -74,19 +103,79 @@ def _require(dev, **tensors):
                             f"{'' if not torch.is_tensor(t) or t.is_contiguous() else ' (not contiguous)'}")
 
 
-_status_words = {}
+class _StatusRing:
+    """The status words (two int32: error code, index of the offender) of the launches on ONE stream of one device: a ring of `N` words in
+    device memory, zeroed once - the kernels only ever write a word on an error, so no fill launch in front of a call (4 us of GPU time next to a
+    6 us projection, profiles/r03_config5_kernel_stats.csv) - each launch taking the next word.  `pending` holds (slot, message, on_fail) of the
+    launches nobody has checked yet; check() waits for the stream, reads the whole ring in one copy, forgets the launches that succeeded and raises
+    for the first that did not (clearing its word, calling its on_fail first)."""
+    N = 64
+
+    def __init__(self, dev, stream):
+        self.buf = torch.zeros(self.N, 2, dtype=torch.int32, device=dev)
+        self.stream = stream
+        self.next = 0
+        self.pending = []
+
+    def take(self):
+        k = self.next = self.next % (self.N - 1) + 1          # slots 1 ... N - 1 (slot 0: the word of launches nobody checks)
+        w = self.buf[k]
+        w._gabo_slot = (self, k)
+        return w
+
+    def reset(self):
+        with torch.cuda.stream(self.stream):
+            self.buf.zero_()
+        self.pending.clear()
+
+    def prefetch(self):
+        """Enqueue, behind everything on the ring's stream so far, a copy of the ring into page-locked host memory; -> how many pending launches
+        it covers.  For a caller that is about to wait for the stream anyway: evaluate() afterwards costs no device access."""
+        if getattr(self, "host", None) is None:
+            self.host = torch.zeros(self.N, 2, dtype=torch.int32).pin_memory()
+        if _stream_ptr(self.buf.device) == self.stream.cuda_stream:
+            self.host.copy_(self.buf, non_blocking=True)
+        else:
+            with torch.cuda.stream(self.stream):
+                self.host.copy_(self.buf, non_blocking=True)
+        return len(self.pending)
+
+    def check(self):
+        if not self.pending:
+            return
+        with torch.cuda.stream(self.stream):
+            vals = self.buf.cpu()              # (waits for everything enqueued on the ring's stream)
+        self.evaluate(vals.tolist(), len(self.pending))
+
+    def evaluate(self, vals, count):
+        """the first `count` pending launches against a host copy of the ring taken after they had completed"""
+        for _ in range(min(count, len(self.pending))):
+            k, message, on_fail = self.pending.pop(0)
+            st = vals[k]
+            if st[0] != 0:
+                st = [int(st[0]), int(st[1])]
+                with torch.cuda.stream(self.stream):
+                    self.buf[k].zero_()
+                if on_fail is not None:
+                    on_fail()
+                raise RuntimeError(message(st) if callable(message) else message)
 
 
-def _status_word(dev):
-    """The device status word of the entry points (two int32: error code, index of the offender), one cached buffer per device: the kernels
-    only ever write it on an error, so it is zeroed when created and again after an error has been raised - not by a fill launch in front
-    of every call (4 us of GPU time next to a 6 us projection, profiles/r03_config5_kernel_stats.csv).  With error checking off nobody
-    reads it; set_error_checking(True) starts from a clean word."""
-    key = (dev.type, dev.index)
-    w = _status_words.get(key)
-    if w is None:
-        w = _status_words[key] = torch.zeros(2, dtype=torch.int32, device=dev)
-    return w
+_status_rings = {}
+
+
+def _status_word(dev, force=False):
+    """A status word for the launch about to be enqueued on the current stream of `dev` (a view of that stream's ring: _StatusRing).
+    force: a word that is registered and read even while error checking is off (the GP's Cholesky: see gp_factor)."""
+    key = (dev.index, _stream_ptr(dev))
+    ring = _status_rings.get(key)
+    if ring is None:
+        ring = _status_rings[key] = _StatusRing(dev, torch.cuda.current_stream(dev))
+    if _check_errors is False and not force:
+        return ring.buf[0]          # (never read while checking is off; set_error_checking clears the ring when it comes back on)
+    if len(ring.pending) >= ring.N - 2:
+        ring.check()
+    return ring.take()
 
 
 def _mandel_dim(dv):
@@ -96,23 +185,79 @@ def _mandel_dim(dv):
     return d
 
 
-def _raise_if_not_spd(status, what):
-    if _check_errors:
+def _not_spd_message(what):
+    return lambda st: f"{what}: input matrix #{st[1]} is not positive definite (Cholesky pivot <= 0)"
+
+
+def _raise_if_not_spd(status, what, message=None, on_fail=None, force=False):
+    """Called after the launch that was handed `status`: registers the launch for the next check (deferred), or reads the word now (sync).
+    message: the RuntimeError's text, or a callable of the two status ints; on_fail: called before raising (e.g. to drop a cache the failed launch
+    was meant to fill)."""
+    if _check_errors is False and not force:
+        return
+    message = message or _not_spd_message(what)
+    slot = getattr(status, "_gabo_slot", None)
+    if slot is not None:
+        ring, k = slot
+        ring.pending.append((k, message, on_fail))
+        if _check_errors is True:
+            ring.check()
+        return
+    # a word of the caller's own (fixed address: captured in a hipGraph, or owned by a solver object)
+    if _check_errors is True:
         st = status.tolist()
         if st[0] != 0:
             status.zero_()
-            raise RuntimeError(f"{what}: input matrix #{st[1]} is not positive definite (Cholesky pivot <= 0)")
+            if on_fail is not None:
+                on_fail()
+            raise RuntimeError(message(st) if callable(message) else message)
+    else:
+        _deferred.append((status, message, on_fail))
+        if len(_deferred) > 32:
+            check_deferred()
 
 
-def _check_launch(rc, status, what):
-    """return code first, then the device status word.  The cached per-device word (_status_word) must never outlive the call that wrote it: if
-    the return code already raises, the word is cleared on the way out, so a later valid call cannot be blamed for this one's matrix."""
+def _check_launch(rc, status, what, on_fail=None):
+    """return code first, then the device status word.  A launch refused by its return code never ran: its word is not registered."""
     try:
         _lib.check(rc, what)
     except Exception:
-        status.zero_()
+        if on_fail is not None:
+            on_fail()
         raise
-    _raise_if_not_spd(status, what)
+    _raise_if_not_spd(status, what, on_fail=on_fail)
+
+
+_deferred = []
+
+
+def prefetch_deferred():
+    """For a caller that is about to wait for its stream anyway (the acquisition sweep before its scoring call returns): enqueue the read-back of
+    every status ring that has unchecked launches and return a token for check_prefetched - which then needs no device access at all."""
+    return [(ring, ring.prefetch()) for ring in _status_rings.values() if ring.pending]
+
+
+def check_prefetched(token):
+    """check_deferred for the launches covered by prefetch_deferred's token; ONLY after the streams those copies were enqueued on have been
+    waited for (the data is read from host memory as it is)."""
+    for ring, count in token:
+        ring.evaluate(ring.host.numpy(), count)
+
+
+def check_deferred():
+    """Reads the status words of every launch that has not been checked yet - one copy per stream that has any - and raises for the first failure,
+    naming the launch.  Called at the natural host synchronisation points of a sweep (after the raw samples' scores have reached the host, after a
+    solve, before a posterior); free when nothing is pending.  The launches that were still queued behind a failed one stay queued."""
+    for ring in list(_status_rings.values()):
+        ring.check()
+    while _deferred:
+        status, message, on_fail = _deferred.pop(0)
+        st = status.tolist()
+        if st[0] != 0:
+            status.zero_()
+            if on_fail is not None:
+                on_fail()
+            raise RuntimeError(message(st) if callable(message) else message)
 
 
 def spd_ai_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, symmetric=False, return_dist=False):
@@ -137,7 +282,7 @@ def spd_ai_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, symmetric=Fal
     ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
     status = _status_word(dev)
     flags = int(mode) | (_lib.GABO_SYMMETRIC if symmetric else 0)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.gabo_spd_ai_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), dist.data_ptr() if return_dist else None,
                                       nb, n1, n2, d, s1, s2, float(beta), flags, ws.data_ptr(), wsb, status.data_ptr(),
                                       _stream_ptr(dev))
@@ -170,8 +315,8 @@ def spd_ai_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, wrt
         return gx.to(out_device)
     wsb = lib.gabo_spd_ai_workspace_bytes(nb, m1, m2, d)
     ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
-    status = torch.zeros(2, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    status = _status_word(dev)
+    with _on(dev):
         rc = lib.gabo_spd_ai_backward(first.data_ptr(), second.data_ptr(), g.data_ptr(), gx.data_ptr(), nb, m1, m2, d, sf, ss,
                                       n1 * n2, go_si, go_sj, float(beta), int(mode), ws.data_ptr(), wsb, status.data_ptr(),
                                       _stream_ptr(dev))
@@ -207,8 +352,8 @@ def spd_ai_backward2(x1, x2, grad_out, u, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN,
         return hv.to(out_device), (None if dg is None else dg.to(out_device)), (None if mx is None else mx.to(x2.device))
     wsb = lib.gabo_spd_ai_backward2_workspace_bytes(nb, n1, n2, d)
     ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
-    status = torch.zeros(2, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    status = _status_word(dev)
+    with _on(dev):
         rc = lib.gabo_spd_ai_backward2(a2.data_ptr(), b2.data_ptr(), g.data_ptr(), uu.data_ptr(), hv.data_ptr(), None if dg is None else dg.data_ptr(),
                                        None if mx is None else mx.data_ptr(), nb, n1, n2, d, s1, s2, n1 * n2, n2, 1, float(beta), int(mode),
                                        ws.data_ptr(), wsb, status.data_ptr(), _stream_ptr(dev))
@@ -347,7 +492,7 @@ def sphere_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, diag=False, s
     if out.numel() == 0:
         return out.to(out_device)
     flags = int(mode) | (_lib.GABO_SYMMETRIC if symmetric and not diag else 0)
-    with torch.cuda.device(dev):
+    with _on(dev):
         stream = _stream_ptr(dev)
         ktable = None
         # (not while a hipGraph is being captured: a build recorded into the graph would not have run for eager launches that find it cached)
@@ -385,7 +530,7 @@ def sphere_from_inner(inner, beta, mode, order):
     dev = _device_for(inner)
     c = _prep(inner, dev).contiguous()
     out = torch.empty_like(c)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_sphere_from_inner(c.data_ptr(), out.data_ptr(), c.numel(), float(beta), int(mode), int(order),
                                               _stream_ptr(dev)), "gabo_sphere_from_inner")
     return out.to(out_device)
@@ -462,7 +607,7 @@ def mandel_to_matrix(vec):
         raise RuntimeError(f"last dimension {dv} is not d(d+1)/2")
     n = v.numel() // dv if dv else 0
     out = torch.empty(v.shape[:-1] + (d, d), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_mandel_to_matrix(v.data_ptr(), out.data_ptr(), n, d, _stream_ptr(dev)), "gabo_mandel_to_matrix")
     return out.to(out_device)
 
@@ -478,7 +623,7 @@ def matrix_to_mandel(mat):
         raise RuntimeError("last two dimensions must be square")
     n = m.numel() // (d * d)
     out = torch.empty(m.shape[:-2] + (d * (d + 1) // 2,), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_matrix_to_mandel(m.data_ptr(), out.data_ptr(), n, d, _stream_ptr(dev)), "gabo_matrix_to_mandel")
     return out.to(out_device)
 
@@ -521,7 +666,7 @@ def spd_manifold_op(op, a, b=None, c=None, e=None, want_grad=False):
         out2 = torch.empty(shape[:-2] + (d * d + d,), dtype=torch.float64, device=dev)      # V and the eigenvalues, for the backward
     status = _status_word(dev)
     ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.gabo_spd_manifold_op(int(op), ptr(A), ptr(B), ptr(C), ptr(E), out.data_ptr(), ptr(out2), n, d, status.data_ptr(),
                                       _stream_ptr(dev))
     _check_launch(rc, status, "gabo_spd_manifold_op")
@@ -550,7 +695,7 @@ class _SpdMatFun(torch.autograd.Function):
         d = ctx.shape[-1]
         G = _prep(g, dev).expand(eig.shape[:-1] + (d, d)).contiguous()
         out = torch.empty_like(G)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.gabo_spd_matfun_backward_eig(ctx.op, eig.data_ptr(), G.data_ptr(), out.data_ptr(), G.numel() // (d * d), d,
                                                         _stream_ptr(dev)), "gabo_spd_matfun_backward_eig")
         return out.reshape(ctx.shape).to(ctx.device, ctx.dtype), None
@@ -579,8 +724,8 @@ class NestedSpdReconstruction:
             raise RuntimeError(f"shapes: x_data {tuple(X.shape)}, x_data_projected {tuple(self.y.shape)}, projection_matrix {tuple(self.w.shape)}")
         self.sqrt_y = (spd_manifold_op(_lib.GABO_SPD_SQRTM, self.y) if sqrt_low is None else _prep(sqrt_low, dev)).contiguous()
         self.data = torch.empty_like(X)
-        status = torch.zeros(2, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        status = _status_word(dev)
+        with _on(dev):
             _lib.check(lib.gabo_nested_spd_reconstruction_prepare(X.data_ptr(), self.data.data_ptr(), self.N, self.D, self.metric,
                                                                   status.data_ptr(), _stream_ptr(dev)), "gabo_nested_spd_reconstruction_prepare")
         _raise_if_not_spd(status, "gabo_nested_spd_reconstruction_prepare")
@@ -760,7 +905,7 @@ def nested_spd_lift_prepare(w, v, c, k):
         raise RuntimeError(f"nested SPD mapping shapes: W {tuple(W.shape)}, V {tuple(V.shape)}, C {tuple(C.shape)}, K {tuple(K.shape)}")
     x0 = torch.empty(D, D, dtype=torch.float64, device=dev)
     p = torch.empty(D, d, dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_nested_spd_lift_prepare(V.data_ptr(), C.data_ptr(), K.data_ptr(), x0.data_ptr(), p.data_ptr(), D, d, _stream_ptr(dev)),
                    "gabo_nested_spd_lift_prepare")
     return W, x0, p
@@ -777,7 +922,7 @@ def nested_spd_extreme_eigenvalues(y, w, p, x0, want_grad=False):
     R = Y.numel() // (d * d)
     lam = torch.empty(Y.shape[:-2] + (2,), dtype=torch.float64, device=dev)
     grad = torch.empty(Y.shape[:-2] + (2, d, d), dtype=torch.float64, device=dev) if want_grad else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_nested_spd_extreme_eigenvalues(Y.data_ptr(), w.data_ptr(), p.data_ptr(), x0.data_ptr(), lam.data_ptr(),
                                                            None if grad is None else grad.data_ptr(), R, D, d, _stream_ptr(dev)),
                    "gabo_nested_spd_extreme_eigenvalues")
@@ -820,7 +965,7 @@ def spd_project(x_mandel, w):
     dl = W.shape[1]
     n = x.numel() // x.shape[-1]
     out = torch.empty(x.shape[:-1] + (dl * (dl + 1) // 2,), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_spd_project(x.data_ptr(), W.data_ptr(), out.data_ptr(), n, D, dl, _stream_ptr(dev)), "gabo_spd_project")
     return out.to(out_device)
 
@@ -883,7 +1028,7 @@ def nested_spd_gram(x1, x2, w, beta, metric=_lib.GABO_METRIC_AFFINE_INVARIANT, m
     wsb = lib.gabo_nested_spd_gram_workspace_bytes(nb, n1, n2, dl)
     ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
     status = _status_word(dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.gabo_nested_spd_gram(a.data_ptr(), b.data_ptr(), W.data_ptr(), out.data_ptr(), nb, n1, n2, D, dl, int(metric), float(beta), int(mode),
                                       ws.data_ptr(), wsb, status.data_ptr(), _stream_ptr(dev))
     _check_launch(rc, status, "gabo_nested_spd_gram")
@@ -910,7 +1055,7 @@ def spd_logm_mandel(x_mandel):
     x = _prep(x_mandel, dev).contiguous()
     d = _mandel_dim(x.shape[-1])
     out = torch.empty_like(x)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_spd_logm_mandel(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], d, _stream_ptr(dev)),
                    "gabo_spd_logm_mandel")
     return out.to(out_device)
@@ -929,7 +1074,7 @@ def frobenius_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN):
     a2, nb, s1 = _flatten_batch(a, 2)
     b2, _, s2 = _flatten_batch(b, 2)
     out = torch.empty(a.shape[:-2] + (n1, n2), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_frobenius_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), nb, n1, n2, d, s1, s2, float(beta),
                                                int(mode), _stream_ptr(dev)), "gabo_frobenius_pairwise")
     return out.to(out_device)
@@ -944,7 +1089,7 @@ def spd_logm_mandel_backward(x_mandel, grad_y):
     g = _prep(grad_y, dev).expand(x.shape).contiguous()
     d = _mandel_dim(x.shape[-1])
     out = torch.empty_like(x)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_spd_logm_mandel_backward(x.data_ptr(), g.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], d,
                                                      _stream_ptr(dev)), "gabo_spd_logm_mandel_backward")
     return out.to(out_device)
@@ -988,7 +1133,7 @@ def frobenius_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, 
     gx = torch.zeros(bshape + (m1, a.shape[-1]), dtype=torch.float64, device=dev)
     if gx.numel() == 0 or m2 == 0:
         return gx.to(out_device)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_frobenius_backward(first.data_ptr(), second.data_ptr(), g.data_ptr(), gx.data_ptr(), nb, m1, m2, d, sf,
                                                ss, n1 * n2, go_si, go_sj, float(beta), int(mode), sgn, _stream_ptr(dev)),
                    "gabo_frobenius_backward")
@@ -1051,31 +1196,21 @@ def gp_acquisition(kstar, alpha, linv, linv_t, mean, outputscale, kxx, best_f, k
     value = torch.empty(r, dtype=torch.float64, device=dev)
     grad = torch.empty_like(ks) if need_grad else None
     ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_gp_acquisition(ks.data_ptr(), alpha.data_ptr(), ptr(linv), ptr(linv_t), value.data_ptr(), ptr(grad), r, n,
                                            float(mean), float(outputscale), float(kxx), float(best_f), int(kind), 1 if maximize else 0,
                                            float(out_sign), _stream_ptr(dev)), "gabo_gp_acquisition")
     return value, grad
 
 
-_deferred = []
+_GP_FACTOR_MESSAGE = "gabo_gp_factor: the training covariance outputscale * K + noise * I is not positive definite (Cholesky pivot <= 0)"
 
 
-def check_deferred():
-    """Reads the status words queued by launches whose error check was deferred (gp_factor) and raises for the first failure.  Called at
-    the natural host synchronisation points of a sweep; cheap when the queue is empty."""
-    while _deferred:
-        status, message = _deferred.pop(0)
-        if status.tolist()[0] != 0:
-            _deferred.clear()
-            raise RuntimeError(message)
-
-
-def gp_factor(kbase, y, outputscale, noise, mean, defer_check=False):
+def gp_factor(kbase, y, outputscale, noise, mean, defer_check=False, on_fail=None):
     """Prediction cache of the exact GP in one launch (gabo_gp_factor): kbase n x n BASE kernel matrix of the training set, y its targets ->
     (L^-1, L^-T, alpha) with L = chol(outputscale kbase + noise I), alpha = (outputscale kbase + noise I)^-1 (y - mean); n <= GABO_GP_FACTOR_MAX_N.
-    Raises like torch.linalg.cholesky when the matrix is not positive definite - at once, or (defer_check=True) at the next check_deferred().
-    All tensors fp64 on one HIP device."""
+    Raises like torch.linalg.cholesky when the matrix is not positive definite - at once, or (defer_check=True) at the next check_deferred();
+    on_fail: called before that error is raised (the caller drops whatever it built on the factor).  All tensors fp64 on one HIP device."""
     lib = _lib.load()
     dev = kbase.device
     kb, yy = kbase.contiguous(), y.to(dev, torch.float64).contiguous()
@@ -1084,19 +1219,59 @@ def gp_factor(kbase, y, outputscale, noise, mean, defer_check=False):
     linv = torch.empty(n, n, dtype=torch.float64, device=dev)
     linv_t = torch.empty(n, n, dtype=torch.float64, device=dev)
     alpha = torch.empty(n, dtype=torch.float64, device=dev)
-    status = torch.zeros(2, dtype=torch.int32, device=dev)        # (a word of its own: it is read later, see below)
-    with torch.cuda.device(dev):
+    status = _status_word(dev, force=True)
+    with _on(dev):
         rc = lib.gabo_gp_factor(kb.data_ptr(), yy.data_ptr(), n, float(outputscale), float(noise), float(mean), linv.data_ptr(), linv_t.data_ptr(),
                                 alpha.data_ptr(), status.data_ptr(), _stream_ptr(dev))
     _lib.check(rc, "gabo_gp_factor")
     # The status is read back whatever set_error_checking says (torch.linalg.cholesky would raise here too, and a silent garbage factor would
     # poison every acquisition value) - but not HERE: the read-back would park the host behind the launch (~0.1 ms of a 4-ms sweep) while it
-    # has the rest of the sweep's launches to issue.  It is queued and checked at the caller's next natural synchronisation point
+    # has the rest of the sweep's launches to issue.  It is registered and checked at the caller's next natural synchronisation point
     # (check_deferred: after the raw samples' scores have been copied to the host, after a solve, or whenever error checking reads a status).
-    _deferred.append((status, "gabo_gp_factor: the training covariance outputscale * K + noise * I is not positive definite (Cholesky pivot <= 0)"))
-    if defer_check is False or len(_deferred) > 32:       # (never an unbounded queue: a caller that only ever factors is checked every 32 launches)
+    _raise_if_not_spd(status, "gabo_gp_factor", message=_GP_FACTOR_MESSAGE, on_fail=on_fail, force=True)
+    if defer_check is False:
         check_deferred()
     return linv, linv_t, alpha
+
+
+_gp_prepare_ws = {}
+
+
+def spd_gp_prepare(train_mandel, y, beta, mode, outputscale, noise, mean, want_factors=True, on_fail=None):
+    """Everything an acquisition sweep needs from a fitted exact GP with an affine-invariant kernel, from ONE host call (gabo_spd_gp_prepare):
+    the training Gram matrix, (L^-1, L^-T, alpha) of gp_factor and the entry-major training factors of spd_acq_prepare_train (d_vec x n, or None).
+    The Cholesky status is checked at the next check_deferred() (as gp_factor(defer_check=True)); on_fail as there."""
+    lib = _lib.load()
+    dev = train_mandel.device
+    x = train_mandel if train_mandel.is_contiguous() else train_mandel.contiguous()
+    yy = y if (y.device == dev and y.dtype == torch.float64 and y.is_contiguous()) else y.to(dev, torch.float64).contiguous()
+    if not (x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and yy.numel() == x.shape[0]):
+        raise TypeError("spd_gp_prepare: train_mandel must be an n x d_vec fp64 tensor on a HIP device and y its n targets")
+    n, dv = x.shape
+    d = _mandel_dim(dv)
+    # one allocation for the outputs: [L^-1 | L^-T | alpha | factors]
+    nn = n * n
+    flat = torch.empty(2 * nn + n + (dv * n if want_factors else 0), dtype=torch.float64, device=dev)
+    base = flat.data_ptr()
+    stream = _stream_ptr(dev)
+    key = (dev.index, stream, n, d)
+    ent = _gp_prepare_ws.get(key)
+    if ent is None:
+        if len(_gp_prepare_ws) > 16:
+            _gp_prepare_ws.clear()
+        wsb = int(lib.gabo_spd_gp_prepare_workspace_bytes(n, d))
+        ent = _gp_prepare_ws[key] = (torch.empty(wsb, dtype=torch.uint8, device=dev), wsb)
+    ws, wsb = ent
+    status, fstatus = _status_word(dev), _status_word(dev, force=True)
+    with _on(dev):
+        rc = lib.gabo_spd_gp_prepare(x.data_ptr(), yy.data_ptr(), n, d, beta, mode, outputscale, noise, mean, base, base + 8 * nn, base + 16 * nn,
+                                     base + 8 * (2 * nn + n) if want_factors else None, ws.data_ptr(), wsb, status.data_ptr(), fstatus.data_ptr(),
+                                     stream)
+    _check_launch(rc, status, "gabo_spd_gp_prepare", on_fail=on_fail)
+    _raise_if_not_spd(fstatus, "gabo_gp_factor", message=_GP_FACTOR_MESSAGE, on_fail=on_fail, force=True)
+    linv, linv_t, alpha = flat[:nn].view(n, n), flat[nn:2 * nn].view(n, n), flat[2 * nn:2 * nn + n]
+    factors = flat[2 * nn + n:].view(dv, n) if want_factors else None
+    return linv, linv_t, alpha, factors
 
 
 _mll_large_ws = {}
@@ -1114,7 +1289,7 @@ def _gp_mll_large(e, y, theta, outputscale, noise, mean, gram, want_w):
         ws = _mll_large_ws[key] = torch.empty(int(lib.gabo_gp_mll_large_workspace_bytes(n)) // 8 + 1, dtype=torch.float64, device=dev)
     out = torch.empty(6, dtype=torch.float64, device=dev)
     w = torch.empty(n, n, dtype=torch.float64, device=dev) if want_w else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_gp_mll_large(e.data_ptr(), y.data_ptr(), n, float(theta), float(outputscale), float(noise), float(mean),
                                          1 if gram else 0, out.data_ptr(), None if w is None else w.data_ptr(), ws.data_ptr(),
                                          ws.numel() * 8, _stream_ptr(dev)), "gabo_gp_mll_large")
@@ -1133,7 +1308,7 @@ def gp_mll(e, y, theta, outputscale, noise, mean):
     if n > _lib.GABO_GP_MLL_MAX_N:
         return _gp_mll_large(e, y, theta, outputscale, noise, mean, False, False)[0].tolist()
     out = torch.empty(6, dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_gp_mll(e.data_ptr(), y.data_ptr(), n, float(theta), float(outputscale), float(noise), float(mean),
                                    out.data_ptr(), _stream_ptr(dev)), "gabo_gp_mll")
     return out.tolist()
@@ -1153,7 +1328,7 @@ def gp_mll_gram(k, y, outputscale, noise, mean, want_w=True):
         return _gp_mll_large(k, y, 0.0, outputscale, noise, mean, True, want_w)
     out = torch.empty(6, dtype=torch.float64, device=dev)
     w = torch.empty(n, n, dtype=torch.float64, device=dev) if want_w else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_gp_mll_gram(k.data_ptr(), y.data_ptr(), n, float(outputscale), float(noise), float(mean), out.data_ptr(),
                                         None if w is None else w.data_ptr(), _stream_ptr(dev)), "gabo_gp_mll_gram")
     return out, w
@@ -1166,8 +1341,8 @@ def spd_acq_prepare_train(train_mandel):
     n, dv = x.shape
     d = _mandel_dim(dv)
     out = torch.empty(dv, n, dtype=torch.float64, device=x.device)
-    status = torch.zeros(2, dtype=torch.int32, device=x.device)
-    with torch.cuda.device(x.device):
+    status = _status_word(x.device)
+    with _on(x.device):
         _lib.check(lib.gabo_spd_acq_prepare_train(x.data_ptr(), out.data_ptr(), n, d, status.data_ptr(), _stream_ptr(x.device)),
                    "gabo_spd_acq_prepare_train")
     _raise_if_not_spd(status, "gabo_spd_acq_prepare_train")
@@ -1190,9 +1365,9 @@ def spd_acq_eval(x_mandel, train_factors, alpha, linv, linv_t, beta, mode, mean,
         grad = torch.empty_like(x) if need_grad else None
     affine = (int(mode) & 24) == 0           # only the affine-invariant metric spills logm(M_j) to scratch
     scratch = torch.empty(r * dv * n, dtype=torch.float64, device=dev) if (need_grad and affine) else None
-    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    status = _status_word(dev)
     ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_spd_acq_eval(x.data_ptr(), train_factors.data_ptr(), alpha.data_ptr(), ptr(linv), ptr(linv_t),
                                          value.data_ptr(), ptr(grad), ptr(scratch), r, n, _mandel_dim(dv), float(beta), int(mode),
                                          float(mean), float(outputscale), float(kxx), float(best_f), int(kind), 1 if maximize else 0,
@@ -1207,7 +1382,7 @@ def spd_sample(n, d, min_eig, max_eig, seed, device, mandel=False, first=0):
     lib = _lib.load()
     dev = torch.device(device)
     out = torch.empty((n, d * (d + 1) // 2) if mandel else (n, d, d), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_spd_sample_range(out.data_ptr(), int(first), n, d, float(min_eig), float(max_eig), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                              1 if mandel else 0, _stream_ptr(dev)), "gabo_spd_sample_range")
     return out
@@ -1222,7 +1397,7 @@ def nested_sphere_epilogue(rotated, dist_to_axis, mode=0):
     d = u.shape[-1]
     n = u.numel() // d
     out = torch.empty(u.shape[:-1] + ((d - 1) if mode == 0 else d,), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_nested_sphere_epilogue(u.data_ptr(), out.data_ptr(), n, d, float(dist_to_axis), int(mode), _stream_ptr(dev)),
                    "gabo_nested_sphere_epilogue")
     return out.to(out_device)
@@ -1236,7 +1411,7 @@ def nested_sphere_epilogue_backward(rotated, grad_out, dist_to_axis):
     g = _prep(grad_out, dev).contiguous()
     d = u.shape[-1]
     gu = torch.empty_like(u)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_nested_sphere_epilogue_backward(u.data_ptr(), g.data_ptr(), gu.data_ptr(), u.numel() // d, d,
                                                             float(dist_to_axis), _stream_ptr(dev)), "gabo_nested_sphere_epilogue_backward")
     return gu.to(out_device)
@@ -1281,7 +1456,7 @@ def _nested_sphere_frames(sphere_axes, sphere_distances, dim, dev):
     dists = torch.cat([(d.detach().reshape(-1)[:1].to(dev, torch.float64) if torch.is_tensor(d)
                         else torch.tensor([float(d)], dtype=torch.float64, device=dev)) for d in sphere_distances])
     frames = torch.empty(axes.numel() + 2 * levels, dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_nested_sphere_frames(axes.data_ptr(), frames.data_ptr(), dim, levels, _stream_ptr(dev)), "gabo_nested_sphere_frames")
     return frames, dists
 
@@ -1302,7 +1477,7 @@ def nested_sphere_project_all(x, sphere_axes, sphere_distances):
     off = _level_offsets(dim, levels)
     z = torch.empty(n, dim - levels, dtype=torch.float64, device=dev)
     store = torch.empty(n, off[-1], dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_nested_sphere_project(X.data_ptr(), frames.data_ptr(), dists.data_ptr(), z.data_ptr(), store.data_ptr(), n, dim, levels,
                                                   _stream_ptr(dev)), "gabo_nested_sphere_project")
     return [store[:, off[k]:off[k + 1]] for k in range(levels)] + [z]
@@ -1319,7 +1494,7 @@ def nested_sphere_lift_all(x_subsphere, sphere_axes, sphere_distances):
     frames, dists = _nested_sphere_frames(sphere_axes, sphere_distances, dim, dev)
     off = _level_offsets(dim, levels)
     store = torch.empty(n, off[-1], dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_nested_sphere_lift(Z.data_ptr(), frames.data_ptr(), dists.data_ptr(), None, store.data_ptr(), n, dim, levels,
                                                _stream_ptr(dev)), "gabo_nested_sphere_lift")
     return [Z] + [store[:, off[k]:off[k + 1]] for k in range(levels - 1, -1, -1)]
@@ -1340,7 +1515,7 @@ class NestedSphereReconstruction:
             raise RuntimeError(f"shapes: x_data {tuple(self.x.shape)}, x_subsphere {tuple(self.z.shape)}, {len(sphere_axes)} axes")
         axes = torch.as_tensor(pack_nested_sphere_axes(sphere_axes, self.D), device=dev)
         self.frames = torch.empty(axes.numel() + 2 * self.L, dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.gabo_nested_sphere_frames(axes.data_ptr(), self.frames.data_ptr(), self.D, self.L, _stream_ptr(dev)), "gabo_nested_sphere_frames")
         self._buffers = {}
 
@@ -1403,7 +1578,7 @@ class SpdTcg:
         self._keep = (x.contiguous(), g.contiguous(), None if gc is None else gc.contiguous(), None if fc is None else fc.contiguous(),
                       active.to(torch.uint8).contiguous(), Delta.contiguous())
         xx, gg, gcc, fcc, act, dl = self._keep
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             _lib.check(self.lib.gabo_spd_tcg_begin(xx.data_ptr(), gg.data_ptr(), ptr(gcc), ptr(fcc), act.data_ptr(), dl.data_ptr(),
                                                    self.ws.data_ptr(), self.wsb, self.r, self.d, self.c, self.status.data_ptr(),
                                                    _stream_ptr(self.dev)), "gabo_spd_tcg_begin")
@@ -1412,19 +1587,19 @@ class SpdTcg:
         """use_rand (robust_trust_regions.py:173-181, 407-452), after begin(): start from eta0 with heta0 = hess(x, eta0), no preconditioner."""
         self._keep_rand = (eta0.contiguous(), heta0.contiguous())
         _require(self.dev, eta0=self._keep_rand[0], heta0=self._keep_rand[1])
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             _lib.check(self.lib.gabo_spd_tcg_begin_rand(self.ws.data_ptr(), self._keep_rand[0].data_ptr(), self._keep_rand[1].data_ptr(),
                                                         self.r, self.d, self.c, _stream_ptr(self.dev)), "gabo_spd_tcg_begin_rand")
 
     def fd_point(self):
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             _lib.check(self.lib.gabo_spd_tcg_fd_point(self.ws.data_ptr(), self.x_fd.data_ptr(), self.r, self.d, self.c,
                                                       _stream_ptr(self.dev)), "gabo_spd_tcg_fd_point")
         return self.x_fd
 
     def step(self, egrad_mandel, neq, delta_cons, theta, kappa, mininner):
         eg = egrad_mandel.contiguous()
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             _lib.check(self.lib.gabo_spd_tcg_step(self.ws.data_ptr(), eg.data_ptr(), self.any_running.data_ptr(), self.r, self.d,
                                                   self.c, int(neq), float(delta_cons), float(theta), float(kappa), int(mininner),
                                                   _stream_ptr(self.dev)), "gabo_spd_tcg_step")
@@ -1433,7 +1608,7 @@ class SpdTcg:
         eta = torch.empty(self.r, self.d, self.d, dtype=torch.float64, device=self.dev)
         heta = torch.empty_like(eta)
         stop = torch.empty(self.r, dtype=torch.int32, device=self.dev)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             _lib.check(self.lib.gabo_spd_tcg_end(self.ws.data_ptr(), eta.data_ptr(), heta.data_ptr(), stop.data_ptr(), self.r,
                                                  self.d, self.c, _stream_ptr(self.dev)), "gabo_spd_tcg_end")
         return eta, heta, stop.long()
@@ -1457,7 +1632,7 @@ class SpdTr:
     def propose(self, x, g, Delta, active, gc, fc, neq, delta_cons, theta, kappa, mininner, maxinner):
         _require(self.dev, x=x, g=g, Delta=Delta, active=active, gc=gc, fc=fc)
         ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             _lib.check(self.lib.gabo_spd_tr_propose(x.data_ptr(), g.data_ptr(), Delta.data_ptr(), active.data_ptr(), ptr(gc), ptr(fc),
                                                     self.acq_ref, self.ws.data_ptr(), self.wsb, self.x_prop.data_ptr(), self.r, self.d,
                                                     self.c, int(neq), float(delta_cons), float(theta), float(kappa), int(mininner),
@@ -1482,7 +1657,7 @@ class SpdTr:
             lift_args = (lw.data_ptr(), lp.data_ptr(), lx0.data_ptr(), int(lw.shape[0]))
         else:
             lift_args = (None, None, None, 0)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             if record is not None:
                 assert tuple(record.shape[1:]) == (self.r, self.d * self.d + 2)
                 _lib.check(self.lib.gabo_tr_solve_record(record.data_ptr(), int(record.shape[0])), "gabo_tr_solve_record")
@@ -1495,7 +1670,7 @@ class SpdTr:
 
     def update(self, x, fx, g, ng, Delta, active, iters, invalid, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter):
         _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters, invalid=invalid)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             _lib.check(self.lib.gabo_spd_tr_update(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
                                                    active.data_ptr(), iters.data_ptr(), None if invalid is None else invalid.data_ptr(),
                                                    self.x_prop.data_ptr(), self.ws.data_ptr(), self.r, self.d, self.c, self.n,
@@ -1512,7 +1687,7 @@ def sphere_acq_eval(x, acq_params, need_grad=True):
     r = xx.shape[0]
     value = torch.empty(r, dtype=torch.float64, device=dev)
     grad = torch.empty_like(xx) if need_grad else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_sphere_acq_eval(xx.data_ptr(), ctypes.byref(acq_params), value.data_ptr(), None if grad is None else grad.data_ptr(),
                                             r, _stream_ptr(dev)), "gabo_sphere_acq_eval")
     return value, grad
@@ -1536,7 +1711,7 @@ class SphereTr:
     def propose(self, x, g, Delta, active, gc, fc, neq, delta_cons, theta, kappa, mininner, maxinner):
         _require(self.dev, x=x, g=g, Delta=Delta, active=active, gc=gc, fc=fc)
         ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             _lib.check(self.lib.gabo_sphere_tr_propose(x.data_ptr(), g.data_ptr(), Delta.data_ptr(), active.data_ptr(), ptr(gc), ptr(fc),
                                                        self.acq_ref, self.ws.data_ptr(), self.wsb, self.x_prop.data_ptr(), self.r, self.c,
                                                        int(neq), float(delta_cons), float(theta), float(kappa), int(mininner),
@@ -1546,7 +1721,7 @@ class SphereTr:
 
     def update(self, x, fx, g, ng, Delta, active, iters, invalid, delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter):
         _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters, invalid=invalid)
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             _lib.check(self.lib.gabo_sphere_tr_update(x.data_ptr(), fx.data_ptr(), g.data_ptr(), ng.data_ptr(), Delta.data_ptr(),
                                                       active.data_ptr(), iters.data_ptr(), None if invalid is None else invalid.data_ptr(),
                                                       self.ws.data_ptr(), self.r, self.d, self.c, float(delta_bar), float(rho_prime),
@@ -1557,7 +1732,7 @@ class SphereTr:
               rho_prime, rho_regularization, mingradnorm, maxiter, record=None):
         _require(self.dev, x=x, fx=fx, g=g, ng=ng, Delta=Delta, active=active, iters=iters, record=record)
         assert not kinds, "the sphere has no built-in constraints"
-        with torch.cuda.device(self.dev):
+        with _on(self.dev):
             if record is not None:                     # (K, r, dim + 2), pre-filled with NaN: gabo_tr_solve_record
                 assert tuple(record.shape[1:]) == (self.r, self.d + 2)
                 _lib.check(self.lib.gabo_tr_solve_record(record.data_ptr(), int(record.shape[0])), "gabo_tr_solve_record")
@@ -1581,7 +1756,7 @@ def sphere_manifold_op(op, x, u, v=None, w=None):
     n = X.numel() // dim
     out = torch.empty(shape[:-1] if op == _lib.GABO_SPH_DIST else shape, dtype=torch.float64, device=dev)
     ptr = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.gabo_sphere_manifold_op(int(op), ptr(X), ptr(U), ptr(V), ptr(W), out.data_ptr(), n, dim, _stream_ptr(dev)),
                    "gabo_sphere_manifold_op")
     return out.to(out_device)

@@ -522,6 +522,49 @@ int gabo_spd_sweep_solve(const gabo_spd_sweep_config* cfg, const int64_t* picked
                          gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Round 6: the same sweep with its set-up, start and end INSIDE the launches, and laid out for sharding over the GPUs of a node.
+ *
+ * gabo_spd_gp_prepare: everything the sweep needs from a fitted exact GP with an affine-invariant kernel, from ONE host call - the Gram matrix
+ *   K(X, X) of the training set (SpdAffineInvariant{Gaussian,Laplace}Kernel.forward, kernels_spd.py:72-100,157-187; `flags` = GABO_OUT_GAUSSIAN /
+ *   GABO_OUT_LAPLACE), the prediction cache gabo_gp_factor computes from it ([3P] gpytorch's prediction strategy behind manifold_optimize.py:182-184)
+ *   and, train_factors != NULL, gabo_spd_acq_prepare_train's factors (d_vec x n).  status: a training matrix that is not SPD; factor_status: a
+ *   covariance that is not positive definite (both device int[2], zeroed by the caller).  n <= GABO_GP_FACTOR_MAX_N, d <= GABO_SPD_REG_MAX_DIM.
+ *
+ * The sweep keeps two tables in its workspace (gabo_spd_sweep_rows_tables returns their device addresses):
+ *   raw rows     max_raw x (1 + d_vec):    [acquisition value, raw sample as a Mandel vector]
+ *   result rows  restarts x (2 + d_vec):   [final cost = -acquisition, trust-region iterations, final iterate as a Mandel vector]
+ * A multi-GPU sweep all_gathers exactly these two tables (raw rows by sample index after scoring, result rows after solving): the caller's
+ * collective, on the tables, between / after the calls - the driver has none of its own.
+ *   gabo_spd_sweep_score_rows: raw samples first_sample ... first_sample + count - 1 of the stream `seed` (gabo_spd_sample_range; raw_matrices_host !=
+ *     NULL: the count x d x d matrices the caller's sampler drew) into rows first_row ... first_row + count - 1 of the table (< max_raw: a rank of a
+ *     sharded sweep fills its own block), scored (gen_batch_initial_conditions_manifold, manifold_optimize.py:288-309).
+ *     values_mapped (may be NULL): count doubles the KERNEL writes the values to as well - memory the device can address: page-locked host memory
+ *     (hipHostMalloc, torch's pinned allocator) or device memory; pageable host memory is refused (GABO_ERR_ARG).
+ *   gabo_spd_sweep_solve_rows: ONE launch for gen_candidates_manifold (manifold_optimize.py:124-228) on the restarts that start from rows
+ *     picked_mapped[0 ... restarts - 1] (device-addressable like values_mapped): the two Mandel maps, cost, gradient, [3P] egrad2rgrad / norm at the
+ *     start, the whole trust-region solve (gabo_spd_tr_solve's kernel), the result row.  results_mapped (may be NULL): restarts x (2 + d_vec) doubles
+ *     of device-addressable memory that receive the result rows as well.  get_best_candidates (:118-120) is an argmax over column 0 of the result rows:
+ *     the caller's, after its all_gather if there is one.
+ *   status: device int[2] as everywhere (zeroed by the caller); status_mapped (may be NULL): int[2] of device-addressable host memory, zeroed by
+ *     the caller, that receives the same two ints when a launch of the call reports an error - the host reads it after the stream has drained,
+ *     without a copy.
+ *   synchronize != 0: the call returns after the stream has drained (the mapped copies are then readable by the host).
+ * Same conditions as gabo_spd_sweep_score / _solve; the numbers are those of that pair and of this package's Python path, bit for bit. */
+size_t gabo_spd_gp_prepare_workspace_bytes(int64_t n, int d);
+int gabo_spd_gp_prepare(const double* train_mandel, const double* y, int64_t n, int d, double beta, int flags, double outputscale, double noise,
+                        double mean, double* linv, double* linv_t, double* alpha, double* train_factors, void* workspace, size_t workspace_bytes,
+                        int* status, int* factor_status, gabo_stream_t stream);
+size_t gabo_spd_sweep_rows_workspace_bytes(int64_t n_train, int d, int64_t max_raw, int64_t restarts, int n_constraints);
+int gabo_spd_sweep_rows_tables(void* workspace, int64_t n_train, int d, int64_t max_raw, int64_t restarts, int n_constraints, double** raw_rows,
+                               double** result_rows);
+int gabo_spd_sweep_score_rows(const gabo_spd_sweep_config* cfg, int64_t first_sample, int64_t first_row, int64_t count, int64_t max_raw,
+                              int64_t restarts, uint64_t seed, const double* raw_matrices_host, double* values_mapped, void* workspace,
+                              size_t workspace_bytes, int* status, int* status_mapped, int synchronize, gabo_stream_t stream);
+int gabo_spd_sweep_solve_rows(const gabo_spd_sweep_config* cfg, const int64_t* picked_mapped, int64_t restarts, int64_t max_raw,
+                              double* results_mapped, void* workspace, size_t workspace_bytes, int* status, int* status_mapped, int synchronize,
+                              gabo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Acquisition maximisation on the sphere S^(dim-1) (the sphere twins of gabo_spd_acq_eval / gabo_spd_tr_*): kernel strip of
  * SphereGaussianKernel / SphereLaplaceKernel (kernels_sphere.py:71-94,118-134) + exact-GP posterior + EI / posterior mean + gradient
  * in one launch, and the trust-region iteration of robust_trust_regions.py / constrained_trust_regions.py with the finite-difference

@@ -111,7 +111,7 @@ def test_native_sweep_on_the_log_euclidean_surrogate_of_config_5():
         assert bool(solver.log.get("native_sweep")) == native and solver.log.get("one_launch_solve")
         outs.append((best.clone(), solver.log["final_cost"].clone(), solver.log["per_restart_iterations"].clone()))
     assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2].cpu(), outs[1][2].cpu())
+    assert torch.equal(outs[0][1].cpu(), outs[1][1].cpu()) and torch.equal(outs[0][2].cpu(), outs[1][2].cpu())
 
 
 @pytest.mark.parametrize("approx", [False, True])
