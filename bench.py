@@ -595,16 +595,36 @@ def main():
             run_sweep(device, **kw)                  # (two warm-ups, as for the latency table below: 8192 restarts is the first use of the generic-workspace kernels)
             if dist is not None:
                 dist.barrier()
-            best_s, best_v = float("inf"), None
+            best_s, best_v, best_log = float("inf"), None, {}
             for _ in range(5):
-                s_, _, v_, _ = run_sweep(device, **kw)
+                s_, _, v_, log_ = run_sweep(device, **kw)
                 if s_ < best_s:
-                    best_s, best_v = s_, v_
+                    best_s, best_v, best_log = s_, v_, log_
             ts_ = torch.tensor([best_s], dtype=torch.float64, device=device)
+            fl_ = torch.tensor([1.0 if best_log.get("native_sweep") else 0.0, 1.0 if best_log.get("device_selection") else 0.0], dtype=torch.float64, device=device)
+            coll_s = 0.0
             if dist is not None:
                 dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+                dist.all_reduce(fl_, op=dist.ReduceOp.MIN)
+                # the two collectives of a sharded sweep on their own (same shapes: the raw-row table, the result rows), max over ranks
+                from gabotorch_amd.manifold_optimization.manifold_optimize import _all_gather_rows
+                per_, rper_ = (4 * total + world - 1) // world, (total + world - 1) // world
+                tab_, res_ = torch.zeros(world * (per_ + 1), 16, dtype=torch.float64, device=device), torch.zeros(world * rper_, 17, dtype=torch.float64, device=device)
+                for rep_ in range(4):
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t0_ = time.perf_counter()
+                    _all_gather_rows(dist, tab_, tab_[:per_ + 1].clone())
+                    _all_gather_rows(dist, res_, res_[:rper_].clone())
+                    res_.cpu()
+                    coll_s = time.perf_counter() - t0_
+                tc_ = torch.tensor([coll_s], dtype=torch.float64, device=device)
+                dist.all_reduce(tc_, op=dist.ReduceOp.MAX)
+                coll_s = float(tc_.item())
             strong[str(total)] = {"restarts": total, "raw_samples": 4 * total, "n_gpus": world, "seconds": float(ts_.item()),
-                                  "restarts_per_s": total / float(ts_.item()), "best_acq": best_v}
+                                  "restarts_per_s": total / float(ts_.item()), "best_acq": best_v,
+                                  "native_sweep_on_every_rank": bool(fl_[0].item() > 0), "selection_on_the_device_on_every_rank": bool(fl_[1].item() > 0),
+                                  "seconds_of_the_two_collectives_alone": coll_s}
         # one GPU: the sweep's latency as a function of the number of restarts IT holds, which is what a rank of a P-GPU run sees (R / P restarts):
         # predicted strong-scaling speed-up S_P(R) = t_1(R) / t_1(R / P), the all_gather of R x 16 doubles (< 20 us over xGMI) neglected
         latency_table = None

@@ -13,6 +13,7 @@
 // The workspace is the caller's (gabo_spd_sweep_workspace_bytes); nothing is allocated here.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -20,6 +21,7 @@
 #include "../../include/gabo_hip.h"
 #include "spd_tr_body.hpp"
 #include "spd_acq_kernel.hpp"
+#include "gabo_philox.hpp"
 
 namespace gabo {
 
@@ -339,6 +341,168 @@ extern "C" int gabo_spd_sweep_score_rows(const gabo_spd_sweep_config* cfg, int64
     if ((rc = gabo::acq_launch(al)) != GABO_OK) return rc;
     if (synchronize && hipStreamSynchronize(st) != hipSuccess) return GABO_ERR_LAUNCH;
     return GABO_OK;
+}
+
+namespace gabo {
+
+// ---- which raw samples become restarts, on the device -------------------------------------------------------------------------------------------
+// gen_batch_initial_conditions_manifold hands the scored raw samples to botorch's initialize_q_batch_nonneg ([3P] botorch.optim.initializers;
+// manifold_optimize.py:296-317 of the reference; this package's restatement: models.initialize_q_batch_nonneg / select_rows): the samples whose
+// value is at least alpha * max (alpha shrunk by tens until n of them qualify) are drawn WITHOUT REPLACEMENT with weights
+// exp(eta (y / max - 1)), and the arg-max is forced into the last slot when the draw missed it.  torch.multinomial draws without replacement by
+// the exponential race - keys w_i / E_i, E_i ~ Exp(1), the n largest keys win - and so does this kernel, with E_i = -log(u_i) from the Philox
+// stream (seed, sample index): the same distribution, the library's own random stream instead of the host generator's.
+// Done on the host (rounds 3-5, and still the path for acquisition functions that are not non-negative, for more than kSelectMaxTotal raw samples
+// and when this kernel reports that the heuristic has to fall back) the step costs a device -> host wait, 0.1-0.25 ms of tensor bookkeeping and
+// a host -> device hand-over in the MIDDLE of a 1.2-ms sweep; here it is one launch of one workgroup between the scoring and the solve launches.
+// One workgroup of 1024 threads; keys and sample indices live in LDS (total <= kSelectMaxTotal); the n largest keys, in order, come from a bitonic
+// sort (ties: the lower sample index).  (Counting, for every key, the keys that beat it - total^2 / 1024 comparisons per thread - was the first
+// version: fine at 256 raw samples, ~0.2 ms at 2048.)
+constexpr int kSelectMaxTotal = 8192;
+
+template <typename T, typename Op>
+static __device__ __forceinline__ T block_reduce_1024(T v, T* scratch, Op op) {
+    const int tid = threadIdx.x;
+    scratch[tid] = v;
+    __syncthreads();
+    for (int step = 512; step >= 1; step >>= 1) {
+        if (tid < step) scratch[tid] = op(scratch[tid], scratch[tid + step]);
+        __syncthreads();
+    }
+    const T r = scratch[0];
+    __syncthreads();
+    return r;
+}
+
+// flag: 0 = picked; 1 = the heuristic needs its random fall-backs (no positive value, fewer positive values than restarts) or the values hold a NaN:
+// the caller selects on the host.  picked_rows: the table rows of THIS rank's restarts (restart k belongs to rank k % world) in restart order;
+// picked_samples (may be null): the sample index of every restart.
+__global__ __launch_bounds__(1024) void sweep_select_kernel(const double* __restrict__ raw_rows, int64_t stride, int total, int per, int n, double eta,
+                                                            double alpha, uint64_t seed, int seed_in_header, int rank, int world,
+                                                            int64_t* __restrict__ picked_rows, int64_t* __restrict__ picked_samples,
+                                                            int* __restrict__ flag_dev, int* __restrict__ flag_mapped) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    int P2 = 1;
+    while (P2 < total) P2 <<= 1;
+    double* key = sm;                      // P2 (total rounded up to a power of two)
+    double* dred = sm + P2;                // 1024
+    int* ired = (int*)(dred + 1024);       // 1024
+    int* sidx_of = ired + 1024;            // P2
+    __shared__ int max_rank;
+    const int tid = threadIdx.x;
+    auto row_of = [&](int smp) -> int64_t { return (int64_t)(smp / per) * (per + 1) + 1 + smp % per; };
+    if (seed_in_header) seed = (uint64_t)raw_rows[0];       // (rank 0's proposal: the header row of block 0, < 2^52)
+    double best = -__builtin_inf();
+    int npos = 0, nnan = 0;
+    for (int sidx = tid; sidx < total; sidx += 1024) {
+        const double v = raw_rows[row_of(sidx) * stride];
+        key[sidx] = v;
+        nnan += (v != v) ? 1 : 0;
+        npos += (v > 0.0) ? 1 : 0;
+        best = v > best ? v : best;
+    }
+    const double max_val = block_reduce_1024<double>(best, dred, [](double a, double b) { return a > b ? a : b; });
+    int first = 0x7fffffff;
+    for (int sidx = tid; sidx < total; sidx += 1024)
+        if (key[sidx] == max_val && sidx < first) first = sidx;
+    const int max_idx = block_reduce_1024<int>(first, ired, [](int a, int b) { return a < b ? a : b; });
+    const int num_pos = block_reduce_1024<int>(npos, ired, [](int a, int b) { return a + b; });
+    const int num_nan = block_reduce_1024<int>(nnan, ired, [](int a, int b) { return a + b; });
+    if (num_nan > 0 || !(max_val > 0.0) || num_pos < n) {
+        if (tid == 0) {
+            *flag_dev = 1;
+            if (flag_mapped) *flag_mapped = 1;
+        }
+        return;
+    }
+    double thr = alpha * max_val;
+    for (int guard = 0; guard < 400; ++guard) {           // (alpha -> 0: thr -> 0 and the num_pos >= n positive values all qualify)
+        int c = 0;
+        for (int sidx = tid; sidx < total; sidx += 1024) c += (key[sidx] >= thr) ? 1 : 0;
+        const int cnt = block_reduce_1024<int>(c, ired, [](int a, int b) { return a + b; });
+        if (cnt >= n) break;
+        alpha = 0.1 * alpha;
+        thr = alpha * max_val;
+    }
+    for (int sidx = tid; sidx < total; sidx += 1024) {
+        const double v = key[sidx];
+        Philox rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint64_t)sidx, 0u, 0x73656c65u};
+        double u1, u2;
+        rng.uniform2(u1, u2);
+        const double w = exp(eta * (v / max_val - 1.0));
+        key[sidx] = (v >= thr) ? w / -log(u1) : -1.0;      // (u1 in (0, 1]: E >= 0; E = 0 gives +inf, the sure winner it should be)
+    }
+    // the n largest keys, in order: bitonic sort of (key, sample) over the next power of two (padding: key -2, behind every real entry);
+    // "a before b" = larger key, ties by the lower sample index
+    int P = 1;
+    while (P < total) P <<= 1;
+    for (int e = tid; e < P; e += 1024) {
+        sidx_of[e] = e;
+        if (e >= total) key[e] = -2.0;
+    }
+    if (tid == 0) max_rank = n;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;
+                const double ka = key[a], kb = key[b];
+                const int ia = sidx_of[a], ib = sidx_of[b];
+                const bool b_first = kb > ka || (kb == ka && ib < ia);
+                const bool up = (a & k) == 0;
+                if (b_first == up) {
+                    key[a] = kb; key[b] = ka;
+                    sidx_of[a] = ib; sidx_of[b] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int r = tid; r < n; r += 1024) {
+        const int smp = sidx_of[r];
+        if (smp == max_idx) max_rank = r;
+        if (picked_samples) picked_samples[r] = smp;
+        if (r % world == rank) picked_rows[r / world] = row_of(smp);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (max_rank >= n) {                               // the draw missed the arg-max: it takes the last slot (botorch: idcs[-1] = max_idx)
+            if (picked_samples) picked_samples[n - 1] = max_idx;
+            if ((n - 1) % world == rank) picked_rows[(n - 1) / world] = row_of(max_idx);
+        }
+        *flag_dev = 0;
+        if (flag_mapped) *flag_mapped = 0;
+    }
+}
+
+}  // namespace gabo
+
+extern "C" int gabo_spd_sweep_select_supported(int64_t total, int64_t restarts) {
+    return (total >= 1 && total <= gabo::kSelectMaxTotal && restarts >= 1 && restarts < total) ? 1 : 0;
+}
+
+extern "C" int gabo_spd_sweep_select_rows(const double* raw_rows, int d, int64_t total, int64_t per_rank, int64_t restarts, double eta, double alpha,
+                                          uint64_t seed, int seed_in_header, int rank, int world, int64_t* picked_rows, int64_t* picked_samples,
+                                          int* flag, int* flag_mapped, gabo_stream_t stream) {
+    if (!raw_rows || !picked_rows || !flag || d < 2 || rank < 0 || world < 1 || rank >= world || per_rank < 1 || per_rank * world < total) return GABO_ERR_ARG;
+    if (!gabo_spd_sweep_select_supported(total, restarts)) return GABO_ERR_DIM;
+    int* fm = nullptr;
+    if (flag_mapped && !(fm = (int*)gabo::device_visible(flag_mapped))) return GABO_ERR_ARG;
+    size_t p2 = 1;
+    while ((int64_t)p2 < total) p2 <<= 1;
+    const size_t lds = p2 * 12 + 1024 * 12;
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return GABO_ERR_LAUNCH;
+    if (!(attr_set.load(std::memory_order_acquire) >> dev & 1)) {
+        if (hipFuncSetAttribute((const void*)gabo::sweep_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(gabo::kSelectMaxTotal * 12 + 1024 * 12)) != hipSuccess)
+            return GABO_ERR_LAUNCH;
+        attr_set.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(gabo::sweep_select_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, raw_rows, (int64_t)(1 + d * (d + 1) / 2), (int)total,
+                       (int)per_rank, (int)restarts, eta, alpha, seed, seed_in_header, rank, world, picked_rows, picked_samples, flag, fm);
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 
 extern "C" int gabo_spd_sweep_solve_rows(const gabo_spd_sweep_config* cfg, const int64_t* picked_mapped, int64_t restarts, int64_t max_raw,

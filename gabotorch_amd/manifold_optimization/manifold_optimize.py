@@ -495,17 +495,19 @@ class _RowsState:
         o_raw, o_res = (raw_p.value - self.ws.data_ptr()) // 8, (res_p.value - self.ws.data_ptr()) // 8
         self.raw = self.ws[o_raw:o_raw + max_rows * (1 + dv)].view(max_rows, 1 + dv)
         self.res = self.ws[o_res:o_res + restarts * (2 + dv)].view(restarts, 2 + dv)
-        self.pinned = torch.zeros(2 + max_rows + restarts + restarts * (2 + dv), dtype=torch.float64).pin_memory()
+        self.pinned = torch.zeros(3 + max_rows + restarts + restarts * (2 + dv), dtype=torch.float64).pin_memory()
         host = self.pinned.numpy()
-        self.err = host[:2].view(np.int32)                  # two status mirrors (score, solve): int32[2] each, written by a failing launch only
-        self.values = host[2:2 + max_rows]
-        self.picked = host[2 + max_rows:2 + max_rows + restarts].view(np.int64)
-        self.results = host[2 + max_rows + restarts:].reshape(restarts, 2 + dv)
+        self.err = host[:3].view(np.int32)                  # mirrors of (score status, solve status, selection flag): int32[2] each
+        self.values = host[3:3 + max_rows]
+        self.picked = host[3 + max_rows:3 + max_rows + restarts].view(np.int64)
+        self.results = host[3 + max_rows + restarts:].reshape(restarts, 2 + dv)
         base = self.pinned.data_ptr()
-        self.err_ptr = (base, base + 8)
-        self.values_ptr, self.picked_ptr, self.results_ptr = base + 16, base + 8 * (2 + max_rows), base + 8 * (2 + max_rows + restarts)
-        self.status = torch.zeros(2, 2, dtype=torch.int32, device=dev)      # the device words behind the mirrors (only a failing launch writes them)
-        self.status_ptr = (self.status.data_ptr(), self.status.data_ptr() + 8)
+        self.err_ptr = (base, base + 8, base + 16)
+        self.values_ptr, self.picked_ptr, self.results_ptr = base + 24, base + 8 * (3 + max_rows), base + 8 * (3 + max_rows + restarts)
+        self.status = torch.zeros(3, 2, dtype=torch.int32, device=dev)      # the device words behind the mirrors (only a failing launch writes them)
+        self.status_ptr = tuple(self.status.data_ptr() + 8 * k for k in range(3))
+        self.picked_dev = torch.zeros(restarts, dtype=torch.int64, device=dev)      # device selection: this rank's rows
+        self.samples_dev = None                                                     # ... and every restart's sample index (sized on first use)
 
     def raise_if_failed(self, which, what):
         """after the stream has drained: did a launch of call `which` (0 score, 1 solve) report a non-SPD matrix?  Host memory only."""
@@ -562,6 +564,8 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
     nonneg, eta, alpha = _selection(acq_function, options)
     cfg_ref = ctypes.byref(cfg)
     checking = ops._check_errors is not False
+    # the selection on the device (gabo_spd_sweep_select_rows) when it is botorch's non-negative heuristic on a table the kernel takes
+    on_device = bool(options.get("device_selection", True)) and nonneg and bool(lib.gabo_spd_sweep_select_supported(raw_samples, R))
     r_loc, r_per = len(range(rank, R, world)), (R + world - 1) // world
     n_train = int(fused.train.shape[0])
     time0 = time.time()
@@ -589,12 +593,27 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
             pending = ops.prefetch_deferred()           # (the GP's set-up launches: their status words travel while the scoring launches run)
             if cnt:
                 rc = lib.gabo_spd_sweep_score_rows(cfg_ref, lo, row0, cnt, world * (per + 1), max(r_per, 1), seed & 0xFFFFFFFFFFFFFFFF,
-                                                   None if raw is None else raw.ctypes.data, st.values_ptr if world == 1 else None, st.ws.data_ptr(),
-                                                   st.wsb, st.status_ptr[0], st.err_ptr[0], 1 if world == 1 else 0, stream)
+                                                   None if raw is None else raw.ctypes.data, st.values_ptr if (world == 1 and not on_device) else None,
+                                                   st.ws.data_ptr(), st.wsb, st.status_ptr[0], st.err_ptr[0], 1 if (world == 1 and not on_device) else 0,
+                                                   stream)
                 if rc != 0:
                     _lib.check(rc, "gabo_spd_sweep_score_rows")
             _mark(options, "<- score")
             sel_seed = int(torch.randint(0, 2 ** 52, (1,)).item())
+            if on_device:
+                # score -> (all_gather) -> selection kernel -> solve, back to back on the stream: the host waits once, at the end
+                if world > 1:
+                    block = st.raw[rank * (per + 1):(rank + 1) * (per + 1)]
+                    block[0, 0] = float(sel_seed)
+                    _all_gather_rows(dist, st.raw, block.clone())
+                if st.samples_dev is None or st.samples_dev.numel() < R:
+                    st.samples_dev = torch.zeros(R, dtype=torch.int64, device=dev)
+                st.err[4] = -1
+                rc = lib.gabo_spd_sweep_select_rows(st.raw.data_ptr(), d, total, per, R, eta, alpha, sel_seed, 1 if world > 1 else 0, rank, world,
+                                                    st.picked_dev.data_ptr(), st.samples_dev.data_ptr(), st.status_ptr[2], st.err_ptr[2], stream)
+                if rc != 0:
+                    _lib.check(rc, "gabo_spd_sweep_select_rows")
+                break
             if world == 1:
                 y = st.values[:total]
             else:
@@ -618,13 +637,15 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
             warnings.warn("Unable to find non-zero acquisition function values - initial conditions are being selected randomly.",
                           BadInitialCandidatesWarning)
         _mark(options, "<- selection")
-        mine = picked[rank::world]                       # restart k belongs to rank k % world (trust-region iteration counts vary: interleaved)
-        st.picked[:r_loc] = (mine // per) * (per + 1) + 1 + mine % per          # sample index -> row of the table
+        if not on_device:
+            mine = picked[rank::world]                   # restart k belongs to rank k % world (trust-region iteration counts vary: interleaved)
+            st.picked[:r_loc] = (mine // per) * (per + 1) + 1 + mine % per          # sample index -> row of the table
         if world > 1 and r_loc < r_per:
             st.res[r_loc:, 0] = float("inf")             # (a rank with one restart fewer: its padding row loses every argmax)
         if r_loc:
-            rc = lib.gabo_spd_sweep_solve_rows(cfg_ref, st.picked_ptr, r_loc, world * (per + 1), st.results_ptr if world == 1 else None,
-                                               st.ws.data_ptr(), st.wsb, st.status_ptr[1], st.err_ptr[1], 1 if world == 1 else 0, stream)
+            rc = lib.gabo_spd_sweep_solve_rows(cfg_ref, st.picked_dev.data_ptr() if on_device else st.picked_ptr, r_loc, world * (per + 1),
+                                               st.results_ptr if world == 1 else None, st.ws.data_ptr(), st.wsb, st.status_ptr[1], st.err_ptr[1],
+                                               1 if world == 1 else 0, stream)
             if rc != 0:
                 _lib.check(rc, "gabo_spd_sweep_solve_rows")
         _mark(options, "<- solve")
@@ -635,14 +656,24 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
             _all_gather_rows(dist, gathered, st.res[:r_per].clone())
             # rank r's row j is restart j * world + r           (the copy to the host waits for the stream)
             rows = gathered.cpu().numpy().reshape(world, r_per, 2 + dv).transpose(1, 0, 2).reshape(world * r_per, 2 + dv)[:R]
+        if on_device:
+            ops.check_prefetched(pending)
+            if checking:
+                st.raise_if_failed(0, "gabo_spd_sweep_score_rows")
+            if st.err[4] != 0:
+                # the heuristic needs its random fall-backs (no positive value among the raw samples, or fewer than restarts), a value is NaN - or the
+                # flag never arrived: the host heuristic decides, with its retries (manifold_optimize.py:283-320)
+                return _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, dict(options, device_selection=False))
         if checking:
             st.raise_if_failed(1, "gabo_spd_sweep_solve_rows")
     cost = rows[:, 0]
-    nan = np.isnan(cost)
-    best = int(np.argmax(nan)) if nan.any() else int(np.argmin(cost))         # torch.argmax(-cost): a NaN wins, the first of equal values
+    best = int(np.argmin(cost))          # torch.argmax(-cost): the first of equal values; a NaN wins (numpy's argmin returns the first NaN too)
     solver.log = {"iterations": int(rows[:, 1].max()), "per_restart_iterations": torch.from_numpy(rows[:, 1].astype(np.int64)),
                   "final_cost": torch.from_numpy(cost.copy()), "final_gradnorm": None, "cost_evals": 0, "grad_evals": 0,
-                  "time": time.time() - time0, "one_launch_solve": True, "native_sweep": True, "world_size": world}
+                  "time": time.time() - time0, "one_launch_solve": True, "native_sweep": True, "world_size": world,
+                  "device_selection": on_device}
+    if on_device and options.get("log_picked"):
+        solver.log["picked_samples"] = st.samples_dev[:R].cpu().numpy()
     if world == 1:
         out = st.res[best, 2:].clone().reshape(1, dv)          # (the winner's row of the device table: no host -> device copy)
     else:

@@ -14,6 +14,8 @@ import warnings
 
 import torch
 
+from . import _lib as _l, ops as _ops
+
 
 class BadInitialCandidatesWarning(RuntimeWarning):
     pass
@@ -35,7 +37,6 @@ class ExactGP(torch.nn.Module):
 
     def _train_cache(self):
         if self._cache is None:
-            from . import _lib as _l, ops as _ops
             n = self.train_x.shape[-2]
             if self.train_x.is_cuda and 0 < n <= _l.GABO_GP_FACTOR_MAX_N:
                 # one launch instead of Cholesky (+ its info read-back), cholesky_solve and a triangular solve (csrc/gp_factor.hip)

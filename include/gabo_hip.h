@@ -560,6 +560,23 @@ int gabo_spd_sweep_rows_tables(void* workspace, int64_t n_train, int d, int64_t 
 int gabo_spd_sweep_score_rows(const gabo_spd_sweep_config* cfg, int64_t first_sample, int64_t first_row, int64_t count, int64_t max_raw,
                               int64_t restarts, uint64_t seed, const double* raw_matrices_host, double* values_mapped, void* workspace,
                               size_t workspace_bytes, int* status, int* status_mapped, int synchronize, gabo_stream_t stream);
+/* The selection between the two, on the device (one launch): which `restarts` of the `total` scored raw samples become restarts - [3P] botorch's
+ * initialize_q_batch_nonneg (the heuristic gen_batch_initial_conditions_manifold applies to non-negative acquisition functions,
+ * manifold_optimize.py:296-317): samples with value >= alpha * max (alpha shrunk by tens until `restarts` qualify) drawn without replacement with
+ * weights exp(eta (y / max - 1)) by the exponential race torch.multinomial runs (keys w_i / E_i, the largest win; E_i from the library's Philox
+ * stream (seed, sample index) instead of the host generator), the arg-max forced into the last slot when the draw missed it.
+ *   raw_rows: the raw-row table (gabo_spd_sweep_rows_tables) laid out in `world` blocks of per_rank + 1 rows - a header row, then the block's
+ *     samples: sample s sits in row (s / per_rank) * (per_rank + 1) + 1 + s % per_rank (one rank: world = 1, per_rank = total); seed_in_header != 0:
+ *     the seed is read from column 0 of row 0 (after an all_gather: rank 0's proposal, identical on every rank).
+ *   picked_rows: device memory, ceil(restarts / world) int64 - the table rows of the restarts this rank owns (restart k belongs to rank k % world),
+ *     ready for gabo_spd_sweep_solve_rows; picked_samples (may be NULL): `restarts` int64, the sample index of every restart.
+ *   flag (device int) / flag_mapped (device-addressable host int, may be NULL): 0 = picked; 1 = the heuristic has to fall back on its random
+ *     choices (no positive value, fewer positive values than restarts) or a value is NaN: nothing was picked, the caller selects on the host.
+ * gabo_spd_sweep_select_supported: total <= 8192 and restarts < total (otherwise the caller selects on the host as well). */
+int gabo_spd_sweep_select_supported(int64_t total, int64_t restarts);
+int gabo_spd_sweep_select_rows(const double* raw_rows, int d, int64_t total, int64_t per_rank, int64_t restarts, double eta, double alpha, uint64_t seed,
+                               int seed_in_header, int rank, int world, int64_t* picked_rows, int64_t* picked_samples, int* flag, int* flag_mapped,
+                               gabo_stream_t stream);
 int gabo_spd_sweep_solve_rows(const gabo_spd_sweep_config* cfg, const int64_t* picked_mapped, int64_t restarts, int64_t max_raw,
                               double* results_mapped, void* workspace, size_t workspace_bytes, int* status, int* status_mapped, int synchronize,
                               gabo_stream_t stream);

@@ -105,3 +105,12 @@ def test_bench_eight_ranks_on_one_device(tmp_path):
         single = run_sweep("cuda:0", num_restarts=total, raw_samples=4 * total, device_rand=True, builtin_constraint=True)[2]
         got = strong[str(total)]["best_acq"]
         assert abs(got - single) <= 1e-9 * abs(single), (total, got, single)
+    # every rank ran the native driver (round 6: it no longer steps aside when a process group exists), the 512-restart sweep with the selection
+    # on the device; a rank's sweep of its 64 restarts costs what a one-rank 64-restart sweep costs, plus the two collectives (here: gloo through
+    # the host, eight processes on one GPU - hence the slack)
+    assert strong["512"]["native_sweep_on_every_rank"] and strong["512"]["selection_on_the_device_on_every_rank"]
+    assert strong["8192"]["native_sweep_on_every_rank"]
+    kw64 = dict(num_restarts=64, raw_samples=256, device_rand=True, builtin_constraint=True)
+    run_sweep("cuda:0", **kw64)
+    t64 = min(run_sweep("cuda:0", **kw64)[0] for _ in range(5))
+    assert strong["512"]["seconds"] <= 2.0 * t64 + 1.5 * strong["512"]["seconds_of_the_two_collectives_alone"] + 1e-3, (strong["512"], t64)

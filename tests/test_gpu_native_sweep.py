@@ -1,7 +1,8 @@
-"""The config-4 sweep as two native host calls (gabo_spd_sweep_score / gabo_spd_sweep_solve, csrc/spd_sweep.hip) against the Python path of
-joint_optimize_manifold (manifold_optimize.py:36-120 of the reference: initial conditions, the restarts' solves, argmax): the native driver
-enqueues the same launches in the same order and leaves the selection heuristic and both random generators where they are, so the returned
-candidate is the same BIT FOR BIT."""
+"""The config-4 sweep through the native driver (gabo_spd_sweep_score_rows / _select_rows / _solve_rows, csrc/spd_sweep.hip) against the Python path
+of joint_optimize_manifold (manifold_optimize.py:36-120 of the reference: initial conditions, the restarts' solves, argmax): the device executes the
+same statements in the same order and, with the selection heuristic left on the host (device_selection=False), both random generators are consumed
+as on the Python path - so the returned candidate is the same BIT FOR BIT.  With the selection on the device (the default) the picks come from the
+library's own random stream; given those picks the Python path returns the same candidate, again bit for bit."""
 import os
 import sys
 
@@ -16,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def _both(device_rand=True, **kw):
     from tools.sweep_bench import run_sweep
-    _, best_n, val_n, log_n = run_sweep("cuda:0", device_rand=device_rand, builtin_constraint=True, native_sweep=True, **kw)
+    _, best_n, val_n, log_n = run_sweep("cuda:0", device_rand=device_rand, builtin_constraint=True, native_sweep=True, device_selection=False, **kw)
     _, best_p, val_p, log_p = run_sweep("cuda:0", device_rand=device_rand, builtin_constraint=True, native_sweep=False, **kw)
     assert log_n.get("native_sweep") and not log_p.get("native_sweep")
     return (best_n, val_n, log_n), (best_p, val_p, log_p)
@@ -106,7 +107,7 @@ def test_native_sweep_on_the_log_euclidean_surrogate_of_config_5():
         torch.manual_seed(7)
         solver = BatchedTrustRegions(mingradnorm=2e-4, maxiter=60, strict_constraints=True)
         best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=48, raw_samples=192, bounds=None,
-                                       options={"device": "cuda:0", "batched_rand": True, "native_sweep": native}, inequality_constraints=cons,
+                                       options={"device": "cuda:0", "batched_rand": True, "native_sweep": native, "device_selection": False}, inequality_constraints=cons,
                                        pre_processing_manifold=to_mat, post_processing_manifold=to_vec, approx_hessian=True)
         assert bool(solver.log.get("native_sweep")) == native and solver.log.get("one_launch_solve")
         outs.append((best.clone(), solver.log["final_cost"].clone(), solver.log["per_restart_iterations"].clone()))
@@ -130,3 +131,83 @@ def test_native_sphere_sweep_returns_the_python_path_candidate(approx):
     np.testing.assert_array_equal(outs[0][3], outs[1][3])
     # a constrained sphere sweep (constraints on the sphere are user callables) stays on the Python path
     assert not run(approx=True, constrained=True, device="cuda:0", R=16, raw=64, maxiter=5)[3].get("native_sweep")
+
+
+@pytest.mark.parametrize("total,n,world", [(256, 64, 1), (2048, 512, 1), (2048, 512, 8), (50, 7, 3), (4096, 100, 1), (8192, 1, 2), (3, 1, 1)])
+def test_device_selection_picks_the_oracles_rows(total, n, world):
+    """gabo_spd_sweep_select_rows against oracle/selection.py (botorch's initialize_q_batch_nonneg as an exponential race on the library's Philox
+    stream): the same restarts in the same order, for one rank and for every rank of a sharded table; where two keys agree to 1e-12 the order may
+    differ (device exp / log against numpy's)."""
+    import ctypes
+    from gabotorch_amd import _lib
+    from oracle import selection as osel
+    lib = _lib.load()
+    d, dv = 5, 15
+    rng = np.random.default_rng(total + n)
+    y = np.maximum(rng.standard_normal(total), 0.0) * np.exp(2.0 * rng.standard_normal(total)) + (rng.random(total) < 0.3) * 1e-3
+    y[rng.integers(total)] = y.max() * 1.5
+    if n > int((y > 0).sum()):
+        y = np.abs(y) + 1e-6
+    per = (total + world - 1) // world
+    table = np.zeros((world * (per + 1), 1 + dv))
+    rows = (np.arange(total) // per) * (per + 1) + 1 + np.arange(total) % per
+    table[rows, 0] = y
+    seed = 0x1234567 + total
+    table[0, 0] = float(seed)
+    want, keys = osel.select_nonneg(y, n, seed, eta=1.3, alpha=1e-4)
+    assert want is not None
+    tab = torch.tensor(table, device="cuda:0")
+    flag = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+    got_samples = None
+    for rank in range(world):
+        r_loc = len(range(rank, n, world))
+        picked = torch.full((max((n + world - 1) // world, 1),), -1, dtype=torch.int64, device="cuda:0")
+        samples = torch.full((n,), -1, dtype=torch.int64, device="cuda:0")
+        rc = lib.gabo_spd_sweep_select_rows(tab.data_ptr(), d, total, per, n, 1.3, 1e-4, 0 if world > 1 else seed, 1 if world > 1 else 0, rank, world,
+                                            picked.data_ptr(), samples.data_ptr(), flag.data_ptr(), None, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int(flag) == 0
+        s_ = samples.cpu().numpy()
+        if got_samples is None:
+            got_samples = s_
+        np.testing.assert_array_equal(s_, got_samples)                   # every rank picks the same restarts
+        np.testing.assert_array_equal(picked.cpu().numpy()[:r_loc], rows[s_[rank::world]])
+    assert len(set(got_samples.tolist())) == n and int(np.argmax(y)) in got_samples
+    differs = np.nonzero(got_samples != want)[0]
+    for k in differs:              # only where the race was a photo finish
+        a, b = keys[got_samples[k]], keys[want[k]]
+        assert abs(a - b) <= 1e-12 * max(abs(a), abs(b)), (k, a, b)
+
+
+def test_device_selection_raises_its_flag_where_the_heuristic_falls_back():
+    from gabotorch_amd import _lib
+    lib = _lib.load()
+    for y in (-np.ones(16), np.r_[1.0, np.zeros(15)], np.r_[np.nan, np.ones(15)]):
+        table = np.zeros((17, 16))
+        table[1:, 0] = y
+        tab = torch.tensor(table, device="cuda:0")
+        flag = torch.full((1,), -1, dtype=torch.int32, device="cuda:0")
+        picked = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        assert lib.gabo_spd_sweep_select_rows(tab.data_ptr(), 5, 16, 16, 4, 1.0, 1e-4, 1, 0, 0, 1, picked.data_ptr(), None, flag.data_ptr(), None, None) == 0
+        torch.cuda.synchronize()
+        assert int(flag) == 1
+    assert lib.gabo_spd_sweep_select_supported(8193, 4) == 0 and lib.gabo_spd_sweep_select_supported(16, 16) == 0
+
+
+@pytest.mark.parametrize("restarts,raw", [(512, 2048), (64, 256), (7, 50)])
+def test_native_sweep_with_the_selection_on_the_device(restarts, raw, monkeypatch):
+    """score -> selection kernel -> solve without a host wait in between: the restarts are the oracle's picks for the scores the sweep saw, and the
+    Python path handed the same picks returns the same candidate, costs and iteration counts bit for bit."""
+    from tools.sweep_bench import run_sweep
+    from gabotorch_amd.manifold_optimization import manifold_optimize as mo
+    _, best_d, val_d, log_d = run_sweep("cuda:0", device_rand=True, builtin_constraint=True, num_restarts=restarts, raw_samples=raw, log_picked=True)
+    assert log_d.get("native_sweep") and log_d.get("device_selection")
+    picks = log_d["picked_samples"]
+    assert picks.shape == (restarts,) and len(set(picks.tolist())) == restarts and picks.min() >= 0 and picks.max() < raw
+    monkeypatch.setattr(mo, "select_rows", lambda y, n, gen, nonneg, eta=1.0, alpha=1e-4: (picks.astype(np.int64), False))
+    _, best_p, val_p, log_p = run_sweep("cuda:0", device_rand=True, builtin_constraint=True, num_restarts=restarts, raw_samples=raw, native_sweep=False)
+    assert not log_p.get("native_sweep")
+    assert torch.equal(best_d, best_p) and val_d == val_p
+    assert torch.equal(log_d["per_restart_iterations"].cpu(), log_p["per_restart_iterations"].cpu())
+    np.testing.assert_array_equal(log_d["final_cost"].cpu().numpy(), log_p["final_cost"].cpu().numpy())

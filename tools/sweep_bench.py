@@ -20,7 +20,7 @@ def mandel(m):
     return np.ascontiguousarray(m[..., r, c] * np.where(r == c, 1.0, 2 ** 0.5))
 
 
-def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=1234, maxiter=100, hip_graphs=False, batched_rand=False, fused=True, device_tcg=True, device_outer=True, capture_constraints=False, strict=False, device_iteration=True, device_rand=False, device_solve=True, builtin_constraint=False, native_sweep=True, constraint=True, use_rand=False):
+def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=1234, maxiter=100, hip_graphs=False, batched_rand=False, fused=True, device_tcg=True, device_outer=True, capture_constraints=False, strict=False, device_iteration=True, device_rand=False, device_solve=True, builtin_constraint=False, native_sweep=True, constraint=True, use_rand=False, device_selection=None, log_picked=False):
     rng = np.random.default_rng(seed)
     q = np.linalg.qr(rng.standard_normal((n_train, d, d)))[0]
     X = np.einsum("nab,nb,ncb->nac", q, rng.uniform(1e-3, 5.0, (n_train, d)), q)
@@ -52,7 +52,7 @@ def run_sweep(device, num_restarts=512, raw_samples=2048, d=5, n_train=50, seed=
     solver = BatchedTrustRegions(mingradnorm=1e-4, maxiter=maxiter, strict_constraints=strict, use_rand=use_rand)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=num_restarts, raw_samples=raw_samples, bounds=None,
-                                   options={"device": device, "hip_graphs": hip_graphs, "batched_rand": batched_rand, "fused_acquisition": fused, "device_tcg": device_tcg, "device_outer": device_outer, "capture_constraints": capture_constraints, "device_iteration": device_iteration, "device_rand": device_rand, "device_solve": device_solve, "native_sweep": native_sweep}, inequality_constraints=None if not constraint else [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=5.0) if builtin_constraint
+                                   options={"device": device, "hip_graphs": hip_graphs, "batched_rand": batched_rand, "fused_acquisition": fused, "device_tcg": device_tcg, "device_outer": device_outer, "capture_constraints": capture_constraints, "device_iteration": device_iteration, "device_rand": device_rand, "device_solve": device_solve, "native_sweep": native_sweep, "log_picked": log_picked, **({} if device_selection is None else {"device_selection": device_selection})}, inequality_constraints=None if not constraint else [functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=5.0) if builtin_constraint
                                                            else (lambda x: scut.max_eigenvalue_constraint_torch(x, 5.0))],
                                    pre_processing_manifold=to_mat, post_processing_manifold=to_vec, approx_hessian=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
