@@ -402,6 +402,82 @@ def hd_sphere_pieces(device):
             "parity": {"projection_max_abs": e_proj, "reconstruction_cost_rel": e_rec}}
 
 
+def plugin_surface_timings(device, x, kernel_ms, steps):
+    """What a GaBOtorch user calls (`kernel.forward(X, X)`), timed next to the C-ABI launch the headline times: the kernel classes'
+    `forward` on the headline point set under torch.no_grad() and with X.requires_grad_(), HIP events on torch's current stream, `steps` calls each
+    after 3 untimed ones.  kernels_spd.py:72-100 / kernels_sphere.py:71-94 of the reference."""
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel
+    from gabotorch_amd.kernel_utils.kernels_sphere import SphereGaussianKernel
+
+    def ev_ms(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        ev[0].record()
+        for i in range(steps):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        per = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        return float(np.mean(per)), float(np.median(per))
+
+    out = {}
+    kern = SpdAffineInvariantGaussianKernel(beta_min=0.2)            # beta = softplus(0) + 0.2 = BETA (parameter on the host, as the examples keep it)
+    X = torch.tensor(np.ascontiguousarray(x), device=device)
+    X2 = X.clone()
+    with torch.no_grad():
+        same = ev_ms(lambda: kern.forward(X, X))
+        full = ev_ms(lambda: kern.forward(X, X2))
+        want = ops_pairwise_reference(X, X2, float(kern.beta.double()))
+        err = float((kern.forward(X, X2) - want).abs().max())
+        err_same = float((kern.forward(X, X) - want).abs().max())
+    Xg = X.clone().requires_grad_()
+    grad = ev_ms(lambda: kern.forward(Xg, X2))
+    nbytes = float(X.shape[0]) ** 2 * 8
+    out["spd"] = {
+        "class": "SpdAffineInvariantGaussianKernel(beta_min=0.2)", "n_points": int(X.shape[0]), "dim": DIM,
+        "forward_ms_no_grad_x_is_x": same[0], "forward_ms_no_grad_x_is_x_median": same[1],
+        "forward_ms_no_grad": full[0], "forward_ms_no_grad_median": full[1],
+        "forward_ms_grad_enabled": grad[0], "forward_ms_grad_enabled_median": grad[1],
+        "c_abi_kernel_ms": kernel_ms,
+        "overhead_no_grad_vs_c_abi": full[0] / kernel_ms - 1.0,
+        "overhead_grad_enabled_vs_c_abi": grad[0] / kernel_ms - 1.0,
+        "max_abs_diff_vs_c_abi_output": err, "max_abs_diff_x_is_x_vs_c_abi_output": err_same,
+        "note": "forward(X, X) with the SAME tensor takes the x1-is-x2 build (i <= j evaluated, mirrored: half the pairs - what a GP's train-train Gram "
+                "is); forward(X, X.clone()) evaluates all N^2 pairs like `value`: the class path adds the output allocation and a few us of Python to "
+                "the launch.  With a gradient requested the launch also writes the distance matrix (a second N^2 x 8 B = "
+                f"{nbytes / 1e6:.0f} MB store, kept for the beta-gradient) and uses the strict QL deflation threshold (both outputs leave the kernel)"}
+    rng = np.random.default_rng(1234)
+    sx = rng.standard_normal((N_POINTS, 10))
+    sx /= np.linalg.norm(sx, axis=1, keepdims=True)
+    S = torch.tensor(sx, device=device)
+    S2 = S.clone()
+    sk = SphereGaussianKernel(beta_min=0.6)
+    from gabotorch_amd import ops as _o
+    with torch.no_grad():
+        for _ in range(200):                 # (write-bound: the clocks settle over a few hundred launches, see sphere_gram below)
+            sk.forward(S, S2)
+        s_full = ev_ms(lambda: sk.forward(S, S2))
+        s_abi = ev_ms(lambda: _o.sphere_pairwise(S, S2, beta=0.6 + float(np.log(2.0))))
+    Sg = S.clone().requires_grad_()
+    s_grad = ev_ms(lambda: sk.forward(Sg, S2))
+    out["sphere"] = {"class": "SphereGaussianKernel(beta_min=0.6)", "n_points": N_POINTS, "dim": 10,
+                     "forward_ms_no_grad": s_full[0], "forward_ms_no_grad_median": s_full[1],
+                     "forward_ms_grad_enabled": s_grad[0], "forward_ms_grad_enabled_median": s_grad[1],
+                     "ops_sphere_pairwise_ms_same_conditions": s_abi[0],
+                     "overhead_no_grad_vs_ops_call": s_full[0] / s_abi[0] - 1.0,
+                     "note": "same stream and clock state for the class call and the ops call (the sustained figure of `sphere_gram` is taken on a private "
+                             "stream after 600 launches); with a gradient requested the autograd wrapper saves the inner products for the backward"}
+    return out
+
+
+def ops_pairwise_reference(X, X2, beta):
+    """the C-ABI launch `value` times, with the kernel object's own beta (an fp32 parameter: softplus(0) + 0.2 to 1e-8 of BETA)"""
+    from gabotorch_amd import ops as _o
+    return _o.spd_ai_pairwise(X, X2, beta=beta)
+
+
 def _collective_selfcheck(dist, device, world, rank):
     """The collectives of the data path executed once each on the initialised backend with the shapes the path uses, results
     checked, durations reported: the row-block slab of the sharded Gram (all_gather_into_tensor), the packed (value, candidate) rows of the
@@ -473,6 +549,7 @@ def main():
                     "--pmc passes (auto: when rocprofv3 is on PATH, one rank, not already under a profiler; ~30 s) or read from profiles/pmc_summary.json")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--sweep-lite", action="store_true", help="only the single-launch-solve variants of the config-4 sweep (tests: the eight-rank run on one device)")
+    ap.add_argument("--no-plugin-surface", action="store_true", help="skip the kernel classes' forward timings (profiling runs)")
     ap.add_argument("--no-symmetric", action="store_true", help="skip the separately reported x1-is-x2 run (profiling: keeps "
                     "the rocprof average of the pairwise kernel equal to the `value` launches)")
     args = ap.parse_args()
@@ -515,6 +592,10 @@ def main():
     if not args.no_symmetric:
         sym = GramJob(x, device, symmetric=True)
         _, sym_ms, _ = timed(sym, args.steps, args.warmup, None)
+
+    plugin = None
+    if rank == 0 and world == 1 and not args.no_plugin_surface:
+        plugin = plugin_surface_timings(device, x, ev_ms, args.steps)
 
     sharded = None
     if world > 1:
@@ -781,6 +862,12 @@ def main():
                 "smallest_total_restarts_reaching_6x_at_8_gpus": reach[0] if reach else None,
                 "north_star_512_restarts": f"predicted {pred.get('512', float('nan')):.2f}x at 8 GPUs: the 512-restart sweep is latency-bound (one wave per restart, "
                                            "2 waves per CU on one GPU already), so the >= 6x of north_star is reached only from the restart count above"}
+        if plugin is not None:
+            line["plugin_surface"] = plugin
+            line["forward_ms"] = {"no_grad": plugin["spd"]["forward_ms_no_grad"], "grad_enabled": plugin["spd"]["forward_ms_grad_enabled"],
+                                  "no_grad_x_is_x": plugin["spd"]["forward_ms_no_grad_x_is_x"], "sphere_no_grad": plugin["sphere"]["forward_ms_no_grad"],
+                                  "sphere_grad_enabled": plugin["sphere"]["forward_ms_grad_enabled"],
+                                  "what": "SpdAffineInvariantGaussianKernel.forward / SphereGaussianKernel.forward at N = 4096 (details: plugin_surface)"}
         if collectives is not None:
             line["collectives"] = collectives
         if sweep is not None:

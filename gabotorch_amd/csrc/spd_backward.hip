@@ -96,7 +96,13 @@ __global__ __launch_bounds__(64, (D > GABO_BWD_TWO_WAVE_MAX_DIM ? 1 : 2)) void s
 #endif
             double qe = GABO_BWD_QL_EPS2;
             asm volatile("" : "+s"(qe));
-            sym_eig_reg<D>(m, lam, vreg, qe);
+            // (round 6: eigenvalues first, then ONE vector-accumulating sweep per stage shifted by its known eigenvalue - spd_eigvec.hpp,
+            // sym_eig_reg_two_pass; -DGABO_BWD_TWO_PASS_MIN_DIM=99 keeps the one-pass solver)
+#ifndef GABO_BWD_TWO_PASS_MIN_DIM
+#define GABO_BWD_TWO_PASS_MIN_DIM 4
+#endif
+            if constexpr (D >= GABO_BWD_TWO_PASS_MIN_DIM) sym_eig_reg_two_pass<D>(m, lam, vreg, qe);
+            else sym_eig_reg<D>(m, lam, vreg, qe);
         }
         auto Vat = [&](int r, int c) -> double { return vreg[r * D + c]; };
         double lg[D];

@@ -174,6 +174,80 @@ __device__ __forceinline__ void tridiag_ql_vectors(double (&dg)[D], double (&e)[
     });
 }
 
+// The vector pass of the TWO-PASS decomposition (sym_eig_reg_two_pass below): the same implicit QL step, with the rotations accumulated into z, but
+// the first sweep of stage l shifted by `known[l]` - the eigenvalue an eigenvalue-only pass over the same tridiagonal matrix left at position l.
+// Shifted by an exact eigenvalue, ONE sweep deflates e[l] (in exact arithmetic to zero; in fp64, on the benchmark distribution, to below the
+// threshold in 99.7 % of the lane-stages: tools/sim/perfect_shift_sim.py); a stage whose test fails in some lane goes on with Wilkinson shifts as
+// the one-pass solver does, so the result never depends on the shortcut having worked.  No look-ahead: every lane starts stage l at its first sweep.
+template <int D, int ROWS = D>
+__device__ __forceinline__ void tridiag_ql_vectors_known(double (&dg)[D], double (&e)[D], double (&z)[ROWS * D], const double (&known)[D],
+                                                         const double eps2_arg = 0.0) {
+    const double eps2 = eps2_arg > 0.0 ? eps2_arg : 1.2e-32;
+    static_for<D - 1>([&](auto ll) {
+        constexpr int l = decltype(ll)::value;
+        for (int it = 0; it < 60; ++it) {
+            const double s01 = __builtin_fabs(dg[l]) + __builtin_fabs(dg[l + 1]);
+            const bool done0 = e[l] * e[l] <= eps2 * (s01 * s01);
+            if (__builtin_amdgcn_ballot_w64(done0) == __builtin_amdgcn_ballot_w64(true)) break;
+            if (done0) continue;
+            double sigma;
+            if (it == 0) {
+                sigma = known[l];
+            } else {
+                const double sa = dg[l], sb = dg[l + 1], se = e[l];
+                const double delta = 0.5 * (sb - sa);
+                const double root = sqrt_nz(__builtin_fma(delta, delta, se * se));
+                sigma = sa - copysign_d(root - __builtin_fabs(delta), delta);
+            }
+            double g = dg[D - 1] - sigma;
+            double s = 1.0, c = 1.0, p = 0.0;
+            static_for_down<D - 2, l>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const double ei = e[i];
+                double f = s * ei;
+                double b = c * ei;
+                g = copysign_d(__builtin_fmax(__builtin_fabs(g), 1e-150), g);
+                double r2 = __builtin_fma(f, f, g * g);
+                double ir = rsqrt_nz(r2);
+                e[i + 1] = r2 * ir;
+                s = f * ir;
+                c = g * ir;
+                g = dg[i + 1] - p;
+                double r = __builtin_fma(dg[i] - g, s, 2.0 * c * b);
+                p = s * r;
+                dg[i + 1] = g + p;
+                g = __builtin_fma(c, r, -b);
+                static_for<ROWS>([&](auto kk) {
+                    constexpr int k = decltype(kk)::value;
+                    double zi = z[k * D + i], zj = z[k * D + i + 1];
+                    z[k * D + i + 1] = __builtin_fma(s, zi, c * zj);
+                    z[k * D + i] = __builtin_fma(c, zi, -s * zj);
+                });
+            });
+            dg[l] -= p;
+            e[l] = g;
+            e[D - 1] = 0.0;
+        }
+    });
+}
+
+// m = V diag(lam) V^T like sym_eig_reg, in TWO passes over the tridiagonal matrix: the eigenvalues first (the O(1)-per-rotation recurrence alone,
+// with its look-ahead), then the rotations that build V with every stage shifted by its known eigenvalue - one sweep per stage, D (D - 1) / 2
+// rotations on the vectors instead of the ~2 sweeps per eigenvalue of the slowest lane the one-pass solver applies to them.  A rotation with
+// vectors costs 17 + 4 D instructions, without 17: at D = 10 and 130 sweep steps per wave the QL part goes from ~7.4 k to ~2.2 k + ~2.9 k
+// instructions per pair.  lam: the eigenvalues the vector pass ends with (they go with V; they differ from the first pass's by rounding).
+template <int D>
+__device__ __forceinline__ void sym_eig_reg_two_pass(double (&m)[tri_size(D)], double (&lam)[D], double (&v)[D * D], const double eps2 = 0.0) {
+    double sub[D], known[D], e1[D], none[D];
+    tridiagonalize_q<D>(m, lam, sub, v);
+    static_for<D>([&](auto kk) {
+        known[decltype(kk)::value] = lam[decltype(kk)::value];
+        e1[decltype(kk)::value] = sub[decltype(kk)::value];
+    });
+    tridiag_ql_vectors<D, 1, false>(known, e1, none, eps2);
+    tridiag_ql_vectors_known<D>(lam, sub, v, known, eps2);
+}
+
 // m (packed lower triangle, destroyed) = V diag(lam) V^T: eigenvalues (unordered) and eigenvectors (columns of v, row-major D x D).
 // Every lane of the wave must call it (the iteration leaves a stage by a wave-wide vote).
 template <int D>

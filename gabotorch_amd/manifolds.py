@@ -16,9 +16,9 @@ def _wrap(fn):
         targs = [torch.as_tensor(a) if isinstance(a, np.ndarray) else a for a in args]
         out = fn(*targs)
         if np_in:
-            if isinstance(out, tuple):
-                return tuple(o.cpu().numpy() for o in out)
-            return out.cpu().numpy()
+            res = tuple(o.cpu().numpy() for o in out) if isinstance(out, tuple) else out.cpu().numpy()
+            ops.check_deferred()          # (numpy in, numpy out: the copy above waited for the device - a launch that failed is reported here)
+            return res
         return out
     return inner
 

@@ -178,6 +178,17 @@ def _status_word(dev, force=False):
     return ring.take()
 
 
+def _out(t, out_device):
+    """The result on the caller's device.  A caller that handed CPU tensors gets a CPU tensor back - a device -> host copy that waits for the
+    stream anyway: the natural point to look at the status words of the launches behind it (deferred error checking: one more small copy)."""
+    if t.device == out_device:
+        return t
+    r = t.to(out_device)
+    if _check_errors == "deferred" and out_device.type == "cpu":
+        check_deferred()
+    return r
+
+
 def _mandel_dim(dv):
     d = int((-1.0 + (1.0 + 8.0 * dv) ** 0.5) / 2.0)
     if d * (d + 1) // 2 != dv:
@@ -288,8 +299,8 @@ def spd_ai_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, symmetric=Fal
                                       _stream_ptr(dev))
     _check_launch(rc, status, "gabo_spd_ai_pairwise")
     if return_dist:
-        return out.to(out_device), dist.to(out_device)
-    return out.to(out_device)
+        return _out(out, out_device), dist.to(out_device)
+    return _out(out, out_device)
 
 
 def spd_ai_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, wrt=1):
@@ -312,7 +323,7 @@ def spd_ai_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, wrt
         go_si, go_sj = 1, n2
     gx = torch.zeros(bshape + (m1, a.shape[-1]), dtype=torch.float64, device=dev)
     if gx.numel() == 0 or m2 == 0:
-        return gx.to(out_device)
+        return _out(gx, out_device)
     wsb = lib.gabo_spd_ai_workspace_bytes(nb, m1, m2, d)
     ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
     status = _status_word(dev)
@@ -324,7 +335,7 @@ def spd_ai_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, wrt
     _raise_if_not_spd(status, "gabo_spd_ai_backward")
     # (a set handed over as ONE expand()ed set, batch stride 0: the result is still the gradient with respect to the expanded tensor, one slice
     # per batch entry - autograd's ExpandBackward sums them for the base tensor; summing here as well would count the batch twice)
-    return gx.to(out_device)
+    return _out(gx, out_device)
 
 
 def spd_ai_backward2(x1, x2, grad_out, u, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, want_dgrad_out=True, want_mixed=False):
@@ -349,7 +360,7 @@ def spd_ai_backward2(x1, x2, grad_out, u, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN,
     dg = torch.zeros(bshape + (n1, n2), dtype=torch.float64, device=dev) if want_dgrad_out else None
     mx = torch.zeros(bshape + (n2, a.shape[-1]), dtype=torch.float64, device=dev) if want_mixed else None
     if hv.numel() == 0 or n2 == 0:
-        return hv.to(out_device), (None if dg is None else dg.to(out_device)), (None if mx is None else mx.to(x2.device))
+        return _out(hv, out_device), (None if dg is None else dg.to(out_device)), (None if mx is None else mx.to(x2.device))
     wsb = lib.gabo_spd_ai_backward2_workspace_bytes(nb, n1, n2, d)
     ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
     status = _status_word(dev)
@@ -360,7 +371,7 @@ def spd_ai_backward2(x1, x2, grad_out, u, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN,
     _lib.check(rc, "gabo_spd_ai_backward2")
     _raise_if_not_spd(status, "gabo_spd_ai_backward2")
     # (x2 as one expand()ed set: mx stays per batch entry, like spd_ai_backward's result - ExpandBackward does the sum)
-    return hv.to(out_device), (None if dg is None else dg.to(out_device)), (None if mx is None else mx.to(x2.device))
+    return _out(hv, out_device), (None if dg is None else dg.to(out_device)), (None if mx is None else mx.to(x2.device))
 
 
 class _SpdAiGradFunction(torch.autograd.Function):
@@ -490,7 +501,7 @@ def sphere_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, diag=False, s
     b2, _, s2 = _flatten_batch(b, 2)
     out = torch.empty(bshape + ((n1, 1) if diag else (n1, n2)), dtype=torch.float64, device=dev)
     if out.numel() == 0:
-        return out.to(out_device)
+        return _out(out, out_device)
     flags = int(mode) | (_lib.GABO_SYMMETRIC if symmetric and not diag else 0)
     with _on(dev):
         stream = _stream_ptr(dev)
@@ -501,7 +512,7 @@ def sphere_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, diag=False, s
         rc = lib.gabo_sphere_pairwise_cached(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), nb, n1, n2, dim, s1, s2, float(beta), flags,
                                              1 if diag else 0, None if ktable is None else ktable.data_ptr(), stream)
     _lib.check(rc, "gabo_sphere_pairwise")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 _sphere_ktables = {}
@@ -533,7 +544,7 @@ def sphere_from_inner(inner, beta, mode, order):
     with _on(dev):
         _lib.check(lib.gabo_sphere_from_inner(c.data_ptr(), out.data_ptr(), c.numel(), float(beta), int(mode), int(order),
                                               _stream_ptr(dev)), "gabo_sphere_from_inner")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 class _SphereFromInner(torch.autograd.Function):
@@ -609,7 +620,7 @@ def mandel_to_matrix(vec):
     out = torch.empty(v.shape[:-1] + (d, d), dtype=torch.float64, device=dev)
     with _on(dev):
         _lib.check(lib.gabo_mandel_to_matrix(v.data_ptr(), out.data_ptr(), n, d, _stream_ptr(dev)), "gabo_mandel_to_matrix")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 def matrix_to_mandel(mat):
@@ -625,7 +636,7 @@ def matrix_to_mandel(mat):
     out = torch.empty(m.shape[:-2] + (d * (d + 1) // 2,), dtype=torch.float64, device=dev)
     with _on(dev):
         _lib.check(lib.gabo_matrix_to_mandel(m.data_ptr(), out.data_ptr(), n, d, _stream_ptr(dev)), "gabo_matrix_to_mandel")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 # ------------------------------------------------------------------------------------------ batched manifold operations
@@ -671,8 +682,8 @@ def spd_manifold_op(op, a, b=None, c=None, e=None, want_grad=False):
                                       _stream_ptr(dev))
     _check_launch(rc, status, "gabo_spd_manifold_op")
     if out2 is not None:
-        return out.to(out_device), (out2 if matfun else out2.to(out_device))
-    return out.to(out_device)
+        return _out(out, out_device), (out2 if matfun else out2.to(out_device))
+    return _out(out, out_device)
 
 
 class _SpdMatFun(torch.autograd.Function):
@@ -967,7 +978,7 @@ def spd_project(x_mandel, w):
     out = torch.empty(x.shape[:-1] + (dl * (dl + 1) // 2,), dtype=torch.float64, device=dev)
     with _on(dev):
         _lib.check(lib.gabo_spd_project(x.data_ptr(), W.data_ptr(), out.data_ptr(), n, D, dl, _stream_ptr(dev)), "gabo_spd_project")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 class _SpdProject(torch.autograd.Function):
@@ -1024,7 +1035,7 @@ def nested_spd_gram(x1, x2, w, beta, metric=_lib.GABO_METRIC_AFFINE_INVARIANT, m
         nb *= int(k)
     out = torch.empty(bshape + (n1, n2), dtype=torch.float64, device=dev)
     if out.numel() == 0:
-        return out.to(out_device)
+        return _out(out, out_device)
     wsb = lib.gabo_nested_spd_gram_workspace_bytes(nb, n1, n2, dl)
     ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
     status = _status_word(dev)
@@ -1032,7 +1043,7 @@ def nested_spd_gram(x1, x2, w, beta, metric=_lib.GABO_METRIC_AFFINE_INVARIANT, m
         rc = lib.gabo_nested_spd_gram(a.data_ptr(), b.data_ptr(), W.data_ptr(), out.data_ptr(), nb, n1, n2, D, dl, int(metric), float(beta), int(mode),
                                       ws.data_ptr(), wsb, status.data_ptr(), _stream_ptr(dev))
     _check_launch(rc, status, "gabo_nested_spd_gram")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 def nested_spd_gram_applicable(x1, x2, w, *params):
@@ -1058,7 +1069,7 @@ def spd_logm_mandel(x_mandel):
     with _on(dev):
         _lib.check(lib.gabo_spd_logm_mandel(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], d, _stream_ptr(dev)),
                    "gabo_spd_logm_mandel")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 def frobenius_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN):
@@ -1077,7 +1088,7 @@ def frobenius_pairwise(x1, x2, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN):
     with _on(dev):
         _lib.check(lib.gabo_frobenius_pairwise(a2.data_ptr(), b2.data_ptr(), out.data_ptr(), nb, n1, n2, d, s1, s2, float(beta),
                                                int(mode), _stream_ptr(dev)), "gabo_frobenius_pairwise")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 def spd_logm_mandel_backward(x_mandel, grad_y):
@@ -1092,7 +1103,7 @@ def spd_logm_mandel_backward(x_mandel, grad_y):
     with _on(dev):
         _lib.check(lib.gabo_spd_logm_mandel_backward(x.data_ptr(), g.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], d,
                                                      _stream_ptr(dev)), "gabo_spd_logm_mandel_backward")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 class _SpdLogmMandel(torch.autograd.Function):
@@ -1132,14 +1143,14 @@ def frobenius_backward(x1, x2, grad_out, beta=1.0, mode=_lib.GABO_OUT_GAUSSIAN, 
         first, second, m1, m2, sf, ss, go_si, go_sj, sgn = b2, a2, n2, n1, s2, s1, 1, n2, -1.0
     gx = torch.zeros(bshape + (m1, a.shape[-1]), dtype=torch.float64, device=dev)
     if gx.numel() == 0 or m2 == 0:
-        return gx.to(out_device)
+        return _out(gx, out_device)
     with _on(dev):
         _lib.check(lib.gabo_frobenius_backward(first.data_ptr(), second.data_ptr(), g.data_ptr(), gx.data_ptr(), nb, m1, m2, d, sf,
                                                ss, n1 * n2, go_si, go_sj, float(beta), int(mode), sgn, _stream_ptr(dev)),
                    "gabo_frobenius_backward")
     if sf == 0 and nb > 1:
         gx = gx.reshape(nb, m1, -1).sum(0).expand(bshape + (m1, a.shape[-1]))
-    return gx.to(out_device)
+    return _out(gx, out_device)
 
 
 class _FrobeniusKernelFunction(torch.autograd.Function):
@@ -1400,7 +1411,7 @@ def nested_sphere_epilogue(rotated, dist_to_axis, mode=0):
     with _on(dev):
         _lib.check(lib.gabo_nested_sphere_epilogue(u.data_ptr(), out.data_ptr(), n, d, float(dist_to_axis), int(mode), _stream_ptr(dev)),
                    "gabo_nested_sphere_epilogue")
-    return out.to(out_device)
+    return _out(out, out_device)
 
 
 def nested_sphere_epilogue_backward(rotated, grad_out, dist_to_axis):
@@ -1414,7 +1425,7 @@ def nested_sphere_epilogue_backward(rotated, grad_out, dist_to_axis):
     with _on(dev):
         _lib.check(lib.gabo_nested_sphere_epilogue_backward(u.data_ptr(), g.data_ptr(), gu.data_ptr(), u.numel() // d, d,
                                                             float(dist_to_axis), _stream_ptr(dev)), "gabo_nested_sphere_epilogue_backward")
-    return gu.to(out_device)
+    return _out(gu, out_device)
 
 
 class _NestedSphereEpilogue(torch.autograd.Function):
@@ -1759,4 +1770,4 @@ def sphere_manifold_op(op, x, u, v=None, w=None):
     with _on(dev):
         _lib.check(lib.gabo_sphere_manifold_op(int(op), ptr(X), ptr(U), ptr(V), ptr(W), out.data_ptr(), n, dim, _stream_ptr(dev)),
                    "gabo_sphere_manifold_op")
-    return out.to(out_device)
+    return _out(out, out_device)

@@ -94,3 +94,91 @@ def test_a_refused_solve_consumes_its_record_buffer():
                             symmetric_matrix_to_vector_mandel_torch, approx_hessian=True)
     torch.cuda.synchronize()
     assert bool(torch.isnan(buf).all())
+
+
+def _bad_and_good(rng, n=12, d=3, bad_row=5):
+    q = np.linalg.qr(rng.standard_normal((n, d, d)))[0]
+    m = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.5, 2.0, (n, d)), q)
+    from oracle import spd as ospd
+    good = ospd.symmetric_matrix_to_vector_mandel(0.5 * (m + m.transpose(0, 2, 1)))
+    bad = good.copy()
+    bad[bad_row, 0] = -1.0
+    return torch.tensor(bad, device=DEV), torch.tensor(good, device=DEV)
+
+
+def test_deferred_error_checking_does_not_synchronise_and_names_the_launch():
+    """The default: a launch is handed a status word of its own and returns without waiting for the device; the RuntimeError the reference raises
+    from torch.cholesky (spd_utils_torch.py:87) comes at the next synchronisation point, naming the launch and the matrix - and only that launch:
+    the valid ones queued behind it stay valid."""
+    assert ops.set_error_checking("deferred") == "deferred"            # (the default, restored by conftest)
+    bad, good = _bad_and_good(np.random.default_rng(0))
+    ops.spd_ai_pairwise(good, good)                                     # warm: workspaces, the stream's status ring
+    torch.cuda.synchronize()
+    try:
+        torch.cuda.set_sync_debug_mode("error")                         # any synchronising call below raises
+        guarded = True
+    except Exception:                                                   # noqa: BLE001  (not available in this build: the assertion is skipped)
+        guarded = False
+    try:
+        k_bad = ops.spd_ai_pairwise(bad, good, beta=0.7)                # no exception here, no wait
+        k_good = ops.spd_ai_pairwise(good, good, beta=0.7)
+    finally:
+        if guarded:
+            torch.cuda.set_sync_debug_mode("default")
+    with pytest.raises(RuntimeError, match=r"gabo_spd_ai_pairwise: input matrix #5 is not positive definite"):
+        ops.check_deferred()
+    ops.check_deferred()                                                # the launch behind it was fine, and nothing is pending any more
+    assert bool(torch.isfinite(k_good).all()) and k_bad.shape == (12, 12)
+    # sync mode: at the call, as the reference
+    ops.set_error_checking(True)
+    with pytest.raises(RuntimeError, match="input matrix #5"):
+        ops.spd_ai_pairwise(bad, good, beta=0.7)
+    ops.spd_ai_pairwise(good, good, beta=0.7)
+    # off: never
+    ops.set_error_checking(False)
+    ops.spd_ai_pairwise(bad, good, beta=0.7)
+    ops.check_deferred()
+    ops.set_error_checking("deferred")                                  # (coming back from False starts from clean words)
+    ops.spd_ai_pairwise(good, good, beta=0.7)
+    ops.check_deferred()
+
+
+def test_deferred_errors_on_two_streams_are_attributed_to_their_launches():
+    """One status ring per (device, stream): launches on different streams fail independently and each error names its own launch."""
+    ops.set_error_checking("deferred")
+    rng = np.random.default_rng(1)
+    bad_a, good = _bad_and_good(rng, bad_row=3)
+    bad_b, _ = _bad_and_good(rng, bad_row=7)
+    sa, sb = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        ops.spd_ai_pairwise(good, good)
+        ops.spd_ai_pairwise(bad_a, good)                                # stream A: the Gram launch fails at matrix 3
+    with torch.cuda.stream(sb):
+        ops.spd_acq_prepare_train(bad_b)                                # stream B: factoring a training set fails at matrix 7
+        ops.spd_ai_pairwise(good, good)
+    seen = []
+    for _ in range(2):
+        with pytest.raises(RuntimeError) as err:
+            ops.check_deferred()
+        seen.append(str(err.value))
+    ops.check_deferred()                                                # both reported, nothing left
+    assert any("gabo_spd_ai_pairwise: input matrix #3" in m for m in seen), seen
+    assert any("gabo_spd_acq_prepare_train: input matrix #7" in m for m in seen), seen
+
+
+def test_a_failed_factorisation_drops_the_models_cache():
+    """models.ExactGP published its prediction cache before the Cholesky status was known; a caller that caught the RuntimeError and asked
+    again got values computed from uninitialised memory.  The cache is now dropped before the error is raised, so the second request fails the same way."""
+    from gabotorch_amd import models
+    rng = np.random.default_rng(2)
+    _, good = _bad_and_good(rng)
+    y = torch.tensor(rng.standard_normal(12), device=DEV)
+    gp = models.ExactGP(good, y, SpdAffineInvariantGaussianKernel(beta_min=0.5), outputscale=1.0, noise=-2.0)      # K - 2 I: indefinite
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="not positive definite"):
+            gp.posterior(good[:3, None])
+        assert gp._cache is None
+    gp.noise = 1e-2
+    mean, var = gp.posterior(good[:3, None])
+    assert bool(torch.isfinite(mean).all()) and bool((var > -1e-9).all())

@@ -68,14 +68,15 @@ def test_kernel_classes_take_the_fused_path_only_without_gradients():
         np.testing.assert_allclose(fused.cpu().numpy(), graph.detach().cpu().numpy(), rtol=1e-12, atol=1e-14)
 
 
-def test_fused_nested_gram_error_semantics():
+def test_fused_nested_gram_error_semantics(raising):
     rng = np.random.default_rng(2)
     x, w = _data(rng, 20, 8, 2)
     bad = x.copy()
     bad[3] = -bad[3]                                       # negative definite: its projection too
     X, B, W = torch.tensor(x, device=DEV), torch.tensor(bad, device=DEV), torch.tensor(w, device=DEV)
-    with pytest.raises(RuntimeError, match="not positive definite"):
+    with raising("not positive definite"):
         ops.nested_spd_gram(B, X, W, 0.5)                  # x1 is factored: raises (spd_utils_torch.py:87)
     k = ops.nested_spd_gram(X, B, W, 0.5).cpu().numpy()    # x2: a NaN column (spd_utils_torch.py:109-120)
     assert np.isnan(k[:, 3]).all() and not np.isnan(np.delete(k, 3, axis=1)).any()
     ops.nested_spd_gram(X, X, W, 0.5)                      # the status word is clean again after the raise
+    ops.check_deferred()

@@ -164,15 +164,15 @@ def test_spd_ai_shapes_batches_and_edges():
     assert k.device.type == "cpu" and k.dtype == torch.float64
 
 
-def test_spd_not_spd_is_reported():
+def test_spd_not_spd_is_reported(raising):
     bad = np.array([[1.0, 1.0, 3.0 * 2 ** 0.5]])       # [[1,3],[3,1]]: indefinite
     good = ospd.symmetric_matrix_to_vector_mandel(np.eye(2)[None])
-    with pytest.raises(RuntimeError, match="not positive definite"):
+    with raising("not positive definite"):
         ops.spd_ai_pairwise(t(bad), t(good))
     # an indefinite matrix in the SECOND set: the reference factors x1 only - the pair goes through symeig and log and comes out NaN, without an
     # exception (spd_utils_torch.py:87, 109-120; tests/test_gpu_nan.py)
     assert bool(torch.isnan(ops.spd_ai_pairwise(t(good), t(bad))).all())
-    with pytest.raises(RuntimeError, match="not positive definite"):
+    with raising("not positive definite"):
         ops.spd_ai_pairwise(t(good), t(np.array([[1.0, float("nan"), 0.0]])))
     with pytest.raises(RuntimeError, match="unsupported dimension"):
         ops.spd_ai_pairwise(t(np.ones((2, 33 * 34 // 2))), t(np.ones((2, 33 * 34 // 2))))
