@@ -733,20 +733,21 @@ def main():
                  "seconds_single_launch_solve": sw_s, "seconds_single_launch_solve_device_rand": sw_sd, "best_acq_single_launch_solve": sw_val_s,
                  "best_acq_single_launch_solve_device_rand": sw_val_sd,
                  "seconds_single_launch_solve_device_rand_python_path": sw_sd_py, "best_acq_single_launch_solve_device_rand_python_path": sw_val_sd_py,
-                 "native_host_driver": "with one process the device-sampled sweep runs through gabo_spd_sweep_score / gabo_spd_sweep_solve (csrc/spd_sweep.hip): the "
-                                       "launches of the Python path enqueued from C++, the selection heuristic still on torch's generator between the two calls; the "
-                                       "two paths return the same candidate bit for bit (tests/test_gpu_native_sweep.py); with several ranks the Python path runs "
-                                       "(its all_gathers sit between the launches)",
+                 "native_host_driver": "the device-sampled sweep runs through the native driver (csrc/spd_sweep.hip): gabo_spd_gp_prepare (one host call for the GP's "
+                                       "set-up), then gabo_spd_sweep_score_rows -> gabo_spd_sweep_select_rows (botorch's initialize_q_batch_nonneg as a kernel on the "
+                                       "library's Philox stream) -> gabo_spd_sweep_solve_rows (start, solve and end of every restart in ONE launch): three launches and "
+                                       "one host wait; with the selection left on the host (options['device_selection'] = False) it returns the Python path's candidate "
+                                       "bit for bit, with the selection on the device the Python path returns the same candidate when handed the kernel's picks "
+                                       "(tests/test_gpu_native_sweep.py); with several ranks the SAME driver runs on every rank (two all_gathers on its two tables)",
                  "weak_scaling_512_restarts_per_gpu": weak,
                  "strong_scaling_fixed_total_restarts": strong,
                  "seconds_by_restarts_one_gpu": latency_table,
-                 "note": "latency-bound: 512 restarts are 2 waves per CU and each wave runs its restart serially (about 0.065 ms per full "
-                         "trust-region iteration).  Round 5: the restarts that sit on the eigenvalue bound (4 of 512: 99 of their 100 proposals rejected) "
-                         "no longer set the launch's duration - the solve evaluates a proposal's value before its gradient after a rejection and reuses the "
-                         "previous proposal when tCG returns the same step again (bit-identical results) - so the kernel lasts as long as the longest chain "
-                         "of accepted iterations (12).  Around it: ~0.3 ms per-GP set-up, ~0.25 ms selection heuristic, two host synchronisations; 1-2 ms "
-                         "more when the raw samples are drawn by the host sampler.  Opaque constraint callables cost 0.4 ms per iteration and one graph "
-                         "replay each.  Does not speed up with more GPUs at this size (weak scaling only)"}
+                 "note": "latency-bound: one wave per restart walks its trust-region iterations serially (an accepted iteration is ~140 k cycles = ~58 us, the "
+                         "longest chain of accepted iterations 12: ~0.72 ms of the sweep is this one launch whatever the number of restarts up to ~1024).  Round 6 "
+                         "removed what surrounded it: per-GP set-up in one host call (gp_factor 104 -> ~15 us), ten launches in front of the solve and three behind "
+                         "it folded into the solve launch, the selection heuristic on the device (no host wait between scoring and solving), scores / picks / results "
+                         "in page-locked memory the kernels address directly.  Does not speed up with more GPUs at this size (see expected_scaling)"}
+
 
 
     sphere_sweep_result = None
@@ -843,10 +844,11 @@ def main():
             "sharded_gram.all_gathered": "strong, ~3x at P = 8: each rank receives (P-1)/P of the 134 MB result, 16.8 MB from each of 7 peers over its own "
                                          "xGMI link (76.8 GB/s per direction peak, ~50 GB/s assumed): 0.34 ms on top of the 0.31 ms of compute; leave the "
                                          "Gram sharded when the consumer is sharded",
-            "acq_sweep.strong_512_restarts": "~1.0x at any P (see acq_sweep.strong_measured_model for this run's table): a restart is ONE wave that runs its "
-                                             "trust-region iterations serially, and the 512-restart sweep is 2 waves per CU already. north_star's >= 6x at 8 GPUs is "
-                                             "NOT reachable for a sweep of this size with a wave-per-restart solver; what round 5 did instead is cut the one-GPU time "
-                                             "of this sweep 2.8x (4.2-4.6 -> 1.5 ms)",
+            "acq_sweep.strong_512_restarts": "~1.1-1.2x at P = 8 before the two collectives (see acq_sweep.strong_measured_model for this run's table): a restart is ONE "
+                                             "wave that runs ~12 accepted trust-region iterations of ~58 us serially, one GPU holds 512 such waves at one per SIMD with room to "
+                                             "spare, so a rank with 64 restarts finishes barely earlier than one GPU with all 512. north_star's >= 6x at 8 GPUs is NOT reachable for "
+                                             "a sweep of this size with a wave-per-restart solver (it is from ~16 384 restarts); what rounds 5-6 did instead is cut the one-GPU "
+                                             "time of this sweep 3.8x (4.2-4.6 -> 1.5 -> 1.15-1.18 ms) and make every rank of a sharded sweep run the native driver",
             "acq_sweep.weak_scaling_512_restarts_per_gpu": "~P x restarts/s: per-rank work unchanged, one all_gather of (value, sample) rows for the raw samples "
                                                            "(2048 x 16 doubles per rank) and one of (value, candidate) per restart (512 x 16 doubles per rank)",
             "measured_single_gpu_latencies_us": {"tr_iteration_launch_64_restarts": 86, "tr_iteration_launch_512_restarts": 113,

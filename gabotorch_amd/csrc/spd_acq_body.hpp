@@ -126,7 +126,11 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
         double lam[D];
         if constexpr (kRegV) {
             // (value only: the same eigenvalues, bit for bit, without the eigenvectors - a third of the eigen-solver's instructions)
+#ifdef GABO_ACQ_TWO_PASS       /* A/B (round 6): the backward's two-pass decomposition here too - measured, see DESIGN.md */
+            if (want_grad) sym_eig_reg_two_pass<D>(m, lam, vreg);
+#else
             if (want_grad) sym_eig_reg<D>(m, lam, vreg);
+#endif
             else sym_eig_reg_values<D>(m, lam);
         } else {
             jacobi_eig<D>(m, vl);

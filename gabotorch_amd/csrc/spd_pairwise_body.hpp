@@ -393,6 +393,9 @@ __global__ __launch_bounds__(256) void spd_ai_gauss2_log_kernel(const double* __
 // 1e-15) in units of ln2/256, whose exp needs no argument reduction products (Y - rint(Y) is exact).  ~36 instructions per pair where the
 // sqrt + log form had ~64.  tau >= 2^12 (eigenvalue ratio of M beyond e^18) or NaN: those lanes take acosh = log(tau + sqrt(tau^2 - 1)) from OCML
 // behind a wave-uniform branch.
+#ifndef GABO_GAUSS2_MAX_ROWS      /* rows of W a block of the d = 2 Gaussian kernel prepares (<= its 256 threads); GABO_PAIR_ROWS_GAUSS2 <= this */
+#define GABO_GAUSS2_MAX_ROWS 64
+#endif
 constexpr double kGauss2L = 0.0027076061740622863;      // ln2 / 256
 // [0..3] l^k / k! (k = 1..4), [4] 1.5 2^52, [5] 2^12
 __constant__ double kGauss2C[6] = {kGauss2L, kGauss2L * kGauss2L / 2.0, kGauss2L * kGauss2L * kGauss2L / 6.0,
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __rest
 #endif
     __shared__ double etab[256];
     __shared__ __attribute__((aligned(16))) double atab[kAcosh2Slots * kAcosh2Stride];
-    __shared__ __attribute__((aligned(16))) double wrow[64 * 4];
+    __shared__ __attribute__((aligned(16))) double wrow[GABO_GAUSS2_MAX_ROWS * 4];
     const int tid = threadIdx.x;
 #ifndef GABO_GAUSS2_OCML_LOG
     for (int k = tid; k < 512; k += blockDim.x) ltab[k] = kLogTab[k];
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(256) void spd_ai_gauss2_kernel(const double* __rest
     const int nrows = __builtin_amdgcn_readfirstlane((int)(i1 - i0));      // (wave-uniform: the loop counter and its compare stay on the scalar unit)
     // x1 is x2: row r of the block is stored by the lanes with i0 + r <= j
     const int64_t jrel = j - i0;
-    const int rmax = j >= n2 ? -1 : (SYM ? (jrel < 0 ? -1 : (jrel > 63 ? 63 : (int)jrel)) : 63);
+    const int rmax = j >= n2 ? -1 : (SYM ? (jrel < 0 ? -1 : (jrel > GABO_GAUSS2_MAX_ROWS - 1 ? GABO_GAUSS2_MAX_ROWS - 1 : (int)jrel)) : GABO_GAUSS2_MAX_ROWS - 1);
     typedef double g2_v2d __attribute__((ext_vector_type(2)));
     if (!SYM && j >= n2) return;       // (no barrier below; the full build then stores without a per-row predicate)
     for (int r = 0; r < nrows; ++r, orow += n2) {
@@ -594,7 +597,7 @@ static int launch_spd_ai(const double* x1, const double* x2, double* out, double
     if (nblocks > 0x7fffffffLL) return GABO_ERR_ARG;
     bool special2 = false;
 #ifndef GABO_PAIR_NO_GAUSS2
-    if constexpr (D == 2) special2 = gauss2 && rows <= 64;
+    if constexpr (D == 2) special2 = gauss2 && rows <= GABO_GAUSS2_MAX_ROWS;
 #endif
     if (special2) {
 #ifdef GABO_GAUSS2_NO_NT      /* A/B: plain stores whatever the size */

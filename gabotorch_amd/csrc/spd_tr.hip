@@ -40,9 +40,10 @@ int propose_affine_invariant(const ProposeArgs& a) { return a.d <= 8 ? dispatch_
 }  // namespace gabo
 
 namespace gabo {
-// gabo_tr_solve_record: one pending buffer per process, consumed by the next single-launch solve (a parity / debugging facility, not thread-safe)
-static double* g_tr_record = nullptr;
-static int64_t g_tr_record_cap = 0;
+// gabo_tr_solve_record: one pending buffer per host THREAD, consumed by that thread's next gabo_spd_tr_solve / gabo_sphere_tr_solve (a parity /
+// debugging facility).  The sweep drivers (spd_sweep.hip) launch their solves through tr_solve_dispatch and never take it.
+static thread_local double* g_tr_record = nullptr;
+static thread_local int64_t g_tr_record_cap = 0;
 void tr_record_take(double** buffer, int64_t* capacity) {
     *buffer = g_tr_record;
     *capacity = g_tr_record_cap;

@@ -30,15 +30,24 @@ class _BetaKernel(Kernel):
         self._set_beta(value)
 
     def beta_float(self):
-        """beta as a Python float (the fp64 value of the parameter), for the launch arguments of the fused paths.  The constraint's transform is
-        four small tensor operations (25 us of a sweep's set-up); the result is remembered per raw value."""
+        """beta as a Python float (the fp64 value of the fp32 parameter), for the launch arguments of the fused paths: the bits of
+        `float(self.beta.double())` from ONE tensor operation - softplus of the raw parameter; the constraint's lower bound is added as the
+        float32 sum the transform forms (exactly rounded either way) - and remembered per raw value.  The property costs five small tensor
+        operations, 25-30 us of a sweep's set-up."""
         raw = self.raw_beta
-        if raw.numel() != 1:
+        con = self.raw_beta_constraint
+        if raw.numel() != 1 or type(con) is not GreaterThan or getattr(con, "lower_bound", None) is None:
             return float(self.beta.double())
-        key = (raw.item(), id(self.raw_beta_constraint))
+        key = (raw.detach().item(), id(con))
         held = self.__dict__.get("_beta_float_held")
         if held is None or held[0] != key:
-            held = self.__dict__["_beta_float_held"] = (key, float(self.beta.double()))
+            import numpy as np
+            lb = con.__dict__.get("_lower_bound_float")
+            if lb is None:
+                lb = con.__dict__["_lower_bound_float"] = float(con.lower_bound)
+            with torch.no_grad():
+                sp = torch.nn.functional.softplus(raw.detach().float()).item()
+            held = self.__dict__["_beta_float_held"] = (key, float(np.float32(sp) + np.float32(lb)))
         return held[1]
 
     def _set_beta(self, value):

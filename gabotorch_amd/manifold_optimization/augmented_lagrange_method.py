@@ -212,6 +212,8 @@ class _BatchedSubproblem:
     def cost_egrad(self, x, create_graph=False):
         self.n_grad += 1
         f, eg, xx = self.problem.cost_egrad(x)
+        # (kept for hess below: the ORIGINAL problem's Euclidean gradient at this very tensor, its Riemannian form made on first use)
+        self._orig = [x, x._version, eg.detach(), None]
         p, g = self._penalty(x, True)
         return f + p, eg.detach() + g, xx
 
@@ -223,7 +225,16 @@ class _BatchedSubproblem:
         return self.cost_grad(x)[1]
 
     def hess(self, x, u, grad_x=None):
-        return self.problem.hess(x, u)              # (the original problem's own gradient differences: `grad_x` is the subproblem's)
+        # the original problem's own gradient differences (`grad_x` is the SUBPROBLEM's gradient).  Its gradient at x was evaluated by the
+        # cost_egrad call that opened this trust-region iteration: handed over when x is that same tensor, unmodified - otherwise problem.hess
+        # evaluates it again (one more gradient evaluation per Hessian-vector product, which is what every tCG step of every inner solve paid)
+        o = getattr(self, "_orig", None)
+        g0 = None
+        if o is not None and o[0] is x and o[1] == x._version:
+            if o[3] is None:
+                o[3] = self.manifold.egrad2rgrad(x, o[2])
+            g0 = o[3]
+        return self.problem.hess(x, u, g0)
 
 
 def _solve_batched(self, problem, x, eq_constraints=None, ineq_constraints=None):

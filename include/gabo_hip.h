@@ -481,23 +481,11 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
 int gabo_spd_tr_solve_supported(const gabo_spd_acq_params* acq, int64_t r, int d, int n_constraints, int lift_dim);
 
 /* ------------------------------------------------------------------------------------------------------------
- * One multi-start acquisition sweep on S^d_++ as TWO HOST CALLS (they return with the numbers): the device work of
- *   gen_batch_initial_conditions_manifold   manifold_optimize.py:232-321  (raw samples drawn on the device and scored)
+ * One multi-start acquisition sweep on S^d_++ through a native host driver: the device work of
+ *   gen_batch_initial_conditions_manifold   manifold_optimize.py:232-321  (raw samples drawn on the device and scored, the restarts selected)
  *   gen_candidates_manifold + get_best_candidates   :124-228, :118-120   (initial value / gradient, the whole trust-region solve, argmax)
- * enqueued from C++ through the entry points above (gabo_spd_sample_range, the Mandel maps, gabo_spd_acq_eval, gabo_spd_manifold_op,
- * gabo_spd_tr_solve) - the same launches, in the same order, as this package's Python path, minus ~1 ms of interpreter time around a
- * 2.7-ms solve.  The selection of the restarts among the raw samples (botorch's initialize_q_batch heuristics [3P], driven by the caller's
- * random generator) happens between the two calls, on the host, in the caller's language.  Conditions of gabo_spd_tr_solve (2 <= d <= 8,
- * constraints = bounds on the extreme eigenvalues of the iterate or none); `acq` as for gabo_spd_acq_eval.
- *   score: raw samples 0 ... count - 1 of the stream `seed` (gabo_spd_sample) - or, raw_matrices_host != NULL, the count x d x d matrices the
- *          caller's own sampler drew on the host (`manifold.rand` is user code) - -> workspace, their acquisition values -> values_host.
- *   solve: restarts from the raw samples picked_host[0 ... restarts - 1] of the LAST score call on this workspace; *best_index_host = the
- *          restart with the largest final acquisition value (first on ties, NaN wins: torch.argmax), *best_value_host its value,
- *          *max_iterations_host the largest iteration count; candidates_dev / cost_dev / iterations_dev (NULL to skip) receive DEVICE
- *          pointers into the workspace: the final iterates as Mandel vectors (restarts x d_vec), their costs (= -acquisition) and
- *          iteration counts - valid until the workspace is reused.
- * workspace: gabo_spd_sweep_workspace_bytes(n_train, d, max_raw, restarts, n_constraints) bytes, the same (max_raw, restarts) in both
- * calls; status: device int[2], zeroed by the caller. */
+ * Conditions of gabo_spd_tr_solve (2 <= d <= 8, constraints = bounds on the extreme eigenvalues of the iterate or none); `acq` as for
+ * gabo_spd_acq_eval.  The configuration of one sweep: */
 #define GABO_SWEEP_MAX_CONSTRAINTS 8
 typedef struct {
     gabo_spd_acq_params acq;
@@ -512,17 +500,9 @@ typedef struct {
     double rho_prime, rho_regularization, mingradnorm;
     int64_t maxiter;
 } gabo_spd_sweep_config;
-size_t gabo_spd_sweep_workspace_bytes(int64_t n_train, int d, int64_t max_raw, int64_t restarts, int n_constraints);
-int gabo_spd_sweep_score(const gabo_spd_sweep_config* cfg, int64_t count, int64_t max_raw, int64_t restarts, uint64_t seed,
-                         const double* raw_matrices_host, double* values_host, void* workspace, size_t workspace_bytes, int* status,
-                         gabo_stream_t stream);
-int gabo_spd_sweep_solve(const gabo_spd_sweep_config* cfg, const int64_t* picked_host, int64_t restarts, int64_t max_raw,
-                         int64_t* best_index_host, double* best_value_host, int64_t* max_iterations_host, double** candidates_dev,
-                         double** cost_dev, int64_t** iterations_dev, void* workspace, size_t workspace_bytes, int* status,
-                         gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Round 6: the same sweep with its set-up, start and end INSIDE the launches, and laid out for sharding over the GPUs of a node.
+ * The sweep with its set-up, start and end INSIDE the launches, laid out for sharding over the GPUs of a node.
  *
  * gabo_spd_gp_prepare: everything the sweep needs from a fitted exact GP with an affine-invariant kernel, from ONE host call - the Gram matrix
  *   K(X, X) of the training set (SpdAffineInvariant{Gaussian,Laplace}Kernel.forward, kernels_spd.py:72-100,157-187; `flags` = GABO_OUT_GAUSSIAN /
@@ -549,7 +529,7 @@ int gabo_spd_sweep_solve(const gabo_spd_sweep_config* cfg, const int64_t* picked
  *     the caller, that receives the same two ints when a launch of the call reports an error - the host reads it after the stream has drained,
  *     without a copy.
  *   synchronize != 0: the call returns after the stream has drained (the mapped copies are then readable by the host).
- * Same conditions as gabo_spd_sweep_score / _solve; the numbers are those of that pair and of this package's Python path, bit for bit. */
+ * The numbers are those of this package's Python path (the same device statements in the same order), bit for bit. */
 size_t gabo_spd_gp_prepare_workspace_bytes(int64_t n, int d);
 int gabo_spd_gp_prepare(const double* train_mandel, const double* y, int64_t n, int d, double beta, int flags, double outputscale, double noise,
                         double mean, double* linv, double* linv_t, double* alpha, double* train_factors, void* workspace, size_t workspace_bytes,
@@ -632,7 +612,7 @@ int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm,
                          int mininner, int maxinner, int exact_hessian, double delta_bar, double rho_prime, double rho_regularization,
                          double mingradnorm, int64_t maxiter, gabo_stream_t stream);
 
-/* The sphere twin of gabo_spd_sweep_score / gabo_spd_sweep_solve: one multi-start acquisition sweep of the reference's gabo_sphere examples
+/* The sphere counterpart, as two host calls around the caller's selection heuristic (score, then solve): one multi-start acquisition sweep of the reference's gabo_sphere examples
  * (examples/bo_sphere/benchmark_examples/gabo_sphere.py:151-175: stock TrustRegions, no constraints; manifold_optimize.py:36-321) as two host
  * calls around the caller's selection heuristic.  The raw samples are the caller's (count x dim points drawn by `manifold.rand` on the host).
  * Launches: gabo_sphere_acq_eval, gabo_sphere_manifold_op (proj), gabo_sphere_tr_solve.  candidates_dev: the final iterates, restarts x dim. */
