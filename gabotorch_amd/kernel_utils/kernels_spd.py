@@ -30,7 +30,7 @@ class _BetaKernel(Kernel):
         self._set_beta(value)
 
     def beta_float(self):
-        """beta as a Python float (the fp64 value of the fp32 parameter), for the launch arguments of the fused paths: the bits of
+        """beta as a Python float (the fp64 value of the parameter, fp32 unless the module was cast), for the launch arguments of the fused paths: the bits of
         `float(self.beta.double())` from ONE tensor operation - softplus of the raw parameter; the constraint's lower bound is added as the
         float32 sum the transform forms (exactly rounded either way) - and remembered per raw value.  The property costs five small tensor
         operations, 25-30 us of a sweep's set-up."""
@@ -45,9 +45,13 @@ class _BetaKernel(Kernel):
             lb = con.__dict__.get("_lower_bound_float")
             if lb is None:
                 lb = con.__dict__["_lower_bound_float"] = float(con.lower_bound)
+            if raw.dtype not in (torch.float32, torch.float64) or con.lower_bound.dtype != torch.float32 and con.lower_bound.dtype != raw.dtype:
+                return float(self.beta.double())
             with torch.no_grad():
-                sp = torch.nn.functional.softplus(raw.detach().float()).item()
-            held = self.__dict__["_beta_float_held"] = (key, float(np.float32(sp) + np.float32(lb)))
+                sp = torch.nn.functional.softplus(raw.detach()).item()          # (in the parameter's own precision)
+            # the transform's `softplus(raw) + lower_bound.to(raw)`: one exactly rounded sum in the parameter's precision
+            val = float(np.float32(sp) + np.float32(lb)) if raw.dtype == torch.float32 else sp + lb
+            held = self.__dict__["_beta_float_held"] = (key, val)
         return held[1]
 
     def _set_beta(self, value):

@@ -1,6 +1,7 @@
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools import sweep_bench
 from gabotorch_amd import ops, models, fused_acquisition as fa
 from gabotorch_amd.manifold_optimization import manifold_optimize as mo
