@@ -735,7 +735,7 @@ def main():
                  "seconds_single_launch_solve_device_rand_python_path": sw_sd_py, "best_acq_single_launch_solve_device_rand_python_path": sw_val_sd_py,
                  "native_host_driver": "the device-sampled sweep runs through the native driver (csrc/spd_sweep.hip): gabo_spd_gp_prepare (one host call for the GP's "
                                        "set-up), then gabo_spd_sweep_score_rows -> gabo_spd_sweep_select_rows (botorch's initialize_q_batch_nonneg as a kernel on the "
-                                       "library's Philox stream) -> gabo_spd_sweep_solve_rows (start, solve and end of every restart in ONE launch): three launches and "
+                                       "library's Philox stream) -> gabo_spd_sweep_solve_rows (a start launch and the solve, which ends with the result rows): five launches and "
                                        "one host wait; with the selection left on the host (options['device_selection'] = False) it returns the Python path's candidate "
                                        "bit for bit, with the selection on the device the Python path returns the same candidate when handed the kernel's picks "
                                        "(tests/test_gpu_native_sweep.py); with several ranks the SAME driver runs on every rank (two all_gathers on its two tables)",

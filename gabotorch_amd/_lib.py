@@ -106,7 +106,7 @@ SIGNATURES = {
     "gabo_gp_acquisition": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _D, _D, _D, _D, _I, _I, _D, _P]),
     "gabo_gp_mll": (_I, [_P, _P, _I64, _D, _D, _D, _D, _P, _P]),
     "gabo_gp_mll_gram": (_I, [_P, _P, _I64, _D, _D, _D, _P, _P, _P]),
-    "gabo_gp_factor": (_I, [_P, _P, _I64, _D, _D, _D, _P, _P, _P, _P, _P]),
+    "gabo_gp_factor": (_I, [_P, _P, _I64, _D, _D, _D, _P, _P, _P, _P, _P, _P]),
     "gabo_gp_mll_large_workspace_bytes": (_SZ, [_I64]),
     "gabo_gp_mll_large": (_I, [_P, _P, _I64, _D, _D, _D, _D, _I, _P, _P, _P, _SZ, _P]),
     "gabo_spd_acq_max_train": (_I64, [_I]),
@@ -130,7 +130,7 @@ SIGNATURES = {
     "gabo_sphere_sweep_score": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "gabo_sphere_sweep_solve": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gabo_spd_gp_prepare_workspace_bytes": (_SZ, [_I64, _I]),
-    "gabo_spd_gp_prepare": (_I, [_P, _P, _I64, _I, _D, _I, _D, _D, _D, _P, _P, _P, _P, _P, _SZ, _P, _P, _P]),
+    "gabo_spd_gp_prepare": (_I, [_P, _P, _I64, _I, _D, _I, _D, _D, _D, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P]),
     "gabo_spd_sweep_rows_workspace_bytes": (_SZ, [_I64, _I, _I64, _I64, _I]),
     "gabo_spd_sweep_rows_tables": (_I, [_P, _I64, _I, _I64, _I64, _I, _P, _P]),
     "gabo_spd_sweep_score_rows": (_I, [_P, _I64, _I64, _I64, _I64, _I64, _c.c_uint64, _P, _P, _P, _SZ, _P, _P, _I, _P]),

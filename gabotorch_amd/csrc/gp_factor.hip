@@ -17,7 +17,7 @@ namespace gabo {
 
 __global__ __launch_bounds__(256) void gp_factor_kernel(const double* __restrict__ kb, const double* __restrict__ y, int n, double outputscale,
                                                         double noise, double mean, double* __restrict__ linv, double* __restrict__ linv_t,
-                                                        double* __restrict__ alpha, int* __restrict__ status) {
+                                                        double* __restrict__ alpha, double* __restrict__ kinv, int* __restrict__ status) {
     extern __shared__ double sm[];
     const int nw = n + 1;
     double* A = sm;              // n x n: the matrix; its trailing block is updated in place (lower triangle read)
@@ -63,13 +63,31 @@ __global__ __launch_bounds__(256) void gp_factor_kernel(const double* __restrict
         const double w = W[i * nw + j];
         linv[e] = w;
         linv_t[j * n + i] = w;
+    }    if (kinv != nullptr) {
+        // A = (outputscale K + noise I)^-1 = L^-T L^-1: A[i][j] = sum_{k >= i} W[k][i] W[k][j] for i >= j, mirrored (exactly symmetric).  With it the
+        // posterior variance and its gradient need ONE n-term product per training point instead of the two triangular ones (spd_acq_body.hpp).
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            if (i < j) continue;
+            double s0 = 0.0, s1 = 0.0;
+            int k = i;
+            for (; k + 2 <= n; k += 2) {
+                s0 = __builtin_fma(W[k * nw + i], W[k * nw + j], s0);
+                s1 = __builtin_fma(W[(k + 1) * nw + i], W[(k + 1) * nw + j], s1);
+            }
+            if (k < n) s0 = __builtin_fma(W[k * nw + i], W[k * nw + j], s0);
+            const double a = s0 + s1;
+            kinv[i * n + j] = a;
+            kinv[j * n + i] = a;
+        }
     }
 }
+
 
 }  // namespace gabo
 
 extern "C" int gabo_gp_factor(const double* k, const double* y, int64_t n, double outputscale, double noise, double mean, double* linv,
-                              double* linv_t, double* alpha, int* status, gabo_stream_t stream) {
+                              double* linv_t, double* alpha, double* kinv, int* status, gabo_stream_t stream) {
     if (n < 0 || !k || !y || !linv || !linv_t || !alpha || !status) return GABO_ERR_ARG;
     if (n > GABO_GP_FACTOR_MAX_N) return GABO_ERR_DIM;
     if (n == 0) return GABO_OK;
@@ -85,6 +103,6 @@ extern "C" int gabo_gp_factor(const double* k, const double* y, int64_t n, doubl
         attr_set.fetch_or((uint64_t)1 << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL(gabo::gp_factor_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, k, y, (int)n, outputscale, noise, mean, linv, linv_t,
-                       alpha, status);
+                       alpha, kinv, status);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }

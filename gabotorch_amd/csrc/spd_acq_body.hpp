@@ -50,8 +50,13 @@ struct AcqLds {
 // One wave: acquisition value and (grad != nullptr) Euclidean gradient, Mandel, at the SPD point xrow (Mandel, global or LDS).
 // F: T * n doubles of global scratch owned by this wave; dyn: 3 n doubles of LDS.  All 64 lanes call it; ends with the outputs
 // written by the owning lanes (no trailing barrier).
+#ifdef GABO_ACQ_NOINLINE        /* A/B (round 6): one out-of-line copy per translation unit instead of one inlined copy per call site */
+#define GABO_ACQ_INLINE __attribute__((noinline))
+#else
+#define GABO_ACQ_INLINE __forceinline__
+#endif
 template <int D>
-__device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const AcqParams& P, double* __restrict__ value_out,
+__device__ GABO_ACQ_INLINE void acq_eval(const double* __restrict__ xrow, const AcqParams& P, double* __restrict__ value_out,
                                          double* __restrict__ grad_out, double* __restrict__ F, AcqLds<D>& L, double* dyn,
                                          int* __restrict__ status, int64_t index) {
     constexpr int T = tri_size(D);
@@ -89,6 +94,20 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
     GABO_TICK(101);
     const double* w = wl;
     const LogRegs logc = LogRegs::load();
+    // An experiment of round 6, off by default (-DGABO_ACQ_COMPACT): for D <= 8 and n <= 64 logm(M_j) stays in the lane's registers until its weight
+    // is known and the weighted sum over the lanes is a wave reduction in registers, instead of the spill to F, the LDS column per lane and the
+    // reduction by T lanes reading 64 entries each.  The instrumented build showed the two phases 4.2 k + 3.4 k -> 1.0 k + 4.0 k cycles, the product
+    // build was 23 % SLOWER over the whole solve.
+#ifdef GABO_ACQ_COMPACT          /* A/B (round 6): measured SLOWER - the single-launch solve at d = 5, n = 50 went from 781 to 964 us (rocprofv3) with it: */
+    constexpr bool kCompact = D <= 8;      /* fifteen more doubles live across the posterior phase of a kernel that already fills 512 registers */
+#else
+    constexpr bool kCompact = false;
+#endif
+    const bool compact = kCompact && want_grad && n <= 64;
+    double freg[kCompact ? T : 1];
+    // L^-1 and L^-T the same pointer: the caller handed over the symmetric A = (outputscale K + noise I)^-1 instead (gabo_gp_factor's `kinv`):
+    // var = k** - ks^T A ks and the gradient's L^-T L^-1 ks are then ONE matrix-vector product u = A ks instead of two triangular ones
+    const bool sym_inverse = linv != nullptr && linv == linv_t;
     for (int64_t j0 = 0; j0 < n; j0 += 64) {
         const int64_t j = j0 + lane;
         const bool live = j < n;
@@ -167,7 +186,12 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
                             constexpr int k = decltype(kk)::value;
                             f = __builtin_fma(Vat(r, k) * lg[k], Vat(c, k), f);
                         });
-                        F[(int64_t)tri(r, c) * n + j] = f;
+                        if constexpr (kCompact) {
+                            if (compact) freg[tri(r, c)] = f;
+                            else F[(int64_t)tri(r, c) * n + j] = f;
+                        } else {
+                            F[(int64_t)tri(r, c) * n + j] = f;
+                        }
                     });
                 });
             }
@@ -186,9 +210,16 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
         g_mean = sgn;
     } else {
         part = 0.0;
-        for (int64_t r = lane; r < n; r += 64) {
-            vv[r] = strided_dot(linv_t + r, ks, (int)n);      // (L^-1 ks)_r = sum_j L^-T[j][r] ks[j]  (zero for j > r)
-            part = __builtin_fma(vv[r], vv[r], part);
+        if (sym_inverse) {
+            for (int64_t r = lane; r < n; r += 64) {
+                vv[r] = strided_dot(linv + r, ks, (int)n);        // u_r = (A ks)_r  (A symmetric: its column r)
+                part = __builtin_fma(ks[r], vv[r], part);
+            }
+        } else {
+            for (int64_t r = lane; r < n; r += 64) {
+                vv[r] = strided_dot(linv_t + r, ks, (int)n);      // (L^-1 ks)_r = sum_j L^-T[j][r] ks[j]  (zero for j > r)
+                part = __builtin_fma(vv[r], vv[r], part);
+            }
         }
         const double var = os * kxx - wave_sum64(part);
         const bool clamped = !(var > 1e-9);
@@ -203,11 +234,31 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
     if (!want_grad) return;
     __syncthreads();
     GABO_TICK(103);
-    // ---- weights w_j = d(out_sign acq)/d(d_j^2) and S = sum_j w_j logm(M_j), one accumulator column per lane
+    // ---- weights w_j = d(out_sign acq)/d(d_j^2) and S = sum_j w_j logm(M_j)
+    bool reduced = false;
+    if constexpr (kCompact) {
+        if (compact) {
+            double wj = 0.0;
+            if (lane < n) {
+                double ws = 0.0;
+                if (kind != GABO_ACQ_POSTERIOR_MEAN) ws = sym_inverse ? vv[lane] : strided_dot(linv + lane, vv, (int)n);
+                wj = (out_sign * os * (g_mean * alpha[lane] - 2.0 * g_var * ws)) * kd[lane];
+            }
+            GABO_TICK(104);
+            static_for<T>([&](auto ee) {
+                constexpr int e = decltype(ee)::value;
+                const double sume = wave_sum64(lane < n ? wj * freg[e] : 0.0);
+                if (lane == 0) red[e] = sume;
+            });
+            reduced = true;
+        }
+    }
+    if (!reduced) {
+    // (one accumulator column per lane in LDS)
     static_for<T>([&](auto ee) { acc[decltype(ee)::value * LD + lane] = 0.0; });
     for (int64_t j = lane; j < n; j += 64) {
         double ws = 0.0;
-        if (kind != GABO_ACQ_POSTERIOR_MEAN) ws = strided_dot(linv + j, vv, (int)n);     // (L^-T v)_j = sum_r L^-1[r][j] v[r]  (zero for r < j)
+        if (kind != GABO_ACQ_POSTERIOR_MEAN) ws = sym_inverse ? vv[j] : strided_dot(linv + j, vv, (int)n);     // (L^-T v)_j = sum_r L^-1[r][j] v[r]  (zero for r < j)
         const double gk = out_sign * os * (g_mean * alpha[j] - 2.0 * g_var * ws);
         const double wj = gk * kd[j];
         static_for<T>([&](auto ee) {
@@ -229,6 +280,7 @@ __device__ __forceinline__ void acq_eval(const double* __restrict__ xrow, const 
             t3 += acc[e * LD + ((l + 3 + e) & 63)];
         }
         red[e] = (t0 + t1) + (t2 + t3);
+    }
     }
     __syncthreads();
     GABO_TICK(105);
@@ -265,6 +317,7 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
     const double* __restrict__ alpha = P.alpha;
     const double* __restrict__ linv = P.linv;
     const double* __restrict__ linv_t = P.linv_t;
+    const bool sym_inverse = linv != nullptr && linv == linv_t;
     const int64_t n = P.n;
     const double beta = P.beta, mean0 = P.mean, os = P.outputscale, kxx = P.kxx, best_f = P.best_f, out_sign = P.out_sign;
     const int kind = P.kind, maximize = P.maximize;
@@ -333,8 +386,9 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
     } else {
         part = 0.0;
         for (int64_t r = lane; r < n; r += 64) {
-            vv[r] = strided_dot(linv_t + r, ks, (int)n);      // (L^-1 ks)_r = sum_j L^-T[j][r] ks[j]  (zero for j > r)
-            part = __builtin_fma(vv[r], vv[r], part);
+            // (linv == linv_t: the symmetric inverse A was handed over instead - see acq_eval)
+            vv[r] = strided_dot((sym_inverse ? linv : linv_t) + r, ks, (int)n);      // (L^-1 ks)_r = sum_j L^-T[j][r] ks[j]  (zero for j > r)
+            part = sym_inverse ? __builtin_fma(ks[r], vv[r], part) : __builtin_fma(vv[r], vv[r], part);
         }
         const double var = os * kxx - wave_sum64(part);
         const bool clamped = !(var > 1e-9);
@@ -353,7 +407,7 @@ __device__ __forceinline__ void acq_eval_frob(const double* __restrict__ xrow, c
     static_for<T>([&](auto ee) { gacc[decltype(ee)::value] = 0.0; });
     for (int64_t j = lane; j < n; j += 64) {
         double ws = 0.0;
-        if (kind != GABO_ACQ_POSTERIOR_MEAN) ws = strided_dot(linv + j, vv, (int)n);     // (L^-T v)_j = sum_r L^-1[r][j] v[r]  (zero for r < j)
+        if (kind != GABO_ACQ_POSTERIOR_MEAN) ws = sym_inverse ? vv[j] : strided_dot(linv + j, vv, (int)n);     // (L^-T v)_j = sum_r L^-1[r][j] v[r]  (zero for r < j)
         const double gk = out_sign * os * (g_mean * alpha[j] - 2.0 * g_var * ws);
         const double wj = 2.0 * gk * kd[j];
         static_for<T>([&](auto ee) {

@@ -71,14 +71,94 @@ __global__ __launch_bounds__(64) void spd_sample_kernel(double* __restrict__ out
     }
 }
 
+
+// The same sampler for d <= 8 with the matrix in the lane's REGISTERS (compile-time indices): the draws, their order and every arithmetic statement
+// are those of spd_sample_kernel above - same stream, same bits - without the LDS round trip of each of its ~10 d^3 accesses (the kernel is one
+// dependent chain per lane: 26 us for 256 matrices of order 5 under rocprofv3, on the critical path of an acquisition sweep between its set-up and
+// its scoring launch).
+template <int D>
+__global__ __launch_bounds__(64) void spd_sample_reg_kernel(double* __restrict__ out, int64_t first, int64_t n, double min_eig, double max_eig,
+                                                            uint64_t seed, int mandel, int64_t out_stride) {
+    constexpr int dd = D * D;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double q[dd + 1];
+    Philox rng{(uint32_t)seed, (uint32_t)(seed >> 32), (uint64_t)(first + i), 0u};
+    static_for<(dd + 1) / 2>([&](auto hh) {
+        constexpr int e = 2 * decltype(hh)::value;
+        double z0, z1;
+        rng.normal2(z0, z1);
+        q[e] = z0;
+        q[e + 1] = z1;          // (e + 1 == dd for odd dd: the spare slot)
+    });
+    static_for<D>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        static_for<2>([&](auto) {
+            static_for<c>([&](auto pp) {
+                constexpr int p = decltype(pp)::value;
+                double dot = 0.0;
+                static_for<D>([&](auto rr) { constexpr int r = decltype(rr)::value; dot = __builtin_fma(q[r * D + p], q[r * D + c], dot); });
+                static_for<D>([&](auto rr) { constexpr int r = decltype(rr)::value; q[r * D + c] = __builtin_fma(-dot, q[r * D + p], q[r * D + c]); });
+            });
+        });
+        double nn = 0.0;
+        static_for<D>([&](auto rr) { constexpr int r = decltype(rr)::value; nn = __builtin_fma(q[r * D + c], q[r * D + c], nn); });
+        const double inv = 1.0 / __builtin_sqrt(nn);
+        static_for<D>([&](auto rr) { constexpr int r = decltype(rr)::value; q[r * D + c] *= inv; });
+    });
+    static_for<(D + 1) / 2>([&](auto hh) {
+        constexpr int k = 2 * decltype(hh)::value;
+        double u1, u2;
+        rng.uniform2(u1, u2);
+        const double s0 = __builtin_sqrt(min_eig + (max_eig - min_eig) * u2);
+        const double s1 = __builtin_sqrt(min_eig + (max_eig - min_eig) * (1.0 - u1));
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            q[r * D + k] *= s0;
+            if constexpr (k + 1 < D) q[r * D + k + 1] *= s1;
+        });
+    });
+    double* o = out + i * out_stride;
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<r + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            double sacc = 0.0;
+            static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; sacc = __builtin_fma(q[r * D + k], q[c * D + k], sacc); });
+            if (mandel) {
+                o[mandel_pos(D, r, c)] = (r == c) ? sacc : sacc * kSqrt2;
+            } else {
+                o[r * D + c] = sacc;
+                o[c * D + r] = sacc;
+            }
+        });
+    });
+}
+
+// launches the register form for d <= 8, the LDS form above it
+static int launch_spd_sample(double* out, int64_t out_stride, int64_t first, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, int mandel,
+                             hipStream_t st) {
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+#define GABO_CASE(DD)                                                                                                              \
+    case DD:                                                                                                                       \
+        hipLaunchKernelGGL((spd_sample_reg_kernel<DD>), grid, block, 0, st, out, first, n, min_eig, max_eig, seed, mandel, out_stride); \
+        break;
+    switch (d) {
+        GABO_CASE(1) GABO_CASE(2) GABO_CASE(3) GABO_CASE(4) GABO_CASE(5) GABO_CASE(6) GABO_CASE(7) GABO_CASE(8)
+        default: {
+            size_t lds = (size_t)d * d * 64 * sizeof(double);
+            hipLaunchKernelGGL(spd_sample_kernel, grid, block, lds, st, out, first, n, d, min_eig, max_eig, seed, mandel, out_stride);
+        }
+    }
+#undef GABO_CASE
+    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+}
 }  // namespace gabo
 
 namespace gabo {
 // samples first ... first + n - 1 as Mandel vectors at out + i * out_stride (arguments checked by the caller)
 int spd_sample_rows(double* out, int64_t out_stride, int64_t first, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, hipStream_t st) {
-    size_t lds = (size_t)d * d * 64 * sizeof(double);
-    hipLaunchKernelGGL(spd_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, out, first, n, d, min_eig, max_eig, seed, 1, out_stride);
-    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+    return launch_spd_sample(out, out_stride, first, n, d, min_eig, max_eig, seed, 1, st);
 }
 }  // namespace gabo
 
@@ -88,10 +168,7 @@ extern "C" int gabo_spd_sample_range(double* out, int64_t first, int64_t n, int 
     if (first < 0 || n < 0 || !(min_eig > 0.0) || !(max_eig >= min_eig)) return GABO_ERR_ARG;
     if (n == 0) return GABO_OK;
     if (!out) return GABO_ERR_ARG;
-    size_t lds = (size_t)d * d * 64 * sizeof(double);
-    hipLaunchKernelGGL(gabo::spd_sample_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream, out, first, n, d,
-                       min_eig, max_eig, seed, mandel, (int64_t)(mandel ? d * (d + 1) / 2 : d * d));
-    return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
+    return gabo::launch_spd_sample(out, (int64_t)(mandel ? d * (d + 1) / 2 : d * d), first, n, d, min_eig, max_eig, seed, mandel, (hipStream_t)stream);
 }
 
 extern "C" int gabo_spd_sample(double* out, int64_t n, int d, double min_eig, double max_eig, uint64_t seed, int mandel,

@@ -2,8 +2,8 @@
 //   joint_optimize_manifold -> gen_batch_initial_conditions_manifold (raw samples drawn and scored, manifold_optimize.py:232-321)
 //                           -> gen_candidates_manifold (the restarts' local solves, :124-228) -> get_best_candidates (:118-120).
 // Rounds 4-5 enqueued the Python path's launches from C++ (two host calls around the selection heuristic, ten launches in front of the solve kernel
-// and three behind it).  Round 6: three launches - score the raw samples into a table, select the restarts on the device, solve (every wave starts
-// its restart from its picked row and leaves a result row) - plus one host call for the GP's set-up; the tables are laid out so that a multi-GPU
+// and three behind it).  Round 6: score the raw samples into a table (sampler + evaluation), select the restarts on the device, start every restart
+// from its picked row, solve (ends with the result row) - five launches behind one host wait, plus one host call for the GP's set-up; the tables are laid out so that a multi-GPU
 // sweep all_gathers exactly them.  Below, after the helpers: gabo_spd_gp_prepare, gabo_spd_sweep_score_rows / _select_rows / _solve_rows, then the
 // sphere twin (two host calls around the host heuristic, as in round 5).
 #include <hip/hip_runtime.h>
@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void sweep_init_kernel(double* __restrict__ de
 //                            call (rounds 4-5: ~0.24 ms of Python around them, the GPU waiting for the next launch most of that time)
 // gabo_spd_sweep_score_rows: samples [first, first + count) of the stream (or the caller's host draws) as rows [value, Mandel vector] of ONE table, their
 //                            acquisition values into the table and, densely, into MAPPED HOST memory: two launches, no copy
-// gabo_spd_sweep_solve_rows: ONE launch - every wave starts its restart from its picked row (pre- / post-processing maps, value, gradient, Riemannian
-//                            gradient and norm: tr_start_body), iterates to the end and leaves [cost, iterations, Mandel vector] in a result row, on the
-//                            device and in mapped host memory.
+// gabo_spd_sweep_solve_rows: every wave starts its restart from its picked row (pre- / post-processing maps, value, gradient, Riemannian gradient and
+//                            norm: spd_tr_start_kernel), then iterates to the end (the solve launch) and leaves [cost, iterations, Mandel vector] in a
+//                            result row, on the device and in mapped host memory.
 // Rows, because a multi-GPU sweep all_gathers exactly two things: the scored raw-sample rows and the result rows - the caller does that on
 // the tables themselves between / after the calls (manifold_optimize.py of this package), the driver has no collective of its own.
 namespace gabo {
@@ -126,7 +126,7 @@ extern "C" size_t gabo_spd_gp_prepare_workspace_bytes(int64_t n, int d) {
 }
 
 extern "C" int gabo_spd_gp_prepare(const double* train_mandel, const double* y, int64_t n, int d, double beta, int flags, double outputscale, double noise,
-                                   double mean, double* linv, double* linv_t, double* alpha, double* train_factors, void* workspace,
+                                   double mean, double* linv, double* linv_t, double* alpha, double* kinv, double* train_factors, void* workspace,
                                    size_t workspace_bytes, int* status, int* factor_status, gabo_stream_t stream) {
     if (!train_mandel || !y || !linv || !linv_t || !alpha || !workspace || !status || !factor_status || n < 1) return GABO_ERR_ARG;
     if (d < 2 || d > GABO_SPD_REG_MAX_DIM) return GABO_ERR_DIM;
@@ -141,7 +141,7 @@ extern "C" int gabo_spd_gp_prepare(const double* train_mandel, const double* y, 
     if ((rc = gabo_spd_ai_pairwise(train_mandel, train_mandel, kb, nullptr, 1, n, n, d, 0, 0, beta, out | GABO_SYMMETRIC, pw,
                                    gabo_spd_ai_workspace_bytes(1, n, n, d), status, stream)) != GABO_OK)
         return rc;
-    if ((rc = gabo_gp_factor(kb, y, n, outputscale, noise, mean, linv, linv_t, alpha, factor_status, stream)) != GABO_OK) return rc;
+    if ((rc = gabo_gp_factor(kb, y, n, outputscale, noise, mean, linv, linv_t, alpha, kinv, factor_status, stream)) != GABO_OK) return rc;
     if (train_factors && (rc = gabo_spd_acq_prepare_train(train_mandel, train_factors, n, d, status, stream)) != GABO_OK) return rc;
     return GABO_OK;
 }
@@ -219,17 +219,17 @@ namespace gabo {
 // version: fine at 256 raw samples, ~0.2 ms at 2048.)
 constexpr int kSelectMaxTotal = 8192;
 
+// block-wide reduction, every thread gets the result: shuffles inside a wave, one LDS slot per wave, ONE barrier (the scratch has two banks used
+// in turn: a wave can only reach the reduction after next once every wave has read this one's bank)
 template <typename T, typename Op>
-static __device__ __forceinline__ T block_reduce_1024(T v, T* scratch, Op op) {
-    const int tid = threadIdx.x;
-    scratch[tid] = v;
+static __device__ __forceinline__ T block_reduce_1024(T v, T* scratch, int& bank, Op op) {
+    for (int o = 32; o >= 1; o >>= 1) v = op(v, __shfl_xor(v, o));
+    T* sl = scratch + 16 * bank;
+    bank ^= 1;
+    if ((threadIdx.x & 63) == 0) sl[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int step = 512; step >= 1; step >>= 1) {
-        if (tid < step) scratch[tid] = op(scratch[tid], scratch[tid + step]);
-        __syncthreads();
-    }
-    const T r = scratch[0];
-    __syncthreads();
+    T r = sl[0];
+    for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) r = op(r, sl[wv]);
     return r;
 }
 
@@ -260,13 +260,14 @@ __global__ __launch_bounds__(1024) void sweep_select_kernel(const double* __rest
         npos += (v > 0.0) ? 1 : 0;
         best = v > best ? v : best;
     }
-    const double max_val = block_reduce_1024<double>(best, dred, [](double a, double b) { return a > b ? a : b; });
+    int dbank = 0, ibank = 0;
+    const double max_val = block_reduce_1024<double>(best, dred, dbank, [](double a, double b) { return a > b ? a : b; });
     int first = 0x7fffffff;
     for (int sidx = tid; sidx < total; sidx += 1024)
         if (key[sidx] == max_val && sidx < first) first = sidx;
-    const int max_idx = block_reduce_1024<int>(first, ired, [](int a, int b) { return a < b ? a : b; });
-    const int num_pos = block_reduce_1024<int>(npos, ired, [](int a, int b) { return a + b; });
-    const int num_nan = block_reduce_1024<int>(nnan, ired, [](int a, int b) { return a + b; });
+    const int max_idx = block_reduce_1024<int>(first, ired, ibank, [](int a, int b) { return a < b ? a : b; });
+    const int num_pos = block_reduce_1024<int>(npos, ired, ibank, [](int a, int b) { return a + b; });
+    const int num_nan = block_reduce_1024<int>(nnan, ired, ibank, [](int a, int b) { return a + b; });
     if (num_nan > 0 || !(max_val > 0.0) || num_pos < n) {
         if (tid == 0) {
             *flag_dev = 1;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(1024) void sweep_select_kernel(const double* __rest
     for (int guard = 0; guard < 400; ++guard) {           // (alpha -> 0: thr -> 0 and the num_pos >= n positive values all qualify)
         int c = 0;
         for (int sidx = tid; sidx < total; sidx += 1024) c += (key[sidx] >= thr) ? 1 : 0;
-        const int cnt = block_reduce_1024<int>(c, ired, [](int a, int b) { return a + b; });
+        const int cnt = block_reduce_1024<int>(c, ired, ibank, [](int a, int b) { return a + b; });
         if (cnt >= n) break;
         alpha = 0.1 * alpha;
         thr = alpha * max_val;

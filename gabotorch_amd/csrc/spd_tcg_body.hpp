@@ -159,6 +159,152 @@ static __device__ void tcg_begin(const double* __restrict__ x, const double* __r
     }
 }
 
+// tcg_begin for D <= 8 in registers (round 6): the same quantities - L = chol(x), W = L^-1, the whitened gradient g~ = W sym(g) W^T, L^-1 1, the
+// preconditioned first direction and the scalars of the iteration - computed by EVERY lane redundantly from wave-uniform operands with compile-time
+// indices, then written to the workspace by the lanes that own an entry.  The LDS-phased form above is ~20 barrier-separated steps on 5 x 5 tiles
+// (14 k of an accepted iteration's 145 k cycles at d = 5, tools/tr_clocks.py); here the chain is the Cholesky recurrence and two small products.
+// Host-evaluated constraint gradients (gc != null: the multi-launch plans with opaque callables) are whitened by the LDS loop of tcg_begin, for
+// which W is left in lds[D^2 ...].  Not for `reuse` (the caller takes tcg_begin then: a copy, no arithmetic).  lds: 5 D^2 doubles.
+template <int D>
+static __device__ __forceinline__ void tcg_begin_reg(const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ gc,
+                                                     const double* __restrict__ fc, bool active, double delta_tr, const TcgWs& w, int64_t i,
+                                                     int64_t R, int C, int* __restrict__ status, double* lds) {
+    constexpr int T = tri_size(D);
+    constexpr int dd = D * D;
+    const int lane = threadIdx.x;
+    double a[T], wv[T], gs[T];
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<r + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            a[tri(r, c)] = 0.5 * (x[r * D + c] + x[c * D + r]);
+            gs[tri(r, c)] = 0.5 * (g[r * D + c] + g[c * D + r]);
+        });
+    });
+    bool bad = false;
+    static_for<D>([&](auto cc) {          // Cholesky (the recurrence of mandel_cholesky, spd_prep.hpp)
+        constexpr int c = decltype(cc)::value;
+        double piv = a[tri(c, c)];
+        static_for<c>([&](auto kk) { constexpr int k = decltype(kk)::value; piv = __builtin_fma(-a[tri(c, k)], a[tri(c, k)], piv); });
+        if (!(piv > 0.0)) bad = true;
+        const double inv = rsqrt_nz(piv);
+        a[tri(c, c)] = piv * inv;
+        static_for<D - c - 1>([&](auto rr) {
+            constexpr int r = c + 1 + decltype(rr)::value;
+            double sacc = a[tri(r, c)];
+            static_for<c>([&](auto kk) { constexpr int k = decltype(kk)::value; sacc = __builtin_fma(-a[tri(r, k)], a[tri(c, k)], sacc); });
+            a[tri(r, c)] = sacc * inv;
+        });
+    });
+    if (bad && lane == 0 && status) {
+        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = (int)(i + w.index_base);
+    }
+    static_for<D>([&](auto cc) { constexpr int c = decltype(cc)::value; wv[tri(c, c)] = rcp(a[tri(c, c)]); });
+    static_for<D>([&](auto cc) {          // W = L^-1 (lower_inverse, spd_prep.hpp)
+        constexpr int c = decltype(cc)::value;
+        static_for<D - c - 1>([&](auto rr) {
+            constexpr int r = c + 1 + decltype(rr)::value;
+            double sacc = 0.0;
+            static_for<r - c>([&](auto kk) { constexpr int k = c + decltype(kk)::value; sacc = __builtin_fma(a[tri(r, k)], wv[tri(k, c)], sacc); });
+            wv[tri(r, c)] = -sacc * wv[tri(r, r)];
+        });
+    });
+    // g~ = W gs W^T, lower triangle: t = W gs (full rows), g~[r][c] = sum_{k <= c} t[r][k] W[c][k]
+    double gw[T];
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        double t[D];
+        static_for<D>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            double sacc = 0.0;
+            static_for<r + 1>([&](auto mm) {
+                constexpr int m = decltype(mm)::value;
+                constexpr int hi = m > k ? m : k, lo = m > k ? k : m;
+                sacc = __builtin_fma(wv[tri(r, m)], gs[tri(hi, lo)], sacc);
+            });
+            t[k] = sacc;
+        });
+        static_for<r + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            double sacc = 0.0;
+            static_for<c + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; sacc = __builtin_fma(t[k], wv[tri(c, k)], sacc); });
+            gw[tri(r, c)] = sacc;
+        });
+    });
+    // <g~, g~>, the sum of the elements of the unwhitened L g~ L^T = (L^T 1)^T g~ (L^T 1), L^-1 1
+    double rr2 = 0.0, cs[D], ones[D];
+    static_for<D>([&](auto aa) {
+        constexpr int c = decltype(aa)::value;
+        double sacc = 0.0;
+        static_for<D - c>([&](auto kk) { constexpr int k = c + decltype(kk)::value; sacc += a[tri(k, c)]; });
+        cs[c] = sacc;
+        double o = 0.0;
+        static_for<c + 1>([&](auto kk) { o += wv[tri(c, decltype(kk)::value)]; });
+        ones[c] = o;
+    });
+    double usum = 0.0;
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int hi = r > c ? r : c, lo = r > c ? c : r;
+            const double v = gw[tri(hi, lo)];
+            rr2 = __builtin_fma(v, v, rr2);
+            usum = __builtin_fma(cs[r] * v, cs[c], usum);
+        });
+    });
+    const bool zero_sum = usum == 0.0;
+    double zr = 0.0;
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int hi = r > c ? r : c, lo = r > c ? c : r;
+            const double v = gw[tri(hi, lo)];
+            const double z = zero_sum ? v + 1e-30 * ones[r] * ones[c] : v;
+            zr = __builtin_fma(z, v, zr);
+            if (lane == r * D + c) {          // the lane that owns entry (r, c) writes it
+                w.chol[i * dd + r * D + c] = r >= c ? a[tri(hi, lo)] : 0.0;
+                w.g_w[i * dd + r * D + c] = v;
+                w.r_w[i * dd + r * D + c] = v;
+                w.eta_w[i * dd + r * D + c] = 0.0;
+                w.heta_w[i * dd + r * D + c] = 0.0;
+                w.delta_w[i * dd + r * D + c] = -z;
+                if (gc != nullptr) lds[dd + r * D + c] = r >= c ? wv[tri(hi, lo)] : 0.0;
+            }
+        });
+        if (lane == r) w.w_ones[i * D + r] = ones[r];
+    });
+    static_assert(dd <= 64, "one lane per matrix entry (D <= 8)");
+    __syncthreads();
+    for (int k = 0; gc != nullptr && k < C; ++k) {          // host-evaluated constraint gradients: the LDS loop of tcg_begin
+        double* M1 = lds + dd;
+        double* M2 = M1 + dd;
+        double* M3 = M2 + dd;
+        double* M4 = M3 + dd;
+        lds_load(gc + ((int64_t)k * R + i) * dd, M2, D);
+        lds_symmetrize(M2, M4, D);
+        lds_congruence(M1, M2, M3, M4, D);
+        lds_symmetrize(M3, M4, D);
+        for (int e = lane; e < dd; e += 64) w.gc_w[((int64_t)k * R + i) * dd + e] = M3[e];
+        __syncthreads();
+    }
+    if (lane == 0) {
+        double* sc = w.scal + i * SC_COUNT;
+        sc[SC_DELTA] = delta_tr;
+        sc[SC_E_PE] = 0.0;
+        sc[SC_E_PD] = 0.0;
+        sc[SC_D_PD] = zr;
+        sc[SC_Z_R] = zr;
+        sc[SC_MODEL] = 0.0;
+        sc[SC_NORM_R0] = __builtin_sqrt(rr2 > 0.0 ? rr2 : 0.0);
+        sc[SC_C_FD] = 0.0;
+        w.stop[i] = TCG_MAX_INNER_ITER;
+        w.running[i] = active ? 1 : 0;
+        for (int k = 0; k < C; ++k) { if (fc != nullptr) w.fc[i * C + k] = fc[i * C + k]; w.fcg_pe[i * C + k] = 0.0; }
+    }
+}
+
 // use_rand (robust_trust_regions.py:176-181, 407-452): tCG starts from a tiny random tangent vector eta0 instead of zero, with
 // Heta0 = hess(x, eta0) given by the caller, r = g + Heta0, no preconditioner (z = r), delta = -r, e_Pe = <eta0, eta0>,
 // e_Pd = <eta0, delta>, model = <eta0, g> + <eta0, Heta0> / 2.  Called after tcg_begin for the same restart (which left the factor,

@@ -56,7 +56,7 @@ static __host__ __device__ inline bool builtin_has_kind(const BuiltinCons& B, bo
     return false;
 }
 
-// extreme eigenpair of the symmetric D x D matrix at `a` (row-major, global or LDS), every lane redundantly (D <= 8)
+// eigen-decomposition of the symmetric D x D matrix at `a` (row-major, global or LDS), every lane redundantly (D <= 8)
 template <int D>
 __device__ __forceinline__ void eig_extremes(const double* __restrict__ a, double (&lam)[D], double (&v)[D * D]) {
     constexpr int T = tri_size(D);
@@ -66,6 +66,101 @@ __device__ __forceinline__ void eig_extremes(const double* __restrict__ a, doubl
         static_for<r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; m[tri(r, c)] = 0.5 * (a[r * D + c] + a[c * D + r]); });
     });
     sym_eig_reg<D>(m, lam, v);
+}
+
+// Eigenvector z (unit length) of the symmetric tridiagonal matrix (dg, e) for its eigenvalue lam by the twisted factorisation (Parlett & Dhillon;
+// LAPACK dlar1v): pivots of the LDL^T factorisation of T - lam I from the top (dp) and of the UDU^T factorisation from the bottom (dm) meet at the
+// index k where gamma_k = dp_k + dm_k - (d_k - lam) is smallest in magnitude; z_k = 1 and the two recurrences run outwards from there.  All operands
+// are wave-uniform here (every lane holds the same matrix), so the twist index is made a scalar and its D cases are scalar branches.  Zero pivots
+// are floored at 1e-3 eps of the matrix scale (an exactly decoupled block then gives the unit vector it should).
+template <int D>
+__device__ __forceinline__ void tridiag_twisted_vector(const double (&dg)[D], const double (&e)[D], double lam, double (&z)[D]) {
+    double scale = __builtin_fabs(lam);
+    static_for<D>([&](auto kk) { scale = __builtin_fmax(scale, __builtin_fabs(dg[decltype(kk)::value])); });
+    const double floor_p = __builtin_fmax(scale * 2.2e-19, 1e-290);
+    auto safe = [&](double p) { return __builtin_fabs(p) < floor_p ? copysign_d(floor_p, p) : p; };
+    double dp[D], dm[D], lp[D >= 2 ? D - 1 : 1], um[D >= 2 ? D - 1 : 1];
+    dp[0] = safe(dg[0] - lam);
+    static_for<D - 1>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        lp[i] = e[i] * rcp(dp[i]);
+        dp[i + 1] = safe((dg[i + 1] - lam) - lp[i] * e[i]);
+    });
+    dm[D - 1] = safe(dg[D - 1] - lam);
+    static_for_down<D - 2, 0>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        um[i] = e[i] * rcp(dm[i + 1]);
+        dm[i] = safe((dg[i] - lam) - um[i] * e[i]);
+    });
+    double gbest = __builtin_inf();
+    int kbest = 0;
+    static_for<D>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        const double gam = __builtin_fabs((dp[k] + dm[k]) - (dg[k] - lam));
+        const bool better = gam < gbest;
+        gbest = better ? gam : gbest;
+        kbest = better ? k : kbest;
+    });
+    kbest = __builtin_amdgcn_readfirstlane(kbest);
+    static_for<D>([&](auto kk) {
+        constexpr int K = decltype(kk)::value;
+        if (kbest == K) {
+            z[K] = 1.0;
+            static_for_down<K - 1, 0>([&](auto ii) { constexpr int i = decltype(ii)::value; z[i] = -lp[i] * z[i + 1]; });
+            static_for<D - 1 - K>([&](auto ii) { constexpr int i = K + decltype(ii)::value; z[i + 1] = -um[i] * z[i]; });
+        }
+    });
+    double nn = 0.0;
+    static_for<D>([&](auto kk) { nn = __builtin_fma(z[decltype(kk)::value], z[decltype(kk)::value], nn); });
+    const double inv = rsqrt_nz(nn);
+    static_for<D>([&](auto kk) { z[decltype(kk)::value] *= inv; });
+}
+
+// lambda_max / lambda_min of the symmetric D x D matrix at `a` and, for each that is asked for, a unit eigenvector - every lane redundantly.
+// The eigenvalues by the eigenvalue-only QL recurrence (the bits sym_eig_reg gives), ONE vector per extreme by the twisted factorisation of the
+// tridiagonal form, carried back through the Householder reflectors.  The strict variant's feasibility test uses the eigenvalues alone; for the
+// constraint gradients it is an opt-in experiment (-DGABO_BUILTIN_TWISTED, see builtin_constraints).
+template <int D>
+__device__ __forceinline__ void eig_extreme_pairs(const double* __restrict__ a, bool need_max, bool need_min, double& lmax, double& lmin,
+                                                  double (&vmax)[D], double (&vmin)[D]) {
+    constexpr int T = tri_size(D);
+    double m[T];
+    static_for<D>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        static_for<r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; m[tri(r, c)] = 0.5 * (a[r * D + c] + a[c * D + r]); });
+    });
+    double dg[D], e[D], ihh[D >= 3 ? D - 2 : 1], lam[D], sub[D], none[D];
+    tridiagonalize_reflectors<D>(m, dg, e, ihh);
+    static_for<D>([&](auto kk) {
+        lam[decltype(kk)::value] = dg[decltype(kk)::value];
+        sub[decltype(kk)::value] = e[decltype(kk)::value];
+    });
+    tridiag_ql_vectors<D, 1, false>(lam, sub, none);
+    lmax = lam[0];
+    lmin = lam[0];
+    static_for<D - 1>([&](auto kk) {
+        constexpr int c = decltype(kk)::value + 1;
+        lmax = lam[c] > lmax ? lam[c] : lmax;
+        lmin = lam[c] < lmin ? lam[c] : lmin;
+    });
+    auto back = [&](double (&z)[D]) {          // v = H_0 ... H_{D-3} z: the reflectors from the last to the first (as tridiagonalize_q builds Q)
+        static_for_down<D - 3, 0>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            constexpr int n = D - k - 1;
+            double t = 0.0;
+            static_for<n>([&](auto rr) { constexpr int r = k + 1 + decltype(rr)::value; t = __builtin_fma(m[tri(r, k)], z[r], t); });
+            t *= ihh[k];
+            static_for<n>([&](auto rr) { constexpr int r = k + 1 + decltype(rr)::value; z[r] = __builtin_fma(-m[tri(r, k)], t, z[r]); });
+        });
+    };
+    if (need_max) {
+        tridiag_twisted_vector<D>(dg, e, lmax, vmax);
+        back(vmax);
+    }
+    if (need_min) {
+        tridiag_twisted_vector<D>(dg, e, lmin, vmin);
+        back(vmin);
+    }
 }
 
 // values and WHITENED Riemannian gradients of the built-in constraints at x (L = chol x already in the workspace):
@@ -99,20 +194,41 @@ __device__ __forceinline__ void builtin_constraints(const double* __restrict__ x
         __syncthreads();
     }
     if (!builtin_has_kind(B, false)) return;
-    double lam[D], v[dd];
-    eig_extremes<D>(x, lam, v);
+    bool need_max = false, need_min = false;
+    for (int k = 0; k < B.n; ++k) {
+        need_max = need_max || B.kind[k] == 0;
+        need_min = need_min || B.kind[k] == 1;
+    }
+    double lmax, lmin, vmax[D], vmin[D];
+#ifndef GABO_BUILTIN_TWISTED      /* the full decomposition with all D vectors (rounds 3-6).  -DGABO_BUILTIN_TWISTED: eig_extreme_pairs - eigenvalue-only QL +
+                                     one twisted-factorisation vector per extreme; 15.6 k -> 13.6 k cycles in the instrumented build, 694 against 691 us for
+                                     the whole solve in the product build (tools/ab_solve_kernels.sh): not worth another numerical route */
+    {
+        double lam[D], v[dd];
+        eig_extremes<D>(x, lam, v);
+        lmax = lam[0], lmin = lam[0];
+        static_for<D>([&](auto rr) { vmax[decltype(rr)::value] = v[decltype(rr)::value * D]; vmin[decltype(rr)::value] = v[decltype(rr)::value * D]; });
+        static_for<D - 1>([&](auto kk) {
+            constexpr int c = decltype(kk)::value + 1;
+            const bool up = lam[c] > lmax, dn = lam[c] < lmin;
+            lmax = up ? lam[c] : lmax;
+            lmin = dn ? lam[c] : lmin;
+            static_for<D>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                vmax[r] = up ? v[r * D + c] : vmax[r];
+                vmin[r] = dn ? v[r * D + c] : vmin[r];
+            });
+        });
+    }
+#else
+    eig_extreme_pairs<D>(x, need_max, need_min, lmax, lmin, vmax, vmin);
+#endif
     for (int k = 0; k < B.n; ++k) {
         if (B.kind[k] >= 2) continue;
         const bool want_max = B.kind[k] == 0;
-        double best = lam[0];
+        const double best = want_max ? lmax : lmin;
         double vec[D];
-        static_for<D>([&](auto rr) { vec[decltype(rr)::value] = v[decltype(rr)::value * D]; });
-        static_for<D - 1>([&](auto kk) {
-            constexpr int c = decltype(kk)::value + 1;
-            const bool better = want_max ? (lam[c] > best) : (lam[c] < best);
-            best = better ? lam[c] : best;
-            static_for<D>([&](auto rr) { constexpr int r = decltype(rr)::value; vec[r] = better ? v[r * D + c] : vec[r]; });
-        });
+        static_for<D>([&](auto rr) { vec[decltype(rr)::value] = want_max ? vmax[decltype(rr)::value] : vmin[decltype(rr)::value]; });
         double u[D];       // L^T v
         static_for<D>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
@@ -146,14 +262,8 @@ __device__ __forceinline__ bool builtin_infeasible(const double* __restrict__ xp
         __syncthreads();
     }
     if (!builtin_has_kind(B, false)) return bad;
-    double lam[D], v[D * D];
-    eig_extremes<D>(xp, lam, v);
-    double lmax = lam[0], lmin = lam[0];
-    static_for<D - 1>([&](auto kk) {
-        constexpr int c = decltype(kk)::value + 1;
-        lmax = lam[c] > lmax ? lam[c] : lmax;
-        lmin = lam[c] < lmin ? lam[c] : lmin;
-    });
+    double lmax, lmin, vmax[D], vmin[D];
+    eig_extreme_pairs<D>(xp, false, false, lmax, lmin, vmax, vmin);          // (the eigenvalues alone: a third of the decomposition's instructions)
     for (int k = 0; k < B.n; ++k) {
         if (B.kind[k] >= 2) continue;
         const double f = B.kind[k] == 0 ? B.bound[k] - lmax : lmin - B.bound[k];
@@ -181,7 +291,16 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
     double* egfd = t.eg_fd + i * T;
     double* F = t.F + i * T * P.n;
     GABO_TICK(1);
+#ifdef GABO_TCG_BEGIN_LDS      /* A/B: the LDS-phased form everywhere (rounds 2-5) */
     tcg_begin(x, g, gc, fc, true, delta, w, i, R, D, C, status, mats, x_unchanged);
+#else
+    if constexpr (D <= 8) {
+        if (x_unchanged) tcg_begin(x, g, gc, fc, true, delta, w, i, R, D, C, status, mats, true);
+        else tcg_begin_reg<D>(x, g, gc, fc, true, delta, w, i, R, C, status, mats);
+    } else {
+        tcg_begin(x, g, gc, fc, true, delta, w, i, R, D, C, status, mats, x_unchanged);
+    }
+#endif
     __syncthreads();
     GABO_TICK(2);
     if constexpr (D <= 8) {
@@ -313,13 +432,14 @@ static __device__ __forceinline__ AcqParams stage_gp_factors(const AcqParams& P,
     if (stage_gp && P.linv && P.linv_t) {
         const int64_t nn = P.n * P.n;
         double* gl = dyn + 3 * P.n;
+        const bool one = P.linv == P.linv_t;          // the symmetric inverse handed over for both (spd_acq_body.hpp): staged once
         for (int64_t e = threadIdx.x; e < nn; e += blockDim.x) {
             gl[e] = P.linv[e];
-            gl[nn + e] = P.linv_t[e];
+            if (!one) gl[nn + e] = P.linv_t[e];
         }
         __syncthreads();
         Ps.linv = gl;
-        Ps.linv_t = gl + nn;
+        Ps.linv_t = one ? gl : gl + nn;
     }
     return Ps;
 }
@@ -440,13 +560,13 @@ static __device__ bool tr_update_body(double* __restrict__ x, double* __restrict
     return !(ngi < mingradnorm || it >= maxiter);
 }
 
-// The sweep's own start and end of a restart (gabo_spd_sweep_solve_picked, spd_sweep.hip): restart i begins at raw sample picked[i] of the scored
-// table and the kernel itself does what gen_candidates_manifold does around the solver (manifold_optimize.py:170-205) - pre_processing_manifold
-// (Mandel -> matrix), post_processing_manifold inside the cost (matrix -> Mandel), cost and Euclidean gradient at the start, [3P] egrad2rgrad and
-// norm of pymanopt's PositiveDefinite (robust_trust_regions.py:148-158), radius and counters - and, after the last iteration, the Mandel vector of
-// the final iterate.  Rounds 4-5 issued these as ten launches in front of the solve and three behind it (85 + 15 us of a 1.4-ms sweep); the
-// statements below are THOSE kernels' statements in the same order (mandel.hip, spd_acq_kernel, spd_manifold.hip OP_EGRAD2RGRAD / OP_NORM), so the
-// bits are the ones the separate launches give.
+// The sweep's own start and end of a restart (gabo_spd_sweep_solve_rows, spd_sweep.hip): restart i begins at raw sample picked[i] of the scored table and
+// the device itself does what gen_candidates_manifold does around the solver (manifold_optimize.py:170-205) - pre_processing_manifold (Mandel -> matrix),
+// post_processing_manifold inside the cost (matrix -> Mandel), cost and Euclidean gradient at the start, [3P] egrad2rgrad and norm of pymanopt's
+// PositiveDefinite (robust_trust_regions.py:148-158), radius and counters (spd_tr_start_kernel) - and, after the last iteration, the Mandel vector of the
+// final iterate (tr_finish_body, inside the solve launch).  Rounds 4-5 issued these as ten launches in front of the solve and three behind it; the
+// statements below are THOSE kernels' statements in the same order (mandel.hip, spd_acq_kernel, spd_manifold.hip OP_EGRAD2RGRAD / OP_NORM), so the bits
+// are the ones the separate launches give.
 struct TrStart {
     const double* raw_rows;     // null: the caller filled x, fx, g, ng, delta_tr, active, iters (gabo_spd_tr_solve)
     int64_t raw_stride;         // doubles per row of the table: [value, Mandel vector ...]
@@ -555,8 +675,14 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     __shared__ __attribute__((aligned(16))) double mats[5 * dd + kJacobiScratch];
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
-    const bool own_start = S.raw_rows != nullptr;            // (uniform over the launch)
-    if (!own_start && active[i] == 0) return;
+    // (the sweep's START is a launch of its own, spd_tr_start_kernel below: compiled into this kernel - one more inlined acquisition evaluation in a
+    // function that already fills 512 registers and 712 bytes of scratch per lane - it made EVERY solve 8 % slower, run or not: 756 against 699 us
+    // at 64 restarts, tools/ab_solve_kernels.sh.  The END - the result row - is a dozen stores and stays here.)
+    const bool own_finish = S.res_rows != nullptr;            // (uniform over the launch)
+    if (active[i] == 0) {
+        if (own_finish) tr_finish_body<D>(S, x + i * dd, fx[i], iters[i]);
+        return;
+    }
     const int C = B.n;
     if constexpr (LAT) {
         stage_gp = 1;
@@ -566,13 +692,14 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     if constexpr (LAT) {          // (the dispatcher has checked that the factors exist)
         const int64_t nn = P.n * P.n;
         double* gl = dyn + 3 * P.n;
+        const bool one = P.linv == P.linv_t;          // the symmetric inverse handed over for both (spd_acq_body.hpp): staged once
         for (int64_t e = threadIdx.x; e < nn; e += blockDim.x) {
             gl[e] = P.linv[e];
-            gl[nn + e] = P.linv_t[e];
+            if (!one) gl[nn + e] = P.linv_t[e];
         }
         __syncthreads();
         Ps.linv = gl;
-        Ps.linv_t = gl + nn;
+        Ps.linv_t = one ? gl : gl + nn;
     } else {
         Ps = stage_gp_factors(P, dyn, stage_gp);
     }
@@ -594,14 +721,6 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
     }
     double* xp = t.xp_mat + iw * dd;
     double* nlds = reinterpret_cast<double*>(reinterpret_cast<char*>(dyn) + nested_off);      // (used by nested constraint kinds only)
-    if (own_start) {
-        tr_start_body<D, METRIC>(S, x + i * dd, fx + i, g + i * dd, ng + i, Ps, t, iw, acq, mats, dyn, status);
-        if (threadIdx.x == 0) {
-            delta_tr[i] = S.delta0;
-            iters[i] = 0;
-        }
-        __syncthreads();
-    }
     bool cons_fresh = false;          // wave-uniform: the constraints in the workspace belong to the current x
     int last_inner = 0;               // tCG iterations of the previous trust-region iteration
     constexpr int T_ = tri_size(D);
@@ -652,7 +771,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
         cons_fresh = !accepted;
     }
     if (threadIdx.x == 0) active[i] = 0;
-    if (own_start) {
+    if (own_finish) {
         __syncthreads();
         tr_finish_body<D>(S, x + i * dd, fx[i], iters[i]);
         if (S.status_host != nullptr && threadIdx.x == 0) {          // (mirror_status of spd_acq_kernel.hpp)
@@ -662,6 +781,29 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
                 S.status_host[0] = e;
             }
         }
+    }
+}
+
+// The sweep's start of every restart as a launch of its own, in front of the solve (see the note in spd_tr_solve_kernel): one wave per restart,
+// tr_start_body with the GP factors staged in LDS like the solve; the workspace slices it uses as scratch (xp_mandel, eg_prop, F) are the
+// caller's global ones (the solve zeroes or ignores them).
+template <int D, int METRIC>
+__global__ __launch_bounds__(64) void spd_tr_start_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
+                                                          double* __restrict__ ng, double* __restrict__ delta_tr, uint8_t* __restrict__ active,
+                                                          int64_t* __restrict__ iters, AcqParams P, void* wsbase, int64_t R, int C,
+                                                          int* __restrict__ status, int stage_gp, TrStart S) {
+    constexpr int dd = D * D;
+    __shared__ AcqLds<D> acq;
+    __shared__ __attribute__((aligned(16))) double mats[5 * dd + kJacobiScratch];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int64_t i = blockIdx.x;
+    const AcqParams Ps = stage_gp_factors(P, dyn, stage_gp);
+    TrWs t = tr_layout(wsbase, R, D, C, P.n);
+    tr_start_body<D, METRIC>(S, x + i * dd, fx + i, g + i * dd, ng + i, Ps, t, i, acq, mats, dyn, status);
+    if (threadIdx.x == 0) {
+        delta_tr[i] = S.delta0;
+        iters[i] = 0;
+        active[i] = 1;
     }
 }
 
@@ -771,6 +913,12 @@ static int dispatch_solve(const SolveArgs& a) {
 #define GABO_CASE(DD)                                                                                                              \
     case DD:                                                                                                                       \
         if constexpr (DD >= DMIN && DD <= DMAX) {                                                                                  \
+            if (a.start.raw_rows != nullptr) {                                                                                     \
+                int sgp = 0;                                                                                                       \
+                const size_t slds = tr_dynamic_lds(a.P->n, a.r, &sgp);                                                             \
+                hipLaunchKernelGGL((spd_tr_start_kernel<DD, METRIC>), dim3((unsigned)a.r), dim3(64), slds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
+                                   a.active, a.iters, *a.P, a.ws, a.r, a.B.n, a.status, sgp, a.start);                             \
+            }                                                                                                                      \
             if (lat) GABO_SOLVE_LAUNCH(DD, true);                                                                                  \
             else if constexpr (solve_needs_lds_workspace(METRIC, DD)) return GABO_ERR_DIM;                                         \
             else GABO_SOLVE_LAUNCH(DD, false);                                                                                     \

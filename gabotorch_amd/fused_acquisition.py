@@ -49,6 +49,13 @@ class FusedAcquisition:
             self.linv_t = held[1]
         else:
             self.linv_t = self.linv.t().contiguous()
+        # (... and the symmetric inverse A = L^-T L^-1, which the fused SPD kernels take in place of the two factors: models.*._cache_kinv)
+        heldk = getattr(acq.model, "_cache_kinv", None)
+        self.kinv = heldk[1] if (heldk is not None and heldk[0] is getattr(acq.model, "_cache", None) and heldk[1] is not None
+                                 and heldk[1].device == self.linv.device) else None
+        import os
+        if os.environ.get("GABO_NO_KINV"):          # development A/B: the two triangular factors as in rounds 2-5
+            self.kinv = None
         self.alpha = on(alpha)
         self.train = on(train_x)
         # d <= 12: value + gradient in ONE launch per evaluation (csrc/spd_acq.hip); the training side is factored once here
@@ -180,12 +187,15 @@ class FusedAcquisition:
 
     def acq_params(self):
         """The surrogate as the gabo_spd_acq_params struct of the C ABI (single-launch path only)."""
-        return _lib.AcqParams(self.train_factors.data_ptr(), self.alpha.data_ptr(), self.linv.data_ptr(), self.linv_t.data_ptr(),
+        # (A for both factor slots when the model's cache holds it: one matrix-vector product per evaluation instead of two, csrc/spd_acq_body.hpp)
+        la, lb = (self.kinv.data_ptr(), self.kinv.data_ptr()) if self.kinv is not None else (self.linv.data_ptr(), self.linv_t.data_ptr())
+        return _lib.AcqParams(self.train_factors.data_ptr(), self.alpha.data_ptr(), la, lb,
                               self.train.shape[0], self.beta, int(self.mode) | self.metric, self.mean, self.outputscale, self.kxx, self.best_f,
                               int(self.kind), 1 if self.maximize else 0, -1.0)
 
     def _single(self, pts, need_grad, active_ptr=None, out=None):
-        return ops.spd_acq_eval(pts, self.train_factors, self.alpha, self.linv, self.linv_t, self.beta, int(self.mode) | self.metric, self.mean,
+        la, lb = (self.kinv, self.kinv) if self.kinv is not None else (self.linv, self.linv_t)
+        return ops.spd_acq_eval(pts, self.train_factors, self.alpha, la, lb, self.beta, int(self.mode) | self.metric, self.mean,
                                 self.outputscale, self.kxx, self.best_f, self.kind, self.maximize, out_sign=-1.0, need_grad=need_grad,
                                 active_ptr=active_ptr, out=out)
 

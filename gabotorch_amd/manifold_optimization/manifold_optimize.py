@@ -529,7 +529,7 @@ def _rows_state(lib, dev, stream, n_train, d, max_rows, restarts, n_constraints)
 
 def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options):
     """joint_optimize_manifold through the native driver (csrc/spd_sweep.hip): gabo_spd_sweep_score_rows -> selection on the host ->
-    gabo_spd_sweep_solve_rows -> argmax - three launches and two waits per sweep on one GPU.  The draws from numpy's and torch's generators, the
+    gabo_spd_sweep_solve_rows -> argmin - five launches per sweep on one GPU; with the selection on the device (the default) one host wait.  The draws from numpy's and torch's generators, the
     selection heuristic and every statement executed on the device are those of the Python path, so the candidate returned is the same, bit for bit
     (tests/test_gpu_native_sweep.py).
 

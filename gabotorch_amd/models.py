@@ -45,6 +45,7 @@ class ExactGP(torch.nn.Module):
                     model._cache = None
                     model._cache_linv_t = None
                     model._cache_factors = None
+                    model._cache_kinv = None
                 with torch.no_grad():
                     from .kernel_utils import kernels_spd as _ks
                     bk = self.base_kernel
@@ -52,17 +53,19 @@ class ExactGP(torch.nn.Module):
                             and self.train_x.shape[-1] <= _l.GABO_SPD_REG_MAX_DIM * (_l.GABO_SPD_REG_MAX_DIM + 1) // 2:
                         # (what bk.forward launches - the x1-is-x2 build - then the factor and the fused evaluators' training factors: one host call)
                         mode = _l.GABO_OUT_GAUSSIAN if type(bk) is _ks.SpdAffineInvariantGaussianKernel else _l.GABO_OUT_LAPLACE
-                        Linv, Linv_t, alpha, factors = _ops.spd_gp_prepare(self.train_x, self.train_y, bk.beta_float(), mode, float(self.outputscale),
-                                                                           float(self.noise), float(self.mean), on_fail=drop)
+                        Linv, Linv_t, alpha, factors, kinv = _ops.spd_gp_prepare(self.train_x, self.train_y, bk.beta_float(), mode, float(self.outputscale),
+                                                                                 float(self.noise), float(self.mean), on_fail=drop)
                         self._cache = (Linv, alpha)
                         self._cache_linv_t = (self._cache, Linv_t)
                         self._cache_factors = (self._cache, factors)
+                        self._cache_kinv = (self._cache, kinv)
                         return self._cache
                     kb = bk.forward(self.train_x, self.train_x).double()
-                    Linv, Linv_t, alpha = _ops.gp_factor(kb, self.train_y, float(self.outputscale), float(self.noise), float(self.mean), defer_check=True,
-                                                         on_fail=drop)
+                    Linv, Linv_t, alpha, kinv = _ops.gp_factor(kb, self.train_y, float(self.outputscale), float(self.noise), float(self.mean), defer_check=True,
+                                                               on_fail=drop, want_kinv=True)
                 self._cache = (Linv, alpha)
                 self._cache_linv_t = (self._cache, Linv_t)
+                self._cache_kinv = (self._cache, kinv)
                 return self._cache
             with torch.no_grad():
                 k = self.outputscale * self.base_kernel.forward(self.train_x, self.train_x)
@@ -505,9 +508,12 @@ class SingleTaskGP(torch.nn.Module):
             def drop(model=self):
                 model._cache = None
                 model._cache_linv_t = None
-            Linv, Linv_t, alpha = _ops.gp_factor(kb.double(), self.train_y, outputscale, float(self.noise.detach()), float(mu), defer_check=True, on_fail=drop)
+                model._cache_kinv = None
+            Linv, Linv_t, alpha, kinv = _ops.gp_factor(kb.double(), self.train_y, outputscale, float(self.noise.detach()), float(mu), defer_check=True,
+                                                       on_fail=drop, want_kinv=True)
         self._cache = (Linv, alpha, mu)
         self._cache_linv_t = (self._cache, Linv_t)
+        self._cache_kinv = (self._cache, kinv)
 
     def posterior(self, X):
         if X.dim() == 2:

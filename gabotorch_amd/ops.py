@@ -1217,7 +1217,7 @@ def gp_acquisition(kstar, alpha, linv, linv_t, mean, outputscale, kxx, best_f, k
 _GP_FACTOR_MESSAGE = "gabo_gp_factor: the training covariance outputscale * K + noise * I is not positive definite (Cholesky pivot <= 0)"
 
 
-def gp_factor(kbase, y, outputscale, noise, mean, defer_check=False, on_fail=None):
+def gp_factor(kbase, y, outputscale, noise, mean, defer_check=False, on_fail=None, want_kinv=False):
     """Prediction cache of the exact GP in one launch (gabo_gp_factor): kbase n x n BASE kernel matrix of the training set, y its targets ->
     (L^-1, L^-T, alpha) with L = chol(outputscale kbase + noise I), alpha = (outputscale kbase + noise I)^-1 (y - mean); n <= GABO_GP_FACTOR_MAX_N.
     Raises like torch.linalg.cholesky when the matrix is not positive definite - at once, or (defer_check=True) at the next check_deferred();
@@ -1230,10 +1230,11 @@ def gp_factor(kbase, y, outputscale, noise, mean, defer_check=False, on_fail=Non
     linv = torch.empty(n, n, dtype=torch.float64, device=dev)
     linv_t = torch.empty(n, n, dtype=torch.float64, device=dev)
     alpha = torch.empty(n, dtype=torch.float64, device=dev)
+    kinv = torch.empty(n, n, dtype=torch.float64, device=dev) if want_kinv else None
     status = _status_word(dev, force=True)
     with _on(dev):
         rc = lib.gabo_gp_factor(kb.data_ptr(), yy.data_ptr(), n, float(outputscale), float(noise), float(mean), linv.data_ptr(), linv_t.data_ptr(),
-                                alpha.data_ptr(), status.data_ptr(), _stream_ptr(dev))
+                                alpha.data_ptr(), None if kinv is None else kinv.data_ptr(), status.data_ptr(), _stream_ptr(dev))
     _lib.check(rc, "gabo_gp_factor")
     # The status is read back whatever set_error_checking says (torch.linalg.cholesky would raise here too, and a silent garbage factor would
     # poison every acquisition value) - but not HERE: the read-back would park the host behind the launch (~0.1 ms of a 4-ms sweep) while it
@@ -1242,6 +1243,8 @@ def gp_factor(kbase, y, outputscale, noise, mean, defer_check=False, on_fail=Non
     _raise_if_not_spd(status, "gabo_gp_factor", message=_GP_FACTOR_MESSAGE, on_fail=on_fail, force=True)
     if defer_check is False:
         check_deferred()
+    if want_kinv:          # (+ the symmetric inverse L^-T L^-1: what the fused SPD acquisition kernels take in place of the two factors)
+        return linv, linv_t, alpha, kinv
     return linv, linv_t, alpha
 
 
@@ -1250,7 +1253,8 @@ _gp_prepare_ws = {}
 
 def spd_gp_prepare(train_mandel, y, beta, mode, outputscale, noise, mean, want_factors=True, on_fail=None):
     """Everything an acquisition sweep needs from a fitted exact GP with an affine-invariant kernel, from ONE host call (gabo_spd_gp_prepare):
-    the training Gram matrix, (L^-1, L^-T, alpha) of gp_factor and the entry-major training factors of spd_acq_prepare_train (d_vec x n, or None).
+    the training Gram matrix, (L^-1, L^-T, alpha) of gp_factor, the entry-major training factors of spd_acq_prepare_train (d_vec x n, or None) and
+    the symmetric inverse A = L^-T L^-1 -> (linv, linv_t, alpha, factors, kinv).
     The Cholesky status is checked at the next check_deferred() (as gp_factor(defer_check=True)); on_fail as there."""
     lib = _lib.load()
     dev = train_mandel.device
@@ -1260,9 +1264,9 @@ def spd_gp_prepare(train_mandel, y, beta, mode, outputscale, noise, mean, want_f
         raise TypeError("spd_gp_prepare: train_mandel must be an n x d_vec fp64 tensor on a HIP device and y its n targets")
     n, dv = x.shape
     d = _mandel_dim(dv)
-    # one allocation for the outputs: [L^-1 | L^-T | alpha | factors]
+    # one allocation for the outputs: [L^-1 | L^-T | alpha | A = L^-T L^-1 | factors]
     nn = n * n
-    flat = torch.empty(2 * nn + n + (dv * n if want_factors else 0), dtype=torch.float64, device=dev)
+    flat = torch.empty(3 * nn + n + (dv * n if want_factors else 0), dtype=torch.float64, device=dev)
     base = flat.data_ptr()
     stream = _stream_ptr(dev)
     key = (dev.index, stream, n, d)
@@ -1276,13 +1280,14 @@ def spd_gp_prepare(train_mandel, y, beta, mode, outputscale, noise, mean, want_f
     status, fstatus = _status_word(dev), _status_word(dev, force=True)
     with _on(dev):
         rc = lib.gabo_spd_gp_prepare(x.data_ptr(), yy.data_ptr(), n, d, beta, mode, outputscale, noise, mean, base, base + 8 * nn, base + 16 * nn,
-                                     base + 8 * (2 * nn + n) if want_factors else None, ws.data_ptr(), wsb, status.data_ptr(), fstatus.data_ptr(),
-                                     stream)
+                                     base + 8 * (2 * nn + n), base + 8 * (3 * nn + n) if want_factors else None, ws.data_ptr(), wsb,
+                                     status.data_ptr(), fstatus.data_ptr(), stream)
     _check_launch(rc, status, "gabo_spd_gp_prepare", on_fail=on_fail)
     _raise_if_not_spd(fstatus, "gabo_gp_factor", message=_GP_FACTOR_MESSAGE, on_fail=on_fail, force=True)
     linv, linv_t, alpha = flat[:nn].view(n, n), flat[nn:2 * nn].view(n, n), flat[2 * nn:2 * nn + n]
-    factors = flat[2 * nn + n:].view(dv, n) if want_factors else None
-    return linv, linv_t, alpha, factors
+    kinv = flat[2 * nn + n:3 * nn + n].view(n, n)
+    factors = flat[3 * nn + n:].view(dv, n) if want_factors else None
+    return linv, linv_t, alpha, factors, kinv
 
 
 _mll_large_ws = {}

@@ -247,10 +247,14 @@ int gabo_gp_acquisition(const double* kstar, const double* alpha, const double* 
  * alpha = (outputscale * k + noise * I)^-1 (y - mean).  Replaces the Cholesky / cholesky_solve / triangular solve a fitted [3P] gpytorch
  * ExactGP runs when it is first asked for a posterior (behind manifold_optimize.py:182-184).  One workgroup, both factors in LDS:
  * n <= GABO_GP_FACTOR_MAX_N (GABO_ERR_DIM beyond: factor with a library call instead).  status = {GABO_ERR_NOT_SPD, 0} when a pivot is
- * not positive (outputs then unspecified). */
+ * not positive (outputs then unspecified).
+ * kinv (may be NULL): the symmetric inverse (outputscale * k + noise * I)^-1 = L^-T L^-1, n x n.  The fused SPD acquisition kernels
+ * (gabo_spd_acq_eval and everything built on it) accept it IN PLACE OF the two factors - pass the same pointer as linv and linv_t: the posterior
+ * variance k** - ks^T A ks and its gradient -2 A ks then cost one n-term product per training point instead of two triangular ones.
+ * gabo_gp_acquisition takes the factors. */
 #define GABO_GP_FACTOR_MAX_N 96
 int gabo_gp_factor(const double* k, const double* y, int64_t n, double outputscale, double noise, double mean, double* linv,
-                   double* linv_t, double* alpha, int* status, gabo_stream_t stream);
+                   double* linv_t, double* alpha, double* kinv, int* status, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Exact-GP marginal log likelihood and its analytic gradient, one launch per evaluation of the surrogate fit
@@ -507,7 +511,7 @@ typedef struct {
  * gabo_spd_gp_prepare: everything the sweep needs from a fitted exact GP with an affine-invariant kernel, from ONE host call - the Gram matrix
  *   K(X, X) of the training set (SpdAffineInvariant{Gaussian,Laplace}Kernel.forward, kernels_spd.py:72-100,157-187; `flags` = GABO_OUT_GAUSSIAN /
  *   GABO_OUT_LAPLACE), the prediction cache gabo_gp_factor computes from it ([3P] gpytorch's prediction strategy behind manifold_optimize.py:182-184)
- *   and, train_factors != NULL, gabo_spd_acq_prepare_train's factors (d_vec x n).  status: a training matrix that is not SPD; factor_status: a
+ *   (kinv != NULL: its symmetric inverse too) and, train_factors != NULL, gabo_spd_acq_prepare_train's factors (d_vec x n).  status: a training matrix that is not SPD; factor_status: a
  *   covariance that is not positive definite (both device int[2], zeroed by the caller).  n <= GABO_GP_FACTOR_MAX_N, d <= GABO_SPD_REG_MAX_DIM.
  *
  * The sweep keeps two tables in its workspace (gabo_spd_sweep_rows_tables returns their device addresses):
@@ -520,9 +524,9 @@ typedef struct {
  *     sharded sweep fills its own block), scored (gen_batch_initial_conditions_manifold, manifold_optimize.py:288-309).
  *     values_mapped (may be NULL): count doubles the KERNEL writes the values to as well - memory the device can address: page-locked host memory
  *     (hipHostMalloc, torch's pinned allocator) or device memory; pageable host memory is refused (GABO_ERR_ARG).
- *   gabo_spd_sweep_solve_rows: ONE launch for gen_candidates_manifold (manifold_optimize.py:124-228) on the restarts that start from rows
- *     picked_mapped[0 ... restarts - 1] (device-addressable like values_mapped): the two Mandel maps, cost, gradient, [3P] egrad2rgrad / norm at the
- *     start, the whole trust-region solve (gabo_spd_tr_solve's kernel), the result row.  results_mapped (may be NULL): restarts x (2 + d_vec) doubles
+ *   gabo_spd_sweep_solve_rows: two launches for gen_candidates_manifold (manifold_optimize.py:124-228) on the restarts that start from rows
+ *     picked_mapped[0 ... restarts - 1] (device-addressable like values_mapped): the start of every restart (the two Mandel maps, cost, gradient,
+ *     [3P] egrad2rgrad / norm), then the whole trust-region solve (gabo_spd_tr_solve's kernel), which ends with the result row.  results_mapped (may be NULL): restarts x (2 + d_vec) doubles
  *     of device-addressable memory that receive the result rows as well.  get_best_candidates (:118-120) is an argmax over column 0 of the result rows:
  *     the caller's, after its all_gather if there is one.
  *   status: device int[2] as everywhere (zeroed by the caller); status_mapped (may be NULL): int[2] of device-addressable host memory, zeroed by
@@ -532,8 +536,8 @@ typedef struct {
  * The numbers are those of this package's Python path (the same device statements in the same order), bit for bit. */
 size_t gabo_spd_gp_prepare_workspace_bytes(int64_t n, int d);
 int gabo_spd_gp_prepare(const double* train_mandel, const double* y, int64_t n, int d, double beta, int flags, double outputscale, double noise,
-                        double mean, double* linv, double* linv_t, double* alpha, double* train_factors, void* workspace, size_t workspace_bytes,
-                        int* status, int* factor_status, gabo_stream_t stream);
+                        double mean, double* linv, double* linv_t, double* alpha, double* kinv, double* train_factors, void* workspace,
+                        size_t workspace_bytes, int* status, int* factor_status, gabo_stream_t stream);
 size_t gabo_spd_sweep_rows_workspace_bytes(int64_t n_train, int d, int64_t max_raw, int64_t restarts, int n_constraints);
 int gabo_spd_sweep_rows_tables(void* workspace, int64_t n_train, int d, int64_t max_raw, int64_t restarts, int n_constraints, double** raw_rows,
                                double** result_rows);

@@ -762,8 +762,12 @@ def test_gp_factor_matches_lapack(n):
     kb = np.exp(-0.7 * ((z[:, None] - z[None]) ** 2).sum(-1))
     y = rng.standard_normal(n)
     os_, noise, mean = 1.7, 1e-2, 0.3
-    linv, linv_t, alpha = ops.gp_factor(torch.tensor(kb, device="cuda:0"), torch.tensor(y, device="cuda:0"), os_, noise, mean)
+    linv, linv_t, alpha, kinv = ops.gp_factor(torch.tensor(kb, device="cuda:0"), torch.tensor(y, device="cuda:0"), os_, noise, mean, want_kinv=True)
     K = os_ * kb + noise * np.eye(n)
+    # the symmetric inverse the fused SPD acquisition kernels take in place of the two factors: exactly symmetric, = K^-1
+    ki = kinv.cpu().numpy()
+    np.testing.assert_array_equal(ki, ki.T)
+    np.testing.assert_allclose(ki, np.linalg.inv(K), rtol=0, atol=1e-9 * np.abs(ki).max())
     L = np.linalg.cholesky(K)
     want = np.linalg.inv(L)
     scale = np.abs(want).max()
