@@ -216,6 +216,14 @@ def test_fused_spd_acquisition_matches_autograd(which):
     atol = 1e-7 if which.startswith("laplace") else 1e-11
     np.testing.assert_allclose(g.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-8, atol=atol * scale)
     np.testing.assert_allclose(fused.cost(x).cpu().numpy(), f.cpu().numpy(), rtol=0, atol=0)
+    # the single launch was handed the symmetric inverse A = L^-T L^-1 in place of the two factors (round 6: one product per training point
+    # instead of two); with the factors themselves it computes the same posterior
+    assert fused.kinv is not None
+    held, fused.kinv = fused.kinv, None
+    f_lt, g_lt = fused.cost_egrad(x)
+    fused.kinv = held
+    np.testing.assert_allclose(f_lt.cpu().numpy(), f.cpu().numpy(), rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(g_lt.cpu().numpy(), g.cpu().numpy(), rtol=1e-9, atol=1e-12 * scale)
     # the separate-launch chain (strip -> gabo_gp_acquisition -> kernel backward) serves d > 12; same numbers
     fused.single_launch = False
     f2, g2 = fused.cost_egrad(x)
