@@ -272,24 +272,12 @@ __device__ __forceinline__ bool builtin_infeasible(const double* __restrict__ xp
     return bad;
 }
 
-// tCG + proposal + acquisition at the proposal for restart i (one wave).  gc/fc: host-evaluated constraints, or null with
-// `builtin` set (then the wave evaluates them itself).  mats: 5 D^2 + kJacobiScratch doubles of LDS, dyn: 3 n doubles.
-// Returns the number of tCG iterations it ran.  x_unchanged: the previous call for this restart (same launch) ended in a rejected proposal;
-// fd0_kept: ... and ran exactly ONE tCG iteration, so the first FD point's E = expm(c delta~) and c are still in the workspace.
-template <int D, int METRIC>
-__device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta,
-                                                const double* __restrict__ gc, const double* __restrict__ fc, const AcqParams& P,
-                                                const TrWs& t, double* __restrict__ x_prop, int64_t i, int64_t R, int C, int neq,
-                                                double delta_cons, double theta, double kappa, int mininner, int maxinner,
-                                                AcqLds<D>& acq, double* mats, double* dyn, int* __restrict__ status,
-                                                const BuiltinCons* builtin, bool x_unchanged = false, bool fd0_kept = false,
-                                                double* nlds = nullptr, bool value_only = false, double* step_cache = nullptr) {
-    constexpr int T = tri_size(D);
-    constexpr int dd = D * D;
+// First part of a trust-region iteration for restart i: the state of truncated CG at x (tcg_begin) and the built-in constraints there.
+template <int D>
+__device__ __forceinline__ void tr_begin_part(const double* __restrict__ x, const double* __restrict__ g, double delta, const double* __restrict__ gc,
+                                              const double* __restrict__ fc, const TrWs& t, int64_t i, int64_t R, int C, double* mats,
+                                              int* __restrict__ status, const BuiltinCons* builtin, bool x_unchanged, double* nlds) {
     const TcgWs& w = t.tcg;
-    double* xfd = t.x_fd + i * T;
-    double* egfd = t.eg_fd + i * T;
-    double* F = t.F + i * T * P.n;
     GABO_TICK(1);
 #ifdef GABO_TCG_BEGIN_LDS      /* A/B: the LDS-phased form everywhere (rounds 2-5) */
     tcg_begin(x, g, gc, fc, true, delta, w, i, R, D, C, status, mats, x_unchanged);
@@ -311,29 +299,16 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
             __syncthreads();
         }
     }
-    double* egfd0 = t.eg_fd0 + i * T;
-    GABO_TICK(3);
-    int inner = 0;
-    for (int it = 0; it < maxinner; ++it) {
-        ++inner;
-        // (same x, g, preconditioner => same first direction, same FD point: when nothing has overwritten E and c since, skip it - the
-        // acquisition gradient there is kept too, below)
-        if (!(it == 0 && x_unchanged && fd0_kept)) tcg_fd_point(w, i, D, xfd, mats);
-        __syncthreads();
-        GABO_TICK(4);
-        // tCG restarts from eta = 0 with the same x, g and preconditioner after a rejected proposal (only the radius changed), so its
-        // first direction, first FD point and the acquisition gradient there are bit for bit those of the previous iteration: keep
-        // that gradient instead of evaluating the acquisition again (a restart that sits on a bound does one tCG step per
-        // iteration - this is half of its acquisition evaluations)
-        double* eg_it = (it == 0) ? egfd0 : egfd;
-        if (!(it == 0 && x_unchanged)) acq_eval_any<D, METRIC>(xfd, P, t.val_fd + i, eg_it, F, acq, dyn, status, i + w.index_base);
-        __syncthreads();
-        GABO_TICK(5);
-        const bool running = tcg_step(w, i, R, D, C, eg_it, neq, delta_cons, theta, kappa, mininner, it, mats);
-        __syncthreads();
-        GABO_TICK(6);
-        if (!running) break;
-    }
+}
+
+// Last part before the evaluation at the proposal: x+ = L expm(eta~) L^T, its Mandel vector, the model decrease.  Returns true when the step is the
+// previous one again (see below): nothing was rebuilt, the previous proposal and its value stand.
+template <int D>
+__device__ __forceinline__ bool tr_build_proposal(const TrWs& t, double* __restrict__ x_prop, int64_t i, bool x_unchanged, double* step_cache,
+                                                  double* mats) {
+    constexpr int T = tri_size(D);
+    constexpr int dd = D * D;
+    const TcgWs& w = t.tcg;
     // ---- proposal x+ = L expm(eta~) L^T and the model decrease -<g, eta> - 1/2 <eta, H eta> (whitened Frobenius dots)
     double* M0 = mats;
     double* M1 = M0 + dd;
@@ -368,9 +343,7 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
         if (threadIdx.x == 0) step_cache[T] = 1.0;
         if (same) {
             __syncthreads();
-            GABO_TICK(7);
-            GABO_TICK(8);
-            return inner;
+            return true;
         }
     }
     lds_load(w.chol + i * dd, M0, D);
@@ -415,6 +388,56 @@ __device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, con
         xpm[e] = (k == 0) ? M1[r * D + cc] : kSqrt2 * M1[r * D + cc];
     }
     __syncthreads();
+    return false;
+}
+
+// tCG + proposal + acquisition at the proposal for restart i (one wave).  gc/fc: host-evaluated constraints, or null with
+// `builtin` set (then the wave evaluates them itself).  mats: 5 D^2 + kJacobiScratch doubles of LDS, dyn: 3 n doubles.
+// Returns the number of tCG iterations it ran.  x_unchanged: the previous call for this restart (same launch) ended in a rejected proposal;
+// fd0_kept: ... and ran exactly ONE tCG iteration, so the first FD point's E = expm(c delta~) and c are still in the workspace.
+template <int D, int METRIC>
+__device__ __forceinline__ int tr_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta,
+                                                const double* __restrict__ gc, const double* __restrict__ fc, const AcqParams& P,
+                                                const TrWs& t, double* __restrict__ x_prop, int64_t i, int64_t R, int C, int neq,
+                                                double delta_cons, double theta, double kappa, int mininner, int maxinner,
+                                                AcqLds<D>& acq, double* mats, double* dyn, int* __restrict__ status,
+                                                const BuiltinCons* builtin, bool x_unchanged = false, bool fd0_kept = false,
+                                                double* nlds = nullptr, bool value_only = false, double* step_cache = nullptr) {
+    constexpr int T = tri_size(D);
+    const TcgWs& w = t.tcg;
+    double* xfd = t.x_fd + i * T;
+    double* egfd = t.eg_fd + i * T;
+    double* F = t.F + i * T * P.n;
+    tr_begin_part<D>(x, g, delta, gc, fc, t, i, R, C, mats, status, builtin, x_unchanged, nlds);
+    double* egfd0 = t.eg_fd0 + i * T;
+    GABO_TICK(3);
+    int inner = 0;
+    for (int it = 0; it < maxinner; ++it) {
+        ++inner;
+        // (same x, g, preconditioner => same first direction, same FD point: when nothing has overwritten E and c since, skip it - the
+        // acquisition gradient there is kept too, below)
+        if (!(it == 0 && x_unchanged && fd0_kept)) tcg_fd_point(w, i, D, xfd, mats);
+        __syncthreads();
+        GABO_TICK(4);
+        // tCG restarts from eta = 0 with the same x, g and preconditioner after a rejected proposal (only the radius changed), so its
+        // first direction, first FD point and the acquisition gradient there are bit for bit those of the previous iteration: keep
+        // that gradient instead of evaluating the acquisition again (a restart that sits on a bound does one tCG step per
+        // iteration - this is half of its acquisition evaluations)
+        double* eg_it = (it == 0) ? egfd0 : egfd;
+        if (!(it == 0 && x_unchanged)) acq_eval_any<D, METRIC>(xfd, P, t.val_fd + i, eg_it, F, acq, dyn, status, i + w.index_base);
+        __syncthreads();
+        GABO_TICK(5);
+        const bool running = tcg_step(w, i, R, D, C, eg_it, neq, delta_cons, theta, kappa, mininner, it, mats);
+        __syncthreads();
+        GABO_TICK(6);
+        if (!running) break;
+    }
+    if (tr_build_proposal<D>(t, x_prop, i, x_unchanged, step_cache, mats)) {
+        GABO_TICK(7);
+        GABO_TICK(8);
+        return inner;
+    }
+    double* xpm = t.xp_mandel + i * T;
     GABO_TICK(7);
     // value_only: the acquisition VALUE at the proposal now, its gradient only if the proposal is accepted (tr_solve: a restart that has just
     // had a proposal rejected will most likely have the next one rejected too, and a rejected proposal's gradient is never looked at)
@@ -745,6 +768,7 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
 #else
         const bool lazy = cons_fresh && shortcuts != 0;
 #endif
+#ifndef GABO_TR_SINGLE_SITE     /* the iteration as tr_propose_body (two inlined acquisition evaluations) + a third evaluation here */
         last_inner = tr_propose_body<D, METRIC>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, Ps, t, xp, iw, Rw, C, 0, delta_cons, theta,
                                                 kappa, mininner, maxinner, acq, mats, dyn, status, &B, cons_fresh, last_inner == 1, nlds, lazy, step_cache);
         __syncthreads();
@@ -763,6 +787,83 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
                                     iw + t.tcg.index_base);
             __syncthreads();
         }
+#else
+        // An experiment of round 6 (-DGABO_TR_SINGLE_SITE; bit-identical results, 720 against 700 us for the solve at 64 restarts: not the default).
+        // The same iteration with ONE call site of the acquisition evaluation: the evaluations of an iteration - at the FD point of every tCG step,
+        // at the proposal, again at the proposal for its gradient once it is known to be accepted - are trips of one loop whose body is "prepare the
+        // next evaluation, evaluate, consume".  acq_eval is inlined wherever it is called, and this kernel sits on a register cliff (512 registers,
+        // 712 B of scratch per lane): every copy moves the whole kernel (a fourth one, the sweep's start, cost 8 %: see above).  Same statements in
+        // the same order as tr_propose_body + the block above: same bits.
+        bool inval = false;
+        {
+            const bool x_unchanged = cons_fresh, fd0_kept = last_inner == 1;
+            const TcgWs& w = t.tcg;
+            double* xfd = t.x_fd + iw * T_;
+            double* egfd = t.eg_fd + iw * T_;
+            double* egfd0 = t.eg_fd0 + iw * T_;
+            double* Fw = t.F + iw * T_ * Ps.n;
+            double* xpm = t.xp_mandel + iw * T_;
+            tr_begin_part<D>(x + i * dd, g + i * dd, delta_tr[i], nullptr, nullptr, t, iw, Rw, C, mats, status, &B, x_unchanged, nlds);
+            GABO_TICK(3);
+            enum { PH_FD = 0, PH_PROP = 1, PH_REGRAD = 2 };
+            int phase = PH_FD, it = 0, inner = 0;
+            double* eg_it = egfd0;
+            for (;;) {
+                const double* ex = xfd;
+                double* ev = t.val_fd + iw;
+                double* eg = eg_it;
+                bool do_eval = true;
+                if (phase == PH_FD) {
+                    ++inner;
+                    if (!(it == 0 && x_unchanged && fd0_kept)) tcg_fd_point(w, iw, D, xfd, mats);
+                    __syncthreads();
+                    GABO_TICK(4);
+                    eg_it = (it == 0) ? egfd0 : egfd;
+                    eg = eg_it;
+                    do_eval = !(it == 0 && x_unchanged);
+                } else if (phase == PH_PROP) {
+                    do_eval = !tr_build_proposal<D>(t, xp, iw, x_unchanged, step_cache, mats);
+                    GABO_TICK(7);
+                    ex = xpm;
+                    ev = t.fx_prop + iw;
+                    eg = lazy ? nullptr : t.eg_prop + iw * T_;
+                } else {
+                    ex = xpm;
+                    ev = t.fx_prop + iw;
+                    eg = t.eg_prop + iw * T_;
+                }
+                if (do_eval) acq_eval_any<D, METRIC>(ex, Ps, ev, eg, Fw, acq, dyn, status, iw + w.index_base);
+                if (phase == PH_FD) {
+                    __syncthreads();
+                    GABO_TICK(5);
+                    const bool running = tcg_step(w, iw, Rw, D, C, eg_it, 0, delta_cons, theta, kappa, mininner, it, mats);
+                    __syncthreads();
+                    GABO_TICK(6);
+                    ++it;
+                    if (!running || it >= maxinner) phase = PH_PROP;
+                } else if (phase == PH_PROP) {
+                    GABO_TICK(8);
+                    __syncthreads();
+                    if (rec != nullptr && rec_k < rec_cap) {          // (the iterate, its radius and the stop reason of the tCG run that made the proposal)
+                        double* rr = rec + (rec_k * R + i) * (dd + 2);
+                        for (int e = threadIdx.x; e < dd; e += 64) rr[e] = x[i * dd + e];
+                        if (threadIdx.x == 0) {
+                            rr[dd] = delta_tr[i];
+                            rr[dd + 1] = (double)w.stop[iw];
+                        }
+                    }
+                    ++rec_k;
+                    inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B, nlds) : false;
+                    if (lazy && tr_would_accept(fx[i], t.fx_prop[iw], t.rhoden[iw], inval, rho_prime, rho_regularization)) phase = PH_REGRAD;
+                    else break;
+                } else {
+                    __syncthreads();
+                    break;
+                }
+            }
+            last_inner = inner;
+        }
+#endif
         bool accepted = false;
         const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, iw, D, C, delta_bar,
                                           rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);

@@ -15,4 +15,4 @@ for R in [int(a) for a in sys.argv[2:]] or [64, 512]:
     it = log["per_restart_iterations"].numpy()
     srt = np.sort(it)[::-1]
     print(f"[{tag}] R={R}: median {np.median(ts) * 1e3:.3f} ms (min {min(ts) * 1e3:.3f}); EI* {val:.15e}; iterations: max {it.max()}, at maxiter {int((it >= 100).sum())}, "
-          f"largest below maxiter {srt[srt < 100][:5].tolist()}, mean {it.mean():.2f}")
+          f"largest below maxiter {srt[srt < 100][:5].tolist()}, mean {it.mean():.2f}; sum of final costs {float(log['final_cost'].sum()):.17e}, sum of iterations {int(it.sum())}")
