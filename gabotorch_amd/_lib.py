@@ -136,7 +136,7 @@ SIGNATURES = {
     "gabo_spd_sweep_score_rows": (_I, [_P, _I64, _I64, _I64, _I64, _I64, _c.c_uint64, _P, _P, _P, _SZ, _P, _P, _I, _P]),
     "gabo_spd_sweep_select_supported": (_I, [_I64, _I64]),
     "gabo_spd_sweep_select_rows": (_I, [_P, _I, _I64, _I64, _I64, _D, _D, _c.c_uint64, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "gabo_spd_sweep_solve_rows": (_I, [_P, _P, _I64, _I64, _P, _P, _SZ, _P, _P, _I, _P]),
+    "gabo_spd_sweep_solve_rows": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _SZ, _P, _P, _I, _P]),
     "gabo_spd_tr_solve": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _SZ, _I64, _I, _D, _D, _D, _I, _I, _D, _D, _D, _D, _I64,
                                _P, _P, _P, _I, _P, _P]),
     "gabo_spd_matfun_backward": (_I, [_I, _P, _P, _P, _I64, _I, _P]),

@@ -366,8 +366,8 @@ extern "C" int gabo_spd_sweep_select_rows(const double* raw_rows, int d, int64_t
 }
 
 extern "C" int gabo_spd_sweep_solve_rows(const gabo_spd_sweep_config* cfg, const int64_t* picked_mapped, int64_t restarts, int64_t max_raw,
-                                         double* results_mapped, void* workspace, size_t workspace_bytes, int* status, int* status_mapped,
-                                         int synchronize, gabo_stream_t stream) {
+                                         double* results_mapped, const int* skip_flag, void* workspace, size_t workspace_bytes, int* status,
+                                         int* status_mapped, int synchronize, gabo_stream_t stream) {
     if (!cfg || !picked_mapped || !workspace || !status || restarts < 1 || restarts > 0x7fffffffLL) return GABO_ERR_ARG;
     const int d = cfg->d, c = cfg->n_constraints;
     if (d < 2 || d > 8 || c < 0 || c > GABO_SWEEP_MAX_CONSTRAINTS) return GABO_ERR_DIM;
@@ -408,7 +408,7 @@ extern "C" int gabo_spd_sweep_solve_rows(const gabo_spd_sweep_config* cfg, const
     if (gabo::tr_solve_uses_global_workspace(acq, r, d, c, 0) && hipMemsetAsync(w.tr, 0, w.tr_bytes, st) != hipSuccess) return GABO_ERR_LAUNCH;
     gabo::SolveArgs sa{w.x, w.fx, w.g, w.ng, w.delta, w.active, w.iters, &acq, B, w.tr, r, d, cfg->delta_cons, cfg->theta, cfg->kappa, cfg->mininner,
                        cfg->maxinner, cfg->delta_bar, cfg->rho_prime, cfg->rho_regularization, cfg->mingradnorm, cfg->maxiter, status, st};
-    sa.start = gabo::TrStart{w.raw_rows, 1 + (int64_t)d * (d + 1) / 2, picked, cfg->delta0, w.res_rows, res_host, smirror};
+    sa.start = gabo::TrStart{w.raw_rows, 1 + (int64_t)d * (d + 1) / 2, picked, cfg->delta0, w.res_rows, res_host, smirror, skip_flag};
     int rc;
     if ((rc = gabo::tr_solve_dispatch(sa)) != GABO_OK) return rc;
     if (synchronize && hipStreamSynchronize(st) != hipSuccess) return GABO_ERR_LAUNCH;

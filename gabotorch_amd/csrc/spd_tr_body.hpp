@@ -598,6 +598,8 @@ struct TrStart {
     double* res_rows;           // restarts x (2 + T): final cost, iterations, final iterate as a Mandel vector
     double* res_host;           // the same rows in mapped host memory, or null
     int* status_host;           // mapped host copy of an error this launch reports, or null
+    const int* skip_flag;       // device int, or null: non-zero = the selection in front of this launch picked nothing (it raised its fall-back flag):
+                                // the start marks every restart inactive and the solve returns at once
 };
 
 template <int D, int METRIC>
@@ -898,6 +900,14 @@ __global__ __launch_bounds__(64) void spd_tr_start_kernel(double* __restrict__ x
     __shared__ __attribute__((aligned(16))) double mats[5 * dd + kJacobiScratch];
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
+    if (S.skip_flag != nullptr && *S.skip_flag != 0) {          // (uniform over the launch)
+        if (threadIdx.x == 0) {
+            active[i] = 0;
+            iters[i] = 0;
+            fx[i] = __builtin_nan("");
+        }
+        return;
+    }
     const AcqParams Ps = stage_gp_factors(P, dyn, stage_gp);
     TrWs t = tr_layout(wsbase, R, D, C, P.n);
     tr_start_body<D, METRIC>(S, x + i * dd, fx + i, g + i * dd, ng + i, Ps, t, i, acq, mats, dyn, status);
@@ -971,7 +981,7 @@ struct SolveArgs {
     double* rec = nullptr;  // gabo_tr_solve_record: per-iteration record of this call, or null
     int64_t rec_cap = 0;
     int shortcuts = 1;      // 0: every iteration computes its proposal and the full evaluation (the environment variable GABO_TR_NO_SHORTCUTS: tests)
-    TrStart start = {nullptr, 0, nullptr, 0.0, nullptr, nullptr, nullptr};      // the sweep driver's start / end inside the launch (spd_sweep.hip)
+    TrStart start = {nullptr, 0, nullptr, 0.0, nullptr, nullptr, nullptr, nullptr};      // the sweep driver's start / end inside the launch (spd_sweep.hip)
 };
 
 // Round 5 history of two instantiations (tools/soak_tr.py found them; tools/repro_solve_fault.py walks the whole table): with the

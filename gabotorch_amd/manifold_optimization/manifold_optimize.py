@@ -644,7 +644,8 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
             st.res[r_loc:, 0] = float("inf")             # (a rank with one restart fewer: its padding row loses every argmax)
         if r_loc:
             rc = lib.gabo_spd_sweep_solve_rows(cfg_ref, st.picked_dev.data_ptr() if on_device else st.picked_ptr, r_loc, world * (per + 1),
-                                               st.results_ptr if world == 1 else None, st.ws.data_ptr(), st.wsb, st.status_ptr[1], st.err_ptr[1],
+                                               st.results_ptr if world == 1 else None, st.status_ptr[2] if on_device else None, st.ws.data_ptr(), st.wsb,
+                                               st.status_ptr[1], st.err_ptr[1],
                                                1 if world == 1 else 0, stream)
             if rc != 0:
                 _lib.check(rc, "gabo_spd_sweep_solve_rows")
@@ -663,6 +664,7 @@ def _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, options
             if st.err[4] != 0:
                 # the heuristic needs its random fall-backs (no positive value among the raw samples, or fewer than restarts), a value is NaN - or the
                 # flag never arrived: the host heuristic decides, with its retries (manifold_optimize.py:283-320)
+                # (the launches behind the selection did no work: gabo_spd_sweep_solve_rows' skip_flag)
                 return _native_sweep(plan, acq_function, solver, num_restarts, raw_samples, dict(options, device_selection=False))
         if checking:
             st.raise_if_failed(1, "gabo_spd_sweep_solve_rows")

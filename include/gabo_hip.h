@@ -529,6 +529,8 @@ typedef struct {
  *     [3P] egrad2rgrad / norm), then the whole trust-region solve (gabo_spd_tr_solve's kernel), which ends with the result row.  results_mapped (may be NULL): restarts x (2 + d_vec) doubles
  *     of device-addressable memory that receive the result rows as well.  get_best_candidates (:118-120) is an argmax over column 0 of the result rows:
  *     the caller's, after its all_gather if there is one.
+ *   skip_flag (solve; may be NULL): the DEVICE int gabo_spd_sweep_select_rows wrote its flag to - when it is non-zero (nothing was picked) the
+ *     launches do no work (result rows: cost NaN, 0 iterations) and the caller selects on the host and solves again.
  *   status: device int[2] as everywhere (zeroed by the caller); status_mapped (may be NULL): int[2] of device-addressable host memory, zeroed by
  *     the caller, that receives the same two ints when a launch of the call reports an error - the host reads it after the stream has drained,
  *     without a copy.
@@ -562,8 +564,8 @@ int gabo_spd_sweep_select_rows(const double* raw_rows, int d, int64_t total, int
                                int seed_in_header, int rank, int world, int64_t* picked_rows, int64_t* picked_samples, int* flag, int* flag_mapped,
                                gabo_stream_t stream);
 int gabo_spd_sweep_solve_rows(const gabo_spd_sweep_config* cfg, const int64_t* picked_mapped, int64_t restarts, int64_t max_raw,
-                              double* results_mapped, void* workspace, size_t workspace_bytes, int* status, int* status_mapped, int synchronize,
-                              gabo_stream_t stream);
+                              double* results_mapped, const int* skip_flag, void* workspace, size_t workspace_bytes, int* status,
+                              int* status_mapped, int synchronize, gabo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Acquisition maximisation on the sphere S^(dim-1) (the sphere twins of gabo_spd_acq_eval / gabo_spd_tr_*): kernel strip of

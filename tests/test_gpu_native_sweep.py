@@ -211,3 +211,42 @@ def test_native_sweep_with_the_selection_on_the_device(restarts, raw, monkeypatc
     assert torch.equal(best_d, best_p) and val_d == val_p
     assert torch.equal(log_d["per_restart_iterations"].cpu(), log_p["per_restart_iterations"].cpu())
     np.testing.assert_array_equal(log_d["final_cost"].cpu().numpy(), log_p["final_cost"].cpu().numpy())
+
+
+def test_native_sweep_falls_back_to_the_host_heuristic_when_the_selection_kernel_raises_its_flag():
+    """Expected improvement that underflows to zero at every raw sample (an incumbent far below anything the surrogate predicts): botorch's heuristic
+    has no positive value to weight and picks at random, with its retries and its warning (manifold_optimize.py:283-320) - the selection kernel
+    raises its flag, the launches behind it do no work (skip_flag), and the sweep runs again with the heuristic on the host."""
+    import functools
+    import warnings
+    from gabotorch_amd import manifolds, models
+    from gabotorch_amd.kernel_utils.kernels_spd import SpdAffineInvariantGaussianKernel
+    from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTrustRegions
+    from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold
+    from gabotorch_amd.Riemannian_utils import spd_constraints_utils_torch as scut
+    from gabotorch_amd.Riemannian_utils.spd_utils_torch import symmetric_matrix_to_vector_mandel_torch as to_vec, vector_to_symmetric_matrix_mandel_torch as to_mat
+    from oracle import spd as ospd
+    rng = np.random.default_rng(3)
+    d, n = 3, 20
+    q = np.linalg.qr(rng.standard_normal((n, d, d)))[0]
+    X = np.einsum("nab,nb,ncb->nac", q, rng.uniform(0.3, 3.0, (n, d)), q)
+    xv = torch.tensor(ospd.symmetric_matrix_to_vector_mandel(0.5 * (X + X.transpose(0, 2, 1))), device="cuda:0")
+    y = torch.tensor(rng.standard_normal(n), device="cuda:0")
+    gp = models.ExactGP(xv, y, SpdAffineInvariantGaussianKernel(beta_min=0.3), outputscale=1.0, noise=1e-2)
+    acq = models.ExpectedImprovement(gp, best_f=float(y.min()) - 1e4, maximize=False)
+    man = manifolds.PositiveDefinite(d)
+    man.min_eig, man.max_eig = 0.1, 4.0
+    np.random.seed(5)
+    torch.manual_seed(5)
+    solver = BatchedTrustRegions(mingradnorm=1e-4, maxiter=5)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=8, raw_samples=32, bounds=None,
+                                       options={"device": "cuda:0", "device_rand": True},
+                                       inequality_constraints=[functools.partial(scut.max_eigenvalue_constraint_torch, maximum_eigenvalue=4.0)],
+                                       pre_processing_manifold=to_mat, post_processing_manifold=to_vec, approx_hessian=True)
+    assert solver.log.get("native_sweep") and solver.log.get("device_selection") is False
+    assert any(issubclass(w.category, models.BadInitialCandidatesWarning) for w in caught)
+    assert best.shape == (1, 6) and bool(torch.isfinite(best).all())
+    lam = np.linalg.eigvalsh(ospd.vector_to_symmetric_matrix_mandel(best.cpu().numpy()))
+    assert lam.min() > 0
