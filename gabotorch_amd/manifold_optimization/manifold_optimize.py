@@ -480,21 +480,16 @@ def _all_gather_rows(dist, full, block):
 class _RowsState:
     """What one (device, stream) keeps between sweeps: the device workspace of the native driver (its two tables as tensors) and a block of PAGE-LOCKED
     host memory the kernels write straight into (scores, result rows) and read from (picked rows) - no copy launch, no pageable staging; the host
-    looks at it through numpy once the stream has drained."""
+    looks at it through numpy once the stream has drained.  Keyed by what fixes the tables (d, rows, restarts, constraints); the number of training
+    points only sizes the solver's scratch behind them, so a BO loop whose training set grows by one point per iteration keeps its state and lets the
+    workspace grow when it has to."""
 
     def __init__(self, lib, dev, n_train, d, max_rows, restarts, n_constraints):
-        import ctypes
-        self.key = (n_train, d, max_rows, restarts, n_constraints)
+        self.key = (d, max_rows, restarts, n_constraints)
+        self.dev = dev
         dv = d * (d + 1) // 2
-        self.wsb = int(lib.gabo_spd_sweep_rows_workspace_bytes(n_train, d, max_rows, restarts, n_constraints))
-        self.ws = torch.empty(self.wsb // 8 + 1, dtype=torch.float64, device=dev)
-        raw_p, res_p = ctypes.c_void_p(), ctypes.c_void_p()
-        _lib_check = lib.gabo_spd_sweep_rows_tables(self.ws.data_ptr(), n_train, d, max_rows, restarts, n_constraints, ctypes.byref(raw_p), ctypes.byref(res_p))
-        if _lib_check != 0:
-            raise RuntimeError("gabo_spd_sweep_rows_tables refused the workspace")
-        o_raw, o_res = (raw_p.value - self.ws.data_ptr()) // 8, (res_p.value - self.ws.data_ptr()) // 8
-        self.raw = self.ws[o_raw:o_raw + max_rows * (1 + dv)].view(max_rows, 1 + dv)
-        self.res = self.ws[o_res:o_res + restarts * (2 + dv)].view(restarts, 2 + dv)
+        self.ws, self.wsb = None, 0
+        self.fit(lib, n_train)
         self.pinned = torch.zeros(3 + max_rows + restarts + restarts * (2 + dv), dtype=torch.float64).pin_memory()
         host = self.pinned.numpy()
         self.err = host[:3].view(np.int32)                  # mirrors of (score status, solve status, selection flag): int32[2] each
@@ -509,6 +504,24 @@ class _RowsState:
         self.picked_dev = torch.zeros(restarts, dtype=torch.int64, device=dev)      # device selection: this rank's rows
         self.samples_dev = None                                                     # ... and every restart's sample index (sized on first use)
 
+    def fit(self, lib, n_train):
+        """the workspace for a surrogate on n_train points: grown when the one held is too small (the tables sit at its start, at offsets that do not
+        depend on n_train)"""
+        import ctypes
+        d, max_rows, restarts, n_constraints = self.key
+        dv = d * (d + 1) // 2
+        need = int(lib.gabo_spd_sweep_rows_workspace_bytes(n_train, d, max_rows, restarts, n_constraints))
+        if self.ws is not None and need <= self.wsb:
+            return
+        self.wsb = need + need // 4           # (room for a few more training points before the next growth)
+        self.ws = torch.empty(self.wsb // 8 + 1, dtype=torch.float64, device=self.dev)
+        raw_p, res_p = ctypes.c_void_p(), ctypes.c_void_p()
+        if lib.gabo_spd_sweep_rows_tables(self.ws.data_ptr(), n_train, d, max_rows, restarts, n_constraints, ctypes.byref(raw_p), ctypes.byref(res_p)) != 0:
+            raise RuntimeError("gabo_spd_sweep_rows_tables refused the workspace")
+        o_raw, o_res = (raw_p.value - self.ws.data_ptr()) // 8, (res_p.value - self.ws.data_ptr()) // 8
+        self.raw = self.ws[o_raw:o_raw + max_rows * (1 + dv)].view(max_rows, 1 + dv)
+        self.res = self.ws[o_res:o_res + restarts * (2 + dv)].view(restarts, 2 + dv)
+
     def raise_if_failed(self, which, what):
         """after the stream has drained: did a launch of call `which` (0 score, 1 solve) report a non-SPD matrix?  Host memory only."""
         e = self.err[2 * which:2 * which + 2]
@@ -522,8 +535,10 @@ class _RowsState:
 def _rows_state(lib, dev, stream, n_train, d, max_rows, restarts, n_constraints):
     key = (dev.index, stream)
     st = _sweep_workspaces.get(key)
-    if st is None or st.key != (n_train, d, max_rows, restarts, n_constraints):
+    if st is None or st.key != (d, max_rows, restarts, n_constraints):
         st = _sweep_workspaces[key] = _RowsState(lib, dev, n_train, d, max_rows, restarts, n_constraints)
+    else:
+        st.fit(lib, n_train)
     return st
 
 

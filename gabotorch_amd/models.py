@@ -500,15 +500,30 @@ class SingleTaskGP(torch.nn.Module):
             base, outputscale = cm.base_kernel, float(cm.outputscale.detach())
         else:
             return
+        def drop(model=self):
+            model._cache = None
+            model._cache_linv_t = None
+            model._cache_kinv = None
+            model._cache_factors = None
+        from .kernel_utils import kernels_spd as _ks
+        if type(base) in (_ks.SpdAffineInvariantGaussianKernel, _ks.SpdAffineInvariantLaplaceKernel) and self.train_x.dim() == 2 \
+                and self.train_x.shape[-1] <= _l.GABO_SPD_REG_MAX_DIM * (_l.GABO_SPD_REG_MAX_DIM + 1) // 2:
+            # (as models.ExactGP: Gram of the training set, factor, symmetric inverse and the fused evaluators' training factors from ONE host call)
+            with torch.no_grad():
+                mu = self.mean_constant.detach().to(self.train_x.device)
+                mode = _l.GABO_OUT_GAUSSIAN if type(base) is _ks.SpdAffineInvariantGaussianKernel else _l.GABO_OUT_LAPLACE
+                Linv, Linv_t, alpha, factors, kinv = _ops.spd_gp_prepare(self.train_x, self.train_y, base.beta_float(), mode, outputscale,
+                                                                         float(self.noise.detach()), float(mu), on_fail=drop)
+            self._cache = (Linv, alpha, mu)
+            self._cache_linv_t = (self._cache, Linv_t)
+            self._cache_kinv = (self._cache, kinv)
+            self._cache_factors = (self._cache, factors)
+            return
         with torch.no_grad():
             kb = base.forward(self.train_x, self.train_x)
             if kb.dim() != 2:
                 return
             mu = self.mean_constant.detach().to(kb.device)
-            def drop(model=self):
-                model._cache = None
-                model._cache_linv_t = None
-                model._cache_kinv = None
             Linv, Linv_t, alpha, kinv = _ops.gp_factor(kb.double(), self.train_y, outputscale, float(self.noise.detach()), float(mu), defer_check=True,
                                                        on_fail=drop, want_kinv=True)
         self._cache = (Linv, alpha, mu)
