@@ -744,8 +744,8 @@ def main():
                  "seconds_by_restarts_one_gpu": latency_table,
                  "note": "latency-bound: one wave per restart walks its trust-region iterations serially (an accepted iteration is ~140 k cycles = ~58 us, the "
                          "longest chain of accepted iterations 12: ~0.72 ms of the sweep is this one launch whatever the number of restarts up to ~1024).  Round 6 "
-                         "removed what surrounded it: per-GP set-up in one host call (gp_factor 104 -> ~15 us), ten launches in front of the solve and three behind "
-                         "it folded into the solve launch, the selection heuristic on the device (no host wait between scoring and solving), scores / picks / results "
+                         "removed what surrounded it: per-GP set-up in one host call (gp_factor 104 -> 62 us, hidden behind the host's set-up), ten launches in front of the solve "
+                         "and three behind it folded into one start launch and the solve launch, the selection heuristic on the device (no host wait between scoring and solving), scores / picks / results "
                          "in page-locked memory the kernels address directly.  Does not speed up with more GPUs at this size (see expected_scaling)"}
 
 
