@@ -31,7 +31,7 @@ def _hipcc():
 
 # translation units that instantiate the big unrolled templates, longest first: they are started before everything else so
 # that the parallel build does not end on one of them
-_HEAVY = ["spd_tr_solve_le_hi.hip", "spd_tr_solve_le_mid.hip", "spd_tr_solve_le.hip", "spd_tr_solve_hi.hip", "spd_tr_le_hi.hip", "spd_tr_le.hip", "spd_tr_solve.hip",
+_HEAVY = ["spd_tr_solve_duo.hip", "spd_tr_solve_le_hi.hip", "spd_tr_solve_le_mid.hip", "spd_tr_solve_le.hip", "spd_tr_solve_hi.hip", "spd_tr_le_hi.hip", "spd_tr_le.hip", "spd_tr_solve.hip",
           "spd_backward_duo.hip", "spd_pairwise_wide3.hip", "spd_pairwise_wide2.hip", "spd_tr_wide.hip", "spd_acq.hip", "spd_pairwise_wide.hip", "spd_backward.hip", "spd_tr.hip",
           "spd_pairwise.hip", "spd_tr_solve_frob.hip", "spd_tr_frob.hip", "spd_acq_le.hip"]
 

@@ -1,0 +1,522 @@
+// Single-launch trust-region solve with TWO waves per restart (round 6; affine-invariant surrogate, built-in eigenvalue bounds, latency regime).
+//
+// The one-wave kernel (spd_tr_solve_kernel, spd_tr_body.hpp) walks an accepted iteration as one dependent chain: tCG begin -> constraints at x -> FD point ->
+// acquisition there -> tCG step -> proposal -> acquisition at the proposal -> update (138 k cycles at d = 5, n = 50; two evaluations of 40 k each).  Almost
+// always (config 4: see tools/duo_stats.py) tCG leaves in its FIRST step through the trust-region boundary or negative curvature, and that step does not depend on
+// the Hessian-vector product at all: eta = tau delta_0 with tau from (Delta, <delta_0, delta_0>) and the linearised constraints (robust_trust_regions.py:500-512,
+// constrained_trust_regions.py:583-640) - the product only DECIDES that the branch is taken.  So the block is two waves:
+//   wave 0 (the tCG wave):       begin, FD point, acquisition at the FD point, tCG step(s), model decrease, update
+//   wave 1 (the proposal wave):  eigen-pairs of x for the constraints, the boundary step as tCG would take it, proposal x+ = L expm(eta~) L^T, acquisition at x+
+// running side by side; after both are done the tCG wave's eta~ is compared with the speculated one, element by element.  Equal: the proposal and its value are
+// the ones the one-wave kernel computes (the same statements on the same operands: the same bits), and the iteration took max(...) instead of the sum.  Not equal
+// (an interior step, more tCG iterations): the tCG wave finishes, the proposal wave builds and evaluates the real proposal - the one-wave schedule, nothing lost
+// but the energy.  A rejected proposal shrinks the radius and leaves x, g, delta_0 in place: the next boundary step is speculated the same way.
+//
+// Synchronisation: the device bodies this kernel shares with the one-wave kernels synchronise with __syncthreads(), which for a 64-thread block IS a wave-level
+// fence (the compiler drops the s_barrier).  The translation unit of this kernel (spd_tr_solve_duo.hip) therefore defines __syncthreads() as that wave-level
+// fence before including them, and the block-level barriers between the two waves are explicit duo_block_sync() calls, executed by both waves in the same
+// sequence (every condition around one is block-uniform: read from LDS after the previous barrier).  Between two barriers a wave reads nothing the other writes:
+// the tCG wave snapshots what the speculation needs (delta_0, the scalars) before the first barrier, each wave has its own scratch (AcqLds, mats, 3 n doubles,
+// the logm spill F) and its own copy of the constraints' values and whitened gradients.
+// The block is dim3(64, 2): threadIdx.x stays the lane index the shared bodies use, threadIdx.y is the wave.
+#pragma once
+#ifndef GABO_DUO_TU
+#error "include from spd_tr_solve_duo.hip only (it redefines __syncthreads for the bodies it includes)"
+#endif
+#include "spd_tr_body.hpp"
+
+namespace gabo {
+
+static __device__ __forceinline__ void duo_block_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// lambda_max / lambda_min of x and their eigenvectors: the first half of builtin_constraints (kinds 0 / 1), same statements
+template <int D>
+__device__ __forceinline__ void duo_extremes(const double* __restrict__ x, double& lmax, double& lmin, double (&vmax)[D], double (&vmin)[D]) {
+    double lam[D], v[D * D];
+    eig_extremes<D>(x, lam, v);
+    lmax = lam[0], lmin = lam[0];
+    static_for<D>([&](auto rr) { vmax[decltype(rr)::value] = v[decltype(rr)::value * D]; vmin[decltype(rr)::value] = v[decltype(rr)::value * D]; });
+    static_for<D - 1>([&](auto kk) {
+        constexpr int c = decltype(kk)::value + 1;
+        const bool up = lam[c] > lmax, dn = lam[c] < lmin;
+        lmax = up ? lam[c] : lmax;
+        lmin = dn ? lam[c] : lmin;
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            vmax[r] = up ? v[r * D + c] : vmax[r];
+            vmin[r] = dn ? v[r * D + c] : vmin[r];
+        });
+    });
+}
+
+// ... and the second half: values and whitened gradients from the eigen-pairs and L = chol(x); fc_out: C doubles, gc_out: C x D^2
+template <int D>
+__device__ __forceinline__ void duo_cons_publish(const double* L, const BuiltinCons& B, double lmax, double lmin, const double (&vmax)[D],
+                                                 const double (&vmin)[D], double* fc_out, double* gc_out) {
+    constexpr int dd = D * D;
+    for (int k = 0; k < B.n; ++k) {
+        const bool want_max = B.kind[k] == 0;
+        const double best = want_max ? lmax : lmin;
+        double vec[D];
+        static_for<D>([&](auto rr) { vec[decltype(rr)::value] = want_max ? vmax[decltype(rr)::value] : vmin[decltype(rr)::value]; });
+        double u[D];       // L^T v
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            double sacc = 0.0;
+            static_for<D - c>([&](auto rr) { constexpr int r = c + decltype(rr)::value; sacc = __builtin_fma(L[r * D + c], vec[r], sacc); });
+            u[c] = sacc;
+        });
+        if (threadIdx.x == 0) {
+            const double sign = want_max ? -1.0 : 1.0;
+            fc_out[k] = want_max ? B.bound[k] - best : best - B.bound[k];
+            double* out = gc_out + (int64_t)k * dd;
+            static_for<D>([&](auto rr) {
+                static_for<D>([&](auto cc) { out[decltype(rr)::value * D + decltype(cc)::value] = sign * u[decltype(rr)::value] * u[decltype(cc)::value]; });
+            });
+        }
+    }
+}
+
+// "The same step again" of tr_build_proposal: is sym(etaw) the step the proposal in the workspace was built from (x unchanged)?  Rewrites the cache.
+template <int D>
+__device__ __forceinline__ bool duo_same_step(const double* etaw, double* step_cache, bool x_unchanged) {
+    constexpr int T = tri_size(D);
+    constexpr int dd = D * D;
+    if (step_cache == nullptr) return false;
+    bool same = x_unchanged && step_cache[T] != 0.0;
+    for (int e = threadIdx.x; e < dd; e += 64) {
+        const int r = e / D, c = e - r * D;
+        const double sym = 0.5 * (etaw[r * D + c] + etaw[c * D + r]);
+        if (r >= c) {
+            same = same && (sym == step_cache[tri(r, c)]);
+        }
+    }
+    same = __builtin_amdgcn_ballot_w64(!same) == 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < dd; e += 64) {
+        const int r = e / D, c = e - r * D;
+        if (r >= c) step_cache[tri(r, c)] = 0.5 * (etaw[r * D + c] + etaw[c * D + r]);
+    }
+    if (threadIdx.x == 0) step_cache[T] = 1.0;
+    __syncthreads();
+    return same;
+}
+
+// x+ = L expm(eta~) L^T and its Mandel vector: the second half of tr_build_proposal (D <= 8), same statements
+template <int D>
+__device__ __forceinline__ void duo_proposal_from_eta(const double* chol, const double* etaw, double* __restrict__ x_prop, double* __restrict__ xpm,
+                                                      double* mats) {
+    constexpr int T = tri_size(D);
+    constexpr int dd = D * D;
+    double* M0 = mats;
+    double* M1 = M0 + dd;
+    double* M2 = M1 + dd;
+    double* M3 = M2 + dd;
+    lds_load(chol, M0, D);
+    {
+        double m[T], v[D * D];
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            static_for<r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; m[tri(r, c)] = 0.5 * (etaw[r * D + c] + etaw[c * D + r]); });
+        });
+        double lam_e[D];
+        sym_eig_reg<D>(m, lam_e, v);
+        double ex[D];
+        static_for<D>([&](auto kk) { ex[decltype(kk)::value] = exp(lam_e[decltype(kk)::value]); });
+        if (threadIdx.x == 0) {
+            static_for<D>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                static_for<r + 1>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    double f = 0.0;
+                    static_for<D>([&](auto kk) { constexpr int k = decltype(kk)::value; f = __builtin_fma(v[r * D + k] * ex[k], v[c * D + k], f); });
+                    M3[r * D + c] = f;
+                    M3[c * D + r] = f;
+                });
+            });
+        }
+        __syncthreads();
+    }
+    lds_congruence(M0, M3, M1, M2, D);
+    lds_symmetrize(M1, M2, D);
+    lds_store(M1, x_prop, D);
+    for (int e = threadIdx.x; e < T; e += 64) {
+        int k = 0;
+        while (k + 1 < D && (k + 1) * D - (k + 1) * k / 2 <= e) ++k;
+        int cc = e - (k * D - k * (k - 1) / 2);
+        int r = cc + k;
+        xpm[e] = (k == 0) ? M1[r * D + cc] : kSqrt2 * M1[r * D + cc];
+    }
+    __syncthreads();
+}
+
+// The step tCG takes when it leaves in its first iteration through the boundary branch of tcg_step_core (d_Hd <= 0 or the full step beyond the radius),
+// from the state tcg_begin left: the same statements with the same operands (sc: the scalars as stored, zero: a stored 0.0 standing for eta~ and <grad c, eta>
+// before the first step, gc / fc: this wave's copy of the constraints).  out: eta~ = 0 + tau delta~.
+template <int D>
+__device__ __forceinline__ void duo_boundary_step(const double* sc, const double* dl, const double* gc, const double* fc, int C, double delta_cons,
+                                                  const double* zero, double* out) {
+    constexpr int dd = D * D;
+    const double Delta = sc[SC_DELTA], e_Pe = sc[SC_E_PE], e_Pd = sc[SC_E_PD], d_Pd = sc[SC_D_PD];
+    const double dc2 = delta_cons * delta_cons;
+    const double Delta2 = Delta * Delta;
+    double fcl[kMaxCons], fpe[kMaxCons], fpd[kMaxCons];
+    for (int k = 0; k < C; ++k) {
+        fcl[k] = fc[k];
+        fpe[k] = zero[0];
+        fpd[k] = wave_dot(gc + (int64_t)k * dd, dl, dd);
+    }
+    double tau = (-e_Pd + __builtin_sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;
+    if (C > 0) {
+        if (tau != tau) tau = 0.0;
+        ConsStep cst = cons_step(tau, fcl, fpe, fpd, C, 0, dc2);
+        if (cst.cin > dc2) tau = cst.tau;
+    }
+    const double step = tau;
+    for (int e = threadIdx.x; e < dd; e += 64) out[e] = zero[0] + step * dl[e];
+    __syncthreads();
+}
+
+// The first iteration of tcg_step_core as a function of the radius alone: which way tCG leaves (or -1: it takes the tentative step and goes on) and the step
+// along delta_0, from the quantities that do not change while x stands (the scalars of tcg_begin, <delta_0, H delta_0>, the constraints' values and their
+// directional derivatives).  The statements of tcg_step_core with eta = 0.
+struct DuoFirstStep { int stop; double step; };
+static __device__ __forceinline__ DuoFirstStep duo_first_step(double Delta, const double* sc, double d_Hd, const double* fcl, const double* fpe, const double* fpd,
+                                                              int C, double delta_cons) {
+    const double e_Pe = sc[SC_E_PE], e_Pd = sc[SC_E_PD], d_Pd = sc[SC_D_PD], z_r = sc[SC_Z_R];
+    const double dc2 = delta_cons * delta_cons;
+    const bool nz = d_Hd != 0.0;
+    const double alpha = nz ? z_r / d_Hd : 0.0;
+    const double e_Pe_new = nz ? e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd : e_Pe;
+    const double Delta2 = Delta * Delta;
+    DuoFirstStep r{-1, 0.0};
+    if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {
+        double tau = (-e_Pd + __builtin_sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;
+        r.stop = d_Hd <= 0.0 ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;
+        if (C > 0) {
+            if (tau != tau) tau = 0.0;
+            ConsStep cst = cons_step(tau, fcl, fpe, fpd, C, 0, dc2);
+            if (cst.cin > dc2) {
+                tau = cst.tau;
+                if (d_Hd > 0.0) r.stop = TCG_REACHED_CONSTRAINTS;
+            }
+        }
+        r.step = tau;
+    } else if (C > 0) {
+        ConsStep cst = cons_step(alpha, fcl, fpe, fpd, C, 0, dc2);
+        if (cst.cin > dc2) { r.stop = TCG_REACHED_CONSTRAINTS; r.step = cst.tau; }
+    }
+    return r;
+}
+
+// dynamic LDS of the two-wave kernel (bytes) for n training points, dimension d, C constraints; offsets in doubles
+struct DuoLds {
+    size_t scratch1, kinv, ws, f1, gc1, fc1, snap, bytes;
+};
+static __host__ __device__ inline DuoLds duo_lds_layout(int64_t n, int d, int C) {
+    DuoLds l;
+    const int dd = d * d;
+    const size_t dv = (size_t)d * (d + 1) / 2;
+    size_t off = 0;                                 // wave 0's 3 n doubles first
+    off += 3 * n;
+    l.scratch1 = off;  off += 3 * n;
+    l.kinv = off;      off += (size_t)n * n;
+    off = (off + 1) & ~(size_t)1;
+    l.ws = off;        off += (tr_layout(nullptr, 1, d, C, n).bytes + 15) / 8;
+    off = (off + 1) & ~(size_t)1;
+    l.f1 = off;        off += dv * n;
+    l.gc1 = off;       off += (size_t)(C > 0 ? C : 1) * dd;
+    l.fc1 = off;       off += kMaxCons;
+    l.snap = off;      off += dd + SC_COUNT + 2;      // delta_0~, the scalars, a stored zero
+    l.bytes = off * sizeof(double);
+    return l;
+}
+
+#ifdef GABO_DUO_TIMES
+static __device__ long long g_duo_times[4 * 1024];
+#endif
+
+template <int D>
+struct DuoStatic {
+    static constexpr int dd = D * D;
+    static constexpr int T = tri_size(D);
+    AcqLds<D> acq[2];
+    double mats[2][5 * dd + kJacobiScratch];
+    double spec_eta[dd];
+    double step_cache[T + 1];
+    double cons_pub[2 + 2 * D];
+    int flags[8];
+};
+enum { DF_STILL = 0, DF_ACCEPTED, DF_INNER, DF_INVAL };
+
+template <int D>
+__global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
+                                                               double* __restrict__ ng, double* __restrict__ delta_tr,
+                                                               uint8_t* __restrict__ active, int64_t* __restrict__ iters, AcqParams P,
+                                                               BuiltinCons B, int64_t R, double delta_cons, double theta, double kappa,
+                                                               int mininner, int maxinner, double delta_bar, double rho_prime,
+                                                               double rho_regularization, double mingradnorm, int64_t maxiter,
+                                                               int* __restrict__ status, int shortcuts, double* __restrict__ rec, int64_t rec_cap,
+                                                               TrStart S, int* __restrict__ counters) {      // counters: {hits, misses} or null
+    static_assert(D <= 8, "register eigen-solvers");
+    constexpr int dd = D * D;
+    constexpr int T = tri_size(D);
+    __shared__ DuoStatic<D> sh;
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const int lane = threadIdx.x;
+#ifdef GABO_DUO_TIMES       /* development (tools/duo_times.py): cycles, iterations, hits and misses of every restart */
+    const long long t_start = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    const int64_t i = blockIdx.x;
+    const bool own_finish = S.res_rows != nullptr;
+    if (active[i] == 0) {          // (block-uniform)
+        if (own_finish && wv == 0) tr_finish_body<D>(S, x + i * dd, fx[i], iters[i]);
+        return;
+    }
+    const int C = B.n;
+    const DuoLds lay = duo_lds_layout(P.n, D, C);
+    double* dynw = wv == 0 ? dyn : dyn + lay.scratch1;        // this wave's 3 n doubles
+    double* gl = dyn + lay.kinv;
+    {   // the symmetric inverse of the Gram matrix, staged once by both waves
+        const int64_t nn = P.n * P.n;
+        for (int64_t e = lane + 64 * wv; e < nn; e += 128) gl[e] = P.linv[e];
+    }
+    AcqParams Ps = P;
+    Ps.linv = gl;
+    Ps.linv_t = gl;
+    // the per-restart workspace of the one-wave kernel, in LDS
+    char* wsbase = reinterpret_cast<char*>(dyn + lay.ws);
+    TrWs t = tr_layout(wsbase, 1, D, C, P.n);
+    for (size_t e = lane + 64 * wv; e < t.bytes / sizeof(double); e += 128) reinterpret_cast<double*>(wsbase)[e] = 0.0;
+    t.tcg.index_base = i;
+    const TcgWs& w = t.tcg;
+    double* F1 = dyn + lay.f1;
+    double* gc1 = dyn + lay.gc1;
+    double* fc1 = dyn + lay.fc1;
+    double* snap_dl = dyn + lay.snap;
+    double* snap_sc = snap_dl + dd;
+    double* zero = snap_sc + SC_COUNT;
+    double* mats = sh.mats[wv];
+    AcqLds<D>& acq = sh.acq[wv];
+    if (wv == 0 && lane == 0) {
+        sh.step_cache[T] = 0.0;
+        zero[0] = 0.0;
+    }
+    double* const step_cache = shortcuts != 0 ? sh.step_cache : nullptr;
+    double* xp = t.xp_mat;
+    double* xpm = t.xp_mandel;
+    const double* xi = x + i * dd;
+    duo_block_sync();
+    bool cons_fresh = false;          // block-uniform: the previous proposal was rejected (x, g, the constraints stand)
+    int last_inner = 0;
+    int64_t rec_k = rec != nullptr ? iters[i] : 0;
+    int n_hit = 0, n_miss = 0, n_skip = 0;
+    for (;;) {
+        const bool x_unchanged = cons_fresh;
+        const bool lazy = cons_fresh && shortcuts != 0;
+        const bool fd0_kept = last_inner == 1;
+        const double fx_now = fx[i];          // (read here by both waves: the update of this iteration may rewrite it while the other wave still decides)
+        // ---- part 1: tCG begin | eigen-pairs of x
+        if (wv == 0) {
+            tr_begin_part<D>(xi, g + i * dd, delta_tr[i], nullptr, nullptr, t, 0, 1, C, mats, status, nullptr, x_unchanged, nullptr);
+            for (int e = lane; e < dd; e += 64) snap_dl[e] = w.delta_w[e];
+            if (lane < SC_COUNT) snap_sc[lane] = w.scal[lane];
+        } else if (C > 0 && !x_unchanged) {
+            double lmax, lmin, vmax[D], vmin[D];
+            duo_extremes<D>(xi, lmax, lmin, vmax, vmin);
+            if (lane == 0) {
+                sh.cons_pub[0] = lmax;
+                sh.cons_pub[1] = lmin;
+                static_for<D>([&](auto rr) {
+                    sh.cons_pub[2 + decltype(rr)::value] = vmax[decltype(rr)::value];
+                    sh.cons_pub[2 + D + decltype(rr)::value] = vmin[decltype(rr)::value];
+                });
+            }
+        }
+        duo_block_sync();
+        if (C > 0 && !x_unchanged) {          // both waves: the constraints' values and whitened gradients, each into its own copy
+            double vmax[D], vmin[D];
+            const double lmax = sh.cons_pub[0], lmin = sh.cons_pub[1];
+            static_for<D>([&](auto rr) {
+                vmax[decltype(rr)::value] = sh.cons_pub[2 + decltype(rr)::value];
+                vmin[decltype(rr)::value] = sh.cons_pub[2 + D + decltype(rr)::value];
+            });
+            duo_cons_publish<D>(w.chol, B, lmax, lmin, vmax, vmin, wv == 0 ? w.fc : fc1, wv == 0 ? w.gc_w : gc1);
+            __syncthreads();
+        }
+        // ---- part 2 and the rest of the iteration.  Barrier sequence of BOTH waves: B2, [B3 when the speculation missed], B4, [B5 when a value-only
+        // evaluation is followed by the gradient], B6 - every bracket decided from LDS / global words that the previous barrier ordered.
+        auto speculation_hit = [&]() -> bool {          // did tCG stop in its first iteration with the speculated step?
+            bool eq = true;
+            for (int e = lane; e < dd; e += 64) eq = eq && (w.eta_w[e] == sh.spec_eta[e]);
+            return ((w.running[0] == 0) || maxinner <= 1) && (__builtin_amdgcn_ballot_w64(!eq) == 0);
+        };
+        if (wv == 0) {
+            // ---- the tCG wave: the loop of tr_propose_body
+            int inner = 0;
+            bool hit = false;
+            for (int it = 0; it < maxinner; ++it) {
+                ++inner;
+                if (!(it == 0 && x_unchanged && fd0_kept)) tcg_fd_point(w, 0, D, t.x_fd, mats);
+                __syncthreads();
+                double* eg_it = (it == 0) ? t.eg_fd0 : t.eg_fd;
+                if (!(it == 0 && x_unchanged)) acq_eval<D>(t.x_fd, Ps, t.val_fd, eg_it, t.F, acq, dynw, status, i);
+                __syncthreads();
+                const bool running = tcg_step(w, 0, 1, D, C, eg_it, 0, delta_cons, theta, kappa, mininner, it, mats);
+                __syncthreads();
+                if (it == 0) {
+                    duo_block_sync();                                   // B2
+                    hit = speculation_hit();
+                    if (hit) break;
+                }
+                if (!running) break;
+            }
+            if (!hit) duo_block_sync();                                 // B3
+            n_hit += hit ? 1 : 0;
+            n_miss += hit ? 0 : 1;
+            // the model decrease -<g, eta> - 1/2 <eta, H eta>
+            const double ge = wave_dot(w.g_w, w.eta_w, dd);
+            const double ehe = wave_dot(w.eta_w, w.heta_w, dd);
+            if (lane == 0) {
+                t.rhoden[0] = -ge - 0.5 * ehe;
+                sh.flags[DF_INNER] = inner;
+            }
+            if (rec != nullptr && rec_k < rec_cap) {
+                double* rr = rec + (rec_k * R + i) * (dd + 2);
+                for (int e = lane; e < dd; e += 64) rr[e] = xi[e];
+                if (lane == 0) {
+                    rr[dd] = delta_tr[i];
+                    rr[dd + 1] = (double)w.stop[0];
+                }
+            }
+            duo_block_sync();                                           // B4
+            const bool inval = sh.flags[DF_INVAL] != 0;
+            if (lazy && tr_would_accept(fx_now, t.fx_prop[0], t.rhoden[0], inval, rho_prime, rho_regularization)) duo_block_sync();      // B5
+            bool accepted = false;
+            const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, 0, D, C, delta_bar,
+                                              rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
+            bool still_ff = still;
+#ifndef GABO_DUO_NO_FAST_FORWARD
+            // A rejected proposal quarters the radius and changes nothing else: the next iteration's tCG runs from the same x, gradient, delta_0,
+            // H delta_0 and constraints, and when it leaves in its first step with the SAME step along delta_0 (a restart that sits outside an eigenvalue
+            // bound: the step is set by the linearised constraint whatever the radius - config 4 has such restarts reject 98 proposals in a row, 17 k cycles
+            // each, and they were the duration of the launch), eta, the proposal, its value, the model decrease and therefore the verdict are those of this
+            // iteration again.  What the iteration does to the state is then known - one more count, the radius quartered again - and it is applied here,
+            // for as many iterations as the first-step logic (duo_first_step: scalars only) returns the same step.  Bit for bit the state the iterations
+            // would have left (tests/test_gpu_native_sweep.py compares with GABO_TR_NO_SHORTCUTS); not while a record of the iterations is being taken.
+            if (still && !accepted && inner == 1 && w.running[0] == 0 && shortcuts != 0 && rec == nullptr && rho_prime < 0.25) {
+                const double* Hd = mats + 4 * dd;          // tcg_step left H delta_0~ and delta_0~ here (M4, M2)
+                const double* dl0 = mats + 2 * dd;
+                const double d_Hd = wave_dot(dl0, Hd, dd);
+                double fcl[kMaxCons], fpe[kMaxCons], fpd[kMaxCons];
+                for (int k = 0; k < C; ++k) {
+                    fcl[k] = w.fc[k];
+                    fpe[k] = zero[0];
+                    fpd[k] = wave_dot(w.gc_w + (int64_t)k * dd, dl0, dd);
+                }
+                const DuoFirstStep ref = duo_first_step(snap_sc[SC_DELTA], snap_sc, d_Hd, fcl, fpe, fpd, C, delta_cons);
+                double Dk = delta_tr[i];
+                int64_t itk = iters[i];
+                int skipped = 0;
+                while (ref.stop >= 0) {
+                    const DuoFirstStep nxt = duo_first_step(Dk, snap_sc, d_Hd, fcl, fpe, fpd, C, delta_cons);
+                    if (nxt.stop < 0 || !(nxt.step == ref.step)) break;
+                    ++itk;                        // tr_update_body for a rejected proposal: iters + 1, radius / 4, stop at maxiter
+                    Dk = Dk / 4;
+                    ++skipped;
+                    if (itk >= maxiter) { still_ff = false; break; }
+                }
+                if (skipped > 0 && lane == 0) {
+                    delta_tr[i] = Dk;
+                    iters[i] = itk;
+                }
+                n_skip += skipped;
+            }
+#endif
+            if (lane == 0) {
+                sh.flags[DF_STILL] = still_ff ? 1 : 0;
+                sh.flags[DF_ACCEPTED] = accepted ? 1 : 0;
+            }
+        } else {
+            // ---- the proposal wave: one evaluation site, three uses - the speculated proposal, the real one after a miss, the gradient after a
+            // value-only evaluation whose proposal is going to be accepted
+            duo_boundary_step<D>(snap_sc, snap_dl, gc1, fc1, C, delta_cons, zero, sh.spec_eta);
+            enum { PH_SPEC = 0, PH_REAL = 1, PH_REGRAD = 2 };
+            int phase = PH_SPEC;
+            for (;;) {
+                bool do_eval = true;
+                double* gout = t.eg_prop;
+                if (phase != PH_REGRAD) {
+                    const double* src = phase == PH_SPEC ? sh.spec_eta : w.eta_w;
+                    do_eval = !duo_same_step<D>(src, step_cache, x_unchanged);
+                    if (do_eval) duo_proposal_from_eta<D>(w.chol, src, xp, xpm, mats);
+                    gout = lazy ? nullptr : t.eg_prop;
+                }
+                if (do_eval) {
+                    acq_eval<D>(xpm, Ps, t.fx_prop, gout, F1, acq, dynw, status, i);
+                    __syncthreads();
+                }
+                if (phase == PH_SPEC) {
+                    duo_block_sync();                                   // B2
+                    if (!speculation_hit()) {
+                        duo_block_sync();                               // B3
+                        phase = PH_REAL;
+                        continue;
+                    }
+                }
+                if (phase == PH_REGRAD) {
+                    duo_block_sync();                                   // B5
+                    break;
+                }
+                // feasibility of the proposal (strict variant)
+                const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B, nullptr) : false;
+                if (lane == 0) sh.flags[DF_INVAL] = inval ? 1 : 0;
+                duo_block_sync();                                       // B4
+                if (lazy && tr_would_accept(fx_now, t.fx_prop[0], t.rhoden[0], inval, rho_prime, rho_regularization)) {
+                    phase = PH_REGRAD;
+                    continue;
+                }
+                break;
+            }
+        }
+        ++rec_k;
+        duo_block_sync();                                               // B6
+        last_inner = sh.flags[DF_INNER];
+        if (sh.flags[DF_STILL] == 0) break;
+        cons_fresh = sh.flags[DF_ACCEPTED] == 0;
+    }
+    if (wv != 0) return;
+#ifdef GABO_DUO_TIMES
+    if (lane == 0 && i < 1024) {
+        g_duo_times[4 * i] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+        g_duo_times[4 * i + 1] = iters[i];
+        g_duo_times[4 * i + 2] = n_hit;
+        g_duo_times[4 * i + 3] = n_miss + 1000 * n_skip;
+    }
+#endif
+    if (lane == 0) {
+        active[i] = 0;
+        if (counters != nullptr) {
+            atomicAdd(counters, n_hit);
+            atomicAdd(counters + 1, n_miss);
+        }
+    }
+    if (own_finish) {
+        __syncthreads();
+        tr_finish_body<D>(S, x + i * dd, fx[i], iters[i]);
+        if (S.status_host != nullptr && lane == 0) {
+            const int e = __atomic_load_n(status, __ATOMIC_RELAXED);
+            if (e != 0) {
+                S.status_host[1] = __atomic_load_n(status + 1, __ATOMIC_RELAXED);
+                S.status_host[0] = e;
+            }
+        }
+    }
+}
+
+}  // namespace gabo

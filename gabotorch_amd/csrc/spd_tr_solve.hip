@@ -4,7 +4,12 @@
 
 namespace gabo {
 int solve_affine_invariant_hi(const SolveArgs& a);
-int solve_affine_invariant(const SolveArgs& a) { return a.d >= 7 ? solve_affine_invariant_hi(a) : dispatch_solve<0, 2, 6>(a); }
+bool solve_duo_wanted(const SolveArgs& a);                // spd_tr_solve_duo.hip: two waves per restart (latency regime, <= 512 restarts)
+int solve_affine_invariant_duo(const SolveArgs& a);
+int solve_affine_invariant(const SolveArgs& a) {
+    if (solve_duo_wanted(a)) return solve_affine_invariant_duo(a);
+    return a.d >= 7 ? solve_affine_invariant_hi(a) : dispatch_solve<0, 2, 6>(a);
+}
 }  // namespace gabo
 
 #ifdef GABO_TR_CLOCKS

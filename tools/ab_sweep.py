@@ -16,3 +16,12 @@ for R in [int(a) for a in sys.argv[2:]] or [64, 512]:
     srt = np.sort(it)[::-1]
     print(f"[{tag}] R={R}: median {np.median(ts) * 1e3:.3f} ms (min {min(ts) * 1e3:.3f}); EI* {val:.15e}; iterations: max {it.max()}, at maxiter {int((it >= 100).sum())}, "
           f"largest below maxiter {srt[srt < 100][:5].tolist()}, mean {it.mean():.2f}; sum of final costs {float(log['final_cost'].sum()):.17e}, sum of iterations {int(it.sum())}")
+    try:      # the two-wave solve's speculation counters (spd_tr_solve_duo.hip), when that kernel ran
+        import ctypes
+        from gabotorch_amd import _lib
+        h, m = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        _lib.load().gabo_spd_tr_duo_counters(ctypes.byref(h), ctypes.byref(m), 1)
+        if h.value + m.value:
+            print(f"[{tag}] R={R}: two-wave solve: {h.value} iterations with the speculated step, {m.value} without ({h.value / (h.value + m.value):.3f})")
+    except Exception as e:
+        print("no counters:", e)
