@@ -146,6 +146,8 @@ SIGNATURES = {
     "gabo_sphere_tr_stop_offset": (_SZ, [_I64, _I, _I]),
     "gabo_tr_solve_record": (_I, [_P, _I64]),
     "gabo_spd_tr_solve_supported": (_I, [_P, _I64, _I, _I, _I]),
+    "gabo_spd_tr_two_waves": (_I, [_I]),
+    "gabo_spd_tr_two_waves_counters": (_I, [_P, _P, _I]),
     "gabo_spd_tr_propose_supported": (_I, [_I, _I]),
     "gabo_sphere_tr_propose": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _I64, _I, _I, _D, _D, _D, _I, _I, _I, _P, _P]),
     "gabo_sphere_tr_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _D, _D, _D, _D, _I64, _P, _P]),

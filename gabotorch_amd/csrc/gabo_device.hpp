@@ -8,7 +8,9 @@
 
 // Development instrumentation (builds with -DGABO_TR_CLOCKS only; tools/tr_clocks.py): block 0 / lane 0 appends (tag, s_memtime) pairs
 // to a per-translation-unit buffer that the exported gabo_debug_clocks of that unit copies out.  Compiles to nothing otherwise.
-#ifdef GABO_TR_CLOCKS
+#ifdef GABO_TICK
+/* (the translation unit brought its own recorder: spd_tr_solve_duo.hip with -DGABO_DUO_TIMES) */
+#elif defined(GABO_TR_CLOCKS)
 #ifndef GABO_TR_CLOCKS_BLOCK
 #define GABO_TR_CLOCKS_BLOCK 0      /* the restart (block) whose waves record: -DGABO_TR_CLOCKS_BLOCK=<index of a restart that runs to maxiter> */
 #endif

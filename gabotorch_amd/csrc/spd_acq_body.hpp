@@ -285,6 +285,8 @@ __device__ GABO_ACQ_INLINE void acq_eval(const double* __restrict__ xrow, const 
     __syncthreads();
     GABO_TICK(105);
     // grad = -2 W^T S W, Mandel  (as in spd_backward.hip)
+#ifdef GABO_ACQ_TAIL_LOOPS      /* A/B: rounds 1-6a - every output entry by one lane as a double loop with lane-dependent bounds: 25 dependent LDS round trips,
+                                   7.3 k of an evaluation's 40 k cycles at d = 5 (tools/tr_clocks.py: what remains of "two acquisition evaluations" after its phases) */
     for (int e = lane; e < T; e += 64) {
         int a = 0;
         while (tri(a + 1, 0) <= e) ++a;
@@ -301,6 +303,38 @@ __device__ GABO_ACQ_INLINE void acq_eval(const double* __restrict__ xrow, const 
         t *= -2.0;
         grad_out[mandel_pos(D, a, bb)] = (a == bb) ? t : t * kSqrt2;
     }
+#else
+    // The same sums in the same order as two phases with one entry per lane, the loops unrolled with their lane-dependent bounds as selects, so that the
+    // LDS reads of a phase go out together: U[r][b] = sum_{c >= b} S[r][c] W[c][b] for all (r, b), then -2 sum_{r >= a} W[r][a] U[r][b].
+    // U goes where the accumulator columns were (the reduction above has consumed them).
+    double* U = acc;
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int r = idx / D, b = idx - r * D;
+        double inner = 0.0;
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const double srs = r >= c ? red[tri(r, c)] : red[tri(c, r)];
+            const double wcb = wl[c >= b ? tri(c, b) : 0];
+            inner = c >= b ? __builtin_fma(srs, wcb, inner) : inner;
+        });
+        U[idx] = inner;
+    }
+    __syncthreads();
+    for (int e = lane; e < T; e += 64) {
+        int a = 0;
+        while (tri(a + 1, 0) <= e) ++a;
+        const int bb = e - tri(a, 0);
+        double t = 0.0;
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            const double wra = wl[r >= a ? tri(r, a) : 0];
+            const double u = U[r * D + bb];
+            t = r >= a ? __builtin_fma(wra, u, t) : t;
+        });
+        t *= -2.0;
+        grad_out[mandel_pos(D, a, bb)] = (a == bb) ? t : t * kSqrt2;
+    }
+#endif
 }
 
 // Same contract as acq_eval<D> for the two Frobenius-type surrogates (kernels_spd.py:190-313):

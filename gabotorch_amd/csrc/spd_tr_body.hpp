@@ -583,6 +583,85 @@ static __device__ bool tr_update_body(double* __restrict__ x, double* __restrict
     return !(ngi < mingradnorm || it >= maxiter);
 }
 
+// The first iteration of tcg_step_core as a function of the radius alone: which way tCG leaves (or -1: it takes the tentative step and goes on) and the step
+// along delta_0, from the quantities that do not change while x stands (the scalars of tcg_begin, <delta_0, H delta_0>, the constraints' values and their
+// directional derivatives).  The statements of tcg_step_core with eta = 0.
+struct TrFirstStep { int stop; double step; };
+static __device__ __forceinline__ TrFirstStep tr_first_step(double Delta, const double* sc, double d_Hd, const double* fcl, const double* fpe, const double* fpd,
+                                                            int C, double delta_cons) {
+    const double e_Pe = sc[SC_E_PE], e_Pd = sc[SC_E_PD], d_Pd = sc[SC_D_PD], z_r = sc[SC_Z_R];
+    const double dc2 = delta_cons * delta_cons;
+    const bool nz = d_Hd != 0.0;
+    const double alpha = nz ? z_r / d_Hd : 0.0;
+    const double e_Pe_new = nz ? e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd : e_Pe;
+    const double Delta2 = Delta * Delta;
+    TrFirstStep r{-1, 0.0};
+    if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {
+        double tau = (-e_Pd + __builtin_sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;
+        r.stop = d_Hd <= 0.0 ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;
+        if (C > 0) {
+            if (tau != tau) tau = 0.0;
+            ConsStep cst = cons_step(tau, fcl, fpe, fpd, C, 0, dc2);
+            if (cst.cin > dc2) {
+                tau = cst.tau;
+                if (d_Hd > 0.0) r.stop = TCG_REACHED_CONSTRAINTS;
+            }
+        }
+        r.step = tau;
+    } else if (C > 0) {
+        ConsStep cst = cons_step(alpha, fcl, fpe, fpd, C, 0, dc2);
+        if (cst.cin > dc2) { r.stop = TCG_REACHED_CONSTRAINTS; r.step = cst.tau; }
+    }
+    return r;
+}
+
+// Rejected again and again (single-launch solves, after an update that rejected a proposal whose tCG ran ONE iteration and stopped).  A rejected proposal
+// quarters the radius and changes nothing else: the next iteration's tCG runs from the same x, gradient, delta_0, H delta_0 and constraints, and when it leaves
+// in its first step with the SAME step along delta_0 - a restart that sits outside an eigenvalue bound has its step set by the linearised constraint whatever the
+// radius: config 4 has such restarts reject 98 proposals in a row, 17 k cycles each, and they were the duration of the launch - eta, the proposal, its value,
+// the model decrease and therefore the verdict are those of this iteration again.  What such an iteration does to the state is known - one more count, the
+// radius quartered again (tr_update_body) - and is applied here for as many iterations as the first-step logic (scalars only) returns the same step: bit
+// for bit the state those iterations would have left (tests/test_gpu_native_sweep.py compares with GABO_TR_NO_SHORTCUTS).  Hd: H delta_0~ as tcg_step left it
+// (M4 of its LDS tile); the workspace still holds delta_0~, the scalars of tcg_begin and the constraints (tCG's stop path does not touch them).
+// Returns the number of iterations applied; *still becomes false when maxiter is reached.
+#ifdef GABO_TR_FF_INLINE
+#define GABO_FF_INLINE __forceinline__
+#else
+#define GABO_FF_INLINE
+#endif
+static __device__ GABO_FF_INLINE int tr_repeat_rejected(const TcgWs& w, int64_t iw, int64_t Rw, int d, int C, const double* Hd, double delta_cons, double* __restrict__ delta_tr,
+                                         int64_t* __restrict__ iters, int64_t maxiter, bool* still) {
+    const int dd = d * d;
+    const double* dl0 = w.delta_w + iw * dd;
+    const double* sc = w.scal + iw * SC_COUNT;
+    const double d_Hd = wave_dot(dl0, Hd, dd);
+    double fcl[kMaxCons], fpe[kMaxCons], fpd[kMaxCons];
+    for (int k = 0; k < C; ++k) {
+        fcl[k] = w.fc[iw * C + k];
+        fpe[k] = w.fcg_pe[iw * C + k];
+        fpd[k] = wave_dot(w.gc_w + ((int64_t)k * Rw + iw) * dd, dl0, dd);
+    }
+    const TrFirstStep ref = tr_first_step(sc[SC_DELTA], sc, d_Hd, fcl, fpe, fpd, C, delta_cons);
+    double Dk = *delta_tr;
+    int64_t itk = *iters;
+    int skipped = 0;
+    while (ref.stop >= 0) {
+        const TrFirstStep nxt = tr_first_step(Dk, sc, d_Hd, fcl, fpe, fpd, C, delta_cons);
+        if (nxt.stop < 0 || !(nxt.step == ref.step)) break;
+        ++itk;
+        Dk = Dk / 4;
+        ++skipped;
+        if (itk >= maxiter) { *still = false; break; }
+    }
+    __syncthreads();                 // every lane has read the scalars before lane 0 rewrites them
+    if (skipped > 0 && threadIdx.x == 0) {
+        *delta_tr = Dk;
+        *iters = itk;
+    }
+    __syncthreads();
+    return skipped;
+}
+
 // The sweep's own start and end of a restart (gabo_spd_sweep_solve_rows, spd_sweep.hip): restart i begins at raw sample picked[i] of the scored table and
 // the device itself does what gen_candidates_manifold does around the solver (manifold_optimize.py:170-205) - pre_processing_manifold (Mandel -> matrix),
 // post_processing_manifold inside the cost (matrix -> Mandel), cost and Euclidean gradient at the start, [3P] egrad2rgrad and norm of pymanopt's
@@ -870,6 +949,13 @@ __global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x
         const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, iw, D, C, delta_bar,
                                           rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
         GABO_TICK(9);
+#ifndef GABO_TR_NO_FAST_FORWARD
+        if (still && !accepted && last_inner == 1 && t.tcg.running[iw] == 0 && shortcuts != 0 && rec == nullptr && rho_prime < 0.25) {
+            bool still_ff = true;
+            tr_repeat_rejected(t.tcg, iw, Rw, D, C, mats + 4 * dd, delta_cons, delta_tr + i, iters + i, maxiter, &still_ff);
+            if (!still_ff) break;
+        }
+#endif
         if (!still) break;
         cons_fresh = !accepted;
     }

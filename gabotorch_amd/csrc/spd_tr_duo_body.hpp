@@ -181,38 +181,6 @@ __device__ __forceinline__ void duo_boundary_step(const double* sc, const double
     __syncthreads();
 }
 
-// The first iteration of tcg_step_core as a function of the radius alone: which way tCG leaves (or -1: it takes the tentative step and goes on) and the step
-// along delta_0, from the quantities that do not change while x stands (the scalars of tcg_begin, <delta_0, H delta_0>, the constraints' values and their
-// directional derivatives).  The statements of tcg_step_core with eta = 0.
-struct DuoFirstStep { int stop; double step; };
-static __device__ __forceinline__ DuoFirstStep duo_first_step(double Delta, const double* sc, double d_Hd, const double* fcl, const double* fpe, const double* fpd,
-                                                              int C, double delta_cons) {
-    const double e_Pe = sc[SC_E_PE], e_Pd = sc[SC_E_PD], d_Pd = sc[SC_D_PD], z_r = sc[SC_Z_R];
-    const double dc2 = delta_cons * delta_cons;
-    const bool nz = d_Hd != 0.0;
-    const double alpha = nz ? z_r / d_Hd : 0.0;
-    const double e_Pe_new = nz ? e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd : e_Pe;
-    const double Delta2 = Delta * Delta;
-    DuoFirstStep r{-1, 0.0};
-    if (d_Hd <= 0.0 || e_Pe_new >= Delta2) {
-        double tau = (-e_Pd + __builtin_sqrt(e_Pd * e_Pd + d_Pd * (Delta2 - e_Pe))) / d_Pd;
-        r.stop = d_Hd <= 0.0 ? TCG_NEGATIVE_CURVATURE : TCG_EXCEEDED_TR;
-        if (C > 0) {
-            if (tau != tau) tau = 0.0;
-            ConsStep cst = cons_step(tau, fcl, fpe, fpd, C, 0, dc2);
-            if (cst.cin > dc2) {
-                tau = cst.tau;
-                if (d_Hd > 0.0) r.stop = TCG_REACHED_CONSTRAINTS;
-            }
-        }
-        r.step = tau;
-    } else if (C > 0) {
-        ConsStep cst = cons_step(alpha, fcl, fpe, fpd, C, 0, dc2);
-        if (cst.cin > dc2) { r.stop = TCG_REACHED_CONSTRAINTS; r.step = cst.tau; }
-    }
-    return r;
-}
-
 // dynamic LDS of the two-wave kernel (bytes) for n training points, dimension d, C constraints; offsets in doubles
 struct DuoLds {
     size_t scratch1, kinv, ws, f1, gc1, fc1, snap, bytes;
@@ -246,12 +214,12 @@ struct DuoStatic {
     static constexpr int T = tri_size(D);
     AcqLds<D> acq[2];
     double mats[2][5 * dd + kJacobiScratch];
-    double spec_eta[dd];
+    double spec_eta[2][dd];       // the speculated step, one copy per wave
     double step_cache[T + 1];
     double cons_pub[2 + 2 * D];
     int flags[8];
 };
-enum { DF_STILL = 0, DF_ACCEPTED, DF_INNER, DF_INVAL };
+enum { DF_STILL = 0, DF_ACCEPTED, DF_HIT, DF_INVAL };
 
 template <int D>
 __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
@@ -312,55 +280,42 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
     double* xpm = t.xp_mandel;
     const double* xi = x + i * dd;
     duo_block_sync();
-    bool cons_fresh = false;          // block-uniform: the previous proposal was rejected (x, g, the constraints stand)
-    int last_inner = 0;
-    int64_t rec_k = rec != nullptr ? iters[i] : 0;
     int n_hit = 0, n_miss = 0, n_skip = 0;
-    for (;;) {
-        const bool x_unchanged = cons_fresh;
-        const bool lazy = cons_fresh && shortcuts != 0;
-        const bool fd0_kept = last_inner == 1;
-        const double fx_now = fx[i];          // (read here by both waves: the update of this iteration may rewrite it while the other wave still decides)
-        // ---- part 1: tCG begin | eigen-pairs of x
-        if (wv == 0) {
+    // Barrier sequence of BOTH waves, per iteration: B1, B2, [B4 after a miss], [B5 when a value-only evaluation is followed by the gradient]; every
+    // bracket is decided from words the previous barrier ordered.  The iteration of the tCG wave ends with the update and runs straight into the next
+    // begin; the proposal wave spends that time on the eigen-pairs of the proposal it expects to be accepted (the next iterate's constraints).
+    if (wv == 0) {
+        // ================= the tCG wave
+        bool x_unchanged = false;          // the previous proposal was rejected: x, g, the constraints stand
+        int last_inner = 0;
+        int64_t rec_k = rec != nullptr ? iters[i] : 0;
+        for (;;) {
+            const bool lazy = x_unchanged && shortcuts != 0;
+            const bool fd0_kept = last_inner == 1;
+            const double fx_now = fx[i];
+            GABO_TICK(20);
             tr_begin_part<D>(xi, g + i * dd, delta_tr[i], nullptr, nullptr, t, 0, 1, C, mats, status, nullptr, x_unchanged, nullptr);
             for (int e = lane; e < dd; e += 64) snap_dl[e] = w.delta_w[e];
             if (lane < SC_COUNT) snap_sc[lane] = w.scal[lane];
-        } else if (C > 0 && !x_unchanged) {
-            double lmax, lmin, vmax[D], vmin[D];
-            duo_extremes<D>(xi, lmax, lmin, vmax, vmin);
-            if (lane == 0) {
-                sh.cons_pub[0] = lmax;
-                sh.cons_pub[1] = lmin;
+            GABO_TICK(21);
+            duo_block_sync();                                           // B1
+            GABO_TICK(22);
+            if (C > 0 && !x_unchanged) {          // the constraints' values and whitened gradients from the other wave's eigen-pairs: this wave's copy
+                double vmax[D], vmin[D];
+                const double lmax = sh.cons_pub[0], lmin = sh.cons_pub[1];
                 static_for<D>([&](auto rr) {
-                    sh.cons_pub[2 + decltype(rr)::value] = vmax[decltype(rr)::value];
-                    sh.cons_pub[2 + D + decltype(rr)::value] = vmin[decltype(rr)::value];
+                    vmax[decltype(rr)::value] = sh.cons_pub[2 + decltype(rr)::value];
+                    vmin[decltype(rr)::value] = sh.cons_pub[2 + D + decltype(rr)::value];
                 });
+                duo_cons_publish<D>(w.chol, B, lmax, lmin, vmax, vmin, w.fc, w.gc_w);
+                __syncthreads();
             }
-        }
-        duo_block_sync();
-        if (C > 0 && !x_unchanged) {          // both waves: the constraints' values and whitened gradients, each into its own copy
-            double vmax[D], vmin[D];
-            const double lmax = sh.cons_pub[0], lmin = sh.cons_pub[1];
-            static_for<D>([&](auto rr) {
-                vmax[decltype(rr)::value] = sh.cons_pub[2 + decltype(rr)::value];
-                vmin[decltype(rr)::value] = sh.cons_pub[2 + D + decltype(rr)::value];
-            });
-            duo_cons_publish<D>(w.chol, B, lmax, lmin, vmax, vmin, wv == 0 ? w.fc : fc1, wv == 0 ? w.gc_w : gc1);
-            __syncthreads();
-        }
-        // ---- part 2 and the rest of the iteration.  Barrier sequence of BOTH waves: B2, [B3 when the speculation missed], B4, [B5 when a value-only
-        // evaluation is followed by the gradient], B6 - every bracket decided from LDS / global words that the previous barrier ordered.
-        auto speculation_hit = [&]() -> bool {          // did tCG stop in its first iteration with the speculated step?
-            bool eq = true;
-            for (int e = lane; e < dd; e += 64) eq = eq && (w.eta_w[e] == sh.spec_eta[e]);
-            return ((w.running[0] == 0) || maxinner <= 1) && (__builtin_amdgcn_ballot_w64(!eq) == 0);
-        };
-        if (wv == 0) {
-            // ---- the tCG wave: the loop of tr_propose_body
+            // the step the other wave is speculating on, here for the comparison alone (so that a miss is known without waiting for that wave)
+            duo_boundary_step<D>(snap_sc, snap_dl, w.gc_w, w.fc, C, delta_cons, zero, sh.spec_eta[0]);
+            GABO_TICK(23);
             int inner = 0;
             bool hit = false;
-            for (int it = 0; it < maxinner; ++it) {
+            for (int it = 0; it < maxinner; ++it) {          // the loop of tr_propose_body
                 ++inner;
                 if (!(it == 0 && x_unchanged && fd0_kept)) tcg_fd_point(w, 0, D, t.x_fd, mats);
                 __syncthreads();
@@ -369,14 +324,14 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
                 __syncthreads();
                 const bool running = tcg_step(w, 0, 1, D, C, eg_it, 0, delta_cons, theta, kappa, mininner, it, mats);
                 __syncthreads();
-                if (it == 0) {
-                    duo_block_sync();                                   // B2
-                    hit = speculation_hit();
+                if (it == 0) {          // did tCG stop here, with the speculated step?
+                    bool eq = true;
+                    for (int e = lane; e < dd; e += 64) eq = eq && (w.eta_w[e] == sh.spec_eta[0][e]);
+                    hit = (!running || maxinner <= 1) && (__builtin_amdgcn_ballot_w64(!eq) == 0);
                     if (hit) break;
                 }
                 if (!running) break;
             }
-            if (!hit) duo_block_sync();                                 // B3
             n_hit += hit ? 1 : 0;
             n_miss += hit ? 0 : 1;
             // the model decrease -<g, eta> - 1/2 <eta, H eta>
@@ -384,7 +339,7 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
             const double ehe = wave_dot(w.eta_w, w.heta_w, dd);
             if (lane == 0) {
                 t.rhoden[0] = -ge - 0.5 * ehe;
-                sh.flags[DF_INNER] = inner;
+                sh.flags[DF_HIT] = hit ? 1 : 0;
             }
             if (rec != nullptr && rec_k < rec_cap) {
                 double* rr = rec + (rec_k * R + i) * (dd + 2);
@@ -394,101 +349,122 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
                     rr[dd + 1] = (double)w.stop[0];
                 }
             }
-            duo_block_sync();                                           // B4
+            ++rec_k;
+            GABO_TICK(24);
+            duo_block_sync();                                           // B2
+            GABO_TICK(25);
+            if (!hit) duo_block_sync();                                 // B4
+            GABO_TICK(26);
             const bool inval = sh.flags[DF_INVAL] != 0;
-            if (lazy && tr_would_accept(fx_now, t.fx_prop[0], t.rhoden[0], inval, rho_prime, rho_regularization)) duo_block_sync();      // B5
+            // (the verdict as the other wave computes it: it decides there whether the gradient is evaluated after a value-only evaluation and whether the
+            // proposal's eigen-pairs are prepared for the next iteration)
+            const bool accept_pred = tr_would_accept(fx_now, t.fx_prop[0], t.rhoden[0], inval, rho_prime, rho_regularization);
+            if (lazy && accept_pred) duo_block_sync();                  // B5
             bool accepted = false;
-            const bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, 0, D, C, delta_bar,
-                                              rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
-            bool still_ff = still;
-#ifndef GABO_DUO_NO_FAST_FORWARD
-            // A rejected proposal quarters the radius and changes nothing else: the next iteration's tCG runs from the same x, gradient, delta_0,
-            // H delta_0 and constraints, and when it leaves in its first step with the SAME step along delta_0 (a restart that sits outside an eigenvalue
-            // bound: the step is set by the linearised constraint whatever the radius - config 4 has such restarts reject 98 proposals in a row, 17 k cycles
-            // each, and they were the duration of the launch), eta, the proposal, its value, the model decrease and therefore the verdict are those of this
-            // iteration again.  What the iteration does to the state is then known - one more count, the radius quartered again - and it is applied here,
-            // for as many iterations as the first-step logic (duo_first_step: scalars only) returns the same step.  Bit for bit the state the iterations
-            // would have left (tests/test_gpu_native_sweep.py compares with GABO_TR_NO_SHORTCUTS); not while a record of the iterations is being taken.
-            if (still && !accepted && inner == 1 && w.running[0] == 0 && shortcuts != 0 && rec == nullptr && rho_prime < 0.25) {
-                const double* Hd = mats + 4 * dd;          // tcg_step left H delta_0~ and delta_0~ here (M4, M2)
-                const double* dl0 = mats + 2 * dd;
-                const double d_Hd = wave_dot(dl0, Hd, dd);
-                double fcl[kMaxCons], fpe[kMaxCons], fpd[kMaxCons];
-                for (int k = 0; k < C; ++k) {
-                    fcl[k] = w.fc[k];
-                    fpe[k] = zero[0];
-                    fpd[k] = wave_dot(w.gc_w + (int64_t)k * dd, dl0, dd);
-                }
-                const DuoFirstStep ref = duo_first_step(snap_sc[SC_DELTA], snap_sc, d_Hd, fcl, fpe, fpd, C, delta_cons);
-                double Dk = delta_tr[i];
-                int64_t itk = iters[i];
-                int skipped = 0;
-                while (ref.stop >= 0) {
-                    const DuoFirstStep nxt = duo_first_step(Dk, snap_sc, d_Hd, fcl, fpe, fpd, C, delta_cons);
-                    if (nxt.stop < 0 || !(nxt.step == ref.step)) break;
-                    ++itk;                        // tr_update_body for a rejected proposal: iters + 1, radius / 4, stop at maxiter
-                    Dk = Dk / 4;
-                    ++skipped;
-                    if (itk >= maxiter) { still_ff = false; break; }
-                }
-                if (skipped > 0 && lane == 0) {
-                    delta_tr[i] = Dk;
-                    iters[i] = itk;
-                }
-                n_skip += skipped;
-            }
+            bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, 0, D, C, delta_bar,
+                                        rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
+#ifndef GABO_TR_NO_FAST_FORWARD
+            // (a run of rejected proposals with the same first tCG step: applied as scalar updates, see tr_repeat_rejected)
+            if (still && !accepted && inner == 1 && w.running[0] == 0 && shortcuts != 0 && rec == nullptr && rho_prime < 0.25)
+                n_skip += tr_repeat_rejected(w, 0, 1, D, C, mats + 4 * dd, delta_cons, delta_tr + i, iters + i, maxiter, &still);
 #endif
             if (lane == 0) {
-                sh.flags[DF_STILL] = still_ff ? 1 : 0;
+                sh.flags[DF_STILL] = still ? 1 : 0;
                 sh.flags[DF_ACCEPTED] = accepted ? 1 : 0;
+                // tr_would_accept and tr_update_body are the same statements; should they ever disagree the other wave has prepared the wrong constraints:
+                // reported as a failed launch rather than computed with
+                if (accepted != accept_pred && status != nullptr && atomicCAS(status, 0, GABO_ERR_LAUNCH) == 0) status[1] = (int)i;
             }
-        } else {
-            // ---- the proposal wave: one evaluation site, three uses - the speculated proposal, the real one after a miss, the gradient after a
-            // value-only evaluation whose proposal is going to be accepted
-            duo_boundary_step<D>(snap_sc, snap_dl, gc1, fc1, C, delta_cons, zero, sh.spec_eta);
+            __syncthreads();
+            GABO_TICK(27);
+            if (!still) {
+                duo_block_sync();                                       // the B1 the other wave is waiting at
+                break;
+            }
+            x_unchanged = !accepted;
+            last_inner = inner;
+        }
+    } else {
+        // ================= the proposal wave
+        bool first = true;
+        bool accept_pred = false;          // the verdict of the update of the previous iteration, as this wave computed it (tr_would_accept)
+        for (;;) {
+            // eigen-pairs of the next iterate for its constraints: the start, or the proposal that is being accepted (the update copies it into x)
+            GABO_TICK(30);
+            if (C > 0 && (first || accept_pred)) {
+                double lmax, lmin, vmax[D], vmin[D];
+                duo_extremes<D>(first ? xi : xp, lmax, lmin, vmax, vmin);
+                if (lane == 0) {
+                    sh.cons_pub[0] = lmax;
+                    sh.cons_pub[1] = lmin;
+                    static_for<D>([&](auto rr) {
+                        sh.cons_pub[2 + decltype(rr)::value] = vmax[decltype(rr)::value];
+                        sh.cons_pub[2 + D + decltype(rr)::value] = vmin[decltype(rr)::value];
+                    });
+                }
+                __syncthreads();
+            }
+            GABO_TICK(31);
+            duo_block_sync();                                           // B1
+            GABO_TICK(32);
+            if (!first && sh.flags[DF_STILL] == 0) break;
+            const bool x_unchanged = !first && sh.flags[DF_ACCEPTED] == 0;
+            const bool lazy = x_unchanged && shortcuts != 0;
+            const double fx_now = fx[i];
+            first = false;
+            if (C > 0 && !x_unchanged) {
+                double vmax[D], vmin[D];
+                const double lmax = sh.cons_pub[0], lmin = sh.cons_pub[1];
+                static_for<D>([&](auto rr) {
+                    vmax[decltype(rr)::value] = sh.cons_pub[2 + decltype(rr)::value];
+                    vmin[decltype(rr)::value] = sh.cons_pub[2 + D + decltype(rr)::value];
+                });
+                duo_cons_publish<D>(w.chol, B, lmax, lmin, vmax, vmin, fc1, gc1);
+                __syncthreads();
+            }
+            // one evaluation site, three uses: the speculated proposal, the real one after a miss, the gradient after a value-only evaluation whose
+            // proposal is going to be accepted
+            duo_boundary_step<D>(snap_sc, snap_dl, gc1, fc1, C, delta_cons, zero, sh.spec_eta[1]);
+            GABO_TICK(33);
             enum { PH_SPEC = 0, PH_REAL = 1, PH_REGRAD = 2 };
             int phase = PH_SPEC;
+            bool inval = false;
             for (;;) {
                 bool do_eval = true;
                 double* gout = t.eg_prop;
                 if (phase != PH_REGRAD) {
-                    const double* src = phase == PH_SPEC ? sh.spec_eta : w.eta_w;
+                    const double* src = phase == PH_SPEC ? sh.spec_eta[1] : w.eta_w;
                     do_eval = !duo_same_step<D>(src, step_cache, x_unchanged);
                     if (do_eval) duo_proposal_from_eta<D>(w.chol, src, xp, xpm, mats);
                     gout = lazy ? nullptr : t.eg_prop;
+                    GABO_TICK(34);
                 }
                 if (do_eval) {
                     acq_eval<D>(xpm, Ps, t.fx_prop, gout, F1, acq, dynw, status, i);
                     __syncthreads();
-                }
-                if (phase == PH_SPEC) {
-                    duo_block_sync();                                   // B2
-                    if (!speculation_hit()) {
-                        duo_block_sync();                               // B3
-                        phase = PH_REAL;
-                        continue;
-                    }
                 }
                 if (phase == PH_REGRAD) {
                     duo_block_sync();                                   // B5
                     break;
                 }
                 // feasibility of the proposal (strict variant)
-                const bool inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B, nullptr) : false;
+                inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B, nullptr) : false;
                 if (lane == 0) sh.flags[DF_INVAL] = inval ? 1 : 0;
-                duo_block_sync();                                       // B4
-                if (lazy && tr_would_accept(fx_now, t.fx_prop[0], t.rhoden[0], inval, rho_prime, rho_regularization)) {
+                GABO_TICK(35);
+                duo_block_sync();                                       // B2 (speculated proposal) / B4 (real one)
+                GABO_TICK(36);
+                if (phase == PH_SPEC && sh.flags[DF_HIT] == 0) {
+                    phase = PH_REAL;
+                    continue;
+                }
+                accept_pred = tr_would_accept(fx_now, t.fx_prop[0], t.rhoden[0], inval, rho_prime, rho_regularization);
+                if (lazy && accept_pred) {
                     phase = PH_REGRAD;
                     continue;
                 }
                 break;
             }
         }
-        ++rec_k;
-        duo_block_sync();                                               // B6
-        last_inner = sh.flags[DF_INNER];
-        if (sh.flags[DF_STILL] == 0) break;
-        cons_fresh = sh.flags[DF_ACCEPTED] == 0;
     }
     if (wv != 0) return;
 #ifdef GABO_DUO_TIMES

@@ -13,6 +13,23 @@ static __device__ __forceinline__ void duo_wave_sync() {
 }
 }  // namespace gabo
 #define __syncthreads() ::gabo::duo_wave_sync()
+#ifdef GABO_DUO_TIMES       /* development (tools/duo_times.py): lane 0 of both waves of one restart records (tag + 1000 wave, cycle) pairs */
+#ifndef GABO_DUO_CLOCKS_BLOCK
+#define GABO_DUO_CLOCKS_BLOCK 55
+#endif
+static __device__ long long gabo_duo_clk[2 * 8192];
+static __device__ int gabo_duo_clk_n;
+#define GABO_TICK(tag)                                                                        \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x == GABO_DUO_CLOCKS_BLOCK) {                        \
+            const int k_ = atomicAdd(&gabo_duo_clk_n, 1);                                     \
+            if (k_ < 8192) {                                                                  \
+                gabo_duo_clk[2 * k_] = (tag) + 1000 * (int)threadIdx.y;                       \
+                gabo_duo_clk[2 * k_ + 1] = (long long)__builtin_amdgcn_s_memtime();           \
+            }                                                                                 \
+        }                                                                                     \
+    } while (0)
+#endif
 #define GABO_DUO_TU 1
 #include "spd_tr_duo_body.hpp"
 
@@ -45,9 +62,12 @@ static size_t duo_static_lds(int d) {
 
 // whether solve_affine_invariant_duo takes this problem: the latency regime of the one-wave kernel (everything in LDS), the symmetric inverse of the Gram
 // matrix, eigenvalue bounds of the iterate itself (kinds 0 / 1) or no constraints.  GABO_TR_DUO=0 in the environment keeps the one-wave kernel (A/B, tests).
+static int& duo_enabled() {
+    static int enabled = []() { const char* e = getenv("GABO_TR_DUO"); return (e && e[0] == '0') ? 0 : 1; }();
+    return enabled;
+}
 bool solve_duo_wanted(const SolveArgs& a) {
-    static const int enabled = []() { const char* e = getenv("GABO_TR_DUO"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (!enabled) return false;
+    if (!duo_enabled()) return false;
     if (a.d < GABO_DUO_MIN_DIM || a.d > GABO_DUO_MAX_DIM || a.r > GABO_DUO_MAX_RESTARTS) return false;
     if ((a.P->flags & GABO_METRIC_MASK) != GABO_METRIC_AFFINE_INVARIANT) return false;
     if (!a.P->linv || a.P->linv != a.P->linv_t) return false;
@@ -87,8 +107,13 @@ int solve_affine_invariant_duo(const SolveArgs& a) {
 
 }  // namespace gabo
 
-// development / bench: how many trust-region iterations of the two-wave solves so far found tCG leaving with the speculated step (hits) and how many did not
-extern "C" int gabo_spd_tr_duo_counters(long long* hits, long long* misses, int reset) {
+extern "C" int gabo_spd_tr_two_waves(int enable) {
+    const int before = gabo::duo_enabled();
+    if (enable == 0 || enable == 1) gabo::duo_enabled() = enable;
+    return before;
+}
+
+extern "C" int gabo_spd_tr_two_waves_counters(long long* hits, long long* misses, int reset) {
     int h[2] = {0, 0};
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gabo::g_duo_counters), sizeof(h)) != hipSuccess) return GABO_ERR_LAUNCH;
     if (hits) *hits = h[0];
@@ -101,6 +126,18 @@ extern "C" int gabo_spd_tr_duo_counters(long long* hits, long long* misses, int 
 }
 
 #ifdef GABO_DUO_TIMES
+extern "C" int gabo_debug_duo_clocks(long long* out, int max_pairs, int reset) {
+    int n = 0;
+    hipMemcpyFromSymbol(&n, HIP_SYMBOL(gabo_duo_clk_n), sizeof(int));
+    if (n > max_pairs) n = max_pairs;
+    if (n > 8192) n = 8192;
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(gabo_duo_clk), (size_t)n * 2 * sizeof(long long));
+    if (reset) {
+        const int zero = 0;
+        hipMemcpyToSymbol(HIP_SYMBOL(gabo_duo_clk_n), &zero, sizeof(int));
+    }
+    return n;
+}
 extern "C" int gabo_debug_duo_times(long long* out, int restarts) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(gabo::g_duo_times), (size_t)restarts * 4 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }

@@ -483,6 +483,14 @@ int gabo_spd_tr_solve(double* x, double* fx, double* grad, double* grad_norm, do
  * gabo_spd_tr_update instead (same results, two launches per iteration): d outside 2 ... 8, an unknown surrogate metric, more dynamic LDS than a block has - or an instantiation this build of the library leaves out
  * (-DGABO_LE_MAX_GENERIC_DIM, csrc/spd_tr_body.hpp).  lift_dim: as in gabo_spd_tr_solve, 0 without nested kinds. */
 int gabo_spd_tr_solve_supported(const gabo_spd_acq_params* acq, int64_t r, int d, int n_constraints, int lift_dim);
+/* The two-wave form of the single launch (csrc/spd_tr_duo_body.hpp): for the affine-invariant surrogate with the symmetric inverse of the Gram matrix
+ * (acq->linv == acq->linv_t), d <= 6, at most 512 restarts, constraints of kinds 0 / 1 or none, gabo_spd_tr_solve gives every restart a second wave that
+ * evaluates the proposal truncated CG is about to make while the first wave is still evaluating the finite-difference point (same results, bit for bit).
+ * gabo_spd_tr_two_waves(0 / 1) turns the form off / on for this process and returns the previous setting (-1: only query; initially on unless GABO_TR_DUO=0
+ * is in the environment); gabo_spd_tr_two_waves_counters reads (and with reset != 0 clears) how many trust-region iterations of such launches so far found
+ * truncated CG leaving with the speculated step (hits) and how many did not (misses: the proposal was evaluated again, the one-wave schedule). */
+int gabo_spd_tr_two_waves(int enable);
+int gabo_spd_tr_two_waves_counters(long long* hits, long long* misses, int reset);
 
 /* ------------------------------------------------------------------------------------------------------------
  * One multi-start acquisition sweep on S^d_++ through a native host driver: the device work of

@@ -20,7 +20,7 @@ for R in [int(a) for a in sys.argv[2:]] or [64, 512]:
         import ctypes
         from gabotorch_amd import _lib
         h, m = ctypes.c_longlong(0), ctypes.c_longlong(0)
-        _lib.load().gabo_spd_tr_duo_counters(ctypes.byref(h), ctypes.byref(m), 1)
+        _lib.load().gabo_spd_tr_two_waves_counters(ctypes.byref(h), ctypes.byref(m), 1)
         if h.value + m.value:
             print(f"[{tag}] R={R}: two-wave solve: {h.value} iterations with the speculated step, {m.value} without ({h.value / (h.value + m.value):.3f})")
     except Exception as e:

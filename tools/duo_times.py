@@ -19,3 +19,20 @@ for k in order[:12]:
 print("...")
 for k in order[-4:]:
     print(f"{k:6d} {a[k, 0]:9d} {a[k, 1]:6d} {a[k, 2]:6d} {a[k, 3]:6d}   {a[k, 0] / max(1, a[k, 1]):10.0f}")
+# the (tag, cycle) pairs both waves of restart GABO_DUO_CLOCKS_BLOCK (default 55) recorded during the LAST sweep
+try:
+    lib = _lib.load()
+    lib.gabo_debug_duo_clocks((ctypes.c_longlong * 2)(), 0, 1)
+    run_sweep("cuda:0", **kw)
+    cb = (ctypes.c_longlong * (2 * 8192))()
+    n = lib.gabo_debug_duo_clocks(cb, 8192, 1)
+    pairs = np.array(cb[:2 * n]).reshape(n, 2)
+    t0 = pairs[:, 1].min()
+    rows = {0: [], 1: []}
+    for tag, c in pairs:
+        rows[int(tag) // 1000].append((int(tag) % 1000, int(c - t0)))
+    for wv in (0, 1):
+        rows[wv].sort(key=lambda r: r[1])
+        print(f"wave {wv}: " + " ".join(f"{tag}@{c}" for tag, c in rows[wv][:150]))
+except Exception as e:
+    print("no clocks:", e)
