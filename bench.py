@@ -721,6 +721,34 @@ def main():
                     print(f"sweep with {total} restarts failed: {err}", file=sys.stderr)
             latency_table[512], latency_table[8192] = strong["512"]["seconds"], strong["8192"]["seconds"]
             latency_table = {str(k): latency_table[k] for k in sorted(latency_table)}
+        # the two forms of the single-launch solve side by side (gabo_spd_tr_two_waves): one wave per restart, and two - the second evaluating the
+        # proposal truncated CG is about to make while the first evaluates the finite-difference point; bit-identical results
+        two_waves = None
+        if world == 1 and not lite:
+            import ctypes
+            from gabotorch_amd import _lib as _gl
+            lib_ = _gl.load()
+            two_waves = {}
+            before_ = lib_.gabo_spd_tr_two_waves(-1)
+            try:
+                for total in (64, 512):
+                    kw = dict(num_restarts=total, raw_samples=4 * total, device_rand=True, builtin_constraint=True)
+                    row = {}
+                    for name_, flag_ in (("one_wave", 0), ("two_waves", 1)):
+                        lib_.gabo_spd_tr_two_waves(flag_)
+                        run_sweep(device, **kw)
+                        h_, m_ = ctypes.c_longlong(0), ctypes.c_longlong(0)
+                        lib_.gabo_spd_tr_two_waves_counters(ctypes.byref(h_), ctypes.byref(m_), 1)
+                        runs_ = [run_sweep(device, **kw) for _ in range(5)]
+                        lib_.gabo_spd_tr_two_waves_counters(ctypes.byref(h_), ctypes.byref(m_), 1)
+                        row["seconds_" + name_] = min(r_[0] for r_ in runs_)
+                        row["best_acq_" + name_] = runs_[0][2]
+                        if flag_:
+                            row["iterations_with_the_speculated_step"] = h_.value // 5
+                            row["iterations_without"] = m_.value // 5
+                    two_waves[str(total)] = row
+            finally:
+                lib_.gabo_spd_tr_two_waves(before_)
         sweep = {"workload": "gabo_spd S^5_++: GP(50 obs of the Ackley objective, SURVEY 8d)+EI, 2048 raw samples, 512 restarts, ConstrainedTR semantics, FD Hessian, "
                              "lambda_max<=5 constraint built with functools.partial as in the reference example; raw samples drawn in one "
                              "vectorised host call and scored by the fused chain; the trust-region solve is ONE launch (every wave iterates "
@@ -742,9 +770,14 @@ def main():
                  "weak_scaling_512_restarts_per_gpu": weak,
                  "strong_scaling_fixed_total_restarts": strong,
                  "seconds_by_restarts_one_gpu": latency_table,
-                 "note": "latency-bound: one wave per restart walks its trust-region iterations serially (an accepted iteration is ~140 k cycles = ~58 us, the "
-                         "longest chain of accepted iterations 12: ~0.72 ms of the sweep is this one launch whatever the number of restarts up to ~1024).  Round 6 "
-                         "removed what surrounded it: per-GP set-up in one host call (gp_factor 104 -> 62 us, hidden behind the host's set-up), ten launches in front of the solve "
+                 "single_launch_solve_one_and_two_waves_per_restart": two_waves,
+                 "note": "latency-bound: a restart walks its trust-region iterations serially.  Up to 512 restarts the solve launch gives every restart TWO waves "
+                         "(csrc/spd_tr_duo_body.hpp): truncated CG almost always leaves in its first step through the trust-region boundary, a step that does not depend "
+                         "on the Hessian-vector product, so the second wave builds and evaluates that proposal while the first evaluates the finite-difference point "
+                         "(an accepted iteration ~82 k cycles instead of ~138 k when the speculation holds, the one-wave schedule when it does not; bit-identical "
+                         "results, tests/test_gpu_two_waves.py); runs of rejected proposals whose first tCG step does not change (a restart outside an eigenvalue "
+                         "bound: 98 iterations, formerly the duration of the launch) are applied as scalar updates.  Solve launch at 64 restarts 0.70 -> 0.49 ms.  Round 6 "
+                         "also removed what surrounded it: per-GP set-up in one host call (gp_factor 104 -> 62 us, hidden behind the host's set-up), ten launches in front of the solve "
                          "and three behind it folded into one start launch and the solve launch, the selection heuristic on the device (no host wait between scoring and solving), scores / picks / results "
                          "in page-locked memory the kernels address directly.  Does not speed up with more GPUs at this size (see expected_scaling)"}
 

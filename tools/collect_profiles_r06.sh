@@ -13,7 +13,8 @@ cp /tmp/pk/bench_kernel_stats.csv $OUT/bench_kernel_stats.csv
 # 2. instruction / stall counters of the three kernels the round worked on or is judged on (tools/pmc.py: one rocprofv3 run per counter set)
 python $R/tools/pmc.py spd_ai_pairwise_kernel $OUT/pmc_headline.json -- python $R/tools/prof_spd.py 4096 10 x 3 > /dev/null 2>&1
 GABO_AB_DIMS=10 python $R/tools/pmc.py spd_ai_backward_kernel $OUT/pmc_backward.json -- python $R/tools/ab_backward.py prof > /dev/null 2>&1
-python $R/tools/pmc.py spd_tr_solve_kernel $OUT/pmc_tr_solve.json -- python $R/tools/sweep_once.py 512 > /dev/null 2>&1
+python $R/tools/pmc.py spd_tr_solve_duo_kernel $OUT/pmc_tr_solve_two_waves.json -- python $R/tools/sweep_once.py 512 > /dev/null 2>&1
+GABO_TR_DUO=0 python $R/tools/pmc.py spd_tr_solve_kernel $OUT/pmc_tr_solve.json -- python $R/tools/sweep_once.py 512 > /dev/null 2>&1
 # 2b. HBM bytes of the headline launch (FETCH_SIZE and WRITE_SIZE cannot share a pass)
 timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf2 -o f -- python $R/tools/prof_spd.py 4096 10 x 2 > /dev/null 2>&1
 timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw2 -o w -- python $R/tools/prof_spd.py 4096 10 x 2 > /dev/null 2>&1
@@ -28,6 +29,9 @@ GABO_AB_DIMS=10 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv
 cp /tmp/pb/b_kernel_stats.csv $OUT/backward_kernel_stats.csv
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/psph -o sph -- python $R/tools/prof_sphere.py 4096 400 > /dev/null 2>&1
 cp /tmp/psph/sph_kernel_stats.csv $OUT/sphere_kernel_stats.csv
+# 3b. the solve launch with one and with two waves per restart (tools/ab_duo.sh)
+bash $R/tools/ab_duo.sh > $OUT/ab_two_waves.txt 2>&1
+cd /tmp
 # 4. host timelines (no profiler)
 python $R/tools/sweep_native_phases.py 64 512 > $OUT/sweep_phases.txt 2>&1
 python $R/tools/plan_timeline.py > $OUT/sweep_host_timeline.txt 2>&1
