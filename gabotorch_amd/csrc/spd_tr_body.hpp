@@ -764,8 +764,11 @@ __device__ __forceinline__ void tr_finish_body(const TrStart& S, const double* _
 // the two as runtime flags every workspace / factor pointer is "LDS or global", i.e. a generic pointer, and its accesses are flat_load /
 // flat_store - which count in vmcnt and lgkmcnt at once, so each dependent access is a full `s_waitcnt vmcnt(0) lgkmcnt(0)` drain through
 // the memory pipeline (d = 5: 159 flat loads, 89 flat stores, 89 such drains in the kernel).  Specialised, they are ds_read / ds_write.
+#ifndef GABO_TR_SOLVE_MIN_WAVES
+#define GABO_TR_SOLVE_MIN_WAVES 1      /* A/B: 2 = at most 256 registers, two waves per SIMD (tools/ab_build.py) */
+#endif
 template <int D, int METRIC, bool LAT = false>
-__global__ __launch_bounds__(64) void spd_tr_solve_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
+__global__ __launch_bounds__(64, GABO_TR_SOLVE_MIN_WAVES) void spd_tr_solve_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
                                                           double* __restrict__ ng, double* __restrict__ delta_tr,
                                                           uint8_t* __restrict__ active, int64_t* __restrict__ iters, AcqParams P,
                                                           BuiltinCons B, void* wsbase, int64_t R, double delta_cons, double theta,

@@ -49,8 +49,33 @@ static __host__ __device__ inline SphWs sph_layout(void* base, int64_t R, int di
     return w;
 }
 
+// sum_{j < n} col[j * n] * x[j]: one output of a matrix-vector product with an n x n matrix per lane (strided_dot of spd_acq_body.hpp).  The GP factors
+// L^-1 and L^-T are stored dense with exact zeros outside their triangle, so the sum runs over ALL j: a uniform trip count, eight loads issued before the
+// FMAs that use them, four partial sums.  (Rounds 2-6a walked the triangle with a lane-dependent bound, one dependent load per term from L2: the two - in
+// the Hessian-vector evaluation four - such loops were most of an evaluation.)
+static __device__ __forceinline__ double sph_col_dot(const double* __restrict__ col, const double* __restrict__ x, int n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        double av[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = col[(j + u) * n];
+            xv[u] = x[j + u];
+        }
+        s0 = __builtin_fma(av[0], xv[0], s0); s1 = __builtin_fma(av[1], xv[1], s1);
+        s2 = __builtin_fma(av[2], xv[2], s2); s3 = __builtin_fma(av[3], xv[3], s3);
+        s0 = __builtin_fma(av[4], xv[4], s0); s1 = __builtin_fma(av[5], xv[5], s1);
+        s2 = __builtin_fma(av[6], xv[6], s2); s3 = __builtin_fma(av[7], xv[7], s3);
+    }
+    for (; j < n; ++j) s0 = __builtin_fma(col[j * n], x[j], s0);
+    return (s0 + s1) + (s2 + s3);
+}
+
 // value and (grad != nullptr) Euclidean gradient of out_sign * acquisition at x (dim doubles, global or LDS).  dyn: 3 n doubles of LDS.
-static __device__ void sph_acq_eval(const double* __restrict__ x, const SphAcq& P, double* __restrict__ value_out,
+// P.linv == P.linv_t: the caller handed over the symmetric A = (outputscale K + noise I)^-1 (gabo_gp_factor's kinv) for both: one matrix-vector
+// product per evaluation instead of two (as the SPD evaluations, spd_acq_body.hpp).
+static __device__ __forceinline__ void sph_acq_eval(const double* __restrict__ x, const SphAcq& P, double* __restrict__ value_out,
                                     double* __restrict__ grad_out, double* dyn) {
     const int64_t n = P.n;
     const int dim = P.dim;
@@ -59,6 +84,7 @@ static __device__ void sph_acq_eval(const double* __restrict__ x, const SphAcq& 
     double* vv = kd + n;
     const int lane = threadIdx.x;
     const int mode = P.flags & GABO_OUT_MASK;
+    const bool sym = P.linv != nullptr && P.linv == P.linv_t;
     const double lo = -1.0 + 1e-15, hi = 1.0 - 1e-15;       // sphere_utils_torch.py:53
     for (int64_t j = lane; j < n; j += 64) {
         double ip = 0.0;
@@ -90,10 +116,9 @@ static __device__ void sph_acq_eval(const double* __restrict__ x, const SphAcq& 
     } else {
         part = 0.0;
         for (int64_t r = lane; r < n; r += 64) {
-            double a = 0.0;
-            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(P.linv_t[j * n + r], ks[j], a);
+            const double a = sph_col_dot((sym ? P.linv : P.linv_t) + r, ks, (int)n);      // (A ks)_r, or (L^-1 ks)_r = sum_j L^-T[j][r] ks[j]
             vv[r] = a;
-            part = __builtin_fma(a, a, part);
+            part = sym ? __builtin_fma(ks[r], a, part) : __builtin_fma(a, a, part);
         }
         const double var = P.outputscale * P.kxx - wave_sum(part);
         const bool clamped = !(var > 1e-9);
@@ -109,8 +134,7 @@ static __device__ void sph_acq_eval(const double* __restrict__ x, const SphAcq& 
     __syncthreads();
     for (int64_t j = lane; j < n; j += 64) {
         double ws = 0.0;
-        if (P.kind != GABO_ACQ_POSTERIOR_MEAN)
-            for (int64_t r = j; r < n; ++r) ws = __builtin_fma(P.linv[r * n + j], vv[r], ws);
+        if (P.kind != GABO_ACQ_POSTERIOR_MEAN) ws = sym ? vv[j] : sph_col_dot(P.linv + j, vv, (int)n);      // (L^-T v)_j = sum_r L^-1[r][j] v[r]
         const double gk = P.out_sign * P.outputscale * (g_mean * P.alpha[j] - 2.0 * g_var * ws);
         kd[j] = gk * kd[j];                                                    // w_j = d/dc_j
     }
@@ -128,7 +152,7 @@ static __device__ void sph_acq_eval(const double* __restrict__ x, const SphAcq& 
 //   G_j = A_mu alpha_j - 2 A_v q_j,  G'_j = (A_mumu mu' + A_muv var') alpha_j - 2 (A_muv mu' + A_vv var') q_j - 2 A_v qd_j
 //   egrad = sum_j G_j os f'(c_j) X_j,   ehess u = sum_j [G'_j os f'(c_j) + G_j os f''(c_j) s_j] X_j
 // dyn: 7 n doubles of LDS.
-static __device__ void sph_acq_hess(const double* __restrict__ x, const double* __restrict__ u, const SphAcq& P,
+static __device__ __forceinline__ void sph_acq_hess(const double* __restrict__ x, const double* __restrict__ u, const SphAcq& P,
                                     double* __restrict__ egrad_out, double* __restrict__ ehess_out, double* dyn) {
     const int64_t n = P.n;
     const int dim = P.dim;
@@ -186,36 +210,49 @@ static __device__ void sph_acq_hess(const double* __restrict__ x, const double* 
         A_mu = sgn;
         for (int64_t j = lane; j < n; j += 64) { q[j] = 0.0; qd[j] = 0.0; }
     } else {
-        // q = L^-T (L^-1 ks), qd = L^-T (L^-1 d)
-        double pv = 0.0;
-        for (int64_t r = lane; r < n; r += 64) {
-            double a = 0.0;
-            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(P.linv_t[j * n + r], ks[j], a);
-            vv[r] = a;
-            pv = __builtin_fma(a, a, pv);
+        // q = K^-1 ks, qd = K^-1 d with d_j = os f'(c_j) s_j
+        double var;
+        if (P.linv == P.linv_t) {
+            // (the symmetric inverse A for both: two matrix-vector products instead of four)
+            double pv = 0.0;
+            for (int64_t j = lane; j < n; j += 64) {
+                const double a = sph_col_dot(P.linv + j, ks, (int)n);
+                q[j] = a;
+                pv = __builtin_fma(ks[j], a, pv);
+                vv[j] = f1[j] * sj[j];
+            }
+            var = P.outputscale * P.kxx - wave_sum(pv);
+            __syncthreads();
+            double pq = 0.0;
+            for (int64_t j = lane; j < n; j += 64) {
+                qd[j] = sph_col_dot(P.linv + j, vv, (int)n);
+                pq = __builtin_fma(q[j], vv[j], pq);
+            }
+            vard = -2.0 * wave_sum(pq);
+        } else {
+            // q = L^-T (L^-1 ks), qd = L^-T (L^-1 d)
+            double pv = 0.0;
+            for (int64_t r = lane; r < n; r += 64) {
+                const double a = sph_col_dot(P.linv_t + r, ks, (int)n);
+                vv[r] = a;
+                pv = __builtin_fma(a, a, pv);
+            }
+            var = P.outputscale * P.kxx - wave_sum(pv);
+            __syncthreads();
+            for (int64_t j = lane; j < n; j += 64) q[j] = sph_col_dot(P.linv + j, vv, (int)n);
+            __syncthreads();
+            for (int64_t j = lane; j < n; j += 64) qd[j] = f1[j] * sj[j];          // (d, staged where qd will be)
+            __syncthreads();
+            for (int64_t r = lane; r < n; r += 64) vv[r] = sph_col_dot(P.linv_t + r, qd, (int)n);
+            __syncthreads();
+            double pq = 0.0;
+            for (int64_t j = lane; j < n; j += 64) {
+                const double dj = f1[j] * sj[j];
+                qd[j] = sph_col_dot(P.linv + j, vv, (int)n);
+                pq = __builtin_fma(q[j], dj, pq);
+            }
+            vard = -2.0 * wave_sum(pq);
         }
-        const double var = P.outputscale * P.kxx - wave_sum(pv);
-        __syncthreads();
-        for (int64_t j = lane; j < n; j += 64) {
-            double a = 0.0;
-            for (int64_t r = j; r < n; ++r) a = __builtin_fma(P.linv[r * n + j], vv[r], a);
-            q[j] = a;
-        }
-        __syncthreads();
-        for (int64_t r = lane; r < n; r += 64) {
-            double a = 0.0;
-            for (int64_t j = 0; j <= r; ++j) a = __builtin_fma(P.linv_t[j * n + r], f1[j] * sj[j], a);
-            vv[r] = a;
-        }
-        __syncthreads();
-        double pq = 0.0;
-        for (int64_t j = lane; j < n; j += 64) {
-            double a = 0.0;
-            for (int64_t r = j; r < n; ++r) a = __builtin_fma(P.linv[r * n + j], vv[r], a);
-            qd[j] = a;
-            pq = __builtin_fma(q[j], f1[j] * sj[j], pq);
-        }
-        vard = -2.0 * wave_sum(pq);
         const bool clamped = !(var > 1e-9);
         const double sigma = __builtin_sqrt(clamped ? 1e-9 : var);
         const double uu = sgn * (mean - P.best_f) / sigma;
@@ -270,7 +307,7 @@ static __device__ __forceinline__ double dotg(const double* a, const double* b, 
 }
 
 // tCG + proposal + acquisition at the proposal for restart i.  lds: 6 dim doubles; dyn: 3 n doubles.
-static __device__ void sph_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta_tr,
+static __device__ __forceinline__ void sph_propose_body(const double* __restrict__ x, const double* __restrict__ g, double delta_tr,
                                         const double* __restrict__ gc, const double* __restrict__ fc, const SphAcq& P, const SphWs& w,
                                         int64_t i, int64_t R, int C, int neq, double delta_cons, double theta, double kappa,
                                         int mininner, int maxinner, double* lds, double* dyn, int exact_hessian,
@@ -393,7 +430,7 @@ static __device__ void sph_propose_body(const double* __restrict__ x, const doub
     sph_acq_eval(s0, P, w.fx_prop + i, w.eg_prop + i * dim, dyn);
 }
 
-static __device__ bool sph_update_body(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g, double* __restrict__ ng,
+static __device__ __forceinline__ bool sph_update_body(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g, double* __restrict__ ng,
                                        double* __restrict__ delta_tr, int64_t* __restrict__ iters, bool inval, const SphWs& w, int64_t i,
                                        int dim, int C, double delta_bar, double rho_prime, double rho_regularization, double mingradnorm,
                                        int64_t maxiter, bool* accepted = nullptr) {
@@ -483,6 +520,17 @@ __global__ __launch_bounds__(64) void sphere_tr_update_kernel(double* __restrict
     }
 }
 
+// LAT (the latency regime: the symmetric inverse handed over, everything fits, <= 2048 restarts): A and the per-restart workspace live in the block's LDS
+// (the solve owns its restart from the first iteration to the last: nothing in the workspace has to survive the launch), known at compile time so that
+// their accesses are ds_read / ds_write and not flat loads (see spd_tr_solve_kernel).  Dynamic LDS: 7 n + 6 dim doubles, then n^2 + the workspace of ONE restart.
+static inline size_t sph_solve_lds(int64_t n, int dim, int64_t r, bool sym, bool* lat) {
+    const size_t base = (size_t)(7 * n + 6 * dim) * sizeof(double);
+    const size_t extra = (size_t)(n * n) * sizeof(double) + ((sph_layout(nullptr, 1, dim, 0).bytes + 15) & ~(size_t)15);
+    *lat = sym && r <= 2048 && base + extra <= 56 * 1024;
+    return base + (*lat ? extra : 0);
+}
+
+template <bool LAT>
 __global__ __launch_bounds__(64) void sphere_tr_solve_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
                                                              double* __restrict__ ng, double* __restrict__ delta_tr,
                                                              uint8_t* __restrict__ active, int64_t* __restrict__ iters, SphAcq P,
@@ -493,11 +541,28 @@ __global__ __launch_bounds__(64) void sphere_tr_solve_kernel(double* __restrict_
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
     if (active[i] == 0) return;
-    SphWs w = sph_layout(wsbase, R, P.dim, 0);
+    SphAcq Ps = P;
+    SphWs w;
+    int64_t iw = i, Rw = R;
+    if constexpr (LAT) {
+        double* gl = dyn + 7 * P.n + 6 * P.dim;
+        const int64_t nn = P.n * P.n;
+        for (int64_t e = threadIdx.x; e < nn; e += 64) gl[e] = P.linv[e];
+        Ps.linv = gl;
+        Ps.linv_t = gl;
+        double* wb = gl + nn;
+        w = sph_layout(wb, 1, P.dim, 0);
+        for (size_t e = threadIdx.x; e < (w.bytes + 7) / 8; e += 64) wb[e] = 0.0;
+        iw = 0;
+        Rw = 1;
+        __syncthreads();
+    } else {
+        w = sph_layout(wsbase, R, P.dim, 0);
+    }
     bool x_unchanged = false;         // wave-uniform: the previous proposal of this launch was rejected
     int64_t rec_k = rec != nullptr ? iters[i] : 0;      // gabo_tr_solve_record: index of the outer iteration being recorded
     for (;;) {
-        sph_propose_body(x + i * P.dim, g + i * P.dim, delta_tr[i], nullptr, nullptr, P, w, i, R, 0, 0, 1e-6, theta, kappa, mininner,
+        sph_propose_body(x + i * P.dim, g + i * P.dim, delta_tr[i], nullptr, nullptr, Ps, w, iw, Rw, 0, 0, 1e-6, theta, kappa, mininner,
                          maxinner, dyn + 7 * P.n, dyn, exact_hessian, x_unchanged);
         __syncthreads();
         if (rec != nullptr && rec_k < rec_cap) {          // (the iterate, its radius and the stop reason of the tCG run that made the proposal)
@@ -505,12 +570,12 @@ __global__ __launch_bounds__(64) void sphere_tr_solve_kernel(double* __restrict_
             for (int e = threadIdx.x; e < P.dim; e += 64) rr[e] = x[i * P.dim + e];
             if (threadIdx.x == 0) {
                 rr[P.dim] = delta_tr[i];
-                rr[P.dim + 1] = (double)w.stop[i];
+                rr[P.dim + 1] = (double)w.stop[iw];
             }
         }
         ++rec_k;
         bool accepted = false;
-        const bool still = sph_update_body(x + i * P.dim, fx + i, g + i * P.dim, ng + i, delta_tr + i, iters + i, false, w, i, P.dim, 0,
+        const bool still = sph_update_body(x + i * P.dim, fx + i, g + i * P.dim, ng + i, delta_tr + i, iters + i, false, w, iw, P.dim, 0,
                                            delta_bar, rho_prime, rho_regularization, mingradnorm, maxiter, &accepted);
         if (!still) break;
         x_unchanged = !accepted;
@@ -604,10 +669,16 @@ int gabo_sphere_tr_solve(double* x, double* fx, double* grad, double* grad_norm,
     if (r == 0) return GABO_OK;
     if (!x || !fx || !grad || !grad_norm || !trust_radius || !active || !iters || !workspace) return GABO_ERR_ARG;
     if (workspace_bytes < gabo_sphere_tr_workspace_bytes(r, acq->dim, 0)) return GABO_ERR_ARG;
-    size_t lds = (size_t)(7 * acq->n + 6 * acq->dim) * sizeof(double);
-    hipLaunchKernelGGL(gabo::sphere_tr_solve_kernel, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, fx, grad, grad_norm,
-                       trust_radius, active, iters, *acq, workspace, r, theta, kappa, mininner, maxinner, delta_bar, rho_prime,
-                       rho_regularization, mingradnorm, maxiter, exact_hessian, rec, rec_cap);
+    bool lat = false;
+    const size_t lds = gabo::sph_solve_lds(acq->n, acq->dim, r, acq->linv != nullptr && acq->linv == acq->linv_t, &lat);
+    if (lat)
+        hipLaunchKernelGGL(gabo::sphere_tr_solve_kernel<true>, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, fx, grad, grad_norm,
+                           trust_radius, active, iters, *acq, workspace, r, theta, kappa, mininner, maxinner, delta_bar, rho_prime,
+                           rho_regularization, mingradnorm, maxiter, exact_hessian, rec, rec_cap);
+    else
+        hipLaunchKernelGGL(gabo::sphere_tr_solve_kernel<false>, dim3((unsigned)r), dim3(64), lds, (hipStream_t)stream, x, fx, grad, grad_norm,
+                           trust_radius, active, iters, *acq, workspace, r, theta, kappa, mininner, maxinner, delta_bar, rho_prime,
+                           rho_regularization, mingradnorm, maxiter, exact_hessian, rec, rec_cap);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
 }
 

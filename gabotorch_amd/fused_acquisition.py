@@ -181,8 +181,10 @@ class FusedAcquisition:
 
     def sphere_acq_params(self):
         """The surrogate as the gabo_sphere_acq_params struct of the C ABI."""
-        return _lib.SphereAcqParams(self.train.data_ptr(), self.train_t.data_ptr(), self.alpha.data_ptr(), self.linv.data_ptr(),
-                                    self.linv_t.data_ptr(), self.train.shape[0], self.train.shape[1], self.beta, int(self.mode), self.mean,
+        # (A = L^-T L^-1 for both factor slots when the model's cache holds it: half the matrix-vector products of an evaluation, csrc/sphere_tr.hip)
+        la, lb = (self.kinv.data_ptr(), self.kinv.data_ptr()) if self.kinv is not None else (self.linv.data_ptr(), self.linv_t.data_ptr())
+        return _lib.SphereAcqParams(self.train.data_ptr(), self.train_t.data_ptr(), self.alpha.data_ptr(), la,
+                                    lb, self.train.shape[0], self.train.shape[1], self.beta, int(self.mode), self.mean,
                                     self.outputscale, self.kxx, self.best_f, int(self.kind), 1 if self.maximize else 0, -1.0)
 
     def acq_params(self):
