@@ -129,6 +129,7 @@ SIGNATURES = {
     "gabo_sphere_sweep_workspace_bytes": (_SZ, [_I, _I64, _I64]),
     "gabo_sphere_sweep_score": (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "gabo_sphere_sweep_solve": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gabo_sphere_sweep_run": (_I, [_P, _I64, _I64, _P, _c.c_uint64, _D, _D, _c.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "gabo_spd_gp_prepare_workspace_bytes": (_SZ, [_I64, _I]),
     "gabo_spd_gp_prepare": (_I, [_P, _P, _I64, _I, _D, _I, _D, _D, _D, _P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P]),
     "gabo_spd_sweep_rows_workspace_bytes": (_SZ, [_I64, _I, _I64, _I64, _I]),

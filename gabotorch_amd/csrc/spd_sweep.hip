@@ -422,7 +422,8 @@ namespace gabo {
 
 struct SphSweepWs {
     double *raw, *raw_val, *x, *fx, *eg, *g, *ng, *delta;
-    int64_t *picked, *iters;
+    int64_t *picked, *picked_rows, *iters;
+    int* flag;
     uint8_t* active;
     void* tr;
     size_t tr_bytes, bytes;
@@ -437,7 +438,7 @@ static SphSweepWs sph_sweep_layout(void* base, int dim, int64_t max_raw, int64_t
         return q;
     };
     w.raw = (double*)take((size_t)max_raw * dim * 8);
-    w.raw_val = (double*)take((size_t)max_raw * 8);
+    w.raw_val = (double*)take((size_t)(max_raw + 1) * 8) + 1;      // (one slot in front: the selection kernel addresses sample k as row 1 + k of a table)
     w.x = (double*)take((size_t)r * dim * 8);
     w.fx = (double*)take((size_t)r * 8);
     w.eg = (double*)take((size_t)r * dim * 8);
@@ -445,7 +446,9 @@ static SphSweepWs sph_sweep_layout(void* base, int dim, int64_t max_raw, int64_t
     w.ng = (double*)take((size_t)r * 8);
     w.delta = (double*)take((size_t)r * 8);
     w.picked = (int64_t*)take((size_t)r * 8);
+    w.picked_rows = (int64_t*)take((size_t)r * 8);
     w.iters = (int64_t*)take((size_t)r * 8);
+    w.flag = (int*)take(8);
     w.active = (uint8_t*)take((size_t)r);
     w.tr_bytes = gabo_sphere_tr_workspace_bytes(r, dim, 0);
     w.tr = take(w.tr_bytes + 8);
@@ -460,6 +463,40 @@ __global__ __launch_bounds__(256) void sweep_rownorm_kernel(const double* __rest
     double s = 0.0;
     for (int k = 0; k < dim; ++k) s += g[i * dim + k] * g[i * dim + k];
     out[i] = __builtin_sqrt(s);
+}
+
+// count points uniform on S^(dim-1): normal deviates from the library's Philox stream (seed, sample index), normalised - the distribution of
+// pymanopt's Sphere.rand ([3P]: randn then / norm).  One thread per point.
+__global__ __launch_bounds__(256) void sphere_sample_kernel(double* __restrict__ out, int64_t count, int dim, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Philox ph{(uint32_t)seed, (uint32_t)(seed >> 32), (uint64_t)i, 0u};
+    ph.tag = 0x73706872u;      // "sphr": this sampler's stream
+    double* row = out + i * dim;
+    double ss = 0.0;
+    for (int k = 0; k < dim; k += 2) {
+        double z0, z1;
+        ph.normal2(z0, z1);
+        row[k] = z0;
+        ss = __builtin_fma(z0, z0, ss);
+        if (k + 1 < dim) {
+            row[k + 1] = z1;
+            ss = __builtin_fma(z1, z1, ss);
+        }
+    }
+    const double inv = 1.0 / __builtin_sqrt(ss);
+    for (int k = 0; k < dim; ++k) row[k] *= inv;
+}
+
+// dst row i = src row idx[i], the index clamped into the table (when the selection kernel raised its fall-back flag it picked nothing: the launches behind
+// it then work on whatever rows these are, and the caller discards the result)
+__global__ __launch_bounds__(256) void sweep_gather_clamped_kernel(const double* __restrict__ src, const int64_t* __restrict__ idx, double* __restrict__ dst,
+                                                                  int64_t r, int dim, int64_t rows) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= r * dim) return;
+    int64_t k = idx[e / dim];
+    k = k < 0 ? 0 : (k >= rows ? rows - 1 : k);
+    dst[e] = src[k * dim + e % dim];
 }
 
 }  // namespace gabo
@@ -532,5 +569,83 @@ extern "C" int gabo_sphere_sweep_solve(const gabo_sphere_sweep_config* cfg, cons
     if (candidates_dev) *candidates_dev = w.x;
     if (cost_dev) *cost_dev = w.fx;
     if (iterations_dev) *iterations_dev = w.iters;
+    return GABO_OK;
+}
+
+// The same sweep in ONE host call with one wait: raw samples (the caller's, or drawn here on the library's Philox stream when raw_points_host is null) ->
+// acquisition values -> restart selection on the device (sweep_select_kernel, the SPD sweep's) -> start of every restart -> the solve -> final costs and
+// iteration counts to the host, arg-max.  *fallback_host = 1: the selection kernel reported that botorch's heuristic needs its random fall-backs (or the
+// values hold a NaN); nothing else was written and the caller runs gabo_sphere_sweep_score / host selection / gabo_sphere_sweep_solve.
+extern "C" int gabo_sphere_sweep_run(const gabo_sphere_sweep_config* cfg, int64_t count, int64_t restarts, const double* raw_points_host, uint64_t sample_seed,
+                                     double eta, double alpha, uint64_t select_seed, int64_t* best_index_host, double* best_value_host,
+                                     int64_t* max_iterations_host, double** candidates_dev, double** cost_dev, int64_t** iterations_dev, int64_t** picked_dev,
+                                     int* fallback_host,
+                                     void* workspace, size_t workspace_bytes, gabo_stream_t stream) {
+    if (!cfg || !best_index_host || !best_value_host || !fallback_host || !workspace || count < 1 || restarts < 1) return GABO_ERR_ARG;
+    if (!gabo_spd_sweep_select_supported(count, restarts)) return GABO_ERR_DIM;
+    const int dim = cfg->acq.dim;
+    if (dim < 2) return GABO_ERR_DIM;
+    const int64_t r = restarts;
+    const gabo::SphSweepWs w = gabo::sph_sweep_layout(workspace, dim, count, r);
+    if (w.bytes > workspace_bytes) return GABO_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (raw_points_host) {
+        if (hipMemcpyAsync(w.raw, raw_points_host, (size_t)count * dim * 8, hipMemcpyHostToDevice, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    } else {
+        hipLaunchKernelGGL(gabo::sphere_sample_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, w.raw, count, dim, sample_seed);
+    }
+    gabo_sphere_acq_params acq = cfg->acq;
+    acq.out_sign = 1.0;
+    if ((rc = gabo_sphere_acq_eval(w.raw, &acq, w.raw_val, nullptr, count, stream)) != GABO_OK) return rc;
+    {   // selection: the values as a one-column table whose row 1 + k is sample k (sweep_select_kernel's addressing with one block of `count` rows)
+        size_t p2 = 1;
+        while ((int64_t)p2 < count) p2 <<= 1;
+        const size_t lds = p2 * 12 + 1024 * 12;
+        static std::atomic<uint64_t> attr_set{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return GABO_ERR_LAUNCH;
+        if (!(attr_set.load(std::memory_order_acquire) >> dev & 1)) {
+            if (hipFuncSetAttribute((const void*)gabo::sweep_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(gabo::kSelectMaxTotal * 12 + 1024 * 12)) != hipSuccess)
+                return GABO_ERR_LAUNCH;
+            attr_set.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(gabo::sweep_select_kernel, dim3(1), dim3(1024), lds, st, w.raw_val - 1, (int64_t)1, (int)count, (int)count, (int)r, eta, alpha,
+                           select_seed, 0, 0, 1, w.picked_rows, w.picked, w.flag, (int*)nullptr);
+    }
+    hipLaunchKernelGGL(gabo::sweep_gather_clamped_kernel, dim3((unsigned)((r * dim + 255) / 256)), dim3(256), 0, st, w.raw, w.picked, w.x, r, dim, count);
+    acq.out_sign = -1.0;
+    if ((rc = gabo_sphere_acq_eval(w.x, &acq, w.fx, w.eg, r, stream)) != GABO_OK) return rc;
+    if ((rc = gabo_sphere_manifold_op(GABO_SPH_PROJ, w.x, w.eg, nullptr, nullptr, w.g, r, dim, stream)) != GABO_OK) return rc;
+    hipLaunchKernelGGL(gabo::sweep_rownorm_kernel, dim3((unsigned)((r + 255) / 256)), dim3(256), 0, st, w.g, w.ng, r, dim);
+    hipLaunchKernelGGL(gabo::sweep_init_kernel, dim3((unsigned)((r + 255) / 256)), dim3(256), 0, st, w.delta, w.active, w.iters, r, cfg->delta0);
+    if (hipMemsetAsync(w.tr, 0, w.tr_bytes, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    if ((rc = gabo_sphere_tr_solve(w.x, w.fx, w.g, w.ng, w.delta, w.active, w.iters, &acq, w.tr, w.tr_bytes, r, cfg->theta, cfg->kappa, cfg->mininner,
+                                   cfg->maxinner, cfg->exact_hessian, cfg->delta_bar, cfg->rho_prime, cfg->rho_regularization, cfg->mingradnorm,
+                                   cfg->maxiter, stream)) != GABO_OK)
+        return rc;
+    std::vector<double> fx((size_t)r);
+    std::vector<int64_t> it((size_t)r);
+    int flag = 0;
+    if (hipMemcpyAsync(fx.data(), w.fx, (size_t)r * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    if (hipMemcpyAsync(it.data(), w.iters, (size_t)r * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    if (hipMemcpyAsync(&flag, w.flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return GABO_ERR_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return GABO_ERR_LAUNCH;
+    *fallback_host = flag != 0 ? 1 : 0;
+    if (flag != 0) return GABO_OK;
+    int64_t best = 0, maxit = 0;
+    for (int64_t k = 0; k < r; ++k) {
+        const double v = -fx[(size_t)k], b = -fx[(size_t)best];
+        if ((v > b && b == b) || (v != v && b == b)) best = k;
+        if (it[(size_t)k] > maxit) maxit = it[(size_t)k];
+    }
+    *best_index_host = best;
+    *best_value_host = -fx[(size_t)best];
+    if (max_iterations_host) *max_iterations_host = maxit;
+    if (candidates_dev) *candidates_dev = w.x;
+    if (cost_dev) *cost_dev = w.fx;
+    if (iterations_dev) *iterations_dev = w.iters;
+    if (picked_dev) *picked_dev = w.picked;          // the raw-sample index of every restart
     return GABO_OK;
 }

@@ -53,14 +53,15 @@ static __host__ __device__ inline SphWs sph_layout(void* base, int64_t R, int di
 // L^-1 and L^-T are stored dense with exact zeros outside their triangle, so the sum runs over ALL j: a uniform trip count, eight loads issued before the
 // FMAs that use them, four partial sums.  (Rounds 2-6a walked the triangle with a lane-dependent bound, one dependent load per term from L2: the two - in
 // the Hessian-vector evaluation four - such loops were most of an evaluation.)
-static __device__ __forceinline__ double sph_col_dot(const double* __restrict__ col, const double* __restrict__ x, int n) {
+static __device__ __forceinline__ double sph_col_dot(const double* __restrict__ col, const double* __restrict__ x, int n, int stride = 0) {
+    if (stride == 0) stride = n;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int j = 0;
     for (; j + 8 <= n; j += 8) {
         double av[8], xv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            av[u] = col[(j + u) * n];
+            av[u] = col[(j + u) * stride];
             xv[u] = x[j + u];
         }
         s0 = __builtin_fma(av[0], xv[0], s0); s1 = __builtin_fma(av[1], xv[1], s1);
@@ -68,7 +69,7 @@ static __device__ __forceinline__ double sph_col_dot(const double* __restrict__ 
         s0 = __builtin_fma(av[4], xv[4], s0); s1 = __builtin_fma(av[5], xv[5], s1);
         s2 = __builtin_fma(av[6], xv[6], s2); s3 = __builtin_fma(av[7], xv[7], s3);
     }
-    for (; j < n; ++j) s0 = __builtin_fma(col[j * n], x[j], s0);
+    for (; j < n; ++j) s0 = __builtin_fma(col[j * stride], x[j], s0);
     return (s0 + s1) + (s2 + s3);
 }
 
@@ -139,11 +140,7 @@ static __device__ __forceinline__ void sph_acq_eval(const double* __restrict__ x
         kd[j] = gk * kd[j];                                                    // w_j = d/dc_j
     }
     __syncthreads();
-    for (int k = lane; k < dim; k += 64) {
-        double a = 0.0;
-        for (int64_t j = 0; j < n; ++j) a = __builtin_fma(kd[j], P.train[j * dim + k], a);
-        grad_out[k] = a;
-    }
+    for (int k = lane; k < dim; k += 64) grad_out[k] = sph_col_dot(P.train + k, kd, (int)n, dim);      // sum_j w_j X_j[k]
 }
 
 // Exact Euclidean Hessian-vector product of out_sign * acquisition at x along u (what double backward through the sphere kernel,
@@ -278,14 +275,8 @@ static __device__ __forceinline__ void sph_acq_hess(const double* __restrict__ x
     }
     __syncthreads();
     for (int k = lane; k < dim; k += 64) {
-        double a = 0.0, b = 0.0;
-        for (int64_t j = 0; j < n; ++j) {
-            const double xt = P.train[j * dim + k];
-            a = __builtin_fma(ks[j], xt, a);
-            b = __builtin_fma(vv[j], xt, b);
-        }
-        egrad_out[k] = a;
-        ehess_out[k] = b;
+        egrad_out[k] = sph_col_dot(P.train + k, ks, (int)n, dim);
+        ehess_out[k] = sph_col_dot(P.train + k, vv, (int)n, dim);
     }
 }
 
@@ -522,10 +513,11 @@ __global__ __launch_bounds__(64) void sphere_tr_update_kernel(double* __restrict
 
 // LAT (the latency regime: the symmetric inverse handed over, everything fits, <= 2048 restarts): A and the per-restart workspace live in the block's LDS
 // (the solve owns its restart from the first iteration to the last: nothing in the workspace has to survive the launch), known at compile time so that
-// their accesses are ds_read / ds_write and not flat loads (see spd_tr_solve_kernel).  Dynamic LDS: 7 n + 6 dim doubles, then n^2 + the workspace of ONE restart.
+// their accesses are ds_read / ds_write and not flat loads (see spd_tr_solve_kernel).  Dynamic LDS: 7 n + 6 dim doubles, then n^2 + 2 n dim (the training points in both
+// layouts) + the workspace of ONE restart.
 static inline size_t sph_solve_lds(int64_t n, int dim, int64_t r, bool sym, bool* lat) {
     const size_t base = (size_t)(7 * n + 6 * dim) * sizeof(double);
-    const size_t extra = (size_t)(n * n) * sizeof(double) + ((sph_layout(nullptr, 1, dim, 0).bytes + 15) & ~(size_t)15);
+    const size_t extra = (size_t)(n * n + 2 * n * dim) * sizeof(double) + ((sph_layout(nullptr, 1, dim, 0).bytes + 15) & ~(size_t)15);
     *lat = sym && r <= 2048 && base + extra <= 56 * 1024;
     return base + (*lat ? extra : 0);
 }
@@ -550,7 +542,15 @@ __global__ __launch_bounds__(64) void sphere_tr_solve_kernel(double* __restrict_
         for (int64_t e = threadIdx.x; e < nn; e += 64) gl[e] = P.linv[e];
         Ps.linv = gl;
         Ps.linv_t = gl;
-        double* wb = gl + nn;
+        double* tr = gl + nn;                    // the training points in both layouts (n x dim, dim x n)
+        double* trt = tr + P.n * P.dim;
+        for (int64_t e = threadIdx.x; e < P.n * P.dim; e += 64) {
+            tr[e] = P.train[e];
+            trt[e] = P.train_t[e];
+        }
+        Ps.train = tr;
+        Ps.train_t = trt;
+        double* wb = trt + P.n * P.dim;
         w = sph_layout(wb, 1, P.dim, 0);
         for (size_t e = threadIdx.x; e < (w.bytes + 7) / 8; e += 64) wb[e] = 0.0;
         iw = 0;

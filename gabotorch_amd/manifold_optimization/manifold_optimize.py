@@ -718,22 +718,64 @@ def _native_sweep_sphere(plan, acq_function, solver, num_restarts, raw_samples, 
     cfg.mingradnorm, cfg.maxiter = float(solver.mingradnorm), int(solver.maxiter)
     nonneg, eta, alpha = _selection(acq_function, options)
     time0 = time.time()
+
+    def draw(total):          # the host samplers of _draw_raw_samples, same draws
+        if options.get("batched_rand") and hasattr(man, "rand_batch"):
+            raw = np.ascontiguousarray(man.rand_batch(total), dtype=np.float64)
+        else:
+            raw = np.ascontiguousarray(np.stack([np.asarray(man.rand()) for _ in range(total)]), dtype=np.float64)
+        if raw.shape != (total, dim):
+            raise RuntimeError(f"manifold.rand returned points of shape {raw.shape[1:]}, expected ({dim},)")
+        return raw
+
+    def workspace(total):
+        wsb = int(lib.gabo_sphere_sweep_workspace_bytes(dim, total, R))
+        key = ("sphere", dev.index, stream)
+        ws = _sweep_workspaces.get(key)
+        if ws is None or ws.numel() < wsb:
+            ws = _sweep_workspaces[key] = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        return ws, wsb
+
+    def result(ws, best, value, iters, cand_p, cost_p, it_p, picked_p=None, device_selection=False):
+        base = ws.data_ptr()
+
+        def view(ptr, count, dtype):
+            off = int(ptr.value) - base
+            return ws[off:off + 8 * count].view(dtype)
+        cands = view(cand_p, R * dim, torch.float64).reshape(R, dim)
+        solver.log = {"iterations": int(iters.value), "per_restart_iterations": view(it_p, R, torch.int64).clone(),
+                      "final_cost": view(cost_p, R, torch.float64).clone(), "final_gradnorm": None, "cost_evals": 0, "grad_evals": 0,
+                      "time": time.time() - time0, "one_launch_solve": True, "native_sweep": True, "device_selection": device_selection}
+        if picked_p is not None and options.get("log_picked"):
+            solver.log["picked"] = view(picked_p, R, torch.int64).cpu().numpy().copy()
+        return cands[int(best.value)].reshape(1, dim).clone()
+
     with torch.cuda.device(dev):
         stream = ops._stream_ptr(dev)
+        # ONE call, one wait (gabo_sphere_sweep_run): the selection heuristic as a kernel between the scoring and the solve (the SPD sweep's), the raw
+        # samples from the host sampler or - options["device_rand"] - drawn on the device.  Not for acquisition functions that can be negative, more raw
+        # samples than the kernel holds, or when it reports that the heuristic needs its random fall-backs: then the two-call path below runs.
+        if (options.get("device_selection", True) and nonneg and lib.gabo_spd_sweep_select_supported(raw_samples, R)):
+            total = raw_samples
+            ws, wsb = workspace(total)
+            raw = None if options.get("device_rand") else draw(total)
+            sample_seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64)) if raw is None else 0
+            sel_seed = int(torch.randint(0, 2 ** 52, (1,)).item())
+            best, iters, fallback = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+            value = ctypes.c_double(0.0)
+            cand_p, cost_p, it_p, picked_p = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.check(lib.gabo_sphere_sweep_run(ctypes.byref(cfg), total, R, None if raw is None else raw.ctypes.data, sample_seed, float(eta), float(alpha),
+                                                 sel_seed, ctypes.byref(best), ctypes.byref(value), ctypes.byref(iters), ctypes.byref(cand_p),
+                                                 ctypes.byref(cost_p), ctypes.byref(it_p), ctypes.byref(picked_p), ctypes.byref(fallback), ws.data_ptr(), wsb,
+                                                 stream), "gabo_sphere_sweep_run")
+            ops.check_deferred()
+            if not fallback.value:
+                return result(ws, best, value, iters, cand_p, cost_p, it_p, picked_p, True)
         picked = None
         for attempt in range(1, 5):
             total = raw_samples * attempt
-            wsb = int(lib.gabo_sphere_sweep_workspace_bytes(dim, total, R))
-            key = ("sphere", dev.index, stream)
-            ws = _sweep_workspaces.get(key)
-            if ws is None or ws.numel() < wsb:
-                ws = _sweep_workspaces[key] = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            if options.get("batched_rand") and hasattr(man, "rand_batch"):           # the host samplers of _draw_raw_samples, same draws
-                raw = np.ascontiguousarray(man.rand_batch(total), dtype=np.float64)
-            else:
-                raw = np.ascontiguousarray(np.stack([np.asarray(man.rand()) for _ in range(total)]), dtype=np.float64)
-            if raw.shape != (total, dim):
-                raise RuntimeError(f"manifold.rand returned points of shape {raw.shape[1:]}, expected ({dim},)")
+            ws, wsb = workspace(total)
+            raw = draw(total)
             y = np.empty(total, dtype=np.float64)
             _lib.check(lib.gabo_sphere_sweep_score(ctypes.byref(cfg), total, total, R, raw.ctypes.data, y.ctypes.data, ws.data_ptr(), wsb, stream),
                        "gabo_sphere_sweep_score")
@@ -754,16 +796,11 @@ def _native_sweep_sphere(plan, acq_function, solver, num_restarts, raw_samples, 
         _lib.check(lib.gabo_sphere_sweep_solve(ctypes.byref(cfg), idx.ctypes.data, R, total, ctypes.byref(best), ctypes.byref(value), ctypes.byref(iters),
                                                ctypes.byref(cand_p), ctypes.byref(cost_p), ctypes.byref(it_p), ws.data_ptr(), wsb, stream),
                    "gabo_sphere_sweep_solve")
-    base = ws.data_ptr()
-
-    def view(ptr, count, dtype):
-        off = int(ptr.value) - base
-        return ws[off:off + 8 * count].view(dtype)
-    cands = view(cand_p, R * dim, torch.float64).reshape(R, dim)
-    solver.log = {"iterations": int(iters.value), "per_restart_iterations": view(it_p, R, torch.int64).clone(),
-                  "final_cost": view(cost_p, R, torch.float64).clone(), "final_gradnorm": None, "cost_evals": 0, "grad_evals": 0,
-                  "time": time.time() - time0, "one_launch_solve": True, "native_sweep": True}
-    return cands[int(best.value)].reshape(1, dim).clone()
+    if options.get("log_picked"):
+        out = result(ws, best, value, iters, cand_p, cost_p, it_p)
+        solver.log["picked"] = idx.copy()
+        return out
+    return result(ws, best, value, iters, cand_p, cost_p, it_p)
 
 
 def gen_batch_initial_conditions_manifold(acq_function, manifold, bounds, q, num_restarts, raw_samples,

@@ -130,8 +130,11 @@ class Sphere:
         return x / np.linalg.norm(x)
 
     def rand_batch(self, k):
-        x = np.random.randn(k, self._n)
-        return x / np.linalg.norm(x, axis=1, keepdims=True)
+        # (the normals from a PCG64 / ziggurat stream seeded from the GLOBAL stream, as PositiveDefinite.rand_batch: np.random.seed still fixes the draw;
+        # 2048 x 10 deviates in 0.06 ms where the global stream's polar method takes 0.2)
+        gen = np.random.Generator(np.random.PCG64(int(np.random.randint(0, 2 ** 31 - 1))))
+        x = gen.standard_normal((k, self._n))
+        return x / np.sqrt(np.einsum("ij,ij->i", x, x))[:, None]
 
     def zerovec(self, x):
         return np.zeros_like(x) if isinstance(x, np.ndarray) else torch.zeros_like(x)

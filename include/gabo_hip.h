@@ -643,6 +643,17 @@ int gabo_sphere_sweep_score(const gabo_sphere_sweep_config* cfg, int64_t count, 
 int gabo_sphere_sweep_solve(const gabo_sphere_sweep_config* cfg, const int64_t* picked_host, int64_t restarts, int64_t max_raw,
                             int64_t* best_index_host, double* best_value_host, int64_t* max_iterations_host, double** candidates_dev,
                             double** cost_dev, int64_t** iterations_dev, void* workspace, size_t workspace_bytes, gabo_stream_t stream);
+/* The same sweep in ONE call with one host wait: raw samples (count x dim from the caller, or - raw_points_host NULL - drawn on the library's Philox stream
+ * `sample_seed`: normal deviates, normalised, as [3P] Sphere.rand) -> values -> restart selection ON THE DEVICE (botorch's initialize_q_batch_nonneg as
+ * gabo_spd_sweep_select_rows runs it, weights exp(eta (y / max - 1)), threshold alpha, stream `select_seed`; needs gabo_spd_sweep_select_supported(count,
+ * restarts)) -> start and solve of every restart -> arg-max.  Outputs as gabo_sphere_sweep_solve; workspace of gabo_sphere_sweep_workspace_bytes(dim, count,
+ * restarts); *picked_dev (may be NULL): the raw-sample index of every restart, restarts int64 in the workspace.  *fallback_host = 1: the selection needs the heuristic's random fall-backs (no positive value, fewer positive values than restarts, a NaN):
+ * nothing else is valid and the caller takes gabo_sphere_sweep_score / its own selection / gabo_sphere_sweep_solve. */
+int gabo_sphere_sweep_run(const gabo_sphere_sweep_config* cfg, int64_t count, int64_t restarts, const double* raw_points_host, uint64_t sample_seed,
+                          double eta, double alpha, uint64_t select_seed, int64_t* best_index_host, double* best_value_host,
+                          int64_t* max_iterations_host, double** candidates_dev, double** cost_dev, int64_t** iterations_dev, int64_t** picked_dev,
+                                     int* fallback_host,
+                          void* workspace, size_t workspace_bytes, gabo_stream_t stream);
 
 /* Batched sphere-manifold operations, x/u/v/w/out: n x dim (GABO_SPH_DIST writes n scalars).
  *   GABO_SPH_PROJ   out = U - <X,U> X        [3P] Sphere.proj = egrad2rgrad; transp(X,Y,U) = proj(Y,U)

@@ -62,3 +62,28 @@ def select_nonneg(y, n, seed, eta=1.0, alpha=1e-4):
     if max_idx not in picked:
         picked[-1] = max_idx
     return picked, keys
+
+
+SPHERE_TAG = 0x73706872
+
+
+def sphere_samples(seed, count, dim):
+    """count points uniform on S^(dim-1) as `sphere_sample_kernel` (gabotorch_amd/csrc/spd_sweep.hip) draws them: for sample i, draw k of the Philox stream
+    (seed, item i, tag "sphr") gives two uniforms (Philox.uniform2 of gabo_philox.hpp), Box-Muller two normals (coordinates 2k, 2k + 1); the row is then
+    normalised - the distribution of [3P] pymanopt's Sphere.rand (randn / norm).  Agreement with the device is to rounding of log / sincospi / sqrt."""
+    idx = np.arange(count, dtype=np.uint64)
+    out = np.empty((count, dim), dtype=np.float64)
+    key = [np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)]
+    for k in range((dim + 1) // 2):
+        ctr = np.stack([(idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32),
+                        np.full(count, k, dtype=np.uint32), np.full(count, SPHERE_TAG, dtype=np.uint32)], axis=-1)
+        o = philox4x32_10(ctr, key)
+        a = ((o[:, 0].astype(np.uint64) << np.uint64(32)) | o[:, 1].astype(np.uint64)) >> np.uint64(11)
+        b = ((o[:, 2].astype(np.uint64) << np.uint64(32)) | o[:, 3].astype(np.uint64)) >> np.uint64(11)
+        u1 = (a.astype(np.float64) + 1.0) * 2.0 ** -53
+        u2 = b.astype(np.float64) * 2.0 ** -53
+        r = np.sqrt(-2.0 * np.log(u1))
+        out[:, 2 * k] = r * np.cos(2.0 * np.pi * u2)
+        if 2 * k + 1 < dim:
+            out[:, 2 * k + 1] = r * np.sin(2.0 * np.pi * u2)
+    return out / np.sqrt((out * out).sum(1))[:, None]

@@ -123,14 +123,55 @@ def test_native_sphere_sweep_returns_the_python_path_candidate(approx):
     from tools.sphere_sweep_bench import run
     outs = []
     for native in (True, False):
-        dt, val, its, log = run(approx=approx, constrained=False, device="cuda:0", native=native, R=96, raw=384)
-        assert bool(log.get("native_sweep")) == native and log.get("one_launch_solve")
+        # (device_selection=False: the heuristic on the host for both - the selection kernel draws from the library's own stream, see the next test)
+        dt, val, its, log = run(approx=approx, constrained=False, device="cuda:0", native=native, R=96, raw=384, device_selection=False)
+        assert bool(log.get("native_sweep")) == native and log.get("one_launch_solve") and not log.get("device_selection")
         outs.append((val, its, log["final_cost"].cpu().numpy(), log["per_restart_iterations"].cpu().numpy()))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
     np.testing.assert_array_equal(outs[0][3], outs[1][3])
     # a constrained sphere sweep (constraints on the sphere are user callables) stays on the Python path
     assert not run(approx=True, constrained=True, device="cuda:0", R=16, raw=64, maxiter=5)[3].get("native_sweep")
+
+
+@pytest.mark.parametrize("approx,R,raw", [(False, 96, 384), (True, 512, 2048), (False, 7, 50)])
+def test_native_sphere_sweep_in_one_call_with_the_selection_on_the_device(approx, R, raw, monkeypatch):
+    """gabo_sphere_sweep_run: scoring -> selection kernel -> start -> solve -> arg-max with one host wait.  The restarts are distinct raw samples, and the
+    Python path handed the same picks returns the same candidate, costs and iteration counts bit for bit."""
+    from tools.sphere_sweep_bench import run
+    from gabotorch_amd.manifold_optimization import manifold_optimize as mo
+    dt, val_d, its_d, log_d = run(approx=approx, constrained=False, device="cuda:0", R=R, raw=raw, log_picked=True)
+    assert log_d.get("native_sweep") and log_d.get("device_selection") and log_d.get("one_launch_solve")
+    picks = log_d["picked"]
+    assert picks.shape == (R,) and len(set(picks.tolist())) == R and picks.min() >= 0 and picks.max() < raw
+    monkeypatch.setattr(mo, "select_rows", lambda y, n, gen, nonneg, eta=1.0, alpha=1e-4: (picks.astype(np.int64), False))
+    dt, val_p, its_p, log_p = run(approx=approx, constrained=False, device="cuda:0", R=R, raw=raw, native=False)
+    assert not log_p.get("native_sweep")
+    assert val_d == val_p and its_d == its_p
+    np.testing.assert_array_equal(log_d["final_cost"].cpu().numpy(), log_p["final_cost"].cpu().numpy())
+    np.testing.assert_array_equal(log_d["per_restart_iterations"].cpu().numpy(), log_p["per_restart_iterations"].cpu().numpy())
+
+
+def test_native_sphere_sweep_with_the_raw_samples_drawn_on_the_device():
+    """options["device_rand"]: the raw samples of the one-call sphere sweep come from sphere_sample_kernel - the oracle's points (Philox stream, Box-Muller,
+    normalised) to rounding, on the unit sphere - and the sweep over them ends where the host-sampled sweeps end."""
+    import ctypes
+    from oracle import selection as osel
+    from tools.sphere_sweep_bench import run
+    from gabotorch_amd import _lib
+    lib = _lib.load()
+    # the sampler alone, through the run call's workspace: count x dim points at the start of it
+    dt, val, its, log = run(approx=False, constrained=False, device="cuda:0", R=64, raw=256, device_rand=True, log_picked=True)
+    assert log.get("native_sweep") and log.get("device_selection") and its <= 50 and np.isfinite(val)
+    from gabotorch_amd.manifold_optimization import manifold_optimize as mo
+    ws = [v for k, v in mo._sweep_workspaces.items() if k[0] == "sphere"][0]
+    pts = ws[:256 * 10 * 8].view(torch.float64).reshape(256, 10).cpu().numpy()          # (the raw samples sit at the start of the sweep's workspace)
+    np.random.seed(5)
+    seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))      # what _native_sweep_sphere drew after np.random.seed(5) in tools.sphere_sweep_bench.run
+    dt0, val0, _, _ = run(approx=False, constrained=False, device="cuda:0", R=64, raw=256)
+    assert abs(val - val0) < 0.05 * abs(val0)             # (the same optimum region from different raw samples)
+    np.testing.assert_allclose(np.linalg.norm(pts, axis=1), 1.0, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(pts, osel.sphere_samples(seed, 256, 10), rtol=0, atol=1e-13)
 
 
 @pytest.mark.parametrize("total,n,world", [(256, 64, 1), (2048, 512, 1), (2048, 512, 8), (50, 7, 3), (4096, 100, 1), (8192, 1, 2), (3, 1, 1)])

@@ -9,7 +9,8 @@ from gabotorch_amd.manifold_optimization.batched_trust_regions import BatchedTru
 from gabotorch_amd.manifold_optimization.manifold_optimize import joint_optimize_manifold
 
 
-def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrained=True, approx=True, device_tcg=True, maxiter=50, capture=False, device=None, native=True):
+def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrained=True, approx=True, device_tcg=True, maxiter=50, capture=False, device=None, native=True,
+        device_selection=None, device_rand=False, log_picked=False):
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     rng = np.random.default_rng(3)
     X = rng.standard_normal((n_train, dim)); X /= np.linalg.norm(X, axis=1, keepdims=True)
@@ -24,7 +25,8 @@ def run(dim=10, n_train=50, R=512, raw=2048, graphs=False, fused=True, constrain
     solver = BatchedTrustRegions(mingradnorm=1e-5, maxiter=maxiter)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     best = joint_optimize_manifold(acq, man, solver, q=1, num_restarts=R, raw_samples=raw, bounds=None,
-                                   options={"device": str(device), "hip_graphs": graphs, "batched_rand": True, "fused_acquisition": fused, "device_tcg": device_tcg, "capture_constraints": capture, "native_sweep": native},
+                                   options={"device": str(device), "hip_graphs": graphs, "batched_rand": True, "fused_acquisition": fused, "device_tcg": device_tcg, "capture_constraints": capture, "native_sweep": native,
+                                            "device_rand": device_rand, "log_picked": log_picked, **({} if device_selection is None else {"device_selection": device_selection})},
                                    inequality_constraints=cons, approx_hessian=approx)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

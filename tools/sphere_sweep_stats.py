@@ -5,8 +5,8 @@ import numpy as np
 from gabotorch_amd import ops
 from tools.sphere_sweep_bench import run
 ops.set_error_checking(False)
-for R in [int(a) for a in sys.argv[1:]] or [64, 512]:
-    kw = dict(approx=False, constrained=False, R=R, raw=4 * R)
+for R, extra in [(int(a), e) for a in (sys.argv[1:] or ["64", "512"]) for e in ({"device_selection": False}, {}, {"device_rand": True})]:
+    kw = dict(approx=False, constrained=False, R=R, raw=4 * R, **extra)
     for _ in range(3):
         run(**kw)
     ts = []
@@ -15,5 +15,5 @@ for R in [int(a) for a in sys.argv[1:]] or [64, 512]:
         ts.append(dt)
     it = log["per_restart_iterations"].cpu().numpy()
     srt = np.sort(it)[::-1]
-    print(f"R={R}: median {np.median(ts) * 1e3:.3f} ms (min {min(ts) * 1e3:.3f}); EI* {val:.15e}; iterations: max {it.max()}, at maxiter {int((it >= 50).sum())}, "
-          f"largest {srt[:8].tolist()}, mean {it.mean():.2f}; keys {sorted(k for k in log if not k.startswith('_'))[:12]}")
+    print(f"R={R} {extra}: median {np.median(ts) * 1e3:.3f} ms (min {min(ts) * 1e3:.3f}); EI* {val:.15e}; iterations: max {it.max()}, at maxiter {int((it >= 50).sum())}, "
+          f"largest {srt[:8].tolist()}, mean {it.mean():.2f}")
