@@ -42,7 +42,7 @@ template <int D>
 struct AcqLds {
     static constexpr int T = tri_size(D);
     double acc[T * 64];
-    double vls[(D <= 8) ? 64 : D * D * 64];      // eigenvector columns of the lanes: only when they do not live in registers
+    double vls[(D <= 8) ? 2 : D * D * 64];       // eigenvector columns of the lanes: only when they do not live in registers (D > 8)
     double red[T];
     double wl[T];
 };

@@ -67,7 +67,7 @@ int tr_solve_dispatch(const SolveArgs& a0) {
 
 bool tr_solve_uses_global_workspace(const AcqParams& P, int64_t r, int d, int C, size_t nested_bytes) {
     int stage_gp = 0, ws_lds = 0;
-    tr_solve_dynamic_lds(P.n, r, d, C, &stage_gp, &ws_lds, nested_bytes);
+    tr_solve_dynamic_lds(P.n, r, d, C, &stage_gp, &ws_lds, nested_bytes, nullptr, tr_factor_count(P));
     return !ws_lds;
 }
 }  // namespace gabo
@@ -144,7 +144,8 @@ int gabo_spd_tr_solve_supported(const gabo_spd_acq_params* acq, int64_t r, int d
 #else
     const bool has_factors = acq->linv && acq->linv_t;
 #endif
-    return gabo::solve_supported(metric == GABO_METRIC_LOG_EUCLIDEAN ? 1 : metric == GABO_METRIC_FROBENIUS ? 2 : 0, acq->n, r, d, n_constraints, has_factors, nested_bytes) ? 1 : 0;
+    return gabo::solve_supported(metric == GABO_METRIC_LOG_EUCLIDEAN ? 1 : metric == GABO_METRIC_FROBENIUS ? 2 : 0, acq->n, r, d, n_constraints, has_factors, nested_bytes,
+                                 gabo::tr_factor_count(*acq)) ? 1 : 0;
 }
 
 int gabo_tr_solve_record(double* buffer, int64_t max_iterations) {

@@ -470,9 +470,13 @@ static __device__ __forceinline__ AcqParams stage_gp_factors(const AcqParams& P,
 // dynamic LDS bytes of the trust-region kernels and whether the GP factors are staged: when they fit (total LDS of a block below 64 KB)
 // and the launch is in the latency regime.  With thousands of restarts the CUs are full and LDS capacity limits the blocks per CU:
 // measured per propose launch, staged vs not: 113 vs 137 us at 512 restarts, 242 vs 209 at 2048, 757 vs 689 at 8192.
-static inline size_t tr_dynamic_lds(int64_t n, int64_t restarts, int* stage_gp) {
-    const size_t base = (size_t)(3 * n) * sizeof(double), staged = (size_t)(2 * n * n) * sizeof(double);
-    *stage_gp = (base + staged <= 48 * 1024 && restarts <= 1024) ? 1 : 0;
+// factors: how many n x n matrices are staged - 2 (L^-1 and L^-T), or 1 when the caller handed over the symmetric inverse for both (tr_factor_count).  With one
+// (20 KB at n = 50) the block's LDS no longer decides how many blocks a CU holds (four waves of 512 registers do), so the restart limit does not apply:
+// 1024 restarts run in one round instead of two (sweep 1.60 -> 0.95 ms), and the LDS-resident forms serve every restart count.
+static __host__ __device__ inline int tr_factor_count(const AcqParams& P) { return (P.linv != nullptr && P.linv == P.linv_t) ? 1 : 2; }
+static inline size_t tr_dynamic_lds(int64_t n, int64_t restarts, int* stage_gp, int factors = 2) {
+    const size_t base = (size_t)(3 * n) * sizeof(double), staged = (size_t)(factors * n * n) * sizeof(double);
+    *stage_gp = (base + staged <= 48 * 1024 && (restarts <= 1024 || (factors == 1 && base + staged <= 24 * 1024))) ? 1 : 0;
     return base + (*stage_gp ? staged : 0);
 }
 
@@ -482,11 +486,12 @@ static inline size_t tr_dynamic_lds(int64_t n, int64_t restarts, int* stage_gp) 
 // when it fits next to the staged GP factors (static LDS of the kernel is below 12 KB for d <= 8).
 // nested_bytes: LDS of the nested eigenvalue constraints (nested_extremes_lds_doubles), placed last; *nested_off receives its offset.
 static inline size_t tr_solve_dynamic_lds(int64_t n, int64_t restarts, int d, int C, int* stage_gp, int* ws_lds, size_t nested_bytes = 0,
-                                          int* nested_off = nullptr) {
-    size_t bytes = tr_dynamic_lds(n, restarts, stage_gp);
+                                          int* nested_off = nullptr, int factors = 2) {
+    size_t bytes = tr_dynamic_lds(n, restarts, stage_gp, factors);
     bytes = (bytes + 15) & ~(size_t)15;
     const size_t ws = tr_layout(nullptr, 1, d, C, n).bytes + 16;
-    *ws_lds = (restarts <= 1024 && bytes + ws + nested_bytes <= 52 * 1024) ? 1 : 0;
+    // (beyond 1024 restarts only while four blocks still fit a CU's 160 KB next to the ~10 KB of static LDS: 30 KB of dynamic LDS)
+    *ws_lds = ((restarts <= 1024 || (factors == 1 && bytes + ws + nested_bytes <= 30 * 1024)) && bytes + ws + nested_bytes <= 52 * 1024) ? 1 : 0;
     bytes += (*ws_lds ? ws : 0);
     bytes = (bytes + 15) & ~(size_t)15;
     if (nested_off) *nested_off = (int)bytes;
@@ -779,7 +784,9 @@ __global__ __launch_bounds__(64, GABO_TR_SOLVE_MIN_WAVES) void spd_tr_solve_kern
     static_assert(D <= 8, "built-in constraints use the register eigen-solver");
     constexpr int dd = D * D;
     __shared__ AcqLds<D> acq;
-    __shared__ __attribute__((aligned(16))) double mats[5 * dd + kJacobiScratch];
+    // (five tiles; the eigen-solvers' LDS scratch behind them is only used above d = 8.  Every byte counts here: with the symmetric inverse staged a block is
+    // 39 KB at d = 5, n = 50, and FOUR blocks - one wave of 512 registers per SIMD - have to fit a CU's 160 KB for 1024 restarts to run in one round)
+    __shared__ __attribute__((aligned(16))) double mats[5 * dd + 8];
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int64_t i = blockIdx.x;
     // (the sweep's START is a launch of its own, spd_tr_start_kernel below: compiled into this kernel - one more inlined acquisition evaluation in a
@@ -814,7 +821,7 @@ __global__ __launch_bounds__(64, GABO_TR_SOLVE_MIN_WAVES) void spd_tr_solve_kern
     TrWs t;
     int64_t iw = i, Rw = R;
     if (ws_lds) {
-        size_t off = (size_t)(3 * P.n + (stage_gp ? 2 * P.n * P.n : 0)) * sizeof(double);
+        size_t off = (size_t)(3 * P.n + (stage_gp ? tr_factor_count(P) * P.n * P.n : 0)) * sizeof(double);
         off = (off + 15) & ~(size_t)15;
         char* base = (char*)dyn + off;
         t = tr_layout(base, 1, D, C, P.n);
@@ -1014,7 +1021,7 @@ static int launch_propose_one(const double* x, const double* g, const double* de
                               double delta_cons, double theta, double kappa, int mininner, int maxinner, int* any_active, int* status,
                               hipStream_t st) {
     int stage_gp = 0;
-    size_t lds = tr_dynamic_lds(P.n, r, &stage_gp);
+    size_t lds = tr_dynamic_lds(P.n, r, &stage_gp, tr_factor_count(P));
     hipLaunchKernelGGL((spd_tr_propose_kernel<D, METRIC>), dim3((unsigned)r), dim3(64), lds, st, x, g, delta_tr, active, gc, fc, P, ws,
                        x_prop, r, c, neq, delta_cons, theta, kappa, mininner, maxinner, any_active, status, stage_gp);
     return hipGetLastError() == hipSuccess ? GABO_OK : GABO_ERR_LAUNCH;
@@ -1086,9 +1093,9 @@ struct SolveArgs {
 static constexpr bool solve_needs_lds_workspace(int metric, int d) { return metric == 1 && d > GABO_LE_MAX_GENERIC_DIM; }
 
 // whether dispatch_solve would launch for this problem (the same sizing decisions)
-static inline bool solve_supported(int metric, int64_t n, int64_t r, int d, int C, bool has_factors, size_t nested_bytes) {
+static inline bool solve_supported(int metric, int64_t n, int64_t r, int d, int C, bool has_factors, size_t nested_bytes, int factors = 2) {
     int stage_gp = 0, ws_lds = 0;
-    const size_t lds = tr_solve_dynamic_lds(n, r, d, C, &stage_gp, &ws_lds, nested_bytes);
+    const size_t lds = tr_solve_dynamic_lds(n, r, d, C, &stage_gp, &ws_lds, nested_bytes, nullptr, factors);
     if (lds > 64 * 1024 || d < 2 || d > 8) return false;
     const bool lat = stage_gp && ws_lds && has_factors;
     return lat || !solve_needs_lds_workspace(metric, d);
@@ -1098,7 +1105,7 @@ template <int METRIC, int DMIN = 2, int DMAX = 8>
 static int dispatch_solve(const SolveArgs& a) {
     int stage_gp = 0, ws_lds = 0, nested_off = 0;
     const size_t nested_bytes = builtin_has_kind(a.B, true) ? nested_extremes_lds_doubles(a.B.big_dim, a.d) * sizeof(double) : 0;
-    size_t lds = tr_solve_dynamic_lds(a.P->n, a.r, a.d, a.B.n, &stage_gp, &ws_lds, nested_bytes, &nested_off);
+    size_t lds = tr_solve_dynamic_lds(a.P->n, a.r, a.d, a.B.n, &stage_gp, &ws_lds, nested_bytes, &nested_off, tr_factor_count(*a.P));
     if (lds > 64 * 1024) return GABO_ERR_ARG;
 #ifdef GABO_TR_NO_LAT    /* A/B: the runtime-flag kernel everywhere */
     const bool lat = false;
@@ -1115,7 +1122,7 @@ static int dispatch_solve(const SolveArgs& a) {
         if constexpr (DD >= DMIN && DD <= DMAX) {                                                                                  \
             if (a.start.raw_rows != nullptr) {                                                                                     \
                 int sgp = 0;                                                                                                       \
-                const size_t slds = tr_dynamic_lds(a.P->n, a.r, &sgp);                                                             \
+                const size_t slds = tr_dynamic_lds(a.P->n, a.r, &sgp, tr_factor_count(*a.P));                                      \
                 hipLaunchKernelGGL((spd_tr_start_kernel<DD, METRIC>), dim3((unsigned)a.r), dim3(64), slds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, \
                                    a.active, a.iters, *a.P, a.ws, a.r, a.B.n, a.status, sgp, a.start);                             \
             }                                                                                                                      \

@@ -80,7 +80,7 @@ template <int D>
 static int launch_duo(const SolveArgs& a) {
     if (a.start.raw_rows != nullptr) {
         int sgp = 0;
-        const size_t slds = tr_dynamic_lds(a.P->n, a.r, &sgp);
+        const size_t slds = tr_dynamic_lds(a.P->n, a.r, &sgp, tr_factor_count(*a.P));
         hipLaunchKernelGGL((spd_tr_start_kernel<D, 0>), dim3((unsigned)a.r), dim3(64), slds, a.st, a.x, a.fx, a.g, a.ng, a.delta_tr, a.active, a.iters,
                            *a.P, a.ws, a.r, a.B.n, a.status, sgp, a.start);
     }
