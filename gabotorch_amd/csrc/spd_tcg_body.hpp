@@ -546,7 +546,8 @@ static __device__ bool tcg_step_core(const TcgVecs& v, int L, int C, double* Hd,
     // ---- residual small enough
     if (iter >= mininner) {
         const double nr0 = sc[SC_NORM_R0];
-        const double p = pow(nr0, theta);
+        // (theta = 1 - pymanopt's default, the reference's setting - needs no pow: ~300 dependent instructions of every tCG step)
+        const double p = theta == 1.0 ? nr0 : pow(nr0, theta);
         const double target = nr0 * (p < kappa ? p : kappa);
         if (norm_r <= target) {
             stop = kappa < p ? TCG_REACHED_TARGET_LINEAR : TCG_REACHED_TARGET_SUPERLINEAR;
