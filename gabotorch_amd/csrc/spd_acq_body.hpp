@@ -337,6 +337,240 @@ __device__ GABO_ACQ_INLINE void acq_eval(const double* __restrict__ xrow, const 
 #endif
 }
 
+// ---- acq_eval<D> split between TWO waves (the two-wave trust-region solve, spd_tr_duo_body.hpp: used while one of its waves would otherwise idle) ---------------
+// The evaluation is one dependent chain per lane: M_j -> eigen-decomposition with vectors (13 k cycles at D = 5) -> logm(M_j) -> posterior -> weights -> weighted sum ->
+// congruence.  But the posterior and the weights need the EIGENVALUES only (a third of the eigen-solver), and logm(M_j) needs nothing of the posterior:
+//   helper wave:  acq_eval_values    M_j, eigenvalues (sym_eig_reg_values: the bits of the full solver), kernel values, posterior, acquisition VALUE, weights w_j -> wts[n]
+//   owner wave:   acq_eval_vectors   M_j, eigen-decomposition, logm(M_j) -> F           ... barrier (the caller's) ...
+//                 acq_eval_finish    S = sum_j w_j logm(M_j), gradient = -2 W^T S W
+// The statements are acq_eval's, in its order, so value and gradient are its bits; each wave has its own AcqLds / 3 n doubles / W.  D <= 8, n <= 64 lanes per pass as there.
+template <int D>
+__device__ __forceinline__ void acq_eval_pair_matrix(const double* __restrict__ Gj, int64_t n, const double* __restrict__ w, double (&m)[tri_size(D)]) {
+    constexpr int T = tri_size(D);
+    static_for<T>([&](auto ee) { m[decltype(ee)::value] = 0.0; });
+    static_for<D>([&](auto cc) {
+        constexpr int col = decltype(cc)::value;
+        double g[D - col], c[D - col];
+        static_for<D - col>([&](auto kk) { g[decltype(kk)::value] = Gj[(int64_t)tri(col + decltype(kk)::value, col) * n]; });
+        static_for<D - col>([&](auto rr) {
+            constexpr int r = col + decltype(rr)::value;
+            double a = w[tri(r, col)] * g[0];
+            static_for<r - col>([&](auto kk) {
+                constexpr int k = col + 1 + decltype(kk)::value;
+                a = __builtin_fma(w[tri(r, k)], g[k - col], a);
+            });
+            c[r - col] = a;
+        });
+        static_for<D - col>([&](auto rr) {
+            constexpr int r = col + decltype(rr)::value;
+            static_for<r - col + 1>([&](auto qq) {
+                constexpr int q = col + decltype(qq)::value;
+                m[tri(r, q)] = __builtin_fma(c[r - col], c[q - col], m[tri(r, q)]);
+            });
+        });
+    });
+}
+
+template <int D>
+__device__ __forceinline__ void acq_eval_candidate_side(const double* __restrict__ xrow, AcqLds<D>& L, int* __restrict__ status, int64_t index) {
+    constexpr int T = tri_size(D);
+    double a[T], w[T];
+    const bool bad = mandel_cholesky<D>(xrow, a);
+    if (bad && threadIdx.x == 0 && status) {
+        if (atomicCAS(status, 0, GABO_ERR_NOT_SPD) == 0) status[1] = (int)index;
+    }
+    lower_inverse<D>(a, w);
+    if (threadIdx.x == 0) static_for<T>([&](auto ee) { L.wl[decltype(ee)::value] = w[decltype(ee)::value]; });
+    __syncthreads();
+}
+
+template <int D>
+__device__ __forceinline__ void acq_eval_values(const double* __restrict__ xrow, const AcqParams& P, double* __restrict__ value_out, double* __restrict__ wts,
+                                                AcqLds<D>& L, double* dyn, int* __restrict__ status, int64_t index) {
+    static_assert(D <= 8, "register eigen-solver");
+    constexpr int T = tri_size(D);
+    const double* __restrict__ G = P.train_factors;
+    const double* __restrict__ alpha = P.alpha;
+    const double* __restrict__ linv = P.linv;
+    const double* __restrict__ linv_t = P.linv_t;
+    const int64_t n = P.n;
+    const double beta = P.beta, mean0 = P.mean, os = P.outputscale, kxx = P.kxx, best_f = P.best_f, out_sign = P.out_sign;
+    const int mode = P.flags & GABO_OUT_MASK, kind = P.kind, maximize = P.maximize;
+    double* ks = dyn;
+    double* kd = ks + n;
+    double* vv = kd + n;
+    const int lane = threadIdx.x;
+    acq_eval_candidate_side<D>(xrow, L, status, index);
+    const double* w = L.wl;
+    const LogRegs logc = LogRegs::load();
+    const bool sym_inverse = linv != nullptr && linv == linv_t;
+    for (int64_t j0 = 0; j0 < n; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const bool live = j < n;
+        double m[T];
+        acq_eval_pair_matrix<D>(G + (live ? j : n - 1), n, w, m);
+        double lam[D];
+        sym_eig_reg_values<D>(m, lam);
+        double s = 0.0;
+        static_for<D>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const double lgk = log_pos(lam[k], logc);
+            s = __builtin_fma(lgk, lgk, s);
+        });
+        const double d2 = s + 1e-15;
+        const double dist = __builtin_sqrt(d2);
+        double kj, dk;
+        if (mode == GABO_OUT_GAUSSIAN) {
+            kj = exp(-((dist * dist) * beta));
+            dk = -beta * kj;
+        } else {
+            kj = exp(-(dist * beta));
+            dk = -beta * kj / (2.0 * dist);
+        }
+        if (live) {
+            ks[j] = os * kj;
+            kd[j] = dk;
+        }
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int64_t j = lane; j < n; j += 64) part = __builtin_fma(ks[j], alpha[j], part);
+    const double mean = mean0 + wave_sum64(part);
+    const double sgn = maximize ? 1.0 : -1.0;
+    double g_mean, g_var = 0.0;
+    if (kind == GABO_ACQ_POSTERIOR_MEAN) {
+        if (lane == 0) *value_out = out_sign * sgn * mean;
+        g_mean = sgn;
+    } else {
+        part = 0.0;
+        if (sym_inverse) {
+            for (int64_t r = lane; r < n; r += 64) {
+                vv[r] = strided_dot(linv + r, ks, (int)n);
+                part = __builtin_fma(ks[r], vv[r], part);
+            }
+        } else {
+            for (int64_t r = lane; r < n; r += 64) {
+                vv[r] = strided_dot(linv_t + r, ks, (int)n);
+                part = __builtin_fma(vv[r], vv[r], part);
+            }
+        }
+        const double var = os * kxx - wave_sum64(part);
+        const bool clamped = !(var > 1e-9);
+        const double sigma = __builtin_sqrt(clamped ? 1e-9 : var);
+        const double u = sgn * (mean - best_f) / sigma;
+        const double pdf = exp(-0.5 * u * u) * 0.3989422804014327;
+        const double cdf = 0.5 * (1.0 + erf(u * 0.7071067811865476));
+        if (lane == 0) *value_out = out_sign * sigma * (pdf + u * cdf);
+        g_mean = sgn * cdf;
+        g_var = clamped ? 0.0 : 0.5 * pdf / sigma;
+    }
+    __syncthreads();
+    for (int64_t j = lane; j < n; j += 64) {
+        double ws = 0.0;
+        if (kind != GABO_ACQ_POSTERIOR_MEAN) ws = sym_inverse ? vv[j] : strided_dot(linv + j, vv, (int)n);
+        const double gk = out_sign * os * (g_mean * alpha[j] - 2.0 * g_var * ws);
+        wts[j] = gk * kd[j];
+    }
+    __syncthreads();
+}
+
+template <int D>
+__device__ __forceinline__ void acq_eval_vectors(const double* __restrict__ xrow, const AcqParams& P, double* __restrict__ F, AcqLds<D>& L,
+                                                 int* __restrict__ status, int64_t index) {
+    static_assert(D <= 8, "register eigen-solver");
+    constexpr int T = tri_size(D);
+    const double* __restrict__ G = P.train_factors;
+    const int64_t n = P.n;
+    const int lane = threadIdx.x;
+    acq_eval_candidate_side<D>(xrow, L, nullptr, index);       // (the helper wave reports a candidate that is not positive definite)
+    const double* w = L.wl;
+    const LogRegs logc = LogRegs::load();
+    for (int64_t j0 = 0; j0 < n; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const bool live = j < n;
+        double m[T];
+        acq_eval_pair_matrix<D>(G + (live ? j : n - 1), n, w, m);
+        double vreg[D * D], lam[D], lg[D];
+        sym_eig_reg<D>(m, lam, vreg);
+        static_for<D>([&](auto kk) { lg[decltype(kk)::value] = log_pos(lam[decltype(kk)::value], logc); });
+        if (live) {
+            static_for<D>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                static_for<r + 1>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    double f = 0.0;
+                    static_for<D>([&](auto kk) {
+                        constexpr int k = decltype(kk)::value;
+                        f = __builtin_fma(vreg[r * D + k] * lg[k], vreg[c * D + k], f);
+                    });
+                    F[(int64_t)tri(r, c) * n + j] = f;
+                });
+            });
+        }
+    }
+    __syncthreads();
+}
+
+template <int D>
+__device__ __forceinline__ void acq_eval_finish(const AcqParams& P, double* __restrict__ grad_out, const double* __restrict__ F, const double* __restrict__ wts,
+                                                AcqLds<D>& L) {
+    constexpr int T = tri_size(D);
+    constexpr int LD = 64;
+    const int64_t n = P.n;
+    const int lane = threadIdx.x;
+    double* acc = L.acc;
+    double* red = L.red;
+    const double* wl = L.wl;
+    static_for<T>([&](auto ee) { acc[decltype(ee)::value * LD + lane] = 0.0; });
+    for (int64_t j = lane; j < n; j += 64) {
+        const double wj = wts[j];
+        static_for<T>([&](auto ee) {
+            constexpr int e = decltype(ee)::value;
+            acc[e * LD + lane] = __builtin_fma(wj, F[(int64_t)e * n + j], acc[e * LD + lane]);
+        });
+    }
+    __syncthreads();
+    for (int e = lane; e < T; e += 64) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+        for (int l = 0; l < 64; l += 4) {
+            t0 += acc[e * LD + ((l + e) & 63)];
+            t1 += acc[e * LD + ((l + 1 + e) & 63)];
+            t2 += acc[e * LD + ((l + 2 + e) & 63)];
+            t3 += acc[e * LD + ((l + 3 + e) & 63)];
+        }
+        red[e] = (t0 + t1) + (t2 + t3);
+    }
+    __syncthreads();
+    double* U = acc;
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int r = idx / D, b = idx - r * D;
+        double inner = 0.0;
+        static_for<D>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const double srs = r >= c ? red[tri(r, c)] : red[tri(c, r)];
+            const double wcb = wl[c >= b ? tri(c, b) : 0];
+            inner = c >= b ? __builtin_fma(srs, wcb, inner) : inner;
+        });
+        U[idx] = inner;
+    }
+    __syncthreads();
+    for (int e = lane; e < T; e += 64) {
+        int a = 0;
+        while (tri(a + 1, 0) <= e) ++a;
+        const int bb = e - tri(a, 0);
+        double t = 0.0;
+        static_for<D>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            const double wra = wl[r >= a ? tri(r, a) : 0];
+            const double u = U[r * D + bb];
+            t = r >= a ? __builtin_fma(wra, u, t) : t;
+        });
+        t *= -2.0;
+        grad_out[mandel_pos(D, a, bb)] = (a == bb) ? t : t * kSqrt2;
+    }
+}
+
 // Same contract as acq_eval<D> for the two Frobenius-type surrogates (kernels_spd.py:190-313):
 //   METRIC 1: log-Euclidean  k_j = exp(-beta ||logm x - logm X_j + 1e-15||_F^2),  P.train_factors = Mandel(logm X_j), entry-major [T][n]
 //   METRIC 2: Frobenius      k_j = exp(-beta ||x - X_j + 1e-15||_F^2),            P.train_factors = Mandel(X_j),      entry-major [T][n]

@@ -183,7 +183,7 @@ __device__ __forceinline__ void duo_boundary_step(const double* sc, const double
 
 // dynamic LDS of the two-wave kernel (bytes) for n training points, dimension d, C constraints; offsets in doubles
 struct DuoLds {
-    size_t scratch1, kinv, ws, f1, gc1, fc1, snap, bytes;
+    size_t scratch1, kinv, ws, f1, gc1, fc1, snap, coopw, bytes;
 };
 static __host__ __device__ inline DuoLds duo_lds_layout(int64_t n, int d, int C) {
     DuoLds l;
@@ -200,6 +200,7 @@ static __host__ __device__ inline DuoLds duo_lds_layout(int64_t n, int d, int C)
     l.gc1 = off;       off += (size_t)(C > 0 ? C : 1) * dd;
     l.fc1 = off;       off += kMaxCons;
     l.snap = off;      off += dd + SC_COUNT + 2;      // delta_0~, the scalars, a stored zero
+    l.coopw = off;     off += n;                      // the weights w_j of an evaluation shared by the two waves (acq_eval_values -> acq_eval_finish)
     l.bytes = off * sizeof(double);
     return l;
 }
@@ -219,7 +220,7 @@ struct DuoStatic {
     double cons_pub[2 + 2 * D];
     int flags[8];
 };
-enum { DF_STILL = 0, DF_ACCEPTED, DF_HIT, DF_INVAL };
+enum { DF_STILL = 0, DF_ACCEPTED, DF_HIT, DF_INVAL, DF_COOP, DF_COOP2 };
 
 template <int D>
 __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restrict__ x, double* __restrict__ fx, double* __restrict__ g,
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
     double* snap_dl = dyn + lay.snap;
     double* snap_sc = snap_dl + dd;
     double* zero = snap_sc + SC_COUNT;
+    double* coopw = dyn + lay.coopw;
     double* mats = sh.mats[wv];
     AcqLds<D>& acq = sh.acq[wv];
     if (wv == 0 && lane == 0) {
@@ -320,7 +322,21 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
                 if (!(it == 0 && x_unchanged && fd0_kept)) tcg_fd_point(w, 0, D, t.x_fd, mats);
                 __syncthreads();
                 double* eg_it = (it == 0) ? t.eg_fd0 : t.eg_fd;
+#ifdef GABO_DUO_COOP
+                if (it == 0) {
+                    if (!x_unchanged) acq_eval<D>(t.x_fd, Ps, t.val_fd, eg_it, t.F, acq, dynw, status, i);
+                } else {
+                    // the speculation has missed and the other wave has nothing to do: the evaluation is shared with it (acq_eval_values there, the
+                    // eigenvectors and the gradient here)
+                    if (lane == 0) sh.flags[DF_COOP] = 1;
+                    duo_block_sync();                                   // Ba: the FD point is published, the helper starts
+                    acq_eval_vectors<D>(t.x_fd, Ps, t.F, acq, status, i);
+                    duo_block_sync();                                   // Bc: the weights are there
+                    acq_eval_finish<D>(Ps, eg_it, t.F, coopw, acq);
+                }
+#else
                 if (!(it == 0 && x_unchanged)) acq_eval<D>(t.x_fd, Ps, t.val_fd, eg_it, t.F, acq, dynw, status, i);
+#endif
                 __syncthreads();
                 const bool running = tcg_step(w, 0, 1, D, C, eg_it, 0, delta_cons, theta, kappa, mininner, it, mats);
                 __syncthreads();
@@ -340,6 +356,7 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
             if (lane == 0) {
                 t.rhoden[0] = -ge - 0.5 * ehe;
                 sh.flags[DF_HIT] = hit ? 1 : 0;
+                sh.flags[DF_COOP] = 0;          // (no further evaluation to share: the barrier below ends the helper's loop)
             }
             if (rec != nullptr && rec_k < rec_cap) {
                 double* rr = rec + (rec_k * R + i) * (dd + 2);
@@ -353,6 +370,37 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
             GABO_TICK(24);
             duo_block_sync();                                           // B2
             GABO_TICK(25);
+#ifdef GABO_DUO_COOP
+            // after a miss the other wave builds and evaluates the real proposal, and after a value-only evaluation that is going to be accepted it evaluates
+            // the gradient: this wave takes the value half of those evaluations (one site for both: trip 0 / trip 1)
+            bool inval = false, accept_pred = false;
+            for (int trip = 0; trip < 2; ++trip) {
+                bool help;
+                if (trip == 0) {
+                    if (hit) {
+                        help = false;
+                    } else {
+                        duo_block_sync();                               // Bp: the proposal is built
+                        help = sh.flags[DF_COOP2] != 0;
+                    }
+                } else {
+                    inval = sh.flags[DF_INVAL] != 0;
+                    accept_pred = tr_would_accept(fx_now, t.fx_prop[0], t.rhoden[0], inval, rho_prime, rho_regularization);
+                    help = lazy && accept_pred;
+                    if (!help) break;
+                }
+                if (help) {
+                    acq_eval_values<D>(xpm, Ps, t.fx_prop, coopw, acq, dynw, status, i);
+                    duo_block_sync();                                   // Bc
+                }
+                if (trip == 0) {
+                    if (!hit) duo_block_sync();                         // B4
+                } else {
+                    duo_block_sync();                                   // B5
+                }
+            }
+            GABO_TICK(26);
+#else
             if (!hit) duo_block_sync();                                 // B4
             GABO_TICK(26);
             const bool inval = sh.flags[DF_INVAL] != 0;
@@ -360,6 +408,7 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
             // proposal's eigen-pairs are prepared for the next iteration)
             const bool accept_pred = tr_would_accept(fx_now, t.fx_prop[0], t.rhoden[0], inval, rho_prime, rho_regularization);
             if (lazy && accept_pred) duo_block_sync();                  // B5
+#endif
             bool accepted = false;
             bool still = tr_update_body(x + i * dd, fx + i, g + i * dd, ng + i, delta_tr + i, iters + i, inval, xp, t, 0, D, C, delta_bar,
                                         rho_prime, rho_regularization, mingradnorm, maxiter, mats, &accepted);
@@ -439,10 +488,29 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
                     gout = lazy ? nullptr : t.eg_prop;
                     GABO_TICK(34);
                 }
+#ifdef GABO_DUO_COOP
+                // the real proposal after a miss and the gradient after a value-only evaluation are evaluated WITH the other wave (it has nothing else to
+                // do then): the eigenvectors and the gradient here, the value half there.  The speculated proposal is this wave's alone.
+                bool shared = phase != PH_SPEC && do_eval && gout != nullptr;
+                if (phase == PH_REAL) {
+                    if (lane == 0) sh.flags[DF_COOP2] = shared ? 1 : 0;
+                    duo_block_sync();                                   // Bp
+                }
+                if (shared) {
+                    acq_eval_vectors<D>(xpm, Ps, F1, acq, status, i);
+                    duo_block_sync();                                   // Bc
+                    acq_eval_finish<D>(Ps, gout, F1, coopw, acq);
+                    __syncthreads();
+                } else if (do_eval) {
+                    acq_eval<D>(xpm, Ps, t.fx_prop, gout, F1, acq, dynw, status, i);
+                    __syncthreads();
+                }
+#else
                 if (do_eval) {
                     acq_eval<D>(xpm, Ps, t.fx_prop, gout, F1, acq, dynw, status, i);
                     __syncthreads();
                 }
+#endif
                 if (phase == PH_REGRAD) {
                     duo_block_sync();                                   // B5
                     break;
@@ -451,7 +519,21 @@ __global__ __launch_bounds__(128) void spd_tr_solve_duo_kernel(double* __restric
                 inval = (B.strict && C > 0) ? builtin_infeasible<D>(xp, B, nullptr) : false;
                 if (lane == 0) sh.flags[DF_INVAL] = inval ? 1 : 0;
                 GABO_TICK(35);
+#ifdef GABO_DUO_COOP
+                if (phase == PH_SPEC) {
+                    // B2, or before it the barriers of the evaluations the tCG wave shares with this one while it runs further tCG iterations
+                    for (;;) {
+                        duo_block_sync();                               // Ba / B2
+                        if (sh.flags[DF_COOP] == 0) break;
+                        acq_eval_values<D>(t.x_fd, Ps, t.val_fd, coopw, acq, dynw, status, i);
+                        duo_block_sync();                               // Bc
+                    }
+                } else {
+                    duo_block_sync();                                   // B4
+                }
+#else
                 duo_block_sync();                                       // B2 (speculated proposal) / B4 (real one)
+#endif
                 GABO_TICK(36);
                 if (phase == PH_SPEC && sh.flags[DF_HIT] == 0) {
                     phase = PH_REAL;

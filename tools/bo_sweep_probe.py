@@ -63,5 +63,13 @@ for it in range(16):
     srt = np.sort(its)[::-1]
     ph = " ".join(f"{n.split()[-1]}={1e3*(t-tl[0][1]):.2f}" for n, t in tl)
     print(f"it {it:2d} n={len(y):2d} sweep {dt*1e3:.2f} ms native={lg.get('native_sweep')} devsel={lg.get('device_selection')} iters max {its.max()} at100 {(its>=100).sum()} top<100 {srt[srt<100][:4].tolist()} mean {its.mean():.1f} | {ph}")
+    if os.environ.get("GABO_DUO_TIMES_PROBE"):      # library built with -DGABO_DUO_TIMES (tools/duo_times.py): the longest restarts of this sweep's solve launch
+        import ctypes
+        from gabotorch_amd import _lib
+        buf = (ctypes.c_longlong * (4 * 512))()
+        _lib.load().gabo_debug_duo_times(buf, 512)
+        a = np.array(buf[:]).reshape(512, 4)
+        for k in np.argsort(-a[:, 0])[:4]:
+            print(f"      restart {k:3d}: {a[k, 0] / 1e6:6.2f} M cycles, {a[k, 1]:3d} iterations, speculated {a[k, 2]:3d}, not {a[k, 3] % 1000:3d}, applied as scalar updates {a[k, 3] // 1000:3d}")
     ny = objective(nx[0]).reshape(-1).to(dev)
     x, y = torch.cat([x, nx.detach()]), torch.cat([y, ny])
