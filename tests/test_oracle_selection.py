@@ -37,3 +37,18 @@ def test_selection_invariants():
     for seed in range(4000):
         wins[int(np.argmax(osel.select_nonneg(yy, 1, seed, eta=2.0, alpha=1e-9)[1]))] += 1
     np.testing.assert_allclose(wins / 4000, w / w.sum(), atol=0.03)
+
+
+def test_sphere_sampler_oracle_is_uniform_on_the_sphere():
+    """oracle.selection.sphere_samples (what sphere_sample_kernel draws): unit rows, reproducible per (seed, index), independent of how many are drawn,
+    and the distribution of [3P] Sphere.rand - coordinates with mean 0 and variance 1 / dim, no preferred direction."""
+    a = osel.sphere_samples(99, 4096, 10)
+    np.testing.assert_allclose(np.linalg.norm(a, axis=1), 1.0, rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(a[:100], osel.sphere_samples(99, 100, 10))          # addressed by sample index
+    assert np.abs(a - osel.sphere_samples(100, 4096, 10)).max() > 0.1                  # another seed, another draw
+    assert np.abs(a.mean(0)).max() < 0.02 and np.abs(a.var(0) - 0.1).max() < 0.01
+    cov = a.T @ a / 4096
+    assert np.abs(cov - np.eye(10) / 10).max() < 0.01
+    odd = osel.sphere_samples(5, 1000, 7)                                              # odd dimension: the second deviate of the last pair is dropped
+    np.testing.assert_allclose(np.linalg.norm(odd, axis=1), 1.0, rtol=0, atol=1e-15)
+    assert odd.shape == (1000, 7) and np.abs(odd.mean(0)).max() < 0.06
