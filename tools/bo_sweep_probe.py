@@ -43,7 +43,7 @@ for it in range(16):
         De = torch.stack([e["Delta"] for e in tr]).cpu().numpy()
         Stp = torch.stack([e["stop_inner"] for e in tr]).cpu().numpy()
         names = ["negcurv", "exceededTR", "lin", "superlin", "maxinner", "modelinc", "constraints"]
-        long = np.argsort(-its)[:12]
+        long = list(np.argsort(-its)[:4]) + list(np.argsort(-np.where(its < 100, its, 0))[:10])      # the longest, and the longest that did not hit maxiter
         for r in long:
             k = int(its[r])
             moved = [bool(np.abs(X[j + 1, r] - X[j, r]).max() > 0) for j in range(min(k, len(tr)) - 1)]
