@@ -1,24 +1,30 @@
 // Single-launch trust-region solve with TWO waves per restart (round 6; affine-invariant surrogate, built-in eigenvalue bounds, latency regime).
 //
 // The one-wave kernel (spd_tr_solve_kernel, spd_tr_body.hpp) walks an accepted iteration as one dependent chain: tCG begin -> constraints at x -> FD point ->
-// acquisition there -> tCG step -> proposal -> acquisition at the proposal -> update (138 k cycles at d = 5, n = 50; two evaluations of 40 k each).  Almost
-// always (config 4: see tools/duo_stats.py) tCG leaves in its FIRST step through the trust-region boundary or negative curvature, and that step does not depend on
-// the Hessian-vector product at all: eta = tau delta_0 with tau from (Delta, <delta_0, delta_0>) and the linearised constraints (robust_trust_regions.py:500-512,
-// constrained_trust_regions.py:583-640) - the product only DECIDES that the branch is taken.  So the block is two waves:
-//   wave 0 (the tCG wave):       begin, FD point, acquisition at the FD point, tCG step(s), model decrease, update
-//   wave 1 (the proposal wave):  eigen-pairs of x for the constraints, the boundary step as tCG would take it, proposal x+ = L expm(eta~) L^T, acquisition at x+
-// running side by side; after both are done the tCG wave's eta~ is compared with the speculated one, element by element.  Equal: the proposal and its value are
-// the ones the one-wave kernel computes (the same statements on the same operands: the same bits), and the iteration took max(...) instead of the sum.  Not equal
-// (an interior step, more tCG iterations): the tCG wave finishes, the proposal wave builds and evaluates the real proposal - the one-wave schedule, nothing lost
-// but the energy.  A rejected proposal shrinks the radius and leaves x, g, delta_0 in place: the next boundary step is speculated the same way.
+// acquisition there -> tCG step -> proposal -> acquisition at the proposal -> update (138 k cycles at d = 5, n = 50; two evaluations of 40 k each).  In config 4
+// 56 % of the iterations (gabo_spd_tr_two_waves_counters; per restart: tools/duo_times.py) tCG leaves in its FIRST step through the trust-region boundary or
+// negative curvature, and that step does not depend on the Hessian-vector product at all: eta = tau delta_0 with tau from (Delta, <delta_0, delta_0>) and the
+// linearised constraints (robust_trust_regions.py:500-512, constrained_trust_regions.py:583-640) - the product only DECIDES that the branch is taken.  So the
+// block is two waves:
+//   wave 0 (the tCG wave):       begin, FD point, acquisition at the FD point, tCG step(s), model decrease, update (and straight into the next begin)
+//   wave 1 (the proposal wave):  the boundary step as tCG would take it, proposal x+ = L expm(eta~) L^T, acquisition at x+; then, while the other wave runs the
+//                                update and the next begin, the eigen-pairs of the proposal it expects to be accepted (the next iterate's constraints)
+// running side by side.  The tCG wave computes the speculated step too (scalars and one axpy) and compares its own eta~ with it element by element.  Equal: the
+// proposal and its value are the ones the one-wave kernel computes (the same statements on the same operands: the same bits), and the iteration took
+// max(...) instead of the sum (82 k cycles).  Not equal (an interior step, more tCG iterations): the tCG wave - which knows without waiting - finishes, then the
+// proposal wave builds and evaluates the real proposal: the one-wave schedule.  A rejected proposal shrinks the radius and leaves x, g, delta_0 in place: the
+// next boundary step is speculated the same way, and a run of rejected proposals whose first step does not change is applied as scalar updates
+// (tr_repeat_rejected, spd_tr_body.hpp).
 //
 // Synchronisation: the device bodies this kernel shares with the one-wave kernels synchronise with __syncthreads(), which for a 64-thread block IS a wave-level
 // fence (the compiler drops the s_barrier).  The translation unit of this kernel (spd_tr_solve_duo.hip) therefore defines __syncthreads() as that wave-level
 // fence before including them, and the block-level barriers between the two waves are explicit duo_block_sync() calls, executed by both waves in the same
-// sequence (every condition around one is block-uniform: read from LDS after the previous barrier).  Between two barriers a wave reads nothing the other writes:
-// the tCG wave snapshots what the speculation needs (delta_0, the scalars) before the first barrier, each wave has its own scratch (AcqLds, mats, 3 n doubles,
-// the logm spill F) and its own copy of the constraints' values and whitened gradients.
+// sequence - per iteration B1 (begin done | eigen-pairs done), B2 (tCG done | speculated proposal evaluated), B4 after a miss (real proposal evaluated), B5 when a
+// value-only evaluation is followed by its gradient; every condition around one is block-uniform (words written before the previous barrier).  Between two
+// barriers a wave reads nothing the other writes: the tCG wave snapshots what the speculation needs (delta_0, the scalars) before B1, each wave has its own
+// scratch (AcqLds, mats, 3 n doubles, the logm spill F), its own copy of the constraints' values and whitened gradients and of the speculated step.
 // The block is dim3(64, 2): threadIdx.x stays the lane index the shared bodies use, threadIdx.y is the wave.
+// -DGABO_DUO_COOP (off: measured 2-3 % slower, CHANGELOG round 6 item 11): the evaluations during which one wave would idle are shared by both.
 #pragma once
 #ifndef GABO_DUO_TU
 #error "include from spd_tr_solve_duo.hip only (it redefines __syncthreads for the bodies it includes)"
