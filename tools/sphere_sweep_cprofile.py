@@ -14,4 +14,5 @@ for _ in range(20):
     run(**kw)
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(45)
+st.sort_stats("cumulative").print_stats(30)
+st.sort_stats("tottime").print_stats(14)
